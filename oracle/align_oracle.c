@@ -1,0 +1,470 @@
+/*
+ * align_oracle.c - CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the seed-and-extend protein search that replaces the
+ * `diamond blastp` calls of the reference (uberBlast.py:531-552).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * PARITY UNPINNED for this half: the reference delegates the arithmetic to the
+ * DIAMOND binary, which is absent from /root/reference (.MISSING_LARGE_BLOBS:2),
+ * unpinned (setup.py:22 lists no version) and cannot be run here.  This file
+ * therefore DEFINES the algorithm (published DIAMOND design: reduced-alphabet
+ * spaced seeds -> banded affine Smith-Waterman, BLOSUM62 11/1, e-value /
+ * identity / query-cover filters, top-k targets per query) and the HIP kernels
+ * are held bit-exact to it.  The reference's own call site fixes the parameters:
+ *   --id 100*min_id --query-cover 100*min_ratio --evalue 1 -k 10 --dbsize 5000000
+ *   5 round-robin database splits                     (uberBlast.py:546-552)
+ * and the consumer fixes the fields each hit must carry: POS, CIGAR, |SEQ|, NM,
+ * ZR (raw score), ZS (query start)                    (uberBlast.py:25-58).
+ *
+ * Algorithm (all integer; every tie broken explicitly so results are unique):
+ *  1. seeds: residues -> 11-letter reduced alphabet; for each spaced shape a key
+ *     = sum g[p+off_k]*base^k; every (query pos, target pos) pair with equal key
+ *     is a seed hit on diagonal d = tpos - qpos.
+ *  2. candidates: unique (q, t, bin) with bin = floor((d + 2^23)/64); the band
+ *     of a candidate covers diagonals [c-32, c+95], c = 64*bin - 2^23.
+ *  3. banded affine local alignment per candidate (gap of length k costs
+ *     open+k*ext); best cell = max H, ties -> smallest i, then smallest j.
+ *  4. per (q,t): keep the best candidate (score desc, bin asc); require
+ *     score >= min_score[q] (Karlin-Altschul e-value cut, see oracle_min_score).
+ *  5. traceback (H==0 stop, then diagonal, then E, then F; gap extension only
+ *     when strictly better than opening) -> CIGAR (M / I = query only / D =
+ *     target only), start cell, identities.
+ *  6. filters: 100*ident/alnlen >= min_id_pct, 100*qspan/qlen >= min_qcov_pct.
+ *  7. top-k per (q, t mod n_splits): rank by (score desc, t asc), keep rank<k.
+ *  8. output ordered by (q, t).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define NEG (-(1 << 28))
+#define DIAG_OFF (1 << 23)
+#define BIN_W 64
+#define BAND 128
+#define BAND_LEAD 32
+
+typedef struct {
+    int32_t gap_open;      /* 11 */
+    int32_t gap_ext;       /* 1  */
+    int32_t n_shapes;
+    int32_t base;          /* size of the reduced alphabet */
+    int32_t weight[4];
+    int32_t offs[4][32];
+    uint8_t reduce[32];    /* residue code -> reduced letter, 0xFF = never seeds */
+    int8_t  sub[32 * 32];  /* substitution scores, [q*32 + t] */
+    double  min_id_pct;    /* diamond --id */
+    double  min_qcov_pct;  /* diamond --query-cover */
+    int32_t top_k;         /* diamond -k */
+    int32_t n_splits;      /* 5 database splits */
+} oracle_params;
+
+typedef struct {
+    uint32_t q, t;
+    uint32_t q_start, q_end;   /* 1-based, inclusive, residues */
+    uint32_t t_start, t_end;
+    int32_t  score;
+    uint32_t nm;               /* aln_len - n_ident */
+    uint32_t n_ident, aln_len;
+    uint32_t cigar_runs;
+    int32_t  bin;
+    uint64_t cigar_off;
+    uint64_t cells;            /* in-band in-matrix cells of the winning candidate */
+} oracle_hit;
+
+/* standard BLOSUM62, order ARNDCQEGHILKMFPSTWYVBZX* (public domain, NCBI) */
+static const char B62_ORDER[] = "ARNDCQEGHILKMFPSTWYVBZX*";
+static const int8_t B62[24][24] = {
+    { 4,-1,-2,-2, 0,-1,-1, 0,-2,-1,-1,-1,-1,-2,-1, 1, 0,-3,-2, 0,-2,-1, 0,-4},
+    {-1, 5, 0,-2,-3, 1, 0,-2, 0,-3,-2, 2,-1,-3,-2,-1,-1,-3,-2,-3,-1, 0,-1,-4},
+    {-2, 0, 6, 1,-3, 0, 0, 0, 1,-3,-3, 0,-2,-3,-2, 1, 0,-4,-2,-3, 3, 0,-1,-4},
+    {-2,-2, 1, 6,-3, 0, 2,-1,-1,-3,-4,-1,-3,-3,-1, 0,-1,-4,-3,-3, 4, 1,-1,-4},
+    { 0,-3,-3,-3, 9,-3,-4,-3,-3,-1,-1,-3,-1,-2,-3,-1,-1,-2,-2,-1,-3,-3,-2,-4},
+    {-1, 1, 0, 0,-3, 5, 2,-2, 0,-3,-2, 1, 0,-3,-1, 0,-1,-2,-1,-2, 0, 3,-1,-4},
+    {-1, 0, 0, 2,-4, 2, 5,-2, 0,-3,-3, 1,-2,-3,-1, 0,-1,-3,-2,-2, 1, 4,-1,-4},
+    { 0,-2, 0,-1,-3,-2,-2, 6,-2,-4,-4,-2,-3,-3,-2, 0,-2,-2,-3,-3,-1,-2,-1,-4},
+    {-2, 0, 1,-1,-3, 0, 0,-2, 8,-3,-3,-1,-2,-1,-2,-1,-2,-2, 2,-3, 0, 0,-1,-4},
+    {-1,-3,-3,-3,-1,-3,-3,-4,-3, 4, 2,-3, 1, 0,-3,-2,-1,-3,-1, 3,-3,-3,-1,-4},
+    {-1,-2,-3,-4,-1,-2,-3,-4,-3, 2, 4,-2, 2, 0,-3,-2,-1,-2,-1, 1,-4,-3,-1,-4},
+    {-1, 2, 0,-1,-3, 1, 1,-2,-1,-3,-2, 5,-1,-3,-1, 0,-1,-3,-2,-2, 0, 1,-1,-4},
+    {-1,-1,-2,-3,-1, 0,-2,-3,-2, 1, 2,-1, 5, 0,-2,-1,-1,-1,-1, 1,-3,-1,-1,-4},
+    {-2,-3,-3,-3,-2,-3,-3,-3,-1, 0, 0,-3, 0, 6,-4,-2,-2, 1, 3,-1,-3,-3,-1,-4},
+    {-1,-2,-2,-1,-3,-1,-1,-2,-2,-3,-3,-1,-2,-4, 7,-1,-1,-4,-3,-2,-2,-1,-2,-4},
+    { 1,-1, 1, 0,-1, 0, 0, 0,-1,-2,-2, 0,-1,-2,-1, 4, 1,-3,-2,-2, 0, 0, 0,-4},
+    { 0,-1, 0,-1,-1,-1,-1,-2,-2,-1,-1,-1,-1,-2,-1, 1, 5,-2,-2, 0,-1,-1, 0,-4},
+    {-3,-3,-4,-4,-2,-2,-3,-2,-2,-3,-2,-3,-1, 1,-4,-3,-2,11, 2,-3,-4,-3,-2,-4},
+    {-2,-2,-2,-3,-2,-1,-2,-3, 2,-1,-1,-2,-1, 3,-3,-2,-2, 2, 7,-1,-3,-2,-1,-4},
+    { 0,-3,-3,-3,-1,-2,-2,-3,-3, 3, 1,-2, 1,-1,-2,-2, 0,-3,-1, 4,-3,-2,-1,-4},
+    {-2,-1, 3, 4,-3, 0, 1,-1, 0,-3,-4, 0,-3,-3,-2, 0,-1,-4,-3,-3, 4, 1,-1,-4},
+    {-1, 0, 0, 1,-3, 3, 4,-2, 0,-3,-3, 1,-1,-3,-1, 0,-1,-3,-2,-2, 1, 4,-1,-4},
+    { 0,-1,-1,-1,-2,-1,-1,-1,-1,-1,-1,-1,-1,-1,-2, 0, 0,-2,-1,-1,-1,-1,-1,-4},
+    {-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4,-4, 1},
+};
+
+/* Fill protein defaults: residue code = letter - 'A'; J,O,U score as X; codes >= 26 are
+ * padding and score -64 against everything.  Reduced alphabet (Buchfink et al. 2015):
+ * [KREDQN] [C] [G] [H] [ILV] [M] [F] [Y] [W] [P] [STA]; B,J,O,U,X,Z never seed.
+ * Shapes: 111101110111 and 111011010010111 (weight 10). */
+void oracle_default_params(oracle_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->gap_open = 11; p->gap_ext = 1;
+    int idx[26];
+    for (int c = 0; c < 26; ++c) {
+        const char *f = strchr(B62_ORDER, 'A' + c);
+        idx[c] = f ? (int)(f - B62_ORDER) : 22;   /* X */
+    }
+    for (int a = 0; a < 32; ++a)
+        for (int b = 0; b < 32; ++b)
+            p->sub[a * 32 + b] = (a < 26 && b < 26) ? B62[idx[a]][idx[b]] : -64;
+    memset(p->reduce, 0xFF, 32);
+    const char *groups[11] = {"KREDQN", "C", "G", "H", "ILV", "M", "F", "Y", "W", "P", "STA"};
+    for (int g = 0; g < 11; ++g)
+        for (const char *c = groups[g]; *c; ++c) p->reduce[*c - 'A'] = (uint8_t)g;
+    p->base = 11;
+    const char *shapes[2] = {"111101110111", "111011010010111"};
+    p->n_shapes = 2;
+    for (int s = 0; s < 2; ++s) {
+        int w = 0;
+        for (int k = 0; shapes[s][k]; ++k)
+            if (shapes[s][k] == '1') p->offs[s][w++] = k;
+        p->weight[s] = w;
+    }
+    p->min_id_pct = 0.; p->min_qcov_pct = 0.; p->top_k = 10; p->n_splits = 5;
+}
+
+/* smallest raw score whose e-value m*n*K*exp(-lambda*S) is <= max_evalue
+ * (gapped BLOSUM62 11/1 statistics: lambda 0.267, K 0.041; n = --dbsize) */
+int32_t oracle_min_score(uint32_t qlen, double dbsize, double max_evalue)
+{
+    const double lambda = 0.267, K = 0.041;
+    double s = log(K * (double)qlen * dbsize / max_evalue) / lambda;
+    int32_t r = (int32_t)ceil(s);
+    return r < 1 ? 1 : r;
+}
+
+/* ------------------------------------------------------------------ seeds */
+typedef struct { uint64_t key; uint32_t seq, pos; } seed_t;
+
+static int cmp_seed(const void *a, const void *b)
+{
+    const seed_t *x = a, *y = b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    if (x->seq != y->seq) return x->seq < y->seq ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos);
+}
+static int cmp_u64(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? -1 : (x > y);
+}
+
+static int seed_key(const oracle_params *p, int sh, const uint8_t *s, uint32_t len, uint32_t pos, uint64_t *key)
+{
+    int w = p->weight[sh];
+    if ((uint64_t)pos + p->offs[sh][w - 1] >= len) return 0;
+    uint64_t k = 0, mul = 1;
+    for (int i = 0; i < w; ++i) {
+        uint8_t c = s[pos + p->offs[sh][i]];
+        uint8_t g = c < 32 ? p->reduce[c] : 0xFF;
+        if (g == 0xFF) return 0;
+        k += mul * g; mul *= (uint64_t)p->base;
+    }
+    *key = k;
+    return 1;
+}
+
+static inline uint64_t cand_key(uint32_t q, uint32_t t, int32_t bin)
+{
+    return ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)(uint32_t)bin;
+}
+
+/* candidates: sorted unique keys (q:21 | t:25 | bin:18) */
+static uint64_t *find_candidates(const oracle_params *p,
+                                 const uint8_t *qr, const uint64_t *qo, uint32_t nq,
+                                 const uint8_t *tr, const uint64_t *to, uint32_t nt, uint64_t *n_out)
+{
+    uint64_t cap = 1 << 16, n = 0;
+    uint64_t *c = malloc(cap * sizeof(uint64_t));
+    uint64_t aq = qo[nq];
+    seed_t *qs = malloc((aq + 1) * sizeof(seed_t));
+    for (int sh = 0; sh < p->n_shapes; ++sh) {
+        uint64_t m = 0;
+        for (uint32_t q = 0; q < nq; ++q) {
+            uint32_t len = (uint32_t)(qo[q + 1] - qo[q]);
+            for (uint32_t pos = 0; pos < len; ++pos) {
+                uint64_t k;
+                if (seed_key(p, sh, qr + qo[q], len, pos, &k)) { qs[m].key = k; qs[m].seq = q; qs[m].pos = pos; ++m; }
+            }
+        }
+        qsort(qs, m, sizeof(seed_t), cmp_seed);
+        for (uint32_t t = 0; t < nt; ++t) {
+            uint32_t len = (uint32_t)(to[t + 1] - to[t]);
+            for (uint32_t pos = 0; pos < len; ++pos) {
+                uint64_t k;
+                if (!seed_key(p, sh, tr + to[t], len, pos, &k)) continue;
+                uint64_t lo = 0, hi = m;
+                while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (qs[mid].key < k) lo = mid + 1; else hi = mid; }
+                for (; lo < m && qs[lo].key == k; ++lo) {
+                    int32_t d = (int32_t)pos - (int32_t)qs[lo].pos;
+                    int32_t bin = (d + DIAG_OFF) / BIN_W;
+                    if (n == cap) { cap *= 2; c = realloc(c, cap * sizeof(uint64_t)); }
+                    c[n++] = cand_key(qs[lo].seq, t, bin);
+                }
+            }
+        }
+    }
+    free(qs);
+    qsort(c, n, sizeof(uint64_t), cmp_u64);
+    uint64_t u = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        if (i == 0 || c[i] != c[i - 1]) c[u++] = c[i];
+    *n_out = u;
+    return c;
+}
+
+/* ------------------------------------------------------------------ banded SW */
+typedef struct {
+    int32_t score, iend, jend;
+    uint64_t cells;
+    uint8_t *dir;       /* [Lq][BAND] nibble per byte: bits0-1 src, bit2 eExt, bit3 fExt */
+} sw_out;
+
+static void banded_sw(const oracle_params *p, const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt,
+                      int32_t dlo, int keep_dir, sw_out *o)
+{
+    const int32_t oe = p->gap_open + p->gap_ext, ext = p->gap_ext;
+    int32_t dhi = dlo + BAND - 1;
+    /* rolling rows indexed by band column c = d - dlo */
+    int32_t *base = malloc(sizeof(int32_t) * (BAND + 2) * 4);
+    int32_t *Hp = base;
+    int32_t *Fp = Hp + (BAND + 2), *Hc = Fp + (BAND + 2), *Fc = Hc + (BAND + 2);
+    for (int c = 0; c < BAND + 2; ++c) { Hp[c] = 0; Fp[c] = NEG; Hc[c] = 0; Fc[c] = NEG; }
+    o->score = 0; o->iend = -1; o->jend = -1; o->cells = 0;
+    o->dir = keep_dir ? calloc((size_t)Lq * BAND, 1) : NULL;
+    for (int32_t i = 0; i < Lq; ++i) {
+        int32_t jlo = i + dlo, jhi = i + dhi;
+        int32_t hl = 0, el = NEG;            /* left neighbour (i, j-1) inside the band */
+        for (int c = 0; c < BAND; ++c) {
+            int32_t j = jlo + c;
+            if (j < 0 || j >= Lt) { Hc[c] = 0; Fc[c] = NEG; hl = 0; el = NEG; continue; }
+            /* previous row, same diagonal -> band column c; up (i-1, j) -> diagonal d+1 -> column c+1 */
+            int32_t hd = (i > 0 && j > 0) ? Hp[c] : 0;
+            int32_t hu = 0, fu = NEG;
+            if (i > 0 && c + 1 < BAND) { hu = Hp[c + 1]; fu = Fp[c + 1]; }
+            if (c == 0 || j == 0) { hl = 0; el = NEG; }
+            int32_t e_ext = el - ext, e_open = hl - oe;
+            int32_t f_ext = fu - ext, f_open = hu - oe;
+            int32_t E = e_ext > e_open ? e_ext : e_open;
+            int32_t F = f_ext > f_open ? f_ext : f_open;
+            int32_t h = hd + p->sub[(q[i] & 31) * 32 + (t[j] & 31)];
+            int32_t H = h;
+            if (E > H) H = E;
+            if (F > H) H = F;
+            if (H < 0) H = 0;
+            if (keep_dir) {
+                uint8_t src = (H == 0) ? 0 : (H == h) ? 1 : (H == E) ? 2 : 3;
+                o->dir[(size_t)i * BAND + c] = (uint8_t)(src | ((e_ext > e_open) ? 4 : 0) | ((f_ext > f_open) ? 8 : 0));
+            }
+            if (H > o->score) { o->score = H; o->iend = i; o->jend = j; }   /* row-major scan => min i, then min j */
+            Hc[c] = H; Fc[c] = F;
+            hl = H; el = E;
+            o->cells++;
+        }
+        (void)jhi;
+        int32_t *tmp = Hp; Hp = Hc; Hc = tmp; tmp = Fp; Fp = Fc; Fc = tmp;
+    }
+    free(base);
+}
+
+typedef struct { uint32_t *runs; uint32_t n, cap; } runbuf;
+static void push_op(runbuf *b, uint32_t op)
+{
+    if (b->n && (b->runs[b->n - 1] & 3) == op) { b->runs[b->n - 1] += 4; return; }
+    if (b->n == b->cap) { b->cap = b->cap ? b->cap * 2 : 16; b->runs = realloc(b->runs, b->cap * sizeof(uint32_t)); }
+    b->runs[b->n++] = (1u << 2) | op;
+}
+
+/* ops: 0 = M, 1 = I (query only), 2 = D (target only); runs come out reversed (end -> start) */
+static void traceback(const sw_out *o, const uint8_t *q, const uint8_t *t, int32_t dlo,
+                      runbuf *rb, int32_t *istart, int32_t *jstart, uint32_t *n_ident, uint32_t *aln_len)
+{
+    int32_t i = o->iend, j = o->jend, state = 0;
+    *n_ident = 0; *aln_len = 0; rb->n = 0;
+    *istart = i; *jstart = j;
+    for (;;) {
+        uint8_t nib = o->dir[(size_t)i * BAND + (j - i - dlo)];
+        if (state == 0) {
+            uint8_t src = nib & 3;
+            if (src == 0) break;
+            if (src == 1) {
+                push_op(rb, 0); ++*aln_len;
+                if (q[i] == t[j]) ++*n_ident;
+                *istart = i; *jstart = j;
+                if (i == 0 || j == 0) break;
+                --i; --j;
+            } else state = (src == 2) ? 1 : 2;
+        } else if (state == 1) {         /* E: gap consuming the target */
+            push_op(rb, 2); ++*aln_len;
+            state = (nib & 4) ? 1 : 0;
+            --j;
+        } else {                          /* F: gap consuming the query */
+            push_op(rb, 1); ++*aln_len;
+            state = (nib & 8) ? 2 : 0;
+            --i;
+        }
+    }
+}
+
+static int cmp_hit_rank(const void *a, const void *b)
+{
+    const oracle_hit *x = *(const oracle_hit *const *)a, *y = *(const oracle_hit *const *)b;
+    if (x->score != y->score) return x->score > y->score ? -1 : 1;
+    return x->t < y->t ? -1 : (x->t > y->t);
+}
+
+/* full search.  q_off/t_off have n+1 entries (plain concatenation, no padding).
+ * min_score[nq] per query.  Returns 0; caller frees *hits and *cigar with oracle_free. */
+int oracle_search(const oracle_params *p,
+                  const uint8_t *q_res, const uint64_t *q_off, uint32_t nq,
+                  const uint8_t *t_res, const uint64_t *t_off, uint32_t nt,
+                  const int32_t *min_score,
+                  oracle_hit **hits_out, uint64_t *n_hits, uint32_t **cigar_out, uint64_t *n_cigar,
+                  uint64_t *stats /* [0]=candidates [1]=cells over all candidates [2]=pairs after best-per-(q,t) */)
+{
+    uint64_t nc = 0;
+    uint64_t *cand = find_candidates(p, q_res, q_off, nq, t_res, t_off, nt, &nc);
+    oracle_hit *hits = malloc((nc + 1) * sizeof(oracle_hit));
+    uint32_t *cig = NULL; uint64_t ncig = 0, capcig = 0, nh = 0, cells_all = 0, pairs = 0;
+    runbuf rb = {0};
+    uint64_t g0 = 0;
+    while (g0 < nc) {
+        uint64_t g1 = g0;
+        while (g1 < nc && (cand[g1] >> 18) == (cand[g0] >> 18)) ++g1;
+        uint32_t q = (uint32_t)(cand[g0] >> 43), t = (uint32_t)((cand[g0] >> 18) & ((1u << 25) - 1));
+        const uint8_t *qs = q_res + q_off[q], *ts = t_res + t_off[t];
+        int32_t Lq = (int32_t)(q_off[q + 1] - q_off[q]), Lt = (int32_t)(t_off[t + 1] - t_off[t]);
+        int32_t best = -1, best_bin = 0;
+        for (uint64_t g = g0; g < g1; ++g) {
+            int32_t bin = (int32_t)(cand[g] & ((1u << 18) - 1));
+            int32_t dlo = bin * BIN_W - DIAG_OFF - BAND_LEAD;
+            sw_out o;
+            banded_sw(p, qs, Lq, ts, Lt, dlo, 0, &o);
+            cells_all += o.cells;
+            if (o.score > best) { best = o.score; best_bin = bin; }
+        }
+        ++pairs;
+        if (best > 0 && best >= min_score[q]) {
+            int32_t dlo = best_bin * BIN_W - DIAG_OFF - BAND_LEAD;
+            sw_out o;
+            banded_sw(p, qs, Lq, ts, Lt, dlo, 1, &o);
+            int32_t is, js; uint32_t nid, al;
+            traceback(&o, qs, ts, dlo, &rb, &is, &js, &nid, &al);
+            free(o.dir);
+            double idp = (double)nid * 100.0 / (double)al;
+            double qcov = (double)(o.iend - is + 1) * 100.0 / (double)Lq;
+            if (idp >= p->min_id_pct && qcov >= p->min_qcov_pct) {
+                oracle_hit *h = &hits[nh++];
+                h->q = q; h->t = t; h->q_start = is + 1; h->q_end = o.iend + 1; h->t_start = js + 1; h->t_end = o.jend + 1;
+                h->score = o.score; h->n_ident = nid; h->aln_len = al; h->nm = al - nid; h->bin = best_bin;
+                h->cigar_runs = rb.n; h->cigar_off = ncig; h->cells = o.cells;
+                if (ncig + rb.n > capcig) { capcig = (ncig + rb.n) * 2 + 64; cig = realloc(cig, capcig * sizeof(uint32_t)); }
+                for (uint32_t r = 0; r < rb.n; ++r) cig[ncig++] = rb.runs[rb.n - 1 - r];
+            }
+        }
+        g0 = g1;
+    }
+    /* top-k per (q, split): hits are ordered by (q, t) already */
+    uint64_t out = 0, a = 0;
+    uint8_t *keep = calloc(nh + 1, 1);
+    const oracle_hit **tmp = malloc((nh + 1) * sizeof(*tmp));
+    while (a < nh) {
+        uint64_t b = a;
+        while (b < nh && hits[b].q == hits[a].q) ++b;
+        for (int s = 0; s < p->n_splits; ++s) {
+            uint64_t m = 0;
+            for (uint64_t k = a; k < b; ++k) if ((int)(hits[k].t % (uint32_t)p->n_splits) == s) tmp[m++] = &hits[k];
+            qsort(tmp, m, sizeof(*tmp), cmp_hit_rank);
+            for (uint64_t k = 0; k < m && k < (uint64_t)p->top_k; ++k) keep[tmp[k] - hits] = 1;
+        }
+        a = b;
+    }
+    /* compact hits and cigar arena */
+    uint32_t *cig2 = malloc((ncig + 1) * sizeof(uint32_t)); uint64_t nc2 = 0;
+    for (uint64_t k = 0; k < nh; ++k) if (keep[k]) {
+        oracle_hit h = hits[k];
+        memcpy(cig2 + nc2, cig + h.cigar_off, h.cigar_runs * sizeof(uint32_t));
+        h.cigar_off = nc2; nc2 += h.cigar_runs;
+        hits[out++] = h;
+    }
+    free(cig); free(keep); free(tmp); free(rb.runs); free(cand);
+    *hits_out = hits; *n_hits = out; *cigar_out = cig2; *n_cigar = nc2;
+    if (stats) { stats[0] = nc; stats[1] = cells_all; stats[2] = pairs; }
+    return 0;
+}
+
+/* one banded alignment with traceback, for kernel-level tests */
+int oracle_align_one(const oracle_params *p, const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt, int32_t bin,
+                     oracle_hit *h, uint32_t *cigar, uint32_t cigar_cap)
+{
+    int32_t dlo = bin * BIN_W - DIAG_OFF - BAND_LEAD;
+    sw_out o; runbuf rb = {0};
+    banded_sw(p, q, Lq, t, Lt, dlo, 1, &o);
+    memset(h, 0, sizeof(*h));
+    h->score = o.score; h->cells = o.cells; h->bin = bin;
+    if (o.score > 0) {
+        int32_t is, js; uint32_t nid, al;
+        traceback(&o, q, t, dlo, &rb, &is, &js, &nid, &al);
+        h->q_start = is + 1; h->q_end = o.iend + 1; h->t_start = js + 1; h->t_end = o.jend + 1;
+        h->n_ident = nid; h->aln_len = al; h->nm = al - nid; h->cigar_runs = rb.n;
+        for (uint32_t r = 0; r < rb.n && r < cigar_cap; ++r) cigar[r] = rb.runs[rb.n - 1 - r];
+    }
+    free(o.dir); free(rb.runs);
+    return 0;
+}
+
+void oracle_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------ nucleotide rescoring, mode 1
+ * restates cigar2score mode 1 (uberBlast.py:226-249) on integer counts: walks the nt CIGAR
+ * (len<<2|op, op 0=M 1=I 2=D) over encoded bases (A0 C1 G3 T4 other 2, uberBlast.py:270-271);
+ * reverse hits read the reference slice backwards as 4-code (uberBlast.py:412).
+ * out[5] = nMatch, nMismatch, nGap, bGap, mGap */
+void oracle_rescore_counts(const uint8_t *q, const uint8_t *r, int64_t qs, int64_t rs, int64_t re,
+                           const uint32_t *cigar, uint32_t n_runs, int64_t *out)
+{
+    int64_t qi = qs - 1, nmatch = 0, nmis = 0, ngap = 0, bgap = 0, mgap = 0;
+    int rev = rs > re;
+    int64_t ri = rev ? rs - 1 : rs - 1;   /* 0-based index of the first aligned reference base */
+    for (uint32_t k = 0; k < n_runs; ++k) {
+        int64_t n = cigar[k] >> 2; int op = cigar[k] & 3;
+        if (op == 0) {
+            for (int64_t x = 0; x < n; ++x) {
+                int a = q[qi + x];
+                int b = rev ? 4 - r[ri - x] : r[ri + x];
+                if (a == b) ++nmatch; else ++nmis;
+            }
+            qi += n; ri += rev ? -n : n;
+        } else {
+            ++ngap; bgap += n; if (n > 3) mgap += n;
+            if (op == 1) qi += n; else ri += rev ? -n : n;
+        }
+    }
+    out[0] = nmatch; out[1] = nmis; out[2] = ngap; out[3] = bgap; out[4] = mgap;
+}
+
+/* ------------------------------------------------------------------ connected components (single linkage)
+ * label[x] = smallest node id in x's component; restates the PARTITION produced by the
+ * reference's union-find (PEPPAN.py:1598-1607), not its root choice / member order. */
+static uint32_t uf_find(uint32_t *p, uint32_t x) { while (p[x] != x) { p[x] = p[p[x]]; x = p[x]; } return x; }
+void oracle_components(uint32_t n, uint64_t m, const uint32_t *a, const uint32_t *b, uint32_t *label)
+{
+    for (uint32_t i = 0; i < n; ++i) label[i] = i;
+    for (uint64_t e = 0; e < m; ++e) {
+        uint32_t x = uf_find(label, a[e]), y = uf_find(label, b[e]);
+        if (x == y) continue;
+        if (x < y) label[y] = x; else label[x] = y;
+    }
+    for (uint32_t i = 0; i < n; ++i) label[i] = uf_find(label, i);
+}

@@ -1,0 +1,248 @@
+"""CPU ORACLE - test infrastructure, never imported by the product (peppan_amd/).
+
+ctypes front end of oracle/_build/liboracle.so (align_oracle.c) plus numpy/pure-Python
+restatements of the reference's small host-side algorithms that the HIP path moves
+to the GPU (translation, query-frame choice, reference chunking, mode-1 rescoring).
+Every function cites the reference lines it restates; each is pinned against the golden
+vectors in tests/golden (tests/test_oracle_golden.py).
+
+The aligner half (seeds / banded Smith-Waterman / traceback / filters / top-k) is
+PARITY UNPINNED: the reference runs it inside the DIAMOND binary, which is not in
+/root/reference and cannot be executed here; see align_oracle.c's header.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, '_build', 'liboracle.so')
+
+
+class Params(C.Structure):
+    _fields_ = [('gap_open', C.c_int32), ('gap_ext', C.c_int32), ('n_shapes', C.c_int32), ('base', C.c_int32),
+                ('weight', C.c_int32 * 4), ('offs', (C.c_int32 * 32) * 4), ('reduce', C.c_uint8 * 32),
+                ('sub', C.c_int8 * 1024), ('min_id_pct', C.c_double), ('min_qcov_pct', C.c_double),
+                ('top_k', C.c_int32), ('n_splits', C.c_int32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [('q', C.c_uint32), ('t', C.c_uint32), ('q_start', C.c_uint32), ('q_end', C.c_uint32),
+                ('t_start', C.c_uint32), ('t_end', C.c_uint32), ('score', C.c_int32), ('nm', C.c_uint32),
+                ('n_ident', C.c_uint32), ('aln_len', C.c_uint32), ('cigar_runs', C.c_uint32), ('bin', C.c_int32),
+                ('cigar_off', C.c_uint64), ('cells', C.c_uint64)]
+
+
+HIT_DTYPE = np.dtype([('q', '<u4'), ('t', '<u4'), ('q_start', '<u4'), ('q_end', '<u4'), ('t_start', '<u4'), ('t_end', '<u4'),
+                      ('score', '<i4'), ('nm', '<u4'), ('n_ident', '<u4'), ('aln_len', '<u4'), ('cigar_runs', '<u4'),
+                      ('bin', '<i4'), ('cigar_off', '<u8'), ('cells', '<u8')])
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(['make', '-C', HERE, '-s'])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.oracle_min_score.restype = C.c_int32
+        _lib.oracle_min_score.argtypes = [C.c_uint32, C.c_double, C.c_double]
+    return _lib
+
+
+def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5):
+    p = Params()
+    lib().oracle_default_params(C.byref(p))
+    p.min_id_pct, p.min_qcov_pct, p.top_k, p.n_splits = min_id_pct, min_qcov_pct, top_k, n_splits
+    return p
+
+
+def min_score(qlen, dbsize=5e6, max_evalue=1.):
+    return int(lib().oracle_min_score(int(qlen), float(dbsize), float(max_evalue)))
+
+
+def aa_codes(s):
+    """protein letters -> residue codes (letter - 'A'); '-' and anything else -> X (23)"""
+    a = np.frombuffer(s.encode('ascii'), dtype=np.uint8).astype(np.int16) - 65
+    a[(a < 0) | (a > 25)] = 23
+    return a.astype(np.uint8)
+
+
+def pack(seqs):
+    """list of uint8 arrays -> (concatenated residues, uint64 offsets[n+1])"""
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    if len(seqs):
+        off[1:] = np.cumsum([len(s) for s in seqs])
+    res = np.concatenate(seqs).astype(np.uint8) if len(seqs) and off[-1] else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(res), off
+
+
+def search(q_seqs, t_seqs, params=None, min_scores=None, dbsize=5e6, max_evalue=1.):
+    """q_seqs / t_seqs: lists of uint8 residue-code arrays.
+    returns (hits structured array, cigar uint32 array (len<<2|op), stats dict)"""
+    L = lib()
+    p = params or default_params()
+    qr, qo = pack(q_seqs)
+    tr, to = pack(t_seqs)
+    if min_scores is None:
+        min_scores = np.array([min_score(len(s), dbsize, max_evalue) for s in q_seqs], dtype=np.int32)
+    min_scores = np.ascontiguousarray(min_scores, dtype=np.int32)
+    hits_p, cig_p = C.POINTER(Hit)(), C.POINTER(C.c_uint32)()
+    nh, ncg = C.c_uint64(), C.c_uint64()
+    stats = (C.c_uint64 * 3)()
+    if len(qr) == 0:
+        qr = np.zeros(1, np.uint8)
+    if len(tr) == 0:
+        tr = np.zeros(1, np.uint8)
+    rc = L.oracle_search(C.byref(p), qr.ctypes.data_as(C.c_void_p), qo.ctypes.data_as(C.c_void_p), C.c_uint32(len(q_seqs)),
+                         tr.ctypes.data_as(C.c_void_p), to.ctypes.data_as(C.c_void_p), C.c_uint32(len(t_seqs)),
+                         min_scores.ctypes.data_as(C.c_void_p), C.byref(hits_p), C.byref(nh), C.byref(cig_p), C.byref(ncg), stats)
+    assert rc == 0
+    n = nh.value
+    hits = np.zeros(n, dtype=HIT_DTYPE)
+    if n:
+        C.memmove(hits.ctypes.data, hits_p, n * C.sizeof(Hit))
+    cig = np.zeros(ncg.value, dtype=np.uint32)
+    if ncg.value:
+        C.memmove(cig.ctypes.data, cig_p, ncg.value * 4)
+    L.oracle_free(hits_p)
+    L.oracle_free(cig_p)
+    return hits, cig, dict(candidates=int(stats[0]), cells=int(stats[1]), pairs=int(stats[2]))
+
+
+def align_one(q, t, bin_, params=None):
+    L = lib()
+    p = params or default_params()
+    h = Hit()
+    cig = np.zeros(2 * min(len(q), len(t)) + 4, dtype=np.uint32)
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    L.oracle_align_one(C.byref(p), q.ctypes.data_as(C.c_void_p), C.c_int32(len(q)), t.ctypes.data_as(C.c_void_p), C.c_int32(len(t)),
+                       C.c_int32(bin_), C.byref(h), cig.ctypes.data_as(C.c_void_p), C.c_uint32(len(cig)))
+    return h, cig[:h.cigar_runs].copy()
+
+
+def rescore_counts(q_codes, r_codes, qs, rs, re_, cigar):
+    """mode-1 integer counts (nMatch, nMismatch, nGap, bGap, mGap); uberBlast.py:226-249, 412"""
+    out = np.zeros(5, dtype=np.int64)
+    cigar = np.ascontiguousarray(cigar, np.uint32)
+    q_codes = np.ascontiguousarray(q_codes, np.uint8)
+    r_codes = np.ascontiguousarray(r_codes, np.uint8)
+    lib().oracle_rescore_counts(q_codes.ctypes.data_as(C.c_void_p), r_codes.ctypes.data_as(C.c_void_p), C.c_int64(qs), C.c_int64(rs),
+                                C.c_int64(re_), cigar.ctypes.data_as(C.c_void_p), C.c_uint32(len(cigar)), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def components(n, a, b):
+    a = np.ascontiguousarray(a, np.uint32)
+    b = np.ascontiguousarray(b, np.uint32)
+    lab = np.zeros(n, dtype=np.uint32)
+    lib().oracle_components(C.c_uint32(n), C.c_uint64(len(a)), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), lab.ctypes.data_as(C.c_void_p))
+    return lab
+
+
+# --------------------------------------------------------------------------------------------
+# numpy / Python restatements of the reference's host-side steps that the HIP path runs on the GPU
+# --------------------------------------------------------------------------------------------
+_CODON_AA_11 = 'KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVVXYXYSSSSXCWCLFLF'   # index a<<4|b<<2|c, A0 C1 G2 T3
+
+
+def nt_encode_rescore(s):
+    """A0 C1 G3 T4 other 2  (uberBlast.py:270-271)"""
+    lut = np.full(256, 2, dtype=np.uint8)
+    for ch, v in zip('ACGT', (0, 1, 3, 4)):
+        lut[ord(ch)] = v
+    return lut[np.frombuffer(s.encode('ascii'), dtype=np.uint8)]
+
+
+def translate_frames(nt, frames, table=11):
+    """configure.transeq (configure.py:160-194) for one upper-case nt string.
+    frames: iterable of 1..6.  Returns list of protein strings ('X' = stop or ambiguous, '-' = gap codon)."""
+    tab = list(_CODON_AA_11)
+    if table == 4:
+        tab[56] = 'W'          # TGA -> W (configure.py:167-168)
+    conv = {'A': 0, 'C': 1, 'G': 2, 'T': 3}
+    fw = [conv.get(c, -1 if c != '-' else -2) for c in nt.upper()]
+    rv = [(3 - v) if v >= 0 else v for v in reversed(fw)]
+    out = []
+    for f in frames:
+        s = fw[f - 1:] if f <= 3 else rv[f - 4:]
+        aa = []
+        for k in range(0, len(s), 3):
+            cod = s[k:k + 3]
+            cod = cod + [-1] * (3 - len(cod))       # partial codon padded with 'ambiguous' (configure.py:186-187)
+            if -2 in cod:
+                aa.append('-')                      # any '-' -> index 64 (configure.py:190)
+            elif -1 in cod:
+                aa.append('X')                      # ambiguous -> index 50 (configure.py:191)
+            else:
+                aa.append(tab[(cod[0] << 4) | (cod[1] << 2) | cod[2]])
+        out.append(''.join(aa))
+    return out
+
+
+def query_frame(nt, table=11):
+    """frame choice of runDiamond (uberBlast.py:525-529): min over (number of X-separated
+    segments of s[:-1], frame index); returns (frame 1..3, protein string)"""
+    ss = translate_frames(nt, (1, 2, 3), table)
+    best = min((s[:-1].count('X') + 1, i, s) for i, s in enumerate(ss))
+    return best[1] + 1, best[2]
+
+
+def ref_chunks(aa):
+    """chunking of a reference frame string (uberBlast.py:539-544): cut after the first 'X'
+    at or beyond 1000 residues from the chunk start; returns [(offset, chunk_string)], empty chunks dropped"""
+    s = aa + 'X'
+    out, c0, n = [], 0, len(s)
+    while c0 < n:
+        if n - c0 >= 1001:
+            x = s.find('X', c0 + 1000)
+            out.append((c0, s[c0:x + 1]))
+            c0 = x + 1
+        else:
+            out.append((c0, s[c0:]))
+            c0 = n
+    off, last = out[-1]
+    out[-1] = (off, last[:-1])
+    return [(o, c) for o, c in out if len(c)]
+
+
+def diamond_fasta(query, ref, frames='7', table=11):
+    """the qryAA text and the 5 refAA.i texts runDiamond writes (uberBlast.py:525-549)"""
+    q_txt = []
+    for n in sorted(query):
+        f, s = query_frame(query[n], table)
+        q_txt.append('>{0}:{1}\n{2}\n'.format(n, f, s))
+    fl = (1, 2, 3, 4, 5, 6) if frames == '7' else (1, 2, 3)
+    recs = []
+    for n in sorted(ref):
+        for f, aa in zip(fl, translate_frames(ref[n], fl, table)):
+            for off, cs in ref_chunks(aa):
+                recs.append('>{0}:{1}:{2}\n{3}\n'.format(n, f, off, cs))
+    return ''.join(q_txt), [''.join(recs[i::5]) for i in range(5)]
+
+
+def parse_diamond_record(qf, rf, rx, pos, cigar_aa, nm, zs, score, ql, rl):
+    """parseDiamond coordinate algebra (uberBlast.py:25-58) for one record with forward query frame.
+    cigar_aa: list of (n, op) in residues.  Returns the 15-column row minus names, or None if filtered is decided by caller."""
+    rs = pos + rx
+    cigar = [[3 * n, op] for n, op in cigar_aa]
+    qm = sum(n for n, op in cigar_aa if op in 'MI')
+    cl = sum(n for n, _ in cigar)
+    variation = 3. * nm
+    iden = 1 - round(variation / cl, 3)
+    rm = sum(n for n, op in cigar_aa if op in 'MD')
+    if rf <= 3:
+        rs_nt, re_nt = rs * 3 + rf - 3, (rs + rm - 1) * 3 + rf - 1
+    else:
+        rs_nt, re_nt = rl - (rs * 3 + rf - 6) + 1, rl - ((rs + rm - 1) * 3 + rf - 4) + 1
+    qs_nt, qe_nt = zs * 3 + qf - 3, (zs + qm - 1) * 3 + qf - 1
+    gaps = [n for n, op in cigar if op != 'M']
+    return dict(iden=iden, cl=cl, mismatch=int(variation - sum(gaps)), gapopen=len(gaps), qs=qs_nt, qe=qe_nt, rs=rs_nt, re=re_nt,
+                score=score, qm=qm, cigar=cigar)
