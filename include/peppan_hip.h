@@ -1,0 +1,152 @@
+/*
+ * peppan_hip.h - C ABI of libpeppan_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the one data-parallel hot path of PEPPAN: the similarity search that
+ * modules/uberBlast.py delegates to the `diamond` executable and the single-linkage grouping
+ * of its hits.  Plain pointers and sizes only; every buffer handed IN is caller-owned and only
+ * read; every buffer handed OUT is filled into caller-allocated memory (sizes are queried first),
+ * except pep_result handles, which are released with pep_result_free.
+ *
+ * All functions returning int return PEP_OK (0) or a negative PEP_ERR_* code; the message of the
+ * last failure on a context is available from pep_last_error().  Nothing is ever silently dropped:
+ * capacity problems are errors, not truncation.
+ *
+ * Threading: one context per GPU; calls on one context must be serialised by the caller; distinct
+ * contexts are independent.  A context must be created in the process that uses it (HIP state does
+ * not survive fork(); the reference calls uberBlast from forked pool workers, PEPPAN.py:922).
+ *
+ * Reference interface each entry point replaces (file:line in zheminzhou/PEPPAN):
+ *   pep_set_query_nt + K1   transeq(frame='F') + per-gene frame choice     uberBlast.py:525-529, configure.py:160-194
+ *   pep_set_ref_nt   + K1   transeq(frames 6|3) + stop-codon chunking      uberBlast.py:535-544
+ *   pep_search              `diamond makedb` + 5 x `diamond blastp ... --outfmt 101`   uberBlast.py:531-533, 546-552
+ *   pep_hit fields          the SAM fields parseDiamond consumes (POS, CIGAR, |SEQ|, NM, ZR, ZS)   uberBlast.py:25-58
+ *   pep_rescore_nt          cigar2score mode 1 inside RunBlast.reScore      uberBlast.py:226-249, 397-415
+ *   pep_components          union-find of get_gene_group (partition only)   PEPPAN.py:1598-1607
+ */
+#ifndef PEPPAN_HIP_H
+#define PEPPAN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PEP_ABI_VERSION 1
+
+#define PEP_OK 0
+#define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
+#define PEP_ERR_ARG (-2)       /* invalid argument */
+#define PEP_ERR_LIMIT (-3)     /* input exceeds a documented limit */
+#define PEP_ERR_STATE (-4)     /* call order (e.g. search before sequences were set) */
+#define PEP_ERR_INTERNAL (-5)
+
+/* documented limits (candidate key packs q:21 | t:25 | diagonal bin:18) */
+#define PEP_MAX_QUERIES ((1u << 21) - 2)
+#define PEP_MAX_TARGETS ((1u << 25) - 1)
+#define PEP_MAX_SEQ_LEN ((1u << 23) - 256)
+#define PEP_MAX_RESIDUES ((1u << 29) - 1)   /* per side, padded */
+
+typedef struct pep_ctx pep_ctx;
+typedef struct pep_result pep_result;
+
+/* search parameters; pep_default_params fills the protein defaults that mirror the reference's
+ * diamond command line (uberBlast.py:550): BLOSUM62, gap 11/1, --evalue 1, --dbsize 5000000, -k 10, 5 splits */
+typedef struct {
+    int32_t gap_open, gap_ext;
+    int32_t n_shapes, base;       /* spaced seeds over a reduced alphabet of `base` letters */
+    int32_t weight[4];
+    int32_t offs[4][32];
+    uint8_t reduce[32];           /* residue code -> reduced letter; 0xFF never seeds */
+    int8_t sub[1024];             /* substitution score [q*32 + t] */
+    double min_id_pct;            /* --id           (100 * identities / alignment length) */
+    double min_qcov_pct;          /* --query-cover  (100 * aligned query span / query length) */
+    int32_t top_k;                /* -k : targets kept per query per split */
+    int32_t n_splits;             /* targets are dealt round-robin into this many splits */
+    double dbsize, max_evalue;    /* --dbsize, --evalue */
+    int32_t use_lds;              /* 1: residues staged in LDS (default); 0: read from global memory */
+    int32_t reserved[7];
+} pep_search_params;
+
+/* one alignment; coordinates are 1-based, inclusive, in residues of the query / target protein */
+typedef struct {
+    uint32_t q, t;                /* query index, target (chunk) index */
+    uint32_t q_start, q_end;      /* ZS .. */
+    uint32_t t_start, t_end;      /* POS .. */
+    int32_t score;                /* ZR raw score */
+    uint32_t nm;                  /* NM = aln_len - n_ident */
+    uint32_t n_ident, aln_len;
+    uint32_t cigar_runs;
+    int32_t bin;                  /* diagonal bin of the band that produced it */
+    uint64_t cigar_off;           /* into the result's CIGAR arena: runs of (len << 2 | op), op 0=M 1=I 2=D */
+    uint64_t cells;               /* in-band, in-matrix DP cells of this alignment's band */
+} pep_hit;
+
+typedef struct { uint32_t seq, frame, aa_len, nt_len; } pep_query_meta;       /* frame 1..3 */
+typedef struct { uint32_t seq, frame, chunk_off, aa_len; } pep_target_meta;   /* frame 1..6; name = seq:frame:chunk_off */
+
+/* a nucleotide-level hit for rescoring (uberBlast.py:412): 1-based inclusive nt coordinates, rs > re = reverse strand */
+typedef struct {
+    uint32_t q, r;
+    uint32_t qs, qe, rs, re;
+    uint32_t cigar_runs, pad;
+    uint64_t cigar_off;
+} pep_nt_hit;
+
+typedef struct {
+    uint64_t query_residues, target_residues;
+    uint64_t query_seeds, target_seeds, seed_hits;
+    uint64_t candidates;          /* unique (q, t, band) */
+    uint64_t pairs;               /* unique (q, t) */
+    uint64_t tracebacks;
+    uint64_t hits;
+    uint64_t cells;               /* in-band in-matrix DP cells over all candidates (SW cell updates) */
+    uint64_t cells_swept;         /* 64 lanes x anti-diagonal steps actually executed */
+    uint64_t dir_bytes;           /* traceback direction workspace written by the SW kernel */
+    uint64_t sw_launches;
+    double ms_seed, ms_sw, ms_trace, ms_total;   /* HIP-event times on the context's stream */
+    double ms_k1;
+} pep_stats;
+
+int pep_version(void);
+int pep_device_count(void);
+int pep_ctx_create(int device, pep_ctx **out);
+void pep_ctx_destroy(pep_ctx *ctx);
+const char *pep_last_error(const pep_ctx *ctx);
+void pep_default_params(pep_search_params *p);
+/* smallest raw score passing the e-value cut for a query of qlen residues */
+int32_t pep_min_score(uint32_t qlen, double dbsize, double max_evalue);
+
+/* nucleotide inputs (ASCII, any case), concatenated, off[n+1].  Stored on the device; K1 (translation,
+ * frame choice / chunking, packing) runs on the GPU at the next pep_translate or pep_search. */
+int pep_set_query_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint32_t n, int gtable);
+int pep_set_ref_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint32_t n, int frames /* 6 or 3 */, int gtable);
+/* protein inputs (residue code = letter - 'A'), used as they are (no K1) */
+int pep_set_query_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n);
+int pep_set_ref_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n);
+/* run K1 for the sides given as nucleotides (idempotent until the inputs change; force != 0 re-runs it) */
+int pep_translate(pep_ctx *ctx, int force);
+int pep_query_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues);
+int pep_target_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues);
+int pep_get_query_meta(pep_ctx *ctx, pep_query_meta *out, uint32_t cap);
+int pep_get_target_meta(pep_ctx *ctx, pep_target_meta *out, uint32_t cap);
+/* download the packed proteins (plain concatenation, off[n+1]) - for tests and debugging */
+int pep_get_query_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off);
+int pep_get_target_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off);
+
+/* K2..K8: seeds, candidates, banded Smith-Waterman, traceback, filters, top-k.  Hits ordered by (q, t). */
+int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out);
+int pep_result_size(const pep_result *r, uint64_t *n_hits, uint64_t *n_cigar);
+int pep_result_copy(const pep_result *r, pep_hit *hits, uint32_t *cigar);
+int pep_result_stats(const pep_result *r, pep_stats *stats);
+void pep_result_free(pep_result *r);
+
+/* K7: integer counts of mode-1 rescoring per hit, out[5*i..] = nMatch, nMismatch, nGap, bGap, mGap.
+ * Uses the nucleotide sets given to pep_set_query_nt / pep_set_ref_nt. */
+int pep_rescore_nt(pep_ctx *ctx, uint64_t n, const pep_nt_hit *hits, const uint32_t *cigar, uint64_t n_cigar, int64_t *out);
+
+/* K10: connected components; label[x] = smallest node id of x's component */
+int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *a, const uint32_t *b, uint32_t *label);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

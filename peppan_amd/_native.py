@@ -1,0 +1,225 @@
+"""ctypes binding of libpeppan_hip.so (include/peppan_hip.h).  No torch, no CPU fallback:
+if the HIP library is missing or no MI355X is visible every entry point raises."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
+
+ABI_VERSION = 1
+EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
+           'pep_min_score', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
+           'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
+           'pep_get_target_aa', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
+           'pep_rescore_nt', 'pep_components']
+
+
+class PepError(RuntimeError):
+    pass
+
+
+class SearchParams(C.Structure):
+    _fields_ = [('gap_open', C.c_int32), ('gap_ext', C.c_int32), ('n_shapes', C.c_int32), ('base', C.c_int32),
+                ('weight', C.c_int32 * 4), ('offs', (C.c_int32 * 32) * 4), ('reduce', C.c_uint8 * 32),
+                ('sub', C.c_int8 * 1024), ('min_id_pct', C.c_double), ('min_qcov_pct', C.c_double),
+                ('top_k', C.c_int32), ('n_splits', C.c_int32), ('dbsize', C.c_double), ('max_evalue', C.c_double),
+                ('use_lds', C.c_int32), ('reserved', C.c_int32 * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ('query_residues', 'target_residues', 'query_seeds', 'target_seeds', 'seed_hits',
+                                           'candidates', 'pairs', 'tracebacks', 'hits', 'cells', 'cells_swept', 'dir_bytes',
+                                           'sw_launches')] + \
+               [(n, C.c_double) for n in ('ms_seed', 'ms_sw', 'ms_trace', 'ms_total', 'ms_k1')]
+
+
+HIT_DTYPE = np.dtype([('q', '<u4'), ('t', '<u4'), ('q_start', '<u4'), ('q_end', '<u4'), ('t_start', '<u4'), ('t_end', '<u4'),
+                      ('score', '<i4'), ('nm', '<u4'), ('n_ident', '<u4'), ('aln_len', '<u4'), ('cigar_runs', '<u4'),
+                      ('bin', '<i4'), ('cigar_off', '<u8'), ('cells', '<u8')])
+QUERY_META_DTYPE = np.dtype([('seq', '<u4'), ('frame', '<u4'), ('aa_len', '<u4'), ('nt_len', '<u4')])
+TARGET_META_DTYPE = np.dtype([('seq', '<u4'), ('frame', '<u4'), ('chunk_off', '<u4'), ('aa_len', '<u4')])
+NT_HIT_DTYPE = np.dtype([('q', '<u4'), ('r', '<u4'), ('qs', '<u4'), ('qe', '<u4'), ('rs', '<u4'), ('re', '<u4'),
+                         ('cigar_runs', '<u4'), ('pad', '<u4'), ('cigar_off', '<u8')])
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree library; raises PepError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PepError('libpeppan_hip.so is not built (run `python -c "import __graft_entry__ as g; g.build()"` '
+                       'or `make -C peppan_amd/csrc`); there is no CPU fallback')
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise PepError('libpeppan_hip.so does not export ' + name)
+    lib.pep_last_error.restype = C.c_char_p
+    lib.pep_last_error.argtypes = [C.c_void_p]
+    lib.pep_min_score.restype = C.c_int32
+    lib.pep_min_score.argtypes = [C.c_uint32, C.c_double, C.c_double]
+    lib.pep_ctx_destroy.argtypes = [C.c_void_p]
+    lib.pep_ctx_destroy.restype = None
+    lib.pep_result_free.argtypes = [C.c_void_p]
+    lib.pep_result_free.restype = None
+    if lib.pep_version() != ABI_VERSION:
+        raise PepError('libpeppan_hip.so ABI version mismatch')
+    _lib = lib
+    return lib
+
+
+def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5, dbsize=5e6, max_evalue=1., use_lds=1):
+    p = SearchParams()
+    load_library().pep_default_params(C.byref(p))
+    p.min_id_pct, p.min_qcov_pct, p.top_k, p.n_splits = float(min_id_pct), float(min_qcov_pct), int(top_k), int(n_splits)
+    p.dbsize, p.max_evalue, p.use_lds = float(dbsize), float(max_evalue), int(use_lds)
+    return p
+
+
+def min_score(qlen, dbsize=5e6, max_evalue=1.):
+    return int(load_library().pep_min_score(int(qlen), float(dbsize), float(max_evalue)))
+
+
+def _pack(seqs):
+    """list of bytes / uint8 arrays -> (uint8 concatenation, uint64 offsets[n+1])"""
+    arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else
+            (np.frombuffer(s.encode('ascii'), dtype=np.uint8) if isinstance(s, str) else np.asarray(s, dtype=np.uint8)) for s in seqs]
+    off = np.zeros(len(arrs) + 1, dtype=np.uint64)
+    if arrs:
+        off[1:] = np.cumsum([a.size for a in arrs])
+    res = np.concatenate(arrs) if arrs and off[-1] else np.zeros(1, dtype=np.uint8)
+    return np.ascontiguousarray(res, dtype=np.uint8), off
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context(object):
+    """one GPU context (one per process per device; create it AFTER any fork)"""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        if self._lib.pep_device_count() <= 0:
+            raise PepError('no HIP device visible: peppan_amd needs an MI355X (there is no CPU fallback)')
+        h = C.c_void_p()
+        rc = self._lib.pep_ctx_create(int(device), C.byref(h))
+        self._h = h
+        if rc != 0:
+            msg = self._lib.pep_last_error(h).decode() if h else 'pep_ctx_create failed'
+            if h:
+                self._lib.pep_ctx_destroy(h)
+                self._h = None
+            raise PepError('pep_ctx_create(%d): %d %s' % (device, rc, msg))
+        self.device = device
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.pep_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PepError('%s failed (%d): %s' % (what, rc, self._lib.pep_last_error(self._h).decode()))
+
+    # ---- inputs
+    def set_query_nt(self, seqs, gtable=11):
+        nt, off = _pack(seqs)
+        self._check(self._lib.pep_set_query_nt(self._h, _ptr(nt), _ptr(off), C.c_uint32(len(seqs)), C.c_int(gtable)), 'pep_set_query_nt')
+
+    def set_ref_nt(self, seqs, frames=6, gtable=11):
+        nt, off = _pack(seqs)
+        self._check(self._lib.pep_set_ref_nt(self._h, _ptr(nt), _ptr(off), C.c_uint32(len(seqs)), C.c_int(frames), C.c_int(gtable)), 'pep_set_ref_nt')
+
+    def set_query_aa(self, seqs):
+        aa, off = _pack(seqs)
+        self._check(self._lib.pep_set_query_aa(self._h, _ptr(aa), _ptr(off), C.c_uint32(len(seqs))), 'pep_set_query_aa')
+
+    def set_ref_aa(self, seqs):
+        aa, off = _pack(seqs)
+        self._check(self._lib.pep_set_ref_aa(self._h, _ptr(aa), _ptr(off), C.c_uint32(len(seqs))), 'pep_set_ref_aa')
+
+    def translate(self, force=False):
+        self._check(self._lib.pep_translate(self._h, C.c_int(1 if force else 0)), 'pep_translate')
+
+    # ---- K1 products
+    def query_meta(self):
+        n, r = C.c_uint32(), C.c_uint64()
+        self._check(self._lib.pep_query_count(self._h, C.byref(n), C.byref(r)), 'pep_query_count')
+        out = np.zeros(n.value, dtype=QUERY_META_DTYPE)
+        self._check(self._lib.pep_get_query_meta(self._h, _ptr(out), C.c_uint32(n.value)), 'pep_get_query_meta')
+        return out
+
+    def target_meta(self):
+        n, r = C.c_uint32(), C.c_uint64()
+        self._check(self._lib.pep_target_count(self._h, C.byref(n), C.byref(r)), 'pep_target_count')
+        out = np.zeros(n.value, dtype=TARGET_META_DTYPE)
+        self._check(self._lib.pep_get_target_meta(self._h, _ptr(out), C.c_uint32(n.value)), 'pep_get_target_meta')
+        return out
+
+    def _get_aa(self, count_fn, get_fn, what):
+        n, r = C.c_uint32(), C.c_uint64()
+        self._check(count_fn(self._h, C.byref(n), C.byref(r)), what)
+        codes = np.zeros(max(1, r.value), dtype=np.uint8)
+        off = np.zeros(n.value + 1, dtype=np.uint64)
+        self._check(get_fn(self._h, _ptr(codes), C.c_uint64(r.value), _ptr(off)), what)
+        return codes[:r.value], off
+
+    def query_aa(self):
+        return self._get_aa(self._lib.pep_query_count, self._lib.pep_get_query_aa, 'pep_get_query_aa')
+
+    def target_aa(self):
+        return self._get_aa(self._lib.pep_target_count, self._lib.pep_get_target_aa, 'pep_get_target_aa')
+
+    # ---- search
+    def search(self, params=None):
+        """returns (hits [HIT_DTYPE], cigar uint32 [len<<2|op], stats dict)"""
+        r = C.c_void_p()
+        self._check(self._lib.pep_search(self._h, C.byref(params) if params is not None else None, C.byref(r)), 'pep_search')
+        try:
+            nh, nc = C.c_uint64(), C.c_uint64()
+            self._check(self._lib.pep_result_size(r, C.byref(nh), C.byref(nc)), 'pep_result_size')
+            hits = np.zeros(nh.value, dtype=HIT_DTYPE)
+            cig = np.zeros(nc.value, dtype=np.uint32)
+            self._check(self._lib.pep_result_copy(r, _ptr(hits), _ptr(cig)), 'pep_result_copy')
+            st = Stats()
+            self._check(self._lib.pep_result_stats(r, C.byref(st)), 'pep_result_stats')
+        finally:
+            self._lib.pep_result_free(r)
+        return hits, cig, {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    # ---- K7
+    def rescore_nt(self, nt_hits, cigar):
+        nt_hits = np.ascontiguousarray(nt_hits, dtype=NT_HIT_DTYPE)
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        out = np.zeros((len(nt_hits), 5), dtype=np.int64)
+        if len(nt_hits):
+            cg = cigar if len(cigar) else np.zeros(1, np.uint32)
+            self._check(self._lib.pep_rescore_nt(self._h, C.c_uint64(len(nt_hits)), _ptr(nt_hits), _ptr(cg), C.c_uint64(len(cigar)), _ptr(out)), 'pep_rescore_nt')
+        return out
+
+    # ---- K10
+    def components(self, n_nodes, a, b):
+        a = np.ascontiguousarray(a, dtype=np.uint32)
+        b = np.ascontiguousarray(b, dtype=np.uint32)
+        lab = np.zeros(n_nodes, dtype=np.uint32)
+        if n_nodes:
+            aa = a if len(a) else np.zeros(1, np.uint32)
+            bb = b if len(b) else np.zeros(1, np.uint32)
+            self._check(self._lib.pep_components(self._h, C.c_uint32(n_nodes), C.c_uint64(len(a)), _ptr(aa), _ptr(bb), _ptr(lab)), 'pep_components')
+        return lab

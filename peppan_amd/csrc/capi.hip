@@ -1,0 +1,463 @@
+// C ABI of libpeppan_hip.so (declared in include/peppan_hip.h): context, inputs, orchestration of K1..K8.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+int pep_fail(pep_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int dev_reserve(pep_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return PEP_OK;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = std::max<size_t>(bytes + bytes / 4, 256);
+    want = (want + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return pep_fail(ctx, PEP_ERR_HIP, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    }
+    b.cap = want;
+    return PEP_OK;
+}
+
+void dev_release(DevBuf &b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+namespace {
+
+// BLOSUM62 in the NCBI text layout (public domain); parsed once into the 32x32 code-indexed table
+const char *kBlosum62Text =
+    "   A  R  N  D  C  Q  E  G  H  I  L  K  M  F  P  S  T  W  Y  V  B  Z  X  *\n"
+    "A  4 -1 -2 -2  0 -1 -1  0 -2 -1 -1 -1 -1 -2 -1  1  0 -3 -2  0 -2 -1  0 -4\n"
+    "R -1  5  0 -2 -3  1  0 -2  0 -3 -2  2 -1 -3 -2 -1 -1 -3 -2 -3 -1  0 -1 -4\n"
+    "N -2  0  6  1 -3  0  0  0  1 -3 -3  0 -2 -3 -2  1  0 -4 -2 -3  3  0 -1 -4\n"
+    "D -2 -2  1  6 -3  0  2 -1 -1 -3 -4 -1 -3 -3 -1  0 -1 -4 -3 -3  4  1 -1 -4\n"
+    "C  0 -3 -3 -3  9 -3 -4 -3 -3 -1 -1 -3 -1 -2 -3 -1 -1 -2 -2 -1 -3 -3 -2 -4\n"
+    "Q -1  1  0  0 -3  5  2 -2  0 -3 -2  1  0 -3 -1  0 -1 -2 -1 -2  0  3 -1 -4\n"
+    "E -1  0  0  2 -4  2  5 -2  0 -3 -3  1 -2 -3 -1  0 -1 -3 -2 -2  1  4 -1 -4\n"
+    "G  0 -2  0 -1 -3 -2 -2  6 -2 -4 -4 -2 -3 -3 -2  0 -2 -2 -3 -3 -1 -2 -1 -4\n"
+    "H -2  0  1 -1 -3  0  0 -2  8 -3 -3 -1 -2 -1 -2 -1 -2 -2  2 -3  0  0 -1 -4\n"
+    "I -1 -3 -3 -3 -1 -3 -3 -4 -3  4  2 -3  1  0 -3 -2 -1 -3 -1  3 -3 -3 -1 -4\n"
+    "L -1 -2 -3 -4 -1 -2 -3 -4 -3  2  4 -2  2  0 -3 -2 -1 -2 -1  1 -4 -3 -1 -4\n"
+    "K -1  2  0 -1 -3  1  1 -2 -1 -3 -2  5 -1 -3 -1  0 -1 -3 -2 -2  0  1 -1 -4\n"
+    "M -1 -1 -2 -3 -1  0 -2 -3 -2  1  2 -1  5  0 -2 -1 -1 -1 -1  1 -3 -1 -1 -4\n"
+    "F -2 -3 -3 -3 -2 -3 -3 -3 -1  0  0 -3  0  6 -4 -2 -2  1  3 -1 -3 -3 -1 -4\n"
+    "P -1 -2 -2 -1 -3 -1 -1 -2 -2 -3 -3 -1 -2 -4  7 -1 -1 -4 -3 -2 -2 -1 -2 -4\n"
+    "S  1 -1  1  0 -1  0  0  0 -1 -2 -2  0 -1 -2 -1  4  1 -3 -2 -2  0  0  0 -4\n"
+    "T  0 -1  0 -1 -1 -1 -1 -2 -2 -1 -1 -1 -1 -2 -1  1  5 -2 -2  0 -1 -1  0 -4\n"
+    "W -3 -3 -4 -4 -2 -2 -3 -2 -2 -3 -2 -3 -1  1 -4 -3 -2 11  2 -3 -4 -3 -2 -4\n"
+    "Y -2 -2 -2 -3 -2 -1 -2 -3  2 -1 -1 -2 -1  3 -3 -2 -2  2  7 -1 -3 -2 -1 -4\n"
+    "V  0 -3 -3 -3 -1 -2 -2 -3 -3  3  1 -2  1 -1 -2 -2  0 -3 -1  4 -3 -2 -1 -4\n"
+    "B -2 -1  3  4 -3  0  1 -1  0 -3 -4  0 -3 -3 -2  0 -1 -4 -3 -3  4  1 -1 -4\n"
+    "Z -1  0  0  1 -3  3  4 -2  0 -3 -3  1 -1 -3 -1  0 -1 -3 -2 -2  1  4 -1 -4\n"
+    "X  0 -1 -1 -1 -2 -1 -1 -1 -1 -1 -1 -1 -1 -1 -2  0  0 -2 -1 -1 -1 -1 -1 -4\n"
+    "* -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4  1\n";
+
+void parse_blosum(int8_t sub[1024])
+{
+    char cols[32];
+    int ncol = 0;
+    const char *p = kBlosum62Text;
+    while (*p != '\n') { if (*p != ' ') cols[ncol++] = *p; ++p; }
+    ++p;
+    int m[26][26];
+    bool have[26] = {false};
+    for (int r = 0; r < ncol; ++r) {
+        while (*p == ' ') ++p;
+        const char row = *p++;
+        for (int c = 0; c < ncol; ++c) {
+            char *end;
+            const long v = strtol(p, &end, 10);
+            p = end;
+            if (row >= 'A' && row <= 'Z' && cols[c] >= 'A' && cols[c] <= 'Z') { m[row - 'A'][cols[c] - 'A'] = (int)v; have[row - 'A'] = true; }
+        }
+        while (*p && *p != '\n') ++p;
+        if (*p) ++p;
+    }
+    const int X = 'X' - 'A';
+    for (int a = 0; a < 32; ++a)
+        for (int b = 0; b < 32; ++b) {
+            int v = -64;                                   // padding codes kill every path
+            if (a < 26 && b < 26) v = m[have[a] ? a : X][have[b] ? b : X];    // J, O, U score as X
+            sub[a * 32 + b] = (int8_t)v;
+        }
+}
+
+// image of the substitution table as the SW kernel keeps it in LDS: dword (q*8 + t/4)*32 + bank, replicated over the 32 banks
+int upload_sub_image(pep_ctx *ctx)
+{
+    std::vector<uint32_t> img(8192);
+    const int8_t *s = ctx->params.sub;
+    for (int w = 0; w < 256; ++w) {
+        const int q = w >> 3, t0 = (w & 7) * 4;
+        uint32_t v = 0;
+        for (int k = 0; k < 4; ++k) v |= (uint32_t)(uint8_t)s[q * 32 + t0 + k] << (8 * k);
+        for (int b = 0; b < 32; ++b) img[w * 32 + b] = v;
+    }
+    PEP_TRY(dev_reserve(ctx, ctx->sub_lds, img.size() * 4));
+    PEP_HIP(ctx, hipMemcpy(ctx->sub_lds.p, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+    return PEP_OK;
+}
+
+int upload_nt(pep_ctx *ctx, NtSet &s, const uint8_t *nt, const uint64_t *off, uint32_t n)
+{
+    if (n && (!nt || !off)) return pep_fail(ctx, PEP_ERR_ARG, "null sequence buffer");
+    s.n = n;
+    s.h_off.assign(n + 1, 0);
+    for (uint32_t i = 0; i <= n; ++i) {
+        s.h_off[i] = n ? off[i] : 0;
+        if (i && s.h_off[i] < s.h_off[i - 1]) return pep_fail(ctx, PEP_ERR_ARG, "offsets must be non-decreasing");
+    }
+    s.total = s.h_off[n];
+    PEP_TRY(dev_reserve(ctx, s.nt, s.total + 64));
+    PEP_TRY(dev_reserve(ctx, s.off, (size_t)(n + 1) * 8));
+    if (s.total) PEP_HIP(ctx, hipMemcpy(s.nt.p, nt, s.total, hipMemcpyHostToDevice));
+    PEP_HIP(ctx, hipMemcpy(s.off.p, s.h_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+    return PEP_OK;
+}
+
+int upload_aa(pep_ctx *ctx, SeqSet &s, const uint8_t *codes, const uint64_t *off, uint32_t n, uint32_t max_n)
+{
+    if (n && (!codes || !off)) return pep_fail(ctx, PEP_ERR_ARG, "null sequence buffer");
+    if (n > max_n) return pep_fail(ctx, PEP_ERR_LIMIT, "too many sequences");
+    s.n = n;
+    s.h_off.assign(n + 1, 0);
+    s.h_len.assign(n, 0);
+    uint64_t pos = PEP_END_PAD, residues = 0;
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (off[i + 1] < off[i]) return pep_fail(ctx, PEP_ERR_ARG, "offsets must be non-decreasing");
+        const uint64_t len = off[i + 1] - off[i];
+        if (len > PEP_MAX_SEQ_LEN) return pep_fail(ctx, PEP_ERR_LIMIT, "sequence longer than PEP_MAX_SEQ_LEN");
+        s.h_off[i] = (uint32_t)pos;
+        s.h_len[i] = (uint32_t)len;
+        residues += len;
+        max_len = std::max<uint32_t>(max_len, (uint32_t)len);
+        pos += (len + 15) / 16 * 16 + PEP_SEQ_GAP;
+        if (pos > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "packed protein set exceeds 2^29 bytes");
+    }
+    pos += PEP_END_PAD;
+    s.h_off[n] = (uint32_t)pos;
+    s.total = pos; s.residues = residues; s.max_len = max_len;
+    std::vector<uint8_t> img(pos, (uint8_t)PEP_PAD_CODE);
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t x = 0; x < s.h_len[i]; ++x) {
+            const uint8_t c = codes[off[i] + x];
+            img[s.h_off[i] + x] = c < 26 ? c : (uint8_t)23;     // anything that is not a letter is X
+        }
+    PEP_TRY(dev_reserve(ctx, s.res, pos + 64));
+    PEP_TRY(dev_reserve(ctx, s.off, (size_t)(n + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, s.len, (size_t)(n + 1) * 4));
+    PEP_HIP(ctx, hipMemcpy(s.res.p, img.data(), pos, hipMemcpyHostToDevice));
+    PEP_HIP(ctx, hipMemcpy(s.off.p, s.h_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
+    if (n) PEP_HIP(ctx, hipMemcpy(s.len.p, s.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    return PEP_OK;
+}
+
+int download_aa(pep_ctx *ctx, const SeqSet &s, uint8_t *codes, uint64_t cap, uint64_t *off)
+{
+    if (s.residues > cap) return pep_fail(ctx, PEP_ERR_ARG, "output buffer too small");
+    std::vector<uint8_t> img(s.total);
+    if (s.total) PEP_HIP(ctx, hipMemcpy(img.data(), s.res.p, s.total, hipMemcpyDeviceToHost));
+    uint64_t pos = 0;
+    for (uint32_t i = 0; i < s.n; ++i) {
+        off[i] = pos;
+        memcpy(codes + pos, img.data() + s.h_off[i], s.h_len[i]);
+        pos += s.h_len[i];
+    }
+    off[s.n] = pos;
+    return PEP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pep_version(void) { return PEP_ABI_VERSION; }
+
+int pep_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void pep_default_params(pep_search_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->gap_open = 11; p->gap_ext = 1;
+    parse_blosum(p->sub);
+    memset(p->reduce, 0xFF, sizeof(p->reduce));
+    // reduced alphabet of Buchfink, Xie & Huson 2015: [KREDQN] [C] [G] [H] [ILV] [M] [F] [Y] [W] [P] [STA]
+    const char *groups = "KREDQN/C/G/H/ILV/M/F/Y/W/P/STA";
+    int g = 0;
+    for (const char *c = groups; *c; ++c) { if (*c == '/') ++g; else p->reduce[*c - 'A'] = (uint8_t)g; }
+    p->base = g + 1;
+    const char *shapes[2] = {"111101110111", "111011010010111"};
+    p->n_shapes = 2;
+    for (int s = 0; s < 2; ++s) {
+        int w = 0;
+        for (int k = 0; shapes[s][k]; ++k) if (shapes[s][k] == '1') p->offs[s][w++] = k;
+        p->weight[s] = w;
+    }
+    p->min_id_pct = 0.; p->min_qcov_pct = 0.; p->top_k = 10; p->n_splits = 5;
+    p->dbsize = 5e6; p->max_evalue = 1.;
+    p->use_lds = 1;
+}
+
+int32_t pep_min_score(uint32_t qlen, double dbsize, double max_evalue)
+{
+    // Karlin-Altschul statistics of gapped BLOSUM62 11/1: E = K m n exp(-lambda S)
+    const double lambda = 0.267, K = 0.041;
+    const double s = log(K * (double)qlen * dbsize / max_evalue) / lambda;
+    const int32_t r = (int32_t)ceil(s);
+    return r < 1 ? 1 : r;
+}
+
+int pep_ctx_create(int device, pep_ctx **out)
+{
+    if (!out) return PEP_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return PEP_ERR_HIP;
+    pep_ctx *ctx = new (std::nothrow) pep_ctx();
+    if (!ctx) return PEP_ERR_INTERNAL;
+    ctx->device = device;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    pep_default_params(&ctx->params);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PEP_ERR_HIP; }
+    int rc = pep_selftest_dpp(ctx);
+    if (rc != PEP_OK) { *out = ctx; return rc; }      // caller can read the message, then destroy
+    *out = ctx;
+    return PEP_OK;
+}
+
+void pep_ctx_destroy(pep_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto &b : ctx->ws) dev_release(b);
+    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->d_t_meta, &ctx->d_q_meta, &ctx->d_min_score, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
+                      &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len};
+    for (DevBuf *b : bufs) dev_release(*b);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *pep_last_error(const pep_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int pep_set_query_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint32_t n, int gtable)
+{
+    if (!ctx) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    if (n > PEP_MAX_QUERIES) return pep_fail(ctx, PEP_ERR_LIMIT, "too many queries");
+    PEP_TRY(upload_nt(ctx, ctx->q_nt, nt, off, n));
+    ctx->q_from_nt = true; ctx->q_gtable = gtable; ctx->q_ready = false;
+    return PEP_OK;
+}
+
+int pep_set_ref_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint32_t n, int frames, int gtable)
+{
+    if (!ctx) return PEP_ERR_ARG;
+    if (frames != 3 && frames != 6) return pep_fail(ctx, PEP_ERR_ARG, "frames must be 3 or 6");
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    PEP_TRY(upload_nt(ctx, ctx->r_nt, nt, off, n));
+    ctx->t_from_nt = true; ctx->t_gtable = gtable; ctx->t_frames = frames; ctx->t_ready = false;
+    return PEP_OK;
+}
+
+int pep_set_query_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n)
+{
+    if (!ctx) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    PEP_TRY(upload_aa(ctx, ctx->q, codes, off, n, PEP_MAX_QUERIES));
+    ctx->q_meta.resize(n);
+    for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, 0u, ctx->q.h_len[i], 0u};
+    ctx->q_from_nt = false; ctx->q_ready = true;
+    return PEP_OK;
+}
+
+int pep_set_ref_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n)
+{
+    if (!ctx) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    PEP_TRY(upload_aa(ctx, ctx->t, codes, off, n, PEP_MAX_TARGETS));
+    ctx->t_meta.resize(n);
+    for (uint32_t i = 0; i < n; ++i) ctx->t_meta[i] = pep_target_meta{i, 0u, 0u, ctx->t.h_len[i]};
+    ctx->t_from_nt = false; ctx->t_ready = true;
+    return PEP_OK;
+}
+
+int pep_translate(pep_ctx *ctx, int force)
+{
+    if (!ctx) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e0, e1;
+    PEP_HIP(ctx, hipEventCreate(&e0));
+    PEP_HIP(ctx, hipEventCreate(&e1));
+    PEP_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    if (ctx->q_from_nt && (force || !ctx->q_ready)) { PEP_TRY(pep_k1_query(ctx, ctx->q_gtable)); ctx->q_ready = true; }
+    if (ctx->t_from_nt && (force || !ctx->t_ready)) { PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable)); ctx->t_ready = true; }
+    PEP_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    PEP_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    PEP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    ctx->stats.ms_k1 = ms;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return PEP_OK;
+}
+
+int pep_query_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues)
+{
+    if (!ctx || !ctx->q_ready) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
+    if (n) *n = ctx->q.n;
+    if (residues) *residues = ctx->q.residues;
+    return PEP_OK;
+}
+
+int pep_target_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues)
+{
+    if (!ctx || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
+    if (n) *n = ctx->t.n;
+    if (residues) *residues = ctx->t.residues;
+    return PEP_OK;
+}
+
+int pep_get_query_meta(pep_ctx *ctx, pep_query_meta *out, uint32_t cap)
+{
+    if (!ctx || !ctx->q_ready) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
+    if (cap < ctx->q_meta.size()) return pep_fail(ctx, PEP_ERR_ARG, "output buffer too small");
+    if (!ctx->q_meta.empty()) memcpy(out, ctx->q_meta.data(), ctx->q_meta.size() * sizeof(pep_query_meta));
+    return PEP_OK;
+}
+
+int pep_get_target_meta(pep_ctx *ctx, pep_target_meta *out, uint32_t cap)
+{
+    if (!ctx || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
+    if (cap < ctx->t_meta.size()) return pep_fail(ctx, PEP_ERR_ARG, "output buffer too small");
+    if (!ctx->t_meta.empty()) memcpy(out, ctx->t_meta.data(), ctx->t_meta.size() * sizeof(pep_target_meta));
+    return PEP_OK;
+}
+
+int pep_get_query_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off)
+{
+    if (!ctx || !ctx->q_ready) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    return download_aa(ctx, ctx->q, codes, cap, off);
+}
+
+int pep_get_target_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off)
+{
+    if (!ctx || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    return download_aa(ctx, ctx->t, codes, cap, off);
+}
+
+int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
+{
+    if (!ctx || !out) return PEP_ERR_ARG;
+    *out = nullptr;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    if (params) {
+        if (params->n_shapes < 1 || params->n_shapes > 4 || params->base < 2 || params->top_k < 1 || params->n_splits < 1)
+            return pep_fail(ctx, PEP_ERR_ARG, "invalid search parameters");
+        for (int s = 0; s < params->n_shapes; ++s) {
+            if (params->weight[s] < 1 || params->weight[s] > 32) return pep_fail(ctx, PEP_ERR_ARG, "invalid seed weight");
+            if (params->offs[s][params->weight[s] - 1] > 31) return pep_fail(ctx, PEP_ERR_ARG, "seed span above 32");
+            if (pow((double)params->base, params->weight[s]) > 34359738368.0) return pep_fail(ctx, PEP_ERR_ARG, "seed key does not fit 35 bits");
+        }
+        ctx->params = *params;
+        ctx->sub_ready = false;
+    }
+    PEP_TRY(pep_translate(ctx, 0));
+    if (!ctx->q_ready || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "pep_search before both sequence sets were given");
+    if (!ctx->sub_ready) { PEP_TRY(upload_sub_image(ctx)); ctx->sub_ready = true; }
+
+    pep_result *res = new (std::nothrow) pep_result();
+    if (!res) return pep_fail(ctx, PEP_ERR_INTERNAL, "out of host memory");
+    res->ctx = ctx;
+    const double ms_k1 = ctx->stats.ms_k1;
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    ctx->stats.ms_k1 = ms_k1;
+    ctx->stats.query_residues = ctx->q.residues;
+    ctx->stats.target_residues = ctx->t.residues;
+
+    hipEvent_t e0, e1, e2;
+    hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
+    hipEventRecord(e0, ctx->stream);
+    uint64_t *d_cands = nullptr, n_cands = 0;
+    int rc = pep_find_candidates(ctx, &d_cands, &n_cands);
+    hipEventRecord(e1, ctx->stream);
+    if (rc == PEP_OK) {
+        std::vector<int32_t> min_score(ctx->q.n + 1);
+        for (uint32_t i = 0; i < ctx->q.n; ++i) min_score[i] = pep_min_score(ctx->q.h_len[i], ctx->params.dbsize, ctx->params.max_evalue);
+        rc = pep_extend(ctx, d_cands, n_cands, min_score.data(), res);
+    }
+    hipEventRecord(e2, ctx->stream);
+    hipError_t se = hipStreamSynchronize(ctx->stream);
+    if (rc == PEP_OK && se != hipSuccess) rc = pep_fail(ctx, PEP_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
+    float a = 0.f, b = 0.f;
+    if (rc == PEP_OK) {
+        hipEventElapsedTime(&a, e0, e1);
+        hipEventElapsedTime(&b, e0, e2);
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    if (rc != PEP_OK) { delete res; return rc; }
+    ctx->stats.ms_seed = a;
+    ctx->stats.ms_total = b;
+    res->stats = ctx->stats;
+    *out = res;
+    return PEP_OK;
+}
+
+int pep_result_size(const pep_result *r, uint64_t *n_hits, uint64_t *n_cigar)
+{
+    if (!r) return PEP_ERR_ARG;
+    if (n_hits) *n_hits = r->hits.size();
+    if (n_cigar) *n_cigar = r->cigar.size();
+    return PEP_OK;
+}
+
+int pep_result_copy(const pep_result *r, pep_hit *hits, uint32_t *cigar)
+{
+    if (!r) return PEP_ERR_ARG;
+    if (hits && !r->hits.empty()) memcpy(hits, r->hits.data(), r->hits.size() * sizeof(pep_hit));
+    if (cigar && !r->cigar.empty()) memcpy(cigar, r->cigar.data(), r->cigar.size() * sizeof(uint32_t));
+    return PEP_OK;
+}
+
+int pep_result_stats(const pep_result *r, pep_stats *stats)
+{
+    if (!r || !stats) return PEP_ERR_ARG;
+    *stats = r->stats;
+    return PEP_OK;
+}
+
+void pep_result_free(pep_result *r) { delete r; }
+
+int pep_rescore_nt(pep_ctx *ctx, uint64_t n, const pep_nt_hit *hits, const uint32_t *cigar, uint64_t n_cigar, int64_t *out)
+{
+    if (!ctx || (n && (!hits || !cigar || !out))) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    return pep_k7_rescore(ctx, n, hits, cigar, n_cigar, out);
+}
+
+int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *a, const uint32_t *b, uint32_t *label)
+{
+    if (!ctx || (n_nodes && !label) || (n_edges && (!a || !b))) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    return pep_k10_components(ctx, n_nodes, n_edges, a, b, label);
+}
+
+}  // extern "C"

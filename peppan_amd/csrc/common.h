@@ -1,0 +1,118 @@
+// Internal declarations shared by the HIP translation units of libpeppan_hip.so.
+// gfx950 (MI355X, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+#include "../../include/peppan_hip.h"
+
+#define PEP_WAVE 64
+
+struct PepError {
+    int code;
+    std::string msg;
+};
+
+#define PEP_HIP(ctx, expr)                                                                            \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            return pep_fail((ctx), PEP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));   \
+        }                                                                                             \
+    } while (0)
+
+#define PEP_TRY(expr)                  \
+    do {                               \
+        int _rc = (expr);              \
+        if (_rc != PEP_OK) return _rc; \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// packed sequence set on the device.  Residues of sequence i live at res[off[i] .. off[i]+len[i]);
+// at least PEP_SEQ_GAP bytes of PEP_PAD_CODE separate consecutive sequences and PEP_END_PAD pad both ends,
+// so a spaced seed can never straddle two sequences.
+#define PEP_PAD_CODE 31
+#define PEP_SEQ_GAP 16
+#define PEP_END_PAD 64
+struct SeqSet {
+    uint32_t n = 0;
+    uint64_t total = 0;          // bytes in res (with padding)
+    uint64_t residues = 0;       // sum of len
+    uint32_t max_len = 0;
+    DevBuf res;                  // u8
+    DevBuf off;                  // u32[n+1]  (off[n] = total, sentinel for binary search)
+    DevBuf len;                  // u32[n]
+    // host mirrors
+    std::vector<uint32_t> h_off, h_len;
+};
+
+// nucleotide sequence set (ASCII upper-cased on upload is NOT required: kernels fold case)
+struct NtSet {
+    uint32_t n = 0;
+    uint64_t total = 0;
+    DevBuf nt;                   // u8 ASCII, concatenated
+    DevBuf off;                  // u64[n+1]
+    std::vector<uint64_t> h_off;
+};
+
+struct pep_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    pep_search_params params;
+    // inputs
+    NtSet q_nt, r_nt;
+    SeqSet q, t;
+    std::vector<pep_query_meta> q_meta;     // frame chosen per query (K1)
+    std::vector<pep_target_meta> t_meta;    // (seq, frame, chunk offset, length) per target (K1)
+    DevBuf d_t_meta, d_q_meta;
+    bool q_from_nt = false, t_from_nt = false;
+    bool q_ready = false, t_ready = false, sub_ready = false;
+    int q_gtable = 11, t_gtable = 11, t_frames = 6;
+    DevBuf d_min_score;
+    // workspaces (grow-only, reused between searches)
+    DevBuf ws[24];
+    DevBuf sub_lds;                         // replicated substitution table image (32 KiB)
+    DevBuf d_params;                        // device copy of seed params
+    // stats of the last search
+    pep_stats stats;
+};
+
+struct pep_result {
+    pep_ctx *ctx = nullptr;
+    std::vector<pep_hit> hits;
+    std::vector<uint32_t> cigar;
+    pep_stats stats;
+};
+
+int pep_fail(pep_ctx *ctx, int code, const std::string &msg);
+int dev_reserve(pep_ctx *ctx, DevBuf &b, size_t bytes);
+void dev_release(DevBuf &b);
+
+// ---- scan.hip
+int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp);   // exclusive; d_out[n] = total (n+1 outputs)
+int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp);
+// ---- sort.hip
+int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, int bits, DevBuf &hist);   // result in d_keys
+// ---- translate.hip  (K1)
+int pep_k1_query(pep_ctx *ctx, int gtable);
+int pep_k1_ref(pep_ctx *ctx, int frames, int gtable);
+// ---- seeds.hip  (K2-K4)
+int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands);
+// ---- sw.hip / trace.hip (K5, K6, K8)
+int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n_cands, const int32_t *h_min_score, pep_result *res);
+int pep_selftest_dpp(pep_ctx *ctx);
+// ---- rescore.hip (K7)
+int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uint32_t *h_cigar, uint64_t n_cigar, int64_t *h_out);
+// ---- unionfind.hip (K10)
+int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *h_a, const uint32_t *h_b, uint32_t *h_label);
+
+static inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }

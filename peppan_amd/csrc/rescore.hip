@@ -1,0 +1,93 @@
+// K7: nucleotide rescoring counts (mode 1 of the reference's cigar2score, uberBlast.py:226-249, called from
+// RunBlast.reScore uberBlast.py:397-415).  One wavefront per hit walks the nt CIGAR; the 64 lanes stride over the
+// columns of every M run comparing encoded bases (A0 C1 G3 T4 other 2, uberBlast.py:270-271; a reverse-strand hit
+// reads the reference backwards as 4 - code, uberBlast.py:412).  Integer outputs only: the float identity / score
+// and numpy's round-half-even are applied on the host in float64 exactly as the reference does.
+// HBM-bound scan: 2 x aligned length bytes read per hit.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int enc(uint8_t ch)
+{
+    switch (ch & 0xDF) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 3;
+        case 'T': return 4;
+        default: return 2;
+    }
+}
+
+__global__ __launch_bounds__(256) void k7_rescore(uint64_t n, const pep_nt_hit *__restrict__ hits, const uint32_t *__restrict__ cigar,
+                                                  const uint8_t *__restrict__ q_nt, const uint64_t *__restrict__ q_off,
+                                                  const uint8_t *__restrict__ r_nt, const uint64_t *__restrict__ r_off, long long *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t h = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= n) return;
+    const pep_nt_hit hit = hits[h];
+    const uint8_t *q = q_nt + q_off[hit.q], *r = r_nt + r_off[hit.r];
+    const bool rev = hit.rs > hit.re;
+    long long qi = (long long)hit.qs - 1, ri = (long long)hit.rs - 1;
+    long long nmatch = 0, ncol = 0, ngap = 0, bgap = 0, mgap = 0;
+    const uint32_t *cg = cigar + hit.cigar_off;
+    for (uint32_t k = 0; k < hit.cigar_runs; ++k) {
+        const uint32_t run = cg[k];
+        const long long len = run >> 2;
+        const uint32_t op = run & 3u;
+        if (op == 0) {
+            for (long long x = lane; x < len; x += 64) {
+                const int a = enc(q[qi + x]);
+                const int b = rev ? 4 - enc(r[ri - x]) : enc(r[ri + x]);
+                nmatch += (a == b) ? 1 : 0;
+            }
+            ncol += len;
+            qi += len; ri += rev ? -len : len;
+        } else {
+            ++ngap; bgap += len; if (len > 3) mgap += len;
+            if (op == 1) qi += len; else ri += rev ? -len : len;
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) nmatch += __shfl_xor(nmatch, d, 64);
+    if (lane == 0) {
+        long long *o = out + h * 5;
+        o[0] = nmatch; o[1] = ncol - nmatch; o[2] = ngap; o[3] = bgap; o[4] = mgap;
+    }
+}
+
+}  // namespace
+
+int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uint32_t *h_cigar, uint64_t n_cigar, int64_t *h_out)
+{
+    if (n == 0) return PEP_OK;
+    if (!ctx->q_nt.nt.p || !ctx->r_nt.nt.p) return pep_fail(ctx, PEP_ERR_STATE, "pep_rescore_nt needs pep_set_query_nt and pep_set_ref_nt first");
+    // validate coordinates on the host so that a bad table is an error, not an out-of-bounds read
+    for (uint64_t i = 0; i < n; ++i) {
+        const pep_nt_hit &h = h_hits[i];
+        if (h.q >= ctx->q_nt.n || h.r >= ctx->r_nt.n || h.cigar_off + h.cigar_runs > n_cigar) return pep_fail(ctx, PEP_ERR_ARG, "pep_rescore_nt: hit index out of range");
+        const uint64_t ql = ctx->q_nt.h_off[h.q + 1] - ctx->q_nt.h_off[h.q], rl = ctx->r_nt.h_off[h.r + 1] - ctx->r_nt.h_off[h.r];
+        uint64_t qa = 0, ra = 0;
+        for (uint32_t k = 0; k < h.cigar_runs; ++k) {
+            const uint32_t run = h_cigar[h.cigar_off + k];
+            if ((run & 3u) != 2) qa += run >> 2;
+            if ((run & 3u) != 1) ra += run >> 2;
+        }
+        const bool rev = h.rs > h.re;
+        const uint64_t rlo = rev ? h.re : h.rs, rhi = rev ? h.rs : h.re;
+        if (h.qs < 1 || h.qs - 1 + qa > ql || rlo < 1 || rhi > rl || ra != rhi - rlo + 1)
+            return pep_fail(ctx, PEP_ERR_ARG, "pep_rescore_nt: CIGAR inconsistent with the hit coordinates");
+    }
+    PEP_TRY(dev_reserve(ctx, ctx->ws[0], n * sizeof(pep_nt_hit)));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_cigar + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[2], n * 5 * 8));
+    PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[0].p, h_hits, n * sizeof(pep_nt_hit), hipMemcpyHostToDevice, ctx->stream));
+    PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[1].p, h_cigar, n_cigar * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k7_rescore, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, n, ctx->ws[0].as<const pep_nt_hit>(), ctx->ws[1].as<const uint32_t>(),
+                       ctx->q_nt.nt.as<const uint8_t>(), ctx->q_nt.off.as<const uint64_t>(), ctx->r_nt.nt.as<const uint8_t>(), ctx->r_nt.off.as<const uint64_t>(),
+                       ctx->ws[2].as<long long>());
+    PEP_HIP(ctx, hipGetLastError());
+    PEP_HIP(ctx, hipMemcpyAsync(h_out, ctx->ws[2].p, n * 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PEP_OK;
+}

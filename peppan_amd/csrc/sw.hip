@@ -1,0 +1,269 @@
+// K5: banded affine Smith-Waterman, one wavefront (64 lanes) per candidate, anti-diagonal sweep.
+//
+// Mapping.  A candidate's band holds 128 diagonals d = j - i in [dlo, dlo+127].  Lane l owns the two
+// adjacent diagonals A = dlo+2l and B = dlo+2l+1.  Cells of one anti-diagonal s = i+j all have the parity
+// of s, so even steps update every lane's A cell and odd steps every lane's B cell: all 64 lanes work on
+// every step, and the three DP dependencies are
+//     diagonal  (i-1,j-1): same diagonal, two steps ago      -> the lane's own register
+//     left      (i,  j-1): diagonal d-1, previous step        -> own B->A... i.e. own other register, or lane l-1 (DPP wave_shr:1)
+//     up        (i-1,j  ): diagonal d+1, previous step        -> own other register, or lane l+1 (DPP wave_shl:1)
+// so a step costs two DPP moves and no LDS traffic for the recurrences.  Residues of the pair are staged
+// in LDS (coalesced global reads once per candidate); the 32x32 substitution table is replicated across
+// the 32 banks (dword w*32+bank) so the per-lane gather is conflict-free.
+//
+// Per cell a 4-bit traceback code is produced (bits0-1 source of H: 0 none/1 diagonal/2 E/3 F, bit2 E was an
+// extension, bit3 F was an extension); a lane packs 8 consecutive steps in one dword and the wave stores
+// 256 B per 8 steps, fully coalesced, into the direction workspace read back by the walk kernel (trace.hip).
+//
+// Integer DP in int32.  Algorithmic HBM bytes per candidate: Lq + Lt residues + 16 B result
+// (+ 32 B per anti-diagonal step of traceback codes).  VALU-bound by construction.
+#include "common.h"
+
+namespace {
+
+constexpr int NEGV = -(1 << 28);
+constexpr int RES_PAD = 80;              // sentinel bytes either side of a staged sequence
+constexpr int LDS_TABLE_BYTES = 32768;   // 256 dwords x 32 banks
+constexpr int WAVES_PER_BLOCK = 4;
+
+struct SwArgs {
+    const uint64_t *cands;
+    uint64_t n;
+    const uint8_t *q_res, *t_res;
+    const uint32_t *q_off, *q_len, *t_off, *t_len;
+    const uint32_t *sub_image;     // 8192 dwords
+    const uint64_t *dir_off;       // per candidate, in 256-byte blocks
+    const uint32_t *nblk;          // per candidate: 8-step blocks
+    uint32_t *dirs;
+    int4 *out;                     // score, iend, jend, a0
+    int oe, ext;
+    int lds_res_bytes;             // per-wave residue staging capacity (0 = global path only)
+};
+
+__device__ __forceinline__ int shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // lane l <- lane l-1
+__device__ __forceinline__ int shl1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }   // lane l <- lane l+1
+
+template <bool LDS_RES>
+__device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32_t *lds_tab, uint8_t *lds_res, int lane)
+{
+    const uint64_t key = a.cands[c];
+    const uint32_t q = (uint32_t)(key >> 43), t = (uint32_t)((key >> 18) & ((1u << 25) - 1));
+    const int bin = (int)(key & ((1u << 18) - 1));
+    const int dlo = bin * 64 - (1 << 23) - 32;
+    const int Lq = (int)a.q_len[q], Lt = (int)a.t_len[t];
+    const uint8_t *qg = a.q_res + a.q_off[q], *tg = a.t_res + a.t_off[t];
+    // first anti-diagonal that meets band and matrix, rounded so that step 0 is an A step
+    const int dl = max(dlo, -(Lq - 1)), dh = min(dlo + 127, Lt - 1);
+    const int s_lo = (dl <= 0 && dh >= 0) ? 0 : (dl > 0 ? dl : -dh);
+    const int s0 = s_lo - ((s_lo - dlo) & 1);
+    const int a0 = (s0 - dlo) / 2;                 // exact: s0 - dlo is even
+    const int nblk = (int)a.nblk[c];
+    uint32_t *dir = a.dirs + a.dir_off[c] * 64;
+
+    // index of the residues used by step pair m:  A: (i, j) = (a0 + m - lane, a0 + dlo + m + lane),  B: (i, j + 1)
+    int i = a0 - lane, j = a0 + dlo + lane;
+    uint8_t *lq = nullptr, *lt = nullptr;
+    int qlo = 0, tlo = 0;
+    if (LDS_RES) {
+        // stage the residue windows the sweep can touch: i in [a0-63, a0+4*nblk], j in [a0+dlo, a0+dlo+4*nblk+64]
+        qlo = a0 - 64; tlo = a0 + dlo - 1;
+        const int qn = 4 * nblk + 72, tn = 4 * nblk + 72;
+        lq = lds_res; lt = lds_res + ((qn + 15) & ~15);
+        for (int x = lane; x < qn; x += 64) { const int g = qlo + x; lq[x] = ((unsigned)g < (unsigned)Lq) ? qg[g] : (uint8_t)PEP_PAD_CODE; }
+        for (int x = lane; x < tn; x += 64) { const int g = tlo + x; lt[x] = ((unsigned)g < (unsigned)Lt) ? tg[g] : (uint8_t)PEP_PAD_CODE; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    auto Qat = [&](int ii) -> int { return LDS_RES ? (int)lq[ii - qlo] : (((unsigned)ii < (unsigned)Lq) ? (int)qg[ii] : PEP_PAD_CODE); };
+    auto Tat = [&](int jj) -> int { return LDS_RES ? (int)lt[jj - tlo] : (((unsigned)jj < (unsigned)Lt) ? (int)tg[jj] : PEP_PAD_CODE); };
+    const int bank4 = (lane & 31) * 4;
+    auto Sub = [&](int qc, int tc) -> int {
+        const int w = qc * 8 + (tc >> 2);
+        const uint32_t v = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + w * 128 + bank4);
+        return (int)(int8_t)(v >> ((tc & 3) * 8));
+    };
+
+    int HA = 0, EA = NEGV, FA = NEGV, HB = 0, EB = NEGV, FB = NEGV;
+    int best = 0, best_k = -1;
+    const int oe = a.oe, ext = a.ext;
+    int tc = Tat(j), qc;
+    int k = 0;
+    for (int b = 0; b < nblk; ++b) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // ---- A step: cell (i, j) on diagonal dlo + 2*lane
+            qc = Qat(i);
+            {
+                const int sub = Sub(qc, tc);
+                const int hl = shr1(0, HB), el = shr1(NEGV, EB);
+                const int e_ext = el - ext, e_open = hl - oe;
+                const int f_ext = FB - ext, f_open = HB - oe;
+                const int E = max(e_ext, e_open), F = max(f_ext, f_open);
+                const int h = HA + sub;
+                const int H = max(max(max(h, E), F), 0);
+                const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
+                const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
+                acc = (acc >> 4) | (nib << 28);
+                if (H > best) { best = H; best_k = k; }
+                HA = H; EA = E; FA = F;
+            }
+            ++k; ++j;
+            // ---- B step: cell (i, j) on diagonal dlo + 2*lane + 1   (j already advanced)
+            tc = Tat(j);
+            {
+                const int sub = Sub(qc, tc);
+                const int hu = shl1(0, HA), fu = shl1(NEGV, FA);
+                const int e_ext = EA - ext, e_open = HA - oe;
+                const int f_ext = fu - ext, f_open = hu - oe;
+                const int E = max(e_ext, e_open), F = max(f_ext, f_open);
+                const int h = HB + sub;
+                const int H = max(max(max(h, E), F), 0);
+                const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
+                const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
+                acc = (acc >> 4) | (nib << 28);
+                if (H > best) { best = H; best_k = k; }
+                HB = H; EB = E; FB = F;
+            }
+            ++k; ++i;
+        }
+        dir[(size_t)b * 64 + lane] = acc;
+    }
+    // the lane's best cell: earliest step with the lane maximum == (min i, then min j) among its two diagonals
+    int bi = 0x7fffffff, bj = 0x7fffffff;
+    if (best_k >= 0) {
+        const int m = best_k >> 1;
+        bi = a0 + m - lane;
+        bj = a0 + dlo + m + lane + (best_k & 1);
+    }
+    // wave reduction: max score, then min i, then min j
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int os = __shfl_xor(best, d, 64), oi = __shfl_xor(bi, d, 64), oj = __shfl_xor(bj, d, 64);
+        const bool take = (os > best) || (os == best && (oi < bi || (oi == bi && oj < bj)));
+        if (take) { best = os; bi = oi; bj = oj; }
+    }
+    if (lane == 0) a.out[c] = make_int4(best, best > 0 ? bi : -1, best > 0 ? bj : -1, a0);
+}
+
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(SwArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *lds_tab = reinterpret_cast<uint32_t *>(smem);
+    for (int x = threadIdx.x; x < LDS_TABLE_BYTES / 4; x += blockDim.x) lds_tab[x] = a.sub_image[x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint8_t *lds_res = smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes;
+    for (uint64_t c = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; c < a.n; c += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const int need = 2 * ((4 * (int)a.nblk[c] + 72 + 15) & ~15);
+        if (need <= a.lds_res_bytes) sw_one<true>(a, c, lds_tab, lds_res, lane);
+        else sw_one<false>(a, c, lds_tab, lds_res, lane);
+    }
+}
+
+// per candidate: number of 8-step blocks and the exact count of in-band in-matrix cells
+__global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cands, uint64_t n, const uint32_t *__restrict__ q_len,
+                                               const uint32_t *__restrict__ t_len, uint32_t *__restrict__ nblk, uint64_t *__restrict__ nblk64,
+                                               unsigned long long *__restrict__ cells_total)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long cells = 0;
+    if (c < n) {
+        const uint64_t key = cands[c];
+        const uint32_t q = (uint32_t)(key >> 43), t = (uint32_t)((key >> 18) & ((1u << 25) - 1));
+        const int bin = (int)(key & ((1u << 18) - 1));
+        const int dlo = bin * 64 - (1 << 23) - 32;
+        const int Lq = (int)q_len[q], Lt = (int)t_len[t];
+        const int dl = max(dlo, -(Lq - 1)), dh = min(dlo + 127, Lt - 1);
+        int steps = 0;
+        if (dl <= dh) {
+            const int s_lo = (dl <= 0 && dh >= 0) ? 0 : (dl > 0 ? dl : -dh);
+            const int s0 = s_lo - ((s_lo - dlo) & 1);
+            const int dstar = min(max(Lt - Lq, dl), dh);
+            const int s_hi = 2 * min(Lq - 1, Lt - 1 - dstar) + dstar;
+            steps = s_hi - s0 + 1;
+            for (int d = dl; d <= dh; ++d) cells += (unsigned long long)(min(Lq - 1, Lt - 1 - d) - max(0, -d) + 1);
+        }
+        const uint32_t nb = (uint32_t)((steps + 7) / 8);
+        nblk[c] = nb;
+        nblk64[c] = nb;
+    }
+    for (int d = 32; d > 0; d >>= 1) cells += __shfl_down(cells, d, 64);
+    if ((threadIdx.x & 63) == 0 && cells) atomicAdd(cells_total, cells);
+}
+
+__global__ void dpp_probe(int *out)
+{
+    const int lane = threadIdx.x;
+    out[lane] = shr1(-1, lane);
+    out[64 + lane] = shl1(-2, lane);
+}
+
+}  // namespace
+
+int pep_selftest_dpp(pep_ctx *ctx)
+{
+    PEP_TRY(dev_reserve(ctx, ctx->ws[9], 128 * sizeof(int)));
+    hipLaunchKernelGGL(dpp_probe, dim3(1), dim3(64), 0, ctx->stream, ctx->ws[9].as<int>());
+    int h[128];
+    PEP_HIP(ctx, hipMemcpyAsync(h, ctx->ws[9].p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < 64; ++l) {
+        const int e_shr = l == 0 ? -1 : l - 1, e_shl = l == 63 ? -2 : l + 1;
+        if (h[l] != e_shr || h[64 + l] != e_shl) return pep_fail(ctx, PEP_ERR_INTERNAL, "DPP wave shift self-test failed (unexpected lane semantics)");
+    }
+    return PEP_OK;
+}
+
+// Runs K5 over all candidates.  Fills ws[10] nblk, ws[11] dir_off (u64, n+1), ws[12] sw_out (int4), ws[13] dirs.
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, float *ms_kernel)
+{
+    const pep_search_params &P = ctx->params;
+    PEP_TRY(dev_reserve(ctx, ctx->ws[10], (n + 1) * sizeof(uint32_t)));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[11], (n + 2) * sizeof(uint64_t)));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[14], (n + 2) * sizeof(uint64_t)));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[12], (n + 1) * sizeof(int4)));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[15], 64));
+    unsigned long long *cells = ctx->ws[15].as<unsigned long long>();
+    PEP_HIP(ctx, hipMemsetAsync(cells, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(sw_prep, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_cands, n, ctx->q.len.as<const uint32_t>(),
+                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells);
+    PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
+    uint64_t total_blk = 0;
+    unsigned long long h_cells = 0;
+    PEP_HIP(ctx, hipMemcpyAsync(&total_blk, ctx->ws[11].as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PEP_HIP(ctx, hipMemcpyAsync(&h_cells, cells, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stats.cells = h_cells;
+    ctx->stats.cells_swept = total_blk * 8 * 64;
+    ctx->stats.dir_bytes = total_blk * 256;
+    PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 256 + 256));
+
+    SwArgs a;
+    a.cands = d_cands; a.n = n;
+    a.q_res = ctx->q.res.as<const uint8_t>(); a.t_res = ctx->t.res.as<const uint8_t>();
+    a.q_off = ctx->q.off.as<const uint32_t>(); a.q_len = ctx->q.len.as<const uint32_t>();
+    a.t_off = ctx->t.off.as<const uint32_t>(); a.t_len = ctx->t.len.as<const uint32_t>();
+    a.sub_image = ctx->sub_lds.as<const uint32_t>();
+    a.dir_off = ctx->ws[11].as<const uint64_t>(); a.nblk = ctx->ws[10].as<const uint32_t>();
+    a.dirs = ctx->ws[13].as<uint32_t>(); a.out = ctx->ws[12].as<int4>();
+    a.oe = P.gap_open + P.gap_ext; a.ext = P.gap_ext;
+    a.lds_res_bytes = P.use_lds ? 4096 : 0;
+    const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
+    // enough blocks to fill the chip several times over; the grid-stride loop amortises the table load
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(n, WAVES_PER_BLOCK), 256ull * 12);
+    hipEvent_t e0, e1;
+    PEP_HIP(ctx, hipEventCreate(&e0));
+    PEP_HIP(ctx, hipEventCreate(&e1));
+    PEP_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    hipLaunchKernelGGL(sw_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+    PEP_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    PEP_HIP(ctx, hipGetLastError());
+    PEP_HIP(ctx, hipEventSynchronize(e1));
+    PEP_HIP(ctx, hipEventElapsedTime(ms_kernel, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    ctx->stats.sw_launches += 1;
+    return PEP_OK;
+}

@@ -1,0 +1,321 @@
+// K6 + K8: choose the best band per (query, target), walk the traceback codes written by K5,
+// run-length encode the CIGAR, count identities, apply the identity / query-cover filters and the
+// per-(query, split) top-k, and emit fixed-size hit records + a CIGAR arena ordered by (q, t).
+#include "common.h"
+
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, float *ms_kernel);
+
+namespace {
+
+struct SelInfo {          // one per selected (q,t) pair
+    uint32_t cand;        // index into the candidate list
+    int32_t score, iend, jend;
+    int32_t istart, jstart;
+    uint32_t n_runs, aln_len, n_ident;
+    uint32_t pass;        // survived the filters
+    uint32_t keep;        // survived top-k
+    uint32_t pad;
+};
+
+__device__ __forceinline__ uint32_t key_q(uint64_t k) { return (uint32_t)(k >> 43); }
+__device__ __forceinline__ uint32_t key_t(uint64_t k) { return (uint32_t)((k >> 18) & ((1u << 25) - 1)); }
+__device__ __forceinline__ int key_dlo(uint64_t k) { return (int)(k & ((1u << 18) - 1)) * 64 - (1 << 23) - 32; }
+
+// group heads pick the best band of their (q,t) group: score desc, then lowest bin (= first in sorted order)
+__global__ __launch_bounds__(256) void select_best(const uint64_t *__restrict__ cands, uint64_t n, const int4 *__restrict__ sw,
+                                                   const int32_t *__restrict__ min_score, uint32_t *__restrict__ flag, uint32_t *__restrict__ best_idx,
+                                                   uint32_t *__restrict__ n_pairs)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    const uint64_t g = cands[c] >> 18;
+    uint32_t f = 0;
+    if (c == 0 || (cands[c - 1] >> 18) != g) {
+        atomicAdd(n_pairs, 1u);
+        int best = sw[c].x;
+        uint64_t bi = c;
+        for (uint64_t x = c + 1; x < n && (cands[x] >> 18) == g; ++x)
+            if (sw[x].x > best) { best = sw[x].x; bi = x; }
+        if (best > 0 && best >= min_score[key_q(cands[c])]) { f = 1; best_idx[c] = (uint32_t)bi; }
+    }
+    flag[c] = f;
+}
+
+__global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
+                                                  const uint32_t *__restrict__ best_idx, const int4 *__restrict__ sw,
+                                                  const uint64_t *__restrict__ cands, const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len,
+                                                  SelInfo *__restrict__ sel, uint64_t *__restrict__ run_cap)
+{
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n || !flag[c]) return;
+    const uint32_t b = best_idx[c];
+    SelInfo s;
+    s.cand = b; s.score = sw[b].x; s.iend = sw[b].y; s.jend = sw[b].z;
+    s.istart = s.jstart = 0; s.n_runs = s.aln_len = s.n_ident = 0; s.pass = s.keep = 0; s.pad = 0;
+    sel[pos[c]] = s;
+    // an alignment has at most 2*min(Lq,Lt)+1 runs (M runs consume a residue of both sequences)
+    const uint64_t k = cands[b];
+    run_cap[pos[c]] = 2ull * min(q_len[key_q(k)], t_len[key_t(k)]) + 2;
+}
+
+// one wavefront per selected pair; the walk itself is wave-uniform (scalar) work: a tile of 64 lanes x 8 steps
+// of traceback codes is fetched with one coalesced 256-byte load and decoded with v_readlane
+__global__ __launch_bounds__(256) void walk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
+                                            const uint64_t *__restrict__ dir_off, const uint32_t *__restrict__ dirs,
+                                            const uint64_t *__restrict__ run_off, uint32_t *__restrict__ runs)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_sel) return;
+    SelInfo info = sel[s];
+    const uint64_t key = cands[info.cand];
+    const int dlo = key_dlo(key);
+    const int a0 = sw[info.cand].w;
+    const uint32_t *dir = dirs + dir_off[info.cand] * 64;
+    uint32_t *out = runs + run_off[s];
+
+    int i = info.iend, j = info.jend, state = 0;
+    int istart = i, jstart = j;
+    uint32_t n_runs = 0, aln_len = 0, cur_op = 3, cur_len = 0;
+    int cur_blk = -1;
+    uint32_t w_cur = 0, w_prev = 0;
+    for (;;) {
+        const int rel = j - i - dlo;
+        const int m = i - a0 + (rel >> 1);
+        const int k = 2 * m + (rel & 1);
+        const int blk = k >> 3;
+        if (blk != cur_blk) {
+            if (cur_blk >= 0 && blk == cur_blk - 1) w_cur = w_prev;
+            else w_cur = dir[(size_t)blk * 64 + lane];
+            cur_blk = blk;
+            if (blk > 0) w_prev = dir[(size_t)(blk - 1) * 64 + lane];     // prefetch the tile the walk reaches next
+        }
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w_cur, __builtin_amdgcn_readfirstlane(rel >> 1));
+        const uint32_t nib = (word >> ((k & 7) * 4)) & 15u;
+        uint32_t op;
+        if (state == 0) {
+            const uint32_t src = nib & 3u;
+            if (src == 0) break;
+            if (src != 1) { state = (src == 2) ? 1 : 2; continue; }
+            op = 0; istart = i; jstart = j;
+        } else if (state == 1) {
+            op = 2; state = (nib & 4u) ? 1 : 0;
+        } else {
+            op = 1; state = (nib & 8u) ? 2 : 0;
+        }
+        ++aln_len;
+        if (op == cur_op) ++cur_len;
+        else {
+            if (cur_len && lane == 0) out[n_runs] = (cur_len << 2) | cur_op;
+            n_runs += cur_len ? 1 : 0;
+            cur_op = op; cur_len = 1;
+        }
+        if (op == 0) {
+            if (i == 0 || j == 0) break;
+            --i; --j;
+        } else if (op == 2) --j;
+        else --i;
+    }
+    if (cur_len) { if (lane == 0) out[n_runs] = (cur_len << 2) | cur_op; ++n_runs; }
+    if (lane == 0) {
+        info.istart = istart; info.jstart = jstart; info.n_runs = n_runs; info.aln_len = aln_len;
+        sel[s] = info;
+    }
+}
+
+// identities + filters; one wavefront per selected pair, lanes parallel over the columns of each M run
+__global__ __launch_bounds__(256) void finalize(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands,
+                                                const uint8_t *__restrict__ q_res, const uint32_t *__restrict__ q_off, const uint32_t *__restrict__ q_len,
+                                                const uint8_t *__restrict__ t_res, const uint32_t *__restrict__ t_off,
+                                                const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ runs, double min_id_pct, double min_qcov_pct)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_sel) return;
+    const SelInfo info = sel[s];
+    const uint64_t key = cands[info.cand];
+    const uint32_t q = key_q(key), t = key_t(key);
+    const uint8_t *qs = q_res + q_off[q], *ts = t_res + t_off[t];
+    const uint32_t *rv = runs + run_off[s];
+    int i = info.istart, j = info.jstart;
+    uint32_t ident = 0;
+    for (uint32_t r = 0; r < info.n_runs; ++r) {
+        const uint32_t run = rv[info.n_runs - 1 - r];     // the walk stored them end -> start
+        const int len = (int)(run >> 2);
+        const uint32_t op = run & 3u;
+        if (op == 0) {
+            for (int x = lane; x < len; x += 64) ident += (qs[i + x] == ts[j + x]) ? 1u : 0u;
+            i += len; j += len;
+        } else if (op == 1) i += len;
+        else j += len;
+    }
+    for (int d = 32; d > 0; d >>= 1) ident += __shfl_xor(ident, d, 64);
+    if (lane == 0) {
+        const double idp = (double)ident * 100.0 / (double)info.aln_len;
+        const double qcov = (double)(info.iend - info.istart + 1) * 100.0 / (double)q_len[q];
+        sel[s].n_ident = ident;
+        sel[s].pass = (idp >= min_id_pct && qcov >= min_qcov_pct) ? 1u : 0u;
+    }
+}
+
+// rank inside (query, target mod n_splits): score desc, target asc.  sel is ordered by (q, t).
+__global__ __launch_bounds__(256) void topk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int top_k, int n_splits,
+                                            uint32_t *__restrict__ keep_flag, uint64_t *__restrict__ keep_runs)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_sel) return;
+    const SelInfo me = sel[s];
+    uint32_t keep = 0;
+    if (me.pass) {
+        const uint64_t key = cands[me.cand];
+        const uint32_t q = key_q(key), t = key_t(key), split = t % (uint32_t)n_splits;
+        uint32_t rank = 0;
+        for (int dir = -1; dir <= 1; dir += 2) {
+            for (int64_t x = (int64_t)s + dir; x >= 0 && x < (int64_t)n_sel; x += dir) {
+                const SelInfo o = sel[x];
+                const uint64_t ko = cands[o.cand];
+                if (key_q(ko) != q) break;
+                const uint32_t to = key_t(ko);
+                if (!o.pass || to % (uint32_t)n_splits != split) continue;
+                if (o.score > me.score || (o.score == me.score && to < t)) ++rank;
+            }
+        }
+        keep = rank < (uint32_t)top_k ? 1u : 0u;
+    }
+    keep_flag[s] = keep;
+    keep_runs[s] = keep ? me.n_runs : 0;
+}
+
+__global__ __launch_bounds__(256) void emit(uint64_t n_sel, const SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands,
+                                            const uint32_t *__restrict__ keep_flag, const uint32_t *__restrict__ hit_pos, const uint64_t *__restrict__ cig_pos,
+                                            const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ runs, const uint32_t *__restrict__ nblk,
+                                            const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len,
+                                            pep_hit *__restrict__ hits, uint32_t *__restrict__ cigar)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_sel || !keep_flag[s]) return;
+    const SelInfo info = sel[s];
+    const uint64_t key = cands[info.cand];
+    const uint64_t co = cig_pos[s];
+    const uint32_t *rv = runs + run_off[s];
+    for (uint32_t r = lane; r < info.n_runs; r += 64) cigar[co + r] = rv[info.n_runs - 1 - r];
+    if (lane == 0) {
+        pep_hit h;
+        h.q = key_q(key); h.t = key_t(key);
+        h.q_start = (uint32_t)info.istart + 1; h.q_end = (uint32_t)info.iend + 1;
+        h.t_start = (uint32_t)info.jstart + 1; h.t_end = (uint32_t)info.jend + 1;
+        h.score = info.score; h.n_ident = info.n_ident; h.aln_len = info.aln_len; h.nm = info.aln_len - info.n_ident;
+        h.cigar_runs = info.n_runs; h.bin = (int32_t)(key & ((1u << 18) - 1)); h.cigar_off = co;
+        // exact in-band in-matrix cell count of the winning band
+        const int dlo = key_dlo(key), Lq = (int)q_len[h.q], Lt = (int)t_len[h.t];
+        const int dl = max(dlo, -(Lq - 1)), dh = min(dlo + 127, Lt - 1);
+        uint64_t cells = 0;
+        for (int d = dl; d <= dh; ++d) cells += (uint64_t)(min(Lq - 1, Lt - 1 - d) - max(0, -d) + 1);
+        h.cells = cells;
+        hits[hit_pos[s]] = h;
+    }
+    (void)nblk;
+}
+
+}  // namespace
+
+// workspace slots: ws[16] flag, ws[17] pos, ws[18] best_idx, ws[19] sel, ws[20] run_cap/run_off (u64 x2), ws[21] runs,
+//                  ws[22] keep arrays, ws[23] output hits + cigar, ws[9] small counters
+int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t *h_min_score, pep_result *res)
+{
+    const pep_search_params &P = ctx->params;
+    res->hits.clear();
+    res->cigar.clear();
+    ctx->stats.candidates = n;
+    ctx->stats.pairs = ctx->stats.tracebacks = ctx->stats.hits = 0;
+    ctx->stats.cells = ctx->stats.cells_swept = ctx->stats.dir_bytes = 0;
+    if (n == 0) return PEP_OK;
+    hipStream_t st = ctx->stream;
+    float ms_sw = 0.f;
+    PEP_TRY(pep_sw_run(ctx, d_cands, n, &ms_sw));
+    ctx->stats.ms_sw = ms_sw;
+
+    hipEvent_t e0, e1;
+    PEP_HIP(ctx, hipEventCreate(&e0));
+    PEP_HIP(ctx, hipEventCreate(&e1));
+    PEP_HIP(ctx, hipEventRecord(e0, st));
+
+    const int4 *sw = ctx->ws[12].as<const int4>();
+    PEP_TRY(dev_reserve(ctx, ctx->ws[16], (n + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[17], (n + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[18], (n + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[9], 256));
+    // per-query score thresholds
+    DevBuf &dms = ctx->d_min_score;
+    PEP_TRY(dev_reserve(ctx, dms, (size_t)(ctx->q.n + 1) * 4));
+    PEP_HIP(ctx, hipMemcpyAsync(dms.p, h_min_score, (size_t)ctx->q.n * 4, hipMemcpyHostToDevice, st));
+    uint32_t *flag = ctx->ws[16].as<uint32_t>(), *pos = ctx->ws[17].as<uint32_t>(), *best_idx = ctx->ws[18].as<uint32_t>();
+    uint32_t *counters = ctx->ws[9].as<uint32_t>();
+    PEP_HIP(ctx, hipMemsetAsync(counters, 0, 256, st));
+    const unsigned gb = (unsigned)ceil_div(n, 256);
+    hipLaunchKernelGGL(select_best, dim3(gb), dim3(256), 0, st, d_cands, n, sw, dms.as<const int32_t>(), flag, best_idx, counters);
+    PEP_TRY(pep_scan_u32(ctx, flag, pos, n, ctx->ws[7]));
+    uint32_t n_sel = 0, n_pairs = 0;
+    PEP_HIP(ctx, hipMemcpyAsync(&n_sel, pos + n, 4, hipMemcpyDeviceToHost, st));
+    PEP_HIP(ctx, hipMemcpyAsync(&n_pairs, counters, 4, hipMemcpyDeviceToHost, st));
+    PEP_HIP(ctx, hipStreamSynchronize(st));
+    ctx->stats.pairs = n_pairs;
+    ctx->stats.tracebacks = n_sel;
+    if (n_sel) {
+        PEP_TRY(dev_reserve(ctx, ctx->ws[19], (size_t)n_sel * sizeof(SelInfo)));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[20], ((size_t)n_sel + 2) * 8 * 2));
+        SelInfo *sel = ctx->ws[19].as<SelInfo>();
+        uint64_t *run_cap = ctx->ws[20].as<uint64_t>(), *run_off = run_cap + n_sel + 2;
+        hipLaunchKernelGGL(gather_sel, dim3(gb), dim3(256), 0, st, n, (const uint32_t *)flag, (const uint32_t *)pos, (const uint32_t *)best_idx, sw, d_cands,
+                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap);
+        PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_sel, ctx->ws[7]));
+        uint64_t total_runs = 0;
+        PEP_HIP(ctx, hipMemcpyAsync(&total_runs, run_off + n_sel, 8, hipMemcpyDeviceToHost, st));
+        PEP_HIP(ctx, hipStreamSynchronize(st));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
+        uint32_t *runs = ctx->ws[21].as<uint32_t>();
+        const unsigned gw = (unsigned)ceil_div(n_sel, 4);
+        hipLaunchKernelGGL(walk, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, d_cands, sw, ctx->ws[11].as<const uint64_t>(),
+                           ctx->ws[13].as<const uint32_t>(), (const uint64_t *)run_off, runs);
+        hipLaunchKernelGGL(finalize, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, d_cands, ctx->q.res.as<const uint8_t>(),
+                           ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(),
+                           ctx->t.off.as<const uint32_t>(), (const uint64_t *)run_off, (const uint32_t *)runs, P.min_id_pct, P.min_qcov_pct);
+        // top-k, then compaction of hits and CIGAR runs
+        PEP_TRY(dev_reserve(ctx, ctx->ws[22], ((size_t)n_sel + 2) * (4 + 4 + 8 + 8)));
+        uint32_t *keep_flag = ctx->ws[22].as<uint32_t>(), *hit_pos = keep_flag + n_sel + 2;
+        uint64_t *keep_runs = reinterpret_cast<uint64_t *>(hit_pos + n_sel + 2), *cig_pos = keep_runs + n_sel + 2;
+        hipLaunchKernelGGL(topk, dim3((unsigned)ceil_div(n_sel, 256)), dim3(256), 0, st, (uint64_t)n_sel, sel, d_cands, P.top_k, P.n_splits, keep_flag, keep_runs);
+        PEP_TRY(pep_scan_u32(ctx, keep_flag, hit_pos, n_sel, ctx->ws[7]));
+        PEP_TRY(pep_scan_u64(ctx, keep_runs, cig_pos, n_sel, ctx->ws[7]));
+        uint32_t n_hits = 0;
+        uint64_t n_cig = 0;
+        PEP_HIP(ctx, hipMemcpyAsync(&n_hits, hit_pos + n_sel, 4, hipMemcpyDeviceToHost, st));
+        PEP_HIP(ctx, hipMemcpyAsync(&n_cig, cig_pos + n_sel, 8, hipMemcpyDeviceToHost, st));
+        PEP_HIP(ctx, hipStreamSynchronize(st));
+        ctx->stats.hits = n_hits;
+        if (n_hits) {
+            const size_t hb = (size_t)n_hits * sizeof(pep_hit);
+            PEP_TRY(dev_reserve(ctx, ctx->ws[23], hb + (n_cig + 1) * 4));
+            pep_hit *d_hits = ctx->ws[23].as<pep_hit>();
+            uint32_t *d_cig = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctx->ws[23].p) + hb);
+            hipLaunchKernelGGL(emit, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, (const SelInfo *)sel, d_cands, (const uint32_t *)keep_flag,
+                               (const uint32_t *)hit_pos, (const uint64_t *)cig_pos, (const uint64_t *)run_off, (const uint32_t *)runs,
+                               ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig);
+            PEP_HIP(ctx, hipGetLastError());
+            res->hits.resize(n_hits);
+            res->cigar.resize(n_cig);
+            PEP_HIP(ctx, hipMemcpyAsync(res->hits.data(), d_hits, hb, hipMemcpyDeviceToHost, st));
+            if (n_cig) PEP_HIP(ctx, hipMemcpyAsync(res->cigar.data(), d_cig, n_cig * 4, hipMemcpyDeviceToHost, st));
+        }
+    }
+    PEP_HIP(ctx, hipEventRecord(e1, st));
+    PEP_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    PEP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    ctx->stats.ms_trace = ms;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    PEP_HIP(ctx, hipGetLastError());
+    return PEP_OK;
+}

@@ -1,0 +1,69 @@
+// K10: connected components of the (representative, member) / ortholog edge list = the PARTITION that the
+// reference's union-find produces in get_gene_group (PEPPAN.py:1598-1607).  Lock-free union-find: every edge
+// hooks the larger root under the smaller with an atomic compare-and-swap, so the final root of a component is
+// its smallest node id whatever the execution order; a second kernel flattens.  HBM-bound: 8 B per edge read,
+// 4 B per node written; parent look-ups are random 4-byte reads.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t uf_root(uint32_t *parent, uint32_t x)
+{
+    for (;;) {
+        const uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        x = p;
+    }
+}
+
+__global__ __launch_bounds__(256) void uf_init(uint32_t *parent, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) parent[i] = i;
+}
+
+__global__ __launch_bounds__(256) void uf_union(uint32_t *parent, const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint64_t m)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m) return;
+    uint32_t x = a[e], y = b[e];
+    for (;;) {
+        x = uf_root(parent, x);
+        y = uf_root(parent, y);
+        if (x == y) return;
+        if (x < y) { const uint32_t t = x; x = y; y = t; }          // x = larger root, hooked under y
+        if (atomicCAS(&parent[x], x, y) == x) return;
+    }
+}
+
+__global__ __launch_bounds__(256) void uf_flatten(uint32_t *parent, uint32_t *__restrict__ label, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) label[i] = uf_root(parent, i);
+}
+
+}  // namespace
+
+int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *h_a, const uint32_t *h_b, uint32_t *h_label)
+{
+    if (n_nodes == 0) return PEP_OK;
+    for (uint64_t e = 0; e < n_edges; ++e)
+        if (h_a[e] >= n_nodes || h_b[e] >= n_nodes) return pep_fail(ctx, PEP_ERR_ARG, "pep_components: edge endpoint out of range");
+    PEP_TRY(dev_reserve(ctx, ctx->ws[0], (size_t)n_nodes * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[1], (size_t)n_nodes * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[2], (n_edges + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[3], (n_edges + 1) * 4));
+    uint32_t *parent = ctx->ws[0].as<uint32_t>(), *label = ctx->ws[1].as<uint32_t>();
+    hipLaunchKernelGGL(uf_init, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, n_nodes);
+    if (n_edges) {
+        PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[2].p, h_a, n_edges * 4, hipMemcpyHostToDevice, ctx->stream));
+        PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[3].p, h_b, n_edges * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(uf_union, dim3((unsigned)ceil_div(n_edges, 256)), dim3(256), 0, ctx->stream, parent, ctx->ws[2].as<const uint32_t>(),
+                           ctx->ws[3].as<const uint32_t>(), n_edges);
+    }
+    hipLaunchKernelGGL(uf_flatten, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, label, n_nodes);
+    PEP_HIP(ctx, hipGetLastError());
+    PEP_HIP(ctx, hipMemcpyAsync(h_label, label, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PEP_OK;
+}

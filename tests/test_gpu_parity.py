@@ -1,0 +1,176 @@
+"""GPU parity tests proper: every call goes through the C ABI (libpeppan_hip.so) and is compared
+bit-exactly with the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from peppan_amd import _native as N
+    c = N.Context(0)
+    yield c
+    c.close()
+
+
+def _cmp_hits(gh, gc, oh, oc):
+    assert len(gh) == len(oh), (len(gh), len(oh))
+    for f in ('q', 't', 'q_start', 'q_end', 't_start', 't_end', 'score', 'nm', 'n_ident', 'aln_len', 'cigar_runs', 'bin', 'cigar_off', 'cells'):
+        assert np.array_equal(gh[f], oh[f]), f
+    assert np.array_equal(gc, oc)
+
+
+@pytest.mark.parametrize('use_lds', [1, 0])
+@pytest.mark.parametrize('min_id,min_qcov,top_k', [(0., 0., 10), (45., 25., 10), (30., 10., 2)])
+def test_search_protein_families(ctx, use_lds, min_id, min_qcov, top_k):
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    prots = synth.make_proteins(240, length=(60, 420), seed=11, family=4, sub=0.25)
+    ctx.set_query_aa(prots)
+    ctx.set_ref_aa(prots)
+    gh, gc, st = ctx.search(N.default_params(min_id, min_qcov, top_k, 5, use_lds=use_lds))
+    oh, oc, ost = O.search(prots, prots, O.default_params(min_id, min_qcov, top_k, 5))
+    assert st['candidates'] == ost['candidates'] and st['pairs'] == ost['pairs'] and st['cells'] == ost['cells']
+    _cmp_hits(gh, gc, oh, oc)
+    assert len(gh) > 300
+
+
+def test_search_ragged_and_empty(ctx):
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    prots = synth.make_proteins(40, length=(10, 90), seed=3, family=2, sub=0.1)
+    prots[3] = prots[3][:0]                       # empty sequence
+    prots[7] = prots[7][:5]                       # shorter than any seed
+    prots[9] = np.full(300, 23, np.uint8)         # all X: never seeds
+    long_ = synth.make_proteins(2, length=2600, seed=5, family=2, sub=0.1)    # exceeds the LDS staging window -> global path
+    qs, ts = prots + long_, long_ + prots[::-1]
+    ctx.set_query_aa(qs)
+    ctx.set_ref_aa(ts)
+    gh, gc, st = ctx.search(N.default_params(0., 0., 10, 5))
+    oh, oc, ost = O.search(qs, ts, O.default_params(0., 0., 10, 5))
+    _cmp_hits(gh, gc, oh, oc)
+    assert len(gh) > 20
+    # no queries / no targets
+    ctx.set_query_aa([])
+    gh, gc, st = ctx.search(N.default_params())
+    assert len(gh) == 0 and len(gc) == 0
+
+
+def test_search_offdiagonal_bands(ctx):
+    """a short query inside a long target at various offsets: exercises bands far from the main diagonal,
+    both signs, and bin boundaries"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    aa = np.frombuffer(b'ARNDCQEGHILKMFPSTWYV', dtype=np.uint8) - 65
+    qs, ts = [], []
+    for off in (0, 1, 31, 32, 33, 63, 64, 65, 100, 500, 997):
+        q = aa[rng.integers(0, 20, 120)]
+        t = np.concatenate([aa[rng.integers(0, 20, off)], q, aa[rng.integers(0, 20, 37)]])
+        qs.append(q); ts.append(t.astype(np.uint8))
+        qs.append(t.astype(np.uint8)); ts.append(q)       # and the transposed case (negative diagonals)
+    ctx.set_query_aa(qs)
+    ctx.set_ref_aa(ts)
+    gh, gc, st = ctx.search(N.default_params(0., 0., 50, 1))
+    oh, oc, ost = O.search(qs, ts, O.default_params(0., 0., 50, 1))
+    _cmp_hits(gh, gc, oh, oc)
+    assert len(gh) >= 22
+
+
+def test_k1_translation_golden_and_oracle(ctx):
+    from oracle import oracle as O
+    g = load_golden('g02_rundiamond.json')
+    qn, rn = sorted(g['query']), sorted(g['ref'])
+    for frames, key in ((6, '7'), (3, 'F')):
+        ctx.set_query_nt([g['query'][n] for n in qn], 11)
+        ctx.set_ref_nt([g['ref'][n] for n in rn], frames, 11)
+        ctx.translate()
+        qm, tm = ctx.query_meta(), ctx.target_meta()
+        qa, qo = ctx.query_aa()
+        ta, to = ctx.target_aa()
+        q_txt = ''.join('>{0}:{1}\n{2}\n'.format(qn[m['seq']], m['frame'], ''.join(chr(65 + c) for c in qa[int(qo[i]):int(qo[i + 1])])) for i, m in enumerate(qm))
+        recs = ['>{0}:{1}:{2}\n{3}\n'.format(rn[m['seq']], m['frame'], m['chunk_off'], ''.join(chr(65 + c) for c in ta[int(to[i]):int(to[i + 1])])) for i, m in enumerate(tm)]
+        assert q_txt == g['out'][key]['qryAA']
+        assert [''.join(recs[i::5]) for i in range(5)] == g['out'][key]['refAA']
+    # ambiguous bases, gaps, lower case, table 4, lengths not divisible by 3 (golden G1 inputs) against the oracle restatement
+    t = load_golden('g01_transeq.json')
+    names = sorted(t['seqs'])
+    for table in (11, 4):
+        ctx.set_query_nt([t['seqs'][n] for n in names], table)
+        ctx.set_ref_nt([t['seqs'][n] for n in names], 6, table)
+        ctx.translate()
+        qa, qo = ctx.query_aa()
+        for i, m in enumerate(ctx.query_meta()):
+            f, s = O.query_frame(t['seqs'][names[i]], table)
+            assert m['frame'] == f and ''.join(chr(65 + c) for c in qa[int(qo[i]):int(qo[i + 1])]) == s.replace('-', 'X')
+        ta, to = ctx.target_aa()
+        exp = []
+        for n in names:
+            for f, aa_ in zip(range(1, 7), O.translate_frames(t['seqs'][n], range(1, 7), table)):
+                exp += [(n, f, o, c.replace('-', 'X')) for o, c in O.ref_chunks(aa_)]
+        got = [(names[m['seq']], int(m['frame']), int(m['chunk_off']), ''.join(chr(65 + c) for c in ta[int(to[i]):int(to[i + 1])])) for i, m in enumerate(ctx.target_meta())]
+        assert got == exp
+
+
+def test_search_from_nucleotides_1k(ctx):
+    """BASELINE config 1k synthetic 1 kb genes, all-vs-all, from nucleotides: K1..K8 against the oracle"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    names, seqs = synth.make_genes(1000, 1002, seed=355)
+    order = sorted(range(len(names)), key=lambda i: names[i])      # the reference writes FASTA in sorted(name) order
+    nts = [seqs[i] for i in order]
+    ctx.set_query_nt(nts, 11)
+    ctx.set_ref_nt(nts, 6, 11)
+    gh, gc, st = ctx.search(N.default_params(45., 25., 10, 5))
+    q_aa = [O.aa_codes(O.query_frame(s.decode(), 11)[1].replace('-', 'X')) for s in nts]
+    t_aa = []
+    for s in nts:
+        for aa_ in O.translate_frames(s.decode(), range(1, 7), 11):
+            t_aa += [O.aa_codes(c.replace('-', 'X')) for o, c in O.ref_chunks(aa_)]
+    oh, oc, ost = O.search(q_aa, t_aa, O.default_params(45., 25., 10, 5))
+    _cmp_hits(gh, gc, oh, oc)
+    assert len(gh) > 2000 and st['cells'] == ost['cells']
+
+
+def test_k7_rescore_counts(ctx):
+    from peppan_amd import _native as N
+    from oracle import oracle as O
+    g = load_golden('g05_rescore.json')
+    qn, rn = sorted(g['query']), sorted(g['ref'])
+    qi, ri = {n: i for i, n in enumerate(qn)}, {n: i for i, n in enumerate(rn)}
+    ctx.set_query_nt([g['query'][n] for n in qn], 11)
+    ctx.set_ref_nt([g['ref'][n] for n in rn], 6, 11)
+    opc = {'M': 0, 'I': 1, 'D': 2}
+    hits = np.zeros(len(g['table']), dtype=N.NT_HIT_DTYPE)
+    cig = []
+    for k, row in enumerate(g['table']):
+        hits[k] = (qi[row[0]], ri[row[1]], row[6], row[7], row[8], row[9], len(row[14]), 0, len(cig))
+        cig += [(n << 2) | opc[o] for n, o in row[14]]
+    out = ctx.rescore_nt(hits, np.array(cig, dtype=np.uint32))
+    for k, row in enumerate(g['table']):
+        exp = O.rescore_counts(O.nt_encode_rescore(g['query'][row[0]].upper()), O.nt_encode_rescore(g['ref'][row[1]].upper()), row[6], row[8], row[9],
+                               np.array(cig[hits[k]['cigar_off']:hits[k]['cigar_off'] + len(row[14])], dtype=np.uint32))
+        assert np.array_equal(out[k], exp), row[:2]
+    # a CIGAR that does not fit its coordinates is an error, not a wild read
+    bad = hits[:1].copy(); bad['re'] += 7
+    with pytest.raises(N.PepError):
+        ctx.rescore_nt(bad, np.array(cig, dtype=np.uint32))
+
+
+def test_k10_components(ctx):
+    from oracle import oracle as O
+    rng = np.random.default_rng(10)
+    for n, m in ((1, 0), (60, 40), (5000, 3000), (200000, 350000)):
+        a, b = rng.integers(0, n, m), rng.integers(0, n, m)
+        assert np.array_equal(ctx.components(n, a, b), O.components(n, a, b))
+    g = load_golden('g11_groups.json')
+    for case in g['cases']:
+        clu, bsn = np.array(case['clu']), np.array(case['bsn'])
+        e = np.vstack([clu[:, :2], bsn[bsn[:, 2] > 0][:, :2]])
+        lab = ctx.components(60, e[:, 0], e[:, 1])
+        got = {}
+        for i, l in enumerate(lab):
+            got.setdefault(int(l), set()).add(i)
+        assert {frozenset(s) for s in got.values() if len(s) > 1} == {frozenset(m) for _, m in case['groups']}
