@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py - one "step" = one full pass of the hot path over the 10k-gene all-vs-all workload:
+K1 translate/pack -> K2-K4 seeds/candidates -> K5 banded Smith-Waterman -> K6 traceback -> K8 filters/top-k ->
+hit table to the host -> (N>1: RCCL all-gather of the shard hit tables) -> K10 union-find.
+Inputs (nucleotides) are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--genes G] [--no-cpu-baseline]
+
+N>1 is launched by torch.distributed.run, one rank per GPU; queries are sharded, the reference replicated
+(strong scaling: the total workload is the named 10k x 10k configuration whatever N is)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+
+def cpu_baseline(nts, n_sample, min_id, min_qcov):
+    """CPU oracle (scalar C port, 1 thread) timed on a bounded sample of the same workload: the first
+    n_sample queries against the whole reference.  Reported beside the GPU number, never the target."""
+    from oracle import oracle as O
+    q_aa = [O.aa_codes(O.query_frame(s.decode(), 11)[1].replace('-', 'X')) for s in nts[:n_sample]]
+    t_aa = []
+    for s in nts:
+        for aa in O.translate_frames(s.decode(), range(1, 7), 11):
+            t_aa += [O.aa_codes(c.replace('-', 'X')) for o, c in O.ref_chunks(aa)]
+    t0 = time.perf_counter()
+    hits, cig, st = O.search(q_aa, t_aa, O.default_params(min_id, min_qcov, 10, 5))
+    dt = time.perf_counter() - t0
+    return dict(value=st['candidates'] / dt, unit='gene-pairs/s', cores=1, kind='port',
+                sample='first %d of %d queries vs all %d genes x 6 frames; %.1f s; %d candidates, %.3g SW cells (%.3g cells/s); '
+                       'reference binaries (diamond/blastn/mmseqs) are absent, so this is the oracle C port, 1 thread'
+                       % (n_sample, len(nts), len(nts), dt, st['candidates'], st['cells'], st['cells'] / dt),
+                seconds=dt, sw_cells_per_s=st['cells'] / dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--genes', type=int, default=10000)
+    ap.add_argument('--gene-len', type=int, default=1002)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample', type=int, default=150)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+
+    from peppan_amd import _native as N, synth, dist as pdist
+    names, seqs = synth.make_genes(args.genes, args.gene_len, seed=355)
+    order = sorted(range(len(names)), key=lambda i: names[i])     # FASTA order of the reference: sorted(names) (uberBlast.py:527, 537)
+    nts = [seqs[i] for i in order]
+    bounds = pdist.shard_bounds([len(s) for s in nts], world)
+    q0, q1 = bounds[rank], bounds[rank + 1]
+    min_id, min_qcov = 45.0, 25.0                                  # PEPPAN.py:229-230 with defaults (match_identity 0.5 - 0.05, match_frag_prop 0.25)
+    params = N.default_params(min_id, min_qcov, 10, 5)
+
+    ctx = N.Context(local_rank)
+    ctx.set_query_nt(nts[q0:q1], 11)
+    ctx.set_ref_nt(nts, 6, 11)
+    gene_of_target = None
+
+    def step():
+        nonlocal gene_of_target
+        ctx.translate(force=True)
+        hits, cig, st = ctx.search(params)
+        if gene_of_target is None:
+            gene_of_target = ctx.target_meta()['seq'].astype(np.uint32)
+        allh, allc = pdist.allgather_hits(hits, cig, q0, device=dev if world > 1 else None)
+        labels = ctx.components(len(nts), allh['q'], gene_of_target[allh['t']])
+        return hits, st, allh, labels
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    acc = dict(candidates=0, cells=0, ms_sw=0.0, ms_seed=0.0, ms_trace=0.0, ms_k1=0.0, ms_total=0.0, hits=0, dir_bytes=0, tracebacks=0)
+    for _ in range(args.steps):
+        hits, st, allh, labels = step()
+        for k in acc:
+            acc[k] += st[k]
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot = torch.tensor([acc['candidates'], acc['cells']], dtype=torch.float64, device=dev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_pairs, total_cells = float(tot[0].item()), float(tot[1].item())
+    else:
+        total_pairs, total_cells = float(acc['candidates']), float(acc['cells'])
+
+    if rank == 0:
+        K = args.steps
+        cand = acc['candidates'] / K
+        ms_sw = acc['ms_sw'] / K
+        # dominant kernel = K5 sw_kernel (one launch per step).  Algorithmic bytes per launch, SURVEY.md 8(d):
+        # sum over candidate pairs of (Lq + Lr) residue bytes + 64 B per reported hit.
+        Lq = args.gene_len // 3
+        alg_bytes = cand * (2 * Lq) + (acc['hits'] / K) * 64
+        achieved = alg_bytes / (ms_sw * 1e-3) / 1e9
+        line = {
+            'metric': 'gene_pairs_aligned_per_s', 'value': total_pairs / dt, 'unit': 'gene-pairs/s',
+            'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': dt / K * 1e3,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32', 'data': 'synthetic',
+            'config': {'workload': 'synthgenes-v1 seed 355: %d genes x %d nt, all-vs-all (BASELINE configs[2] search stage), '
+                                   'min_id 0.45 min_ratio 0.25 top-k 10 x 5 splits' % (args.genes, args.gene_len),
+                       'queries_per_rank': q1 - q0, 'parallelism': 'query-shard x%d, reference replicated' % world},
+            'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3),
+            'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
+            'hits_per_step': acc['hits'] / K, 'clusters': int(len(np.unique(labels))),
+            'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_sw', 'ms_trace', 'ms_total')},
+            'roofline': {'bound': 'hbm', 'kernel': 'sw_kernel (K5 banded Smith-Waterman)', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': achieved / 8000.0, 'traffic': None,
+                         'note': 'integer-VALU-bound by construction (SURVEY 8d); the kernel also writes %.3g B/launch of traceback codes '
+                                 'that the SURVEY formula does not count' % (acc['dir_bytes'] / K)},
+            'cpu_baseline': None,
+        }
+        if not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(nts, min(args.cpu_sample, len(nts)), min_id, min_qcov)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == '__main__':
+    main()

@@ -63,7 +63,10 @@ typedef struct {
     int32_t n_splits;             /* targets are dealt round-robin into this many splits */
     double dbsize, max_evalue;    /* --dbsize, --evalue */
     int32_t use_lds;              /* 1: residues staged in LDS (default); 0: read from global memory */
-    int32_t reserved[7];
+    int32_t ungapped_min;         /* a seed hit nominates a candidate only if its ungapped x-drop score reaches this (0 = off) */
+    int32_t xdrop;                /* x-drop of that ungapped extension (must stay below 64) */
+    int32_t ext_right, ext_left;  /* residues scored right of (from) / left of the seed's first position (<= 48 / <= 48) */
+    int32_t reserved[3];
 } pep_search_params;
 
 /* one alignment; coordinates are 1-based, inclusive, in residues of the query / target protein */
@@ -93,17 +96,18 @@ typedef struct {
 
 typedef struct {
     uint64_t query_residues, target_residues;
-    uint64_t query_seeds, target_seeds, seed_hits;
+    uint64_t query_seeds, target_seeds, seed_hits, seed_hits_passed;
     uint64_t candidates;          /* unique (q, t, band) */
     uint64_t pairs;               /* unique (q, t) */
     uint64_t tracebacks;
     uint64_t hits;
-    uint64_t cells;               /* in-band in-matrix DP cells over all candidates (SW cell updates) */
+    uint64_t cells;               /* in-band in-matrix DP cells over all candidates, score pass (SW cell updates) */
     uint64_t cells_swept;         /* 64 lanes x anti-diagonal steps actually executed */
     uint64_t dir_bytes;           /* traceback direction workspace written by the SW kernel */
     uint64_t sw_launches;
-    double ms_seed, ms_sw, ms_trace, ms_total;   /* HIP-event times on the context's stream */
-    double ms_k1;
+    uint64_t cells_trace;         /* DP cells recomputed by the traceback pass (selected pairs only) */
+    double ms_seed, ms_sw, ms_trace, ms_total;   /* HIP-event times on the context's stream; ms_sw = score pass kernel */
+    double ms_k1, ms_sw_trace;                   /* ms_sw_trace = traceback-pass kernel (selected pairs only) */
 } pep_stats;
 
 int pep_version(void);

@@ -58,6 +58,10 @@ typedef struct {
     double  min_qcov_pct;  /* diamond --query-cover */
     int32_t top_k;         /* diamond -k */
     int32_t n_splits;      /* 5 database splits */
+    int32_t ungapped_min;  /* a seed hit only nominates a candidate if its ungapped x-drop score reaches this (0 = off) */
+    int32_t xdrop;         /* x-drop of the ungapped extension */
+    int32_t ext_right;     /* max residues scored to the right, starting at the seed's first position */
+    int32_t ext_left;      /* max residues scored to the left of the seed's first position */
 } oracle_params;
 
 typedef struct {
@@ -132,6 +136,7 @@ void oracle_default_params(oracle_params *p)
         p->weight[s] = w;
     }
     p->min_id_pct = 0.; p->min_qcov_pct = 0.; p->top_k = 10; p->n_splits = 5;
+    p->ungapped_min = 45; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24;
 }
 
 /* smallest raw score whose e-value m*n*K*exp(-lambda*S) is <= max_evalue
@@ -175,6 +180,25 @@ static int seed_key(const oracle_params *p, int sh, const uint8_t *s, uint32_t l
     return 1;
 }
 
+/* ungapped x-drop score of the diagonal through a seed hit: right part starts AT (qpos, tpos), left part just before it;
+ * each part stops at the sequence end, after `ext` residues, or once the running sum falls more than xdrop below its best */
+static int32_t ungapped_score(const oracle_params *p, const uint8_t *q, int32_t Lq, int32_t qpos, const uint8_t *t, int32_t Lt, int32_t tpos)
+{
+    int32_t s = 0, br = 0, bl = 0;
+    for (int32_t k = 0; k < p->ext_right && qpos + k < Lq && tpos + k < Lt; ++k) {
+        s += p->sub[(q[qpos + k] & 31) * 32 + (t[tpos + k] & 31)];
+        if (s > br) br = s;
+        else if (br - s > p->xdrop) break;
+    }
+    s = 0;
+    for (int32_t k = 1; k <= p->ext_left && qpos - k >= 0 && tpos - k >= 0; ++k) {
+        s += p->sub[(q[qpos - k] & 31) * 32 + (t[tpos - k] & 31)];
+        if (s > bl) bl = s;
+        else if (bl - s > p->xdrop) break;
+    }
+    return br + bl;
+}
+
 static inline uint64_t cand_key(uint32_t q, uint32_t t, int32_t bin)
 {
     return ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)(uint32_t)bin;
@@ -207,6 +231,10 @@ static uint64_t *find_candidates(const oracle_params *p,
                 uint64_t lo = 0, hi = m;
                 while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (qs[mid].key < k) lo = mid + 1; else hi = mid; }
                 for (; lo < m && qs[lo].key == k; ++lo) {
+                    if (p->ungapped_min > 0) {
+                        uint32_t qq = qs[lo].seq;
+                        if (ungapped_score(p, qr + qo[qq], (int32_t)(qo[qq + 1] - qo[qq]), (int32_t)qs[lo].pos, tr + to[t], (int32_t)len, (int32_t)pos) < p->ungapped_min) continue;
+                    }
                     int32_t d = (int32_t)pos - (int32_t)qs[lo].pos;
                     int32_t bin = (d + DIAG_OFF) / BIN_W;
                     if (n == cap) { cap *= 2; c = realloc(c, cap * sizeof(uint64_t)); }

@@ -24,7 +24,8 @@ class Params(C.Structure):
     _fields_ = [('gap_open', C.c_int32), ('gap_ext', C.c_int32), ('n_shapes', C.c_int32), ('base', C.c_int32),
                 ('weight', C.c_int32 * 4), ('offs', (C.c_int32 * 32) * 4), ('reduce', C.c_uint8 * 32),
                 ('sub', C.c_int8 * 1024), ('min_id_pct', C.c_double), ('min_qcov_pct', C.c_double),
-                ('top_k', C.c_int32), ('n_splits', C.c_int32)]
+                ('top_k', C.c_int32), ('n_splits', C.c_int32), ('ungapped_min', C.c_int32), ('xdrop', C.c_int32),
+                ('ext_right', C.c_int32), ('ext_left', C.c_int32)]
 
 
 class Hit(C.Structure):
@@ -56,10 +57,12 @@ def lib():
     return _lib
 
 
-def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5):
+def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5, ungapped_min=None):
     p = Params()
     lib().oracle_default_params(C.byref(p))
     p.min_id_pct, p.min_qcov_pct, p.top_k, p.n_splits = min_id_pct, min_qcov_pct, top_k, n_splits
+    if ungapped_min is not None:
+        p.ungapped_min = ungapped_min
     return p
 
 

@@ -24,14 +24,15 @@ class SearchParams(C.Structure):
                 ('weight', C.c_int32 * 4), ('offs', (C.c_int32 * 32) * 4), ('reduce', C.c_uint8 * 32),
                 ('sub', C.c_int8 * 1024), ('min_id_pct', C.c_double), ('min_qcov_pct', C.c_double),
                 ('top_k', C.c_int32), ('n_splits', C.c_int32), ('dbsize', C.c_double), ('max_evalue', C.c_double),
-                ('use_lds', C.c_int32), ('reserved', C.c_int32 * 7)]
+                ('use_lds', C.c_int32), ('ungapped_min', C.c_int32), ('xdrop', C.c_int32), ('ext_right', C.c_int32),
+                ('ext_left', C.c_int32), ('reserved', C.c_int32 * 3)]
 
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ('query_residues', 'target_residues', 'query_seeds', 'target_seeds', 'seed_hits',
-                                           'candidates', 'pairs', 'tracebacks', 'hits', 'cells', 'cells_swept', 'dir_bytes',
-                                           'sw_launches')] + \
-               [(n, C.c_double) for n in ('ms_seed', 'ms_sw', 'ms_trace', 'ms_total', 'ms_k1')]
+                                           'seed_hits_passed', 'candidates', 'pairs', 'tracebacks', 'hits', 'cells', 'cells_swept', 'dir_bytes',
+                                           'sw_launches', 'cells_trace')] + \
+               [(n, C.c_double) for n in ('ms_seed', 'ms_sw', 'ms_trace', 'ms_total', 'ms_k1', 'ms_sw_trace')]
 
 
 HIT_DTYPE = np.dtype([('q', '<u4'), ('t', '<u4'), ('q_start', '<u4'), ('q_end', '<u4'), ('t_start', '<u4'), ('t_end', '<u4'),
@@ -71,9 +72,11 @@ def load_library():
     return lib
 
 
-def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5, dbsize=5e6, max_evalue=1., use_lds=1):
+def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5, dbsize=5e6, max_evalue=1., use_lds=1, ungapped_min=None):
     p = SearchParams()
     load_library().pep_default_params(C.byref(p))
+    if ungapped_min is not None:
+        p.ungapped_min = int(ungapped_min)
     p.min_id_pct, p.min_qcov_pct, p.top_k, p.n_splits = float(min_id_pct), float(min_qcov_pct), int(top_k), int(n_splits)
     p.dbsize, p.max_evalue, p.use_lds = float(dbsize), float(max_evalue), int(use_lds)
     return p

@@ -33,6 +33,20 @@ void dev_release(DevBuf &b)
     b.cap = 0;
 }
 
+// block -> sequence map of a packed set (host build from the offsets, then upload)
+int pep_upload_blk2seq(pep_ctx *ctx, SeqSet &s)
+{
+    const uint64_t nblk = s.total / 16 + 1;
+    std::vector<uint32_t> m(nblk, 0u);
+    for (uint32_t i = 0; i < s.n; ++i) {
+        const uint64_t b0 = s.h_off[i] / 16, b1 = ((uint64_t)s.h_off[i] + s.h_len[i] + 15) / 16;
+        for (uint64_t b = b0; b < b1 && b < nblk; ++b) m[b] = i;
+    }
+    PEP_TRY(dev_reserve(ctx, s.blk2seq, nblk * 4));
+    PEP_HIP(ctx, hipMemcpy(s.blk2seq.p, m.data(), nblk * 4, hipMemcpyHostToDevice));
+    return PEP_OK;
+}
+
 namespace {
 
 // BLOSUM62 in the NCBI text layout (public domain); parsed once into the 32x32 code-indexed table
@@ -161,7 +175,7 @@ int upload_aa(pep_ctx *ctx, SeqSet &s, const uint8_t *codes, const uint64_t *off
     PEP_HIP(ctx, hipMemcpy(s.res.p, img.data(), pos, hipMemcpyHostToDevice));
     PEP_HIP(ctx, hipMemcpy(s.off.p, s.h_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice));
     if (n) PEP_HIP(ctx, hipMemcpy(s.len.p, s.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    return PEP_OK;
+    return pep_upload_blk2seq(ctx, s);
 }
 
 int download_aa(pep_ctx *ctx, const SeqSet &s, uint8_t *codes, uint64_t cap, uint64_t *off)
@@ -213,6 +227,7 @@ void pep_default_params(pep_search_params *p)
     p->min_id_pct = 0.; p->min_qcov_pct = 0.; p->top_k = 10; p->n_splits = 5;
     p->dbsize = 5e6; p->max_evalue = 1.;
     p->use_lds = 1;
+    p->ungapped_min = 45; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24;
 }
 
 int32_t pep_min_score(uint32_t qlen, double dbsize, double max_evalue)
@@ -248,7 +263,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     for (auto &b : ctx->ws) dev_release(b);
     DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->d_t_meta, &ctx->d_q_meta, &ctx->d_min_score, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
-                      &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len};
+                      &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -377,6 +392,8 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
             if (params->offs[s][params->weight[s] - 1] > 31) return pep_fail(ctx, PEP_ERR_ARG, "seed span above 32");
             if (pow((double)params->base, params->weight[s]) > 34359738368.0) return pep_fail(ctx, PEP_ERR_ARG, "seed key does not fit 35 bits");
         }
+        if (params->xdrop < 0 || params->xdrop > 48 || params->ext_right < 1 || params->ext_right > 48 || params->ext_left < 0 || params->ext_left > 48)
+            return pep_fail(ctx, PEP_ERR_ARG, "invalid ungapped-extension parameters");
         ctx->params = *params;
         ctx->sub_ready = false;
     }

@@ -50,6 +50,7 @@ struct SeqSet {
     DevBuf res;                  // u8
     DevBuf off;                  // u32[n+1]  (off[n] = total, sentinel for binary search)
     DevBuf len;                  // u32[n]
+    DevBuf blk2seq;              // u32[total/16]: sequence owning each 16-byte block (starts are 16-aligned, gaps >= 16)
     // host mirrors
     std::vector<uint32_t> h_off, h_len;
 };
@@ -116,3 +117,4 @@ int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uin
 int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *h_a, const uint32_t *h_b, uint32_t *h_label);
 
 static inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+int pep_upload_blk2seq(pep_ctx *ctx, SeqSet &s);

@@ -84,15 +84,21 @@ struct JoinArgs {
     uint32_t nt;
     const uint32_t *q_off;
     uint32_t nq;
+    const uint32_t *q_blk2seq, *t_blk2seq;
     const uint32_t *start;
     const uint64_t *entries;
     int bucket_bits;
     uint64_t *table;
     int table_bits;
-    uint64_t *list;
-    uint32_t list_cap;
-    uint32_t *counters;      // [0] = list length, [1] = overflow flag
-    unsigned long long *stats;   // [0] = target seeds, [1] = seed hits
+    uint32_t *counters;      // [0] = list length (filled by set_compact), [1] = set overflow flag, [2] = hit buffer overflow
+    unsigned long long *stats;   // [0] = target seeds, [1] = seed hits, [2] = seed hits passing the ungapped filter
+    const uint8_t *q_res;
+    const int8_t *sub;       // 32x32 substitution scores (global; staged in LDS by the kernel)
+    int ungapped_min, xdrop, ext_right, ext_left;
+    uint64_t *hits;          // raw seed hits (qpos << 32 | tpos)
+    unsigned long long *hit_count;
+    uint64_t hit_cap;
+    int debug;               // profiling aid: 1 = keys only, 2 = keys + bucket lookup, 3 = + entry compare (no extension)
 };
 
 __device__ __forceinline__ void set_insert(const JoinArgs &a, uint64_t k)
@@ -105,50 +111,161 @@ __device__ __forceinline__ void set_insert(const JoinArgs &a, uint64_t k)
         if (cur == EMPTY) {
             const uint64_t old = atomicCAS((unsigned long long *)&a.table[slot], (unsigned long long)EMPTY, (unsigned long long)k);
             if (old == k) return;
-            if (old == EMPTY) {
-                const uint32_t idx = atomicAdd(&a.counters[0], 1u);
-                if (idx < a.list_cap) a.list[idx] = k; else a.counters[1] = 1u;
-                return;
-            }
+            if (old == EMPTY) return;
         }
         slot = (slot + 1) & mask;
     }
     a.counters[1] = 1u;
 }
 
-__global__ __launch_bounds__(256) void seed_join(SeedShape sh, JoinArgs a)
+__device__ __forceinline__ bool set_contains(const JoinArgs &a, uint64_t k)
 {
-    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t mask = (1u << a.table_bits) - 1;
+    uint32_t slot = hash_u64(k, a.table_bits);
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const uint64_t cur = a.table[slot];
+        if (cur == k) return true;
+        if (cur == EMPTY) return false;          // possibly stale: the caller then extends and inserts with a CAS
+        slot = (slot + 1) & mask;
+    }
+    return false;
+}
+
+// ungapped x-drop score of the diagonal through a seed hit, on PACKED positions: the >= 16 padding bytes around every
+// sequence score -64, which ends an extension exactly where the sequence ends (x-drop < 64), so no bounds are needed
+// Returns as soon as the threshold is reached (the outcome score >= ungapped_min is all that is used).
+__device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *sub, uint32_t qp, uint64_t tp)
+{
+    int s = 0, br = 0, bl = 0;
+    for (int k = 0; k < a.ext_right; ++k) {
+        s += sub[(a.q_res[qp + k] & 31) * 32 + (a.t_res[tp + k] & 31)];
+        if (s > br) { br = s; if (br >= a.ungapped_min) return true; }
+        else if (br - s > a.xdrop) break;
+    }
+    s = 0;
+    for (int k = 1; k <= a.ext_left; ++k) {
+        s += sub[(a.q_res[qp - k] & 31) * 32 + (a.t_res[tp - k] & 31)];
+        if (s > bl) { bl = s; if (br + bl >= a.ungapped_min) return true; }
+        else if (bl - s > a.xdrop) break;
+    }
+    return false;
+}
+
+// Phase 1 of the join (persistent, grid-stride over 256-position tiles): target seed keys are looked up in the
+// query index and every equal-key pair is appended as a raw seed hit (qpos << 32 | tpos).  Hits are staged in an
+// LDS buffer and flushed with ONE global atomic per flush (a single global counter word only sustains ~90
+// atomics/us).  Every memory operation of this phase is independent across lanes: high memory-level parallelism.
+constexpr int HIT_BUF = 3072;
+__global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
+{
+    __shared__ uint64_t buf[HIT_BUF];
+    __shared__ uint32_t nbuf, blk_stats[2];
+    __shared__ unsigned long long gbase;
+    if (threadIdx.x == 0) { nbuf = 0; blk_stats[0] = blk_stats[1] = 0; }
+    __syncthreads();
     uint32_t n_seed = 0, n_hit = 0;
-    uint64_t key;
-    if (p + 32 <= a.t_total && seed_key(sh, a.t_res, p, key)) {
-        n_seed = 1;
-        const uint32_t b = hash_u64(key, a.bucket_bits);
-        const uint32_t e0 = a.start[b], e1 = a.start[b + 1];
-        uint32_t t = 0xFFFFFFFFu, tpos = 0;
+    const uint64_t n_tiles = (a.t_total + 255) / 256;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint64_t p = tile * 256 + threadIdx.x;
+        uint64_t key = 0;
+        uint32_t e0 = 0, e1 = 0;
+        if (p + 32 <= a.t_total && seed_key(sh, a.t_res, p, key)) {
+            ++n_seed;
+            if (a.debug != 1) {
+                const uint32_t b = hash_u64(key, a.bucket_bits);
+                e0 = a.start[b]; e1 = a.start[b + 1];
+                if (a.debug == 2) { n_hit += e1 - e0; e1 = e0; }
+            }
+        }
         for (uint32_t e = e0; e < e1; ++e) {
             const uint64_t ent = a.entries[e];
             if ((ent >> POS_BITS) != key) continue;
             ++n_hit;
-            if (t == 0xFFFFFFFFu) {
-                t = find_seq(a.t_off, a.nt, (uint32_t)p);
-                tpos = (uint32_t)p - a.t_off[t];
+            if (a.debug == 3) continue;
+            const uint64_t hit = ((ent & POS_MASK) << 32) | p;
+            const uint32_t idx = atomicAdd(&nbuf, 1u);
+            if (idx < HIT_BUF) buf[idx] = hit;
+            else {                                   // staging buffer full: rare direct append
+                const unsigned long long g = atomicAdd(a.hit_count, 1ull);
+                if (g < a.hit_cap) a.hits[g] = hit; else a.counters[2] = 1u;
             }
-            const uint32_t qp = (uint32_t)(ent & POS_MASK);
-            const uint32_t q = find_seq(a.q_off, a.nq, qp);
-            const int32_t diag = (int32_t)tpos - (int32_t)(qp - a.q_off[q]);
-            const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
-            set_insert(a, ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)bin);
+        }
+        __syncthreads();
+        const uint32_t cnt = nbuf;                   // block-uniform after the barrier
+        if (cnt > HIT_BUF / 2 || tile + gridDim.x >= n_tiles) {
+            const uint32_t n = min(cnt, (uint32_t)HIT_BUF);
+            if (threadIdx.x == 0) gbase = n ? atomicAdd(a.hit_count, (unsigned long long)n) : 0ull;
+            __syncthreads();
+            const unsigned long long g = gbase;
+            for (uint32_t x = threadIdx.x; x < n; x += 256) {
+                if (g + x < a.hit_cap) a.hits[g + x] = buf[x]; else a.counters[2] = 1u;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) nbuf = 0;
+            __syncthreads();
         }
     }
-    // per-wave statistics: one atomic per wave
     for (int d = 32; d > 0; d >>= 1) {
         n_seed += __shfl_down(n_seed, d, 64);
         n_hit += __shfl_down(n_hit, d, 64);
     }
-    if ((threadIdx.x & 63) == 0 && (n_seed | n_hit)) {
-        atomicAdd(&a.stats[0], (unsigned long long)n_seed);
-        atomicAdd(&a.stats[1], (unsigned long long)n_hit);
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&blk_stats[0], n_seed); atomicAdd(&blk_stats[1], n_hit); }
+    __syncthreads();
+    if (threadIdx.x < 2 && blk_stats[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)blk_stats[threadIdx.x]);
+}
+
+// Phase 2: one thread per raw seed hit, fully converged.  (q, t, diagonal bin) from the block->sequence maps;
+// a candidate already in the set needs nothing more; otherwise the ungapped x-drop extension decides, and the
+// first passer inserts the key.  The set is order-independent, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void seed_extend(JoinArgs a)
+{
+    __shared__ int8_t sub[1024];
+    __shared__ uint32_t blk_pass;
+    reinterpret_cast<uint32_t *>(sub)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.sub)[threadIdx.x];
+    if (threadIdx.x == 0) blk_pass = 0;
+    __syncthreads();
+    unsigned long long n_hits = *a.hit_count;
+    if (n_hits > a.hit_cap) n_hits = a.hit_cap;
+    uint32_t n_pass = 0;
+    for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < n_hits; h += (uint64_t)gridDim.x * 256) {
+        const uint64_t hit = a.hits[h];
+        const uint32_t qp = (uint32_t)(hit >> 32), p = (uint32_t)hit;
+        const uint32_t t = a.t_blk2seq[p >> 4], q = a.q_blk2seq[qp >> 4];
+        const int32_t diag = (int32_t)(p - a.t_off[t]) - (int32_t)(qp - a.q_off[q]);
+        const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
+        const uint64_t ck = ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)bin;
+        if (set_contains(a, ck)) { ++n_pass; continue; }
+        if (a.ungapped_min > 0 && !ungapped_pass(a, sub, qp, p)) continue;
+        ++n_pass;
+        set_insert(a, ck);
+    }
+    for (int d = 32; d > 0; d >>= 1) n_pass += __shfl_down(n_pass, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&blk_pass, n_pass);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_pass) atomicAdd(&a.stats[2], (unsigned long long)blk_pass);
+}
+
+// hash set -> dense list (arbitrary order; sorted afterwards).  One global atomic per block.
+__global__ __launch_bounds__(256) void set_compact(const uint64_t *__restrict__ table, uint64_t cap, uint64_t *__restrict__ list, uint32_t list_cap,
+                                                   uint32_t *__restrict__ counters)
+{
+    __shared__ uint32_t wave_cnt[4], blk_base;
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t k = i < cap ? table[i] : EMPTY;
+    const bool occ = k != EMPTY;
+    const unsigned long long m = __ballot(occ);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        blk_base = tot ? atomicAdd(&counters[0], tot) : 0u;
+    }
+    __syncthreads();
+    if (occ) {
+        uint32_t idx = blk_base + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+        for (int w = 0; w < wave; ++w) idx += wave_cnt[w];
+        if (idx < list_cap) list[idx] = k; else counters[1] = 1u;
     }
 }
 
@@ -162,7 +279,7 @@ int ilog2_ceil(uint64_t x)
 }  // namespace
 
 // workspace slots used here: ws[0] cnt, ws[1] start, ws[2] entries, ws[3] table, ws[4] list, ws[5] list tmp (sort),
-// ws[6] counters+stats, ws[7] scan scratch, ws[8] sort histogram
+// ws[6] counters+stats, ws[7] scan scratch, ws[8] raw seed hits (the sort histogram reuses ws[0])
 int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
 {
     const pep_search_params &P = ctx->params;
@@ -183,9 +300,14 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     uint64_t *entries = ctx->ws[2].as<uint64_t>();
     uint32_t *counters = ctx->ws[6].as<uint32_t>();
     unsigned long long *stats = reinterpret_cast<unsigned long long *>(counters + 4);
+    PEP_TRY(dev_reserve(ctx, ctx->d_params, 1024));
+    PEP_HIP(ctx, hipMemcpyAsync(ctx->d_params.p, P.sub, 1024, hipMemcpyHostToDevice, ctx->stream));
 
-    int table_bits = 22;
-    for (int attempt = 0; attempt < 8; ++attempt, table_bits += 2) {
+    int table_bits = 20;
+    uint64_t hit_cap = std::max<uint64_t>(1ull << 22, 2 * T.total);
+    unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(counters + 12);
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        PEP_TRY(dev_reserve(ctx, ctx->ws[8], hit_cap * sizeof(uint64_t)));
         const uint64_t cap = 1ull << table_bits;
         const uint32_t list_cap = (uint32_t)(cap >> 1);
         PEP_TRY(dev_reserve(ctx, ctx->ws[3], cap * sizeof(uint64_t)));
@@ -194,6 +316,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         PEP_HIP(ctx, hipMemsetAsync(ctx->ws[3].p, 0xFF, cap * sizeof(uint64_t), ctx->stream));
         PEP_HIP(ctx, hipMemsetAsync(counters, 0, 64, ctx->stream));
         uint64_t q_seeds = 0;
+        uint32_t h_nseed[4] = {0, 0, 0, 0};
         for (int s = 0; s < P.n_shapes; ++s) {
             SeedShape sh;
             sh.weight = P.weight[s];
@@ -207,27 +330,34 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             hipLaunchKernelGGL(seed_fill, dim3(qb), dim3(256), 0, ctx->stream, sh, Q.res.as<const uint8_t>(), Q.total, (const uint32_t *)start, cnt, entries, bucket_bits);
             JoinArgs a;
             a.t_res = T.res.as<const uint8_t>(); a.t_total = T.total; a.t_off = T.off.as<const uint32_t>(); a.nt = T.n;
-            a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.start = start; a.entries = entries; a.bucket_bits = bucket_bits;
-            a.table = ctx->ws[3].as<uint64_t>(); a.table_bits = table_bits; a.list = ctx->ws[4].as<uint64_t>(); a.list_cap = list_cap;
+            a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint32_t>(); a.t_blk2seq = T.blk2seq.as<const uint32_t>(); a.start = start; a.entries = entries; a.bucket_bits = bucket_bits;
+            a.table = ctx->ws[3].as<uint64_t>(); a.table_bits = table_bits;
             a.counters = counters; a.stats = stats;
-            hipLaunchKernelGGL(seed_join, dim3(tb), dim3(256), 0, ctx->stream, sh, a);
+            a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
+            a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
+            a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
+            PEP_HIP(ctx, hipMemsetAsync(hit_count, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(seed_match, dim3(std::min(tb, 256u * 5u)), dim3(256), 0, ctx->stream, sh, a);
+            hipLaunchKernelGGL(seed_extend, dim3(256u * 8u), dim3(256), 0, ctx->stream, a);
             PEP_HIP(ctx, hipGetLastError());
-            uint32_t nseed = 0;
-            PEP_HIP(ctx, hipMemcpyAsync(&nseed, start + n_buckets, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-            PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            q_seeds += nseed;
+            PEP_HIP(ctx, hipMemcpyAsync(&h_nseed[s], start + n_buckets, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         }
+        hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ws[3].as<uint64_t>(), cap,
+                           ctx->ws[4].as<uint64_t>(), list_cap, counters);
         uint32_t h_counters[4];
-        unsigned long long h_stats[2];
+        unsigned long long h_stats[3];
         PEP_HIP(ctx, hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
         PEP_HIP(ctx, hipMemcpyAsync(h_stats, stats, sizeof(h_stats), hipMemcpyDeviceToHost, ctx->stream));
         PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (h_counters[1] || h_counters[0] > list_cap) continue;     // table too small: retry 4x larger
+        if (h_counters[2]) { hit_cap *= 4; continue; }                // raw hit buffer too small: retry 4x larger
+        if (h_counters[1] || h_counters[0] > list_cap) { table_bits += 2; continue; }     // set too small: retry 4x larger
+        for (int s = 0; s < P.n_shapes; ++s) q_seeds += h_nseed[s];
         ctx->stats.query_seeds = q_seeds;
         ctx->stats.target_seeds = h_stats[0];
         ctx->stats.seed_hits = h_stats[1];
+        ctx->stats.seed_hits_passed = h_stats[2];
         const uint64_t n = h_counters[0];
-        PEP_TRY(pep_sort_u64(ctx, ctx->ws[4].as<uint64_t>(), ctx->ws[5].as<uint64_t>(), n, 64, ctx->ws[8]));
+        PEP_TRY(pep_sort_u64(ctx, ctx->ws[4].as<uint64_t>(), ctx->ws[5].as<uint64_t>(), n, 64, ctx->ws[0]));
         *d_cands = ctx->ws[4].as<uint64_t>();
         *n_cands = n;
         return PEP_OK;

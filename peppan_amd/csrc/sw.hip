@@ -43,7 +43,7 @@ struct SwArgs {
 __device__ __forceinline__ int shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // lane l <- lane l-1
 __device__ __forceinline__ int shl1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }   // lane l <- lane l+1
 
-template <bool LDS_RES>
+template <bool LDS_RES, bool TRACE>
 __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32_t *lds_tab, uint8_t *lds_res, int lane)
 {
     const uint64_t key = a.cands[c];
@@ -58,7 +58,7 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32
     const int s0 = s_lo - ((s_lo - dlo) & 1);
     const int a0 = (s0 - dlo) / 2;                 // exact: s0 - dlo is even
     const int nblk = (int)a.nblk[c];
-    uint32_t *dir = a.dirs + a.dir_off[c] * 64;
+    uint32_t *dir = TRACE ? a.dirs + a.dir_off[c] * 64 : nullptr;
 
     // index of the residues used by step pair m:  A: (i, j) = (a0 + m - lane, a0 + dlo + m + lane),  B: (i, j + 1)
     int i = a0 - lane, j = a0 + dlo + lane;
@@ -103,9 +103,11 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32
                 const int E = max(e_ext, e_open), F = max(f_ext, f_open);
                 const int h = HA + sub;
                 const int H = max(max(max(h, E), F), 0);
-                const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
-                const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
-                acc = (acc >> 4) | (nib << 28);
+                if (TRACE) {
+                    const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
+                    const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
+                    acc = (acc >> 4) | (nib << 28);
+                }
                 if (H > best) { best = H; best_k = k; }
                 HA = H; EA = E; FA = F;
             }
@@ -120,15 +122,17 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32
                 const int E = max(e_ext, e_open), F = max(f_ext, f_open);
                 const int h = HB + sub;
                 const int H = max(max(max(h, E), F), 0);
-                const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
-                const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
-                acc = (acc >> 4) | (nib << 28);
+                if (TRACE) {
+                    const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
+                    const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
+                    acc = (acc >> 4) | (nib << 28);
+                }
                 if (H > best) { best = H; best_k = k; }
                 HB = H; EB = E; FB = F;
             }
             ++k; ++i;
         }
-        dir[(size_t)b * 64 + lane] = acc;
+        if (TRACE) dir[(size_t)b * 64 + lane] = acc;
     }
     // the lane's best cell: earliest step with the lane maximum == (min i, then min j) among its two diagonals
     int bi = 0x7fffffff, bj = 0x7fffffff;
@@ -147,6 +151,9 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32
     if (lane == 0) a.out[c] = make_int4(best, best > 0 ? bi : -1, best > 0 ? bj : -1, a0);
 }
 
+// TRACE = false: score pass over every candidate (score + end cell only, no HBM writes beyond 16 B per candidate)
+// TRACE = true : traceback pass over the pairs that survived best-per-(q,t) and the e-value cut
+template <bool TRACE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(SwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -157,8 +164,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(SwArgs a)
     uint8_t *lds_res = smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes;
     for (uint64_t c = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; c < a.n; c += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
         const int need = 2 * ((4 * (int)a.nblk[c] + 72 + 15) & ~15);
-        if (need <= a.lds_res_bytes) sw_one<true>(a, c, lds_tab, lds_res, lane);
-        else sw_one<false>(a, c, lds_tab, lds_res, lane);
+        if (need <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, lds_tab, lds_res, lane);
+        else sw_one<false, TRACE>(a, c, lds_tab, lds_res, lane);
     }
 }
 
@@ -216,10 +223,13 @@ int pep_selftest_dpp(pep_ctx *ctx)
     return PEP_OK;
 }
 
-// Runs K5 over all candidates.  Fills ws[10] nblk, ws[11] dir_off (u64, n+1), ws[12] sw_out (int4), ws[13] dirs.
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, float *ms_kernel)
+// Runs K5 over `n` candidate keys.  trace = false: score pass (ws[12] <- score / end cell / a0 per candidate).
+// trace = true: same DP plus traceback codes (ws[11] dir_off u64[n+1], ws[13] dirs).  ws[10] nblk, ws[14] scan input.
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, float *ms_kernel)
 {
     const pep_search_params &P = ctx->params;
+    *ms_kernel = 0.f;
+    if (n == 0) return PEP_OK;
     PEP_TRY(dev_reserve(ctx, ctx->ws[10], (n + 1) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[11], (n + 2) * sizeof(uint64_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[14], (n + 2) * sizeof(uint64_t)));
@@ -235,10 +245,12 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, float *ms_kern
     PEP_HIP(ctx, hipMemcpyAsync(&total_blk, ctx->ws[11].as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
     PEP_HIP(ctx, hipMemcpyAsync(&h_cells, cells, 8, hipMemcpyDeviceToHost, ctx->stream));
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->stats.cells = h_cells;
-    ctx->stats.cells_swept = total_blk * 8 * 64;
-    ctx->stats.dir_bytes = total_blk * 256;
-    PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 256 + 256));
+    if (trace) ctx->stats.cells_trace += h_cells; else ctx->stats.cells += h_cells;
+    ctx->stats.cells_swept += total_blk * 8 * 64;
+    if (trace) {
+        ctx->stats.dir_bytes += total_blk * 256;
+        PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 256 + 256));
+    }
 
     SwArgs a;
     a.cands = d_cands; a.n = n;
@@ -247,7 +259,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, float *ms_kern
     a.t_off = ctx->t.off.as<const uint32_t>(); a.t_len = ctx->t.len.as<const uint32_t>();
     a.sub_image = ctx->sub_lds.as<const uint32_t>();
     a.dir_off = ctx->ws[11].as<const uint64_t>(); a.nblk = ctx->ws[10].as<const uint32_t>();
-    a.dirs = ctx->ws[13].as<uint32_t>(); a.out = ctx->ws[12].as<int4>();
+    a.dirs = trace ? ctx->ws[13].as<uint32_t>() : nullptr; a.out = ctx->ws[12].as<int4>();
     a.oe = P.gap_open + P.gap_ext; a.ext = P.gap_ext;
     a.lds_res_bytes = P.use_lds ? 4096 : 0;
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
@@ -257,13 +269,14 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, float *ms_kern
     PEP_HIP(ctx, hipEventCreate(&e0));
     PEP_HIP(ctx, hipEventCreate(&e1));
     PEP_HIP(ctx, hipEventRecord(e0, ctx->stream));
-    hipLaunchKernelGGL(sw_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+    if (trace) hipLaunchKernelGGL(sw_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+    else hipLaunchKernelGGL(sw_kernel<false>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     PEP_HIP(ctx, hipEventRecord(e1, ctx->stream));
     PEP_HIP(ctx, hipGetLastError());
     PEP_HIP(ctx, hipEventSynchronize(e1));
     PEP_HIP(ctx, hipEventElapsedTime(ms_kernel, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     ctx->stats.sw_launches += 1;
     return PEP_OK;
 }

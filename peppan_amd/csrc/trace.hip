@@ -3,12 +3,12 @@
 // per-(query, split) top-k, and emit fixed-size hit records + a CIGAR arena ordered by (q, t).
 #include "common.h"
 
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, float *ms_kernel);
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, float *ms_kernel);
 
 namespace {
 
 struct SelInfo {          // one per selected (q,t) pair
-    uint32_t cand;        // index into the candidate list
+    uint32_t cand;        // index into the compacted key list of selected pairs (== own index)
     int32_t score, iend, jend;
     int32_t istart, jstart;
     uint32_t n_runs, aln_len, n_ident;
@@ -44,13 +44,14 @@ __global__ __launch_bounds__(256) void select_best(const uint64_t *__restrict__ 
 __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
                                                   const uint32_t *__restrict__ best_idx, const int4 *__restrict__ sw,
                                                   const uint64_t *__restrict__ cands, const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len,
-                                                  SelInfo *__restrict__ sel, uint64_t *__restrict__ run_cap)
+                                                  SelInfo *__restrict__ sel, uint64_t *__restrict__ run_cap, uint64_t *__restrict__ sel_keys)
 {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n || !flag[c]) return;
     const uint32_t b = best_idx[c];
     SelInfo s;
-    s.cand = b; s.score = sw[b].x; s.iend = sw[b].y; s.jend = sw[b].z;
+    s.cand = pos[c]; s.score = sw[b].x; s.iend = sw[b].y; s.jend = sw[b].z;
+    sel_keys[pos[c]] = cands[b];
     s.istart = s.jstart = 0; s.n_runs = s.aln_len = s.n_ident = 0; s.pass = s.keep = 0; s.pad = 0;
     sel[pos[c]] = s;
     // an alignment has at most 2*min(Lq,Lt)+1 runs (M runs consume a residue of both sequences)
@@ -220,8 +221,8 @@ __global__ __launch_bounds__(256) void emit(uint64_t n_sel, const SelInfo *__res
 
 }  // namespace
 
-// workspace slots: ws[16] flag, ws[17] pos, ws[18] best_idx, ws[19] sel, ws[20] run_cap/run_off (u64 x2), ws[21] runs,
-//                  ws[22] keep arrays, ws[23] output hits + cigar, ws[9] small counters
+// workspace slots: ws[16] flag, ws[17] pos, ws[18] best_idx, ws[19] sel, ws[20] run_cap/run_off (u64 x2) + selected keys,
+//                  ws[21] runs, ws[22] keep arrays, ws[23] output hits + cigar, ws[9] small counters
 int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t *h_min_score, pep_result *res)
 {
     const pep_search_params &P = ctx->params;
@@ -232,8 +233,9 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     ctx->stats.cells = ctx->stats.cells_swept = ctx->stats.dir_bytes = 0;
     if (n == 0) return PEP_OK;
     hipStream_t st = ctx->stream;
+    // ---- pass 1: score-only banded SW over every candidate
     float ms_sw = 0.f;
-    PEP_TRY(pep_sw_run(ctx, d_cands, n, &ms_sw));
+    PEP_TRY(pep_sw_run(ctx, d_cands, n, false, &ms_sw));
     ctx->stats.ms_sw = ms_sw;
 
     hipEvent_t e0, e1;
@@ -264,28 +266,33 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     ctx->stats.tracebacks = n_sel;
     if (n_sel) {
         PEP_TRY(dev_reserve(ctx, ctx->ws[19], (size_t)n_sel * sizeof(SelInfo)));
-        PEP_TRY(dev_reserve(ctx, ctx->ws[20], ((size_t)n_sel + 2) * 8 * 2));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[20], ((size_t)n_sel + 2) * 8 * 3));
         SelInfo *sel = ctx->ws[19].as<SelInfo>();
-        uint64_t *run_cap = ctx->ws[20].as<uint64_t>(), *run_off = run_cap + n_sel + 2;
+        uint64_t *run_cap = ctx->ws[20].as<uint64_t>(), *run_off = run_cap + n_sel + 2, *sel_keys = run_off + n_sel + 2;
         hipLaunchKernelGGL(gather_sel, dim3(gb), dim3(256), 0, st, n, (const uint32_t *)flag, (const uint32_t *)pos, (const uint32_t *)best_idx, sw, d_cands,
-                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap);
+                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys);
         PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_sel, ctx->ws[7]));
         uint64_t total_runs = 0;
         PEP_HIP(ctx, hipMemcpyAsync(&total_runs, run_off + n_sel, 8, hipMemcpyDeviceToHost, st));
         PEP_HIP(ctx, hipStreamSynchronize(st));
+        // ---- pass 2: the same DP with traceback codes, selected pairs only (overwrites the pass-1 per-candidate arrays)
+        float ms_tr = 0.f;
+        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, &ms_tr));
+        ctx->stats.ms_sw_trace = ms_tr;
+        const int4 *sw2 = ctx->ws[12].as<const int4>();
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
         uint32_t *runs = ctx->ws[21].as<uint32_t>();
         const unsigned gw = (unsigned)ceil_div(n_sel, 4);
-        hipLaunchKernelGGL(walk, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, d_cands, sw, ctx->ws[11].as<const uint64_t>(),
+        hipLaunchKernelGGL(walk, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, sw2, ctx->ws[11].as<const uint64_t>(),
                            ctx->ws[13].as<const uint32_t>(), (const uint64_t *)run_off, runs);
-        hipLaunchKernelGGL(finalize, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, d_cands, ctx->q.res.as<const uint8_t>(),
+        hipLaunchKernelGGL(finalize, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
                            ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(),
                            ctx->t.off.as<const uint32_t>(), (const uint64_t *)run_off, (const uint32_t *)runs, P.min_id_pct, P.min_qcov_pct);
         // top-k, then compaction of hits and CIGAR runs
         PEP_TRY(dev_reserve(ctx, ctx->ws[22], ((size_t)n_sel + 2) * (4 + 4 + 8 + 8)));
         uint32_t *keep_flag = ctx->ws[22].as<uint32_t>(), *hit_pos = keep_flag + n_sel + 2;
         uint64_t *keep_runs = reinterpret_cast<uint64_t *>(hit_pos + n_sel + 2), *cig_pos = keep_runs + n_sel + 2;
-        hipLaunchKernelGGL(topk, dim3((unsigned)ceil_div(n_sel, 256)), dim3(256), 0, st, (uint64_t)n_sel, sel, d_cands, P.top_k, P.n_splits, keep_flag, keep_runs);
+        hipLaunchKernelGGL(topk, dim3((unsigned)ceil_div(n_sel, 256)), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, P.top_k, P.n_splits, keep_flag, keep_runs);
         PEP_TRY(pep_scan_u32(ctx, keep_flag, hit_pos, n_sel, ctx->ws[7]));
         PEP_TRY(pep_scan_u64(ctx, keep_runs, cig_pos, n_sel, ctx->ws[7]));
         uint32_t n_hits = 0;
@@ -299,7 +306,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
             PEP_TRY(dev_reserve(ctx, ctx->ws[23], hb + (n_cig + 1) * 4));
             pep_hit *d_hits = ctx->ws[23].as<pep_hit>();
             uint32_t *d_cig = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctx->ws[23].p) + hb);
-            hipLaunchKernelGGL(emit, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, (const SelInfo *)sel, d_cands, (const uint32_t *)keep_flag,
+            hipLaunchKernelGGL(emit, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, (const SelInfo *)sel, (const uint64_t *)sel_keys, (const uint32_t *)keep_flag,
                                (const uint32_t *)hit_pos, (const uint64_t *)cig_pos, (const uint64_t *)run_off, (const uint32_t *)runs,
                                ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig);
             PEP_HIP(ctx, hipGetLastError());
@@ -314,8 +321,8 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     float ms = 0.f;
     PEP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     ctx->stats.ms_trace = ms;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }

@@ -207,7 +207,7 @@ int pack_from_desc(pep_ctx *ctx, const NtSet &nt, int tab, const std::vector<Pac
     PEP_HIP(ctx, hipGetLastError());
     // the host vectors must outlive the async copies
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PEP_OK;
+    return pep_upload_blk2seq(ctx, out);
 }
 
 }  // namespace

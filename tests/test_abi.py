@@ -25,7 +25,7 @@ def test_struct_sizes_match_header():
     assert N.HIT_DTYPE.itemsize == 64 and N.NT_HIT_DTYPE.itemsize == 40
     assert N.QUERY_META_DTYPE.itemsize == 16 and N.TARGET_META_DTYPE.itemsize == 16
     assert C.sizeof(N.SearchParams) == 4 * 4 + 16 + 512 + 32 + 1024 + 16 + 8 + 16 + 32
-    assert C.sizeof(N.Stats) == 13 * 8 + 5 * 8
+    assert C.sizeof(N.Stats) == 15 * 8 + 6 * 8
 
 
 def test_no_gpu_is_a_loud_error():
@@ -45,6 +45,7 @@ def test_default_params_and_min_score_match_oracle():
     assert p.base == o.base and p.n_shapes == o.n_shapes and list(p.weight) == list(o.weight)
     assert [list(x) for x in p.offs] == [list(x) for x in o.offs]
     assert (p.gap_open, p.gap_ext, p.top_k, p.n_splits) == (o.gap_open, o.gap_ext, o.top_k, o.n_splits)
+    assert (p.ungapped_min, p.xdrop, p.ext_right, p.ext_left) == (o.ungapped_min, o.xdrop, o.ext_right, o.ext_left) == (45, 12, 40, 24)
     for L in (1, 30, 100, 334, 1000, 3164, 50000):
         assert N.min_score(L) == O.min_score(L)
     assert N.min_score(334) == 68          # ~63/68/72 for 100/334/1000-aa queries
