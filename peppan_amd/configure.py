@@ -1,0 +1,200 @@
+"""Host-side utilities with the reference's names and semantics (modules/configure.py of PEPPAN) but none of its
+external-binary discovery: nothing here shells out, the arithmetic lives in libpeppan_hip.so.
+
+    logger                 configure.py:197-199
+    uopen                  configure.py:90-115   (gzip handled in-process instead of a pigz/gzip pipe)
+    readFasta / readFastq  configure.py:118-150
+    rc                     configure.py:152-154
+    transeq                configure.py:160-194  (host mirror; the search path translates on the GPU, K1)
+    blosum62               configure.py:49-87    (same 32-stride letter indexing, built from the standard matrix)
+"""
+import gzip
+import io
+import re
+import sys
+from datetime import datetime
+
+import numpy as np
+
+xrange = range
+asc2int = np.uint32
+
+
+def logger(log, pipe=sys.stderr):
+    pipe.write('{0}\t{1}\n'.format(str(datetime.now()), log))
+    pipe.flush()
+
+
+class uopen(object):
+    """context manager over a plain or gzipped text file ('r' or 'w')"""
+
+    def __init__(self, fname, label='r'):
+        gz = fname.lower().endswith('gz')
+        if 'r' in label:
+            self.fstream = io.TextIOWrapper(gzip.open(fname, 'rb'), encoding='utf-8') if gz else open(fname)
+        else:
+            self.fstream = io.TextIOWrapper(gzip.open(fname, 'wb'), encoding='utf-8')
+
+    def __enter__(self):
+        return self.fstream
+
+    def __exit__(self, *exc):
+        self.fstream.close()
+
+    def __iter__(self):
+        return iter(self.fstream)
+
+    def write(self, doc):
+        self.fstream.write(doc)
+
+    def close(self):
+        self.fstream.close()
+
+
+def readFasta(fasta, headOnly=False):
+    """name (first token of the header) -> upper-cased sequence; '#' lines ignored"""
+    names, chunks = [], {}
+    with uopen(fasta) as fin:
+        cur = None
+        for line in fin:
+            if line.startswith('>'):
+                cur = line[1:].strip().split()[0]
+                chunks[cur] = []
+                names.append(cur)
+            elif len(line) > 0 and not line.startswith('#') and not headOnly:
+                chunks[cur].extend(line.strip().split())
+    return {n: ''.join(chunks[n]).upper() for n in chunks}
+
+
+def readFastq(fastq):
+    """FASTQ or FASTA -> (sequences, qualities); FASTA input gets 'I'/'!' pseudo-qualities like the reference"""
+    with uopen(fastq) as fin:
+        first = fin.readline()
+    if not first.startswith('@'):
+        seq = readFasta(fastq)
+        return seq, {n: re.sub(r'[^!]', 'I', re.sub(r'[^ACGTacgt]', '!', s)) for n, s in seq.items()}
+    seq, qual = {}, {}
+    with uopen(fastq) as fin:
+        for k, line in enumerate(fin):
+            m = k % 4
+            if m == 0:
+                name = line[1:].strip().split()[0]
+                seq[name], qual[name] = [], []
+            elif m == 1:
+                seq[name].extend(line.strip().split())
+            elif m == 3:
+                qual[name].extend(line.strip().split())
+    return {n: ''.join(s).upper() for n, s in seq.items()}, {n: ''.join(q) for n, q in qual.items()}
+
+
+_COMP = str.maketrans('ACGTN', 'TGCAN')
+
+
+def rc(seq, missingValue='N'):
+    s = seq.upper()
+    if missingValue == 'N' and not re.search(r'[^ACGTN]', s):
+        return s.translate(_COMP)[::-1]
+    comp = {'A': 'T', 'T': 'A', 'G': 'C', 'C': 'G', 'N': 'N'}
+    return ''.join(comp.get(c, missingValue) for c in reversed(s))
+
+
+# ---------------------------------------------------------------------------------------------- translation
+_AA64 = 'KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVVXYXYSSSSXCWCLFLF'
+
+
+def _codon_table(transl_table, markStarts):
+    tab = np.array(list(_AA64 + '-'))
+    if transl_table == 4:
+        tab[56] = 'W'
+    if markStarts:
+        tab[[46, 62]] = 'M'
+    return tab
+
+
+_NT = np.full(256, -1, dtype=np.int64)
+_NT[[ord(c) for c in 'ACGT']] = (0, 1, 2, 3)
+_NT[ord('-')] = -2
+
+
+def _translate_codes(codes, tab):
+    """codes: int array (0..3, -1 ambiguous, -2 gap) of any length -> protein string"""
+    n = codes.size
+    if n == 0:
+        return ''
+    pad = (-n) % 3
+    if pad:
+        codes = np.concatenate([codes, np.full(pad, -1, dtype=np.int64)])
+    c = codes.reshape(-1, 3)
+    idx = (c[:, 0] << 4) | (c[:, 1] << 2) | c[:, 2]
+    bad = (c < 0).any(1)
+    gap = (c == -2).any(1)
+    idx = np.where(bad, 0, idx)
+    aa = tab[idx]
+    aa[bad] = 'X'
+    aa[gap] = '-'
+    return ''.join(aa.tolist())
+
+
+def transeq(seq, frame=7, transl_table=None, markStarts=False):
+    """dict name->nt (or list of [name, nt]) -> dict name->[protein per frame] (or list of [name, [..]]).
+    frame: 'F' (1,2,3), 'R' (4,5,6), '7' (all six) or a comma list; stops and ambiguous codons are 'X',
+    codons containing '-' are '-', a trailing partial codon is 'X'; transl_table 4 reads TGA as W."""
+    frames = {'F': [1, 2, 3], 'R': [4, 5, 6], '7': [1, 2, 3, 4, 5, 6]}.get(str(frame).upper())
+    if frames is None:
+        frames = [int(f) for f in str(frame).split(',')]
+    tab = _codon_table(transl_table, markStarts)
+    items = seq.items() if isinstance(seq, dict) else seq
+    out = []
+    for name, s in items:
+        fw = _NT[np.frombuffer(s.upper().encode('ascii'), dtype=np.uint8)]
+        rv = None
+        prots = []
+        for f in frames:
+            if f <= 3:
+                prots.append(_translate_codes(fw[f - 1:], tab))
+            else:
+                if rv is None:
+                    rv = np.where(fw >= 0, 3 - fw, fw)[::-1]
+                prots.append(_translate_codes(rv[f - 4:], tab))
+        out.append([name, prots])
+    return dict(out) if isinstance(seq, dict) else out
+
+
+# ---------------------------------------------------------------------------------------------- BLOSUM62
+def _blosum62():
+    order = 'ARNDCQEGHILKMFPSTWYVBZX*'
+    rows = """ 4 -1 -2 -2  0 -1 -1  0 -2 -1 -1 -1 -1 -2 -1  1  0 -3 -2  0 -2 -1  0 -4
+-1  5  0 -2 -3  1  0 -2  0 -3 -2  2 -1 -3 -2 -1 -1 -3 -2 -3 -1  0 -1 -4
+-2  0  6  1 -3  0  0  0  1 -3 -3  0 -2 -3 -2  1  0 -4 -2 -3  3  0 -1 -4
+-2 -2  1  6 -3  0  2 -1 -1 -3 -4 -1 -3 -3 -1  0 -1 -4 -3 -3  4  1 -1 -4
+ 0 -3 -3 -3  9 -3 -4 -3 -3 -1 -1 -3 -1 -2 -3 -1 -1 -2 -2 -1 -3 -3 -2 -4
+-1  1  0  0 -3  5  2 -2  0 -3 -2  1  0 -3 -1  0 -1 -2 -1 -2  0  3 -1 -4
+-1  0  0  2 -4  2  5 -2  0 -3 -3  1 -2 -3 -1  0 -1 -3 -2 -2  1  4 -1 -4
+ 0 -2  0 -1 -3 -2 -2  6 -2 -4 -4 -2 -3 -3 -2  0 -2 -2 -3 -3 -1 -2 -1 -4
+-2  0  1 -1 -3  0  0 -2  8 -3 -3 -1 -2 -1 -2 -1 -2 -2  2 -3  0  0 -1 -4
+-1 -3 -3 -3 -1 -3 -3 -4 -3  4  2 -3  1  0 -3 -2 -1 -3 -1  3 -3 -3 -1 -4
+-1 -2 -3 -4 -1 -2 -3 -4 -3  2  4 -2  2  0 -3 -2 -1 -2 -1  1 -4 -3 -1 -4
+-1  2  0 -1 -3  1  1 -2 -1 -3 -2  5 -1 -3 -1  0 -1 -3 -2 -2  0  1 -1 -4
+-1 -1 -2 -3 -1  0 -2 -3 -2  1  2 -1  5  0 -2 -1 -1 -1 -1  1 -3 -1 -1 -4
+-2 -3 -3 -3 -2 -3 -3 -3 -1  0  0 -3  0  6 -4 -2 -2  1  3 -1 -3 -3 -1 -4
+-1 -2 -2 -1 -3 -1 -1 -2 -2 -3 -3 -1 -2 -4  7 -1 -1 -4 -3 -2 -2 -1 -2 -4
+ 1 -1  1  0 -1  0  0  0 -1 -2 -2  0 -1 -2 -1  4  1 -3 -2 -2  0  0  0 -4
+ 0 -1  0 -1 -1 -1 -1 -2 -2 -1 -1 -1 -1 -2 -1  1  5 -2 -2  0 -1 -1  0 -4
+-3 -3 -4 -4 -2 -2 -3 -2 -2 -3 -2 -3 -1  1 -4 -3 -2 11  2 -3 -4 -3 -2 -4
+-2 -2 -2 -3 -2 -1 -2 -3  2 -1 -1 -2 -1  3 -3 -2 -2  2  7 -1 -3 -2 -1 -4
+ 0 -3 -3 -3 -1 -2 -2 -3 -3  3  1 -2  1 -1 -2 -2  0 -3 -1  4 -3 -2 -1 -4
+-2 -1  3  4 -3  0  1 -1  0 -3 -4  0 -3 -3 -2  0 -1 -4 -3 -3  4  1 -1 -4
+-1  0  0  1 -3  3  4 -2  0 -3 -3  1 -1 -3 -1  0 -1 -3 -2 -2  1  4 -1 -4
+ 0 -1 -1 -1 -2 -1 -1 -1 -1 -1 -1 -1 -1 -1 -2  0  0 -2 -1 -1 -1 -1 -1 -4
+-4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4 -4  1"""
+    m = np.array([[int(v) for v in r.split()] for r in rows.split('\n')])
+    # the reference stores '*' under the letter U ("* is designated as U", configure.py:48)
+    letters = [c if c != '*' else 'U' for c in order]
+    tab = np.zeros(858, dtype=float)
+    for i, a in enumerate(letters):
+        for j, b in enumerate(letters):
+            tab[(ord(a) - 65) * 32 + ord(b) - 65] = m[i, j]
+    return tab
+
+
+blosum62 = _blosum62()

@@ -1,0 +1,370 @@
+"""Drop-in for PEPPAN's modules/uberBlast.py with the external aligners replaced by libpeppan_hip.so.
+
+Same entry points and table format:
+    uberBlast(args, extPool=None)                       uberBlast.py:564-613   same argparse flags (+ --gpu, --device)
+    RunBlast().run(ref, qry, methods, min_id, ...)      uberBlast.py:326-376   same positional / keyword arguments
+    tools: 'diamond', 'diamondself', 'gpu'  -> translated search on the MI355X (K1..K8), replaces runDiamond
+                                              (uberBlast.py:513-560) and parseDiamond (uberBlast.py:16-70)
+           'blastn'                          -> nucleotide search on the same engine (see run_blastn)
+Each tool returns the reference's 15-column object rows (names str, CIGAR as [[n, op], ...] in nucleotides);
+run() then applies reScore (K7 on the GPU for mode 1), the -f/-m filters, fixEnd, -O overlaps and the final
+string-keyed sort exactly as the reference does.  There is no CPU fallback: without the HIP library or a GPU
+the tools raise.
+"""
+import os
+import re
+import sys
+
+import numpy as np
+import pandas as pd
+
+from . import _native as N
+from . import mapfilters
+from .configure import logger, readFastq, blosum62, asc2int
+
+_OPS = np.array(['M', 'I', 'D'])
+_OP_CODE = {'M': 0, 'I': 1, 'D': 2}
+
+# ---- tables of the rescoring modes (uberBlast.py:270-272)
+nucEncoder = np.repeat(2, 255).astype(int)
+nucEncoder[[ord(c) for c in 'ACGT']] = (0, 1, 3, 4)
+# codon (base-5 digits of the A0 C1 N2 G3 T4 code) -> amino-acid letter index; built from the standard table
+def _make_gtable():
+    aa64 = 'KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVVXYXYSSSSXCWCLFLF'   # A0 C1 G2 T3 order
+    five = {0: 0, 1: 1, 2: 3, 3: 4}
+    t = np.full(125, ord('X') - 65, dtype=int)
+    for i, a in enumerate(aa64):
+        d = [five[(i >> 4) & 3], five[(i >> 2) & 3], five[i & 3]]
+        t[d[0] * 25 + d[1] * 5 + d[2]] = ord(a) - 65
+    return t
+
+
+gtable = _make_gtable()
+
+_CTX = {}
+
+
+def get_context(device=None):
+    """one HIP context per (process, device), created lazily so that forked workers make their own
+    (the reference forks pool workers before calling uberBlast, PEPPAN.py:922)"""
+    if device is None:
+        device = int(os.environ.get('PEPPAN_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    key = (os.getpid(), device)
+    if key not in _CTX:
+        _CTX[key] = N.Context(device)
+    return _CTX[key]
+
+
+# ------------------------------------------------------------------------------------------------------------
+# GPU hits -> the reference's table rows (coordinate algebra of parseDiamond, uberBlast.py:25-58)
+# ------------------------------------------------------------------------------------------------------------
+def hits_to_blastab(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
+    """hits/cigar: output of Context.search for a translated search.  q_len / r_len: nucleotide lengths per sequence index.
+    Returns ndarray(object)[n, 15]."""
+    n = len(hits)
+    if n == 0:
+        return np.empty([0, 15], dtype=object)
+    qi, ti = hits['q'].astype(np.int64), hits['t'].astype(np.int64)
+    qseq, qf = q_meta['seq'][qi].astype(np.int64), q_meta['frame'][qi].astype(np.int64)
+    rseq, rf, rx = t_meta['seq'][ti].astype(np.int64), t_meta['frame'][ti].astype(np.int64), t_meta['chunk_off'][ti].astype(np.int64)
+    ql, rl = np.asarray(q_len, dtype=np.int64)[qseq], np.asarray(r_len, dtype=np.int64)[rseq]
+    qs_aa, qe_aa = hits['q_start'].astype(np.int64), hits['q_end'].astype(np.int64)
+    rs_aa = hits['t_start'].astype(np.int64) + rx                       # POS + chunk offset
+    qm = qe_aa - qs_aa + 1                                              # aligned query residues = len(SEQ)
+    rm = hits['t_end'].astype(np.int64) - hits['t_start'].astype(np.int64) + 1
+    cl = 3 * hits['aln_len'].astype(np.int64)
+    variation = 3. * hits['nm'].astype(np.float64)
+    iden = 1 - np.round(variation / cl, 3)          # round() of a numpy float64 is numpy's round (uberBlast.py:38)
+    keep = (qm * 3 >= min_cov) & (qm * 3. / ql >= min_ratio) & (iden >= min_id)
+    fwd = rf <= 3
+    rs_nt = np.where(fwd, rs_aa * 3 + rf - 3, rl - (rs_aa * 3 + rf - 6) + 1)
+    re_nt = np.where(fwd, (rs_aa + rm - 1) * 3 + rf - 1, rl - ((rs_aa + rm - 1) * 3 + rf - 4) + 1)
+    qs_nt, qe_nt = qs_aa * 3 + qf - 3, (qs_aa + qm - 1) * 3 + qf - 1
+    runs_len = (cigar >> 2).astype(np.int64) * 3
+    runs_op = (cigar & 3).astype(np.int64)
+    owner = np.repeat(np.arange(n), hits['cigar_runs'].astype(np.int64))
+    gap_nt = np.bincount(owner, weights=runs_len * (runs_op != 0), minlength=n).astype(np.int64)
+    gap_open = np.bincount(owner, weights=(runs_op != 0), minlength=n).astype(np.int64)
+    mismatch = (variation - gap_nt).astype(np.int64)
+    idx = np.nonzero(keep)[0]
+    out = np.empty([len(idx), 15], dtype=object)
+    off = hits['cigar_off'].astype(np.int64)
+    nr = hits['cigar_runs'].astype(np.int64)
+    len_l, op_l = runs_len.tolist(), _OPS[runs_op].tolist()
+    for k, h in enumerate(idx.tolist()):
+        o, r = off[h], nr[h]
+        out[k] = [str(q_names[qseq[h]]), str(r_names[rseq[h]]), float(iden[h]), int(cl[h]), int(mismatch[h]), int(gap_open[h]),
+                  int(qs_nt[h]), int(qe_nt[h]), int(rs_nt[h]), int(re_nt[h]), 0.0, int(hits['score'][h]), int(ql[h]), int(rl[h]),
+                  [[len_l[x], op_l[x]] for x in range(o, o + r)]]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# rescoring (cigar2score, uberBlast.py:221-269)
+# ------------------------------------------------------------------------------------------------------------
+def cigar2score(data):
+    """(cigar, rSeq, qSeq, frame, mode, gapOpen, gapExtend, table_id) -> (identity, score); host version of all
+    three modes on encoded sequences (A0 C1 G3 T4 other 2).  Mode 1 is what RunBlast.reScore runs on the GPU."""
+    cigar, r_seq, q_seq, frame, mode, gap_open, gap_ext, table_id = data
+    gt = gtable
+    if table_id == 4:
+        gt = gtable.copy()
+        gt[56] = 22            # TGA -> W; the reference patches its module table in place (uberBlast.py:223-224)
+    phase = (frame - 1) % 3
+    gaps, q_cols, r_cols = [], [], []
+    qi = ri = 0
+    for n, op in cigar:
+        if op == 'M':
+            q_cols.append(q_seq[qi:qi + n]); r_cols.append(r_seq[ri:ri + n])
+            qi += n; ri += n
+        elif op == 'D':
+            gaps.append(n); ri += n
+        elif op == 'I':
+            gaps.append(n)
+            if mode > 1:
+                q_cols.append(q_seq[qi:qi + n]); r_cols.append(np.full(n, -1, dtype=int))
+            qi += n
+    n_gap, b_gap = len(gaps), int(np.sum(gaps)) if gaps else 0
+    m_gap = int(np.sum([g for g in gaps if g > 3])) if gaps else 0
+    qa, ra = np.concatenate(q_cols), np.concatenate(r_cols)
+    gap_cost = n_gap * (gap_open - gap_ext) + b_gap * gap_ext
+    if mode == 1:
+        n_match = int(np.sum(qa == ra))
+        n_mis = qa.size - n_match
+        return float(n_match) / (n_match + n_mis + b_gap - m_gap), n_match * 3 - n_mis - gap_cost
+    qa, ra = qa[phase:], ra[phase:]
+    if qa.size % 3:
+        cut = qa.size % 3
+        qa, ra = qa[:-cut], ra[:-cut]
+    qa, ra = qa.reshape(-1, 3), ra.reshape(-1, 3)
+    if mode == 3:
+        n_match = np.sum(np.sum(qa == ra, 0) * (9. / 7., 9. / 7., 3. / 7.))
+        n_mis = np.sum(ra >= 0) - n_match
+        return float(n_match) / (n_match + n_mis + b_gap - m_gap), n_match * 3 - n_mis - gap_cost
+    whole = ~np.any(ra < 0, 1)
+    qa, ra = qa[whole], ra[whole]
+    q_aa, r_aa = gt[np.sum(qa * (25, 5, 1), 1)], gt[np.sum(ra * (25, 5, 1), 1)]
+    n_match = np.sum(q_aa == r_aa) * 3.
+    return n_match / (q_aa.size * 3. + b_gap - m_gap), np.sum(blosum62[(q_aa << 5) + r_aa]) - gap_cost
+
+
+def _encode_cigars(cigars):
+    """list of [[n, op], ...] -> (uint32 arena len<<2|op, offsets, counts)"""
+    counts = np.array([len(c) for c in cigars], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    arena = np.empty(int(offs[-1]), dtype=np.uint32)
+    k = 0
+    for c in cigars:
+        for n, op in c:
+            arena[k] = (int(n) << 2) | _OP_CODE[op]
+            k += 1
+    return arena, offs[:-1], counts
+
+
+class RunBlast(object):
+    def __init__(self, device=None):
+        self.qrySeq = self.refSeq = None
+        self.device = device
+        self._nt_loaded = None
+
+    # ---------------------------------------------------------------------------------------------- driver
+    def run(self, ref, qry, methods, min_id, min_cov, min_ratio, table_id=11, n_thread=8, useProcess=False, re_score=0,
+            filter=[False, 0.9, 0.], linear_merge=[False, 300., 1.2], return_overlap=[True, 300, 0.6], fix_end=[6., 6.]):
+        tools = dict(blastn=self.runBlast, diamond=self.runDiamond, diamondself=self.runDiamondSELF, gpu=self.runDiamond)
+        self.min_id, self.min_cov, self.min_ratio = min_id, min_cov, min_ratio
+        self.table_id, self.n_thread = table_id, n_thread
+        self.pool = useProcess            # accepted for signature compatibility; the GPU path does not fan out
+        blastab = []
+        try:
+            for method in methods:
+                if method.lower() in tools:
+                    blastab.append(tools[method.lower()](ref, qry))
+            blastab = [b for b in blastab if b.shape[0] > 0]
+        except Exception:
+            # same convention as the reference (uberBlast.py:347-349): report, keep what the other tools produced
+            import traceback
+            traceback.print_exc()
+            blastab = [b for b in blastab if hasattr(b, 'shape') and b.shape[0] > 0]
+        if blastab:
+            blastab = np.vstack(blastab)
+            blastab = np.hstack([blastab, np.arange(blastab.shape[0], dtype=int)[:, np.newaxis]])
+        else:
+            if return_overlap[0]:
+                return np.empty([0, 16], dtype=object), np.empty([0, 3], dtype=int)
+            return np.empty([0, 16], dtype=object)
+        if re_score:
+            blastab = self.reScore(ref, qry, blastab, re_score, self.min_id, self.table_id)
+        if filter[0]:
+            blastab = self.ovlFilter(blastab, filter)
+        if linear_merge[0]:
+            blastab = self.linearMerge(blastab, linear_merge)
+        self.fixEnd(blastab, *fix_end)
+        if return_overlap[0]:
+            overlap = self.returnOverlap(blastab, return_overlap)
+            return pd.DataFrame(blastab).sort_values([0, 1, 11]).values, overlap
+        return pd.DataFrame(blastab).sort_values([0, 1, 11]).values
+
+    # ---------------------------------------------------------------------------------------------- inputs
+    def _load(self, ref, qry):
+        if not self.qrySeq:
+            self.qrySeq, self.qryQual = readFastq(qry)
+        if not self.refSeq:
+            self.refSeq, self.refQual = readFastq(ref)
+
+    def _ensure_nt(self, ctx, frames):
+        """sorted(name) order is the order in which the reference writes its FASTA files (uberBlast.py:527, 537),
+        so sequence / target indices follow it and the 5-way split membership is reproduced"""
+        key = (id(ctx), frames, self.table_id)
+        if self._nt_loaded == key:
+            return
+        self.q_names = sorted(self.qrySeq)
+        self.r_names = sorted(self.refSeq)
+        self.q_index = {n: i for i, n in enumerate(self.q_names)}
+        self.r_index = {n: i for i, n in enumerate(self.r_names)}
+        ctx.set_query_nt([self._text(self.qrySeq[n]) for n in self.q_names], self.table_id)
+        ctx.set_ref_nt([self._text(self.refSeq[n]) for n in self.r_names], frames, self.table_id)
+        self._nt_loaded = key
+
+    @staticmethod
+    def _text(s):
+        return s if isinstance(s, (str, bytes)) else ''.join('ACNGT'[int(x)] for x in s)
+
+    # ---------------------------------------------------------------------------------------------- tools
+    def runDiamondSELF(self, ref, qry):
+        return self.runDiamond(ref, qry, nhits=200, frames='F')
+
+    def runDiamond(self, ref, qry, nhits=10, frames='7'):
+        """translated search on the GPU: K1 translate/pack, K2-K4 seeds, K5/K6 banded Smith-Waterman + traceback,
+        K8 filters/top-k; thresholds as on the reference's diamond command line (uberBlast.py:550)"""
+        logger('Run diamond starts')
+        self._load(ref, qry)
+        ctx = get_context(self.device)
+        self._ensure_nt(ctx, 6 if frames == '7' else 3)
+        params = N.default_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100., top_k=nhits, n_splits=5,
+                                  dbsize=5000000., max_evalue=1.)
+        hits, cigar, stats = ctx.search(params)
+        q_len = [len(self.qrySeq[n]) for n in self.q_names]
+        r_len = [len(self.refSeq[n]) for n in self.r_names]
+        blastab = hits_to_blastab(hits, cigar, ctx.query_meta(), ctx.target_meta(), self.q_names, self.r_names, q_len, r_len,
+                                  self.min_id, self.min_cov, self.min_ratio)
+        self.last_stats = stats
+        logger('Run diamond finishes. Got {0} alignments'.format(blastab.shape[0]))
+        return blastab
+
+    def runBlast(self, ref, qry):
+        raise NotImplementedError('the nucleotide (blastn-equivalent) search is not built yet (SURVEY.md 8f rank 3); '
+                                  'use --diamond / --gpu')
+
+    # ---------------------------------------------------------------------------------------------- post-processing
+    def reScore(self, ref, qry, blastab, mode, min_id, table_id=11, perBatch=10000):
+        """recompute identity / score of every hit from its CIGAR over the nucleotide sequences (uberBlast.py:397-415).
+        Mode 1: integer counts on the GPU (K7), float arithmetic and np.round in float64 here."""
+        self._load(ref, qry)
+        if blastab.shape[0] == 0:
+            return blastab
+        if mode == 1:
+            ctx = get_context(self.device)
+            if self._nt_loaded is None:
+                self._ensure_nt(ctx, 6)
+            arena, offs, counts = _encode_cigars(blastab.T[14])
+            h = np.zeros(blastab.shape[0], dtype=N.NT_HIT_DTYPE)
+            h['q'] = [self.q_index[str(x)] for x in blastab.T[0]]
+            h['r'] = [self.r_index[str(x)] for x in blastab.T[1]]
+            h['qs'], h['qe'], h['rs'], h['re'] = blastab.T[6].astype(np.int64), blastab.T[7].astype(np.int64), blastab.T[8].astype(np.int64), blastab.T[9].astype(np.int64)
+            h['cigar_runs'], h['cigar_off'] = counts, offs
+            c = ctx.rescore_nt(h, arena).astype(np.int64)
+            n_match, n_mis, n_gap, b_gap, m_gap = c.T
+            iden = n_match.astype(np.float64) / (n_match + n_mis + b_gap - m_gap)
+            score = (n_match * 3 - n_mis - n_gap * (6 - 1) - b_gap * 1).astype(np.float64)
+            scores = np.vstack([iden, score])
+        else:
+            q_enc = {k: nucEncoder[np.array(list(v)).view(asc2int)] for k, v in self.qrySeq.items()}
+            r_enc = {k: nucEncoder[np.array(list(v)).view(asc2int)] for k, v in self.refSeq.items()}
+            vals = []
+            for t in blastab:
+                r = r_enc[str(t[1])]
+                r_sl = r[t[8] - 1:t[9]] if t[8] < t[9] else 4 - r[t[9] - 1:t[8]][::-1]
+                vals.append(cigar2score([t[14], r_sl, q_enc[str(t[0])][t[6] - 1:t[7]], t[6], mode, 6, 1, table_id]))
+            scores = np.array(vals).T
+        blastab.T[2], blastab.T[11] = np.round(scores, 3)
+        return blastab[blastab.T[2] >= min_id]
+
+    def ovlFilter(self, blastab, params):
+        return mapfilters.ovl_filter(blastab, params[1], params[2])
+
+    def linearMerge(self, blastab, params):
+        return mapfilters.linear_merge(blastab, params[1], params[2])
+
+    def returnOverlap(self, blastab, param):
+        return mapfilters.overlaps(blastab, param[1], param[2])
+
+    def fixEnd(self, blastab, se, ee):
+        """extend alignments over short unaligned ends (<= se at the query head, <= ee at its tail) and turn the CIGAR
+        into its string form; identity and score stay as they are (uberBlast.py:462-480)"""
+        for p in blastab:
+            head, tail = p[6] - 1, p[12] - p[7]
+            cigar = p[14]
+            fwd = p[9] > p[8]
+            if 0 < head <= se:
+                d = min(head, p[8] - 1) if fwd else min(head, p[13] - p[8])
+                p[6] -= d
+                p[8] += -d if fwd else d
+                cigar[0][0] += d
+            if 0 < tail <= ee:
+                d = min(tail, p[13] - p[9]) if fwd else min(tail, p[9] - 1)
+                p[7] += d
+                p[9] += d if fwd else -d
+                cigar[-1][0] += d
+            p[14] = ''.join('{0}{1}'.format(n, t) for n, t in cigar)
+
+
+def uberBlast(args, extPool=None):
+    import argparse
+    parser = argparse.ArgumentParser(description='Similarity search on MI355X with PEPPAN uberBlast semantics.')
+    parser.add_argument('-r', '--reference', help='[INPUT; REQUIRED] filename for the reference.', required=True)
+    parser.add_argument('-q', '--query', help='[INPUT; REQUIRED] filename for the query.', required=True)
+    parser.add_argument('-o', '--output', help='[OUTPUT; Default: None] save result to a file or to screen (stdout).', default=None)
+    parser.add_argument('--blastn', help='nucleotide search', action='store_true', default=False)
+    parser.add_argument('--diamond', help='translated search (GPU)', action='store_true', default=False)
+    parser.add_argument('--diamondSELF', help='translated search, forward frames only, 200 hits (GPU)', action='store_true', default=False)
+    parser.add_argument('--gpu', help='alias of --diamond', action='store_true', default=False)
+    parser.add_argument('--device', help='HIP device index [default: $LOCAL_RANK or 0]', type=int, default=None)
+    parser.add_argument('--gtable', help='[DEFAULT: 11] genetic table to use. 11 for bacterial genomes and 4 for Mycoplasma', default=11, type=int)
+    parser.add_argument('--min_id', help='[DEFAULT: 0.3] Minimum identity before reScore for an alignment to be kept', type=float, default=0.3)
+    parser.add_argument('--min_cov', help='[DEFAULT: 40] Minimum length for an alignment to be kept', type=float, default=40.)
+    parser.add_argument('--min_ratio', help='[DEFAULT: 0.05] Minimum length for an alignment to be kept, proportional to the length of the query', type=float, default=0.05)
+    parser.add_argument('-s', '--re_score', help='[DEFAULT: 0] 0: No rescore; 1: nucleotides; 2: amino acid; 3: codons', type=int, default=0)
+    parser.add_argument('-f', '--filter', help='[DEFAULT: False] Remove secondary alignments if they overlap with any other regions', default=False, action='store_true')
+    parser.add_argument('--filter_cov', help='[DEFAULT: 0.9] ', default=0.9, type=float)
+    parser.add_argument('--filter_score', help='[DEFAULT: 0] ', default=0., type=float)
+    parser.add_argument('-m', '--linear_merge', help='[DEFAULT: False] Merge consecutive alignments', default=False, action='store_true')
+    parser.add_argument('--merge_gap', help='[DEFAULT: 600] ', default=600., type=float)
+    parser.add_argument('--merge_diff', help='[DEFAULT: 1.5] ', default=1.5, type=float)
+    parser.add_argument('-O', '--return_overlap', help='[DEFAULT: False] Report overlapped alignments', default=False, action='store_true')
+    parser.add_argument('--overlap_length', help='[DEFAULT: 300] Minimum overlap to report', default=300, type=float)
+    parser.add_argument('--overlap_proportion', help='[DEFAULT: 0.6] Minimum overlap proportion to report', default=0.6, type=float)
+    parser.add_argument('-e', '--fix_end', help='[FORMAT: L,R; DEFAULT: 0,0] Extend alignment to the edges if the un-aligned regions are <= [L,R] basepairs.', default='0,0')
+    parser.add_argument('-t', '--n_thread', help='[DEFAULT: 1] accepted for compatibility', type=int, default=1)
+    parser.add_argument('-p', '--process', help='accepted for compatibility', action='store_true', default=False)
+    args = parser.parse_args(args)
+    if extPool is not None:
+        args.process = extPool
+    methods = [m for m in ('blastn', 'diamond', 'diamondSELF', 'gpu') if getattr(args, m)]
+    if 'gpu' in methods and 'diamond' in methods:
+        methods.remove('gpu')
+    fix_end = args.fix_end.split(',')
+    fix_end[-2:] = list(map(float, fix_end[-2:]))
+    data = RunBlast(args.device).run(args.reference, args.query, methods, args.min_id, args.min_cov, args.min_ratio, args.gtable,
+                                     args.n_thread, args.process, args.re_score, [args.filter, args.filter_cov, args.filter_score],
+                                     [args.linear_merge, args.merge_gap, args.merge_diff],
+                                     [args.return_overlap, args.overlap_length, args.overlap_proportion], fix_end)
+    if args.output:
+        fout = sys.stdout if args.output.upper() == 'STDOUT' else open(args.output, 'w')
+        for t in data:
+            fout.write('\t'.join([str(tt) for tt in t]) + '\n')
+        fout.close()
+    return data
+
+
+if __name__ == '__main__':
+    uberBlast(sys.argv[1:])
