@@ -1,0 +1,111 @@
+"""clust.py / pipeline.py (callers of the search) against golden vectors from the reference's Python."""
+import contextlib
+import copy
+import io
+import os
+import numpy as np
+import pytest
+from conftest import load_golden
+from peppan_amd import clust as CL, pipeline as PL
+
+
+def _scripted(script, seen):
+    it = iter(script)
+
+    def fn(fasta, identity, coverage, n_thread):
+        seen.append(open(fasta).read())
+        return next(it)
+    return fn
+
+
+def test_getclust_scripted_rounds(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    g = load_golden('g09_clust.json')
+    for k, case in enumerate(c for c in g['cases'] if 'script' in c):
+        gf = tmp_path / ('genes%d.fa' % k)
+        gf.write_text(case['genes_fasta'])
+        seen = []
+        ex, tb = CL.getClust(str(tmp_path / ('o%d' % k)), str(gf), dict(identity=0.9, coverage=0.9, n_thread=2, translate=False,
+                                                                           cluster_fn=_scripted(case['script'], seen)))
+        assert open(ex).read() == case['exemplar']
+        assert open(tb).read() == case['tab']
+        assert len(seen) == case['n_rounds'] and seen == case['round_inputs']
+
+
+def test_getclust_translate(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    g = load_golden('g09_clust.json')
+    case = [c for c in g['cases'] if c.get('translate')][0]
+    gf = tmp_path / 'genes.fa'
+    gf.write_text(case['genes_fasta'])
+    names = [l[1:].split()[0] for l in case['genes_fasta'].split('\n') if l.startswith('>')]
+    script = [[(names[0] if n in names[:3] else n, n) for n in names], [(n, n) for n in names[3:] + names[:1]]]
+    seen = []
+    ex, tb = CL.getClust(str(tmp_path / 'o'), str(gf), dict(identity=0.9, coverage=0.9, n_thread=2, translate=True, cluster_fn=_scripted(script, seen)))
+    assert open(ex).read() == case['exemplar'] and open(tb).read() == case['tab']
+    assert seen[0] == case['round_inputs'][0]
+
+
+def test_iterclust_header_line_quirk(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    g = load_golden('g09_clust.json')
+    case = [c for c in g['cases'] if c.get('iterClust')][0]
+    gf = tmp_path / 'genes.fa'
+    gf.write_text(case['genes_fasta'])
+    names = [l[1:].split()[0] for l in case['genes_fasta'].split('\n') if l.startswith('>')]
+    plan = {int(k): [tuple(x) for x in v] for k, v in case['plan'].items()}
+    tables, cur = [], list(names)
+    for step in range(11):
+        merges = plan.get(step, [])
+        tables.append([([r for r, m in merges if m == n] or [n])[0], n] for n in cur)
+        tables[-1] = [(([r for r, m in merges if m == n] or [n])[0], n) for n in cur]
+        cur = [n for n in cur if n not in {m for r, m in merges}]
+        tables.append([(n, n) for n in cur])
+    seen = []
+    with contextlib.redirect_stderr(io.StringIO()):
+        out = PL.iterClust(str(tmp_path / 'it'), str(gf), [[5, 900, 10000]], dict(identity=0.9, coverage=0.8, n_thread=2, translate=False,
+                                                                                   cluster_fn=_scripted(tables, seen)))
+    assert open(out).read() == case['exemplar']
+    assert np.load(str(tmp_path / 'it.clust.npy')).tolist() == case['clust_npy']
+    assert open(str(tmp_path / 'it.clust.tab')).read() == case['final_tab']
+
+
+def test_get_similar_pairs(tmp_path, monkeypatch):
+    g = load_golden('g10_pairs.json')
+    for params_in, exp in ((g['params'], g), (g['variant_sife']['params'], g['variant_sife'])):
+        cl = tmp_path / 'p.clust.exemplar'
+        cl.write_text(g['exemplar_in'])
+        np.save(str(tmp_path / 'p.clust.npy'), np.array(g['clust_npy_in'], dtype=int))
+        tab = np.empty([len(g['table']), 16], dtype=object)
+        for i, r in enumerate(g['table']):
+            for j, v in enumerate(r):
+                tab[i, j] = v
+        calls = []
+        monkeypatch.setattr(PL, 'uberBlast', lambda argv, pool=None: (calls.append(argv), copy.deepcopy(tab))[1])
+        params = dict(params_in, clust=str(cl))
+        prio = {int(k): v for k, v in g['priorities'].items()}
+        res = PL.get_similar_pairs(str(cl), prio, params)
+        assert res.tolist() == exp['pairs']
+        assert cl.read_text() == exp['exemplar_out']
+        assert np.load(str(tmp_path / 'p.clust.npy'), allow_pickle=True).tolist() == exp['clust_npy_out']
+        if exp is g:
+            ref_argv = [a for a in g['uber_argv']]
+            ref_argv[1] = ref_argv[3] = str(cl)
+            assert calls[0] == ref_argv
+
+
+def test_get_gene_group(tmp_path):
+    g = load_golden('g11_groups.json')
+    for k, case in enumerate(g['cases']):
+        np.save(str(tmp_path / ('g%d.clust.npy' % k)), np.array(case['clu'], dtype=int))
+        np.save(str(tmp_path / ('g%d.self_bsn.npy' % k)), np.array(case['bsn'], dtype=int))
+        grp = PL.get_gene_group(str(tmp_path / ('g%d.clust.exemplar' % k)), str(tmp_path / ('g%d.self_bsn.npy' % k)))
+        assert [[int(a), [int(x) for x in b]] for a, b in grp.items()] == case['groups']
+
+
+def test_writegenes(tmp_path):
+    g = load_golden('g12_writegenes.json')
+    genes = {int(k): ['f', '', 0, 0, '+', v[0], v[1]] for k, v in g['genes'].items()}
+    prio = {int(k): v for k, v in g['priority'].items()}
+    fn, groups = PL.writeGenes(str(tmp_path / 'w.genes'), genes, prio)
+    assert open(fn).read() == g['fasta'] and groups == g['groups']
