@@ -1,0 +1,59 @@
+"""Test helper: an object with the interface of peppan_amd._native.Context whose every result comes from the CPU
+oracle (oracle/).  Lets the GPU tests run the product's host code twice - once over the HIP library, once over
+the oracle - and compare whole tables."""
+import numpy as np
+from oracle import oracle as O
+from peppan_amd import _native as N
+
+
+class OracleContext(object):
+    def set_query_nt(self, seqs, gtable=11):
+        self.q_nt = [s.decode() if isinstance(s, bytes) else s for s in seqs]
+        self.q_table = gtable
+
+    def set_ref_nt(self, seqs, frames=6, gtable=11):
+        self.r_nt = [s.decode() if isinstance(s, bytes) else s for s in seqs]
+        self.r_frames, self.r_table = frames, gtable
+
+    def translate(self, force=False):
+        qm, self.q_aa = [], []
+        for i, s in enumerate(self.q_nt):
+            f, p = O.query_frame(s.upper(), self.q_table)
+            qm.append((i, f, len(p), len(s)))
+            self.q_aa.append(O.aa_codes(p))
+        tm, self.t_aa = [], []
+        for i, s in enumerate(self.r_nt):
+            fl = range(1, 7) if self.r_frames == 6 else range(1, 4)
+            for f, aa in zip(fl, O.translate_frames(s.upper(), fl, self.r_table)):
+                for off, c in O.ref_chunks(aa):
+                    tm.append((i, f, off, len(c)))
+                    self.t_aa.append(O.aa_codes(c))
+        self._qm = np.array(qm, dtype=N.QUERY_META_DTYPE).reshape(-1)
+        self._tm = np.array(tm, dtype=N.TARGET_META_DTYPE).reshape(-1)
+
+    def query_meta(self):
+        return self._qm
+
+    def target_meta(self):
+        return self._tm
+
+    def search(self, params=None):
+        self.translate()
+        p = O.default_params(params.min_id_pct, params.min_qcov_pct, params.top_k, params.n_splits, ungapped_min=params.ungapped_min)
+        ms = np.array([O.min_score(len(s), params.dbsize, params.max_evalue) for s in self.q_aa], dtype=np.int32)
+        h, c, st = O.search(self.q_aa, self.t_aa, p, min_scores=ms)
+        out = np.zeros(len(h), dtype=N.HIT_DTYPE)
+        for f in out.dtype.names:
+            out[f] = h[f]
+        return out, c, st
+
+    def rescore_nt(self, h, arena):
+        out = np.zeros((len(h), 5), dtype=np.int64)
+        for k in range(len(h)):
+            q, r = O.nt_encode_rescore(self.q_nt[h['q'][k]].upper()), O.nt_encode_rescore(self.r_nt[h['r'][k]].upper())
+            out[k] = O.rescore_counts(q, r, int(h['qs'][k]), int(h['rs'][k]), int(h['re'][k]),
+                                      arena[int(h['cigar_off'][k]):int(h['cigar_off'][k]) + int(h['cigar_runs'][k])])
+        return out
+
+    def components(self, n, a, b):
+        return O.components(n, a, b)

@@ -1,0 +1,80 @@
+"""N>1 path on CPU: two gloo ranks shard the queries and all-gather their hit tables (same code path that runs
+over RCCL on the GPU box)."""
+import os
+import socket
+import sys
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_hits(q0, q1, seed):
+    from peppan_amd import _native as N
+    rng = np.random.default_rng(seed)
+    rows, cig = [], []
+    for q in range(q0, q1):
+        for t in sorted(rng.choice(50, size=int(rng.integers(0, 4)), replace=False).tolist()):
+            runs = [(int(rng.integers(5, 90)) << 2) | 0, (int(rng.integers(1, 4)) << 2) | int(rng.integers(1, 3)), (int(rng.integers(5, 90)) << 2) | 0][:int(rng.integers(1, 4)) | 1]
+            rows.append((q - q0, t, 1, 10, 1, 10, int(rng.integers(60, 900)), 0, 10, 10, len(runs), 0, len(cig), 7))
+            cig += runs
+    return np.array(rows, dtype=N.HIT_DTYPE), np.array(cig, dtype=np.uint32)
+
+
+def _worker(rank, world, port, lengths, out_q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from peppan_amd import dist as pdist
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    b = pdist.shard_bounds(lengths, world)
+    hits, cig = _fake_hits(b[rank], b[rank + 1], seed=100 + rank)
+    allh, allc = pdist.allgather_hits(hits, cig, b[rank])
+    out_q.put((rank, b, allh.tobytes(), allc.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    from peppan_amd import dist as pdist
+    assert pdist.shard_bounds([], 4) == [0, 0, 0, 0, 0]
+    b = pdist.shard_bounds([100] * 10, 4)
+    assert b[0] == 0 and b[-1] == 10 and all(x <= y for x, y in zip(b, b[1:]))
+    b = pdist.shard_bounds([1000, 1, 1, 1, 1, 1, 1, 1], 2)
+    assert b == [0, 1, 8]
+    assert pdist.shard_bounds([5, 5], 8)[-1] == 2
+
+
+def test_allgather_hits_two_ranks_gloo():
+    from peppan_amd import _native as N, dist as pdist
+    world, port = 2, _free_port()
+    lengths = [300 + 7 * i for i in range(41)]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    b = res[0][1]
+    exp_h, exp_c, coff = [], [], 0
+    for r in range(world):
+        h, c = _fake_hits(b[r], b[r + 1], seed=100 + r)
+        h = h.copy(); h['q'] += b[r]; h['cigar_off'] += coff
+        exp_h.append(h); exp_c.append(c); coff += len(c)
+    exp_h, exp_c = np.concatenate(exp_h), np.concatenate(exp_c)
+    for rank, _, hb, cb in res:
+        got_h = np.frombuffer(hb, dtype=N.HIT_DTYPE)
+        got_c = np.frombuffer(cb, dtype=np.uint32)
+        assert np.array_equal(got_h, exp_h) and np.array_equal(got_c, exp_c)
+    assert len(exp_h) > 20

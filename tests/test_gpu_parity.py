@@ -174,3 +174,58 @@ def test_k10_components(ctx):
         for i, l in enumerate(lab):
             got.setdefault(int(l), set()).add(i)
         assert {frozenset(s) for s in got.values() if len(s) > 1} == {frozenset(m) for _, m in case['groups']}
+
+
+def _write_fasta(path, names, seqs):
+    with open(path, 'w') as f:
+        for n, s in zip(names, seqs):
+            f.write('>%s\n%s\n' % (n, s.decode()))
+
+
+def test_uberblast_dropin_self_search(tmp_path, monkeypatch):
+    """the call PEPPAN makes for the exemplar all-vs-all (PEPPAN.py:229-230, minus --blastn): whole 16-column
+    table from the HIP path == the same host code over the oracle, and the union-find partitions agree"""
+    import io, contextlib
+    from peppan_amd import uberBlast as UB, synth
+    from oracle_context import OracleContext
+    monkeypatch.chdir(tmp_path)
+    names, seqs = synth.make_genes(240, 0, seed=77)           # log-normal lengths
+    names = [str(1000 + 7 * i) for i in range(len(seqs))]     # string order != numeric order
+    fa = str(tmp_path / 'ex.fa')
+    _write_fasta(fa, names, seqs)
+    argv = '-r {0} -q {0} --diamond -s 1 --min_id 0.45 --min_cov 50 -t 2 --min_ratio 0.25 -e 3,3 -p --gtable 11'.format(fa).split()
+    with contextlib.redirect_stderr(io.StringIO()):
+        gpu = UB.uberBlast(argv)
+        octx = OracleContext()
+        monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
+        ora = UB.uberBlast(argv)
+    assert gpu.shape == ora.shape and gpu.shape[0] > 300 and gpu.shape[1] == 16
+    for a, b in zip(gpu.tolist(), ora.tolist()):
+        assert a == b
+    # floats within 1e-4 is the stated tolerance; they are in fact identical (integer counts + float64 on the host)
+    assert all(isinstance(r[14], str) for r in gpu.tolist())
+
+
+def test_uberblast_dropin_genome_mapping(tmp_path, monkeypatch):
+    """genes against a contig carrying them on both strands: reverse frames, chunk offsets, -f -m -O post-filters"""
+    import io, contextlib
+    from peppan_amd import uberBlast as UB, synth, configure
+    from oracle_context import OracleContext
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(5)
+    names, seqs = synth.make_genes(40, 0, seed=9, family=2)
+    spacer = lambda: bytes(rng.choice(list(b'ACGT'), int(rng.integers(50, 300))).tolist())
+    contig = spacer()
+    for k, s in enumerate(seqs[::2]):
+        contig += (s if k % 2 else configure.rc(s.decode()).encode()) + spacer()
+    _write_fasta(str(tmp_path / 'genes.fa'), names, seqs)
+    _write_fasta(str(tmp_path / 'genome.fa'), ['7:contig1'], [contig])
+    argv = ('-r {0} -q {1} -f -m -O --diamond --min_id 0.4 --min_cov 50 --min_ratio 0.25 --merge_gap 600 --merge_diff 1.5 -t 1 -s 1 -e 0,3 --gtable 11'
+            .format(tmp_path / 'genome.fa', tmp_path / 'genes.fa')).split()
+    with contextlib.redirect_stderr(io.StringIO()):
+        gpu_tab, gpu_ovl = UB.uberBlast(argv)
+        octx = OracleContext()
+        monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
+        ora_tab, ora_ovl = UB.uberBlast(argv)
+    assert gpu_tab.shape[0] >= 20 and gpu_tab.tolist() == ora_tab.tolist() and gpu_ovl.tolist() == ora_ovl.tolist()
+    assert any(r[8] > r[9] for r in gpu_tab.tolist()) and any(r[8] < r[9] for r in gpu_tab.tolist())
