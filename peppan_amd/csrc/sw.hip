@@ -21,10 +21,8 @@
 
 namespace {
 
-constexpr int NEGV = -(1 << 28);
-constexpr int RES_PAD = 80;              // sentinel bytes either side of a staged sequence
 constexpr int LDS_TABLE_BYTES = 32768;   // 256 dwords x 32 banks
-constexpr int WAVES_PER_BLOCK = 4;
+constexpr int WAVES_PER_BLOCK = 8;
 
 struct SwArgs {
     const uint64_t *cands;
@@ -42,9 +40,17 @@ struct SwArgs {
 
 __device__ __forceinline__ int shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // lane l <- lane l-1
 __device__ __forceinline__ int shl1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }   // lane l <- lane l+1
+// band-edge lanes read 0: for H that is the local-alignment boundary; for E/F it stands in for -inf, which is
+// equivalent because a gap state <= 0 can never be selected over H >= 0 and only decays further
+__device__ __forceinline__ int shr1z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
+__device__ __forceinline__ int shl1z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+
+// LDS images of the residues, ready to be added into a table address: q -> qc * 1024, t -> (tc >> 2) * 128 + (tc & 3)
+__device__ __forceinline__ uint16_t q_addr_part(int qc) { return (uint16_t)(qc << 10); }
+__device__ __forceinline__ uint16_t t_addr_part(int tc) { return (uint16_t)(((tc >> 2) << 7) | (tc & 3)); }
 
 template <bool LDS_RES, bool TRACE>
-__device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32_t *lds_tab, uint8_t *lds_res, int lane)
+__device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsigned char *lds_tab, uint16_t *lds_res, int lane)
 {
     const uint64_t key = a.cands[c];
     const uint32_t q = (uint32_t)(key >> 43), t = (uint32_t)((key >> 18) & ((1u << 25) - 1));
@@ -60,44 +66,43 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32
     const int nblk = (int)a.nblk[c];
     uint32_t *dir = TRACE ? a.dirs + a.dir_off[c] * 64 : nullptr;
 
-    // index of the residues used by step pair m:  A: (i, j) = (a0 + m - lane, a0 + dlo + m + lane),  B: (i, j + 1)
+    // residues used by step pair m:  A: (i, j) = (a0 + m - lane, a0 + dlo + m + lane),  B: (i, j + 1)
     int i = a0 - lane, j = a0 + dlo + lane;
-    uint8_t *lq = nullptr, *lt = nullptr;
+    uint16_t *lq = nullptr, *lt = nullptr;
     int qlo = 0, tlo = 0;
     if (LDS_RES) {
         // stage the residue windows the sweep can touch: i in [a0-63, a0+4*nblk], j in [a0+dlo, a0+dlo+4*nblk+64]
         qlo = a0 - 64; tlo = a0 + dlo - 1;
         const int qn = 4 * nblk + 72, tn = 4 * nblk + 72;
-        lq = lds_res; lt = lds_res + ((qn + 15) & ~15);
-        for (int x = lane; x < qn; x += 64) { const int g = qlo + x; lq[x] = ((unsigned)g < (unsigned)Lq) ? qg[g] : (uint8_t)PEP_PAD_CODE; }
-        for (int x = lane; x < tn; x += 64) { const int g = tlo + x; lt[x] = ((unsigned)g < (unsigned)Lt) ? tg[g] : (uint8_t)PEP_PAD_CODE; }
+        lq = lds_res; lt = lds_res + ((qn + 7) & ~7);
+        for (int x = lane; x < qn; x += 64) { const int g = qlo + x; lq[x] = q_addr_part(((unsigned)g < (unsigned)Lq) ? qg[g] : PEP_PAD_CODE); }
+        for (int x = lane; x < tn; x += 64) { const int g = tlo + x; lt[x] = t_addr_part(((unsigned)g < (unsigned)Lt) ? tg[g] : PEP_PAD_CODE); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    auto Qat = [&](int ii) -> int { return LDS_RES ? (int)lq[ii - qlo] : (((unsigned)ii < (unsigned)Lq) ? (int)qg[ii] : PEP_PAD_CODE); };
-    auto Tat = [&](int jj) -> int { return LDS_RES ? (int)lt[jj - tlo] : (((unsigned)jj < (unsigned)Lt) ? (int)tg[jj] : PEP_PAD_CODE); };
-    const int bank4 = (lane & 31) * 4;
-    auto Sub = [&](int qc, int tc) -> int {
-        const int w = qc * 8 + (tc >> 2);
-        const uint32_t v = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lds_tab) + w * 128 + bank4);
-        return (int)(int8_t)(v >> ((tc & 3) * 8));
-    };
+    // volatile: keeps hipcc from fusing neighbouring 2-byte reads into ds_read_b64 at 2-byte alignment, which the LDS
+    // replays at 64 cycles per instruction (SQ_LDS_UNALIGNED_STALL; cdna guide G17)
+    const volatile uint16_t *vq = lq, *vt = lt;
+    auto Qat = [&](int ii) -> int { return LDS_RES ? (int)vq[ii - qlo] : (int)q_addr_part(((unsigned)ii < (unsigned)Lq) ? (int)qg[ii] : PEP_PAD_CODE); };
+    auto Tat = [&](int jj) -> int { return LDS_RES ? (int)vt[jj - tlo] : (int)t_addr_part(((unsigned)jj < (unsigned)Lt) ? (int)tg[jj] : PEP_PAD_CODE); };
+    // conflict-free gather: byte (q*8 + t/4)*128 + bank*4 + (t&3) of the bank-replicated table, read as a signed byte
+    const signed char *tab = reinterpret_cast<const signed char *>(lds_tab) + (lane & 31) * 4;
 
-    int HA = 0, EA = NEGV, FA = NEGV, HB = 0, EB = NEGV, FB = NEGV;
+    int HA = 0, EA = 0, FA = 0, HB = 0, EB = 0, FB = 0;
     int best = 0, best_k = -1;
     const int oe = a.oe, ext = a.ext;
-    int tc = Tat(j), qc;
+    int tv = Tat(j), qv = 0;
     int k = 0;
     for (int b = 0; b < nblk; ++b) {
         uint32_t acc = 0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // ---- A step: cell (i, j) on diagonal dlo + 2*lane
-            qc = Qat(i);
+            qv = Qat(i);
             {
-                const int sub = Sub(qc, tc);
-                const int hl = shr1(0, HB), el = shr1(NEGV, EB);
+                const int sub = tab[qv + tv];
+                const int hl = shr1z(HB), el = shr1z(EB);
                 const int e_ext = el - ext, e_open = hl - oe;
                 const int f_ext = FB - ext, f_open = HB - oe;
                 const int E = max(e_ext, e_open), F = max(f_ext, f_open);
@@ -107,16 +112,16 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32
                     const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
                     const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
                     acc = (acc >> 4) | (nib << 28);
-                }
-                if (H > best) { best = H; best_k = k; }
+                    if (H > best) { best = H; best_k = k; }
+                } else best = max(best, H);
                 HA = H; EA = E; FA = F;
             }
             ++k; ++j;
             // ---- B step: cell (i, j) on diagonal dlo + 2*lane + 1   (j already advanced)
-            tc = Tat(j);
+            tv = Tat(j);
             {
-                const int sub = Sub(qc, tc);
-                const int hu = shl1(0, HA), fu = shl1(NEGV, FA);
+                const int sub = tab[qv + tv];
+                const int hu = shl1z(HA), fu = shl1z(FA);
                 const int e_ext = EA - ext, e_open = HA - oe;
                 const int f_ext = fu - ext, f_open = hu - oe;
                 const int E = max(e_ext, e_open), F = max(f_ext, f_open);
@@ -126,13 +131,20 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32
                     const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
                     const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
                     acc = (acc >> 4) | (nib << 28);
-                }
-                if (H > best) { best = H; best_k = k; }
+                    if (H > best) { best = H; best_k = k; }
+                } else best = max(best, H);
                 HB = H; EB = E; FB = F;
             }
             ++k; ++i;
         }
         if (TRACE) dir[(size_t)b * 64 + lane] = acc;
+    }
+    if (!TRACE) {
+        // score pass: only the maximum is needed (the end cell comes from the traceback pass of the selected pairs)
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
+        if (lane == 0) a.out[c] = make_int4(best, -1, -1, a0);
+        return;
     }
     // the lane's best cell: earliest step with the lane maximum == (min i, then min j) among its two diagonals
     int bi = 0x7fffffff, bj = 0x7fffffff;
@@ -151,7 +163,7 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const uint32
     if (lane == 0) a.out[c] = make_int4(best, best > 0 ? bi : -1, best > 0 ? bj : -1, a0);
 }
 
-// TRACE = false: score pass over every candidate (score + end cell only, no HBM writes beyond 16 B per candidate)
+// TRACE = false: score pass over every candidate (max score only, no HBM writes beyond 16 B per candidate)
 // TRACE = true : traceback pass over the pairs that survived best-per-(q,t) and the e-value cut
 template <bool TRACE>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(SwArgs a)
@@ -161,11 +173,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(SwArgs a)
     for (int x = threadIdx.x; x < LDS_TABLE_BYTES / 4; x += blockDim.x) lds_tab[x] = a.sub_image[x];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint8_t *lds_res = smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes;
+    uint16_t *lds_res = reinterpret_cast<uint16_t *>(smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes);
     for (uint64_t c = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; c < a.n; c += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
-        const int need = 2 * ((4 * (int)a.nblk[c] + 72 + 15) & ~15);
-        if (need <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, lds_tab, lds_res, lane);
-        else sw_one<false, TRACE>(a, c, lds_tab, lds_res, lane);
+        const int need = 2 * 2 * ((4 * (int)a.nblk[c] + 72 + 7) & ~7);
+        if (need <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, smem, lds_res, lane);
+        else sw_one<false, TRACE>(a, c, smem, lds_res, lane);
     }
 }
 
@@ -261,10 +273,13 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     a.dir_off = ctx->ws[11].as<const uint64_t>(); a.nblk = ctx->ws[10].as<const uint32_t>();
     a.dirs = trace ? ctx->ws[13].as<uint32_t>() : nullptr; a.out = ctx->ws[12].as<int4>();
     a.oe = P.gap_open + P.gap_ext; a.ext = P.gap_ext;
-    a.lds_res_bytes = P.use_lds ? 4096 : 0;
+    // per-wave staging window (u16 per residue, query + target), sized for the longest possible pair, capped at 8 KiB
+    const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 8 + 2;
+    const uint64_t want = 2 * 2 * ((4 * max_blk + 72 + 7) & ~7ull);
+    a.lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, (want + 255) & ~255ull) : 0;
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
     // enough blocks to fill the chip several times over; the grid-stride loop amortises the table load
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(n, WAVES_PER_BLOCK), 256ull * 12);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(n, WAVES_PER_BLOCK), 256ull * 8);
     hipEvent_t e0, e1;
     PEP_HIP(ctx, hipEventCreate(&e0));
     PEP_HIP(ctx, hipEventCreate(&e1));

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
     if (c >= n || !flag[c]) return;
     const uint32_t b = best_idx[c];
     SelInfo s;
-    s.cand = pos[c]; s.score = sw[b].x; s.iend = sw[b].y; s.jend = sw[b].z;
+    s.cand = pos[c]; s.score = sw[b].x; s.iend = s.jend = -1;      // the end cell comes from the traceback pass
     sel_keys[pos[c]] = cands[b];
     s.istart = s.jstart = 0; s.n_runs = s.aln_len = s.n_ident = 0; s.pass = s.keep = 0; s.pad = 0;
     sel[pos[c]] = s;
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void walk(uint64_t n_sel, SelInfo *__restrict_
     const uint32_t *dir = dirs + dir_off[info.cand] * 64;
     uint32_t *out = runs + run_off[s];
 
+    info.iend = sw[info.cand].y; info.jend = sw[info.cand].z;     // (the trace pass recomputes the same score)
     int i = info.iend, j = info.jend, state = 0;
     int istart = i, jstart = j;
     uint32_t n_runs = 0, aln_len = 0, cur_op = 3, cur_len = 0;
