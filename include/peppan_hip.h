@@ -22,6 +22,7 @@
  *   pep_hit fields          the SAM fields parseDiamond consumes (POS, CIGAR, |SEQ|, NM, ZR, ZS)   uberBlast.py:25-58
  *   pep_rescore_nt          cigar2score mode 1 inside RunBlast.reScore      uberBlast.py:226-249, 397-415
  *   pep_components          union-find of get_gene_group (partition only)   PEPPAN.py:1598-1607
+ *   pep_linclust            `mmseqs createdb / linclust / createtsv`        clust.py:62-66
  */
 #ifndef PEPPAN_HIP_H
 #define PEPPAN_HIP_H
@@ -149,6 +150,12 @@ int pep_rescore_nt(pep_ctx *ctx, uint64_t n, const pep_nt_hit *hits, const uint3
 
 /* K10: connected components; label[x] = smallest node id of x's component */
 int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *a, const uint32_t *b, uint32_t *label);
+
+/* K9: linear-time clustering.  codes: residue codes (< base are valid k-mer letters), concatenated, off[n+1].
+ * rep[i] = index of sequence i's representative (rep[i] == i for representatives).  stats (may be NULL):
+ * [0] selected k-mers, [1] verified (sequence, centre, diagonal) pairs, [2] accepted edges. */
+int pep_linclust(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n, int base, int k, int m,
+                 double min_id, double min_cov, uint32_t *rep, uint64_t *stats);
 
 #ifdef __cplusplus
 }

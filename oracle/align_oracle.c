@@ -496,3 +496,136 @@ void oracle_components(uint32_t n, uint64_t m, const uint32_t *a, const uint32_t
     }
     for (uint32_t i = 0; i < n; ++i) label[i] = uf_find(label, i);
 }
+
+/* ------------------------------------------------------------------ linear-time clustering (replaces `mmseqs linclust`)
+ * PARITY UNPINNED (MMseqs2 is absent, clust.py:62-66 only consumes its "representative, member" relation).
+ * Definition (published linclust idea, Steinegger & Soeding 2018, reduced to an exactly reproducible form):
+ *  1. every sequence selects the m k-mers with the smallest (hash, position) among its valid k-mers
+ *     (codes < base; hash = splitmix64 finaliser of the base-`base` k-mer value);
+ *  2. the centre of a k-mer is the longest sequence that selected it (ties: lowest index);
+ *  3. each (sequence s, selected k-mer) whose centre c != s defines one diagonal (position in c - position in s);
+ *     the UNGAPPED overlap of s and c on that diagonal is accepted when matches >= min_id * overlap and
+ *     overlap >= min_cov * len(c) and overlap >= min_cov * len(s)   (double arithmetic, no division);
+ *  4. greedy assignment in priority order (length desc, index asc): an unassigned sequence becomes a
+ *     representative and takes every still unassigned sequence it was accepted as the centre of.
+ * rep_out[s] = index of s's representative. */
+static uint64_t lc_mix(uint64_t x)
+{
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+
+typedef struct { uint64_t h, key; uint32_t pos; } lc_sel;
+
+static int lc_cmp_sel(const void *a, const void *b)
+{
+    const lc_sel *x = a, *y = b;
+    if (x->h != y->h) return x->h < y->h ? -1 : 1;
+    return x->pos < y->pos ? -1 : (x->pos > y->pos);
+}
+
+typedef struct { uint64_t key; uint32_t len, idx; } lc_ctr;
+
+static int lc_cmp_ctr(const void *a, const void *b)
+{
+    const lc_ctr *x = a, *y = b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    if (x->len != y->len) return x->len > y->len ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+typedef struct { uint32_t len, idx; } lc_pri;
+static int lc_cmp_pri(const void *a, const void *b)
+{
+    const lc_pri *x = a, *y = b;
+    if (x->len != y->len) return x->len > y->len ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+int oracle_linclust(const uint8_t *res, const uint64_t *off, uint32_t n, int base, int k, int m, double min_id, double min_cov,
+                    uint32_t *rep_out, uint64_t *stats /* [0] selected k-mers [1] verified pairs [2] accepted edges */)
+{
+    lc_sel *sel = calloc((size_t)n * m + 1, sizeof(lc_sel));
+    uint32_t *cnt = calloc(n + 1, sizeof(uint32_t));
+    uint32_t maxlen = 0;
+    for (uint32_t s = 0; s < n; ++s) { uint32_t L = (uint32_t)(off[s + 1] - off[s]); if (L > maxlen) maxlen = L; }
+    lc_sel *tmp = malloc(((size_t)maxlen + 1) * sizeof(lc_sel));
+    uint64_t n_sel = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint8_t *q = res + off[s];
+        uint32_t L = (uint32_t)(off[s + 1] - off[s]), c = 0;
+        for (uint32_t p = 0; p + k <= L; ++p) {
+            uint64_t key = 0, mul = 1; int ok = 1;
+            for (int i = 0; i < k; ++i) { if (q[p + i] >= base) { ok = 0; break; } key += mul * q[p + i]; mul *= (uint64_t)base; }
+            if (!ok) continue;
+            tmp[c].h = lc_mix(key); tmp[c].key = key; tmp[c].pos = p; ++c;
+        }
+        qsort(tmp, c, sizeof(lc_sel), lc_cmp_sel);
+        cnt[s] = c < (uint32_t)m ? c : (uint32_t)m;
+        memcpy(sel + (size_t)s * m, tmp, cnt[s] * sizeof(lc_sel));
+        n_sel += cnt[s];
+    }
+    free(tmp);
+    /* centres */
+    lc_ctr *ctr = malloc((n_sel + 1) * sizeof(lc_ctr));
+    uint64_t nc = 0;
+    for (uint32_t s = 0; s < n; ++s)
+        for (uint32_t r = 0; r < cnt[s]; ++r) { ctr[nc].key = sel[(size_t)s * m + r].key; ctr[nc].len = (uint32_t)(off[s + 1] - off[s]); ctr[nc].idx = s; ++nc; }
+    qsort(ctr, nc, sizeof(lc_ctr), lc_cmp_ctr);
+    /* accepted centres per member */
+    uint32_t *acc = malloc(((size_t)n * m + 1) * sizeof(uint32_t));
+    uint32_t *nacc = calloc(n + 1, sizeof(uint32_t));
+    uint64_t n_ver = 0, n_acc = 0;
+    for (uint32_t s = 0; s < n; ++s) {
+        const uint8_t *qs = res + off[s];
+        int64_t Ls = (int64_t)(off[s + 1] - off[s]);
+        uint32_t seen_c[64]; int64_t seen_d[64]; int ns = 0;
+        for (uint32_t r = 0; r < cnt[s]; ++r) {
+            uint64_t key = sel[(size_t)s * m + r].key;
+            uint64_t lo = 0, hi = nc;
+            while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (ctr[mid].key < key) lo = mid + 1; else hi = mid; }
+            uint32_t c = ctr[lo].idx;                       /* first of its key group = longest, lowest index */
+            if (c == s) continue;
+            int64_t pc = -1;
+            for (uint32_t r2 = 0; r2 < cnt[c]; ++r2) if (sel[(size_t)c * m + r2].key == key) { pc = sel[(size_t)c * m + r2].pos; break; }
+            int64_t d = pc - (int64_t)sel[(size_t)s * m + r].pos;
+            int dup = 0;
+            for (int z = 0; z < ns; ++z) if (seen_c[z] == c && seen_d[z] == d) { dup = 1; break; }
+            if (dup) continue;
+            seen_c[ns] = c; seen_d[ns] = d; ++ns;
+            ++n_ver;
+            const uint8_t *qc = res + off[c];
+            int64_t Lc = (int64_t)(off[c + 1] - off[c]);
+            int64_t x0 = d < 0 ? -d : 0, x1 = Ls < Lc - d ? Ls : Lc - d, match = 0;
+            for (int64_t x = x0; x < x1; ++x) match += qs[x] == qc[x + d];
+            int64_t ovl = x1 - x0;
+            if (ovl > 0 && (double)match >= min_id * (double)ovl && (double)ovl >= min_cov * (double)Lc && (double)ovl >= min_cov * (double)Ls) {
+                int have = 0;
+                for (uint32_t z = 0; z < nacc[s]; ++z) if (acc[(size_t)s * m + z] == c) have = 1;
+                if (!have) { acc[(size_t)s * m + nacc[s]++] = c; ++n_acc; }
+            }
+        }
+    }
+    /* greedy in priority order */
+    lc_pri *pri = malloc((n + 1) * sizeof(lc_pri));
+    uint32_t *rank = malloc((n + 1) * sizeof(uint32_t));
+    for (uint32_t s = 0; s < n; ++s) { pri[s].len = (uint32_t)(off[s + 1] - off[s]); pri[s].idx = s; }
+    qsort(pri, n, sizeof(lc_pri), lc_cmp_pri);
+    for (uint32_t i = 0; i < n; ++i) rank[pri[i].idx] = i;
+    for (uint32_t s = 0; s < n; ++s) rep_out[s] = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t s = pri[i].idx;
+        /* s is a member of its highest-priority accepted centre that is itself a representative; else a representative */
+        uint32_t best = 0xFFFFFFFFu;
+        for (uint32_t z = 0; z < nacc[s]; ++z) {
+            uint32_t c = acc[(size_t)s * m + z];
+            if (rep_out[c] == c && (best == 0xFFFFFFFFu || rank[c] < rank[best])) best = c;
+        }
+        rep_out[s] = best == 0xFFFFFFFFu ? s : best;
+    }
+    if (stats) { stats[0] = n_sel; stats[1] = n_ver; stats[2] = n_acc; }
+    free(sel); free(cnt); free(ctr); free(acc); free(nacc); free(pri); free(rank);
+    return 0;
+}

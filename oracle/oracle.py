@@ -249,3 +249,23 @@ def parse_diamond_record(qf, rf, rx, pos, cigar_aa, nm, zs, score, ql, rl):
     gaps = [n for n, op in cigar if op != 'M']
     return dict(iden=iden, cl=cl, mismatch=int(variation - sum(gaps)), gapopen=len(gaps), qs=qs_nt, qe=qe_nt, rs=rs_nt, re=re_nt,
                 score=score, qm=qm, cigar=cigar)
+
+
+def nt_codes(s):
+    """A0 C1 G2 T3, anything else 4 (the clustering alphabet)"""
+    lut = np.full(256, 4, dtype=np.uint8)
+    for ch, v in zip('ACGTacgt', (0, 1, 2, 3, 0, 1, 2, 3)):
+        lut[ord(ch)] = v
+    return lut[np.frombuffer(s.encode('ascii') if isinstance(s, str) else s, dtype=np.uint8)]
+
+
+def linclust(seqs, min_id, min_cov, base=4, k=17, m=20):
+    """seqs: list of uint8 code arrays -> (rep index per sequence, stats)"""
+    res, off = pack(seqs)
+    if len(res) == 0:
+        res = np.zeros(1, np.uint8)
+    rep = np.zeros(len(seqs), dtype=np.uint32)
+    stats = (C.c_uint64 * 3)()
+    lib().oracle_linclust(res.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.c_uint32(len(seqs)), C.c_int(base), C.c_int(k), C.c_int(m),
+                          C.c_double(min_id), C.c_double(min_cov), rep.ctypes.data_as(C.c_void_p), stats)
+    return rep, dict(selected=int(stats[0]), verified=int(stats[1]), accepted=int(stats[2]))

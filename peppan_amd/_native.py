@@ -12,7 +12,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_min_score', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
-           'pep_rescore_nt', 'pep_components']
+           'pep_rescore_nt', 'pep_components', 'pep_linclust']
 
 
 class PepError(RuntimeError):
@@ -215,6 +215,17 @@ class Context(object):
             cg = cigar if len(cigar) else np.zeros(1, np.uint32)
             self._check(self._lib.pep_rescore_nt(self._h, C.c_uint64(len(nt_hits)), _ptr(nt_hits), _ptr(cg), C.c_uint64(len(cigar)), _ptr(out)), 'pep_rescore_nt')
         return out
+
+    # ---- K9
+    def linclust(self, seqs, min_id, min_cov, base=4, k=17, m=20):
+        """seqs: list of uint8 code arrays -> (uint32 representative index per sequence, stats dict)"""
+        codes, off = _pack(seqs)
+        rep = np.zeros(len(seqs), dtype=np.uint32)
+        stats = np.zeros(3, dtype=np.uint64)
+        if len(seqs):
+            self._check(self._lib.pep_linclust(self._h, _ptr(codes), _ptr(off), C.c_uint32(len(seqs)), C.c_int(base), C.c_int(k), C.c_int(m),
+                                               C.c_double(min_id), C.c_double(min_cov), _ptr(rep), _ptr(stats)), 'pep_linclust')
+        return rep, dict(selected=int(stats[0]), verified=int(stats[1]), accepted=int(stats[2]))
 
     # ---- K10
     def components(self, n_nodes, a, b):

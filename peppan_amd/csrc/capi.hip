@@ -477,4 +477,14 @@ int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint3
     return pep_k10_components(ctx, n_nodes, n_edges, a, b, label);
 }
 
+int pep_linclust(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n, int base, int k, int m, double min_id, double min_cov,
+                 uint32_t *rep, uint64_t *stats)
+{
+    if (!ctx || (n && (!codes || !off || !rep))) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i]) return pep_fail(ctx, PEP_ERR_ARG, "offsets must be non-decreasing");
+    return pep_k9_linclust(ctx, codes, off, n, base, k, m, min_id, min_cov, rep, stats);
+}
+
 }  // extern "C"

@@ -116,5 +116,9 @@ int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uin
 // ---- unionfind.hip (K10)
 int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *h_a, const uint32_t *h_b, uint32_t *h_label);
 
+// ---- linclust.hip (K9)
+int pep_k9_linclust(pep_ctx *ctx, const uint8_t *h_res, const uint64_t *h_off, uint32_t n, int base, int k, int m, double min_id, double min_cov,
+                    uint32_t *h_rep, uint64_t *h_stats);
+
 static inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 int pep_upload_blk2seq(pep_ctx *ctx, SeqSet &s);

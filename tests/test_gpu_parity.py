@@ -229,3 +229,54 @@ def test_uberblast_dropin_genome_mapping(tmp_path, monkeypatch):
         ora_tab, ora_ovl = UB.uberBlast(argv)
     assert gpu_tab.shape[0] >= 20 and gpu_tab.tolist() == ora_tab.tolist() and gpu_ovl.tolist() == ora_ovl.tolist()
     assert any(r[8] > r[9] for r in gpu_tab.tolist()) and any(r[8] < r[9] for r in gpu_tab.tolist())
+
+
+@pytest.mark.parametrize('min_id', [1.0, 0.97, 0.9])
+def test_k9_linclust_vs_oracle(ctx, min_id):
+    from peppan_amd import synth
+    from oracle import oracle as O
+    names, seqs = synth.make_genes(3000, 0, seed=21)
+    seqs = list(seqs) + [seqs[5], seqs[5][:-30], b'ACGT' * 3, b'', b'ACGTNNNNACGTACGTACGTACGTNACGT' * 4, seqs[7][10:]]     # duplicates, fragments, short, empty, ambiguous
+    codes = [O.nt_codes(s) for s in seqs]
+    g_rep, g_st = ctx.linclust(codes, min_id, 0.9)
+    o_rep, o_st = O.linclust(codes, min_id, 0.9)
+    assert g_st == o_st
+    assert np.array_equal(g_rep, o_rep)
+    assert (g_rep[g_rep] == g_rep).all()                      # representatives represent themselves
+    if min_id < 1.0:
+        assert len(set(g_rep.tolist())) < len(seqs) - 20
+    # protein alphabet (clust -a): base 20, k 7
+    prots = synth.make_proteins(300, length=(50, 300), seed=4, family=3, sub=0.03)
+    aa20 = np.full(26, 20, dtype=np.uint8)
+    for i, c in enumerate('ACDEFGHIKLMNPQRSTVWY'):
+        aa20[ord(c) - 65] = i
+    pc = [aa20[p] for p in prots]
+    g_rep, g_st = ctx.linclust(pc, 0.9, 0.8, base=20, k=7, m=20)
+    o_rep, o_st = O.linclust(pc, 0.9, 0.8, base=20, k=7, m=20)
+    assert np.array_equal(g_rep, o_rep) and g_st == o_st
+
+
+def test_getclust_and_iterclust_on_gpu(tmp_path, monkeypatch):
+    """clust.getClust / pipeline.iterClust with the GPU clusterer == the same host code over the oracle's relation"""
+    import io, contextlib
+    from peppan_amd import clust as CL, pipeline as PL, linclust as LC, synth
+    from oracle import oracle as O
+    monkeypatch.chdir(tmp_path)
+    names, seqs = synth.make_genes(1200, 0, seed=31)
+    names = [str(i) for i in range(len(seqs))]
+    with open('genes.fa', 'w') as f:
+        for n, s in zip(names, seqs):
+            f.write('>%s\n%s\n' % (n, s.decode()))
+
+    def oracle_fn(fasta, identity, coverage, n_thread):
+        recs = CL.readFasta(fasta)
+        rep, _ = O.linclust([O.nt_codes(s) for _, s in recs], float(identity), float(coverage))
+        return [(recs[r][0], recs[i][0]) for i, r in enumerate(rep.tolist())]
+    out = {}
+    for tag, fn in (('gpu', None), ('ora', oracle_fn)):
+        with contextlib.redirect_stderr(io.StringIO()):
+            groups = [[0, 999999, 10000]]
+            ex = PL.iterClust(tag, 'genes.fa', groups, dict(identity=0.9, coverage=0.8, n_thread=1, translate=False, cluster_fn=fn))
+        out[tag] = (open(ex).read(), open(tag + '.clust.tab').read(), np.load(tag + '.clust.npy').tolist())
+    assert out['gpu'] == out['ora']
+    assert out['gpu'][0].count('>') < 1200 and len(out['gpu'][2]) > 50
