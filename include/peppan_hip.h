@@ -68,6 +68,7 @@ typedef struct {
     int32_t xdrop;                /* x-drop of that ungapped extension (must stay below 64) */
     int32_t ext_right, ext_left;  /* residues scored right of (from) / left of the seed's first position (<= 48 / <= 48) */
     int32_t reserved[3];
+    double ka_lambda, ka_k;       /* Karlin-Altschul parameters of the scoring system (protein default 0.267 / 0.041) */
 } pep_search_params;
 
 /* one alignment; coordinates are 1-based, inclusive, in residues of the query / target protein */
@@ -119,6 +120,7 @@ const char *pep_last_error(const pep_ctx *ctx);
 void pep_default_params(pep_search_params *p);
 /* smallest raw score passing the e-value cut for a query of qlen residues */
 int32_t pep_min_score(uint32_t qlen, double dbsize, double max_evalue);
+int32_t pep_min_score_ka(uint32_t qlen, double dbsize, double max_evalue, double ka_lambda, double ka_k);
 
 /* nucleotide inputs (ASCII, any case), concatenated, off[n+1].  Stored on the device; K1 (translation,
  * frame choice / chunking, packing) runs on the GPU at the next pep_translate or pep_search. */

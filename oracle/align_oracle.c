@@ -141,6 +141,13 @@ void oracle_default_params(oracle_params *p)
 
 /* smallest raw score whose e-value m*n*K*exp(-lambda*S) is <= max_evalue
  * (gapped BLOSUM62 11/1 statistics: lambda 0.267, K 0.041; n = --dbsize) */
+int32_t oracle_min_score_ka(uint32_t qlen, double dbsize, double max_evalue, double lambda, double K)
+{
+    double s = log(K * (double)qlen * dbsize / max_evalue) / lambda;
+    int32_t r = (int32_t)ceil(s);
+    return r < 1 ? 1 : r;
+}
+
 int32_t oracle_min_score(uint32_t qlen, double dbsize, double max_evalue)
 {
     const double lambda = 0.267, K = 0.041;

@@ -66,8 +66,29 @@ def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5, ungappe
     return p
 
 
-def min_score(qlen, dbsize=5e6, max_evalue=1.):
-    return int(lib().oracle_min_score(int(qlen), float(dbsize), float(max_evalue)))
+def min_score(qlen, dbsize=5e6, max_evalue=1., ka_lambda=None, ka_k=None):
+    if ka_lambda is None:
+        return int(lib().oracle_min_score(int(qlen), float(dbsize), float(max_evalue)))
+    f = lib().oracle_min_score_ka
+    f.restype = C.c_int32
+    f.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double]
+    return int(f(int(qlen), float(dbsize), float(max_evalue), float(ka_lambda), float(ka_k)))
+
+
+def params_from(native):
+    """oracle parameter block with the same algorithmic fields as a peppan_amd._native.SearchParams"""
+    p = Params()
+    for f in ('gap_open', 'gap_ext', 'n_shapes', 'base', 'min_id_pct', 'min_qcov_pct', 'top_k', 'n_splits', 'ungapped_min', 'xdrop', 'ext_right', 'ext_left'):
+        setattr(p, f, getattr(native, f))
+    for i in range(4):
+        p.weight[i] = native.weight[i]
+        for j in range(32):
+            p.offs[i][j] = native.offs[i][j]
+    for i in range(32):
+        p.reduce[i] = native.reduce[i]
+    for i in range(1024):
+        p.sub[i] = native.sub[i]
+    return p
 
 
 def aa_codes(s):

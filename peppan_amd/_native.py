@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
 ABI_VERSION = 1
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
-           'pep_min_score', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
+           'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
            'pep_rescore_nt', 'pep_components', 'pep_linclust']
@@ -25,7 +25,7 @@ class SearchParams(C.Structure):
                 ('sub', C.c_int8 * 1024), ('min_id_pct', C.c_double), ('min_qcov_pct', C.c_double),
                 ('top_k', C.c_int32), ('n_splits', C.c_int32), ('dbsize', C.c_double), ('max_evalue', C.c_double),
                 ('use_lds', C.c_int32), ('ungapped_min', C.c_int32), ('xdrop', C.c_int32), ('ext_right', C.c_int32),
-                ('ext_left', C.c_int32), ('reserved', C.c_int32 * 3)]
+                ('ext_left', C.c_int32), ('reserved', C.c_int32 * 3), ('ka_lambda', C.c_double), ('ka_k', C.c_double)]
 
 
 class Stats(C.Structure):
@@ -62,6 +62,8 @@ def load_library():
     lib.pep_last_error.argtypes = [C.c_void_p]
     lib.pep_min_score.restype = C.c_int32
     lib.pep_min_score.argtypes = [C.c_uint32, C.c_double, C.c_double]
+    lib.pep_min_score_ka.restype = C.c_int32
+    lib.pep_min_score_ka.argtypes = [C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double]
     lib.pep_ctx_destroy.argtypes = [C.c_void_p]
     lib.pep_ctx_destroy.restype = None
     lib.pep_result_free.argtypes = [C.c_void_p]
@@ -84,6 +86,27 @@ def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5, dbsize=
 
 def min_score(qlen, dbsize=5e6, max_evalue=1.):
     return int(load_library().pep_min_score(int(qlen), float(dbsize), float(max_evalue)))
+
+
+def nucleotide_params(min_id_pct=0., min_qcov_pct=0., top_k=1000, dbsize=5e6, max_evalue=1e-2):
+    """the search engine configured like the reference's blastn call (uberBlast.py:294): residues A0 C1 G2 T3 (other 4),
+    exact 17-mers (-word_size 17), reward 2 / penalty -3, gap 6 + 2k, e-value 1e-2 at dbsize 5e6, 1000 targets per query.
+    Karlin-Altschul lambda 0.625 / K 0.41 are NCBI's published values for 2/-3 with gap costs 5/2 (closest tabulated)."""
+    p = default_params(min_id_pct, min_qcov_pct, top_k, 1, dbsize, max_evalue)
+    p.gap_open, p.gap_ext = 6, 2
+    p.n_shapes, p.base = 1, 4
+    for s in range(4):
+        p.weight[s] = 0
+    p.weight[0] = 17
+    for i in range(32):
+        p.offs[0][i] = i if i < 17 else 0
+        p.reduce[i] = i if i < 4 else 0xFF
+    for a in range(32):
+        for b in range(32):
+            p.sub[a * 32 + b] = (2 if a == b else -3) if (a < 4 and b < 4) else (-3 if (a < 5 and b < 5) else -64)
+    p.ungapped_min, p.xdrop, p.ext_right, p.ext_left = 40, 16, 40, 24
+    p.ka_lambda, p.ka_k = 0.625, 0.41
+    return p
 
 
 def _pack(seqs):

@@ -228,15 +228,20 @@ void pep_default_params(pep_search_params *p)
     p->dbsize = 5e6; p->max_evalue = 1.;
     p->use_lds = 1;
     p->ungapped_min = 45; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24;
+    p->ka_lambda = 0.267; p->ka_k = 0.041;
+}
+
+int32_t pep_min_score_ka(uint32_t qlen, double dbsize, double max_evalue, double ka_lambda, double ka_k)
+{
+    // E = K m n exp(-lambda S)  ->  smallest integer S with E <= max_evalue
+    const double s = log(ka_k * (double)qlen * dbsize / max_evalue) / ka_lambda;
+    const int32_t r = (int32_t)ceil(s);
+    return r < 1 ? 1 : r;
 }
 
 int32_t pep_min_score(uint32_t qlen, double dbsize, double max_evalue)
 {
-    // Karlin-Altschul statistics of gapped BLOSUM62 11/1: E = K m n exp(-lambda S)
-    const double lambda = 0.267, K = 0.041;
-    const double s = log(K * (double)qlen * dbsize / max_evalue) / lambda;
-    const int32_t r = (int32_t)ceil(s);
-    return r < 1 ? 1 : r;
+    return pep_min_score_ka(qlen, dbsize, max_evalue, 0.267, 0.041);      // gapped BLOSUM62 11/1
 }
 
 int pep_ctx_create(int device, pep_ctx **out)
@@ -392,6 +397,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
             if (params->offs[s][params->weight[s] - 1] > 31) return pep_fail(ctx, PEP_ERR_ARG, "seed span above 32");
             if (pow((double)params->base, params->weight[s]) > 34359738368.0) return pep_fail(ctx, PEP_ERR_ARG, "seed key does not fit 35 bits");
         }
+        if (!(params->ka_lambda > 0.) || !(params->ka_k > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "invalid Karlin-Altschul parameters");
         if (params->xdrop < 0 || params->xdrop > 48 || params->ext_right < 1 || params->ext_right > 48 || params->ext_left < 0 || params->ext_left > 48)
             return pep_fail(ctx, PEP_ERR_ARG, "invalid ungapped-extension parameters");
         ctx->params = *params;
@@ -418,7 +424,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     hipEventRecord(e1, ctx->stream);
     if (rc == PEP_OK) {
         std::vector<int32_t> min_score(ctx->q.n + 1);
-        for (uint32_t i = 0; i < ctx->q.n; ++i) min_score[i] = pep_min_score(ctx->q.h_len[i], ctx->params.dbsize, ctx->params.max_evalue);
+        for (uint32_t i = 0; i < ctx->q.n; ++i) min_score[i] = pep_min_score_ka(ctx->q.h_len[i], ctx->params.dbsize, ctx->params.max_evalue, ctx->params.ka_lambda, ctx->params.ka_k);
         rc = pep_extend(ctx, d_cands, n_cands, min_score.data(), res);
     }
     hipEventRecord(e2, ctx->stream);

@@ -5,7 +5,8 @@ Same entry points and table format:
     RunBlast().run(ref, qry, methods, min_id, ...)      uberBlast.py:326-376   same positional / keyword arguments
     tools: 'diamond', 'diamondself', 'gpu'  -> translated search on the MI355X (K1..K8), replaces runDiamond
                                               (uberBlast.py:513-560) and parseDiamond (uberBlast.py:16-70)
-           'blastn'                          -> nucleotide search on the same engine (see run_blastn)
+           'blastn'                          -> nucleotide search on the same engine (runBlast), replaces
+                                              runBlast / poolBlast / parseBlast / getCIGAR (uberBlast.py:274-320, 482-509)
 Each tool returns the reference's 15-column object rows (names str, CIGAR as [[n, op], ...] in nucleotides);
 run() then applies reScore (K7 on the GPU for mode 1), the -f/-m filters, fixEnd, -O overlaps and the final
 string-keyed sort exactly as the reference does.  There is no CPU fallback: without the HIP library or a GPU
@@ -95,6 +96,47 @@ def hits_to_blastab(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len,
         o, r = off[h], nr[h]
         out[k] = [str(q_names[qseq[h]]), str(r_names[rseq[h]]), float(iden[h]), int(cl[h]), int(mismatch[h]), int(gap_open[h]),
                   int(qs_nt[h]), int(qe_nt[h]), int(rs_nt[h]), int(re_nt[h]), 0.0, int(hits['score'][h]), int(ql[h]), int(rl[h]),
+                  [[len_l[x], op_l[x]] for x in range(o, o + r)]]
+    return out
+
+
+_NT_CODE = np.full(256, 4, dtype=np.uint8)
+for _c, _v in zip('ACGTacgt', (0, 1, 2, 3, 0, 1, 2, 3)):
+    _NT_CODE[ord(_c)] = _v
+_NT_RC = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+
+
+def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params):
+    """nucleotide-search hits -> the rows parseBlast builds from blastn's outfmt 6 (uberBlast.py:275-290, 311-320):
+    target index >= len(r_names) is the reverse strand (sstart > send); identity carries blastn's 3 printed decimals"""
+    n = len(hits)
+    if n == 0:
+        return np.empty([0, 15], dtype=object)
+    nr = len(r_names)
+    qi = hits['q'].astype(np.int64)
+    ti = hits['t'].astype(np.int64)
+    rev, ri = ti >= nr, ti % nr
+    ql, sl = np.asarray(q_len, dtype=np.int64)[qi], np.asarray(r_len, dtype=np.int64)[ri]
+    qs, qe = hits['q_start'].astype(np.int64), hits['q_end'].astype(np.int64)
+    ts, te = hits['t_start'].astype(np.int64), hits['t_end'].astype(np.int64)
+    ss, se = np.where(rev, sl - ts + 1, ts), np.where(rev, sl - te + 1, te)
+    aln, ident = hits['aln_len'].astype(np.int64), hits['n_ident'].astype(np.int64)
+    iden = np.array([float('%.3f' % v) for v in (100. * ident / aln).tolist()]) / 100.
+    runs_len, runs_op = (cigar >> 2).astype(np.int64), (cigar & 3).astype(np.int64)
+    owner = np.repeat(np.arange(n), hits['cigar_runs'].astype(np.int64))
+    gap_cols = np.bincount(owner, weights=runs_len * (runs_op != 0), minlength=n).astype(np.int64)
+    gap_open = np.bincount(owner, weights=(runs_op != 0), minlength=n).astype(np.int64)
+    score = hits['score'].astype(np.int64)
+    evalue = params.ka_k * ql * params.dbsize * np.exp(-params.ka_lambda * score)
+    keep = (iden >= min_id) & (qe - qs + 1 >= min_cov) & (qe - qs + 1 >= min_ratio * ql)
+    idx = np.nonzero(keep)[0]
+    out = np.empty([len(idx), 15], dtype=object)
+    off, cnt = hits['cigar_off'].astype(np.int64), hits['cigar_runs'].astype(np.int64)
+    len_l, op_l = runs_len.tolist(), _OPS[runs_op].tolist()
+    for k, h in enumerate(idx.tolist()):
+        o, r = off[h], cnt[h]
+        out[k] = [str(q_names[qi[h]]), str(r_names[ri[h]]), float(iden[h]), int(aln[h]), int(aln[h] - ident[h] - gap_cols[h]), int(gap_open[h]),
+                  int(qs[h]), int(qe[h]), int(ss[h]), int(se[h]), float(evalue[h]), int(score[h]), int(ql[h]), int(sl[h]),
                   [[len_l[x], op_l[x]] for x in range(o, o + r)]]
     return out
 
@@ -252,8 +294,25 @@ class RunBlast(object):
         return blastab
 
     def runBlast(self, ref, qry):
-        raise NotImplementedError('the nucleotide (blastn-equivalent) search is not built yet (SURVEY.md 8f rank 3); '
-                                  'use --diamond / --gpu')
+        """nucleotide search on the same GPU engine, configured like the reference's blastn call (uberBlast.py:294):
+        exact 17-mer seeds, +2/-3, gap 6+2k, e-value 1e-2 at dbsize 5e6, both strands of the reference, the
+        -perc_identity / -qcov_hsp_perc cuts, then parseBlast's filters (uberBlast.py:283).  One alignment per
+        (query, subject, strand) - see DESIGN.md for this difference to blastn's multiple HSPs."""
+        logger('Run BLASTn starts')
+        self._load(ref, qry)
+        ctx = get_context(self.device)
+        q_names, r_names = sorted(self.qrySeq), sorted(self.refSeq)
+        q_codes = [_NT_CODE[np.frombuffer(self._text(self.qrySeq[n]).encode('ascii'), dtype=np.uint8)] for n in q_names]
+        r_codes = [_NT_CODE[np.frombuffer(self._text(self.refSeq[n]).encode('ascii'), dtype=np.uint8)] for n in r_names]
+        ctx.set_query_aa(q_codes)
+        ctx.set_ref_aa(r_codes + [_NT_RC[c[::-1]] for c in r_codes])
+        self._nt_loaded = None                      # the packed protein sets of a previous translated search are gone
+        params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100.)
+        hits, cigar, stats = ctx.search(params)
+        blastab = blast_hits_to_blastab(hits, cigar, q_names, r_names, [len(c) for c in q_codes], [len(c) for c in r_codes],
+                                        self.min_id, self.min_cov, self.min_ratio, params)
+        logger('Run BLASTn finishes. Got {0} alignments'.format(blastab.shape[0]))
+        return blastab
 
     # ---------------------------------------------------------------------------------------------- post-processing
     def reScore(self, ref, qry, blastab, mode, min_id, table_id=11, perBatch=10000):

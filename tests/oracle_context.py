@@ -10,12 +10,23 @@ class OracleContext(object):
     def set_query_nt(self, seqs, gtable=11):
         self.q_nt = [s.decode() if isinstance(s, bytes) else s for s in seqs]
         self.q_table = gtable
+        self._direct = False
 
     def set_ref_nt(self, seqs, frames=6, gtable=11):
         self.r_nt = [s.decode() if isinstance(s, bytes) else s for s in seqs]
         self.r_frames, self.r_table = frames, gtable
 
+    def set_query_aa(self, seqs):
+        self.q_aa = [np.asarray(s, dtype=np.uint8) for s in seqs]
+        self._direct = True
+
+    def set_ref_aa(self, seqs):
+        self.t_aa = [np.asarray(s, dtype=np.uint8) for s in seqs]
+        self._direct = True
+
     def translate(self, force=False):
+        if getattr(self, '_direct', False):
+            return
         qm, self.q_aa = [], []
         for i, s in enumerate(self.q_nt):
             f, p = O.query_frame(s.upper(), self.q_table)
@@ -39,8 +50,8 @@ class OracleContext(object):
 
     def search(self, params=None):
         self.translate()
-        p = O.default_params(params.min_id_pct, params.min_qcov_pct, params.top_k, params.n_splits, ungapped_min=params.ungapped_min)
-        ms = np.array([O.min_score(len(s), params.dbsize, params.max_evalue) for s in self.q_aa], dtype=np.int32)
+        p = O.params_from(params)
+        ms = np.array([O.min_score(len(s), params.dbsize, params.max_evalue, params.ka_lambda, params.ka_k) for s in self.q_aa], dtype=np.int32)
         h, c, st = O.search(self.q_aa, self.t_aa, p, min_scores=ms)
         out = np.zeros(len(h), dtype=N.HIT_DTYPE)
         for f in out.dtype.names:

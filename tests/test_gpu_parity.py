@@ -280,3 +280,43 @@ def test_getclust_and_iterclust_on_gpu(tmp_path, monkeypatch):
         out[tag] = (open(ex).read(), open(tag + '.clust.tab').read(), np.load(tag + '.clust.npy').tolist())
     assert out['gpu'] == out['ora']
     assert out['gpu'][0].count('>') < 1200 and len(out['gpu'][2]) > 50
+
+
+def test_nucleotide_search_engine_vs_oracle(ctx):
+    """the blastn-like configuration of the engine (base-4 exact 17-mers, +2/-3, gap 6+2k), both strands"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    names, seqs = synth.make_genes(400, 0, seed=41)
+    codes = [O.nt_codes(s) for s in seqs]
+    rc = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    targets = codes + [rc[c[::-1]] for c in codes]
+    p = N.nucleotide_params(70., 25.)
+    ctx.set_query_aa(codes)
+    ctx.set_ref_aa(targets)
+    gh, gc, st = ctx.search(p)
+    ms = np.array([O.min_score(len(c), p.dbsize, p.max_evalue, p.ka_lambda, p.ka_k) for c in codes], dtype=np.int32)
+    oh, oc, ost = O.search(codes, targets, O.params_from(p), min_scores=ms)
+    _cmp_hits(gh, gc, oh, oc)
+    assert st['candidates'] == ost['candidates'] and len(gh) > 500
+    assert (gh['q'] == gh['t']).sum() == 400           # every gene finds itself on the forward strand
+
+
+def test_uberblast_dropin_blastn_and_diamond(tmp_path, monkeypatch):
+    """the reference's actual exemplar call: --blastn --diamond -s 1 (PEPPAN.py:229-230), both tools on the GPU"""
+    import io, contextlib
+    from peppan_amd import uberBlast as UB, synth
+    from oracle_context import OracleContext
+    monkeypatch.chdir(tmp_path)
+    names, seqs = synth.make_genes(160, 0, seed=55)
+    names = [str(3 * i + 1) for i in range(len(seqs))]
+    fa = str(tmp_path / 'ex.fa')
+    _write_fasta(fa, names, seqs)
+    argv = '-r {0} -q {0} --blastn --diamond -s 1 --min_id 0.45 --min_cov 50 -t 2 --min_ratio 0.25 -e 3,3 -p --gtable 11'.format(fa).split()
+    with contextlib.redirect_stderr(io.StringIO()):
+        gpu = UB.uberBlast(argv)
+        octx = OracleContext()
+        monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
+        ora = UB.uberBlast(argv)
+    assert gpu.shape == ora.shape and gpu.tolist() == ora.tolist()
+    n_self = sum(1 for r in gpu.tolist() if r[0] == r[1])
+    assert n_self >= 2 * 160 - 5            # blastn and diamond rows of the same pair coexist (uberBlast.py:343-346, 353)
