@@ -118,6 +118,15 @@ def main():
         Lq = args.gene_len // 3
         alg_bytes = cand * (2 * Lq) + (acc['hits'] / K) * 64
         achieved = alg_bytes / (ms_sw * 1e-3) / 1e9
+        traffic, traffic_note = None, ''
+        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if os.path.exists(tfile) and args.genes == 10000 and args.gene_len == 1002 and world == 1:
+            k = json.load(open(tfile))['kernels'].get('sw_kernel<false>')
+            if k:
+                # rocprofv3 PMC passes of the same workload (profiles/r01_pmc_hbm_traffic.txt): FETCH_SIZE is doubled per the gfx950
+                # correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE matched the known output bytes exactly
+                traffic = (2 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
+                traffic_note = '; PMC traffic = 2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_hbm_traffic.txt (below the algorithmic bytes: residues shared by candidates are served from L2)'
         line = {
             'metric': 'gene_pairs_aligned_per_s', 'value': total_pairs / dt, 'unit': 'gene-pairs/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': dt / K * 1e3,
@@ -129,10 +138,10 @@ def main():
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
             'hits_per_step': acc['hits'] / K, 'clusters': int(len(np.unique(labels))),
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_sw', 'ms_trace', 'ms_total')},
-            'roofline': {'bound': 'hbm', 'kernel': 'sw_kernel (K5 banded Smith-Waterman)', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': None,
-                         'note': 'integer-VALU-bound by construction (SURVEY 8d); the kernel also writes %.3g B/launch of traceback codes '
-                                 'that the SURVEY formula does not count' % (acc['dir_bytes'] / K)},
+            'roofline': {'bound': 'hbm', 'kernel': 'sw_kernel<false> (K5 banded Smith-Waterman, score pass)', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': achieved / 8000.0, 'traffic': traffic,
+                         'note': 'score-pass kernel sw_kernel<false>: integer-VALU-bound by construction (SURVEY 8d), measured at the VALU issue limit '
+                                 '(14 VALU/step x 4 cycles); the separate traceback pass writes %.3g B/step of traceback codes' % (acc['dir_bytes'] / K) + traffic_note},
             'cpu_baseline': None,
         }
         if not args.no_cpu_baseline:

@@ -320,3 +320,54 @@ def test_uberblast_dropin_blastn_and_diamond(tmp_path, monkeypatch):
     assert gpu.shape == ora.shape and gpu.tolist() == ora.tolist()
     n_self = sum(1 for r in gpu.tolist() if r[0] == r[1])
     assert n_self >= 2 * 160 - 5            # blastn and diamond rows of the same pair coexist (uberBlast.py:343-346, 353)
+
+
+def test_config1_1k_genes_cluster_membership_bit_exact(tmp_path, monkeypatch):
+    """BASELINE configs[1]: 1k synthetic 1 kb genes, all-vs-all on one MI355X, cluster membership bit-exact vs the CPU path.
+    Whole hot path through the reference-shaped entry points: iterClust -> get_similar_pairs -> get_gene_group."""
+    import io, contextlib, shutil
+    from peppan_amd import uberBlast as UB, pipeline as PL, clust as CL, synth
+    from oracle import oracle as O
+    from oracle_context import OracleContext
+    names, seqs = synth.make_genes(1000, 1002, seed=355)
+    prio = {i: [0, -len(s), i] for i, s in enumerate(seqs)}
+    params = dict(noDiamond=False, match_identity=0.5, match_frag_len=50, n_thread=2, match_frag_prop=0.25, gtable=11,
+                  clust_identity=0.9, clust_match_prop=0.8, incompleteCDS='', match_len=250., match_len1=100., match_len2=400.,
+                  match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+
+    def oracle_fn(fasta, identity, coverage, n_thread):
+        recs = CL.readFasta(fasta)
+        rep, _ = O.linclust([O.nt_codes(s) for _, s in recs], float(identity), float(coverage))
+        return [(recs[r][0], recs[i][0]) for i, r in enumerate(rep.tolist())]
+
+    results = {}
+    for tag in ('gpu', 'ora'):
+        d = tmp_path / tag
+        d.mkdir()
+        monkeypatch.chdir(d)
+        with open('p.genes', 'w') as f:
+            for i, s in enumerate(seqs):
+                f.write('>%d\n%s\n' % (i, s.decode()))
+        if tag == 'ora':
+            octx = OracleContext()
+            monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
+            monkeypatch.setattr(PL, 'get_context', lambda device=None: octx)
+        with contextlib.redirect_stderr(io.StringIO()):
+            ex = PL.iterClust('p', 'p.genes', [], dict(identity=0.9, coverage=0.8, n_thread=2, translate=False,
+                                                       cluster_fn=oracle_fn if tag == 'ora' else None))
+            pairs = PL.get_similar_pairs(ex, prio, dict(params, clust=ex))
+        np.save('p.self_bsn.npy', pairs)
+        groups = PL.get_gene_group(ex, 'p.self_bsn.npy')
+        labels = PL.gene_group_labels(ex, 'p.self_bsn.npy', n_genes=len(seqs))
+        results[tag] = (open(ex).read(), np.load('p.clust.npy').tolist(), pairs.tolist(),
+                        [[int(k), [int(x) for x in v]] for k, v in groups.items()], labels.tolist())
+    g, o = results['gpu'], results['ora']
+    assert g[0] == o[0] and g[1] == o[1]          # exemplars, clust.npy
+    assert g[2] == o[2]                           # ortholog pairs with their integer identities
+    assert g[3] == o[3] and g[4] == o[4]          # gene groups: exact dict and GPU labels
+    # the GPU labels describe the same partition as the reference-shaped dict
+    part = {}
+    for i, l in enumerate(g[4]):
+        part.setdefault(l, set()).add(i)
+    assert {frozenset(v) for v in part.values() if len(v) > 1} == {frozenset(m) for _, m in g[3]}
+    assert len(g[2]) > 300 and len(g[3]) > 100
