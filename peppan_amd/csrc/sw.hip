@@ -12,8 +12,9 @@
 // the 32 banks (dword w*32+bank) so the per-lane gather is conflict-free.
 //
 // Per cell a 4-bit traceback code is produced (bits0-1 source of H: 0 none/1 diagonal/2 E/3 F, bit2 E was an
-// extension, bit3 F was an extension); a lane packs 8 consecutive steps in one dword and the wave stores
-// 256 B per 8 steps, fully coalesced, into the direction workspace read back by the walk kernel (trace.hip).
+// extension, bit3 F was an extension); a lane packs 8 consecutive cells of EACH of its two diagonals in one dword
+// and the wave stores 512 B (one uint2 per lane) per 16 steps, fully coalesced, into the direction workspace read
+// back by the walk kernel (trace.hip), which can then follow a diagonal run inside one word.
 //
 // Integer DP in int32.  Algorithmic HBM bytes per candidate: Lq + Lt residues + 16 B result
 // (+ 32 B per anti-diagonal step of traceback codes).  VALU-bound by construction.
@@ -31,7 +32,7 @@ struct SwArgs {
     const uint32_t *q_off, *q_len, *t_off, *t_len;
     const uint32_t *sub_image;     // 8192 dwords
     const uint64_t *dir_off;       // per candidate, in 256-byte blocks
-    const uint32_t *nblk;          // per candidate: 8-step blocks
+    const uint32_t *nblk;          // per candidate: 16-step blocks (8 A/B step pairs)
     uint32_t *dirs;
     int4 *out;                     // score, iend, jend, a0
     int oe, ext;
@@ -64,16 +65,16 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
     const int s0 = s_lo - ((s_lo - dlo) & 1);
     const int a0 = (s0 - dlo) / 2;                 // exact: s0 - dlo is even
     const int nblk = (int)a.nblk[c];
-    uint32_t *dir = TRACE ? a.dirs + a.dir_off[c] * 64 : nullptr;
+    uint2 *dir = TRACE ? reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c] * 64 : nullptr;
 
     // residues used by step pair m:  A: (i, j) = (a0 + m - lane, a0 + dlo + m + lane),  B: (i, j + 1)
     int i = a0 - lane, j = a0 + dlo + lane;
     uint16_t *lq = nullptr, *lt = nullptr;
     int qlo = 0, tlo = 0;
     if (LDS_RES) {
-        // stage the residue windows the sweep can touch: i in [a0-63, a0+4*nblk], j in [a0+dlo, a0+dlo+4*nblk+64]
+        // stage the residue windows the sweep can touch: i in [a0-63, a0+8*nblk], j in [a0+dlo, a0+dlo+8*nblk+64]
         qlo = a0 - 64; tlo = a0 + dlo - 1;
-        const int qn = 4 * nblk + 72, tn = 4 * nblk + 72;
+        const int qn = 8 * nblk + 72, tn = 8 * nblk + 72;
         lq = lds_res; lt = lds_res + ((qn + 7) & ~7);
         for (int x = lane; x < qn; x += 64) { const int g = qlo + x; lq[x] = q_addr_part(((unsigned)g < (unsigned)Lq) ? qg[g] : PEP_PAD_CODE); }
         for (int x = lane; x < tn; x += 64) { const int g = tlo + x; lt[x] = t_addr_part(((unsigned)g < (unsigned)Lt) ? tg[g] : PEP_PAD_CODE); }
@@ -95,7 +96,9 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
     int tv = Tat(j), qv = 0;
     int k = 0;
     for (int b = 0; b < nblk; ++b) {
-        uint32_t acc = 0;
+        uint32_t accA = 0, accB = 0;       // 8 consecutive cells of diagonal A / of diagonal B, 4 bits each
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // ---- A step: cell (i, j) on diagonal dlo + 2*lane
@@ -111,7 +114,7 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
                 if (TRACE) {
                     const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
                     const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
-                    acc = (acc >> 4) | (nib << 28);
+                    accA = (accA >> 4) | (nib << 28);
                     if (H > best) { best = H; best_k = k; }
                 } else best = max(best, H);
                 HA = H; EA = E; FA = F;
@@ -130,14 +133,14 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
                 if (TRACE) {
                     const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
                     const uint32_t nib = src | (e_ext > e_open ? 4u : 0u) | (f_ext > f_open ? 8u : 0u);
-                    acc = (acc >> 4) | (nib << 28);
+                    accB = (accB >> 4) | (nib << 28);
                     if (H > best) { best = H; best_k = k; }
                 } else best = max(best, H);
                 HB = H; EB = E; FB = F;
             }
             ++k; ++i;
         }
-        if (TRACE) dir[(size_t)b * 64 + lane] = acc;
+        if (TRACE) dir[(size_t)b * 64 + lane] = make_uint2(accA, accB);
     }
     if (!TRACE) {
         // score pass: only the maximum is needed (the end cell comes from the traceback pass of the selected pairs)
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(SwArgs a)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t *lds_res = reinterpret_cast<uint16_t *>(smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes);
     for (uint64_t c = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; c < a.n; c += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
-        const int need = 2 * 2 * ((4 * (int)a.nblk[c] + 72 + 7) & ~7);
+        const int need = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
         if (need <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, smem, lds_res, lane);
         else sw_one<false, TRACE>(a, c, smem, lds_res, lane);
     }
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
             steps = s_hi - s0 + 1;
             for (int d = dl; d <= dh; ++d) cells += (unsigned long long)(min(Lq - 1, Lt - 1 - d) - max(0, -d) + 1);
         }
-        const uint32_t nb = (uint32_t)((steps + 7) / 8);
+        const uint32_t nb = (uint32_t)((steps + 15) / 16);
         nblk[c] = nb;
         nblk64[c] = nb;
     }
@@ -258,10 +261,10 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     PEP_HIP(ctx, hipMemcpyAsync(&h_cells, cells, 8, hipMemcpyDeviceToHost, ctx->stream));
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) ctx->stats.cells_trace += h_cells; else ctx->stats.cells += h_cells;
-    ctx->stats.cells_swept += total_blk * 8 * 64;
+    ctx->stats.cells_swept += total_blk * 16 * 64;
     if (trace) {
-        ctx->stats.dir_bytes += total_blk * 256;
-        PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 256 + 256));
+        ctx->stats.dir_bytes += total_blk * 512;
+        PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 512 + 512));
     }
 
     SwArgs a;
@@ -274,8 +277,8 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     a.dirs = trace ? ctx->ws[13].as<uint32_t>() : nullptr; a.out = ctx->ws[12].as<int4>();
     a.oe = P.gap_open + P.gap_ext; a.ext = P.gap_ext;
     // per-wave staging window (u16 per residue, query + target), sized for the longest possible pair, capped at 8 KiB
-    const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 8 + 2;
-    const uint64_t want = 2 * 2 * ((4 * max_blk + 72 + 7) & ~7ull);
+    const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 16 + 2;
+    const uint64_t want = 2 * 2 * ((8 * max_blk + 72 + 7) & ~7ull);
     a.lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, (want + 255) & ~255ull) : 0;
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
     // enough blocks to fill the chip several times over; the grid-stride loop amortises the table load

@@ -59,8 +59,9 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
     run_cap[pos[c]] = 2ull * min(q_len[key_q(k)], t_len[key_t(k)]) + 2;
 }
 
-// one wavefront per selected pair; the walk itself is wave-uniform (scalar) work: a tile of 64 lanes x 8 steps
-// of traceback codes is fetched with one coalesced 256-byte load and decoded with v_readlane
+// one wavefront per selected pair; the walk itself is wave-uniform (scalar) work: a tile of 64 lanes x 16 steps
+// of traceback codes is fetched with one coalesced 512-byte load and decoded with v_readlane; diagonal runs are
+// followed inside one word (8 cells of one diagonal)
 __global__ __launch_bounds__(256) void walk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
                                             const uint64_t *__restrict__ dir_off, const uint32_t *__restrict__ dirs,
                                             const uint64_t *__restrict__ run_off, uint32_t *__restrict__ runs)
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void walk(uint64_t n_sel, SelInfo *__restrict_
     const uint64_t key = cands[info.cand];
     const int dlo = key_dlo(key);
     const int a0 = sw[info.cand].w;
-    const uint32_t *dir = dirs + dir_off[info.cand] * 64;
+    const uint2 *dir = reinterpret_cast<const uint2 *>(dirs) + dir_off[info.cand] * 64;
     uint32_t *out = runs + run_off[s];
 
     info.iend = sw[info.cand].y; info.jend = sw[info.cand].z;     // (the trace pass recomputes the same score)
@@ -80,41 +81,48 @@ __global__ __launch_bounds__(256) void walk(uint64_t n_sel, SelInfo *__restrict_
     int istart = i, jstart = j;
     uint32_t n_runs = 0, aln_len = 0, cur_op = 3, cur_len = 0;
     int cur_blk = -1;
-    uint32_t w_cur = 0, w_prev = 0;
+    uint2 w_cur = make_uint2(0, 0), w_prev = make_uint2(0, 0);
     for (;;) {
+        // cell (i, j): diagonal rel = lane*2 + parity; it is the (m & 7)-th cell of block m >> 3 of that diagonal
         const int rel = j - i - dlo;
-        const int m = i - a0 + (rel >> 1);
-        const int k = 2 * m + (rel & 1);
-        const int blk = k >> 3;
+        const int L = rel >> 1, par = rel & 1;
+        const int m = i - a0 + L;
+        const int blk = m >> 3;
         if (blk != cur_blk) {
             if (cur_blk >= 0 && blk == cur_blk - 1) w_cur = w_prev;
             else w_cur = dir[(size_t)blk * 64 + lane];
             cur_blk = blk;
             if (blk > 0) w_prev = dir[(size_t)(blk - 1) * 64 + lane];     // prefetch the tile the walk reaches next
         }
-        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)w_cur, __builtin_amdgcn_readfirstlane(rel >> 1));
-        const uint32_t nib = (word >> ((k & 7) * 4)) & 15u;
-        uint32_t op;
+        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)(par ? w_cur.y : w_cur.x), __builtin_amdgcn_readfirstlane(L));
+        int nidx = m & 7;
+        const uint32_t nib = (word >> (nidx * 4)) & 15u;
+        uint32_t op, cnt = 1;
         if (state == 0) {
             const uint32_t src = nib & 3u;
             if (src == 0) break;
             if (src != 1) { state = (src == 2) ? 1 : 2; continue; }
-            op = 0; istart = i; jstart = j;
+            // follow the diagonal inside this word: up to nidx + 1 cells, never past row 0 / column 0
+            const int lim = min(i, j);
+            int r = 0;
+            do { ++r; --nidx; } while (nidx >= 0 && r <= lim && ((word >> (nidx * 4)) & 3u) == 1u);
+            op = 0; cnt = (uint32_t)r;
+            istart = i - r + 1; jstart = j - r + 1;
         } else if (state == 1) {
             op = 2; state = (nib & 4u) ? 1 : 0;
         } else {
             op = 1; state = (nib & 8u) ? 2 : 0;
         }
-        ++aln_len;
-        if (op == cur_op) ++cur_len;
+        aln_len += cnt;
+        if (op == cur_op) cur_len += cnt;
         else {
             if (cur_len && lane == 0) out[n_runs] = (cur_len << 2) | cur_op;
             n_runs += cur_len ? 1 : 0;
-            cur_op = op; cur_len = 1;
+            cur_op = op; cur_len = cnt;
         }
         if (op == 0) {
-            if (i == 0 || j == 0) break;
-            --i; --j;
+            if ((int)cnt > min(i, j)) break;            // the last cell of the run lies on row 0 or column 0
+            i -= (int)cnt; j -= (int)cnt;
         } else if (op == 2) --j;
         else --i;
     }
