@@ -396,6 +396,10 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
             if (params->weight[s] < 1 || params->weight[s] > 32) return pep_fail(ctx, PEP_ERR_ARG, "invalid seed weight");
             if (params->offs[s][params->weight[s] - 1] > 31) return pep_fail(ctx, PEP_ERR_ARG, "seed span above 32");
             if (pow((double)params->base, params->weight[s]) > 34359738368.0) return pep_fail(ctx, PEP_ERR_ARG, "seed key does not fit 35 bits");
+            if (params->base > 15 || pow((double)params->base, (params->weight[s] + 1) / 2) > 4294967295.0)
+                return pep_fail(ctx, PEP_ERR_ARG, "reduced alphabet above 15 letters / half key above 32 bits");
+            for (int c = 0; c < 32; ++c)
+                if (params->reduce[c] != 0xFF && params->reduce[c] >= params->base) return pep_fail(ctx, PEP_ERR_ARG, "reduced letter outside the alphabet");
         }
         if (!(params->ka_lambda > 0.) || !(params->ka_k > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "invalid Karlin-Altschul parameters");
         if (params->xdrop < 0 || params->xdrop > 48 || params->ext_right < 1 || params->ext_right > 48 || params->ext_left < 0 || params->ext_left > 48)

@@ -17,8 +17,12 @@ struct SeedShape {
     int32_t weight;
     int32_t base;
     int32_t offs[32];
-    uint8_t reduce[32];
+    uint32_t red4[4];       // reduced letter of residue code c: nibble (c & 7) of red4[c >> 3]; 15 = never seeds
+    int32_t h1;             // the key is assembled as hi * base^h1 + lo with 32-bit halves
+    uint32_t pow_h1;
 };
+
+constexpr int TILE = 256, TILE_HALO = 32;
 
 constexpr uint64_t EMPTY = ~0ull;
 constexpr int POS_BITS = 29;
@@ -29,20 +33,27 @@ __device__ __forceinline__ uint32_t hash_u64(uint64_t k, int bits)
     return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64 - bits));
 }
 
-__device__ __forceinline__ bool seed_key(const SeedShape &sh, const uint8_t *__restrict__ res, uint64_t p, uint64_t &key)
+// reduced letters of one 256-position tile (+32 halo) into LDS: one coalesced pass, the reduction table lives in SGPRs
+__device__ __forceinline__ void stage_reduced(const SeedShape &sh, const uint8_t *__restrict__ res, uint64_t tile_base, uint64_t total, uint8_t *red)
 {
-    uint64_t k = 0, mul = 1;
-    bool ok = true;
-#pragma unroll 1
-    for (int i = 0; i < sh.weight; ++i) {
-        const uint8_t c = res[p + sh.offs[i]];
-        const uint8_t g = sh.reduce[c & 31];
-        ok = ok && (g != 0xFF);
-        k += mul * g;
-        mul *= (uint64_t)sh.base;
+    for (int x = threadIdx.x; x < TILE + TILE_HALO; x += TILE) {
+        const uint64_t p = tile_base + x;
+        const uint32_t c = (p < total ? res[p] : (uint8_t)PEP_PAD_CODE) & 31u;
+        const uint32_t w = (c & 16u) ? ((c & 8u) ? sh.red4[3] : sh.red4[2]) : ((c & 8u) ? sh.red4[1] : sh.red4[0]);
+        red[x] = (uint8_t)((w >> ((c & 7u) * 4u)) & 15u);
     }
-    key = k;
-    return ok;
+}
+
+// key of the seed starting at tile offset x: sum g_i * base^i, Horner over two 32-bit halves
+__device__ __forceinline__ bool tile_key(const SeedShape &sh, const uint8_t *red, int x, uint64_t &key)
+{
+    uint32_t lo = 0, hi = 0, bad = 0;
+#pragma unroll 1
+    for (int i = sh.h1 - 1; i >= 0; --i) { const uint32_t g = red[x + sh.offs[i]]; bad |= (g == 15u); lo = lo * (uint32_t)sh.base + g; }
+#pragma unroll 1
+    for (int i = sh.weight - 1; i >= sh.h1; --i) { const uint32_t g = red[x + sh.offs[i]]; bad |= (g == 15u); hi = hi * (uint32_t)sh.base + g; }
+    key = (uint64_t)hi * sh.pow_h1 + lo;
+    return bad == 0;
 }
 
 // largest i in [0, n) with off[i] <= p   (off[n] is a sentinel > every position)
@@ -58,19 +69,25 @@ __device__ __forceinline__ uint32_t find_seq(const uint32_t *__restrict__ off, u
 
 __global__ __launch_bounds__(256) void seed_count(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, uint32_t *__restrict__ cnt, int bucket_bits)
 {
-    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint8_t red[TILE + TILE_HALO];
+    stage_reduced(sh, res, (uint64_t)blockIdx.x * TILE, total, red);
+    __syncthreads();
+    const uint64_t p = (uint64_t)blockIdx.x * TILE + threadIdx.x;
     if (p + 32 > total) return;             // the trailing PEP_END_PAD bytes hold no residues
     uint64_t key;
-    if (seed_key(sh, res, p, key)) atomicAdd(&cnt[hash_u64(key, bucket_bits)], 1u);
+    if (tile_key(sh, red, threadIdx.x, key)) atomicAdd(&cnt[hash_u64(key, bucket_bits)], 1u);
 }
 
 __global__ __launch_bounds__(256) void seed_fill(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, const uint32_t *__restrict__ start,
                                                  uint32_t *__restrict__ fill, uint64_t *__restrict__ entries, int bucket_bits)
 {
-    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint8_t red[TILE + TILE_HALO];
+    stage_reduced(sh, res, (uint64_t)blockIdx.x * TILE, total, red);
+    __syncthreads();
+    const uint64_t p = (uint64_t)blockIdx.x * TILE + threadIdx.x;
     if (p + 32 > total) return;
     uint64_t key;
-    if (seed_key(sh, res, p, key)) {
+    if (tile_key(sh, red, threadIdx.x, key)) {
         const uint32_t b = hash_u64(key, bucket_bits);
         const uint32_t slot = start[b] + atomicAdd(&fill[b], 1u);
         entries[slot] = (key << POS_BITS) | p;
@@ -133,22 +150,40 @@ __device__ __forceinline__ bool set_contains(const JoinArgs &a, uint64_t k)
 
 // ungapped x-drop score of the diagonal through a seed hit, on PACKED positions: the >= 16 padding bytes around every
 // sequence score -64, which ends an extension exactly where the sequence ends (x-drop < 64), so no bounds are needed
-// Returns as soon as the threshold is reached (the outcome score >= ungapped_min is all that is used).
+// Returns as soon as the threshold is reached (only the outcome score >= ungapped_min is used).  The two 48-byte
+// windows per side are fetched with unaligned 16-byte loads up front, so a hit costs one memory latency instead of
+// one per residue; the loops are fully unrolled so that the windows stay in registers.
 __device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *sub, uint32_t qp, uint64_t tp)
 {
+    uint32_t qr[12], tr[12], ql[12], tl[12];
+    __builtin_memcpy(qr, a.q_res + qp, 48);
+    __builtin_memcpy(tr, a.t_res + tp, 48);
+    __builtin_memcpy(ql, a.q_res + qp - 48, 48);
+    __builtin_memcpy(tl, a.t_res + tp - 48, 48);
     int s = 0, br = 0, bl = 0;
-    for (int k = 0; k < a.ext_right; ++k) {
-        s += sub[(a.q_res[qp + k] & 31) * 32 + (a.t_res[tp + k] & 31)];
-        if (s > br) { br = s; if (br >= a.ungapped_min) return true; }
-        else if (br - s > a.xdrop) break;
+    bool live = true, pass = false;
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {
+        if (live && k < a.ext_right) {
+            const int qc = (qr[k >> 2] >> ((k & 3) * 8)) & 31, tc = (tr[k >> 2] >> ((k & 3) * 8)) & 31;
+            s += sub[qc * 32 + tc];
+            if (s > br) { br = s; if (br >= a.ungapped_min) { pass = true; live = false; } }
+            else if (br - s > a.xdrop) live = false;
+        }
     }
-    s = 0;
-    for (int k = 1; k <= a.ext_left; ++k) {
-        s += sub[(a.q_res[qp - k] & 31) * 32 + (a.t_res[tp - k] & 31)];
-        if (s > bl) { bl = s; if (br + bl >= a.ungapped_min) return true; }
-        else if (bl - s > a.xdrop) break;
+    if (pass) return true;
+    s = 0; live = true;
+#pragma unroll
+    for (int k = 1; k <= 48; ++k) {
+        if (live && k <= a.ext_left) {
+            const int b = 48 - k;                    // byte index inside the left window
+            const int qc = (ql[b >> 2] >> ((b & 3) * 8)) & 31, tc = (tl[b >> 2] >> ((b & 3) * 8)) & 31;
+            s += sub[qc * 32 + tc];
+            if (s > bl) { bl = s; if (br + bl >= a.ungapped_min) { pass = true; live = false; } }
+            else if (bl - s > a.xdrop) live = false;
+        }
     }
-    return false;
+    return pass;
 }
 
 // Phase 1 of the join (persistent, grid-stride over 256-position tiles): target seed keys are looked up in the
@@ -159,6 +194,7 @@ constexpr int HIT_BUF = 3072;
 __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
 {
     __shared__ uint64_t buf[HIT_BUF];
+    __shared__ uint8_t red[TILE + TILE_HALO];
     __shared__ uint32_t nbuf, blk_stats[2];
     __shared__ unsigned long long gbase;
     if (threadIdx.x == 0) { nbuf = 0; blk_stats[0] = blk_stats[1] = 0; }
@@ -169,7 +205,9 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
         const uint64_t p = tile * 256 + threadIdx.x;
         uint64_t key = 0;
         uint32_t e0 = 0, e1 = 0;
-        if (p + 32 <= a.t_total && seed_key(sh, a.t_res, p, key)) {
+        stage_reduced(sh, a.t_res, tile * TILE, a.t_total, red);
+        __syncthreads();
+        if (p + 32 <= a.t_total && tile_key(sh, red, threadIdx.x, key)) {
             ++n_seed;
             if (a.debug != 1) {
                 const uint32_t b = hash_u64(key, a.bucket_bits);
@@ -321,7 +359,15 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             SeedShape sh;
             sh.weight = P.weight[s];
             sh.base = P.base;
-            for (int i = 0; i < 32; ++i) { sh.offs[i] = P.offs[s][i]; sh.reduce[i] = P.reduce[i]; }
+            for (int i = 0; i < 32; ++i) sh.offs[i] = P.offs[s][i];
+            for (int w = 0; w < 4; ++w) sh.red4[w] = 0;
+            for (int c = 0; c < 32; ++c) {
+                const uint32_t g = P.reduce[c] == 0xFF ? 15u : (uint32_t)P.reduce[c];
+                sh.red4[c >> 3] |= g << ((c & 7) * 4);
+            }
+            sh.h1 = (sh.weight + 1) / 2;
+            sh.pow_h1 = 1;
+            for (int i = 0; i < sh.h1; ++i) sh.pow_h1 *= (uint32_t)sh.base;
             PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
             const unsigned qb = (unsigned)ceil_div(Q.total, 256), tb = (unsigned)ceil_div(T.total, 256);
             hipLaunchKernelGGL(seed_count, dim3(qb), dim3(256), 0, ctx->stream, sh, Q.res.as<const uint8_t>(), Q.total, cnt, bucket_bits);

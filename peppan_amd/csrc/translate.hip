@@ -139,13 +139,14 @@ __device__ __forceinline__ uint32_t find_seq(const uint32_t *__restrict__ off, u
 // one thread per byte of the packed layout (residue or padding)
 __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, int tab,
                                                const PackDesc *__restrict__ desc, const uint32_t *__restrict__ pk_off, uint32_t n_packed,
-                                               uint8_t *__restrict__ res, uint64_t total)
+                                               uint8_t *__restrict__ res, uint32_t *__restrict__ blk2seq, uint64_t total)
 {
     const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= total) return;
     uint8_t out = PEP_PAD_CODE;
     if (n_packed && p >= pk_off[0]) {
         const uint32_t s = find_seq(pk_off, n_packed, (uint32_t)p);
+        if ((p & 15) == 0) blk2seq[p >> 4] = s;        // sequence starts are 16-aligned: the block's owner (if any) is s
         const PackDesc d = desc[s];
         const uint32_t x = (uint32_t)p - pk_off[s];
         if (x < d.len) {
@@ -197,17 +198,18 @@ int pack_from_desc(pep_ctx *ctx, const NtSet &nt, int tab, const std::vector<Pac
     PEP_TRY(dev_reserve(ctx, out.off, (size_t)(n + 1) * 4));
     PEP_TRY(dev_reserve(ctx, out.len, (size_t)(n + 1) * 4));
     PEP_TRY(dev_reserve(ctx, d_desc, (size_t)(n + 1) * sizeof(PackDesc)));
+    PEP_TRY(dev_reserve(ctx, out.blk2seq, (pos / 16 + 2) * 4));
     PEP_HIP(ctx, hipMemcpyAsync(out.off.p, out.h_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     if (n) {
         PEP_HIP(ctx, hipMemcpyAsync(out.len.p, out.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         PEP_HIP(ctx, hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n * sizeof(PackDesc), hipMemcpyHostToDevice, ctx->stream));
     }
     hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div(pos, 256)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
-                       d_desc.as<const PackDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), pos);
+                       d_desc.as<const PackDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>(), pos);
     PEP_HIP(ctx, hipGetLastError());
     // the host vectors must outlive the async copies
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return pep_upload_blk2seq(ctx, out);
+    return PEP_OK;
 }
 
 }  // namespace

@@ -32,9 +32,10 @@ def allgather_hits(hits, cigar, q_base, group=None, device=None):
     import torch
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        out = hits.copy()
-        out['q'] += q_base
-        return out, cigar.copy()
+        if q_base:
+            hits = hits.copy()
+            hits['q'] += q_base
+        return hits, cigar
     world = dist.get_world_size(group)
     dev = device if device is not None else torch.device('cpu')
     mine = hits.copy()
