@@ -92,7 +92,7 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    acc = dict(candidates=0, cells=0, ms_sw=0.0, ms_seed=0.0, ms_trace=0.0, ms_k1=0.0, ms_total=0.0, hits=0, dir_bytes=0, tracebacks=0)
+    acc = dict(candidates=0, cells=0, cells_swept=0, ms_sw=0.0, ms_seed=0.0, ms_trace=0.0, ms_k1=0.0, ms_total=0.0, hits=0, dir_bytes=0, tracebacks=0)
     for _ in range(args.steps):
         hits, st, allh, labels = step()
         for k in acc:
@@ -140,6 +140,9 @@ def main():
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_sw', 'ms_trace', 'ms_total')},
             'roofline': {'bound': 'hbm', 'kernel': 'sw_kernel<false> (K5 banded Smith-Waterman, score pass)', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic,
+                         # what actually bounds it: 14 VALU instructions per 64-cell anti-diagonal step (ISA of sw_kernel<false>), each
+                         # occupying a SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles), 1024 SIMDs at 2.4 GHz
+                         'valu_issue_frac': (acc['cells_swept'] / K / 64) * 14 * 4 / (1024 * 2.4e9 * ms_sw * 1e-3),
                          'note': 'score-pass kernel sw_kernel<false>: integer-VALU-bound by construction (SURVEY 8d), measured at the VALU issue limit '
                                  '(14 VALU/step x 4 cycles); the separate traceback pass writes %.3g B/step of traceback codes' % (acc['dir_bytes'] / K) + traffic_note},
             'cpu_baseline': None,

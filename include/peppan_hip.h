@@ -104,10 +104,11 @@ typedef struct {
     uint64_t tracebacks;
     uint64_t hits;
     uint64_t cells;               /* in-band in-matrix DP cells over all candidates, score pass (SW cell updates) */
-    uint64_t cells_swept;         /* 64 lanes x anti-diagonal steps actually executed */
+    uint64_t cells_swept;         /* 64 lanes x anti-diagonal steps executed by the score pass */
     uint64_t dir_bytes;           /* traceback direction workspace written by the SW kernel */
     uint64_t sw_launches;
     uint64_t cells_trace;         /* DP cells recomputed by the traceback pass (selected pairs only) */
+    uint64_t cells_swept_trace;   /* 64 lanes x steps executed by the traceback pass */
     double ms_seed, ms_sw, ms_trace, ms_total;   /* HIP-event times on the context's stream; ms_sw = score pass kernel */
     double ms_k1, ms_sw_trace;                   /* ms_sw_trace = traceback-pass kernel (selected pairs only) */
 } pep_stats;

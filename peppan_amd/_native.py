@@ -31,7 +31,7 @@ class SearchParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ('query_residues', 'target_residues', 'query_seeds', 'target_seeds', 'seed_hits',
                                            'seed_hits_passed', 'candidates', 'pairs', 'tracebacks', 'hits', 'cells', 'cells_swept', 'dir_bytes',
-                                           'sw_launches', 'cells_trace')] + \
+                                           'sw_launches', 'cells_trace', 'cells_swept_trace')] + \
                [(n, C.c_double) for n in ('ms_seed', 'ms_sw', 'ms_trace', 'ms_total', 'ms_k1', 'ms_sw_trace')]
 
 

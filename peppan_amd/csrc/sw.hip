@@ -261,7 +261,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     PEP_HIP(ctx, hipMemcpyAsync(&h_cells, cells, 8, hipMemcpyDeviceToHost, ctx->stream));
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) ctx->stats.cells_trace += h_cells; else ctx->stats.cells += h_cells;
-    ctx->stats.cells_swept += total_blk * 16 * 64;
+    if (trace) ctx->stats.cells_swept_trace += total_blk * 16 * 64; else ctx->stats.cells_swept += total_blk * 16 * 64;
     if (trace) {
         ctx->stats.dir_bytes += total_blk * 512;
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 512 + 512));

@@ -371,3 +371,96 @@ def test_config1_1k_genes_cluster_membership_bit_exact(tmp_path, monkeypatch):
         part.setdefault(l, set()).add(i)
     assert {frozenset(v) for v in part.values() if len(v) > 1} == {frozenset(m) for _, m in g[3]}
     assert len(g[2]) > 300 and len(g[3]) > 100
+
+
+def test_full_size_10k_properties(ctx):
+    """BASELINE configs[2] size (10k genes x 1002 nt, all-vs-all): size-independent properties instead of the oracle"""
+    from peppan_amd import _native as N, synth, uberBlast as UB
+    names, seqs = synth.make_genes(10000, 1002, seed=355)
+    ctx.set_query_nt(seqs, 11)
+    ctx.set_ref_nt(seqs, 6, 11)
+    p = N.default_params(45., 25., 10, 5)
+    h1, c1, s1 = ctx.search(p)
+    h2, c2, s2 = ctx.search(N.default_params(45., 25., 10, 5, use_lds=0))      # global-memory residue path
+    ctx.translate(force=True)
+    h3, c3, s3 = ctx.search(p)                                                  # determinism across runs
+    for h, c in ((h2, c2), (h3, c3)):
+        assert np.array_equal(h1, h) and np.array_equal(c1, c)
+    assert len(h1) > 30000 and s1['candidates'] > 70000
+    qm, tm = ctx.query_meta(), ctx.target_meta()
+    # ordered by (q, t), at most top_k per (q, split)
+    key = h1['q'].astype(np.int64) * (1 << 32) + h1['t']
+    assert (np.diff(key) > 0).all()
+    per = np.bincount(h1['q'].astype(np.int64) * 5 + h1['t'] % 5)
+    assert per.max() <= 10
+    # CIGAR consistency for every hit
+    lens, ops = (c1 >> 2).astype(np.int64), c1 & 3
+    owner = np.repeat(np.arange(len(h1)), h1['cigar_runs'])
+    assert np.array_equal(np.bincount(owner, weights=lens * (ops != 2), minlength=len(h1)).astype(np.int64), h1['q_end'].astype(np.int64) - h1['q_start'] + 1)
+    assert np.array_equal(np.bincount(owner, weights=lens * (ops != 1), minlength=len(h1)).astype(np.int64), h1['t_end'].astype(np.int64) - h1['t_start'] + 1)
+    assert np.array_equal(np.bincount(owner, weights=lens, minlength=len(h1)).astype(np.int64), h1['aln_len'].astype(np.int64))
+    # every gene finds its own frame-1 translation: one M run over the whole protein, all identities, score = BLOSUM62 self score
+    self_hit = (tm['seq'][h1['t']] == h1['q']) & (tm['frame'][h1['t']] == qm['frame'][h1['q']])
+    assert self_hit.sum() == 10000
+    sh = h1[self_hit]
+    # (the final residue is the stop codon 'X', X-X scores -1, so the local alignment ends one residue earlier)
+    assert (sh['cigar_runs'] == 1).all() and (sh['n_ident'] == sh['aln_len']).all() and (sh['aln_len'] == qm['aa_len'][sh['q']] - 1).all()
+    assert (sh['q_start'] == 1).all() and (sh['t_start'] == 1).all()
+    qa, qo = ctx.query_aa()
+    diag = np.array(list(p.sub), dtype=np.int64).reshape(32, 32).diagonal()
+    cum = np.concatenate([[0], np.cumsum(diag[qa])])
+    assert np.array_equal(sh['score'].astype(np.int64), cum[qo[sh['q'] + 1].astype(np.int64) - 1] - cum[qo[sh['q']].astype(np.int64)])
+    # union-find: labels are canonical (smallest member), idempotent, and each family of 4 ends up together or split, never mixed
+    genes_t = tm['seq'][h1['t']]
+    lab = ctx.components(10000, h1['q'], genes_t)
+    assert np.array_equal(lab[lab], lab) and (lab <= np.arange(10000)).all()
+    assert np.array_equal(ctx.components(10000, np.arange(10000), lab), lab)
+    assert (lab // 4 == np.arange(10000) // 4).all()
+
+
+def _shard_worker(rank, world, port, out_q):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import numpy as np
+    import torch.distributed as dist
+    from peppan_amd import _native as N, synth, dist as pdist
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    names, seqs = synth.make_genes(600, 0, seed=91)
+    b = pdist.shard_bounds([len(s) for s in seqs], world)
+    with N.Context(0) as ctx:                     # both ranks share the one GPU of the test box; on a node each has its own
+        ctx.set_query_nt(seqs[b[rank]:b[rank + 1]], 11)
+        ctx.set_ref_nt(seqs, 6, 11)
+        hits, cig, st = ctx.search(N.default_params(45., 25., 10, 5))
+        allh, allc = pdist.allgather_hits(hits, cig, b[rank])
+        lab = ctx.components(len(seqs), allh['q'], ctx.target_meta()['seq'][allh['t']])
+    out_q.put((rank, allh.tobytes(), allc.tobytes(), lab.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_query_sharded_search_equals_single_gpu(ctx):
+    """N>1 path end to end: two ranks (gloo transport, one shared GPU here) shard the queries, all-gather their hit
+    tables, and every rank ends with exactly the single-process table and the same clusters"""
+    import socket
+    import torch.multiprocessing as mp
+    from peppan_amd import _native as N, synth
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context('spawn')
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    names, seqs = synth.make_genes(600, 0, seed=91)
+    ctx.set_query_nt(seqs, 11)
+    ctx.set_ref_nt(seqs, 6, 11)
+    h, c, st = ctx.search(N.default_params(45., 25., 10, 5))
+    lab = ctx.components(len(seqs), h['q'], ctx.target_meta()['seq'][h['t']])
+    for rank, hb, cb, lb in res:
+        gh = np.frombuffer(hb, dtype=N.HIT_DTYPE)
+        assert np.array_equal(gh, h) and np.array_equal(np.frombuffer(cb, dtype=np.uint32), c)
+        assert np.array_equal(np.frombuffer(lb, dtype=np.uint32), lab)
+    assert len(h) > 1000
