@@ -136,26 +136,35 @@ __device__ __forceinline__ uint32_t find_seq(const uint32_t *__restrict__ off, u
     return lo;
 }
 
-// one thread per byte of the packed layout (residue or padding)
+// one thread per 16-byte block of the packed layout: sequence starts are 16-aligned and separated by >= 16 padding
+// bytes, so a block belongs to at most one sequence -> one owner search and one 16-byte store per thread
 __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, int tab,
                                                const PackDesc *__restrict__ desc, const uint32_t *__restrict__ pk_off, uint32_t n_packed,
                                                uint8_t *__restrict__ res, uint32_t *__restrict__ blk2seq, uint64_t total)
 {
-    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= total) return;
-    uint8_t out = PEP_PAD_CODE;
-    if (n_packed && p >= pk_off[0]) {
-        const uint32_t s = find_seq(pk_off, n_packed, (uint32_t)p);
-        if ((p & 15) == 0) blk2seq[p >> 4] = s;        // sequence starts are 16-aligned: the block's owner (if any) is s
+    const uint64_t blk = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t p0 = blk * 16;
+    if (p0 >= total) return;
+    uint32_t w[4] = {0x1F1F1F1Fu, 0x1F1F1F1Fu, 0x1F1F1F1Fu, 0x1F1F1F1Fu};      // PEP_PAD_CODE x 16
+    if (n_packed && p0 >= pk_off[0]) {
+        const uint32_t s = find_seq(pk_off, n_packed, (uint32_t)p0);
+        blk2seq[blk] = s;
         const PackDesc d = desc[s];
-        const uint32_t x = (uint32_t)p - pk_off[s];
-        if (x < d.len) {
+        const uint32_t x0 = (uint32_t)p0 - pk_off[s];
+        if (x0 < d.len) {
             const uint8_t *src = nt + nt_off[d.seq];
             const int64_t L = (int64_t)(nt_off[d.seq + 1] - nt_off[d.seq]);
-            out = (uint8_t)translate_at(src, L, (int)d.frame, (int64_t)d.aa_off + x, tab, nullptr);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (x0 + k < d.len) {
+                    const uint32_t c = (uint32_t)translate_at(src, L, (int)d.frame, (int64_t)d.aa_off + x0 + k, tab, nullptr);
+                    w[k >> 2] = (w[k >> 2] & ~(0xFFu << ((k & 3) * 8))) | (c << ((k & 3) * 8));
+                }
+            }
         }
     }
-    res[p] = out;
+    if (p0 + 16 <= total) *reinterpret_cast<uint4 *>(res + p0) = make_uint4(w[0], w[1], w[2], w[3]);
+    else for (uint64_t k = 0; p0 + k < total; ++k) res[p0 + k] = (uint8_t)(w[k >> 2] >> ((k & 3) * 8));
 }
 
 void fill_codon_table(uint8_t tab[2][64])
@@ -204,7 +213,7 @@ int pack_from_desc(pep_ctx *ctx, const NtSet &nt, int tab, const std::vector<Pac
         PEP_HIP(ctx, hipMemcpyAsync(out.len.p, out.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         PEP_HIP(ctx, hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n * sizeof(PackDesc), hipMemcpyHostToDevice, ctx->stream));
     }
-    hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div(pos, 256)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
+    hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div(ceil_div(pos, 16), 256)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
                        d_desc.as<const PackDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>(), pos);
     PEP_HIP(ctx, hipGetLastError());
     // the host vectors must outlive the async copies
