@@ -46,7 +46,7 @@ def main():
     ap.add_argument('--genes', type=int, default=10000)
     ap.add_argument('--gene-len', type=int, default=1002)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=150)
+    ap.add_argument('--cpu-sample', type=int, default=1000)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -92,7 +92,7 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    acc = dict(candidates=0, cells=0, cells_swept=0, ms_sw=0.0, ms_seed=0.0, ms_trace=0.0, ms_k1=0.0, ms_total=0.0, hits=0, dir_bytes=0, tracebacks=0)
+    acc = dict(candidates=0, cells=0, cells_swept=0, ms_sw_trace=0.0, ms_sw=0.0, ms_seed=0.0, ms_trace=0.0, ms_k1=0.0, ms_total=0.0, hits=0, dir_bytes=0, tracebacks=0)
     for _ in range(args.steps):
         hits, st, allh, labels = step()
         for k in acc:
@@ -121,7 +121,7 @@ def main():
         traffic, traffic_note = None, ''
         tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
         if os.path.exists(tfile) and args.genes == 10000 and args.gene_len == 1002 and world == 1:
-            k = json.load(open(tfile))['kernels'].get('sw_kernel<false>')
+            k = json.load(open(tfile))['kernels'].get('sw_score_kernel')
             if k:
                 # rocprofv3 PMC passes of the same workload (profiles/r01_pmc_hbm_traffic.txt): FETCH_SIZE is doubled per the gfx950
                 # correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE matched the known output bytes exactly
@@ -137,14 +137,16 @@ def main():
             'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3),
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
             'hits_per_step': acc['hits'] / K, 'clusters': int(len(np.unique(labels))),
-            'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_sw', 'ms_trace', 'ms_total')},
-            'roofline': {'bound': 'hbm', 'kernel': 'sw_kernel<false> (K5 banded Smith-Waterman, score pass)', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
+            'phase_ms': {k: acc[k] / K for k in ('ms_seed', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
+            'roofline': {'bound': 'hbm', 'kernel': 'sw_score_kernel (K5 banded Smith-Waterman, score pass over all candidate pairs)', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic,
-                         # what actually bounds it: 14 VALU instructions per 64-cell anti-diagonal step (ISA of sw_kernel<false>), each
-                         # occupying a SIMD for 4 cycles (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles), 1024 SIMDs at 2.4 GHz
-                         'valu_issue_frac': (acc['cells_swept'] / K / 64) * 14 * 4 / (1024 * 2.4e9 * ms_sw * 1e-3),
-                         'note': 'score-pass kernel sw_kernel<false>: integer-VALU-bound by construction (SURVEY 8d), measured at the VALU issue limit '
-                                 '(14 VALU/step x 4 cycles); the separate traceback pass writes %.3g B/step of traceback codes' % (acc['dir_bytes'] / K) + traffic_note},
+                         # what actually bounds it: 145 VALU instructions per 16 candidate-steps of 64 cells (ISA of sw_score_kernel's
+                         # packed 16-bit loop body), each occupying a SIMD for 4 cycles (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU
+                         # quad-cycles), 1024 SIMDs at 2.4 GHz
+                         'valu_issue_frac': (acc['cells_swept'] / K / 64) * (145. / 16.) * 4 / (1024 * 2.4e9 * ms_sw * 1e-3),
+                         'note': 'integer-VALU-bound by construction (SURVEY 8d): valu_issue_frac = share of the VALU issue ceiling; the traceback '
+                                 'pass sw_kernel<true> (selected pairs only) is a second launch that writes %.3g B of traceback codes in %.2f ms '
+                                 '= %.0f GB/s' % (acc['dir_bytes'] / K, acc['ms_sw_trace'] / K, acc['dir_bytes'] / K / (acc['ms_sw_trace'] / K * 1e-3) / 1e9) + traffic_note},
             'cpu_baseline': None,
         }
         if not args.no_cpu_baseline:
