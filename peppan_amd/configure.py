@@ -66,12 +66,15 @@ def readFasta(fasta, headOnly=False):
     return {n: ''.join(chunks[n]).upper() for n in chunks}
 
 
-def readFastq(fastq):
-    """FASTQ or FASTA -> (sequences, qualities); FASTA input gets 'I'/'!' pseudo-qualities like the reference"""
+def readFastq(fastq, with_qual=True):
+    """FASTQ or FASTA -> (sequences, qualities); FASTA input gets 'I'/'!' pseudo-qualities like the reference.
+    with_qual=False skips building them (nothing on the search path reads qualities; they cost more than the search)."""
     with uopen(fastq) as fin:
         first = fin.readline()
     if not first.startswith('@'):
         seq = readFasta(fastq)
+        if not with_qual:
+            return seq, None
         return seq, {n: re.sub(r'[^!]', 'I', re.sub(r'[^ACGTacgt]', '!', s)) for n, s in seq.items()}
     seq, qual = {}, {}
     with uopen(fastq) as fin:

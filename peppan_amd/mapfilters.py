@@ -83,8 +83,9 @@ def _pair_score(m1, m2, span1, span2, overlap):
 
 def _merge_one_query(matches, gap_dist, len_diff):
     """all hits of ONE query gene, sorted by (reference, folded start, query start): chain collinear neighbours"""
-    extra = pd.Series(data=[[]] * matches.shape[0])
-    matches = np.hstack([matches, extra.values[:, np.newaxis]])
+    extra = np.empty((matches.shape[0], 1), dtype=object)
+    extra.fill([])                                  # one shared empty list, as pd.Series([[]] * n) gives the reference
+    matches = np.hstack([matches, extra])
     tail = 20
     n = len(matches)
     groups = []

@@ -249,9 +249,9 @@ class RunBlast(object):
     # ---------------------------------------------------------------------------------------------- inputs
     def _load(self, ref, qry):
         if not self.qrySeq:
-            self.qrySeq, self.qryQual = readFastq(qry)
+            self.qrySeq, self.qryQual = readFastq(qry, with_qual=False)
         if not self.refSeq:
-            self.refSeq, self.refQual = readFastq(ref)
+            self.refSeq, self.refQual = readFastq(ref, with_qual=False)
 
     def _ensure_nt(self, ctx, frames):
         """sorted(name) order is the order in which the reference writes its FASTA files (uberBlast.py:527, 537),
