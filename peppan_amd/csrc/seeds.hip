@@ -122,7 +122,7 @@ __device__ __forceinline__ void set_insert(const JoinArgs &a, uint64_t k)
 {
     const uint32_t mask = (1u << a.table_bits) - 1;
     uint32_t slot = hash_u64(k, a.table_bits);
-    for (uint32_t probe = 0; probe <= mask; ++probe) {
+    for (uint32_t probe = 0; probe < 256 && probe <= mask; ++probe) {
         const uint64_t cur = a.table[slot];
         if (cur == k) return;
         if (cur == EMPTY) {
@@ -139,7 +139,7 @@ __device__ __forceinline__ bool set_contains(const JoinArgs &a, uint64_t k)
 {
     const uint32_t mask = (1u << a.table_bits) - 1;
     uint32_t slot = hash_u64(k, a.table_bits);
-    for (uint32_t probe = 0; probe <= mask; ++probe) {
+    for (uint32_t probe = 0; probe < 256 && probe <= mask; ++probe) {
         const uint64_t cur = a.table[slot];
         if (cur == k) return true;
         if (cur == EMPTY) return false;          // possibly stale: the caller then extends and inserts with a CAS
@@ -266,6 +266,7 @@ __global__ __launch_bounds__(256) void seed_extend(JoinArgs a)
     if (n_hits > a.hit_cap) n_hits = a.hit_cap;
     uint32_t n_pass = 0;
     for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < n_hits; h += (uint64_t)gridDim.x * 256) {
+        if (*reinterpret_cast<volatile uint32_t *>(&a.counters[1])) break;      // the set overflowed: this attempt is void anyway
         const uint64_t hit = a.hits[h];
         const uint32_t qp = (uint32_t)(hit >> 32), p = (uint32_t)hit;
         const uint32_t t = a.t_blk2seq[p >> 4], q = a.q_blk2seq[qp >> 4];
@@ -341,7 +342,8 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     PEP_TRY(dev_reserve(ctx, ctx->d_params, 1024));
     PEP_HIP(ctx, hipMemcpyAsync(ctx->d_params.p, P.sub, 1024, hipMemcpyHostToDevice, ctx->stream));
 
-    int table_bits = 20;
+    // candidate set: start near 64 slots per query (chance hits grow with |Q| x |T|), grow x4 on overflow
+    int table_bits = std::max(20, std::min(28, ilog2_ceil(64ull * Q.n)));
     uint64_t hit_cap = std::max<uint64_t>(1ull << 22, 2 * T.total);
     unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(counters + 12);
     for (int attempt = 0; attempt < 8; ++attempt) {
