@@ -266,7 +266,6 @@ __global__ __launch_bounds__(256) void seed_extend(JoinArgs a)
     if (n_hits > a.hit_cap) n_hits = a.hit_cap;
     uint32_t n_pass = 0;
     for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < n_hits; h += (uint64_t)gridDim.x * 256) {
-        if (*reinterpret_cast<volatile uint32_t *>(&a.counters[1])) break;      // the set overflowed: this attempt is void anyway
         const uint64_t hit = a.hits[h];
         const uint32_t qp = (uint32_t)(hit >> 32), p = (uint32_t)hit;
         const uint32_t t = a.t_blk2seq[p >> 4], q = a.q_blk2seq[qp >> 4];

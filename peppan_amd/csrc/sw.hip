@@ -412,6 +412,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     a.lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, ((a.pk16 ? 2 * want : want) + 255) & ~255ull) : 0;
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
     // enough blocks to fill the chip several times over; the grid-stride loop amortises the table load
+    // several times more blocks than fit at once: blocks that finish early are replaced, which balances uneven items
     const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(trace ? n : (n + 1) / 2, WAVES_PER_BLOCK), 256ull * 8);
     hipEvent_t e0, e1;
     PEP_HIP(ctx, hipEventCreate(&e0));
