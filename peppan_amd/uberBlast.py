@@ -43,6 +43,20 @@ def _make_gtable():
 gtable = _make_gtable()
 
 _CTX = {}
+_FASTA_CACHE = {}
+
+
+def _read_cached(path):
+    """sequences of a FASTA/FASTQ file, re-parsed only when the file changed: PEPPAN maps the SAME gene file against
+    every genome (PEPPAN.py:768-772), one uberBlast call per genome"""
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
+    hit = _FASTA_CACHE.get(key)
+    if hit is None:
+        if len(_FASTA_CACHE) >= 4:
+            _FASTA_CACHE.clear()
+        hit = _FASTA_CACHE[key] = readFastq(path, with_qual=False)[0]
+    return dict(hit)         # callers may mutate their copy (the reference's reScore does, uberBlast.py:402-405)
 
 
 def get_context(device=None):
@@ -249,9 +263,9 @@ class RunBlast(object):
     # ---------------------------------------------------------------------------------------------- inputs
     def _load(self, ref, qry):
         if not self.qrySeq:
-            self.qrySeq, self.qryQual = readFastq(qry, with_qual=False)
+            self.qrySeq, self.qryQual = _read_cached(qry), None
         if not self.refSeq:
-            self.refSeq, self.refQual = readFastq(ref, with_qual=False)
+            self.refSeq, self.refQual = _read_cached(ref), None
 
     def _ensure_nt(self, ctx, frames):
         """sorted(name) order is the order in which the reference writes its FASTA files (uberBlast.py:527, 537),
