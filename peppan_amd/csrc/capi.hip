@@ -267,7 +267,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto &b : ctx->ws) dev_release(b);
-    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->d_t_meta, &ctx->d_q_meta, &ctx->d_min_score, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
+    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->d_min_score, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -322,19 +322,10 @@ int pep_translate(pep_ctx *ctx, int force)
 {
     if (!ctx) return PEP_ERR_ARG;
     PEP_HIP(ctx, hipSetDevice(ctx->device));
-    hipEvent_t e0, e1;
-    PEP_HIP(ctx, hipEventCreate(&e0));
-    PEP_HIP(ctx, hipEventCreate(&e1));
-    PEP_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    EventTimer timer(ctx->stream);
     if (ctx->q_from_nt && (force || !ctx->q_ready)) { PEP_TRY(pep_k1_query(ctx, ctx->q_gtable)); ctx->q_ready = true; }
     if (ctx->t_from_nt && (force || !ctx->t_ready)) { PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable)); ctx->t_ready = true; }
-    PEP_HIP(ctx, hipEventRecord(e1, ctx->stream));
-    PEP_HIP(ctx, hipEventSynchronize(e1));
-    float ms = 0.f;
-    PEP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    ctx->stats.ms_k1 = ms;
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    ctx->stats.ms_k1 = timer.stop();
     return PEP_OK;
 }
 
@@ -420,26 +411,19 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     ctx->stats.query_residues = ctx->q.residues;
     ctx->stats.target_residues = ctx->t.residues;
 
-    hipEvent_t e0, e1, e2;
-    hipEventCreate(&e0); hipEventCreate(&e1); hipEventCreate(&e2);
-    hipEventRecord(e0, ctx->stream);
+    EventTimer t_seed(ctx->stream), t_total(ctx->stream);
     uint64_t *d_cands = nullptr, n_cands = 0;
     int rc = pep_find_candidates(ctx, &d_cands, &n_cands);
-    hipEventRecord(e1, ctx->stream);
+    const float ms_seed = t_seed.stop();
     if (rc == PEP_OK) {
         std::vector<int32_t> min_score(ctx->q.n + 1);
         for (uint32_t i = 0; i < ctx->q.n; ++i) min_score[i] = pep_min_score_ka(ctx->q.h_len[i], ctx->params.dbsize, ctx->params.max_evalue, ctx->params.ka_lambda, ctx->params.ka_k);
         rc = pep_extend(ctx, d_cands, n_cands, min_score.data(), res);
     }
-    hipEventRecord(e2, ctx->stream);
-    hipError_t se = hipStreamSynchronize(ctx->stream);
+    const float ms_all = t_total.stop();
+    const hipError_t se = hipStreamSynchronize(ctx->stream);
     if (rc == PEP_OK && se != hipSuccess) rc = pep_fail(ctx, PEP_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
-    float a = 0.f, b = 0.f;
-    if (rc == PEP_OK) {
-        hipEventElapsedTime(&a, e0, e1);
-        hipEventElapsedTime(&b, e0, e2);
-    }
-    hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+    const float a = ms_seed, b = ms_all;
     if (rc != PEP_OK) { delete res; return rc; }
     ctx->stats.ms_seed = a;
     ctx->stats.ms_total = b;

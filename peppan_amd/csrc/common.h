@@ -10,11 +10,6 @@
 
 #define PEP_WAVE 64
 
-struct PepError {
-    int code;
-    std::string msg;
-};
-
 #define PEP_HIP(ctx, expr)                                                                            \
     do {                                                                                              \
         hipError_t _e = (expr);                                                                       \
@@ -74,7 +69,6 @@ struct pep_ctx {
     SeqSet q, t;
     std::vector<pep_query_meta> q_meta;     // frame chosen per query (K1)
     std::vector<pep_target_meta> t_meta;    // (seq, frame, chunk offset, length) per target (K1)
-    DevBuf d_t_meta, d_q_meta;
     bool q_from_nt = false, t_from_nt = false;
     bool q_ready = false, t_ready = false, sub_ready = false;
     int q_gtable = 11, t_gtable = 11, t_frames = 6;
@@ -92,6 +86,32 @@ struct pep_result {
     std::vector<pep_hit> hits;
     std::vector<uint32_t> cigar;
     pep_stats stats;
+};
+
+// HIP-event stopwatch on one stream (the kernel times bench.py reports are taken with it, inside the library,
+// on the stream the kernels are launched on); destroys its events on every exit path
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st;
+    explicit EventTimer(hipStream_t s) : st(s)
+    {
+        if (hipEventCreate(&a) != hipSuccess) a = nullptr;
+        if (hipEventCreate(&b) != hipSuccess) b = nullptr;
+        if (a) (void)hipEventRecord(a, st);
+    }
+    float stop()                      // records the end event, waits for it, returns milliseconds (0 on failure)
+    {
+        float ms = 0.f;
+        if (a && b && hipEventRecord(b, st) == hipSuccess && hipEventSynchronize(b) == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
+        return ms;
+    }
+    ~EventTimer()
+    {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+    EventTimer(const EventTimer &) = delete;
+    EventTimer &operator=(const EventTimer &) = delete;
 };
 
 int pep_fail(pep_ctx *ctx, int code, const std::string &msg);

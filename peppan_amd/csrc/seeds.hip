@@ -56,17 +56,6 @@ __device__ __forceinline__ bool tile_key(const SeedShape &sh, const uint8_t *red
     return bad == 0;
 }
 
-// largest i in [0, n) with off[i] <= p   (off[n] is a sentinel > every position)
-__device__ __forceinline__ uint32_t find_seq(const uint32_t *__restrict__ off, uint32_t n, uint32_t p)
-{
-    uint32_t lo = 0, hi = n;
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (off[mid] <= p) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
 __global__ __launch_bounds__(256) void seed_count(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, uint32_t *__restrict__ cnt, int bucket_bits)
 {
     __shared__ uint8_t red[TILE + TILE_HALO];

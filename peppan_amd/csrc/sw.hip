@@ -414,18 +414,12 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     // enough blocks to fill the chip several times over; the grid-stride loop amortises the table load
     // several times more blocks than fit at once: blocks that finish early are replaced, which balances uneven items
     const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(trace ? n : (n + 1) / 2, WAVES_PER_BLOCK), 256ull * 8);
-    hipEvent_t e0, e1;
-    PEP_HIP(ctx, hipEventCreate(&e0));
-    PEP_HIP(ctx, hipEventCreate(&e1));
-    PEP_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    EventTimer timer(ctx->stream);
     if (trace) hipLaunchKernelGGL(sw_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     else hipLaunchKernelGGL(sw_score_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
-    PEP_HIP(ctx, hipEventRecord(e1, ctx->stream));
     PEP_HIP(ctx, hipGetLastError());
-    PEP_HIP(ctx, hipEventSynchronize(e1));
-    PEP_HIP(ctx, hipEventElapsedTime(ms_kernel, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    *ms_kernel = timer.stop();
+    PEP_HIP(ctx, hipGetLastError());
     ctx->stats.sw_launches += 1;
     return PEP_OK;
 }

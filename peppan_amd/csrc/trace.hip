@@ -247,10 +247,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     PEP_TRY(pep_sw_run(ctx, d_cands, n, false, &ms_sw));
     ctx->stats.ms_sw = ms_sw;
 
-    hipEvent_t e0, e1;
-    PEP_HIP(ctx, hipEventCreate(&e0));
-    PEP_HIP(ctx, hipEventCreate(&e1));
-    PEP_HIP(ctx, hipEventRecord(e0, st));
+    EventTimer timer(st);
 
     const int4 *sw = ctx->ws[12].as<const int4>();
     PEP_TRY(dev_reserve(ctx, ctx->ws[16], (n + 1) * 4));
@@ -325,13 +322,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
             if (n_cig) PEP_HIP(ctx, hipMemcpyAsync(res->cigar.data(), d_cig, n_cig * 4, hipMemcpyDeviceToHost, st));
         }
     }
-    PEP_HIP(ctx, hipEventRecord(e1, st));
-    PEP_HIP(ctx, hipEventSynchronize(e1));
-    float ms = 0.f;
-    PEP_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
-    ctx->stats.ms_trace = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    ctx->stats.ms_trace = timer.stop();
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }
