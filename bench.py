@@ -23,10 +23,13 @@ def cpu_baseline(nts, n_sample, min_id, min_qcov):
     """CPU oracle (scalar C port, 1 thread) timed on a bounded sample of the same workload: the first
     n_sample queries against the whole reference.  Reported beside the GPU number, never the target."""
     from oracle import oracle as O
-    q_aa = [O.aa_codes(O.query_frame(s.decode(), 11)[1].replace('-', 'X')) for s in nts[:n_sample]]
+    from peppan_amd.configure import transeq          # numpy translation (pinned to the same golden vectors as the oracle's)
+    q_aa = []
+    for n, frames in transeq([[i, s.decode()] for i, s in enumerate(nts[:n_sample])], frame='F', transl_table=11):
+        q_aa.append(O.aa_codes(min((f[:-1].count('X'), k, f) for k, f in enumerate(frames))[2].replace('-', 'X')))
     t_aa = []
-    for s in nts:
-        for aa in O.translate_frames(s.decode(), range(1, 7), 11):
+    for n, frames in transeq([[i, s.decode()] for i, s in enumerate(nts)], frame='7', transl_table=11):
+        for aa in frames:
             t_aa += [O.aa_codes(c.replace('-', 'X')) for o, c in O.ref_chunks(aa)]
     t0 = time.perf_counter()
     hits, cig, st = O.search(q_aa, t_aa, O.default_params(min_id, min_qcov, 10, 5))
