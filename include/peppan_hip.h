@@ -70,6 +70,9 @@ typedef struct {
     int32_t reserved[3];          /* profiling/test switches, 0 in production: [0] seed-join stage limiter (1 keys, 2 +buckets, 3 +entries),
                                      [1] != 0 forces the 32-bit score pass instead of the packed 16-bit one */
     double ka_lambda, ka_k;       /* Karlin-Altschul parameters of the scoring system (protein default 0.267 / 0.041) */
+    int32_t hsp_mode;             /* 0: one alignment per (q, t), its best band (diamond --max-hsps 1); 1: every band reaching the
+                                     score threshold, duplicates (same end cell) removed - several copies on one subject */
+    int32_t pad0;
 } pep_search_params;
 
 /* one alignment; coordinates are 1-based, inclusive, in residues of the query / target protein */

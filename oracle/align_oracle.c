@@ -62,6 +62,9 @@ typedef struct {
     int32_t xdrop;         /* x-drop of the ungapped extension */
     int32_t ext_right;     /* max residues scored to the right, starting at the seed's first position */
     int32_t ext_left;      /* max residues scored to the left of the seed's first position */
+    int32_t hsp_mode;      /* 0: one alignment per (q, t) = its best band (diamond --max-hsps 1);
+                              1: every band of (q, t) that reaches min_score, minus duplicates (same end cell: keep the
+                                 higher score, then the lower bin) - the nucleotide tool, where a subject can carry several copies */
 } oracle_params;
 
 typedef struct {
@@ -356,8 +359,11 @@ static int cmp_hit_rank(const void *a, const void *b)
 {
     const oracle_hit *x = *(const oracle_hit *const *)a, *y = *(const oracle_hit *const *)b;
     if (x->score != y->score) return x->score > y->score ? -1 : 1;
-    return x->t < y->t ? -1 : (x->t > y->t);
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->bin < y->bin ? -1 : (x->bin > y->bin);
 }
+
+typedef struct { int32_t bin, score, iend, jend, is, js; uint32_t nid, al, nruns; uint64_t cells; uint32_t *runs; int dead; } band_aln;
 
 /* full search.  q_off/t_off have n+1 entries (plain concatenation, no padding).
  * min_score[nq] per query.  Returns 0; caller frees *hits and *cigar with oracle_free. */
@@ -366,12 +372,12 @@ int oracle_search(const oracle_params *p,
                   const uint8_t *t_res, const uint64_t *t_off, uint32_t nt,
                   const int32_t *min_score,
                   oracle_hit **hits_out, uint64_t *n_hits, uint32_t **cigar_out, uint64_t *n_cigar,
-                  uint64_t *stats /* [0]=candidates [1]=cells over all candidates [2]=pairs after best-per-(q,t) */)
+                  uint64_t *stats /* [0]=candidates [1]=cells over all candidates [2]=(q,t) pairs [3]=tracebacks */)
 {
     uint64_t nc = 0;
     uint64_t *cand = find_candidates(p, q_res, q_off, nq, t_res, t_off, nt, &nc);
     oracle_hit *hits = malloc((nc + 1) * sizeof(oracle_hit));
-    uint32_t *cig = NULL; uint64_t ncig = 0, capcig = 0, nh = 0, cells_all = 0, pairs = 0;
+    uint32_t *cig = NULL; uint64_t ncig = 0, capcig = 0, nh = 0, cells_all = 0, pairs = 0, traced = 0;
     runbuf rb = {0};
     uint64_t g0 = 0;
     while (g0 < nc) {
@@ -390,23 +396,64 @@ int oracle_search(const oracle_params *p,
             if (o.score > best) { best = o.score; best_bin = bin; }
         }
         ++pairs;
-        if (best > 0 && best >= min_score[q]) {
-            int32_t dlo = best_bin * BIN_W - DIAG_OFF - BAND_LEAD;
-            sw_out o;
-            banded_sw(p, qs, Lq, ts, Lt, dlo, 1, &o);
-            int32_t is, js; uint32_t nid, al;
-            traceback(&o, qs, ts, dlo, &rb, &is, &js, &nid, &al);
-            free(o.dir);
-            double idp = (double)nid * 100.0 / (double)al;
-            double qcov = (double)(o.iend - is + 1) * 100.0 / (double)Lq;
-            if (idp >= p->min_id_pct && qcov >= p->min_qcov_pct) {
-                oracle_hit *h = &hits[nh++];
-                h->q = q; h->t = t; h->q_start = is + 1; h->q_end = o.iend + 1; h->t_start = js + 1; h->t_end = o.jend + 1;
-                h->score = o.score; h->n_ident = nid; h->aln_len = al; h->nm = al - nid; h->bin = best_bin;
-                h->cigar_runs = rb.n; h->cigar_off = ncig; h->cells = o.cells;
-                if (ncig + rb.n > capcig) { capcig = (ncig + rb.n) * 2 + 64; cig = realloc(cig, capcig * sizeof(uint32_t)); }
-                for (uint32_t r = 0; r < rb.n; ++r) cig[ncig++] = rb.runs[rb.n - 1 - r];
+        if (p->hsp_mode == 0) {
+            if (best > 0 && best >= min_score[q]) {
+                int32_t dlo = best_bin * BIN_W - DIAG_OFF - BAND_LEAD;
+                sw_out o;
+                banded_sw(p, qs, Lq, ts, Lt, dlo, 1, &o);
+                int32_t is, js; uint32_t nid, al;
+                traceback(&o, qs, ts, dlo, &rb, &is, &js, &nid, &al);
+                free(o.dir);
+                ++traced;
+                double idp = (double)nid * 100.0 / (double)al;
+                double qcov = (double)(o.iend - is + 1) * 100.0 / (double)Lq;
+                if (idp >= p->min_id_pct && qcov >= p->min_qcov_pct) {
+                    oracle_hit *h = &hits[nh++];
+                    h->q = q; h->t = t; h->q_start = is + 1; h->q_end = o.iend + 1; h->t_start = js + 1; h->t_end = o.jend + 1;
+                    h->score = o.score; h->n_ident = nid; h->aln_len = al; h->nm = al - nid; h->bin = best_bin;
+                    h->cigar_runs = rb.n; h->cigar_off = ncig; h->cells = o.cells;
+                    if (ncig + rb.n > capcig) { capcig = (ncig + rb.n) * 2 + 64; cig = realloc(cig, capcig * sizeof(uint32_t)); }
+                    for (uint32_t r = 0; r < rb.n; ++r) cig[ncig++] = rb.runs[rb.n - 1 - r];
+                }
             }
+        } else {
+            uint64_t nb = g1 - g0, na = 0;
+            band_aln *al_ = calloc(nb + 1, sizeof(band_aln));
+            for (uint64_t g = g0; g < g1; ++g) {
+                int32_t bin = (int32_t)(cand[g] & ((1u << 18) - 1));
+                int32_t dlo = bin * BIN_W - DIAG_OFF - BAND_LEAD;
+                sw_out o;
+                banded_sw(p, qs, Lq, ts, Lt, dlo, 1, &o);
+                if (o.score > 0 && o.score >= min_score[q]) {
+                    band_aln *b = &al_[na++];
+                    traceback(&o, qs, ts, dlo, &rb, &b->is, &b->js, &b->nid, &b->al);
+                    ++traced;
+                    b->bin = bin; b->score = o.score; b->iend = o.iend; b->jend = o.jend; b->cells = o.cells; b->nruns = rb.n;
+                    b->runs = malloc((rb.n + 1) * sizeof(uint32_t));
+                    for (uint32_t r = 0; r < rb.n; ++r) b->runs[r] = rb.runs[rb.n - 1 - r];
+                }
+                free(o.dir);
+            }
+            for (uint64_t x = 0; x < na; ++x)
+                for (uint64_t y = 0; y < na; ++y)
+                    if (x != y && al_[x].iend == al_[y].iend && al_[x].jend == al_[y].jend &&
+                        (al_[y].score > al_[x].score || (al_[y].score == al_[x].score && al_[y].bin < al_[x].bin))) al_[x].dead = 1;
+            for (uint64_t x = 0; x < na; ++x) {
+                band_aln *b = &al_[x];
+                double idp = (double)b->nid * 100.0 / (double)b->al;
+                double qcov = (double)(b->iend - b->is + 1) * 100.0 / (double)Lq;
+                if (!b->dead && idp >= p->min_id_pct && qcov >= p->min_qcov_pct) {
+                    oracle_hit *h = &hits[nh++];
+                    h->q = q; h->t = t; h->q_start = b->is + 1; h->q_end = b->iend + 1; h->t_start = b->js + 1; h->t_end = b->jend + 1;
+                    h->score = b->score; h->n_ident = b->nid; h->aln_len = b->al; h->nm = b->al - b->nid; h->bin = b->bin;
+                    h->cigar_runs = b->nruns; h->cigar_off = ncig; h->cells = b->cells;
+                    if (ncig + b->nruns > capcig) { capcig = (ncig + b->nruns) * 2 + 64; cig = realloc(cig, capcig * sizeof(uint32_t)); }
+                    memcpy(cig + ncig, b->runs, b->nruns * sizeof(uint32_t));
+                    ncig += b->nruns;
+                }
+                free(b->runs);
+            }
+            free(al_);
         }
         g0 = g1;
     }
@@ -435,7 +482,7 @@ int oracle_search(const oracle_params *p,
     }
     free(cig); free(keep); free(tmp); free(rb.runs); free(cand);
     *hits_out = hits; *n_hits = out; *cigar_out = cig2; *n_cigar = nc2;
-    if (stats) { stats[0] = nc; stats[1] = cells_all; stats[2] = pairs; }
+    if (stats) { stats[0] = nc; stats[1] = cells_all; stats[2] = pairs; stats[3] = traced; }
     return 0;
 }
 

@@ -25,7 +25,7 @@ class Params(C.Structure):
                 ('weight', C.c_int32 * 4), ('offs', (C.c_int32 * 32) * 4), ('reduce', C.c_uint8 * 32),
                 ('sub', C.c_int8 * 1024), ('min_id_pct', C.c_double), ('min_qcov_pct', C.c_double),
                 ('top_k', C.c_int32), ('n_splits', C.c_int32), ('ungapped_min', C.c_int32), ('xdrop', C.c_int32),
-                ('ext_right', C.c_int32), ('ext_left', C.c_int32)]
+                ('ext_right', C.c_int32), ('ext_left', C.c_int32), ('hsp_mode', C.c_int32)]
 
 
 class Hit(C.Structure):
@@ -78,7 +78,7 @@ def min_score(qlen, dbsize=5e6, max_evalue=1., ka_lambda=None, ka_k=None):
 def params_from(native):
     """oracle parameter block with the same algorithmic fields as a peppan_amd._native.SearchParams"""
     p = Params()
-    for f in ('gap_open', 'gap_ext', 'n_shapes', 'base', 'min_id_pct', 'min_qcov_pct', 'top_k', 'n_splits', 'ungapped_min', 'xdrop', 'ext_right', 'ext_left'):
+    for f in ('gap_open', 'gap_ext', 'n_shapes', 'base', 'min_id_pct', 'min_qcov_pct', 'top_k', 'n_splits', 'ungapped_min', 'xdrop', 'ext_right', 'ext_left', 'hsp_mode'):
         setattr(p, f, getattr(native, f))
     for i in range(4):
         p.weight[i] = native.weight[i]
@@ -119,7 +119,7 @@ def search(q_seqs, t_seqs, params=None, min_scores=None, dbsize=5e6, max_evalue=
     min_scores = np.ascontiguousarray(min_scores, dtype=np.int32)
     hits_p, cig_p = C.POINTER(Hit)(), C.POINTER(C.c_uint32)()
     nh, ncg = C.c_uint64(), C.c_uint64()
-    stats = (C.c_uint64 * 3)()
+    stats = (C.c_uint64 * 4)()
     if len(qr) == 0:
         qr = np.zeros(1, np.uint8)
     if len(tr) == 0:
@@ -137,7 +137,7 @@ def search(q_seqs, t_seqs, params=None, min_scores=None, dbsize=5e6, max_evalue=
         C.memmove(cig.ctypes.data, cig_p, ncg.value * 4)
     L.oracle_free(hits_p)
     L.oracle_free(cig_p)
-    return hits, cig, dict(candidates=int(stats[0]), cells=int(stats[1]), pairs=int(stats[2]))
+    return hits, cig, dict(candidates=int(stats[0]), cells=int(stats[1]), pairs=int(stats[2]), tracebacks=int(stats[3]))
 
 
 def align_one(q, t, bin_, params=None):

@@ -392,6 +392,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
             for (int c = 0; c < 32; ++c)
                 if (params->reduce[c] != 0xFF && params->reduce[c] >= params->base) return pep_fail(ctx, PEP_ERR_ARG, "reduced letter outside the alphabet");
         }
+        if (params->hsp_mode != 0 && params->hsp_mode != 1) return pep_fail(ctx, PEP_ERR_ARG, "hsp_mode must be 0 or 1");
         if (!(params->ka_lambda > 0.) || !(params->ka_k > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "invalid Karlin-Altschul parameters");
         if (params->xdrop < 0 || params->xdrop > 48 || params->ext_right < 1 || params->ext_right > 48 || params->ext_left < 0 || params->ext_left > 48)
             return pep_fail(ctx, PEP_ERR_ARG, "invalid ungapped-extension parameters");

@@ -24,13 +24,18 @@ __device__ __forceinline__ int key_dlo(uint64_t k) { return (int)(k & ((1u << 18
 // group heads pick the best band of their (q,t) group: score desc, then lowest bin (= first in sorted order)
 __global__ __launch_bounds__(256) void select_best(const uint64_t *__restrict__ cands, uint64_t n, const int4 *__restrict__ sw,
                                                    const int32_t *__restrict__ min_score, uint32_t *__restrict__ flag, uint32_t *__restrict__ best_idx,
-                                                   uint32_t *__restrict__ n_pairs)
+                                                   uint32_t *__restrict__ n_pairs, int hsp_mode)
 {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n) return;
     const uint64_t g = cands[c] >> 18;
     uint32_t f = 0;
-    if (c == 0 || (cands[c - 1] >> 18) != g) {
+    const bool head = c == 0 || (cands[c - 1] >> 18) != g;
+    if (hsp_mode == 1) {
+        // every band that reaches the threshold is traced; duplicates are removed after the walk (dedupe_bands)
+        if (head) atomicAdd(n_pairs, 1u);
+        if (sw[c].x > 0 && sw[c].x >= min_score[key_q(cands[c])]) { f = 1; best_idx[c] = (uint32_t)c; }
+    } else if (head) {
         atomicAdd(n_pairs, 1u);
         int best = sw[c].x;
         uint64_t bi = c;
@@ -168,7 +173,32 @@ __global__ __launch_bounds__(256) void finalize(uint64_t n_sel, SelInfo *__restr
     }
 }
 
-// rank inside (query, target mod n_splits): score desc, target asc.  sel is ordered by (q, t).
+// hsp_mode 1: two bands of one (q, t) that end in the same cell found the same alignment: keep the higher score, then the
+// lower bin (= lower index, sel is ordered by (q, t, bin)); the decision ignores whether the other one survives its filters
+__global__ __launch_bounds__(256) void dedupe_bands(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_sel) return;
+    const SelInfo me = sel[s];
+    const uint64_t g = cands[me.cand] >> 18;
+    bool dead = false;
+    for (int dir = -1; dir <= 1 && !dead; dir += 2) {
+        for (int64_t x = (int64_t)s + dir; x >= 0 && x < (int64_t)n_sel; x += dir) {
+            const SelInfo o = sel[x];
+            if ((cands[o.cand] >> 18) != g) break;
+            if (o.iend == me.iend && o.jend == me.jend && (o.score > me.score || (o.score == me.score && x < (int64_t)s))) { dead = true; break; }
+        }
+    }
+    if (dead) sel[s].pad = 1u;
+}
+
+__global__ __launch_bounds__(256) void apply_dedupe(uint64_t n_sel, SelInfo *__restrict__ sel)
+{
+    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s < n_sel && sel[s].pad) sel[s].pass = 0u;
+}
+
+// rank inside (query, target mod n_splits): score desc, target asc, band asc.  sel is ordered by (q, t, bin).
 __global__ __launch_bounds__(256) void topk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int top_k, int n_splits,
                                             uint32_t *__restrict__ keep_flag, uint64_t *__restrict__ keep_runs)
 {
@@ -187,7 +217,7 @@ __global__ __launch_bounds__(256) void topk(uint64_t n_sel, SelInfo *__restrict_
                 if (key_q(ko) != q) break;
                 const uint32_t to = key_t(ko);
                 if (!o.pass || to % (uint32_t)n_splits != split) continue;
-                if (o.score > me.score || (o.score == me.score && to < t)) ++rank;
+                if (o.score > me.score || (o.score == me.score && (to < t || (to == t && x < (int64_t)s)))) ++rank;
             }
         }
         keep = rank < (uint32_t)top_k ? 1u : 0u;
@@ -262,7 +292,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     uint32_t *counters = ctx->ws[9].as<uint32_t>();
     PEP_HIP(ctx, hipMemsetAsync(counters, 0, 256, st));
     const unsigned gb = (unsigned)ceil_div(n, 256);
-    hipLaunchKernelGGL(select_best, dim3(gb), dim3(256), 0, st, d_cands, n, sw, dms.as<const int32_t>(), flag, best_idx, counters);
+    hipLaunchKernelGGL(select_best, dim3(gb), dim3(256), 0, st, d_cands, n, sw, dms.as<const int32_t>(), flag, best_idx, counters, P.hsp_mode);
     PEP_TRY(pep_scan_u32(ctx, flag, pos, n, ctx->ws[7]));
     uint32_t n_sel = 0, n_pairs = 0;
     PEP_HIP(ctx, hipMemcpyAsync(&n_sel, pos + n, 4, hipMemcpyDeviceToHost, st));
@@ -294,6 +324,10 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         hipLaunchKernelGGL(finalize, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
                            ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(),
                            ctx->t.off.as<const uint32_t>(), (const uint64_t *)run_off, (const uint32_t *)runs, P.min_id_pct, P.min_qcov_pct);
+        if (P.hsp_mode == 1) {
+            hipLaunchKernelGGL(dedupe_bands, dim3((unsigned)ceil_div(n_sel, 256)), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys);
+            hipLaunchKernelGGL(apply_dedupe, dim3((unsigned)ceil_div(n_sel, 256)), dim3(256), 0, st, (uint64_t)n_sel, sel);
+        }
         // top-k, then compaction of hits and CIGAR runs
         PEP_TRY(dev_reserve(ctx, ctx->ws[22], ((size_t)n_sel + 2) * (4 + 4 + 8 + 8)));
         uint32_t *keep_flag = ctx->ws[22].as<uint32_t>(), *hit_pos = keep_flag + n_sel + 2;

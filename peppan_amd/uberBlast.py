@@ -310,8 +310,8 @@ class RunBlast(object):
     def runBlast(self, ref, qry):
         """nucleotide search on the same GPU engine, configured like the reference's blastn call (uberBlast.py:294):
         exact 17-mer seeds, +2/-3, gap 6+2k, e-value 1e-2 at dbsize 5e6, both strands of the reference, the
-        -perc_identity / -qcov_hsp_perc cuts, then parseBlast's filters (uberBlast.py:283).  One alignment per
-        (query, subject, strand) - see DESIGN.md for this difference to blastn's multiple HSPs."""
+        -perc_identity / -qcov_hsp_perc cuts, then parseBlast's filters (uberBlast.py:283).  hsp_mode 1: every
+        64-diagonal band of a (query, subject strand) that reaches the score threshold yields an alignment."""
         logger('Run BLASTn starts')
         self._load(ref, qry)
         ctx = get_context(self.device)

@@ -464,3 +464,36 @@ def test_query_sharded_search_equals_single_gpu(ctx):
         assert np.array_equal(gh, h) and np.array_equal(np.frombuffer(cb, dtype=np.uint32), c)
         assert np.array_equal(np.frombuffer(lb, dtype=np.uint32), lab)
     assert len(h) > 1000
+
+
+def test_multiple_hsps_per_subject(ctx):
+    """hsp_mode 1 (nucleotide tool): a contig carrying two diverged copies of a gene plus an adjacent-band duplicate case"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    names, seqs = synth.make_genes(60, 0, seed=23)
+    codes = [O.nt_codes(s) for s in seqs]
+    rc = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    sp = lambda n: rng.integers(0, 4, n).astype(np.uint8)
+    def mutated(c, rate):
+        c = c.copy(); m = rng.random(len(c)) < rate; c[m] = rng.integers(0, 4, int(m.sum())); return c
+    contig = np.concatenate([sp(700), codes[0], sp(333), mutated(codes[0], 0.04), sp(90), rc[codes[4][::-1]], sp(2000), mutated(codes[4], 0.08), sp(50)])
+    targets = [contig, rc[contig[::-1]]] + codes[:10]
+    p = N.nucleotide_params(70., 25.)
+    assert p.hsp_mode == 1
+    ctx.set_query_aa(codes)
+    ctx.set_ref_aa(targets)
+    gh, gc, st = ctx.search(p)
+    ms = np.array([O.min_score(len(c), p.dbsize, p.max_evalue, p.ka_lambda, p.ka_k) for c in codes], dtype=np.int32)
+    oh, oc, ost = O.search(codes, targets, O.params_from(p), min_scores=ms)
+    _cmp_hits(gh, gc, oh, oc)
+    assert st['tracebacks'] == ost['tracebacks']
+    # both copies of gene 0 on the forward strand of the contig, both copies of gene 4 (one per strand)
+    assert ((gh['q'] == 0) & (gh['t'] == 0)).sum() == 2
+    assert ((gh['q'] == 4) & (gh['t'] == 0)).sum() == 1 and ((gh['q'] == 4) & (gh['t'] == 1)).sum() == 1
+    # the same search with one alignment per (q, t) keeps only the better copy
+    p0 = N.nucleotide_params(70., 25.); p0.hsp_mode = 0
+    g0, c0, s0 = ctx.search(p0)
+    assert ((g0['q'] == 0) & (g0['t'] == 0)).sum() == 1 and len(g0) < len(gh)
+    o0, oc0, _ = O.search(codes, targets, O.params_from(p0), min_scores=ms)
+    _cmp_hits(g0, c0, o0, oc0)
