@@ -497,3 +497,38 @@ def test_multiple_hsps_per_subject(ctx):
     assert ((g0['q'] == 0) & (g0['t'] == 0)).sum() == 1 and len(g0) < len(gh)
     o0, oc0, _ = O.search(codes, targets, O.params_from(p0), min_scores=ms)
     _cmp_hits(g0, c0, o0, oc0)
+
+
+def test_c_abi_error_conventions():
+    """errors are loud and carry a message; nothing is truncated silently (include/peppan_hip.h)"""
+    from peppan_amd import _native as N
+    with N.Context(0) as c:
+        with pytest.raises(N.PepError, match='before both sequence sets'):
+            c.search(N.default_params())
+        c.set_query_aa([np.zeros(10, np.uint8)])
+        with pytest.raises(N.PepError):
+            c.target_meta()
+        c.set_ref_aa([np.zeros(10, np.uint8)])
+        bad = N.default_params(); bad.top_k = 0
+        with pytest.raises(N.PepError, match='invalid search parameters'):
+            c.search(bad)
+        bad = N.default_params(); bad.base = 40
+        with pytest.raises(N.PepError):
+            c.search(bad)
+        bad = N.default_params(); bad.xdrop = 99
+        with pytest.raises(N.PepError, match='ungapped'):
+            c.search(bad)
+        bad = N.default_params(); bad.hsp_mode = 7
+        with pytest.raises(N.PepError, match='hsp_mode'):
+            c.search(bad)
+        with pytest.raises(N.PepError, match='frames'):
+            c.set_ref_nt([b'ACGT'], frames=5)
+        with pytest.raises(N.PepError, match='out of range'):
+            c.components(4, [0, 9], [1, 2])
+        with pytest.raises(N.PepError):
+            c.linclust([np.zeros(30, np.uint8)], 0.9, 0.9, base=4, k=40)
+        # after errors the context still works
+        h, cg, st = c.search(N.default_params())
+        assert len(h) == 0
+    with pytest.raises(N.PepError):
+        N.Context(99)
