@@ -144,6 +144,12 @@ int pep_get_target_meta(pep_ctx *ctx, pep_target_meta *out, uint32_t cap);
 int pep_get_query_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off);
 int pep_get_target_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off);
 
+/* Optional: batch several reference sets (e.g. genomes) into one search.  group[i] = set of reference sequence i (sequences
+ * of one set must be contiguous).  The top-k / split competition then runs inside each set, with targets numbered from 0
+ * inside it, so the hits of a set are exactly those of searching it alone.  n = 0 clears the grouping.  Call after the
+ * reference sequences are set; a new pep_set_ref_* clears it. */
+int pep_set_target_groups(pep_ctx *ctx, const uint32_t *group, uint32_t n);
+
 /* K2..K8: seeds, candidates, banded Smith-Waterman, traceback, filters, top-k.  Hits ordered by (q, t). */
 int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out);
 int pep_result_size(const pep_result *r, uint64_t *n_hits, uint64_t *n_cigar);

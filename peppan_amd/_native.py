@@ -11,7 +11,7 @@ ABI_VERSION = 1
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
-           'pep_get_target_aa', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
+           'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
            'pep_rescore_nt', 'pep_components', 'pep_linclust']
 
 
@@ -180,6 +180,11 @@ class Context(object):
     def set_ref_aa(self, seqs):
         aa, off = _pack(seqs)
         self._check(self._lib.pep_set_ref_aa(self._h, _ptr(aa), _ptr(off), C.c_uint32(len(seqs))), 'pep_set_ref_aa')
+
+    def set_target_groups(self, groups):
+        """groups: one non-decreasing id per reference sequence (None / empty clears): batch of reference sets in one search"""
+        g = np.ascontiguousarray(groups if groups is not None else [], dtype=np.uint32)
+        self._check(self._lib.pep_set_target_groups(self._h, _ptr(g) if len(g) else None, C.c_uint32(len(g))), 'pep_set_target_groups')
 
     def translate(self, force=False):
         self._check(self._lib.pep_translate(self._h, C.c_int(1 if force else 0)), 'pep_translate')

@@ -267,7 +267,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto &b : ctx->ws) dev_release(b);
-    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->d_min_score, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
+    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->d_min_score, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -293,6 +293,7 @@ int pep_set_ref_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint32_
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     PEP_TRY(upload_nt(ctx, ctx->r_nt, nt, off, n));
     ctx->t_from_nt = true; ctx->t_gtable = gtable; ctx->t_frames = frames; ctx->t_ready = false;
+    ctx->group_of_seq.clear(); ctx->t_class_ready = false;
     return PEP_OK;
 }
 
@@ -315,6 +316,7 @@ int pep_set_ref_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint
     ctx->t_meta.resize(n);
     for (uint32_t i = 0; i < n; ++i) ctx->t_meta[i] = pep_target_meta{i, 0u, 0u, ctx->t.h_len[i]};
     ctx->t_from_nt = false; ctx->t_ready = true;
+    ctx->group_of_seq.clear(); ctx->t_class_ready = false;
     return PEP_OK;
 }
 
@@ -375,6 +377,39 @@ int pep_get_target_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off)
     return download_aa(ctx, ctx->t, codes, cap, off);
 }
 
+int pep_set_target_groups(pep_ctx *ctx, const uint32_t *group, uint32_t n)
+{
+    if (!ctx || (n && !group)) return PEP_ERR_ARG;
+    for (uint32_t i = 1; i < n; ++i)
+        if (group[i] < group[i - 1]) return pep_fail(ctx, PEP_ERR_ARG, "pep_set_target_groups: groups must be contiguous and non-decreasing");
+    ctx->group_of_seq.assign(group, group + n);
+    ctx->t_class_ready = false;
+    return PEP_OK;
+}
+
+// competition class per target from the group of its reference sequence (host build, small)
+static int build_t_class(pep_ctx *ctx)
+{
+    ctx->t_class_ready = false;
+    if (ctx->group_of_seq.empty()) return PEP_OK;
+    const uint32_t n_seq = ctx->t_from_nt ? ctx->r_nt.n : ctx->t.n;
+    if (ctx->group_of_seq.size() != n_seq) return pep_fail(ctx, PEP_ERR_ARG, "pep_set_target_groups: one group per reference sequence expected");
+    const uint32_t nt = ctx->t.n, ns = (uint32_t)ctx->params.n_splits;
+    std::vector<uint32_t> cls(nt + 1, 0u);
+    uint32_t cur = 0xFFFFFFFFu, local = 0;
+    for (uint32_t t = 0; t < nt; ++t) {
+        const uint32_t g = ctx->group_of_seq[ctx->t_meta[t].seq];
+        if (g != cur) { cur = g; local = 0; }
+        if ((uint64_t)g * ns + ns > 0xFFFFFFFFull) return pep_fail(ctx, PEP_ERR_LIMIT, "too many target groups");
+        cls[t] = g * ns + local % ns;
+        ++local;
+    }
+    PEP_TRY(dev_reserve(ctx, ctx->d_t_class, (size_t)(nt + 1) * 4));
+    PEP_HIP(ctx, hipMemcpy(ctx->d_t_class.p, cls.data(), (size_t)(nt + 1) * 4, hipMemcpyHostToDevice));
+    ctx->t_class_ready = true;
+    return PEP_OK;
+}
+
 int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
 {
     if (!ctx || !out) return PEP_ERR_ARG;
@@ -402,6 +437,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     PEP_TRY(pep_translate(ctx, 0));
     if (!ctx->q_ready || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "pep_search before both sequence sets were given");
     if (!ctx->sub_ready) { PEP_TRY(upload_sub_image(ctx)); ctx->sub_ready = true; }
+    PEP_TRY(build_t_class(ctx));
 
     pep_result *res = new (std::nothrow) pep_result();
     if (!res) return pep_fail(ctx, PEP_ERR_INTERNAL, "out of host memory");

@@ -73,6 +73,9 @@ struct pep_ctx {
     bool q_ready = false, t_ready = false, sub_ready = false;
     int q_gtable = 11, t_gtable = 11, t_frames = 6;
     DevBuf d_min_score;
+    std::vector<uint32_t> group_of_seq;     // optional: competition group of every reference sequence (pep_set_target_groups)
+    DevBuf d_t_class;
+    bool t_class_ready = false;
     // workspaces (grow-only, reused between searches)
     DevBuf ws[24];
     DevBuf sub_lds;                         // replicated substitution table image (32 KiB)

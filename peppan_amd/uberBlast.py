@@ -120,16 +120,16 @@ for _c, _v in zip('ACGTacgt', (0, 1, 2, 3, 0, 1, 2, 3)):
 _NT_RC = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
 
 
-def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params):
+def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev):
     """nucleotide-search hits -> the rows parseBlast builds from blastn's outfmt 6 (uberBlast.py:275-290, 311-320):
-    target index >= len(r_names) is the reverse strand (sstart > send); identity carries blastn's 3 printed decimals"""
+    t_seq / t_rev give the reference sequence and strand of every target (reverse strand: sstart > send); identity
+    carries blastn's 3 printed decimals"""
     n = len(hits)
     if n == 0:
         return np.empty([0, 15], dtype=object)
-    nr = len(r_names)
     qi = hits['q'].astype(np.int64)
     ti = hits['t'].astype(np.int64)
-    rev, ri = ti >= nr, ti % nr
+    rev, ri = t_rev[ti], t_seq[ti]
     ql, sl = np.asarray(q_len, dtype=np.int64)[qi], np.asarray(r_len, dtype=np.int64)[ri]
     qs, qe = hits['q_start'].astype(np.int64), hits['q_end'].astype(np.int64)
     ts, te = hits['t_start'].astype(np.int64), hits['t_end'].astype(np.int64)
@@ -222,6 +222,7 @@ class RunBlast(object):
         self.qrySeq = self.refSeq = None
         self.device = device
         self._nt_loaded = None
+        self._batch = None                  # (reference names genome-major, genome id per name) in run_batch
 
     # ---------------------------------------------------------------------------------------------- driver
     def run(self, ref, qry, methods, min_id, min_cov, min_ratio, table_id=11, n_thread=8, useProcess=False, re_score=0,
@@ -241,6 +242,10 @@ class RunBlast(object):
             import traceback
             traceback.print_exc()
             blastab = [b for b in blastab if hasattr(b, 'shape') and b.shape[0] > 0]
+        return self._post(blastab, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end)
+
+    def _post(self, blastab, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end):
+        """everything RunBlast.run does after the tools returned (uberBlast.py:352-376)"""
         if blastab:
             blastab = np.vstack(blastab)
             blastab = np.hstack([blastab, np.arange(blastab.shape[0], dtype=int)[:, np.newaxis]])
@@ -260,8 +265,49 @@ class RunBlast(object):
             return pd.DataFrame(blastab).sort_values([0, 1, 11]).values, overlap
         return pd.DataFrame(blastab).sort_values([0, 1, 11]).values
 
+    def run_batch(self, refs, qry, methods, min_id, min_cov, min_ratio, table_id=11, n_thread=8, useProcess=False, re_score=0,
+                  filter=[False, 0.9, 0.], linear_merge=[False, 300., 1.2], return_overlap=[True, 300, 0.6], fix_end=[6., 6.]):
+        """run() for MANY reference files (genomes) against one query file with ONE search per tool: the references are
+        packed genome-major, the GPU ranks hits inside each genome (pep_set_target_groups), and the tables are split per
+        genome before the post-processing chain - each result equals run(ref_i, qry, ...).  This is the GPU-native form
+        of PEPPAN's per-genome fan-out (PEPPAN.py:907-922, iter_map_bsn :759-772): the query index is built once and no
+        worker process ever touches the device."""
+        tools = dict(blastn=self.runBlast, diamond=self.runDiamond, diamondself=self.runDiamondSELF, gpu=self.runDiamond)
+        self.min_id, self.min_cov, self.min_ratio = min_id, min_cov, min_ratio
+        self.table_id, self.n_thread, self.pool = table_id, n_thread, useProcess
+        self.qrySeq = _read_cached(qry)
+        combined, names, groups = {}, [], []
+        for g, path in enumerate(refs):
+            rs = _read_cached(path)
+            for n in sorted(rs):
+                if n in combined:
+                    raise ValueError('run_batch: reference sequence name {0} occurs in more than one file'.format(n))
+                combined[n] = rs[n]
+                names.append(n)
+                groups.append(g)
+        self.refSeq, self._batch = combined, (names, groups)
+        genome_of = dict(zip(names, groups))
+        tables = []
+        try:
+            for method in methods:
+                if method.lower() in tools:
+                    tables.append(tools[method.lower()](None, None))
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            tables = [b for b in tables if hasattr(b, 'shape')]
+        out = []
+        owners = [np.array([genome_of[r] for r in b.T[1]], dtype=np.int64) if b.shape[0] else np.zeros(0, np.int64) for b in tables]
+        for g in range(len(refs)):
+            part = [b[o == g] for b, o in zip(tables, owners)]
+            part = [b for b in part if b.shape[0] > 0]
+            out.append(self._post(part, None, None, re_score, filter, linear_merge, return_overlap, fix_end))
+        return out
+
     # ---------------------------------------------------------------------------------------------- inputs
     def _load(self, ref, qry):
+        if self._batch is not None:
+            return                          # run_batch filled qrySeq / refSeq itself
         if not self.qrySeq:
             self.qrySeq, self.qryQual = _read_cached(qry), None
         if not self.refSeq:
@@ -274,11 +320,12 @@ class RunBlast(object):
         if self._nt_loaded == key:
             return
         self.q_names = sorted(self.qrySeq)
-        self.r_names = sorted(self.refSeq)
+        self.r_names = sorted(self.refSeq) if self._batch is None else list(self._batch[0])
         self.q_index = {n: i for i, n in enumerate(self.q_names)}
         self.r_index = {n: i for i, n in enumerate(self.r_names)}
         ctx.set_query_nt([self._text(self.qrySeq[n]) for n in self.q_names], self.table_id)
         ctx.set_ref_nt([self._text(self.refSeq[n]) for n in self.r_names], frames, self.table_id)
+        ctx.set_target_groups(None if self._batch is None else self._batch[1])
         self._nt_loaded = key
 
     @staticmethod
@@ -315,16 +362,26 @@ class RunBlast(object):
         logger('Run BLASTn starts')
         self._load(ref, qry)
         ctx = get_context(self.device)
-        q_names, r_names = sorted(self.qrySeq), sorted(self.refSeq)
+        q_names = sorted(self.qrySeq)
+        r_names = sorted(self.refSeq) if self._batch is None else list(self._batch[0])
+        groups = [0] * len(r_names) if self._batch is None else list(self._batch[1])
         q_codes = [_NT_CODE[np.frombuffer(self._text(self.qrySeq[n]).encode('ascii'), dtype=np.uint8)] for n in q_names]
         r_codes = [_NT_CODE[np.frombuffer(self._text(self.refSeq[n]).encode('ascii'), dtype=np.uint8)] for n in r_names]
+        # targets: per reference set all forward strands, then all reverse strands
+        t_seq, t_rev, t_grp = [], [], []
+        for g in sorted(set(groups)):
+            members = [i for i, x in enumerate(groups) if x == g]
+            t_seq += members + members
+            t_rev += [False] * len(members) + [True] * len(members)
+            t_grp += [g] * (2 * len(members))
         ctx.set_query_aa(q_codes)
-        ctx.set_ref_aa(r_codes + [_NT_RC[c[::-1]] for c in r_codes])
+        ctx.set_ref_aa([_NT_RC[r_codes[i][::-1]] if rv else r_codes[i] for i, rv in zip(t_seq, t_rev)])
+        ctx.set_target_groups(None if self._batch is None else t_grp)
         self._nt_loaded = None                      # the packed protein sets of a previous translated search are gone
         params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100.)
         hits, cigar, stats = ctx.search(params)
         blastab = blast_hits_to_blastab(hits, cigar, q_names, r_names, [len(c) for c in q_codes], [len(c) for c in r_codes],
-                                        self.min_id, self.min_cov, self.min_ratio, params)
+                                        self.min_id, self.min_cov, self.min_ratio, params, np.array(t_seq, dtype=np.int64), np.array(t_rev, dtype=bool))
         logger('Run BLASTn finishes. Got {0} alignments'.format(blastab.shape[0]))
         return blastab
 
@@ -437,6 +494,35 @@ def uberBlast(args, extPool=None):
             fout.write('\t'.join([str(tt) for tt in t]) + '\n')
         fout.close()
     return data
+
+
+def uberBlastBatch(references, args, device=None):
+    """uberBlast for a LIST of reference files and one query file: `args` are uberBlast's flags without -r/-o.
+    Returns one result per reference, each identical to uberBlast(['-r', ref] + args).  One GPU search per tool."""
+    import argparse
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-q', '--query', required=True)
+    for flag in ('--blastn', '--diamond', '--diamondSELF', '--gpu', '-f', '-m', '-O', '-p'):
+        parser.add_argument(flag, action='store_true', default=False)
+    parser.add_argument('--gtable', default=11, type=int)
+    parser.add_argument('--min_id', type=float, default=0.3)
+    parser.add_argument('--min_cov', type=float, default=40.)
+    parser.add_argument('--min_ratio', type=float, default=0.05)
+    parser.add_argument('-s', '--re_score', type=int, default=0)
+    parser.add_argument('--filter_cov', default=0.9, type=float)
+    parser.add_argument('--filter_score', default=0., type=float)
+    parser.add_argument('--merge_gap', default=600., type=float)
+    parser.add_argument('--merge_diff', default=1.5, type=float)
+    parser.add_argument('--overlap_length', default=300, type=float)
+    parser.add_argument('--overlap_proportion', default=0.6, type=float)
+    parser.add_argument('-e', '--fix_end', default='0,0')
+    parser.add_argument('-t', '--n_thread', type=int, default=1)
+    a = parser.parse_args(args)
+    methods = [m for m, on in (('blastn', a.blastn), ('diamond', a.diamond or a.gpu), ('diamondSELF', a.diamondSELF)) if on]
+    fix_end = list(map(float, a.fix_end.split(',')))
+    return RunBlast(device).run_batch(references, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread, a.p, a.re_score,
+                                      [a.f, a.filter_cov, a.filter_score], [a.m, a.merge_gap, a.merge_diff],
+                                      [a.O, a.overlap_length, a.overlap_proportion], fix_end)
 
 
 if __name__ == '__main__':

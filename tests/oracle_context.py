@@ -24,6 +24,9 @@ class OracleContext(object):
         self.t_aa = [np.asarray(s, dtype=np.uint8) for s in seqs]
         self._direct = True
 
+    def set_target_groups(self, groups):
+        assert groups is None or len(groups) == 0, 'the oracle searches one reference set at a time'
+
     def translate(self, force=False):
         if getattr(self, '_direct', False):
             return

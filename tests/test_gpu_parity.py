@@ -532,3 +532,36 @@ def test_c_abi_error_conventions():
         assert len(h) == 0
     with pytest.raises(N.PepError):
         N.Context(99)
+
+
+def test_run_batch_equals_per_genome_runs(tmp_path, monkeypatch):
+    """GPU-native batching of the genes->genomes mapping (PEPPAN.py:907-922): ONE search per tool over several genomes,
+    ranking inside each genome, gives exactly the per-genome uberBlast results (tables and overlaps)"""
+    import io, contextlib
+    from peppan_amd import uberBlast as UB, synth, configure
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(12)
+    names, seqs = synth.make_genes(80, 0, seed=19, family=4)
+    _write_fasta('genes.fa', [str(i) for i in range(len(seqs))], seqs)
+    spacer = lambda: bytes(rng.choice(list(b'ACGT'), int(rng.integers(40, 400))).tolist())
+    genomes = []
+    for g in range(4):
+        contigs, cur = [], spacer()
+        for k in rng.permutation(len(seqs))[:45]:
+            s = seqs[k]
+            if rng.random() < 0.5:
+                s = configure.rc(s.decode()).encode()
+            cur += s + spacer()
+            if rng.random() < 0.12:
+                contigs.append(cur); cur = spacer()
+        contigs.append(cur + seqs[3] + spacer() + seqs[3] + spacer())          # a duplicated gene on one contig
+        path = 'genome%d.fa' % g
+        _write_fasta(path, ['%d:c%d' % (g, i) for i in range(len(contigs))], contigs)
+        genomes.append(path)
+    flags = '-f -m -O --blastn --diamond --min_id 0.4 --min_cov 50 --min_ratio 0.25 --merge_gap 600 --merge_diff 1.5 -t 1 -s 1 -e 0,3 --gtable 11'
+    with contextlib.redirect_stderr(io.StringIO()):
+        single = [UB.uberBlast(('-r %s -q genes.fa ' % p + flags).split()) for p in genomes]
+        batch = UB.uberBlastBatch(genomes, ('-q genes.fa ' + flags).split())
+    assert len(batch) == 4
+    for (t1, o1), (t2, o2) in zip(single, batch):
+        assert t1.shape[0] > 40 and t1.tolist() == t2.tolist() and o1.tolist() == o2.tolist()

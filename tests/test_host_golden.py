@@ -121,6 +121,9 @@ class OracleCtx(object):
     def set_ref_nt(self, *a):
         pass
 
+    def set_target_groups(self, groups):
+        assert not groups
+
 
 @pytest.fixture
 def oracle_ctx(monkeypatch):
