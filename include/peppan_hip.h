@@ -23,6 +23,7 @@
  *   pep_rescore_nt          cigar2score mode 1 inside RunBlast.reScore      uberBlast.py:226-249, 397-415
  *   pep_components          union-find of get_gene_group (partition only)   PEPPAN.py:1598-1607
  *   pep_linclust            `mmseqs createdb / linclust / createtsv`        clust.py:62-66
+ *   pep_overlaps            numba tab2overlaps inside returnOverlap          uberBlast.py:73-97, 378-395
  */
 #ifndef PEPPAN_HIP_H
 #define PEPPAN_HIP_H
@@ -169,6 +170,12 @@ int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint3
  * [0] selected k-mers, [1] verified (sequence, centre, diagonal) pairs, [2] accepted edges. */
 int pep_linclust(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n, int base, int k, int m,
                  double min_id, double min_cov, uint32_t *rep, uint64_t *stats);
+
+/* K11: overlapping reference intervals (flag -O; tab2overlaps, uberBlast.py:73-97).  Rows sorted by (contig, start, end).
+ * out receives (id1, id2, overlap) triples in (i, j) order; *n_pairs is the full count - when it exceeds cap nothing is
+ * written and the caller calls again with a buffer of *n_pairs triples. */
+int pep_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *contig, const int64_t *start, const int64_t *end, const int64_t *row_id,
+                 double ovl_l, double ovl_p, int64_t *out, uint64_t cap, uint64_t *n_pairs);
 
 #ifdef __cplusplus
 }

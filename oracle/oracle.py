@@ -290,3 +290,19 @@ def linclust(seqs, min_id, min_cov, base=4, k=17, m=20):
     lib().oracle_linclust(res.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.c_uint32(len(seqs)), C.c_int(base), C.c_int(k), C.c_int(m),
                           C.c_double(min_id), C.c_double(min_cov), rep.ctypes.data_as(C.c_void_p), stats)
     return rep, dict(selected=int(stats[0]), verified=int(stats[1]), accepted=int(stats[2]))
+
+
+def overlaps_sweep(contig, start, end, row_id, ovl_l, ovl_p):
+    """interval sweep of tab2overlaps (uberBlast.py:73-97) without its 1e6 batching: rows sorted by (contig, start, end);
+    returns int64[m, 3] (id1, id2, overlap) in (i, j) order"""
+    out = []
+    n = len(contig)
+    for i in range(n):
+        need = min(ovl_l, ovl_p * (end[i] - start[i] + 1))
+        for j in range(i + 1, n):
+            if contig[j] != contig[i] or start[j] > end[i]:
+                break
+            ovl = min(end[i], end[j]) - start[j] + 1
+            if ovl >= need or ovl >= ovl_p * (end[j] - start[j] + 1):
+                out.append((row_id[i], row_id[j], ovl))
+    return np.array(out, dtype=np.int64).reshape(-1, 3)

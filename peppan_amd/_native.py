@@ -12,7 +12,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
-           'pep_rescore_nt', 'pep_components', 'pep_linclust']
+           'pep_rescore_nt', 'pep_components', 'pep_linclust', 'pep_overlaps']
 
 
 class PepError(RuntimeError):
@@ -255,6 +255,25 @@ class Context(object):
             self._check(self._lib.pep_linclust(self._h, _ptr(codes), _ptr(off), C.c_uint32(len(seqs)), C.c_int(base), C.c_int(k), C.c_int(m),
                                                C.c_double(min_id), C.c_double(min_cov), _ptr(rep), _ptr(stats)), 'pep_linclust')
         return rep, dict(selected=int(stats[0]), verified=int(stats[1]), accepted=int(stats[2]))
+
+    # ---- K11
+    def overlaps(self, contig, start, end, row_id, ovl_l, ovl_p):
+        """rows sorted by (contig, start, end) -> int64[m, 3] (id1, id2, overlap) in sweep order"""
+        contig = np.ascontiguousarray(contig, dtype=np.int32)
+        start, end, row_id = (np.ascontiguousarray(x, dtype=np.int64) for x in (start, end, row_id))
+        n = len(contig)
+        if n == 0:
+            return np.zeros((0, 3), dtype=np.int64)
+        m = C.c_uint64()
+        cap = max(1024, 4 * n)
+        for _ in range(2):
+            out = np.zeros((cap, 3), dtype=np.int64)
+            self._check(self._lib.pep_overlaps(self._h, C.c_uint64(n), _ptr(contig), _ptr(start), _ptr(end), _ptr(row_id), C.c_double(ovl_l),
+                                               C.c_double(ovl_p), _ptr(out), C.c_uint64(cap), C.byref(m)), 'pep_overlaps')
+            if m.value <= cap:
+                return out[:m.value]
+            cap = m.value
+        raise PepError('pep_overlaps: inconsistent pair count')
 
     # ---- K10
     def components(self, n_nodes, a, b):

@@ -518,4 +518,12 @@ int pep_linclust(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32
     return pep_k9_linclust(ctx, codes, off, n, base, k, m, min_id, min_cov, rep, stats);
 }
 
+int pep_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *contig, const int64_t *start, const int64_t *end, const int64_t *row_id,
+                 double ovl_l, double ovl_p, int64_t *out, uint64_t cap, uint64_t *n_pairs)
+{
+    if (!ctx || !n_pairs || (n && (!contig || !start || !end || !row_id)) || (cap && !out)) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    return pep_k11_overlaps(ctx, n, contig, start, end, row_id, ovl_l, ovl_p, out, cap, n_pairs);
+}
+
 }  // extern "C"

@@ -139,6 +139,9 @@ int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uin
 // ---- unionfind.hip (K10)
 int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *h_a, const uint32_t *h_b, uint32_t *h_label);
 
+// ---- overlaps.hip (K11)
+int pep_k11_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *h_contig, const int64_t *h_start, const int64_t *h_end, const int64_t *h_rid,
+                     double ovl_l, double ovl_p, int64_t *h_out, uint64_t cap, uint64_t *n_pairs);
 // ---- linclust.hip (K9)
 int pep_k9_linclust(pep_ctx *ctx, const uint8_t *h_res, const uint64_t *h_off, uint32_t n, int base, int k, int m, double min_id, double min_cov,
                     uint32_t *h_rep, uint64_t *h_stats);

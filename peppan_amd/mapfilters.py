@@ -182,13 +182,20 @@ def linear_merge(blastab, gap_dist, len_diff):
 
 
 # ------------------------------------------------------------------------------------------------ -O
-def overlaps(blastab, ovl_l, ovl_p, batch=1000000):
+def overlaps(blastab, ovl_l, ovl_p, batch=1000000, sweep=None):
     """pairs of hits (row ids) whose reference intervals overlap by >= min(ovl_l, ovl_p*len1) or >= ovl_p*len2.
     The reference sweeps in batches of 1e6 pairs and, on resuming, emits the last pair of a full batch again
-    (uberBlast.py:76-92); reproduced."""
+    (uberBlast.py:76-92); reproduced.  `sweep(contig, start, end, row_id, ovl_l, ovl_p)` runs the sweep itself
+    (the GPU kernel K11 in the product); without it a plain Python loop does (used by the CPU tests)."""
     contig_id = {row[R]: k for k, row in enumerate(blastab)}
     iv = [[contig_id[row[R]], row[RID]] + sorted([row[SS], row[SE]]) for row in blastab]
     iv = np.array(sorted(iv, key=itemgetter(0, 2, 3)), dtype=int)
+    if sweep is not None and len(iv):
+        res = np.asarray(sweep(iv[:, 0], iv[:, 2], iv[:, 3], iv[:, 1], float(ovl_l), float(ovl_p)), dtype=int).reshape(-1, 3)
+        if len(res) >= batch:                   # the reference's resume quirk: pair number k*1e6 appears twice
+            dup = np.arange(batch - 1, len(res), batch)
+            res = np.insert(res, dup + 1, res[dup], axis=0)
+        return res[res.T[2] > 0]
     out = []
     n = len(iv)
     emitted = 0

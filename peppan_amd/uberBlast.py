@@ -426,7 +426,8 @@ class RunBlast(object):
         return mapfilters.linear_merge(blastab, params[1], params[2])
 
     def returnOverlap(self, blastab, param):
-        return mapfilters.overlaps(blastab, param[1], param[2])
+        """interval sweep on the GPU (K11); the host only sorts the intervals the way the reference does"""
+        return mapfilters.overlaps(blastab, param[1], param[2], sweep=get_context(self.device).overlaps)
 
     def fixEnd(self, blastab, se, ee):
         """extend alignments over short unaligned ends (<= se at the query head, <= ee at its tail) and turn the CIGAR

@@ -71,3 +71,6 @@ class OracleContext(object):
 
     def components(self, n, a, b):
         return O.components(n, a, b)
+
+    def overlaps(self, contig, start, end, row_id, ovl_l, ovl_p):
+        return O.overlaps_sweep(contig, start, end, row_id, ovl_l, ovl_p)

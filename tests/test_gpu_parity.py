@@ -565,3 +565,30 @@ def test_run_batch_equals_per_genome_runs(tmp_path, monkeypatch):
     assert len(batch) == 4
     for (t1, o1), (t2, o2) in zip(single, batch):
         assert t1.shape[0] > 40 and t1.tolist() == t2.tolist() and o1.tolist() == o2.tolist()
+
+
+def test_k11_overlaps_vs_oracle_and_golden(ctx):
+    from oracle import oracle as O
+    from peppan_amd import mapfilters
+    rng = np.random.default_rng(3)
+    for n, span in ((0, 10), (1, 10), (500, 40000), (20000, 2000000)):
+        contig = np.sort(rng.integers(0, 7, n)).astype(np.int32)
+        start = rng.integers(1, span, n)
+        end = start + rng.integers(30, 3000, n)
+        order = np.lexsort((end, start, contig))
+        contig, start, end = contig[order], start[order], end[order]
+        rid = rng.permutation(n)
+        for ovl_l, ovl_p in ((300., 0.6), (30., 0.1)):
+            got = ctx.overlaps(contig, start, end, rid, ovl_l, ovl_p)
+            assert np.array_equal(got, O.overlaps_sweep(contig.tolist(), start.tolist(), end.tolist(), rid.tolist(), ovl_l, ovl_p))
+    g = load_golden('g07_filters.json')
+    for case in g['cases']:
+        tab = np.empty([len(case['table']), 16], dtype=object)
+        for i, r in enumerate(case['table']):
+            for j, v in enumerate(r):
+                tab[i, j] = v
+        assert mapfilters.overlaps(tab, 30, 0.1, sweep=ctx.overlaps).tolist() == case['overlap_30_01_raw']
+    # unsorted input is an error, not garbage
+    from peppan_amd import _native as N
+    with pytest.raises(N.PepError, match='sorted'):
+        ctx.overlaps([1, 0], [5, 5], [9, 9], [0, 1], 300., 0.6)

@@ -124,6 +124,9 @@ class OracleCtx(object):
     def set_target_groups(self, groups):
         assert not groups
 
+    def overlaps(self, contig, start, end, row_id, ovl_l, ovl_p):
+        return O.overlaps_sweep(contig, start, end, row_id, ovl_l, ovl_p)
+
 
 @pytest.fixture
 def oracle_ctx(monkeypatch):
@@ -170,10 +173,11 @@ def test_fixend():
         rows_equal(t, case['rows'])
 
 
-def test_map_filters():
+def test_map_filters(oracle_ctx):
     g = load_golden('g07_filters.json')
     for case in g['cases']:
         rb = UB.RunBlast()
+        oracle_ctx['ctx'] = OracleCtx(rb)
         f = rb.ovlFilter(_table(case['table']), [True, 0.9, 0.])
         rows_equal(f, case['ovlFilter_09_0'])
         rows_equal(rb.ovlFilter(_table(case['table']), [True, 0.5, 10.]), case['ovlFilter_05_10'])
@@ -182,6 +186,8 @@ def test_map_filters():
         rows_equal(rb.linearMerge(_table(case['table']), [True, 300., 1.2]), case['linearMerge_300_12_raw'])
         assert rb.returnOverlap(_table(case['linearMerge_600_15']), [True, 300, 0.6]).tolist() == case['overlap_300_06']
         assert rb.returnOverlap(_table(case['table']), [True, 30, 0.1]).tolist() == case['overlap_30_01_raw']
+        # the plain host loop (no sweep function) gives the same
+        assert mapfilters.overlaps(_table(case['table']), 30, 0.1).tolist() == case['overlap_30_01_raw']
 
 
 def _canned_tools(monkeypatch, g5):
