@@ -87,3 +87,35 @@ def make_proteins(n, length=300, seed=1, family=3, sub=0.2):
                 m = np.concatenate([m[:p], m[p + k:]]) if rng.random() < 0.5 else np.concatenate([m[:p], aa[rng.integers(0, 20, k)], m[p:]])
             out.append(m)
     return [np.ascontiguousarray(x, dtype=np.uint8) for x in out[:n]]
+
+
+def make_genomes(gene_seqs, n_genomes, seed=355, family=4):
+    """synthgenes-v1 genomes: a family is present with p = 0.99 (70 % of families), 0.5 (20 %) or 0.05
+    (10 %); the allele is one family member with a per-genome substitution rate U(0, 0.02); one contig, random strand,
+    50-300 nt random spacers.  Returns [(genome name, contig bytes, [(gene index, start, end, strand), ...]), ...]"""
+    rng = np.random.default_rng(seed + 1)
+    n_fam = (len(gene_seqs) + family - 1) // family
+    p_present = rng.choice([0.99, 0.5, 0.05], size=n_fam, p=[0.7, 0.2, 0.1])
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b'ACGT')] = list(b'TGCA')
+    out = []
+    for g in range(n_genomes):
+        rate = rng.uniform(0, 0.02)
+        parts, ann, pos = [], [], 0
+        for f in np.nonzero(rng.random(n_fam) < p_present)[0]:
+            k = int(f) * family + int(rng.integers(0, min(family, len(gene_seqs) - int(f) * family)))
+            s = np.frombuffer(gene_seqs[k], dtype=np.uint8).copy()
+            m = rng.random(s.size) < rate
+            m[:3] = m[-3:] = False
+            s[m] = _B[rng.integers(0, 4, int(m.sum()))]
+            sp = _B[rng.integers(0, 4, int(rng.integers(50, 301)))]
+            strand = '+' if rng.random() < 0.5 else '-'
+            if strand == '-':
+                s = comp[s[::-1]]
+            parts += [sp, s]
+            pos += sp.size
+            ann.append((k, pos + 1, pos + s.size, strand))
+            pos += s.size
+        parts.append(_B[rng.integers(0, 4, 100)])
+        out.append(('g%04d' % g, np.concatenate(parts).tobytes(), ann))
+    return out
