@@ -265,13 +265,31 @@ class RunBlast(object):
             return pd.DataFrame(blastab).sort_values([0, 1, 11]).values, overlap
         return pd.DataFrame(blastab).sort_values([0, 1, 11]).values
 
+    MAX_BATCH_NT = 120000000        # nucleotides per search: 6 frames -> 2 packed protein bytes per nt, under the 2^29 limit
+
     def run_batch(self, refs, qry, methods, min_id, min_cov, min_ratio, table_id=11, n_thread=8, useProcess=False, re_score=0,
                   filter=[False, 0.9, 0.], linear_merge=[False, 300., 1.2], return_overlap=[True, 300, 0.6], fix_end=[6., 6.]):
-        """run() for MANY reference files (genomes) against one query file with ONE search per tool: the references are
-        packed genome-major, the GPU ranks hits inside each genome (pep_set_target_groups), and the tables are split per
-        genome before the post-processing chain - each result equals run(ref_i, qry, ...).  This is the GPU-native form
-        of PEPPAN's per-genome fan-out (PEPPAN.py:907-922, iter_map_bsn :759-772): the query index is built once and no
-        worker process ever touches the device."""
+        """run() for MANY reference files (genomes) against one query file with ONE search per tool and sub-batch: the
+        references are packed genome-major, the GPU ranks hits inside each genome (pep_set_target_groups), and the tables
+        are split per genome before the post-processing chain - each result equals run(ref_i, qry, ...).  This is the
+        GPU-native form of PEPPAN's per-genome fan-out (PEPPAN.py:907-922, iter_map_bsn :759-772): the query index is
+        shared and no worker process ever touches the device.  Genomes are grouped into sub-batches of at most
+        MAX_BATCH_NT nucleotides so that a packed reference set stays inside the library's 2^29-byte limit."""
+        sizes = [sum(len(v) for v in _read_cached(p).values()) for p in refs]
+        out, start = [], 0
+        while start < len(refs):
+            stop, tot = start, 0
+            while stop < len(refs) and (stop == start or tot + sizes[stop] <= self.MAX_BATCH_NT):
+                tot += sizes[stop]
+                stop += 1
+            sub = RunBlast(self.device) if (start, stop) != (0, len(refs)) else self
+            out += sub._run_one_batch(refs[start:stop], qry, methods, min_id, min_cov, min_ratio, table_id, n_thread, useProcess, re_score,
+                                      filter, linear_merge, return_overlap, fix_end)
+            start = stop
+        return out
+
+    def _run_one_batch(self, refs, qry, methods, min_id, min_cov, min_ratio, table_id, n_thread, useProcess, re_score,
+                       filter, linear_merge, return_overlap, fix_end):
         tools = dict(blastn=self.runBlast, diamond=self.runDiamond, diamondself=self.runDiamondSELF, gpu=self.runDiamond)
         self.min_id, self.min_cov, self.min_ratio = min_id, min_cov, min_ratio
         self.table_id, self.n_thread, self.pool = table_id, n_thread, useProcess

@@ -562,9 +562,12 @@ def test_run_batch_equals_per_genome_runs(tmp_path, monkeypatch):
     with contextlib.redirect_stderr(io.StringIO()):
         single = [UB.uberBlast(('-r %s -q genes.fa ' % p + flags).split()) for p in genomes]
         batch = UB.uberBlastBatch(genomes, ('-q genes.fa ' + flags).split())
-    assert len(batch) == 4
-    for (t1, o1), (t2, o2) in zip(single, batch):
+        monkeypatch.setattr(UB.RunBlast, 'MAX_BATCH_NT', 130000)       # forces two sub-batches of two genomes
+        split = UB.uberBlastBatch(genomes, ('-q genes.fa ' + flags).split())
+    assert len(batch) == 4 and len(split) == 4
+    for (t1, o1), (t2, o2), (t3, o3) in zip(single, batch, split):
         assert t1.shape[0] > 40 and t1.tolist() == t2.tolist() and o1.tolist() == o2.tolist()
+        assert t1.tolist() == t3.tolist() and o1.tolist() == o3.tolist()
 
 
 def test_k11_overlaps_vs_oracle_and_golden(ctx):
