@@ -27,6 +27,7 @@ Fixture index:
   g10_pairs.json         get_similar_pairs              (PEPPAN.py:194-294)
   g11_groups.json        get_gene_group                 (PEPPAN.py:1590-1609)
   g12_writegenes.json    writeGenes                     (PEPPAN.py:1023-1039)
+  g13_readers.json       readFasta / readFastq / uopen  (configure.py:90-150, clust.py:7-18)
 """
 import json, os, sys, stat, tempfile, shutil, io, contextlib, copy
 
@@ -804,7 +805,30 @@ def g10_g11_g12():
                                      fasta=open(fn).read(), groups=groups))
 
 
+def g13():
+    """readers (configure.py:118-150, clust.py:7-18): multi-line FASTA with comments / lower case / descriptions, FASTQ, gz"""
+    import gzip
+    d = fake_dir()
+    fasta = '>g1 first gene\nACGTacgtNN\nacgt\n#comment line\n>g2\n\nTTGA CC\n>g3 desc\nA\n'
+    fastq = '@r1 some\nACGTN\n+\nIIII!\n@r2\nacgtacgt\n+r2\nABCDEFGH\n'
+    out = {}
+    for name, text in (('x.fa', fasta), ('x.fq', fastq)):
+        p_ = os.path.join(d, name)
+        open(p_, 'w').write(text)
+        with gzip.open(p_ + '.gz', 'wt') as f:
+            f.write(text)
+        for q in (p_, p_ + '.gz'):
+            seq, qual = configure.readFastq(q)
+            out[os.path.basename(q)] = dict(readFastq=[seq, qual])
+        if name.endswith('.fa'):
+            out[name]['readFasta'] = configure.readFasta(p_)
+            out[name]['readFasta_headOnly'] = configure.readFasta(p_, headOnly=True)
+            out[name]['clust_readFasta'] = clust.readFasta(p_)
+    dump('g13_readers.json', dict(fasta=fasta, fastq=fastq, out=out))
+
+
 if __name__ == '__main__':
+    g13()
     g01()
     genes, refs, rel = g02()
     sam_text = g03(genes, refs, rel)

@@ -240,3 +240,22 @@ def test_run_end_to_end_with_canned_aligner_output(tmp_path, monkeypatch, oracle
     assert list(UB.uberBlast(('-r %s -q %s --blastn -t 1' % (rf, qf)).split()).shape) == e['shape']
     r2 = UB.uberBlast(('-r %s -q %s --blastn -O -t 1' % (rf, qf)).split())
     assert [list(r2[0].shape), list(r2[1].shape)] == e['shape_O']
+
+
+def test_readers(tmp_path):
+    import gzip
+    from peppan_amd import clust as CL
+    g = load_golden('g13_readers.json')
+    for name, text in (('x.fa', g['fasta']), ('x.fq', g['fastq'])):
+        p = tmp_path / name
+        p.write_text(text)
+        with gzip.open(str(p) + '.gz', 'wt') as f:
+            f.write(text)
+        for q in (str(p), str(p) + '.gz'):
+            seq, qual = configure.readFastq(q)
+            assert [seq, qual] == g['out'][os.path.basename(q)]['readFastq']
+            assert configure.readFastq(q, with_qual=False)[0] == seq
+    fa = str(tmp_path / 'x.fa')
+    assert configure.readFasta(fa) == g['out']['x.fa']['readFasta']
+    assert configure.readFasta(fa, headOnly=True) == g['out']['x.fa']['readFasta_headOnly']
+    assert CL.readFasta(fa) == g['out']['x.fa']['clust_readFasta']
