@@ -566,11 +566,41 @@ def genome_table(rng, n_gene=12, n_contig=2):
     return tab
 
 
+def crafted_filter_table():
+    """rows built to walk every branch of ovlFilter (uberBlast.py:423-448) and the merge / edge logic of _linearMerge"""
+    rows = []
+
+    def add(q, r, iden, qs, qe, ss, se, score, ql=900, sl=20000):
+        rows.append([q, r, iden, qe - qs + 1, 2, 0, qs, qe, ss, se, 0.0, float(score), ql, sl, [[qe - qs + 1, 'M']], len(rows)])
+    add('500', 'c9', 0.95, 1, 900, 1000, 1899, 800)        # A
+    add('500', 'c9', 0.90, 40, 860, 1050, 1870, 700)       # B inside A, weaker -> dropped (2nd branch)
+    add('500', 'c9', 0.80, 1, 500, 3000, 3500, 300)        # C
+    add('500', 'c9', 0.92, 1, 590, 3010, 3600, 500)        # D covers C, stronger -> C dropped (1st branch)
+    add('500', 'c9', 0.85, 100, 200, 5000, 5100, 100)      # G short, contained in H on ref AND query (3rd branch, no-op + break)
+    add('500', 'c9', 0.85, 50, 850, 5000, 5800, 100)       # H
+    add('500', 'c9', 0.85, 1, 700, 7000, 7700, 90)         # I long
+    add('500', 'c9', 0.85, 300, 400, 7100, 7200, 90)       # J contained in I on both axes (4th branch -> dropped)
+    add('501', 'c9', 0.97, 1, 900, 1899, 1000, 850)        # reverse strand duplicates of A/B
+    add('501', 'c9', 0.91, 30, 870, 1880, 1040, 650)
+    add('502', 'c9', 0.9, 1, 300, 9000, 9299, 250)         # collinear fragments of one gene -> linearMerge chains them
+    add('502', 'c9', 0.88, 320, 600, 9330, 9610, 230)
+    add('502', 'c9', 0.86, 620, 900, 9640, 9920, 220)
+    add('503', 'c7', 0.9, 1, 450, 19551, 20000, 400, 900, 20000)   # gene split over two contig ends (resolve_edges)
+    add('503', 'c8', 0.9, 451, 900, 1, 450, 410, 900, 20000)
+    add('504', 'c7', 0.9, 1, 450, 450, 1, 400, 900, 20000)         # same, reverse strand
+    add('504', 'c8', 0.9, 451, 900, 20000, 19551, 410, 900, 20000)
+    tab = np.empty([len(rows), 16], dtype=object)
+    for i, r in enumerate(rows):
+        for j, v in enumerate(r):
+            tab[i, j] = v
+    return tab
+
+
 def g07():
     rng = np.random.default_rng(77)
     cases = []
-    for rep in range(3):
-        tab = genome_table(rng)
+    for rep in range(4):
+        tab = genome_table(rng) if rep < 3 else crafted_filter_table()
         rb = uberBlast.RunBlast()
         f = rb.ovlFilter(copy.deepcopy(tab), [True, 0.9, 0.])
         f2 = rb.ovlFilter(copy.deepcopy(tab), [True, 0.5, 10.])
