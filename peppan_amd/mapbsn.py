@@ -1,0 +1,436 @@
+"""The caller and the on-disk formats on the far side of the genes->genomes mapping search.
+
+    MapBsn              PEPPAN.py:27-114    zip archive whose members are .npy payloads keyed by str(key)
+    decodeSeq           PEPPAN.py:318-324   base-5 triple packing of the aligned-allele strings
+    compare_prediction  PEPPAN.py:869-901   overlap of every hit with the genome's original annotation (column 10)
+    iter_map_bsn        PEPPAN.py:759-867   one genome: search + grouping of merged fragments + allele strings + overlap classes
+    get_map_bsn         PEPPAN.py:907-989   all genomes -> the four stores (.tab / .seq / .mat / .conflicts)
+
+The reference runs one forked worker and one uberBlast call per genome (PEPPAN.py:922).  Here `get_map_bsn` hands MANY
+genomes to one GPU search (`uberBlastBatch`, pep_set_target_groups keeps the per-genome ranking) and then performs the
+same per-genome bookkeeping, in genome order, so the stores are those of the reference's in-order `map` variant
+(PEPPAN.py:923).  Everything below the search is host logic pinned by tests/golden/g14_mapbsn.json / g15_getmapbsn.json.
+"""
+import io
+import os
+import re
+import zipfile
+
+import numpy as np
+
+from .configure import logger, rc
+
+__all__ = ['MapBsn', 'decodeSeq', 'encodeSeq', 'compare_prediction', 'build_bsn', 'iter_map_bsn', 'get_map_bsn']
+
+
+def _npy_bytes(val):
+    buf = io.BytesIO()
+    np.lib.format.write_array(buf, np.asanyarray(val), allow_pickle=True)
+    return buf.getvalue()
+
+
+class MapBsn(object):
+    """dict-like store: zip member `str(key)` holds one array in .npy format (object arrays pickled).  Readable by
+    `np.load(fname, allow_pickle=True)` like the reference's files (PEPPAN.py:1931)."""
+
+    def __init__(self, fname, mode='r'):
+        self.fname, self.mode = fname, mode
+        self.conn = zipfile.ZipFile(fname, mode=mode, compression=zipfile.ZIP_DEFLATED, allowZip64=True)
+        self.namelist = set(self.conn.namelist())
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.conn.close()
+
+    def exists(self, key):
+        return str(key) in self.namelist
+
+    def get(self, key, default=[]):
+        key = str(key)
+        if key not in self.namelist:
+            return default
+        return np.lib.format.read_array(io.BytesIO(self.conn.read(key)), allow_pickle=True)
+
+    __getitem__ = get
+
+    def keys(self):
+        return self.namelist
+
+    def values(self):
+        for key in self.namelist:
+            yield self.get(key)
+
+    def items(self):
+        for key in self.namelist:
+            yield key, self.get(key)
+
+    def size(self):
+        return len(self.namelist)
+
+    def delete(self, key):
+        """logical delete: the member stays in the archive but is no longer listed"""
+        self.namelist.discard(str(key))
+
+    def pop(self, key, default=[]):
+        val = self.get(key, default)
+        self.delete(key)
+        return val
+
+    def delete_real(self, key):
+        """physically drop a member.  The reference shells out to `zip -d` and reopens the archive with mode 'w'
+        (PEPPAN.py:71-77), which truncates it; here the archive is rewritten in-process without the member and every other
+        member is kept."""
+        key = str(key)
+        if key not in self.namelist:
+            return
+        self.namelist.discard(key)
+        self.conn.close()
+        tmp = self.fname + '.rewrite'
+        with zipfile.ZipFile(self.fname) as src, zipfile.ZipFile(tmp, 'w', compression=zipfile.ZIP_DEFLATED, allowZip64=True) as dst:
+            for name in src.namelist():
+                if name != key:
+                    dst.writestr(name, src.read(name))
+        os.replace(tmp, self.fname)
+        self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True)
+
+    def _save(self, db, key, val):
+        db.writestr(key, _npy_bytes(val))
+
+    def save(self, key, val):
+        key = str(key)
+        self.delete_real(key)
+        self._save(self.conn, key, val)
+        self.namelist.add(key)
+
+    def update(self, dataset):
+        """merge a list of 2-D arrays, each keyed by its [0][0], into the store (rows appended to what the key holds)"""
+        tmp_name = self.fname[:-4] + '.tmp.npz'
+        seen = set()
+        with zipfile.ZipFile(tmp_name, mode='w', compression=zipfile.ZIP_DEFLATED, allowZip64=True) as tmp:
+            for d in dataset:
+                key = str(d[0][0])
+                seen.add(key)
+                old = self.get(key)
+                self._save(tmp, key, np.vstack([old, d]) if len(old) else d)
+            for key in list(self.keys()):
+                if key not in seen:
+                    data = self.get(key)
+                    if len(data):
+                        seen.add(key)
+                        self._save(tmp, key, data)
+        self.conn.close()
+        self.namelist = seen
+        os.rename(tmp_name, self.fname)
+        self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True)
+
+
+# ------------------------------------------------------------------------------------------------ allele strings
+_BASE = np.zeros(256, dtype=np.uint8)
+_BASE[[ord(c) for c in 'ACGT']] = (1, 2, 3, 4)
+
+
+def encodeSeq(b):
+    """uint8 base codes (0 gap/unknown, 1..4 ACGT) of length L -> ceil(L/3) bytes: first third * 25 + second third * 5 +
+    last third (zero padded), the packing at PEPPAN.py:847-848"""
+    s = -(-b.shape[0] // 3)
+    tail = np.concatenate([b, np.zeros(-b.shape[0] % 3, dtype=int)])[2 * s:]
+    return (b[:s] * 25 + b[s:2 * s] * 5 + tail).astype(np.uint8)
+
+
+def decodeSeq(seqs):
+    """inverse of encodeSeq for a [n, s] matrix (PEPPAN.py:318-324): [n, 3s] codes"""
+    n, s = seqs.shape
+    out = np.zeros([n, s * 3], dtype=np.uint8)
+    out[:, :s] = seqs // 25
+    out[:, s:2 * s] = (seqs % 25) // 5
+    out[:, 2 * s:] = seqs % 5
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ old annotation
+def _stable_order(tab, keys):
+    """row order of a stable multi-key sort (first key most significant), like DataFrame.sort_values(by=keys)"""
+    cols = []
+    for k in reversed(keys):
+        c = (k if isinstance(k, np.ndarray) else tab[:, k]).tolist()
+        if any(isinstance(v, str) for v in c):
+            cols.append(np.unique(np.array(c, dtype=str), return_inverse=True)[1])
+        elif all(isinstance(v, (int, np.integer)) for v in c):
+            cols.append(np.asarray(c, dtype=np.int64))
+        else:
+            cols.append(np.asarray(c, dtype=np.float64))
+    return np.lexsort(cols)
+
+
+def compare_prediction(blastab, old_prediction):
+    """column 10 <- the largest fraction of an in-frame, same-strand original gene that a hit covers (0.1 if none);
+    returns the table sorted by (query, contig, score).  PEPPAN.py:869-901."""
+    lo = np.minimum(blastab[:, 8].astype(np.int64), blastab[:, 9].astype(np.int64))
+    blastab = blastab[_stable_order(blastab, [1, lo])]
+    blastab[:, 10] = 0.1
+    with MapBsn(old_prediction) as op:
+        contig, genes, at = None, [], 0
+        for bsn in blastab:
+            if contig != bsn[1]:
+                contig, genes, at = bsn[1], op.get(bsn[1]), 0
+            head, tail = bsn[8] - bsn[6] + 1, bsn[9] + (bsn[12] - bsn[7])
+            if bsn[8] < bsn[9]:
+                s, e = bsn[8], bsn[9]
+                frames = {head % 3 + 1, (tail + 1) % 3 + 1}
+            else:
+                s, e = bsn[9], bsn[8]
+                frames = {(-head) % 3 - 1, (-(tail - 1)) % 3 - 1}
+            while at < len(genes) and s > genes[at][2]:
+                at += 1
+            for p in genes[at:]:
+                if e < p[1]:
+                    break
+                if p[3] == '+':
+                    if p[1] % 3 + 1 not in frames and (p[2] + 1) % 3 + 1 not in frames:
+                        continue
+                elif (-(p[1] - 1)) % 3 - 1 not in frames and (-p[2]) % 3 - 1 not in frames:
+                    continue
+                plen = p[2] - p[1] + 1
+                ovl = min(e, p[2]) - max(s, p[1]) + 1.
+                if ovl >= 0.6 * plen or ovl >= 0.6 * (e - s + 1):
+                    ovl = ovl / plen
+                    if ovl > bsn[10]:
+                        bsn[10] = ovl
+    return blastab[_stable_order(blastab, [0, 1, 11])]
+
+
+# ------------------------------------------------------------------------------------------------ one genome
+def _passes(length, ql, params):
+    return (length >= max(params['match_prop'] * ql, params['match_len']) or
+            length >= max(params['match_prop1'] * ql, params['match_len1']) or
+            length >= max(params['match_prop2'] * ql, params['match_len2']))
+
+
+_CIGAR_RUN = re.compile(r'(\d+)([A-Z])')
+
+
+def _allele(tab, seq, stop):
+    """aligned allele string of one hit ('-' for query-only columns), the in-frame score and the longest ORF stretch"""
+    if tab[8] < tab[9]:
+        ref = seq[tab[1]][tab[8] - 1:tab[9]]
+    else:
+        ref = rc(seq[tab[1]][tab[9] - 1:tab[8]])
+    parts, at, frame, per_frame = [], 0, 0, [0, 0, 0]
+    for n, op in _CIGAR_RUN.findall(tab[14]):
+        n = int(n)
+        if op == 'M':
+            parts.append(ref[at:at + n])
+            at += n
+            per_frame[frame] += n
+        elif op == 'D':
+            at += n
+            frame = (frame - n) % 3
+        else:
+            parts.append('-' * n)
+            frame = (frame + n) % 3
+    ms = ''.join(parts)
+    codons = re.findall('...', ms)
+    stops = np.array([i for i, c in enumerate(codons) if c in stop], dtype=np.int64) * 3
+    orf = np.max(np.diff(np.concatenate([[0], stops, [len(ms)]])))
+    return ms, np.min([np.max(per_frame), orf + 3])
+
+
+def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params):
+    """(17-column table with merge groups, int[m,3] overlaps) of ONE genome -> (bsn object[n,7], ovl int[k,3]).
+    bsn row = [gene, contig, score, identity, packed allele, group id, rows(object[k,16])].  PEPPAN.py:773-866."""
+    stop = ['TAG', 'TAA', 'TGA'] if params['gtable'] != 4 else ['TAA', 'TAG']
+    if blastab.shape[0] == 0:
+        return np.empty([0, 7], dtype=object), np.zeros([0, 3], dtype=np.int64)
+    blastab.T[:2] = blastab.T[:2].astype(int)
+    blastab = compare_prediction(blastab, old_prediction)
+    n_id = int(np.max(blastab.T[15])) + 1
+    kept = np.zeros(n_id, dtype=bool)
+    single, chained = [], {}
+    mi = params['match_identity']
+    for tab in blastab:
+        grp = tab[16]
+        if not (grp[1] >= mi and _passes(grp[2], tab[12], params)):
+            tab[2] = -1
+            continue
+        kept[tab[15]] = True
+        if len(grp) <= 4:
+            single.append([tab[0], tab[1], grp[0], grp[1], None, 0, [tab[:16]]])
+            continue
+        if tab[2] >= mi and _passes(tab[7] - tab[6] + 1, tab[12], params):
+            single.append([tab[0], tab[1], tab[11], tab[2], None, 0, [tab[:16]]])
+        members = grp[3:]
+        if grp[3] not in chained:
+            chained[grp[3]] = [tab[0], tab[1], grp[0], grp[1], None, 0, [[]] * len(members)]
+        chained[grp[3]][6][members.index(tab[15])] = tab[:16]
+    groups = single + list(chained.values())
+    overlap = overlap[kept[overlap.T[0]] & kept[overlap.T[1]], :2]
+    as_single, as_chain = np.full(n_id, -1, dtype=np.int64), np.full(n_id, -1, dtype=np.int64)
+    seq = dict(seq)
+    for gid, group in enumerate(groups):
+        rows = np.array(group[6])
+        codes = np.zeros(rows[0][12], dtype=np.uint8)
+        (as_single if rows.shape[0] == 1 else as_chain)[rows.T[15].astype(int)] = gid
+        spans = []
+        for tab in rows:
+            ms, sc = _allele(tab, seq, stop)
+            x = _BASE[np.frombuffer(ms.encode('ascii'), dtype=np.uint8)]
+            codes[tab[6] - 1:tab[6] + len(x) - 1] = x
+            r = np.sqrt(float(sc) / tab[12] * tab[10])
+            msc = (sc * tab[2]) * np.sqrt(sc * r)
+            spans.append([tab[6], tab[7], float(msc) / (tab[7] - tab[6] + 1), msc])
+        for prev, cur in zip(spans[:-1], spans[1:]):          # fragments overlapping on the query: the weaker one is trimmed
+            if cur[0] < prev[1]:
+                if cur[2] > prev[2]:
+                    prev[1] = cur[0] - 1
+                    prev[3] = prev[2] * (prev[1] - prev[0] + 1)
+                else:
+                    cur[0] = prev[1] + 1
+                    cur[3] = cur[2] * (cur[1] - cur[0] + 1)
+        group[2] = np.sum([c[3] for c in spans])
+        group[4], group[5], group[6] = encodeSeq(codes), gid, rows
+    a0, c0, a1, c1 = as_single[overlap.T[0]], as_chain[overlap.T[0]], as_single[overlap.T[1]], as_chain[overlap.T[1]]
+    overlap = np.vstack([np.vstack([m, n]).T[(m >= 0) & (n >= 0)] for m in (a0, c0) for n in (a1, c1)] +
+                        [np.vstack([as_single, as_chain]).T[(as_single >= 0) & (as_chain >= 0)]])
+    bsn = np.empty([len(groups), 7], dtype=object)
+    for i, group in enumerate(groups):
+        for j, v in enumerate(group):
+            bsn[i, j] = v
+    if overlap.shape[0]:
+        og = np.load(orthoGroup, allow_pickle=True) if isinstance(orthoGroup, str) else orthoGroup
+        rel = {}
+        for g in og[og.T[2] != 0]:
+            rel[(g[0], g[1])] = 1 if g[2] > 0 else -1
+        for g in og[og.T[2] != 0]:
+            rel[(g[1], g[0])] = 1 if g[2] > 0 else -1
+        score = np.array([0 if m == n else rel.get((m, n), 2) for m, n in zip(bsn[overlap.T[0], 0], bsn[overlap.T[1], 0])], dtype=np.int64)
+        overlap = np.hstack([overlap, score[:, np.newaxis]])[score >= 0]
+    else:
+        overlap = np.zeros([0, 3], dtype=np.int64)
+    return bsn, overlap
+
+
+def _map_argv(clust, params):
+    tools = '--blastn' if params.get('noDiamond') else '--blastn --diamond'
+    tail = '-t 1 -e 0,3' if params.get('noDiamond') else '-t 1 -s 1 -e 0,3'
+    return '-q {0} -f -m -O {1} --min_id {2} --min_cov {3} --min_ratio {4} --merge_gap {5} --merge_diff {6} {7} --gtable {8}'.format(
+        clust, tools, params['match_identity'] - 0.1, params['match_frag_len'], params['match_frag_prop'], params['link_gap'],
+        params['link_diff'], tail, params['gtable']).split()
+
+
+def _write_genome(prefix, id, seq):
+    gfile = '{0}.{1}.genome'.format(prefix, id)
+    with open(gfile, 'w') as fout:
+        for n, s in seq:
+            fout.write('>{0}\n{1}\n'.format(n, s))
+    return gfile
+
+
+def iter_map_bsn(data):
+    """one genome, the reference's worker signature (PEPPAN.py:759-867): writes `<prefix>.<id>.bsn.npz`, returns its prefix"""
+    from .uberBlast import uberBlast
+    prefix, clust, id, taxon, seq, orthoGroup, old_prediction, params = data
+    gfile = _write_genome(prefix, id, seq)
+    try:
+        blastab, overlap = uberBlast(['-r', gfile] + _map_argv(clust, params))
+    finally:
+        os.unlink(gfile)
+    bsn, ovl = build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params)
+    out_prefix = '{0}.{1}'.format(prefix, id)
+    np.savez_compressed(out_prefix + '.bsn.npz', bsn=bsn, ovl=ovl)
+    return out_prefix
+
+
+# ------------------------------------------------------------------------------------------------ all genomes
+CHUNK = 1000          # arrays per member of the .seq / .mat stores (PEPPAN.py:953, 962)
+BLOCK = 30000         # group ids per member of the .conflicts store (PEPPAN.py:934-947)
+
+
+def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
+    """yield (blastab, overlap) per genome, `genomes_per_batch` genomes per GPU search"""
+    from .uberBlast import uberBlastBatch
+    argv = _map_argv(clust, params)
+    for lo in range(0, len(jobs), genomes_per_batch):
+        files = [_write_genome(prefix, id, seq) for id, taxon, seq in jobs[lo:lo + genomes_per_batch]]
+        try:
+            results = uberBlastBatch(files, argv)
+        finally:
+            for f in files:
+                os.unlink(f)
+        for r in results:
+            yield r
+
+
+def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_conn, mat_conn, clf_conn, saveSeq, params, search=None):
+    """genomes: {contig id: [taxon id, sequence]} -> fills the four MapBsn stores like PEPPAN.py:907-989:
+      conn      gene id -> int rows [gene, taxon, score*1e4, ident*1e4, ident*1e4, group id, n fragments], best score first
+      seq_conn  chunk no -> object array of packed alleles (only with saveSeq)
+      mat_conn  chunk no -> object array of the hit rows of each group
+      clf_conn  block no -> CSR [30001 offsets + 30001, partner*10 + class] of group-overlap conflicts
+    `search(prefix, clust, jobs, params)` yields (blastab, overlap) per genome in job order (default: batched GPU search)."""
+    if len(genomes) == 0:
+        raise ValueError('get_map_bsn: no genome to map against')
+    taxa = {}
+    for g, s in genomes.items():
+        taxa.setdefault(s[0], []).append([g, s[1]])
+    jobs = [(id, taxon, seq) for id, (taxon, seq) in enumerate(taxa.items())]
+    og = np.load(orthoGroup, allow_pickle=True)
+    n_group = 0
+    seqs, seq_cnt = [], 0
+    mats, mat_cnt = [], 0
+    tabs, conflicts = [], {}
+
+    def flush_conflicts(block):
+        ovl = np.vstack(conflicts.pop(block))
+        clf_conn.save(block, np.concatenate([np.cumsum(np.concatenate([[0], np.bincount(ovl.T[0], minlength=BLOCK)])) + BLOCK + 1, ovl.T[1]]))
+
+    results = (search or _gpu_search)(prefix, clust, jobs, params)
+    for bId, ((id, taxon, seq), (blastab, overlap)) in enumerate(zip(jobs, results)):
+        bsn, ovl = build_bsn(blastab, overlap, seq, og, old_prediction, params)
+        last = bId == len(jobs) - 1
+        if bsn.shape[0]:
+            bsn.T[5] += n_group
+            ovl[:, :2] += n_group
+            first, n_group = n_group, n_group + bsn.shape[0]
+            bsn.T[1] = genomes.get(bsn[0, 1], [-1])[0]
+            if ovl.shape[0]:
+                for block in np.unique((ovl[:, :2] / BLOCK).astype(int)):
+                    conflicts.setdefault(block, [])
+                ovl = np.vstack([ovl, ovl[:, (1, 0, 2)]])
+                ovl = ovl[np.argsort(ovl.T[0])]
+                ovl = np.hstack([(ovl[:, :1] / BLOCK).astype(int), ovl[:, :1] % BLOCK, ovl[:, 1:2] * 10 + ovl[:, 2:]])
+                for part in np.split(ovl, np.cumsum(np.unique(ovl.T[0], return_counts=True)[1])[:-1]):
+                    conflicts[part[0, 0]].append(part[:, 1:])
+                for block in np.arange(int(first / BLOCK), int(n_group / BLOCK)):
+                    if block in conflicts:
+                        flush_conflicts(block)
+            if saveSeq:
+                seqs = np.concatenate([seqs, bsn.T[4]])
+                pieces = np.split(seqs, np.arange(CHUNK, seqs.shape[0], CHUNK))
+                seqs = pieces[-1]
+                for s in pieces[:-1]:
+                    seq_conn.save(seq_cnt, s)
+                    seq_cnt += 1
+            bsn.T[4] = bsn.T[3]
+            mats = np.concatenate([mats, bsn.T[6]])
+            pieces = np.split(mats, np.arange(CHUNK, mats.shape[0], CHUNK))
+            mats = pieces[-1]
+            for m in pieces[:-1]:
+                mat_conn.save(mat_cnt, m)
+                mat_cnt += 1
+            bsn.T[6] = np.array([len(b) for b in bsn.T[6]], dtype=np.uint8)
+            bsn.T[2:5] = bsn.T[2:5] * 10000
+            tabs.append(bsn[np.argsort(-bsn.T[2])].astype(int))
+        logger('Merged {0}.{1}'.format(prefix, id))
+        if (bId % 500 == 499 or last) and len(tabs):
+            tab = np.vstack(tabs)
+            tab = tab[np.argsort(tab.T[0], kind='mergesort')]
+            conn.update(np.split(tab, np.cumsum(np.unique(tab.T[0], return_counts=True)[1])[:-1]))
+            tabs = []
+    if saveSeq and len(seqs):
+        seq_conn.save(seq_cnt, seqs)
+    if len(mats):
+        mat_conn.save(mat_cnt, mats)
+    for block in list(conflicts.keys()):
+        flush_conflicts(block)

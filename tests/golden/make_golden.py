@@ -28,6 +28,8 @@ Fixture index:
   g11_groups.json        get_gene_group                 (PEPPAN.py:1590-1609)
   g12_writegenes.json    writeGenes                     (PEPPAN.py:1023-1039)
   g13_readers.json       readFasta / readFastq / uopen  (configure.py:90-150, clust.py:7-18)
+  g14_mapbsn.json        iter_map_bsn / compare_prediction / decodeSeq (PEPPAN.py:318-324, 759-905)
+  g15_getmapbsn.json     get_map_bsn -> MapBsn stores   (PEPPAN.py:27-114, 907-989)
 """
 import json, os, sys, stat, tempfile, shutil, io, contextlib, copy
 
@@ -99,6 +101,8 @@ os.chdir(os.path.join(SHIM, 'cwd'))
 
 import numpy as np
 import pandas as pd
+if not hasattr(np.lib.npyio, 'format'):   # numpy >= 2 dropped this alias of np.lib.format; MapBsn (PEPPAN.py:40, 89) spells it the old way
+    np.lib.npyio.format = np.lib.format
 import configure, uberBlast, clust  # noqa: E402  (the reference, flat imports)
 import PEPPAN as PEP                 # noqa: E402
 
@@ -857,6 +861,224 @@ def g13():
     dump('g13_readers.json', dict(fasta=fasta, fastq=fastq, out=out))
 
 
+# ----------------------------------------------------------------------------- G14/G15 genome mapping callers
+def nt_runs(ops):
+    return [[3 * n, o] for n, o in rle(ops)]
+
+
+def walk_identity(q, r, runs):
+    i = j = mat = mis = 0
+    for n, o in runs:
+        if o == 'M':
+            for k in range(n):
+                if q[i + k] == r[j + k]:
+                    mat += 1
+                else:
+                    mis += 1
+            i += n; j += n
+        elif o == 'I':
+            i += n
+        else:
+            j += n
+    gaps = sum(n for n, o in runs if o != 'M')
+    return mat, mis, gaps
+
+
+def map_world(rng, gid):
+    """one genome (2 contigs, integer names) + the 17-column table uberBlast -f -m -O would hand to iter_map_bsn"""
+    gene_ids = [5, 12, 13, 20, 31, 44, 45, 60, 61]
+    genes = MAP_GENES
+    contigs = {}
+    rows = []
+    old = {}
+
+    def hit(g, cid, pos, allele, runs, strand, qs=1, qe=None, extra_iden=0.0):
+        q = genes[g]
+        qe = len(q) if qe is None else qe
+        mat, mis, gaps = walk_identity(q[qs - 1:qe], allele, runs)
+        alen = sum(n for n, o in runs)
+        iden = round(mat / float(mat + mis + gaps), 3) - extra_iden
+        score = float(3 * mat - mis - 5 * sum(1 for n, o in runs if o != 'M') - gaps)
+        rl = sum(n for n, o in runs if o != 'I')
+        ss, se = (pos + 1, pos + rl) if strand > 0 else (pos + rl, pos + 1)
+        rows.append([str(g), str(cid), iden, alen, mis, sum(1 for n, o in runs if o != 'M'), qs, qe, ss, se, 0.0, score, len(q), None,
+                     [list(r) for r in runs], len(rows)])
+
+    for ci in range(2):
+        cid = 1000 + 10 * gid + ci
+        parts, pos = [], 0
+
+        def spacer(n):
+            nonlocal pos
+            t = ''.join('ACGT'[i] for i in rng.integers(0, 4, n))
+            parts.append(t); pos += n
+
+        def place(g, sub, indel, strand, record_old=None, frame_shift=False, stop_at=None):
+            nonlocal pos
+            allele, ops = mutate_cds(rng, genes[g], sub, indel)
+            runs = nt_runs(ops)
+            if stop_at is not None:
+                allele = allele[:stop_at * 3] + 'TAG' + allele[stop_at * 3 + 3:]
+            if frame_shift:                               # drop one base inside the first M run -> 1I in the middle
+                k = min(runs[0][0] - 10, 100)
+                allele = allele[:k] + allele[k + 1:]
+                runs = [[k, 'M'], [1, 'I'], [runs[0][0] - k - 1, 'M']] + runs[1:]
+            start = pos
+            parts.append(allele if strand > 0 else revcomp(allele)); pos += len(allele)
+            hit(g, cid, start, allele, runs, strand)
+            if record_old is not None:
+                old.setdefault(str(cid), []).append([g, start + 1 + record_old, start + len(allele) + record_old, '+' if strand > 0 else '-', int(rng.integers(1, 1 << 40))])
+            return start, allele, runs
+
+        spacer(int(rng.integers(50, 300)))
+        if ci == 0:
+            st, al, ru = place(12, 0.02, 0.0, 1, record_old=0)
+            # paralog 13 hits the same locus with a weaker alignment (same length genes) -> overlap pair
+            a13, o13 = genes[13], None
+            hit(13, cid, st, al[:len(genes[13])] if len(al) >= len(genes[13]) else al, [[min(len(al), len(genes[13])), 'M']], 1,
+                qe=min(len(al), len(genes[13])))
+            spacer(int(rng.integers(50, 300)))
+            place(5, 0.05, 0.0, -1, record_old=0)
+            spacer(int(rng.integers(50, 300)))
+            place(20, 0.03, 0.0, 1, record_old=1, frame_shift=True)           # old prediction in another frame
+            spacer(int(rng.integers(50, 300)))
+            place(31, 0.01, 0.0, -1, stop_at=40)                               # premature stop inside the allele
+            spacer(int(rng.integers(50, 300)))
+            # gene 44 split into two collinear fragments 150 nt apart (linearMerge chains them); 45 competes on the first
+            q = genes[44]
+            h = (len(q) // 6) * 3
+            a1, o1 = mutate_cds(rng, q[:h], 0.03, 0.0)
+            a2, o2 = mutate_cds(rng, q[h:], 0.03, 0.0)
+            s1 = pos; parts.append(a1); pos += len(a1)
+            hit(44, cid, s1, a1, nt_runs(o1), 1, qs=1, qe=h)
+            hit(45, cid, s1, a1[:min(len(a1), len(genes[45]))], [[min(len(a1), len(genes[45])), 'M']], 1, qs=1, qe=min(len(a1), len(genes[45])))
+            spacer(150)
+            s2 = pos; parts.append(a2); pos += len(a2)
+            hit(44, cid, s2, a2, nt_runs(o2), 1, qs=h + 1, qe=len(q))
+            old.setdefault(str(cid), []).append([44, s1 + 1, s2 + len(a2), '+', 77])
+        else:
+            st, al, ru = place(60, 0.04, 0.0, -1, record_old=0)
+            hit(62, cid, st, al, [[len(al), 'M']], -1)                        # unlisted paralog pair (60, 62) -> overlap score 2
+            spacer(int(rng.integers(50, 300)))
+            # short partial hit (fails every match_len / match_prop rule -> identity set to -1)
+            q = genes[61]
+            a, o = mutate_cds(rng, q[:60], 0.02, 0.0)
+            s0 = pos; parts.append(a); pos += len(a)
+            hit(61, cid, s0, a, nt_runs(o), 1, qs=1, qe=60)
+            spacer(int(rng.integers(50, 300)))
+            place(5, 0.10, 0.0, 1)
+            spacer(int(rng.integers(50, 300)))
+            # reverse-strand fragments of gene 12 that overlap on the query (tests the max_sc overlap trimming)
+            q = genes[12]
+            h = (len(q) // 6) * 3
+            a1, o1 = mutate_cds(rng, q[:h + 30], 0.02, 0.0)
+            a2, o2 = mutate_cds(rng, q[h:], 0.06, 0.0)
+            s2 = pos; parts.append(revcomp(a2)); pos += len(a2)
+            hit(12, cid, s2, a2, nt_runs(o2), -1, qs=h + 1, qe=len(q))
+            spacer(90)
+            s1 = pos; parts.append(revcomp(a1)); pos += len(a1)
+            hit(12, cid, s1, a1, nt_runs(o1), -1, qs=1, qe=h + 30)
+        spacer(int(rng.integers(50, 300)))
+        contigs[cid] = ''.join(parts)
+    for r in rows:
+        r[13] = len(contigs[int(r[1])])
+    tab = np.empty([len(rows), 16], dtype=object)
+    for i, r in enumerate(rows):
+        for j, v in enumerate(r):
+            tab[i, j] = v
+    rb = uberBlast.RunBlast()
+    tab = rb.linearMerge(tab, [True, 600., 1.5])
+    rb.fixEnd(tab, 0, 3)
+    ov = rb.returnOverlap(tab, [True, 300, 0.6])
+    tab = pd.DataFrame(tab).sort_values([0, 1, 11]).values
+    old = {c: sorted(v, key=lambda x: x[1]) for c, v in old.items()}
+    return contigs, tab, ov, old
+
+
+MAP_GENES = {}
+MAP_PARAMS = dict(noDiamond=False, match_identity=0.65, match_frag_len=50, match_frag_prop=0.25, link_gap=600, link_diff=1.5, gtable=11,
+                  match_len=250., match_len1=100., match_len2=400., match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+
+
+class InOrderPool(object):
+    def imap_unordered(self, fn, items):
+        return map(fn, items)
+
+    def close(self):
+        pass
+
+    def join(self):
+        pass
+
+
+def store_dump(fname):
+    with PEP.MapBsn(fname) as c:
+        return {k: c.get(k) for k in sorted(c.keys())}
+
+
+def g14_g15():
+    rng = np.random.default_rng(1414)
+    for g in [5, 12, 20, 31, 44, 60, 61]:
+        MAP_GENES[g] = rand_cds(rng, int(rng.integers(100, 300)))
+    MAP_GENES[13] = mutate_cds(rng, MAP_GENES[12], 0.12, 0.0)[0]
+    MAP_GENES[45] = mutate_cds(rng, MAP_GENES[44], 0.15, 0.0)[0]
+    MAP_GENES[62] = mutate_cds(rng, MAP_GENES[60], 0.10, 0.0)[0]
+    d = fake_dir()
+    os.chdir(d)
+    clust_fn = os.path.join(d, 'm.clust.exemplar')
+    with open(clust_fn, 'w') as f:
+        for g, s in MAP_GENES.items():
+            f.write('>%d\n%s\n' % (g, s))
+    self_bsn = np.array([[12, 13, 8800], [44, 45, -2], [5, 60, 0], [20, 31, 7000]], dtype=int)
+    np.save(os.path.join(d, 'm.self_bsn.npy'), self_bsn)
+    worlds = [map_world(rng, k) for k in range(3)]
+    old_fn = os.path.join(d, 'm.old_prediction.npz')
+    old_all = {}
+    with PEP.MapBsn(old_fn, 'w') as op:
+        for contigs, tab, ov, old in worlds:
+            for c, v in old.items():
+                op.save(c, np.array(v, dtype=object))
+                old_all[c] = v
+    tables = {}
+    calls = []
+
+    def fake_uber(argv, pool=None):
+        calls.append(list(argv))
+        gfile = argv[argv.index('-r') + 1]
+        first = open(gfile).readline()[1:].strip()
+        tab, ov = tables[int(first)]
+        return copy.deepcopy(tab), ov.copy()
+    PEP.uberBlast = fake_uber
+    PEP.params = dict(MAP_PARAMS)
+    # --- G14: iter_map_bsn + compare_prediction, one genome at a time
+    cases = []
+    for k, (contigs, tab, ov, old) in enumerate(worlds):
+        tables[min(contigs)] = (tab, ov)
+        seq = [[c, s] for c, s in contigs.items()]
+        cp = PEP.compare_prediction(np.array([list(r) for r in copy.deepcopy(tab)], dtype=object), old_fn)
+        pref = PEP.iter_map_bsn((os.path.join(d, 'm'), clust_fn, k, 'taxon%d' % k, seq, os.path.join(d, 'm.self_bsn.npy'), old_fn, dict(MAP_PARAMS)))
+        z = np.load(pref + '.bsn.npz', allow_pickle=True)
+        cases.append(dict(contigs=contigs, table=tab, overlap=ov, compare_prediction=cp, bsn=z['bsn'], ovl=z['ovl'], argv=calls[-1][4:]))
+        os.unlink(pref + '.bsn.npz')
+    seqs = np.array([[0, 1, 2, 3, 4, 124], [31, 62, 93, 7, 100, 55]], dtype=np.uint8)
+    dump('g14_mapbsn.json', dict(genes=MAP_GENES, self_bsn=self_bsn, params=MAP_PARAMS, old_prediction=old_all, cases=cases,
+                                 decodeSeq_in=seqs, decodeSeq_out=PEP.decodeSeq(seqs)))
+    # --- G15: get_map_bsn over the three genomes, in-order pool -> the four MapBsn stores
+    genomes = {}
+    for k, (contigs, tab, ov, old) in enumerate(worlds):
+        for c, s in contigs.items():
+            genomes[c] = [900 + k, s]
+    PEP.pool = InOrderPool()
+    out = {}
+    for save_seq in (True, False):
+        names = [os.path.join(d, 'mm%d.%s.npz' % (save_seq, x)) for x in ('tab', 'seq', 'mat', 'conflicts')]
+        with PEP.MapBsn(names[0], 'w') as c0, PEP.MapBsn(names[1], 'w') as c1, PEP.MapBsn(names[2], 'w') as c2, PEP.MapBsn(names[3], 'w') as c3:
+            PEP.get_map_bsn(os.path.join(d, 'm'), clust_fn, genomes, os.path.join(d, 'm.self_bsn.npy'), old_fn, c0, c1, c2, c3, save_seq)
+        out['saveSeq_%d' % save_seq] = {x: store_dump(n) for x, n in zip(('tab', 'seq', 'mat', 'conflicts'), names)}
+    dump('g15_getmapbsn.json', dict(genomes={str(c): v[0] for c, v in genomes.items()}, stores=out))
+    os.chdir(HERE)
+
+
 if __name__ == '__main__':
     g13()
     g01()
@@ -868,4 +1090,5 @@ if __name__ == '__main__':
     g08(genes, refs, sam_text, bsn_text)
     g09()
     g10_g11_g12()
+    g14_g15()
     shutil.rmtree(SHIM, ignore_errors=True)

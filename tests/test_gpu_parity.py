@@ -595,3 +595,74 @@ def test_k11_overlaps_vs_oracle_and_golden(ctx):
     from peppan_amd import _native as N
     with pytest.raises(N.PepError, match='sorted'):
         ctx.overlaps([1, 0], [5, 5], [9, 9], [0, 1], 300., 0.6)
+
+
+def test_get_map_bsn_batched_equals_per_genome_workers(tmp_path, monkeypatch):
+    """PEPPAN.py:907-989 on the GPU: get_map_bsn's batched search fills the same four stores as the reference's scheme of one
+    iter_map_bsn call per genome (PEPPAN.py:759-867, 922), and every full-length planted gene comes back as a group"""
+    import io, contextlib
+    from peppan_amd import mapbsn, synth
+    monkeypatch.chdir(tmp_path)
+    names, seqs = synth.make_genes(120, 0, seed=23, family=4)
+    _write_fasta('m.clust.exemplar', [str(i) for i in range(len(seqs))], seqs)
+    worlds = synth.make_genomes(seqs, 5, seed=77)
+    genomes, old = {}, {}
+    for g, (gname, contig, ann) in enumerate(worlds):
+        cid = 5000 + g
+        genomes[cid] = [900 + g, contig.decode()]
+        old[str(cid)] = np.array([[k, s, e, strand, 1] for k, s, e, strand in ann[::2]], dtype=object)    # half of them were annotated
+    with mapbsn.MapBsn('m.old_prediction.npz', 'w') as op:
+        for c, v in old.items():
+            op.save(c, v)
+    np.save('m.self_bsn.npy', np.array([[0, 1, 9000], [4, 5, -2], [8, 9, 0]], dtype=int))
+    params = dict(noDiamond=False, match_identity=0.65, match_frag_len=50, match_frag_prop=0.25, link_gap=600, link_diff=1.5, gtable=11,
+                  match_len=250., match_len1=100., match_len2=400., match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+
+    def per_genome(prefix, clust, jobs, p):                     # the reference's scheme: one worker call per genome
+        for id, taxon, seq in jobs:
+            z = np.load(mapbsn.iter_map_bsn((prefix, clust, id, taxon, seq, 'm.self_bsn.npy', 'm.old_prediction.npz', p)) + '.bsn.npz',
+                        allow_pickle=True)
+            yield z['bsn'], z['ovl']
+    stores = {}
+    with contextlib.redirect_stderr(io.StringIO()):
+        per = list(per_genome('m', 'm.clust.exemplar', [(i, t, [[c, s]]) for i, (c, (t, s)) in enumerate(genomes.items())], params))
+        for tag, kw in (('batch', {}), ('batch2', {'search': lambda *a: mapbsn._gpu_search(*a, genomes_per_batch=2)})):
+            fn = ['%s.%s.npz' % (tag, x) for x in ('tab', 'seq', 'mat', 'conflicts')]
+            with mapbsn.MapBsn(fn[0], 'w') as c0, mapbsn.MapBsn(fn[1], 'w') as c1, mapbsn.MapBsn(fn[2], 'w') as c2, mapbsn.MapBsn(fn[3], 'w') as c3:
+                mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params, **kw)
+            out = {}
+            for x, f in zip(('tab', 'seq', 'mat', 'conflicts'), fn):
+                with mapbsn.MapBsn(f) as c:
+                    out[x] = {k: c.get(k) for k in sorted(c.keys())}
+            stores[tag] = out
+
+    def plain(x):
+        if isinstance(x, np.ndarray):
+            return [plain(v) for v in x.tolist()]
+        if isinstance(x, (list, tuple)):
+            return [plain(v) for v in x]
+        return x
+    assert plain(stores['batch']) == plain(stores['batch2'])
+    # the stores against the per-genome worker outputs
+    mats = [m for k in sorted(stores['batch']['mat'], key=int) for m in stores['batch']['mat'][k]]
+    alle = [m for k in sorted(stores['batch']['seq'], key=int) for m in stores['batch']['seq'][k]]
+    want_m = [rows for bsn, ovl in per for rows in bsn.T[6]]
+    want_s = [a for bsn, ovl in per for a in bsn.T[4]]
+    assert len(mats) == len(want_m) > 300 and plain(mats) == plain(want_m) and plain(alle) == plain(want_s)
+    tab = np.vstack(list(stores['batch']['tab'].values()))
+    assert tab.shape[0] == len(want_m) and sorted(tab.T[5].tolist()) == list(range(len(want_m)))
+    # every planted allele (<= 2 % substitutions, full length) is found in its genome with identity >= 0.97
+    for g, (gname, contig, ann) in enumerate(worlds):
+        found = {(int(r[0]), int(r[1])) for r in tab if r[3] >= 9700}
+        for k, s, e, strand in ann:
+            assert (k, 900 + g) in found
+    # column 10 of the hit rows: a locus the old annotation holds is recognised (>= 0.9 of it covered, in frame)
+    best = {}
+    for rows in want_m:
+        for r in rows:
+            key = (r[1], r[0])
+            best.setdefault(key, []).append((min(r[8], r[9]), max(r[8], r[9]), r[10]))
+    for g, (gname, contig, ann) in enumerate(worlds):
+        for i, (k, s, e, strand) in enumerate(ann[::2]):
+            hits = [v for lo, hi, v in best.get((5000 + g, k), []) if min(hi, e) - max(lo, s) + 1 >= 0.9 * (e - s + 1)]
+            assert hits and max(hits) >= 0.9
