@@ -24,6 +24,7 @@
  *   pep_components          union-find of get_gene_group (partition only)   PEPPAN.py:1598-1607
  *   pep_linclust            `mmseqs createdb / linclust / createtsv`        clust.py:62-66
  *   pep_overlaps            numba tab2overlaps inside returnOverlap          uberBlast.py:73-97, 378-395
+ *   pep_alleles             aligned-allele strings + base-5 packing of iter_map_bsn   PEPPAN.py:812-835, 846-848
  */
 #ifndef PEPPAN_HIP_H
 #define PEPPAN_HIP_H
@@ -176,6 +177,25 @@ int pep_linclust(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32
  * written and the caller calls again with a buffer of *n_pairs triples. */
 int pep_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *contig, const int64_t *start, const int64_t *end, const int64_t *row_id,
                  double ovl_l, double ovl_p, int64_t *out, uint64_t cap, uint64_t *n_pairs);
+
+/* K12: aligned alleles of the genes->genomes mapping (iter_map_bsn, PEPPAN.py:812-835, 846-848).
+ * A row is one aligned locus of a gene on a contig; rows of one gene group are contiguous, group g owning rows
+ * [grp_off[g], grp_off[g+1]) in the order the reference writes them (later rows overwrite earlier ones where they share
+ * query positions).  nt / nt_off[n_contigs+1]: the contigs, ASCII, upper case.  CIGAR runs are len<<2|op (0=M 1=I 2=D), nt.
+ * Outputs: in_frame[row] = most M columns falling into one codon frame; orf[row] = longest stretch of the allele string
+ * between stop codons (gtable 4: TAA TAG, else TAG TAA TGA); packed = for every group ceil(q_len/3) bytes
+ * codes[j]*25 + codes[s+j]*5 + codes[2s+j] over the gene's coordinate system (A1 C2 G3 T4, anything else 0), groups
+ * concatenated in order.  packed_cap = bytes available in `packed`. */
+typedef struct {
+    uint32_t contig;          /* index into nt_off */
+    uint32_t q_start;         /* 1-based first query position of the alignment (column 6) */
+    uint32_t rs, re;          /* 1-based reference start / end (columns 8, 9); rs > re = reverse strand */
+    uint32_t cigar_runs, group;
+    uint64_t cigar_off;
+} pep_locus;
+int pep_alleles(pep_ctx *ctx, const uint8_t *nt, const uint64_t *nt_off, uint32_t n_contigs, uint64_t n_rows, const pep_locus *rows,
+                const uint32_t *cigar, uint64_t n_cigar, uint32_t n_groups, const uint64_t *grp_off, const uint32_t *grp_qlen, int gtable,
+                int64_t *in_frame, int64_t *orf, uint8_t *packed, uint64_t packed_cap);
 
 #ifdef __cplusplus
 }

@@ -683,3 +683,84 @@ int oracle_linclust(const uint8_t *res, const uint64_t *off, uint32_t n, int bas
     free(sel); free(cnt); free(ctr); free(acc); free(nacc); free(pri); free(rank);
     return 0;
 }
+
+/* ------------------------------------------------------------------ aligned-allele strings of the genome mapping (K12)
+ * restates the per-hit loop of iter_map_bsn (PEPPAN.py:812-835) and the base-5 packing (PEPPAN.py:846-848).
+ * PINNED: tests check it against the `bsn` arrays the reference's own iter_map_bsn wrote (tests/golden/g14_mapbsn.json).
+ * row:   contig, q_start (1-based), rs/re (1-based, rs > re = reverse strand), CIGAR runs len<<2|op (0=M 1=I 2=D) in nt.
+ * per row:  ms = the contig bases under the M columns ('-' for I columns, D columns skipped); reverse rows read the
+ *           reverse complement (any letter outside ACGT complements to 'N', configure.py:152-154);
+ *           in_frame = max over the three frames of the M columns counted in it (frame shifts: D -> f-n, I -> f+n mod 3);
+ *           orf = longest distance between consecutive stop codons of ms read in non-overlapping triples from its start
+ *                 (0 and |ms| count as borders);  stops TAG TAA TGA, table 4: TAA TAG.
+ * per group: codes[q_len] (A1 C2 G3 T4 else 0) with every row's ms written at q_start-1 in row order (later rows win),
+ *           packed[j] = codes[j]*25 + codes[s+j]*5 + codes[2s+j] (0 beyond q_len), s = ceil(q_len/3).
+ * returns 0, or -1 on inconsistent input. */
+typedef struct { uint32_t contig, q_start, rs, re, cigar_runs, pad; uint64_t cigar_off; } oracle_locus;
+
+static int allele_code(uint8_t ch) { switch (ch) { case 'A': return 1; case 'C': return 2; case 'G': return 3; case 'T': return 4; default: return 0; } }
+
+int oracle_alleles(const uint8_t *nt, const uint64_t *nt_off, uint32_t n_contigs, uint64_t n_rows, const oracle_locus *rows,
+                   const uint32_t *cigar, uint32_t n_groups, const uint64_t *grp_off, const uint32_t *grp_qlen, int gtable,
+                   int64_t *in_frame, int64_t *orf, uint8_t *packed)
+{
+    uint64_t pk = 0;
+    if (n_groups && grp_off[n_groups] != n_rows) return -1;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const int64_t ql = grp_qlen[g], s = (ql + 2) / 3;
+        uint8_t *codes = calloc((size_t)(3 * s + 3), 1);
+        for (uint64_t r = grp_off[g]; r < grp_off[g + 1]; ++r) {
+            const oracle_locus *L = rows + r;
+            if (L->contig >= n_contigs) { free(codes); return -1; }
+            const uint8_t *c = nt + nt_off[L->contig];
+            const int64_t cl = (int64_t)(nt_off[L->contig + 1] - nt_off[L->contig]);
+            const int rev = L->rs > L->re;
+            int64_t span = 0, rcons = 0;
+            for (uint32_t k = 0; k < L->cigar_runs; ++k) {
+                const uint32_t run = cigar[L->cigar_off + k];
+                if ((run & 3) != 2) span += run >> 2;
+                if ((run & 3) != 1) rcons += run >> 2;
+            }
+            const int64_t lo = rev ? L->re : L->rs, hi = rev ? L->rs : L->re;
+            if (lo < 1 || hi > cl || rcons != hi - lo + 1 || L->q_start < 1 || (int64_t)L->q_start - 1 + span > ql) { free(codes); return -1; }
+            uint8_t *ms = malloc((size_t)span + 1);
+            int64_t at = 0, o = 0, fr[3] = {0, 0, 0};
+            int f = 0;
+            for (uint32_t k = 0; k < L->cigar_runs; ++k) {
+                const uint32_t run = cigar[L->cigar_off + k];
+                const int64_t n = run >> 2;
+                const int op = run & 3;
+                if (op == 0) {
+                    for (int64_t x = 0; x < n; ++x) {
+                        int b = rev ? allele_code(c[L->rs - 1 - (at + x)]) : allele_code(c[L->rs - 1 + at + x]);
+                        if (rev && b) b = 5 - b;
+                        ms[o++] = (uint8_t)b;
+                    }
+                    at += n; fr[f] += n;
+                } else if (op == 2) {
+                    at += n; f = (int)(((f - n) % 3 + 3) % 3);
+                } else {
+                    for (int64_t x = 0; x < n; ++x) ms[o++] = 0;
+                    f = (int)((f + n) % 3);
+                }
+            }
+            int64_t best = fr[0] > fr[1] ? fr[0] : fr[1];
+            if (fr[2] > best) best = fr[2];
+            in_frame[r] = best;
+            int64_t prev = 0, longest = 0;
+            for (int64_t cd = 0; cd + 3 <= span; cd += 3) {
+                const int a = ms[cd], b = ms[cd + 1], d = ms[cd + 2];
+                const int stop = a == 4 && ((b == 1 && (d == 1 || d == 3)) || (gtable != 4 && b == 3 && d == 1));
+                if (stop) { if (cd - prev > longest) longest = cd - prev; prev = cd; }
+            }
+            if (span - prev > longest) longest = span - prev;
+            orf[r] = longest;
+            for (int64_t x = 0; x < span; ++x) codes[L->q_start - 1 + x] = ms[x];
+            free(ms);
+        }
+        for (int64_t j = 0; j < s; ++j) packed[pk + j] = (uint8_t)(codes[j] * 25 + codes[s + j] * 5 + (2 * s + j < ql ? codes[2 * s + j] : 0));
+        pk += s;
+        free(codes);
+    }
+    return 0;
+}

@@ -171,6 +171,30 @@ def components(n, a, b):
     return lab
 
 
+LOCUS_DTYPE = np.dtype([('contig', '<u4'), ('q_start', '<u4'), ('rs', '<u4'), ('re', '<u4'), ('cigar_runs', '<u4'), ('group', '<u4'),
+                        ('cigar_off', '<u8')])
+
+
+def alleles(contigs, rows, cigar, grp_off, grp_qlen, gtable=11):
+    """K12 restatement (PEPPAN.py:812-835, 846-848): contigs = list of ASCII byte strings; rows = LOCUS_DTYPE records grouped
+    by gene group -> (in_frame int64[n], orf int64[n], packed uint8[sum ceil(qlen/3)])"""
+    rows = np.ascontiguousarray(rows, dtype=LOCUS_DTYPE)
+    cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+    grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
+    grp_qlen = np.ascontiguousarray(grp_qlen, dtype=np.uint32)
+    nt = np.frombuffer(b''.join(contigs), dtype=np.uint8)
+    off = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(c) for c in contigs])
+    in_frame, orf = np.zeros(len(rows), np.int64), np.zeros(len(rows), np.int64)
+    packed = np.zeros(int(((grp_qlen.astype(np.int64) + 2) // 3).sum()), dtype=np.uint8)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc_ = lib().oracle_alleles(P(nt), P(off), C.c_uint32(len(contigs)), C.c_uint64(len(rows)), P(rows), P(cigar), C.c_uint32(len(grp_qlen)),
+                               P(grp_off), P(grp_qlen), C.c_int(gtable), P(in_frame), P(orf), P(packed))
+    if rc_ != 0:
+        raise ValueError('oracle_alleles: inconsistent rows')
+    return in_frame, orf, packed
+
+
 # --------------------------------------------------------------------------------------------
 # numpy / Python restatements of the reference's host-side steps that the HIP path runs on the GPU
 # --------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
-           'pep_rescore_nt', 'pep_components', 'pep_linclust', 'pep_overlaps']
+           'pep_rescore_nt', 'pep_components', 'pep_linclust', 'pep_overlaps', 'pep_alleles']
 
 
 class PepError(RuntimeError):
@@ -42,6 +42,9 @@ QUERY_META_DTYPE = np.dtype([('seq', '<u4'), ('frame', '<u4'), ('aa_len', '<u4')
 TARGET_META_DTYPE = np.dtype([('seq', '<u4'), ('frame', '<u4'), ('chunk_off', '<u4'), ('aa_len', '<u4')])
 NT_HIT_DTYPE = np.dtype([('q', '<u4'), ('r', '<u4'), ('qs', '<u4'), ('qe', '<u4'), ('rs', '<u4'), ('re', '<u4'),
                          ('cigar_runs', '<u4'), ('pad', '<u4'), ('cigar_off', '<u8')])
+
+LOCUS_DTYPE = np.dtype([('contig', '<u4'), ('q_start', '<u4'), ('rs', '<u4'), ('re', '<u4'), ('cigar_runs', '<u4'), ('group', '<u4'),
+                        ('cigar_off', '<u8')])
 
 _lib = None
 
@@ -274,6 +277,25 @@ class Context(object):
                 return out[:m.value]
             cap = m.value
         raise PepError('pep_overlaps: inconsistent pair count')
+
+    # ---- K12
+    def alleles(self, contigs, rows, cigar, grp_off, grp_qlen, gtable=11):
+        """contigs: list of ASCII contig strings/bytes; rows: LOCUS_DTYPE records, the rows of group g at [grp_off[g], grp_off[g+1]);
+        cigar: uint32 runs len<<2|op -> (in_frame int64[n], orf int64[n], packed uint8[sum ceil(q_len/3)])"""
+        rows = np.ascontiguousarray(rows, dtype=LOCUS_DTYPE)
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
+        grp_qlen = np.ascontiguousarray(grp_qlen, dtype=np.uint32)
+        nt, off = _pack(contigs)
+        n, ng = len(rows), len(grp_qlen)
+        in_frame, orf = np.zeros(max(n, 1), dtype=np.int64), np.zeros(max(n, 1), dtype=np.int64)
+        total = int(((grp_qlen.astype(np.int64) + 2) // 3).sum())
+        packed = np.zeros(max(total, 1), dtype=np.uint8)
+        cg = cigar if len(cigar) else np.zeros(1, np.uint32)
+        self._check(self._lib.pep_alleles(self._h, _ptr(nt), _ptr(off), C.c_uint32(len(contigs)), C.c_uint64(n), _ptr(rows), _ptr(cg), C.c_uint64(len(cigar)),
+                                          C.c_uint32(ng), _ptr(grp_off), _ptr(grp_qlen) if ng else None, C.c_int(gtable), _ptr(in_frame), _ptr(orf),
+                                          _ptr(packed), C.c_uint64(total)), 'pep_alleles')
+        return in_frame[:n], orf[:n], packed[:total]
 
     # ---- K10
     def components(self, n_nodes, a, b):

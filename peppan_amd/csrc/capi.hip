@@ -526,4 +526,16 @@ int pep_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *contig, const int64_t 
     return pep_k11_overlaps(ctx, n, contig, start, end, row_id, ovl_l, ovl_p, out, cap, n_pairs);
 }
 
+int pep_alleles(pep_ctx *ctx, const uint8_t *nt, const uint64_t *nt_off, uint32_t n_contigs, uint64_t n_rows, const pep_locus *rows,
+                const uint32_t *cigar, uint64_t n_cigar, uint32_t n_groups, const uint64_t *grp_off, const uint32_t *grp_qlen, int gtable,
+                int64_t *in_frame, int64_t *orf, uint8_t *packed, uint64_t packed_cap)
+{
+    if (!ctx || !nt_off || (n_rows && (!rows || !cigar || !in_frame || !orf)) || (n_groups && (!grp_off || !grp_qlen || !packed))) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < n_contigs; ++i)
+        if (nt_off[i + 1] < nt_off[i]) return pep_fail(ctx, PEP_ERR_ARG, "offsets must be non-decreasing");
+    if (n_contigs && nt_off[n_contigs] && !nt) return PEP_ERR_ARG;
+    return pep_k12_alleles(ctx, nt, nt_off, n_contigs, n_rows, rows, cigar, n_cigar, n_groups, grp_off, grp_qlen, gtable, in_frame, orf, packed, packed_cap);
+}
+
 }  // extern "C"

@@ -18,7 +18,7 @@ import zipfile
 
 import numpy as np
 
-from .configure import logger, rc
+from .configure import logger
 
 __all__ = ['MapBsn', 'decodeSeq', 'encodeSeq', 'compare_prediction', 'build_bsn', 'iter_map_bsn', 'get_map_bsn']
 
@@ -208,41 +208,28 @@ def _passes(length, ql, params):
             length >= max(params['match_prop2'] * ql, params['match_len2']))
 
 
-_CIGAR_RUN = re.compile(r'(\d+)([A-Z])')
+def _encode_cigar_strings(cigars):
+    """['60M3D90M', ...] -> (uint32 runs len<<2|op with op 0=M 1=I 2=D, runs per string) with two regex passes over one joined string"""
+    joined = '|'.join(cigars) + '|'
+    lens = np.array(re.findall(r'\d+', joined), dtype=np.int64)
+    ops = np.frombuffer(re.sub(r'\d+', '', joined).encode('ascii'), dtype=np.uint8)
+    sep = ops == ord('|')
+    code = np.full(256, 3, dtype=np.uint32)
+    code[[ord('M'), ord('I'), ord('D')]] = (0, 1, 2)
+    runs = (lens.astype(np.uint32) << 2) | code[ops[~sep]]
+    per = np.diff(np.concatenate([[-1], np.nonzero(sep)[0]])) - 1
+    return runs, per
 
 
-def _allele(tab, seq, stop):
-    """aligned allele string of one hit ('-' for query-only columns), the in-frame score and the longest ORF stretch"""
-    if tab[8] < tab[9]:
-        ref = seq[tab[1]][tab[8] - 1:tab[9]]
-    else:
-        ref = rc(seq[tab[1]][tab[9] - 1:tab[8]])
-    parts, at, frame, per_frame = [], 0, 0, [0, 0, 0]
-    for n, op in _CIGAR_RUN.findall(tab[14]):
-        n = int(n)
-        if op == 'M':
-            parts.append(ref[at:at + n])
-            at += n
-            per_frame[frame] += n
-        elif op == 'D':
-            at += n
-            frame = (frame - n) % 3
-        else:
-            parts.append('-' * n)
-            frame = (frame + n) % 3
-    ms = ''.join(parts)
-    codons = re.findall('...', ms)
-    stops = np.array([i for i, c in enumerate(codons) if c in stop], dtype=np.int64) * 3
-    orf = np.max(np.diff(np.concatenate([[0], stops, [len(ms)]])))
-    return ms, np.min([np.max(per_frame), orf + 3])
-
-
-def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params):
+def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=None):
     """(17-column table with merge groups, int[m,3] overlaps) of ONE genome -> (bsn object[n,7], ovl int[k,3]).
-    bsn row = [gene, contig, score, identity, packed allele, group id, rows(object[k,16])].  PEPPAN.py:773-866."""
-    stop = ['TAG', 'TAA', 'TGA'] if params['gtable'] != 4 else ['TAA', 'TAG']
+    bsn row = [gene, contig, score, identity, packed allele, group id, rows(object[k,16])].  PEPPAN.py:773-866.
+    The per-hit allele strings, their in-frame / stop-free lengths and the packing run on the GPU (K12, `ctx.alleles`)."""
     if blastab.shape[0] == 0:
         return np.empty([0, 7], dtype=object), np.zeros([0, 3], dtype=np.int64)
+    if ctx is None:
+        from .uberBlast import get_context
+        ctx = get_context()
     blastab.T[:2] = blastab.T[:2].astype(int)
     blastab = compare_prediction(blastab, old_prediction)
     n_id = int(np.max(blastab.T[15])) + 1
@@ -256,47 +243,70 @@ def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params):
             continue
         kept[tab[15]] = True
         if len(grp) <= 4:
-            single.append([tab[0], tab[1], grp[0], grp[1], None, 0, [tab[:16]]])
+            single.append([tab[0], tab[1], grp[0], grp[1], None, 0, [tab]])
             continue
         if tab[2] >= mi and _passes(tab[7] - tab[6] + 1, tab[12], params):
-            single.append([tab[0], tab[1], tab[11], tab[2], None, 0, [tab[:16]]])
+            single.append([tab[0], tab[1], tab[11], tab[2], None, 0, [tab]])
         members = grp[3:]
         if grp[3] not in chained:
             chained[grp[3]] = [tab[0], tab[1], grp[0], grp[1], None, 0, [[]] * len(members)]
-        chained[grp[3]][6][members.index(tab[15])] = tab[:16]
+        chained[grp[3]][6][members.index(tab[15])] = tab
     groups = single + list(chained.values())
     overlap = overlap[kept[overlap.T[0]] & kept[overlap.T[1]], :2]
+    # ---- K12 over every row of every group
+    flat = [tab for group in groups for tab in group[6]]
+    n_rows = np.array([len(group[6]) for group in groups], dtype=np.int64)
+    grp_off = np.concatenate([[0], np.cumsum(n_rows)]).astype(np.uint64)
+    contigs = [s for n, s in seq]
+    cidx = {n: i for i, (n, s) in enumerate(seq)}
+    runs, per = _encode_cigar_strings([tab[14] for tab in flat])
+    from ._native import LOCUS_DTYPE
+    loci = np.zeros(len(flat), dtype=LOCUS_DTYPE)
+    loci['contig'] = [cidx[tab[1]] for tab in flat]
+    cols = np.array([[tab[6], tab[7], tab[8], tab[9], tab[12], tab[15]] for tab in flat], dtype=np.int64).reshape(-1, 6)
+    loci['q_start'], loci['rs'], loci['re'] = cols[:, 0], cols[:, 2], cols[:, 3]
+    loci['cigar_runs'] = per
+    loci['cigar_off'] = np.concatenate([[0], np.cumsum(per)[:-1]]) if len(per) else []
+    loci['group'] = np.repeat(np.arange(len(groups)), n_rows)
+    first = grp_off[:-1].astype(np.int64)
+    in_frame, orf, packed = ctx.alleles(contigs, loci, runs, grp_off, cols[first, 4], params['gtable'])
+    sc = np.minimum(in_frame, orf + 3)
+    iden = np.array([tab[2] for tab in flat], dtype=np.float64)
+    known = np.array([tab[10] for tab in flat], dtype=np.float64)
+    qspan = cols[:, 1] - cols[:, 0] + 1
+    r = np.sqrt(sc.astype(np.float64) / cols[:, 4] * known)
+    msc = (sc * iden) * np.sqrt(sc * r)
+    amsc = msc / qspan
+    pack_off = np.concatenate([[0], np.cumsum((cols[first, 4] + 2) // 3)])
+    # ---- assemble
     as_single, as_chain = np.full(n_id, -1, dtype=np.int64), np.full(n_id, -1, dtype=np.int64)
-    seq = dict(seq)
+    gid_of_row = loci['group'].astype(np.int64)
+    multi = np.repeat(n_rows > 1, n_rows)
+    as_single[cols[~multi, 5]] = gid_of_row[~multi]
+    as_chain[cols[multi, 5]] = gid_of_row[multi]
+    bsn = np.empty([len(groups), 7], dtype=object)
     for gid, group in enumerate(groups):
-        rows = np.array(group[6])
-        codes = np.zeros(rows[0][12], dtype=np.uint8)
-        (as_single if rows.shape[0] == 1 else as_chain)[rows.T[15].astype(int)] = gid
-        spans = []
-        for tab in rows:
-            ms, sc = _allele(tab, seq, stop)
-            x = _BASE[np.frombuffer(ms.encode('ascii'), dtype=np.uint8)]
-            codes[tab[6] - 1:tab[6] + len(x) - 1] = x
-            r = np.sqrt(float(sc) / tab[12] * tab[10])
-            msc = (sc * tab[2]) * np.sqrt(sc * r)
-            spans.append([tab[6], tab[7], float(msc) / (tab[7] - tab[6] + 1), msc])
-        for prev, cur in zip(spans[:-1], spans[1:]):          # fragments overlapping on the query: the weaker one is trimmed
-            if cur[0] < prev[1]:
-                if cur[2] > prev[2]:
-                    prev[1] = cur[0] - 1
-                    prev[3] = prev[2] * (prev[1] - prev[0] + 1)
-                else:
-                    cur[0] = prev[1] + 1
-                    cur[3] = cur[2] * (cur[1] - cur[0] + 1)
-        group[2] = np.sum([c[3] for c in spans])
-        group[4], group[5], group[6] = encodeSeq(codes), gid, rows
+        lo, hi = int(grp_off[gid]), int(grp_off[gid + 1])
+        if hi - lo == 1:
+            score = np.sum([msc[lo]])
+            rows = group[6][0][:16].reshape(1, 16)
+        else:
+            spans = [[cols[k, 0], cols[k, 1], amsc[k], msc[k]] for k in range(lo, hi)]
+            for prev, cur in zip(spans[:-1], spans[1:]):          # fragments overlapping on the query: the weaker one is trimmed
+                if cur[0] < prev[1]:
+                    if cur[2] > prev[2]:
+                        prev[1] = cur[0] - 1
+                        prev[3] = prev[2] * (prev[1] - prev[0] + 1)
+                    else:
+                        cur[0] = prev[1] + 1
+                        cur[3] = cur[2] * (cur[1] - cur[0] + 1)
+            score = np.sum([c[3] for c in spans])
+            rows = np.array([tab[:16] for tab in group[6]])
+        row = bsn[gid]
+        row[0], row[1], row[2], row[3], row[4], row[5], row[6] = group[0], group[1], score, group[3], packed[pack_off[gid]:pack_off[gid + 1]], gid, rows
     a0, c0, a1, c1 = as_single[overlap.T[0]], as_chain[overlap.T[0]], as_single[overlap.T[1]], as_chain[overlap.T[1]]
     overlap = np.vstack([np.vstack([m, n]).T[(m >= 0) & (n >= 0)] for m in (a0, c0) for n in (a1, c1)] +
                         [np.vstack([as_single, as_chain]).T[(as_single >= 0) & (as_chain >= 0)]])
-    bsn = np.empty([len(groups), 7], dtype=object)
-    for i, group in enumerate(groups):
-        for j, v in enumerate(group):
-            bsn[i, j] = v
     if overlap.shape[0]:
         og = np.load(orthoGroup, allow_pickle=True) if isinstance(orthoGroup, str) else orthoGroup
         rel = {}
@@ -362,7 +372,7 @@ def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
             yield r
 
 
-def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_conn, mat_conn, clf_conn, saveSeq, params, search=None):
+def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_conn, mat_conn, clf_conn, saveSeq, params, search=None, ctx=None):
     """genomes: {contig id: [taxon id, sequence]} -> fills the four MapBsn stores like PEPPAN.py:907-989:
       conn      gene id -> int rows [gene, taxon, score*1e4, ident*1e4, ident*1e4, group id, n fragments], best score first
       seq_conn  chunk no -> object array of packed alleles (only with saveSeq)
@@ -387,7 +397,7 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
 
     results = (search or _gpu_search)(prefix, clust, jobs, params)
     for bId, ((id, taxon, seq), (blastab, overlap)) in enumerate(zip(jobs, results)):
-        bsn, ovl = build_bsn(blastab, overlap, seq, og, old_prediction, params)
+        bsn, ovl = build_bsn(blastab, overlap, seq, og, old_prediction, params, ctx)
         last = bId == len(jobs) - 1
         if bsn.shape[0]:
             bsn.T[5] += n_group

@@ -24,6 +24,9 @@ class OracleContext(object):
         self.t_aa = [np.asarray(s, dtype=np.uint8) for s in seqs]
         self._direct = True
 
+    def alleles(self, contigs, rows, cigar, grp_off, grp_qlen, gtable=11):
+        return O.alleles([c.encode('ascii') if isinstance(c, str) else bytes(c) for c in contigs], rows, cigar, grp_off, grp_qlen, gtable)
+
     def set_target_groups(self, groups):
         assert groups is None or len(groups) == 0, 'the oracle searches one reference set at a time'
 

@@ -24,6 +24,7 @@ def test_struct_sizes_match_header():
     from peppan_amd import _native as N
     assert N.HIT_DTYPE.itemsize == 64 and N.NT_HIT_DTYPE.itemsize == 40
     assert N.QUERY_META_DTYPE.itemsize == 16 and N.TARGET_META_DTYPE.itemsize == 16
+    assert N.LOCUS_DTYPE.itemsize == 32
     assert C.sizeof(N.SearchParams) == 4 * 4 + 16 + 512 + 32 + 1024 + 16 + 8 + 16 + 32 + 16 + 8
     assert C.sizeof(N.Stats) == 16 * 8 + 6 * 8
 

@@ -668,3 +668,101 @@ def test_get_map_bsn_batched_equals_per_genome_workers(tmp_path, monkeypatch):
         for i, (k, s, e, strand) in enumerate(ann[::2]):
             hits = [v for lo, hi, v in best.get((5000 + g, k), []) if min(hi, e) - max(lo, s) + 1 >= 0.9 * (e - s + 1)]
             assert hits and max(hits) >= 0.9
+
+
+def _random_loci(rng, n_groups, contig_len=20000, n_contigs=3):
+    """random K12 input: contigs with N runs and planted stops, groups of 1-3 rows with indels, both strands"""
+    from peppan_amd import _native as N
+    contigs = []
+    for c in range(n_contigs):
+        s = rng.choice(list(b'ACGT'), contig_len).astype(np.uint8)
+        for _ in range(6):
+            p = int(rng.integers(0, contig_len - 40)); s[p:p + int(rng.integers(1, 30))] = ord('N')
+        for p in rng.integers(0, contig_len - 3, 300):
+            s[p:p + 3] = list(rng.choice([b'TAA', b'TAG', b'TGA']))
+        contigs.append(s.tobytes())
+    rows, cigar, grp_off, grp_qlen = [], [], [0], []
+    for g in range(n_groups):
+        ql = int(rng.integers(60, 2500))
+        q_at = 1
+        for k in range(int(rng.choice([1, 1, 1, 2, 3]))):
+            if q_at > ql - 30:
+                break
+            qs = max(1, q_at - int(rng.integers(0, 20)) * (k > 0))
+            budget = ql - qs + 1
+            runs, q_used, r_used = [], 0, 0
+            while q_used < budget:
+                m = int(min(budget - q_used, rng.integers(1, 400)))
+                runs.append((m, 0)); q_used += m; r_used += m
+                if q_used >= budget or rng.random() < 0.3:
+                    break
+                op = int(rng.choice([1, 2])); n = int(rng.integers(1, 8))
+                if op == 1:
+                    n = min(n, budget - q_used)
+                    if n == 0:
+                        break
+                    q_used += n
+                else:
+                    r_used += n
+                runs.append((n, op))
+            if runs[-1][1] == 2:
+                r_used -= runs[-1][0]; runs.pop()
+            c = int(rng.integers(0, n_contigs))
+            lo = int(rng.integers(1, contig_len - r_used))
+            rs, re_ = (lo, lo + r_used - 1) if rng.random() < 0.5 else (lo + r_used - 1, lo)
+            rows.append((c, qs, rs, re_, len(runs), g, len(cigar)))
+            cigar += [(n << 2) | op for n, op in runs]
+            q_at = qs + q_used
+        grp_off.append(len(rows)); grp_qlen.append(ql)
+    return contigs, np.array(rows, dtype=N.LOCUS_DTYPE), np.array(cigar, dtype=np.uint32), np.array(grp_off, dtype=np.uint64), np.array(grp_qlen, dtype=np.uint32)
+
+
+def test_k12_alleles_vs_oracle(ctx):
+    from oracle import oracle as O
+    from peppan_amd import _native as N
+    rng = np.random.default_rng(1212)
+    for n_groups, gtable in ((1, 11), (7, 4), (600, 11), (5000, 4)):
+        contigs, rows, cigar, grp_off, grp_qlen = _random_loci(rng, n_groups)
+        want = O.alleles(contigs, rows, cigar, grp_off, grp_qlen, gtable)
+        got = ctx.alleles(contigs, rows, cigar, grp_off, grp_qlen, gtable)
+        for w, g in zip(want, got):
+            assert w.shape == g.shape and np.array_equal(w, g)
+        assert want[1].min() >= 0 and (want[0] > 0).all()
+    # nothing to do / inconsistent input is an error, not a silent truncation
+    e = ctx.alleles([b'ACGT'], np.zeros(0, N.LOCUS_DTYPE), np.zeros(0, np.uint32), np.zeros(1, np.uint64), np.zeros(0, np.uint32))
+    assert all(len(x) == 0 for x in e)
+    contigs, rows, cigar, grp_off, grp_qlen = _random_loci(rng, 5)
+    bad = rows.copy(); bad['re'][0] += 1
+    with pytest.raises(N.PepError, match='inconsistent'):
+        ctx.alleles(contigs, bad, cigar, grp_off, grp_qlen)
+    bad = rows.copy(); bad['contig'][0] = 99
+    with pytest.raises(N.PepError, match='out of range'):
+        ctx.alleles(contigs, bad, cigar, grp_off, grp_qlen)
+
+
+def test_k12_build_bsn_matches_reference_golden(ctx, tmp_path):
+    """the GPU allele kernel inside build_bsn reproduces the bsn arrays the reference's own iter_map_bsn wrote (golden G14)"""
+    import copy
+    from conftest import load_golden
+    from peppan_amd import mapbsn
+    g = load_golden('g14_mapbsn.json')
+    old_fn = str(tmp_path / 'old.npz')
+    with mapbsn.MapBsn(old_fn, 'w') as op:
+        for contig, rows in g['old_prediction'].items():
+            op.save(contig, np.array(rows, dtype=object))
+
+    def plain(x):
+        if isinstance(x, np.ndarray):
+            return [plain(v) for v in x.tolist()]
+        if isinstance(x, (list, tuple)):
+            return [plain(v) for v in x]
+        return x
+    for case in g['cases']:
+        tab = np.empty([len(case['table']), 17], dtype=object)
+        for i, r in enumerate(case['table']):
+            for j, v in enumerate(r):
+                tab[i, j] = copy.deepcopy(v)
+        seq = [[int(c), s] for c, s in case['contigs'].items()]
+        bsn, ovl = mapbsn.build_bsn(tab, np.array(case['overlap'], dtype=int).reshape(-1, 3), seq, np.array(g['self_bsn'], dtype=int), old_fn,
+                                    dict(g['params']), ctx=ctx)
+        assert plain(ovl) == case['ovl'] and plain(bsn) == case['bsn']

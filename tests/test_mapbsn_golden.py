@@ -8,6 +8,7 @@ import pytest
 
 from conftest import load_golden
 from peppan_amd import mapbsn
+from oracle_context import OracleContext
 
 
 def obj_table(rows):
@@ -80,10 +81,10 @@ def test_build_bsn(world):
     for case in g['cases']:
         seq = [[int(c), s] for c, s in case['contigs'].items()]
         bsn, ovl = mapbsn.build_bsn(obj_table(case['table']), np.array(case['overlap'], dtype=int).reshape(-1, 3), seq, bsn_fn, old_fn,
-                                    dict(g['params']))
+                                    dict(g['params']), ctx=OracleContext())
         assert plain(ovl) == case['ovl']
         assert plain(bsn) == case['bsn']
-    empty, eo = mapbsn.build_bsn(np.empty([0, 17], dtype=object), np.zeros([0, 3], dtype=int), [], bsn_fn, old_fn, dict(g['params']))
+    empty, eo = mapbsn.build_bsn(np.empty([0, 17], dtype=object), np.zeros([0, 3], dtype=int), [], bsn_fn, old_fn, dict(g['params']), ctx=OracleContext())
     assert empty.shape == (0, 7) and eo.shape == (0, 3)
 
 
@@ -110,7 +111,7 @@ def test_get_map_bsn(world, tmp_path, save_seq):
         return iter(canned)
     with mapbsn.MapBsn(names[0], 'w') as c0, mapbsn.MapBsn(names[1], 'w') as c1, mapbsn.MapBsn(names[2], 'w') as c2, \
             mapbsn.MapBsn(names[3], 'w') as c3:
-        mapbsn.get_map_bsn(str(tmp_path / 'm'), 'CL', genomes, bsn_fn, old_fn, c0, c1, c2, c3, save_seq, dict(g['params']), search=search)
+        mapbsn.get_map_bsn(str(tmp_path / 'm'), 'CL', genomes, bsn_fn, old_fn, c0, c1, c2, c3, save_seq, dict(g['params']), search=search, ctx=OracleContext())
     exp = want['stores']['saveSeq_%d' % save_seq]
     for x, fn in zip(('tab', 'seq', 'mat', 'conflicts'), names):
         with mapbsn.MapBsn(fn) as c:
