@@ -24,6 +24,8 @@
  *   pep_components          union-find of get_gene_group (partition only)   PEPPAN.py:1598-1607
  *   pep_linclust            `mmseqs createdb / linclust / createtsv`        clust.py:62-66
  *   pep_overlaps            numba tab2overlaps inside returnOverlap          uberBlast.py:73-97, 378-395
+ *   pep_ovl_filter          RunBlast.ovlFilter (host C++)                    uberBlast.py:417-452
+ *   pep_linear_merge        RunBlast.linearMerge + _linearMerge (host C++)   uberBlast.py:100-218, 453-460
  *   pep_alleles             aligned-allele strings + base-5 packing of iter_map_bsn   PEPPAN.py:812-835, 846-848
  */
 #ifndef PEPPAN_HIP_H
@@ -196,6 +198,29 @@ typedef struct {
 int pep_alleles(pep_ctx *ctx, const uint8_t *nt, const uint64_t *nt_off, uint32_t n_contigs, uint64_t n_rows, const pep_locus *rows,
                 const uint32_t *cigar, uint64_t n_cigar, uint32_t n_groups, const uint64_t *grp_off, const uint32_t *grp_qlen, int gtable,
                 int64_t *in_frame, int64_t *orf, uint8_t *packed, uint64_t packed_cap);
+
+/* Host-side C++ (no GPU work, no context): the order-dependent greedy filters of the genome mapping.
+ * Both take the numeric columns of the hit table ALREADY SORTED the way the reference sorts it, with reverse-strand
+ * reference coordinates negated (uberBlast.py:420, 455): q / r = integer codes of the query / reference names.
+ *
+ * pep_ovl_filter (flag -f, RunBlast.ovlFilter uberBlast.py:417-452): rows sorted by (r, q, ss, qs).  iden is in/out:
+ * a dropped row gets iden = -1.
+ *
+ * pep_linear_merge (flag -m, RunBlast.linearMerge + _linearMerge uberBlast.py:100-218, 453-460): rows sorted by
+ * (q, r, ss, qs).  Per query (maximal run of equal q) it reports
+ *   keep_seq[query_off[k] .. query_off[k+1])  row indices that survive, in the insertion order of the reference's `used`
+ *                                             dictionary (duplicates possible); query_ascending[k] = 1 when nothing was chained
+ *                                             and every row is kept in order.  The reference builds a Python set from this
+ *                                             sequence and emits rows in the set's iteration order; the caller does the same.
+ *   per row i: grp_score/grp_iden/grp_span[i] and grp_ids[grp_ids_off[i] .. grp_ids_off[i+1]) = column 16 of the reference
+ *                                             ([score, identity, span, row ids...]); grp_span = -1 for rows without a group.
+ * n_keep / n_ids return the needed sizes; when they exceed keep_cap / ids_cap nothing is written and the caller calls again. */
+int pep_ovl_filter(uint64_t n, const int64_t *q, const int64_t *r, const int64_t *qs, const int64_t *qe, const int64_t *ss, const int64_t *se,
+                   const double *score, double *iden, double coverage, double delta);
+int pep_linear_merge(uint64_t n, const int64_t *q, const int64_t *r, const double *iden, const int64_t *qs, const int64_t *qe, const int64_t *ss,
+                     const int64_t *se, const double *score, const int64_t *ql, const int64_t *sl, const int64_t *rid, double gap_dist, double len_diff,
+                     int64_t *keep_seq, uint64_t keep_cap, uint64_t *n_keep, uint64_t *query_off, uint8_t *query_ascending, uint64_t *n_query,
+                     double *grp_score, double *grp_iden, int64_t *grp_span, uint64_t *grp_ids_off, int64_t *grp_ids, uint64_t ids_cap, uint64_t *n_ids);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
-           'pep_rescore_nt', 'pep_components', 'pep_linclust', 'pep_overlaps', 'pep_alleles']
+           'pep_rescore_nt', 'pep_components', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge']
 
 
 class PepError(RuntimeError):
@@ -126,6 +126,49 @@ def _pack(seqs):
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def ovl_filter(q, r, qs, qe, ss, se, score, iden, coverage, delta):
+    """pep_ovl_filter on sorted numeric columns; `iden` (float64) is updated in place: dropped rows get -1"""
+    lib = load_library()
+    n = len(q)
+    arrs = [np.ascontiguousarray(a, dtype=np.int64) for a in (q, r, qs, qe, ss, se)]
+    score = np.ascontiguousarray(score, dtype=np.float64)
+    assert iden.dtype == np.float64 and iden.flags['C_CONTIGUOUS']
+    rc_ = lib.pep_ovl_filter(C.c_uint64(n), *[_ptr(a) for a in arrs], _ptr(score), _ptr(iden), C.c_double(coverage), C.c_double(delta))
+    if rc_ != 0:
+        raise PepError('pep_ovl_filter failed (%d)' % rc_)
+
+
+def linear_merge(q, r, iden, qs, qe, ss, se, score, ql, sl, rid, gap_dist, len_diff):
+    """pep_linear_merge on sorted numeric columns -> (keep_seq, query_off, query_ascending, grp_score, grp_iden, grp_span, grp_ids_off, grp_ids)"""
+    lib = load_library()
+    n = len(q)
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+    q, r, qs, qe, ss, se, ql, sl, rid = (i64(a) for a in (q, r, qs, qe, ss, se, ql, sl, rid))
+    iden, score = f64(iden), f64(score)
+    keep_cap, ids_cap = 2 * n + 16, 2 * n + 16
+    for _ in range(2):
+        keep = np.zeros(keep_cap, dtype=np.int64)
+        q_off = np.zeros(n + 2, dtype=np.uint64)
+        asc = np.zeros(n + 1, dtype=np.uint8)
+        g_score, g_iden, g_span = np.zeros(n + 1), np.zeros(n + 1), np.zeros(n + 1, dtype=np.int64)
+        ids_off = np.zeros(n + 2, dtype=np.uint64)
+        ids = np.zeros(ids_cap, dtype=np.int64)
+        n_keep, n_query, n_ids = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        rc_ = lib.pep_linear_merge(C.c_uint64(n), _ptr(q), _ptr(r), _ptr(iden), _ptr(qs), _ptr(qe), _ptr(ss), _ptr(se), _ptr(score), _ptr(ql), _ptr(sl),
+                                   _ptr(rid), C.c_double(gap_dist), C.c_double(len_diff), _ptr(keep), C.c_uint64(keep_cap), C.byref(n_keep), _ptr(q_off),
+                                   _ptr(asc), C.byref(n_query), _ptr(g_score), _ptr(g_iden), _ptr(g_span), _ptr(ids_off), _ptr(ids), C.c_uint64(ids_cap),
+                                   C.byref(n_ids))
+        if rc_ != 0:
+            raise PepError('pep_linear_merge failed (%d)' % rc_)
+        if n_keep.value <= keep_cap and n_ids.value <= ids_cap:
+            nq = n_query.value
+            return (keep[:n_keep.value], q_off[:nq + 1].astype(np.int64), asc[:nq], g_score[:n], g_iden[:n], g_span[:n], ids_off[:n + 1].astype(np.int64),
+                    ids[:n_ids.value])
+        keep_cap, ids_cap = n_keep.value + 16, n_ids.value + 16
+    raise PepError('pep_linear_merge: inconsistent sizes')
 
 
 class Context(object):

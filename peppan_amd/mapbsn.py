@@ -96,7 +96,9 @@ class MapBsn(object):
         self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True)
 
     def _save(self, db, key, val):
-        db.writestr(key, _npy_bytes(val))
+        data = _npy_bytes(val)
+        # members are read back whole either way; deflating a few hundred bytes costs more than it saves (zlib set-up per member)
+        db.writestr(key, data, compress_type=zipfile.ZIP_STORED if len(data) < 4096 else None)
 
     def save(self, key, val):
         key = str(key)

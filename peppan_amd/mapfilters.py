@@ -27,8 +27,9 @@ def _unfold_strand(tab):
 
 
 # ------------------------------------------------------------------------------------------------ -f
-def ovl_filter(blastab, coverage, delta):
-    """drop the weaker of two hits of the same (query, reference) that overlap >= `coverage` on the reference"""
+def ovl_filter_py(blastab, coverage, delta):
+    """pure-Python statement of ovl_filter (kept as the cross-check of the C++ port in the tests)
+    drop the weaker of two hits of the same (query, reference) that overlap >= `coverage` on the reference"""
     _fold_strand(blastab)
     tab = pd.DataFrame(blastab).sort_values(by=[R, Q, SS, QS]).values
     n = tab.shape[0]
@@ -171,7 +172,8 @@ def _merge_one_query(matches, gap_dist, len_diff):
     return matches[np.array(list(keep))]
 
 
-def linear_merge(blastab, gap_dist, len_diff):
+def linear_merge_py(blastab, gap_dist, len_diff):
+    """pure-Python statement of linear_merge (kept as the cross-check of the C++ port in the tests)"""
     _fold_strand(blastab)
     tab = pd.DataFrame(blastab).sort_values([Q, R, SS, QS]).values
     qid = np.unique(tab.T[Q], return_inverse=True)[1]
@@ -179,6 +181,79 @@ def linear_merge(blastab, gap_dist, len_diff):
     tab = np.vstack([_merge_one_query(p, gap_dist, len_diff) for p in parts])
     _unfold_strand(tab)
     return tab
+
+
+# ------------------------------------------------------------------------------------------------ C++ ports (libpeppan_hip.so)
+def _codes(col):
+    """integer rank of every name, in the order pandas sorts the column (numeric for ints, code-point order for strings)"""
+    vals = col.tolist()
+    if len(vals) and all(isinstance(v, (int, np.integer)) for v in vals):
+        return np.asarray(vals, dtype=np.int64)
+    return np.unique(np.array(vals, dtype=str), return_inverse=True)[1].astype(np.int64)
+
+
+def _numeric(tab, cols, dtype):
+    return [np.ascontiguousarray([row[c] for row in tab], dtype=dtype) for c in cols]
+
+
+def ovl_filter(blastab, coverage, delta):
+    """flag -f (RunBlast.ovlFilter, uberBlast.py:417-452): drop the weaker of two hits of the same (query, reference) that overlap
+    >= `coverage` on the reference.  The greedy pass itself is pep_ovl_filter (host C++ in libpeppan_hip.so)."""
+    from . import _native as N
+    _fold_strand(blastab)
+    if blastab.shape[0] == 0:
+        return blastab
+    q, r = _codes(blastab[:, Q]), _codes(blastab[:, R])
+    qs, ss = _numeric(blastab, (QS, SS), np.int64)
+    tab = blastab[np.lexsort((qs, ss, q, r))]
+    q, r = _codes(tab[:, Q]), _codes(tab[:, R])
+    qs, qe, ss, se = _numeric(tab, (QS, QE, SS, SE), np.int64)
+    score, iden = _numeric(tab, (SCORE, IDEN), np.float64)
+    N.ovl_filter(q, r, qs, qe, ss, se, score, iden, coverage, delta)
+    tab = tab[iden >= 0]
+    _unfold_strand(tab)
+    return tab
+
+
+def linear_merge(blastab, gap_dist, len_diff):
+    """flag -m (RunBlast.linearMerge + _linearMerge, uberBlast.py:100-218, 453-460): chain collinear hits of one gene; column 16 =
+    [score, identity, span, row ids...].  The chaining is pep_linear_merge (host C++); the row order inside a query that chained
+    something is the iteration order of a Python set, as in the reference, so that part stays a set comprehension here."""
+    from . import _native as N
+    _fold_strand(blastab)
+    n = blastab.shape[0]
+    if n == 0:
+        return np.hstack([blastab, np.empty((0, 1), dtype=object)])
+    q, r = _codes(blastab[:, Q]), _codes(blastab[:, R])
+    qs, ss = _numeric(blastab, (QS, SS), np.int64)
+    tab = blastab[np.lexsort((qs, ss, r, q))]
+    q, r = _codes(tab[:, Q]), _codes(tab[:, R])
+    qs, qe, ss, se, ql, sl, rid = _numeric(tab, (QS, QE, SS, SE, QLEN, SLEN, RID), np.int64)
+    score, iden = _numeric(tab, (SCORE, IDEN), np.float64)
+    keep, q_off, asc, g_score, g_iden, g_span, ids_off, ids = N.linear_merge(q, r, iden, qs, qe, ss, se, score, ql, sl, rid, gap_dist, len_diff)
+    if asc.all():
+        order = keep
+    else:
+        first_row = np.concatenate([[0], np.flatnonzero(np.diff(q)) + 1])
+        parts = []
+        for k in range(len(asc)):
+            seq = keep[q_off[k]:q_off[k + 1]]
+            if asc[k]:
+                parts.append(seq)
+            else:
+                lo = first_row[k]
+                local = (seq - lo).tolist()
+                parts.append(np.array(list({i for i in local}), dtype=np.int64) + lo)
+        order = np.concatenate(parts)
+    out = np.empty((len(order), tab.shape[1] + 1), dtype=object)
+    out[:, :-1] = tab[order]
+    s_l, i_l, sp_l, ids_l, off_l = g_score.tolist(), g_iden.tolist(), g_span.tolist(), ids.tolist(), ids_off.tolist()
+    shared = []
+    last = out.shape[1] - 1
+    for j, i in enumerate(order.tolist()):
+        out[j, last] = [s_l[i], i_l[i], sp_l[i]] + ids_l[off_l[i]:off_l[i + 1]] if sp_l[i] >= 0 else shared
+    _unfold_strand(out)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ -O
