@@ -20,8 +20,9 @@ import numpy as np  # noqa: E402
 
 
 def cpu_baseline(nts, n_sample, min_id, min_qcov):
-    """CPU oracle (scalar C port, 1 thread) timed on a bounded sample of the same workload: the first
-    n_sample queries against the whole reference.  Reported beside the GPU number, never the target."""
+    """CPU oracle (C port, OpenMP over targets in the seed phase and over (query, target) pairs in the alignment phase, all host
+    cores) timed on a bounded sample of the same workload: the first n_sample queries against the whole reference.
+    Reported beside the GPU number, never the target."""
     from oracle import oracle as O
     from peppan_amd.configure import transeq          # numpy translation (pinned to the same golden vectors as the oracle's)
     q_aa = []
@@ -31,13 +32,15 @@ def cpu_baseline(nts, n_sample, min_id, min_qcov):
     for n, frames in transeq([[i, s.decode()] for i, s in enumerate(nts)], frame='7', transl_table=11):
         for aa in frames:
             t_aa += [O.aa_codes(c.replace('-', 'X')) for o, c in O.ref_chunks(aa)]
+    cores = len(os.sched_getaffinity(0))
+    O.lib().oracle_set_threads(cores)
     t0 = time.perf_counter()
     hits, cig, st = O.search(q_aa, t_aa, O.default_params(min_id, min_qcov, 10, 5))
     dt = time.perf_counter() - t0
-    return dict(value=st['candidates'] / dt, unit='gene-pairs/s', cores=1, kind='port',
-                sample='first %d of %d queries vs all %d genes x 6 frames; %.1f s; %d candidates, %.3g SW cells (%.3g cells/s); '
-                       'reference binaries (diamond/blastn/mmseqs) are absent, so this is the oracle C port, 1 thread'
-                       % (n_sample, len(nts), len(nts), dt, st['candidates'], st['cells'], st['cells'] / dt),
+    return dict(value=st['candidates'] / dt, unit='gene-pairs/s', cores=cores, kind='port',
+                sample='first %d of %d queries vs all %d genes x 6 frames; %.1f s on %d threads; %d candidates, %.3g SW cells (%.3g cells/s); '
+                       'reference binaries (diamond/blastn/mmseqs) are absent, so this is the oracle C port (scalar code, OpenMP)'
+                       % (n_sample, len(nts), len(nts), dt, cores, st['candidates'], st['cells'], st['cells'] / dt),
                 seconds=dt, sw_cells_per_s=st['cells'] / dt)
 
 
@@ -49,12 +52,22 @@ def main():
     ap.add_argument('--genes', type=int, default=10000)
     ap.add_argument('--gene-len', type=int, default=1002)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample', type=int, default=1000)
+    ap.add_argument('--cpu-sample', type=int, default=10000, help='leading queries of the workload the CPU baseline runs (all host cores)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    # the workload, and (rank 0, N=1 only) the CPU baseline (run first: its OpenMP team is idle while the GPU steps are timed)
+    from peppan_amd import synth
+    names, seqs = synth.make_genes(args.genes, args.gene_len, seed=355)
+    order = sorted(range(len(names)), key=lambda i: names[i])     # FASTA order of the reference: sorted(names) (uberBlast.py:527, 537)
+    nts = [seqs[i] for i in order]
+    min_id, min_qcov = 45.0, 25.0                                  # PEPPAN.py:229-230 with defaults (match_identity 0.5 - 0.05, match_frag_prop 0.25)
+    cpu_line = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_line = cpu_baseline(nts, min(args.cpu_sample, len(nts)), min_id, min_qcov)
+
     import torch
     import torch.distributed as dist
     # PEPPAN_BENCH_SHARE_GPU=1 is a test hook for a one-GPU box: all ranks use device 0 and the exchange runs over gloo on
@@ -70,13 +83,9 @@ def main():
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = torch.device('cpu') if (share and world > 1) else torch.device('cuda', local_rank)
 
-    from peppan_amd import _native as N, synth, dist as pdist
-    names, seqs = synth.make_genes(args.genes, args.gene_len, seed=355)
-    order = sorted(range(len(names)), key=lambda i: names[i])     # FASTA order of the reference: sorted(names) (uberBlast.py:527, 537)
-    nts = [seqs[i] for i in order]
+    from peppan_amd import _native as N, dist as pdist
     bounds = pdist.shard_bounds([len(s) for s in nts], world)
     q0, q1 = bounds[rank], bounds[rank + 1]
-    min_id, min_qcov = 45.0, 25.0                                  # PEPPAN.py:229-230 with defaults (match_identity 0.5 - 0.05, match_frag_prop 0.25)
     params = N.default_params(min_id, min_qcov, 10, 5)
 
     ctx = N.Context(local_rank)
@@ -158,10 +167,8 @@ def main():
                          'note': 'integer-VALU-bound by construction (SURVEY 8d): valu_issue_frac = share of the VALU issue ceiling; the traceback '
                                  'pass sw_kernel<true> (selected pairs only) is a second launch that writes %.3g B of traceback codes in %.2f ms '
                                  '= %.0f GB/s' % (acc['dir_bytes'] / K, acc['ms_sw_trace'] / K, acc['dir_bytes'] / K / (acc['ms_sw_trace'] / K * 1e-3) / 1e9) + traffic_note},
-            'cpu_baseline': None,
+            'cpu_baseline': cpu_line,
         }
-        if not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(nts, min(args.cpu_sample, len(nts)), min_id, min_qcov)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -233,24 +233,38 @@ static uint64_t *find_candidates(const oracle_params *p,
             }
         }
         qsort(qs, m, sizeof(seed_t), cmp_seed);
-        for (uint32_t t = 0; t < nt; ++t) {
-            uint32_t len = (uint32_t)(to[t + 1] - to[t]);
-            for (uint32_t pos = 0; pos < len; ++pos) {
-                uint64_t k;
-                if (!seed_key(p, sh, tr + to[t], len, pos, &k)) continue;
-                uint64_t lo = 0, hi = m;
-                while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (qs[mid].key < k) lo = mid + 1; else hi = mid; }
-                for (; lo < m && qs[lo].key == k; ++lo) {
-                    if (p->ungapped_min > 0) {
-                        uint32_t qq = qs[lo].seq;
-                        if (ungapped_score(p, qr + qo[qq], (int32_t)(qo[qq + 1] - qo[qq]), (int32_t)qs[lo].pos, tr + to[t], (int32_t)len, (int32_t)pos) < p->ungapped_min) continue;
+        /* targets are independent; the candidate SET does not depend on the order they are visited in (sorted + deduplicated below) */
+        #pragma omp parallel
+        {
+            uint64_t lcap = 1 << 12, ln = 0;
+            uint64_t *lc = malloc(lcap * sizeof(uint64_t));
+            #pragma omp for schedule(dynamic, 64) nowait
+            for (uint32_t t = 0; t < nt; ++t) {
+                uint32_t len = (uint32_t)(to[t + 1] - to[t]);
+                for (uint32_t pos = 0; pos < len; ++pos) {
+                    uint64_t k;
+                    if (!seed_key(p, sh, tr + to[t], len, pos, &k)) continue;
+                    uint64_t lo = 0, hi = m;
+                    while (lo < hi) { uint64_t mid = (lo + hi) >> 1; if (qs[mid].key < k) lo = mid + 1; else hi = mid; }
+                    for (; lo < m && qs[lo].key == k; ++lo) {
+                        if (p->ungapped_min > 0) {
+                            uint32_t qq = qs[lo].seq;
+                            if (ungapped_score(p, qr + qo[qq], (int32_t)(qo[qq + 1] - qo[qq]), (int32_t)qs[lo].pos, tr + to[t], (int32_t)len, (int32_t)pos) < p->ungapped_min) continue;
+                        }
+                        int32_t d = (int32_t)pos - (int32_t)qs[lo].pos;
+                        int32_t bin = (d + DIAG_OFF) / BIN_W;
+                        if (ln == lcap) { lcap *= 2; lc = realloc(lc, lcap * sizeof(uint64_t)); }
+                        lc[ln++] = cand_key(qs[lo].seq, t, bin);
                     }
-                    int32_t d = (int32_t)pos - (int32_t)qs[lo].pos;
-                    int32_t bin = (d + DIAG_OFF) / BIN_W;
-                    if (n == cap) { cap *= 2; c = realloc(c, cap * sizeof(uint64_t)); }
-                    c[n++] = cand_key(qs[lo].seq, t, bin);
                 }
             }
+            #pragma omp critical
+            {
+                if (n + ln > cap) { while (n + ln > cap) cap *= 2; c = realloc(c, cap * sizeof(uint64_t)); }
+                memcpy(c + n, lc, ln * sizeof(uint64_t));
+                n += ln;
+            }
+            free(lc);
         }
     }
     free(qs);
@@ -365,24 +379,43 @@ static int cmp_hit_rank(const void *a, const void *b)
 
 typedef struct { int32_t bin, score, iend, jend, is, js; uint32_t nid, al, nruns; uint64_t cells; uint32_t *runs; int dead; } band_aln;
 
-/* full search.  q_off/t_off have n+1 entries (plain concatenation, no padding).
- * min_score[nq] per query.  Returns 0; caller frees *hits and *cigar with oracle_free. */
-int oracle_search(const oracle_params *p,
-                  const uint8_t *q_res, const uint64_t *q_off, uint32_t nq,
-                  const uint8_t *t_res, const uint64_t *t_off, uint32_t nt,
-                  const int32_t *min_score,
-                  oracle_hit **hits_out, uint64_t *n_hits, uint32_t **cigar_out, uint64_t *n_cigar,
-                  uint64_t *stats /* [0]=candidates [1]=cells over all candidates [2]=(q,t) pairs [3]=tracebacks */)
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* threads used by oracle_search (0 = all cores); the results do not depend on it */
+void oracle_set_threads(int n)
 {
-    uint64_t nc = 0;
-    uint64_t *cand = find_candidates(p, q_res, q_off, nq, t_res, t_off, nt, &nc);
-    oracle_hit *hits = malloc((nc + 1) * sizeof(oracle_hit));
-    uint32_t *cig = NULL; uint64_t ncig = 0, capcig = 0, nh = 0, cells_all = 0, pairs = 0, traced = 0;
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+#else
+    (void)n;
+#endif
+}
+int oracle_get_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+typedef struct { oracle_hit *hits; uint32_t nh, caph; uint32_t *cig; uint64_t ncig, capcig, cells, traced; } group_out;
+
+static oracle_hit *group_new_hit(group_out *r, uint32_t n_runs)
+{
+    if (r->nh == r->caph) { r->caph = r->caph ? r->caph * 2 : 4; r->hits = realloc(r->hits, r->caph * sizeof(oracle_hit)); }
+    if (r->ncig + n_runs > r->capcig) { r->capcig = (r->ncig + n_runs) * 2 + 64; r->cig = realloc(r->cig, r->capcig * sizeof(uint32_t)); }
+    return &r->hits[r->nh++];
+}
+
+/* all bands [g0, g1) of one (query, target) pair; cigar_off of the emitted hits is relative to r->cig */
+static void align_group(const oracle_params *p, const uint64_t *cand, uint64_t g0, uint64_t g1,
+                        const uint8_t *q_res, const uint64_t *q_off, const uint8_t *t_res, const uint64_t *t_off,
+                        const int32_t *min_score, group_out *r)
+{
     runbuf rb = {0};
-    uint64_t g0 = 0;
-    while (g0 < nc) {
-        uint64_t g1 = g0;
-        while (g1 < nc && (cand[g1] >> 18) == (cand[g0] >> 18)) ++g1;
+    {
         uint32_t q = (uint32_t)(cand[g0] >> 43), t = (uint32_t)((cand[g0] >> 18) & ((1u << 25) - 1));
         const uint8_t *qs = q_res + q_off[q], *ts = t_res + t_off[t];
         int32_t Lq = (int32_t)(q_off[q + 1] - q_off[q]), Lt = (int32_t)(t_off[t + 1] - t_off[t]);
@@ -392,10 +425,9 @@ int oracle_search(const oracle_params *p,
             int32_t dlo = bin * BIN_W - DIAG_OFF - BAND_LEAD;
             sw_out o;
             banded_sw(p, qs, Lq, ts, Lt, dlo, 0, &o);
-            cells_all += o.cells;
+            r->cells += o.cells;
             if (o.score > best) { best = o.score; best_bin = bin; }
         }
-        ++pairs;
         if (p->hsp_mode == 0) {
             if (best > 0 && best >= min_score[q]) {
                 int32_t dlo = best_bin * BIN_W - DIAG_OFF - BAND_LEAD;
@@ -404,16 +436,15 @@ int oracle_search(const oracle_params *p,
                 int32_t is, js; uint32_t nid, al;
                 traceback(&o, qs, ts, dlo, &rb, &is, &js, &nid, &al);
                 free(o.dir);
-                ++traced;
+                ++r->traced;
                 double idp = (double)nid * 100.0 / (double)al;
                 double qcov = (double)(o.iend - is + 1) * 100.0 / (double)Lq;
                 if (idp >= p->min_id_pct && qcov >= p->min_qcov_pct) {
-                    oracle_hit *h = &hits[nh++];
+                    oracle_hit *h = group_new_hit(r, rb.n);
                     h->q = q; h->t = t; h->q_start = is + 1; h->q_end = o.iend + 1; h->t_start = js + 1; h->t_end = o.jend + 1;
                     h->score = o.score; h->n_ident = nid; h->aln_len = al; h->nm = al - nid; h->bin = best_bin;
-                    h->cigar_runs = rb.n; h->cigar_off = ncig; h->cells = o.cells;
-                    if (ncig + rb.n > capcig) { capcig = (ncig + rb.n) * 2 + 64; cig = realloc(cig, capcig * sizeof(uint32_t)); }
-                    for (uint32_t r = 0; r < rb.n; ++r) cig[ncig++] = rb.runs[rb.n - 1 - r];
+                    h->cigar_runs = rb.n; h->cigar_off = r->ncig; h->cells = o.cells;
+                    for (uint32_t x = 0; x < rb.n; ++x) r->cig[r->ncig++] = rb.runs[rb.n - 1 - x];
                 }
             }
         } else {
@@ -427,10 +458,10 @@ int oracle_search(const oracle_params *p,
                 if (o.score > 0 && o.score >= min_score[q]) {
                     band_aln *b = &al_[na++];
                     traceback(&o, qs, ts, dlo, &rb, &b->is, &b->js, &b->nid, &b->al);
-                    ++traced;
+                    ++r->traced;
                     b->bin = bin; b->score = o.score; b->iend = o.iend; b->jend = o.jend; b->cells = o.cells; b->nruns = rb.n;
                     b->runs = malloc((rb.n + 1) * sizeof(uint32_t));
-                    for (uint32_t r = 0; r < rb.n; ++r) b->runs[r] = rb.runs[rb.n - 1 - r];
+                    for (uint32_t x = 0; x < rb.n; ++x) b->runs[x] = rb.runs[rb.n - 1 - x];
                 }
                 free(o.dir);
             }
@@ -443,20 +474,60 @@ int oracle_search(const oracle_params *p,
                 double idp = (double)b->nid * 100.0 / (double)b->al;
                 double qcov = (double)(b->iend - b->is + 1) * 100.0 / (double)Lq;
                 if (!b->dead && idp >= p->min_id_pct && qcov >= p->min_qcov_pct) {
-                    oracle_hit *h = &hits[nh++];
+                    oracle_hit *h = group_new_hit(r, b->nruns);
                     h->q = q; h->t = t; h->q_start = b->is + 1; h->q_end = b->iend + 1; h->t_start = b->js + 1; h->t_end = b->jend + 1;
                     h->score = b->score; h->n_ident = b->nid; h->aln_len = b->al; h->nm = b->al - b->nid; h->bin = b->bin;
-                    h->cigar_runs = b->nruns; h->cigar_off = ncig; h->cells = b->cells;
-                    if (ncig + b->nruns > capcig) { capcig = (ncig + b->nruns) * 2 + 64; cig = realloc(cig, capcig * sizeof(uint32_t)); }
-                    memcpy(cig + ncig, b->runs, b->nruns * sizeof(uint32_t));
-                    ncig += b->nruns;
+                    h->cigar_runs = b->nruns; h->cigar_off = r->ncig; h->cells = b->cells;
+                    memcpy(r->cig + r->ncig, b->runs, b->nruns * sizeof(uint32_t));
+                    r->ncig += b->nruns;
                 }
                 free(b->runs);
             }
             free(al_);
         }
-        g0 = g1;
     }
+    free(rb.runs);
+}
+
+/* full search.  q_off/t_off have n+1 entries (plain concatenation, no padding).
+ * min_score[nq] per query.  Returns 0; caller frees *hits and *cigar with oracle_free. */
+int oracle_search(const oracle_params *p,
+                  const uint8_t *q_res, const uint64_t *q_off, uint32_t nq,
+                  const uint8_t *t_res, const uint64_t *t_off, uint32_t nt,
+                  const int32_t *min_score,
+                  oracle_hit **hits_out, uint64_t *n_hits, uint32_t **cigar_out, uint64_t *n_cigar,
+                  uint64_t *stats /* [0]=candidates [1]=cells over all candidates [2]=(q,t) pairs [3]=tracebacks */)
+{
+    uint64_t nc = 0;
+    uint64_t *cand = find_candidates(p, q_res, q_off, nq, t_res, t_off, nt, &nc);
+    /* (q, t) groups of candidates are independent: aligned in parallel, results appended in group order */
+    uint64_t n_grp = 0;
+    uint64_t *grp = malloc((nc + 2) * sizeof(uint64_t));
+    for (uint64_t g = 0; g < nc; ++g)
+        if (g == 0 || (cand[g] >> 18) != (cand[g - 1] >> 18)) grp[n_grp++] = g;
+    grp[n_grp] = nc;
+    group_out *res = calloc(n_grp + 1, sizeof(group_out));
+    #pragma omp parallel for schedule(dynamic, 16)
+    for (uint64_t k = 0; k < n_grp; ++k)
+        align_group(p, cand, grp[k], grp[k + 1], q_res, q_off, t_res, t_off, min_score, &res[k]);
+    uint64_t nh = 0, ncig = 0, cells_all = 0, traced = 0;
+    const uint64_t pairs = n_grp;
+    for (uint64_t k = 0; k < n_grp; ++k) { nh += res[k].nh; ncig += res[k].ncig; }
+    oracle_hit *hits = malloc((nh + 1) * sizeof(oracle_hit));
+    uint32_t *cig = malloc((ncig + 1) * sizeof(uint32_t));
+    nh = 0; ncig = 0;
+    for (uint64_t k = 0; k < n_grp; ++k) {
+        for (uint32_t x = 0; x < res[k].nh; ++x) {
+            oracle_hit h = res[k].hits[x];
+            h.cigar_off += ncig;
+            hits[nh++] = h;
+        }
+        memcpy(cig + ncig, res[k].cig, res[k].ncig * sizeof(uint32_t));
+        ncig += res[k].ncig;
+        cells_all += res[k].cells; traced += res[k].traced;
+        free(res[k].hits); free(res[k].cig);
+    }
+    free(res); free(grp);
     /* top-k per (q, split): hits are ordered by (q, t) already */
     uint64_t out = 0, a = 0;
     uint8_t *keep = calloc(nh + 1, 1);
@@ -480,7 +551,7 @@ int oracle_search(const oracle_params *p,
         h.cigar_off = nc2; nc2 += h.cigar_runs;
         hits[out++] = h;
     }
-    free(cig); free(keep); free(tmp); free(rb.runs); free(cand);
+    free(cig); free(keep); free(tmp); free(cand);
     *hits_out = hits; *n_hits = out; *cigar_out = cig2; *n_cigar = nc2;
     if (stats) { stats[0] = nc; stats[1] = cells_all; stats[2] = pairs; stats[3] = traced; }
     return 0;
