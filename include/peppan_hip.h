@@ -24,6 +24,7 @@
  *   pep_components          union-find of get_gene_group (partition only)   PEPPAN.py:1598-1607
  *   pep_linclust            `mmseqs createdb / linclust / createtsv`        clust.py:62-66
  *   pep_overlaps            numba tab2overlaps inside returnOverlap          uberBlast.py:73-97, 378-395
+ *   pep_sha1, pep_dedup     hashlib.sha1 per gene + the duplicate collapse of writeGenes   PEPPAN.py:62, 1019, 1023-1039
  *   pep_ovl_filter          RunBlast.ovlFilter (host C++)                    uberBlast.py:417-452
  *   pep_linear_merge        RunBlast.linearMerge + _linearMerge (host C++)   uberBlast.py:100-218, 453-460
  *   pep_alleles             aligned-allele strings + base-5 packing of iter_map_bsn   PEPPAN.py:812-835, 846-848
@@ -198,6 +199,15 @@ typedef struct {
 int pep_alleles(pep_ctx *ctx, const uint8_t *nt, const uint64_t *nt_off, uint32_t n_contigs, uint64_t n_rows, const pep_locus *rows,
                 const uint32_t *cigar, uint64_t n_cigar, uint32_t n_groups, const uint64_t *grp_off, const uint32_t *grp_qlen, int gtable,
                 int64_t *in_frame, int64_t *orf, uint8_t *packed, uint64_t packed_cap);
+
+/* K13: exact-duplicate collapse of gene instances (front end of the clustering path).
+ * pep_sha1: digest[20*i..] = SHA-1 of sequence i (bytes[off[i]..off[i+1])), big-endian bytes as hashlib.sha1(seq).digest();
+ *   PEPPAN keys duplicates with int(hexdigest, 16) of it (PEPPAN.py:62, 1019).
+ * pep_dedup: writeGenes (PEPPAN.py:1023-1039) over n genes ALREADY in priority order: rep[i] = index of the first gene j <= i
+ *   with len[j..i] all equal (the same "length run": the reference forgets what it has seen whenever a different length shows
+ *   up, PEPPAN.py:1032-1033) and the same digest; rep[i] == i for a gene that is written out. */
+int pep_sha1(pep_ctx *ctx, const uint8_t *bytes, const uint64_t *off, uint32_t n, uint8_t *digest);
+int pep_dedup(pep_ctx *ctx, uint32_t n, const uint32_t *len, const uint8_t *digest, uint32_t *rep);
 
 /* Host-side C++ (no GPU work, no context): the order-dependent greedy filters of the genome mapping.
  * Both take the numeric columns of the hit table ALREADY SORTED the way the reference sorts it, with reverse-strand

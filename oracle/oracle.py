@@ -171,6 +171,28 @@ def components(n, a, b):
     return lab
 
 
+def sha1_digests(seqs):
+    """K13 restatement: the reference's own hash (hashlib.sha1, PEPPAN.py:62, 1019) as uint8[n, 20]"""
+    import hashlib
+    out = np.zeros((len(seqs), 20), dtype=np.uint8)
+    for i, s in enumerate(seqs):
+        out[i] = np.frombuffer(hashlib.sha1(s if isinstance(s, (bytes, bytearray)) else s.encode('utf-8')).digest(), dtype=np.uint8)
+    return out
+
+
+def dedup(lengths, digests):
+    """K13 restatement of the loop of writeGenes (PEPPAN.py:1026-1038) on genes in priority order: rep[i] = first gene with the same
+    digest since the last change of length; the seen-table is rebuilt whenever a different length shows up"""
+    digests = np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 20)
+    rep = np.zeros(len(lengths), dtype=np.uint32)
+    seen, open_len = {}, None
+    for i, (ln, d) in enumerate(zip(np.asarray(lengths).tolist(), digests)):
+        if ln != open_len:
+            seen, open_len = {}, ln
+        rep[i] = seen.setdefault(d.tobytes(), i)
+    return rep
+
+
 LOCUS_DTYPE = np.dtype([('contig', '<u4'), ('q_start', '<u4'), ('rs', '<u4'), ('re', '<u4'), ('cigar_runs', '<u4'), ('group', '<u4'),
                         ('cigar_off', '<u8')])
 

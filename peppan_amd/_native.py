@@ -12,7 +12,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
-           'pep_rescore_nt', 'pep_components', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge']
+           'pep_rescore_nt', 'pep_components', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup']
 
 
 class PepError(RuntimeError):
@@ -339,6 +339,25 @@ class Context(object):
                                           C.c_uint32(ng), _ptr(grp_off), _ptr(grp_qlen) if ng else None, C.c_int(gtable), _ptr(in_frame), _ptr(orf),
                                           _ptr(packed), C.c_uint64(total)), 'pep_alleles')
         return in_frame[:n], orf[:n], packed[:total]
+
+    # ---- K13
+    def sha1(self, seqs):
+        """list of str / bytes -> uint8[n, 20] SHA-1 digests (hashlib.sha1(s).digest() of each)"""
+        data, off = _pack(seqs)
+        out = np.zeros((max(len(seqs), 1), 20), dtype=np.uint8)
+        if len(seqs):
+            self._check(self._lib.pep_sha1(self._h, _ptr(data), _ptr(off), C.c_uint32(len(seqs)), _ptr(out)), 'pep_sha1')
+        return out[:len(seqs)]
+
+    def dedup(self, lengths, digests):
+        """genes in priority order -> uint32 rep[i] = first gene of the same (length run, digest); rep[i] == i for the ones kept"""
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        digests = np.ascontiguousarray(digests, dtype=np.uint8).reshape(-1, 20)
+        assert len(lengths) == len(digests)
+        rep = np.zeros(max(len(lengths), 1), dtype=np.uint32)
+        if len(lengths):
+            self._check(self._lib.pep_dedup(self._h, C.c_uint32(len(lengths)), _ptr(lengths), _ptr(digests), _ptr(rep)), 'pep_dedup')
+        return rep[:len(lengths)]
 
     # ---- K10
     def components(self, n_nodes, a, b):

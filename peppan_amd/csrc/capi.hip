@@ -538,4 +538,22 @@ int pep_alleles(pep_ctx *ctx, const uint8_t *nt, const uint64_t *nt_off, uint32_
     return pep_k12_alleles(ctx, nt, nt_off, n_contigs, n_rows, rows, cigar, n_cigar, n_groups, grp_off, grp_qlen, gtable, in_frame, orf, packed, packed_cap);
 }
 
+int pep_sha1(pep_ctx *ctx, const uint8_t *bytes, const uint64_t *off, uint32_t n, uint8_t *digest)
+{
+    if (!ctx || (n && (!off || !digest))) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < n; ++i)
+        if (off[i + 1] < off[i]) return pep_fail(ctx, PEP_ERR_ARG, "offsets must be non-decreasing");
+    if (n && off[n] && !bytes) return PEP_ERR_ARG;
+    return pep_k13_sha1(ctx, bytes, off, n, digest);
+}
+
+int pep_dedup(pep_ctx *ctx, uint32_t n, const uint32_t *len, const uint8_t *digest, uint32_t *rep)
+{
+    if (!ctx || (n && (!len || !digest || !rep))) return PEP_ERR_ARG;
+    if (n >= 0x7FFFFFFFu) return pep_fail(ctx, PEP_ERR_LIMIT, "pep_dedup: at most 2^31 - 2 genes");
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    return pep_k13_dedup(ctx, n, len, digest, rep);
+}
+
 }  // extern "C"

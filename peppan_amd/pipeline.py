@@ -19,25 +19,30 @@ from .configure import logger, readFasta, uopen
 from .uberBlast import uberBlast, get_context
 
 
-def writeGenes(fname, genes, priority):
+def gene_hashes(seqs, ctx=None):
+    """the integer PEPPAN stores per gene and breaks priority ties with: int(hashlib.sha1(seq).hexdigest(), 16)
+    (PEPPAN.py:62, 1019), computed for the whole list on the GPU (K13 `pep_sha1`)"""
+    ctx = ctx or get_context()
+    return [int.from_bytes(d.tobytes(), 'big') for d in ctx.sha1(seqs)]
+
+
+def writeGenes(fname, genes, priority, ctx=None):
     """genes in priority order; a gene whose (length, sha1) equals an already written one of the SAME length run is
-    reported as its duplicate.  The seen-table is rebuilt whenever a length not currently in it shows up
-    (PEPPAN.py:1032-1033), so duplicates are only found while one length is 'open'."""
-    seen, groups = {}, []
+    reported as its duplicate.  The reference rebuilds its seen-table whenever a length not currently in it shows up
+    (PEPPAN.py:1032-1033), so duplicates are only found while one length is 'open'.  The collapse itself runs on the GPU
+    (K13 `pep_dedup`: smallest priority index per (length run, digest))."""
+    ctx = ctx or get_context()
+    order = [n for n, _ in sorted(priority.items(), key=itemgetter(1)) if n in genes and len(genes[n][6])]
+    lengths = np.array([len(genes[n][6]) for n in order], dtype=np.uint32)
+    digests = np.frombuffer(b''.join(int(genes[n][5]).to_bytes(20, 'big') for n in order), dtype=np.uint8).reshape(-1, 20)
+    rep = ctx.dedup(lengths, digests).tolist()
+    groups = []
     with open(fname, 'w') as fout:
-        for n, _ in sorted(priority.items(), key=itemgetter(1)):
-            if n not in genes:
-                continue
-            s, code = genes[n][6], genes[n][5]
-            if not len(s):
-                continue
-            if len(s) not in seen:
-                seen = {len(s): {code: n}}
-            elif code in seen[len(s)]:
-                groups.append([seen[len(s)][code], n, 10000])
-                continue
-            seen[len(s)][code] = n
-            fout.write('>{0}\n{1}\n'.format(n, s))
+        for i, n in enumerate(order):
+            if rep[i] == i:
+                fout.write('>{0}\n{1}\n'.format(n, genes[n][6]))
+            else:
+                groups.append([order[rep[i]], n, 10000])
     return fname, groups
 
 

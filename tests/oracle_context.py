@@ -27,6 +27,12 @@ class OracleContext(object):
     def alleles(self, contigs, rows, cigar, grp_off, grp_qlen, gtable=11):
         return O.alleles([c.encode('ascii') if isinstance(c, str) else bytes(c) for c in contigs], rows, cigar, grp_off, grp_qlen, gtable)
 
+    def sha1(self, seqs):
+        return O.sha1_digests(seqs)
+
+    def dedup(self, lengths, digests):
+        return O.dedup(lengths, digests)
+
     def set_target_groups(self, groups):
         assert groups is None or len(groups) == 0, 'the oracle searches one reference set at a time'
 

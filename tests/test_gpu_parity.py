@@ -766,3 +766,38 @@ def test_k12_build_bsn_matches_reference_golden(ctx, tmp_path):
         bsn, ovl = mapbsn.build_bsn(tab, np.array(case['overlap'], dtype=int).reshape(-1, 3), seq, np.array(g['self_bsn'], dtype=int), old_fn,
                                     dict(g['params']), ctx=ctx)
         assert plain(ovl) == case['ovl'] and plain(bsn) == case['bsn']
+
+
+def test_k13_sha1_and_dedup(ctx, tmp_path):
+    """K13: SHA-1 per gene == hashlib (every padding case), duplicate collapse == the loop of writeGenes, writeGenes over the GPU == golden G12"""
+    import hashlib
+    from conftest import load_golden
+    from oracle import oracle as O
+    from peppan_amd import pipeline as PL
+    rng = np.random.default_rng(13)
+    lens = list(range(0, 140)) + [255, 256, 257, 1000, 1002, 9492, 100000] + [int(x) for x in rng.integers(1, 4000, 300)]
+    seqs = [bytes(rng.choice(list(b'ACGTN'), n).tolist()) for n in lens]
+    got = ctx.sha1(seqs)
+    assert got.shape == (len(seqs), 20)
+    for s, d in zip(seqs, got):
+        assert d.tobytes() == hashlib.sha1(s).digest()
+    assert PL.gene_hashes([s.decode() for s in seqs[:50]], ctx=ctx) == [int(hashlib.sha1(s).hexdigest(), 16) for s in seqs[:50]]
+    assert ctx.sha1([]).shape == (0, 20) and len(ctx.dedup([], np.zeros((0, 20), np.uint8))) == 0
+    # dedup: few distinct sequences, lengths arranged in runs that re-open
+    for n, n_distinct in ((1, 1), (50, 4), (20000, 300), (300000, 5000)):
+        pool = [bytes(rng.choice(list(b'ACGT'), int(rng.choice([30, 30, 33, 36]))).tolist()) for _ in range(n_distinct)]
+        pick = rng.integers(0, n_distinct, n)
+        if n > 100:                                      # mostly length-sorted like PEPPAN's priority, with a few runs out of place
+            pick = pick[np.argsort([-len(pool[k]) for k in pick], kind='stable')]
+            cut = n // 3
+            pick = np.concatenate([pick[cut:], pick[:cut]])
+        lengths = np.array([len(pool[k]) for k in pick], dtype=np.uint32)
+        dig = O.sha1_digests(pool)[pick]
+        want = O.dedup(lengths, dig)
+        assert np.array_equal(ctx.dedup(lengths, dig), want)
+        assert (want <= np.arange(n)).all()
+    g = load_golden('g12_writegenes.json')
+    genes = {int(k): ['f', '', 0, 0, '+', v[0], v[1]] for k, v in g['genes'].items()}
+    prio = {int(k): v for k, v in g['priority'].items()}
+    fn, groups = PL.writeGenes(str(tmp_path / 'w.genes'), genes, prio, ctx=ctx)
+    assert open(fn).read() == g['fasta'] and groups == g['groups']

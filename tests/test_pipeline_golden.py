@@ -107,5 +107,14 @@ def test_writegenes(tmp_path):
     g = load_golden('g12_writegenes.json')
     genes = {int(k): ['f', '', 0, 0, '+', v[0], v[1]] for k, v in g['genes'].items()}
     prio = {int(k): v for k, v in g['priority'].items()}
-    fn, groups = PL.writeGenes(str(tmp_path / 'w.genes'), genes, prio)
+    from oracle_context import OracleContext
+    from oracle import oracle as O
+    fn, groups = PL.writeGenes(str(tmp_path / 'w.genes'), genes, prio, ctx=OracleContext())     # the GPU test runs the same call over K13
     assert open(fn).read() == g['fasta'] and groups == g['groups']
+    # the fixture's hash column IS the reference's int(sha1) of each sequence: pins the hashing half as well
+    seqs = [v[1] for v in g['genes'].values() if v[1]]
+    want = [v[0] for v in g['genes'].values() if v[1]]
+    assert PL.gene_hashes(seqs, ctx=OracleContext()) == want
+    # run semantics of the duplicate table: equal digests collapse only while the length stays the same
+    d = O.sha1_digests(['A', 'A', 'CC', 'A', 'A', 'CC', 'CC'])
+    assert O.dedup([1, 1, 2, 1, 1, 2, 2], d).tolist() == [0, 0, 2, 3, 3, 5, 5]
