@@ -267,7 +267,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto &b : ctx->ws) dev_release(b);
-    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->d_min_score, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
+    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->d_min_score, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -292,7 +292,7 @@ int pep_set_ref_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint32_
     if (frames != 3 && frames != 6) return pep_fail(ctx, PEP_ERR_ARG, "frames must be 3 or 6");
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     PEP_TRY(upload_nt(ctx, ctx->r_nt, nt, off, n));
-    ctx->t_from_nt = true; ctx->t_gtable = gtable; ctx->t_frames = frames; ctx->t_ready = false;
+    ctx->t_from_nt = true; ctx->t_gtable = gtable; ctx->t_frames = frames; ctx->t_ready = false; ctx->k1_base_frames = 0;
     ctx->group_of_seq.clear(); ctx->t_class_ready = false;
     return PEP_OK;
 }

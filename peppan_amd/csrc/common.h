@@ -72,6 +72,12 @@ struct pep_ctx {
     bool q_from_nt = false, t_from_nt = false;
     bool q_ready = false, t_ready = false, sub_ready = false;
     int q_gtable = 11, t_gtable = 11, t_frames = 6;
+    // K1 reference side: chunk-slot prefix per (sequence, frame), a function of the input lengths only - kept between translations
+    DevBuf d_k1_base;
+    std::vector<uint64_t> k1_base;
+    uint64_t k1_upper = 0;
+    int k1_base_frames = 0;            // 0 = not computed for the current reference set
+    std::vector<uint8_t> k1_stage;     // host staging of downloaded descriptors (grow-only)
     DevBuf d_min_score;
     std::vector<uint32_t> group_of_seq;     // optional: competition group of every reference sequence (pep_set_target_groups)
     DevBuf d_t_class;

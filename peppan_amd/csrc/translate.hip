@@ -9,6 +9,9 @@
 // Byte-granular, HBM-bound: 3 nt bytes read per residue byte written.
 #include "common.h"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -138,10 +141,14 @@ __device__ __forceinline__ uint32_t find_seq(const uint32_t *__restrict__ off, u
 
 // one thread per 16-byte block of the packed layout: sequence starts are 16-aligned and separated by >= 16 padding
 // bytes, so a block belongs to at most one sequence -> one owner search and one 16-byte store per thread
+// The number of packed sequences and the layout's size live on the device (*n_ptr, pk_off[n]): the grid is sized from a host
+// upper bound and the surplus blocks leave at once, so the host never waits for the chunk count before launching.
 __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, int tab,
-                                               const PackDesc *__restrict__ desc, const uint32_t *__restrict__ pk_off, uint32_t n_packed,
-                                               uint8_t *__restrict__ res, uint32_t *__restrict__ blk2seq, uint64_t total)
+                                               const PackDesc *__restrict__ desc, const uint32_t *__restrict__ pk_off, const uint32_t *__restrict__ n_ptr,
+                                               uint8_t *__restrict__ res, uint32_t *__restrict__ blk2seq)
 {
+    const uint32_t n_packed = *n_ptr;
+    const uint64_t total = pk_off[n_packed];
     const uint64_t blk = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint64_t p0 = blk * 16;
     if (p0 >= total) return;
@@ -182,12 +189,74 @@ int upload_codon_table(pep_ctx *ctx)
     return PEP_OK;
 }
 
-// builds the padded layout (host prefix sums) and launches k1_pack
-int pack_from_desc(pep_ctx *ctx, const NtSet &nt, int tab, const std::vector<PackDesc> &desc, SeqSet &out, DevBuf &d_desc)
+__device__ __forceinline__ uint32_t padded_len(uint32_t len) { return (len + 15u) / 16u * 16u + PEP_SEQ_GAP; }
+
+// query side: one packed sequence per gene, the chosen frame from its start
+__global__ void k1_query_desc(uint32_t n, const uint32_t *__restrict__ frame, const uint32_t *__restrict__ len, PackDesc *__restrict__ desc,
+                              uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, uint32_t *__restrict__ n_out)
 {
-    const uint32_t n = (uint32_t)desc.size();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *n_out = n;
+    if (i >= n) return;
+    desc[i] = PackDesc{i, frame[i], 0u, len[i]};
+    padded[i] = padded_len(len[i]);
+    len_out[i] = len[i];
+}
+
+// reference side: the chunks of (sequence, frame) w become packed sequences first[w] .. first[w] + cnt[w] - 1
+__global__ void k1_ref_desc(uint64_t nw, int n_frames, const uint64_t *__restrict__ chunk_base, const uint32_t *__restrict__ chunk_cnt,
+                            const uint32_t *__restrict__ first, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_len,
+                            PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nw) return;
+    const uint32_t g = (uint32_t)(w / n_frames), f = (uint32_t)(w % n_frames) + 1;
+    const uint64_t base = chunk_base[w];
+    const uint32_t at = first[w];
+    for (uint32_t c = 0; c < chunk_cnt[w]; ++c) {
+        desc[at + c] = PackDesc{g, f, chunk_off[base + c], chunk_len[base + c]};
+        padded[at + c] = padded_len(chunk_len[base + c]);
+        len_out[at + c] = chunk_len[base + c];
+    }
+}
+
+// pk_off[i] = start of packed sequence i; entries n .. cap hold the layout's total size (sentinel of the owner search)
+__global__ void k1_offsets(const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ scan, uint32_t cap, uint32_t *__restrict__ pk_off)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > cap) return;
+    pk_off[i] = i < *n_ptr ? scan[i] + PEP_END_PAD : scan[cap] + 2 * PEP_END_PAD;
+}
+
+int reserve_packed(pep_ctx *ctx, SeqSet &out, uint32_t cap, uint64_t upper)
+{
+    if (upper > PEP_MAX_RESIDUES + (uint64_t)cap * 32) return pep_fail(ctx, PEP_ERR_LIMIT, "packed protein set exceeds 2^29 bytes");
+    PEP_TRY(dev_reserve(ctx, out.res, upper + 64));
+    PEP_TRY(dev_reserve(ctx, out.off, ((size_t)cap + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, out.len, ((size_t)cap + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, out.blk2seq, (upper / 16 + 2) * 4));
+    return PEP_OK;
+}
+
+// Device-side layout + packing (after reserve_packed).  d_desc / d_padded hold up to `cap` entries (padded = 0 beyond the *d_n real ones); `upper` bounds the
+// layout's size.  Nothing is read back here: the caller downloads the descriptors once, after everything is queued.
+int layout_and_pack(pep_ctx *ctx, const NtSet &nt, int tab, const PackDesc *d_desc, const uint32_t *d_padded, uint32_t cap, const uint32_t *d_n,
+                    uint64_t upper, SeqSet &out, DevBuf &d_scan, DevBuf &tmp)
+{
+    PEP_TRY(dev_reserve(ctx, d_scan, ((size_t)cap + 2) * 4));
+    PEP_TRY(pep_scan_u32(ctx, d_padded, d_scan.as<uint32_t>(), cap, tmp));
+    hipLaunchKernelGGL(k1_offsets, dim3((unsigned)ceil_div((uint64_t)cap + 1, 256)), dim3(256), 0, ctx->stream, d_n, d_scan.as<const uint32_t>(), cap, out.off.as<uint32_t>());
+    hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div(ceil_div(upper, 16), 256)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
+                       d_desc, out.off.as<const uint32_t>(), d_n, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>());
+    PEP_HIP(ctx, hipGetLastError());
+    return PEP_OK;
+}
+
+// host mirrors of a packed set from its downloaded descriptors (same arithmetic as k1_offsets)
+int finish_layout(pep_ctx *ctx, const PackDesc *desc, uint32_t n, SeqSet &out)
+{
     out.n = n;
-    out.h_off.assign(n + 1, 0);
+    out.h_off.assign((size_t)n + 1, 0);
     out.h_len.assign(n, 0);
     uint64_t pos = PEP_END_PAD, residues = 0;
     uint32_t max_len = 0;
@@ -197,28 +266,19 @@ int pack_from_desc(pep_ctx *ctx, const NtSet &nt, int tab, const std::vector<Pac
         residues += desc[i].len;
         max_len = std::max(max_len, desc[i].len);
         pos += ((uint64_t)desc[i].len + 15) / 16 * 16 + PEP_SEQ_GAP;
-        if (pos > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "packed protein set exceeds 2^29 bytes");
     }
     pos += PEP_END_PAD;
+    if (pos > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "packed protein set exceeds 2^29 bytes");
     out.h_off[n] = (uint32_t)pos;
     out.total = pos; out.residues = residues; out.max_len = max_len;
     if (max_len > PEP_MAX_SEQ_LEN) return pep_fail(ctx, PEP_ERR_LIMIT, "protein longer than PEP_MAX_SEQ_LEN");
-    PEP_TRY(dev_reserve(ctx, out.res, pos + 64));
-    PEP_TRY(dev_reserve(ctx, out.off, (size_t)(n + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, out.len, (size_t)(n + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, d_desc, (size_t)(n + 1) * sizeof(PackDesc)));
-    PEP_TRY(dev_reserve(ctx, out.blk2seq, (pos / 16 + 2) * 4));
-    PEP_HIP(ctx, hipMemcpyAsync(out.off.p, out.h_off.data(), (size_t)(n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (n) {
-        PEP_HIP(ctx, hipMemcpyAsync(out.len.p, out.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-        PEP_HIP(ctx, hipMemcpyAsync(d_desc.p, desc.data(), (size_t)n * sizeof(PackDesc), hipMemcpyHostToDevice, ctx->stream));
-    }
-    hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div(ceil_div(pos, 16), 256)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
-                       d_desc.as<const PackDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>(), pos);
-    PEP_HIP(ctx, hipGetLastError());
-    // the host vectors must outlive the async copies
-    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PEP_OK;
+}
+
+PackDesc *stage_desc(pep_ctx *ctx, uint64_t n)
+{
+    if (ctx->k1_stage.size() < (n + 1) * sizeof(PackDesc)) ctx->k1_stage.resize((n + 1) * sizeof(PackDesc));
+    return reinterpret_cast<PackDesc *>(ctx->k1_stage.data());
 }
 
 }  // namespace
@@ -230,24 +290,25 @@ int pep_k1_query(pep_ctx *ctx, int gtable)
     PEP_TRY(upload_codon_table(ctx));
     const uint32_t n = nt.n;
     if (n > PEP_MAX_QUERIES) return pep_fail(ctx, PEP_ERR_LIMIT, "too many queries");
-    PEP_TRY(dev_reserve(ctx, ctx->ws[0], (size_t)(n + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[1], (size_t)(n + 1) * 4));
-    std::vector<uint32_t> frame(n), len(n);
-    if (n) {
-        hipLaunchKernelGGL(k1_query_frames, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, tab,
-                           ctx->ws[0].as<uint32_t>(), ctx->ws[1].as<uint32_t>());
-        PEP_HIP(ctx, hipGetLastError());
-        PEP_HIP(ctx, hipMemcpyAsync(frame.data(), ctx->ws[0].p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        PEP_HIP(ctx, hipMemcpyAsync(len.data(), ctx->ws[1].p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
-    std::vector<PackDesc> desc(n);
+    DevBuf *W = ctx->ws;
+    PEP_TRY(dev_reserve(ctx, W[0], ((size_t)n + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, W[1], ((size_t)n + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, W[2], ((size_t)n + 1) * sizeof(PackDesc)));
+    PEP_TRY(dev_reserve(ctx, W[3], ((size_t)n + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, W[5], 16));
+    const uint64_t upper = 2 * PEP_END_PAD + (nt.total + 2 * (uint64_t)n) / 3 + (uint64_t)n * (16 + PEP_SEQ_GAP);
+    PEP_TRY(reserve_packed(ctx, ctx->q, n, upper));
+    if (n) hipLaunchKernelGGL(k1_query_frames, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, tab,
+                              W[0].as<uint32_t>(), W[1].as<uint32_t>());
+    hipLaunchKernelGGL(k1_query_desc, dim3((unsigned)ceil_div((uint64_t)n + 1, 256)), dim3(256), 0, ctx->stream, n, W[0].as<const uint32_t>(), W[1].as<const uint32_t>(),
+                       W[2].as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>());
+    PEP_TRY(layout_and_pack(ctx, nt, tab, W[2].as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6]));
+    PackDesc *desc = stage_desc(ctx, n);
+    if (n) PEP_HIP(ctx, hipMemcpyAsync(desc, W[2].p, (size_t)n * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
+    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->q_meta.resize(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        desc[i] = PackDesc{i, frame[i], 0u, len[i]};
-        ctx->q_meta[i] = pep_query_meta{i, frame[i], len[i], (uint32_t)(nt.h_off[i + 1] - nt.h_off[i])};
-    }
-    return pack_from_desc(ctx, nt, tab, desc, ctx->q, ctx->ws[2]);
+    for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, desc[i].frame, desc[i].len, (uint32_t)(nt.h_off[i + 1] - nt.h_off[i])};
+    return finish_layout(ctx, desc, n, ctx->q);
 }
 
 int pep_k1_ref(pep_ctx *ctx, int frames, int gtable)
@@ -258,43 +319,60 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable)
     const uint32_t n = nt.n;
     const int nf = frames == 3 ? 3 : 6;
     const uint64_t nw = (uint64_t)n * nf;
-    // upper bound of chunks per frame: one per started 1001 residues of (frame string + 'X')
-    std::vector<uint64_t> base(nw + 1, 0);
-    for (uint32_t g = 0; g < n; ++g) {
-        const uint64_t L = nt.h_off[g + 1] - nt.h_off[g];
-        for (int f = 1; f <= nf; ++f) {
-            const uint64_t shift = (uint64_t)(f <= 3 ? f - 1 : f - 4);
-            const uint64_t na = L > shift ? (L - shift + 2) / 3 : 0;
-            base[(uint64_t)g * nf + f] = base[(uint64_t)g * nf + f - 1] + (na + 1) / 1001 + 1;
+    if (ctx->k1_base_frames != nf) {
+        // upper bound of chunks per frame: one per started 1001 residues of (frame string + 'X'); and of the packed layout's size.
+        // Depends on the input lengths only: computed and uploaded once per reference set.
+        std::vector<uint64_t> &base = ctx->k1_base;
+        base.assign(nw + 1, 0);
+        uint64_t upper = 2 * PEP_END_PAD;
+        for (uint32_t g = 0; g < n; ++g) {
+            const uint64_t L = nt.h_off[g + 1] - nt.h_off[g];
+            for (int f = 1; f <= nf; ++f) {
+                const uint64_t shift = (uint64_t)(f <= 3 ? f - 1 : f - 4);
+                const uint64_t na = L > shift ? (L - shift + 2) / 3 : 0;
+                const uint64_t slots_w = (na + 1) / 1001 + 1;
+                base[(uint64_t)g * nf + f] = base[(uint64_t)g * nf + f - 1] + slots_w;
+                upper += na + slots_w * (15 + PEP_SEQ_GAP);
+            }
         }
+        ctx->k1_upper = upper;
+        PEP_TRY(dev_reserve(ctx, ctx->d_k1_base, (nw + 1) * 8));
+        PEP_HIP(ctx, hipMemcpy(ctx->d_k1_base.p, base.data(), (nw + 1) * 8, hipMemcpyHostToDevice));
+        ctx->k1_base_frames = nf;
     }
-    const uint64_t slots = base[nw];
-    PEP_TRY(dev_reserve(ctx, ctx->ws[0], (nw + 1) * 8));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[1], (nw + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[2], (slots + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[3], (slots + 1) * 4));
-    std::vector<uint32_t> cnt(nw), coff(slots), clen(slots);
+    const uint64_t slots = ctx->k1_base[nw], upper = ctx->k1_upper;
+    if (slots > PEP_MAX_TARGETS) return pep_fail(ctx, PEP_ERR_LIMIT, "too many targets");
+    DevBuf *W = ctx->ws;
+    PEP_TRY(dev_reserve(ctx, W[1], (nw + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, W[2], (slots + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, W[3], (slots + 1) * 4));
+    PEP_TRY(dev_reserve(ctx, W[4], (slots + 1) * sizeof(PackDesc)));
+    PEP_TRY(dev_reserve(ctx, W[5], (nw + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, W[6], (slots + 1) * 4));
+    PEP_TRY(reserve_packed(ctx, ctx->t, (uint32_t)slots, upper));
+    uint32_t n_targets = 0;
+    PackDesc *desc = stage_desc(ctx, slots);
+    const uint64_t *d_base = ctx->d_k1_base.as<const uint64_t>();
     if (nw) {
-        PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[0].p, base.data(), (nw + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        PEP_HIP(ctx, hipMemsetAsync(W[6].p, 0, (slots + 1) * 4, ctx->stream));
         hipLaunchKernelGGL(k1_ref_chunks, dim3((unsigned)ceil_div(nw, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, nf, tab,
-                           ctx->ws[0].as<const uint64_t>(), ctx->ws[1].as<uint32_t>(), ctx->ws[2].as<uint32_t>(), ctx->ws[3].as<uint32_t>());
-        PEP_HIP(ctx, hipGetLastError());
-        PEP_HIP(ctx, hipMemcpyAsync(cnt.data(), ctx->ws[1].p, nw * 4, hipMemcpyDeviceToHost, ctx->stream));
-        PEP_HIP(ctx, hipMemcpyAsync(coff.data(), ctx->ws[2].p, slots * 4, hipMemcpyDeviceToHost, ctx->stream));
-        PEP_HIP(ctx, hipMemcpyAsync(clen.data(), ctx->ws[3].p, slots * 4, hipMemcpyDeviceToHost, ctx->stream));
+                           d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>());
+        PEP_TRY(pep_scan_u32(ctx, W[1].as<const uint32_t>(), W[5].as<uint32_t>(), nw, W[8]));          // W[5][nw] = number of targets
+        hipLaunchKernelGGL(k1_ref_desc, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, ctx->stream, nw, nf, d_base, W[1].as<const uint32_t>(),
+                           W[5].as<const uint32_t>(), W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), W[4].as<PackDesc>(), W[6].as<uint32_t>(),
+                           ctx->t.len.as<uint32_t>());
+        PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
+                                W[7], W[8]));
+        PEP_HIP(ctx, hipMemcpyAsync(&n_targets, W[5].as<const uint32_t>() + nw, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PEP_HIP(ctx, hipMemcpyAsync(desc, W[4].p, slots * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
+        PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else {
+        PEP_HIP(ctx, hipMemsetAsync(W[5].p, 0, 8, ctx->stream));
+        PEP_HIP(ctx, hipMemsetAsync(W[6].p, 0, 4, ctx->stream));
+        PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), 0, W[5].as<const uint32_t>(), upper, ctx->t, W[7], W[8]));
         PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    std::vector<PackDesc> desc;
-    desc.reserve(nw);
-    ctx->t_meta.clear();
-    for (uint64_t w = 0; w < nw; ++w) {
-        const uint32_t g = (uint32_t)(w / nf), f = (uint32_t)(w % nf) + 1;
-        for (uint32_t c = 0; c < cnt[w]; ++c) {
-            const uint64_t k = base[w] + c;
-            desc.push_back(PackDesc{g, f, coff[k], clen[k]});
-            ctx->t_meta.push_back(pep_target_meta{g, f, coff[k], clen[k]});
-        }
-    }
-    if (desc.size() > PEP_MAX_TARGETS) return pep_fail(ctx, PEP_ERR_LIMIT, "too many targets");
-    return pack_from_desc(ctx, nt, tab, desc, ctx->t, ctx->ws[4]);
+    ctx->t_meta.resize(n_targets);
+    for (uint32_t i = 0; i < n_targets; ++i) ctx->t_meta[i] = pep_target_meta{desc[i].seq, desc[i].frame, desc[i].aa_off, desc[i].len};
+    return finish_layout(ctx, desc, n_targets, ctx->t);
 }
