@@ -64,42 +64,51 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
     run_cap[pos[c]] = 2ull * min(q_len[key_q(k)], t_len[key_t(k)]) + 2;
 }
 
-// one wavefront per selected pair; the walk itself is wave-uniform (scalar) work: a tile of 64 lanes x 16 steps
-// of traceback codes is fetched with one coalesced 512-byte load and decoded with v_readlane; diagonal runs are
-// followed inside one word (8 cells of one diagonal)
-__global__ __launch_bounds__(256) void walk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
-                                            const uint64_t *__restrict__ dir_off, const uint32_t *__restrict__ dirs,
-                                            const uint64_t *__restrict__ run_off, uint32_t *__restrict__ runs)
+// One THREAD per selected pair.  The walk is a serial chain of tiny decisions; spread over a wavefront (one alignment per wave, as the
+// first version did) every decision costs an issue slot of the whole CU - vector or scalar unit alike - and 40 k alignments took
+// 0.48 ms.  One alignment per lane keeps all 64 lanes busy with different alignments.  A lane reads the code word of 8 consecutive
+// cells of its current diagonal (4 bytes) and keeps the next three words down the same diagonal in flight, so the latency of the
+// scattered 4-byte loads is paid once per 32 cells of a diagonal run, not once per word.
+__global__ __launch_bounds__(64) void walk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
+                                           const uint64_t *__restrict__ dir_off, const uint32_t *__restrict__ dirs,
+                                           const uint64_t *__restrict__ run_off, uint32_t *__restrict__ runs)
 {
-    const int lane = threadIdx.x & 63;
-    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
     if (s >= n_sel) return;
     SelInfo info = sel[s];
     const uint64_t key = cands[info.cand];
     const int dlo = key_dlo(key);
-    const int a0 = sw[info.cand].w;
-    const uint2 *dir = reinterpret_cast<const uint2 *>(dirs) + dir_off[info.cand] * 64;
+    const int4 cell = sw[info.cand];
+    const int a0 = cell.w;
+    // word of (block b, diagonal rel): dword ((b * 64 + (rel >> 1)) * 2 + (rel & 1)) of this pair's traceback area
+    const uint32_t *dir = dirs + dir_off[info.cand] * 128;
     uint32_t *out = runs + run_off[s];
 
-    info.iend = sw[info.cand].y; info.jend = sw[info.cand].z;     // (the trace pass recomputes the same score)
+    info.iend = cell.y; info.jend = cell.z;     // (the trace pass recomputes the same score)
     int i = info.iend, j = info.jend, state = 0;
     int istart = i, jstart = j;
     uint32_t n_runs = 0, aln_len = 0, cur_op = 3, cur_len = 0;
-    int cur_blk = -1;
-    uint2 w_cur = make_uint2(0, 0), w_prev = make_uint2(0, 0);
+    int cur_rel = -1, cur_blk = -1;
+    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;                 // words of blocks cur_blk, -1, -2, -3 of diagonal cur_rel
     for (;;) {
-        // cell (i, j): diagonal rel = lane*2 + parity; it is the (m & 7)-th cell of block m >> 3 of that diagonal
+        // cell (i, j) is the (m & 7)-th cell of block m >> 3 of diagonal rel
         const int rel = j - i - dlo;
-        const int L = rel >> 1, par = rel & 1;
-        const int m = i - a0 + L;
+        const int m = i - a0 + (rel >> 1);
         const int blk = m >> 3;
-        if (blk != cur_blk) {
-            if (cur_blk >= 0 && blk == cur_blk - 1) w_cur = w_prev;
-            else w_cur = dir[(size_t)blk * 64 + lane];
-            cur_blk = blk;
-            if (blk > 0) w_prev = dir[(size_t)(blk - 1) * 64 + lane];     // prefetch the tile the walk reaches next
+        if (rel != cur_rel || blk != cur_blk) {
+            const uint32_t *col = dir + rel;
+            if (rel == cur_rel && blk == cur_blk - 1) {
+                w0 = w1; w1 = w2; w2 = w3;
+                w3 = blk >= 3 ? col[(size_t)(blk - 3) * 128] : 0u;
+            } else {
+                w0 = col[(size_t)blk * 128];
+                w1 = blk >= 1 ? col[(size_t)(blk - 1) * 128] : 0u;
+                w2 = blk >= 2 ? col[(size_t)(blk - 2) * 128] : 0u;
+                w3 = blk >= 3 ? col[(size_t)(blk - 3) * 128] : 0u;
+            }
+            cur_rel = rel; cur_blk = blk;
         }
-        const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)(par ? w_cur.y : w_cur.x), __builtin_amdgcn_readfirstlane(L));
+        const uint32_t word = w0;
         int nidx = m & 7;
         const uint32_t nib = (word >> (nidx * 4)) & 15u;
         uint32_t op, cnt = 1;
@@ -121,8 +130,7 @@ __global__ __launch_bounds__(256) void walk(uint64_t n_sel, SelInfo *__restrict_
         aln_len += cnt;
         if (op == cur_op) cur_len += cnt;
         else {
-            if (cur_len && lane == 0) out[n_runs] = (cur_len << 2) | cur_op;
-            n_runs += cur_len ? 1 : 0;
+            if (cur_len) out[n_runs++] = (cur_len << 2) | cur_op;
             cur_op = op; cur_len = cnt;
         }
         if (op == 0) {
@@ -131,11 +139,9 @@ __global__ __launch_bounds__(256) void walk(uint64_t n_sel, SelInfo *__restrict_
         } else if (op == 2) --j;
         else --i;
     }
-    if (cur_len) { if (lane == 0) out[n_runs] = (cur_len << 2) | cur_op; ++n_runs; }
-    if (lane == 0) {
-        info.istart = istart; info.jstart = jstart; info.n_runs = n_runs; info.aln_len = aln_len;
-        sel[s] = info;
-    }
+    if (cur_len) out[n_runs++] = (cur_len << 2) | cur_op;
+    info.istart = istart; info.jstart = jstart; info.n_runs = n_runs; info.aln_len = aln_len;
+    sel[s] = info;
 }
 
 // identities + filters; one wavefront per selected pair, lanes parallel over the columns of each M run
@@ -321,7 +327,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
         uint32_t *runs = ctx->ws[21].as<uint32_t>();
         const unsigned gw = (unsigned)ceil_div(n_sel, 4);
-        hipLaunchKernelGGL(walk, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, sw2, ctx->ws[11].as<const uint64_t>(),
+        hipLaunchKernelGGL(walk, dim3((unsigned)ceil_div(n_sel, 64)), dim3(64), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, sw2, ctx->ws[11].as<const uint64_t>(),
                            ctx->ws[13].as<const uint32_t>(), (const uint64_t *)run_off, runs);
         hipLaunchKernelGGL(finalize, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
                            ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(),
