@@ -66,14 +66,18 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
 
 // One THREAD per selected pair.  The walk is a serial chain of tiny decisions; spread over a wavefront (one alignment per wave, as the
 // first version did) every decision costs an issue slot of the whole CU - vector or scalar unit alike - and 40 k alignments took
-// 0.48 ms.  One alignment per lane keeps all 64 lanes busy with different alignments.  A lane reads the code word of 8 consecutive
-// cells of its current diagonal (4 bytes) and keeps the next three words down the same diagonal in flight, so the latency of the
-// scattered 4-byte loads is paid once per 32 cells of a diagonal run, not once per word.
-__global__ __launch_bounds__(64) void walk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
+// 0.48 ms.  One alignment per lane instead; with all 64 lanes of a wave in use there are too few waves to hide the load latency
+// of the chain (0.15 ms), so a wave carries WALK_LANES alignments and the chip runs n / WALK_LANES waves.  A lane reads the code word of 8 consecutive
+// cells of its current diagonal (4 bytes) and fetches WALK_AHEAD words down that diagonal at once, so the latency of the scattered
+// 4-byte loads is paid once per 8 * WALK_AHEAD cells of a diagonal run, not once per word.  (Keeping single loads in flight across
+// iterations does not work: rotating the word registers reads them, which makes the compiler wait for every outstanding load.)
+#define WALK_AHEAD 8
+#define WALK_LANES 64         // alignments per wavefront: few, so that many wavefronts overlap their load latencies (see above)
+__global__ __launch_bounds__(WALK_LANES) void walk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
                                            const uint64_t *__restrict__ dir_off, const uint32_t *__restrict__ dirs,
                                            const uint64_t *__restrict__ run_off, uint32_t *__restrict__ runs)
 {
-    const uint64_t s = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    const uint64_t s = (uint64_t)blockIdx.x * WALK_LANES + threadIdx.x;
     if (s >= n_sel) return;
     SelInfo info = sel[s];
     const uint64_t key = cands[info.cand];
@@ -88,8 +92,10 @@ __global__ __launch_bounds__(64) void walk(uint64_t n_sel, SelInfo *__restrict__
     int i = info.iend, j = info.jend, state = 0;
     int istart = i, jstart = j;
     uint32_t n_runs = 0, aln_len = 0, cur_op = 3, cur_len = 0;
-    int cur_rel = -1, cur_blk = -1;
-    uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;                 // words of blocks cur_blk, -1, -2, -3 of diagonal cur_rel
+    int cur_rel = -1, cur_blk = -1, have = 0;
+    uint32_t w[WALK_AHEAD];                                    // words of blocks cur_blk, -1, ... of diagonal cur_rel
+#pragma unroll
+    for (int k = 0; k < WALK_AHEAD; ++k) w[k] = 0;
     for (;;) {
         // cell (i, j) is the (m & 7)-th cell of block m >> 3 of diagonal rel
         const int rel = j - i - dlo;
@@ -97,18 +103,19 @@ __global__ __launch_bounds__(64) void walk(uint64_t n_sel, SelInfo *__restrict__
         const int blk = m >> 3;
         if (rel != cur_rel || blk != cur_blk) {
             const uint32_t *col = dir + rel;
-            if (rel == cur_rel && blk == cur_blk - 1) {
-                w0 = w1; w1 = w2; w2 = w3;
-                w3 = blk >= 3 ? col[(size_t)(blk - 3) * 128] : 0u;
+            if (rel == cur_rel && blk == cur_blk - 1 && have > 1) {
+                // the next word down the same diagonal is already here (no load in flight: a refill waits for all of its loads)
+#pragma unroll
+                for (int k = 0; k + 1 < WALK_AHEAD; ++k) w[k] = w[k + 1];
+                --have;
             } else {
-                w0 = col[(size_t)blk * 128];
-                w1 = blk >= 1 ? col[(size_t)(blk - 1) * 128] : 0u;
-                w2 = blk >= 2 ? col[(size_t)(blk - 2) * 128] : 0u;
-                w3 = blk >= 3 ? col[(size_t)(blk - 3) * 128] : 0u;
+#pragma unroll
+                for (int k = 0; k < WALK_AHEAD; ++k) w[k] = blk >= k ? col[(size_t)(blk - k) * 128] : 0u;
+                have = WALK_AHEAD;
             }
             cur_rel = rel; cur_blk = blk;
         }
-        const uint32_t word = w0;
+        const uint32_t word = w[0];
         int nidx = m & 7;
         const uint32_t nib = (word >> (nidx * 4)) & 15u;
         uint32_t op, cnt = 1;
@@ -327,7 +334,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
         uint32_t *runs = ctx->ws[21].as<uint32_t>();
         const unsigned gw = (unsigned)ceil_div(n_sel, 4);
-        hipLaunchKernelGGL(walk, dim3((unsigned)ceil_div(n_sel, 64)), dim3(64), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, sw2, ctx->ws[11].as<const uint64_t>(),
+        hipLaunchKernelGGL(walk, dim3((unsigned)ceil_div(n_sel, WALK_LANES)), dim3(WALK_LANES), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, sw2, ctx->ws[11].as<const uint64_t>(),
                            ctx->ws[13].as<const uint32_t>(), (const uint64_t *)run_off, runs);
         hipLaunchKernelGGL(finalize, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
                            ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(),
