@@ -28,7 +28,7 @@ def shard_bounds(lengths, world):
 def allgather_hits(hits, cigar, q_base, group=None, device=None):
     """hits: structured array (peppan_amd._native.HIT_DTYPE) with shard-local q indices; cigar: uint32 arena.
     Returns the concatenated (hits, cigar) of all ranks in rank order with global q indices and re-based
-    cigar offsets.  Collectives: one all-gather of two counts, one of padded hit records, one of padded arenas."""
+    cigar offsets.  Collectives: one all-gather of the two counts, one of a padded payload (hit records + arena)."""
     import torch
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
@@ -41,26 +41,29 @@ def allgather_hits(hits, cigar, q_base, group=None, device=None):
     mine = hits.copy()
     mine['q'] += q_base
     counts = torch.tensor([len(mine), len(cigar)], dtype=torch.int64, device=dev)
-    all_counts = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(all_counts, counts, group=group)
-    all_counts = torch.stack(all_counts).cpu().numpy()
+    all_counts = torch.empty(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_counts, counts, group=group)
+    all_counts = all_counts.cpu().numpy().reshape(world, 2)
     max_h, max_c = int(all_counts[:, 0].max()), int(all_counts[:, 1].max())
     rec = mine.dtype.itemsize
-    hbuf = np.zeros(max(1, max_h) * rec, dtype=np.uint8)
-    hbuf[:len(mine) * rec] = mine.view(np.uint8).reshape(-1)
-    cbuf = np.zeros(max(1, max_c), dtype=np.int32)
-    cbuf[:len(cigar)] = cigar.view(np.int32)
-    th, tc = torch.from_numpy(hbuf).to(dev), torch.from_numpy(cbuf).to(dev)
-    gh = [torch.empty_like(th) for _ in range(world)]
-    gc = [torch.empty_like(tc) for _ in range(world)]
-    dist.all_gather(gh, th, group=group)
-    dist.all_gather(gc, tc, group=group)
+    # one payload per rank: [hit records, padded to max_h][CIGAR arena, padded to max_c] -> one collective, one copy back
+    slot = max_h * rec + max_c * 4
+    if slot == 0:
+        return mine, np.zeros(0, dtype=np.uint32)
+    buf = np.zeros(slot, dtype=np.uint8)
+    buf[:len(mine) * rec] = mine.view(np.uint8).reshape(-1)
+    buf[max_h * rec:max_h * rec + len(cigar) * 4] = np.ascontiguousarray(cigar, dtype=np.uint32).view(np.uint8)
+    mine_t = torch.from_numpy(buf).to(dev)
+    all_t = torch.empty(slot * world, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(all_t, mine_t, group=group)
+    flat = all_t.cpu().numpy()
     out_h, out_c, coff = [], [], 0
     for r in range(world):
         nh, nc = int(all_counts[r, 0]), int(all_counts[r, 1])
-        h = gh[r].cpu().numpy()[:nh * rec].view(mine.dtype).copy()
+        base = r * slot
+        h = flat[base:base + nh * rec].view(mine.dtype).copy()
         h['cigar_off'] += coff
         out_h.append(h)
-        out_c.append(gc[r].cpu().numpy()[:nc].view(np.uint32))
+        out_c.append(flat[base + max_h * rec:base + max_h * rec + nc * 4].view(np.uint32))
         coff += nc
     return np.concatenate(out_h), np.concatenate(out_c)
