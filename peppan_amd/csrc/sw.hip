@@ -37,7 +37,8 @@ struct SwArgs {
     int4 *out;                     // score, iend, jend, a0
     int oe, ext;
     int lds_res_bytes;             // per-wave residue staging capacity (0 = global path only)
-    int pk16;                      // score pass: sweep two candidates per wavefront in packed 16-bit
+    int pk16;                      // sweep two candidates per wavefront in packed 16-bit (score pass; traceback pass when `known` is set)
+    const int32_t *known;          // traceback pass: the score of every candidate, from the score pass
 };
 
 __device__ __forceinline__ int shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // lane l <- lane l-1
@@ -268,6 +269,145 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
     }
 }
 
+// ---- packed 16-bit TRACEBACK pass: the same two-candidates-per-wavefront sweep, plus the 4-bit codes of both candidates.
+// The codes come out of packed arithmetic instead of compare/select pairs (which would have to run once per candidate):
+//   gt(x, y) = (y - x) >> 15 per 16-bit half (the sign bit of the difference): 0/1 flags without compare instructions
+//   nz = gt(H, 0), neh = gt(H, h), nee = gt(H, E)                         (H >= 0, H >= h, H >= E: "greater" is "not equal")
+//   src = nz * (1 + neh * (1 + nee))                                      -> 0 none, 1 diagonal, 2 E, 3 F   (same priority as sw_one)
+//   eflag = gt(e_ext, e_open), fflag likewise;  nibble = src + 4 * eflag + 8 * fflag
+// Four nibbles per candidate accumulate in the halves of one register (v_pk_lshrrev_b16 + v_pk_mad_u16); two such
+// registers make the 8-cell word of one diagonal, rearranged per candidate with v_perm_b32 once per 16 steps.
+// The end cell is the first step at which H equals the candidate's score, which the score pass already delivered:
+//   first = umin(first, k + 0x8000 * gt(T, H))                            (k < 0x8000)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// The flag arithmetic goes through inline assembly: written as C, LLVM recognises the 0/1 values, turns the multiplications into
+// selects and ends up with one 16-bit compare + select per HALF and v_perm to repack - more instructions than the 32-bit kernel.
+// x > y per half as 0/1: the sign bit of y - x (no overflow: all DP values stay far inside +-2^15)
+__device__ __forceinline__ u16x2 pk_gt(s16x2 x, s16x2 y)
+{
+    u16x2 r;
+    asm("v_pk_sub_i16 %0, %1, %2\n\tv_pk_lshrrev_b16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(r) : "v"(y), "v"(x));
+    return r;
+}
+__device__ __forceinline__ u16x2 pk_mad(u16x2 a, u16x2 b, u16x2 c)
+{
+    u16x2 r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ u16x2 pk_shr4(u16x2 a)
+{
+    u16x2 r;
+    asm("v_pk_lshrrev_b16 %0, 4, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
+    return r;
+}
+
+struct PkConst { u16x2 four, eight, c4096, big; };
+
+__device__ __forceinline__ u16x2 pk_codes(const PkConst &K, s16x2 H, s16x2 h, s16x2 E, s16x2 e_ext, s16x2 e_open, s16x2 f_ext, s16x2 f_open)
+{
+    const s16x2 zero = {0, 0};
+    const u16x2 nz = pk_gt(H, zero), neh = pk_gt(H, h), nee = pk_gt(H, E);      // H >= 0, H >= h, H >= E: "greater" == "not equal"
+    const u16x2 t = pk_mad(neh, nee, neh);
+    const u16x2 src = pk_mad(nz, t, nz);
+    const u16x2 ef = pk_gt(e_ext, e_open), ff = pk_gt(f_ext, f_open);
+    return pk_mad(ff, K.eight, pk_mad(ef, K.four, src));
+}
+
+__device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, uint64_t c1, const CandGeom &g0, const CandGeom &g1,
+                                                  const unsigned char *lds_tab, uint16_t *lds_res, int lane)
+{
+    const int nb = max(g0.nblk, g1.nblk);
+    const int win = (8 * nb + 72 + 7) & ~7;
+    uint16_t *q0 = lds_res, *t0 = q0 + win, *q1 = t0 + win, *t1 = q1 + win;
+    stage_windows(g0, nb, q0, t0, lane);
+    stage_windows(g1, nb, q1, t1, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    typedef const volatile __attribute__((address_space(3))) uint16_t lds_cu16;
+    typedef const __attribute__((address_space(3))) signed char lds_ci8;
+    lds_cu16 *vq0 = (lds_cu16 *)(q0 + (64 - lane)), *vt0 = (lds_cu16 *)(t0 + (1 + lane));
+    lds_cu16 *vq1 = (lds_cu16 *)(q1 + (64 - lane)), *vt1 = (lds_cu16 *)(t1 + (1 + lane));
+    lds_ci8 *tab = (lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & 31) * 4);
+    uint2 *dir0 = reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c0] * 64, *dir1 = reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c1] * 64;
+    const s16x2 zero = {0, 0};
+    const s16x2 oe2 = {(short)a.oe, (short)a.oe}, ext2 = {(short)a.ext, (short)a.ext};
+    const s16x2 T2 = {(short)a.known[c0], (short)a.known[c1]};
+    const u16x2 one_u = {1, 1};
+    PkConst K;
+    K.four = u16x2{4, 4}; K.eight = u16x2{8, 8}; K.c4096 = u16x2{4096, 4096}; K.big = u16x2{0x8000, 0x8000};
+    s16x2 HA = zero, EA = zero, FA = zero, HB = zero, EB = zero, FB = zero;
+    u16x2 first = {0xFFFF, 0xFFFF}, kk = {0, 0};
+    int tv0 = vt0[0], tv1 = vt1[0], qv0 = 0, qv1 = 0;
+    int m = 0;
+    for (int b = 0; b < nb; ++b) {
+        u16x2 accA = {0, 0}, accB = {0, 0}, loA = {0, 0}, loB = {0, 0};
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // ---- A step
+                qv0 = vq0[m]; qv1 = vq1[m];
+                {
+                    const s16x2 sub = {(short)tab[qv0 + tv0], (short)tab[qv1 + tv1]};
+                    const s16x2 hl = pk_shr1z(HB), el = pk_shr1z(EB);
+                    const s16x2 e_ext = el - ext2, e_open = hl - oe2, f_ext = FB - ext2, f_open = HB - oe2;
+                    const s16x2 E = pk_max(e_ext, e_open), F = pk_max(f_ext, f_open);
+                    const s16x2 h = HA + sub;
+                    const s16x2 H = pk_max(pk_max(pk_max(h, E), F), zero);
+                    accA = pk_mad(pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open), K.c4096, pk_shr4(accA));
+                    first = __builtin_elementwise_min(first, pk_mad(pk_gt(T2, H), K.big, kk));
+                    kk += one_u;
+                    HA = H; EA = E; FA = F;
+                }
+                // ---- B step (target cursor advances)
+                tv0 = vt0[m + 1]; tv1 = vt1[m + 1];
+                {
+                    const s16x2 sub = {(short)tab[qv0 + tv0], (short)tab[qv1 + tv1]};
+                    const s16x2 hu = pk_shl1z(HA), fu = pk_shl1z(FA);
+                    const s16x2 e_ext = EA - ext2, e_open = HA - oe2, f_ext = fu - ext2, f_open = hu - oe2;
+                    const s16x2 E = pk_max(e_ext, e_open), F = pk_max(f_ext, f_open);
+                    const s16x2 h = HB + sub;
+                    const s16x2 H = pk_max(pk_max(pk_max(h, E), F), zero);
+                    accB = pk_mad(pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open), K.c4096, pk_shr4(accB));
+                    first = __builtin_elementwise_min(first, pk_mad(pk_gt(T2, H), K.big, kk));
+                    kk += one_u;
+                    HB = H; EB = E; FB = F;
+                }
+                ++m;
+            }
+            if (half == 0) { loA = accA; loB = accB; }
+        }
+        // word of candidate 0 = low halves (first four cells | next four cells), candidate 1 = high halves
+        const uint32_t la = __builtin_bit_cast(uint32_t, loA), ha = __builtin_bit_cast(uint32_t, accA);
+        const uint32_t lb = __builtin_bit_cast(uint32_t, loB), hb = __builtin_bit_cast(uint32_t, accB);
+        if (b < g0.nblk) dir0[(size_t)b * 64 + lane] = make_uint2(__builtin_amdgcn_perm(ha, la, 0x05040100u), __builtin_amdgcn_perm(hb, lb, 0x05040100u));
+        if (b < g1.nblk) dir1[(size_t)b * 64 + lane] = make_uint2(__builtin_amdgcn_perm(ha, la, 0x07060302u), __builtin_amdgcn_perm(hb, lb, 0x07060302u));
+    }
+    // end cell per candidate: earliest step with H == T in the lane, then min i, then min j over the lanes
+    const int fk[2] = {(int)first.x, (int)first.y};
+    const CandGeom *gg[2] = {&g0, &g1};
+    const uint64_t cc[2] = {c0, c1};
+    const int TT[2] = {(int)T2.x, (int)T2.y};
+#pragma unroll
+    for (int x = 0; x < 2; ++x) {
+        int bi = 0x7fffffff, bj = 0x7fffffff;
+        if (fk[x] < 0x8000) {
+            const int mm = fk[x] >> 1;
+            bi = gg[x]->a0 + mm - lane;
+            bj = gg[x]->a0 + gg[x]->dlo + mm + lane + (fk[x] & 1);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            const int oi = __shfl_xor(bi, d, 64), oj = __shfl_xor(bj, d, 64);
+            if (oi < bi || (oi == bi && oj < bj)) { bi = oi; bj = oj; }
+        }
+        if (lane == 0 && (x == 0 || c1 != c0)) a.out[cc[x]] = make_int4(TT[x], bi, bj, gg[x]->a0);
+    }
+}
+
 // score pass: wave w of the grid-stride loop takes the candidate pair (2w, 2w+1)
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a)
 {
@@ -298,7 +438,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a
 // TRACE = false: score pass over every candidate (max score only, no HBM writes beyond 16 B per candidate)
 // TRACE = true : traceback pass over the pairs that survived best-per-(q,t) and the e-value cut
 template <bool TRACE>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(SwArgs a)
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_kernel(SwArgs a)      // 4 waves per SIMD is what the LDS budget allows: keep the VGPRs within that
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *lds_tab = reinterpret_cast<uint32_t *>(smem);
@@ -306,6 +446,26 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_kernel(SwArgs a)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t *lds_res = reinterpret_cast<uint16_t *>(smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes);
+    if (TRACE && a.pk16 && a.known) {
+        // candidates in pairs (2w, 2w+1), both halves of the packed registers busy; pairs that do not fit 16 bits / the staging area fall back
+        const uint64_t n_pairs = (a.n + 1) / 2;
+        for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < n_pairs; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
+            const uint64_t c0 = 2 * w, c1 = min(2 * w + 1, a.n - 1);
+            const CandGeom g0 = cand_geom(a, c0), g1 = cand_geom(a, c1);
+            const int nb = max(g0.nblk, g1.nblk);
+            const int need = 4 * 2 * ((8 * nb + 72 + 7) & ~7);
+            if (c1 != c0 && fits16(g0) && fits16(g1) && need <= a.lds_res_bytes && nb < 2040 && a.known[c0] > 0 && a.known[c1] > 0) {
+                sw_two_pk16_trace(a, c0, c1, g0, g1, smem, lds_res, lane);
+            } else {
+                for (uint64_t c = c0; c <= c1; ++c) {
+                    const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
+                    if (need1 <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, smem, lds_res, lane);
+                    else sw_one<false, TRACE>(a, c, smem, lds_res, lane);
+                }
+            }
+        }
+        return;
+    }
     for (uint64_t c = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; c < a.n; c += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
         const int need = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
         if (need <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, smem, lds_res, lane);
@@ -369,7 +529,7 @@ int pep_selftest_dpp(pep_ctx *ctx)
 
 // Runs K5 over `n` candidate keys.  trace = false: score pass (ws[12] <- score / end cell / a0 per candidate).
 // trace = true: same DP plus traceback codes (ws[11] dir_off u64[n+1], ws[13] dirs).  ws[10] nblk, ws[14] scan input.
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, float *ms_kernel)
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, float *ms_kernel, const int32_t *d_known)
 {
     const pep_search_params &P = ctx->params;
     *ms_kernel = 0.f;
@@ -408,12 +568,13 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     // per-wave staging window (u16 per residue, query + target), sized for the longest possible pair, capped at 8 KiB
     const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 16 + 2;
     const uint64_t want = 2 * 2 * ((8 * max_blk + 72 + 7) & ~7ull);
-    a.pk16 = (!trace && P.use_lds && P.reserved[1] == 0) ? 1 : 0;       // reserved[1] != 0 forces the 32-bit score pass (tests)
+    a.pk16 = (P.use_lds && P.reserved[1] == 0 && (!trace || d_known)) ? 1 : 0;       // reserved[1] != 0 forces the 32-bit passes (tests)
+    a.known = trace ? d_known : nullptr;
     a.lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, ((a.pk16 ? 2 * want : want) + 255) & ~255ull) : 0;
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
     // enough blocks to fill the chip several times over; the grid-stride loop amortises the table load
     // several times more blocks than fit at once: blocks that finish early are replaced, which balances uneven items
-    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(trace ? n : (n + 1) / 2, WAVES_PER_BLOCK), 256ull * 8);
+    const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(a.pk16 ? (n + 1) / 2 : n, WAVES_PER_BLOCK), 256ull * 8);
     EventTimer timer(ctx->stream);
     if (trace) hipLaunchKernelGGL(sw_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     else hipLaunchKernelGGL(sw_score_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);

@@ -3,8 +3,6 @@
 // per-(query, split) top-k, and emit fixed-size hit records + a CIGAR arena ordered by (q, t).
 #include "common.h"
 
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, float *ms_kernel);
-
 namespace {
 
 struct SelInfo {          // one per selected (q,t) pair
@@ -49,7 +47,8 @@ __global__ __launch_bounds__(256) void select_best(const uint64_t *__restrict__ 
 __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
                                                   const uint32_t *__restrict__ best_idx, const int4 *__restrict__ sw,
                                                   const uint64_t *__restrict__ cands, const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len,
-                                                  SelInfo *__restrict__ sel, uint64_t *__restrict__ run_cap, uint64_t *__restrict__ sel_keys)
+                                                  SelInfo *__restrict__ sel, uint64_t *__restrict__ run_cap, uint64_t *__restrict__ sel_keys,
+                                                  int32_t *__restrict__ known)
 {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n || !flag[c]) return;
@@ -57,6 +56,7 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
     SelInfo s;
     s.cand = pos[c]; s.score = sw[b].x; s.iend = s.jend = -1;      // the end cell comes from the traceback pass
     sel_keys[pos[c]] = cands[b];
+    known[pos[c]] = sw[b].x;            // the traceback pass looks for the first cell that reaches this score
     s.istart = s.jstart = 0; s.n_runs = s.aln_len = s.n_ident = 0; s.pass = s.keep = 0; s.pad = 0;
     sel[pos[c]] = s;
     // an alignment has at most 2*min(Lq,Lt)+1 runs (M runs consume a residue of both sequences)
@@ -318,17 +318,19 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     if (n_sel) {
         PEP_TRY(dev_reserve(ctx, ctx->ws[19], (size_t)n_sel * sizeof(SelInfo)));
         PEP_TRY(dev_reserve(ctx, ctx->ws[20], ((size_t)n_sel + 2) * 8 * 3));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[8], ((size_t)n_sel + 2) * 4));      // ws[8]: raw seed hits of K4, free again
+        int32_t *known = ctx->ws[8].as<int32_t>();
         SelInfo *sel = ctx->ws[19].as<SelInfo>();
         uint64_t *run_cap = ctx->ws[20].as<uint64_t>(), *run_off = run_cap + n_sel + 2, *sel_keys = run_off + n_sel + 2;
         hipLaunchKernelGGL(gather_sel, dim3(gb), dim3(256), 0, st, n, (const uint32_t *)flag, (const uint32_t *)pos, (const uint32_t *)best_idx, sw, d_cands,
-                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys);
+                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known);
         PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_sel, ctx->ws[7]));
         uint64_t total_runs = 0;
         PEP_HIP(ctx, hipMemcpyAsync(&total_runs, run_off + n_sel, 8, hipMemcpyDeviceToHost, st));
         PEP_HIP(ctx, hipStreamSynchronize(st));
         // ---- pass 2: the same DP with traceback codes, selected pairs only (overwrites the pass-1 per-candidate arrays)
         float ms_tr = 0.f;
-        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, &ms_tr));
+        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, &ms_tr, known));
         ctx->stats.ms_sw_trace = ms_tr;
         const int4 *sw2 = ctx->ws[12].as<const int4>();
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
