@@ -107,16 +107,16 @@ void parse_blosum(int8_t sub[1024])
         }
 }
 
-// image of the substitution table as the SW kernel keeps it in LDS: dword (q*8 + t/4)*32 + bank, replicated over the 32 banks
+// image of the substitution table as the SW kernel keeps it in LDS: dword (q*8 + t/4)*PEP_TAB_REP + copy
 int upload_sub_image(pep_ctx *ctx)
 {
-    std::vector<uint32_t> img(8192);
+    std::vector<uint32_t> img(256 * PEP_TAB_REP);
     const int8_t *s = ctx->params.sub;
     for (int w = 0; w < 256; ++w) {
         const int q = w >> 3, t0 = (w & 7) * 4;
         uint32_t v = 0;
         for (int k = 0; k < 4; ++k) v |= (uint32_t)(uint8_t)s[q * 32 + t0 + k] << (8 * k);
-        for (int b = 0; b < 32; ++b) img[w * 32 + b] = v;
+        for (int b = 0; b < PEP_TAB_REP; ++b) img[w * PEP_TAB_REP + b] = v;
     }
     PEP_TRY(dev_reserve(ctx, ctx->sub_lds, img.size() * 4));
     PEP_HIP(ctx, hipMemcpy(ctx->sub_lds.p, img.data(), img.size() * 4, hipMemcpyHostToDevice));

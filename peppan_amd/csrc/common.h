@@ -9,6 +9,8 @@
 #include "../../include/peppan_hip.h"
 
 #define PEP_WAVE 64
+// copies of the 1 KiB substitution table in LDS (one per bank group): 32 = conflict-free gather, 16 = half the LDS for at most 2-way conflicts
+#define PEP_TAB_REP 16
 
 #define PEP_HIP(ctx, expr)                                                                            \
     do {                                                                                              \

@@ -22,7 +22,8 @@
 
 namespace {
 
-constexpr int LDS_TABLE_BYTES = 32768;   // 256 dwords x 32 banks
+constexpr int LDS_TABLE_BYTES = 256 * PEP_TAB_REP * 4;   // 256 dwords x PEP_TAB_REP copies
+constexpr int TAB_ROW_SHIFT = PEP_TAB_REP == 32 ? 7 : 6; // log2(bytes per table row of 4 scores)
 constexpr int WAVES_PER_BLOCK = 8;
 
 struct SwArgs {
@@ -48,9 +49,9 @@ __device__ __forceinline__ int shl1(int fill, int v) { return __builtin_amdgcn_u
 __device__ __forceinline__ int shr1z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
 __device__ __forceinline__ int shl1z(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
 
-// LDS images of the residues, ready to be added into a table address: q -> qc * 1024, t -> (tc >> 2) * 128 + (tc & 3)
-__device__ __forceinline__ uint16_t q_addr_part(int qc) { return (uint16_t)(qc << 10); }
-__device__ __forceinline__ uint16_t t_addr_part(int tc) { return (uint16_t)(((tc >> 2) << 7) | (tc & 3)); }
+// LDS images of the residues, ready to be added into a table address: q -> qc * 8 rows, t -> (tc >> 2) rows + (tc & 3)  (row = PEP_TAB_REP dwords)
+__device__ __forceinline__ uint16_t q_addr_part(int qc) { return (uint16_t)(qc << (TAB_ROW_SHIFT + 3)); }
+__device__ __forceinline__ uint16_t t_addr_part(int tc) { return (uint16_t)(((tc >> 2) << TAB_ROW_SHIFT) | (tc & 3)); }
 
 template <bool LDS_RES, bool TRACE>
 __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsigned char *lds_tab, uint16_t *lds_res, int lane)
@@ -90,8 +91,8 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
     lds_cu16 *vq = (lds_cu16 *)lq, *vt = (lds_cu16 *)lt;
     auto Qat = [&](int ii) -> int { return LDS_RES ? (int)vq[ii - qlo] : (int)q_addr_part(((unsigned)ii < (unsigned)Lq) ? (int)qg[ii] : PEP_PAD_CODE); };
     auto Tat = [&](int jj) -> int { return LDS_RES ? (int)vt[jj - tlo] : (int)t_addr_part(((unsigned)jj < (unsigned)Lt) ? (int)tg[jj] : PEP_PAD_CODE); };
-    // conflict-free gather: byte (q*8 + t/4)*128 + bank*4 + (t&3) of the bank-replicated table, read as a signed byte
-    const signed char *tab = reinterpret_cast<const signed char *>(lds_tab) + (lane & 31) * 4;
+    // gather: byte ((q*8 + t/4)*PEP_TAB_REP + copy)*4 + (t&3) of the replicated table, read as a signed byte (copy = lane mod PEP_TAB_REP)
+    const signed char *tab = reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4;
 
     int HA = 0, EA = 0, FA = 0, HB = 0, EB = 0, FB = 0;
     int best = 0, best_k = -1;
@@ -226,7 +227,7 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
     typedef const __attribute__((address_space(3))) signed char lds_ci8;
     lds_cu16 *vq0 = (lds_cu16 *)(q0 + (64 - lane)), *vt0 = (lds_cu16 *)(t0 + (1 + lane));
     lds_cu16 *vq1 = (lds_cu16 *)(q1 + (64 - lane)), *vt1 = (lds_cu16 *)(t1 + (1 + lane));
-    lds_ci8 *tab = (lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & 31) * 4);
+    lds_ci8 *tab = (lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
     const s16x2 zero = {0, 0};
     const s16x2 oe2 = {(short)a.oe, (short)a.oe}, ext2 = {(short)a.ext, (short)a.ext};
     s16x2 HA = zero, EA = zero, FA = zero, HB = zero, EB = zero, FB = zero, best = zero;
@@ -330,7 +331,7 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
     typedef const __attribute__((address_space(3))) signed char lds_ci8;
     lds_cu16 *vq0 = (lds_cu16 *)(q0 + (64 - lane)), *vt0 = (lds_cu16 *)(t0 + (1 + lane));
     lds_cu16 *vq1 = (lds_cu16 *)(q1 + (64 - lane)), *vt1 = (lds_cu16 *)(t1 + (1 + lane));
-    lds_ci8 *tab = (lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & 31) * 4);
+    lds_ci8 *tab = (lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
     uint2 *dir0 = reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c0] * 64, *dir1 = reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c1] * 64;
     const s16x2 zero = {0, 0};
     const s16x2 oe2 = {(short)a.oe, (short)a.oe}, ext2 = {(short)a.ext, (short)a.ext};
