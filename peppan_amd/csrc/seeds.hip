@@ -10,6 +10,7 @@
 //                           q:21 | t:25 | bin:18 into a device hash set; first inserter appends it to the list.
 //  The candidate list is then radix-sorted (sort.hip) so every later stage is order-deterministic.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -20,6 +21,7 @@ struct SeedShape {
     uint32_t red4[4];       // reduced letter of residue code c: nibble (c & 7) of red4[c >> 3]; 15 = never seeds
     int32_t h1;             // the key is assembled as hi * base^h1 + lo with 32-bit halves
     uint32_t pow_h1;
+    uint32_t pw[32];        // weight of letter i inside its half: base^i (i < h1), base^(i - h1) otherwise
 };
 
 constexpr int TILE = 256, TILE_HALO = 32;
@@ -44,18 +46,34 @@ __device__ __forceinline__ void stage_reduced(const SeedShape &sh, const uint8_t
     }
 }
 
-// key of the seed starting at tile offset x: sum g_i * base^i, Horner over two 32-bit halves
+// key of the seed starting at tile offset x: sum g_i * base^i, assembled from two 32-bit halves.
+// W > 0: the weight is a compile-time constant - all letter reads are issued together and every term is one multiply-add with a
+// power held in an SGPR (the rolled loop paid one LDS round trip per letter, ~1000 cycles per position);  W = 0: any weight.
+template <int W>
 __device__ __forceinline__ bool tile_key(const SeedShape &sh, const uint8_t *red, int x, uint64_t &key)
 {
-    uint32_t lo = 0, hi = 0, bad = 0;
+    uint32_t lo = 0, hi = 0, mx = 0;
+    if (W > 0) {
+        constexpr int H1 = (W + 1) / 2;
+        uint32_t g[W > 0 ? W : 1];
+#pragma unroll
+        for (int i = 0; i < W; ++i) g[i] = red[x + sh.offs[i]];
+#pragma unroll
+        for (int i = 0; i < W; ++i) {
+            mx = max(mx, g[i]);
+            if (i < H1) lo += g[i] * sh.pw[i]; else hi += g[i] * sh.pw[i];
+        }
+    } else {
 #pragma unroll 1
-    for (int i = sh.h1 - 1; i >= 0; --i) { const uint32_t g = red[x + sh.offs[i]]; bad |= (g == 15u); lo = lo * (uint32_t)sh.base + g; }
+        for (int i = sh.h1 - 1; i >= 0; --i) { const uint32_t g = red[x + sh.offs[i]]; mx = max(mx, g); lo = lo * (uint32_t)sh.base + g; }
 #pragma unroll 1
-    for (int i = sh.weight - 1; i >= sh.h1; --i) { const uint32_t g = red[x + sh.offs[i]]; bad |= (g == 15u); hi = hi * (uint32_t)sh.base + g; }
+        for (int i = sh.weight - 1; i >= sh.h1; --i) { const uint32_t g = red[x + sh.offs[i]]; mx = max(mx, g); hi = hi * (uint32_t)sh.base + g; }
+    }
     key = (uint64_t)hi * sh.pow_h1 + lo;
-    return bad == 0;
+    return mx != 15u;                     // 15 = a letter that never seeds (padding, X, ...)
 }
 
+template <int W>
 __global__ __launch_bounds__(256) void seed_count(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, uint32_t *__restrict__ cnt, int bucket_bits)
 {
     __shared__ uint8_t red[TILE + TILE_HALO];
@@ -64,9 +82,10 @@ __global__ __launch_bounds__(256) void seed_count(SeedShape sh, const uint8_t *_
     const uint64_t p = (uint64_t)blockIdx.x * TILE + threadIdx.x;
     if (p + 32 > total) return;             // the trailing PEP_END_PAD bytes hold no residues
     uint64_t key;
-    if (tile_key(sh, red, threadIdx.x, key)) atomicAdd(&cnt[hash_u64(key, bucket_bits)], 1u);
+    if (tile_key<W>(sh, red, threadIdx.x, key)) atomicAdd(&cnt[hash_u64(key, bucket_bits)], 1u);
 }
 
+template <int W>
 __global__ __launch_bounds__(256) void seed_fill(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, const uint32_t *__restrict__ start,
                                                  uint32_t *__restrict__ fill, uint64_t *__restrict__ entries, int bucket_bits)
 {
@@ -76,11 +95,21 @@ __global__ __launch_bounds__(256) void seed_fill(SeedShape sh, const uint8_t *__
     const uint64_t p = (uint64_t)blockIdx.x * TILE + threadIdx.x;
     if (p + 32 > total) return;
     uint64_t key;
-    if (tile_key(sh, red, threadIdx.x, key)) {
+    if (tile_key<W>(sh, red, threadIdx.x, key)) {
         const uint32_t b = hash_u64(key, bucket_bits);
         const uint32_t slot = start[b] + atomicAdd(&fill[b], 1u);
         entries[slot] = (key << POS_BITS) | p;
     }
+}
+
+// bit b of `occupied` = bucket b of the query index holds at least one seed.  Two thirds of the target seeds hash to an empty
+// bucket; the bitmap answers that from L2 instead of a 64-byte line of start[] from the memory side.
+__global__ __launch_bounds__(256) void bucket_bitmap(const uint32_t *__restrict__ start, uint64_t n_buckets, unsigned long long *__restrict__ occupied)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool occ = b < n_buckets && start[b + 1] != start[b];
+    const unsigned long long m = __ballot(occ);
+    if ((threadIdx.x & 63) == 0 && b < n_buckets) occupied[b >> 6] = m;
 }
 
 struct JoinArgs {
@@ -93,6 +122,7 @@ struct JoinArgs {
     const uint32_t *q_blk2seq, *t_blk2seq;
     const uint32_t *start;
     const uint64_t *entries;
+    const unsigned long long *occupied;   // one bit per bucket (1 MiB for 2^23 buckets: stays in L2, unlike start[])
     int bucket_bits;
     uint64_t *table;
     int table_bits;
@@ -180,6 +210,7 @@ __device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *s
 // LDS buffer and flushed with ONE global atomic per flush (a single global counter word only sustains ~90
 // atomics/us).  Every memory operation of this phase is independent across lanes: high memory-level parallelism.
 constexpr int HIT_BUF = 3072;
+template <int W>
 __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
 {
     __shared__ uint64_t buf[HIT_BUF];
@@ -196,11 +227,11 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
         uint32_t e0 = 0, e1 = 0;
         stage_reduced(sh, a.t_res, tile * TILE, a.t_total, red);
         __syncthreads();
-        if (p + 32 <= a.t_total && tile_key(sh, red, threadIdx.x, key)) {
+        if (p + 32 <= a.t_total && tile_key<W>(sh, red, threadIdx.x, key)) {
             ++n_seed;
             if (a.debug != 1) {
                 const uint32_t b = hash_u64(key, a.bucket_bits);
-                e0 = a.start[b]; e1 = a.start[b + 1];
+                if ((a.occupied[b >> 6] >> (b & 63)) & 1ull) { e0 = a.start[b]; e1 = a.start[b + 1]; }
                 if (a.debug == 2) { n_hit += e1 - e0; e1 = e0; }
             }
         }
@@ -254,17 +285,44 @@ __global__ __launch_bounds__(256) void seed_extend(JoinArgs a)
     unsigned long long n_hits = *a.hit_count;
     if (n_hits > a.hit_cap) n_hits = a.hit_cap;
     uint32_t n_pass = 0;
-    for (uint64_t h = (uint64_t)blockIdx.x * 256 + threadIdx.x; h < n_hits; h += (uint64_t)gridDim.x * 256) {
-        const uint64_t hit = a.hits[h];
-        const uint32_t qp = (uint32_t)(hit >> 32), p = (uint32_t)hit;
-        const uint32_t t = a.t_blk2seq[p >> 4], q = a.q_blk2seq[qp >> 4];
-        const int32_t diag = (int32_t)(p - a.t_off[t]) - (int32_t)(qp - a.q_off[q]);
-        const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
-        const uint64_t ck = ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)bin;
-        if (set_contains(a, ck)) { ++n_pass; continue; }
-        if (a.ungapped_min > 0 && !ungapped_pass(a, sub, qp, p)) continue;
-        ++n_pass;
-        set_insert(a, ck);
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t h0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63); h0 < n_hits; h0 += stride) {      // wave-uniform trip count
+        const uint64_t h = h0 + lane;
+        const bool valid = h < n_hits;
+        uint64_t ck = ~0ull;
+        uint32_t qp = 0, p = 0;
+        if (valid) {
+            const uint64_t hit = a.hits[h];
+            qp = (uint32_t)(hit >> 32); p = (uint32_t)hit;
+            const uint32_t t = a.t_blk2seq[p >> 4], q = a.q_blk2seq[qp >> 4];
+            const int32_t diag = (int32_t)(p - a.t_off[t]) - (int32_t)(qp - a.q_off[q]);
+            const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
+            ck = ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)bin;
+        }
+        // Neighbouring hits of the buffer usually come from neighbouring positions of one diagonal, i.e. the same candidate.
+        // The first lane of every run of equal keys decides; the rest of the run is done if that lane's hit nominated the
+        // candidate, and only has to look for itself if it did not (a candidate needs ONE passing hit).
+        const uint32_t lo = (uint32_t)ck, hi = (uint32_t)(ck >> 32);
+        const uint32_t lo_prev = __shfl_up(lo, 1, 64), hi_prev = __shfl_up(hi, 1, 64);     // unconditional: every lane must take part in the shuffles
+        const bool follower = a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi;
+        const unsigned long long leaders = __ballot(valid && !follower);
+        bool pass = false;
+        if (valid && !follower) {
+            pass = set_contains(a, ck);
+            if (!pass && (a.ungapped_min <= 0 || ungapped_pass(a, sub, qp, p))) { pass = true; set_insert(a, ck); }
+        }
+        const unsigned long long passed = __ballot(pass);
+        if (valid && follower) {
+            const unsigned long long below = leaders & ((2ull << lane) - 1ull);          // leaders at or below this lane: never empty
+            const int lead = 63 - __builtin_clzll(below);
+            pass = (passed >> lead) & 1ull;
+            if (!pass) {
+                pass = set_contains(a, ck);
+                if (!pass && (a.ungapped_min <= 0 || ungapped_pass(a, sub, qp, p))) { pass = true; set_insert(a, ck); }
+            }
+        }
+        n_pass += pass ? 1u : 0u;
     }
     for (int d = 32; d > 0; d >>= 1) n_pass += __shfl_down(n_pass, d, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&blk_pass, n_pass);
@@ -323,6 +381,8 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_buckets + 2) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[2], (Q.total + 1) * sizeof(uint64_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[6], 64));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[9], (n_buckets / 64 + 2) * 8));
+    unsigned long long *occupied = ctx->ws[9].as<unsigned long long>();
     uint32_t *cnt = ctx->ws[0].as<uint32_t>(), *start = ctx->ws[1].as<uint32_t>();
     uint64_t *entries = ctx->ws[2].as<uint64_t>();
     uint32_t *counters = ctx->ws[6].as<uint32_t>();
@@ -358,22 +418,33 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             sh.h1 = (sh.weight + 1) / 2;
             sh.pow_h1 = 1;
             for (int i = 0; i < sh.h1; ++i) sh.pow_h1 *= (uint32_t)sh.base;
+            for (int i = 0; i < 32; ++i) sh.pw[i] = 0;
+            for (int i = 0, pl = 1, ph = 1; i < sh.weight; ++i) {
+                if (i < sh.h1) { sh.pw[i] = (uint32_t)pl; pl *= sh.base; } else { sh.pw[i] = (uint32_t)ph; ph *= sh.base; }
+            }
             PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
             const unsigned qb = (unsigned)ceil_div(Q.total, 256), tb = (unsigned)ceil_div(T.total, 256);
-            hipLaunchKernelGGL(seed_count, dim3(qb), dim3(256), 0, ctx->stream, sh, Q.res.as<const uint8_t>(), Q.total, cnt, bucket_bits);
+#define PEP_SEED_DISPATCH(KERNEL, GRID, ...)                                                                          \
+    do {                                                                                                              \
+        if (sh.weight == 10) hipLaunchKernelGGL(KERNEL<10>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);            \
+        else if (sh.weight == 17) hipLaunchKernelGGL(KERNEL<17>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);       \
+        else hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);                             \
+    } while (0)
+            PEP_SEED_DISPATCH(seed_count, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, cnt, bucket_bits);
             PEP_TRY(pep_scan_u32(ctx, cnt, start, n_buckets, ctx->ws[7]));
             PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
-            hipLaunchKernelGGL(seed_fill, dim3(qb), dim3(256), 0, ctx->stream, sh, Q.res.as<const uint8_t>(), Q.total, (const uint32_t *)start, cnt, entries, bucket_bits);
+            PEP_SEED_DISPATCH(seed_fill, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, (const uint32_t *)start, cnt, entries, bucket_bits);
+            hipLaunchKernelGGL(bucket_bitmap, dim3((unsigned)ceil_div(n_buckets, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)start, n_buckets, occupied);
             JoinArgs a;
             a.t_res = T.res.as<const uint8_t>(); a.t_total = T.total; a.t_off = T.off.as<const uint32_t>(); a.nt = T.n;
-            a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint32_t>(); a.t_blk2seq = T.blk2seq.as<const uint32_t>(); a.start = start; a.entries = entries; a.bucket_bits = bucket_bits;
+            a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint32_t>(); a.t_blk2seq = T.blk2seq.as<const uint32_t>(); a.start = start; a.entries = entries; a.occupied = occupied; a.bucket_bits = bucket_bits;
             a.table = ctx->ws[3].as<uint64_t>(); a.table_bits = table_bits;
             a.counters = counters; a.stats = stats;
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
-            a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
+            a.debug = P.reserved[0]; if (getenv("PEP_NO_DEDUPE")) a.debug = 9; a.ungapped_min = P.ungapped_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
             PEP_HIP(ctx, hipMemsetAsync(hit_count, 0, 8, ctx->stream));
-            hipLaunchKernelGGL(seed_match, dim3(std::min(tb, 256u * 5u)), dim3(256), 0, ctx->stream, sh, a);
+            PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 5u)), sh, a);
             hipLaunchKernelGGL(seed_extend, dim3(256u * 8u), dim3(256), 0, ctx->stream, a);
             PEP_HIP(ctx, hipGetLastError());
             PEP_HIP(ctx, hipMemcpyAsync(&h_nseed[s], start + n_buckets, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
