@@ -35,7 +35,7 @@ class MapBsn(object):
 
     def __init__(self, fname, mode='r'):
         self.fname, self.mode = fname, mode
-        self.conn = zipfile.ZipFile(fname, mode=mode, compression=zipfile.ZIP_DEFLATED, allowZip64=True)
+        self.conn = zipfile.ZipFile(fname, mode=mode, compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
         self.namelist = set(self.conn.namelist())
 
     def __enter__(self):
@@ -88,12 +88,12 @@ class MapBsn(object):
         self.namelist.discard(key)
         self.conn.close()
         tmp = self.fname + '.rewrite'
-        with zipfile.ZipFile(self.fname) as src, zipfile.ZipFile(tmp, 'w', compression=zipfile.ZIP_DEFLATED, allowZip64=True) as dst:
+        with zipfile.ZipFile(self.fname) as src, zipfile.ZipFile(tmp, 'w', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as dst:
             for name in src.namelist():
                 if name != key:
                     dst.writestr(name, src.read(name))
         os.replace(tmp, self.fname)
-        self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True)
+        self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
 
     def _save(self, db, key, val):
         data = _npy_bytes(val)
@@ -110,7 +110,7 @@ class MapBsn(object):
         """merge a list of 2-D arrays, each keyed by its [0][0], into the store (rows appended to what the key holds)"""
         tmp_name = self.fname[:-4] + '.tmp.npz'
         seen = set()
-        with zipfile.ZipFile(tmp_name, mode='w', compression=zipfile.ZIP_DEFLATED, allowZip64=True) as tmp:
+        with zipfile.ZipFile(tmp_name, mode='w', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as tmp:
             for d in dataset:
                 key = str(d[0][0])
                 seen.add(key)
@@ -125,7 +125,7 @@ class MapBsn(object):
         self.conn.close()
         self.namelist = seen
         os.rename(tmp_name, self.fname)
-        self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True)
+        self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
 
 
 # ------------------------------------------------------------------------------------------------ allele strings
@@ -290,7 +290,7 @@ def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=Non
     for gid, group in enumerate(groups):
         lo, hi = int(grp_off[gid]), int(grp_off[gid + 1])
         if hi - lo == 1:
-            score = np.sum([msc[lo]])
+            score = msc[lo]
             rows = group[6][0][:16].reshape(1, 16)
         else:
             spans = [[cols[k, 0], cols[k, 1], amsc[k], msc[k]] for k in range(lo, hi)]
