@@ -102,15 +102,22 @@ def hits_to_blastab(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len,
     gap_open = np.bincount(owner, weights=(runs_op != 0), minlength=n).astype(np.int64)
     mismatch = (variation - gap_nt).astype(np.int64)
     idx = np.nonzero(keep)[0]
-    out = np.empty([len(idx), 15], dtype=object)
-    off = hits['cigar_off'].astype(np.int64)
-    nr = hits['cigar_runs'].astype(np.int64)
-    len_l, op_l = runs_len.tolist(), _OPS[runs_op].tolist()
-    for k, h in enumerate(idx.tolist()):
-        o, r = off[h], nr[h]
-        out[k] = [str(q_names[qseq[h]]), str(r_names[rseq[h]]), float(iden[h]), int(cl[h]), int(mismatch[h]), int(gap_open[h]),
-                  int(qs_nt[h]), int(qe_nt[h]), int(rs_nt[h]), int(re_nt[h]), 0.0, int(hits['score'][h]), int(ql[h]), int(rl[h]),
-                  [[len_l[x], op_l[x]] for x in range(o, o + r)]]
+    pairs = list(map(list, zip(runs_len.tolist(), _OPS[runs_op].tolist())))           # one [length, op] list per CIGAR run
+    cols = [[str(q_names[i]) for i in qseq[idx].tolist()], [str(r_names[i]) for i in rseq[idx].tolist()], iden[idx].tolist(), cl[idx].tolist(),
+            mismatch[idx].tolist(), gap_open[idx].tolist(), qs_nt[idx].tolist(), qe_nt[idx].tolist(), rs_nt[idx].tolist(), re_nt[idx].tolist(),
+            [0.0] * len(idx), hits['score'][idx].astype(np.int64).tolist(), ql[idx].tolist(), rl[idx].tolist()]
+    return _object_table(cols, pairs, hits['cigar_off'][idx].tolist(), hits['cigar_runs'][idx].tolist())
+
+
+def _object_table(cols, pairs, cigar_off, cigar_runs):
+    """14 scalar columns (lists of Python values) + the CIGAR runs of every row -> ndarray(object)[n, 15]"""
+    n = len(cigar_off)
+    out = np.empty([n, 15], dtype=object)
+    for j, c in enumerate(cols):
+        out[:, j] = c
+    cig = out[:, 14]
+    for k, (o, r) in enumerate(zip(cigar_off, cigar_runs)):
+        cig[k] = pairs[o:o + r]
     return out
 
 
@@ -144,15 +151,11 @@ def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, m
     evalue = params.ka_k * ql * params.dbsize * np.exp(-params.ka_lambda * score)
     keep = (iden >= min_id) & (qe - qs + 1 >= min_cov) & (qe - qs + 1 >= min_ratio * ql)
     idx = np.nonzero(keep)[0]
-    out = np.empty([len(idx), 15], dtype=object)
-    off, cnt = hits['cigar_off'].astype(np.int64), hits['cigar_runs'].astype(np.int64)
-    len_l, op_l = runs_len.tolist(), _OPS[runs_op].tolist()
-    for k, h in enumerate(idx.tolist()):
-        o, r = off[h], cnt[h]
-        out[k] = [str(q_names[qi[h]]), str(r_names[ri[h]]), float(iden[h]), int(aln[h]), int(aln[h] - ident[h] - gap_cols[h]), int(gap_open[h]),
-                  int(qs[h]), int(qe[h]), int(ss[h]), int(se[h]), float(evalue[h]), int(score[h]), int(ql[h]), int(sl[h]),
-                  [[len_l[x], op_l[x]] for x in range(o, o + r)]]
-    return out
+    pairs = list(map(list, zip(runs_len.tolist(), _OPS[runs_op].tolist())))
+    cols = [[str(q_names[i]) for i in qi[idx].tolist()], [str(r_names[i]) for i in ri[idx].tolist()], iden[idx].tolist(), aln[idx].tolist(),
+            (aln - ident - gap_cols)[idx].tolist(), gap_open[idx].tolist(), qs[idx].tolist(), qe[idx].tolist(), ss[idx].tolist(), se[idx].tolist(),
+            evalue[idx].tolist(), score[idx].tolist(), ql[idx].tolist(), sl[idx].tolist()]
+    return _object_table(cols, pairs, hits['cigar_off'][idx].tolist(), hits['cigar_runs'][idx].tolist())
 
 
 # ------------------------------------------------------------------------------------------------------------
