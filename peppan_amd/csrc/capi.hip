@@ -7,7 +7,11 @@
 
 int pep_fail(pep_ctx *ctx, int code, const std::string &msg)
 {
-    if (ctx) ctx->err = msg;
+    if (ctx) {
+        ctx->err = msg;
+        ctx->n_pending = 0;              // queued read-backs point at the failing caller's locals: drop them
+        ctx->pin_small_used = 0;
+    }
     return code;
 }
 
@@ -31,6 +35,51 @@ void dev_release(DevBuf &b)
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+}
+
+int pin_reserve(pep_ctx *ctx, PinBuf &b, size_t bytes)
+{
+    if (bytes <= b.cap) return PEP_OK;
+    if (b.p) (void)hipHostFree(b.p);
+    b.p = nullptr; b.cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    PEP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&b.p), want, hipHostMallocDefault));
+    b.cap = want;
+    return PEP_OK;
+}
+
+int pep_read_back(pep_ctx *ctx, void *dst, const void *d_src, size_t n)
+{
+    const size_t n8 = (n + 7) & ~size_t(7);
+    if (ctx->n_pending >= 32 || ctx->pin_small_used + n8 > ctx->pin_small.cap) PEP_TRY(pep_sync_reads(ctx));
+    if (n8 > ctx->pin_small.cap) return pep_fail(ctx, PEP_ERR_INTERNAL, "pep_read_back: value larger than the pinned page");
+    PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_small.p + ctx->pin_small_used, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pending[ctx->n_pending++] = pep_ctx::PendingRead{dst, ctx->pin_small_used, n};
+    ctx->pin_small_used += n8;
+    return PEP_OK;
+}
+
+int pep_sync_reads(pep_ctx *ctx)
+{
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess)
+        for (int i = 0; i < ctx->n_pending; ++i) memcpy(ctx->pending[i].dst, ctx->pin_small.p + ctx->pending[i].off, ctx->pending[i].n);
+    ctx->n_pending = 0;
+    ctx->pin_small_used = 0;
+    if (e != hipSuccess) return pep_fail(ctx, PEP_ERR_HIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+    return PEP_OK;
+}
+
+// the hit table of the newest search lives in the context's pinned staging area until it is copied out; before that area is
+// reused (next search, K1) a result that is still alive takes its own copy
+void pep_materialise_staged(pep_ctx *ctx)
+{
+    pep_result *r = ctx->staged_result;
+    if (!r) return;
+    r->hits.assign(r->st_hits, r->st_hits + r->n_hits);
+    r->cigar.assign(r->st_cigar, r->st_cigar + r->n_cigar);
+    r->st_hits = nullptr; r->st_cigar = nullptr;
+    ctx->staged_result = nullptr;
 }
 
 // block -> sequence map of a packed set (host build from the offsets, then upload)
@@ -256,6 +305,7 @@ int pep_ctx_create(int device, pep_ctx **out)
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     pep_default_params(&ctx->params);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PEP_ERR_HIP; }
+    if (pin_reserve(ctx, ctx->pin_small, 4096) != PEP_OK) { *out = ctx; return PEP_ERR_HIP; }
     int rc = pep_selftest_dpp(ctx);
     if (rc != PEP_OK) { *out = ctx; return rc; }      // caller can read the message, then destroy
     *out = ctx;
@@ -267,6 +317,10 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto &b : ctx->ws) dev_release(b);
+    if (ctx->staged_result) pep_materialise_staged(ctx);
+    if (ctx->pin_small.p) (void)hipHostFree(ctx->pin_small.p);
+    if (ctx->pin_stage.p) (void)hipHostFree(ctx->pin_stage.p);
+    if (ctx->pin_k1.p) (void)hipHostFree(ctx->pin_k1.p);
     DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->d_min_score, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq};
     for (DevBuf *b : bufs) dev_release(*b);
@@ -415,6 +469,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     if (!ctx || !out) return PEP_ERR_ARG;
     *out = nullptr;
     PEP_HIP(ctx, hipSetDevice(ctx->device));
+    pep_materialise_staged(ctx);                 // an earlier result that was not copied out yet keeps its own copy
     if (params) {
         if (params->n_shapes < 1 || params->n_shapes > 4 || params->base < 2 || params->top_k < 1 || params->n_splits < 1)
             return pep_fail(ctx, PEP_ERR_ARG, "invalid search parameters");
@@ -465,6 +520,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     ctx->stats.ms_seed = a;
     ctx->stats.ms_total = b;
     res->stats = ctx->stats;
+    if (res->st_hits || res->st_cigar) ctx->staged_result = res;
     *out = res;
     return PEP_OK;
 }
@@ -472,16 +528,18 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
 int pep_result_size(const pep_result *r, uint64_t *n_hits, uint64_t *n_cigar)
 {
     if (!r) return PEP_ERR_ARG;
-    if (n_hits) *n_hits = r->hits.size();
-    if (n_cigar) *n_cigar = r->cigar.size();
+    if (n_hits) *n_hits = r->n_hits;
+    if (n_cigar) *n_cigar = r->n_cigar;
     return PEP_OK;
 }
 
 int pep_result_copy(const pep_result *r, pep_hit *hits, uint32_t *cigar)
 {
     if (!r) return PEP_ERR_ARG;
-    if (hits && !r->hits.empty()) memcpy(hits, r->hits.data(), r->hits.size() * sizeof(pep_hit));
-    if (cigar && !r->cigar.empty()) memcpy(cigar, r->cigar.data(), r->cigar.size() * sizeof(uint32_t));
+    const pep_hit *h = r->st_hits ? r->st_hits : r->hits.data();
+    const uint32_t *c = r->st_cigar ? r->st_cigar : r->cigar.data();
+    if (hits && r->n_hits) memcpy(hits, h, r->n_hits * sizeof(pep_hit));
+    if (cigar && r->n_cigar) memcpy(cigar, c, r->n_cigar * sizeof(uint32_t));
     return PEP_OK;
 }
 
@@ -492,7 +550,11 @@ int pep_result_stats(const pep_result *r, pep_stats *stats)
     return PEP_OK;
 }
 
-void pep_result_free(pep_result *r) { delete r; }
+void pep_result_free(pep_result *r)
+{
+    if (r && r->ctx && r->ctx->staged_result == r) r->ctx->staged_result = nullptr;
+    delete r;
+}
 
 int pep_rescore_nt(pep_ctx *ctx, uint64_t n, const pep_nt_hit *hits, const uint32_t *cigar, uint64_t n_cigar, int64_t *out)
 {

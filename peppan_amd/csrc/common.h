@@ -61,9 +61,26 @@ struct NtSet {
     std::vector<uint64_t> h_off;
 };
 
+// pinned host memory of a context: small read-backs (counts) and the staging area of downloaded tables.  A device -> host copy into
+// pageable memory costs ~27 us per round trip on this box, into pinned memory ~16 us (tools/micro/sync_cost.hip), and large copies
+// run at DMA speed only into pinned memory.
+struct PinBuf {
+    uint8_t *p = nullptr;
+    size_t cap = 0;
+};
+
+struct pep_result;
+
 struct pep_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    PinBuf pin_small;                       // 4 KiB: counters read back between kernels
+    size_t pin_small_used = 0;
+    struct PendingRead { void *dst; size_t off, n; } pending[32];
+    int n_pending = 0;
+    PinBuf pin_k1;                          // grow-only: K1 descriptors
+    PinBuf pin_stage;                       // grow-only: the hit table of the newest search
+    pep_result *staged_result = nullptr;    // the result whose hits still live in pin_stage (materialised before it is overwritten)
     std::string err;
     pep_search_params params;
     // inputs
@@ -79,7 +96,6 @@ struct pep_ctx {
     std::vector<uint64_t> k1_base;
     uint64_t k1_upper = 0;
     int k1_base_frames = 0;            // 0 = not computed for the current reference set
-    std::vector<uint8_t> k1_stage;     // host staging of downloaded descriptors (grow-only)
     DevBuf d_min_score;
     std::vector<uint32_t> group_of_seq;     // optional: competition group of every reference sequence (pep_set_target_groups)
     DevBuf d_t_class;
@@ -94,8 +110,11 @@ struct pep_ctx {
 
 struct pep_result {
     pep_ctx *ctx = nullptr;
-    std::vector<pep_hit> hits;
+    std::vector<pep_hit> hits;              // used once the result no longer lives in the context's staging area
     std::vector<uint32_t> cigar;
+    const pep_hit *st_hits = nullptr;       // while staged: views into ctx->pin_stage
+    const uint32_t *st_cigar = nullptr;
+    uint64_t n_hits = 0, n_cigar = 0;
     pep_stats stats;
 };
 
@@ -126,6 +145,12 @@ struct EventTimer {
 };
 
 int pep_fail(pep_ctx *ctx, int code, const std::string &msg);
+// small device -> host reads: queue any number with pep_read_back (async copy into the pinned page), then ONE pep_sync_reads
+// waits for the stream and stores the values
+int pep_read_back(pep_ctx *ctx, void *dst, const void *d_src, size_t n);
+int pep_sync_reads(pep_ctx *ctx);
+int pin_reserve(pep_ctx *ctx, PinBuf &b, size_t bytes);
+void pep_materialise_staged(pep_ctx *ctx);
 int dev_reserve(pep_ctx *ctx, DevBuf &b, size_t bytes);
 void dev_release(DevBuf &b);
 

@@ -447,15 +447,15 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 5u)), sh, a);
             hipLaunchKernelGGL(seed_extend, dim3(256u * 8u), dim3(256), 0, ctx->stream, a);
             PEP_HIP(ctx, hipGetLastError());
-            PEP_HIP(ctx, hipMemcpyAsync(&h_nseed[s], start + n_buckets, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+            PEP_TRY(pep_read_back(ctx, &h_nseed[s], start + n_buckets, sizeof(uint32_t)));
         }
         hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ws[3].as<uint64_t>(), cap,
                            ctx->ws[4].as<uint64_t>(), list_cap, counters);
         uint32_t h_counters[4];
         unsigned long long h_stats[3];
-        PEP_HIP(ctx, hipMemcpyAsync(h_counters, counters, sizeof(h_counters), hipMemcpyDeviceToHost, ctx->stream));
-        PEP_HIP(ctx, hipMemcpyAsync(h_stats, stats, sizeof(h_stats), hipMemcpyDeviceToHost, ctx->stream));
-        PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PEP_TRY(pep_read_back(ctx, h_counters, counters, sizeof(h_counters)));
+        PEP_TRY(pep_read_back(ctx, h_stats, stats, sizeof(h_stats)));
+        PEP_TRY(pep_sync_reads(ctx));
         if (h_counters[2]) { hit_cap *= 4; continue; }                // raw hit buffer too small: retry 4x larger
         if (h_counters[1] || h_counters[0] > list_cap) { table_bits += 2; continue; }     // set too small: retry 4x larger
         for (int s = 0; s < P.n_shapes; ++s) q_seeds += h_nseed[s];

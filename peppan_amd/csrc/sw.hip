@@ -547,9 +547,9 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
     uint64_t total_blk = 0;
     unsigned long long h_cells = 0;
-    PEP_HIP(ctx, hipMemcpyAsync(&total_blk, ctx->ws[11].as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PEP_HIP(ctx, hipMemcpyAsync(&h_cells, cells, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PEP_TRY(pep_read_back(ctx, &total_blk, ctx->ws[11].as<uint64_t>() + n, 8));
+    PEP_TRY(pep_read_back(ctx, &h_cells, cells, 8));
+    PEP_TRY(pep_sync_reads(ctx));
     if (trace) ctx->stats.cells_trace += h_cells; else ctx->stats.cells += h_cells;
     if (trace) ctx->stats.cells_swept_trace += total_blk * 16 * 64; else ctx->stats.cells_swept += total_blk * 16 * 64;
     if (trace) {

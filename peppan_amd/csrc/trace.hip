@@ -310,9 +310,9 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     hipLaunchKernelGGL(select_best, dim3(gb), dim3(256), 0, st, d_cands, n, sw, dms.as<const int32_t>(), flag, best_idx, counters, P.hsp_mode);
     PEP_TRY(pep_scan_u32(ctx, flag, pos, n, ctx->ws[7]));
     uint32_t n_sel = 0, n_pairs = 0;
-    PEP_HIP(ctx, hipMemcpyAsync(&n_sel, pos + n, 4, hipMemcpyDeviceToHost, st));
-    PEP_HIP(ctx, hipMemcpyAsync(&n_pairs, counters, 4, hipMemcpyDeviceToHost, st));
-    PEP_HIP(ctx, hipStreamSynchronize(st));
+    PEP_TRY(pep_read_back(ctx, &n_sel, pos + n, 4));
+    PEP_TRY(pep_read_back(ctx, &n_pairs, counters, 4));
+    PEP_TRY(pep_sync_reads(ctx));
     ctx->stats.pairs = n_pairs;
     ctx->stats.tracebacks = n_sel;
     if (n_sel) {
@@ -326,8 +326,8 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
                            ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known);
         PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_sel, ctx->ws[7]));
         uint64_t total_runs = 0;
-        PEP_HIP(ctx, hipMemcpyAsync(&total_runs, run_off + n_sel, 8, hipMemcpyDeviceToHost, st));
-        PEP_HIP(ctx, hipStreamSynchronize(st));
+        PEP_TRY(pep_read_back(ctx, &total_runs, run_off + n_sel, 8));
+        PEP_TRY(pep_sync_reads(ctx));
         // ---- pass 2: the same DP with traceback codes, selected pairs only (overwrites the pass-1 per-candidate arrays)
         float ms_tr = 0.f;
         PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, &ms_tr, known));
@@ -355,9 +355,9 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         PEP_TRY(pep_scan_u64(ctx, keep_runs, cig_pos, n_sel, ctx->ws[7]));
         uint32_t n_hits = 0;
         uint64_t n_cig = 0;
-        PEP_HIP(ctx, hipMemcpyAsync(&n_hits, hit_pos + n_sel, 4, hipMemcpyDeviceToHost, st));
-        PEP_HIP(ctx, hipMemcpyAsync(&n_cig, cig_pos + n_sel, 8, hipMemcpyDeviceToHost, st));
-        PEP_HIP(ctx, hipStreamSynchronize(st));
+        PEP_TRY(pep_read_back(ctx, &n_hits, hit_pos + n_sel, 4));
+        PEP_TRY(pep_read_back(ctx, &n_cig, cig_pos + n_sel, 8));
+        PEP_TRY(pep_sync_reads(ctx));
         ctx->stats.hits = n_hits;
         if (n_hits) {
             const size_t hb = (size_t)n_hits * sizeof(pep_hit);
@@ -368,10 +368,12 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
                                (const uint32_t *)hit_pos, (const uint64_t *)cig_pos, (const uint64_t *)run_off, (const uint32_t *)runs,
                                ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig);
             PEP_HIP(ctx, hipGetLastError());
-            res->hits.resize(n_hits);
-            res->cigar.resize(n_cig);
-            PEP_HIP(ctx, hipMemcpyAsync(res->hits.data(), d_hits, hb, hipMemcpyDeviceToHost, st));
-            if (n_cig) PEP_HIP(ctx, hipMemcpyAsync(res->cigar.data(), d_cig, n_cig * 4, hipMemcpyDeviceToHost, st));
+            // the table goes to the context's pinned staging area (DMA speed, no page faults); pep_result_copy reads it from there
+            PEP_TRY(pin_reserve(ctx, ctx->pin_stage, hb + (n_cig + 1) * 4));
+            PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_stage.p, d_hits, hb + n_cig * 4, hipMemcpyDeviceToHost, st));       // hits and arena are adjacent in ws[23]
+            res->st_hits = reinterpret_cast<const pep_hit *>(ctx->pin_stage.p);
+            res->st_cigar = reinterpret_cast<const uint32_t *>(ctx->pin_stage.p + hb);
+            res->n_hits = n_hits; res->n_cigar = n_cig;
         }
     }
     ctx->stats.ms_trace = timer.stop();

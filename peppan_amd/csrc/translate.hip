@@ -277,8 +277,8 @@ int finish_layout(pep_ctx *ctx, const PackDesc *desc, uint32_t n, SeqSet &out)
 
 PackDesc *stage_desc(pep_ctx *ctx, uint64_t n)
 {
-    if (ctx->k1_stage.size() < (n + 1) * sizeof(PackDesc)) ctx->k1_stage.resize((n + 1) * sizeof(PackDesc));
-    return reinterpret_cast<PackDesc *>(ctx->k1_stage.data());
+    if (pin_reserve(ctx, ctx->pin_k1, (n + 1) * sizeof(PackDesc)) != PEP_OK) return nullptr;
+    return reinterpret_cast<PackDesc *>(ctx->pin_k1.p);
 }
 
 }  // namespace
@@ -304,6 +304,7 @@ int pep_k1_query(pep_ctx *ctx, int gtable)
                        W[2].as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>());
     PEP_TRY(layout_and_pack(ctx, nt, tab, W[2].as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6]));
     PackDesc *desc = stage_desc(ctx, n);
+    if (!desc) return PEP_ERR_HIP;
     if (n) PEP_HIP(ctx, hipMemcpyAsync(desc, W[2].p, (size_t)n * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->q_meta.resize(n);
@@ -352,6 +353,7 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable)
     PEP_TRY(reserve_packed(ctx, ctx->t, (uint32_t)slots, upper));
     uint32_t n_targets = 0;
     PackDesc *desc = stage_desc(ctx, slots);
+    if (!desc) return PEP_ERR_HIP;
     const uint64_t *d_base = ctx->d_k1_base.as<const uint64_t>();
     if (nw) {
         PEP_HIP(ctx, hipMemsetAsync(W[6].p, 0, (slots + 1) * 4, ctx->stream));
@@ -363,9 +365,9 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable)
                            ctx->t.len.as<uint32_t>());
         PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
                                 W[7], W[8]));
-        PEP_HIP(ctx, hipMemcpyAsync(&n_targets, W[5].as<const uint32_t>() + nw, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PEP_TRY(pep_read_back(ctx, &n_targets, W[5].as<const uint32_t>() + nw, 4));
         PEP_HIP(ctx, hipMemcpyAsync(desc, W[4].p, slots * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
-        PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PEP_TRY(pep_sync_reads(ctx));
     } else {
         PEP_HIP(ctx, hipMemsetAsync(W[5].p, 0, 8, ctx->stream));
         PEP_HIP(ctx, hipMemsetAsync(W[6].p, 0, 4, ctx->stream));
