@@ -5,7 +5,9 @@
  * modules/uberBlast.py delegates to the `diamond` executable and the single-linkage grouping
  * of its hits.  Plain pointers and sizes only; every buffer handed IN is caller-owned and only
  * read; every buffer handed OUT is filled into caller-allocated memory (sizes are queried first),
- * except pep_result handles, which are released with pep_result_free.
+ * except pep_result handles, which are released with pep_result_free.  A pep_result stays valid and unchanged
+ * whatever is called on its context afterwards (the newest one is served from the context's pinned staging area and is
+ * given its own copy before that area is reused).
  *
  * All functions returning int return PEP_OK (0) or a negative PEP_ERR_* code; the message of the
  * last failure on a context is available from pep_last_error().  Nothing is ever silently dropped:

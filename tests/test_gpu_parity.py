@@ -801,3 +801,33 @@ def test_k13_sha1_and_dedup(ctx, tmp_path):
     prio = {int(k): v for k, v in g['priority'].items()}
     fn, groups = PL.writeGenes(str(tmp_path / 'w.genes'), genes, prio, ctx=ctx)
     assert open(fn).read() == g['fasta'] and groups == g['groups']
+
+
+def test_results_stay_valid_across_searches(ctx):
+    """a pep_result handle is independent of later calls on its context: its table lives in the context's pinned staging area only
+    until the next search, which first gives the older result its own copy (include/peppan_hip.h: ownership)"""
+    import ctypes as C
+    from peppan_amd import _native as N, synth
+    lib = N.load_library()
+    names, seqs = synth.make_genes(300, 0, seed=77)
+    ctx.set_query_nt(seqs[:150], 11); ctx.set_ref_nt(seqs, 6, 11)
+    p = N.default_params(45., 25., 10, 5)
+    want_h, want_c, _ = ctx.search(p)
+    r1, r2 = C.c_void_p(), C.c_void_p()
+    assert lib.pep_search(ctx._h, C.byref(p), C.byref(r1)) == 0
+    ctx.set_query_nt(seqs[150:], 11)                                   # different second search; r1 not copied out yet
+    assert lib.pep_search(ctx._h, C.byref(p), C.byref(r2)) == 0
+    ctx.translate(force=True)                                          # K1 staging is a different buffer, but exercise it anyway
+    for r in (r1, r2):
+        nh, nc = C.c_uint64(), C.c_uint64()
+        assert lib.pep_result_size(r, C.byref(nh), C.byref(nc)) == 0
+        h, c = np.zeros(nh.value, dtype=N.HIT_DTYPE), np.zeros(max(nc.value, 1), dtype=np.uint32)
+        assert lib.pep_result_copy(r, h.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p)) == 0
+        if r is r1:
+            assert nh.value == len(want_h) > 50 and h.tobytes() == want_h.tobytes() and c[:nc.value].tobytes() == want_c.tobytes()
+        else:
+            assert nh.value > 50 and h.tobytes() != want_h.tobytes()
+    lib.pep_result_free(r2)
+    lib.pep_result_free(r1)
+    again, _, _ = ctx.search(p)                                        # freeing a staged result leaves the context usable
+    assert len(again) == nh.value
