@@ -96,7 +96,7 @@ def main():
     def step():
         nonlocal gene_of_target
         ctx.translate(force=True)
-        hits, cig, st = ctx.search(params)
+        hits, cig, st = ctx.search(params, copy=False)          # views of the pinned staging area: consumed within the step
         if gene_of_target is None:
             gene_of_target = ctx.target_meta()['seq'].astype(np.uint32)
         allh, allc = pdist.allgather_hits(hits, cig, q0, device=dev if world > 1 else None)

@@ -11,7 +11,7 @@ ABI_VERSION = 1
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
-           'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_stats', 'pep_result_free',
+           'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_stats', 'pep_result_free',
            'pep_rescore_nt', 'pep_components', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup']
 
 
@@ -181,6 +181,7 @@ class Context(object):
         h = C.c_void_p()
         rc = self._lib.pep_ctx_create(int(device), C.byref(h))
         self._h = h
+        self._view = None
         if rc != 0:
             msg = self._lib.pep_last_error(h).decode() if h else 'pep_ctx_create failed'
             if h:
@@ -191,6 +192,9 @@ class Context(object):
 
     def close(self):
         if getattr(self, '_h', None):
+            if getattr(self, '_view', None) is not None:
+                self._lib.pep_result_free(self._view)
+                self._view = None
             self._lib.pep_ctx_destroy(self._h)
             self._h = None
 
@@ -265,20 +269,33 @@ class Context(object):
         return self._get_aa(self._lib.pep_target_count, self._lib.pep_get_target_aa, 'pep_get_target_aa')
 
     # ---- search
-    def search(self, params=None):
-        """returns (hits [HIT_DTYPE], cigar uint32 [len<<2|op], stats dict)"""
+    def search(self, params=None, copy=True):
+        """returns (hits [HIT_DTYPE], cigar uint32 [len<<2|op], stats dict).
+        copy=False: the arrays are views of the library's pinned staging memory - no 2 MB copy and no fresh pages - valid only
+        until the next search on this context (for callers that consume the table at once, like hits_to_blastab)."""
+        if self._view is not None:                      # the handle behind the previous zero-copy views: released first, so that
+            self._lib.pep_result_free(self._view)       # the library does not preserve a table nobody may look at any more
+            self._view = None
         r = C.c_void_p()
         self._check(self._lib.pep_search(self._h, C.byref(params) if params is not None else None, C.byref(r)), 'pep_search')
         try:
             nh, nc = C.c_uint64(), C.c_uint64()
             self._check(self._lib.pep_result_size(r, C.byref(nh), C.byref(nc)), 'pep_result_size')
-            hits = np.zeros(nh.value, dtype=HIT_DTYPE)
-            cig = np.zeros(nc.value, dtype=np.uint32)
-            self._check(self._lib.pep_result_copy(r, _ptr(hits), _ptr(cig)), 'pep_result_copy')
             st = Stats()
             self._check(self._lib.pep_result_stats(r, C.byref(st)), 'pep_result_stats')
+            if copy or nh.value == 0:
+                hits = np.empty(nh.value, dtype=HIT_DTYPE)
+                cig = np.empty(nc.value, dtype=np.uint32)
+                self._check(self._lib.pep_result_copy(r, _ptr(hits), _ptr(cig)), 'pep_result_copy')
+            else:
+                ph, pc = C.c_void_p(), C.c_void_p()
+                self._check(self._lib.pep_result_data(r, C.byref(ph), C.byref(pc)), 'pep_result_data')
+                hits = np.frombuffer((C.c_char * (nh.value * HIT_DTYPE.itemsize)).from_address(ph.value), dtype=HIT_DTYPE)
+                cig = (np.frombuffer((C.c_char * (nc.value * 4)).from_address(pc.value), dtype=np.uint32) if nc.value else np.empty(0, np.uint32))
+                self._view, r = r, None                 # keep the handle alive while the views may be in use
         finally:
-            self._lib.pep_result_free(r)
+            if r is not None:
+                self._lib.pep_result_free(r)
         return hits, cig, {n: getattr(st, n) for n, _ in Stats._fields_}
 
     # ---- K7

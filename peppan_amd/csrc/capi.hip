@@ -543,6 +543,14 @@ int pep_result_copy(const pep_result *r, pep_hit *hits, uint32_t *cigar)
     return PEP_OK;
 }
 
+int pep_result_data(const pep_result *r, const pep_hit **hits, const uint32_t **cigar)
+{
+    if (!r) return PEP_ERR_ARG;
+    if (hits) *hits = r->st_hits ? r->st_hits : r->hits.data();
+    if (cigar) *cigar = r->st_cigar ? r->st_cigar : r->cigar.data();
+    return PEP_OK;
+}
+
 int pep_result_stats(const pep_result *r, pep_stats *stats)
 {
     if (!r || !stats) return PEP_ERR_ARG;

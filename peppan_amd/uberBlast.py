@@ -366,7 +366,7 @@ class RunBlast(object):
         self._ensure_nt(ctx, 6 if frames == '7' else 3)
         params = N.default_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100., top_k=nhits, n_splits=5,
                                   dbsize=5000000., max_evalue=1.)
-        hits, cigar, stats = ctx.search(params)
+        hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
         q_len = [len(self.qrySeq[n]) for n in self.q_names]
         r_len = [len(self.refSeq[n]) for n in self.r_names]
         blastab = hits_to_blastab(hits, cigar, ctx.query_meta(), ctx.target_meta(), self.q_names, self.r_names, q_len, r_len,
@@ -400,7 +400,7 @@ class RunBlast(object):
         ctx.set_target_groups(None if self._batch is None else t_grp)
         self._nt_loaded = None                      # the packed protein sets of a previous translated search are gone
         params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100.)
-        hits, cigar, stats = ctx.search(params)
+        hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
         blastab = blast_hits_to_blastab(hits, cigar, q_names, r_names, [len(c) for c in q_codes], [len(c) for c in r_codes],
                                         self.min_id, self.min_cov, self.min_ratio, params, np.array(t_seq, dtype=np.int64), np.array(t_rev, dtype=bool))
         logger('Run BLASTn finishes. Got {0} alignments'.format(blastab.shape[0]))

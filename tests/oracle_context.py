@@ -60,7 +60,7 @@ class OracleContext(object):
     def target_meta(self):
         return self._tm
 
-    def search(self, params=None):
+    def search(self, params=None, copy=True):
         self.translate()
         p = O.params_from(params)
         ms = np.array([O.min_score(len(s), params.dbsize, params.max_evalue, params.ka_lambda, params.ka_k) for s in self.q_aa], dtype=np.int32)
