@@ -509,7 +509,18 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     const float ms_seed = t_seed.stop();
     if (rc == PEP_OK) {
         std::vector<int32_t> min_score(ctx->q.n + 1);
-        for (uint32_t i = 0; i < ctx->q.n; ++i) min_score[i] = pep_min_score_ka(ctx->q.h_len[i], ctx->params.dbsize, ctx->params.max_evalue, ctx->params.ka_lambda, ctx->params.ka_k);
+        // the threshold depends on the length only and lengths repeat: one logarithm per distinct length (direct-mapped memo)
+        uint32_t memo_len[1024];
+        int32_t memo_val[1024];
+        for (int i = 0; i < 1024; ++i) memo_len[i] = 0xFFFFFFFFu;
+        for (uint32_t i = 0; i < ctx->q.n; ++i) {
+            const uint32_t L = ctx->q.h_len[i], slot = L & 1023u;
+            if (memo_len[slot] != L) {
+                memo_len[slot] = L;
+                memo_val[slot] = pep_min_score_ka(L, ctx->params.dbsize, ctx->params.max_evalue, ctx->params.ka_lambda, ctx->params.ka_k);
+            }
+            min_score[i] = memo_val[slot];
+        }
         rc = pep_extend(ctx, d_cands, n_cands, min_score.data(), res);
     }
     const float ms_all = t_total.stop();

@@ -10,7 +10,6 @@
 //                           q:21 | t:25 | bin:18 into a device hash set; first inserter appends it to the list.
 //  The candidate list is then radix-sorted (sort.hip) so every later stage is order-deterministic.
 #include "common.h"
-#include <cstdlib>
 
 namespace {
 
@@ -134,7 +133,7 @@ struct JoinArgs {
     uint64_t *hits;          // raw seed hits (qpos << 32 | tpos)
     unsigned long long *hit_count;
     uint64_t hit_cap;
-    int debug;               // profiling aid: 1 = keys only, 2 = keys + bucket lookup, 3 = + entry compare (no extension)
+    int debug;               // profiling aid (params.reserved[0]): 1 = keys only, 2 = keys + bucket lookup, 3 = + entry compare (no extension), 9 = no wave-level de-duplication
 };
 
 __device__ __forceinline__ void set_insert(const JoinArgs &a, uint64_t k)
@@ -441,7 +440,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             a.table = ctx->ws[3].as<uint64_t>(); a.table_bits = table_bits;
             a.counters = counters; a.stats = stats;
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
-            a.debug = P.reserved[0]; if (getenv("PEP_NO_DEDUPE")) a.debug = 9; a.ungapped_min = P.ungapped_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
+            a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
             PEP_HIP(ctx, hipMemsetAsync(hit_count, 0, 8, ctx->stream));
             PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 5u)), sh, a);

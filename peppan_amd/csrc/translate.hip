@@ -9,9 +9,6 @@
 // Byte-granular, HBM-bound: 3 nt bytes read per residue byte written.
 #include "common.h"
 #include <algorithm>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
 
 namespace {
 
@@ -256,8 +253,8 @@ int layout_and_pack(pep_ctx *ctx, const NtSet &nt, int tab, const PackDesc *d_de
 int finish_layout(pep_ctx *ctx, const PackDesc *desc, uint32_t n, SeqSet &out)
 {
     out.n = n;
-    out.h_off.assign((size_t)n + 1, 0);
-    out.h_len.assign(n, 0);
+    out.h_off.resize((size_t)n + 1);
+    out.h_len.resize(n);
     uint64_t pos = PEP_END_PAD, residues = 0;
     uint32_t max_len = 0;
     for (uint32_t i = 0; i < n; ++i) {
