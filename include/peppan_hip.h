@@ -176,7 +176,11 @@ int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint3
 
 /* K9: linear-time clustering.  codes: residue codes (< base are valid k-mer letters), concatenated, off[n+1].
  * rep[i] = index of sequence i's representative (rep[i] == i for representatives).  stats (may be NULL):
- * [0] selected k-mers, [1] verified (sequence, centre, diagonal) pairs, [2] accepted edges. */
+ * [0] selected k-mers, [1] verified (sequence, centre, diagonal) pairs, [2] accepted edges.
+ * Pairs that fail on their k-mer diagonal without gaps are aligned by the search's banded Smith-Waterman engine (base 4:
+ * +2 / -3, gap 6 + 2k; otherwise residues in the order ACDEFGHIKLMNPQRSTVWY + one code for anything else, BLOSUM62, gap 11 + k).
+ * That stage uses the context's packed sequence sets: after pep_linclust a pep_search re-runs K1 for nucleotide inputs and
+ * needs pep_set_query_aa / pep_set_ref_aa inputs to be given again (PEP_ERR_STATE otherwise). */
 int pep_linclust(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n, int base, int k, int m,
                  double min_id, double min_cov, uint32_t *rep, uint64_t *stats);
 

@@ -631,6 +631,10 @@ void oracle_components(uint32_t n, uint64_t m, const uint32_t *a, const uint32_t
  *  3. each (sequence s, selected k-mer) whose centre c != s defines one diagonal (position in c - position in s);
  *     the UNGAPPED overlap of s and c on that diagonal is accepted when matches >= min_id * overlap and
  *     overlap >= min_cov * len(c) and overlap >= min_cov * len(s)   (double arithmetic, no division);
+ *  3b. a centre that no diagonal of s accepted is aligned WITH gaps: banded affine local alignment (the engine of the search,
+ *     band = the 128 diagonals around 64 * floor((d + 2^23) / 64) - 2^23 - 32 for every failed diagonal d, best band by score
+ *     then lowest bin; nucleotides +2 / -3 gap 6 + 2k, amino acids BLOSUM62 gap 11 + k); accepted when identical columns >=
+ *     min_id * alignment columns and the aligned span covers >= min_cov of s and of c;
  *  4. greedy assignment in priority order (length desc, index asc): an unassigned sequence becomes a
  *     representative and takes every still unassigned sequence it was accepted as the centre of.
  * rep_out[s] = index of s's representative. */
@@ -669,6 +673,25 @@ static int lc_cmp_pri(const void *a, const void *b)
     return x->idx < y->idx ? -1 : (x->idx > y->idx);
 }
 
+/* scoring of the gapped verification (mirrors k9_params of linclust.hip): base 4 = nucleotides, +2 / -3, gap 6 + 2k;
+ * otherwise amino acids in the order ACDEFGHIKLMNPQRSTVWY (+ one code for anything else = X), BLOSUM62, gap 11 + k */
+static void lc_gapped_params(int base, oracle_params *p)
+{
+    oracle_params d;
+    oracle_default_params(&d);
+    *p = d;
+    for (int a = 0; a < 32; ++a) for (int b = 0; b < 32; ++b) p->sub[a * 32 + b] = -64;
+    if (base == 4) {
+        for (int a = 0; a < 5; ++a) for (int b = 0; b < 5; ++b) p->sub[a * 32 + b] = (int8_t)((a == b && a < 4) ? 2 : -3);
+        p->gap_open = 6; p->gap_ext = 2;
+    } else {
+        static const char *letters = "ACDEFGHIKLMNPQRSTVWYX";
+        for (int a = 0; a <= 20 && a <= base; ++a)
+            for (int b = 0; b <= 20 && b <= base; ++b) p->sub[a * 32 + b] = d.sub[(letters[a] - 'A') * 32 + (letters[b] - 'A')];
+        p->gap_open = 11; p->gap_ext = 1;
+    }
+}
+
 int oracle_linclust(const uint8_t *res, const uint64_t *off, uint32_t n, int base, int k, int m, double min_id, double min_cov,
                     uint32_t *rep_out, uint64_t *stats /* [0] selected k-mers [1] verified pairs [2] accepted edges */)
 {
@@ -699,6 +722,8 @@ int oracle_linclust(const uint8_t *res, const uint64_t *off, uint32_t n, int bas
     for (uint32_t s = 0; s < n; ++s)
         for (uint32_t r = 0; r < cnt[s]; ++r) { ctr[nc].key = sel[(size_t)s * m + r].key; ctr[nc].len = (uint32_t)(off[s + 1] - off[s]); ctr[nc].idx = s; ++nc; }
     qsort(ctr, nc, sizeof(lc_ctr), lc_cmp_ctr);
+    oracle_params gp;
+    lc_gapped_params(base, &gp);
     /* accepted centres per member */
     uint32_t *acc = malloc(((size_t)n * m + 1) * sizeof(uint32_t));
     uint32_t *nacc = calloc(n + 1, sizeof(uint32_t));
@@ -707,6 +732,7 @@ int oracle_linclust(const uint8_t *res, const uint64_t *off, uint32_t n, int bas
         const uint8_t *qs = res + off[s];
         int64_t Ls = (int64_t)(off[s + 1] - off[s]);
         uint32_t seen_c[64]; int64_t seen_d[64]; int ns = 0;
+        uint32_t pend_c[64]; int32_t pend_bin[64]; int np = 0;      /* (centre, band) of the diagonals that failed without gaps */
         for (uint32_t r = 0; r < cnt[s]; ++r) {
             uint64_t key = sel[(size_t)s * m + r].key;
             uint64_t lo = 0, hi = nc;
@@ -730,6 +756,37 @@ int oracle_linclust(const uint8_t *res, const uint64_t *off, uint32_t n, int bas
                 int have = 0;
                 for (uint32_t z = 0; z < nacc[s]; ++z) if (acc[(size_t)s * m + z] == c) have = 1;
                 if (!have) { acc[(size_t)s * m + nacc[s]++] = c; ++n_acc; }
+            } else {
+                pend_c[np] = c; pend_bin[np] = (int32_t)((d + DIAG_OFF) / BIN_W); ++np;
+            }
+        }
+        /* gapped verification: for every centre not accepted yet, the best band (score, then lowest bin) among its failed
+         * diagonals' bands is aligned with traceback; accepted when identities >= min_id * alignment columns and the aligned
+         * span covers min_cov of both sequences */
+        for (int a = 0; a < np; ++a) {
+            uint32_t c = pend_c[a];
+            int first = 1, have = 0;
+            for (int b = 0; b < a; ++b) if (pend_c[b] == c) first = 0;
+            for (uint32_t z = 0; z < nacc[s]; ++z) if (acc[(size_t)s * m + z] == c) have = 1;
+            if (!first || have) continue;
+            const uint8_t *qc = res + off[c];
+            int32_t Lc = (int32_t)(off[c + 1] - off[c]);
+            int32_t best = 0, best_bin = 0;
+            for (int b = a; b < np; ++b) {
+                if (pend_c[b] != c) continue;
+                sw_out o;
+                banded_sw(&gp, qs, (int32_t)Ls, qc, Lc, pend_bin[b] * BIN_W - DIAG_OFF - BAND_LEAD, 0, &o);
+                if (o.score > best || (o.score == best && o.score > 0 && pend_bin[b] < best_bin)) { best = o.score; best_bin = pend_bin[b]; }
+            }
+            if (best < 1) continue;
+            int32_t dlo = best_bin * BIN_W - DIAG_OFF - BAND_LEAD, is, js; uint32_t nid, al;
+            sw_out o; runbuf rb = {0};
+            banded_sw(&gp, qs, (int32_t)Ls, qc, Lc, dlo, 1, &o);
+            traceback(&o, qs, qc, dlo, &rb, &is, &js, &nid, &al);
+            free(o.dir); free(rb.runs);
+            double qspan = (double)(o.iend - is + 1), tspan = (double)(o.jend - js + 1);
+            if ((double)nid >= min_id * (double)al && qspan >= min_cov * (double)Ls && tspan >= min_cov * (double)Lc) {
+                acc[(size_t)s * m + nacc[s]++] = c; ++n_acc;
             }
         }
     }

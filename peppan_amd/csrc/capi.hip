@@ -244,6 +244,10 @@ int download_aa(pep_ctx *ctx, const SeqSet &s, uint8_t *codes, uint64_t cap, uin
 
 }  // namespace
 
+// entry points for other translation units (K9's gapped verification drives the alignment engine on its own sequence sets)
+int pep_upload_codes(pep_ctx *ctx, SeqSet &s, const uint8_t *codes, const uint64_t *off, uint32_t n, uint32_t max_n) { return upload_aa(ctx, s, codes, off, n, max_n); }
+int pep_upload_sub(pep_ctx *ctx) { return upload_sub_image(ctx); }
+
 extern "C" {
 
 int pep_version(void) { return PEP_ABI_VERSION; }

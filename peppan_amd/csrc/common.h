@@ -189,3 +189,5 @@ int pep_k9_linclust(pep_ctx *ctx, const uint8_t *h_res, const uint64_t *h_off, u
 
 static inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 int pep_upload_blk2seq(pep_ctx *ctx, SeqSet &s);
+int pep_upload_codes(pep_ctx *ctx, SeqSet &s, const uint8_t *codes, const uint64_t *off, uint32_t n, uint32_t max_n);
+int pep_upload_sub(pep_ctx *ctx);

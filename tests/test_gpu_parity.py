@@ -831,3 +831,42 @@ def test_results_stay_valid_across_searches(ctx):
     lib.pep_result_free(r1)
     again, _, _ = ctx.search(p)                                        # freeing a staged result leaves the context usable
     assert len(again) == nh.value
+
+
+def test_k9_gapped_verification_and_context_state(ctx):
+    """alleles that differ from their centre by an indel are absorbed through the alignment engine (== oracle), and a context
+    keeps working for searches afterwards: nucleotide inputs are re-translated, amino-acid inputs must be given again"""
+    from oracle import oracle as O
+    from peppan_amd import _native as N, synth
+    rng = np.random.default_rng(99)
+    fam = []
+    for f in range(60):
+        centre = rng.integers(0, 4, int(rng.integers(300, 2500))).astype(np.uint8)
+        fam.append(centre)
+        for v in range(int(rng.integers(1, 5))):
+            x = centre.copy()
+            for p in rng.choice(len(x), max(1, len(x) // 60), replace=False):
+                x[p] = (x[p] + 1) % 4
+            cut = int(rng.integers(20, len(x) - 40))
+            if rng.random() < 0.5:
+                x = np.concatenate([x[:cut], x[cut + int(rng.integers(1, 13)):]])
+            else:
+                x = np.concatenate([x[:cut], rng.integers(0, 4, int(rng.integers(1, 13))).astype(np.uint8), x[cut:]])
+            fam.append(x)
+    long_pair = rng.integers(0, 4, 9400).astype(np.uint8)                      # beyond the packed 16-bit range of the DP
+    fam += [long_pair, np.concatenate([long_pair[:4000], long_pair[4003:]])]
+    names, seqs = synth.make_genes(200, 0, seed=5)
+    ctx.set_query_nt(seqs[:50], 11); ctx.set_ref_nt(seqs, 6, 11)
+    p = N.default_params(45., 25., 10, 5)
+    before, _, _ = ctx.search(p)
+    for min_id, cov in ((0.95, 0.9), (0.9, 0.5)):
+        g_rep, g_st = ctx.linclust(fam, min_id, cov)
+        o_rep, o_st = O.linclust(fam, min_id, cov)
+        assert np.array_equal(g_rep, o_rep) and g_st == o_st
+        assert len(set(g_rep.tolist())) <= 70 and g_rep[-1] == g_rep[-2]
+    after, _, _ = ctx.search(p)                                               # nucleotide inputs: K1 runs again by itself
+    assert before.tobytes() == after.tobytes() and len(before) > 20
+    ctx.set_query_aa([np.arange(20, dtype=np.uint8)] * 3); ctx.set_ref_aa([np.arange(20, dtype=np.uint8)] * 3)
+    ctx.linclust(fam[:10], 0.9, 0.9)
+    with pytest.raises(N.PepError):
+        ctx.search(p)

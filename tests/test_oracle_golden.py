@@ -111,3 +111,31 @@ def test_oracle_search_self_consistency():
     h = [h for h in hits if h['q'] == 0 and h['t'] == 1][0]
     runs = cig[h['cigar_off']:h['cigar_off'] + h['cigar_runs']]
     assert list(runs & 3) == [0, 1, 0] and (runs >> 2)[1] == 4
+
+
+def test_linclust_gapped_verification():
+    """K9 restatement: an allele that differs from its centre by an indel fails every ungapped diagonal and is absorbed by the
+    gapped verification (identity over alignment columns, coverage of both sequences by the aligned span)"""
+    rng = np.random.default_rng(99)
+    centre = rng.integers(0, 4, 900).astype(np.uint8)
+
+    def variant(n_sub, cut=None, ins=None):
+        v = centre.copy()
+        for p in rng.choice(len(v), n_sub, replace=False):
+            v[p] = (v[p] + 1) % 4
+        if cut:
+            v = np.concatenate([v[:cut[0]], v[cut[0] + cut[1]:]])
+        if ins:
+            v = np.concatenate([v[:ins[0]], rng.integers(0, 4, ins[1]).astype(np.uint8), v[ins[0]:]])
+        return v
+    seqs = [centre, variant(10, cut=(450, 3)), variant(12, ins=(300, 6)), variant(8), variant(200, cut=(500, 9)),
+            rng.integers(0, 4, 880).astype(np.uint8), variant(5, cut=(100, 360))]
+    rep, st = O.linclust(seqs, 0.95, 0.9)
+    # the longest sequence (index 2, carries a 6-nt insertion) is the centre: every other allele needs gaps to reach it
+    assert rep.tolist()[:4] == [2, 2, 2, 2]
+    assert rep[4] == 4 and rep[5] == 5                  # too diverged / unrelated
+    assert rep[6] == 6                                  # the part after its 360-nt deletion covers 49 % of the centre
+    rep2, _ = O.linclust(seqs, 0.95, 0.4)
+    assert rep2[6] == 2                                 # ... which is enough at coverage 0.4
+    rep3, st3 = O.linclust([centre, seqs[3]], 0.95, 0.9)
+    assert rep3.tolist() == [0, 0] and st3['accepted'] == 1          # substitutions only: accepted on the diagonal, no gaps needed
