@@ -870,3 +870,36 @@ def test_k9_gapped_verification_and_context_state(ctx):
     ctx.linclust(fam[:10], 0.9, 0.9)
     with pytest.raises(N.PepError):
         ctx.search(p)
+
+
+@pytest.mark.parametrize('seed', [1, 2, 3, 4, 5, 6])
+def test_search_parameter_fuzz(ctx, seed):
+    """random gap costs, ungapped-filter settings, top-k / splits, HSP mode and thresholds: GPU == oracle on every field;
+    then the packed 16-bit passes against the 32-bit passes of the GPU itself on a larger set"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(1000 + seed)
+    prots = synth.make_proteins(180, length=(40, 520), seed=50 + seed, family=int(rng.integers(2, 6)), sub=float(rng.uniform(0.05, 0.4)))
+    p = N.default_params(float(rng.choice([0., 30., 60.])), float(rng.choice([0., 20., 70.])), int(rng.choice([1, 3, 10])), int(rng.choice([1, 5])),
+                         ungapped_min=int(rng.choice([0, 30, 45, 60])))
+    p.gap_open, p.gap_ext = int(rng.integers(5, 15)), int(rng.integers(1, 4))
+    p.xdrop, p.ext_right, p.ext_left = int(rng.integers(8, 21)), int(rng.integers(20, 49)), int(rng.integers(0, 41))
+    p.hsp_mode = int(rng.integers(0, 2))
+    p.max_evalue = float(rng.choice([1., 1e-3, 10.]))
+    nq = int(rng.integers(1, len(prots)))
+    ctx.set_query_aa(prots[:nq]); ctx.set_ref_aa(prots)
+    gh, gc, st = ctx.search(p)
+    ms = np.array([N.min_score(len(s), p.dbsize, p.max_evalue) for s in prots[:nq]], dtype=np.int32)
+    oh, oc, ost = O.search(prots[:nq], prots, O.params_from(p), min_scores=ms)
+    assert st['candidates'] == ost['candidates'] and st['pairs'] == ost['pairs'] and st['cells'] == ost['cells'] and st['tracebacks'] == ost['tracebacks']
+    _cmp_hits(gh, gc, oh, oc)
+    # packed (two candidates per wavefront, 16-bit) vs 32-bit passes
+    names, seqs = synth.make_genes(1500, 0, seed=200 + seed)
+    ctx.set_query_nt(seqs[:700], 11); ctx.set_ref_nt(seqs, 6, 11)
+    q = N.default_params(40., 20., 10, 5)
+    q.gap_open, q.gap_ext, q.hsp_mode = p.gap_open, p.gap_ext, p.hsp_mode
+    a_h, a_c, a_st = ctx.search(q)
+    q.reserved[1] = 1
+    b_h, b_c, b_st = ctx.search(q)
+    assert len(a_h) > 500 and a_h.tobytes() == b_h.tobytes() and a_c.tobytes() == b_c.tobytes()
+    assert a_st['cells'] == b_st['cells'] and a_st['tracebacks'] == b_st['tracebacks']
