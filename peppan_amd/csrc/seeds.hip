@@ -35,6 +35,22 @@ __device__ __forceinline__ uint32_t hash_u64(uint64_t k, int bits)
 }
 
 // reduced letters of one 256-position tile (+32 halo) into LDS: one coalesced pass, the reduction table lives in SGPRs
+__device__ __forceinline__ uint8_t reduce_letter(const SeedShape &sh, uint32_t code)
+{
+    const uint32_t c = code & 31u;
+    const uint32_t w = (c & 16u) ? ((c & 8u) ? sh.red4[3] : sh.red4[2]) : ((c & 8u) ? sh.red4[1] : sh.red4[0]);
+    return (uint8_t)((w >> ((c & 7u) * 4u)) & 15u);
+}
+
+// residues of tile `tile` owned by this thread: position x = threadIdx.x and, for the first TILE_HALO threads, the halo byte x + TILE
+__device__ __forceinline__ uint32_t fetch_tile(const uint8_t *__restrict__ res, uint64_t tile, uint64_t total)
+{
+    const uint64_t p = tile * TILE + threadIdx.x;
+    uint32_t v = p < total ? res[p] : (uint32_t)PEP_PAD_CODE;
+    if (threadIdx.x < TILE_HALO) v |= (uint32_t)(p + TILE < total ? res[p + TILE] : (uint8_t)PEP_PAD_CODE) << 8;
+    return v;
+}
+
 __device__ __forceinline__ void stage_reduced(const SeedShape &sh, const uint8_t *__restrict__ res, uint64_t tile_base, uint64_t total, uint8_t *red)
 {
     for (int x = threadIdx.x; x < TILE + TILE_HALO; x += TILE) {
@@ -220,11 +236,16 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
     __syncthreads();
     uint32_t n_seed = 0, n_hit = 0;
     const uint64_t n_tiles = (a.t_total + 255) / 256;
+    // the residues of the NEXT tile are fetched into a register while this one is processed: a block walks ~60 tiles one after the
+    // other, and without this every tile starts with an exposed global-memory latency
+    uint32_t fetched = blockIdx.x < n_tiles ? fetch_tile(a.t_res, blockIdx.x, a.t_total) : 0u;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t p = tile * 256 + threadIdx.x;
         uint64_t key = 0;
         uint32_t e0 = 0, e1 = 0;
-        stage_reduced(sh, a.t_res, tile * TILE, a.t_total, red);
+        red[threadIdx.x] = reduce_letter(sh, fetched);
+        if (threadIdx.x < TILE_HALO) red[TILE + threadIdx.x] = reduce_letter(sh, fetched >> 8);
+        if (tile + gridDim.x < n_tiles) fetched = fetch_tile(a.t_res, tile + gridDim.x, a.t_total);
         __syncthreads();
         if (p + 32 <= a.t_total && tile_key<W>(sh, red, threadIdx.x, key)) {
             ++n_seed;
