@@ -350,28 +350,37 @@ __global__ __launch_bounds__(256) void seed_extend(JoinArgs a)
     if (threadIdx.x == 0 && blk_pass) atomicAdd(&a.stats[2], (unsigned long long)blk_pass);
 }
 
-// hash set -> dense list (arbitrary order; sorted afterwards).  One global atomic per block.
+// hash set -> dense list (arbitrary order; sorted afterwards).  One global atomic per block and per COMPACT_ROUNDS x 256 slots:
+// the single counter word sustains ~90 atomics/us, so 4096 blocks with one atomic each spent 45 us waiting for it.
+constexpr int COMPACT_ROUNDS = 16;
 __global__ __launch_bounds__(256) void set_compact(const uint64_t *__restrict__ table, uint64_t cap, uint64_t *__restrict__ list, uint32_t list_cap,
                                                    uint32_t *__restrict__ counters)
 {
     __shared__ uint32_t wave_cnt[4], blk_base;
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const uint64_t k = i < cap ? table[i] : EMPTY;
-    const bool occ = k != EMPTY;
-    const unsigned long long m = __ballot(occ);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) wave_cnt[wave] = (uint32_t)__popcll(m);
+    uint64_t k[COMPACT_ROUNDS];
+    uint32_t mine = 0;
+#pragma unroll
+    for (int r = 0; r < COMPACT_ROUNDS; ++r) {
+        const uint64_t i = ((uint64_t)blockIdx.x * COMPACT_ROUNDS + r) * 256 + threadIdx.x;
+        k[r] = i < cap ? table[i] : EMPTY;
+        mine += k[r] != EMPTY ? 1u : 0u;
+    }
+    // exclusive prefix of `mine` over the block
+    uint32_t incl = mine;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) wave_cnt[wave] = incl;
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t tot = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
         blk_base = tot ? atomicAdd(&counters[0], tot) : 0u;
     }
     __syncthreads();
-    if (occ) {
-        uint32_t idx = blk_base + (uint32_t)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-        for (int w = 0; w < wave; ++w) idx += wave_cnt[w];
-        if (idx < list_cap) list[idx] = k; else counters[1] = 1u;
-    }
+    uint32_t idx = blk_base + incl - mine;
+    for (int w = 0; w < wave; ++w) idx += wave_cnt[w];
+#pragma unroll
+    for (int r = 0; r < COMPACT_ROUNDS; ++r)
+        if (k[r] != EMPTY) { if (idx < list_cap) list[idx] = k[r]; else counters[1] = 1u; ++idx; }
 }
 
 int ilog2_ceil(uint64_t x)
@@ -469,7 +478,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             PEP_HIP(ctx, hipGetLastError());
             PEP_TRY(pep_read_back(ctx, &h_nseed[s], start + n_buckets, sizeof(uint32_t)));
         }
-        hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ws[3].as<uint64_t>(), cap,
+        hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256 * COMPACT_ROUNDS)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ws[3].as<uint64_t>(), cap,
                            ctx->ws[4].as<uint64_t>(), list_cap, counters);
         uint32_t h_counters[4];
         unsigned long long h_stats[3];

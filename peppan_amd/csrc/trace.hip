@@ -255,18 +255,20 @@ __global__ __launch_bounds__(256) void emit(uint64_t n_sel, const SelInfo *__res
     const uint64_t co = cig_pos[s];
     const uint32_t *rv = runs + run_off[s];
     for (uint32_t r = lane; r < info.n_runs; r += 64) cigar[co + r] = rv[info.n_runs - 1 - r];
+    // exact in-band in-matrix cell count of the winning band: the 128 diagonals are spread over the lanes
+    const uint32_t q = key_q(key), t = key_t(key);
+    const int dlo = key_dlo(key), Lq = (int)q_len[q], Lt = (int)t_len[t];
+    const int dl = max(dlo, -(Lq - 1)), dh = min(dlo + 127, Lt - 1);
+    unsigned long long cells = 0;
+    for (int d = dl + lane; d <= dh; d += 64) cells += (unsigned long long)(min(Lq - 1, Lt - 1 - d) - max(0, -d) + 1);
+    for (int x = 32; x > 0; x >>= 1) cells += __shfl_xor(cells, x, 64);
     if (lane == 0) {
         pep_hit h;
-        h.q = key_q(key); h.t = key_t(key);
+        h.q = q; h.t = t;
         h.q_start = (uint32_t)info.istart + 1; h.q_end = (uint32_t)info.iend + 1;
         h.t_start = (uint32_t)info.jstart + 1; h.t_end = (uint32_t)info.jend + 1;
         h.score = info.score; h.n_ident = info.n_ident; h.aln_len = info.aln_len; h.nm = info.aln_len - info.n_ident;
         h.cigar_runs = info.n_runs; h.bin = (int32_t)(key & ((1u << 18) - 1)); h.cigar_off = co;
-        // exact in-band in-matrix cell count of the winning band
-        const int dlo = key_dlo(key), Lq = (int)q_len[h.q], Lt = (int)t_len[h.t];
-        const int dl = max(dlo, -(Lq - 1)), dh = min(dlo + 127, Lt - 1);
-        uint64_t cells = 0;
-        for (int d = dl; d <= dh; ++d) cells += (uint64_t)(min(Lq - 1, Lt - 1 - d) - max(0, -d) + 1);
         h.cells = cells;
         hits[hit_pos[s]] = h;
     }
