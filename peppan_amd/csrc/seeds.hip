@@ -4,11 +4,14 @@
 //  seed_count / seed_fill : one thread per packed query byte position; key = sum red[r[p+off_k]] * base^k.
 //                           Padding bytes (code 31) never seed, so a seed cannot straddle two sequences.
 //                           Index = counting sort by hash(key): counts -> exclusive scan -> fill (8 B entries
-//                           key << 29 | pos).  Algorithmic traffic 1 B read + 8 B written per query residue.
-//  seed_join              : one thread per packed target byte position; reads its bucket (start/end = 8 B,
-//                           entries 8 B each), and for every equal key inserts the candidate key
-//                           q:21 | t:25 | bin:18 into a device hash set; first inserter appends it to the list.
-//  The candidate list is then radix-sorted (sort.hip) so every later stage is order-deterministic.
+//                           key << 29 | pos) + one occupancy bit per bucket.  1 B read + 8 B written per query residue.
+//  seed_match             : persistent blocks stream the packed target bytes tile by tile; every position whose bucket is
+//                           occupied compares its key with the bucket's entries; equal keys are raw seed hits
+//                           (qpos << 32 | tpos), staged in LDS and flushed with one global atomic per ~1.5 k hits.
+//  seed_extend            : one thread per raw hit; neighbouring hits of one diagonal share their candidate key
+//                           q:21 | t:25 | bin:18, so the first lane of each run decides for the run: already in the
+//                           device hash set, or ungapped x-drop extension -> insert.
+//  The candidate set is compacted and radix-sorted (sort.hip) so every later stage is order-deterministic.
 #include "common.h"
 
 namespace {

@@ -1,4 +1,5 @@
-// K5: banded affine Smith-Waterman, one wavefront (64 lanes) per candidate, anti-diagonal sweep.
+// K5: banded affine Smith-Waterman, anti-diagonal sweep by one wavefront (64 lanes) - over ONE candidate in the 32-bit kernels,
+// over TWO candidates at once in the packed 16-bit kernels (score pass and traceback pass) that run whenever the scores fit.
 //
 // Mapping.  A candidate's band holds 128 diagonals d = j - i in [dlo, dlo+127].  Lane l owns the two
 // adjacent diagonals A = dlo+2l and B = dlo+2l+1.  Cells of one anti-diagonal s = i+j all have the parity
@@ -8,8 +9,8 @@
 //     left      (i,  j-1): diagonal d-1, previous step        -> own B->A... i.e. own other register, or lane l-1 (DPP wave_shr:1)
 //     up        (i-1,j  ): diagonal d+1, previous step        -> own other register, or lane l+1 (DPP wave_shl:1)
 // so a step costs two DPP moves and no LDS traffic for the recurrences.  Residues of the pair are staged
-// in LDS (coalesced global reads once per candidate); the 32x32 substitution table is replicated across
-// the 32 banks (dword w*32+bank) so the per-lane gather is conflict-free.
+// in LDS (coalesced global reads once per candidate); the 32x32 substitution table is held in PEP_TAB_REP copies
+// (dword w*PEP_TAB_REP + lane mod PEP_TAB_REP) so that the per-lane gather meets at most 2-way bank conflicts.
 //
 // Per cell a 4-bit traceback code is produced (bits0-1 source of H: 0 none/1 diagonal/2 E/3 F, bit2 E was an
 // extension, bit3 F was an extension); a lane packs 8 consecutive cells of EACH of its two diagonals in one dword

@@ -1,4 +1,4 @@
-// K6 + K8: choose the best band per (query, target), walk the traceback codes written by K5,
+// K6 + K8: choose the best band per (query, target), walk the traceback codes written by K5 (one alignment per lane),
 // run-length encode the CIGAR, count identities, apply the identity / query-cover filters and the
 // per-(query, split) top-k, and emit fixed-size hit records + a CIGAR arena ordered by (q, t).
 #include "common.h"
