@@ -14,6 +14,7 @@ same per-genome bookkeeping, in genome order, so the stores are those of the ref
 import io
 import os
 import re
+import sys
 import zipfile
 
 import numpy as np
@@ -374,13 +375,46 @@ def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
             yield r
 
 
-def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_conn, mat_conn, clf_conn, saveSeq, params, search=None, ctx=None):
+def _all_bsn(prefix, clust, jobs, og, old_prediction, params, search, ctx, group, per_round):
+    """(job, (bsn, ovl)) for every genome in job order.  With torch.distributed initialised the genomes are dealt to the ranks in
+    blocks of `per_round` (independent units, no data-path collective); every rank maps its block on its own GPU and rank 0
+    gathers the finished per-genome objects - only rank 0 yields, the others just take part."""
+    def local(mine):
+        out = []
+        for (id, taxon, seq), (blastab, overlap) in zip(mine, search(prefix, clust, mine, params) if mine else ()):
+            out.append(build_bsn(blastab, overlap, seq, og, old_prediction, params, ctx))
+        return out
+    world, rank = 1, 0
+    dist = sys.modules.get('torch.distributed')            # only a caller that set up a process group has imported it
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        for job, (blastab, overlap) in zip(jobs, search(prefix, clust, jobs, params)):
+            yield job, build_bsn(blastab, overlap, job[2], og, old_prediction, params, ctx)
+        return
+    n_rounds = -(-len(jobs) // (per_round * world))
+    for k in range(n_rounds):
+        lo = (k * world + rank) * per_round
+        done = local(jobs[lo:lo + per_round])
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(done, gathered, dst=0, group=group)
+        if rank == 0:
+            for r in range(world):
+                lo_r = (k * world + r) * per_round
+                for job, out in zip(jobs[lo_r:lo_r + per_round], gathered[r]):
+                    yield job, out
+
+
+def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_conn, mat_conn, clf_conn, saveSeq, params, search=None, ctx=None,
+                group=None, genomes_per_round=64):
     """genomes: {contig id: [taxon id, sequence]} -> fills the four MapBsn stores like PEPPAN.py:907-989:
       conn      gene id -> int rows [gene, taxon, score*1e4, ident*1e4, ident*1e4, group id, n fragments], best score first
       seq_conn  chunk no -> object array of packed alleles (only with saveSeq)
       mat_conn  chunk no -> object array of the hit rows of each group
       clf_conn  block no -> CSR [30001 offsets + 30001, partner*10 + class] of group-overlap conflicts
-    `search(prefix, clust, jobs, params)` yields (blastab, overlap) per genome in job order (default: batched GPU search)."""
+    `search(prefix, clust, jobs, params)` yields (blastab, overlap) per genome in job order (default: batched GPU search).
+    Under torch.distributed (one process per GPU) the genomes are sharded over the ranks in blocks of `genomes_per_round`; rank 0
+    writes the stores (the other ranks pass None for them), whose contents do not depend on the number of ranks."""
     if len(genomes) == 0:
         raise ValueError('get_map_bsn: no genome to map against')
     taxa = {}
@@ -397,9 +431,10 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         ovl = np.vstack(conflicts.pop(block))
         clf_conn.save(block, np.concatenate([np.cumsum(np.concatenate([[0], np.bincount(ovl.T[0], minlength=BLOCK)])) + BLOCK + 1, ovl.T[1]]))
 
-    results = (search or _gpu_search)(prefix, clust, jobs, params)
-    for bId, ((id, taxon, seq), (blastab, overlap)) in enumerate(zip(jobs, results)):
-        bsn, ovl = build_bsn(blastab, overlap, seq, og, old_prediction, params, ctx)
+    per_round = max(1, int(genomes_per_round))
+    searcher = search or (lambda *a: _gpu_search(*a, genomes_per_batch=per_round))
+    for (id, taxon, seq), (bsn, ovl) in _all_bsn(prefix, clust, jobs, og, old_prediction, params, searcher, ctx, group, per_round):
+        bId = id
         last = bId == len(jobs) - 1
         if bsn.shape[0]:
             bsn.T[5] += n_group

@@ -78,3 +78,80 @@ def test_allgather_hits_two_ranks_gloo():
         got_c = np.frombuffer(cb, dtype=np.uint32)
         assert np.array_equal(got_h, exp_h) and np.array_equal(got_c, exp_c)
     assert len(exp_h) > 20
+
+
+def _map_worker(rank, world, port, tmp, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import copy
+    import torch.distributed as dist
+    from conftest import load_golden
+    from oracle_context import OracleContext
+    from peppan_amd import mapbsn
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    g = load_golden('g14_mapbsn.json')
+    want = load_golden('g15_getmapbsn.json')
+    old_fn, bsn_fn = os.path.join(tmp, 'old.%d.npz' % rank), os.path.join(tmp, 'self.%d.npy' % rank)
+    with mapbsn.MapBsn(old_fn, 'w') as op:
+        for contig, rows in g['old_prediction'].items():
+            op.save(contig, np.array(rows, dtype=object))
+    np.save(bsn_fn, np.array(g['self_bsn'], dtype=int))
+    genomes, canned = {}, {}
+    for k, case in enumerate(g['cases']):
+        for c, s in case['contigs'].items():
+            genomes[int(c)] = [want['genomes'][c], s]
+        tab = np.empty([len(case['table']), 17], dtype=object)
+        for i, r in enumerate(case['table']):
+            for j, v in enumerate(r):
+                tab[i, j] = copy.deepcopy(v)
+        canned[k] = (tab, np.array(case['overlap'], dtype=int).reshape(-1, 3))
+    seen = []
+
+    def search(prefix, clust, jobs, params):              # every rank is handed only its own genomes
+        seen.extend(j[0] for j in jobs)
+        return iter([canned[j[0]] for j in jobs])
+    if rank == 0:
+        names = [os.path.join(tmp, 'mm.%s.npz' % x) for x in ('tab', 'seq', 'mat', 'conflicts')]
+        with mapbsn.MapBsn(names[0], 'w') as c0, mapbsn.MapBsn(names[1], 'w') as c1, mapbsn.MapBsn(names[2], 'w') as c2, mapbsn.MapBsn(names[3], 'w') as c3:
+            mapbsn.get_map_bsn(os.path.join(tmp, 'm'), 'CL', genomes, bsn_fn, old_fn, c0, c1, c2, c3, True, dict(g['params']), search=search,
+                               ctx=OracleContext(), genomes_per_round=1)
+    else:
+        mapbsn.get_map_bsn(os.path.join(tmp, 'm'), 'CL', genomes, bsn_fn, old_fn, None, None, None, None, True, dict(g['params']), search=search,
+                           ctx=OracleContext(), genomes_per_round=1)
+    out_q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_get_map_bsn_sharded_over_two_ranks(tmp_path):
+    """genomes dealt to two gloo ranks (PEPPAN.py:907-989 with one process per GPU instead of one forked worker per genome): rank 0's
+    stores are exactly the single-process stores of golden G15, and each rank searched only its own genomes"""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from conftest import load_golden
+    from peppan_amd import mapbsn
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_map_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == [0, 2] and got[1] == [1]
+    want = load_golden('g15_getmapbsn.json')['stores']['saveSeq_1']
+
+    def plain(x):
+        if isinstance(x, np.ndarray):
+            return [plain(v) for v in x.tolist()]
+        if isinstance(x, (list, tuple)):
+            return [plain(v) for v in x]
+        if isinstance(x, (np.integer,)):
+            return int(x)
+        if isinstance(x, (np.floating,)):
+            return float(x)
+        return x
+    for x in ('tab', 'seq', 'mat', 'conflicts'):
+        with mapbsn.MapBsn(str(tmp_path / ('mm.%s.npz' % x))) as c:
+            assert {k: plain(c.get(k)) for k in sorted(c.keys())} == want[x], x
