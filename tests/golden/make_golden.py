@@ -30,6 +30,7 @@ Fixture index:
   g13_readers.json       readFasta / readFastq / uopen  (configure.py:90-150, clust.py:7-18)
   g14_mapbsn.json        iter_map_bsn / compare_prediction / decodeSeq (PEPPAN.py:318-324, 759-905)
   g15_getmapbsn.json     get_map_bsn -> MapBsn stores   (PEPPAN.py:27-114, 907-989)
+  g16_real.json (+ g16_real_genes.fa.gz, g16_real_contig.fa.gz)  real genes of the reference's examples/ through its own front end
 """
 import json, os, sys, stat, tempfile, shutil, io, contextlib, copy
 
@@ -1079,6 +1080,39 @@ def g14_g15():
     os.chdir(HERE)
 
 
+# ----------------------------------------------------------------------------- G16 real genes (the reference's examples/)
+def g16_real():
+    """the first ~450 kb of the main chromosome of the four example genomes through the reference's own front end
+    (iter_readGFF, checkPseu, writeGenes; PEPPAN.py:117-182, 989-1010, 1023-1039): real gene sequences, their sha1 codes,
+    priorities, the reference's duplicate groups and unique-gene order - data for the K13 / search / clustering tests"""
+    import gzip, glob
+    PEP.params = dict(min_cds=120, incompleteCDS='')
+    genes, priority, contig_piece = {}, {}, None
+    gid = 0
+    for rank, fn in enumerate(sorted(glob.glob(os.path.join(REF, 'examples', '*.gff.gz')))):
+        seq, cds = PEP.iter_readGFF((fn, 'CDS', 11))
+        main = max(seq, key=lambda n: len(seq[n][1]))
+        if contig_piece is None:
+            contig_piece = seq[main][1][:300000]
+        picked = sorted((c[2], n) for n, c in cds.items() if c[1] == main and c[3] < 450000 and len(c[6]))
+        for start, n in picked:
+            c = cds[n]
+            genes[gid] = [os.path.basename(fn), c[1], c[2], c[3], c[4], c[5], c[6]]
+            priority[gid] = [rank // 2, -len(c[6]), c[5]]          # two priority classes of two genomes each
+            gid += 1
+    d = fake_dir()
+    fn, groups = PEP.writeGenes(os.path.join(d, 'real.genes'), genes, priority)
+    unique_order = [int(l[1:]) for l in open(fn) if l.startswith('>')]
+    with gzip.open(os.path.join(HERE, 'g16_real_genes.fa.gz'), 'wt') as f:
+        for g, v in genes.items():
+            f.write('>%d\n%s\n' % (g, v[6]))
+    with gzip.open(os.path.join(HERE, 'g16_real_contig.fa.gz'), 'wt') as f:
+        f.write('>900001\n%s\n' % contig_piece)
+    dump('g16_real.json', dict(n_genes=len(genes), hash={g: str(v[5]) for g, v in genes.items()}, priority={g: [p[0], p[1], str(p[2])] for g, p in priority.items()},
+                               meta={g: v[:5] for g, v in genes.items()}, groups=groups, unique_order=unique_order))
+    print('g16: %d gene instances, %d unique, %d duplicate pairs' % (len(genes), len(unique_order), len(groups)))
+
+
 if __name__ == '__main__':
     g13()
     g01()
@@ -1091,4 +1125,5 @@ if __name__ == '__main__':
     g09()
     g10_g11_g12()
     g14_g15()
+    g16_real()
     shutil.rmtree(SHIM, ignore_errors=True)

@@ -1,5 +1,6 @@
 """GPU parity tests proper: every call goes through the C ABI (libpeppan_hip.so) and is compared
 bit-exactly with the CPU oracle on the same seeded inputs."""
+import os
 import numpy as np
 import pytest
 from conftest import load_golden
@@ -903,3 +904,65 @@ def test_search_parameter_fuzz(ctx, seed):
     b_h, b_c, b_st = ctx.search(q)
     assert len(a_h) > 500 and a_h.tobytes() == b_h.tobytes() and a_c.tobytes() == b_c.tobytes()
     assert a_st['cells'] == b_st['cells'] and a_st['tracebacks'] == b_st['tracebacks']
+
+
+def _real_fixture(tmp_path):
+    """golden G16: 1 644 real genes of the reference's examples/ and a 300 kb piece of one chromosome"""
+    import gzip
+    from conftest import load_golden
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    g = load_golden('g16_real.json')
+    seqs = {}
+    with gzip.open(os.path.join(here, 'g16_real_genes.fa.gz'), 'rt') as f:
+        for line in f:
+            if line.startswith('>'):
+                cur = int(line[1:])
+            else:
+                seqs[cur] = line.strip()
+    contig = ''.join(l.strip() for l in gzip.open(os.path.join(here, 'g16_real_contig.fa.gz'), 'rt') if not l.startswith('>'))
+    return g, seqs, contig
+
+
+def test_real_genes_on_the_gpu(ctx, tmp_path, monkeypatch):
+    """real sequences instead of synthetic ones (variable lengths, paralogs, low-complexity stretches): front end, clustering,
+    all-vs-all search and genome mapping on the GPU against the reference's golden values / the oracle-driven host code"""
+    import io, contextlib, hashlib
+    from peppan_amd import uberBlast as UB, pipeline as PL, clust as CL
+    from oracle import oracle as O
+    from oracle_context import OracleContext
+    monkeypatch.chdir(tmp_path)
+    g, seqs, contig = _real_fixture(tmp_path)
+    ids = sorted(seqs)
+    # K13 on real genes: sha1 codes and duplicate groups are the reference's
+    assert PL.gene_hashes([seqs[i] for i in ids], ctx=ctx) == [int(g['hash'][str(i)]) for i in ids]
+    genes = {i: ['f', '', 0, 0, '+', int(g['hash'][str(i)]), seqs[i]] for i in ids}
+    prio = {int(k): [v[0], v[1], int(v[2])] for k, v in g['priority'].items()}
+    fn, groups = PL.writeGenes('real.genes', genes, prio, ctx=ctx)
+    assert groups == g['groups'] and [int(l[1:]) for l in open(fn) if l.startswith('>')] == g['unique_order']
+    # clustering of the unique genes: GPU clusterer == oracle relation through the same round logic
+    def oracle_fn(fasta, identity, coverage, n_thread):
+        recs = CL.readFasta(fasta)
+        rep, _ = O.linclust([O.nt_codes(s) for _, s in recs], float(identity), float(coverage))
+        return [(recs[r][0], recs[i][0]) for i, r in enumerate(rep.tolist())]
+    out = {}
+    for tag, cfn in (('gpu', None), ('ora', oracle_fn)):
+        with contextlib.redirect_stderr(io.StringIO()):
+            ex = PL.iterClust(tag, 'real.genes', [[0, 999999, 10000]], dict(identity=0.9, coverage=0.8, n_thread=1, translate=False, cluster_fn=cfn))
+        out[tag] = (open(ex).read(), open(tag + '.clust.tab').read(), np.load(tag + '.clust.npy').tolist())
+    assert out['gpu'] == out['ora']
+    n_ex = out['gpu'][0].count('>')
+    assert 300 < n_ex < 1301                          # the four genomes share most genes: alleles collapse onto exemplars
+    # all-vs-all of the exemplars and mapping onto the chromosome piece: whole tables, GPU vs the same host code over the oracle
+    with open('genome.fa', 'w') as f:
+        f.write('>900001\n%s\n' % contig)
+    self_argv = '-r gpu.clust.exemplar -q gpu.clust.exemplar --blastn --diamond -s 1 --min_id 0.45 --min_cov 50 -t 2 --min_ratio 0.25 -e 3,3 -p --gtable 11'.split()
+    map_argv = '-r genome.fa -q gpu.clust.exemplar -f -m -O --blastn --diamond --min_id 0.55 --min_cov 50 --min_ratio 0.25 --merge_gap 600 --merge_diff 1.5 -t 1 -s 1 -e 0,3 --gtable 11'.split()
+    with contextlib.redirect_stderr(io.StringIO()):
+        gpu_self = UB.uberBlast(self_argv)
+        gpu_map, gpu_ovl = UB.uberBlast(map_argv)
+        octx = OracleContext()
+        monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
+        ora_self = UB.uberBlast(self_argv)
+        ora_map, ora_ovl = UB.uberBlast(map_argv)
+    assert gpu_self.shape[0] > n_ex and gpu_self.tolist() == ora_self.tolist()
+    assert gpu_map.shape[0] > 150 and gpu_map.tolist() == ora_map.tolist() and gpu_ovl.tolist() == ora_ovl.tolist()

@@ -118,3 +118,31 @@ def test_writegenes(tmp_path):
     # run semantics of the duplicate table: equal digests collapse only while the length stays the same
     d = O.sha1_digests(['A', 'A', 'CC', 'A', 'A', 'CC', 'CC'])
     assert O.dedup([1, 1, 2, 1, 1, 2, 2], d).tolist() == [0, 0, 2, 3, 3, 5, 5]
+
+
+def _real_genes():
+    import gzip
+    g = load_golden('g16_real.json')
+    seqs = {}
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g16_real_genes.fa.gz'), 'rt') as f:
+        for line in f:
+            if line.startswith('>'):
+                cur = int(line[1:])
+            else:
+                seqs[cur] = line.strip()
+    genes = {int(k): ['f', '', 0, 0, '+', int(g['hash'][k]), seqs[int(k)]] for k in g['hash']}
+    prio = {int(k): [v[0], v[1], int(v[2])] for k, v in g['priority'].items()}
+    return g, genes, prio
+
+
+def test_real_genes_front_end(tmp_path):
+    """1 644 real genes of the reference's examples/ (4 E. coli genomes) through writeGenes / gene_hashes: the duplicate groups, the
+    order of the unique genes and every sha1 code are the ones the reference's own front end produced (golden G16)"""
+    from oracle_context import OracleContext
+    g, genes, prio = _real_genes()
+    assert len(genes) == g['n_genes'] == 1644
+    ids = sorted(genes)
+    assert PL.gene_hashes([genes[i][6] for i in ids], ctx=OracleContext()) == [genes[i][5] for i in ids]
+    fn, groups = PL.writeGenes(str(tmp_path / 'real.genes'), genes, prio, ctx=OracleContext())
+    assert groups == g['groups'] and len(groups) == 343
+    assert [int(l[1:]) for l in open(fn) if l.startswith('>')] == g['unique_order']
