@@ -199,25 +199,38 @@ __device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *s
     __builtin_memcpy(tl, a.t_res + tp - 48, 48);
     int s = 0, br = 0, bl = 0;
     bool live = true, pass = false;
+    // Straight-line predicated code costs its full length as long as ONE lane of the wave is still extending; most extensions
+    // end within a dozen residues (x-drop on a chance hit, threshold reached on a true one), so the wave checks every 8
+    // residues whether anybody is left and skips the rest of the window otherwise.
 #pragma unroll
-    for (int k = 0; k < 48; ++k) {
-        if (live && k < a.ext_right) {
-            const int qc = (qr[k >> 2] >> ((k & 3) * 8)) & 31, tc = (tr[k >> 2] >> ((k & 3) * 8)) & 31;
-            s += sub[qc * 32 + tc];
-            if (s > br) { br = s; if (br >= a.ungapped_min) { pass = true; live = false; } }
-            else if (br - s > a.xdrop) live = false;
+    for (int blk8 = 0; blk8 < 6; ++blk8) {
+        if (__ballot(live && blk8 * 8 < a.ext_right)) {
+#pragma unroll
+            for (int k = blk8 * 8; k < blk8 * 8 + 8; ++k) {
+                if (live && k < a.ext_right) {
+                    const int qc = (qr[k >> 2] >> ((k & 3) * 8)) & 31, tc = (tr[k >> 2] >> ((k & 3) * 8)) & 31;
+                    s += sub[qc * 32 + tc];
+                    if (s > br) { br = s; if (br >= a.ungapped_min) { pass = true; live = false; } }
+                    else if (br - s > a.xdrop) live = false;
+                }
+            }
         }
     }
     if (pass) return true;
     s = 0; live = true;
 #pragma unroll
-    for (int k = 1; k <= 48; ++k) {
-        if (live && k <= a.ext_left) {
-            const int b = 48 - k;                    // byte index inside the left window
-            const int qc = (ql[b >> 2] >> ((b & 3) * 8)) & 31, tc = (tl[b >> 2] >> ((b & 3) * 8)) & 31;
-            s += sub[qc * 32 + tc];
-            if (s > bl) { bl = s; if (br + bl >= a.ungapped_min) { pass = true; live = false; } }
-            else if (bl - s > a.xdrop) live = false;
+    for (int blk8 = 0; blk8 < 6; ++blk8) {
+        if (__ballot(live && blk8 * 8 + 1 <= a.ext_left)) {
+#pragma unroll
+            for (int k = blk8 * 8 + 1; k <= blk8 * 8 + 8; ++k) {
+                if (live && k <= a.ext_left) {
+                    const int b = 48 - k;                    // byte index inside the left window
+                    const int qc = (ql[b >> 2] >> ((b & 3) * 8)) & 31, tc = (tl[b >> 2] >> ((b & 3) * 8)) & 31;
+                    s += sub[qc * 32 + tc];
+                    if (s > bl) { bl = s; if (br + bl >= a.ungapped_min) { pass = true; live = false; } }
+                    else if (bl - s > a.xdrop) live = false;
+                }
+            }
         }
     }
     return pass;
@@ -310,19 +323,24 @@ __global__ __launch_bounds__(256) void seed_extend(JoinArgs a)
     uint32_t n_pass = 0;
     const int lane = threadIdx.x & 63;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t h0 = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63); h0 < n_hits; h0 += stride) {      // wave-uniform trip count
+    const uint64_t h_first = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63);
+    // the hit of the NEXT round is requested after this round's look-ups have been issued, so that it travels while the set
+    // probe / extension of this round is under way (loads return in order: requested earlier it would only delay them)
+    uint64_t hit_next = h_first + lane < n_hits ? a.hits[h_first + lane] : 0ull;
+    for (uint64_t h0 = h_first; h0 < n_hits; h0 += stride) {      // wave-uniform trip count
         const uint64_t h = h0 + lane;
         const bool valid = h < n_hits;
         uint64_t ck = ~0ull;
         uint32_t qp = 0, p = 0;
+        const uint64_t hit = hit_next;
         if (valid) {
-            const uint64_t hit = a.hits[h];
             qp = (uint32_t)(hit >> 32); p = (uint32_t)hit;
             const uint32_t t = a.t_blk2seq[p >> 4], q = a.q_blk2seq[qp >> 4];
             const int32_t diag = (int32_t)(p - a.t_off[t]) - (int32_t)(qp - a.q_off[q]);
             const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
             ck = ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)bin;
         }
+        hit_next = h + stride < n_hits ? a.hits[h + stride] : 0ull;
         // Neighbouring hits of the buffer usually come from neighbouring positions of one diagonal, i.e. the same candidate.
         // The first lane of every run of equal keys decides; the rest of the run is done if that lane's hit nominated the
         // candidate, and only has to look for itself if it did not (a candidate needs ONE passing hit).
