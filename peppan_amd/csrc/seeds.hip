@@ -308,62 +308,94 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
     if (threadIdx.x < 2 && blk_stats[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)blk_stats[threadIdx.x]);
 }
 
-// Phase 2: one thread per raw seed hit, fully converged.  (q, t, diagonal bin) from the block->sequence maps;
-// a candidate already in the set needs nothing more; otherwise the ungapped x-drop extension decides, and the
-// first passer inserts the key.  The set is order-independent, so the result does not depend on scheduling.
-__global__ __launch_bounds__(256) void seed_extend(JoinArgs a)
+// Phase 2a: one thread per raw seed hit, fully converged.  (q, t, diagonal bin) from the block->sequence maps.  Neighbouring hits
+// of the buffer usually come from neighbouring positions of one diagonal, i.e. they nominate the same candidate: every run of
+// equal candidate keys inside a wavefront becomes ONE work item (first hit, length, key) unless the candidate is in the set already.
+// No extension here: in the first version the extension code ran in this loop with one to three active lanes per wavefront
+// (the leaders of new runs) and cost its full instruction stream each time - 0.27 ms per shape, 53 % scalar-unit utilisation.
+constexpr int RUN_BUF = 1024;
+__global__ __launch_bounds__(256) void seed_runs(JoinArgs a, uint64_t *__restrict__ run_first, uint32_t *__restrict__ run_len, uint64_t *__restrict__ run_key,
+                                                 unsigned long long *__restrict__ n_runs)
+{
+    // work items are staged in LDS and appended with ONE global atomic per flush: a single counter word sustains only ~90
+    // atomics/us, and one atomic per wavefront and round (90 k per launch) made this kernel take a millisecond
+    __shared__ uint64_t s_first[RUN_BUF], s_key[RUN_BUF];
+    __shared__ uint32_t s_len[RUN_BUF];
+    __shared__ uint32_t s_n;
+    __shared__ unsigned long long s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    unsigned long long n_hits = *a.hit_count;
+    if (n_hits > a.hit_cap) n_hits = a.hit_cap;
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t b0 = (uint64_t)blockIdx.x * 256; b0 < n_hits; b0 += stride) {      // block-uniform trip count
+        const uint64_t h = b0 + threadIdx.x;
+        const bool valid = h < n_hits;
+        uint64_t ck = ~0ull;
+        if (valid) {
+            const uint64_t hit = a.hits[h];
+            const uint32_t qp = (uint32_t)(hit >> 32), p = (uint32_t)hit;
+            const uint32_t t = a.t_blk2seq[p >> 4], q = a.q_blk2seq[qp >> 4];
+            const int32_t diag = (int32_t)(p - a.t_off[t]) - (int32_t)(qp - a.q_off[q]);
+            const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
+            ck = ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)bin;
+        }
+        const uint32_t lo = (uint32_t)ck, hi = (uint32_t)(ck >> 32);
+        const uint32_t lo_prev = __shfl_up(lo, 1, 64), hi_prev = __shfl_up(hi, 1, 64);     // unconditional: every lane must take part in the shuffles
+        const bool leader = valid && !(a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi);
+        const unsigned long long leaders = __ballot(leader);
+        const unsigned long long valid_m = __ballot(valid);
+        const bool emit_run = leader && !set_contains(a, ck);              // (a candidate of an earlier shape / launch)
+        const unsigned long long emit_m = __ballot(emit_run);
+        uint32_t off = 0;
+        if (lane == 0 && emit_m) off = atomicAdd(&s_n, (uint32_t)__popcll(emit_m));
+        off = (uint32_t)__shfl((int)off, 0, 64);
+        if (emit_run) {
+            const unsigned long long above = lane == 63 ? 0ull : (leaders & (~0ull << (lane + 1)));      // next run starts at its lowest set bit
+            const int next = above ? __builtin_ctzll(above) : __popcll(valid_m);                          // valid lanes are a prefix
+            const uint32_t slot = off + (uint32_t)__popcll(emit_m & ((1ull << lane) - 1ull));           // < RUN_BUF: flushed above RUN_BUF / 2, <= 256 per round
+            s_first[slot] = h; s_len[slot] = (uint32_t)(next - lane); s_key[slot] = ck;
+        }
+        __syncthreads();
+        const uint32_t cnt = s_n;                    // block-uniform after the barrier
+        if (cnt > RUN_BUF / 2 || b0 + stride >= n_hits) {
+            if (threadIdx.x == 0) s_base = cnt ? atomicAdd(n_runs, (unsigned long long)cnt) : 0ull;
+            __syncthreads();
+            const unsigned long long g = s_base;
+            for (uint32_t x = threadIdx.x; x < cnt; x += 256) { run_first[g + x] = s_first[x]; run_len[g + x] = s_len[x]; run_key[g + x] = s_key[x]; }
+            __syncthreads();
+            if (threadIdx.x == 0) s_n = 0;
+            __syncthreads();
+        }
+    }
+}
+
+// Phase 2b: one thread per run, every lane busy with a different candidate.  A candidate needs ONE hit whose ungapped x-drop
+// extension reaches the threshold: the hits of the run are tried in order until one passes (true homologues pass at the first or
+// second, chance runs are one or two hits long); the first passer inserts the key.  The set is order-independent, so the result
+// does not depend on scheduling.
+__global__ __launch_bounds__(256) void seed_extend(JoinArgs a, const uint64_t *__restrict__ run_first, const uint32_t *__restrict__ run_len,
+                                                   const uint64_t *__restrict__ run_key, const unsigned long long *__restrict__ n_runs)
 {
     __shared__ int8_t sub[1024];
     __shared__ uint32_t blk_pass;
     reinterpret_cast<uint32_t *>(sub)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.sub)[threadIdx.x];
     if (threadIdx.x == 0) blk_pass = 0;
     __syncthreads();
-    unsigned long long n_hits = *a.hit_count;
-    if (n_hits > a.hit_cap) n_hits = a.hit_cap;
+    const unsigned long long n = *n_runs;
     uint32_t n_pass = 0;
-    const int lane = threadIdx.x & 63;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    const uint64_t h_first = (uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63);
-    // the hit of the NEXT round is requested after this round's look-ups have been issued, so that it travels while the set
-    // probe / extension of this round is under way (loads return in order: requested earlier it would only delay them)
-    uint64_t hit_next = h_first + lane < n_hits ? a.hits[h_first + lane] : 0ull;
-    for (uint64_t h0 = h_first; h0 < n_hits; h0 += stride) {      // wave-uniform trip count
-        const uint64_t h = h0 + lane;
-        const bool valid = h < n_hits;
-        uint64_t ck = ~0ull;
-        uint32_t qp = 0, p = 0;
-        const uint64_t hit = hit_next;
-        if (valid) {
-            qp = (uint32_t)(hit >> 32); p = (uint32_t)hit;
-            const uint32_t t = a.t_blk2seq[p >> 4], q = a.q_blk2seq[qp >> 4];
-            const int32_t diag = (int32_t)(p - a.t_off[t]) - (int32_t)(qp - a.q_off[q]);
-            const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
-            ck = ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)bin;
+    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (uint64_t)gridDim.x * 256) {
+        const uint64_t ck = run_key[r];
+        if (set_contains(a, ck)) { ++n_pass; continue; }
+        const uint64_t first = run_first[r];
+        const uint32_t len = run_len[r];
+        bool pass = a.ungapped_min <= 0;
+        for (uint32_t x = 0; x < len && !pass; ++x) {
+            const uint64_t hit = a.hits[first + x];
+            pass = ungapped_pass(a, sub, (uint32_t)(hit >> 32), (uint32_t)hit);
         }
-        hit_next = h + stride < n_hits ? a.hits[h + stride] : 0ull;
-        // Neighbouring hits of the buffer usually come from neighbouring positions of one diagonal, i.e. the same candidate.
-        // The first lane of every run of equal keys decides; the rest of the run is done if that lane's hit nominated the
-        // candidate, and only has to look for itself if it did not (a candidate needs ONE passing hit).
-        const uint32_t lo = (uint32_t)ck, hi = (uint32_t)(ck >> 32);
-        const uint32_t lo_prev = __shfl_up(lo, 1, 64), hi_prev = __shfl_up(hi, 1, 64);     // unconditional: every lane must take part in the shuffles
-        const bool follower = a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi;
-        const unsigned long long leaders = __ballot(valid && !follower);
-        bool pass = false;
-        if (valid && !follower) {
-            pass = set_contains(a, ck);
-            if (!pass && (a.ungapped_min <= 0 || ungapped_pass(a, sub, qp, p))) { pass = true; set_insert(a, ck); }
-        }
-        const unsigned long long passed = __ballot(pass);
-        if (valid && follower) {
-            const unsigned long long below = leaders & ((2ull << lane) - 1ull);          // leaders at or below this lane: never empty
-            const int lead = 63 - __builtin_clzll(below);
-            pass = (passed >> lead) & 1ull;
-            if (!pass) {
-                pass = set_contains(a, ck);
-                if (!pass && (a.ungapped_min <= 0 || ungapped_pass(a, sub, qp, p))) { pass = true; set_insert(a, ck); }
-            }
-        }
-        n_pass += pass ? 1u : 0u;
+        if (pass) { ++n_pass; set_insert(a, ck); }
     }
     for (int d = 32; d > 0; d >>= 1) n_pass += __shfl_down(n_pass, d, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&blk_pass, n_pass);
@@ -414,7 +446,7 @@ int ilog2_ceil(uint64_t x)
 }  // namespace
 
 // workspace slots used here: ws[0] cnt, ws[1] start, ws[2] entries, ws[3] table, ws[4] list, ws[5] list tmp (sort),
-// ws[6] counters+stats, ws[7] scan scratch, ws[8] raw seed hits (the sort histogram reuses ws[0])
+// ws[6] counters+stats, ws[7] scan scratch, ws[8] raw seed hits, ws[10..12] runs of hits (the sort histogram reuses ws[0])
 int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
 {
     const pep_search_params &P = ctx->params;
@@ -446,6 +478,12 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(counters + 12);
     for (int attempt = 0; attempt < 8; ++attempt) {
         PEP_TRY(dev_reserve(ctx, ctx->ws[8], hit_cap * sizeof(uint64_t)));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[10], hit_cap * 8));          // runs of equal candidate keys: first hit, key, length
+        PEP_TRY(dev_reserve(ctx, ctx->ws[11], hit_cap * 8));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[12], hit_cap * 4 + 64));
+        uint64_t *run_first = ctx->ws[10].as<uint64_t>(), *run_key = ctx->ws[11].as<uint64_t>();
+        uint32_t *run_len = ctx->ws[12].as<uint32_t>();
+        unsigned long long *n_runs = reinterpret_cast<unsigned long long *>(counters + 14);
         const uint64_t cap = 1ull << table_bits;
         const uint32_t list_cap = (uint32_t)(cap >> 1);
         PEP_TRY(dev_reserve(ctx, ctx->ws[3], cap * sizeof(uint64_t)));
@@ -495,7 +533,10 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
             PEP_HIP(ctx, hipMemsetAsync(hit_count, 0, 8, ctx->stream));
             PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 5u)), sh, a);
-            hipLaunchKernelGGL(seed_extend, dim3(256u * 8u), dim3(256), 0, ctx->stream, a);
+            PEP_HIP(ctx, hipMemsetAsync(n_runs, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(seed_runs, dim3(256u * 8u), dim3(256), 0, ctx->stream, a, run_first, run_len, run_key, n_runs);
+            hipLaunchKernelGGL(seed_extend, dim3(256u * 4u), dim3(256), 0, ctx->stream, a, (const uint64_t *)run_first, (const uint32_t *)run_len,
+                               (const uint64_t *)run_key, (const unsigned long long *)n_runs);
             PEP_HIP(ctx, hipGetLastError());
             PEP_TRY(pep_read_back(ctx, &h_nseed[s], start + n_buckets, sizeof(uint32_t)));
         }
