@@ -436,6 +436,25 @@ __global__ __launch_bounds__(256) void set_compact(const uint64_t *__restrict__ 
         if (k[r] != EMPTY) { if (idx < list_cap) list[idx] = k[r]; else counters[1] = 1u; ++idx; }
 }
 
+// candidate keys q:21 | t:25 | bin:18 <-> the dense form q | t | bin - bin_min with only as many bits per field as this search
+// needs: the radix sort then runs over ~36 instead of 64 bits (each of its 8-bit passes is five small launches)
+__global__ __launch_bounds__(256) void keys_pack(uint64_t *__restrict__ keys, const uint32_t *__restrict__ n_ptr, int tb, int bb, uint32_t bin_min)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const uint64_t k = keys[i];
+    const uint64_t q = k >> 43, t = (k >> 18) & ((1u << 25) - 1), bin = (k & ((1u << 18) - 1)) - bin_min;
+    keys[i] = (q << (tb + bb)) | (t << bb) | bin;
+}
+__global__ __launch_bounds__(256) void keys_unpack(uint64_t *__restrict__ keys, uint64_t n, int tb, int bb, uint32_t bin_min)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    const uint64_t q = k >> (tb + bb), t = (k >> bb) & ((1ull << tb) - 1), bin = (k & ((1ull << bb) - 1)) + bin_min;
+    keys[i] = (q << 43) | (t << 18) | bin;
+}
+
 int ilog2_ceil(uint64_t x)
 {
     int b = 0;
@@ -540,6 +559,10 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             PEP_HIP(ctx, hipGetLastError());
             PEP_TRY(pep_read_back(ctx, &h_nseed[s], start + n_buckets, sizeof(uint32_t)));
         }
+        // field widths of the dense key form (see keys_pack)
+        const uint32_t bin_min = (uint32_t)(((1 << 23) - (int)std::max<uint32_t>(Q.max_len, 1u) + 1) >> 6);
+        const uint32_t bin_max = (uint32_t)(((1 << 23) + (int)std::max<uint32_t>(T.max_len, 1u) - 1) >> 6);
+        const int tb = std::max(1, ilog2_ceil(T.n)), qb = std::max(1, ilog2_ceil(Q.n)), bb = std::max(1, ilog2_ceil((uint64_t)bin_max - bin_min + 1));
         hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256 * COMPACT_ROUNDS)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ws[3].as<uint64_t>(), cap,
                            ctx->ws[4].as<uint64_t>(), list_cap, counters);
         uint32_t h_counters[4];
@@ -555,7 +578,11 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         ctx->stats.seed_hits = h_stats[1];
         ctx->stats.seed_hits_passed = h_stats[2];
         const uint64_t n = h_counters[0];
-        PEP_TRY(pep_sort_u64(ctx, ctx->ws[4].as<uint64_t>(), ctx->ws[5].as<uint64_t>(), n, 64, ctx->ws[0]));
+        if (n) {
+            hipLaunchKernelGGL(keys_pack, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[4].as<uint64_t>(), (const uint32_t *)counters, tb, bb, bin_min);
+            PEP_TRY(pep_sort_u64(ctx, ctx->ws[4].as<uint64_t>(), ctx->ws[5].as<uint64_t>(), n, qb + tb + bb, ctx->ws[0]));
+            hipLaunchKernelGGL(keys_unpack, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[4].as<uint64_t>(), n, tb, bb, bin_min);
+        }
         *d_cands = ctx->ws[4].as<uint64_t>();
         *n_cands = n;
         return PEP_OK;

@@ -81,7 +81,7 @@ int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, in
     uint64_t *src = d_keys, *dst = d_tmp;
     for (int p = 0; p < passes; ++p) {
         const int shift = p * 8;
-        if (shift >= 64) {                  // padding pass beyond the key width: plain copy
+        if (shift >= bits || shift >= 64) {  // padding pass beyond the key width (keeps the pass count even): plain copy
             PEP_HIP(ctx, hipMemcpyAsync(dst, src, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
         } else {
             hipLaunchKernelGGL(sort_hist, dim3(nb), dim3(ST), 0, ctx->stream, (const uint64_t *)src, hist.as<uint32_t>(), n, shift, nb);
