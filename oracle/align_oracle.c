@@ -522,7 +522,7 @@ int oracle_search(const oracle_params *p,
             h.cigar_off += ncig;
             hits[nh++] = h;
         }
-        memcpy(cig + ncig, res[k].cig, res[k].ncig * sizeof(uint32_t));
+        if (res[k].ncig) memcpy(cig + ncig, res[k].cig, res[k].ncig * sizeof(uint32_t));
         ncig += res[k].ncig;
         cells_all += res[k].cells; traced += res[k].traced;
         free(res[k].hits); free(res[k].cig);
