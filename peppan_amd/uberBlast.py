@@ -13,7 +13,6 @@ string-keyed sort exactly as the reference does.  There is no CPU fallback: with
 the tools raise.
 """
 import os
-import re
 import sys
 
 import numpy as np
