@@ -478,10 +478,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_kernel(SwArgs a)  
 // per candidate: number of 8-step blocks and the exact count of in-band in-matrix cells
 __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cands, uint64_t n, const uint32_t *__restrict__ q_len,
                                                const uint32_t *__restrict__ t_len, uint32_t *__restrict__ nblk, uint64_t *__restrict__ nblk64,
-                                               unsigned long long *__restrict__ cells_total)
+                                               unsigned long long *__restrict__ cells_total)           // [0] cells, [1] 16-step blocks
 {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned long long cells = 0;
+    unsigned long long cells = 0, blocks = 0;
     if (c < n) {
         const uint64_t key = cands[c];
         const uint32_t q = (uint32_t)(key >> 43), t = (uint32_t)((key >> 18) & ((1u << 25) - 1));
@@ -501,9 +501,11 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
         const uint32_t nb = (uint32_t)((steps + 15) / 16);
         nblk[c] = nb;
         nblk64[c] = nb;
+        blocks = nb;
     }
-    for (int d = 32; d > 0; d >>= 1) cells += __shfl_down(cells, d, 64);
-    if ((threadIdx.x & 63) == 0 && cells) atomicAdd(cells_total, cells);
+    for (int d = 32; d > 0; d >>= 1) { cells += __shfl_down(cells, d, 64); blocks += __shfl_down(blocks, d, 64); }
+    if ((threadIdx.x & 63) == 0 && cells) atomicAdd(&cells_total[0], cells);
+    if ((threadIdx.x & 63) == 0 && blocks) atomicAdd(&cells_total[1], blocks);
 }
 
 __global__ void dpp_probe(int *out)
@@ -542,18 +544,20 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     PEP_TRY(dev_reserve(ctx, ctx->ws[12], (n + 1) * sizeof(int4)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[15], 64));
     unsigned long long *cells = ctx->ws[15].as<unsigned long long>();
-    PEP_HIP(ctx, hipMemsetAsync(cells, 0, 8, ctx->stream));
+    PEP_HIP(ctx, hipMemsetAsync(cells, 0, 16, ctx->stream));
     hipLaunchKernelGGL(sw_prep, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_cands, n, ctx->q.len.as<const uint32_t>(),
                        ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells);
-    PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
     uint64_t total_blk = 0;
     unsigned long long h_cells = 0;
-    PEP_TRY(pep_read_back(ctx, &total_blk, ctx->ws[11].as<uint64_t>() + n, 8));
     PEP_TRY(pep_read_back(ctx, &h_cells, cells, 8));
-    PEP_TRY(pep_sync_reads(ctx));
-    if (trace) ctx->stats.cells_trace += h_cells; else ctx->stats.cells += h_cells;
-    if (trace) ctx->stats.cells_swept_trace += total_blk * 16 * 64; else ctx->stats.cells_swept += total_blk * 16 * 64;
+    PEP_TRY(pep_read_back(ctx, &total_blk, cells + 1, 8));
     if (trace) {
+        // the traceback area is sized from the block total, so the host has to see it before the launch; the score pass needs neither
+        // the per-candidate offsets nor the totals up front (they are folded into the statistics after the kernel)
+        PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
+        PEP_TRY(pep_sync_reads(ctx));
+        ctx->stats.cells_trace += h_cells;
+        ctx->stats.cells_swept_trace += total_blk * 16 * 64;
         ctx->stats.dir_bytes += total_blk * 512;
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 512 + 512));
     }
@@ -583,6 +587,11 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     PEP_HIP(ctx, hipGetLastError());
     *ms_kernel = timer.stop();
     PEP_HIP(ctx, hipGetLastError());
+    if (!trace) {
+        PEP_TRY(pep_sync_reads(ctx));             // the stream is idle here: this only stores the values queued before the launch
+        ctx->stats.cells += h_cells;
+        ctx->stats.cells_swept += total_blk * 16 * 64;
+    }
     ctx->stats.sw_launches += 1;
     return PEP_OK;
 }
