@@ -120,6 +120,120 @@ __global__ __launch_bounds__(256) void seed_fill(SeedShape sh, const uint8_t *__
     }
 }
 
+// ---- query index by partition (the default build): instead of one memory-side atomic per seed in a count pass and another in a
+// fill pass (bound by the ~27 G/s such atomics sustain), the seeds are first split into 2^C coarse buckets with LDS counters
+// (one [coarse][block] histogram, scanned once), then every coarse bucket - a few thousand entries - is bucket-sorted by its 2^F
+// fine buckets inside LDS by one block, which also writes its slice of start[] and of the occupancy bitmap.
+// bucket = coarse << F | fine, C + F = bucket_bits.  A coarse bucket that does not fit LDS (pathologically repetitive input) raises
+// a flag and the host rebuilds with the count -> scan -> fill kernels.
+constexpr int PART_TILES = 16;                 // 256-position tiles per block in the two partition passes
+constexpr int PART_CAP = 5632;                 // entries of one coarse bucket that fit LDS next to 4096 fine counters
+
+template <int W>
+__global__ __launch_bounds__(256) void idx_hist(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, int bucket_bits, int fine_bits,
+                                                uint32_t *__restrict__ hist, uint32_t n_blocks)
+{
+    extern __shared__ uint32_t part_lds[];
+    uint32_t *h = part_lds;                                  // 2^C counters
+    uint8_t *red = reinterpret_cast<uint8_t *>(h + (1u << (bucket_bits - fine_bits)));
+    const uint32_t n_coarse = 1u << (bucket_bits - fine_bits);
+    for (uint32_t x = threadIdx.x; x < n_coarse; x += 256) h[x] = 0;
+    for (int t = 0; t < PART_TILES; ++t) {
+        const uint64_t base = ((uint64_t)blockIdx.x * PART_TILES + t) * TILE;
+        __syncthreads();
+        if (base >= total) break;                           // block-uniform
+        stage_reduced(sh, res, base, total, red);
+        __syncthreads();
+        const uint64_t p = base + threadIdx.x;
+        uint64_t key;
+        if (p + 32 <= total && tile_key<W>(sh, red, threadIdx.x, key)) atomicAdd(&h[hash_u64(key, bucket_bits) >> fine_bits], 1u);
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < n_coarse; x += 256) hist[(uint64_t)x * n_blocks + blockIdx.x] = h[x];
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void idx_scatter(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, int bucket_bits, int fine_bits,
+                                                   const uint32_t *__restrict__ hist_scan, uint32_t n_blocks, uint64_t *__restrict__ part)
+{
+    extern __shared__ uint32_t part_lds[];
+    uint32_t *at = part_lds;                                 // running write position of every coarse bucket for this block
+    const uint32_t n_coarse = 1u << (bucket_bits - fine_bits);
+    uint8_t *red = reinterpret_cast<uint8_t *>(at + n_coarse);
+    for (uint32_t x = threadIdx.x; x < n_coarse; x += 256) at[x] = hist_scan[(uint64_t)x * n_blocks + blockIdx.x];
+    for (int t = 0; t < PART_TILES; ++t) {
+        const uint64_t base = ((uint64_t)blockIdx.x * PART_TILES + t) * TILE;
+        __syncthreads();
+        if (base >= total) break;
+        stage_reduced(sh, res, base, total, red);
+        __syncthreads();
+        const uint64_t p = base + threadIdx.x;
+        uint64_t key;
+        if (p + 32 <= total && tile_key<W>(sh, red, threadIdx.x, key)) {
+            const uint32_t slot = atomicAdd(&at[hash_u64(key, bucket_bits) >> fine_bits], 1u);
+            part[slot] = (key << POS_BITS) | p;
+        }
+    }
+}
+
+// one block per coarse bucket c: entries part[cbase .. cend) -> entries[] ordered by fine bucket, start[c << F .. (c + 1) << F), bitmap
+__global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ part, const uint32_t *__restrict__ hist_scan, uint32_t n_blocks, int bucket_bits,
+                                                  int fine_bits, uint32_t *__restrict__ start, uint64_t *__restrict__ entries,
+                                                  unsigned long long *__restrict__ occupied, uint32_t *__restrict__ counters)
+{
+    __shared__ uint32_t pos[4096];
+    __shared__ uint64_t ents[PART_CAP];
+    __shared__ uint32_t wave_sum[4];
+    const uint32_t c = blockIdx.x, n_coarse = 1u << (bucket_bits - fine_bits), n_fine = 1u << fine_bits;
+    const uint32_t lo = hist_scan[(uint64_t)c * n_blocks], hi = hist_scan[(uint64_t)(c + 1) * n_blocks];     // scan has n_coarse * n_blocks + 1 entries
+    const uint32_t n = hi - lo;
+    if (c == n_coarse - 1 && threadIdx.x == 0) start[(size_t)n_coarse << fine_bits] = hi;
+    if (n > PART_CAP) { if (threadIdx.x == 0) counters[3] = 1u; return; }                                       // host falls back to count -> scan -> fill
+    for (uint32_t x = threadIdx.x; x < n_fine; x += 256) pos[x] = 0;
+    __syncthreads();
+    const uint32_t fmask = n_fine - 1;
+    for (uint32_t x = threadIdx.x; x < n; x += 256) {
+        const uint64_t e = part[lo + x];
+        ents[x] = e;
+        atomicAdd(&pos[hash_u64(e >> POS_BITS, bucket_bits) & fmask], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the fine counters: thread t owns n_fine / 256 consecutive counters
+    const uint32_t per = n_fine / 256;                       // fine_bits >= 8
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < per; ++k) sum += pos[threadIdx.x * per + k];
+    uint32_t incl = sum;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63) wave_sum[wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wave_sum[w];
+    unsigned long long bits = 0;                             // occupancy of this thread's counters (per <= 16 of them)
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t f = threadIdx.x * per + k, cnt = pos[f];
+        pos[f] = run;
+        start[((size_t)c << fine_bits) + f] = lo + run;
+        bits |= (unsigned long long)(cnt != 0) << k;
+        run += cnt;
+    }
+    // bitmap: 64 buckets per word = 64 / per threads per word
+    {
+        const uint32_t first_bucket = threadIdx.x * per;
+        const int sh_in_word = (int)(first_bucket & 63u);
+        unsigned long long word = bits << sh_in_word;
+        const int group = 64 / (int)per;                     // threads that share one word (1 when per == 64... per <= 16 here: group >= 4)
+        for (int d = 1; d < group; d <<= 1) word |= ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)word, d, 64)) | ((unsigned long long)(uint32_t)__shfl_xor((int)(word >> 32), d, 64) << 32);
+        if ((threadIdx.x % group) == 0) occupied[(((size_t)c << fine_bits) + first_bucket) >> 6] = word;
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < n; x += 256) {
+        const uint64_t e = ents[x];
+        const uint32_t slot = atomicAdd(&pos[hash_u64(e >> POS_BITS, bucket_bits) & fmask], 1u);
+        entries[lo + slot] = e;
+    }
+}
+
 // bit b of `occupied` = bucket b of the query index holds at least one seed.  Two thirds of the target seeds hash to an empty
 // bucket; the bitmap answers that from L2 instead of a 64-byte line of start[] from the memory side.
 __global__ __launch_bounds__(256) void bucket_bitmap(const uint32_t *__restrict__ start, uint64_t n_buckets, unsigned long long *__restrict__ occupied)
@@ -495,6 +609,10 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     int table_bits = std::max(20, std::min(28, ilog2_ceil(64ull * Q.n)));
     uint64_t hit_cap = std::max<uint64_t>(1ull << 22, 2 * T.total);
     unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(counters + 12);
+    // query index build: by partition when the bucket count splits into <= 2^13 coarse x <= 2^12 fine buckets (reserved[2] != 0 forces the
+    // count -> scan -> fill build, as does a coarse bucket that overflows LDS)
+    const int fine_bits = std::min(12, bucket_bits - 8);
+    bool use_partition = P.reserved[2] == 0 && bucket_bits >= 16 && bucket_bits - fine_bits <= 13;
     for (int attempt = 0; attempt < 8; ++attempt) {
         PEP_TRY(dev_reserve(ctx, ctx->ws[8], hit_cap * sizeof(uint64_t)));
         PEP_TRY(dev_reserve(ctx, ctx->ws[10], hit_cap * 8));          // runs of equal candidate keys: first hit, key, length
@@ -529,7 +647,6 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             for (int i = 0, pl = 1, ph = 1; i < sh.weight; ++i) {
                 if (i < sh.h1) { sh.pw[i] = (uint32_t)pl; pl *= sh.base; } else { sh.pw[i] = (uint32_t)ph; ph *= sh.base; }
             }
-            PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
             const unsigned qb = (unsigned)ceil_div(Q.total, 256), tb = (unsigned)ceil_div(T.total, 256);
 #define PEP_SEED_DISPATCH(KERNEL, GRID, ...)                                                                          \
     do {                                                                                                              \
@@ -537,11 +654,32 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         else if (sh.weight == 17) hipLaunchKernelGGL(KERNEL<17>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);                             \
     } while (0)
-            PEP_SEED_DISPATCH(seed_count, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, cnt, bucket_bits);
-            PEP_TRY(pep_scan_u32(ctx, cnt, start, n_buckets, ctx->ws[7]));
-            PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
-            PEP_SEED_DISPATCH(seed_fill, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, (const uint32_t *)start, cnt, entries, bucket_bits);
-            hipLaunchKernelGGL(bucket_bitmap, dim3((unsigned)ceil_div(n_buckets, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)start, n_buckets, occupied);
+#define PEP_SEED_DISPATCH_LDS(KERNEL, GRID, LDS, ...)                                                                 \
+    do {                                                                                                              \
+        if (sh.weight == 10) hipLaunchKernelGGL(KERNEL<10>, GRID, dim3(256), LDS, ctx->stream, __VA_ARGS__);          \
+        else if (sh.weight == 17) hipLaunchKernelGGL(KERNEL<17>, GRID, dim3(256), LDS, ctx->stream, __VA_ARGS__);     \
+        else hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(256), LDS, ctx->stream, __VA_ARGS__);                           \
+    } while (0)
+            if (use_partition) {
+                // partition build: [coarse][block] histogram -> scan -> scatter into coarse buckets -> per-bucket LDS sort
+                const unsigned pb = (unsigned)ceil_div(Q.total, (uint64_t)PART_TILES * TILE);
+                const uint32_t n_coarse = 1u << (bucket_bits - fine_bits);
+                const size_t lds = (size_t)n_coarse * 4 + TILE + TILE_HALO;
+                PEP_TRY(dev_reserve(ctx, ctx->ws[13], (Q.total + 1) * sizeof(uint64_t)));
+                uint64_t *part = ctx->ws[13].as<uint64_t>();
+                PEP_SEED_DISPATCH_LDS(idx_hist, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, cnt, pb);
+                PEP_TRY(pep_scan_u32(ctx, cnt, cnt, (uint64_t)n_coarse * pb, ctx->ws[7]));
+                PEP_SEED_DISPATCH_LDS(idx_scatter, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, (const uint32_t *)cnt, pb, part);
+                hipLaunchKernelGGL(idx_finish, dim3(n_coarse), dim3(256), 0, ctx->stream, (const uint64_t *)part, (const uint32_t *)cnt, pb, bucket_bits, fine_bits,
+                                   start, entries, occupied, counters);
+            } else {
+                PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
+                PEP_SEED_DISPATCH(seed_count, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, cnt, bucket_bits);
+                PEP_TRY(pep_scan_u32(ctx, cnt, start, n_buckets, ctx->ws[7]));
+                PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
+                PEP_SEED_DISPATCH(seed_fill, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, (const uint32_t *)start, cnt, entries, bucket_bits);
+                hipLaunchKernelGGL(bucket_bitmap, dim3((unsigned)ceil_div(n_buckets, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)start, n_buckets, occupied);
+            }
             JoinArgs a;
             a.t_res = T.res.as<const uint8_t>(); a.t_total = T.total; a.t_off = T.off.as<const uint32_t>(); a.nt = T.n;
             a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint32_t>(); a.t_blk2seq = T.blk2seq.as<const uint32_t>(); a.start = start; a.entries = entries; a.occupied = occupied; a.bucket_bits = bucket_bits;
@@ -570,6 +708,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         PEP_TRY(pep_read_back(ctx, h_counters, counters, sizeof(h_counters)));
         PEP_TRY(pep_read_back(ctx, h_stats, stats, sizeof(h_stats)));
         PEP_TRY(pep_sync_reads(ctx));
+        if (h_counters[3]) { use_partition = false; continue; }       // a coarse index bucket did not fit LDS: rebuild the plain way
         if (h_counters[2]) { hit_cap *= 4; continue; }                // raw hit buffer too small: retry 4x larger
         if (h_counters[1] || h_counters[0] > list_cap) { table_bits += 2; continue; }     // set too small: retry 4x larger
         for (int s = 0; s < P.n_shapes; ++s) q_seeds += h_nseed[s];

@@ -966,3 +966,21 @@ def test_real_genes_on_the_gpu(ctx, tmp_path, monkeypatch):
         ora_map, ora_ovl = UB.uberBlast(map_argv)
     assert gpu_self.shape[0] > n_ex and gpu_self.tolist() == ora_self.tolist()
     assert gpu_map.shape[0] > 150 and gpu_map.tolist() == ora_map.tolist() and gpu_ovl.tolist() == ora_ovl.tolist()
+
+
+def test_query_index_partition_build_equals_plain_build(ctx):
+    """the query seed index built by partition (coarse buckets in LDS, per-bucket LDS sort) gives the same search as the count -> scan
+    -> fill build (params.reserved[2] = 1), also when a coarse bucket overflows LDS and the library falls back by itself"""
+    from peppan_amd import _native as N, synth
+    names, seqs = synth.make_genes(2500, 0, seed=91)
+    rep = b'ATG' + b'GCTGCTGCAGCA' * 250 + b'TAA'                  # 1 000 alanines: one k-mer, a thousand times per gene, in 60 genes
+    cases = [(seqs, seqs), (list(seqs[:300]) + [rep] * 60, list(seqs[:600]) + [rep] * 2)]
+    for qs, ts in cases:
+        ctx.set_query_nt(qs, 11); ctx.set_ref_nt(ts, 6, 11)
+        out = []
+        for flag in (0, 1):
+            p = N.default_params(45., 25., 10, 5)
+            p.reserved[2] = flag
+            h, c, st = ctx.search(p)
+            out.append((h.tobytes(), c.tobytes(), st['query_seeds'], st['target_seeds'], st['seed_hits'], st['candidates'], st['pairs']))
+        assert out[0] == out[1] and len(out[0][0]) > 64 * 100
