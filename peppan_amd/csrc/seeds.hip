@@ -354,7 +354,7 @@ __device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *s
 // query index and every equal-key pair is appended as a raw seed hit (qpos << 32 | tpos).  Hits are staged in an
 // LDS buffer and flushed with ONE global atomic per flush (a single global counter word only sustains ~90
 // atomics/us).  Every memory operation of this phase is independent across lanes: high memory-level parallelism.
-constexpr int HIT_BUF = 3072;
+constexpr int HIT_BUF = 2048;
 template <int W>
 __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
 {
@@ -689,7 +689,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
             PEP_HIP(ctx, hipMemsetAsync(hit_count, 0, 8, ctx->stream));
-            PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 5u)), sh, a);
+            PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 8u)), sh, a);
             PEP_HIP(ctx, hipMemsetAsync(n_runs, 0, 8, ctx->stream));
             hipLaunchKernelGGL(seed_runs, dim3(256u * 8u), dim3(256), 0, ctx->stream, a, run_first, run_len, run_key, n_runs);
             hipLaunchKernelGGL(seed_extend, dim3(256u * 16u), dim3(256), 0, ctx->stream, a, (const uint64_t *)run_first, (const uint32_t *)run_len,
