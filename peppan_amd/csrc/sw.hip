@@ -180,6 +180,17 @@ __device__ __forceinline__ s16x2 pk_shr1z(s16x2 v) { return __builtin_bit_cast(s
 __device__ __forceinline__ s16x2 pk_shl1z(s16x2 v) { return __builtin_bit_cast(s16x2, shl1z(__builtin_bit_cast(int, v))); }
 __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 
+// table address = replica base + q part + t part in ONE instruction: left to itself hipcc keeps (base + q) for the B step and spends
+// three additions per candidate and step pair instead of two
+__device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+typedef const __attribute__((address_space(3))) signed char lds_ci8;
+__device__ __forceinline__ short tab_at(uint32_t base, int qv, int tv) { return (short)*(lds_ci8 *)(uintptr_t)add3(base, (uint32_t)qv, (uint32_t)tv); }
+
 struct CandGeom {
     const uint8_t *qg, *tg;
     int Lq, Lt, dlo, a0, nblk;
@@ -225,41 +236,41 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
     // per-lane read cursors: the A cell of step pair m is (a0 + m - lane, a0 + dlo + m + lane); window origins a0-64 / a0+dlo-1
     // explicit LDS address space: through a generic volatile pointer hipcc emits flat_load_ushort instead of ds_read_u16
     typedef const volatile __attribute__((address_space(3))) uint16_t lds_cu16;
-    typedef const __attribute__((address_space(3))) signed char lds_ci8;
     lds_cu16 *vq0 = (lds_cu16 *)(q0 + (64 - lane)), *vt0 = (lds_cu16 *)(t0 + (1 + lane));
     lds_cu16 *vq1 = (lds_cu16 *)(q1 + (64 - lane)), *vt1 = (lds_cu16 *)(t1 + (1 + lane));
-    lds_ci8 *tab = (lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
+    const uint32_t tab = (uint32_t)(uintptr_t)(lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
     const s16x2 zero = {0, 0};
     const s16x2 oe2 = {(short)a.oe, (short)a.oe}, ext2 = {(short)a.ext, (short)a.ext};
+    // The gap states are carried as E + (open + extend) and F + (open + extend): "open a gap from H" then needs no subtraction, and the
+    // one subtraction moves to the single place where max(E, F) meets H - one instruction less per step.  Every POSITIVE E / F (the
+    // only ones that can reach H >= 0) is the same as in the plain recurrence; the traceback pass keeps the plain form for its flags.
     s16x2 HA = zero, EA = zero, FA = zero, HB = zero, EB = zero, FB = zero, best = zero;
     int tv0 = vt0[0], tv1 = vt1[0], qv0 = 0, qv1 = 0;
-    int m = 0;
     for (int b = 0; b < nb; ++b) {
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half)
+        for (int half = 0; half < 2; ++half, vq0 += 4, vq1 += 4, vt0 += 4, vt1 += 4)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             // ---- A step
-            qv0 = vq0[m]; qv1 = vq1[m];
+            qv0 = vq0[u]; qv1 = vq1[u];
             {
-                const s16x2 sub = {(short)tab[qv0 + tv0], (short)tab[qv1 + tv1]};
+                const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
                 const s16x2 hl = pk_shr1z(HB), el = pk_shr1z(EB);
-                const s16x2 E = pk_max(el - ext2, hl - oe2), F = pk_max(FB - ext2, HB - oe2);
-                const s16x2 H = pk_max(pk_max(pk_max(HA + sub, E), F), zero);
+                const s16x2 E = pk_max(el - ext2, hl), F = pk_max(FB - ext2, HB);
+                const s16x2 H = pk_max(pk_max(HA + sub, pk_max(E, F) - oe2), zero);
                 best = pk_max(best, H);
                 HA = H; EA = E; FA = F;
             }
             // ---- B step (target cursor advances)
-            tv0 = vt0[m + 1]; tv1 = vt1[m + 1];
+            tv0 = vt0[u + 1]; tv1 = vt1[u + 1];
             {
-                const s16x2 sub = {(short)tab[qv0 + tv0], (short)tab[qv1 + tv1]};
+                const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
                 const s16x2 hu = pk_shl1z(HA), fu = pk_shl1z(FA);
-                const s16x2 E = pk_max(EA - ext2, HA - oe2), F = pk_max(fu - ext2, hu - oe2);
-                const s16x2 H = pk_max(pk_max(pk_max(HB + sub, E), F), zero);
+                const s16x2 E = pk_max(EA - ext2, HA), F = pk_max(fu - ext2, hu);
+                const s16x2 H = pk_max(pk_max(HB + sub, pk_max(E, F) - oe2), zero);
                 best = pk_max(best, H);
                 HB = H; EB = E; FB = F;
             }
-            ++m;
         }
     }
     int b0 = best.x, b1 = best.y;
@@ -329,10 +340,9 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     typedef const volatile __attribute__((address_space(3))) uint16_t lds_cu16;
-    typedef const __attribute__((address_space(3))) signed char lds_ci8;
     lds_cu16 *vq0 = (lds_cu16 *)(q0 + (64 - lane)), *vt0 = (lds_cu16 *)(t0 + (1 + lane));
     lds_cu16 *vq1 = (lds_cu16 *)(q1 + (64 - lane)), *vt1 = (lds_cu16 *)(t1 + (1 + lane));
-    lds_ci8 *tab = (lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
+    const uint32_t tab = (uint32_t)(uintptr_t)(lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
     uint2 *dir0 = reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c0] * 64, *dir1 = reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c1] * 64;
     const s16x2 zero = {0, 0};
     const s16x2 oe2 = {(short)a.oe, (short)a.oe}, ext2 = {(short)a.ext, (short)a.ext};
@@ -343,7 +353,6 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
     s16x2 HA = zero, EA = zero, FA = zero, HB = zero, EB = zero, FB = zero;
     u16x2 first = {0xFFFF, 0xFFFF}, kk = {0, 0};
     int tv0 = vt0[0], tv1 = vt1[0], qv0 = 0, qv1 = 0;
-    int m = 0;
     for (int b = 0; b < nb; ++b) {
         u16x2 accA = {0, 0}, accB = {0, 0}, loA = {0, 0}, loB = {0, 0};
 #pragma unroll 1
@@ -351,9 +360,9 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 // ---- A step
-                qv0 = vq0[m]; qv1 = vq1[m];
+                qv0 = vq0[u]; qv1 = vq1[u];
                 {
-                    const s16x2 sub = {(short)tab[qv0 + tv0], (short)tab[qv1 + tv1]};
+                    const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
                     const s16x2 hl = pk_shr1z(HB), el = pk_shr1z(EB);
                     const s16x2 e_ext = el - ext2, e_open = hl - oe2, f_ext = FB - ext2, f_open = HB - oe2;
                     const s16x2 E = pk_max(e_ext, e_open), F = pk_max(f_ext, f_open);
@@ -365,9 +374,9 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                     HA = H; EA = E; FA = F;
                 }
                 // ---- B step (target cursor advances)
-                tv0 = vt0[m + 1]; tv1 = vt1[m + 1];
+                tv0 = vt0[u + 1]; tv1 = vt1[u + 1];
                 {
-                    const s16x2 sub = {(short)tab[qv0 + tv0], (short)tab[qv1 + tv1]};
+                    const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
                     const s16x2 hu = pk_shl1z(HA), fu = pk_shl1z(FA);
                     const s16x2 e_ext = EA - ext2, e_open = HA - oe2, f_ext = fu - ext2, f_open = hu - oe2;
                     const s16x2 E = pk_max(e_ext, e_open), F = pk_max(f_ext, f_open);
@@ -378,8 +387,8 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                     kk += one_u;
                     HB = H; EB = E; FB = F;
                 }
-                ++m;
             }
+            vq0 += 4; vq1 += 4; vt0 += 4; vt1 += 4;
             if (half == 0) { loA = accA; loB = accB; }
         }
         // word of candidate 0 = low halves (first four cells | next four cells), candidate 1 = high halves
