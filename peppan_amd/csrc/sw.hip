@@ -27,6 +27,9 @@ constexpr int LDS_TABLE_BYTES = 256 * PEP_TAB_REP * 4;   // 256 dwords x PEP_TAB
 constexpr int TAB_ROW_SHIFT = PEP_TAB_REP == 32 ? 7 : 6; // log2(bytes per table row of 4 scores)
 constexpr int WAVES_PER_BLOCK = 8;
 
+constexpr int LEN_BUCKETS = 1024;        // sw_order: candidates are ordered by min(16-step blocks, LEN_BUCKETS - 1)
+__device__ __forceinline__ uint32_t len_bucket(uint32_t nb) { return nb < (uint32_t)LEN_BUCKETS ? nb : (uint32_t)LEN_BUCKETS - 1; }
+
 struct SwArgs {
     const uint64_t *cands;
     uint64_t n;
@@ -42,6 +45,7 @@ struct SwArgs {
     int pk16;                      // sweep two candidates per wavefront in packed 16-bit (score pass; traceback pass when `known` is set)
     const int32_t *known;          // traceback pass: the score of every candidate, from the score pass
     int max_sub;                   // largest table entry: bounds the scores of a pair for the 16-bit passes
+    const uint32_t *order;         // candidates by decreasing length (sw_order): item w of a launch is order[w] (order[2w], order[2w+1] packed)
 };
 
 __device__ __forceinline__ int shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // lane l <- lane l-1
@@ -420,7 +424,8 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
     }
 }
 
-// score pass: wave w of the grid-stride loop takes the candidate pair (2w, 2w+1)
+// score pass: wave w of the grid-stride loop takes the candidate pair (order[2w], order[2w+1]): neighbours in the length order, so the
+// two halves of the packed registers finish together, and the longest pairs start first
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -431,14 +436,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a
     uint16_t *lds_res = reinterpret_cast<uint16_t *>(smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes);
     const uint64_t n_pairs = (a.n + 1) / 2;
     for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < n_pairs; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
-        const uint64_t c0 = 2 * w, c1 = min(2 * w + 1, a.n - 1);
+        const uint64_t c0 = a.order[2 * w], c1 = a.order[min(2 * w + 1, a.n - 1)];
         const CandGeom g0 = cand_geom(a, c0), g1 = cand_geom(a, c1);
         const int nb = max(g0.nblk, g1.nblk);
         const int need = 4 * 2 * ((8 * nb + 72 + 7) & ~7);
         if (a.pk16 && fits16(g0, a.max_sub) && fits16(g1, a.max_sub) && need <= a.lds_res_bytes) {
             sw_two_pk16(a, c0, c1, g0, g1, smem, lds_res, lane);
         } else {
-            for (uint64_t c = c0; c <= c1; ++c) {
+            for (int x = 0; x < (c1 != c0 ? 2 : 1); ++x) {
+                const uint64_t c = x ? c1 : c0;
                 const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
                 if (need1 <= a.lds_res_bytes) sw_one<true, false>(a, c, smem, lds_res, lane);
                 else sw_one<false, false>(a, c, smem, lds_res, lane);
@@ -462,14 +468,15 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_kernel(SwArgs a)  
         // candidates in pairs (2w, 2w+1), both halves of the packed registers busy; pairs that do not fit 16 bits / the staging area fall back
         const uint64_t n_pairs = (a.n + 1) / 2;
         for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < n_pairs; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
-            const uint64_t c0 = 2 * w, c1 = min(2 * w + 1, a.n - 1);
+            const uint64_t c0 = a.order[2 * w], c1 = a.order[min(2 * w + 1, a.n - 1)];
             const CandGeom g0 = cand_geom(a, c0), g1 = cand_geom(a, c1);
             const int nb = max(g0.nblk, g1.nblk);
             const int need = 4 * 2 * ((8 * nb + 72 + 7) & ~7);
             if (c1 != c0 && fits16(g0, a.max_sub) && fits16(g1, a.max_sub) && need <= a.lds_res_bytes && nb < 2040 && a.known[c0] > 0 && a.known[c1] > 0) {
                 sw_two_pk16_trace(a, c0, c1, g0, g1, smem, lds_res, lane);
             } else {
-                for (uint64_t c = c0; c <= c1; ++c) {
+                for (int x = 0; x < (c1 != c0 ? 2 : 1); ++x) {
+                    const uint64_t c = x ? c1 : c0;
                     const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
                     if (need1 <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, smem, lds_res, lane);
                     else sw_one<false, TRACE>(a, c, smem, lds_res, lane);
@@ -478,7 +485,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_kernel(SwArgs a)  
         }
         return;
     }
-    for (uint64_t c = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; c < a.n; c += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
+    for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < a.n; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
+        const uint64_t c = a.order[w];
         const int need = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
         if (need <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, smem, lds_res, lane);
         else sw_one<false, TRACE>(a, c, smem, lds_res, lane);
@@ -488,8 +496,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_kernel(SwArgs a)  
 // per candidate: number of 8-step blocks and the exact count of in-band in-matrix cells
 __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cands, uint64_t n, const uint32_t *__restrict__ q_len,
                                                const uint32_t *__restrict__ t_len, uint32_t *__restrict__ nblk, uint64_t *__restrict__ nblk64,
-                                               unsigned long long *__restrict__ cells_total)           // [0] cells, [1] 16-step blocks
+                                               unsigned long long *__restrict__ cells_total,           // [0] cells, [1] 16-step blocks
+                                               uint32_t *__restrict__ len_hist)                        // [LEN_BUCKETS] candidates per length bucket
 {
+    __shared__ uint32_t lh[LEN_BUCKETS];
+    for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) lh[x] = 0;
+    __syncthreads();
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long cells = 0, blocks = 0;
     if (c < n) {
@@ -512,10 +524,45 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
         nblk[c] = nb;
         nblk64[c] = nb;
         blocks = nb;
+        atomicAdd(&lh[len_bucket(nb)], 1u);
     }
     for (int d = 32; d > 0; d >>= 1) { cells += __shfl_down(cells, d, 64); blocks += __shfl_down(blocks, d, 64); }
     if ((threadIdx.x & 63) == 0 && cells) atomicAdd(&cells_total[0], cells);
     if ((threadIdx.x & 63) == 0 && blocks) atomicAdd(&cells_total[1], blocks);
+    __syncthreads();
+    for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) if (lh[x]) atomicAdd(&len_hist[x], lh[x]);
+}
+
+// candidates in the order of decreasing length bucket (counting sort over sw_prep's histogram; the order inside a bucket is whatever the
+// atomics hand out - results are per candidate, so it does not matter).  Equal lengths side by side keep both halves of a packed
+// wavefront busy to the end; longest first keeps the tail of the launch short.
+__global__ __launch_bounds__(256) void sw_order(const uint32_t *__restrict__ nblk, uint64_t n, const uint32_t *__restrict__ len_hist,
+                                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ order)
+{
+    __shared__ uint32_t start[LEN_BUCKETS], lh[LEN_BUCKETS], base[LEN_BUCKETS], part[256];
+    // start[b] = candidates in longer buckets: every block rebuilds the (tiny) scan
+    uint32_t mine[LEN_BUCKETS / 256], sum = 0;
+#pragma unroll
+    for (int k = 0; k < LEN_BUCKETS / 256; ++k) { mine[k] = len_hist[LEN_BUCKETS - 1 - (threadIdx.x * (LEN_BUCKETS / 256) + k)]; sum += mine[k]; }
+    part[threadIdx.x] = sum;
+    for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) lh[x] = 0;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < LEN_BUCKETS / 256; ++k) { start[LEN_BUCKETS - 1 - (threadIdx.x * (LEN_BUCKETS / 256) + k)] = run; run += mine[k]; }
+    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t b = 0, rank = 0;
+    if (c < n) { b = len_bucket(nblk[c]); rank = atomicAdd(&lh[b], 1u); }
+    __syncthreads();
+    for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) if (lh[x]) base[x] = atomicAdd(&cursor[x], lh[x]);
+    __syncthreads();
+    if (c < n) order[start[b] + base[b] + rank] = (uint32_t)c;
 }
 
 __global__ void dpp_probe(int *out)
@@ -552,11 +599,17 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     PEP_TRY(dev_reserve(ctx, ctx->ws[11], (n + 2) * sizeof(uint64_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[14], (n + 2) * sizeof(uint64_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[12], (n + 1) * sizeof(int4)));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[15], 64));
+    if (n >= (1ull << 32)) return pep_fail(ctx, PEP_ERR_LIMIT, "pep_sw_run: more than 2^32 candidates in one launch");
+    // ws[15]: [0..15] cell / block totals, [64..) length histogram, then the scatter cursors, then the order itself
+    const size_t hist_bytes = LEN_BUCKETS * sizeof(uint32_t);
+    PEP_TRY(dev_reserve(ctx, ctx->ws[15], 64 + 2 * hist_bytes + (n + 1) * sizeof(uint32_t)));
     unsigned long long *cells = ctx->ws[15].as<unsigned long long>();
-    PEP_HIP(ctx, hipMemsetAsync(cells, 0, 16, ctx->stream));
+    uint32_t *len_hist = reinterpret_cast<uint32_t *>(ctx->ws[15].as<unsigned char>() + 64), *cursor = len_hist + LEN_BUCKETS, *order = cursor + LEN_BUCKETS;
+    PEP_HIP(ctx, hipMemsetAsync(cells, 0, 64 + 2 * hist_bytes, ctx->stream));
     hipLaunchKernelGGL(sw_prep, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_cands, n, ctx->q.len.as<const uint32_t>(),
-                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells);
+                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist);
+    hipLaunchKernelGGL(sw_order, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[10].as<const uint32_t>(), n,
+                       (const uint32_t *)len_hist, cursor, order);
     uint64_t total_blk = 0;
     unsigned long long h_cells = 0;
     PEP_TRY(pep_read_back(ctx, &h_cells, cells, 8));
@@ -586,6 +639,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     const uint64_t want = 2 * 2 * ((8 * max_blk + 72 + 7) & ~7ull);
     a.pk16 = (P.use_lds && P.reserved[1] == 0 && (!trace || d_known)) ? 1 : 0;       // reserved[1] != 0 forces the 32-bit passes (tests)
     a.known = trace ? d_known : nullptr;
+    a.order = order;
     a.max_sub = 1;
     for (int x = 0; x < 32 * 32; ++x) a.max_sub = std::max(a.max_sub, (int)P.sub[x]);
     a.lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, ((a.pk16 ? 2 * want : want) + 255) & ~255ull) : 0;
