@@ -644,11 +644,11 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     for (int x = 0; x < 32 * 32; ++x) a.max_sub = std::max(a.max_sub, (int)P.sub[x]);
     a.lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, ((a.pk16 ? 2 * want : want) + 255) & ~255ull) : 0;
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
-    // score pass: one candidate pair per wavefront - the hardware's block dispatcher balances the load better than a grid-stride loop
-    // inside fewer blocks (0.82 -> 0.80 ms on the benchmark), and the 16 KiB table load per block comes out of the L2.  Traceback
-    // pass: 2048 blocks measured best (its items are fewer and longer; more blocks only add table loads).
+    // one item (a packed candidate pair, or one candidate) per wavefront: the hardware's block dispatcher balances the load better than a
+    // grid-stride loop inside fewer blocks (score pass 0.82 -> 0.80 ms on the benchmark; traceback pass 0.97 -> 0.96 ms), and the 16 KiB
+    // table load per block comes out of the L2
     const uint64_t items = ceil_div(a.pk16 ? (n + 1) / 2 : n, WAVES_PER_BLOCK);
-    const unsigned grid = (unsigned)std::min<uint64_t>(items, trace ? 256ull * 8 : 256ull * 256);
+    const unsigned grid = (unsigned)std::min<uint64_t>(items, 256ull * 256);
     EventTimer timer(ctx->stream);
     if (trace) hipLaunchKernelGGL(sw_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     else hipLaunchKernelGGL(sw_score_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(WALK_LANES) void walk(uint64_t n_sel, SelInfo *__re
             cur_rel = rel; cur_blk = blk;
         }
         const uint32_t word = w[0];
-        int nidx = m & 7;
+        const int nidx = m & 7;
         const uint32_t nib = (word >> (nidx * 4)) & 15u;
         uint32_t op, cnt = 1;
         if (state == 0) {
@@ -124,9 +124,20 @@ __global__ __launch_bounds__(WALK_LANES) void walk(uint64_t n_sel, SelInfo *__re
             if (src == 0) break;
             if (src != 1) { state = (src == 2) ? 1 : 2; continue; }
             // follow the diagonal inside this word: up to nidx + 1 cells, never past row 0 / column 0
+            // (a zero nibble of x = a diagonal code; the cells of the word below this one are shifted to the top and counted at once)
             const int lim = min(i, j);
-            int r = 0;
-            do { ++r; --nidx; } while (nidx >= 0 && r <= lim && ((word >> (nidx * 4)) & 3u) == 1u);
+            const uint32_t x = ((word & 0x33333333u) ^ 0x11111111u) << ((7 - nidx) * 4);
+            const int run = x ? (__clz(x) >> 2) : 8;
+            int r = min(min(run, nidx + 1), lim + 1);
+            // whole words of diagonal codes further down the same diagonal, as far as they are already here: a long ungapped stretch
+            // costs a handful of instructions per 8 cells instead of a trip through the general step
+            if (r == nidx + 1)
+                while (have > 1 && cur_blk > 0 && r + 8 <= lim + 1 && ((w[1] & 0x33333333u) ^ 0x11111111u) == 0u) {
+                    r += 8;
+#pragma unroll
+                    for (int k = 0; k + 1 < WALK_AHEAD; ++k) w[k] = w[k + 1];
+                    --have; --cur_blk;
+                }
             op = 0; cnt = (uint32_t)r;
             istart = i - r + 1; jstart = j - r + 1;
         } else if (state == 1) {
