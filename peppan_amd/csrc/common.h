@@ -104,6 +104,8 @@ struct pep_ctx {
     DevBuf ws[24];
     DevBuf sub_lds;                         // replicated substitution table image (32 KiB)
     DevBuf d_params;                        // device copy of seed params
+    DevBuf scan_state;                      // single-launch scan: ticket counter + one status word per tile (scan.hip)
+    uint32_t scan_epoch = 0, scan_ticket_base = 0;
     // stats of the last search
     pep_stats stats;
 };

@@ -1,6 +1,8 @@
 // Exclusive prefix sums over device arrays (u32 / u64), n+1 outputs (out[n] = total).
-// Three passes: per-tile reduce -> scan of the tile sums (one block) -> per-tile scan + offset.
-// HBM-bound: reads the input twice and writes it once.
+// u32: ONE launch - every tile publishes its sum, looks back over the tiles before it (a wavefront inspects 64 predecessors at a
+// time) and publishes its inclusive prefix ("decoupled look-back").  Reads the input once and writes it once; the searches run a
+// dozen short scans per pass, so the two launches saved per scan matter more than the bytes.
+// u64 (three per search): per-tile reduce -> scan of the tile sums (one block) -> per-tile scan + offset.
 #include "common.h"
 
 namespace {
@@ -94,6 +96,86 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const T *in, T *out, 
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = partial[nb];
 }
 
+// ---- single-launch u32 scan.  state[0] = ticket counter (tiles take their index from it, so a tile only ever waits for tiles that
+// are already running); state[1 + tile] = (epoch << 34) | (flag << 32) | value with flag 1 = the tile's own sum, 2 = sum of everything
+// up to and including the tile.  The epoch is a per-call number: words left by earlier scans never match, so nothing is cleared.
+constexpr uint64_t FLAG_SUM = 1, FLAG_PREFIX = 2;
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_lookback(const uint32_t *in, uint32_t *out, uint64_t n, uint32_t nb, uint64_t *state,
+                                                              uint32_t ticket_base, uint64_t epoch)
+{
+    __shared__ uint32_t lds[4];
+    __shared__ uint32_t s_tile, s_prefix;
+    if (threadIdx.x == 0) s_tile = atomicAdd(reinterpret_cast<uint32_t *>(state), 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    uint64_t *status = state + 1;
+    const uint64_t base = (uint64_t)tile * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    uint32_t tot;
+    uint32_t ex = block_excl_scan(s, &tot, lds);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t prefix = 0;
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&status[tile], (epoch << 34) | (FLAG_SUM << 32) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // window of 64 predecessors, lane 0 = the nearest; stop at the nearest tile that already knows its inclusive prefix
+            for (int64_t hi = (int64_t)tile - 1; hi >= 0; hi -= 64) {
+                const int64_t idx = hi - lane;
+                uint64_t w = (epoch << 34) | (FLAG_PREFIX << 32);                 // before tile 0: prefix 0
+                if (idx >= 0)
+                    do { w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 34) != epoch);
+                const uint64_t is_prefix = __ballot(((w >> 32) & 3u) == FLAG_PREFIX);
+                const int stop = is_prefix ? __ffsll((unsigned long long)is_prefix) - 1 : 63;      // lanes 0..stop contribute
+                uint32_t part = lane <= stop ? (uint32_t)w : 0u;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+                prefix += part;
+                if (is_prefix) break;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&status[tile], (epoch << 34) | (FLAG_PREFIX << 32) | (uint32_t)(prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = prefix;
+        }
+    }
+    __syncthreads();
+    ex += s_prefix;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = ex;
+        ex += v[k];
+    }
+    if (tile == nb - 1 && threadIdx.x == SCAN_THREADS - 1) out[n] = ex;
+}
+
+int scan_u32_onepass(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n)
+{
+    const uint64_t nb = ceil_div(n, SCAN_TILE);
+    if ((nb + 1) * sizeof(uint64_t) > ctx->scan_state.cap) {
+        // a new (or larger) state area starts from zeros: epoch 0 is never used, so no word of it can pass for a published one
+        PEP_TRY(dev_reserve(ctx, ctx->scan_state, (nb + 1) * sizeof(uint64_t) * 2));
+        PEP_HIP(ctx, hipMemsetAsync(ctx->scan_state.p, 0, ctx->scan_state.cap, ctx->stream));
+        ctx->scan_ticket_base = 0;
+    }
+    ctx->scan_epoch = (ctx->scan_epoch + 1) & ((1u << 30) - 1);
+    if (ctx->scan_epoch == 0) {             // wrapped: forget every old word
+        PEP_HIP(ctx, hipMemsetAsync(ctx->scan_state.p, 0, ctx->scan_state.cap, ctx->stream));
+        ctx->scan_ticket_base = 0;
+        ctx->scan_epoch = 1;
+    }
+    hipLaunchKernelGGL(scan_lookback, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, n, (uint32_t)nb, ctx->scan_state.as<uint64_t>(),
+                       ctx->scan_ticket_base, (uint64_t)ctx->scan_epoch);
+    ctx->scan_ticket_base += (uint32_t)nb;
+    PEP_HIP(ctx, hipGetLastError());
+    return PEP_OK;
+}
+
 template <class T>
 int scan_impl(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n, DevBuf &tmp)
 {
@@ -113,5 +195,9 @@ int scan_impl(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n, DevBuf &tmp)
 
 }  // namespace
 
-int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp) { return scan_impl<uint32_t>(ctx, d_in, d_out, n, tmp); }
+int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp)
+{
+    if (n == 0 || n >= (1ull << 40)) return scan_impl<uint32_t>(ctx, d_in, d_out, n, tmp);
+    return scan_u32_onepass(ctx, d_in, d_out, n);
+}
 int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp) { return scan_impl<uint64_t>(ctx, d_in, d_out, n, tmp); }
