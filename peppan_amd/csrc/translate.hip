@@ -17,13 +17,11 @@ __constant__ uint8_t c_codon[2][64];
 
 __device__ __forceinline__ int base2(uint8_t ch)
 {
-    switch (ch & 0xDF) {              // fold case
-        case 'A': return 0;
-        case 'C': return 1;
-        case 'G': return 2;
-        case 'T': return 3;
-        default: return ch == '-' ? -2 : -1;
-    }
+    // A 0x41, C 0x43, G 0x47, T 0x54 (case folded): bits 1 and 2 spell 0..3 in that order; then check that it really was that letter
+    const uint32_t u = ch & 0xDFu;
+    const int code = (int)(((u >> 1) ^ (u >> 2)) & 3u);
+    if (u == ((0x54474341u >> (code * 8)) & 0xFFu)) return code;
+    return ch == '-' ? -2 : -1;
 }
 
 // residue `aa` of frame `frame` (1..6) of the sequence nt[0..L): returns code 0..25, X for ambiguous/partial codons;
@@ -63,18 +61,30 @@ __global__ __launch_bounds__(256) void k1_query_frames(const uint8_t *__restrict
     if (g >= n) return;
     const uint8_t *s = nt + off[g];
     const int64_t L = (int64_t)(off[g + 1] - off[g]);
-    // the three frames are walked together: their codon reads are independent, so one pass pays the memory latency once per
-    // 64 codons instead of three times
+    // the three frames are walked together: codon a of frames 1, 2, 3 is bytes 3a .. 3a+4, five loads instead of nine, and two
+    // codon positions per lane and trip keep ten loads in flight (the kernel is bound by their latency, not by the bytes)
     const int64_t na1 = frame_len(L, 1), na2 = frame_len(L, 2), na3 = frame_len(L, 3);
     uint32_t x1 = 0, x2 = 0, x3 = 0;
-    for (int64_t a = lane; a + 1 < na1; a += 64) {              // s[:-1] of every frame; frame 1 is the longest
-        bool g1, g2 = false, g3 = false;
-        const int c1 = translate_at(s, L, 1, a, tab, &g1);
-        const int c2 = a + 1 < na2 ? translate_at(s, L, 2, a, tab, &g2) : 0;
-        const int c3 = a + 1 < na3 ? translate_at(s, L, 3, a, tab, &g3) : 0;
-        x1 += (c1 == 23 && !g1) ? 1u : 0u;
-        x2 += (c2 == 23 && !g2) ? 1u : 0u;
-        x3 += (c3 == 23 && !g3) ? 1u : 0u;
+    for (int64_t a0 = lane; a0 + 1 < na1; a0 += 128) {         // s[:-1] of every frame; frame 1 is the longest
+        int b[2][5];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) { const int64_t p = 3 * (a0 + 64 * h) + k; b[h][k] = p < L ? base2(s[p]) : -1; }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int64_t a = a0 + 64 * h;
+            const int64_t lim[3] = {na1, na2, na3};
+            uint32_t *cnt[3] = {&x1, &x2, &x3};
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                if (a + 1 >= lim[f]) continue;
+                const int u = b[h][f], v = b[h][f + 1], w = b[h][f + 2];
+                const bool gap = (u == -2) | (v == -2) | (w == -2);
+                const bool stop = !gap && ((u | v | w) < 0 || c_codon[tab][(u << 4) | (v << 2) | w] == 23);
+                *cnt[f] += stop ? 1u : 0u;
+            }
+        }
     }
     for (int d = 32; d > 0; d >>= 1) { x1 += __shfl_xor(x1, d, 64); x2 += __shfl_xor(x2, d, 64); x3 += __shfl_xor(x3, d, 64); }
     uint32_t best_cnt = x1, best_f = 1, best_len = (uint32_t)na1;
@@ -154,10 +164,17 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
     const uint8_t *src = nt + nt_off[d.seq];
     const int64_t L = (int64_t)(nt_off[d.seq + 1] - nt_off[d.seq]);
     if (s == 0) for (uint32_t x = lane; x < start; x += 64) res[x] = (uint8_t)PEP_PAD_CODE;          // leading pad
-    for (uint32_t x = lane; x < next - start; x += 64) {
-        uint32_t c = PEP_PAD_CODE;
-        if (x < d.len) c = (uint32_t)translate_at(src, L, (int)d.frame, (int64_t)d.aa_off + x, tab, nullptr);
-        res[start + x] = (uint8_t)c;
+    // eight residues per lane and trip: one 8-byte store (sequence starts and spans are multiples of 16) and 24 loads in flight -
+    // the kernel is bound by load latency, and a 1000-nt gene is done in a single trip
+    for (uint32_t x0 = 8 * lane; x0 < next - start; x0 += 512) {
+        uint32_t word[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t c = PEP_PAD_CODE;
+            if (x0 + k < d.len) c = (uint32_t)translate_at(src, L, (int)d.frame, (int64_t)d.aa_off + x0 + k, tab, nullptr);
+            word[k >> 2] |= c << (8 * (k & 3));
+        }
+        *reinterpret_cast<uint2 *>(res + start + x0) = make_uint2(word[0], word[1]);
     }
     for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = s;
 }
