@@ -526,10 +526,15 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
         blocks = nb;
         atomicAdd(&lh[len_bucket(nb)], 1u);
     }
+    // totals: one pair of atomics per block (every wavefront adding to the same two words serialises in the L2)
+    __shared__ unsigned long long tot[2][4];
     for (int d = 32; d > 0; d >>= 1) { cells += __shfl_down(cells, d, 64); blocks += __shfl_down(blocks, d, 64); }
-    if ((threadIdx.x & 63) == 0 && cells) atomicAdd(&cells_total[0], cells);
-    if ((threadIdx.x & 63) == 0 && blocks) atomicAdd(&cells_total[1], blocks);
+    if ((threadIdx.x & 63) == 0) { tot[0][threadIdx.x >> 6] = cells; tot[1][threadIdx.x >> 6] = blocks; }
     __syncthreads();
+    if (threadIdx.x < 2) {
+        const unsigned long long v = tot[threadIdx.x][0] + tot[threadIdx.x][1] + tot[threadIdx.x][2] + tot[threadIdx.x][3];
+        if (v) atomicAdd(&cells_total[threadIdx.x], v);
+    }
     for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) if (lh[x]) atomicAdd(&len_hist[x], lh[x]);
 }
 
