@@ -25,16 +25,17 @@ __global__ __launch_bounds__(256) void select_best(const uint64_t *__restrict__ 
                                                    uint32_t *__restrict__ n_pairs, int hsp_mode)
 {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= n) return;
-    const uint64_t g = cands[c] >> 18;
+    const bool live = c < n;
+    const uint64_t g = live ? cands[c] >> 18 : 0;
     uint32_t f = 0;
-    const bool head = c == 0 || (cands[c - 1] >> 18) != g;
+    const bool head = live && (c == 0 || (cands[c - 1] >> 18) != g);
+    const int heads = __syncthreads_count(head);                 // (q, t) groups that start in this block: one atomic per block
+    if (threadIdx.x == 0 && heads) atomicAdd(n_pairs, (uint32_t)heads);
+    if (!live) return;
     if (hsp_mode == 1) {
         // every band that reaches the threshold is traced; duplicates are removed after the walk (dedupe_bands)
-        if (head) atomicAdd(n_pairs, 1u);
         if (sw[c].x > 0 && sw[c].x >= min_score[key_q(cands[c])]) { f = 1; best_idx[c] = (uint32_t)c; }
     } else if (head) {
-        atomicAdd(n_pairs, 1u);
         int best = sw[c].x;
         uint64_t bi = c;
         for (uint64_t x = c + 1; x < n && (cands[x] >> 18) == g; ++x)
