@@ -4,9 +4,9 @@
 //  seed_count / seed_fill : one thread per packed query byte position; key = sum red[r[p+off_k]] * base^k.
 //                           Padding bytes (code 31) never seed, so a seed cannot straddle two sequences.
 //                           Index = counting sort by hash(key): counts -> exclusive scan -> fill (8 B entries
-//                           key << 29 | pos) + one occupancy bit per bucket.  1 B read + 8 B written per query residue.
-//  seed_match             : persistent blocks stream the packed target bytes tile by tile; every position whose bucket is
-//                           occupied compares its key with the bucket's entries; equal keys are raw seed hits
+//                           key << 29 | pos) + a two-bit Bloom filter (filter_mask).  1 B read + 8 B written per query residue.
+//  seed_match             : persistent blocks stream the packed target bytes tile by tile; every position that passes the
+//                           filter compares its key with the bucket's entries; equal keys are raw seed hits
 //                           (qpos << 32 | tpos), staged in LDS and flushed with one global atomic per ~1.5 k hits.
 //  seed_extend            : one thread per raw hit; neighbouring hits of one diagonal share their candidate key
 //                           q:21 | t:25 | bin:18, so the first lane of each run decides for the run: already in the
@@ -35,6 +35,18 @@ constexpr uint64_t POS_MASK = (1ull << POS_BITS) - 1;
 __device__ __forceinline__ uint32_t hash_u64(uint64_t k, int bits)
 {
     return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> (64 - bits));
+}
+
+// Filter in front of the index ("is this key possibly there?"): a Bloom filter blocked by 64-bit word, two bits per key, 2 bits of
+// filter per bucket (2 MiB for 2^23 buckets - it stays in the L2).  word = the top (bucket_bits - 5) bits of the key's hash, so the
+// words of one coarse bucket are contiguous; the two bit numbers are the next 6 + 6 bits.  A plain one-bit-per-bucket map lets 33 % of
+// the foreign keys through to start[] / entries[] (one 64-byte line each from the memory side), this one 12 %.
+__device__ __forceinline__ uint64_t filter_mask(uint64_t k, int bucket_bits, uint32_t &word)
+{
+    const uint64_t h = k * 0x9E3779B97F4A7C15ull;
+    const int wb = bucket_bits - 5;
+    word = (uint32_t)(h >> (64 - wb));
+    return (1ull << ((h >> (58 - wb)) & 63u)) | (1ull << ((h >> (52 - wb)) & 63u));
 }
 
 // reduced letters of one 256-position tile (+32 halo) into LDS: one coalesced pass, the reduction table lives in SGPRs
@@ -176,13 +188,14 @@ __global__ __launch_bounds__(256) void idx_scatter(SeedShape sh, const uint8_t *
     }
 }
 
-// one block per coarse bucket c: entries part[cbase .. cend) -> entries[] ordered by fine bucket, start[c << F .. (c + 1) << F), bitmap
+// one block per coarse bucket c: entries part[cbase .. cend) -> entries[] ordered by fine bucket, start[c << F .. (c + 1) << F), filter slice
 __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ part, const uint32_t *__restrict__ hist_scan, uint32_t n_blocks, int bucket_bits,
                                                   int fine_bits, uint32_t *__restrict__ start, uint64_t *__restrict__ entries,
-                                                  unsigned long long *__restrict__ occupied, uint32_t *__restrict__ counters)
+                                                  unsigned long long *__restrict__ filter, uint32_t *__restrict__ counters)
 {
     __shared__ uint32_t pos[4096];
     __shared__ uint64_t ents[PART_CAP];
+    __shared__ unsigned long long fw[128];
     __shared__ uint32_t wave_sum[4];
     const uint32_t c = blockIdx.x, n_coarse = 1u << (bucket_bits - fine_bits), n_fine = 1u << fine_bits;
     const uint32_t lo = hist_scan[(uint64_t)c * n_blocks], hi = hist_scan[(uint64_t)(c + 1) * n_blocks];     // scan has n_coarse * n_blocks + 1 entries
@@ -190,12 +203,16 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
     if (c == n_coarse - 1 && threadIdx.x == 0) start[(size_t)n_coarse << fine_bits] = hi;
     if (n > PART_CAP) { if (threadIdx.x == 0) counters[3] = 1u; return; }                                       // host falls back to count -> scan -> fill
     for (uint32_t x = threadIdx.x; x < n_fine; x += 256) pos[x] = 0;
+    for (uint32_t x = threadIdx.x; x < (n_fine >> 5); x += 256) fw[x] = 0;
     __syncthreads();
     const uint32_t fmask = n_fine - 1;
     for (uint32_t x = threadIdx.x; x < n; x += 256) {
         const uint64_t e = part[lo + x];
         ents[x] = e;
         atomicAdd(&pos[hash_u64(e >> POS_BITS, bucket_bits) & fmask], 1u);
+        uint32_t word;
+        const uint64_t m = filter_mask(e >> POS_BITS, bucket_bits, word);
+        atomicOr(&fw[word & ((n_fine >> 5) - 1)], (unsigned long long)m);
     }
     __syncthreads();
     // exclusive scan of the fine counters: thread t owns n_fine / 256 consecutive counters
@@ -209,23 +226,14 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
     __syncthreads();
     uint32_t run = incl - sum;
     for (int w = 0; w < wave; ++w) run += wave_sum[w];
-    unsigned long long bits = 0;                             // occupancy of this thread's counters (per <= 16 of them)
     for (uint32_t k = 0; k < per; ++k) {
         const uint32_t f = threadIdx.x * per + k, cnt = pos[f];
         pos[f] = run;
         start[((size_t)c << fine_bits) + f] = lo + run;
-        bits |= (unsigned long long)(cnt != 0) << k;
         run += cnt;
     }
-    // bitmap: 64 buckets per word = 64 / per threads per word
-    {
-        const uint32_t first_bucket = threadIdx.x * per;
-        const int sh_in_word = (int)(first_bucket & 63u);
-        unsigned long long word = bits << sh_in_word;
-        const int group = 64 / (int)per;                     // threads that share one word (1 when per == 64... per <= 16 here: group >= 4)
-        for (int d = 1; d < group; d <<= 1) word |= ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)word, d, 64)) | ((unsigned long long)(uint32_t)__shfl_xor((int)(word >> 32), d, 64) << 32);
-        if ((threadIdx.x % group) == 0) occupied[(((size_t)c << fine_bits) + first_bucket) >> 6] = word;
-    }
+    // this coarse bucket's slice of the filter: 2^(fine_bits - 5) words
+    for (uint32_t x = threadIdx.x; x < (n_fine >> 5); x += 256) filter[((size_t)c << (fine_bits - 5)) + x] = fw[x];
     __syncthreads();
     for (uint32_t x = threadIdx.x; x < n; x += 256) {
         const uint64_t e = ents[x];
@@ -234,14 +242,16 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
     }
 }
 
-// bit b of `occupied` = bucket b of the query index holds at least one seed.  Two thirds of the target seeds hash to an empty
-// bucket; the bitmap answers that from L2 instead of a 64-byte line of start[] from the memory side.
-__global__ __launch_bounds__(256) void bucket_bitmap(const uint32_t *__restrict__ start, uint64_t n_buckets, unsigned long long *__restrict__ occupied)
+// the filter for an index built the plain way (count -> scan -> fill): every entry sets its two bits (filter zeroed by the caller)
+__global__ __launch_bounds__(256) void filter_fill(const uint64_t *__restrict__ entries, const uint32_t *__restrict__ n_entries, int bucket_bits,
+                                                   unsigned long long *__restrict__ filter)
 {
-    const uint64_t b = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool occ = b < n_buckets && start[b + 1] != start[b];
-    const unsigned long long m = __ballot(occ);
-    if ((threadIdx.x & 63) == 0 && b < n_buckets) occupied[b >> 6] = m;
+    const uint32_t n = *n_entries;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256) {
+        uint32_t word;
+        const uint64_t m = filter_mask(entries[e] >> POS_BITS, bucket_bits, word);
+        atomicOr(&filter[word], (unsigned long long)m);
+    }
 }
 
 struct JoinArgs {
@@ -254,7 +264,7 @@ struct JoinArgs {
     const uint32_t *q_blk2seq, *t_blk2seq;
     const uint32_t *start;
     const uint64_t *entries;
-    const unsigned long long *occupied;   // one bit per bucket (1 MiB for 2^23 buckets: stays in L2, unlike start[])
+    const unsigned long long *filter;     // filter_mask(): two bits per key in one 64-bit word (2 MiB for 2^23 buckets: stays in L2, unlike start[])
     int bucket_bits;
     uint64_t *table;
     int table_bits;
@@ -381,7 +391,9 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
             ++n_seed;
             if (a.debug != 1) {
                 const uint32_t b = hash_u64(key, a.bucket_bits);
-                if ((a.occupied[b >> 6] >> (b & 63)) & 1ull) { e0 = a.start[b]; e1 = a.start[b + 1]; }
+                uint32_t word;
+                const uint64_t m = filter_mask(key, a.bucket_bits, word);
+                if ((a.filter[word] & m) == m) { e0 = a.start[b]; e1 = a.start[b + 1]; }
                 if (a.debug == 2) { n_hit += e1 - e0; e1 = e0; }
             }
         }
@@ -596,8 +608,8 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_buckets + 2) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[2], (Q.total + 1) * sizeof(uint64_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[6], 64));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[9], (n_buckets / 64 + 2) * 8));
-    unsigned long long *occupied = ctx->ws[9].as<unsigned long long>();
+    PEP_TRY(dev_reserve(ctx, ctx->ws[9], (n_buckets / 32 + 2) * 8));
+    unsigned long long *filter = ctx->ws[9].as<unsigned long long>();
     uint32_t *cnt = ctx->ws[0].as<uint32_t>(), *start = ctx->ws[1].as<uint32_t>();
     uint64_t *entries = ctx->ws[2].as<uint64_t>();
     uint32_t *counters = ctx->ws[6].as<uint32_t>();
@@ -671,18 +683,19 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
                 PEP_TRY(pep_scan_u32(ctx, cnt, cnt, (uint64_t)n_coarse * pb, ctx->ws[7]));
                 PEP_SEED_DISPATCH_LDS(idx_scatter, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, (const uint32_t *)cnt, pb, part);
                 hipLaunchKernelGGL(idx_finish, dim3(n_coarse), dim3(256), 0, ctx->stream, (const uint64_t *)part, (const uint32_t *)cnt, pb, bucket_bits, fine_bits,
-                                   start, entries, occupied, counters);
+                                   start, entries, filter, counters);
             } else {
                 PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
                 PEP_SEED_DISPATCH(seed_count, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, cnt, bucket_bits);
                 PEP_TRY(pep_scan_u32(ctx, cnt, start, n_buckets, ctx->ws[7]));
                 PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
                 PEP_SEED_DISPATCH(seed_fill, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, (const uint32_t *)start, cnt, entries, bucket_bits);
-                hipLaunchKernelGGL(bucket_bitmap, dim3((unsigned)ceil_div(n_buckets, 256)), dim3(256), 0, ctx->stream, (const uint32_t *)start, n_buckets, occupied);
+                PEP_HIP(ctx, hipMemsetAsync(filter, 0, (n_buckets >> 5) * 8, ctx->stream));
+                hipLaunchKernelGGL(filter_fill, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)entries, (const uint32_t *)(start + n_buckets), bucket_bits, filter);
             }
             JoinArgs a;
             a.t_res = T.res.as<const uint8_t>(); a.t_total = T.total; a.t_off = T.off.as<const uint32_t>(); a.nt = T.n;
-            a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint32_t>(); a.t_blk2seq = T.blk2seq.as<const uint32_t>(); a.start = start; a.entries = entries; a.occupied = occupied; a.bucket_bits = bucket_bits;
+            a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint32_t>(); a.t_blk2seq = T.blk2seq.as<const uint32_t>(); a.start = start; a.entries = entries; a.filter = filter; a.bucket_bits = bucket_bits;
             a.table = ctx->ws[3].as<uint64_t>(); a.table_bits = table_bits;
             a.counters = counters; a.stats = stats;
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
