@@ -12,6 +12,8 @@ same per-genome bookkeeping, in genome order, so the stores are those of the ref
 (PEPPAN.py:923).  Everything below the search is host logic pinned by tests/golden/g14_mapbsn.json / g15_getmapbsn.json.
 """
 import io
+import queue
+import threading
 import os
 import re
 import sys
@@ -38,12 +40,48 @@ class MapBsn(object):
         self.fname, self.mode = fname, mode
         self.conn = zipfile.ZipFile(fname, mode=mode, compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
         self.namelist = set(self.conn.namelist())
+        # writes go through ONE background thread per store, in order: deflate releases the GIL, so the compression of a genome's
+        # tables overlaps with the Python bookkeeping of the next one (a third of get_map_bsn's time was spent inside zlib)
+        self._queue = self._thread = self._error = None
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
-        self.conn.close()
+        self.close()
+
+    def close(self):
+        try:
+            self._flush()
+        finally:
+            if self._thread is not None:
+                self._queue.put(None)
+                self._thread.join()
+                self._thread = None
+            self.conn.close()
+
+    def _writer(self):
+        while True:
+            item = self._queue.get()
+            try:
+                if item is None:
+                    return
+                db, key, data = item
+                if self._error is None:
+                    # members are read back whole either way; deflating a few hundred bytes costs more than it saves (zlib set-up per member)
+                    db.writestr(key, data, compress_type=zipfile.ZIP_STORED if len(data) < 4096 else None)
+            except BaseException as e:              # reported by the next _flush() on the owning thread
+                self._error = e
+            finally:
+                self._queue.task_done()
+
+    def _flush(self):
+        """wait until every queued member is in its archive"""
+        if self._thread is not None:
+            self._queue.join()
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
 
     def exists(self, key):
         return str(key) in self.namelist
@@ -52,6 +90,7 @@ class MapBsn(object):
         key = str(key)
         if key not in self.namelist:
             return default
+        self._flush()
         return np.lib.format.read_array(io.BytesIO(self.conn.read(key)), allow_pickle=True)
 
     __getitem__ = get
@@ -86,6 +125,7 @@ class MapBsn(object):
         key = str(key)
         if key not in self.namelist:
             return
+        self._flush()
         self.namelist.discard(key)
         self.conn.close()
         tmp = self.fname + '.rewrite'
@@ -97,9 +137,12 @@ class MapBsn(object):
         self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
 
     def _save(self, db, key, val):
-        data = _npy_bytes(val)
-        # members are read back whole either way; deflating a few hundred bytes costs more than it saves (zlib set-up per member)
-        db.writestr(key, data, compress_type=zipfile.ZIP_STORED if len(data) < 4096 else None)
+        data = _npy_bytes(val)                      # serialised here: the caller may change `val` afterwards
+        if self._thread is None:
+            self._queue = queue.Queue(maxsize=256)
+            self._thread = threading.Thread(target=self._writer, daemon=True)
+            self._thread.start()
+        self._queue.put((db, key, data))
 
     def save(self, key, val):
         key = str(key)
@@ -123,6 +166,7 @@ class MapBsn(object):
                     if len(data):
                         seen.add(key)
                         self._save(tmp, key, data)
+            self._flush()
         self.conn.close()
         self.namelist = seen
         os.rename(tmp_name, self.fname)

@@ -14,6 +14,8 @@ the tools raise.
 """
 import os
 import sys
+from itertools import chain
+from operator import itemgetter
 
 import numpy as np
 import pandas as pd
@@ -208,14 +210,14 @@ def cigar2score(data):
 
 def _encode_cigars(cigars):
     """list of [[n, op], ...] -> (uint32 arena len<<2|op, offsets, counts)"""
-    counts = np.array([len(c) for c in cigars], dtype=np.int64)
+    n = len(cigars)
+    counts = np.fromiter(map(len, cigars), dtype=np.int64, count=n)
     offs = np.concatenate([[0], np.cumsum(counts)])
-    arena = np.empty(int(offs[-1]), dtype=np.uint32)
-    k = 0
-    for c in cigars:
-        for n, op in c:
-            arena[k] = (int(n) << 2) | _OP_CODE[op]
-            k += 1
+    total = int(offs[-1])
+    flat = list(chain.from_iterable(cigars))                 # the [n, op] pairs of all rows, one after the other
+    lens = np.fromiter(map(itemgetter(0), flat), dtype=np.int64, count=total)
+    ops = np.fromiter(map(_OP_CODE.__getitem__, map(itemgetter(1), flat)), dtype=np.int64, count=total)
+    arena = ((lens << 2) | ops).astype(np.uint32)
     return arena, offs[:-1], counts
 
 
@@ -466,7 +468,7 @@ class RunBlast(object):
                 p[7] += d
                 p[9] += d if fwd else -d
                 cigar[-1][0] += d
-            p[14] = ''.join('{0}{1}'.format(n, t) for n, t in cigar)
+            p[14] = ''.join([str(n) + t for n, t in cigar])
 
 
 def uberBlast(args, extPool=None):
