@@ -138,20 +138,20 @@ __global__ __launch_bounds__(256) void seed_fill(SeedShape sh, const uint8_t *__
 // fine buckets inside LDS by one block, which also writes its slice of start[] and of the occupancy bitmap.
 // bucket = coarse << F | fine, C + F = bucket_bits.  A coarse bucket that does not fit LDS (pathologically repetitive input) raises
 // a flag and the host rebuilds with the count -> scan -> fill kernels.
-constexpr int PART_TILES = 16;                 // 256-position tiles per block in the two partition passes
+constexpr int PART_TILES = 16;                 // 256-position tiles per block in the two partition passes (more for large query sets: <= 2048 blocks)
 constexpr int PART_CAP = 5632;                 // entries of one coarse bucket that fit LDS next to 4096 fine counters
 
 template <int W>
 __global__ __launch_bounds__(256) void idx_hist(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, int bucket_bits, int fine_bits,
-                                                uint32_t *__restrict__ hist, uint32_t n_blocks)
+                                                uint32_t *__restrict__ hist, uint32_t n_blocks, int tiles)
 {
     extern __shared__ uint32_t part_lds[];
     uint32_t *h = part_lds;                                  // 2^C counters
     uint8_t *red = reinterpret_cast<uint8_t *>(h + (1u << (bucket_bits - fine_bits)));
     const uint32_t n_coarse = 1u << (bucket_bits - fine_bits);
     for (uint32_t x = threadIdx.x; x < n_coarse; x += 256) h[x] = 0;
-    for (int t = 0; t < PART_TILES; ++t) {
-        const uint64_t base = ((uint64_t)blockIdx.x * PART_TILES + t) * TILE;
+    for (int t = 0; t < tiles; ++t) {
+        const uint64_t base = ((uint64_t)blockIdx.x * tiles + t) * TILE;
         __syncthreads();
         if (base >= total) break;                           // block-uniform
         stage_reduced(sh, res, base, total, red);
@@ -166,15 +166,15 @@ __global__ __launch_bounds__(256) void idx_hist(SeedShape sh, const uint8_t *__r
 
 template <int W>
 __global__ __launch_bounds__(256) void idx_scatter(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, int bucket_bits, int fine_bits,
-                                                   const uint32_t *__restrict__ hist_scan, uint32_t n_blocks, uint64_t *__restrict__ part)
+                                                   const uint32_t *__restrict__ hist_scan, uint32_t n_blocks, uint64_t *__restrict__ part, int tiles)
 {
     extern __shared__ uint32_t part_lds[];
     uint32_t *at = part_lds;                                 // running write position of every coarse bucket for this block
     const uint32_t n_coarse = 1u << (bucket_bits - fine_bits);
     uint8_t *red = reinterpret_cast<uint8_t *>(at + n_coarse);
     for (uint32_t x = threadIdx.x; x < n_coarse; x += 256) at[x] = hist_scan[(uint64_t)x * n_blocks + blockIdx.x];
-    for (int t = 0; t < PART_TILES; ++t) {
-        const uint64_t base = ((uint64_t)blockIdx.x * PART_TILES + t) * TILE;
+    for (int t = 0; t < tiles; ++t) {
+        const uint64_t base = ((uint64_t)blockIdx.x * tiles + t) * TILE;
         __syncthreads();
         if (base >= total) break;
         stage_reduced(sh, res, base, total, red);
@@ -602,7 +602,11 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     ctx->stats.query_seeds = ctx->stats.target_seeds = ctx->stats.seed_hits = 0;
     if (Q.n == 0 || T.n == 0) return PEP_OK;
 
-    const int bucket_bits = std::max(10, std::min(28, ilog2_ceil(2 * Q.total)));
+    // two buckets per query position, except that up to 2^25 positions stay at 2^25 buckets: that is the largest index the partition
+    // build handles (2^13 coarse x 2^12 fine buckets), which is worth more than the last halving of the load (the filter in front of
+    // the index keeps most foreign keys away from the buckets anyway)
+    int bucket_bits = std::max(10, std::min(28, ilog2_ceil(2 * Q.total)));
+    if (bucket_bits == 26 && P.reserved[2] == 0) bucket_bits = 25;
     const uint64_t n_buckets = 1ull << bucket_bits;
     PEP_TRY(dev_reserve(ctx, ctx->ws[0], (n_buckets + 1) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_buckets + 2) * sizeof(uint32_t)));
@@ -674,14 +678,15 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     } while (0)
             if (use_partition) {
                 // partition build: [coarse][block] histogram -> scan -> scatter into coarse buckets -> per-bucket LDS sort
-                const unsigned pb = (unsigned)ceil_div(Q.total, (uint64_t)PART_TILES * TILE);
+                const int tiles = (int)std::max<uint64_t>(PART_TILES, ceil_div(Q.total, (uint64_t)TILE * 2048));
+                const unsigned pb = (unsigned)ceil_div(Q.total, (uint64_t)tiles * TILE);
                 const uint32_t n_coarse = 1u << (bucket_bits - fine_bits);
                 const size_t lds = (size_t)n_coarse * 4 + TILE + TILE_HALO;
                 PEP_TRY(dev_reserve(ctx, ctx->ws[13], (Q.total + 1) * sizeof(uint64_t)));
                 uint64_t *part = ctx->ws[13].as<uint64_t>();
-                PEP_SEED_DISPATCH_LDS(idx_hist, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, cnt, pb);
+                PEP_SEED_DISPATCH_LDS(idx_hist, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, cnt, pb, tiles);
                 PEP_TRY(pep_scan_u32(ctx, cnt, cnt, (uint64_t)n_coarse * pb, ctx->ws[7]));
-                PEP_SEED_DISPATCH_LDS(idx_scatter, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, (const uint32_t *)cnt, pb, part);
+                PEP_SEED_DISPATCH_LDS(idx_scatter, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, (const uint32_t *)cnt, pb, part, tiles);
                 hipLaunchKernelGGL(idx_finish, dim3(n_coarse), dim3(256), 0, ctx->stream, (const uint64_t *)part, (const uint32_t *)cnt, pb, bucket_bits, fine_bits,
                                    start, entries, filter, counters);
             } else {
