@@ -64,7 +64,7 @@ typedef struct {
     int32_t weight[4];
     int32_t offs[4][32];
     uint8_t reduce[32];           /* residue code -> reduced letter; 0xFF never seeds */
-    int8_t sub[1024];             /* substitution score [q*32 + t] */
+    int8_t sub[1024];             /* substitution score [q*32 + t]; row and column 31 (padding code) must be <= -64 */
     double min_id_pct;            /* --id           (100 * identities / alignment length) */
     double min_qcov_pct;          /* --query-cover  (100 * aligned query span / query length) */
     int32_t top_k;                /* -k : targets kept per query per split */

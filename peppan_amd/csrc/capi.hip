@@ -490,6 +490,10 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         if (!(params->ka_lambda > 0.) || !(params->ka_k > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "invalid Karlin-Altschul parameters");
         if (params->xdrop < 0 || params->xdrop > 48 || params->ext_right < 1 || params->ext_right > 48 || params->ext_left < 0 || params->ext_left > 48)
             return pep_fail(ctx, PEP_ERR_ARG, "invalid ungapped-extension parameters");
+        // code 31 is the padding between packed sequences: its scores end every extension and keep the DP out of the padding
+        for (int c = 0; c < 32; ++c)
+            if (params->sub[PEP_PAD_CODE * 32 + c] > -64 || params->sub[c * 32 + PEP_PAD_CODE] > -64)
+                return pep_fail(ctx, PEP_ERR_ARG, "substitution table: row and column 31 (the padding code) must be <= -64");
         ctx->params = *params;
         ctx->sub_ready = false;
     }

@@ -522,6 +522,9 @@ def test_c_abi_error_conventions():
         bad = N.default_params(); bad.hsp_mode = 7
         with pytest.raises(N.PepError, match='hsp_mode'):
             c.search(bad)
+        bad = N.default_params(); bad.sub[31 * 32 + 3] = 5
+        with pytest.raises(N.PepError, match='padding code'):
+            c.search(bad)
         with pytest.raises(N.PepError, match='frames'):
             c.set_ref_nt([b'ACGT'], frames=5)
         with pytest.raises(N.PepError, match='out of range'):
@@ -887,6 +890,10 @@ def test_search_parameter_fuzz(ctx, seed):
     p.xdrop, p.ext_right, p.ext_left = int(rng.integers(8, 21)), int(rng.integers(20, 49)), int(rng.integers(0, 41))
     p.hsp_mode = int(rng.integers(0, 2))
     p.max_evalue = float(rng.choice([1., 1e-3, 10.]))
+    if seed % 3 == 0:                            # a steeper substitution table (x3): the 16-bit passes must size their eligibility from it
+        for x in range(1024):
+            if x // 32 != 31 and x % 32 != 31:   # (row / column 31 = the padding code: stays at -64, the library checks it)
+                p.sub[x] = max(-128, int(p.sub[x]) * 3)
     nq = int(rng.integers(1, len(prots)))
     ctx.set_query_aa(prots[:nq]); ctx.set_ref_aa(prots)
     gh, gc, st = ctx.search(p)
