@@ -59,7 +59,7 @@ typedef struct pep_result pep_result;
 /* search parameters; pep_default_params fills the protein defaults that mirror the reference's
  * diamond command line (uberBlast.py:550): BLOSUM62, gap 11/1, --evalue 1, --dbsize 5000000, -k 10, 5 splits */
 typedef struct {
-    int32_t gap_open, gap_ext;
+    int32_t gap_open, gap_ext;    /* a gap of length k costs gap_open + k * gap_ext; 0 <= gap_open <= 255, 1 <= gap_ext <= 255 */
     int32_t n_shapes, base;       /* spaced seeds over a reduced alphabet of `base` letters */
     int32_t weight[4];
     int32_t offs[4][32];

@@ -477,6 +477,9 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     if (params) {
         if (params->n_shapes < 1 || params->n_shapes > 4 || params->base < 2 || params->top_k < 1 || params->n_splits < 1)
             return pep_fail(ctx, PEP_ERR_ARG, "invalid search parameters");
+        // (the packed 16-bit passes keep H - open - extend inside a signed half word)
+        if (params->gap_open < 0 || params->gap_open > 255 || params->gap_ext < 1 || params->gap_ext > 255)
+            return pep_fail(ctx, PEP_ERR_ARG, "gap costs: 0 <= gap_open <= 255 and 1 <= gap_ext <= 255");
         for (int s = 0; s < params->n_shapes; ++s) {
             if (params->weight[s] < 1 || params->weight[s] > 32) return pep_fail(ctx, PEP_ERR_ARG, "invalid seed weight");
             if (params->offs[s][params->weight[s] - 1] > 31) return pep_fail(ctx, PEP_ERR_ARG, "seed span above 32");
@@ -488,6 +491,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         }
         if (params->hsp_mode != 0 && params->hsp_mode != 1) return pep_fail(ctx, PEP_ERR_ARG, "hsp_mode must be 0 or 1");
         if (!(params->ka_lambda > 0.) || !(params->ka_k > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "invalid Karlin-Altschul parameters");
+        if (!(params->dbsize > 0.) || !(params->max_evalue > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "dbsize and max_evalue must be positive");
         if (params->xdrop < 0 || params->xdrop > 48 || params->ext_right < 1 || params->ext_right > 48 || params->ext_left < 0 || params->ext_left > 48)
             return pep_fail(ctx, PEP_ERR_ARG, "invalid ungapped-extension parameters");
         // code 31 is the padding between packed sequences: its scores end every extension and keep the DP out of the padding

@@ -522,6 +522,9 @@ def test_c_abi_error_conventions():
         bad = N.default_params(); bad.hsp_mode = 7
         with pytest.raises(N.PepError, match='hsp_mode'):
             c.search(bad)
+        bad = N.default_params(); bad.gap_ext = 0
+        with pytest.raises(N.PepError, match='gap costs'):
+            c.search(bad)
         bad = N.default_params(); bad.sub[31 * 32 + 3] = 5
         with pytest.raises(N.PepError, match='padding code'):
             c.search(bad)
