@@ -10,6 +10,7 @@ int pep_fail(pep_ctx *ctx, int code, const std::string &msg)
     if (ctx) {
         ctx->err = msg;
         ctx->n_pending = 0;              // queued read-backs point at the failing caller's locals: drop them
+        ctx->sw_totals_pending = false;
         ctx->pin_small_used = 0;
     }
     return code;
@@ -46,6 +47,27 @@ int pin_reserve(pep_ctx *ctx, PinBuf &b, size_t bytes)
     PEP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&b.p), want, hipHostMallocDefault));
     b.cap = want;
     return PEP_OK;
+}
+
+void pep_timer_begin(pep_ctx *ctx, int id)
+{
+    if (!ctx->tm_a[id] && (hipEventCreate(&ctx->tm_a[id]) != hipSuccess || hipEventCreate(&ctx->tm_b[id]) != hipSuccess)) { ctx->tm_a[id] = nullptr; return; }
+    ctx->tm_state[id] = hipEventRecord(ctx->tm_a[id], ctx->stream) == hipSuccess ? 1 : 0;
+}
+
+void pep_timer_end(pep_ctx *ctx, int id)
+{
+    if (ctx->tm_state[id] == 1) ctx->tm_state[id] = hipEventRecord(ctx->tm_b[id], ctx->stream) == hipSuccess ? 2 : 0;
+}
+
+void pep_timers_resolve(pep_ctx *ctx)
+{
+    double *dst[TM_COUNT] = {&ctx->stats.ms_seed, &ctx->stats.ms_total, &ctx->stats.ms_sw, &ctx->stats.ms_sw_trace, &ctx->stats.ms_trace};
+    for (int id = 0; id < TM_COUNT; ++id) {
+        float ms = 0.f;
+        if (ctx->tm_state[id] == 2 && hipEventSynchronize(ctx->tm_b[id]) == hipSuccess && hipEventElapsedTime(&ms, ctx->tm_a[id], ctx->tm_b[id]) == hipSuccess) *dst[id] = ms;
+        ctx->tm_state[id] = 0;
+    }
 }
 
 int pep_read_back(pep_ctx *ctx, void *dst, const void *d_src, size_t n)
@@ -321,6 +343,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     for (auto &b : ctx->ws) dev_release(b);
+    for (int id = 0; id < TM_COUNT; ++id) { if (ctx->tm_a[id]) (void)hipEventDestroy(ctx->tm_a[id]); if (ctx->tm_b[id]) (void)hipEventDestroy(ctx->tm_b[id]); }
     if (ctx->staged_result) pep_materialise_staged(ctx);
     if (ctx->pin_small.p) (void)hipHostFree(ctx->pin_small.p);
     if (ctx->pin_stage.p) (void)hipHostFree(ctx->pin_stage.p);
@@ -515,10 +538,11 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     ctx->stats.query_residues = ctx->q.residues;
     ctx->stats.target_residues = ctx->t.residues;
 
-    EventTimer t_seed(ctx->stream), t_total(ctx->stream);
+    for (int id = 0; id < TM_COUNT; ++id) ctx->tm_state[id] = 0;
+    pep_timer_begin(ctx, TM_SEED); pep_timer_begin(ctx, TM_TOTAL);
     uint64_t *d_cands = nullptr, n_cands = 0;
     int rc = pep_find_candidates(ctx, &d_cands, &n_cands);
-    const float ms_seed = t_seed.stop();
+    pep_timer_end(ctx, TM_SEED);
     if (rc == PEP_OK) {
         std::vector<int32_t> min_score(ctx->q.n + 1);
         // the threshold depends on the length only and lengths repeat: one logarithm per distinct length (direct-mapped memo)
@@ -535,13 +559,11 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         }
         rc = pep_extend(ctx, d_cands, n_cands, min_score.data(), res);
     }
-    const float ms_all = t_total.stop();
+    pep_timer_end(ctx, TM_TOTAL);
     const hipError_t se = hipStreamSynchronize(ctx->stream);
     if (rc == PEP_OK && se != hipSuccess) rc = pep_fail(ctx, PEP_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
-    const float a = ms_seed, b = ms_all;
     if (rc != PEP_OK) { delete res; return rc; }
-    ctx->stats.ms_seed = a;
-    ctx->stats.ms_total = b;
+    pep_timers_resolve(ctx);
     res->stats = ctx->stats;
     if (res->st_hits || res->st_cigar) ctx->staged_result = res;
     *out = res;

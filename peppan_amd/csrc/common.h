@@ -104,6 +104,12 @@ struct pep_ctx {
     DevBuf ws[24];
     DevBuf sub_lds;                         // replicated substitution table image (32 KiB)
     DevBuf d_params;                        // device copy of seed params
+    // phase timers: events recorded on the stream, read once after the search's final synchronisation (waiting for an end event in
+    // the middle of a search costs a host round trip with the GPU idle, and lets nothing be queued behind a running SW pass)
+    hipEvent_t tm_a[6] = {}, tm_b[6] = {};
+    int tm_state[6] = {};                   // 0 idle, 1 begun, 2 ended (waiting to be read)
+    unsigned long long sw_totals[2] = {};   // score pass: cells / 16-step blocks, read back with the next synchronisation
+    bool sw_totals_pending = false;
     DevBuf scan_state;                      // single-launch scan: ticket counter + one status word per tile (scan.hip)
     uint32_t scan_epoch = 0, scan_ticket_base = 0;
     // stats of the last search
@@ -145,6 +151,11 @@ struct EventTimer {
     EventTimer(const EventTimer &) = delete;
     EventTimer &operator=(const EventTimer &) = delete;
 };
+
+enum PepTimer { TM_SEED = 0, TM_TOTAL, TM_SW, TM_SW_TRACE, TM_TRACE, TM_COUNT };
+void pep_timer_begin(pep_ctx *ctx, int id);
+void pep_timer_end(pep_ctx *ctx, int id);
+void pep_timers_resolve(pep_ctx *ctx);     // after a stream synchronisation: elapsed times -> ctx->stats.ms_*
 
 int pep_fail(pep_ctx *ctx, int code, const std::string &msg);
 // small device -> host reads: queue any number with pep_read_back (async copy into the pinned page), then ONE pep_sync_reads

@@ -615,19 +615,22 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
                        ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist);
     hipLaunchKernelGGL(sw_order, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[10].as<const uint32_t>(), n,
                        (const uint32_t *)len_hist, cursor, order);
-    uint64_t total_blk = 0;
-    unsigned long long h_cells = 0;
-    PEP_TRY(pep_read_back(ctx, &h_cells, cells, 8));
-    PEP_TRY(pep_read_back(ctx, &total_blk, cells + 1, 8));
     if (trace) {
         // the traceback area is sized from the block total, so the host has to see it before the launch; the score pass needs neither
-        // the per-candidate offsets nor the totals up front (they are folded into the statistics after the kernel)
+        // the per-candidate offsets nor the totals up front (they reach the statistics with the next synchronisation, see pep_extend)
+        uint64_t total_blk = 0;
+        unsigned long long h_cells = 0;
+        PEP_TRY(pep_read_back(ctx, &h_cells, cells, 8));
+        PEP_TRY(pep_read_back(ctx, &total_blk, cells + 1, 8));
         PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
         PEP_TRY(pep_sync_reads(ctx));
         ctx->stats.cells_trace += h_cells;
         ctx->stats.cells_swept_trace += total_blk * 16 * 64;
         ctx->stats.dir_bytes += total_blk * 512;
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 512 + 512));
+    } else {
+        PEP_TRY(pep_read_back(ctx, ctx->sw_totals, cells, 16));
+        ctx->sw_totals_pending = true;
     }
 
     SwArgs a;
@@ -654,17 +657,11 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, fl
     // table load per block comes out of the L2
     const uint64_t items = ceil_div(a.pk16 ? (n + 1) / 2 : n, WAVES_PER_BLOCK);
     const unsigned grid = (unsigned)std::min<uint64_t>(items, 256ull * 256);
-    EventTimer timer(ctx->stream);
+    pep_timer_begin(ctx, trace ? TM_SW_TRACE : TM_SW);
     if (trace) hipLaunchKernelGGL(sw_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     else hipLaunchKernelGGL(sw_score_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+    pep_timer_end(ctx, trace ? TM_SW_TRACE : TM_SW);
     PEP_HIP(ctx, hipGetLastError());
-    *ms_kernel = timer.stop();
-    PEP_HIP(ctx, hipGetLastError());
-    if (!trace) {
-        PEP_TRY(pep_sync_reads(ctx));             // the stream is idle here: this only stores the values queued before the launch
-        ctx->stats.cells += h_cells;
-        ctx->stats.cells_swept += total_blk * 16 * 64;
-    }
     ctx->stats.sw_launches += 1;
     return PEP_OK;
 }

@@ -302,11 +302,10 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     if (n == 0) return PEP_OK;
     hipStream_t st = ctx->stream;
     // ---- pass 1: score-only banded SW over every candidate
-    float ms_sw = 0.f;
-    PEP_TRY(pep_sw_run(ctx, d_cands, n, false, &ms_sw));
-    ctx->stats.ms_sw = ms_sw;
+    float ms_unused = 0.f;                       // (the pass times come from the context's phase timers, read after the search)
+    PEP_TRY(pep_sw_run(ctx, d_cands, n, false, &ms_unused));
 
-    EventTimer timer(st);
+    pep_timer_begin(ctx, TM_TRACE);
 
     const int4 *sw = ctx->ws[12].as<const int4>();
     PEP_TRY(dev_reserve(ctx, ctx->ws[16], (n + 1) * 4));
@@ -327,6 +326,11 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     PEP_TRY(pep_read_back(ctx, &n_sel, pos + n, 4));
     PEP_TRY(pep_read_back(ctx, &n_pairs, counters, 4));
     PEP_TRY(pep_sync_reads(ctx));
+    if (ctx->sw_totals_pending) {                // the score pass's totals arrived with this synchronisation
+        ctx->stats.cells += ctx->sw_totals[0];
+        ctx->stats.cells_swept += ctx->sw_totals[1] * 16 * 64;
+        ctx->sw_totals_pending = false;
+    }
     ctx->stats.pairs = n_pairs;
     ctx->stats.tracebacks = n_sel;
     if (n_sel) {
@@ -343,9 +347,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         PEP_TRY(pep_read_back(ctx, &total_runs, run_off + n_sel, 8));
         PEP_TRY(pep_sync_reads(ctx));
         // ---- pass 2: the same DP with traceback codes, selected pairs only (overwrites the pass-1 per-candidate arrays)
-        float ms_tr = 0.f;
-        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, &ms_tr, known));
-        ctx->stats.ms_sw_trace = ms_tr;
+        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, &ms_unused, known));
         const int4 *sw2 = ctx->ws[12].as<const int4>();
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
         uint32_t *runs = ctx->ws[21].as<uint32_t>();
@@ -397,7 +399,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
             res->n_hits = n_hits; res->n_cigar = n_cig;
         }
     }
-    ctx->stats.ms_trace = timer.stop();
+    pep_timer_end(ctx, TM_TRACE);
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }
