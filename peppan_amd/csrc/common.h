@@ -80,6 +80,7 @@ struct pep_ctx {
     int n_pending = 0;
     PinBuf pin_k1;                          // grow-only: K1 descriptors
     PinBuf pin_stage;                       // grow-only: the hit table of the newest search
+    PinBuf pin_ms;                          // grow-only: per-query score thresholds on their way to the device
     pep_result *staged_result = nullptr;    // the result whose hits still live in pin_stage (materialised before it is overwritten)
     std::string err;
     pep_search_params params;

@@ -2,6 +2,7 @@
 // run-length encode the CIGAR, count identities, apply the identity / query-cover filters and the
 // per-(query, split) top-k, and emit fixed-size hit records + a CIGAR arena ordered by (q, t).
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -302,6 +303,13 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     if (n == 0) return PEP_OK;
     hipStream_t st = ctx->stream;
     // ---- pass 1: score-only banded SW over every candidate
+    // per-query score thresholds: uploaded from pinned memory BEFORE the score pass is queued (a copy from pageable memory makes the
+    // host wait for everything queued ahead of it - behind the score pass that was the whole pass)
+    DevBuf &dms = ctx->d_min_score;
+    PEP_TRY(dev_reserve(ctx, dms, (size_t)(ctx->q.n + 1) * 4));
+    PEP_TRY(pin_reserve(ctx, ctx->pin_ms, (size_t)(ctx->q.n + 1) * 4));
+    std::memcpy(ctx->pin_ms.p, h_min_score, (size_t)ctx->q.n * 4);
+    PEP_HIP(ctx, hipMemcpyAsync(dms.p, ctx->pin_ms.p, (size_t)ctx->q.n * 4, hipMemcpyHostToDevice, st));
     float ms_unused = 0.f;                       // (the pass times come from the context's phase timers, read after the search)
     PEP_TRY(pep_sw_run(ctx, d_cands, n, false, &ms_unused));
 
@@ -312,10 +320,6 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     PEP_TRY(dev_reserve(ctx, ctx->ws[17], (n + 2) * 4));
     PEP_TRY(dev_reserve(ctx, ctx->ws[18], (n + 1) * 4));
     PEP_TRY(dev_reserve(ctx, ctx->ws[9], 256));
-    // per-query score thresholds
-    DevBuf &dms = ctx->d_min_score;
-    PEP_TRY(dev_reserve(ctx, dms, (size_t)(ctx->q.n + 1) * 4));
-    PEP_HIP(ctx, hipMemcpyAsync(dms.p, h_min_score, (size_t)ctx->q.n * 4, hipMemcpyHostToDevice, st));
     uint32_t *flag = ctx->ws[16].as<uint32_t>(), *pos = ctx->ws[17].as<uint32_t>(), *best_idx = ctx->ws[18].as<uint32_t>();
     uint32_t *counters = ctx->ws[9].as<uint32_t>();
     PEP_HIP(ctx, hipMemsetAsync(counters, 0, 256, st));
@@ -344,8 +348,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
                            ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known);
         PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_sel, ctx->ws[7]));
         uint64_t total_runs = 0;
-        PEP_TRY(pep_read_back(ctx, &total_runs, run_off + n_sel, 8));
-        PEP_TRY(pep_sync_reads(ctx));
+        PEP_TRY(pep_read_back(ctx, &total_runs, run_off + n_sel, 8));       // arrives with the synchronisation inside pep_sw_run (block total)
         // ---- pass 2: the same DP with traceback codes, selected pairs only (overwrites the pass-1 per-candidate arrays)
         PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, &ms_unused, known));
         const int4 *sw2 = ctx->ws[12].as<const int4>();
