@@ -349,7 +349,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_stage.p) (void)hipHostFree(ctx->pin_stage.p);
     if (ctx->pin_k1.p) (void)hipHostFree(ctx->pin_k1.p);
     if (ctx->pin_ms.p) (void)hipHostFree(ctx->pin_ms.p);
-    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state, &ctx->d_min_score, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
+    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->d_min_score, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -522,8 +522,8 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         for (int c = 0; c < 32; ++c)
             if (params->sub[PEP_PAD_CODE * 32 + c] > -64 || params->sub[c * 32 + PEP_PAD_CODE] > -64)
                 return pep_fail(ctx, PEP_ERR_ARG, "substitution table: row and column 31 (the padding code) must be <= -64");
+        if (memcmp(ctx->params.sub, params->sub, sizeof(params->sub)) != 0) ctx->sub_ready = false;      // the LDS image follows the table only
         ctx->params = *params;
-        ctx->sub_ready = false;
     }
     PEP_TRY(pep_translate(ctx, 0));
     if (!ctx->q_ready || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "pep_search before both sequence sets were given");

@@ -111,8 +111,8 @@ struct pep_ctx {
     int tm_state[6] = {};                   // 0 idle, 1 begun, 2 ended (waiting to be read)
     unsigned long long sw_totals[2] = {};   // score pass: cells / 16-step blocks, read back with the next synchronisation
     bool sw_totals_pending = false;
-    DevBuf scan_state;                      // single-launch scan: ticket counter + one status word per tile (scan.hip)
-    uint32_t scan_epoch = 0, scan_ticket_base = 0;
+    struct ScanState { DevBuf buf; uint32_t epoch = 0, ticket_base = 0; };
+    ScanState scan_state[2];                // single-launch scans (u32, u64): ticket counter + one status word per tile (scan.hip)
     // stats of the last search
     pep_stats stats;
 };

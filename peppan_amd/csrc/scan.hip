@@ -2,7 +2,8 @@
 // u32: ONE launch - every tile publishes its sum, looks back over the tiles before it (a wavefront inspects 64 predecessors at a
 // time) and publishes its inclusive prefix ("decoupled look-back").  Reads the input once and writes it once; the searches run a
 // dozen short scans per pass, so the two launches saved per scan matter more than the bytes.
-// u64 (three per search): per-tile reduce -> scan of the tile sums (one block) -> per-tile scan + offset.
+// u64: the same with 48-bit sums in the status word.  (n = 0 or n >= 2^40: per-tile reduce -> scan of the tile sums -> per-tile
+// scan + offset.)
 #include "common.h"
 
 namespace {
@@ -101,38 +102,47 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_apply(const T *in, T *out, 
 // up to and including the tile.  The epoch is a per-call number: words left by earlier scans never match, so nothing is cleared.
 constexpr uint64_t FLAG_SUM = 1, FLAG_PREFIX = 2;
 
-__global__ __launch_bounds__(SCAN_THREADS) void scan_lookback(const uint32_t *in, uint32_t *out, uint64_t n, uint32_t nb, uint64_t *state,
-                                                              uint32_t ticket_base, uint64_t epoch)
+// status word layout: value in the low VB bits, flag in the next two, epoch above.  u32 sums: 32 value bits, 30 epoch bits.
+// u64 sums (block / run / CIGAR totals, all far below 2^48): 48 value bits, 14 epoch bits - the state is cleared every 2^14 - 1 scans.
+template <class T> struct ScanWord;
+template <> struct ScanWord<uint32_t> { static constexpr int VB = 32; static constexpr uint32_t EPOCH_MASK = (1u << 30) - 1; };
+template <> struct ScanWord<uint64_t> { static constexpr int VB = 48; static constexpr uint32_t EPOCH_MASK = (1u << 14) - 1; };
+
+template <class T>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_lookback(const T *in, T *out, uint64_t n, uint32_t nb, uint64_t *state, uint32_t ticket_base, uint64_t epoch)
 {
-    __shared__ uint32_t lds[4];
-    __shared__ uint32_t s_tile, s_prefix;
+    constexpr int VB = ScanWord<T>::VB;
+    constexpr uint64_t VMASK = (1ull << VB) - 1;
+    __shared__ T lds[4];
+    __shared__ uint32_t s_tile;
+    __shared__ T s_prefix;
     if (threadIdx.x == 0) s_tile = atomicAdd(reinterpret_cast<uint32_t *>(state), 1u) - ticket_base;
     __syncthreads();
     const uint32_t tile = s_tile;
     uint64_t *status = state + 1;
     const uint64_t base = (uint64_t)tile * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
-    uint32_t v[SCAN_ITEMS], s = 0;
+    T v[SCAN_ITEMS], s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         v[k] = (base + k < n) ? in[base + k] : 0;
         s += v[k];
     }
-    uint32_t tot;
-    uint32_t ex = block_excl_scan(s, &tot, lds);
+    T tot;
+    T ex = block_excl_scan(s, &tot, lds);
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        uint32_t prefix = 0;
+        T prefix = 0;
         if (tile > 0) {
-            if (lane == 0) __hip_atomic_store(&status[tile], (epoch << 34) | (FLAG_SUM << 32) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(&status[tile], (epoch << (VB + 2)) | (FLAG_SUM << VB) | ((uint64_t)tot & VMASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // window of 64 predecessors, lane 0 = the nearest; stop at the nearest tile that already knows its inclusive prefix
             for (int64_t hi = (int64_t)tile - 1; hi >= 0; hi -= 64) {
                 const int64_t idx = hi - lane;
-                uint64_t w = (epoch << 34) | (FLAG_PREFIX << 32);                 // before tile 0: prefix 0
+                uint64_t w = (epoch << (VB + 2)) | (FLAG_PREFIX << VB);           // before tile 0: prefix 0
                 if (idx >= 0)
-                    do { w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> 34) != epoch);
-                const uint64_t is_prefix = __ballot(((w >> 32) & 3u) == FLAG_PREFIX);
+                    do { w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((w >> (VB + 2)) != epoch);
+                const uint64_t is_prefix = __ballot(((w >> VB) & 3u) == FLAG_PREFIX);
                 const int stop = is_prefix ? __ffsll((unsigned long long)is_prefix) - 1 : 63;      // lanes 0..stop contribute
-                uint32_t part = lane <= stop ? (uint32_t)w : 0u;
+                T part = lane <= stop ? (T)(w & VMASK) : (T)0;
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
                 prefix += part;
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lookback(const uint32_t *in
             }
         }
         if (lane == 0) {
-            __hip_atomic_store(&status[tile], (epoch << 34) | (FLAG_PREFIX << 32) | (uint32_t)(prefix + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&status[tile], (epoch << (VB + 2)) | (FLAG_PREFIX << VB) | ((uint64_t)(prefix + tot) & VMASK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_prefix = prefix;
         }
     }
@@ -154,24 +164,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lookback(const uint32_t *in
     if (tile == nb - 1 && threadIdx.x == SCAN_THREADS - 1) out[n] = ex;
 }
 
-int scan_u32_onepass(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n)
+template <class T>
+int scan_onepass(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n)
 {
     const uint64_t nb = ceil_div(n, SCAN_TILE);
-    if ((nb + 1) * sizeof(uint64_t) > ctx->scan_state.cap) {
+    pep_ctx::ScanState &S = ctx->scan_state[sizeof(T) == 8];       // one state area per width: the two word layouts must never meet
+    bool clear = false;
+    if ((nb + 1) * sizeof(uint64_t) > S.buf.cap) {
         // a new (or larger) state area starts from zeros: epoch 0 is never used, so no word of it can pass for a published one
-        PEP_TRY(dev_reserve(ctx, ctx->scan_state, (nb + 1) * sizeof(uint64_t) * 2));
-        PEP_HIP(ctx, hipMemsetAsync(ctx->scan_state.p, 0, ctx->scan_state.cap, ctx->stream));
-        ctx->scan_ticket_base = 0;
+        PEP_TRY(dev_reserve(ctx, S.buf, (nb + 1) * sizeof(uint64_t) * 2));
+        clear = true;
     }
-    ctx->scan_epoch = (ctx->scan_epoch + 1) & ((1u << 30) - 1);
-    if (ctx->scan_epoch == 0) {             // wrapped: forget every old word
-        PEP_HIP(ctx, hipMemsetAsync(ctx->scan_state.p, 0, ctx->scan_state.cap, ctx->stream));
-        ctx->scan_ticket_base = 0;
-        ctx->scan_epoch = 1;
+    S.epoch = (S.epoch + 1) & ScanWord<T>::EPOCH_MASK;
+    if (S.epoch == 0) { clear = true; S.epoch = 1; }   // wrapped: forget every old word
+    if (clear) {
+        PEP_HIP(ctx, hipMemsetAsync(S.buf.p, 0, S.buf.cap, ctx->stream));
+        S.ticket_base = 0;
     }
-    hipLaunchKernelGGL(scan_lookback, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, n, (uint32_t)nb, ctx->scan_state.as<uint64_t>(),
-                       ctx->scan_ticket_base, (uint64_t)ctx->scan_epoch);
-    ctx->scan_ticket_base += (uint32_t)nb;
+    hipLaunchKernelGGL(scan_lookback<T>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, n, (uint32_t)nb, S.buf.as<uint64_t>(), S.ticket_base,
+                       (uint64_t)S.epoch);
+    S.ticket_base += (uint32_t)nb;
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }
@@ -198,6 +210,13 @@ int scan_impl(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n, DevBuf &tmp)
 int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp)
 {
     if (n == 0 || n >= (1ull << 40)) return scan_impl<uint32_t>(ctx, d_in, d_out, n, tmp);
-    return scan_u32_onepass(ctx, d_in, d_out, n);
+    return scan_onepass<uint32_t>(ctx, d_in, d_out, n);
 }
-int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp) { return scan_impl<uint64_t>(ctx, d_in, d_out, n, tmp); }
+
+// the single launch carries 48-bit sums; callers whose totals could pass 2^48 say so (none does: the u64 scans add up block, run and
+// CIGAR counts of one search)
+int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp)
+{
+    if (n == 0 || n >= (1ull << 40)) return scan_impl<uint64_t>(ctx, d_in, d_out, n, tmp);
+    return scan_onepass<uint64_t>(ctx, d_in, d_out, n);
+}
