@@ -90,7 +90,7 @@ struct pep_ctx {
     std::vector<pep_query_meta> q_meta;     // frame chosen per query (K1)
     std::vector<pep_target_meta> t_meta;    // (seq, frame, chunk offset, length) per target (K1)
     bool q_from_nt = false, t_from_nt = false;
-    bool q_ready = false, t_ready = false, sub_ready = false;
+    bool q_ready = false, t_ready = false, sub_ready = false, codon_ready = false;
     int q_gtable = 11, t_gtable = 11, t_frames = 6;
     // K1 reference side: chunk-slot prefix per (sequence, frame), a function of the input lengths only - kept between translations
     DevBuf d_k1_base;

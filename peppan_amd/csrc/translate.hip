@@ -188,9 +188,11 @@ void fill_codon_table(uint8_t tab[2][64])
 
 int upload_codon_table(pep_ctx *ctx)
 {
+    if (ctx->codon_ready) return PEP_OK;            // (a constant of the device's code object: once per context is enough)
     uint8_t tab[2][64];
     fill_codon_table(tab);
-    PEP_HIP(ctx, hipMemcpyToSymbolAsync(HIP_SYMBOL(c_codon), tab, sizeof(tab), 0, hipMemcpyHostToDevice, ctx->stream));
+    PEP_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_codon), tab, sizeof(tab), 0, hipMemcpyHostToDevice));
+    ctx->codon_ready = true;
     return PEP_OK;
 }
 
