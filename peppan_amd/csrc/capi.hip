@@ -348,6 +348,9 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_small.p) (void)hipHostFree(ctx->pin_small.p);
     if (ctx->pin_stage.p) (void)hipHostFree(ctx->pin_stage.p);
     if (ctx->pin_k1.p) (void)hipHostFree(ctx->pin_k1.p);
+    if (ctx->pin_k1q.p) (void)hipHostFree(ctx->pin_k1q.p);
+    if (ctx->pin_k1n.p) (void)hipHostFree(ctx->pin_k1n.p);
+    if (ctx->k1_event) (void)hipEventDestroy(ctx->k1_event);
     if (ctx->pin_ms.p) (void)hipHostFree(ctx->pin_ms.p);
     DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->d_min_score, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq};
@@ -407,8 +410,12 @@ int pep_translate(pep_ctx *ctx, int force)
     if (!ctx) return PEP_ERR_ARG;
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     EventTimer timer(ctx->stream);
-    if (ctx->q_from_nt && (force || !ctx->q_ready)) { PEP_TRY(pep_k1_query(ctx, ctx->q_gtable)); ctx->q_ready = true; }
-    if (ctx->t_from_nt && (force || !ctx->t_ready)) { PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable)); ctx->t_ready = true; }
+    // both sides are queued first (reference, then queries); the reference's host-side tables are built while the query kernels run
+    const bool do_q = ctx->q_from_nt && (force || !ctx->q_ready), do_t = ctx->t_from_nt && (force || !ctx->t_ready);
+    if (do_t) PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable, 1));
+    if (do_q) PEP_TRY(pep_k1_query(ctx, ctx->q_gtable, 1));
+    if (do_t) { PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable, 2)); ctx->t_ready = true; }
+    if (do_q) { PEP_TRY(pep_k1_query(ctx, ctx->q_gtable, 2)); ctx->q_ready = true; }
     ctx->stats.ms_k1 = timer.stop();
     return PEP_OK;
 }

@@ -78,7 +78,9 @@ struct pep_ctx {
     size_t pin_small_used = 0;
     struct PendingRead { void *dst; size_t off, n; } pending[32];
     int n_pending = 0;
-    PinBuf pin_k1;                          // grow-only: K1 descriptors
+    PinBuf pin_k1, pin_k1q, pin_k1n;        // grow-only: K1 descriptors of the reference / of the queries, the target count
+    hipEvent_t k1_event = nullptr;          // the point of the stream where the reference side's downloads have arrived
+    bool k1_count_pending = false;
     PinBuf pin_stage;                       // grow-only: the hit table of the newest search
     PinBuf pin_ms;                          // grow-only: per-query score thresholds on their way to the device
     pep_result *staged_result = nullptr;    // the result whose hits still live in pin_stage (materialised before it is overwritten)
@@ -174,8 +176,8 @@ int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n
 // ---- sort.hip
 int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, int bits, DevBuf &hist);   // result in d_keys
 // ---- translate.hip  (K1)
-int pep_k1_query(pep_ctx *ctx, int gtable);
-int pep_k1_ref(pep_ctx *ctx, int frames, int gtable);
+int pep_k1_query(pep_ctx *ctx, int gtable, int phase = 0);
+int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase = 0);
 // ---- seeds.hip  (K2-K4)
 int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands);
 // ---- sw.hip / trace.hip (K5, K6, K8)

@@ -282,47 +282,65 @@ int finish_layout(pep_ctx *ctx, const PackDesc *desc, uint32_t n, SeqSet &out)
     return PEP_OK;
 }
 
-PackDesc *stage_desc(pep_ctx *ctx, uint64_t n)
+PackDesc *stage_desc(pep_ctx *ctx, PinBuf &pin, uint64_t n)
 {
-    if (pin_reserve(ctx, ctx->pin_k1, (n + 1) * sizeof(PackDesc)) != PEP_OK) return nullptr;
-    return reinterpret_cast<PackDesc *>(ctx->pin_k1.p);
+    if (pin_reserve(ctx, pin, (n + 1) * sizeof(PackDesc)) != PEP_OK) return nullptr;
+    return reinterpret_cast<PackDesc *>(pin.p);
+}
+
+int k1_ref_finish(pep_ctx *ctx)
+{
+    PEP_HIP(ctx, hipEventSynchronize(ctx->k1_event));
+    const uint32_t n_targets = ctx->k1_count_pending ? *reinterpret_cast<const uint32_t *>(ctx->pin_k1n.p) : 0u;
+    ctx->k1_count_pending = false;
+    const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1.p);
+    ctx->t_meta.resize(n_targets);
+    for (uint32_t i = 0; i < n_targets; ++i) ctx->t_meta[i] = pep_target_meta{desc[i].seq, desc[i].frame, desc[i].aa_off, desc[i].len};
+    return finish_layout(ctx, desc, n_targets, ctx->t);
 }
 
 }  // namespace
 
-int pep_k1_query(pep_ctx *ctx, int gtable)
+// phase 1 = queue the device work and the download of the descriptors, 2 = wait for it and build the host-side tables, 0 = both.
+// pep_translate queues the reference side, then the query side, and builds the reference tables while the query kernels run.
+int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
 {
     const NtSet &nt = ctx->q_nt;
     const int tab = gtable == 4 ? 1 : 0;
-    PEP_TRY(upload_codon_table(ctx));
     const uint32_t n = nt.n;
-    if (n > PEP_MAX_QUERIES) return pep_fail(ctx, PEP_ERR_LIMIT, "too many queries");
-    DevBuf *W = ctx->ws;
-    PEP_TRY(dev_reserve(ctx, W[0], ((size_t)n + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, W[1], ((size_t)n + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, W[2], ((size_t)n + 1) * sizeof(PackDesc)));
-    PEP_TRY(dev_reserve(ctx, W[3], ((size_t)n + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, W[5], 16));
-    const uint64_t upper = 2 * PEP_END_PAD + (nt.total + 2 * (uint64_t)n) / 3 + (uint64_t)n * (16 + PEP_SEQ_GAP);
-    PEP_TRY(reserve_packed(ctx, ctx->q, n, upper));
-    if (n) hipLaunchKernelGGL(k1_query_frames, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, tab,
-                              W[0].as<uint32_t>(), W[1].as<uint32_t>());
-    hipLaunchKernelGGL(k1_query_desc, dim3((unsigned)ceil_div((uint64_t)n + 1, 256)), dim3(256), 0, ctx->stream, n, W[0].as<const uint32_t>(), W[1].as<const uint32_t>(),
-                       W[2].as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>());
-    PEP_TRY(layout_and_pack(ctx, nt, tab, W[2].as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6]));
-    PackDesc *desc = stage_desc(ctx, n);
-    if (!desc) return PEP_ERR_HIP;
-    if (n) PEP_HIP(ctx, hipMemcpyAsync(desc, W[2].p, (size_t)n * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
+    if (phase != 2) {
+        PEP_TRY(upload_codon_table(ctx));
+        if (n > PEP_MAX_QUERIES) return pep_fail(ctx, PEP_ERR_LIMIT, "too many queries");
+        DevBuf *W = ctx->ws;
+        PEP_TRY(dev_reserve(ctx, W[0], ((size_t)n + 1) * 4));
+        PEP_TRY(dev_reserve(ctx, W[1], ((size_t)n + 1) * 4));
+        PEP_TRY(dev_reserve(ctx, W[2], ((size_t)n + 1) * sizeof(PackDesc)));
+        PEP_TRY(dev_reserve(ctx, W[3], ((size_t)n + 1) * 4));
+        PEP_TRY(dev_reserve(ctx, W[5], 16));
+        const uint64_t upper = 2 * PEP_END_PAD + (nt.total + 2 * (uint64_t)n) / 3 + (uint64_t)n * (16 + PEP_SEQ_GAP);
+        PEP_TRY(reserve_packed(ctx, ctx->q, n, upper));
+        if (n) hipLaunchKernelGGL(k1_query_frames, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, tab,
+                                  W[0].as<uint32_t>(), W[1].as<uint32_t>());
+        hipLaunchKernelGGL(k1_query_desc, dim3((unsigned)ceil_div((uint64_t)n + 1, 256)), dim3(256), 0, ctx->stream, n, W[0].as<const uint32_t>(), W[1].as<const uint32_t>(),
+                           W[2].as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>());
+        PEP_TRY(layout_and_pack(ctx, nt, tab, W[2].as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6]));
+        PackDesc *desc = stage_desc(ctx, ctx->pin_k1q, n);
+        if (!desc) return PEP_ERR_HIP;
+        if (n) PEP_HIP(ctx, hipMemcpyAsync(desc, W[2].p, (size_t)n * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (phase == 1) return PEP_OK;
+    const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1q.p);
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->q_meta.resize(n);
     for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, desc[i].frame, desc[i].len, (uint32_t)(nt.h_off[i + 1] - nt.h_off[i])};
     return finish_layout(ctx, desc, n, ctx->q);
 }
 
-int pep_k1_ref(pep_ctx *ctx, int frames, int gtable)
+int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
 {
     const NtSet &nt = ctx->r_nt;
     const int tab = gtable == 4 ? 1 : 0;
+    if (phase == 2) return k1_ref_finish(ctx);
     PEP_TRY(upload_codon_table(ctx));
     const uint32_t n = nt.n;
     const int nf = frames == 3 ? 3 : 6;
@@ -358,8 +376,7 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable)
     PEP_TRY(dev_reserve(ctx, W[5], (nw + 2) * 4));
     PEP_TRY(dev_reserve(ctx, W[6], (slots + 1) * 4));
     PEP_TRY(reserve_packed(ctx, ctx->t, (uint32_t)slots, upper));
-    uint32_t n_targets = 0;
-    PackDesc *desc = stage_desc(ctx, slots);
+    PackDesc *desc = stage_desc(ctx, ctx->pin_k1, slots);
     if (!desc) return PEP_ERR_HIP;
     const uint64_t *d_base = ctx->d_k1_base.as<const uint64_t>();
     if (nw) {
@@ -372,16 +389,19 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable)
                            ctx->t.len.as<uint32_t>());
         PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
                                 W[7], W[8]));
-        PEP_TRY(pep_read_back(ctx, &n_targets, W[5].as<const uint32_t>() + nw, 4));
+        // the count and the descriptors travel through pinned memory; an event marks the point of the stream where both have arrived
+        PEP_TRY(pin_reserve(ctx, ctx->pin_k1n, 64));
+        PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_k1n.p, W[5].as<const uint32_t>() + nw, 4, hipMemcpyDeviceToHost, ctx->stream));
         PEP_HIP(ctx, hipMemcpyAsync(desc, W[4].p, slots * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
-        PEP_TRY(pep_sync_reads(ctx));
+        ctx->k1_count_pending = true;
     } else {
         PEP_HIP(ctx, hipMemsetAsync(W[5].p, 0, 8, ctx->stream));
         PEP_HIP(ctx, hipMemsetAsync(W[6].p, 0, 4, ctx->stream));
         PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), 0, W[5].as<const uint32_t>(), upper, ctx->t, W[7], W[8]));
-        PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->k1_count_pending = false;
     }
-    ctx->t_meta.resize(n_targets);
-    for (uint32_t i = 0; i < n_targets; ++i) ctx->t_meta[i] = pep_target_meta{desc[i].seq, desc[i].frame, desc[i].aa_off, desc[i].len};
-    return finish_layout(ctx, desc, n_targets, ctx->t);
+    if (!ctx->k1_event && hipEventCreateWithFlags(&ctx->k1_event, hipEventDisableTiming) != hipSuccess) return pep_fail(ctx, PEP_ERR_HIP, "hipEventCreate failed");
+    PEP_HIP(ctx, hipEventRecord(ctx->k1_event, ctx->stream));
+    if (phase == 1) return PEP_OK;
+    return k1_ref_finish(ctx);
 }
