@@ -419,6 +419,32 @@ def test_full_size_10k_properties(ctx):
     assert (lab // 4 == np.arange(10000) // 4).all()
 
 
+@pytest.mark.parametrize('gene_len', [1002, 0])
+def test_full_size_10k_bit_exact_vs_oracle(ctx, gene_len):
+    """gene_len 0: log-normal gene lengths (120 .. 9492 nt, the spread of the reference's example genomes).  gene_len 1002: the headline workload itself (10k genes x 1002 nt all-vs-all, BASELINE configs[2] search stage): every field of every hit and
+    the CIGAR arena equal the CPU oracle's.  The oracle gets the proteins K1 produced (K1 has its own golden / oracle tests) and runs
+    its OpenMP build on all host cores - a few seconds on the GPU box."""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    names, seqs = synth.make_genes(10000, gene_len, seed=355)
+    order = sorted(range(len(names)), key=lambda i: names[i])
+    nts = [seqs[i] for i in order]
+    ctx.set_query_nt(nts, 11)
+    ctx.set_ref_nt(nts, 6, 11)
+    p = N.default_params(45., 25., 10, 5)
+    gh, gc, st = ctx.search(p)
+    qa, qo = ctx.query_aa()
+    ta, to = ctx.target_aa()
+    q_aa = [qa[qo[i]:qo[i + 1]] for i in range(len(qo) - 1)]
+    t_aa = [ta[to[i]:to[i + 1]] for i in range(len(to) - 1)]
+    O.lib().oracle_set_threads(0)                # all host cores (the results do not depend on the thread count)
+    oh, oc, ost = O.search(q_aa, t_aa, O.default_params(45., 25., 10, 5))
+    _cmp_hits(gh, gc, oh, oc)
+    assert len(gh) > 30000
+    for k in ('candidates', 'pairs', 'cells', 'tracebacks'):
+        assert st[k] == ost[k], k
+
+
 def _shard_worker(rank, world, port, out_q):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
