@@ -41,7 +41,7 @@ def cpu_baseline(nts, n_sample, min_id, min_qcov):
                 sample='first %d of %d queries vs all %d genes x 6 frames; %.1f s on %d threads; %d candidates, %.3g SW cells (%.3g cells/s); '
                        'reference binaries (diamond/blastn/mmseqs) are absent, so this is the oracle C port (scalar code, OpenMP)'
                        % (n_sample, len(nts), len(nts), dt, cores, st['candidates'], st['cells'], st['cells'] / dt),
-                seconds=dt, sw_cells_per_s=st['cells'] / dt)
+                seconds=dt, sw_cells_per_s=st['cells'] / dt, _hits=(hits, cig, n_sample))
 
 
 def main():
@@ -129,6 +129,16 @@ def main():
     else:
         total_pairs, total_cells = float(acc['candidates']), float(acc['cells'])
 
+    if rank == 0 and cpu_line is not None:
+        # the oracle's hit table of the baseline run doubles as a check of the GPU's (same queries, same reference): every field, every CIGAR run
+        o_hits, o_cig, n_sample = cpu_line.pop('_hits')
+        hits, cig, _ = ctx.search(params)           # (one more search, outside the timed region: a private copy of hits + CIGARs)
+        g = hits[hits['q'] < n_sample] if n_sample < len(nts) else hits
+        same = len(g) == len(o_hits) and all(np.array_equal(g[f], o_hits[f]) for f in ('q', 't', 'q_start', 'q_end', 't_start', 't_end', 'score', 'nm', 'n_ident', 'aln_len', 'cigar_runs'))
+        if same and n_sample >= len(nts):
+            same = np.array_equal(np.asarray(cig), np.asarray(o_cig))
+        cpu_line['gpu_hits_identical'] = bool(same)
+        cpu_line['hits_compared'] = int(len(o_hits))
     if rank == 0:
         K = args.steps
         cand = acc['candidates'] / K
