@@ -295,8 +295,9 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
 //   eflag = gt(e_ext, e_open), fflag likewise;  nibble = src + 4 * eflag + 8 * fflag
 // Four nibbles per candidate accumulate in the halves of one register (v_pk_lshrrev_b16 + v_pk_mad_u16); two such
 // registers make the 8-cell word of one diagonal, rearranged per candidate with v_perm_b32 once per 16 steps.
-// The end cell is the first step at which H equals the candidate's score, which the score pass already delivered:
-//   first = umin(first, k + 0x8000 * gt(T, H))                            (k < 0x8000)
+// The end cell is the first step at which H equals the candidate's score T, which the score pass already delivered.  The running
+// maximum of a lane only grows, so that step number is the count of steps at which the maximum was still below T:
+//   best = max(best, H);  first += gt(T, best)                             (four instructions per step; < 0x8000 steps)
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 // The flag arithmetic goes through inline assembly: written as C, LLVM recognises the 0/1 values, turns the multiplications into
@@ -321,7 +322,7 @@ __device__ __forceinline__ u16x2 pk_shr4(u16x2 a)
     return r;
 }
 
-struct PkConst { u16x2 four, eight, c4096, big; };
+struct PkConst { u16x2 four, eight, c4096; };
 
 __device__ __forceinline__ u16x2 pk_codes(const PkConst &K, s16x2 H, s16x2 h, s16x2 E, s16x2 e_ext, s16x2 e_open, s16x2 f_ext, s16x2 f_open)
 {
@@ -352,11 +353,11 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
     const s16x2 zero = {0, 0};
     const s16x2 oe2 = {(short)a.oe, (short)a.oe}, ext2 = {(short)a.ext, (short)a.ext};
     const s16x2 T2 = {(short)a.known[c0], (short)a.known[c1]};
-    const u16x2 one_u = {1, 1};
     PkConst K;
-    K.four = u16x2{4, 4}; K.eight = u16x2{8, 8}; K.c4096 = u16x2{4096, 4096}; K.big = u16x2{0x8000, 0x8000};
+    K.four = u16x2{4, 4}; K.eight = u16x2{8, 8}; K.c4096 = u16x2{4096, 4096};
     s16x2 HA = zero, EA = zero, FA = zero, HB = zero, EB = zero, FB = zero;
-    u16x2 first = {0xFFFF, 0xFFFF}, kk = {0, 0};
+    u16x2 first = {0, 0};
+    s16x2 best = zero;
     int tv0 = vt0[0], tv1 = vt1[0], qv0 = 0, qv1 = 0;
     for (int b = 0; b < nb; ++b) {
         u16x2 accA = {0, 0}, accB = {0, 0}, loA = {0, 0}, loB = {0, 0};
@@ -374,8 +375,8 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                     const s16x2 h = HA + sub;
                     const s16x2 H = pk_max(pk_max(pk_max(h, E), F), zero);
                     accA = pk_mad(pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open), K.c4096, pk_shr4(accA));
-                    first = __builtin_elementwise_min(first, pk_mad(pk_gt(T2, H), K.big, kk));
-                    kk += one_u;
+                    best = pk_max(best, H);
+                    first += pk_gt(T2, best);
                     HA = H; EA = E; FA = F;
                 }
                 // ---- B step (target cursor advances)
@@ -388,8 +389,8 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                     const s16x2 h = HB + sub;
                     const s16x2 H = pk_max(pk_max(pk_max(h, E), F), zero);
                     accB = pk_mad(pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open), K.c4096, pk_shr4(accB));
-                    first = __builtin_elementwise_min(first, pk_mad(pk_gt(T2, H), K.big, kk));
-                    kk += one_u;
+                    best = pk_max(best, H);
+                    first += pk_gt(T2, best);
                     HB = H; EB = E; FB = F;
                 }
             }
@@ -410,7 +411,7 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
         int bi = 0x7fffffff, bj = 0x7fffffff;
-        if (fk[x] < 0x8000) {
+        if (fk[x] < 16 * nb) {                    // (a lane that never reaches T counted every step)
             const int mm = fk[x] >> 1;
             bi = gg[x]->a0 + mm - lane;
             bj = gg[x]->a0 + gg[x]->dlo + mm + lane + (fk[x] & 1);
