@@ -293,7 +293,7 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
 //   nz = gt(H, 0), neh = gt(H, h), nee = gt(H, E)                         (H >= 0, H >= h, H >= E: "greater" is "not equal")
 //   src = nz * (1 + neh * (1 + nee))                                      -> 0 none, 1 diagonal, 2 E, 3 F   (same priority as sw_one)
 //   eflag = gt(e_ext, e_open), fflag likewise;  nibble = src + 4 * eflag + 8 * fflag
-// Four nibbles per candidate accumulate in the halves of one register (v_pk_lshrrev_b16 + v_pk_mad_u16); two such
+// Four nibbles per candidate accumulate in the halves of one register (one v_pk_mad_u16 with the place value 16^u each); two such
 // registers make the 8-cell word of one diagonal, rearranged per candidate with v_perm_b32 once per 16 steps.
 // The end cell is the first step at which H equals the candidate's score T, which the score pass already delivered.  The running
 // maximum of a lane only grows, so that step number is the count of steps at which the maximum was still below T:
@@ -315,14 +315,7 @@ __device__ __forceinline__ u16x2 pk_mad(u16x2 a, u16x2 b, u16x2 c)
     asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ u16x2 pk_shr4(u16x2 a)
-{
-    u16x2 r;
-    asm("v_pk_lshrrev_b16 %0, 4, %1 op_sel_hi:[0,1]" : "=v"(r) : "v"(a));
-    return r;
-}
-
-struct PkConst { u16x2 four, eight, c4096; };
+struct PkConst { u16x2 four, eight, place[4]; };      // place[u] = 16^u: the nibble of the u-th cell of a half block goes to bits 4u .. 4u+3
 
 __device__ __forceinline__ u16x2 pk_codes(const PkConst &K, s16x2 H, s16x2 h, s16x2 E, s16x2 e_ext, s16x2 e_open, s16x2 f_ext, s16x2 f_open)
 {
@@ -354,7 +347,8 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
     const s16x2 oe2 = {(short)a.oe, (short)a.oe}, ext2 = {(short)a.ext, (short)a.ext};
     const s16x2 T2 = {(short)a.known[c0], (short)a.known[c1]};
     PkConst K;
-    K.four = u16x2{4, 4}; K.eight = u16x2{8, 8}; K.c4096 = u16x2{4096, 4096};
+    K.four = u16x2{4, 4}; K.eight = u16x2{8, 8};
+    K.place[0] = u16x2{1, 1}; K.place[1] = u16x2{16, 16}; K.place[2] = u16x2{256, 256}; K.place[3] = u16x2{4096, 4096};
     s16x2 HA = zero, EA = zero, FA = zero, HB = zero, EB = zero, FB = zero;
     u16x2 first = {0, 0};
     s16x2 best = zero;
@@ -374,7 +368,10 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                     const s16x2 E = pk_max(e_ext, e_open), F = pk_max(f_ext, f_open);
                     const s16x2 h = HA + sub;
                     const s16x2 H = pk_max(pk_max(pk_max(h, E), F), zero);
-                    accA = pk_mad(pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open), K.c4096, pk_shr4(accA));
+                    {   // u is a compile-time constant of the unrolled loop: the first nibble of a half block simply starts the word
+                        const u16x2 code = pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open);
+                        accA = u == 0 ? code : pk_mad(code, K.place[u], accA);
+                    }
                     best = pk_max(best, H);
                     first += pk_gt(T2, best);
                     HA = H; EA = E; FA = F;
@@ -388,7 +385,10 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                     const s16x2 E = pk_max(e_ext, e_open), F = pk_max(f_ext, f_open);
                     const s16x2 h = HB + sub;
                     const s16x2 H = pk_max(pk_max(pk_max(h, E), F), zero);
-                    accB = pk_mad(pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open), K.c4096, pk_shr4(accB));
+                    {
+                        const u16x2 code = pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open);
+                        accB = u == 0 ? code : pk_mad(code, K.place[u], accB);
+                    }
                     best = pk_max(best, H);
                     first += pk_gt(T2, best);
                     HB = H; EB = E; FB = F;
