@@ -290,8 +290,8 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
 // ---- packed 16-bit TRACEBACK pass: the same two-candidates-per-wavefront sweep, plus the 4-bit codes of both candidates.
 // The codes come out of packed arithmetic instead of compare/select pairs (which would have to run once per candidate):
 //   gt(x, y) = (y - x) >> 15 per 16-bit half (the sign bit of the difference): 0/1 flags without compare instructions
-//   nz = gt(H, 0), neh = gt(H, h), nee = gt(H, E)                         (H >= 0, H >= h, H >= E: "greater" is "not equal")
-//   src = nz * (1 + neh * (1 + nee))                                      -> 0 none, 1 diagonal, 2 E, 3 F   (same priority as sw_one)
+//   nz = min(H, 1), neh = gt(H, h), gfe = gt(F, E)                        (H >= 0, H >= h: "greater" is "not equal")
+//   src = nz * (1 + neh * (1 + gfe))                                      -> 0 none, 1 diagonal, 2 E, 3 F   (same priority as sw_one)
 //   eflag = gt(e_ext, e_open), fflag likewise;  nibble = src + 4 * eflag + 8 * fflag
 // Four nibbles per candidate accumulate in the halves of one register (one v_pk_mad_u16 with the place value 16^u each); two such
 // registers make the 8-cell word of one diagonal, rearranged per candidate with v_perm_b32 once per 16 steps.
@@ -317,11 +317,20 @@ __device__ __forceinline__ u16x2 pk_mad(u16x2 a, u16x2 b, u16x2 c)
 }
 struct PkConst { u16x2 four, eight, place[4]; };      // place[u] = 16^u: the nibble of the u-th cell of a half block goes to bits 4u .. 4u+3
 
-__device__ __forceinline__ u16x2 pk_codes(const PkConst &K, s16x2 H, s16x2 h, s16x2 E, s16x2 e_ext, s16x2 e_open, s16x2 f_ext, s16x2 f_open)
+// min(x, 1) per half = "x != 0" for x >= 0
+__device__ __forceinline__ u16x2 pk_nonzero(s16x2 x)
 {
-    const s16x2 zero = {0, 0};
-    const u16x2 nz = pk_gt(H, zero), neh = pk_gt(H, h), nee = pk_gt(H, E);      // H >= 0, H >= h, H >= E: "greater" == "not equal"
-    const u16x2 t = pk_mad(neh, nee, neh);
+    u16x2 r;
+    asm("v_pk_min_u16 %0, %1, 1 op_sel_hi:[1,0]" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// E and F arrive in the pre-opened form (true value + open + extend, as in the score pass): H is neither h nor 0 exactly when it came
+// out of max(E, F), and then the source is F only if F is strictly greater (the same priority as sw_one: diagonal, E, F)
+__device__ __forceinline__ u16x2 pk_codes(const PkConst &K, s16x2 H, s16x2 h, s16x2 E, s16x2 F, s16x2 e_ext, s16x2 e_open, s16x2 f_ext, s16x2 f_open)
+{
+    const u16x2 nz = pk_nonzero(H), neh = pk_gt(H, h), gfe = pk_gt(F, E);       // H >= 0, H >= h: "greater" == "not equal"
+    const u16x2 t = pk_mad(neh, gfe, neh);
     const u16x2 src = pk_mad(nz, t, nz);
     const u16x2 ef = pk_gt(e_ext, e_open), ff = pk_gt(f_ext, f_open);
     return pk_mad(ff, K.eight, pk_mad(ef, K.four, src));
@@ -364,12 +373,12 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                 {
                     const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
                     const s16x2 hl = pk_shr1z(HB), el = pk_shr1z(EB);
-                    const s16x2 e_ext = el - ext2, e_open = hl - oe2, f_ext = FB - ext2, f_open = HB - oe2;
-                    const s16x2 E = pk_max(e_ext, e_open), F = pk_max(f_ext, f_open);
+                    const s16x2 e_ext = el - ext2, f_ext = FB - ext2;                 // "open from H" needs no subtraction in this form
+                    const s16x2 E = pk_max(e_ext, hl), F = pk_max(f_ext, HB);
                     const s16x2 h = HA + sub;
-                    const s16x2 H = pk_max(pk_max(pk_max(h, E), F), zero);
+                    const s16x2 H = pk_max(pk_max(h, pk_max(E, F) - oe2), zero);
                     {   // u is a compile-time constant of the unrolled loop: the first nibble of a half block simply starts the word
-                        const u16x2 code = pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open);
+                        const u16x2 code = pk_codes(K, H, h, E, F, e_ext, hl, f_ext, HB);
                         accA = u == 0 ? code : pk_mad(code, K.place[u], accA);
                     }
                     best = pk_max(best, H);
@@ -381,12 +390,12 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                 {
                     const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
                     const s16x2 hu = pk_shl1z(HA), fu = pk_shl1z(FA);
-                    const s16x2 e_ext = EA - ext2, e_open = HA - oe2, f_ext = fu - ext2, f_open = hu - oe2;
-                    const s16x2 E = pk_max(e_ext, e_open), F = pk_max(f_ext, f_open);
+                    const s16x2 e_ext = EA - ext2, f_ext = fu - ext2;
+                    const s16x2 E = pk_max(e_ext, HA), F = pk_max(f_ext, hu);
                     const s16x2 h = HB + sub;
-                    const s16x2 H = pk_max(pk_max(pk_max(h, E), F), zero);
+                    const s16x2 H = pk_max(pk_max(h, pk_max(E, F) - oe2), zero);
                     {
-                        const u16x2 code = pk_codes(K, H, h, E, e_ext, e_open, f_ext, f_open);
+                        const u16x2 code = pk_codes(K, H, h, E, F, e_ext, HA, f_ext, hu);
                         accB = u == 0 ? code : pk_mad(code, K.place[u], accB);
                     }
                     best = pk_max(best, H);
