@@ -202,6 +202,7 @@ int upload_nt(pep_ctx *ctx, NtSet &s, const uint8_t *nt, const uint64_t *off, ui
     for (uint32_t i = 0; i <= n; ++i) {
         s.h_off[i] = n ? off[i] : 0;
         if (i && s.h_off[i] < s.h_off[i - 1]) return pep_fail(ctx, PEP_ERR_ARG, "offsets must be non-decreasing");
+        if (i && s.h_off[i] - s.h_off[i - 1] > 0x7FFFFF00ull) return pep_fail(ctx, PEP_ERR_LIMIT, "nucleotide sequence longer than 2^31 - 256");   // K1 indexes a sequence with 32 bits
     }
     s.total = s.h_off[n];
     PEP_TRY(dev_reserve(ctx, s.nt, s.total + 64));

@@ -26,13 +26,15 @@ __device__ __forceinline__ int base2(uint8_t ch)
 
 // residue `aa` of frame `frame` (1..6) of the sequence nt[0..L): returns code 0..25, X for ambiguous/partial codons;
 // *is_gap set when the codon contains '-' (the reference emits '-', which is not an 'X' for frame choice)
-__device__ __forceinline__ int translate_at(const uint8_t *__restrict__ nt, int64_t L, int frame, int64_t aa, int tab, bool *is_gap)
+__device__ __forceinline__ int translate_at(const uint8_t *__restrict__ nt, int L, int frame, int aa, int tab, bool *is_gap)
 {
+    // 32-bit indices inside one sequence (upload_nt keeps a sequence below 2^31 - 256 nucleotides): with 64-bit positions half of
+    // the kernel's instructions were address arithmetic
     int b[3];
-    const int64_t p0 = (frame <= 3 ? frame - 1 : frame - 4) + 3 * aa;
+    const int p0 = (frame <= 3 ? frame - 1 : frame - 4) + 3 * aa;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int64_t p = p0 + k;
+        const int p = p0 + k;
         int v = -1;
         if (p < L) {
             if (frame <= 3) v = base2(nt[p]);
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void k1_ref_chunks(const uint8_t *__restrict__
             while (end < 0) {
                 const int64_t a = x0 + lane;
                 bool isx = false;
-                if (a < na) { bool gap; isx = (translate_at(s, L, f, a, tab, &gap) == 23) && !gap; }
+                if (a < na) { bool gap; isx = (translate_at(s, (int)L, f, (int)a, tab, &gap) == 23) && !gap; }
                 else if (a == na) isx = true;
                 const unsigned long long m = __ballot(isx);
                 if (m) end = x0 + (int64_t)__ffsll((long long)m) - 1; else x0 += 64;
@@ -146,35 +148,78 @@ struct PackDesc {          // one per packed sequence: where its residues come f
 // the block -> sequence map of the blocks it owns.  The number of packed sequences lives on the device (*n_ptr): the grid is
 // sized from a host upper bound and the surplus waves leave at once, so the host never waits for the chunk count.
 // (The first version ran one thread per 16-byte block of the layout with a 16-step binary search for the owner: 0.22 ms for
-// the 20 M reference residues, bound by the latency of that search; this one is bound by the byte traffic.)
+// the 20 M reference residues, bound by the latency of that search.)
 __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, int tab,
-                                               const PackDesc *__restrict__ desc, const uint32_t *__restrict__ pk_off, const uint32_t *__restrict__ n_ptr,
+                                               const PackDesc *__restrict__ desc, const uint32_t *__restrict__ pk_off, const uint32_t *__restrict__ n_ptr, uint32_t cap,
                                                uint8_t *__restrict__ res, uint32_t *__restrict__ blk2seq)
 {
-    const uint32_t n_packed = *n_ptr;
     const int lane = threadIdx.x & 63;
     const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the count, the descriptor and the offsets are fetched together (slot s exists in all three arrays whether or not it is in use):
+    // a wave lives for a chain of dependent loads, and this takes one link out of it
+    const uint32_t n_packed = *n_ptr;
+    const uint32_t sc = min(s, cap);                                   // (the last block's surplus waves stay inside the arrays)
+    const PackDesc d = desc[sc];
+    const uint32_t start = pk_off[sc], next = pk_off[sc + 1];        // pk_off[n] = size of the whole layout (includes the trailing pad)
     if (n_packed == 0) {                      // nothing but the two end pads
         if (s == 0) for (uint32_t x = lane; x < pk_off[0]; x += 64) res[x] = (uint8_t)PEP_PAD_CODE;
         return;
     }
     if (s >= n_packed) return;
-    const PackDesc d = desc[s];
-    const uint32_t start = pk_off[s], next = pk_off[s + 1];          // pk_off[n] = size of the whole layout (includes the trailing pad)
     const uint8_t *src = nt + nt_off[d.seq];
-    const int64_t L = (int64_t)(nt_off[d.seq + 1] - nt_off[d.seq]);
+    const int L = (int)(nt_off[d.seq + 1] - nt_off[d.seq]);
     if (s == 0) for (uint32_t x = lane; x < start; x += 64) res[x] = (uint8_t)PEP_PAD_CODE;          // leading pad
-    // eight residues per lane and trip: one 8-byte store (sequence starts and spans are multiples of 16) and 24 loads in flight -
-    // the kernel is bound by load latency, and a 1000-nt gene is done in a single trip
-    for (uint32_t x0 = 8 * lane; x0 < next - start; x0 += 512) {
-        uint32_t word[2] = {0, 0};
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            uint32_t c = PEP_PAD_CODE;
-            if (x0 + k < d.len) c = (uint32_t)translate_at(src, L, (int)d.frame, (int64_t)d.aa_off + x0 + k, tab, nullptr);
-            word[k >> 2] |= c << (8 * (k & 3));
+    // Chunks of 512 residues: the wavefront copies the 1536 nucleotide bytes behind them into LDS with aligned dword loads (coalesced:
+    // 256 contiguous bytes per instruction), then every lane translates eight residues out of LDS and stores 8 bytes.  Reading the
+    // bytes straight from global memory (three byte loads per residue, 24 bytes apart from lane to lane) made every instruction touch
+    // 24 cache lines: both sides of K1 ran at the same 230 G residues/s whatever their size.
+    __shared__ uint32_t stage_all[4][392];
+    uint32_t *stage = stage_all[threadIdx.x >> 6];
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(stage);
+    const int frame = (int)d.frame;
+    const bool fwd = frame <= 3;
+    const int fo = fwd ? frame - 1 : frame - 4;
+    for (uint32_t c0 = 0; c0 < next - start; c0 += 512) {
+        const int P0 = fo + 3 * (int)(d.aa_off + c0);                    // first nucleotide position (in reading direction) of the chunk
+        // window of source bytes [lo, lo + 1536) that holds positions P0 .. P0 + 1535 (forward: as they are; reverse: mirrored)
+        const int lo = fwd ? P0 : max(0, L - 1 - (P0 + 1535));
+        int shift = 0;
+        if (c0 < d.len && lo < L) {
+            const uintptr_t A = reinterpret_cast<uintptr_t>(src + lo);
+            shift = (int)(A & 3u);
+            const uint32_t *al = reinterpret_cast<const uint32_t *>(A - shift);
+            const int n_dw = (min(1536, L - lo) + shift + 3) >> 2;        // <= 385; the buffer is padded by 64 bytes behind the last sequence
+            for (int x = lane; x < n_dw; x += 64) stage[x] = al[x];
         }
-        *reinterpret_cast<uint2 *>(res + start + x0) = make_uint2(word[0], word[1]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t x0 = c0 + 8 * lane;
+        if (x0 < next - start) {
+            uint32_t word[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t c = PEP_PAD_CODE;
+                if (x0 + k < d.len) {
+                    int b[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int p = P0 + 3 * (8 * lane + k) + j;
+                        int v = -1;
+                        if (p < L) {
+                            v = base2(sb[(fwd ? p - lo : (L - 1 - p) - lo) + shift]);
+                            if (!fwd && v >= 0) v = 3 - v;
+                        }
+                        b[j] = v;
+                    }
+                    const bool gap = (b[0] == -2) | (b[1] == -2) | (b[2] == -2);
+                    c = (gap || (b[0] | b[1] | b[2]) < 0) ? 23u : (uint32_t)c_codon[tab][(b[0] << 4) | (b[1] << 2) | b[2]];
+                }
+                word[k >> 2] |= c << (8 * (k & 3));
+            }
+            *reinterpret_cast<uint2 *>(res + start + x0) = make_uint2(word[0], word[1]);
+        }
+        __builtin_amdgcn_wave_barrier();                                 // the next chunk overwrites the staging area
     }
     for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = s;
 }
@@ -254,7 +299,7 @@ int layout_and_pack(pep_ctx *ctx, const NtSet &nt, int tab, const PackDesc *d_de
     PEP_TRY(pep_scan_u32(ctx, d_padded, d_scan.as<uint32_t>(), cap, tmp));
     hipLaunchKernelGGL(k1_offsets, dim3((unsigned)ceil_div((uint64_t)cap + 1, 256)), dim3(256), 0, ctx->stream, d_n, d_scan.as<const uint32_t>(), cap, out.off.as<uint32_t>());
     hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div((uint64_t)cap + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
-                       d_desc, out.off.as<const uint32_t>(), d_n, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>());
+                       d_desc, out.off.as<const uint32_t>(), d_n, cap, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>());
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }
