@@ -32,4 +32,4 @@ for rep in range(2):
             pr.disable()
     dt = time.perf_counter() - t0
     print('rep', rep, 'seconds %.2f  -> %.1f genomes/s' % (dt, nG / dt))
-pstats.Stats(pr).sort_stats('cumulative').print_stats(35)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)
