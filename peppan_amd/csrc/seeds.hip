@@ -616,11 +616,12 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     ctx->stats.query_seeds = ctx->stats.target_seeds = ctx->stats.seed_hits = 0;
     if (Q.n == 0 || T.n == 0) return PEP_OK;
 
-    // two buckets per query position, except that up to 2^25 positions stay at 2^25 buckets: that is the largest index the partition
+    // two buckets per query position, except that up to 40 M positions stay at 2^25 buckets (the average coarse bucket then holds 4 900
+    // of the 5 632 entries a slab takes; 100k genes x 100k genes: 103 -> 94 ms per pass): that is the largest index the partition
     // build handles (2^13 coarse x 2^12 fine buckets), which is worth more than the last halving of the load (the filter in front of
     // the index keeps most foreign keys away from the buckets anyway)
     int bucket_bits = std::max(10, std::min(28, ilog2_ceil(2 * Q.total)));
-    if (bucket_bits == 26 && P.reserved[2] == 0) bucket_bits = 25;
+    if (bucket_bits > 25 && Q.total <= 40000000ull && P.reserved[2] == 0) bucket_bits = 25;
     const uint64_t n_buckets = 1ull << bucket_bits;
     PEP_TRY(dev_reserve(ctx, ctx->ws[0], (n_buckets + 1) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_buckets + 2) * sizeof(uint32_t)));
