@@ -1,16 +1,18 @@
 // K2-K4: spaced seeds over a reduced alphabet, bucketed query index, streaming join of the target
 // seeds against it, de-duplication of (query, target, diagonal bin) candidates.
 //
-//  seed_count / seed_fill : one thread per packed query byte position; key = sum red[r[p+off_k]] * base^k.
-//                           Padding bytes (code 31) never seed, so a seed cannot straddle two sequences.
-//                           Index = counting sort by hash(key): counts -> exclusive scan -> fill (8 B entries
-//                           key << 29 | pos) + a two-bit Bloom filter (filter_mask).  1 B read + 8 B written per query residue.
+//  query index            : key of the seed at packed query position p = sum red[r[p+off_k]] * base^k.  Padding bytes (code 31)
+//                           never seed, so a seed cannot straddle two sequences.  Index = entries (key << 29 | pos, 8 B) in CSR
+//                           buckets by hash(key) + a two-bit Bloom filter (filter_mask).  Built by partition: idx_slab puts the
+//                           entries into per-coarse-bucket slabs in one pass, idx_finish sorts every coarse bucket by fine
+//                           bucket inside LDS.  seed_count -> scan -> seed_fill (+ filter_fill) is the plain counting sort,
+//                           kept for query sets beyond 40 M positions and for coarse buckets that overflow their slab.
 //  seed_match             : persistent blocks stream the packed target bytes tile by tile; every position that passes the
 //                           filter compares its key with the bucket's entries; equal keys are raw seed hits
 //                           (qpos << 32 | tpos), staged in LDS and flushed with one global atomic per ~1.5 k hits.
-//  seed_extend            : one thread per raw hit; neighbouring hits of one diagonal share their candidate key
-//                           q:21 | t:25 | bin:18, so the first lane of each run decides for the run: already in the
-//                           device hash set, or ungapped x-drop extension -> insert.
+//  seed_runs / seed_extend: neighbouring hits of one diagonal share their candidate key q:21 | t:25 | bin:18; seed_runs turns
+//                           the raw hits into runs of equal keys (one per wave and key), seed_extend takes one run per thread:
+//                           already in the device hash set, or ungapped x-drop extension of its hits until one passes -> insert.
 //  The candidate set is compacted and radix-sorted (sort.hip) so every later stage is order-deterministic.
 #include "common.h"
 

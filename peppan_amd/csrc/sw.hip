@@ -605,10 +605,9 @@ int pep_selftest_dpp(pep_ctx *ctx)
 
 // Runs K5 over `n` candidate keys.  trace = false: score pass (ws[12] <- score / end cell / a0 per candidate).
 // trace = true: same DP plus traceback codes (ws[11] dir_off u64[n+1], ws[13] dirs).  ws[10] nblk, ws[14] scan input.
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, float *ms_kernel, const int32_t *d_known)
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known)
 {
     const pep_search_params &P = ctx->params;
-    *ms_kernel = 0.f;
     if (n == 0) return PEP_OK;
     PEP_TRY(dev_reserve(ctx, ctx->ws[10], (n + 1) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[11], (n + 2) * sizeof(uint64_t)));

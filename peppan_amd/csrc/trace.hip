@@ -310,8 +310,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     PEP_TRY(pin_reserve(ctx, ctx->pin_ms, (size_t)(ctx->q.n + 1) * 4));
     std::memcpy(ctx->pin_ms.p, h_min_score, (size_t)ctx->q.n * 4);
     PEP_HIP(ctx, hipMemcpyAsync(dms.p, ctx->pin_ms.p, (size_t)ctx->q.n * 4, hipMemcpyHostToDevice, st));
-    float ms_unused = 0.f;                       // (the pass times come from the context's phase timers, read after the search)
-    PEP_TRY(pep_sw_run(ctx, d_cands, n, false, &ms_unused));
+    PEP_TRY(pep_sw_run(ctx, d_cands, n, false));                   // (the pass times come from the context's phase timers, read after the search)
 
     pep_timer_begin(ctx, TM_TRACE);
 
@@ -350,7 +349,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         uint64_t total_runs = 0;
         PEP_TRY(pep_read_back(ctx, &total_runs, run_off + n_sel, 8));       // arrives with the synchronisation inside pep_sw_run (block total)
         // ---- pass 2: the same DP with traceback codes, selected pairs only (overwrites the pass-1 per-candidate arrays)
-        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, &ms_unused, known));
+        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, known));
         const int4 *sw2 = ctx->ws[12].as<const int4>();
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
         uint32_t *runs = ctx->ws[21].as<uint32_t>();
