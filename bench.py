@@ -170,10 +170,10 @@ def main():
             'phase_ms': {k: acc[k] / K for k in ('ms_seed', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
             'roofline': {'bound': 'hbm', 'kernel': 'sw_score_kernel (K5 banded Smith-Waterman, score pass over all candidate pairs)', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
                          'frac': achieved / 8000.0, 'traffic': traffic,
-                         # what actually bounds it: 126 VALU instructions per 16 candidate-steps of 64 cells (ISA of sw_score_kernel's
+                         # what actually bounds it: 120 VALU instructions per 16 candidate-steps of 64 cells (ISA of sw_score_kernel's
                          # packed 16-bit loop body), each occupying a SIMD for 4 cycles (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU
                          # quad-cycles), 1024 SIMDs at 2.4 GHz
-                         'valu_issue_frac': (acc['cells_swept'] / K / 64) * (126. / 16.) * 4 / (1024 * 2.4e9 * ms_sw * 1e-3),
+                         'valu_issue_frac': (acc['cells_swept'] / K / 64) * (120. / 16.) * 4 / (1024 * 2.4e9 * ms_sw * 1e-3),
                          'note': 'integer-VALU-bound by construction (SURVEY 8d): valu_issue_frac = share of the VALU issue ceiling; the traceback '
                                  'pass sw_kernel<true> (selected pairs only) is a second launch that writes %.3g B of traceback codes in %.2f ms '
                                  '= %.0f GB/s' % (acc['dir_bytes'] / K, acc['ms_sw_trace'] / K, acc['dir_bytes'] / K / (acc['ms_sw_trace'] / K * 1e-3) / 1e9) + traffic_note},

@@ -196,6 +196,23 @@ __device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t c)
 typedef const __attribute__((address_space(3))) signed char lds_ci8;
 __device__ __forceinline__ short tab_at(uint32_t base, int qv, int tv) { return (short)*(lds_ci8 *)(uintptr_t)add3(base, (uint32_t)qv, (uint32_t)tv); }
 
+// H + score for BOTH candidates of a packed wavefront in one 32-bit addition.  Candidate 0's score is read sign-extended (ds_read_i8),
+// candidate 1's with ds_read_i8_d16_hi, which on gfx950 delivers score << 16 with a zero low half (tools/micro/d16_probe.hip); with
+// H carried as H + PK_BIAS (>= -score for every table entry) the low half never borrows from the high one.  The two loads are inline
+// assembly (the compiler does not select the d16 forms on this target) and bring their own s_waitcnt: the compiler's waits stay correct
+// with extra loads in flight (the counter is in order), they only become stricter.
+constexpr int PK_BIAS = 128;
+__device__ __forceinline__ void diag_issue(uint32_t addr0, uint32_t addr1, uint32_t &s0, uint32_t &s1)
+{
+    asm volatile("ds_read_i8 %0, %2\n\tds_read_i8_d16_hi %1, %3" : "=&v"(s0), "=&v"(s1) : "v"(addr0), "v"(addr1) : "memory");
+}
+__device__ __forceinline__ uint32_t diag_finish(uint32_t Hd, uint32_t s0, uint32_t s1)
+{
+    uint32_t r;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(Hd), "v"(s0), "v"(s1));
+    return r;
+}
+
 struct CandGeom {
     const uint8_t *qg, *tg;
     int Lq, Lt, dlo, a0, nblk;
@@ -218,7 +235,7 @@ __device__ __forceinline__ CandGeom cand_geom(const SwArgs &a, uint64_t c)
     return g;
 }
 
-__device__ __forceinline__ bool fits16(const CandGeom &g, int max_sub) { return min(g.Lq, g.Lt) * max_sub + 64 < 32767; }
+__device__ __forceinline__ bool fits16(const CandGeom &g, int max_sub) { return min(g.Lq, g.Lt) * max_sub + 64 + PK_BIAS < 32767; }
 
 __device__ __forceinline__ void stage_windows(const CandGeom &g, int nb, uint16_t *lq, uint16_t *lt, int lane)
 {
@@ -231,7 +248,7 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
                                             const unsigned char *lds_tab, uint16_t *lds_res, int lane)
 {
     const int nb = max(g0.nblk, g1.nblk);
-    const int win = (8 * nb + 72 + 7) & ~7;
+    const int win = (8 * nb + 80 + 7) & ~7;
     uint16_t *q0 = lds_res, *t0 = q0 + win, *q1 = t0 + win, *t1 = q1 + win;
     stage_windows(g0, nb, q0, t0, lane);
     stage_windows(g1, nb, q1, t1, lane);
@@ -244,41 +261,53 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
     lds_cu16 *vq0 = (lds_cu16 *)(q0 + (64 - lane)), *vt0 = (lds_cu16 *)(t0 + (1 + lane));
     lds_cu16 *vq1 = (lds_cu16 *)(q1 + (64 - lane)), *vt1 = (lds_cu16 *)(t1 + (1 + lane));
     const uint32_t tab = (uint32_t)(uintptr_t)(lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
-    const s16x2 zero = {0, 0};
+    // every H / E / F below is the true value + PK_BIAS (the recurrences are shift-invariant; the floor 0 becomes PK_BIAS; band-edge
+    // lanes read 0 = -PK_BIAS, still "never selected")
+    const s16x2 zero = {PK_BIAS, PK_BIAS};
     const s16x2 oe2 = {(short)a.oe, (short)a.oe}, ext2 = {(short)a.ext, (short)a.ext};
     // The gap states are carried as E + (open + extend) and F + (open + extend): "open a gap from H" then needs no subtraction, and the
     // one subtraction moves to the single place where max(E, F) meets H - one instruction less per step.  Every POSITIVE E / F (the
-    // only ones that can reach H >= 0) is the same as in the plain recurrence; the traceback pass keeps the plain form for its flags.
+    // only ones that can reach H >= 0) is the same as in the plain recurrence.
     s16x2 HA = zero, EA = zero, FA = zero, HB = zero, EB = zero, FB = zero, best = zero;
-    int tv0 = vt0[0], tv1 = vt1[0], qv0 = 0, qv1 = 0;
+    // the residue cursors run one step ahead of the table look-ups: the reads for the next step are issued right behind the two table
+    // reads of this one, and the single s_waitcnt of diag_finish covers all four (the windows are staged with 8 entries of slack)
+    int tv0 = vt0[0], tv1 = vt1[0], qv0 = vq0[0], qv1 = vq1[0];
     for (int b = 0; b < nb; ++b) {
 #pragma unroll 1
         for (int half = 0; half < 2; ++half, vq0 += 4, vq1 += 4, vt0 += 4, vt1 += 4)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            // ---- A step
-            qv0 = vq0[u]; qv1 = vq1[u];
+            // ---- A step: cell (q[u], t[u])
+            int tn0, tn1, qn0, qn1;
             {
-                const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
+                uint32_t s0, s1;
+                diag_issue(add3(tab, (uint32_t)qv0, (uint32_t)tv0), add3(tab, (uint32_t)qv1, (uint32_t)tv1), s0, s1);
+                tn0 = vt0[u + 1]; tn1 = vt1[u + 1];
                 const s16x2 hl = pk_shr1z(HB), el = pk_shr1z(EB);
                 const s16x2 E = pk_max(el - ext2, hl), F = pk_max(FB - ext2, HB);
-                const s16x2 H = pk_max(pk_max(HA + sub, pk_max(E, F) - oe2), zero);
+                const s16x2 m = pk_max(E, F) - oe2;
+                const s16x2 h = __builtin_bit_cast(s16x2, diag_finish(__builtin_bit_cast(uint32_t, HA), s0, s1));
+                const s16x2 H = pk_max(pk_max(h, m), zero);
                 best = pk_max(best, H);
                 HA = H; EA = E; FA = F;
             }
-            // ---- B step (target cursor advances)
-            tv0 = vt0[u + 1]; tv1 = vt1[u + 1];
+            // ---- B step (target cursor advances): cell (q[u], t[u + 1])
             {
-                const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
+                uint32_t s0, s1;
+                diag_issue(add3(tab, (uint32_t)qv0, (uint32_t)tn0), add3(tab, (uint32_t)qv1, (uint32_t)tn1), s0, s1);
+                qn0 = vq0[u + 1]; qn1 = vq1[u + 1];
                 const s16x2 hu = pk_shl1z(HA), fu = pk_shl1z(FA);
                 const s16x2 E = pk_max(EA - ext2, HA), F = pk_max(fu - ext2, hu);
-                const s16x2 H = pk_max(pk_max(HB + sub, pk_max(E, F) - oe2), zero);
+                const s16x2 m = pk_max(E, F) - oe2;
+                const s16x2 h = __builtin_bit_cast(s16x2, diag_finish(__builtin_bit_cast(uint32_t, HB), s0, s1));
+                const s16x2 H = pk_max(pk_max(h, m), zero);
                 best = pk_max(best, H);
                 HB = H; EB = E; FB = F;
             }
+            tv0 = tn0; tv1 = tn1; qv0 = qn0; qv1 = qn1;
         }
     }
-    int b0 = best.x, b1 = best.y;
+    int b0 = best.x - PK_BIAS, b1 = best.y - PK_BIAS;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { b0 = max(b0, __shfl_xor(b0, d, 64)); b1 = max(b1, __shfl_xor(b1, d, 64)); }
     if (lane == 0) {
@@ -340,7 +369,7 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                                                   const unsigned char *lds_tab, uint16_t *lds_res, int lane)
 {
     const int nb = max(g0.nblk, g1.nblk);
-    const int win = (8 * nb + 72 + 7) & ~7;
+    const int win = (8 * nb + 80 + 7) & ~7;
     uint16_t *q0 = lds_res, *t0 = q0 + win, *q1 = t0 + win, *t1 = q1 + win;
     stage_windows(g0, nb, q0, t0, lane);
     stage_windows(g1, nb, q1, t1, lane);
@@ -449,7 +478,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a
         const uint64_t c0 = a.order[2 * w], c1 = a.order[min(2 * w + 1, a.n - 1)];
         const CandGeom g0 = cand_geom(a, c0), g1 = cand_geom(a, c1);
         const int nb = max(g0.nblk, g1.nblk);
-        const int need = 4 * 2 * ((8 * nb + 72 + 7) & ~7);
+        const int need = 4 * 2 * ((8 * nb + 80 + 7) & ~7);
         if (a.pk16 && fits16(g0, a.max_sub) && fits16(g1, a.max_sub) && need <= a.lds_res_bytes) {
             sw_two_pk16(a, c0, c1, g0, g1, smem, lds_res, lane);
         } else {
@@ -481,7 +510,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_kernel(SwArgs a)  
             const uint64_t c0 = a.order[2 * w], c1 = a.order[min(2 * w + 1, a.n - 1)];
             const CandGeom g0 = cand_geom(a, c0), g1 = cand_geom(a, c1);
             const int nb = max(g0.nblk, g1.nblk);
-            const int need = 4 * 2 * ((8 * nb + 72 + 7) & ~7);
+            const int need = 4 * 2 * ((8 * nb + 80 + 7) & ~7);
             if (c1 != c0 && fits16(g0, a.max_sub) && fits16(g1, a.max_sub) && need <= a.lds_res_bytes && nb < 2040 && a.known[c0] > 0 && a.known[c1] > 0) {
                 sw_two_pk16_trace(a, c0, c1, g0, g1, smem, lds_res, lane);
             } else {
@@ -653,7 +682,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     a.oe = P.gap_open + P.gap_ext; a.ext = P.gap_ext;
     // per-wave staging window (u16 per residue, query + target), sized for the longest possible pair, capped at 8 KiB
     const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 16 + 2;
-    const uint64_t want = 2 * 2 * ((8 * max_blk + 72 + 7) & ~7ull);
+    const uint64_t want = 2 * 2 * ((8 * max_blk + 80 + 7) & ~7ull);
     a.pk16 = (P.use_lds && P.reserved[1] == 0 && (!trace || d_known)) ? 1 : 0;       // reserved[1] != 0 forces the 32-bit passes (tests)
     a.known = trace ? d_known : nullptr;
     a.order = order;
