@@ -100,7 +100,7 @@ def main():
         if gene_of_target is None:
             gene_of_target = ctx.target_meta()['seq'].astype(np.uint32)
         allh, allc = pdist.allgather_hits(hits, cig, q0, device=dev if world > 1 else None)
-        labels = ctx.components(len(nts), allh['q'], gene_of_target[allh['t']])
+        labels = ctx.components_of_hits(len(nts), allh, gene_of_target)          # edges (q, gene of t) straight from the table
         return hits, st, allh, labels
 
     def sync():

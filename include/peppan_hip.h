@@ -23,7 +23,7 @@
  *   pep_search              `diamond makedb` + 5 x `diamond blastp ... --outfmt 101`   uberBlast.py:531-533, 546-552
  *   pep_hit fields          the SAM fields parseDiamond consumes (POS, CIGAR, |SEQ|, NM, ZR, ZS)   uberBlast.py:25-58
  *   pep_rescore_nt          cigar2score mode 1 inside RunBlast.reScore      uberBlast.py:226-249, 397-415
- *   pep_components          union-find of get_gene_group (partition only)   PEPPAN.py:1598-1607
+ *   pep_components(_of_hits) union-find of get_gene_group (partition only)  PEPPAN.py:1598-1607
  *   pep_linclust            `mmseqs createdb / linclust / createtsv`        clust.py:62-66
  *   pep_overlaps            numba tab2overlaps inside returnOverlap          uberBlast.py:73-97, 378-395
  *   pep_sha1, pep_dedup     hashlib.sha1 per gene + the duplicate collapse of writeGenes   PEPPAN.py:62, 1019, 1023-1039
@@ -174,6 +174,10 @@ int pep_rescore_nt(pep_ctx *ctx, uint64_t n, const pep_nt_hit *hits, const uint3
 
 /* K10: connected components; label[x] = smallest node id of x's component */
 int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *a, const uint32_t *b, uint32_t *label);
+/* the same over the edges of a hit table: (hit.q + q_base, node_of_target[hit.t]) - the single-linkage step of get_gene_group on
+ * the table of the all-vs-all search (PEPPAN.py:1598-1607), without building the two edge columns on the caller's side */
+int pep_components_of_hits(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_hits, const pep_hit *hits, uint32_t q_base,
+                           const uint32_t *node_of_target, uint64_t n_targets, uint32_t *label);
 
 /* K9: linear-time clustering.  codes: residue codes (< base are valid k-mer letters), concatenated, off[n+1].
  * rep[i] = index of sequence i's representative (rep[i] == i for representatives).  stats (may be NULL):

@@ -12,7 +12,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_stats', 'pep_result_free',
-           'pep_rescore_nt', 'pep_components', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup']
+           'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup']
 
 
 class PepError(RuntimeError):
@@ -377,6 +377,18 @@ class Context(object):
         return rep[:len(lengths)]
 
     # ---- K10
+    def components_of_hits(self, n_nodes, hits, node_of_target, q_base=0):
+        """labels of the graph with one edge (hit.q + q_base, node_of_target[hit.t]) per hit"""
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        node_of_target = np.ascontiguousarray(node_of_target, dtype=np.uint32)
+        lab = np.zeros(n_nodes, dtype=np.uint32)
+        if n_nodes:
+            hh = hits if len(hits) else np.zeros(1, HIT_DTYPE)
+            nn = node_of_target if len(node_of_target) else np.zeros(1, np.uint32)
+            self._check(self._lib.pep_components_of_hits(self._h, C.c_uint32(n_nodes), C.c_uint64(len(hits)), _ptr(hh), C.c_uint32(q_base), _ptr(nn),
+                                                         C.c_uint64(len(node_of_target)), _ptr(lab)), 'pep_components_of_hits')
+        return lab
+
     def components(self, n_nodes, a, b):
         a = np.ascontiguousarray(a, dtype=np.uint32)
         b = np.ascontiguousarray(b, dtype=np.uint32)

@@ -632,6 +632,20 @@ int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint3
     return pep_k10_components(ctx, n_nodes, n_edges, a, b, label);
 }
 
+int pep_components_of_hits(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_hits, const pep_hit *hits, uint32_t q_base,
+                           const uint32_t *node_of_target, uint64_t n_targets, uint32_t *label)
+{
+    if (!ctx || (n_nodes && !label) || (n_hits && (!hits || !node_of_target))) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<uint32_t> a(n_hits + 1), b(n_hits + 1);
+    for (uint64_t h = 0; h < n_hits; ++h) {
+        if (hits[h].t >= n_targets) return pep_fail(ctx, PEP_ERR_ARG, "pep_components_of_hits: target index out of range");
+        a[h] = hits[h].q + q_base;
+        b[h] = node_of_target[hits[h].t];
+    }
+    return pep_k10_components(ctx, n_nodes, n_hits, a.data(), b.data(), label);
+}
+
 int pep_linclust(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n, int base, int k, int m, double min_id, double min_cov,
                  uint32_t *rep, uint64_t *stats)
 {

@@ -414,6 +414,8 @@ def test_full_size_10k_properties(ctx):
     # union-find: labels are canonical (smallest member), idempotent, and each family of 4 ends up together or split, never mixed
     genes_t = tm['seq'][h1['t']]
     lab = ctx.components(10000, h1['q'], genes_t)
+    assert np.array_equal(ctx.components_of_hits(10000, h1, tm['seq']), lab)          # the same graph straight from the hit table
+    assert np.array_equal(ctx.components_of_hits(10004, h1, tm['seq'] + 4, q_base=4)[4:], lab + 4)
     assert np.array_equal(lab[lab], lab) and (lab <= np.arange(10000)).all()
     assert np.array_equal(ctx.components(10000, np.arange(10000), lab), lab)
     assert (lab // 4 == np.arange(10000) // 4).all()
