@@ -13,9 +13,9 @@ def tick(name, t0):
 for rep in range(12):
     if rep == 2: T.clear()
     t0 = time.perf_counter(); ctx.translate(force=True); tick('translate', t0)
-    t0 = time.perf_counter(); hits, cig, st = ctx.search(p); tick('search', t0)
+    t0 = time.perf_counter(); hits, cig, st = ctx.search(p, copy=False); tick('search', t0)
     if gene_of_target is None: gene_of_target = ctx.target_meta()['seq'].astype(np.uint32)
     t0 = time.perf_counter(); allh, allc = pdist.allgather_hits(hits, cig, 0); tick('allgather(n=1)', t0)
-    t0 = time.perf_counter(); lab = ctx.components(len(seqs), allh['q'], gene_of_target[allh['t']]); tick('components', t0)
+    t0 = time.perf_counter(); lab = ctx.components_of_hits(len(seqs), allh, gene_of_target); tick('components_of_hits', t0)
     T['gpu_total_events'] = T.get('gpu_total_events', 0.) + st['ms_total'] / 1e3
 print({k: round(v / 10 * 1e3, 3) for k, v in T.items()})
