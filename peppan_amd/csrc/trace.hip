@@ -164,15 +164,18 @@ __global__ __launch_bounds__(WALK_LANES) void walk(uint64_t n_sel, SelInfo *__re
     sel[s] = info;
 }
 
-// identities + filters; one wavefront per selected pair, lanes parallel over the columns of each M run
+// identities + filters; FIN_LANES lanes per selected pair, parallel over the columns of each M run (a whole wavefront per pair meant
+// 38 k wavefronts that each lived for a chain of dependent loads: 0.039 ms; two pairs per wavefront: 0.031 ms, four: 0.030 ms but
+// slower once alignments are long)
+constexpr int FIN_LANES = 32;
 __global__ __launch_bounds__(256) void finalize(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands,
                                                 const uint8_t *__restrict__ q_res, const uint32_t *__restrict__ q_off, const uint32_t *__restrict__ q_len,
                                                 const uint8_t *__restrict__ t_res, const uint32_t *__restrict__ t_off,
                                                 const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ runs, double min_id_pct, double min_qcov_pct)
 {
-    const int lane = threadIdx.x & 63;
-    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= n_sel) return;
+    const int lane = threadIdx.x & (FIN_LANES - 1);
+    const uint64_t s = (uint64_t)blockIdx.x * (256 / FIN_LANES) + threadIdx.x / FIN_LANES;
+    if (s >= n_sel) return;                                   // (whole lane groups leave together)
     const SelInfo info = sel[s];
     const uint64_t key = cands[info.cand];
     const uint32_t q = key_q(key), t = key_t(key);
@@ -185,12 +188,12 @@ __global__ __launch_bounds__(256) void finalize(uint64_t n_sel, SelInfo *__restr
         const int len = (int)(run >> 2);
         const uint32_t op = run & 3u;
         if (op == 0) {
-            for (int x = lane; x < len; x += 64) ident += (qs[i + x] == ts[j + x]) ? 1u : 0u;
+            for (int x = lane; x < len; x += FIN_LANES) ident += (qs[i + x] == ts[j + x]) ? 1u : 0u;
             i += len; j += len;
         } else if (op == 1) i += len;
         else j += len;
     }
-    for (int d = 32; d > 0; d >>= 1) ident += __shfl_xor(ident, d, 64);
+    for (int d = FIN_LANES / 2; d > 0; d >>= 1) ident += __shfl_xor(ident, d, 64);
     if (lane == 0) {
         const double idp = (double)ident * 100.0 / (double)info.aln_len;
         const double qcov = (double)(info.iend - info.istart + 1) * 100.0 / (double)q_len[q];
@@ -354,9 +357,10 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
         uint32_t *runs = ctx->ws[21].as<uint32_t>();
         const unsigned gw = (unsigned)ceil_div(n_sel, 4);
+        const unsigned gfin = (unsigned)ceil_div(n_sel, 256 / FIN_LANES);
         hipLaunchKernelGGL(walk, dim3((unsigned)ceil_div(n_sel, WALK_LANES)), dim3(WALK_LANES), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, sw2, ctx->ws[11].as<const uint64_t>(),
                            ctx->ws[13].as<const uint32_t>(), (const uint64_t *)run_off, runs);
-        hipLaunchKernelGGL(finalize, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
+        hipLaunchKernelGGL(finalize, dim3(gfin), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
                            ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(),
                            ctx->t.off.as<const uint32_t>(), (const uint64_t *)run_off, (const uint32_t *)runs, P.min_id_pct, P.min_qcov_pct);
         if (P.hsp_mode == 1) {
