@@ -1006,6 +1006,23 @@ def test_real_genes_on_the_gpu(ctx, tmp_path, monkeypatch):
     assert gpu_map.shape[0] > 150 and gpu_map.tolist() == ora_map.tolist() and gpu_ovl.tolist() == ora_ovl.tolist()
 
 
+def test_many_searches_on_one_context(ctx):
+    """a long-lived context: the single-launch scans tag their status words with a per-call epoch (14 bits for the 64-bit scans) and
+    clear the state when it wraps - 6 500 searches (three such scans each) pass that point; every result must equal the first"""
+    from peppan_amd import _native as N, synth
+    prots = synth.make_proteins(48, length=(60, 200), seed=21, family=4, sub=0.2)
+    ctx.set_query_aa(prots); ctx.set_ref_aa(prots)
+    p = N.default_params(0., 0., 10, 5)
+    h0, c0, st0 = ctx.search(p)
+    assert len(h0) > 40
+    for it in range(6500):
+        h, c, st = ctx.search(p, copy=False)
+        if it % 500 == 0 or it > 5300:
+            assert h.tobytes() == h0.tobytes() and c.tobytes() == c0.tobytes(), it
+    h, c, st = ctx.search(p)
+    assert h.tobytes() == h0.tobytes() and c.tobytes() == c0.tobytes()
+
+
 def test_query_index_partition_build_equals_plain_build(ctx):
     """the query seed index built by partition (coarse buckets in LDS, per-bucket LDS sort) gives the same search as the count -> scan
     -> fill build (params.reserved[2] = 1), also when a coarse bucket overflows LDS and the library falls back by itself"""
