@@ -1,0 +1,93 @@
+"""The self-defined aligner pinned to something other than itself: exhaustive full-matrix Smith-Waterman (oracle/full_sw.c,
+independent of align_oracle.c) as ground truth for optimality and recall of the seed-and-band heuristic.  The HIP kernels
+are bit-exact to align_oracle.c (tests/test_gpu_parity.py), so these numbers are the product's.
+
+Reference promise being checked: `diamond blastp --id --query-cover --evalue 1` (uberBlast.py:550) and
+`blastn -word_size 17 ... -evalue 1e-2` (uberBlast.py:294) return every target that meets the thresholds."""
+import numpy as np
+import pytest
+
+import recall_report as R
+
+
+def test_full_sw_is_a_textbook_alignment():
+    """known answers: the vectorised score pass, the matrix version and hand-checked alignments agree"""
+    from oracle import oracle as O, full_sw as F
+    p = O.default_params()
+    a = O.aa_codes('MKTAYIAKQRQISFVKSHFSRQLEERLGLIEVQ')
+    r, cig = F.align(a, a, p)
+    assert (r.q_start, r.q_end, r.t_start, r.t_end, r.n_ident, r.aln_len) == (1, len(a), 1, len(a), len(a), len(a))
+    assert cig.tolist() == [len(a) << 2]
+    assert r.score == sum(int(p.sub[int(c) * 32 + int(c)]) for c in a)
+    # one residue deleted from the target: a single D... no: query has one residue MORE -> one I of length 1, cost 11 + 1
+    b = np.concatenate([a[:15], a[16:]])
+    r, cig = F.align(a, b, p)
+    assert r.score == sum(int(p.sub[int(c) * 32 + int(c)]) for c in b) - 12
+    assert cig.tolist() == [15 << 2, (1 << 2) | 1, (len(a) - 16) << 2] and r.n_ident == len(b) and r.aln_len == len(a)
+    r2, cig2 = F.align(b, a, p)
+    assert r2.score == r.score and cig2.tolist() == [15 << 2, (1 << 2) | 2, (len(a) - 16) << 2]
+    # unrelated sequences: empty or tiny alignment, never negative
+    z = O.aa_codes('WWWWWWWW')
+    r, _ = F.align(z, O.aa_codes('GGGGGGGG'), p)
+    assert r.score == 0 and r.aln_len == 0
+    # the vectorised all-pairs pass equals the matrix version on ragged random proteins (16-bit and 32-bit lanes)
+    from peppan_amd import synth
+    prots = synth.make_proteins(40, length=(5, 180), seed=3, family=4, sub=0.3)
+    M = F.score_matrix(prots[:12], prots, p)
+    for i in range(12):
+        for j in (0, 1, 2, 3, 17, 39):
+            assert M[i, j] == F.align(prots[i], prots[j], p)[0].score
+    long_ = [np.tile(O.aa_codes('W'), 3200), np.tile(O.aa_codes('WC'), 1600)]          # 3200 x 11 > 32767: forces the 32-bit lanes
+    M = F.score_matrix(long_, long_, p)
+    assert M[0, 0] == 3200 * 11 and M[0, 1] == F.align(long_[0], long_[1], p)[0].score and M[1, 1] == 1600 * (11 + 9)
+
+
+def test_banded_oracle_alignment_equals_full_matrix_when_the_band_holds_it():
+    """align_oracle.c's banded alignment of a pair == full_sw.c's (score, end cell, start cell, identities, CIGAR) whenever the
+    optimal path stays inside the band - two independent implementations, same deterministic tie-breaking rules"""
+    from oracle import oracle as O, full_sw as F
+    from peppan_amd import synth
+    p = O.default_params()
+    prots = synth.make_proteins(60, length=(40, 260), seed=11, family=3, sub=0.25)
+    same = 0
+    for k in range(0, 60, 3):
+        for a, b in ((k, k + 1), (k + 1, k + 2), (k, k + 2)):
+            h, cig = O.align_one(prots[a], prots[b], (1 << 23) // 64, p)        # band around the main diagonal
+            r, fc = F.align(prots[a], prots[b], p)
+            if h.score == r.score:
+                assert (h.q_start, h.q_end, h.t_start, h.t_end, h.n_ident, h.aln_len) == (r.q_start, r.q_end, r.t_start, r.t_end, r.n_ident, r.aln_len)
+                assert cig.tolist() == fc.tolist()
+                same += 1
+            else:
+                assert h.score < r.score
+    assert same >= 50
+
+
+@pytest.mark.parametrize('name,n_q', [('protein1k_sample', 128), ('real_sample', 70)])
+def test_translated_search_recall_and_optimality(name, n_q):
+    """BASELINE configs[1] (1 000 synthetic genes) and the real genes of golden G16 through the diamond replacement"""
+    q, t, p, ms, q_idx, desc = R.workload(name)
+    r = R.report(q, t, p, ms, q_idx[:n_q])
+    print(r)
+    assert r['reported_above_optimum'] == 0
+    assert r['reported_below_optimum'] <= 0.005 * r['reported_pairs'], r        # every reported score is the pair's optimum
+    assert r['reported_not_in_truth'] <= 0.005 * r['reported_pairs'], r
+    for b in ('>=0.9', '0.7-0.9'):
+        if r['bins'][b]['truth']:
+            assert r['bins'][b]['recall'] >= 0.99, r                             # the floor VERDICT r1 asked for
+    assert r['lost_to_ungapped_filter'] <= 0.005 * r['truth_pairs'], r           # the pre-filter costs (almost) nothing
+    if name.startswith('protein1k'):
+        assert r['bins']['0.45-0.7']['truth'] > 100 and r['bins']['0.45-0.7']['recall'] >= 0.93, r
+        assert r['recall'] >= 0.975, r
+
+
+def test_nucleotide_search_recall_and_optimality():
+    """the blastn replacement: everything that shares an exact 17-mer (blastn's own -word_size 17 requirement) and passes the
+    cuts in the full matrix is reported; near-identical genes are all found"""
+    q, t, p, ms, q_idx, desc = R.workload('nucl1k_sample')
+    r = R.report(q, t, p, ms, q_idx[:64])
+    print(r)
+    assert r['reported_above_optimum'] == 0 and r['reported_below_optimum'] <= 0.005 * r['reported_pairs'], r
+    assert r['lost_to_ungapped_filter'] == 0, r            # with the filter off (every shared 17-mer aligned) nothing more is found
+    assert r['bins']['>=0.9']['truth'] >= 90 and r['bins']['>=0.9']['recall'] >= 0.99, r
+    assert r['found_of_truth'] + r['lost_to_seeding'] == r['truth_pairs']
