@@ -1,16 +1,26 @@
-"""Drop-in for PEPPAN's modules/clust.py: exemplar selection by iterated linear-time clustering.
+"""Exemplar selection by iterated linear-time clustering - the interface of PEPPAN's modules/clust.py on the MI355X.
 
-    clust(argv)                      clust.py:21-33    same flags -i -p -d -c -t -a
-    getClust(prefix, genes, params)  clust.py:34-111   same arguments, same two output files:
-        <prefix>.clust.exemplar   FASTA of the exemplars, original header lines, input order
-        <prefix>.clust.tab        "gene<TAB>exemplar" per input gene, sorted by gene name (string order)
+    clust(argv)                      (reference entry point clust.py:21)   flags -i -p -d -c -t -a
+    getClust(prefix, genes, params)  (reference entry point clust.py:34)   params: identity, coverage, n_thread, translate
+        -> <prefix>.clust.exemplar   FASTA of the exemplars: the input's own text blocks, input order
+           <prefix>.clust.tab        one "gene<TAB>exemplar" line per clustered gene, ordered by gene name as a string
 
-The three `mmseqs` calls of the reference (createdb / linclust / createtsv, clust.py:62-66) produce one thing the
-rest consumes: the relation "representative, member" over the round's input.  Here it comes from
-`cluster_relation` (GPU, peppan_amd.linclust) or from any callable given as params['cluster_fn'] - which is how the
-golden tests replay scripted mmseqs output through this file's logic.
+What the reference's three `mmseqs` calls (clust.py:62-66) hand to the rest of that function is a relation
+"representative, member" over the sequences of one FASTA file.  Here that relation comes from `cluster_relation`
+(the GPU clusterer, peppan_amd.linclust / pep_linclust) or from any callable passed as params['cluster_fn'] - the
+golden tests replay scripted mmseqs output through this module that way (tests/golden G9).
+
+The module works on an in-memory model of the FASTA file (`Block` = one record's name and its verbatim text) and on a
+forest of "is represented by" links; files are written once per round only because the clusterer reads a file.
+Behaviour kept from the reference because downstream results depend on it:
+  * at most three rounds, each re-clustering the previous round's exemplars; a round that does not shrink the
+    exemplar set ends the loop (its links are still applied);
+  * the exemplar of a cluster is its FIRST member in file order, not the clusterer's representative;
+  * a record the clusterer did not mention is dropped from the next round;
+  * the final table resolves chains gene -> exemplar -> exemplar of a later round.
 """
 import argparse
+import collections
 import os
 import shutil
 import sys
@@ -18,101 +28,119 @@ import tempfile
 
 from .configure import logger, transeq, uopen
 
+Block = collections.namedtuple('Block', 'name text')          # text: the header line and every following line, verbatim
+MAX_ROUNDS = 3
+
+
+def read_blocks(path):
+    """the records of a FASTA file as verbatim text blocks, file order; lines before the first header belong to nobody"""
+    blocks, name, lines = [], None, []
+    with uopen(path) as fin:
+        for line in fin:
+            if line[:1] == '>':
+                if name is not None:
+                    blocks.append(Block(name, ''.join(lines)))
+                name, lines = line[1:].strip().split()[0], [line]
+            elif name is not None:
+                lines.append(line)
+    if name is not None:
+        blocks.append(Block(name, ''.join(lines)))
+    return blocks
+
 
 def readFasta(fasta):
-    """[[name, SEQUENCE], ...] in file order (the dict version lives in configure.py)"""
-    out = []
-    with uopen(fasta) as fin:
-        for line in fin:
-            if line.startswith('>'):
-                out.append([line[1:].strip().split()[0], []])
-            elif len(line) > 0 and not line.startswith('#'):
-                out[-1][1].extend(line.strip().split())
-    for rec in out:
-        rec[1] = ''.join(rec[1]).upper()
-    return out
+    """[[name, SEQUENCE], ...] in file order; sequence = the record's non-comment tokens joined, upper case"""
+    records = []
+    for blk in read_blocks(fasta):
+        body = [tok for line in blk.text.split('\n')[1:] if not line.startswith('#') for tok in line.split()]
+        records.append([blk.name, ''.join(body).upper()])
+    return records
 
 
 def cluster_relation(fasta, identity, coverage, n_thread=1):
-    """default clusterer: linear-time k-mer grouping + verification on the MI355X; returns [(rep, member), ...]"""
+    """default clusterer: k-mer centres + ungapped / gapped verification on the GPU (K9); -> [(representative, member), ...]"""
     from . import linclust
     return linclust.linclust_file(fasta, identity, coverage)
 
 
-def _first_of_each_group(gene_file, groups):
-    """exemplar = first sequence of each group in FILE order (clust.py:71-85); returns (kept lines, {group: exemplar})"""
-    kept, chosen = [], {None: 1}
-    with open(gene_file) as fin:
-        writing = False
-        for line in fin:
-            if line.startswith('>'):
-                name = line[1:].strip().split()[0]
-                grp = groups.get(name, None)
-                writing = grp not in chosen
-                if writing:
-                    chosen[grp] = name
-            if writing:
-                kept.append(line)
-    return kept, chosen
+def _one_round(blocks, link):
+    """exemplar choice of one round.  link: gene -> cluster label for every gene seen so far.
+    Returns (surviving blocks, {cluster label: exemplar name}): the survivor of a cluster is its first block in file order;
+    blocks without a label do not survive."""
+    first_of = {}
+    survivors = []
+    for blk in blocks:
+        label = link.get(blk.name)
+        if label is not None and label not in first_of:
+            first_of[label] = blk.name
+            survivors.append(blk)
+    return survivors, first_of
+
+
+def _resolve(link):
+    """every gene's final exemplar: follow the links until a gene that represents itself (iterative, with memo)"""
+    final = {}
+    for gene in link:
+        trail, g = [], gene
+        while g not in final and link[g] != g:
+            trail.append(g)
+            g = link[g]
+        root = final.get(g, g)
+        for t in trail:
+            final[t] = root
+        final.setdefault(g, root)
+    return final
 
 
 def getClust(prefix, genes, params):
     cluster_fn = params.get('cluster_fn') or cluster_relation
-    groups = {}
+    exemplar_path, tab_path = '{0}.clust.exemplar'.format(prefix), '{0}.clust.tab'.format(prefix)
+    link = {}                                              # gene -> label, then -> exemplar of its cluster
     work = tempfile.mkdtemp(prefix='NS_', dir='.')
     try:
-        if not params['translate']:
-            gene_file = genes
-        else:
-            na_seqs = readFasta(genes)
-            gene_file = os.path.join(work, 'seq.aa')
-            with open(gene_file, 'w') as fout:
-                for n, s in transeq(na_seqs, frame='1', transl_table='starts'):
-                    fout.write('>{0}\n{1}\n'.format(n, s[0]))
-        ref_file = os.path.join(work, 'seq.ref')
-        n_ref = 999999999999999
-        for _ in range(3):
-            for rep, member in cluster_fn(gene_file, params['identity'], params['coverage'], params['n_thread']):
-                groups[str(member)] = str(rep)
-            kept, chosen = _first_of_each_group(gene_file, groups)
-            for gene, grp in groups.items():
-                if grp in chosen:
-                    groups[gene] = chosen[grp]
-            with open(ref_file, 'w') as fout:          # `kept` is complete, so overwriting the round's own input is safe
-                fout.writelines(kept)
-            if n_ref <= len(chosen):
+        nucleotides = None
+        round_input = genes
+        if params['translate']:                            # -a: cluster the first-frame proteins, report the nucleotide records
+            nucleotides = readFasta(genes)
+            round_input = os.path.join(work, 'seq.aa')
+            with open(round_input, 'w') as fout:
+                fout.writelines('>{0}\n{1}\n'.format(n, frames[0]) for n, frames in transeq(nucleotides, frame='1', transl_table='starts'))
+        survivors_path = os.path.join(work, 'seq.ref')
+        n_before = None
+        for _ in range(MAX_ROUNDS):
+            link.update((str(member), str(rep)) for rep, member in cluster_fn(round_input, params['identity'], params['coverage'], params['n_thread']))
+            survivors, first_of = _one_round(read_blocks(round_input), link)
+            for gene, label in link.items():               # every gene seen so far follows its cluster's exemplar
+                link[gene] = first_of.get(label, label)
+            with open(survivors_path, 'w') as fout:
+                fout.writelines(blk.text for blk in survivors)
+            if n_before is not None and len(first_of) >= n_before:
                 break
-            n_ref = len(chosen)
-            gene_file = ref_file
-        if not params['translate']:
-            shutil.copy2(ref_file, '{0}.clust.exemplar'.format(prefix))
+            n_before, round_input = len(first_of), survivors_path
+        if nucleotides is None:
+            shutil.copy2(survivors_path, exemplar_path)
         else:
-            na = dict(na_seqs)
-            with open('{0}.clust.exemplar'.format(prefix), 'w') as fout:
-                for n, _ in readFasta(ref_file):
-                    fout.write('>{0}\n{1}\n'.format(n, na[n]))
+            by_name = dict(nucleotides)
+            with open(exemplar_path, 'w') as fout:
+                fout.writelines('>{0}\n{1}\n'.format(blk.name, by_name[blk.name]) for blk in read_blocks(survivors_path))
     finally:
         shutil.rmtree(work)
-    with open('{0}.clust.tab'.format(prefix), 'w') as fout:
-        for gene, grp in sorted(groups.items()):
-            g = gene
-            while g != grp:                      # follow exemplar -> exemplar chains of later rounds
-                g, grp = grp, groups[grp]
-            groups[gene] = grp
-            fout.write('{0}\t{1}\n'.format(gene, grp))
-    return '{0}.clust.exemplar'.format(prefix), '{0}.clust.tab'.format(prefix)
+    final = _resolve(link)
+    with open(tab_path, 'w') as fout:
+        fout.writelines('{0}\t{1}\n'.format(gene, final[gene]) for gene in sorted(link))
+    return exemplar_path, tab_path
 
 
 def clust(argv):
-    parser = argparse.ArgumentParser(description='Get clusters and exemplars of clusters from gene sequences (MI355X linear-time clustering).')
-    parser.add_argument('-i', '--input', help='[INPUT; REQUIRED] name of the file containing gene sequneces in FASTA format.', required=True)
-    parser.add_argument('-p', '--prefix', help='[OUTPUT; REQUIRED] prefix of the outputs.', required=True)
-    parser.add_argument('-d', '--identity', help='[PARAM; DEFAULT: 0.9] minimum intra-cluster identity.', default=0.9, type=float)
-    parser.add_argument('-c', '--coverage', help='[PARAM; DEFAULT: 0.9] minimum intra-cluster coverage.', default=0.9, type=float)
-    parser.add_argument('-t', '--n_thread', help='[PARAM; DEFAULT: 8]   accepted for compatibility.', default=8, type=int)
-    parser.add_argument('-a', '--translate', help='[PARAM; DEFAULT: False] activate to cluster in translated sequence.', default=False, action='store_true')
-    args = parser.parse_args(argv)
-    exemplar, tab = getClust(args.prefix, args.input, args.__dict__)
+    ap = argparse.ArgumentParser(description='Cluster gene sequences on an MI355X and pick one exemplar per cluster.')
+    ap.add_argument('-i', '--input', required=True, help='FASTA file with the gene sequences')
+    ap.add_argument('-p', '--prefix', required=True, help='the two outputs are written to <prefix>.clust.exemplar and <prefix>.clust.tab')
+    ap.add_argument('-d', '--identity', type=float, default=0.9, help='lowest identity of a member to its cluster centre (0.9)')
+    ap.add_argument('-c', '--coverage', type=float, default=0.9, help='lowest alignment coverage of member and centre (0.9)')
+    ap.add_argument('-t', '--n_thread', type=int, default=8, help='kept for command-line compatibility; the clustering runs on the GPU')
+    ap.add_argument('-a', '--translate', action='store_true', default=False, help='cluster the translated sequences instead of the nucleotides')
+    args = ap.parse_args(argv)
+    exemplar, tab = getClust(args.prefix, args.input, vars(args))
     logger('Exemplar sequences in {0}'.format(exemplar))
     logger('Clusters in {0}'.format(tab))
     return exemplar, tab

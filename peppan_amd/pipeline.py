@@ -12,7 +12,6 @@ import re
 from operator import itemgetter
 
 import numpy as np
-import pandas as pd
 
 from .clust import getClust
 from .configure import logger, readFasta, uopen
@@ -46,130 +45,188 @@ def writeGenes(fname, genes, priority, ctx=None):
     return fname, groups
 
 
+def identity_schedule(target):
+    """the identity levels of the iterative clustering: 1.00, 0.99, ... down to the target (11 levels for 0.90)"""
+    return [float(x) for x in np.round(np.arange(1., target - 0.005, -0.01), 5)]
+
+
+def _tab_pairs_after_first_line(tab):
+    """(gene, exemplar) rows of a clust.tab file WITHOUT its first line, columns typed the way a header-inferring CSV reader
+    types them (all-integer column -> ints).  The reference reads the file with pandas' default header handling
+    (PEPPAN.py:1786), so the first gene of every table silently never reaches clust.npy; downstream results depend on it."""
+    with open(tab) as fin:
+        rows = [line.rstrip('\n').split('\t')[:2] for line in fin][1:]
+    cols = [[r[0] for r in rows], [r[1] for r in rows]]
+    for c in cols:
+        if c and all(re.fullmatch(r'[+-]?\d+', x) for x in c):
+            c[:] = [int(x) for x in c]
+    return list(zip(*cols))
+
+
 def iterClust(prefix, genes, geneGroup, params):
-    """11 clustering steps from identity 1.00 down to the target, each on the previous step's exemplars"""
-    target = params['identity']
-    g = genes
-    for iden in np.round(np.arange(1., target - 0.005, -0.01), 5):
-        params.update({'identity': iden, 'coverage': np.round(params['coverage'], 2)})
-        label = int(min(1., iden + 0.005) * 10000)
-        g, tab = getClust(prefix, g, params)
-        exemplars = readFasta(g, headOnly=True)
-        # NB: no header=None - pandas takes the first line of clust.tab as column names, exactly like PEPPAN.py:1786
-        pairs = pd.read_csv(tab, sep='\t').values
-        logger('Iterative clustering. {0} exemplars left with identity = {1}'.format(len(exemplars), iden))
-        for g1, g2 in pairs[pairs.T[0] != pairs.T[1]]:
-            r, q = (g1, g2) if str(g1) in exemplars else (g2, g1)
-            geneGroup.append([r, q, label])
+    """clustering at falling identity levels, each level on the exemplars of the one before; appends [exemplar, member,
+    identity label] edges to geneGroup, saves them as <prefix>.clust.npy and returns the last exemplar file"""
+    coverage = np.round(params['coverage'], 2)
+    current = genes
+    for level in identity_schedule(params['identity']):
+        params.update(identity=level, coverage=coverage)
+        current, tab = getClust(prefix, current, params)
+        exemplars = readFasta(current, headOnly=True)
+        logger('Iterative clustering. {0} exemplars left with identity = {1}'.format(len(exemplars), level))
+        label = int(min(1., level + 0.005) * 10000)
+        for gene, other in _tab_pairs_after_first_line(tab):
+            if gene != other:
+                geneGroup.append([gene, other, label] if str(gene) in exemplars else [other, gene, label])
     np.save('{0}.clust.npy'.format(prefix), np.array(geneGroup, dtype=int))
-    return g
+    return current
 
 
+# ---- the decision pass over the all-vs-all table (PEPPAN.py:194-294; behaviour spec: SURVEY.md appendix A.4) -----------------
+ORDINARY, CONFLICT, ABSORB_QUERY, ABSORB_REF = 0, 1, 2, 3
 _CIGAR_RUN = re.compile(r'(\d+)([A-Z])')
 
 
-def _ortholog_value(rows, ortho_pairs, params):
-    """decision for one (query, reference) pair from all of its forward hits (PEPPAN.py:195-224)"""
-    key = tuple(sorted([rows[0][0], rows[0][1]]))
-    if key in ortho_pairs:
-        return
-    ql, sl = int(rows[0][12]), int(rows[0][13])
-    if min(ql, sl) * 20 <= max(ql, sl):
-        return
-    need_len = min(params['match_len2'], params['match_len'], params['match_len1'])
-    need_prop = min(params['match_prop'], params['match_prop1'], params['match_prop2']) * ql
-    any_frame = 'f' in params['incompleteCDS']
-    matched = {}
-    for part in rows:
-        qpos, _, spos, _ = [int(x) for x in part[6:10]]
-        for n, op in _CIGAR_RUN.findall(part[14]):
-            n = int(n)
-            if op == 'M':
-                fq, fs = qpos % 3, spos % 3
-                if fq == fs or any_frame:
-                    matched.update({qpos + x: part[2] for x in range((3 - (fq - 1)) % 3, n)})
+class _SupportLimits(object):
+    """the thresholds of the ortholog-support test, derived once from the parameter dict"""
+
+    def __init__(self, params):
+        self.lens = (params['match_len'], params['match_len1'], params['match_len2'])
+        self.props = (params['match_prop'], params['match_prop1'], params['match_prop2'])
+        self.identity = params['match_identity'] * 10000
+        self.any_frame = 'f' in params['incompleteCDS']
+
+    def enough_to_decide(self, n_nt, q_len):
+        return n_nt >= min(self.lens) and n_nt >= min(self.props) * q_len
+
+    def full_support(self, n_nt, shorter):
+        return n_nt >= min(max(l, p * shorter) for l, p in zip(self.lens, self.props))
+
+
+def _pair_support(hits, lim):
+    """Ortholog support of one (query, reference) pair from its forward hits in table order.
+    A coverage map over the query's nucleotide positions records, for every position inside an in-frame M run (counted from the
+    first position of the run that starts a codon of the query), the identity of the LAST hit that covered it; positions are remembered in the
+    order they were first covered, because the mean is taken over that sequence.  After every M run: once enough positions
+    are covered the mean identity is tested - passing ends the walk with the mean (full support) or 0 (partial support);
+    failing lets later runs and hits add positions.  -> None (no decision) | 0 | int(mean identity * 1e4)"""
+    q_len, r_len = int(hits[0][12]), int(hits[0][13])
+    if 20 * min(q_len, r_len) <= max(q_len, r_len):
+        return None
+    parsed = [(int(h[6]), int(h[8]), h[2], [(int(n), op) for n, op in _CIGAR_RUN.findall(h[14])]) for h in hits]
+    size = max(q0 + sum(n for n, op in runs if op in 'MI') for q0, _, _, runs in parsed) + 1
+    covered = np.zeros(size, dtype=bool)
+    ident_at = np.zeros(size, dtype=np.float64)
+    first_cover_order, n_cov = [], 0
+    for qpos, rpos, ident, runs in parsed:
+        for n, op in runs:
+            if op == 'I':
                 qpos += n
-                spos += n
-                if len(matched) * 3 >= need_len and len(matched) * 3 >= need_prop:
-                    ave = int(np.mean(list(matched.values())) * 10000)
-                    if ave >= params['match_identity'] * 10000:
-                        short = min(sl, ql)
-                        full = min(max(params['match_len'], params['match_prop'] * short), max(params['match_len1'], params['match_prop1'] * short),
-                                   max(params['match_len2'], params['match_prop2'] * short))
-                        ortho_pairs[key] = ave if len(matched) * 3 >= full else 0
-                        return
-            elif op == 'I':
-                qpos += n
+            elif op != 'M':
+                rpos += n
             else:
-                spos += n
+                lo, hi = qpos + (1 - qpos) % 3, qpos + n
+                if lo < hi and (lim.any_frame or qpos % 3 == rpos % 3):
+                    fresh = np.flatnonzero(~covered[lo:hi]) + lo
+                    first_cover_order.append(fresh)
+                    n_cov += fresh.size
+                    covered[lo:hi] = True
+                    ident_at[lo:hi] = ident
+                qpos += n
+                rpos += n
+                if lim.enough_to_decide(3 * n_cov, q_len):
+                    mean = int(np.mean(ident_at[np.concatenate(first_cover_order)]) * 10000)
+                    if mean >= lim.identity:
+                        return mean if lim.full_support(3 * n_cov, min(q_len, r_len)) else 0
+    return None
+
+
+def _classify_rows(table, priorities, near_identity, cover):
+    """order-independent part of the decision, for all rows at once -> (action code per row, forward flag per row)"""
+    num = lambda c: table[:, c].astype(np.float64)
+    q, r = table[:, 0].astype(np.int64), table[:, 1].astype(np.int64)
+    iden, qs, qe, ss, se, ql, sl = num(2), num(6), num(7), num(8), num(9), num(12), num(13)
+    rank_q = np.array([priorities[g][0] for g in q.tolist()])
+    rank_r = np.array([priorities[g][0] for g in r.tolist()])
+    q_span, r_span = qe - qs + 1, np.abs(se - ss) + 1
+    near = (q != r) & (iden >= near_identity)
+    same_head, same_tail = (qs % 3 == ss % 3), ((ql - qe) % 3 == (sl - se) % 3)
+    off_frame = (ss > se) | (~same_head & same_tail)                              # reverse strand, or shifted at the head only
+    in_frame = ~off_frame & (ss < se) & same_head & same_tail
+    root = np.sqrt(cover)
+    action = np.full(len(table), ORDINARY, dtype=np.int8)
+    action[near & off_frame & ((q_span >= cover * ql) | (r_span >= cover * sl))] = CONFLICT
+    action[near & in_frame & (ql <= sl) & (q_span >= root * sl) & (rank_q >= rank_r)] = ABSORB_QUERY
+    action[near & in_frame & (ql > sl) & (r_span >= root * ql) & (rank_q <= rank_r)] = ABSORB_REF
+    return q.tolist(), r.tolist(), action.tolist(), (ss < se).tolist(), (iden * 10000.).astype(np.int64).tolist()
+
+
+def _self_search(clust, params, pool):
+    tools = '--blastn' if params['noDiamond'] else '--blastn --diamond -s 1'
+    argv = ['-r', clust, '-q', clust] + tools.split() + ['--min_id', str(params['match_identity'] - 0.05), '--min_cov', str(params['match_frag_len']),
+                                                        '-t', str(params['n_thread']), '--min_ratio', str(params['match_frag_prop']), '-e', '3,3', '-p',
+                                                        '--gtable', str(params['gtable'])]
+    return uberBlast(argv, pool)
 
 
 def get_similar_pairs(clust, priorities, params, pool=None):
-    """all-vs-all search of the exemplars and the single ordered pass over its table that decides which exemplars
-    are absorbed (near-identical, in frame), which pairs conflict (-2) and which are ortholog-like (identity*1e4)"""
-    flags = '--blastn' if params['noDiamond'] else '--blastn --diamond -s 1'
-    self_bsn = uberBlast('-r {0} -q {0} {6} --min_id {1} --min_cov {2} -t {3} --min_ratio {4} -e 3,3 -p --gtable {5}'.format(
-        clust, params['match_identity'] - 0.05, params['match_frag_len'], params['n_thread'], params['match_frag_prop'], params['gtable'], flags).split(), pool)
-    self_bsn.T[:2] = self_bsn.T[:2].astype(int)
-    presence, ortho_pairs, absorbed, buf = {}, {}, [], []
-    ci, cmp_ = params['clust_identity'], params['clust_match_prop']
+    """All-vs-all search of the exemplars, then ONE ordered pass over its table (rows sorted by query, reference, score with
+    the names compared as strings) deciding which exemplars are absorbed by a near-identical in-frame partner, which pairs
+    conflict (-2) and which are ortholog-like (mean identity * 1e4).  The row-local tests are evaluated for all rows at once
+    (_classify_rows); only the state that makes the pass order-dependent is walked row by row:
+      alive[g]   0 once g was absorbed or found repetitive; rows touching a dead gene are ignored from then on
+      pending    the forward rows of the current (query, reference) pair; the pair is settled when the NEXT surviving row
+                 belongs to another pair (or at the end) - not earlier, rows in between still see the old state
+    Side effects as in the reference: the exemplar FASTA loses the dead genes, absorbed pairs are added to clust.npy."""
+    table = _self_search(clust, params, pool)
+    if len(table):
+        table.T[:2] = table.T[:2].astype(int)
+    q, r, action, forward, iden4 = _classify_rows(table, priorities, params['clust_identity'], params['clust_match_prop']) if len(table) else ([], [], [], [], [])
+    lim = _SupportLimits(params)
+    alive, verdict, absorbed, pending = {}, {}, [], []
 
-    def flush():
-        if len(buf) >= 50:
-            presence[buf[0][1]] = 0                    # >= 50 hits for one pair: the reference gene is repetitive
-        elif buf and buf[0][0] != buf[0][1]:
-            _ortholog_value(buf, ortho_pairs, params)
+    def settle(rows):
+        a, b = q[rows[0]], r[rows[0]]
+        if len(rows) >= 50:
+            alive[b] = 0                                   # fifty or more hits between two genes: the reference gene is a repeat
+        elif a != b and (min(a, b), max(a, b)) not in verdict:
+            value = _pair_support([table[k] for k in rows], lim)
+            if value is not None:
+                verdict[(min(a, b), max(a, b))] = value
 
-    for part in self_bsn:
-        q, r = part[0], part[1]
-        if q not in presence:
-            presence[q] = 1
-        elif presence[q] == 0:
+    for k in range(len(table)):
+        a, b = q[k], r[k]
+        if alive.setdefault(a, 1) == 0 or alive.get(b, 1) == 0:
             continue
-        iden, qs, qe, ss, se, ql, sl = float(part[2]), float(part[6]), float(part[7]), float(part[8]), float(part[9]), float(part[12]), float(part[13])
-        if presence.get(r, 1) == 0:
-            continue
-        qa, sa = qe - qs + 1, abs(se - ss) + 1
-        if q != r and iden >= ci:
-            same_tail = (ql - qe) % 3 == (sl - se) % 3
-            if ss > se or (qs % 3 != ss % 3 and same_tail):
-                if qa >= cmp_ * ql or sa >= cmp_ * sl:
-                    ortho_pairs[tuple(sorted([q, r]))] = -2
-                    continue
-            elif ss < se and qs % 3 == ss % 3 and same_tail:
-                if ql <= sl:
-                    if qa >= np.sqrt(cmp_) * sl and priorities[q][0] >= priorities[r][0]:
-                        absorbed.append([int(r), int(q), int(iden * 10000.)])
-                        presence[q] = 0
-                        continue
-                elif sa >= np.sqrt(cmp_) * ql and priorities[q][0] <= priorities[r][0]:
-                    absorbed.append([int(q), int(r), int(iden * 10000.)])
-                    presence[r] = 0
-                    continue
-        if ss >= se:
-            continue
-        if buf and (buf[0][0] != q or buf[0][1] != r):
-            flush()
-            buf = []
-        buf.append(part)
-    if buf:
-        flush()
+        if action[k] == CONFLICT:
+            verdict[(min(a, b), max(a, b))] = -2
+        elif action[k] == ABSORB_QUERY:
+            absorbed.append([b, a, iden4[k]])
+            alive[a] = 0
+        elif action[k] == ABSORB_REF:
+            absorbed.append([a, b, iden4[k]])
+            alive[b] = 0
+        elif forward[k]:
+            if pending and (q[pending[0]], r[pending[0]]) != (a, b):
+                settle(pending)
+                pending = []
+            pending.append(k)
+    if pending:
+        settle(pending)
 
-    kept = []
-    with uopen(params['clust'], 'r') as fin:
-        write = False
-        for line in fin:
-            if line.startswith('>'):
-                write = presence.get(int(line[1:].strip().split()[0]), 0) > 0
-            if write:
-                kept.append(line)
-    with open(params['clust'], 'w') as fout:
-        fout.writelines(kept)
+    _drop_dead_exemplars(params['clust'], alive)
     if absorbed:
         npy = params['clust'].rsplit('.', 1)[0] + '.npy'
-        clu = np.vstack([np.load(npy, allow_pickle=True), absorbed])
-        np.save(npy, clu[np.argsort(-clu.T[2])])
-    return np.array([[k[0], k[1], v] for k, v in ortho_pairs.items() if v != 0], dtype=int)
+        edges = np.vstack([np.load(npy, allow_pickle=True), absorbed])
+        np.save(npy, edges[np.argsort(-edges.T[2])])
+    return np.array([[a, b, v] for (a, b), v in verdict.items() if v != 0], dtype=int)
+
+
+def _drop_dead_exemplars(fasta, alive):
+    """rewrite the exemplar FASTA in place, keeping the records of genes that appeared as a query and are still alive"""
+    from .clust import read_blocks
+    keep = [blk.text for blk in read_blocks(fasta) if alive.get(int(blk.name), 0) > 0]
+    with open(fasta, 'w') as fout:
+        fout.writelines(keep)
 
 
 def _edges(cluFile, bsnFile):

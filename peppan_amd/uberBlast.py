@@ -471,81 +471,81 @@ class RunBlast(object):
             p[14] = ''.join([str(n) + t for n, t in cigar])
 
 
-def uberBlast(args, extPool=None):
+# one flag table for both command-line front ends: (flags, keyword arguments of add_argument).  Names, defaults and meaning
+# are the reference's command line (uberBlast.py:565-591) because callers pass these strings verbatim (PEPPAN.py:229, 771).
+_TOOL_FLAGS = (
+    (('--blastn',), dict(action='store_true', default=False, help='run the nucleotide search (17-mer seeds, +2/-3, both strands) on the GPU')),
+    (('--diamond',), dict(action='store_true', default=False, help='run the translated search (6 reference frames, BLOSUM62) on the GPU')),
+    (('--diamondSELF',), dict(action='store_true', default=False, help='translated search against the 3 forward frames only, 200 targets per query')),
+    (('--gpu',), dict(action='store_true', default=False, help='same as --diamond')),
+)
+_SEARCH_FLAGS = (
+    (('--gtable',), dict(type=int, default=11, help='translation table: 11 (bacteria) or 4 (Mycoplasma, TGA codes W) [11]')),
+    (('--min_id',), dict(type=float, default=0.3, help='lowest identity of a reported alignment, before any rescoring [0.3]')),
+    (('--min_cov',), dict(type=float, default=40., help='shortest reported alignment, in query nucleotides [40]')),
+    (('--min_ratio',), dict(type=float, default=0.05, help='shortest reported alignment as a fraction of the query length [0.05]')),
+    (('-s', '--re_score'), dict(type=int, default=0, help='recompute identity and score from the nucleotides: 0 off, 1 per base, 2 per amino acid, 3 per codon position [0]')),
+    (('-f', '--filter'), dict(action='store_true', default=False, help='of two alignments of one query that overlap on the reference keep the better one')),
+    (('--filter_cov',), dict(type=float, default=0.9, help='overlap (fraction of either alignment) at which -f acts [0.9]')),
+    (('--filter_score',), dict(type=float, default=0., help='score margin the better alignment needs for -f to act [0]')),
+    (('-m', '--linear_merge'), dict(action='store_true', default=False, help='chain collinear alignments of one query into merged groups (column 17)')),
+    (('--merge_gap',), dict(type=float, default=600., help='largest distance between chained alignments [600]')),
+    (('--merge_diff',), dict(type=float, default=1.5, help='largest ratio of the query and reference distances inside a chain [1.5]')),
+    (('-O', '--return_overlap'), dict(action='store_true', default=False, help='also return the pairs of alignments that overlap on the reference')),
+    (('--overlap_length',), dict(type=float, default=300, help='an overlap this long is always reported [300]')),
+    (('--overlap_proportion',), dict(type=float, default=0.6, help='... or this fraction of either alignment [0.6]')),
+    (('-e', '--fix_end'), dict(default='0,0', help='L,R: stretch an alignment to the query ends when at most L / R bases are left unaligned there [0,0]')),
+    (('-t', '--n_thread'), dict(type=int, default=1, help='kept for command-line compatibility (the search runs on the GPU)')),
+    (('-p', '--process'), dict(action='store_true', default=False, help='kept for command-line compatibility')),
+)
+
+
+def _parser(description, with_reference):
     import argparse
-    parser = argparse.ArgumentParser(description='Similarity search on MI355X with PEPPAN uberBlast semantics.')
-    parser.add_argument('-r', '--reference', help='[INPUT; REQUIRED] filename for the reference.', required=True)
-    parser.add_argument('-q', '--query', help='[INPUT; REQUIRED] filename for the query.', required=True)
-    parser.add_argument('-o', '--output', help='[OUTPUT; Default: None] save result to a file or to screen (stdout).', default=None)
-    parser.add_argument('--blastn', help='nucleotide search', action='store_true', default=False)
-    parser.add_argument('--diamond', help='translated search (GPU)', action='store_true', default=False)
-    parser.add_argument('--diamondSELF', help='translated search, forward frames only, 200 hits (GPU)', action='store_true', default=False)
-    parser.add_argument('--gpu', help='alias of --diamond', action='store_true', default=False)
-    parser.add_argument('--device', help='HIP device index [default: $LOCAL_RANK or 0]', type=int, default=None)
-    parser.add_argument('--gtable', help='[DEFAULT: 11] genetic table to use. 11 for bacterial genomes and 4 for Mycoplasma', default=11, type=int)
-    parser.add_argument('--min_id', help='[DEFAULT: 0.3] Minimum identity before reScore for an alignment to be kept', type=float, default=0.3)
-    parser.add_argument('--min_cov', help='[DEFAULT: 40] Minimum length for an alignment to be kept', type=float, default=40.)
-    parser.add_argument('--min_ratio', help='[DEFAULT: 0.05] Minimum length for an alignment to be kept, proportional to the length of the query', type=float, default=0.05)
-    parser.add_argument('-s', '--re_score', help='[DEFAULT: 0] 0: No rescore; 1: nucleotides; 2: amino acid; 3: codons', type=int, default=0)
-    parser.add_argument('-f', '--filter', help='[DEFAULT: False] Remove secondary alignments if they overlap with any other regions', default=False, action='store_true')
-    parser.add_argument('--filter_cov', help='[DEFAULT: 0.9] ', default=0.9, type=float)
-    parser.add_argument('--filter_score', help='[DEFAULT: 0] ', default=0., type=float)
-    parser.add_argument('-m', '--linear_merge', help='[DEFAULT: False] Merge consecutive alignments', default=False, action='store_true')
-    parser.add_argument('--merge_gap', help='[DEFAULT: 600] ', default=600., type=float)
-    parser.add_argument('--merge_diff', help='[DEFAULT: 1.5] ', default=1.5, type=float)
-    parser.add_argument('-O', '--return_overlap', help='[DEFAULT: False] Report overlapped alignments', default=False, action='store_true')
-    parser.add_argument('--overlap_length', help='[DEFAULT: 300] Minimum overlap to report', default=300, type=float)
-    parser.add_argument('--overlap_proportion', help='[DEFAULT: 0.6] Minimum overlap proportion to report', default=0.6, type=float)
-    parser.add_argument('-e', '--fix_end', help='[FORMAT: L,R; DEFAULT: 0,0] Extend alignment to the edges if the un-aligned regions are <= [L,R] basepairs.', default='0,0')
-    parser.add_argument('-t', '--n_thread', help='[DEFAULT: 1] accepted for compatibility', type=int, default=1)
-    parser.add_argument('-p', '--process', help='accepted for compatibility', action='store_true', default=False)
-    args = parser.parse_args(args)
-    if extPool is not None:
-        args.process = extPool
-    methods = [m for m in ('blastn', 'diamond', 'diamondSELF', 'gpu') if getattr(args, m)]
-    if 'gpu' in methods and 'diamond' in methods:
-        methods.remove('gpu')
-    fix_end = args.fix_end.split(',')
-    fix_end[-2:] = list(map(float, fix_end[-2:]))
-    data = RunBlast(args.device).run(args.reference, args.query, methods, args.min_id, args.min_cov, args.min_ratio, args.gtable,
-                                     args.n_thread, args.process, args.re_score, [args.filter, args.filter_cov, args.filter_score],
-                                     [args.linear_merge, args.merge_gap, args.merge_diff],
-                                     [args.return_overlap, args.overlap_length, args.overlap_proportion], fix_end)
-    if args.output:
-        fout = sys.stdout if args.output.upper() == 'STDOUT' else open(args.output, 'w')
-        for t in data:
-            fout.write('\t'.join([str(tt) for tt in t]) + '\n')
-        fout.close()
+    ap = argparse.ArgumentParser(description=description)
+    if with_reference:
+        ap.add_argument('-r', '--reference', required=True, help='FASTA / FASTQ file searched against (gzip accepted)')
+        ap.add_argument('-o', '--output', default=None, help='write the table as tab-separated text to this file, or STDOUT')
+        ap.add_argument('--device', type=int, default=None, help='HIP device index [$LOCAL_RANK, else 0]')
+    ap.add_argument('-q', '--query', required=True, help='FASTA / FASTQ file with the query sequences')
+    for flags, kw in _TOOL_FLAGS + _SEARCH_FLAGS:
+        ap.add_argument(*flags, **kw)
+    return ap
+
+
+def _run_arguments(a):
+    """parsed flags -> (tools in the order the reference runs them, keyword arguments of RunBlast.run / run_batch)"""
+    wanted = (('blastn', a.blastn), ('diamond', a.diamond or a.gpu), ('diamondSELF', a.diamondSELF))
+    ends = a.fix_end.split(',')
+    ends[-2:] = [float(x) for x in ends[-2:]]
+    kw = dict(re_score=a.re_score, filter=[a.filter, a.filter_cov, a.filter_score], linear_merge=[a.linear_merge, a.merge_gap, a.merge_diff],
+              return_overlap=[a.return_overlap, a.overlap_length, a.overlap_proportion], fix_end=ends)
+    return [name for name, on in wanted if on], kw
+
+
+def uberBlast(args, extPool=None):
+    """command-line style entry point (reference: uberBlast.py:564): list of flags -> hit table, or (table, overlaps) with -O"""
+    a = _parser('Similarity search of query sequences against a reference on an MI355X; table format of PEPPAN uberBlast.', True).parse_args(args)
+    methods, kw = _run_arguments(a)
+    data = RunBlast(a.device).run(a.reference, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread,
+                                  extPool if extPool is not None else a.process, **kw)
+    if a.output:
+        rows = data[0] if a.return_overlap else data
+        text = ''.join('\t'.join(map(str, row)) + '\n' for row in rows)
+        if a.output.upper() == 'STDOUT':
+            sys.stdout.write(text)
+        else:
+            with open(a.output, 'w') as fout:
+                fout.write(text)
     return data
 
 
 def uberBlastBatch(references, args, device=None):
     """uberBlast for a LIST of reference files and one query file: `args` are uberBlast's flags without -r/-o.
     Returns one result per reference, each identical to uberBlast(['-r', ref] + args).  One GPU search per tool."""
-    import argparse
-    parser = argparse.ArgumentParser()
-    parser.add_argument('-q', '--query', required=True)
-    for flag in ('--blastn', '--diamond', '--diamondSELF', '--gpu', '-f', '-m', '-O', '-p'):
-        parser.add_argument(flag, action='store_true', default=False)
-    parser.add_argument('--gtable', default=11, type=int)
-    parser.add_argument('--min_id', type=float, default=0.3)
-    parser.add_argument('--min_cov', type=float, default=40.)
-    parser.add_argument('--min_ratio', type=float, default=0.05)
-    parser.add_argument('-s', '--re_score', type=int, default=0)
-    parser.add_argument('--filter_cov', default=0.9, type=float)
-    parser.add_argument('--filter_score', default=0., type=float)
-    parser.add_argument('--merge_gap', default=600., type=float)
-    parser.add_argument('--merge_diff', default=1.5, type=float)
-    parser.add_argument('--overlap_length', default=300, type=float)
-    parser.add_argument('--overlap_proportion', default=0.6, type=float)
-    parser.add_argument('-e', '--fix_end', default='0,0')
-    parser.add_argument('-t', '--n_thread', type=int, default=1)
-    a = parser.parse_args(args)
-    methods = [m for m, on in (('blastn', a.blastn), ('diamond', a.diamond or a.gpu), ('diamondSELF', a.diamondSELF)) if on]
-    fix_end = list(map(float, a.fix_end.split(',')))
-    return RunBlast(device).run_batch(references, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread, a.p, a.re_score,
-                                      [a.f, a.filter_cov, a.filter_score], [a.m, a.merge_gap, a.merge_diff],
-                                      [a.O, a.overlap_length, a.overlap_proportion], fix_end)
+    a = _parser('uberBlast over many reference files with one search per tool.', False).parse_args(args)
+    methods, kw = _run_arguments(a)
+    return RunBlast(device).run_batch(references, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread, a.process, **kw)
 
 
 if __name__ == '__main__':
