@@ -1,22 +1,27 @@
 #!/usr/bin/env python3
 """bench.py - one "step" = one full pass of the hot path over the 10k-gene all-vs-all workload:
 K1 translate/pack -> K2-K4 seeds/candidates -> K5 banded Smith-Waterman -> K6 traceback -> K8 filters/top-k ->
-hit table to the host -> (N>1: RCCL all-gather of the shard hit tables) -> K10 union-find.
+hit table to the host -> (N>1: RCCL all-gather of the shard hit tables + top-k merge) -> K10 union-find.
 Inputs (nucleotides) are resident in HBM before the timed region.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--genes G] [--no-cpu-baseline]
 
-N>1 is launched by torch.distributed.run, one rank per GPU; queries are sharded, the reference replicated
-(strong scaling: the total workload is the named 10k x 10k configuration whatever N is)."""
+N>1: one rank per GPU on an R x C grid of (query range, reference range) shards (peppan_amd/dist.py).  Either the launcher provides
+RANK / WORLD_SIZE (torch.distributed.run), or - when RANK is unset - this script starts the N ranks itself and relays rank 0's line.
+Strong scaling: the total workload is the named 10k x 10k configuration whatever N is."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
+
+PROFILE_COUNTERS = os.path.join(ROOT, 'profiles', 'r02_counters.json')     # rocprofv3 PMC passes of this workload (tools/profile_round.sh)
+PROFILE_VALU = os.path.join(ROOT, 'profiles', 'r02_valu_rate.txt')         # tools/micro/valu_rate on the same GPU
 
 
 def cpu_baseline(nts, n_sample, min_id, min_qcov):
@@ -39,9 +44,54 @@ def cpu_baseline(nts, n_sample, min_id, min_qcov):
     dt = time.perf_counter() - t0
     return dict(value=st['candidates'] / dt, unit='gene-pairs/s', cores=cores, kind='port',
                 sample='first %d of %d queries vs all %d genes x 6 frames; %.1f s on %d threads; %d candidates, %.3g SW cells (%.3g cells/s); '
-                       'reference binaries (diamond/blastn/mmseqs) are absent, so this is the oracle C port (scalar code, OpenMP)'
+                       'reference binaries (diamond/blastn/mmseqs) are absent, so this is the oracle C port (scalar code, OpenMP) - its ratio '
+                       'to the GPU figure says nothing about DIAMOND'
                        % (n_sample, len(nts), len(nts), dt, cores, st['candidates'], st['cells'], st['cells'] / dt),
                 seconds=dt, sw_cells_per_s=st['cells'] / dt, _hits=(hits, cig, n_sample))
+
+
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: this (GPU-free) parent starts one child per rank and relays rank 0's JSON line"""
+    import socket
+    import torch
+    n = args.gpus
+    share = os.environ.get('PEPPAN_BENCH_SHARE_GPU') == '1'
+    have = torch.cuda.device_count()                   # counting devices does not initialise the GPU
+    if have < n and not share:
+        sys.stderr.write('bench.py: --gpus %d but %d device(s) visible (PEPPAN_BENCH_SHARE_GPU=1 runs all ranks on device 0 over gloo)\n' % (n, have))
+        return 2
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
+    if bad:
+        sys.stderr.write('bench.py: ranks failed: %r\n' % bad)
+        return 1
+    return 0
+
+
+def _profile_tables():
+    """tracked evidence the line refers to: per-kernel PMC counters of this workload and the measured VALU issue rates"""
+    counters, cyc4 = {}, None
+    if os.path.exists(PROFILE_COUNTERS):
+        counters = json.load(open(PROFILE_COUNTERS)).get('kernels', {})
+    if os.path.exists(PROFILE_VALU):
+        for line in open(PROFILE_VALU):
+            f = line.split()
+            if len(f) >= 5 and f[0] == 'v_pk_max_i16' and f[1] == '8':
+                cyc4 = float(f[2])                     # cycles per wave64 instruction per SIMD at 8 waves/SIMD (packed-16 / DPP / add3 class)
+    return counters, cyc4
 
 
 def main():
@@ -52,20 +102,24 @@ def main():
     ap.add_argument('--genes', type=int, default=10000)
     ap.add_argument('--gene-len', type=int, default=1002)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-e2e', action='store_true', help='skip the untimed extras (H2D-inclusive step, the real uberBlast() call)')
     ap.add_argument('--cpu-sample', type=int, default=10000, help='leading queries of the workload the CPU baseline runs (all host cores)')
     args = ap.parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    # the workload, and (rank 0, N=1 only) the CPU baseline (run first: its OpenMP team is idle while the GPU steps are timed)
+    # the workload, and (rank 0) the CPU oracle run: the cpu_baseline figure at N = 1, the identity check of the gathered table at any N
+    # (run first: its OpenMP team is idle while the GPU steps are timed)
     from peppan_amd import synth
     names, seqs = synth.make_genes(args.genes, args.gene_len, seed=355)
     order = sorted(range(len(names)), key=lambda i: names[i])     # FASTA order of the reference: sorted(names) (uberBlast.py:527, 537)
     nts = [seqs[i] for i in order]
     min_id, min_qcov = 45.0, 25.0                                  # PEPPAN.py:229-230 with defaults (match_identity 0.5 - 0.05, match_frag_prop 0.25)
     cpu_line = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
         cpu_line = cpu_baseline(nts, min(args.cpu_sample, len(nts)), min_id, min_qcov)
 
     import torch
@@ -84,24 +138,14 @@ def main():
     dev = torch.device('cpu') if (share and world > 1) else torch.device('cuda', local_rank)
 
     from peppan_amd import _native as N, dist as pdist
-    bounds = pdist.shard_bounds([len(s) for s in nts], world)
-    q0, q1 = bounds[rank], bounds[rank + 1]
     params = N.default_params(min_id, min_qcov, 10, 5)
-
     ctx = N.Context(local_rank)
-    ctx.set_query_nt(nts[q0:q1], 11)
-    ctx.set_ref_nt(nts, 6, 11)
-    gene_of_target = None
+    shard = pdist.ShardedSearch(ctx, nts, nts, params, rank, world, device=dev if world > 1 else None)
 
     def step():
-        nonlocal gene_of_target
-        ctx.translate(force=True)
-        hits, cig, st = ctx.search(params, copy=False)          # views of the pinned staging area: consumed within the step
-        if gene_of_target is None:
-            gene_of_target = ctx.target_meta()['seq'].astype(np.uint32)
-        allh, allc = pdist.allgather_hits(hits, cig, q0, device=dev if world > 1 else None)
-        labels = ctx.components_of_hits(len(nts), allh, gene_of_target)          # edges (q, gene of t) straight from the table
-        return hits, st, allh, labels
+        allh, allc, st = shard.search(retranslate=True, copy=False)           # views of the pinned staging area at N = 1: consumed within the step
+        labels = ctx.components_of_hits(len(nts), allh, shard.gene_of_target)   # edges (q, gene of t) straight from the table
+        return st, allh, allc, labels
 
     def sync():
         if world > 1:
@@ -112,9 +156,11 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    acc = dict(candidates=0, cells=0, cells_swept=0, ms_sw_trace=0.0, ms_sw=0.0, ms_seed=0.0, ms_trace=0.0, ms_k1=0.0, ms_total=0.0, hits=0, dir_bytes=0, tracebacks=0)
+    keys = ('candidates', 'cells', 'cells_swept', 'cells_swept_trace', 'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total',
+            'hits', 'dir_bytes', 'tracebacks', 'seed_hits', 'target_residues', 'query_residues')
+    acc = dict.fromkeys(keys, 0.0)
     for _ in range(args.steps):
-        hits, st, allh, labels = step()
+        st, allh, allc, labels = step()
         for k in acc:
             acc[k] += st[k]
     sync()
@@ -129,58 +175,107 @@ def main():
     else:
         total_pairs, total_cells = float(acc['candidates']), float(acc['cells'])
 
+    parity = None
     if rank == 0 and cpu_line is not None:
-        # the oracle's hit table of the baseline run doubles as a check of the GPU's (same queries, same reference): every field, every CIGAR run
+        # the oracle's hit table doubles as a check of the GPU's (same queries, same reference): every field, every CIGAR run.  At N > 1 it
+        # is the all-gathered, merged table that is checked.
         o_hits, o_cig, n_sample = cpu_line.pop('_hits')
-        hits, cig, _ = ctx.search(params)           # (one more search, outside the timed region: a private copy of hits + CIGARs)
+        hits, cig = np.array(allh), np.array(allc)
         g = hits[hits['q'] < n_sample] if n_sample < len(nts) else hits
         same = len(g) == len(o_hits) and all(np.array_equal(g[f], o_hits[f]) for f in ('q', 't', 'q_start', 'q_end', 't_start', 't_end', 'score', 'nm', 'n_ident', 'aln_len', 'cigar_runs'))
         if same and n_sample >= len(nts):
             same = np.array_equal(np.asarray(cig), np.asarray(o_cig))
-        cpu_line['gpu_hits_identical'] = bool(same)
-        cpu_line['hits_compared'] = int(len(o_hits))
+        parity = dict(gpu_hits_identical=bool(same), hits_compared=int(len(o_hits)), against='oracle C port (align_oracle.c), same queries and reference')
+        cpu_line.update(gpu_hits_identical=bool(same), hits_compared=int(len(o_hits)))
+
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_e2e:
+        # (a) the step with the host buffers handed over inside it (H2D of the nucleotides): what the C boundary costs a caller
+        reps = max(3, min(args.steps, 10))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            ctx.set_query_nt(nts, 11)
+            ctx.set_ref_nt(nts, 6, 11)
+            step()
+        torch.cuda.synchronize()
+        extras['ms_per_step_incl_h2d'] = (time.perf_counter() - t1) / reps * 1e3
+        # (b) the reference's own hot call (PEPPAN.py:229-230) through the drop-in: FASTA in, 16-column object table out -
+        # blastn + diamond replacement, -s 1 rescoring (K7), fixEnd, string-keyed sort
+        import tempfile
+        from peppan_amd import uberBlast as UB
+        with tempfile.TemporaryDirectory() as tmp:
+            fa = os.path.join(tmp, 'exemplar.fa')
+            with open(fa, 'w') as f:
+                for i in order:
+                    f.write('>%s\n%s\n' % (names[i], seqs[i].decode()))
+            argv = ('-r %s -q %s --blastn --diamond -s 1 --min_id 0.45 --min_cov 50 -t 1 --min_ratio 0.25 -e 3,3 -p --gtable 11' % (fa, fa)).split()
+            import contextlib
+            import io
+            with contextlib.redirect_stderr(io.StringIO()):
+                UB.uberBlast(argv)                     # warm: FASTA cache, second context, workspaces
+                t2 = time.perf_counter()
+                tab = UB.uberBlast(argv)
+                extras['uberblast_e2e_ms'] = (time.perf_counter() - t2) * 1e3
+            extras['uberblast_e2e_rows'] = int(tab.shape[0])
+
     if rank == 0:
         K = args.steps
-        cand = acc['candidates'] / K
-        ms_sw = acc['ms_sw'] / K
-        # dominant kernel = K5 sw_kernel (one launch per step).  Algorithmic bytes per launch, SURVEY.md 8(d):
-        # sum over candidate pairs of (Lq + Lr) residue bytes + 64 B per reported hit.
-        Lq = args.gene_len // 3
-        alg_bytes = cand * (2 * Lq) + (acc['hits'] / K) * 64
-        achieved = alg_bytes / (ms_sw * 1e-3) / 1e9
-        traffic, traffic_note = None, ''
-        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if os.path.exists(tfile) and args.genes == 10000 and args.gene_len == 1002 and world == 1:
-            k = json.load(open(tfile))['kernels'].get('sw_score_kernel')
-            if k:
-                # rocprofv3 PMC passes of the same workload (profiles/r01_pmc_hbm_traffic.txt): FETCH_SIZE is doubled per the gfx950
-                # correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE matched the known output bytes exactly
-                traffic = (2 * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024.0
-                traffic_note = '; PMC traffic = 2 x FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_hbm_traffic.txt (below the algorithmic bytes: residues shared by candidates are served from L2)'
+        counters, cyc4 = _profile_tables()
+        headline = args.genes == 10000 and args.gene_len == 1002 and world == 1      # the workload the tracked counters were collected on
+        Lq = (args.gene_len // 3) if args.gene_len else int(acc['query_residues'] / K / max(1, shard.q1 - shard.q0))
+        hits_step = acc['hits'] / K
+        n_shapes = params.n_shapes
+
+        def entry(kernel, what, ms, alg_bytes, insts_key=None):
+            achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            prof = counters.get(kernel, {}) if headline else {}
+            traffic = (2 * prof['FETCH_SIZE'] + prof['WRITE_SIZE']) * 1024.0 if 'FETCH_SIZE' in prof and 'WRITE_SIZE' in prof else None
+            e = {'kernel': kernel, 'what': what, 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+                 'ms_per_launch': ms, 'algorithmic_bytes': alg_bytes, 'traffic': traffic,
+                 'traffic_source': 'profiles/r02_counters.json: 2 x FETCH_SIZE + WRITE_SIZE of the same kernel on this workload (separate rocprofv3 --pmc passes; '
+                                   'x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)' if traffic is not None else None}
+            if traffic:
+                e['traffic_over_algorithmic'] = traffic / alg_bytes if alg_bytes else None
+            if insts_key and cyc4 and 'SQ_INSTS_VALU' in prof and ms > 0:
+                # integer-VALU bound kernels: wave-instructions per launch (PMC) x measured cycles per instruction of the packed-16 / DPP / add3
+                # class (tools/micro/valu_rate.hip) against 1024 SIMDs at the 2.4 GHz peak clock for the launch's live duration
+                e['valu_issue_frac'] = prof['SQ_INSTS_VALU'] * cyc4 / (1024 * 2.4e9 * ms * 1e-3)
+                e['valu_issue_source'] = 'SQ_INSTS_VALU from profiles/r02_counters.json x %.3f cycles/instruction from profiles/r02_valu_rate.txt' % cyc4
+            return e
+
+        ms_sw, ms_tr, ms_match = acc['ms_sw'] / K, acc['ms_sw_trace'] / K, acc['ms_seed_match'] / K / max(1, n_shapes)
+        # algorithmic bytes per launch, SURVEY.md 8(d): SW = sum over pairs of (Lq + Lr) residue bytes + 64 B per reported hit;
+        # seed join = 1 B + 8 B index entry per target residue + 8 B per raw seed hit
+        rl = [entry('sw_kernel<true>', 'K5 traceback pass: banded SW + 4-bit codes over the selected pairs', ms_tr, (acc['tracebacks'] / K) * 2 * Lq + hits_step * 64, 'v'),
+              entry('sw_score_kernel', 'K5 score pass: banded SW over all candidate pairs', ms_sw, (acc['candidates'] / K) * 2 * Lq + hits_step * 64, 'v'),
+              entry('seed_match<10>', 'K4a: target seeds streamed through the query index (one launch per seed shape)', ms_match,
+                    9.0 * acc['target_residues'] / K + 8.0 * acc['seed_hits'] / K / max(1, n_shapes))]
+        rl.sort(key=lambda e: -e['ms_per_launch'])
+        top = dict(rl[0])
+        top['note'] = ('dominant kernel by live HIP-event time; the SW passes are integer-VALU bound by construction (SURVEY 8d): valu_issue_frac is '
+                       'the figure that bounds them, the HBM fraction is reported because the contract asks for it; roofline_kernels lists the top three')
         line = {
             'metric': 'gene_pairs_aligned_per_s', 'value': total_pairs / dt, 'unit': 'gene-pairs/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': dt / K * 1e3,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32', 'data': 'synthetic',
             'config': {'workload': 'synthgenes-v1 seed 355: %d genes x %d nt, all-vs-all (BASELINE configs[2] search stage), '
                                    'min_id 0.45 min_ratio 0.25 top-k 10 x 5 splits' % (args.genes, args.gene_len),
-                       'queries_per_rank': q1 - q0, 'parallelism': 'query-shard x%d, reference replicated' % world},
-            'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3),
+                       'queries_per_rank': shard.q1 - shard.q0, 'reference_genes_per_rank': shard.g1 - shard.g0,
+                       'parallelism': 'grid %d query shards x %d reference shards, all-gather + top-k merge of the hit tables' % (shard.R, shard.C)},
+            'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3) if acc['ms_sw'] else None,
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
             'hits_per_step': float(len(allh)), 'clusters': int(len(np.unique(labels))),
-            'phase_ms': {k: acc[k] / K for k in ('ms_seed', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
-            'roofline': {'bound': 'hbm', 'kernel': 'sw_score_kernel (K5 banded Smith-Waterman, score pass over all candidate pairs)', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s',
-                         'frac': achieved / 8000.0, 'traffic': traffic,
-                         # what actually bounds it: 120 VALU instructions per 16 candidate-steps of 64 cells (ISA of sw_score_kernel's
-                         # packed 16-bit loop body), each occupying a SIMD for 4 cycles (PMC: SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU
-                         # quad-cycles), 1024 SIMDs at 2.4 GHz
-                         'valu_issue_frac': (acc['cells_swept'] / K / 64) * (120. / 16.) * 4 / (1024 * 2.4e9 * ms_sw * 1e-3),
-                         'note': 'integer-VALU-bound by construction (SURVEY 8d): valu_issue_frac = share of the VALU issue ceiling; the traceback '
-                                 'pass sw_kernel<true> (selected pairs only) is a second launch that writes %.3g B of traceback codes in %.2f ms '
-                                 '= %.0f GB/s' % (acc['dir_bytes'] / K, acc['ms_sw_trace'] / K, acc['dir_bytes'] / K / (acc['ms_sw_trace'] / K * 1e-3) / 1e9) + traffic_note},
-            'cpu_baseline': cpu_line,
+            'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
+            'roofline': top, 'roofline_kernels': rl,
+            'cpu_baseline': cpu_line if world == 1 else None,
+            'parity_check': parity,
         }
+        line.update(extras)
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     ctx.close()
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 1
+#define PEP_ABI_VERSION 2
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -80,7 +80,9 @@ typedef struct {
     double ka_lambda, ka_k;       /* Karlin-Altschul parameters of the scoring system (protein default 0.267 / 0.041) */
     int32_t hsp_mode;             /* 0: one alignment per (q, t), its best band (diamond --max-hsps 1); 1: every band reaching the
                                      score threshold, duplicates (same end cell) removed - several copies on one subject */
-    int32_t pad0;
+    int32_t t_index_base;         /* index of this context's target 0 in the WHOLE reference set when the targets are one shard of it (multi-GPU
+                                     target sharding, peppan_amd/dist.py): split membership is (t + t_index_base) mod n_splits, so a shard ranks
+                                     its hits exactly as the unsharded search would; 0 otherwise.  Ignored with pep_set_target_groups. */
 } pep_search_params;
 
 /* one alignment; coordinates are 1-based, inclusive, in residues of the query / target protein */
@@ -123,6 +125,8 @@ typedef struct {
     uint64_t cells_swept_trace;   /* 64 lanes x steps executed by the traceback pass */
     double ms_seed, ms_sw, ms_trace, ms_total;   /* HIP-event times on the context's stream; ms_sw = score pass kernel */
     double ms_k1, ms_sw_trace;                   /* ms_sw_trace = traceback-pass kernel (selected pairs only) */
+    double ms_seed_match;                        /* seed_match kernel, summed over the seed shapes (one launch per shape) */
+    double ms_reserved[3];
 } pep_stats;
 
 int pep_version(void);
@@ -167,6 +171,14 @@ int pep_result_copy(const pep_result *r, pep_hit *hits, uint32_t *cigar);
 int pep_result_data(const pep_result *r, const pep_hit **hits, const uint32_t **cigar);
 int pep_result_stats(const pep_result *r, pep_stats *stats);
 void pep_result_free(pep_result *r);
+
+/* Host-side (no GPU work, no context): merge of the hit tables of several TARGET shards of one search (multi-GPU, after the
+ * all-gather).  hits carry global q and t indices; every (q, t) lives in exactly one shard, each shard already applied top-k per
+ * (q, split) locally, and the global top-k of a (q, split) is contained in the union of the local ones.  Ranks inside
+ * (q, t mod n_splits) by (score desc, t asc, bin asc) - the order of K8 - keeps rank < top_k and writes the survivors ordered by
+ * (q, t, bin) with a compacted CIGAR arena.  out_hits / out_cigar must hold n / n_cigar entries. */
+int pep_merge_hits(uint64_t n, const pep_hit *hits, const uint32_t *cigar, uint64_t n_cigar, int32_t top_k, int32_t n_splits,
+                   pep_hit *out_hits, uint32_t *out_cigar, uint64_t *n_out, uint64_t *n_cigar_out);
 
 /* K7: integer counts of mode-1 rescoring per hit, out[5*i..] = nMatch, nMismatch, nGap, bGap, mGap.
  * Uses the nucleotide sets given to pep_set_query_nt / pep_set_ref_nt. */

@@ -65,6 +65,7 @@ typedef struct {
     int32_t hsp_mode;      /* 0: one alignment per (q, t) = its best band (diamond --max-hsps 1);
                               1: every band of (q, t) that reaches min_score, minus duplicates (same end cell: keep the
                                  higher score, then the lower bin) - the nucleotide tool, where a subject can carry several copies */
+    int32_t t_base;        /* index of target 0 in the whole reference set when the targets are one shard of it: split = (t + t_base) mod n_splits */
 } oracle_params;
 
 typedef struct {
@@ -537,7 +538,7 @@ int oracle_search(const oracle_params *p,
         while (b < nh && hits[b].q == hits[a].q) ++b;
         for (int s = 0; s < p->n_splits; ++s) {
             uint64_t m = 0;
-            for (uint64_t k = a; k < b; ++k) if ((int)(hits[k].t % (uint32_t)p->n_splits) == s) tmp[m++] = &hits[k];
+            for (uint64_t k = a; k < b; ++k) if ((int)((hits[k].t + (uint32_t)(p->t_base % p->n_splits)) % (uint32_t)p->n_splits) == s) tmp[m++] = &hits[k];
             qsort(tmp, m, sizeof(*tmp), cmp_hit_rank);
             for (uint64_t k = 0; k < m && k < (uint64_t)p->top_k; ++k) keep[tmp[k] - hits] = 1;
         }

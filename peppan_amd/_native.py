@@ -7,12 +7,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_stats', 'pep_result_free',
-           'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup']
+           'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup']
 
 
 class PepError(RuntimeError):
@@ -25,14 +25,14 @@ class SearchParams(C.Structure):
                 ('sub', C.c_int8 * 1024), ('min_id_pct', C.c_double), ('min_qcov_pct', C.c_double),
                 ('top_k', C.c_int32), ('n_splits', C.c_int32), ('dbsize', C.c_double), ('max_evalue', C.c_double),
                 ('use_lds', C.c_int32), ('ungapped_min', C.c_int32), ('xdrop', C.c_int32), ('ext_right', C.c_int32),
-                ('ext_left', C.c_int32), ('reserved', C.c_int32 * 3), ('ka_lambda', C.c_double), ('ka_k', C.c_double), ('hsp_mode', C.c_int32), ('pad0', C.c_int32)]
+                ('ext_left', C.c_int32), ('reserved', C.c_int32 * 3), ('ka_lambda', C.c_double), ('ka_k', C.c_double), ('hsp_mode', C.c_int32), ('t_index_base', C.c_int32)]
 
 
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ('query_residues', 'target_residues', 'query_seeds', 'target_seeds', 'seed_hits',
                                            'seed_hits_passed', 'candidates', 'pairs', 'tracebacks', 'hits', 'cells', 'cells_swept', 'dir_bytes',
                                            'sw_launches', 'cells_trace', 'cells_swept_trace')] + \
-               [(n, C.c_double) for n in ('ms_seed', 'ms_sw', 'ms_trace', 'ms_total', 'ms_k1', 'ms_sw_trace')]
+               [(n, C.c_double) for n in ('ms_seed', 'ms_sw', 'ms_trace', 'ms_total', 'ms_k1', 'ms_sw_trace', 'ms_seed_match', 'ms_reserved0', 'ms_reserved1', 'ms_reserved2')]
 
 
 HIT_DTYPE = np.dtype([('q', '<u4'), ('t', '<u4'), ('q_start', '<u4'), ('q_end', '<u4'), ('t_start', '<u4'), ('t_end', '<u4'),
@@ -169,6 +169,22 @@ def linear_merge(q, r, iden, qs, qe, ss, se, score, ql, sl, rid, gap_dist, len_d
                     ids[:n_ids.value])
         keep_cap, ids_cap = n_keep.value + 16, n_ids.value + 16
     raise PepError('pep_linear_merge: inconsistent sizes')
+
+
+def merge_hits(hits, cigar, top_k, n_splits):
+    """pep_merge_hits: the union of the hit tables of several TARGET shards (global q / t indices) -> the table of the unsharded
+    search: top-k per (q, t mod n_splits) re-applied, rows ordered by (q, t, bin), CIGAR arena compacted"""
+    lib = load_library()
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+    out_h = np.empty(max(len(hits), 1), dtype=HIT_DTYPE)
+    out_c = np.empty(max(len(cigar), 1), dtype=np.uint32)
+    nh, nc = C.c_uint64(), C.c_uint64()
+    rc_ = lib.pep_merge_hits(C.c_uint64(len(hits)), _ptr(hits) if len(hits) else None, _ptr(cigar) if len(cigar) else None, C.c_uint64(len(cigar)),
+                             C.c_int32(int(top_k)), C.c_int32(int(n_splits)), _ptr(out_h), _ptr(out_c), C.byref(nh), C.byref(nc))
+    if rc_ != 0:
+        raise PepError('pep_merge_hits failed (%d)' % rc_)
+    return out_h[:nh.value], out_c[:nc.value]
 
 
 class Context(object):

@@ -62,12 +62,15 @@ void pep_timer_end(pep_ctx *ctx, int id)
 
 void pep_timers_resolve(pep_ctx *ctx)
 {
-    double *dst[TM_COUNT] = {&ctx->stats.ms_seed, &ctx->stats.ms_total, &ctx->stats.ms_sw, &ctx->stats.ms_sw_trace, &ctx->stats.ms_trace};
+    double match[4] = {0., 0., 0., 0.};
+    double *dst[TM_COUNT] = {&ctx->stats.ms_seed, &ctx->stats.ms_total, &ctx->stats.ms_sw, &ctx->stats.ms_sw_trace, &ctx->stats.ms_trace,
+                             &match[0], &match[1], &match[2], &match[3]};
     for (int id = 0; id < TM_COUNT; ++id) {
         float ms = 0.f;
         if (ctx->tm_state[id] == 2 && hipEventSynchronize(ctx->tm_b[id]) == hipSuccess && hipEventElapsedTime(&ms, ctx->tm_a[id], ctx->tm_b[id]) == hipSuccess) *dst[id] = ms;
         ctx->tm_state[id] = 0;
     }
+    ctx->stats.ms_seed_match = match[0] + match[1] + match[2] + match[3];
 }
 
 int pep_read_back(pep_ctx *ctx, void *dst, const void *d_src, size_t n)
@@ -521,6 +524,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
             for (int c = 0; c < 32; ++c)
                 if (params->reduce[c] != 0xFF && params->reduce[c] >= params->base) return pep_fail(ctx, PEP_ERR_ARG, "reduced letter outside the alphabet");
         }
+        if (params->t_index_base < 0) return pep_fail(ctx, PEP_ERR_ARG, "t_index_base must not be negative");
         if (params->hsp_mode != 0 && params->hsp_mode != 1) return pep_fail(ctx, PEP_ERR_ARG, "hsp_mode must be 0 or 1");
         if (!(params->ka_lambda > 0.) || !(params->ka_k > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "invalid Karlin-Altschul parameters");
         if (!(params->dbsize > 0.) || !(params->max_evalue > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "dbsize and max_evalue must be positive");
@@ -616,6 +620,57 @@ void pep_result_free(pep_result *r)
 {
     if (r && r->ctx && r->ctx->staged_result == r) r->ctx->staged_result = nullptr;
     delete r;
+}
+
+int pep_merge_hits(uint64_t n, const pep_hit *hits, const uint32_t *cigar, uint64_t n_cigar, int32_t top_k, int32_t n_splits,
+                   pep_hit *out_hits, uint32_t *out_cigar, uint64_t *n_out, uint64_t *n_cigar_out)
+{
+    if (!n_out || !n_cigar_out || top_k < 1 || n_splits < 1 || (n && (!hits || !out_hits)) || (n_cigar && (!cigar || !out_cigar))) return PEP_ERR_ARG;
+    *n_out = 0; *n_cigar_out = 0;
+    std::vector<uint64_t> order(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        order[i] = i;
+        if (hits[i].cigar_off + hits[i].cigar_runs > n_cigar) return PEP_ERR_ARG;
+    }
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+        const pep_hit &x = hits[a], &y = hits[b];
+        if (x.q != y.q) return x.q < y.q;
+        if (x.t != y.t) return x.t < y.t;
+        return x.bin < y.bin;
+    });
+    std::vector<uint64_t> grp;
+    std::vector<uint8_t> keep(n, 0);
+    for (uint64_t a = 0; a < n;) {
+        uint64_t b = a;
+        while (b < n && hits[order[b]].q == hits[order[a]].q) ++b;
+        for (int32_t sp = 0; sp < n_splits; ++sp) {
+            grp.clear();
+            for (uint64_t k = a; k < b; ++k)
+                if ((int32_t)(hits[order[k]].t % (uint32_t)n_splits) == sp) grp.push_back(k);
+            if (grp.size() > (size_t)top_k) {
+                std::sort(grp.begin(), grp.end(), [&](uint64_t u, uint64_t v) {
+                    const pep_hit &x = hits[order[u]], &y = hits[order[v]];
+                    if (x.score != y.score) return x.score > y.score;
+                    if (x.t != y.t) return x.t < y.t;
+                    return x.bin < y.bin;
+                });
+                grp.resize((size_t)top_k);
+            }
+            for (uint64_t k : grp) keep[k] = 1;
+        }
+        a = b;
+    }
+    uint64_t no = 0, nc = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        if (!keep[k]) continue;
+        pep_hit h = hits[order[k]];
+        if (h.cigar_runs) memcpy(out_cigar + nc, cigar + h.cigar_off, (size_t)h.cigar_runs * sizeof(uint32_t));
+        h.cigar_off = nc;
+        nc += h.cigar_runs;
+        out_hits[no++] = h;
+    }
+    *n_out = no; *n_cigar_out = nc;
+    return PEP_OK;
 }
 
 int pep_rescore_nt(pep_ctx *ctx, uint64_t n, const pep_nt_hit *hits, const uint32_t *cigar, uint64_t n_cigar, int64_t *out)

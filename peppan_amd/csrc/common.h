@@ -109,8 +109,8 @@ struct pep_ctx {
     DevBuf d_params;                        // device copy of seed params
     // phase timers: events recorded on the stream, read once after the search's final synchronisation (waiting for an end event in
     // the middle of a search costs a host round trip with the GPU idle, and lets nothing be queued behind a running SW pass)
-    hipEvent_t tm_a[6] = {}, tm_b[6] = {};
-    int tm_state[6] = {};                   // 0 idle, 1 begun, 2 ended (waiting to be read)
+    hipEvent_t tm_a[12] = {}, tm_b[12] = {};
+    int tm_state[12] = {};                   // 0 idle, 1 begun, 2 ended (waiting to be read)
     unsigned long long sw_totals[2] = {};   // score pass: cells / 16-step blocks, read back with the next synchronisation
     bool sw_totals_pending = false;
     struct ScanState { DevBuf buf; uint32_t epoch = 0, ticket_base = 0; };
@@ -155,7 +155,7 @@ struct EventTimer {
     EventTimer &operator=(const EventTimer &) = delete;
 };
 
-enum PepTimer { TM_SEED = 0, TM_TOTAL, TM_SW, TM_SW_TRACE, TM_TRACE, TM_COUNT };
+enum PepTimer { TM_SEED = 0, TM_TOTAL, TM_SW, TM_SW_TRACE, TM_TRACE, TM_MATCH0, TM_MATCH1, TM_MATCH2, TM_MATCH3, TM_COUNT };
 void pep_timer_begin(pep_ctx *ctx, int id);
 void pep_timer_end(pep_ctx *ctx, int id);
 void pep_timers_resolve(pep_ctx *ctx);     // after a stream synchronisation: elapsed times -> ctx->stats.ms_*

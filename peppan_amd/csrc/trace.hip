@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void apply_dedupe(uint64_t n_sel, SelInfo *__r
 // rank inside (query, target mod n_splits): score desc, target asc, band asc.  sel is ordered by (q, t, bin).
 // t_class (optional): competition class of every target = group * n_splits + (index inside the group) % n_splits, so that a
 // batch of reference sets (genomes) searched at once ranks exactly as if each had been searched alone
-__global__ __launch_bounds__(256) void topk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int top_k, int n_splits,
+__global__ __launch_bounds__(256) void topk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int top_k, int n_splits, uint32_t t_base,
                                             const uint32_t *__restrict__ t_class, uint32_t *__restrict__ keep_flag, uint64_t *__restrict__ keep_runs)
 {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void topk(uint64_t n_sel, SelInfo *__restrict_
     uint32_t keep = 0;
     if (me.pass) {
         const uint64_t key = cands[me.cand];
-        const uint32_t q = key_q(key), t = key_t(key), split = t_class ? t_class[t] : t % (uint32_t)n_splits;
+        const uint32_t q = key_q(key), t = key_t(key), split = t_class ? t_class[t] : (t + t_base) % (uint32_t)n_splits;
         uint32_t rank = 0;
         for (int dir = -1; dir <= 1; dir += 2) {
             for (int64_t x = (int64_t)s + dir; x >= 0 && x < (int64_t)n_sel; x += dir) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void topk(uint64_t n_sel, SelInfo *__restrict_
                 const uint64_t ko = cands[o.cand];
                 if (key_q(ko) != q) break;
                 const uint32_t to = key_t(ko);
-                if (!o.pass || (t_class ? t_class[to] : to % (uint32_t)n_splits) != split) continue;
+                if (!o.pass || (t_class ? t_class[to] : (to + t_base) % (uint32_t)n_splits) != split) continue;
                 if (o.score > me.score || (o.score == me.score && (to < t || (to == t && x < (int64_t)s)))) ++rank;
             }
         }
@@ -372,7 +372,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         uint32_t *keep_flag = ctx->ws[22].as<uint32_t>(), *hit_pos = keep_flag + n_sel + 2;
         uint64_t *keep_runs = reinterpret_cast<uint64_t *>(hit_pos + n_sel + 2), *cig_pos = keep_runs + n_sel + 2;
         hipLaunchKernelGGL(topk, dim3((unsigned)ceil_div(n_sel, 256)), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, P.top_k, P.n_splits,
-                           ctx->t_class_ready ? ctx->d_t_class.as<const uint32_t>() : (const uint32_t *)nullptr, keep_flag, keep_runs);
+                           (uint32_t)(P.t_index_base % P.n_splits), ctx->t_class_ready ? ctx->d_t_class.as<const uint32_t>() : (const uint32_t *)nullptr, keep_flag, keep_runs);
         PEP_TRY(pep_scan_u32(ctx, keep_flag, hit_pos, n_sel, ctx->ws[7]));
         PEP_TRY(pep_scan_u64(ctx, keep_runs, cig_pos, n_sel, ctx->ws[7]));
         uint32_t n_hits = 0;

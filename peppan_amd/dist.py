@@ -1,15 +1,26 @@
-"""Multi-GPU layer: one process per GPU, queries sharded contiguously by residue count, the packed reference
-replicated, and ONE exchange step - an all-gather of the per-shard hit tables (fixed-size records + CIGAR arena)
-before the order-dependent host pass / union-find.  torch.distributed is plumbing only: backend "nccl" is RCCL
-over xGMI on the GPU box, "gloo" runs the same code on CPU tensors in the tests.
+"""Multi-GPU layer of the all-vs-all search: one process per GPU, a 2-D grid of shards, ONE exchange step.
 
-The reference has no counterpart (it is single-host multiprocessing with files as transport, uberBlast.py:333-338,
-500-503); shards are independent because top-k is per query."""
+The ranks form an R x C grid (rank = r * C + c).  Row r owns a contiguous range of the QUERIES (balanced by residue count),
+column c owns a contiguous range of the REFERENCE sequences - all frames and chunks of its genes, so K1, the streaming of the
+targets through the seed index, the ungapped extensions and both Smith-Waterman passes all shrink with the number of ranks,
+not just the query-side work.  Every rank searches its (query range, reference range) cell; the per-cell hit tables
+(fixed-size records + CIGAR arena) are exchanged with ONE all-gather (RCCL over xGMI on the GPU box, gloo in the CPU tests),
+after which every rank holds the whole table for the order-dependent host pass / the union-find.
+
+Exactness.  The reference's ranking is per query and per database split (`-k 10` on each of 5 round-robin splits,
+uberBlast.py:546-552): split = target index mod 5 over the WHOLE reference set.  A column therefore ranks with
+split = (local target index + number of targets in the columns before it) mod 5 (`pep_search_params.t_index_base`), which
+makes its local top-k a superset of its share of the global top-k; `pep_merge_hits` re-applies the top-k to the union and
+orders the rows by (q, t) - the table is bit-identical to the single-GPU one (gloo tests with 2 and 4 ranks).
+Pure query sharding (C = 1) needs no merge at all.
+
+torch.distributed is plumbing only.  The reference has no counterpart (single-host multiprocessing with files as transport,
+uberBlast.py:333-338, 500-503)."""
 import numpy as np
 
 
 def shard_bounds(lengths, world):
-    """contiguous query shards balanced by cumulative residue count; returns world+1 boundaries"""
+    """contiguous shards balanced by cumulative residue count; returns world+1 boundaries"""
     lengths = np.asarray(lengths, dtype=np.int64)
     n = len(lengths)
     if n == 0:
@@ -25,45 +36,109 @@ def shard_bounds(lengths, world):
     return b
 
 
-def allgather_hits(hits, cigar, q_base, group=None, device=None):
-    """hits: structured array (peppan_amd._native.HIT_DTYPE) with shard-local q indices; cigar: uint32 arena.
-    Returns the concatenated (hits, cigar) of all ranks in rank order with global q indices and re-based
-    cigar offsets.  Collectives: one all-gather of the two counts, one of a padded payload (hit records + arena)."""
+def grid_shape(world):
+    """(R query shards, C reference shards) with R * C == world.  The reference side carries most of the per-rank work that does not
+    depend on the queries (6 frames per gene: K1 and the streaming of 6x more residues than the query side), so C >= R:
+    1 -> 1x1, 2 -> 1x2, 4 -> 2x2, 8 -> 2x4, 16 -> 4x4; a world size without such a factorisation shards the reference only."""
+    r = 1
+    while (r * 2) * (r * 2) <= world and world % (r * 2) == 0:
+        r *= 2
+    return r, world // r
+
+
+def _all_gather_bytes(payload, group, device):
+    """all-gather of one variable-length uint8 array per rank -> list of arrays in rank order (counts first, then padded payloads)"""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    n = torch.tensor([payload.size], dtype=torch.int64, device=device)
+    counts = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts = counts.cpu().numpy()
+    slot = int(counts.max())
+    if slot == 0:
+        return [np.zeros(0, dtype=np.uint8) for _ in range(world)]
+    buf = np.zeros(slot, dtype=np.uint8)
+    buf[:payload.size] = payload
+    out = torch.empty(slot * world, dtype=torch.uint8, device=device)
+    dist.all_gather_into_tensor(out, torch.from_numpy(buf).to(device), group=group)
+    flat = out.cpu().numpy()
+    return [flat[r * slot:r * slot + int(counts[r])] for r in range(world)]
+
+
+def allgather_hits(hits, cigar, q_base, t_base=0, group=None, device=None):
+    """hits: structured array (peppan_amd._native.HIT_DTYPE) with shard-local q / t indices; cigar: uint32 arena.
+    Returns the concatenated (hits, cigar) of all ranks in rank order with global indices and re-based cigar offsets.
+    Collectives: one all-gather of the payload sizes, one of a padded payload (hit records + arena)."""
     import torch
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        if q_base:
+        if q_base or t_base:
             hits = hits.copy()
             hits['q'] += q_base
+            hits['t'] += t_base
         return hits, cigar
-    world = dist.get_world_size(group)
     dev = device if device is not None else torch.device('cpu')
     mine = hits.copy()
     mine['q'] += q_base
-    counts = torch.tensor([len(mine), len(cigar)], dtype=torch.int64, device=dev)
-    all_counts = torch.empty(2 * world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_counts, counts, group=group)
-    all_counts = all_counts.cpu().numpy().reshape(world, 2)
-    max_h, max_c = int(all_counts[:, 0].max()), int(all_counts[:, 1].max())
+    mine['t'] += t_base
     rec = mine.dtype.itemsize
-    # one payload per rank: [hit records, padded to max_h][CIGAR arena, padded to max_c] -> one collective, one copy back
-    slot = max_h * rec + max_c * 4
-    if slot == 0:
-        return mine, np.zeros(0, dtype=np.uint32)
-    buf = np.zeros(slot, dtype=np.uint8)
-    buf[:len(mine) * rec] = mine.view(np.uint8).reshape(-1)
-    buf[max_h * rec:max_h * rec + len(cigar) * 4] = np.ascontiguousarray(cigar, dtype=np.uint32).view(np.uint8)
-    mine_t = torch.from_numpy(buf).to(dev)
-    all_t = torch.empty(slot * world, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(all_t, mine_t, group=group)
-    flat = all_t.cpu().numpy()
+    head = np.array([len(mine)], dtype=np.uint64).view(np.uint8)
+    payload = np.concatenate([head, mine.view(np.uint8).reshape(-1), np.ascontiguousarray(cigar, dtype=np.uint32).view(np.uint8)])
     out_h, out_c, coff = [], [], 0
-    for r in range(world):
-        nh, nc = int(all_counts[r, 0]), int(all_counts[r, 1])
-        base = r * slot
-        h = flat[base:base + nh * rec].view(mine.dtype).copy()
+    for part in _all_gather_bytes(payload, group, dev):
+        nh = int(part[:8].view(np.uint64)[0])
+        h = part[8:8 + nh * rec].view(mine.dtype).copy()
+        c = part[8 + nh * rec:].view(np.uint32)
         h['cigar_off'] += coff
+        coff += len(c)
         out_h.append(h)
-        out_c.append(flat[base + max_h * rec:base + max_h * rec + nc * 4].view(np.uint32))
-        coff += nc
+        out_c.append(c)
     return np.concatenate(out_h), np.concatenate(out_c)
+
+
+class ShardedSearch(object):
+    """The all-vs-all translated search of `query_nt` against `ref_nt` (lists of nucleotide byte strings in the reference's FASTA
+    order) over the ranks of `group` (None + world 1 = single process).  `ctx` is anything with the interface of
+    peppan_amd._native.Context (the tests pass the oracle-backed context).
+
+        s = ShardedSearch(ctx, query_nt, ref_nt, params, rank, world)
+        hits, cigar, stats = s.search()        # the WHOLE table on every rank: global q / t indices, rows by (q, t)
+        s.gene_of_target                       # reference sequence index of every global target (for the single-linkage step)
+    """
+
+    def __init__(self, ctx, query_nt, ref_nt, params, rank=0, world=1, frames=6, gtable=11, grid=None, group=None, device=None):
+        self.ctx, self.params, self.rank, self.world, self.group, self.device = ctx, params, rank, world, group, device
+        self.R, self.C = grid if grid is not None else grid_shape(world)
+        if self.R * self.C != world:
+            raise ValueError('grid %dx%d does not match world size %d' % (self.R, self.C, world))
+        self.r, self.c = divmod(rank, self.C)
+        qb = shard_bounds([len(s) for s in query_nt], self.R)
+        gb = shard_bounds([len(s) for s in ref_nt], self.C)
+        self.q0, self.q1, self.g0, self.g1 = qb[self.r], qb[self.r + 1], gb[self.c], gb[self.c + 1]
+        self.n_queries, self.n_refs = len(query_nt), len(ref_nt)
+        ctx.set_query_nt(query_nt[self.q0:self.q1], gtable)
+        ctx.set_ref_nt(ref_nt[self.g0:self.g1], frames, gtable)
+        ctx.translate()
+        local_gene = ctx.target_meta()['seq'].astype(np.uint32) + np.uint32(self.g0)
+        if world == 1:
+            self.t_base, self.gene_of_target = 0, local_gene
+        else:
+            # what K1 made of every column's genes: the number of targets in front of this column and the global target -> gene map
+            import torch
+            dev = device if device is not None else torch.device('cpu')
+            parts = _all_gather_bytes(local_gene.view(np.uint8), group, dev)
+            cols = [parts[c].view(np.uint32) for c in range(self.C)]          # row 0 holds one rank per column, in column order
+            self.t_base = int(sum(len(x) for x in cols[:self.c]))
+            self.gene_of_target = np.concatenate(cols)
+        self.params.t_index_base = self.t_base
+
+    def search(self, retranslate=False, copy=True):
+        if retranslate:
+            self.ctx.translate(force=True)
+        hits, cigar, stats = self.ctx.search(self.params, copy=(copy and self.world == 1))
+        allh, allc = allgather_hits(hits, cigar, self.q0, self.t_base, group=self.group, device=self.device)
+        if self.C > 1:
+            from . import _native as N
+            allh, allc = N.merge_hits(allh, allc, self.params.top_k, self.params.n_splits)
+        return allh, allc, stats

@@ -155,3 +155,55 @@ def test_get_map_bsn_sharded_over_two_ranks(tmp_path):
     for x in ('tab', 'seq', 'mat', 'conflicts'):
         with mapbsn.MapBsn(str(tmp_path / ('mm.%s.npz' % x))) as c:
             assert {k: plain(c.get(k)) for k in sorted(c.keys())} == want[x], x
+
+
+def _grid_worker(rank, world, port, grid, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch.distributed as dist
+    from oracle_context import OracleContext
+    from peppan_amd import _native as N, dist as pdist, synth
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    names, seqs = synth.make_genes(120, 0, seed=77)              # log-normal lengths: ragged shards
+    params = N.default_params(45., 25., 2, 5)                    # k = 2 per split: the global top-k really cuts across the shards
+    s = pdist.ShardedSearch(OracleContext(), seqs, seqs, params, rank, world, grid=grid)
+    h, c, st = s.search()
+    out_q.put((rank, (s.q0, s.q1, s.g0, s.g1, s.t_base), h.tobytes(), c.tobytes(), s.gene_of_target.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,grid', [(2, (1, 2)), (2, (2, 1)), (4, (2, 2)), (4, None)])
+def test_sharded_all_vs_all_equals_single_process(world, grid):
+    """queries x reference shards on a 2-D grid of gloo ranks (oracle-backed contexts): after the all-gather and pep_merge_hits every
+    rank holds exactly the table of the unsharded search - every field, every CIGAR run - and the same target -> gene map"""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle_context import OracleContext
+    from peppan_amd import _native as N, dist as pdist, synth
+    names, seqs = synth.make_genes(120, 0, seed=77)
+    one = pdist.ShardedSearch(OracleContext(), seqs, seqs, N.default_params(45., 25., 2, 5))
+    want_h, want_c, _ = one.search()
+    assert len(want_h) > 150
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grid_worker, args=(r, world, port, grid, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cells = [r[1] for r in res]
+    assert len(set(cells)) == world                                   # every rank owns a different (query range, reference range) cell
+    if (grid or pdist.grid_shape(world))[1] > 1:
+        assert any(c[4] > 0 for c in cells)                           # some column really starts at a non-zero target index
+    for rank, cell, hb, cb, gb in res:
+        assert np.array_equal(np.frombuffer(hb, dtype=N.HIT_DTYPE), want_h), rank
+        assert np.array_equal(np.frombuffer(cb, dtype=np.uint32), want_c), rank
+        assert np.array_equal(np.frombuffer(gb, dtype=np.uint32), one.gene_of_target), rank
+
+
+def test_grid_shape():
+    from peppan_amd import dist as pdist
+    assert [pdist.grid_shape(w) for w in (1, 2, 3, 4, 6, 8, 16)] == [(1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (2, 4), (4, 4)]

@@ -447,7 +447,7 @@ def test_full_size_10k_bit_exact_vs_oracle(ctx, gene_len):
         assert st[k] == ost[k], k
 
 
-def _shard_worker(rank, world, port, out_q):
+def _shard_worker(rank, world, port, grid, out_q):
     import os, sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import numpy as np
@@ -455,44 +455,66 @@ def _shard_worker(rank, world, port, out_q):
     from peppan_amd import _native as N, synth, dist as pdist
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
     names, seqs = synth.make_genes(600, 0, seed=91)
-    b = pdist.shard_bounds([len(s) for s in seqs], world)
-    with N.Context(0) as ctx:                     # both ranks share the one GPU of the test box; on a node each has its own
-        ctx.set_query_nt(seqs[b[rank]:b[rank + 1]], 11)
-        ctx.set_ref_nt(seqs, 6, 11)
-        hits, cig, st = ctx.search(N.default_params(45., 25., 10, 5))
-        allh, allc = pdist.allgather_hits(hits, cig, b[rank])
-        lab = ctx.components(len(seqs), allh['q'], ctx.target_meta()['seq'][allh['t']])
+    with N.Context(0) as ctx:                     # the ranks share the one GPU of the test box; on a node each has its own
+        shard = pdist.ShardedSearch(ctx, seqs, seqs, N.default_params(45., 25., 3, 5), rank, world, grid=grid)
+        allh, allc, st = shard.search()
+        lab = ctx.components_of_hits(len(seqs), allh, shard.gene_of_target)
     out_q.put((rank, allh.tobytes(), allc.tobytes(), lab.tobytes()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_query_sharded_search_equals_single_gpu(ctx):
-    """N>1 path end to end: two ranks (gloo transport, one shared GPU here) shard the queries, all-gather their hit
-    tables, and every rank ends with exactly the single-process table and the same clusters"""
+@pytest.mark.parametrize('world,grid', [(2, (2, 1)), (2, (1, 2)), (4, (2, 2))])
+def test_sharded_search_equals_single_gpu(ctx, world, grid):
+    """N>1 path end to end on the GPU: the ranks (gloo transport, one shared GPU here) search the cells of a query x reference grid,
+    all-gather their hit tables, merge the top-k, and every rank ends with exactly the single-process table and the same clusters"""
     import socket
     import torch.multiprocessing as mp
-    from peppan_amd import _native as N, synth
+    from peppan_amd import _native as N, synth, dist as pdist
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     mpc = mp.get_context('spawn')
     q = mpc.Queue()
-    procs = [mpc.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [mpc.Process(target=_shard_worker, args=(r, world, port, grid, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(2))
+    res = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     names, seqs = synth.make_genes(600, 0, seed=91)
-    ctx.set_query_nt(seqs, 11)
-    ctx.set_ref_nt(seqs, 6, 11)
-    h, c, st = ctx.search(N.default_params(45., 25., 10, 5))
-    lab = ctx.components(len(seqs), h['q'], ctx.target_meta()['seq'][h['t']])
+    one = pdist.ShardedSearch(ctx, seqs, seqs, N.default_params(45., 25., 3, 5))
+    h, c, st = one.search()
+    lab = ctx.components_of_hits(len(seqs), h, one.gene_of_target)
     for rank, hb, cb, lb in res:
         gh = np.frombuffer(hb, dtype=N.HIT_DTYPE)
         assert np.array_equal(gh, h) and np.array_equal(np.frombuffer(cb, dtype=np.uint32), c)
         assert np.array_equal(np.frombuffer(lb, dtype=np.uint32), lab)
     assert len(h) > 1000
+
+
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher: the parent spawns the ranks (both on device 0 here, gloo exchange), relays ONE JSON line
+    with n_gpus 2, and the gathered + merged table equals the CPU oracle's"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PEPPAN_BENCH_SHARE_GPU='1')
+    env.pop('RANK', None); env.pop('WORLD_SIZE', None)
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--genes', '400', '--steps', '2', '--warmup', '1', '--no-e2e'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['steps'] == 2
+    assert line['parity_check']['gpu_hits_identical'] is True and line['parity_check']['hits_compared'] > 400
+    assert line['cpu_baseline'] is None                         # the CPU baseline figure belongs to the N = 1 line
+    one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--genes', '400', '--steps', '2', '--warmup', '1'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert one.returncode == 0, one.stderr.decode()[-2000:]
+    l1 = json.loads([l for l in one.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert l1['n_gpus'] == 1 and l1['cpu_baseline']['gpu_hits_identical'] is True and l1['hits_per_step'] == line['hits_per_step']
+    assert l1['clusters'] == line['clusters'] and l1['uberblast_e2e_ms'] > 0 and l1['ms_per_step_incl_h2d'] > 0
+    assert len(l1['roofline_kernels']) == 3 and l1['roofline']['kernel'] == l1['roofline_kernels'][0]['kernel']
 
 
 def test_multiple_hsps_per_subject(ctx):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""rocprofv3 PMC databases (one per counter pass) -> profiles/rNN_traffic.json (per-kernel per-dispatch averages, raw counter unit KiB)
-    python tools/pmc_to_json.py out.json fetch_results.db write_results.db"""
+"""rocprofv3 PMC databases (one per counter pass) -> profiles/rNN_counters.json: per kernel the per-dispatch average of every counter
+(raw counter unit: FETCH_SIZE / WRITE_SIZE in KiB) and the average duration of the kernel in that pass.
+    python tools/pmc_to_json.py out.json pass1_results.db pass2_results.db ..."""
 import json
 import sqlite3
 import sys
@@ -16,7 +17,14 @@ def main(out, *dbs):
         c = sqlite3.connect(path)
         for name, ctr, total, n in c.execute("select name, counter_name, sum(counter_value), count(distinct dispatch_id) from pmc_events group by name, counter_name"):
             kernels.setdefault(short(name), {})[ctr] = int(round(total / max(1, n)))
-    json.dump({'workload': '10000 genes x 1002 nt all-vs-all', 'unit': 'KiB per dispatch (raw counter)', 'kernels': kernels}, open(out, 'w'), indent=1)
+        for name, avg, n in c.execute("select name, avg(duration), count(*) from kernels group by name"):
+            k = kernels.setdefault(short(name), {})
+            k.setdefault('avg_us_in_pmc_passes', []).append(round(avg / 1e3, 2))
+            k['dispatches_per_pass'] = n
+    json.dump({'workload': '10000 genes x 1002 nt all-vs-all (tools/one_search.py: 2 searches per pass)',
+               'unit': 'per-dispatch average of the raw counter (FETCH_SIZE / WRITE_SIZE: KiB; SQ_* cycle counters: quad-cycles summed over all SIMDs; '
+                       'GRBM_GUI_ACTIVE: summed over the 8 XCDs)',
+               'kernels': kernels}, open(out, 'w'), indent=1, sort_keys=True)
     print('wrote', out, len(kernels), 'kernels')
 
 
