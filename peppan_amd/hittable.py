@@ -1,0 +1,223 @@
+"""Numeric form of the reference's "blastab" hit table (column layout: SURVEY.md section 8, uberBlast.py:57-58, 280-288, 354).
+
+The reference keeps one Python object per cell from the moment a tool's output is parsed (uberBlast.py:67, 306) and every
+post-processing step (reScore, -f, -m, fixEnd, -O, the final sort; uberBlast.py:352-376) walks rows of Python objects.  Here the
+whole chain runs on flat numpy columns + one CIGAR arena (uint32 runs len << 2 | op, op 0 = M, 1 = I, 2 = D, nucleotide units) -
+the layout the GPU hands over - and the 16/17-column object rows the callers expect are created ONCE, at the end of
+RunBlast.run (`to_rows`).  `from_rows` is the way back in: tables that arrive as object rows (the reference's tool plug-in
+contract, canned tables in the tests) take the same numeric chain.
+"""
+import numpy as np
+
+_OPS = np.array(['M', 'I', 'D'])
+_OP_BYTES = np.frombuffer(b'MID', dtype=np.uint8)
+_OP_CODE = {'M': 0, 'I': 1, 'D': 2}
+_INT_TYPES = (int, np.integer)
+
+
+def _name_codes(names, idx):
+    """integer code of every row's name in the order a sort of the column orders the names: numeric when every name is an integer,
+    code-point order of the strings otherwise (what pandas / numpy do with an object column of that content)"""
+    if len(names) and all(isinstance(v, _INT_TYPES) for v in names):
+        return np.asarray(names, dtype=np.int64)[idx]
+    rank = np.unique(np.array([str(v) for v in names], dtype=str), return_inverse=True)[1].astype(np.int64) if len(names) else np.zeros(0, np.int64)
+    return rank[idx]
+
+
+class HitTable(object):
+    __slots__ = ('q_tab', 'r_tab', 'qi', 'ri', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'score_is_int',
+                 'ql', 'sl', 'arena', 'c_off', 'c_runs', 'rid', 'merge')
+    _ROW_COLS = ('qi', 'ri', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'ql', 'sl', 'c_off', 'c_runs', 'rid')
+
+    def __init__(self, q_tab, r_tab, qi, ri, iden, aln, mis, gap, qs, qe, ss, se, evalue, score, ql, sl, arena, c_off, c_runs,
+                 rid=None, merge=None, score_is_int=True):
+        i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        f64 = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.q_tab, self.r_tab = q_tab, r_tab
+        self.qi, self.ri = i64(qi), i64(ri)
+        self.iden, self.evalue, self.score = f64(iden), f64(evalue), f64(score)
+        self.aln, self.mis, self.gap, self.qs, self.qe, self.ss, self.se, self.ql, self.sl = (i64(a) for a in (aln, mis, gap, qs, qe, ss, se, ql, sl))
+        self.arena = np.ascontiguousarray(arena, dtype=np.uint32)
+        self.c_off, self.c_runs = i64(c_off), i64(c_runs)
+        self.rid = i64(rid) if rid is not None else np.full(len(self.qi), -1, dtype=np.int64)
+        self.merge = merge                      # column 16 after -m: one list per row (or None)
+        self.score_is_int = score_is_int
+
+    def __len__(self):
+        return len(self.qi)
+
+    # ------------------------------------------------------------------------------------------------ construction
+    @classmethod
+    def empty(cls):
+        z = np.zeros(0, dtype=np.int64)
+        return cls([], [], z, z, z, z, z, z, z, z, z, z, z, z, z, z, np.zeros(0, np.uint32), z, z)
+
+    @classmethod
+    def from_rows(cls, rows):
+        """object table [n, 15 | 16 | 17] (CIGAR as [[n, op], ...] lists or as a string) -> HitTable"""
+        import re
+        n = rows.shape[0]
+        if n == 0:
+            return cls.empty()
+        q_tab, r_tab, q_of, r_of = [], [], {}, {}
+        qi = np.fromiter((q_of.setdefault(v, len(q_of)) for v in rows[:, 0].tolist()), dtype=np.int64, count=n)
+        ri = np.fromiter((r_of.setdefault(v, len(r_of)) for v in rows[:, 1].tolist()), dtype=np.int64, count=n)
+        q_tab, r_tab = list(q_of), list(r_of)
+        lens, ops, runs = [], [], np.zeros(n, dtype=np.int64)
+        for k, c in enumerate(rows[:, 14].tolist()):
+            if isinstance(c, str):
+                c = [(int(a), b) for a, b in re.findall(r'(\d+)([MID])', c)]
+            runs[k] = len(c)
+            for a, b in c:
+                lens.append(int(a))
+                ops.append(_OP_CODE[b])
+        arena = ((np.array(lens, dtype=np.int64) << 2) | np.array(ops, dtype=np.int64)).astype(np.uint32) if lens else np.zeros(0, np.uint32)
+        off = np.concatenate([[0], np.cumsum(runs)[:-1]]) if n else runs
+        num = lambda c, dt: np.ascontiguousarray(rows[:, c], dtype=dt)
+        sc = rows[:, 11].tolist()
+        t = cls(q_tab, r_tab, qi, ri, num(2, np.float64), num(3, np.int64), num(4, np.int64), num(5, np.int64), num(6, np.int64), num(7, np.int64),
+                num(8, np.int64), num(9, np.int64), num(10, np.float64), num(11, np.float64), num(12, np.int64), num(13, np.int64), arena, off, runs,
+                rid=num(15, np.int64) if rows.shape[1] > 15 else None,
+                merge=rows[:, 16].tolist() if rows.shape[1] > 16 else None,
+                score_is_int=all(isinstance(v, _INT_TYPES) for v in sc))
+        return t
+
+    def take(self, idx):
+        """rows idx (index array or boolean mask), in that order; name tables and the CIGAR arena are shared"""
+        idx = np.asarray(idx)
+        if idx.dtype == bool:
+            idx = np.flatnonzero(idx)
+        t = HitTable.__new__(HitTable)
+        for f in self.__slots__:
+            setattr(t, f, getattr(self, f))
+        for f in self._ROW_COLS:
+            setattr(t, f, getattr(self, f)[idx])
+        if self.merge is not None:
+            t.merge = [self.merge[i] for i in idx.tolist()]
+        return t
+
+    @staticmethod
+    def concat(tables):
+        """rows of several tables one after the other (uberBlast.py:353 vstack); name tables and arenas are merged"""
+        tables = [t for t in tables if len(t)]
+        if not tables:
+            return HitTable.empty()
+        if len(tables) == 1:
+            return tables[0]
+        q_of, r_of, parts = {}, {}, {f: [] for f in HitTable._ROW_COLS}
+        arena, base = [], 0
+        for t in tables:
+            qmap = np.fromiter((q_of.setdefault(v, len(q_of)) for v in t.q_tab), dtype=np.int64, count=len(t.q_tab))
+            rmap = np.fromiter((r_of.setdefault(v, len(r_of)) for v in t.r_tab), dtype=np.int64, count=len(t.r_tab))
+            for f in HitTable._ROW_COLS:
+                parts[f].append(getattr(t, f))
+            parts['qi'][-1] = qmap[t.qi]
+            parts['ri'][-1] = rmap[t.ri]
+            parts['c_off'][-1] = t.c_off + base
+            arena.append(t.arena)
+            base += len(t.arena)
+        cols = {f: np.concatenate(v) for f, v in parts.items()}
+        out = HitTable(list(q_of), list(r_of), cols['qi'], cols['ri'], cols['iden'], cols['aln'], cols['mis'], cols['gap'], cols['qs'], cols['qe'],
+                       cols['ss'], cols['se'], cols['evalue'], cols['score'], cols['ql'], cols['sl'], np.concatenate(arena), cols['c_off'], cols['c_runs'],
+                       rid=cols['rid'], score_is_int=all(t.score_is_int for t in tables))
+        return out
+
+    # ------------------------------------------------------------------------------------------------ pieces of the chain
+    def q_codes(self):
+        return _name_codes(self.q_tab, self.qi)
+
+    def r_codes(self):
+        return _name_codes(self.r_tab, self.ri)
+
+    def fix_end(self, se_lim, ee_lim):
+        """RunBlast.fixEnd (uberBlast.py:462-480): stretch an alignment over an unaligned query head of at most se_lim bases / tail of at
+        most ee_lim bases, as far as the reference sequence allows; the first / last CIGAR run grows by the same amount whatever its
+        operation is; identity, score and columns 3-5 stay.  All rows at once."""
+        if not len(self):
+            return
+        head, tail = self.qs - 1, self.ql - self.qe
+        fwd = self.se > self.ss
+        d = np.where((head > 0) & (head <= se_lim), np.where(fwd, np.minimum(head, self.ss - 1), np.minimum(head, self.sl - self.ss)), 0)
+        e = np.where((tail > 0) & (tail <= ee_lim), np.where(fwd, np.minimum(tail, self.sl - self.se), np.minimum(tail, self.se - 1)), 0)
+        self.qs = self.qs - d
+        self.ss = self.ss + np.where(fwd, -d, d)
+        self.qe = self.qe + e
+        self.se = self.se + np.where(fwd, e, -e)
+        if d.any() or e.any():
+            # the rows' runs are copied into a private arena first: rows may share runs (and so does the caller's table)
+            owner = np.repeat(np.arange(len(self)), self.c_runs)
+            start = np.concatenate([[0], np.cumsum(self.c_runs)[:-1]])
+            src = np.repeat(self.c_off - start, self.c_runs) + np.arange(len(owner))
+            arena = self.arena[src].astype(np.int64)
+            np.add.at(arena, start, d << 2)
+            np.add.at(arena, start + self.c_runs - 1, e << 2)
+            self.arena, self.c_off = arena.astype(np.uint32), start
+            del owner
+
+    def final_order(self):
+        """the sort that ends RunBlast.run (uberBlast.py:375): by query name, reference name (as the column's values sort: strings
+        lexicographically - '10' < '9'), then score; stable"""
+        return np.lexsort((self.score, self.r_codes(), self.q_codes()))
+
+    # ------------------------------------------------------------------------------------------------ object rows
+    def cigar_strings(self):
+        """'150M3D150M' per row (uberBlast.py:480), built for all rows at once"""
+        n = len(self)
+        if n == 0:
+            return []
+        runs = self.c_runs
+        start = np.concatenate([[0], np.cumsum(runs)])
+        src = np.repeat(self.c_off - start[:-1], runs) + np.arange(int(start[-1]))
+        a = self.arena[src].astype(np.int64)
+        lens, ops = a >> 2, a & 3
+        nd = np.ones(len(a), dtype=np.int64)
+        p = 10
+        while len(lens) and (lens >= p).any():
+            nd += lens >= p
+            p *= 10
+        width = nd + 1
+        pos = np.concatenate([[0], np.cumsum(width)])
+        buf = np.empty(int(pos[-1]), dtype=np.uint8)
+        k, p = 0, 1
+        while len(lens) and (nd > k).any():
+            m = nd > k
+            buf[pos[:-1][m] + nd[m] - 1 - k] = 48 + (lens[m] // p) % 10
+            k += 1
+            p *= 10
+        buf[pos[:-1] + nd] = _OP_BYTES[ops]
+        text = buf.tobytes().decode('ascii')
+        row_pos = pos[start].tolist()
+        return [text[row_pos[i]:row_pos[i + 1]] for i in range(n)]
+
+    def cigar_lists(self):
+        """[[n, op], ...] per row - the form the tools hand over in the reference (uberBlast.py:33, 316-319)"""
+        a = self.arena.astype(np.int64)
+        pairs = list(map(list, zip((a >> 2).tolist(), _OPS[a & 3].tolist())))
+        return [pairs[o:o + r] for o, r in zip(self.c_off.tolist(), self.c_runs.tolist())]
+
+    def to_rows(self, cigar='list', with_rid=True):
+        """ndarray(object)[n, 15 | 16 | 17]: Python scalars per cell, CIGAR as lists ('list') or as text ('str')"""
+        n = len(self)
+        width = 15 + (1 if with_rid else 0) + (1 if (self.merge is not None and with_rid) else 0)
+        out = np.empty([n, width], dtype=object)
+        if n == 0:
+            return out
+        q_tab, r_tab = self.q_tab, self.r_tab
+        score = self.score.astype(np.int64).tolist() if self.score_is_int else self.score.tolist()
+        cols = [[q_tab[i] for i in self.qi.tolist()], [r_tab[i] for i in self.ri.tolist()], self.iden.tolist(), self.aln.tolist(), self.mis.tolist(),
+                self.gap.tolist(), self.qs.tolist(), self.qe.tolist(), self.ss.tolist(), self.se.tolist(), self.evalue.tolist(), score,
+                self.ql.tolist(), self.sl.tolist(), self.cigar_strings() if cigar == 'str' else None]
+        for j, c in enumerate(cols):
+            if c is not None:
+                out[:, j] = c
+        if cigar != 'str':
+            col = out[:, 14]
+            for k, v in enumerate(self.cigar_lists()):
+                col[k] = v
+        if with_rid:
+            out[:, 15] = self.rid.tolist()
+            if self.merge is not None:
+                col = out[:, 16]
+                for k, v in enumerate(self.merge):
+                    col[k] = v
+        return out

@@ -184,54 +184,44 @@ def linear_merge_py(blastab, gap_dist, len_diff):
 
 
 # ------------------------------------------------------------------------------------------------ C++ ports (libpeppan_hip.so)
-def _codes(col):
-    """integer rank of every name, in the order pandas sorts the column (numeric for ints, code-point order for strings)"""
-    vals = col.tolist()
-    if len(vals) and all(isinstance(v, (int, np.integer)) for v in vals):
-        return np.asarray(vals, dtype=np.int64)
-    return np.unique(np.array(vals, dtype=str), return_inverse=True)[1].astype(np.int64)
+# The product path: numeric columns of a HitTable in, HitTable out; the object-table functions below wrap them for callers (and
+# tests) that hold the reference's row format.
+def _folded(T):
+    """reference coordinates with reverse-strand hits negated, so that start < end everywhere (uberBlast.py:420, 455)"""
+    rev = T.ss > T.se
+    return np.where(rev, -T.ss, T.ss), np.where(rev, -T.se, T.se)
 
 
-def _numeric(tab, cols, dtype):
-    # (the conversion of an object column runs inside numpy; a list comprehension over the rows costs 10x as much)
-    return [np.ascontiguousarray(tab[:, c], dtype=dtype) for c in cols]
-
-
-def ovl_filter(blastab, coverage, delta):
+def ovl_filter_table(T, coverage, delta):
     """flag -f (RunBlast.ovlFilter, uberBlast.py:417-452): drop the weaker of two hits of the same (query, reference) that overlap
-    >= `coverage` on the reference.  The greedy pass itself is pep_ovl_filter (host C++ in libpeppan_hip.so)."""
+    >= `coverage` on the reference.  Rows come back in the (reference, query, start, query start) order the filter walks them in.
+    The greedy pass itself is pep_ovl_filter (host C++ in libpeppan_hip.so)."""
     from . import _native as N
-    _fold_strand(blastab)
-    if blastab.shape[0] == 0:
-        return blastab
-    q, r = _codes(blastab[:, Q]), _codes(blastab[:, R])
-    qs, ss = _numeric(blastab, (QS, SS), np.int64)
-    tab = blastab[np.lexsort((qs, ss, q, r))]
-    q, r = _codes(tab[:, Q]), _codes(tab[:, R])
-    qs, qe, ss, se = _numeric(tab, (QS, QE, SS, SE), np.int64)
-    score, iden = _numeric(tab, (SCORE, IDEN), np.float64)
-    N.ovl_filter(q, r, qs, qe, ss, se, score, iden, coverage, delta)
-    tab = tab[iden >= 0]
-    _unfold_strand(tab)
-    return tab
+    if len(T) == 0:
+        return T
+    ss, se = _folded(T)
+    q, r = T.q_codes(), T.r_codes()
+    order = np.lexsort((T.qs, ss, q, r))
+    iden = T.iden[order].copy()
+    N.ovl_filter(q[order], r[order], T.qs[order], T.qe[order], ss[order], se[order], T.score[order], iden, coverage, delta)
+    return T.take(order[iden >= 0])
 
 
-def linear_merge(blastab, gap_dist, len_diff):
+def linear_merge_table(T, gap_dist, len_diff):
     """flag -m (RunBlast.linearMerge + _linearMerge, uberBlast.py:100-218, 453-460): chain collinear hits of one gene; column 16 =
     [score, identity, span, row ids...].  The chaining is pep_linear_merge (host C++); the row order inside a query that chained
     something is the iteration order of a Python set, as in the reference, so that part stays a set comprehension here."""
     from . import _native as N
-    _fold_strand(blastab)
-    n = blastab.shape[0]
+    n = len(T)
     if n == 0:
-        return np.hstack([blastab, np.empty((0, 1), dtype=object)])
-    q, r = _codes(blastab[:, Q]), _codes(blastab[:, R])
-    qs, ss = _numeric(blastab, (QS, SS), np.int64)
-    tab = blastab[np.lexsort((qs, ss, r, q))]
-    q, r = _codes(tab[:, Q]), _codes(tab[:, R])
-    qs, qe, ss, se, ql, sl, rid = _numeric(tab, (QS, QE, SS, SE, QLEN, SLEN, RID), np.int64)
-    score, iden = _numeric(tab, (SCORE, IDEN), np.float64)
-    keep, q_off, asc, g_score, g_iden, g_span, ids_off, ids = N.linear_merge(q, r, iden, qs, qe, ss, se, score, ql, sl, rid, gap_dist, len_diff)
+        T.merge = []
+        return T
+    ss, se = _folded(T)
+    q, r = T.q_codes(), T.r_codes()
+    first = np.lexsort((T.qs, ss, r, q))
+    q = q[first]
+    keep, q_off, asc, g_score, g_iden, g_span, ids_off, ids = N.linear_merge(q, r[first], T.iden[first], T.qs[first], T.qe[first], ss[first], se[first],
+                                                                              T.score[first], T.ql[first], T.sl[first], T.rid[first], gap_dist, len_diff)
     if asc.all():
         order = keep
     else:
@@ -246,39 +236,34 @@ def linear_merge(blastab, gap_dist, len_diff):
                 local = (seq - lo).tolist()
                 parts.append(np.array(list({i for i in local}), dtype=np.int64) + lo)
         order = np.concatenate(parts)
-    out = np.empty((len(order), tab.shape[1] + 1), dtype=object)
-    out[:, :-1] = tab[order]
+    out = T.take(first[order])
     s_l, i_l, sp_l, ids_l, off_l = g_score.tolist(), g_iden.tolist(), g_span.tolist(), ids.tolist(), ids_off.tolist()
     shared = []
-    last = out.shape[1] - 1
-    for j, i in enumerate(order.tolist()):
-        out[j, last] = [s_l[i], i_l[i], sp_l[i]] + ids_l[off_l[i]:off_l[i + 1]] if sp_l[i] >= 0 else shared
-    _unfold_strand(out)
+    out.merge = [[s_l[i], i_l[i], sp_l[i]] + ids_l[off_l[i]:off_l[i + 1]] if sp_l[i] >= 0 else shared for i in order.tolist()]
     return out
 
 
-# ------------------------------------------------------------------------------------------------ -O
-def overlaps(blastab, ovl_l, ovl_p, batch=1000000, sweep=None):
-    """pairs of hits (row ids) whose reference intervals overlap by >= min(ovl_l, ovl_p*len1) or >= ovl_p*len2.
-    The reference sweeps in batches of 1e6 pairs and, on resuming, emits the last pair of a full batch again
-    (uberBlast.py:76-92); reproduced.  `sweep(contig, start, end, row_id, ovl_l, ovl_p)` runs the sweep itself
-    (the GPU kernel K11 in the product); without it a plain Python loop does (used by the CPU tests)."""
+def overlaps_table(T, ovl_l, ovl_p, batch=1000000, sweep=None):
+    """flag -O (RunBlast.returnOverlap + tab2overlaps, uberBlast.py:73-97, 378-395): pairs of hits (row ids) whose reference intervals
+    overlap by >= min(ovl_l, ovl_p*len1) or >= ovl_p*len2.  The reference sweeps in batches of 1e6 pairs and, on resuming, emits
+    the last pair of a full batch again (uberBlast.py:76-92); reproduced.  `sweep(contig, start, end, row_id, ovl_l, ovl_p)` runs
+    the sweep itself (the GPU kernel K11 in the product); without it a plain Python loop does (used by the CPU tests)."""
     # intervals [contig id, row id, start, end] sorted by (contig, start, end), ties in table order; the reference numbers a contig
     # by the LAST row that names it (dict comprehension, uberBlast.py:380)
-    n = blastab.shape[0]
+    n = len(T)
     if n:
-        codes = pd.factorize(blastab[:, R])[0]
-        last = np.zeros(int(codes.max()) + 1, dtype=np.int64)
-        np.maximum.at(last, codes, np.arange(n))
-        ss, se, rid = _numeric(blastab, (SS, SE, RID), np.int64)
-        lo, hi, cid = np.minimum(ss, se), np.maximum(ss, se), last[codes]
-        iv = np.stack([cid, rid, lo, hi], axis=1)[np.lexsort((hi, lo, cid))].astype(int)
+        last = np.zeros(int(T.ri.max()) + 1, dtype=np.int64)
+        np.maximum.at(last, T.ri, np.arange(n))
+        lo, hi, cid = np.minimum(T.ss, T.se), np.maximum(T.ss, T.se), last[T.ri]
+        iv = np.stack([cid, T.rid, lo, hi], axis=1)[np.lexsort((hi, lo, cid))].astype(int)
     else:
         iv = np.empty((0, 4), dtype=int)
     if sweep is not None and len(iv):
         res = np.asarray(sweep(iv[:, 0], iv[:, 2], iv[:, 3], iv[:, 1], float(ovl_l), float(ovl_p)), dtype=int).reshape(-1, 3)
-        if len(res) >= batch:                   # the reference's resume quirk: pair number k*1e6 appears twice
-            dup = np.arange(batch - 1, len(res), batch)
+        if len(res) >= batch:
+            # the reference's resume quirk: the pair that fills a batch is emitted again as the first of the next one, so every later
+            # batch holds batch - 1 new pairs: the duplicated pairs are number batch-1, 2*(batch-1), 3*(batch-1), ... (0-based)
+            dup = np.arange(batch - 1, len(res), batch - 1)
             res = np.insert(res, dup + 1, res[dup], axis=0)
         return res[res.T[2] > 0]
     out = []
@@ -295,7 +280,32 @@ def overlaps(blastab, ovl_l, ovl_p, batch=1000000, sweep=None):
             if ovl >= need or ovl >= ovl_p * (e2 - s2 + 1):
                 out.append([id1, id2, ovl])
                 emitted += 1
-                if emitted % batch == 0:
-                    out.append([id1, id2, ovl])
+                if emitted % batch == 0:            # the batch is full: the resumed sweep emits this pair once more, and it counts
+                    out.append([id1, id2, ovl])     # towards the next batch
+                    emitted += 1
     res = np.array(out, dtype=int).reshape(-1, 3)
     return res[res.T[2] > 0]
+
+
+def _as_table(blastab):
+    from .hittable import HitTable
+    return blastab if isinstance(blastab, HitTable) else HitTable.from_rows(blastab)
+
+
+def ovl_filter(blastab, coverage, delta):
+    """object-table front of ovl_filter_table (same row format in and out)"""
+    if blastab.shape[0] == 0:
+        return blastab
+    return ovl_filter_table(_as_table(blastab), coverage, delta).to_rows()
+
+
+def linear_merge(blastab, gap_dist, len_diff):
+    """object-table front of linear_merge_table: returns the rows with column 16 appended"""
+    if blastab.shape[0] == 0:
+        return np.hstack([blastab, np.empty((0, 1), dtype=object)])
+    return linear_merge_table(_as_table(blastab), gap_dist, len_diff).to_rows()
+
+
+def overlaps(blastab, ovl_l, ovl_p, batch=1000000, sweep=None):
+    """object-table front of overlaps_table"""
+    return overlaps_table(_as_table(blastab), ovl_l, ovl_p, batch, sweep)
