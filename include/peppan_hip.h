@@ -166,8 +166,10 @@ int pep_set_target_groups(pep_ctx *ctx, const uint32_t *group, uint32_t n);
 int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out);
 int pep_result_size(const pep_result *r, uint64_t *n_hits, uint64_t *n_cigar);
 int pep_result_copy(const pep_result *r, pep_hit *hits, uint32_t *cigar);
-/* zero-copy access: pointers to the n_hits records / n_cigar runs of pep_result_size, valid until the next pep_search on the result's
- * context, pep_ctx_destroy or pep_result_free, whichever comes first (use pep_result_copy for anything that must outlive that) */
+/* zero-copy access: pointers to the n_hits records / n_cigar runs of pep_result_size, valid until the next call on the result's
+ * context that produces a hit table or re-translates (pep_search, pep_translate, pep_linclust), pep_ctx_destroy or pep_result_free,
+ * whichever comes first: they point into the context's pinned staging area, which such calls may re-use or re-allocate
+ * (use pep_result_copy for anything that must outlive that) */
 int pep_result_data(const pep_result *r, const pep_hit **hits, const uint32_t **cigar);
 int pep_result_stats(const pep_result *r, pep_stats *stats);
 void pep_result_free(pep_result *r);

@@ -8,6 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
 ABI_VERSION = 2
+MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
@@ -114,14 +115,32 @@ def nucleotide_params(min_id_pct=0., min_qcov_pct=0., top_k=1000, dbsize=5e6, ma
 
 
 def _pack(seqs):
-    """list of bytes / uint8 arrays -> (uint8 concatenation, uint64 offsets[n+1])"""
-    arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else
-            (np.frombuffer(s.encode('ascii'), dtype=np.uint8) if isinstance(s, str) else np.asarray(s, dtype=np.uint8)) for s in seqs]
-    off = np.zeros(len(arrs) + 1, dtype=np.uint64)
-    if arrs:
-        off[1:] = np.cumsum([a.size for a in arrs])
-    res = np.concatenate(arrs) if arrs and off[-1] else np.zeros(1, dtype=np.uint8)
+    """list of str / bytes / uint8 arrays -> (uint8 concatenation, uint64 offsets[n+1]); a ready-made (codes, offsets) tuple passes through"""
+    if isinstance(seqs, tuple) and len(seqs) == 2:
+        res, off = seqs
+        res = np.ascontiguousarray(res, dtype=np.uint8)
+        return (res if res.size else np.zeros(1, dtype=np.uint8)), np.ascontiguousarray(off, dtype=np.uint64)
+    n = len(seqs)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    if n and all(isinstance(s, str) for s in seqs):                  # one join + one buffer view instead of one array per sequence
+        off[1:] = np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=n))
+        res = np.frombuffer(''.join(seqs).encode('ascii'), dtype=np.uint8)
+    elif n and all(isinstance(s, (bytes, bytearray)) for s in seqs):
+        off[1:] = np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=n))
+        res = np.frombuffer(b''.join(seqs), dtype=np.uint8)
+    else:
+        arrs = [np.frombuffer(s, dtype=np.uint8) if isinstance(s, (bytes, bytearray)) else
+                (np.frombuffer(s.encode('ascii'), dtype=np.uint8) if isinstance(s, str) else np.asarray(s, dtype=np.uint8)) for s in seqs]
+        if arrs:
+            off[1:] = np.cumsum([a.size for a in arrs])
+        res = np.concatenate(arrs) if arrs and off[-1] else np.zeros(1, dtype=np.uint8)
+    if res.size == 0:
+        res = np.zeros(1, dtype=np.uint8)
     return np.ascontiguousarray(res, dtype=np.uint8), off
+
+
+def _count(seqs):
+    return len(seqs[1]) - 1 if isinstance(seqs, tuple) and len(seqs) == 2 else len(seqs)
 
 
 def _ptr(a):
@@ -198,6 +217,7 @@ class Context(object):
         rc = self._lib.pep_ctx_create(int(device), C.byref(h))
         self._h = h
         self._view = None
+        self.upload_generation = 0           # bumped by every call that replaces a device-resident sequence set (see RunBlast._ensure_nt)
         if rc != 0:
             msg = self._lib.pep_last_error(h).decode() if h else 'pep_ctx_create failed'
             if h:
@@ -232,20 +252,24 @@ class Context(object):
 
     # ---- inputs
     def set_query_nt(self, seqs, gtable=11):
+        self.upload_generation += 1
         nt, off = _pack(seqs)
-        self._check(self._lib.pep_set_query_nt(self._h, _ptr(nt), _ptr(off), C.c_uint32(len(seqs)), C.c_int(gtable)), 'pep_set_query_nt')
+        self._check(self._lib.pep_set_query_nt(self._h, _ptr(nt), _ptr(off), C.c_uint32(_count(seqs)), C.c_int(gtable)), 'pep_set_query_nt')
 
     def set_ref_nt(self, seqs, frames=6, gtable=11):
+        self.upload_generation += 1
         nt, off = _pack(seqs)
-        self._check(self._lib.pep_set_ref_nt(self._h, _ptr(nt), _ptr(off), C.c_uint32(len(seqs)), C.c_int(frames), C.c_int(gtable)), 'pep_set_ref_nt')
+        self._check(self._lib.pep_set_ref_nt(self._h, _ptr(nt), _ptr(off), C.c_uint32(_count(seqs)), C.c_int(frames), C.c_int(gtable)), 'pep_set_ref_nt')
 
     def set_query_aa(self, seqs):
+        self.upload_generation += 1
         aa, off = _pack(seqs)
-        self._check(self._lib.pep_set_query_aa(self._h, _ptr(aa), _ptr(off), C.c_uint32(len(seqs))), 'pep_set_query_aa')
+        self._check(self._lib.pep_set_query_aa(self._h, _ptr(aa), _ptr(off), C.c_uint32(_count(seqs))), 'pep_set_query_aa')
 
     def set_ref_aa(self, seqs):
+        self.upload_generation += 1
         aa, off = _pack(seqs)
-        self._check(self._lib.pep_set_ref_aa(self._h, _ptr(aa), _ptr(off), C.c_uint32(len(seqs))), 'pep_set_ref_aa')
+        self._check(self._lib.pep_set_ref_aa(self._h, _ptr(aa), _ptr(off), C.c_uint32(_count(seqs))), 'pep_set_ref_aa')
 
     def set_target_groups(self, groups):
         """groups: one non-decreasing id per reference sequence (None / empty clears): batch of reference sets in one search"""
@@ -328,6 +352,7 @@ class Context(object):
     def linclust(self, seqs, min_id, min_cov, base=4, k=17, m=20):
         """seqs: list of uint8 code arrays -> (uint32 representative index per sequence, stats dict)"""
         codes, off = _pack(seqs)
+        self.upload_generation += 1                     # the gapped stage takes over the packed sequence sets
         rep = np.zeros(len(seqs), dtype=np.uint32)
         stats = np.zeros(3, dtype=np.uint64)
         if len(seqs):

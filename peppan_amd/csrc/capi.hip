@@ -348,7 +348,12 @@ void pep_ctx_destroy(pep_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     for (auto &b : ctx->ws) dev_release(b);
     for (int id = 0; id < TM_COUNT; ++id) { if (ctx->tm_a[id]) (void)hipEventDestroy(ctx->tm_a[id]); if (ctx->tm_b[id]) (void)hipEventDestroy(ctx->tm_b[id]); }
-    if (ctx->staged_result) pep_materialise_staged(ctx);
+    if (ctx->staged_result) {
+        // the result outlives the context (freeing it afterwards is allowed): it takes its own copy and forgets the context
+        pep_result *r = ctx->staged_result;
+        pep_materialise_staged(ctx);
+        r->ctx = nullptr;
+    }
     if (ctx->pin_small.p) (void)hipHostFree(ctx->pin_small.p);
     if (ctx->pin_stage.p) (void)hipHostFree(ctx->pin_stage.p);
     if (ctx->pin_k1.p) (void)hipHostFree(ctx->pin_k1.p);

@@ -263,7 +263,7 @@ int k9_gapped(pep_ctx *ctx, const uint8_t *h_res, const uint64_t *h_off, int bas
         for (size_t i = at; i < end; ++i) q_list.push_back(cands[i].s);
         std::sort(q_list.begin(), q_list.end());
         q_list.erase(std::unique(q_list.begin(), q_list.end()), q_list.end());
-        if (q_list.size() > PEP_MAX_QUERIES) return pep_fail(ctx, PEP_ERR_LIMIT, "pep_linclust: gapped batch exceeds the query limit");
+        if (q_list.size() > PEP_MAX_QUERIES) { rc = pep_fail(ctx, PEP_ERR_LIMIT, "pep_linclust: gapped batch exceeds the query limit"); break; }    // (the parameters are restored below)
         auto upload = [&](SeqSet &set, const std::vector<uint32_t> &list, uint32_t max_n) {
             codes.clear(); off.assign(1, 0);
             for (uint32_t x : list) {

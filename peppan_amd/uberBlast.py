@@ -14,14 +14,11 @@ the tools raise.
 """
 import os
 import sys
-from itertools import chain
-from operator import itemgetter
-
 import numpy as np
-import pandas as pd
 
 from . import _native as N
 from . import mapfilters
+from .hittable import HitTable
 from .configure import logger, readFastq, blosum62, asc2int
 
 _OPS = np.array(['M', 'I', 'D'])
@@ -74,12 +71,12 @@ def get_context(device=None):
 # ------------------------------------------------------------------------------------------------------------
 # GPU hits -> the reference's table rows (coordinate algebra of parseDiamond, uberBlast.py:25-58)
 # ------------------------------------------------------------------------------------------------------------
-def hits_to_blastab(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
+def hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
     """hits/cigar: output of Context.search for a translated search.  q_len / r_len: nucleotide lengths per sequence index.
-    Returns ndarray(object)[n, 15]."""
+    Returns the numeric HitTable of the rows parseDiamond would keep (coordinate algebra and filters of uberBlast.py:25-58)."""
     n = len(hits)
     if n == 0:
-        return np.empty([0, 15], dtype=object)
+        return HitTable.empty()
     qi, ti = hits['q'].astype(np.int64), hits['t'].astype(np.int64)
     qseq, qf = q_meta['seq'][qi].astype(np.int64), q_meta['frame'][qi].astype(np.int64)
     rseq, rf, rx = t_meta['seq'][ti].astype(np.int64), t_meta['frame'][ti].astype(np.int64), t_meta['chunk_off'][ti].astype(np.int64)
@@ -103,44 +100,52 @@ def hits_to_blastab(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len,
     gap_open = np.bincount(owner, weights=(runs_op != 0), minlength=n).astype(np.int64)
     mismatch = (variation - gap_nt).astype(np.int64)
     idx = np.nonzero(keep)[0]
-    pairs = list(map(list, zip(runs_len.tolist(), _OPS[runs_op].tolist())))           # one [length, op] list per CIGAR run
-    cols = [[str(q_names[i]) for i in qseq[idx].tolist()], [str(r_names[i]) for i in rseq[idx].tolist()], iden[idx].tolist(), cl[idx].tolist(),
-            mismatch[idx].tolist(), gap_open[idx].tolist(), qs_nt[idx].tolist(), qe_nt[idx].tolist(), rs_nt[idx].tolist(), re_nt[idx].tolist(),
-            [0.0] * len(idx), hits['score'][idx].astype(np.int64).tolist(), ql[idx].tolist(), rl[idx].tolist()]
-    return _object_table(cols, pairs, hits['cigar_off'][idx].tolist(), hits['cigar_runs'][idx].tolist())
+    return HitTable([str(x) for x in q_names], [str(x) for x in r_names], qseq[idx], rseq[idx], iden[idx], cl[idx], mismatch[idx], gap_open[idx],
+                    qs_nt[idx], qe_nt[idx], rs_nt[idx], re_nt[idx], np.zeros(len(idx)), hits['score'][idx], ql[idx], rl[idx],
+                    ((runs_len << 2) | runs_op).astype(np.uint32), hits['cigar_off'][idx], hits['cigar_runs'][idx])
 
 
-def _object_table(cols, pairs, cigar_off, cigar_runs):
-    """14 scalar columns (lists of Python values) + the CIGAR runs of every row -> ndarray(object)[n, 15]"""
-    n = len(cigar_off)
-    out = np.empty([n, 15], dtype=object)
-    for j, c in enumerate(cols):
-        out[:, j] = c
-    cig = out[:, 14]
-    for k, (o, r) in enumerate(zip(cigar_off, cigar_runs)):
-        cig[k] = pairs[o:o + r]
-    return out
+def hits_to_blastab(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
+    """the same as the reference's row format: ndarray(object)[n, 15], CIGAR as [[n, op], ...] in nucleotides"""
+    return hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio).to_rows(with_rid=False)
 
 
 _NT_CODE = np.full(256, 4, dtype=np.uint8)
 for _c, _v in zip('ACGTacgt', (0, 1, 2, 3, 0, 1, 2, 3)):
     _NT_CODE[ord(_c)] = _v
 _NT_RC = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+_TILE_HOME = 1 << 22          # home stretch of one window when a reference strand exceeds PEP_MAX_SEQ_LEN (runBlast)
 
 
-def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev):
-    """nucleotide-search hits -> the rows parseBlast builds from blastn's outfmt 6 (uberBlast.py:275-290, 311-320):
+def _encode_nt(texts):
+    """list of nucleotide strings -> (codes A0 C1 G2 T3 other 4 of the concatenation, uint64 offsets[n+1]); one table pass for all of them"""
+    off = np.zeros(len(texts) + 1, dtype=np.uint64)
+    if texts:
+        off[1:] = np.cumsum(np.fromiter(map(len, texts), dtype=np.int64, count=len(texts)))
+    return _NT_CODE[np.frombuffer(''.join(texts).encode('ascii'), dtype=np.uint8)], off
+
+
+def blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev, windows=None):
+    """nucleotide-search hits -> the rows parseBlast builds from blastn's outfmt 6 (uberBlast.py:275-290, 311-320), as a HitTable:
     t_seq / t_rev give the reference sequence and strand of every target (reverse strand: sstart > send); identity
     carries blastn's 3 printed decimals"""
     n = len(hits)
     if n == 0:
-        return np.empty([0, 15], dtype=object)
+        return HitTable.empty()
     qi = hits['q'].astype(np.int64)
     ti = hits['t'].astype(np.int64)
     rev, ri = t_rev[ti], t_seq[ti]
     ql, sl = np.asarray(q_len, dtype=np.int64)[qi], np.asarray(r_len, dtype=np.int64)[ri]
     qs, qe = hits['q_start'].astype(np.int64), hits['q_end'].astype(np.int64)
     ts, te = hits['t_start'].astype(np.int64), hits['t_end'].astype(np.int64)
+    in_home = True
+    if windows is not None:
+        # targets that are windows of a long strand (runBlast): back to strand coordinates; a hit belongs to the window whose home
+        # stretch holds its midpoint (the neighbouring window found the same alignment inside its halo)
+        w_off, home_lo, home_hi = windows
+        ts, te = ts + w_off[ti], te + w_off[ti]
+        mid = (ts + te - 2) // 2
+        in_home = (mid >= home_lo[ti]) & (mid < home_hi[ti])
     ss, se = np.where(rev, sl - ts + 1, ts), np.where(rev, sl - te + 1, te)
     aln, ident = hits['aln_len'].astype(np.int64), hits['n_ident'].astype(np.int64)
     iden = np.array([float('%.3f' % v) for v in (100. * ident / aln).tolist()]) / 100.
@@ -150,13 +155,14 @@ def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, m
     gap_open = np.bincount(owner, weights=(runs_op != 0), minlength=n).astype(np.int64)
     score = hits['score'].astype(np.int64)
     evalue = params.ka_k * ql * params.dbsize * np.exp(-params.ka_lambda * score)
-    keep = (iden >= min_id) & (qe - qs + 1 >= min_cov) & (qe - qs + 1 >= min_ratio * ql)
+    keep = (iden >= min_id) & (qe - qs + 1 >= min_cov) & (qe - qs + 1 >= min_ratio * ql) & in_home
     idx = np.nonzero(keep)[0]
-    pairs = list(map(list, zip(runs_len.tolist(), _OPS[runs_op].tolist())))
-    cols = [[str(q_names[i]) for i in qi[idx].tolist()], [str(r_names[i]) for i in ri[idx].tolist()], iden[idx].tolist(), aln[idx].tolist(),
-            (aln - ident - gap_cols)[idx].tolist(), gap_open[idx].tolist(), qs[idx].tolist(), qe[idx].tolist(), ss[idx].tolist(), se[idx].tolist(),
-            evalue[idx].tolist(), score[idx].tolist(), ql[idx].tolist(), sl[idx].tolist()]
-    return _object_table(cols, pairs, hits['cigar_off'][idx].tolist(), hits['cigar_runs'][idx].tolist())
+    return HitTable([str(x) for x in q_names], [str(x) for x in r_names], qi[idx], ri[idx], iden[idx], aln[idx], (aln - ident - gap_cols)[idx], gap_open[idx],
+                    qs[idx], qe[idx], ss[idx], se[idx], evalue[idx], score[idx], ql[idx], sl[idx], np.array(cigar, dtype=np.uint32), hits['cigar_off'][idx], hits['cigar_runs'][idx])
+
+
+def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev, windows=None):
+    return blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev, windows).to_rows(with_rid=False)
 
 
 # ------------------------------------------------------------------------------------------------------------
@@ -208,19 +214,6 @@ def cigar2score(data):
     return n_match / (q_aa.size * 3. + b_gap - m_gap), np.sum(blosum62[(q_aa << 5) + r_aa]) - gap_cost
 
 
-def _encode_cigars(cigars):
-    """list of [[n, op], ...] -> (uint32 arena len<<2|op, offsets, counts)"""
-    n = len(cigars)
-    counts = np.fromiter(map(len, cigars), dtype=np.int64, count=n)
-    offs = np.concatenate([[0], np.cumsum(counts)])
-    total = int(offs[-1])
-    flat = list(chain.from_iterable(cigars))                 # the [n, op] pairs of all rows, one after the other
-    lens = np.fromiter(map(itemgetter(0), flat), dtype=np.int64, count=total)
-    ops = np.fromiter(map(_OP_CODE.__getitem__, map(itemgetter(1), flat)), dtype=np.int64, count=total)
-    arena = ((lens << 2) | ops).astype(np.uint32)
-    return arena, offs[:-1], counts
-
-
 class RunBlast(object):
     def __init__(self, device=None):
         self.qrySeq = self.refSeq = None
@@ -235,39 +228,43 @@ class RunBlast(object):
         self.min_id, self.min_cov, self.min_ratio = min_id, min_cov, min_ratio
         self.table_id, self.n_thread = table_id, n_thread
         self.pool = useProcess            # accepted for signature compatibility; the GPU path does not fan out
-        blastab = []
+        tables = []
         try:
             for method in methods:
                 if method.lower() in tools:
-                    blastab.append(tools[method.lower()](ref, qry))
-            blastab = [b for b in blastab if b.shape[0] > 0]
+                    tables.append(_as_table(tools[method.lower()](ref, qry)))
+        except N.PepError as e:
+            if 'PEP_ERR_LIMIT' in str(e) or '(-3)' in str(e):
+                raise                     # an input beyond a documented limit must not silently cost a whole tool's hits
+            import traceback
+            traceback.print_exc()
         except Exception:
             # same convention as the reference (uberBlast.py:347-349): report, keep what the other tools produced
             import traceback
             traceback.print_exc()
-            blastab = [b for b in blastab if hasattr(b, 'shape') and b.shape[0] > 0]
-        return self._post(blastab, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end)
+        return self._post(tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end)
 
-    def _post(self, blastab, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end):
-        """everything RunBlast.run does after the tools returned (uberBlast.py:352-376)"""
-        if blastab:
-            blastab = np.vstack(blastab)
-            blastab = np.hstack([blastab, np.arange(blastab.shape[0], dtype=int)[:, np.newaxis]])
-        else:
+    def _post(self, tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end):
+        """everything RunBlast.run does after the tools returned (uberBlast.py:352-376), on the numeric table; the object rows the
+        caller gets are made at the very end"""
+        T = HitTable.concat(tables)
+        if len(T) == 0:
             if return_overlap[0]:
                 return np.empty([0, 16], dtype=object), np.empty([0, 3], dtype=int)
             return np.empty([0, 16], dtype=object)
+        T.rid = np.arange(len(T), dtype=np.int64)
         if re_score:
-            blastab = self.reScore(ref, qry, blastab, re_score, self.min_id, self.table_id)
+            T = self._rescore_table(ref, qry, T, re_score, self.min_id, self.table_id)
         if filter[0]:
-            blastab = self.ovlFilter(blastab, filter)
+            T = mapfilters.ovl_filter_table(T, filter[1], filter[2])
         if linear_merge[0]:
-            blastab = self.linearMerge(blastab, linear_merge)
-        self.fixEnd(blastab, *fix_end)
+            T = mapfilters.linear_merge_table(T, linear_merge[1], linear_merge[2])
+        T.fix_end(*fix_end)
+        overlap = None
         if return_overlap[0]:
-            overlap = self.returnOverlap(blastab, return_overlap)
-            return pd.DataFrame(blastab).sort_values([0, 1, 11]).values, overlap
-        return pd.DataFrame(blastab).sort_values([0, 1, 11]).values
+            overlap = mapfilters.overlaps_table(T, return_overlap[1], return_overlap[2], sweep=get_context(self.device).overlaps)
+        rows = T.take(T.final_order()).to_rows(cigar='str')
+        return (rows, overlap) if return_overlap[0] else rows
 
     MAX_BATCH_NT = 120000000        # nucleotides per search: 6 frames -> 2 packed protein bytes per nt, under the 2^29 limit
 
@@ -313,16 +310,25 @@ class RunBlast(object):
         try:
             for method in methods:
                 if method.lower() in tools:
-                    tables.append(tools[method.lower()](None, None))
+                    tables.append(_as_table(tools[method.lower()](None, None)))
+        except N.PepError as e:
+            if 'PEP_ERR_LIMIT' in str(e) or '(-3)' in str(e):
+                raise
+            import traceback
+            traceback.print_exc()
         except Exception:
             import traceback
             traceback.print_exc()
-            tables = [b for b in tables if hasattr(b, 'shape')]
+        # rows of every tool's table by genome (the reference set of row's reference sequence), table order kept inside a genome
+        split = []
+        for T in tables:
+            owner = np.array([genome_of[r] for r in T.r_tab], dtype=np.int64)[T.ri] if len(T) else np.zeros(0, np.int64)
+            order = np.argsort(owner, kind='stable')
+            cuts = np.searchsorted(owner[order], np.arange(len(refs) + 1))
+            split.append((T, order, cuts))
         out = []
-        owners = [np.array([genome_of[r] for r in b.T[1]], dtype=np.int64) if b.shape[0] else np.zeros(0, np.int64) for b in tables]
         for g in range(len(refs)):
-            part = [b[o == g] for b, o in zip(tables, owners)]
-            part = [b for b in part if b.shape[0] > 0]
+            part = [T.take(order[cuts[g]:cuts[g + 1]]) for T, order, cuts in split]
             out.append(self._post(part, None, None, re_score, filter, linear_merge, return_overlap, fix_end))
         return out
 
@@ -335,12 +341,15 @@ class RunBlast(object):
         if not self.refSeq:
             self.refSeq, self.refQual = _read_cached(ref), None
 
-    def _ensure_nt(self, ctx, frames):
-        """sorted(name) order is the order in which the reference writes its FASTA files (uberBlast.py:527, 537),
-        so sequence / target indices follow it and the 5-way split membership is reproduced"""
-        key = (id(ctx), frames, self.table_id)
-        if self._nt_loaded == key:
+    def _ensure_nt(self, ctx, frames=None):
+        """this instance's nucleotide sets on the device (K1 and K7 read them there).  sorted(name) order is the order in which the
+        reference writes its FASTA files (uberBlast.py:527, 537), so sequence / target indices follow it and the 5-way split
+        membership is reproduced.  The context is shared by every RunBlast of the process: what this instance uploaded is only
+        still there while the context's upload generation is the one it left behind (frames None = any frame count will do)."""
+        gen = getattr(ctx, 'upload_generation', 0)
+        if self._nt_loaded is not None and self._nt_loaded[2] == gen and self._nt_loaded[1] == self.table_id and frames in (None, self._nt_loaded[0]):
             return
+        frames = frames or 6
         self.q_names = sorted(self.qrySeq)
         self.r_names = sorted(self.refSeq) if self._batch is None else list(self._batch[0])
         self.q_index = {n: i for i, n in enumerate(self.q_names)}
@@ -348,7 +357,7 @@ class RunBlast(object):
         ctx.set_query_nt([self._text(self.qrySeq[n]) for n in self.q_names], self.table_id)
         ctx.set_ref_nt([self._text(self.refSeq[n]) for n in self.r_names], frames, self.table_id)
         ctx.set_target_groups(None if self._batch is None else self._batch[1])
-        self._nt_loaded = key
+        self._nt_loaded = (frames, self.table_id, getattr(ctx, 'upload_generation', 0))
 
     @staticmethod
     def _text(s):
@@ -370,11 +379,11 @@ class RunBlast(object):
         hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
         q_len = [len(self.qrySeq[n]) for n in self.q_names]
         r_len = [len(self.refSeq[n]) for n in self.r_names]
-        blastab = hits_to_blastab(hits, cigar, ctx.query_meta(), ctx.target_meta(), self.q_names, self.r_names, q_len, r_len,
-                                  self.min_id, self.min_cov, self.min_ratio)
+        table = hits_to_table(hits, cigar, ctx.query_meta(), ctx.target_meta(), self.q_names, self.r_names, q_len, r_len,
+                              self.min_id, self.min_cov, self.min_ratio)
         self.last_stats = stats
-        logger('Run diamond finishes. Got {0} alignments'.format(blastab.shape[0]))
-        return blastab
+        logger('Run diamond finishes. Got {0} alignments'.format(len(table)))
+        return table
 
     def runBlast(self, ref, qry):
         """nucleotide search on the same GPU engine, configured like the reference's blastn call (uberBlast.py:294):
@@ -387,59 +396,105 @@ class RunBlast(object):
         q_names = sorted(self.qrySeq)
         r_names = sorted(self.refSeq) if self._batch is None else list(self._batch[0])
         groups = [0] * len(r_names) if self._batch is None else list(self._batch[1])
-        q_codes = [_NT_CODE[np.frombuffer(self._text(self.qrySeq[n]).encode('ascii'), dtype=np.uint8)] for n in q_names]
-        r_codes = [_NT_CODE[np.frombuffer(self._text(self.refSeq[n]).encode('ascii'), dtype=np.uint8)] for n in r_names]
-        # targets: per reference set all forward strands, then all reverse strands
-        t_seq, t_rev, t_grp = [], [], []
+        q_codes, q_off = _encode_nt([self._text(self.qrySeq[n]) for n in q_names])
+        r_codes, r_off = _encode_nt([self._text(self.refSeq[n]) for n in r_names])
+        q_len, r_len = np.diff(q_off.astype(np.int64)), np.diff(r_off.astype(np.int64))
+        # targets: per reference set all forward strands, then all reverse strands.  The reverse complement of the WHOLE concatenation
+        # holds every sequence's reverse complement (in reverse sequence order): sequence i sits at [total - off[i+1], total - off[i])
+        total = int(r_off[-1])
+        r_rc = _NT_RC[r_codes[::-1]]
+        t_seq, t_rev, t_grp, parts = [], [], [], []
+        g_arr = np.asarray(groups, dtype=np.int64)
+        ro = r_off.astype(np.int64).tolist()
+        # a strand longer than the engine's sequence limit (PEP_MAX_SEQ_LEN, 8.39 Mbp: Streptomyces, any eukaryote) is searched as
+        # overlapping windows: window w owns the "home" stretch [w * HOME, (w + 1) * HOME) and carries a halo of one query length + band
+        # width on both sides, so every alignment whose midpoint lies in the home stretch has its whole 128-diagonal band inside the
+        # window; window starts are multiples of 64, which keeps the diagonal bins - and therefore the alignments - those of the
+        # unsplit search.  Hits are kept by the window whose home stretch holds their midpoint (blast_hits_to_table).
+        HOME = _TILE_HOME
+        halo = ((int(q_len.max()) if len(q_len) else 0) + 256 + 63) // 64 * 64
+        tiled = bool(len(r_len)) and int(r_len.max()) > N.MAX_SEQ_LEN
+        if tiled and HOME + 2 * halo > N.MAX_SEQ_LEN:
+            raise N.PepError('runBlast: queries of %d nt are too long to tile a %d nt reference sequence (PEP_ERR_LIMIT)' % (int(q_len.max()), int(r_len.max())))
+        t_woff, t_hlo, t_hhi = [], [], []
         for g in sorted(set(groups)):
-            members = [i for i, x in enumerate(groups) if x == g]
-            t_seq += members + members
-            t_rev += [False] * len(members) + [True] * len(members)
-            t_grp += [g] * (2 * len(members))
-        ctx.set_query_aa(q_codes)
-        ctx.set_ref_aa([_NT_RC[r_codes[i][::-1]] if rv else r_codes[i] for i, rv in zip(t_seq, t_rev)])
+            members = np.flatnonzero(g_arr == g).tolist()
+            if not tiled:
+                # the members of a set are consecutive sequences: their forward strands are one slice of the concatenation
+                parts.append(r_codes[ro[members[0]]:ro[members[-1] + 1]])
+                parts += [r_rc[total - ro[i + 1]:total - ro[i]] for i in members]
+                t_seq += members + members
+                t_rev += [False] * len(members) + [True] * len(members)
+                t_grp += [g] * (2 * len(members))
+                continue
+            for rev in (False, True):
+                for i in members:
+                    L = ro[i + 1] - ro[i]
+                    strand = r_rc[total - ro[i + 1]:total - ro[i]] if rev else r_codes[ro[i]:ro[i + 1]]
+                    if L <= N.MAX_SEQ_LEN:
+                        wins = [(0, L, 0, 1 << 62)]
+                    else:
+                        wins = [(max(0, h - halo), min(L, h + HOME + halo), h, (h + HOME) if h + HOME < L else (1 << 62)) for h in range(0, L, HOME)]
+                    for lo, hi, hlo, hhi in wins:
+                        parts.append(strand[lo:hi])
+                        t_seq.append(i); t_rev.append(rev); t_grp.append(g)
+                        t_woff.append(lo); t_hlo.append(hlo); t_hhi.append(hhi)
+        if tiled:
+            t_len = np.fromiter(map(len, parts), dtype=np.int64, count=len(parts))
+        else:
+            t_len = r_len[np.asarray(t_seq, dtype=np.int64)] if t_seq else np.zeros(0, np.int64)
+        t_off = np.zeros(len(t_len) + 1, dtype=np.uint64)
+        t_off[1:] = np.cumsum(t_len)
+        ctx.set_query_aa((q_codes, q_off))
+        ctx.set_ref_aa((np.concatenate(parts) if parts else np.zeros(0, np.uint8), t_off))
         ctx.set_target_groups(None if self._batch is None else t_grp)
         self._nt_loaded = None                      # the packed protein sets of a previous translated search are gone
         params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100.)
         hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
-        blastab = blast_hits_to_blastab(hits, cigar, q_names, r_names, [len(c) for c in q_codes], [len(c) for c in r_codes],
-                                        self.min_id, self.min_cov, self.min_ratio, params, np.array(t_seq, dtype=np.int64), np.array(t_rev, dtype=bool))
-        logger('Run BLASTn finishes. Got {0} alignments'.format(blastab.shape[0]))
-        return blastab
+        table = blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len,
+                                    self.min_id, self.min_cov, self.min_ratio, params, np.array(t_seq, dtype=np.int64), np.array(t_rev, dtype=bool),
+                                    windows=(np.array(t_woff, dtype=np.int64), np.array(t_hlo, dtype=np.int64), np.array(t_hhi, dtype=np.int64)) if tiled else None)
+        logger('Run BLASTn finishes. Got {0} alignments'.format(len(table)))
+        return table
 
     # ---------------------------------------------------------------------------------------------- post-processing
     def reScore(self, ref, qry, blastab, mode, min_id, table_id=11, perBatch=10000):
-        """recompute identity / score of every hit from its CIGAR over the nucleotide sequences (uberBlast.py:397-415).
-        Mode 1: integer counts on the GPU (K7), float arithmetic and np.round in float64 here."""
-        self._load(ref, qry)
+        """recompute identity / score of every hit from its CIGAR over the nucleotide sequences (uberBlast.py:397-415); object rows in
+        and out (the numeric chain inside run() calls _rescore_table directly)"""
         if blastab.shape[0] == 0:
             return blastab
+        return self._rescore_table(ref, qry, HitTable.from_rows(blastab), mode, min_id, table_id).to_rows()
+
+    def _rescore_table(self, ref, qry, T, mode, min_id, table_id=11):
+        """Mode 1: integer counts on the GPU (K7), float arithmetic and np.round in float64 here.  Modes 2 / 3 (amino-acid / codon-position
+        scoring, not used by PEPPAN's calls) walk the rows on the host."""
+        self._load(ref, qry)
+        if len(T) == 0:
+            return T
         if mode == 1:
             ctx = get_context(self.device)
-            if self._nt_loaded is None:
-                self._ensure_nt(ctx, 6)
-            arena, offs, counts = _encode_cigars(blastab.T[14])
-            h = np.zeros(blastab.shape[0], dtype=N.NT_HIT_DTYPE)
-            h['q'] = [self.q_index[str(x)] for x in blastab.T[0]]
-            h['r'] = [self.r_index[str(x)] for x in blastab.T[1]]
-            h['qs'], h['qe'], h['rs'], h['re'] = blastab.T[6].astype(np.int64), blastab.T[7].astype(np.int64), blastab.T[8].astype(np.int64), blastab.T[9].astype(np.int64)
-            h['cigar_runs'], h['cigar_off'] = counts, offs
-            c = ctx.rescore_nt(h, arena).astype(np.int64)
+            self._ensure_nt(ctx)
+            h = np.zeros(len(T), dtype=N.NT_HIT_DTYPE)
+            h['q'] = np.array([self.q_index[str(x)] for x in T.q_tab], dtype=np.int64)[T.qi]
+            h['r'] = np.array([self.r_index[str(x)] for x in T.r_tab], dtype=np.int64)[T.ri]
+            h['qs'], h['qe'], h['rs'], h['re'] = T.qs, T.qe, T.ss, T.se
+            h['cigar_runs'], h['cigar_off'] = T.c_runs, T.c_off
+            c = ctx.rescore_nt(h, T.arena).astype(np.int64)
             n_match, n_mis, n_gap, b_gap, m_gap = c.T
             iden = n_match.astype(np.float64) / (n_match + n_mis + b_gap - m_gap)
             score = (n_match * 3 - n_mis - n_gap * (6 - 1) - b_gap * 1).astype(np.float64)
-            scores = np.vstack([iden, score])
         else:
-            q_enc = {k: nucEncoder[np.array(list(v)).view(asc2int)] for k, v in self.qrySeq.items()}
-            r_enc = {k: nucEncoder[np.array(list(v)).view(asc2int)] for k, v in self.refSeq.items()}
+            q_enc = {str(k): nucEncoder[np.array(list(v)).view(asc2int)] for k, v in self.qrySeq.items()}
+            r_enc = {str(k): nucEncoder[np.array(list(v)).view(asc2int)] for k, v in self.refSeq.items()}
             vals = []
-            for t in blastab:
+            for t in T.to_rows():
                 r = r_enc[str(t[1])]
                 r_sl = r[t[8] - 1:t[9]] if t[8] < t[9] else 4 - r[t[9] - 1:t[8]][::-1]
                 vals.append(cigar2score([t[14], r_sl, q_enc[str(t[0])][t[6] - 1:t[7]], t[6], mode, 6, 1, table_id]))
-            scores = np.array(vals).T
-        blastab.T[2], blastab.T[11] = np.round(scores, 3)
-        return blastab[blastab.T[2] >= min_id]
+            iden, score = np.array(vals, dtype=np.float64).T
+        T.iden, T.score = np.round(iden, 3), np.round(score, 3)
+        T.score_is_int = False
+        return T.take(T.iden >= min_id)
 
     def ovlFilter(self, blastab, params):
         return mapfilters.ovl_filter(blastab, params[1], params[2])
@@ -453,22 +508,19 @@ class RunBlast(object):
 
     def fixEnd(self, blastab, se, ee):
         """extend alignments over short unaligned ends (<= se at the query head, <= ee at its tail) and turn the CIGAR
-        into its string form; identity and score stay as they are (uberBlast.py:462-480)"""
-        for p in blastab:
-            head, tail = p[6] - 1, p[12] - p[7]
-            cigar = p[14]
-            fwd = p[9] > p[8]
-            if 0 < head <= se:
-                d = min(head, p[8] - 1) if fwd else min(head, p[13] - p[8])
-                p[6] -= d
-                p[8] += -d if fwd else d
-                cigar[0][0] += d
-            if 0 < tail <= ee:
-                d = min(tail, p[13] - p[9]) if fwd else min(tail, p[9] - 1)
-                p[7] += d
-                p[9] += d if fwd else -d
-                cigar[-1][0] += d
-            p[14] = ''.join([str(n) + t for n, t in cigar])
+        into its string form, in place; identity and score stay as they are (uberBlast.py:462-480)"""
+        if blastab.shape[0] == 0:
+            return
+        T = HitTable.from_rows(blastab)
+        T.fix_end(se, ee)
+        for col, vals in ((6, T.qs), (7, T.qe), (8, T.ss), (9, T.se)):
+            blastab[:, col] = vals.tolist()
+        blastab[:, 14] = T.cigar_strings()
+
+
+def _as_table(x):
+    """a tool's product as a HitTable: the GPU tools return one, a plug-in following the reference's contract returns object rows"""
+    return x if isinstance(x, HitTable) else HitTable.from_rows(x)
 
 
 # one flag table for both command-line front ends: (flags, keyword arguments of add_argument).  Names, defaults and meaning

@@ -16,12 +16,19 @@ class OracleContext(object):
         self.r_nt = [s.decode() if isinstance(s, bytes) else s for s in seqs]
         self.r_frames, self.r_table = frames, gtable
 
+    @staticmethod
+    def _unpack(seqs):
+        if isinstance(seqs, tuple) and len(seqs) == 2:                       # (codes, offsets), as Context._pack passes through
+            codes, off = np.asarray(seqs[0], dtype=np.uint8), np.asarray(seqs[1], dtype=np.int64)
+            return [codes[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+        return [np.asarray(s, dtype=np.uint8) for s in seqs]
+
     def set_query_aa(self, seqs):
-        self.q_aa = [np.asarray(s, dtype=np.uint8) for s in seqs]
+        self.q_aa = self._unpack(seqs)
         self._direct = True
 
     def set_ref_aa(self, seqs):
-        self.t_aa = [np.asarray(s, dtype=np.uint8) for s in seqs]
+        self.t_aa = self._unpack(seqs)
         self._direct = True
 
     def alleles(self, contigs, rows, cigar, grp_off, grp_qlen, gtable=11):
