@@ -283,8 +283,9 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
                 uint32_t s0, s1;
                 diag_issue(add3(tab, (uint32_t)qv0, (uint32_t)tv0), add3(tab, (uint32_t)qv1, (uint32_t)tv1), s0, s1);
                 tn0 = vt0[u + 1]; tn1 = vt1[u + 1];
-                const s16x2 hl = pk_shr1z(HB), el = pk_shr1z(EB);
-                const s16x2 E = pk_max(el - ext2, hl), F = pk_max(FB - ext2, HB);
+                // E of this cell = max(E_left - ext, H_left) with both operands in lane l-1: the maximum is taken THERE and one DPP move
+                // brings it over (moving H_left and E_left separately costs a second 4-cycle move per step); band-edge lanes read 0 either way
+                const s16x2 E = pk_shr1z(pk_max(EB - ext2, HB)), F = pk_max(FB - ext2, HB);
                 const s16x2 m = pk_max(E, F) - oe2;
                 const s16x2 h = __builtin_bit_cast(s16x2, diag_finish(__builtin_bit_cast(uint32_t, HA), s0, s1));
                 const s16x2 H = pk_max(pk_max(h, m), zero);
@@ -296,8 +297,7 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
                 uint32_t s0, s1;
                 diag_issue(add3(tab, (uint32_t)qv0, (uint32_t)tn0), add3(tab, (uint32_t)qv1, (uint32_t)tn1), s0, s1);
                 qn0 = vq0[u + 1]; qn1 = vq1[u + 1];
-                const s16x2 hu = pk_shl1z(HA), fu = pk_shl1z(FA);
-                const s16x2 E = pk_max(EA - ext2, HA), F = pk_max(fu - ext2, hu);
+                const s16x2 E = pk_max(EA - ext2, HA), F = pk_shl1z(pk_max(FA - ext2, HA));
                 const s16x2 m = pk_max(E, F) - oe2;
                 const s16x2 h = __builtin_bit_cast(s16x2, diag_finish(__builtin_bit_cast(uint32_t, HB), s0, s1));
                 const s16x2 H = pk_max(pk_max(h, m), zero);

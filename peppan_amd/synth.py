@@ -119,3 +119,21 @@ def make_genomes(gene_seqs, n_genomes, seed=355, family=4):
         parts.append(_B[rng.integers(0, 4, 100)])
         out.append(('g%04d' % g, np.concatenate(parts).tobytes(), ann))
     return out
+
+
+def make_instances(n_base, copies, seed=8):
+    """gene instances of a pan-genome for the front end (writeGenes / iterClust): n_base genes (log-normal lengths), `copies` alleles each -
+    60 % identical to the gene, the rest one of four variants with one to three substitutions.  Returns a list of n_base * copies strings."""
+    rng = np.random.default_rng(seed)
+    names, seqs = make_genes(n_base, 0, seed=seed)
+    out = []
+    for s in seqs:
+        a = np.frombuffer(s, dtype=np.uint8)
+        variants = [s.decode()]
+        for _ in range(4):
+            v = a.copy()
+            pos = rng.integers(3, len(v) - 3, int(rng.integers(1, 4)))
+            v[pos] = _B[rng.integers(0, 4, len(pos))]
+            variants.append(v.tobytes().decode())
+        out += [variants[k] for k in rng.choice(5, size=copies, p=[0.6, 0.1, 0.1, 0.1, 0.1]).tolist()]
+    return out

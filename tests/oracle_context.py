@@ -79,9 +79,14 @@ class OracleContext(object):
 
     def rescore_nt(self, h, arena):
         out = np.zeros((len(h), 5), dtype=np.int64)
+        enc_q, enc_r = {}, {}                          # a genome-sized reference is encoded once, not once per hit
         for k in range(len(h)):
-            q, r = O.nt_encode_rescore(self.q_nt[h['q'][k]].upper()), O.nt_encode_rescore(self.r_nt[h['r'][k]].upper())
-            out[k] = O.rescore_counts(q, r, int(h['qs'][k]), int(h['rs'][k]), int(h['re'][k]),
+            qi, ri = int(h['q'][k]), int(h['r'][k])
+            if qi not in enc_q:
+                enc_q[qi] = O.nt_encode_rescore(self.q_nt[qi].upper())
+            if ri not in enc_r:
+                enc_r[ri] = O.nt_encode_rescore(self.r_nt[ri].upper())
+            out[k] = O.rescore_counts(enc_q[qi], enc_r[ri], int(h['qs'][k]), int(h['rs'][k]), int(h['re'][k]),
                                       arena[int(h['cigar_off'][k]):int(h['cigar_off'][k]) + int(h['cigar_runs'][k])])
         return out
 

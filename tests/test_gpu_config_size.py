@@ -1,0 +1,155 @@
+"""Config-size runs on the MI355X: the stages of BASELINE.json's configs that round 1 only touched at toy sizes.
+  (a) configs[2]/[3] mapping stage: 10 000 exemplar genes x 64 synthetic genomes through get_map_bsn (PEPPAN.py:907-989), batched GPU search;
+      properties on all genomes, whole-table equality with the oracle-driven host code on a sample of them
+  (b) configs[2] front end: writeGenes + iterClust (PEPPAN.py:1023-1039, 1777-1792) on 1 M gene instances, time and memory asserted
+      (tools/front_end_scale.py runs the same at 5 M)
+  (c) configs[4] search stage: 50 000 x 50 000 genes all-vs-all, bit-exact against the OpenMP oracle
+"""
+import contextlib
+import io
+import os
+import resource
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    from peppan_amd import _native as N
+    with N.Context(0) as c:
+        yield c
+
+
+def _cmp_tables(a, b):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert a.tolist() == b.tolist()
+
+
+def test_map_bsn_10k_exemplars_x_64_genomes(tmp_path, monkeypatch):
+    from peppan_amd import mapbsn, synth, uberBlast as UB
+    from oracle_context import OracleContext
+    monkeypatch.chdir(tmp_path)
+    n_genomes, sample = 64, (3, 40)
+    names, seqs = synth.make_genes(10000, 0, seed=355)
+    with open('m.clust.exemplar', 'w') as f:
+        for i, s in enumerate(seqs):
+            f.write('>%d\n%s\n' % (i, s.decode()))
+    worlds = synth.make_genomes(seqs, n_genomes, seed=355)
+    genomes = {}
+    with mapbsn.MapBsn('m.old_prediction.npz', 'w') as op:
+        for g, (gname, contig, ann) in enumerate(worlds):
+            genomes[100000 + g] = [900000 + g, contig.decode()]
+            op.save(100000 + g, np.array([[k, s, e, st, 1] for k, s, e, st in ann[::2]], dtype=object))
+    np.save('m.self_bsn.npy', np.array([[0, 1, 9000], [4, 5, -2]], dtype=int))
+    params = dict(noDiamond=False, match_identity=0.65, match_frag_len=50, match_frag_prop=0.25, link_gap=600, link_diff=1.5, gtable=11,
+                  match_len=250., match_len1=100., match_len2=400., match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+    seen = {}
+
+    def search(prefix, clust, jobs, p):                      # the product's batched search, with the per-genome tables recorded for the sample
+        for job, res in zip(jobs, mapbsn._gpu_search(prefix, clust, jobs, p, genomes_per_batch=32)):
+            if job[0] in sample:
+                seen[job[0]] = (res[0].copy(), res[1].copy())
+            yield res
+    fn = ['s.%s.npz' % x for x in ('tab', 'seq', 'mat', 'conflicts')]
+    t0 = time.perf_counter()
+    with contextlib.redirect_stderr(io.StringIO()):
+        with mapbsn.MapBsn(fn[0], 'w') as c0, mapbsn.MapBsn(fn[1], 'w') as c1, mapbsn.MapBsn(fn[2], 'w') as c2, mapbsn.MapBsn(fn[3], 'w') as c3:
+            mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params, search=search)
+    dt = time.perf_counter() - t0
+    print('get_map_bsn: %d genomes in %.1f s = %.1f genomes/s' % (n_genomes, dt, n_genomes / dt))
+    assert n_genomes / dt > 3.0
+    with mapbsn.MapBsn(fn[0]) as c:
+        tab = np.vstack([c.get(k) for k in c.keys()])
+    with mapbsn.MapBsn(fn[2]) as c:
+        n_mat = sum(len(c.get(k)) for k in c.keys())
+    # one row per group, group ids dense, one hit-row block per group
+    assert tab.shape[0] == n_mat and sorted(tab.T[5].tolist()) == list(range(tab.shape[0]))
+    # every planted allele (<= 2 % substitutions, full length) is found in its genome with identity >= 0.95
+    found = {(int(r[0]), int(r[1])) for r in tab if r[3] >= 9500}
+    planted = 0
+    for g, (gname, contig, ann) in enumerate(worlds):
+        for k, s, e, strand in ann:
+            planted += 1
+            assert (k, 900000 + g) in found, (g, k)
+    assert planted > 64 * 1500
+    # the sampled genomes: whole tables equal to the same host code over the CPU oracle (one uberBlast call per genome)
+    octx = OracleContext()
+    monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
+    jobs = {i: [[g, s[1]]] for i, (g, s) in enumerate(genomes.items())}           # get_map_bsn's job ids: one taxon per genome, in this order
+    for id in sample:
+        gfile = mapbsn._write_genome('o', id, jobs[id])
+        with contextlib.redirect_stderr(io.StringIO()):
+            o_tab, o_ovl = UB.uberBlast(['-r', gfile] + mapbsn._map_argv('m.clust.exemplar', params))
+        _cmp_tables(seen[id][0], o_tab)
+        assert seen[id][1].tolist() == o_ovl.tolist()
+        assert o_tab.shape[0] > 5000
+
+
+def test_front_end_one_million_gene_instances(ctx, tmp_path, monkeypatch):
+    """writeGenes (K13 sha1 + duplicate collapse) and the 11-level iterClust (K9) on 1 M instances of 4 000 genes"""
+    from peppan_amd import pipeline as PL
+    monkeypatch.chdir(tmp_path)
+    t0 = time.perf_counter()
+    from peppan_amd import synth
+    seqs = synth.make_instances(4000, 250, seed=8)
+    n = len(seqs)
+    assert n == 1000000
+    t1 = time.perf_counter()
+    hashes = PL.gene_hashes(seqs, ctx=ctx)
+    t2 = time.perf_counter()
+    import hashlib
+    for i in (0, 1, 777777, n - 1):
+        assert hashes[i] == int(hashlib.sha1(seqs[i].encode()).hexdigest(), 16)
+    genes = {i: ['f', '', 0, 0, '+', hashes[i], seqs[i]] for i in range(n)}
+    prio = {i: [i % 7, -len(seqs[i]), hashes[i]] for i in range(n)}
+    fn, groups = PL.writeGenes('big.genes', genes, prio, ctx=ctx)
+    t3 = time.perf_counter()
+    n_unique = sum(1 for line in open(fn) if line.startswith('>'))
+    assert n_unique + len(groups) == n and 4000 <= n_unique <= 5 * 4000 + 4000      # identical alleles of one length run collapse
+    with contextlib.redirect_stderr(io.StringIO()):
+        ex = PL.iterClust('big', fn, groups, dict(identity=0.9, coverage=0.8, n_thread=1, translate=False))
+    t4 = time.perf_counter()
+    n_ex = sum(1 for line in open(ex) if line.startswith('>'))
+    clu = np.load('big.clust.npy')
+    assert 3000 <= n_ex <= 4400                               # the alleles of a gene end up under one exemplar (families stay apart at 0.9)
+    assert clu.shape[0] >= n - n_ex - 12 * 11                 # (every level loses the first line of its table, PEPPAN.py:1786)
+    rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
+    print('1 M instances: generate %.1f s, sha1 %.1f s, writeGenes %.1f s, iterClust %.1f s; %d unique, %d exemplars; peak RSS %.1f GB'
+          % (t1 - t0, t2 - t1, t3 - t2, t4 - t3, n_unique, n_ex, rss))
+    assert (t2 - t1) + (t3 - t2) + (t4 - t3) < 240 and rss < 24
+
+
+def test_all_vs_all_50k_bit_exact_vs_oracle(ctx):
+    """BASELINE configs[4] search stage: 50 000 genes x 1 002 nt all-vs-all on one GPU; every field of every hit and the CIGAR arena equal the
+    CPU oracle's (OpenMP, all host cores: about a minute and a half)"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    names, seqs = synth.make_genes(50000, 1002, seed=355)
+    order = sorted(range(len(names)), key=lambda i: names[i])
+    nts = [seqs[i] for i in order]
+    ctx.set_query_nt(nts, 11)
+    ctx.set_ref_nt(nts, 6, 11)
+    p = N.default_params(45., 25., 10, 5)
+    ctx.search(p)
+    t0 = time.perf_counter()
+    gh, gc, st = ctx.search(p)
+    t_gpu = time.perf_counter() - t0
+    qa, qo = ctx.query_aa()
+    ta, to = ctx.target_aa()
+    q_aa = [qa[qo[i]:qo[i + 1]] for i in range(len(qo) - 1)]
+    t_aa = [ta[to[i]:to[i + 1]] for i in range(len(to) - 1)]
+    O.lib().oracle_set_threads(0)
+    t0 = time.perf_counter()
+    oh, oc, ost = O.search(q_aa, t_aa, O.default_params(45., 25., 10, 5))
+    t_cpu = time.perf_counter() - t0
+    print('50k x 50k: GPU search %.1f ms, oracle %.1f s, %d candidates, %d hits' % (t_gpu * 1e3, t_cpu, st['candidates'], len(gh)))
+    assert len(gh) == len(oh) > 150000
+    for f in ('q', 't', 'q_start', 'q_end', 't_start', 't_end', 'score', 'nm', 'n_ident', 'aln_len', 'cigar_runs', 'bin', 'cells'):
+        assert np.array_equal(gh[f], oh[f]), f
+    assert np.array_equal(gc, oc)
+    for k in ('candidates', 'pairs', 'cells', 'tracebacks'):
+        assert st[k] == ost[k], k
