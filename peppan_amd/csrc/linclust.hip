@@ -52,9 +52,40 @@ __global__ __launch_bounds__(256) void lc_select(const uint8_t *__restrict__ res
     uint64_t last_h = 0;
     uint32_t last_p = 0, cnt = 0;
     bool first = true;
+    // power-of-two alphabets (nucleotides, the pipeline's default): every lane scans a CONTIGUOUS stretch of positions and rolls the
+    // k-mer value from one position to the next (one byte load, a shift and a multiply-add) instead of re-reading k bytes per position
+    // and round - 17 byte loads per position, twenty times over, was nearly all of this kernel's time
+    const bool pow2 = (base & (base - 1)) == 0;
+    int shift = 0;
+    while ((1 << shift) < base) ++shift;
+    uint64_t top = 1;                                            // base^(k-1): weight of the letter that enters the window
+    for (int i = 1; i < k; ++i) top *= (uint64_t)base;
+    const uint32_t npos = L >= (uint32_t)k ? L - (uint32_t)k + 1 : 0;
+    const uint32_t per = (npos + 63) / 64, p0 = (uint32_t)lane * per, p1 = min(npos, p0 + per);
     for (int r = 0; r < m; ++r) {
         uint64_t bh = ~0ull, bkey = 0;
         uint32_t bp = 0xFFFFFFFFu;
+        if (pow2) {
+            if (p0 < p1) {
+                uint64_t key = 0;
+                long long last_bad = -1;                          // last position holding a letter outside the alphabet
+                for (int i = 0; i < k; ++i) {
+                    const uint8_t c = q[p0 + i];
+                    if (c >= base) last_bad = (long long)p0 + i; else key |= (uint64_t)c << (shift * i);
+                }
+                for (uint32_t p = p0; p < p1; ++p) {
+                    if (last_bad < (long long)p) {
+                        const uint64_t h = lc_mix(key);
+                        if ((first || hp_less(last_h, last_p, h, p)) && hp_less(h, p, bh, bp)) { bh = h; bp = p; bkey = key; }
+                    }
+                    if (p + 1 < p1) {
+                        const uint8_t c = q[p + k];
+                        key >>= shift;
+                        if (c >= base) last_bad = (long long)p + k; else key += top * c;
+                    }
+                }
+            }
+        } else
         for (uint32_t p = lane; p + k <= L; p += 64) {
             uint64_t key;
             if (!kmer_at(q, p, base, k, key)) continue;

@@ -26,8 +26,11 @@ def _name_codes(names, idx):
 
 class HitTable(object):
     __slots__ = ('q_tab', 'r_tab', 'qi', 'ri', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'score_is_int',
-                 'ql', 'sl', 'arena', 'c_off', 'c_runs', 'rid', 'merge')
+                 'ql', 'sl', 'arena', 'c_off', 'c_runs', 'rid', 'merge', 'm_score', 'm_iden', 'm_span', 'm_start', 'm_len', 'm_ids')
     _ROW_COLS = ('qi', 'ri', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'ql', 'sl', 'c_off', 'c_runs', 'rid')
+    # column 16 after -m in numeric form: per row the group's score / identity / span (span < 0: the row has no group and shows the
+    # reference's shared empty list) and the slice [m_start, m_start + m_len) of m_ids that holds the group's row ids
+    _MERGE_COLS = ('m_score', 'm_iden', 'm_span', 'm_start', 'm_len')
 
     def __init__(self, q_tab, r_tab, qi, ri, iden, aln, mis, gap, qs, qe, ss, se, evalue, score, ql, sl, arena, c_off, c_runs,
                  rid=None, merge=None, score_is_int=True):
@@ -40,7 +43,8 @@ class HitTable(object):
         self.arena = np.ascontiguousarray(arena, dtype=np.uint32)
         self.c_off, self.c_runs = i64(c_off), i64(c_runs)
         self.rid = i64(rid) if rid is not None else np.full(len(self.qi), -1, dtype=np.int64)
-        self.merge = merge                      # column 16 after -m: one list per row (or None)
+        self.merge = merge                      # column 16 after -m as Python lists, one per row (made on demand from the m_* arrays)
+        self.m_score = self.m_iden = self.m_span = self.m_start = self.m_len = self.m_ids = None
         self.score_is_int = score_is_int
 
     def __len__(self):
@@ -78,9 +82,32 @@ class HitTable(object):
         t = cls(q_tab, r_tab, qi, ri, num(2, np.float64), num(3, np.int64), num(4, np.int64), num(5, np.int64), num(6, np.int64), num(7, np.int64),
                 num(8, np.int64), num(9, np.int64), num(10, np.float64), num(11, np.float64), num(12, np.int64), num(13, np.int64), arena, off, runs,
                 rid=num(15, np.int64) if rows.shape[1] > 15 else None,
-                merge=rows[:, 16].tolist() if rows.shape[1] > 16 else None,
                 score_is_int=all(isinstance(v, _INT_TYPES) for v in sc))
+        if rows.shape[1] > 16:
+            t.set_merge_lists(rows[:, 16].tolist())
         return t
+
+    def set_merge_lists(self, lists):
+        """column 16 given as [score, identity, span, row ids...] lists (an empty list = no group)"""
+        n = len(lists)
+        self.merge = lists
+        self.m_score = np.array([g[0] if len(g) else 0. for g in lists], dtype=np.float64)
+        self.m_iden = np.array([g[1] if len(g) else 0. for g in lists], dtype=np.float64)
+        self.m_span = np.array([g[2] if len(g) else -1 for g in lists], dtype=np.int64)
+        self.m_len = np.array([max(0, len(g) - 3) for g in lists], dtype=np.int64)
+        self.m_start = np.concatenate([[0], np.cumsum(self.m_len)[:-1]]).astype(np.int64) if n else np.zeros(0, np.int64)
+        self.m_ids = np.array([i for g in lists for i in g[3:]], dtype=np.int64)
+
+    def has_merge(self):
+        return self.m_span is not None
+
+    def merge_lists(self):
+        if self.merge is None and self.m_span is not None:
+            s_l, i_l, sp_l, ids = self.m_score.tolist(), self.m_iden.tolist(), self.m_span.tolist(), self.m_ids.tolist()
+            shared = []
+            self.merge = [[s_l[k], i_l[k], sp_l[k]] + ids[a:a + b] if sp_l[k] >= 0 else shared
+                          for k, (a, b) in enumerate(zip(self.m_start.tolist(), self.m_len.tolist()))]
+        return self.merge
 
     def take(self, idx):
         """rows idx (index array or boolean mask), in that order; name tables and the CIGAR arena are shared"""
@@ -92,6 +119,9 @@ class HitTable(object):
             setattr(t, f, getattr(self, f))
         for f in self._ROW_COLS:
             setattr(t, f, getattr(self, f)[idx])
+        if self.m_span is not None:
+            for f in self._MERGE_COLS:
+                setattr(t, f, getattr(self, f)[idx])
         if self.merge is not None:
             t.merge = [self.merge[i] for i in idx.tolist()]
         return t
@@ -198,7 +228,7 @@ class HitTable(object):
     def to_rows(self, cigar='list', with_rid=True):
         """ndarray(object)[n, 15 | 16 | 17]: Python scalars per cell, CIGAR as lists ('list') or as text ('str')"""
         n = len(self)
-        width = 15 + (1 if with_rid else 0) + (1 if (self.merge is not None and with_rid) else 0)
+        width = 15 + (1 if with_rid else 0) + (1 if (self.has_merge() and with_rid) else 0)
         out = np.empty([n, width], dtype=object)
         if n == 0:
             return out
@@ -216,8 +246,8 @@ class HitTable(object):
                 col[k] = v
         if with_rid:
             out[:, 15] = self.rid.tolist()
-            if self.merge is not None:
+            if self.has_merge():
                 col = out[:, 16]
-                for k, v in enumerate(self.merge):
+                for k, v in enumerate(self.merge_lists()):
                     col[k] = v
         return out

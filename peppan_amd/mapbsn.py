@@ -211,134 +211,201 @@ def _stable_order(tab, keys):
     return np.lexsort(cols)
 
 
+def _known_fraction(T, old_prediction):
+    """Column 10 of the mapping tables (PEPPAN.py:869-901): for every hit the largest fraction of an original gene of the same contig
+    that it covers in frame and on the same strand (0.1 when there is none), for all rows of the HitTable at once.  Returns
+    (order, known): `order` = the row order in which the reference walks the table, (contig, lower reference coordinate), stable;
+    `known[k]` belongs to row order[k].
+    An original gene p = [id, start, end, strand, ...] counts for a hit [s, e] when one of its two frame markers is one of the hit's
+    and the overlap is >= 0.6 of the gene or of the hit; the hit's markers come from where its query would start / end on the
+    reference.  The reference sweeps the contig's genes with a pointer that only moves forward past genes ending before the hit
+    and stops at the first gene starting behind it; with the genes in start order (as the store holds them) that is "every
+    overlapping gene", which is what the vectorised form evaluates - an unsorted gene list takes the row loop instead."""
+    n = len(T)
+    lo, hi = np.minimum(T.ss, T.se), np.maximum(T.ss, T.se)
+    order = np.lexsort((lo, T.r_codes()))
+    known = np.full(n, 0.1, dtype=np.float64)
+    if n == 0:
+        return order, known
+    ri = T.ri[order]
+    s, e = lo[order], hi[order]
+    fwd = (T.ss < T.se)[order]
+    head, tail = (T.ss - T.qs + 1)[order], (T.se + (T.ql - T.qe))[order]
+    f1 = np.where(fwd, head % 3 + 1, (-head) % 3 - 1)
+    f2 = np.where(fwd, (tail + 1) % 3 + 1, (-(tail - 1)) % 3 - 1)
+    bounds = np.concatenate([[0], np.flatnonzero(np.diff(ri)) + 1, [n]])
+    with MapBsn(old_prediction) as op:
+        for a, b in zip(bounds[:-1].tolist(), bounds[1:].tolist()):
+            genes = op.get(T.r_tab[ri[a]])
+            if len(genes) == 0:
+                continue
+            g1 = np.array([p[1] for p in genes], dtype=np.int64)
+            g2 = np.array([p[2] for p in genes], dtype=np.int64)
+            plus = np.array([p[3] == '+' for p in genes], dtype=bool)
+            if np.any(np.diff(g1) < 0):
+                known[a:b] = _known_fraction_rows(s[a:b], e[a:b], f1[a:b], f2[a:b], g1, g2, plus)
+                continue
+            # genes [first, last) can touch the hit: first = the first gene (in store order) that does not end before it
+            first = np.searchsorted(np.maximum.accumulate(g2), s[a:b], side='left')
+            last = np.maximum(np.searchsorted(g1, e[a:b], side='right'), first)
+            cnt = last - first
+            tot = int(cnt.sum())
+            if tot == 0:
+                continue
+            row = np.repeat(np.arange(a, b), cnt)
+            gi = np.repeat(first - np.concatenate([[0], np.cumsum(cnt)[:-1]]), cnt) + np.arange(tot)
+            p1, p2, pl = g1[gi], g2[gi], plus[gi]
+            m1 = np.where(pl, p1 % 3 + 1, (-(p1 - 1)) % 3 - 1)
+            m2 = np.where(pl, (p2 + 1) % 3 + 1, (-p2) % 3 - 1)
+            in_frame = (m1 == f1[row]) | (m1 == f2[row]) | (m2 == f1[row]) | (m2 == f2[row])
+            plen = p2 - p1 + 1
+            ovl = (np.minimum(e[row], p2) - np.maximum(s[row], p1) + 1).astype(np.float64)
+            ok = in_frame & ((ovl >= 0.6 * plen) | (ovl >= 0.6 * (e[row] - s[row] + 1)))
+            if ok.any():
+                np.maximum.at(known, row[ok], ovl[ok] / plen[ok])
+    return order, known
+
+
+def _known_fraction_rows(s, e, f1, f2, g1, g2, plus):
+    """the reference's pointer sweep, row by row (genes not in start order)"""
+    out = np.full(len(s), 0.1, dtype=np.float64)
+    at, ng = 0, len(g1)
+    for k in range(len(s)):
+        while at < ng and s[k] > g2[at]:
+            at += 1
+        for j in range(at, ng):
+            if e[k] < g1[j]:
+                break
+            if plus[j]:
+                m1, m2 = g1[j] % 3 + 1, (g2[j] + 1) % 3 + 1
+            else:
+                m1, m2 = (-(g1[j] - 1)) % 3 - 1, (-g2[j]) % 3 - 1
+            if m1 not in (f1[k], f2[k]) and m2 not in (f1[k], f2[k]):
+                continue
+            plen = g2[j] - g1[j] + 1
+            ovl = min(e[k], g2[j]) - max(s[k], g1[j]) + 1.
+            if ovl >= 0.6 * plen or ovl >= 0.6 * (e[k] - s[k] + 1):
+                out[k] = max(out[k], ovl / plen)
+    return out
+
+
+def _with_known(T, old_prediction):
+    """the table in the order compare_prediction returns it - (query, contig, score), stable on top of the (contig, position) walk -
+    with column 10 replaced"""
+    order, known = _known_fraction(T, old_prediction)
+    T = T.take(order)
+    T.evalue = known
+    return T.take(np.lexsort((T.score, T.r_codes(), T.q_codes())))
+
+
 def compare_prediction(blastab, old_prediction):
     """column 10 <- the largest fraction of an in-frame, same-strand original gene that a hit covers (0.1 if none);
-    returns the table sorted by (query, contig, score).  PEPPAN.py:869-901."""
-    lo = np.minimum(blastab[:, 8].astype(np.int64), blastab[:, 9].astype(np.int64))
-    blastab = blastab[_stable_order(blastab, [1, lo])]
-    blastab[:, 10] = 0.1
-    with MapBsn(old_prediction) as op:
-        contig, genes, at = None, [], 0
-        for bsn in blastab:
-            if contig != bsn[1]:
-                contig, genes, at = bsn[1], op.get(bsn[1]), 0
-            head, tail = bsn[8] - bsn[6] + 1, bsn[9] + (bsn[12] - bsn[7])
-            if bsn[8] < bsn[9]:
-                s, e = bsn[8], bsn[9]
-                frames = {head % 3 + 1, (tail + 1) % 3 + 1}
-            else:
-                s, e = bsn[9], bsn[8]
-                frames = {(-head) % 3 - 1, (-(tail - 1)) % 3 - 1}
-            while at < len(genes) and s > genes[at][2]:
-                at += 1
-            for p in genes[at:]:
-                if e < p[1]:
-                    break
-                if p[3] == '+':
-                    if p[1] % 3 + 1 not in frames and (p[2] + 1) % 3 + 1 not in frames:
-                        continue
-                elif (-(p[1] - 1)) % 3 - 1 not in frames and (-p[2]) % 3 - 1 not in frames:
-                    continue
-                plen = p[2] - p[1] + 1
-                ovl = min(e, p[2]) - max(s, p[1]) + 1.
-                if ovl >= 0.6 * plen or ovl >= 0.6 * (e - s + 1):
-                    ovl = ovl / plen
-                    if ovl > bsn[10]:
-                        bsn[10] = ovl
-    return blastab[_stable_order(blastab, [0, 1, 11])]
+    returns the table sorted by (query, contig, score).  PEPPAN.py:869-901.  Object rows in and out."""
+    from .hittable import HitTable
+    if blastab.shape[0] == 0:
+        return blastab
+    return _with_known(HitTable.from_rows(blastab), old_prediction).to_rows(cigar='str')
 
 
 # ------------------------------------------------------------------------------------------------ one genome
-def _passes(length, ql, params):
-    return (length >= max(params['match_prop'] * ql, params['match_len']) or
-            length >= max(params['match_prop1'] * ql, params['match_len1']) or
-            length >= max(params['match_prop2'] * ql, params['match_len2']))
-
-
-def _encode_cigar_strings(cigars):
-    """['60M3D90M', ...] -> (uint32 runs len<<2|op with op 0=M 1=I 2=D, runs per string) with two regex passes over one joined string"""
-    joined = '|'.join(cigars) + '|'
-    lens = np.array(re.findall(r'\d+', joined), dtype=np.int64)
-    ops = np.frombuffer(re.sub(r'\d+', '', joined).encode('ascii'), dtype=np.uint8)
-    sep = ops == ord('|')
-    code = np.full(256, 3, dtype=np.uint32)
-    code[[ord('M'), ord('I'), ord('D')]] = (0, 1, 2)
-    runs = (lens.astype(np.uint32) << 2) | code[ops[~sep]]
-    per = np.diff(np.concatenate([[-1], np.nonzero(sep)[0]])) - 1
-    return runs, per
+def _passes_all(length, ql, params):
+    return ((length >= np.maximum(params['match_prop'] * ql, params['match_len'])) |
+            (length >= np.maximum(params['match_prop1'] * ql, params['match_len1'])) |
+            (length >= np.maximum(params['match_prop2'] * ql, params['match_len2'])))
 
 
 def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=None):
     """(17-column table with merge groups, int[m,3] overlaps) of ONE genome -> (bsn object[n,7], ovl int[k,3]).
     bsn row = [gene, contig, score, identity, packed allele, group id, rows(object[k,16])].  PEPPAN.py:773-866.
-    The per-hit allele strings, their in-frame / stop-free lengths and the packing run on the GPU (K12, `ctx.alleles`)."""
-    if blastab.shape[0] == 0:
+    `blastab` is the HitTable the search chain ends with (the product path: no Python row is touched before the rows that are
+    stored get made) or the same thing as object rows.  The per-hit allele strings, their in-frame / stop-free lengths and the
+    packing run on the GPU (K12, `ctx.alleles`).
+
+    Groups, in the reference's order: first every row that stands for itself - a row whose merge group is just itself, or a member
+    of a chain that also passes the thresholds alone - in table order; then the chains, in the order their first member shows up,
+    members in chain order."""
+    from .hittable import HitTable
+    T = blastab if isinstance(blastab, HitTable) else HitTable.from_rows(blastab)
+    if len(T) == 0:
         return np.empty([0, 7], dtype=object), np.zeros([0, 3], dtype=np.int64)
     if ctx is None:
         from .uberBlast import get_context
         ctx = get_context()
-    blastab.T[:2] = blastab.T[:2].astype(int)
-    blastab = compare_prediction(blastab, old_prediction)
-    n_id = int(np.max(blastab.T[15])) + 1
-    kept = np.zeros(n_id, dtype=bool)
-    single, chained = [], {}
+    T.q_tab, T.r_tab = [int(x) for x in T.q_tab], [int(x) for x in T.r_tab]
+    T = _with_known(T, old_prediction)
+    n = len(T)
+    n_id = int(T.rid.max()) + 1
     mi = params['match_identity']
-    for tab in blastab:
-        grp = tab[16]
-        if not (grp[1] >= mi and _passes(grp[2], tab[12], params)):
-            tab[2] = -1
-            continue
-        kept[tab[15]] = True
-        if len(grp) <= 4:
-            single.append([tab[0], tab[1], grp[0], grp[1], None, 0, [tab]])
-            continue
-        if tab[2] >= mi and _passes(tab[7] - tab[6] + 1, tab[12], params):
-            single.append([tab[0], tab[1], tab[11], tab[2], None, 0, [tab]])
-        members = grp[3:]
-        if grp[3] not in chained:
-            chained[grp[3]] = [tab[0], tab[1], grp[0], grp[1], None, 0, [[]] * len(members)]
-        chained[grp[3]][6][members.index(tab[15])] = tab
-    groups = single + list(chained.values())
+    ok = (T.m_span >= 0) & (T.m_iden >= mi) & _passes_all(T.m_span, T.ql, params)         # the row's merge group passes
+    kept = np.zeros(n_id, dtype=bool)
+    kept[T.rid[ok]] = True
+    lone = ok & (T.m_len <= 1)
+    also_alone = ok & (T.m_len > 1) & (T.iden >= mi) & _passes_all(T.qe - T.qs + 1, T.ql, params)
+    single = np.flatnonzero(lone | also_alone)
+    # chains: keyed by their first member's row id, in order of first appearance; every member row finds its slot by its row id
+    in_chain = np.flatnonzero(ok & (T.m_len > 1))
+    chain_rows, chain_first = [], []
+    if len(in_chain):
+        key = T.m_ids[T.m_start[in_chain]]
+        uniq, first_pos = np.unique(key, return_index=True)
+        row_of_id = np.full(n_id, -1, dtype=np.int64)
+        row_of_id[T.rid[in_chain]] = in_chain
+        rep = in_chain[np.sort(first_pos)]                                         # one member row per chain, same order
+        for r in rep.tolist():
+            members = T.m_ids[T.m_start[r]:T.m_start[r] + T.m_len[r]]
+            rows = row_of_id[members]
+            if (rows < 0).any():
+                raise ValueError('build_bsn: a chained hit is missing from the table')
+            chain_rows.append(rows)
+            chain_first.append(r)
+    flat = np.concatenate([single] + chain_rows).astype(np.int64) if (len(single) or chain_rows) else np.zeros(0, np.int64)
+    n_rows = np.concatenate([np.ones(len(single), dtype=np.int64), np.array([len(r) for r in chain_rows], dtype=np.int64)])
+    n_groups = len(n_rows)
     overlap = overlap[kept[overlap.T[0]] & kept[overlap.T[1]], :2]
-    # ---- K12 over every row of every group
-    flat = [tab for group in groups for tab in group[6]]
-    n_rows = np.array([len(group[6]) for group in groups], dtype=np.int64)
+    if n_groups == 0:
+        return np.empty([0, 7], dtype=object), np.zeros([0, 3], dtype=np.int64)
     grp_off = np.concatenate([[0], np.cumsum(n_rows)]).astype(np.uint64)
-    contigs = [s for n, s in seq]
-    cidx = {n: i for i, (n, s) in enumerate(seq)}
-    runs, per = _encode_cigar_strings([tab[14] for tab in flat])
-    from ._native import LOCUS_DTYPE
-    loci = np.zeros(len(flat), dtype=LOCUS_DTYPE)
-    loci['contig'] = [cidx[tab[1]] for tab in flat]
-    cols = np.array([[tab[6], tab[7], tab[8], tab[9], tab[12], tab[15]] for tab in flat], dtype=np.int64).reshape(-1, 6)
-    loci['q_start'], loci['rs'], loci['re'] = cols[:, 0], cols[:, 2], cols[:, 3]
-    loci['cigar_runs'] = per
-    loci['cigar_off'] = np.concatenate([[0], np.cumsum(per)[:-1]]) if len(per) else []
-    loci['group'] = np.repeat(np.arange(len(groups)), n_rows)
     first = grp_off[:-1].astype(np.int64)
-    in_frame, orf, packed = ctx.alleles(contigs, loci, runs, grp_off, cols[first, 4], params['gtable'])
+    head_row = np.concatenate([single, np.array(chain_first, dtype=np.int64)]).astype(np.int64)      # the row a group takes gene / contig / group score from
+    is_lone_group = np.concatenate([lone[single], np.zeros(len(chain_rows), dtype=bool)])
+    # ---- K12 over every row of every group
+    from ._native import LOCUS_DTYPE
+    contigs = [sq for nm, sq in seq]
+    cidx = {nm: i for i, (nm, sq) in enumerate(seq)}
+    loci = np.zeros(len(flat), dtype=LOCUS_DTYPE)
+    loci['contig'] = np.array([cidx[nm] for nm in T.r_tab], dtype=np.int64)[T.ri[flat]]
+    loci['q_start'], loci['rs'], loci['re'] = T.qs[flat], T.ss[flat], T.se[flat]
+    loci['cigar_runs'], loci['cigar_off'] = T.c_runs[flat], T.c_off[flat]
+    loci['group'] = np.repeat(np.arange(n_groups), n_rows)
+    ql = T.ql[flat]
+    in_frame, orf, packed = ctx.alleles(contigs, loci, T.arena, grp_off, ql[first], params['gtable'])
     sc = np.minimum(in_frame, orf + 3)
-    iden = np.array([tab[2] for tab in flat], dtype=np.float64)
-    known = np.array([tab[10] for tab in flat], dtype=np.float64)
-    qspan = cols[:, 1] - cols[:, 0] + 1
-    r = np.sqrt(sc.astype(np.float64) / cols[:, 4] * known)
+    iden, known = T.iden[flat], T.evalue[flat]
+    q_lo, q_hi = T.qs[flat], T.qe[flat]
+    qspan = q_hi - q_lo + 1
+    r = np.sqrt(sc.astype(np.float64) / ql * known)
     msc = (sc * iden) * np.sqrt(sc * r)
     amsc = msc / qspan
-    pack_off = np.concatenate([[0], np.cumsum((cols[first, 4] + 2) // 3)])
+    pack_off = np.concatenate([[0], np.cumsum((ql[first] + 2) // 3)])
     # ---- assemble
     as_single, as_chain = np.full(n_id, -1, dtype=np.int64), np.full(n_id, -1, dtype=np.int64)
     gid_of_row = loci['group'].astype(np.int64)
     multi = np.repeat(n_rows > 1, n_rows)
-    as_single[cols[~multi, 5]] = gid_of_row[~multi]
-    as_chain[cols[multi, 5]] = gid_of_row[multi]
-    bsn = np.empty([len(groups), 7], dtype=object)
-    for gid, group in enumerate(groups):
-        lo, hi = int(grp_off[gid]), int(grp_off[gid + 1])
+    rid_flat = T.rid[flat]
+    as_single[rid_flat[~multi]] = gid_of_row[~multi]
+    as_chain[rid_flat[multi]] = gid_of_row[multi]
+    rows16 = T.take(flat).to_rows(cigar='str')[:, :16]              # the object rows the .mat store keeps, made once
+    g_gene, g_contig = [T.q_tab[i] for i in T.qi[head_row].tolist()], [T.r_tab[i] for i in T.ri[head_row].tolist()]
+    # group score / identity: the merge group's for a lone row and for a chain, the row's own for a chain member standing alone
+    g_iden = np.where(is_lone_group | (n_rows > 1), T.m_iden[head_row], T.iden[head_row]).tolist()
+    bsn = np.empty([n_groups, 7], dtype=object)
+    lo_l, hi_l = grp_off[:-1].astype(np.int64).tolist(), grp_off[1:].astype(np.int64).tolist()
+    for gid in range(n_groups):
+        lo, hi = lo_l[gid], hi_l[gid]
         if hi - lo == 1:
             score = msc[lo]
-            rows = group[6][0][:16].reshape(1, 16)
         else:
-            spans = [[cols[k, 0], cols[k, 1], amsc[k], msc[k]] for k in range(lo, hi)]
+            spans = [[q_lo[k], q_hi[k], amsc[k], msc[k]] for k in range(lo, hi)]
             for prev, cur in zip(spans[:-1], spans[1:]):          # fragments overlapping on the query: the weaker one is trimmed
                 if cur[0] < prev[1]:
                     if cur[2] > prev[2]:
@@ -348,11 +415,10 @@ def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=Non
                         cur[0] = prev[1] + 1
                         cur[3] = cur[2] * (cur[1] - cur[0] + 1)
             score = np.sum([c[3] for c in spans])
-            rows = np.array([tab[:16] for tab in group[6]])
         row = bsn[gid]
-        row[0], row[1], row[2], row[3], row[4], row[5], row[6] = group[0], group[1], score, group[3], packed[pack_off[gid]:pack_off[gid + 1]], gid, rows
+        row[0], row[1], row[2], row[3], row[4], row[5], row[6] = g_gene[gid], g_contig[gid], score, g_iden[gid], packed[pack_off[gid]:pack_off[gid + 1]], gid, rows16[lo:hi]
     a0, c0, a1, c1 = as_single[overlap.T[0]], as_chain[overlap.T[0]], as_single[overlap.T[1]], as_chain[overlap.T[1]]
-    overlap = np.vstack([np.vstack([m, n]).T[(m >= 0) & (n >= 0)] for m in (a0, c0) for n in (a1, c1)] +
+    overlap = np.vstack([np.vstack([m, k]).T[(m >= 0) & (k >= 0)] for m in (a0, c0) for k in (a1, c1)] +
                         [np.vstack([as_single, as_chain]).T[(as_single >= 0) & (as_chain >= 0)]])
     if overlap.shape[0]:
         og = np.load(orthoGroup, allow_pickle=True) if isinstance(orthoGroup, str) else orthoGroup
@@ -361,7 +427,7 @@ def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=Non
             rel[(g[0], g[1])] = 1 if g[2] > 0 else -1
         for g in og[og.T[2] != 0]:
             rel[(g[1], g[0])] = 1 if g[2] > 0 else -1
-        score = np.array([0 if m == n else rel.get((m, n), 2) for m, n in zip(bsn[overlap.T[0], 0], bsn[overlap.T[1], 0])], dtype=np.int64)
+        score = np.array([0 if m == k else rel.get((m, k), 2) for m, k in zip(bsn[overlap.T[0], 0], bsn[overlap.T[1], 0])], dtype=np.int64)
         overlap = np.hstack([overlap, score[:, np.newaxis]])[score >= 0]
     else:
         overlap = np.zeros([0, 3], dtype=np.int64)
@@ -411,7 +477,7 @@ def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
     for lo in range(0, len(jobs), genomes_per_batch):
         files = [_write_genome(prefix, id, seq) for id, taxon, seq in jobs[lo:lo + genomes_per_batch]]
         try:
-            results = uberBlastBatch(files, argv)
+            results = uberBlastBatch(files, argv, as_tables=True)        # (HitTable, overlaps) per genome: build_bsn works on the columns
         finally:
             for f in files:
                 os.unlink(f)

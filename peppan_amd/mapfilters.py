@@ -214,7 +214,7 @@ def linear_merge_table(T, gap_dist, len_diff):
     from . import _native as N
     n = len(T)
     if n == 0:
-        T.merge = []
+        T.set_merge_lists([])
         return T
     ss, se = _folded(T)
     q, r = T.q_codes(), T.r_codes()
@@ -237,9 +237,9 @@ def linear_merge_table(T, gap_dist, len_diff):
                 parts.append(np.array(list({i for i in local}), dtype=np.int64) + lo)
         order = np.concatenate(parts)
     out = T.take(first[order])
-    s_l, i_l, sp_l, ids_l, off_l = g_score.tolist(), g_iden.tolist(), g_span.tolist(), ids.tolist(), ids_off.tolist()
-    shared = []
-    out.merge = [[s_l[i], i_l[i], sp_l[i]] + ids_l[off_l[i]:off_l[i + 1]] if sp_l[i] >= 0 else shared for i in order.tolist()]
+    out.merge = None
+    out.m_score, out.m_iden, out.m_span = g_score[order], g_iden[order], g_span[order]
+    out.m_start, out.m_len, out.m_ids = ids_off[:-1][order], np.diff(ids_off)[order], np.asarray(ids, dtype=np.int64)
     return out
 
 

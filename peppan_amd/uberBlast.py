@@ -220,6 +220,7 @@ class RunBlast(object):
         self.device = device
         self._nt_loaded = None
         self._batch = None                  # (reference names genome-major, genome id per name) in run_batch
+        self._as_tables = False             # True: run() / run_batch() hand over the numeric HitTable instead of object rows
 
     # ---------------------------------------------------------------------------------------------- driver
     def run(self, ref, qry, methods, min_id, min_cov, min_ratio, table_id=11, n_thread=8, useProcess=False, re_score=0,
@@ -263,7 +264,8 @@ class RunBlast(object):
         overlap = None
         if return_overlap[0]:
             overlap = mapfilters.overlaps_table(T, return_overlap[1], return_overlap[2], sweep=get_context(self.device).overlaps)
-        rows = T.take(T.final_order()).to_rows(cigar='str')
+        T = T.take(T.final_order())
+        rows = T if self._as_tables else T.to_rows(cigar='str')
         return (rows, overlap) if return_overlap[0] else rows
 
     MAX_BATCH_NT = 120000000        # nucleotides per search: 6 frames -> 2 packed protein bytes per nt, under the 2^29 limit
@@ -284,6 +286,7 @@ class RunBlast(object):
                 tot += sizes[stop]
                 stop += 1
             sub = RunBlast(self.device) if (start, stop) != (0, len(refs)) else self
+            sub._as_tables = self._as_tables
             out += sub._run_one_batch(refs[start:stop], qry, methods, min_id, min_cov, min_ratio, table_id, n_thread, useProcess, re_score,
                                       filter, linear_merge, return_overlap, fix_end)
             start = stop
@@ -592,12 +595,16 @@ def uberBlast(args, extPool=None):
     return data
 
 
-def uberBlastBatch(references, args, device=None):
+def uberBlastBatch(references, args, device=None, as_tables=False):
     """uberBlast for a LIST of reference files and one query file: `args` are uberBlast's flags without -r/-o.
-    Returns one result per reference, each identical to uberBlast(['-r', ref] + args).  One GPU search per tool."""
+    Returns one result per reference, each identical to uberBlast(['-r', ref] + args).  One GPU search per tool.
+    as_tables: the hit tables come as numeric HitTables (same rows, same order) instead of object rows - for callers like
+    mapbsn.build_bsn that work on the columns."""
     a = _parser('uberBlast over many reference files with one search per tool.', False).parse_args(args)
     methods, kw = _run_arguments(a)
-    return RunBlast(device).run_batch(references, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread, a.process, **kw)
+    rb = RunBlast(device)
+    rb._as_tables = bool(as_tables)
+    return rb.run_batch(references, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread, a.process, **kw)
 
 
 if __name__ == '__main__':

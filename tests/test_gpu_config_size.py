@@ -52,7 +52,7 @@ def test_map_bsn_10k_exemplars_x_64_genomes(tmp_path, monkeypatch):
     def search(prefix, clust, jobs, p):                      # the product's batched search, with the per-genome tables recorded for the sample
         for job, res in zip(jobs, mapbsn._gpu_search(prefix, clust, jobs, p, genomes_per_batch=32)):
             if job[0] in sample:
-                seen[job[0]] = (res[0].copy(), res[1].copy())
+                seen[job[0]] = (res[0].to_rows(cigar='str'), res[1].copy())      # (the batch search hands over numeric HitTables)
             yield res
     fn = ['s.%s.npz' % x for x in ('tab', 'seq', 'mat', 'conflicts')]
     t0 = time.perf_counter()
@@ -109,13 +109,13 @@ def test_front_end_one_million_gene_instances(ctx, tmp_path, monkeypatch):
     fn, groups = PL.writeGenes('big.genes', genes, prio, ctx=ctx)
     t3 = time.perf_counter()
     n_unique = sum(1 for line in open(fn) if line.startswith('>'))
-    assert n_unique + len(groups) == n and 4000 <= n_unique <= 5 * 4000 + 4000      # identical alleles of one length run collapse
+    assert n_unique + len(groups) == n and 4000 <= n_unique <= 7 * 5 * 4000     # identical alleles collapse inside a length run: at most 5 alleles x 7 file ranks per gene (PEPPAN.py:1032-1033)
     with contextlib.redirect_stderr(io.StringIO()):
         ex = PL.iterClust('big', fn, groups, dict(identity=0.9, coverage=0.8, n_thread=1, translate=False))
     t4 = time.perf_counter()
     n_ex = sum(1 for line in open(ex) if line.startswith('>'))
     clu = np.load('big.clust.npy')
-    assert 3000 <= n_ex <= 4400                               # the alleles of a gene end up under one exemplar (families stay apart at 0.9)
+    assert 2500 <= n_ex <= 4000                               # the alleles of a gene end up under one exemplar; of the four members of a family the two closest (0 / 5 % substitutions) merge at 0.9
     assert clu.shape[0] >= n - n_ex - 12 * 11                 # (every level loses the first line of its table, PEPPAN.py:1786)
     rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
     print('1 M instances: generate %.1f s, sha1 %.1f s, writeGenes %.1f s, iterClust %.1f s; %d unique, %d exemplars; peak RSS %.1f GB'

@@ -9,6 +9,7 @@ sys.path.insert(0, '.')
 import numpy as np
 from peppan_amd import _native as N, synth, uberBlast as UB, pipeline as PL, mapbsn
 
+_start_dir = os.getcwd()
 os.chdir(tempfile.mkdtemp())
 names, seqs = synth.make_genes(10000, 1002, seed=355)
 with open('ex.fa', 'w') as f:
@@ -25,7 +26,6 @@ print('K7: uberBlast %d rows in %.0f ms; rescoring reads 2 x aligned nt + 40 B p
 
 ctx = UB.get_context()
 g200, s200 = synth.make_genes(200000, 0, seed=5)
-codes = [PL.np.frombuffer(s, dtype=np.uint8) for s in s200[:0]]
 from peppan_amd import linclust as LC
 enc = [LC.encode(s.decode()) for s in s200]
 for rep in range(2):
@@ -66,3 +66,4 @@ for rep in range(2):
             mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params)
     dt = time.perf_counter() - t0
 print('K11/K12: get_map_bsn 8 genomes in %.2f s (%.1f genomes/s)' % (dt, 8 / dt))
+os.chdir(_start_dir)          # rocprofv3 resolves its (relative) output directory when the process ends
