@@ -373,7 +373,10 @@ def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=Non
     contigs = [sq for nm, sq in seq]
     cidx = {nm: i for i, (nm, sq) in enumerate(seq)}
     loci = np.zeros(len(flat), dtype=LOCUS_DTYPE)
-    loci['contig'] = np.array([cidx[nm] for nm in T.r_tab], dtype=np.int64)[T.ri[flat]]
+    contig_of = np.array([cidx.get(nm, -1) for nm in T.r_tab], dtype=np.int64)[T.ri[flat]]       # (the name table of a batch search lists every genome's contigs)
+    if len(contig_of) and contig_of.min() < 0:
+        raise ValueError('build_bsn: a hit names a contig that is not part of this genome')
+    loci['contig'] = contig_of
     loci['q_start'], loci['rs'], loci['re'] = T.qs[flat], T.ss[flat], T.se[flat]
     loci['cigar_runs'], loci['cigar_off'] = T.c_runs[flat], T.c_off[flat]
     loci['group'] = np.repeat(np.arange(n_groups), n_rows)
