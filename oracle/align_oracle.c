@@ -280,32 +280,34 @@ static uint64_t *find_candidates(const oracle_params *p,
 /* ------------------------------------------------------------------ banded SW */
 typedef struct {
     int32_t score, iend, jend;
+    int32_t end_lane;   /* lowest diagonal pair (band column / 2) that holds a cell with the maximal score */
+    int32_t band;       /* diagonals of this band (row length of dir) */
     uint64_t cells;
-    uint8_t *dir;       /* [Lq][BAND] nibble per byte: bits0-1 src, bit2 eExt, bit3 fExt */
+    uint8_t *dir;       /* [Lq][band] nibble per byte: bits0-1 src, bit2 eExt, bit3 fExt */
 } sw_out;
 
+/* affine local alignment restricted to the `band` diagonals dlo .. dlo + band - 1 (band <= BAND) */
 static void banded_sw(const oracle_params *p, const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt,
-                      int32_t dlo, int keep_dir, sw_out *o)
+                      int32_t dlo, int32_t band, int keep_dir, sw_out *o)
 {
     const int32_t oe = p->gap_open + p->gap_ext, ext = p->gap_ext;
-    int32_t dhi = dlo + BAND - 1;
     /* rolling rows indexed by band column c = d - dlo */
     int32_t *base = malloc(sizeof(int32_t) * (BAND + 2) * 4);
     int32_t *Hp = base;
     int32_t *Fp = Hp + (BAND + 2), *Hc = Fp + (BAND + 2), *Fc = Hc + (BAND + 2);
     for (int c = 0; c < BAND + 2; ++c) { Hp[c] = 0; Fp[c] = NEG; Hc[c] = 0; Fc[c] = NEG; }
-    o->score = 0; o->iend = -1; o->jend = -1; o->cells = 0;
-    o->dir = keep_dir ? calloc((size_t)Lq * BAND, 1) : NULL;
+    o->score = 0; o->iend = -1; o->jend = -1; o->cells = 0; o->end_lane = -1; o->band = band;
+    o->dir = keep_dir ? calloc((size_t)Lq * band, 1) : NULL;
     for (int32_t i = 0; i < Lq; ++i) {
-        int32_t jlo = i + dlo, jhi = i + dhi;
+        int32_t jlo = i + dlo;
         int32_t hl = 0, el = NEG;            /* left neighbour (i, j-1) inside the band */
-        for (int c = 0; c < BAND; ++c) {
+        for (int c = 0; c < band; ++c) {
             int32_t j = jlo + c;
             if (j < 0 || j >= Lt) { Hc[c] = 0; Fc[c] = NEG; hl = 0; el = NEG; continue; }
             /* previous row, same diagonal -> band column c; up (i-1, j) -> diagonal d+1 -> column c+1 */
             int32_t hd = (i > 0 && j > 0) ? Hp[c] : 0;
             int32_t hu = 0, fu = NEG;
-            if (i > 0 && c + 1 < BAND) { hu = Hp[c + 1]; fu = Fp[c + 1]; }
+            if (i > 0 && c + 1 < band) { hu = Hp[c + 1]; fu = Fp[c + 1]; }
             if (c == 0 || j == 0) { hl = 0; el = NEG; }
             int32_t e_ext = el - ext, e_open = hl - oe;
             int32_t f_ext = fu - ext, f_open = hu - oe;
@@ -318,14 +320,14 @@ static void banded_sw(const oracle_params *p, const uint8_t *q, int32_t Lq, cons
             if (H < 0) H = 0;
             if (keep_dir) {
                 uint8_t src = (H == 0) ? 0 : (H == h) ? 1 : (H == E) ? 2 : 3;
-                o->dir[(size_t)i * BAND + c] = (uint8_t)(src | ((e_ext > e_open) ? 4 : 0) | ((f_ext > f_open) ? 8 : 0));
+                o->dir[(size_t)i * band + c] = (uint8_t)(src | ((e_ext > e_open) ? 4 : 0) | ((f_ext > f_open) ? 8 : 0));
             }
-            if (H > o->score) { o->score = H; o->iend = i; o->jend = j; }   /* row-major scan => min i, then min j */
+            if (H > o->score) { o->score = H; o->iend = i; o->jend = j; o->end_lane = c >> 1; }   /* row-major scan => min i, then min j */
+            else if (H == o->score && H > 0 && (c >> 1) < o->end_lane) o->end_lane = c >> 1;
             Hc[c] = H; Fc[c] = F;
             hl = H; el = E;
             o->cells++;
         }
-        (void)jhi;
         int32_t *tmp = Hp; Hp = Hc; Hc = tmp; tmp = Fp; Fp = Fc; Fc = tmp;
     }
     free(base);
@@ -347,7 +349,7 @@ static void traceback(const sw_out *o, const uint8_t *q, const uint8_t *t, int32
     *n_ident = 0; *aln_len = 0; rb->n = 0;
     *istart = i; *jstart = j;
     for (;;) {
-        uint8_t nib = o->dir[(size_t)i * BAND + (j - i - dlo)];
+        uint8_t nib = o->dir[(size_t)i * o->band + (j - i - dlo)];
         if (state == 0) {
             uint8_t src = nib & 3;
             if (src == 0) break;
@@ -368,6 +370,45 @@ static void traceback(const sw_out *o, const uint8_t *q, const uint8_t *t, int32
             --i;
         }
     }
+}
+
+/* The alignment a band reports.  Its score T is the maximum of the 128-diagonal band (the score pass).  The traceback is taken in
+ * the 64-diagonal SUB-band centred on the lowest diagonal pair that holds a cell with score T (pairs = the two diagonals one GPU
+ * lane owns; sub-band = pairs [L0, L0 + 32), L0 = that pair - 16 clamped to [0, 32]) whenever the sub-band alone reaches T: its end
+ * cell is then the first cell with score T in row-major order INSIDE the sub-band.  An alignment that needs more room (the sub-band's
+ * maximum stays below T) is traced in the full band, from the full band's first maximal cell.  Either way the reported alignment has
+ * score T; the rule only fixes WHICH optimal alignment is reported and lets the traceback pass sweep half the cells. */
+#define SUB_BAND 64
+static uint64_t g_traced = 0, g_full_band = 0;      /* how often the sub-band was enough (oracle_trace_counts) */
+void oracle_trace_counts(uint64_t *out, int reset) { out[0] = g_traced; out[1] = g_full_band; if (reset) g_traced = g_full_band = 0; }
+static void band_align(const oracle_params *p, const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt, int32_t dlo,
+                       sw_out *o, runbuf *rb, int32_t *is, int32_t *js, uint32_t *nid, uint32_t *al)
+{
+    sw_out wide;
+    banded_sw(p, q, Lq, t, Lt, dlo, BAND, 0, &wide);
+    *o = wide;
+    if (wide.score <= 0) return;
+    #pragma omp atomic
+    ++g_traced;
+    int32_t L0 = wide.end_lane - SUB_BAND / 4;
+    if (L0 < 0) L0 = 0;
+    if (L0 > (BAND - SUB_BAND) / 2) L0 = (BAND - SUB_BAND) / 2;
+    const int32_t ndlo = dlo + 2 * L0;
+    sw_out narrow;
+    banded_sw(p, q, Lq, t, Lt, ndlo, SUB_BAND, 1, &narrow);
+    if (narrow.score == wide.score) {
+        traceback(&narrow, q, t, ndlo, rb, is, js, nid, al);
+        o->iend = narrow.iend; o->jend = narrow.jend;
+        free(narrow.dir);
+        return;
+    }
+    free(narrow.dir);
+    #pragma omp atomic
+    ++g_full_band;
+    banded_sw(p, q, Lq, t, Lt, dlo, BAND, 1, &wide);
+    traceback(&wide, q, t, dlo, rb, is, js, nid, al);
+    free(wide.dir);
+    o->dir = NULL;
 }
 
 static int cmp_hit_rank(const void *a, const void *b)
@@ -425,7 +466,7 @@ static void align_group(const oracle_params *p, const uint64_t *cand, uint64_t g
             int32_t bin = (int32_t)(cand[g] & ((1u << 18) - 1));
             int32_t dlo = bin * BIN_W - DIAG_OFF - BAND_LEAD;
             sw_out o;
-            banded_sw(p, qs, Lq, ts, Lt, dlo, 0, &o);
+            banded_sw(p, qs, Lq, ts, Lt, dlo, BAND, 0, &o);
             r->cells += o.cells;
             if (o.score > best) { best = o.score; best_bin = bin; }
         }
@@ -433,10 +474,8 @@ static void align_group(const oracle_params *p, const uint64_t *cand, uint64_t g
             if (best > 0 && best >= min_score[q]) {
                 int32_t dlo = best_bin * BIN_W - DIAG_OFF - BAND_LEAD;
                 sw_out o;
-                banded_sw(p, qs, Lq, ts, Lt, dlo, 1, &o);
                 int32_t is, js; uint32_t nid, al;
-                traceback(&o, qs, ts, dlo, &rb, &is, &js, &nid, &al);
-                free(o.dir);
+                band_align(p, qs, Lq, ts, Lt, dlo, &o, &rb, &is, &js, &nid, &al);
                 ++r->traced;
                 double idp = (double)nid * 100.0 / (double)al;
                 double qcov = (double)(o.iend - is + 1) * 100.0 / (double)Lq;
@@ -455,16 +494,15 @@ static void align_group(const oracle_params *p, const uint64_t *cand, uint64_t g
                 int32_t bin = (int32_t)(cand[g] & ((1u << 18) - 1));
                 int32_t dlo = bin * BIN_W - DIAG_OFF - BAND_LEAD;
                 sw_out o;
-                banded_sw(p, qs, Lq, ts, Lt, dlo, 1, &o);
+                banded_sw(p, qs, Lq, ts, Lt, dlo, BAND, 0, &o);
                 if (o.score > 0 && o.score >= min_score[q]) {
                     band_aln *b = &al_[na++];
-                    traceback(&o, qs, ts, dlo, &rb, &b->is, &b->js, &b->nid, &b->al);
+                    band_align(p, qs, Lq, ts, Lt, dlo, &o, &rb, &b->is, &b->js, &b->nid, &b->al);
                     ++r->traced;
                     b->bin = bin; b->score = o.score; b->iend = o.iend; b->jend = o.jend; b->cells = o.cells; b->nruns = rb.n;
                     b->runs = malloc((rb.n + 1) * sizeof(uint32_t));
                     for (uint32_t x = 0; x < rb.n; ++x) b->runs[x] = rb.runs[rb.n - 1 - x];
                 }
-                free(o.dir);
             }
             for (uint64_t x = 0; x < na; ++x)
                 for (uint64_t y = 0; y < na; ++y)
@@ -564,17 +602,16 @@ int oracle_align_one(const oracle_params *p, const uint8_t *q, int32_t Lq, const
 {
     int32_t dlo = bin * BIN_W - DIAG_OFF - BAND_LEAD;
     sw_out o; runbuf rb = {0};
-    banded_sw(p, q, Lq, t, Lt, dlo, 1, &o);
+    int32_t is = 0, js = 0; uint32_t nid = 0, al = 0;
+    band_align(p, q, Lq, t, Lt, dlo, &o, &rb, &is, &js, &nid, &al);
     memset(h, 0, sizeof(*h));
     h->score = o.score; h->cells = o.cells; h->bin = bin;
     if (o.score > 0) {
-        int32_t is, js; uint32_t nid, al;
-        traceback(&o, q, t, dlo, &rb, &is, &js, &nid, &al);
         h->q_start = is + 1; h->q_end = o.iend + 1; h->t_start = js + 1; h->t_end = o.jend + 1;
         h->n_ident = nid; h->aln_len = al; h->nm = al - nid; h->cigar_runs = rb.n;
         for (uint32_t r = 0; r < rb.n && r < cigar_cap; ++r) cigar[r] = rb.runs[rb.n - 1 - r];
     }
-    free(o.dir); free(rb.runs);
+    free(rb.runs);
     return 0;
 }
 
@@ -776,15 +813,14 @@ int oracle_linclust(const uint8_t *res, const uint64_t *off, uint32_t n, int bas
             for (int b = a; b < np; ++b) {
                 if (pend_c[b] != c) continue;
                 sw_out o;
-                banded_sw(&gp, qs, (int32_t)Ls, qc, Lc, pend_bin[b] * BIN_W - DIAG_OFF - BAND_LEAD, 0, &o);
+                banded_sw(&gp, qs, (int32_t)Ls, qc, Lc, pend_bin[b] * BIN_W - DIAG_OFF - BAND_LEAD, BAND, 0, &o);
                 if (o.score > best || (o.score == best && o.score > 0 && pend_bin[b] < best_bin)) { best = o.score; best_bin = pend_bin[b]; }
             }
             if (best < 1) continue;
             int32_t dlo = best_bin * BIN_W - DIAG_OFF - BAND_LEAD, is, js; uint32_t nid, al;
             sw_out o; runbuf rb = {0};
-            banded_sw(&gp, qs, (int32_t)Ls, qc, Lc, dlo, 1, &o);
-            traceback(&o, qs, qc, dlo, &rb, &is, &js, &nid, &al);
-            free(o.dir); free(rb.runs);
+            band_align(&gp, qs, (int32_t)Ls, qc, Lc, dlo, &o, &rb, &is, &js, &nid, &al);
+            free(rb.runs);
             double qspan = (double)(o.iend - is + 1), tspan = (double)(o.jend - js + 1);
             if ((double)nid >= min_id * (double)al && qspan >= min_cov * (double)Ls && tspan >= min_cov * (double)Lc) {
                 acc[(size_t)s * m + nacc[s]++] = c; ++n_acc;

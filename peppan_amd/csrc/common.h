@@ -100,6 +100,7 @@ struct pep_ctx {
     uint64_t k1_upper = 0;
     int k1_base_frames = 0;            // 0 = not computed for the current reference set
     DevBuf d_min_score;
+    DevBuf d_trace_mode;                    // per traced pair: first lane of the sub-band its traceback codes cover, -1 = the full band (sw.hip)
     std::vector<uint32_t> group_of_seq;     // optional: competition group of every reference sequence (pep_set_target_groups)
     DevBuf d_t_class;
     bool t_class_ready = false;
@@ -181,7 +182,7 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase = 0);
 // ---- seeds.hip  (K2-K4)
 int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands);
 // ---- sw.hip / trace.hip (K5, K6, K8)
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known = nullptr);   // kernel time: phase timers TM_SW / TM_SW_TRACE
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known = nullptr, const int32_t *d_end_lane = nullptr);   // kernel time: phase timers TM_SW / TM_SW_TRACE
 int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n_cands, const int32_t *h_min_score, pep_result *res);
 int pep_selftest_dpp(pep_ctx *ctx);
 // ---- rescore.hip (K7)

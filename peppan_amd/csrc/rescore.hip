@@ -45,14 +45,17 @@ __global__ __launch_bounds__(256) void k7_rescore(uint64_t n, const pep_nt_hit *
                 const long long todo = len - x < 16 ? len - x : 16;
                 const long long qa = qi + x, ra = rev ? ri - x - 15 : ri + x;              // first byte of the two 16-byte windows
                 if (todo == 16 && qa + 16 <= (long long)q_total && ra >= 0 && ra + 16 <= (long long)r_total) {
-                    uint32_t qw[4], rw[4];
+                    uint32_t qw[4], rl[4], rw[4];
                     __builtin_memcpy(qw, q_nt + qa, 16);
-                    __builtin_memcpy(rw, r_nt + ra, 16);
+                    __builtin_memcpy(rl, r_nt + ra, 16);
+                    // a reverse-strand window is turned round as a whole (byte swap of every dword, dwords in reverse order) so that the
+                    // compare loop indexes both windows with compile-time constants - a run-time byte index would push them out of registers
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) rw[w] = rev ? __builtin_bswap32(rl[3 - w]) : rl[w];
 #pragma unroll
                     for (int c = 0; c < 16; ++c) {
                         const int a = enc((uint8_t)(qw[c >> 2] >> ((c & 3) * 8)));
-                        const int cr = rev ? 15 - c : c;
-                        const int e = enc((uint8_t)(rw[cr >> 2] >> ((cr & 3) * 8)));
+                        const int e = enc((uint8_t)(rw[c >> 2] >> ((c & 3) * 8)));
                         nmatch += (a == (rev ? 4 - e : e)) ? 1 : 0;
                     }
                 } else {

@@ -46,7 +46,30 @@ struct SwArgs {
     const int32_t *known;          // traceback pass: the score of every candidate, from the score pass
     int max_sub;                   // largest table entry: bounds the scores of a pair for the 16-bit passes
     const uint32_t *order;         // candidates by decreasing length (sw_order): item w of a launch is order[w] (order[2w], order[2w+1] packed)
+    const int32_t *end_lane;       // traceback pass: per candidate the lowest lane (diagonal pair) of the score pass that reached the score
+    int32_t *mode;                 // traceback pass, out: first lane L0 of the 64-diagonal sub-band the codes were written for, -1 = the full band
 };
+
+// The traceback of a band is taken in the 64-diagonal sub-band around the lane in which the score pass met the band's score (lanes
+// [L0, L0 + 32) of the 64) whenever that sub-band alone reaches the score, in the full band otherwise (rule and reasons: band_align in
+// oracle/align_oracle.c).  Half the lanes, half the cells, half the traceback codes for nearly every pair.
+constexpr int SUB_LANES = 32;
+__device__ __forceinline__ int sub_band_first_lane(int end_lane) { return min(max(end_lane - SUB_LANES / 2, 0), 64 - SUB_LANES); }
+
+// anti-diagonal geometry of the band [dlo, dlo + width) of an Lq x Lt matrix: a0 (the band row of step 0) and the number of 16-step blocks
+__device__ __forceinline__ void band_geom(int Lq, int Lt, int dlo, int width, int &a0, int &nblk)
+{
+    const int dl = max(dlo, -(Lq - 1)), dh = min(dlo + width - 1, Lt - 1);
+    const int s_lo = (dl <= 0 && dh >= 0) ? 0 : (dl > 0 ? dl : -dh);
+    const int s0 = s_lo - ((s_lo - dlo) & 1);
+    a0 = (s0 - dlo) / 2;
+    nblk = 0;
+    if (dl <= dh) {
+        const int dstar = min(max(Lt - Lq, dl), dh);
+        const int s_hi = 2 * min(Lq - 1, Lt - 1 - dstar) + dstar;
+        nblk = (s_hi - s0 + 1 + 15) / 16;
+    }
+}
 
 __device__ __forceinline__ int shr1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }   // lane l <- lane l-1
 __device__ __forceinline__ int shl1(int fill, int v) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }   // lane l <- lane l+1
@@ -59,31 +82,32 @@ __device__ __forceinline__ int shl1z(int v) { return __builtin_amdgcn_update_dpp
 __device__ __forceinline__ uint16_t q_addr_part(int qc) { return (uint16_t)(qc << (TAB_ROW_SHIFT + 3)); }
 __device__ __forceinline__ uint16_t t_addr_part(int tc) { return (uint16_t)(((tc >> 2) << TAB_ROW_SHIFT) | (tc & 3)); }
 
+// sub < 0: the full band (64 lanes x 2 diagonals).  sub >= 0: the sub-band of lanes [sub, sub + 32) only - lanes 32..63 then mirror lanes
+// 0..31 (same cells, same values), so that the code path stays one; only lanes < 32 store.  Returns the band's best score (wave-uniform).
 template <bool LDS_RES, bool TRACE>
-__device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsigned char *lds_tab, uint16_t *lds_res, int lane)
+__device__ __forceinline__ int sw_one(const SwArgs &a, uint64_t c, const unsigned char *lds_tab, uint16_t *lds_res, int lane, int sub = -1)
 {
     const uint64_t key = a.cands[c];
     const uint32_t q = (uint32_t)(key >> 43), t = (uint32_t)((key >> 18) & ((1u << 25) - 1));
     const int bin = (int)(key & ((1u << 18) - 1));
-    const int dlo = bin * 64 - (1 << 23) - 32;
+    const int W = sub >= 0 ? SUB_LANES : 64;                   // lanes that own diagonals
+    const int dlo = bin * 64 - (1 << 23) - 32 + (sub >= 0 ? 2 * sub : 0);
+    const int ln = lane & (W - 1);
     const int Lq = (int)a.q_len[q], Lt = (int)a.t_len[t];
     const uint8_t *qg = a.q_res + a.q_off[q], *tg = a.t_res + a.t_off[t];
-    // first anti-diagonal that meets band and matrix, rounded so that step 0 is an A step
-    const int dl = max(dlo, -(Lq - 1)), dh = min(dlo + 127, Lt - 1);
-    const int s_lo = (dl <= 0 && dh >= 0) ? 0 : (dl > 0 ? dl : -dh);
-    const int s0 = s_lo - ((s_lo - dlo) & 1);
-    const int a0 = (s0 - dlo) / 2;                 // exact: s0 - dlo is even
-    const int nblk = (int)a.nblk[c];
+    int a0, nblk;
+    band_geom(Lq, Lt, dlo, 2 * W, a0, nblk);
+    if (sub < 0) nblk = (int)a.nblk[c];
     uint2 *dir = TRACE ? reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c] * 64 : nullptr;
 
-    // residues used by step pair m:  A: (i, j) = (a0 + m - lane, a0 + dlo + m + lane),  B: (i, j + 1)
-    int i = a0 - lane, j = a0 + dlo + lane;
+    // residues used by step pair m:  A: (i, j) = (a0 + m - ln, a0 + dlo + m + ln),  B: (i, j + 1)
+    int i = a0 - ln, j = a0 + dlo + ln;
     uint16_t *lq = nullptr, *lt = nullptr;
     int qlo = 0, tlo = 0;
     if (LDS_RES) {
-        // stage the residue windows the sweep can touch: i in [a0-63, a0+8*nblk], j in [a0+dlo, a0+dlo+8*nblk+64]
-        qlo = a0 - 64; tlo = a0 + dlo - 1;
-        const int qn = 8 * nblk + 72, tn = 8 * nblk + 72;
+        // stage the residue windows the sweep can touch: i in [a0-W+1, a0+8*nblk], j in [a0+dlo, a0+dlo+8*nblk+W]
+        qlo = a0 - W; tlo = a0 + dlo - 1;
+        const int qn = 8 * nblk + W + 8, tn = 8 * nblk + W + 8;
         lq = lds_res; lt = lds_res + ((qn + 7) & ~7);
         for (int x = lane; x < qn; x += 64) { const int g = qlo + x; lq[x] = q_addr_part(((unsigned)g < (unsigned)Lq) ? qg[g] : PEP_PAD_CODE); }
         for (int x = lane; x < tn; x += 64) { const int g = tlo + x; lt[x] = t_addr_part(((unsigned)g < (unsigned)Lt) ? tg[g] : PEP_PAD_CODE); }
@@ -99,6 +123,8 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
     auto Tat = [&](int jj) -> int { return LDS_RES ? (int)vt[jj - tlo] : (int)t_addr_part(((unsigned)jj < (unsigned)Lt) ? (int)tg[jj] : PEP_PAD_CODE); };
     // gather: byte ((q*8 + t/4)*PEP_TAB_REP + copy)*4 + (t&3) of the replicated table, read as a signed byte (copy = lane mod PEP_TAB_REP)
     const signed char *tab = reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4;
+    // sub-band: the lanes at its two edges must read the band boundary (0), not the neighbouring mirror lane
+    const int keep_l = (sub >= 0 && ln == 0) ? 0 : -1, keep_r = (sub >= 0 && ln == W - 1) ? 0 : -1;
 
     int HA = 0, EA = 0, FA = 0, HB = 0, EB = 0, FB = 0;
     int best = 0, best_k = -1;
@@ -111,15 +137,15 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
         for (int half = 0; half < 2; ++half)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            // ---- A step: cell (i, j) on diagonal dlo + 2*lane
+            // ---- A step: cell (i, j) on diagonal dlo + 2*ln
             qv = Qat(i);
             {
-                const int sub = tab[qv + tv];
-                const int hl = shr1z(HB), el = shr1z(EB);
+                const int sub_ = tab[qv + tv];
+                const int hl = shr1z(HB) & keep_l, el = shr1z(EB) & keep_l;
                 const int e_ext = el - ext, e_open = hl - oe;
                 const int f_ext = FB - ext, f_open = HB - oe;
                 const int E = max(e_ext, e_open), F = max(f_ext, f_open);
-                const int h = HA + sub;
+                const int h = HA + sub_;
                 const int H = max(max(max(h, E), F), 0);
                 if (TRACE) {
                     const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
@@ -130,15 +156,15 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
                 HA = H; EA = E; FA = F;
             }
             ++k; ++j;
-            // ---- B step: cell (i, j) on diagonal dlo + 2*lane + 1   (j already advanced)
+            // ---- B step: cell (i, j) on diagonal dlo + 2*ln + 1   (j already advanced)
             tv = Tat(j);
             {
-                const int sub = tab[qv + tv];
-                const int hu = shl1z(HA), fu = shl1z(FA);
+                const int sub_ = tab[qv + tv];
+                const int hu = shl1z(HA) & keep_r, fu = shl1z(FA) & keep_r;
                 const int e_ext = EA - ext, e_open = HA - oe;
                 const int f_ext = fu - ext, f_open = hu - oe;
                 const int E = max(e_ext, e_open), F = max(f_ext, f_open);
-                const int h = HB + sub;
+                const int h = HB + sub_;
                 const int H = max(max(max(h, E), F), 0);
                 if (TRACE) {
                     const uint32_t src = (H == 0) ? 0u : (H == h) ? 1u : (H == E) ? 2u : 3u;
@@ -150,21 +176,23 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
             }
             ++k; ++i;
         }
-        if (TRACE) dir[(size_t)b * 64 + lane] = make_uint2(accA, accB);
+        if (TRACE && lane < W) dir[(size_t)b * W + ln] = make_uint2(accA, accB);
     }
     if (!TRACE) {
-        // score pass: only the maximum is needed (the end cell comes from the traceback pass of the selected pairs)
+        // score pass: the maximum and the lowest lane that holds it (the end cell comes from the traceback pass of the selected pairs)
+        const int mine = best;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) best = max(best, __shfl_xor(best, d, 64));
-        if (lane == 0) a.out[c] = make_int4(best, -1, -1, a0);
-        return;
+        const unsigned long long at = __ballot(mine == best);
+        if (lane == 0) a.out[c] = make_int4(best, (int)__builtin_ctzll(at), -1, a0);
+        return best;
     }
     // the lane's best cell: earliest step with the lane maximum == (min i, then min j) among its two diagonals
     int bi = 0x7fffffff, bj = 0x7fffffff;
     if (best_k >= 0) {
         const int m = best_k >> 1;
-        bi = a0 + m - lane;
-        bj = a0 + dlo + m + lane + (best_k & 1);
+        bi = a0 + m - ln;
+        bj = a0 + dlo + m + ln + (best_k & 1);
     }
     // wave reduction: max score, then min i, then min j
 #pragma unroll
@@ -174,6 +202,20 @@ __device__ __forceinline__ void sw_one(const SwArgs &a, uint64_t c, const unsign
         if (take) { best = os; bi = oi; bj = oj; }
     }
     if (lane == 0) a.out[c] = make_int4(best, best > 0 ? bi : -1, best > 0 ? bj : -1, a0);
+    return best;
+}
+
+// traceback of one candidate with the 32-bit sweep: sub-band first, the full band when the sub-band cannot reach the known score
+template <bool LDS_RES>
+__device__ __forceinline__ void trace_one(const SwArgs &a, uint64_t c, const unsigned char *lds_tab, uint16_t *lds_res, int lane)
+{
+    int mode = -1;
+    if (a.known && a.end_lane && a.known[c] > 0) {
+        const int L0 = sub_band_first_lane(a.end_lane[c]);
+        if (sw_one<LDS_RES, true>(a, c, lds_tab, lds_res, lane, L0) == a.known[c]) mode = L0;
+    }
+    if (mode < 0) sw_one<LDS_RES, true>(a, c, lds_tab, lds_res, lane, -1);
+    if (lane == 0 && a.mode) a.mode[c] = mode;
 }
 
 // ---- packed 16-bit score pass: ONE wavefront sweeps TWO candidates, candidate 0 in the low and candidate 1 in the
@@ -308,11 +350,14 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
         }
     }
     int b0 = best.x - PK_BIAS, b1 = best.y - PK_BIAS;
+    const int m0 = b0, m1 = b1;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { b0 = max(b0, __shfl_xor(b0, d, 64)); b1 = max(b1, __shfl_xor(b1, d, 64)); }
+    // the lowest lane that met the maximum: the traceback pass centres its sub-band there
+    const unsigned long long at0 = __ballot(m0 == b0), at1 = __ballot(m1 == b1);
     if (lane == 0) {
-        a.out[c0] = make_int4(b0, -1, -1, g0.a0);
-        a.out[c1] = make_int4(b1, -1, -1, g1.a0);
+        a.out[c0] = make_int4(b0, (int)__builtin_ctzll(at0), -1, g0.a0);
+        a.out[c1] = make_int4(b1, (int)__builtin_ctzll(at1), -1, g1.a0);
     }
 }
 
@@ -365,25 +410,56 @@ __device__ __forceinline__ u16x2 pk_codes(const PkConst &K, s16x2 H, s16x2 h, s1
     return pk_mad(ff, K.eight, pk_mad(ef, K.four, src));
 }
 
-__device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, uint64_t c1, const CandGeom &g0, const CandGeom &g1,
-                                                  const unsigned char *lds_tab, uint16_t *lds_res, int lane)
+// Geometry of a candidate's SUB-band (lanes [L0, L0 + 32) of its band)
+struct SubGeom {
+    const uint8_t *qg, *tg;
+    int Lq, Lt, dlo, a0, nblk;
+};
+__device__ __forceinline__ SubGeom sub_geom(const CandGeom &g, int L0)
 {
-    const int nb = max(g0.nblk, g1.nblk);
-    const int win = (8 * nb + 80 + 7) & ~7;
-    uint16_t *q0 = lds_res, *t0 = q0 + win, *q1 = t0 + win, *t1 = q1 + win;
-    stage_windows(g0, nb, q0, t0, lane);
-    stage_windows(g1, nb, q1, t1, lane);
+    SubGeom s;
+    s.qg = g.qg; s.tg = g.tg; s.Lq = g.Lq; s.Lt = g.Lt;
+    s.dlo = g.dlo + 2 * L0;
+    band_geom(g.Lq, g.Lt, s.dlo, 2 * SUB_LANES, s.a0, s.nblk);
+    return s;
+}
+__device__ __forceinline__ void stage_sub_windows(const SubGeom &g, int nb, uint16_t *lq, uint16_t *lt, int lane)
+{
+    const int qlo = g.a0 - SUB_LANES, tlo = g.a0 + g.dlo - 1, n = 8 * nb + SUB_LANES + 8;
+    for (int x = lane; x < n; x += 64) { const int p = qlo + x; lq[x] = q_addr_part(((unsigned)p < (unsigned)g.Lq) ? g.qg[p] : PEP_PAD_CODE); }
+    for (int x = lane; x < n; x += 64) { const int p = tlo + x; lt[x] = t_addr_part(((unsigned)p < (unsigned)g.Lt) ? g.tg[p] : PEP_PAD_CODE); }
+}
+
+// FOUR candidates per wavefront: lanes 0..31 sweep the sub-bands of candidates 0 / 1 (low / high half of every packed register), lanes
+// 32..63 those of candidates 2 / 3.  The recurrences, the 4-bit codes and the end-cell search are those of the two-candidate packed
+// sweep (see above); the only additions are the AND masks that make lanes 0 / 31 of each half read the band boundary instead of the
+// other half's edge lane (v_and_b32 issues at twice the rate of the packed operations).  ok[x] = candidate x reached its known score
+// inside its sub-band (wave-uniform); a candidate that did not is traced again in its full band by the caller.
+__device__ __forceinline__ void sw_four_pk16_trace(const SwArgs &a, const uint64_t cc[4], const SubGeom gg[4], const int L0[4], bool ok[4],
+                                                   const unsigned char *lds_tab, uint16_t *lds_res, int lane)
+{
+    const int nb = max(max(gg[0].nblk, gg[1].nblk), max(gg[2].nblk, gg[3].nblk));
+    const int win = (8 * nb + SUB_LANES + 16 + 7) & ~7;
+    uint16_t *wq[4], *wt[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) { wq[x] = lds_res + (2 * x) * win; wt[x] = lds_res + (2 * x + 1) * win; stage_sub_windows(gg[x], nb, wq[x], wt[x], lane); }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int hf = lane >> 5, ln = lane & (SUB_LANES - 1);      // which pair of candidates, which lane of the sub-band
     typedef const volatile __attribute__((address_space(3))) uint16_t lds_cu16;
-    lds_cu16 *vq0 = (lds_cu16 *)(q0 + (64 - lane)), *vt0 = (lds_cu16 *)(t0 + (1 + lane));
-    lds_cu16 *vq1 = (lds_cu16 *)(q1 + (64 - lane)), *vt1 = (lds_cu16 *)(t1 + (1 + lane));
+    lds_cu16 *vq0 = (lds_cu16 *)((hf ? wq[2] : wq[0]) + (SUB_LANES - ln)), *vt0 = (lds_cu16 *)((hf ? wt[2] : wt[0]) + (1 + ln));
+    lds_cu16 *vq1 = (lds_cu16 *)((hf ? wq[3] : wq[1]) + (SUB_LANES - ln)), *vt1 = (lds_cu16 *)((hf ? wt[3] : wt[1]) + (1 + ln));
     const uint32_t tab = (uint32_t)(uintptr_t)(lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
+    const uint64_t c0 = hf ? cc[2] : cc[0], c1 = hf ? cc[3] : cc[1];
+    const int nb0 = hf ? gg[2].nblk : gg[0].nblk, nb1 = hf ? gg[3].nblk : gg[1].nblk;
     uint2 *dir0 = reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c0] * 64, *dir1 = reinterpret_cast<uint2 *>(a.dirs) + a.dir_off[c1] * 64;
     const s16x2 zero = {0, 0};
     const s16x2 oe2 = {(short)a.oe, (short)a.oe}, ext2 = {(short)a.ext, (short)a.ext};
     const s16x2 T2 = {(short)a.known[c0], (short)a.known[c1]};
+    const int keep_l = ln == 0 ? 0 : -1, keep_r = ln == SUB_LANES - 1 ? 0 : -1;
+    auto edge_l = [&](s16x2 v) { return __builtin_bit_cast(s16x2, __builtin_bit_cast(int, v) & keep_l); };
+    auto edge_r = [&](s16x2 v) { return __builtin_bit_cast(s16x2, __builtin_bit_cast(int, v) & keep_r); };
     PkConst K;
     K.four = u16x2{4, 4}; K.eight = u16x2{8, 8};
     K.place[0] = u16x2{1, 1}; K.place[1] = u16x2{16, 16}; K.place[2] = u16x2{256, 256}; K.place[3] = u16x2{4096, 4096};
@@ -401,7 +477,7 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                 qv0 = vq0[u]; qv1 = vq1[u];
                 {
                     const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
-                    const s16x2 hl = pk_shr1z(HB), el = pk_shr1z(EB);
+                    const s16x2 hl = edge_l(pk_shr1z(HB)), el = edge_l(pk_shr1z(EB));
                     const s16x2 e_ext = el - ext2, f_ext = FB - ext2;                 // "open from H" needs no subtraction in this form
                     const s16x2 E = pk_max(e_ext, hl), F = pk_max(f_ext, HB);
                     const s16x2 h = HA + sub;
@@ -418,7 +494,7 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
                 tv0 = vt0[u + 1]; tv1 = vt1[u + 1];
                 {
                     const s16x2 sub = {tab_at(tab, qv0, tv0), tab_at(tab, qv1, tv1)};
-                    const s16x2 hu = pk_shl1z(HA), fu = pk_shl1z(FA);
+                    const s16x2 hu = edge_r(pk_shl1z(HA)), fu = edge_r(pk_shl1z(FA));
                     const s16x2 e_ext = EA - ext2, f_ext = fu - ext2;
                     const s16x2 E = pk_max(e_ext, HA), F = pk_max(f_ext, hu);
                     const s16x2 h = HB + sub;
@@ -435,32 +511,40 @@ __device__ __forceinline__ void sw_two_pk16_trace(const SwArgs &a, uint64_t c0, 
             vq0 += 4; vq1 += 4; vt0 += 4; vt1 += 4;
             if (half == 0) { loA = accA; loB = accB; }
         }
-        // word of candidate 0 = low halves (first four cells | next four cells), candidate 1 = high halves
+        // word of the low-half candidate = low halves (first four cells | next four cells), of the high-half candidate = high halves
         const uint32_t la = __builtin_bit_cast(uint32_t, loA), ha = __builtin_bit_cast(uint32_t, accA);
         const uint32_t lb = __builtin_bit_cast(uint32_t, loB), hb = __builtin_bit_cast(uint32_t, accB);
-        if (b < g0.nblk) dir0[(size_t)b * 64 + lane] = make_uint2(__builtin_amdgcn_perm(ha, la, 0x05040100u), __builtin_amdgcn_perm(hb, lb, 0x05040100u));
-        if (b < g1.nblk) dir1[(size_t)b * 64 + lane] = make_uint2(__builtin_amdgcn_perm(ha, la, 0x07060302u), __builtin_amdgcn_perm(hb, lb, 0x07060302u));
+        if (b < nb0) dir0[(size_t)b * SUB_LANES + ln] = make_uint2(__builtin_amdgcn_perm(ha, la, 0x05040100u), __builtin_amdgcn_perm(hb, lb, 0x05040100u));
+        if (b < nb1 && c1 != c0) dir1[(size_t)b * SUB_LANES + ln] = make_uint2(__builtin_amdgcn_perm(ha, la, 0x07060302u), __builtin_amdgcn_perm(hb, lb, 0x07060302u));
     }
-    // end cell per candidate: earliest step with H == T in the lane, then min i, then min j over the lanes
+    // end cell per candidate: earliest step with H == T in the lane, then min i, then min j over the 32 lanes of the half
     const int fk[2] = {(int)first.x, (int)first.y};
-    const CandGeom *gg[2] = {&g0, &g1};
-    const uint64_t cc[2] = {c0, c1};
     const int TT[2] = {(int)T2.x, (int)T2.y};
+    bool okh[2];
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
+        const int ga0 = hf ? gg[2 + x].a0 : gg[x].a0, gdlo = hf ? gg[2 + x].dlo : gg[x].dlo;
+        const uint64_t c = x ? c1 : c0;
         int bi = 0x7fffffff, bj = 0x7fffffff;
         if (fk[x] < 16 * nb) {                    // (a lane that never reaches T counted every step)
             const int mm = fk[x] >> 1;
-            bi = gg[x]->a0 + mm - lane;
-            bj = gg[x]->a0 + gg[x]->dlo + mm + lane + (fk[x] & 1);
+            bi = ga0 + mm - ln;
+            bj = ga0 + gdlo + mm + ln + (fk[x] & 1);
         }
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) {
+        for (int d = SUB_LANES / 2; d > 0; d >>= 1) {
             const int oi = __shfl_xor(bi, d, 64), oj = __shfl_xor(bj, d, 64);
             if (oi < bi || (oi == bi && oj < bj)) { bi = oi; bj = oj; }
         }
-        if (lane == 0 && (x == 0 || c1 != c0)) a.out[cc[x]] = make_int4(TT[x], bi, bj, gg[x]->a0);
+        okh[x] = bi != 0x7fffffff;
+        if (ln == 0 && okh[x] && (x == 0 || c1 != c0)) {
+            a.out[c] = make_int4(TT[x], bi, bj, ga0);
+            a.mode[c] = hf ? L0[2 + x] : L0[x];
+        }
     }
+    // wave-uniform outcome of all four
+    ok[0] = __shfl((int)okh[0], 0, 64) != 0;  ok[1] = __shfl((int)okh[1], 0, 64) != 0;
+    ok[2] = __shfl((int)okh[0], 32, 64) != 0; ok[3] = __shfl((int)okh[1], 32, 64) != 0;
 }
 
 // score pass: wave w of the grid-stride loop takes the candidate pair (order[2w], order[2w+1]): neighbours in the length order, so the
@@ -492,10 +576,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a
     }
 }
 
-// TRACE = false: score pass over every candidate (max score only, no HBM writes beyond 16 B per candidate)
-// TRACE = true : traceback pass over the pairs that survived best-per-(q,t) and the e-value cut
-template <bool TRACE>
-__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_kernel(SwArgs a)      // 4 waves per SIMD is what the LDS budget allows: keep the VGPRs within that
+// traceback pass over the pairs that survived best-per-(q,t) and the e-value cut: four candidates per wavefront in their sub-bands
+// (packed 16-bit), the 32-bit sweep for anything that does not fit (scores beyond 16 bits, windows beyond the LDS staging area), and the
+// full band for the few alignments that leave their sub-band
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArgs a)      // 4 waves per SIMD is what the LDS budget allows: keep the VGPRs within that
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *lds_tab = reinterpret_cast<uint32_t *>(smem);
@@ -503,32 +587,48 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_kernel(SwArgs a)  
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t *lds_res = reinterpret_cast<uint16_t *>(smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes);
-    if (TRACE && a.pk16 && a.known) {
-        // candidates in pairs (2w, 2w+1), both halves of the packed registers busy; pairs that do not fit 16 bits / the staging area fall back
-        const uint64_t n_pairs = (a.n + 1) / 2;
-        for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < n_pairs; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
-            const uint64_t c0 = a.order[2 * w], c1 = a.order[min(2 * w + 1, a.n - 1)];
-            const CandGeom g0 = cand_geom(a, c0), g1 = cand_geom(a, c1);
-            const int nb = max(g0.nblk, g1.nblk);
-            const int need = 4 * 2 * ((8 * nb + 80 + 7) & ~7);
-            if (c1 != c0 && fits16(g0, a.max_sub) && fits16(g1, a.max_sub) && need <= a.lds_res_bytes && nb < 2040 && a.known[c0] > 0 && a.known[c1] > 0) {
-                sw_two_pk16_trace(a, c0, c1, g0, g1, smem, lds_res, lane);
-            } else {
-                for (int x = 0; x < (c1 != c0 ? 2 : 1); ++x) {
-                    const uint64_t c = x ? c1 : c0;
-                    const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
-                    if (need1 <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, smem, lds_res, lane);
-                    else sw_one<false, TRACE>(a, c, smem, lds_res, lane);
-                }
+    auto one = [&](uint64_t c) {
+        const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
+        if (need1 <= a.lds_res_bytes) trace_one<true>(a, c, smem, lds_res, lane);
+        else trace_one<false>(a, c, smem, lds_res, lane);
+    };
+    const uint64_t n_items = (a.n + 3) / 4;
+    for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < n_items; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
+        uint64_t cc[4];
+        int n_own = 0;                                       // candidates of this item (the last item may hold fewer than four)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { const uint64_t k = 4 * w + x; cc[x] = a.order[min(k, a.n - 1)]; n_own += k < a.n ? 1 : 0; }
+        bool packed = a.pk16 && a.known && a.end_lane && n_own == 4;
+        SubGeom gg[4];
+        int L0[4];
+        if (packed) {
+            int nb = 0;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const CandGeom g = cand_geom(a, cc[x]);
+                L0[x] = sub_band_first_lane(a.end_lane[cc[x]]);
+                gg[x] = sub_geom(g, L0[x]);
+                nb = max(nb, gg[x].nblk);
+                packed = packed && fits16(g, a.max_sub) && a.known[cc[x]] > 0;
             }
+            packed = packed && 8 * 2 * ((8 * nb + SUB_LANES + 16 + 7) & ~7) <= a.lds_res_bytes && nb < 2040;
         }
-        return;
-    }
-    for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < a.n; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
-        const uint64_t c = a.order[w];
-        const int need = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
-        if (need <= a.lds_res_bytes) sw_one<true, TRACE>(a, c, smem, lds_res, lane);
-        else sw_one<false, TRACE>(a, c, smem, lds_res, lane);
+        if (packed) {
+            bool ok[4];
+            sw_four_pk16_trace(a, cc, gg, L0, ok, smem, lds_res, lane);
+#pragma unroll 1
+            for (int x = 0; x < 4; ++x)
+                if (!ok[x]) {                                // left its sub-band: once more in the full band
+                    const uint64_t c = cc[x];
+                    const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
+                    if (need1 <= a.lds_res_bytes) sw_one<true, true>(a, c, smem, lds_res, lane, -1);
+                    else sw_one<false, true>(a, c, smem, lds_res, lane, -1);
+                    if (lane == 0) a.mode[c] = -1;
+                }
+        } else {
+#pragma unroll 1
+            for (int x = 0; x < n_own; ++x) one(cc[x]);
+        }
     }
 }
 
@@ -634,7 +734,7 @@ int pep_selftest_dpp(pep_ctx *ctx)
 
 // Runs K5 over `n` candidate keys.  trace = false: score pass (ws[12] <- score / end cell / a0 per candidate).
 // trace = true: same DP plus traceback codes (ws[11] dir_off u64[n+1], ws[13] dirs).  ws[10] nblk, ws[14] scan input.
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known)
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known, const int32_t *d_end_lane)
 {
     const pep_search_params &P = ctx->params;
     if (n == 0) return PEP_OK;
@@ -666,6 +766,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
         ctx->stats.cells_swept_trace += total_blk * 16 * 64;
         ctx->stats.dir_bytes += total_blk * 512;
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 512 + 512));
+        PEP_TRY(dev_reserve(ctx, ctx->d_trace_mode, (n + 1) * sizeof(int32_t)));
     } else {
         PEP_TRY(pep_read_back(ctx, ctx->sw_totals, cells, 16));
         ctx->sw_totals_pending = true;
@@ -685,18 +786,22 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     const uint64_t want = 2 * 2 * ((8 * max_blk + 80 + 7) & ~7ull);
     a.pk16 = (P.use_lds && P.reserved[1] == 0 && (!trace || d_known)) ? 1 : 0;       // reserved[1] != 0 forces the 32-bit passes (tests)
     a.known = trace ? d_known : nullptr;
+    a.end_lane = trace ? d_end_lane : nullptr;
+    a.mode = trace ? ctx->d_trace_mode.as<int32_t>() : nullptr;
     a.order = order;
     a.max_sub = 1;
     for (int x = 0; x < 32 * 32; ++x) a.max_sub = std::max(a.max_sub, (int)P.sub[x]);
-    a.lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, ((a.pk16 ? 2 * want : want) + 255) & ~255ull) : 0;
+    // (the traceback pass stages FOUR candidates' sub-band windows per wavefront: 8 windows of 8 * blocks + 48 entries)
+    const uint64_t want4 = 8 * 2 * ((8 * max_blk + SUB_LANES + 16 + 7) & ~7ull);
+    a.lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, ((a.pk16 ? (trace ? std::max(want4, 2 * want) : 2 * want) : want) + 255) & ~255ull) : 0;
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
     // one item (a packed candidate pair, or one candidate) per wavefront: the hardware's block dispatcher balances the load better than a
     // grid-stride loop inside fewer blocks (score pass 0.82 -> 0.80 ms on the benchmark; traceback pass 0.97 -> 0.96 ms), and the 16 KiB
     // table load per block comes out of the L2
-    const uint64_t items = ceil_div(a.pk16 ? (n + 1) / 2 : n, WAVES_PER_BLOCK);
+    const uint64_t items = ceil_div(trace ? (n + 3) / 4 : (a.pk16 ? (n + 1) / 2 : n), WAVES_PER_BLOCK);
     const unsigned grid = (unsigned)std::min<uint64_t>(items, 256ull * 256);
     pep_timer_begin(ctx, trace ? TM_SW_TRACE : TM_SW);
-    if (trace) hipLaunchKernelGGL(sw_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+    if (trace) hipLaunchKernelGGL(sw_trace_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     else hipLaunchKernelGGL(sw_score_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     pep_timer_end(ctx, trace ? TM_SW_TRACE : TM_SW);
     PEP_HIP(ctx, hipGetLastError());

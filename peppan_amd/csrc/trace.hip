@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
                                                   const uint32_t *__restrict__ best_idx, const int4 *__restrict__ sw,
                                                   const uint64_t *__restrict__ cands, const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len,
                                                   SelInfo *__restrict__ sel, uint64_t *__restrict__ run_cap, uint64_t *__restrict__ sel_keys,
-                                                  int32_t *__restrict__ known)
+                                                  int32_t *__restrict__ known, int32_t *__restrict__ end_lane)
 {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (c >= n || !flag[c]) return;
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
     SelInfo s;
     s.cand = pos[c]; s.score = sw[b].x; s.iend = s.jend = -1;      // the end cell comes from the traceback pass
     sel_keys[pos[c]] = cands[b];
-    known[pos[c]] = sw[b].x;            // the traceback pass looks for the first cell that reaches this score
+    known[pos[c]] = sw[b].x;            // the traceback pass looks for the first cell that reaches this score ...
+    end_lane[pos[c]] = sw[b].y;         // ... in the sub-band around the lane where the score pass met it
     s.istart = s.jstart = 0; s.n_runs = s.aln_len = s.n_ident = 0; s.pass = s.keep = 0; s.pad = 0;
     sel[pos[c]] = s;
     // an alignment has at most 2*min(Lq,Lt)+1 runs (M runs consume a residue of both sequences)
@@ -76,17 +77,21 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
 #define WALK_AHEAD 8
 #define WALK_LANES 64         // alignments per wavefront: few, so that many wavefronts overlap their load latencies (see above)
 __global__ __launch_bounds__(WALK_LANES) void walk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
-                                           const uint64_t *__restrict__ dir_off, const uint32_t *__restrict__ dirs,
+                                           const uint64_t *__restrict__ dir_off, const uint32_t *__restrict__ dirs, const int32_t *__restrict__ mode,
                                            const uint64_t *__restrict__ run_off, uint32_t *__restrict__ runs)
 {
     const uint64_t s = (uint64_t)blockIdx.x * WALK_LANES + threadIdx.x;
     if (s >= n_sel) return;
     SelInfo info = sel[s];
     const uint64_t key = cands[info.cand];
-    const int dlo = key_dlo(key);
+    // the codes cover the full band (64 lanes, mode -1) or the sub-band that starts at lane mode[] (32 lanes): the row of one 16-step
+    // block holds 2 dwords per lane
+    const int md = mode[info.cand];
+    const int dlo = key_dlo(key) + (md > 0 ? 2 * md : 0);
+    const size_t row = md < 0 ? 128 : 64;
     const int4 cell = sw[info.cand];
     const int a0 = cell.w;
-    // word of (block b, diagonal rel): dword ((b * 64 + (rel >> 1)) * 2 + (rel & 1)) of this pair's traceback area
+    // word of (block b, diagonal rel): dword ((b * lanes + (rel >> 1)) * 2 + (rel & 1)) of this pair's traceback area
     const uint32_t *dir = dirs + dir_off[info.cand] * 128;
     uint32_t *out = runs + run_off[s];
 
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(WALK_LANES) void walk(uint64_t n_sel, SelInfo *__re
                 --have;
             } else {
 #pragma unroll
-                for (int k = 0; k < WALK_AHEAD; ++k) w[k] = blk >= k ? col[(size_t)(blk - k) * 128] : 0u;
+                for (int k = 0; k < WALK_AHEAD; ++k) w[k] = blk >= k ? col[(size_t)(blk - k) * row] : 0u;
                 have = WALK_AHEAD;
             }
             cur_rel = rel; cur_blk = blk;
@@ -342,24 +347,24 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     if (n_sel) {
         PEP_TRY(dev_reserve(ctx, ctx->ws[19], (size_t)n_sel * sizeof(SelInfo)));
         PEP_TRY(dev_reserve(ctx, ctx->ws[20], ((size_t)n_sel + 2) * 8 * 3));
-        PEP_TRY(dev_reserve(ctx, ctx->ws[8], ((size_t)n_sel + 2) * 4));      // ws[8]: raw seed hits of K4, free again
-        int32_t *known = ctx->ws[8].as<int32_t>();
+        PEP_TRY(dev_reserve(ctx, ctx->ws[8], ((size_t)n_sel + 2) * 4 * 2));      // ws[8]: raw seed hits of K4, free again
+        int32_t *known = ctx->ws[8].as<int32_t>(), *end_lane = known + n_sel + 2;
         SelInfo *sel = ctx->ws[19].as<SelInfo>();
         uint64_t *run_cap = ctx->ws[20].as<uint64_t>(), *run_off = run_cap + n_sel + 2, *sel_keys = run_off + n_sel + 2;
         hipLaunchKernelGGL(gather_sel, dim3(gb), dim3(256), 0, st, n, (const uint32_t *)flag, (const uint32_t *)pos, (const uint32_t *)best_idx, sw, d_cands,
-                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known);
+                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known, end_lane);
         PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_sel, ctx->ws[7]));
         uint64_t total_runs = 0;
         PEP_TRY(pep_read_back(ctx, &total_runs, run_off + n_sel, 8));       // arrives with the synchronisation inside pep_sw_run (block total)
         // ---- pass 2: the same DP with traceback codes, selected pairs only (overwrites the pass-1 per-candidate arrays)
-        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, known));
+        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, known, end_lane));
         const int4 *sw2 = ctx->ws[12].as<const int4>();
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
         uint32_t *runs = ctx->ws[21].as<uint32_t>();
         const unsigned gw = (unsigned)ceil_div(n_sel, 4);
         const unsigned gfin = (unsigned)ceil_div(n_sel, 256 / FIN_LANES);
         hipLaunchKernelGGL(walk, dim3((unsigned)ceil_div(n_sel, WALK_LANES)), dim3(WALK_LANES), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, sw2, ctx->ws[11].as<const uint64_t>(),
-                           ctx->ws[13].as<const uint32_t>(), (const uint64_t *)run_off, runs);
+                           ctx->ws[13].as<const uint32_t>(), ctx->d_trace_mode.as<const int32_t>(), (const uint64_t *)run_off, runs);
         hipLaunchKernelGGL(finalize, dim3(gfin), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
                            ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(),
                            ctx->t.off.as<const uint32_t>(), (const uint64_t *)run_off, (const uint32_t *)runs, P.min_id_pct, P.min_qcov_pct);
