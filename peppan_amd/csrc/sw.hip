@@ -48,6 +48,7 @@ struct SwArgs {
     const uint32_t *order;         // candidates by decreasing length (sw_order): item w of a launch is order[w] (order[2w], order[2w+1] packed)
     const int32_t *end_lane;       // traceback pass: per candidate the lowest lane (diagonal pair) of the score pass that reached the score
     int32_t *mode;                 // traceback pass, out: first lane L0 of the 64-diagonal sub-band the codes were written for, -1 = the full band
+    unsigned int *queue;           // traceback pass: next item to hand out (the resident wavefronts pull their work from this counter)
 };
 
 // The traceback of a band is taken in the 64-diagonal sub-band around the lane in which the score pass met the band's score (lanes
@@ -592,8 +593,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
         if (need1 <= a.lds_res_bytes) trace_one<true>(a, c, smem, lds_res, lane);
         else trace_one<false>(a, c, smem, lds_res, lane);
     };
+    // The grid is only as large as the chip holds at once and every wavefront PULLS its next item (four candidates) from a counter.
+    // With one item per wavefront and a block per eight items the 80 KB of LDS a block holds came free only when its slowest
+    // wavefront was done: 2.8 of 4 wavefronts per SIMD on average and 64 % VALU utilisation (SQ_WAVE_CYCLES / SQ_INSTS_VALU,
+    // profiles/r02_pmc_counters.txt).  The items are sorted by decreasing length, so the tail of the queue is its shortest work.
     const uint64_t n_items = (a.n + 3) / 4;
-    for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < n_items; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
+    for (;;) {
+        unsigned int wq = 0;
+        if (lane == 0) wq = atomicAdd(a.queue, 1u);
+        const uint64_t w = (uint64_t)__builtin_amdgcn_readfirstlane((int)wq);
+        if (w >= n_items) break;
         uint64_t cc[4];
         int n_own = 0;                                       // candidates of this item (the last item may hold fewer than four)
 #pragma unroll
@@ -788,6 +797,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     a.known = trace ? d_known : nullptr;
     a.end_lane = trace ? d_end_lane : nullptr;
     a.mode = trace ? ctx->d_trace_mode.as<int32_t>() : nullptr;
+    a.queue = reinterpret_cast<unsigned int *>(cells + 2);          // zeroed with the totals above
     a.order = order;
     a.max_sub = 1;
     for (int x = 0; x < 32 * 32; ++x) a.max_sub = std::max(a.max_sub, (int)P.sub[x]);
@@ -799,7 +809,14 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     // grid-stride loop inside fewer blocks (score pass 0.82 -> 0.80 ms on the benchmark; traceback pass 0.97 -> 0.96 ms), and the 16 KiB
     // table load per block comes out of the L2
     const uint64_t items = ceil_div(trace ? (n + 3) / 4 : (a.pk16 ? (n + 1) / 2 : n), WAVES_PER_BLOCK);
-    const unsigned grid = (unsigned)std::min<uint64_t>(items, 256ull * 256);
+    unsigned grid = (unsigned)std::min<uint64_t>(items, 256ull * 256);
+    if (trace) {
+        // resident blocks only (work is pulled from a queue): 160 KB of LDS and four wavefronts per SIMD (the kernel's launch bound) per CU
+        int n_cu = 256;
+        (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16 / WAVES_PER_BLOCK, (160 * 1024) / std::max<size_t>(smem, 1)));
+        grid = (unsigned)std::min<uint64_t>(items, (uint64_t)n_cu * per_cu);
+    }
     pep_timer_begin(ctx, trace ? TM_SW_TRACE : TM_SW);
     if (trace) hipLaunchKernelGGL(sw_trace_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     else hipLaunchKernelGGL(sw_score_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
