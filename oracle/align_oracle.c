@@ -140,7 +140,7 @@ void oracle_default_params(oracle_params *p)
         p->weight[s] = w;
     }
     p->min_id_pct = 0.; p->min_qcov_pct = 0.; p->top_k = 10; p->n_splits = 5;
-    p->ungapped_min = 45; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24;
+    p->ungapped_min = 55; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24;
 }
 
 /* smallest raw score whose e-value m*n*K*exp(-lambda*S) is <= max_evalue

@@ -306,7 +306,7 @@ void pep_default_params(pep_search_params *p)
     p->min_id_pct = 0.; p->min_qcov_pct = 0.; p->top_k = 10; p->n_splits = 5;
     p->dbsize = 5e6; p->max_evalue = 1.;
     p->use_lds = 1;
-    p->ungapped_min = 45; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24;
+    p->ungapped_min = 55; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24;
     p->ka_lambda = 0.267; p->ka_k = 0.041;
 }
 

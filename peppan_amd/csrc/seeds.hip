@@ -29,6 +29,7 @@ struct SeedShape {
 };
 
 constexpr int TILE = 256, TILE_HALO = 32;
+constexpr int FILTER_SHIFT = 5;              // one 64-bit filter word per 2^FILTER_SHIFT buckets: 5 = 2 bits per bucket (2 MiB at 2^23 buckets, L2-resident); 4 bits per bucket lets 3 % instead of 12 % of the foreign keys through but no longer fits the 4 MiB L2 of an XCD beside the rest: seed_match 0.53 -> 0.59 ms
 
 constexpr uint64_t EMPTY = ~0ull;
 constexpr int POS_BITS = 29;
@@ -46,7 +47,7 @@ __device__ __forceinline__ uint32_t hash_u64(uint64_t k, int bits)
 __device__ __forceinline__ uint64_t filter_mask(uint64_t k, int bucket_bits, uint32_t &word)
 {
     const uint64_t h = k * 0x9E3779B97F4A7C15ull;
-    const int wb = bucket_bits - 5;
+    const int wb = bucket_bits - FILTER_SHIFT;
     word = (uint32_t)(h >> (64 - wb));
     return (1ull << ((h >> (58 - wb)) & 63u)) | (1ull << ((h >> (52 - wb)) & 63u));
 }
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
 {
     __shared__ uint32_t pos[4096];
     __shared__ uint64_t ents[PART_CAP];
-    __shared__ unsigned long long fw[128];
+    __shared__ unsigned long long fw[4096 >> FILTER_SHIFT];
     __shared__ uint32_t wave_sum[4];
     const uint32_t c = blockIdx.x, n_coarse = 1u << (bucket_bits - fine_bits), n_fine = 1u << fine_bits;
     // entries before this coarse bucket: every block adds up the (few thousand) counts ahead of it
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
     if (c == n_coarse - 1 && threadIdx.x == 0) start[(size_t)n_coarse << fine_bits] = lo + n;
     if (n > PART_CAP) { if (threadIdx.x == 0) counters[3] = 1u; return; }                                       // host falls back to count -> scan -> fill
     for (uint32_t x = threadIdx.x; x < n_fine; x += 256) pos[x] = 0;
-    for (uint32_t x = threadIdx.x; x < (n_fine >> 5); x += 256) fw[x] = 0;
+    for (uint32_t x = threadIdx.x; x < (n_fine >> FILTER_SHIFT); x += 256) fw[x] = 0;
     __syncthreads();
     const uint32_t fmask = n_fine - 1;
     for (uint32_t x = threadIdx.x; x < n; x += 256) {
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
         atomicAdd(&pos[hash_u64(e >> POS_BITS, bucket_bits) & fmask], 1u);
         uint32_t word;
         const uint64_t m = filter_mask(e >> POS_BITS, bucket_bits, word);
-        atomicOr(&fw[word & ((n_fine >> 5) - 1)], (unsigned long long)m);
+        atomicOr(&fw[word & ((n_fine >> FILTER_SHIFT) - 1)], (unsigned long long)m);
     }
     __syncthreads();
     // exclusive scan of the fine counters: thread t owns n_fine / 256 consecutive counters
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
         run += cnt;
     }
     // this coarse bucket's slice of the filter: 2^(fine_bits - 5) words
-    for (uint32_t x = threadIdx.x; x < (n_fine >> 5); x += 256) filter[((size_t)c << (fine_bits - 5)) + x] = fw[x];
+    for (uint32_t x = threadIdx.x; x < (n_fine >> FILTER_SHIFT); x += 256) filter[((size_t)c << (fine_bits - FILTER_SHIFT)) + x] = fw[x];
     __syncthreads();
     for (uint32_t x = threadIdx.x; x < n; x += 256) {
         const uint64_t e = ents[x];
@@ -629,7 +630,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_buckets + 2) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[2], (Q.total + 1) * sizeof(uint64_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[6], 64));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[9], (n_buckets / 32 + 2) * 8));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[9], ((n_buckets >> FILTER_SHIFT) + 2) * 8));
     unsigned long long *filter = ctx->ws[9].as<unsigned long long>();
     uint32_t *cnt = ctx->ws[0].as<uint32_t>(), *start = ctx->ws[1].as<uint32_t>();
     uint64_t *entries = ctx->ws[2].as<uint64_t>();
@@ -711,7 +712,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
                 PEP_TRY(pep_scan_u32(ctx, cnt, start, n_buckets, ctx->ws[7]));
                 PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
                 PEP_SEED_DISPATCH(seed_fill, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, (const uint32_t *)start, cnt, entries, bucket_bits);
-                PEP_HIP(ctx, hipMemsetAsync(filter, 0, (n_buckets >> 5) * 8, ctx->stream));
+                PEP_HIP(ctx, hipMemsetAsync(filter, 0, (n_buckets >> FILTER_SHIFT) * 8, ctx->stream));
                 hipLaunchKernelGGL(filter_fill, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)entries, (const uint32_t *)(start + n_buckets), bucket_bits, filter);
             }
             JoinArgs a;
