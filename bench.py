@@ -189,6 +189,24 @@ def main():
         cpu_line.update(gpu_hits_identical=bool(same), hits_compared=int(len(o_hits)))
 
     extras = {}
+    if world == 1 and rank == 0:
+        # the SAME unit of work as round 1's line: `value` counts the candidate pairs that enter gapped Smith-Waterman, and since round 2 the
+        # ungapped pre-filter in front of it is stricter (threshold 55 instead of 45: 39 % fewer candidates, identical hit table - DESIGN.md
+        # section 2).  For comparison across rounds the same timed loop is run once more with the round-1 threshold.
+        p45 = N.default_params(min_id, min_qcov, 10, 5, ungapped_min=45)
+        keep = shard.params
+        shard.params = p45
+        step(); step()
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        c45 = 0.0
+        for _ in range(args.steps):
+            c45 += step()[0]['candidates']
+        torch.cuda.synchronize()
+        d45 = time.perf_counter() - t5
+        shard.params = keep
+        extras['same_unit_as_round1'] = {'ungapped_min': 45, 'value': c45 / d45, 'unit': 'gene-pairs/s', 'ms_per_step': d45 / args.steps * 1e3,
+                                         'candidates_per_step': c45 / args.steps}
     if rank == 0 and world == 1 and not args.no_e2e:
         # (a) the step with the host buffers handed over inside it (H2D of the nucleotides): what the C boundary costs a caller
         reps = max(3, min(args.steps, 10))
@@ -265,7 +283,9 @@ def main():
                        'parallelism': 'grid %d query shards x %d reference shards, all-gather + top-k merge of the hit tables' % (shard.R, shard.C)},
             'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3) if acc['ms_sw'] else None,
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
-            'hits_per_step': float(len(allh)), 'clusters': int(len(np.unique(labels))),
+            'hits_per_step': float(len(allh)), 'clusters': int(len(np.unique(labels))), 'candidates_per_step': acc['candidates'] / K,
+            'value_definition': 'candidate (query, target-frame, band) pairs entering gapped Smith-Waterman per second of step wall time (SURVEY.md 8d-i); '
+                                'the pre-filter in front of that stage decides how many there are - see same_unit_as_round1',
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
             'roofline': top, 'roofline_kernels': rl,
             'cpu_baseline': cpu_line if world == 1 else None,

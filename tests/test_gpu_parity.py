@@ -387,7 +387,7 @@ def test_full_size_10k_properties(ctx):
     h3, c3, s3 = ctx.search(p)                                                  # determinism across runs
     for h, c in ((h2, c2), (h3, c3)):
         assert np.array_equal(h1, h) and np.array_equal(c1, c)
-    assert len(h1) > 30000 and s1['candidates'] > 70000
+    assert len(h1) > 30000 and s1['candidates'] > 40000
     qm, tm = ctx.query_meta(), ctx.target_meta()
     # ordered by (q, t), at most top_k per (q, split)
     key = h1['q'].astype(np.int64) * (1 << 32) + h1['t']
