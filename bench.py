@@ -265,7 +265,7 @@ def main():
         ms_sw, ms_tr, ms_match = acc['ms_sw'] / K, acc['ms_sw_trace'] / K, acc['ms_seed_match'] / K / max(1, n_shapes)
         # algorithmic bytes per launch, SURVEY.md 8(d): SW = sum over pairs of (Lq + Lr) residue bytes + 64 B per reported hit;
         # seed join = 1 B + 8 B index entry per target residue + 8 B per raw seed hit
-        rl = [entry('sw_kernel<true>', 'K5 traceback pass: banded SW + 4-bit codes over the selected pairs', ms_tr, (acc['tracebacks'] / K) * 2 * Lq + hits_step * 64, 'v'),
+        rl = [entry('sw_trace_kernel', 'K5 traceback pass: sub-band SW + 4-bit codes over the selected pairs, four per wavefront', ms_tr, (acc['tracebacks'] / K) * 2 * Lq + hits_step * 64, 'v'),
               entry('sw_score_kernel', 'K5 score pass: banded SW over all candidate pairs', ms_sw, (acc['candidates'] / K) * 2 * Lq + hits_step * 64, 'v'),
               entry('seed_match<10>', 'K4a: target seeds streamed through the query index (one launch per seed shape)', ms_match,
                     9.0 * acc['target_residues'] / K + 8.0 * acc['seed_hits'] / K / max(1, n_shapes))]

@@ -1,9 +1,13 @@
 // K7: nucleotide rescoring counts (mode 1 of the reference's cigar2score, uberBlast.py:226-249, called from
 // RunBlast.reScore uberBlast.py:397-415).  One wavefront per hit walks the nt CIGAR; the 64 lanes stride over the
-// columns of every M run (16 per lane and trip) comparing encoded bases (A0 C1 G3 T4 other 2, uberBlast.py:270-271; a reverse-strand hit
+// columns of every M run comparing encoded bases (A0 C1 G3 T4 other 2, uberBlast.py:270-271; a reverse-strand hit
 // reads the reference backwards as 4 - code, uberBlast.py:412).  Integer outputs only: the float identity / score
 // and numpy's round-half-even are applied on the host in float64 exactly as the reference does.
-// HBM-bound scan: 2 x aligned length bytes read per hit.
+// Scan of 2 x aligned length bytes per hit; the sequences of a search (tens of MB) stay in the L2 / Infinity Cache, so what bounds it is
+// the latency of the byte loads, not HBM bandwidth.  Tried in round 2 and dropped: 16 columns per lane and trip through unaligned 16-byte
+// loads (+ a byte-swapped window for reverse-strand hits) - 2 to 2.7x SLOWER (216 - 290 us instead of 107 us per call on the mapping
+// workload of tools/other_kernels.py): the unaligned wide loads are split by the memory pipeline and the per-byte decoding then costs
+// more than the 16 short trips of the byte version.
 #include "common.h"
 
 namespace {
@@ -19,21 +23,17 @@ __device__ __forceinline__ int enc(uint8_t ch)
     }
 }
 
-// One wavefront per hit.  Inside an M run every lane takes 16 columns per trip (one unaligned 16-byte load from each sequence: a
-// wavefront covers 1 024 columns per trip - most M runs in one), reverse-strand hits read their 16 bytes from the other end;
-// byte loads serve the last columns of a run and anything within 16 bytes of the ends of the concatenations.
 __global__ __launch_bounds__(256) void k7_rescore(uint64_t n, const pep_nt_hit *__restrict__ hits, const uint32_t *__restrict__ cigar,
-                                                  const uint8_t *__restrict__ q_nt, const uint64_t *__restrict__ q_off, uint64_t q_total,
-                                                  const uint8_t *__restrict__ r_nt, const uint64_t *__restrict__ r_off, uint64_t r_total,
-                                                  long long *__restrict__ out)
+                                                  const uint8_t *__restrict__ q_nt, const uint64_t *__restrict__ q_off,
+                                                  const uint8_t *__restrict__ r_nt, const uint64_t *__restrict__ r_off, long long *__restrict__ out)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t h = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (h >= n) return;
     const pep_nt_hit hit = hits[h];
-    const long long qb = (long long)q_off[hit.q], rb = (long long)r_off[hit.r];        // positions inside the concatenations
+    const uint8_t *q = q_nt + q_off[hit.q], *r = r_nt + r_off[hit.r];
     const bool rev = hit.rs > hit.re;
-    long long qi = qb + (long long)hit.qs - 1, ri = rb + (long long)hit.rs - 1;
+    long long qi = (long long)hit.qs - 1, ri = (long long)hit.rs - 1;
     long long nmatch = 0, ncol = 0, ngap = 0, bgap = 0, mgap = 0;
     const uint32_t *cg = cigar + hit.cigar_off;
     for (uint32_t k = 0; k < hit.cigar_runs; ++k) {
@@ -41,30 +41,10 @@ __global__ __launch_bounds__(256) void k7_rescore(uint64_t n, const pep_nt_hit *
         const long long len = run >> 2;
         const uint32_t op = run & 3u;
         if (op == 0) {
-            for (long long x = (long long)lane * 16; x < len; x += 64 * 16) {
-                const long long todo = len - x < 16 ? len - x : 16;
-                const long long qa = qi + x, ra = rev ? ri - x - 15 : ri + x;              // first byte of the two 16-byte windows
-                if (todo == 16 && qa + 16 <= (long long)q_total && ra >= 0 && ra + 16 <= (long long)r_total) {
-                    uint32_t qw[4], rl[4], rw[4];
-                    __builtin_memcpy(qw, q_nt + qa, 16);
-                    __builtin_memcpy(rl, r_nt + ra, 16);
-                    // a reverse-strand window is turned round as a whole (byte swap of every dword, dwords in reverse order) so that the
-                    // compare loop indexes both windows with compile-time constants - a run-time byte index would push them out of registers
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) rw[w] = rev ? __builtin_bswap32(rl[3 - w]) : rl[w];
-#pragma unroll
-                    for (int c = 0; c < 16; ++c) {
-                        const int a = enc((uint8_t)(qw[c >> 2] >> ((c & 3) * 8)));
-                        const int e = enc((uint8_t)(rw[c >> 2] >> ((c & 3) * 8)));
-                        nmatch += (a == (rev ? 4 - e : e)) ? 1 : 0;
-                    }
-                } else {
-                    for (long long c = 0; c < todo; ++c) {
-                        const int a = enc(q_nt[qa + c]);
-                        const int e = rev ? 4 - enc(r_nt[ri - x - c]) : enc(r_nt[ri + x + c]);
-                        nmatch += (a == e) ? 1 : 0;
-                    }
-                }
+            for (long long x = lane; x < len; x += 64) {
+                const int a = enc(q[qi + x]);
+                const int b = rev ? 4 - enc(r[ri - x]) : enc(r[ri + x]);
+                nmatch += (a == b) ? 1 : 0;
             }
             ncol += len;
             qi += len; ri += rev ? -len : len;
@@ -108,7 +88,7 @@ int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uin
     PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[0].p, h_hits, n * sizeof(pep_nt_hit), hipMemcpyHostToDevice, ctx->stream));
     PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[1].p, h_cigar, n_cigar * 4, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k7_rescore, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, n, ctx->ws[0].as<const pep_nt_hit>(), ctx->ws[1].as<const uint32_t>(),
-                       ctx->q_nt.nt.as<const uint8_t>(), ctx->q_nt.off.as<const uint64_t>(), ctx->q_nt.total, ctx->r_nt.nt.as<const uint8_t>(), ctx->r_nt.off.as<const uint64_t>(), ctx->r_nt.total,
+                       ctx->q_nt.nt.as<const uint8_t>(), ctx->q_nt.off.as<const uint64_t>(), ctx->r_nt.nt.as<const uint8_t>(), ctx->r_nt.off.as<const uint64_t>(),
                        ctx->ws[2].as<long long>());
     PEP_HIP(ctx, hipGetLastError());
     PEP_HIP(ctx, hipMemcpyAsync(h_out, ctx->ws[2].p, n * 5 * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -49,6 +49,9 @@ struct SwArgs {
     const int32_t *end_lane;       // traceback pass: per candidate the lowest lane (diagonal pair) of the score pass that reached the score
     int32_t *mode;                 // traceback pass, out: first lane L0 of the 64-diagonal sub-band the codes were written for, -1 = the full band
     unsigned int *queue;           // traceback pass: next item to hand out (the resident wavefronts pull their work from this counter)
+    uint64_t item_first;           // traceback pass: this launch covers order[item_first .. item_first + item_count), item_span candidates per item
+    uint64_t item_count;
+    int item_span;                 // 4: packed sub-band sweep of four candidates, 1: one candidate per wavefront (pairs too long for the staging area)
 };
 
 // The traceback of a band is taken in the 64-diagonal sub-band around the lane in which the score pass met the band's score (lanes
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
     // With one item per wavefront and a block per eight items the 80 KB of LDS a block holds came free only when its slowest
     // wavefront was done: 2.8 of 4 wavefronts per SIMD on average and 64 % VALU utilisation (SQ_WAVE_CYCLES / SQ_INSTS_VALU,
     // profiles/r02_pmc_counters.txt).  The items are sorted by decreasing length, so the tail of the queue is its shortest work.
-    const uint64_t n_items = (a.n + 3) / 4;
+    const uint64_t n_items = (a.item_count + a.item_span - 1) / a.item_span;
     for (;;) {
         unsigned int wq = 0;
         if (lane == 0) wq = atomicAdd(a.queue, 1u);
@@ -606,7 +609,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
         uint64_t cc[4];
         int n_own = 0;                                       // candidates of this item (the last item may hold fewer than four)
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { const uint64_t k = 4 * w + x; cc[x] = a.order[min(k, a.n - 1)]; n_own += k < a.n ? 1 : 0; }
+        for (int x = 0; x < 4; ++x) {
+            const uint64_t k = (uint64_t)a.item_span * w + x;
+            const bool own = x < a.item_span && k < a.item_count;
+            cc[x] = a.order[a.item_first + min(k, a.item_count - 1)];
+            n_own += own ? 1 : 0;
+        }
         bool packed = a.pk16 && a.known && a.end_lane && n_own == 4;
         SubGeom gg[4];
         int L0[4];
@@ -644,14 +652,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
 // per candidate: number of 8-step blocks and the exact count of in-band in-matrix cells
 __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cands, uint64_t n, const uint32_t *__restrict__ q_len,
                                                const uint32_t *__restrict__ t_len, uint32_t *__restrict__ nblk, uint64_t *__restrict__ nblk64,
-                                               unsigned long long *__restrict__ cells_total,           // [0] cells, [1] 16-step blocks
-                                               uint32_t *__restrict__ len_hist)                        // [LEN_BUCKETS] candidates per length bucket
+                                               unsigned long long *__restrict__ cells_total,           // [0] cells, [1] 16-step blocks, [3] candidates above nb_limit
+                                               uint32_t *__restrict__ len_hist,                        // [LEN_BUCKETS] candidates per length bucket
+                                               uint32_t nb_limit)
 {
     __shared__ uint32_t lh[LEN_BUCKETS];
     for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) lh[x] = 0;
     __syncthreads();
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long cells = 0, blocks = 0;
+    bool is_long = false;
     if (c < n) {
         const uint64_t key = cands[c];
         const uint32_t q = (uint32_t)(key >> 43), t = (uint32_t)((key >> 18) & ((1u << 25) - 1));
@@ -672,8 +682,11 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
         nblk[c] = nb;
         nblk64[c] = nb;
         blocks = nb;
+        is_long = nb > nb_limit;
         atomicAdd(&lh[len_bucket(nb)], 1u);
     }
+    const int longs = __syncthreads_count(is_long);
+    if (threadIdx.x == 0 && longs) atomicAdd(&cells_total[3], (unsigned long long)longs);
     // totals: one pair of atomics per block (every wavefront adding to the same two words serialises in the L2)
     __shared__ unsigned long long tot[2][4];
     for (int d = 32; d > 0; d >>= 1) { cells += __shfl_down(cells, d, 64); blocks += __shfl_down(blocks, d, 64); }
@@ -752,16 +765,33 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     PEP_TRY(dev_reserve(ctx, ctx->ws[14], (n + 2) * sizeof(uint64_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[12], (n + 1) * sizeof(int4)));
     if (n >= (1ull << 32)) return pep_fail(ctx, PEP_ERR_LIMIT, "pep_sw_run: more than 2^32 candidates in one launch");
-    // ws[15]: [0..15] cell / block totals, [64..) length histogram, then the scatter cursors, then the order itself
+    // per-wave staging area (u16 per residue; score pass: query + target windows of two candidates, traceback pass: of four candidates'
+    // sub-bands), sized for the longest possible pair, capped at 8 KiB: two blocks of eight wavefronts per CU next to their table images
+    const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 16 + 2;
+    const uint64_t want = 2 * 2 * ((8 * max_blk + 80 + 7) & ~7ull);
+    const uint64_t want4 = 8 * 2 * ((8 * max_blk + SUB_LANES + 16 + 7) & ~7ull);
+    const int pk16 = (P.use_lds && P.reserved[1] == 0 && (!trace || d_known)) ? 1 : 0;       // reserved[1] != 0 forces the 32-bit passes (tests)
+    const int lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, ((pk16 ? (trace ? std::max(want4, 2 * want) : 2 * want) : want) + 255) & ~255ull) : 0;
+    // traceback pass: the four-candidate sweep stages 8 windows of 8 * blocks + 48 entries; candidates with more 16-step blocks than fit
+    // are swept one per wavefront.  The order below is by decreasing length, so they are a prefix of it.
+    uint32_t nb_limit = 0;
+    if (trace && pk16) {
+        const int entries = lds_res_bytes / (8 * 2);
+        nb_limit = entries > SUB_LANES + 16 + 8 ? (uint32_t)((entries - SUB_LANES - 16) / 8 - 1) : 0;     // (the sub-band may need one block more than the band)
+        nb_limit = std::min<uint32_t>(nb_limit, LEN_BUCKETS - 2);
+    }
+    // ws[15]: [0..63] totals (cells, 16-step blocks, work-queue counters, candidates above nb_limit), [64..) length histogram, then the
+    // scatter cursors, then the order itself
     const size_t hist_bytes = LEN_BUCKETS * sizeof(uint32_t);
     PEP_TRY(dev_reserve(ctx, ctx->ws[15], 64 + 2 * hist_bytes + (n + 1) * sizeof(uint32_t)));
     unsigned long long *cells = ctx->ws[15].as<unsigned long long>();
     uint32_t *len_hist = reinterpret_cast<uint32_t *>(ctx->ws[15].as<unsigned char>() + 64), *cursor = len_hist + LEN_BUCKETS, *order = cursor + LEN_BUCKETS;
     PEP_HIP(ctx, hipMemsetAsync(cells, 0, 64 + 2 * hist_bytes, ctx->stream));
     hipLaunchKernelGGL(sw_prep, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_cands, n, ctx->q.len.as<const uint32_t>(),
-                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist);
+                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist, nb_limit);
     hipLaunchKernelGGL(sw_order, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[10].as<const uint32_t>(), n,
                        (const uint32_t *)len_hist, cursor, order);
+    unsigned long long n_long = 0;
     if (trace) {
         // the traceback area is sized from the block total, so the host has to see it before the launch; the score pass needs neither
         // the per-candidate offsets nor the totals up front (they reach the statistics with the next synchronisation, see pep_extend)
@@ -769,6 +799,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
         unsigned long long h_cells = 0;
         PEP_TRY(pep_read_back(ctx, &h_cells, cells, 8));
         PEP_TRY(pep_read_back(ctx, &total_blk, cells + 1, 8));
+        PEP_TRY(pep_read_back(ctx, &n_long, cells + 3, 8));
         PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
         PEP_TRY(pep_sync_reads(ctx));
         ctx->stats.cells_trace += h_cells;
@@ -776,6 +807,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
         ctx->stats.dir_bytes += total_blk * 512;
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 512 + 512));
         PEP_TRY(dev_reserve(ctx, ctx->d_trace_mode, (n + 1) * sizeof(int32_t)));
+        if (!pk16) n_long = n;
     } else {
         PEP_TRY(pep_read_back(ctx, ctx->sw_totals, cells, 16));
         ctx->sw_totals_pending = true;
@@ -790,36 +822,41 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     a.dir_off = ctx->ws[11].as<const uint64_t>(); a.nblk = ctx->ws[10].as<const uint32_t>();
     a.dirs = trace ? ctx->ws[13].as<uint32_t>() : nullptr; a.out = ctx->ws[12].as<int4>();
     a.oe = P.gap_open + P.gap_ext; a.ext = P.gap_ext;
-    // per-wave staging window (u16 per residue, query + target), sized for the longest possible pair, capped at 8 KiB
-    const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 16 + 2;
-    const uint64_t want = 2 * 2 * ((8 * max_blk + 80 + 7) & ~7ull);
-    a.pk16 = (P.use_lds && P.reserved[1] == 0 && (!trace || d_known)) ? 1 : 0;       // reserved[1] != 0 forces the 32-bit passes (tests)
+    a.pk16 = pk16;
     a.known = trace ? d_known : nullptr;
     a.end_lane = trace ? d_end_lane : nullptr;
     a.mode = trace ? ctx->d_trace_mode.as<int32_t>() : nullptr;
-    a.queue = reinterpret_cast<unsigned int *>(cells + 2);          // zeroed with the totals above
+    a.queue = nullptr; a.item_first = 0; a.item_count = 0; a.item_span = 4;
     a.order = order;
     a.max_sub = 1;
     for (int x = 0; x < 32 * 32; ++x) a.max_sub = std::max(a.max_sub, (int)P.sub[x]);
-    // (the traceback pass stages FOUR candidates' sub-band windows per wavefront: 8 windows of 8 * blocks + 48 entries)
-    const uint64_t want4 = 8 * 2 * ((8 * max_blk + SUB_LANES + 16 + 7) & ~7ull);
-    a.lds_res_bytes = P.use_lds ? (int)std::min<uint64_t>(8192, ((a.pk16 ? (trace ? std::max(want4, 2 * want) : 2 * want) : want) + 255) & ~255ull) : 0;
+    a.lds_res_bytes = lds_res_bytes;
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
-    // one item (a packed candidate pair, or one candidate) per wavefront: the hardware's block dispatcher balances the load better than a
-    // grid-stride loop inside fewer blocks (score pass 0.82 -> 0.80 ms on the benchmark; traceback pass 0.97 -> 0.96 ms), and the 16 KiB
-    // table load per block comes out of the L2
-    const uint64_t items = ceil_div(trace ? (n + 3) / 4 : (a.pk16 ? (n + 1) / 2 : n), WAVES_PER_BLOCK);
-    unsigned grid = (unsigned)std::min<uint64_t>(items, 256ull * 256);
+    pep_timer_begin(ctx, trace ? TM_SW_TRACE : TM_SW);
     if (trace) {
-        // resident blocks only (work is pulled from a queue): 160 KB of LDS and four wavefronts per SIMD (the kernel's launch bound) per CU
+        // resident blocks only: every wavefront pulls its next item from a counter.  160 KB of LDS and four wavefronts per SIMD (the
+        // kernel's launch bound) per CU
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
         const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16 / WAVES_PER_BLOCK, (160 * 1024) / std::max<size_t>(smem, 1)));
-        grid = (unsigned)std::min<uint64_t>(items, (uint64_t)n_cu * per_cu);
+        struct { uint64_t first, count; int span; unsigned int *queue; } part[2] = {
+            {0, (uint64_t)std::min<unsigned long long>(n_long, n), 1, reinterpret_cast<unsigned int *>(cells + 2)},          // too long for the staging area: one per wavefront
+            {(uint64_t)std::min<unsigned long long>(n_long, n), n - (uint64_t)std::min<unsigned long long>(n_long, n), 4, reinterpret_cast<unsigned int *>(cells + 4)}};
+        for (const auto &pt : part) {
+            if (pt.count == 0) continue;
+            a.item_first = pt.first; a.item_count = pt.count; a.item_span = pt.span; a.queue = pt.queue;
+            const uint64_t items = ceil_div(ceil_div(pt.count, (uint64_t)pt.span), WAVES_PER_BLOCK);
+            const unsigned grid = (unsigned)std::min<uint64_t>(items, (uint64_t)n_cu * per_cu);
+            hipLaunchKernelGGL(sw_trace_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+        }
+    } else {
+        // one item (a packed candidate pair, or one candidate) per wavefront: the hardware's block dispatcher balances the load better than a
+        // grid-stride loop inside fewer blocks (score pass 0.82 -> 0.80 ms on the benchmark), and the 16 KiB table load per block comes out
+        // of the L2
+        const uint64_t items = ceil_div(a.pk16 ? (n + 1) / 2 : n, WAVES_PER_BLOCK);
+        const unsigned grid = (unsigned)std::min<uint64_t>(items, 256ull * 256);
+        hipLaunchKernelGGL(sw_score_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     }
-    pep_timer_begin(ctx, trace ? TM_SW_TRACE : TM_SW);
-    if (trace) hipLaunchKernelGGL(sw_trace_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
-    else hipLaunchKernelGGL(sw_score_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     pep_timer_end(ctx, trace ? TM_SW_TRACE : TM_SW);
     PEP_HIP(ctx, hipGetLastError());
     ctx->stats.sw_launches += 1;
