@@ -378,7 +378,7 @@ class RunBlast(object):
         ctx = get_context(self.device)
         self._ensure_nt(ctx, 6 if frames == '7' else 3)
         params = N.default_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100., top_k=nhits, n_splits=5,
-                                  dbsize=5000000., max_evalue=1.)
+                                  dbsize=5000000., max_evalue=1., sensitive=os.environ.get('PEPPAN_HIP_SENSITIVE') == '1')
         hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
         q_len = [len(self.qrySeq[n]) for n in self.q_names]
         r_len = [len(self.refSeq[n]) for n in self.r_names]

@@ -1061,3 +1061,24 @@ def test_query_index_partition_build_equals_plain_build(ctx):
             h, c, st = ctx.search(p)
             out.append((h.tobytes(), c.tobytes(), st['query_seeds'], st['target_seeds'], st['seed_hits'], st['candidates'], st['pairs']))
         assert out[0] == out[1] and len(out[0][0]) > 64 * 100
+
+
+def test_sensitive_mode_four_shapes_vs_oracle(ctx):
+    """default_params(sensitive=True): four seed shapes through K2-K4 (one index build + join per shape into one candidate set), every
+    field equal to the oracle run with the same parameter block"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    names, seqs = synth.make_genes(1200, 0, seed=19)
+    ctx.set_query_nt(seqs, 11)
+    ctx.set_ref_nt(seqs, 6, 11)
+    p = N.default_params(45., 25., 10, 5, sensitive=True)
+    assert p.n_shapes == 4
+    gh, gc, st = ctx.search(p)
+    base_h, _, base_st = ctx.search(N.default_params(45., 25., 10, 5))
+    qa, qo = ctx.query_aa()
+    ta, to = ctx.target_aa()
+    q_aa = [qa[qo[i]:qo[i + 1]] for i in range(len(qo) - 1)]
+    t_aa = [ta[to[i]:to[i + 1]] for i in range(len(to) - 1)]
+    oh, oc, ost = O.search(q_aa, t_aa, O.params_from(p))
+    _cmp_hits(gh, gc, oh, oc)
+    assert st['candidates'] == ost['candidates'] and st['candidates'] >= base_st['candidates'] and len(gh) >= len(base_h) > 3000

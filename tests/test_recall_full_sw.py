@@ -91,3 +91,18 @@ def test_nucleotide_search_recall_and_optimality():
     assert r['lost_to_ungapped_filter'] == 0, r            # with the filter off (every shared 17-mer aligned) nothing more is found
     assert r['bins']['>=0.9']['truth'] >= 90 and r['bins']['>=0.9']['recall'] >= 0.99, r
     assert r['found_of_truth'] + r['lost_to_seeding'] == r['truth_pairs']
+
+
+def test_sensitive_mode_closes_most_of_the_low_identity_gap():
+    """four seed shapes (peppan_amd._native.default_params(sensitive=True)): recall between 0.45 and 0.7 identity >= 0.97 on configs[1]"""
+    from oracle import oracle as O
+    from peppan_amd import _native as N
+    q, t, p, ms, q_idx, desc = R.workload('protein1k_sample')
+    N.set_shapes(p, ['111101110111', '111011010010111'] + list(N.SENSITIVE_SHAPES))
+    r = R.report(q, t, p, ms, q_idx[:160])
+    print(r)
+    assert r['reported_above_optimum'] == 0 and r['reported_below_optimum'] <= 0.005 * r['reported_pairs']
+    assert r['bins']['0.45-0.7']['truth'] > 100 and r['bins']['0.45-0.7']['recall'] >= 0.97, r
+    for b in ('>=0.9', '0.7-0.9'):
+        assert r['bins'][b]['recall'] >= 0.99, r
+    assert list(O.params_from(N.default_params(sensitive=True)).weight) == [10, 10, 10, 10]
