@@ -112,7 +112,7 @@ typedef struct {
 
 typedef struct {
     uint64_t query_residues, target_residues;
-    uint64_t query_seeds, target_seeds, seed_hits, seed_hits_passed;
+    uint64_t query_seeds, target_seeds, seed_hits, seed_hits_passed;   /* seed_hits_passed: runs of seed hits whose candidate passed the ungapped filter or was known already */
     uint64_t candidates;          /* unique (q, t, band) */
     uint64_t pairs;               /* unique (q, t) */
     uint64_t tracebacks;

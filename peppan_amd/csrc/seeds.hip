@@ -333,11 +333,15 @@ __device__ __forceinline__ bool set_contains(const JoinArgs &a, uint64_t k)
 // one per residue; the loops are fully unrolled so that the windows stay in registers.
 __device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *sub, uint32_t qp, uint64_t tp)
 {
+    // The windows are fetched in 16-byte pieces, and only as far as an extension gets: the first 32 residues to the right and the first
+    // 16 to the left up front (one memory latency for nearly every hit), the rest inside the wave-uniform blocks below and only by the
+    // lanes that are still extending.  A chance hit of the reduced alphabet - most of what arrives here once the gene set is large -
+    // dies inside the first pieces, so it costs 96 window bytes instead of 192 (seed_extend is bound by these scattered line fetches).
     uint32_t qr[12], tr[12], ql[12], tl[12];
-    __builtin_memcpy(qr, a.q_res + qp, 48);
-    __builtin_memcpy(tr, a.t_res + tp, 48);
-    __builtin_memcpy(ql, a.q_res + qp - 48, 48);
-    __builtin_memcpy(tl, a.t_res + tp - 48, 48);
+    __builtin_memcpy(qr, a.q_res + qp, 32);
+    __builtin_memcpy(tr, a.t_res + tp, 32);
+    __builtin_memcpy(ql + 8, a.q_res + qp - 16, 16);
+    __builtin_memcpy(tl + 8, a.t_res + tp - 16, 16);
     int s = 0, br = 0, bl = 0;
     bool live = true, pass = false;
     // Straight-line predicated code costs its full length as long as ONE lane of the wave is still extending; most extensions
@@ -346,6 +350,10 @@ __device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *s
 #pragma unroll
     for (int blk8 = 0; blk8 < 6; ++blk8) {
         if (__ballot(live && blk8 * 8 < a.ext_right)) {
+            if (blk8 == 4 && live && 32 < a.ext_right) {             // residues 32..47: third piece of the right windows
+                __builtin_memcpy(qr + 8, a.q_res + qp + 32, 16);
+                __builtin_memcpy(tr + 8, a.t_res + tp + 32, 16);
+            }
 #pragma unroll
             for (int k = blk8 * 8; k < blk8 * 8 + 8; ++k) {
                 if (live && k < a.ext_right) {
@@ -362,6 +370,11 @@ __device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *s
 #pragma unroll
     for (int blk8 = 0; blk8 < 6; ++blk8) {
         if (__ballot(live && blk8 * 8 + 1 <= a.ext_left)) {
+            if ((blk8 == 2 || blk8 == 4) && live && blk8 * 8 + 1 <= a.ext_left) {      // residues 17..32 / 33..48 to the left: the next piece down
+                const int w = blk8 == 2 ? 4 : 0;
+                __builtin_memcpy(ql + w, a.q_res + qp - 48 + 4 * w, 16);
+                __builtin_memcpy(tl + w, a.t_res + tp - 48 + 4 * w, 16);
+            }
 #pragma unroll
             for (int k = blk8 * 8 + 1; k <= blk8 * 8 + 8; ++k) {
                 if (live && k <= a.ext_left) {
@@ -489,14 +502,17 @@ __global__ __launch_bounds__(256) void seed_runs(JoinArgs a, uint64_t *__restric
         const bool leader = valid && !(a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi);
         const unsigned long long leaders = __ballot(leader);
         const unsigned long long valid_m = __ballot(valid);
-        const bool emit_run = leader && !set_contains(a, ck);              // (a candidate of an earlier shape / launch)
+        const unsigned long long above = lane == 63 ? 0ull : (leaders & (~0ull << (lane + 1)));          // next run starts at its lowest set bit
+        const int next = above ? __builtin_ctzll(above) : __popcll(valid_m);                              // valid lanes are a prefix
+        // a run of ONE hit is almost always a chance hit of the reduced alphabet whose candidate is in no set: it goes straight to the
+        // extension (which decides) instead of paying a scattered probe of the set here and another one there; longer runs - homologous
+        // diagonals - are dropped here when their candidate is established already (an earlier run, shape or launch)
+        const bool emit_run = leader && (next - lane == 1 || !set_contains(a, ck));
         const unsigned long long emit_m = __ballot(emit_run);
         uint32_t off = 0;
         if (lane == 0 && emit_m) off = atomicAdd(&s_n, (uint32_t)__popcll(emit_m));
         off = (uint32_t)__shfl((int)off, 0, 64);
         if (emit_run) {
-            const unsigned long long above = lane == 63 ? 0ull : (leaders & (~0ull << (lane + 1)));      // next run starts at its lowest set bit
-            const int next = above ? __builtin_ctzll(above) : __popcll(valid_m);                          // valid lanes are a prefix
             const uint32_t slot = off + (uint32_t)__popcll(emit_m & ((1ull << lane) - 1ull));           // < RUN_BUF: flushed above RUN_BUF / 2, <= 256 per round
             s_first[slot] = h; s_len[slot] = (uint32_t)(next - lane); s_key[slot] = ck;
         }
@@ -530,9 +546,9 @@ __global__ __launch_bounds__(256) void seed_extend(JoinArgs a, const uint64_t *_
     uint32_t n_pass = 0;
     for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (uint64_t)gridDim.x * 256) {
         const uint64_t ck = run_key[r];
-        if (set_contains(a, ck)) { ++n_pass; continue; }
         const uint64_t first = run_first[r];
         const uint32_t len = run_len[r];
+        if (len > 1 && set_contains(a, ck)) { ++n_pass; continue; }          // (single hits: the extension is cheaper than the probe it would save)
         bool pass = a.ungapped_min <= 0;
         for (uint32_t x = 0; x < len && !pass; ++x) {
             const uint64_t hit = a.hits[first + x];
