@@ -157,10 +157,13 @@ def main():
     sync()
     t0 = time.perf_counter()
     keys = ('candidates', 'cells', 'cells_swept', 'cells_swept_trace', 'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total',
-            'hits', 'dir_bytes', 'tracebacks', 'seed_hits', 'target_residues', 'query_residues')
+            'hits', 'dir_bytes', 'tracebacks', 'seed_hits', 'target_residues', 'query_residues', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')
     acc = dict.fromkeys(keys, 0.0)
+    t_uf = 0.0
     for _ in range(args.steps):
+        t_s = time.perf_counter()
         st, allh, allc, labels = step()
+        t_uf += (time.perf_counter() - t_s) * 1e3 - st['ms_host_search'] - st['ms_host_exchange'] - st['ms_host_merge']
         for k in acc:
             acc[k] += st[k]
     sync()
@@ -287,6 +290,7 @@ def main():
             'value_definition': 'candidate (query, target-frame, band) pairs entering gapped Smith-Waterman per second of step wall time (SURVEY.md 8d-i); '
                                 'the pre-filter in front of that stage decides how many there are - see same_unit_as_round1',
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
+            'host_phase_ms_rank0': dict({k: acc[k] / K for k in ('ms_host_search', 'ms_host_exchange', 'ms_host_merge')}, ms_host_union_find=t_uf / K),
             'roofline': top, 'roofline_kernels': rl,
             'cpu_baseline': cpu_line if world == 1 else None,
             'parity_check': parity,

@@ -211,14 +211,22 @@ def linear_merge(q, r, iden, qs, qe, ss, se, score, ql, sl, rid, gap_dist, len_d
     raise PepError('pep_linear_merge: inconsistent sizes')
 
 
-def merge_hits(hits, cigar, top_k, n_splits):
+def merge_hits(hits, cigar, top_k, n_splits, out=None):
     """pep_merge_hits: the union of the hit tables of several TARGET shards (global q / t indices) -> the table of the unsharded
-    search: top-k per (q, t mod n_splits) re-applied, rows ordered by (q, t, bin), CIGAR arena compacted"""
+    search: top-k per (q, t mod n_splits) re-applied, rows ordered by (q, t, bin), CIGAR arena compacted.
+    `out`: optional dict that keeps the output arrays between calls (the result is then only valid until the next call)."""
     lib = load_library()
     hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
     cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
-    out_h = np.empty(max(len(hits), 1), dtype=HIT_DTYPE)
-    out_c = np.empty(max(len(cigar), 1), dtype=np.uint32)
+    if out is None:
+        out_h = np.empty(max(len(hits), 1), dtype=HIT_DTYPE)
+        out_c = np.empty(max(len(cigar), 1), dtype=np.uint32)
+    else:
+        if len(out.get('h', ())) < max(len(hits), 1):
+            out['h'] = np.empty(int(len(hits) * 1.5) + 64, dtype=HIT_DTYPE)
+        if len(out.get('c', ())) < max(len(cigar), 1):
+            out['c'] = np.empty(int(len(cigar) * 1.5) + 64, dtype=np.uint32)
+        out_h, out_c = out['h'], out['c']
     nh, nc = C.c_uint64(), C.c_uint64()
     rc_ = lib.pep_merge_hits(C.c_uint64(len(hits)), _ptr(hits) if len(hits) else None, _ptr(cigar) if len(cigar) else None, C.c_uint64(len(cigar)),
                              C.c_int32(int(top_k)), C.c_int32(int(n_splits)), _ptr(out_h), _ptr(out_c), C.byref(nh), C.byref(nc))

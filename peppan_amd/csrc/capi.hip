@@ -632,47 +632,73 @@ int pep_merge_hits(uint64_t n, const pep_hit *hits, const uint32_t *cigar, uint6
 {
     if (!n_out || !n_cigar_out || top_k < 1 || n_splits < 1 || (n && (!hits || !out_hits)) || (n_cigar && (!cigar || !out_cigar))) return PEP_ERR_ARG;
     *n_out = 0; *n_cigar_out = 0;
-    std::vector<uint64_t> order(n);
+    if (n == 0) return PEP_OK;
+    if (n > 0xFFFFFFFFull) return PEP_ERR_LIMIT;
+    // The input is the concatenation of per-rank tables, each already in (q, t, bin) order, and the ranks of one grid row hold
+    // increasing target ranges: a STABLE counting sort by q alone restores the global order in one linear pass.  Any group that
+    // turns out not to be in (t, bin) order (a caller with another layout) is sorted on its own, so the result never depends on
+    // that property - only the speed does.
+    uint32_t q_hi = 0;
     for (uint64_t i = 0; i < n; ++i) {
-        order[i] = i;
         if (hits[i].cigar_off + hits[i].cigar_runs > n_cigar) return PEP_ERR_ARG;
+        q_hi = std::max(q_hi, hits[i].q);
     }
-    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) {
+    auto by_t = [&](uint32_t a, uint32_t b) {
         const pep_hit &x = hits[a], &y = hits[b];
-        if (x.q != y.q) return x.q < y.q;
         if (x.t != y.t) return x.t < y.t;
         return x.bin < y.bin;
-    });
-    std::vector<uint64_t> grp;
-    std::vector<uint8_t> keep(n, 0);
+    };
+    std::vector<uint32_t> order((size_t)n), first;
+    if ((uint64_t)q_hi <= 64 * n + (1u << 20)) {
+        first.assign((size_t)q_hi + 2, 0);
+        for (uint64_t i = 0; i < n; ++i) ++first[hits[i].q + 1];
+        for (size_t q = 1; q < first.size(); ++q) first[q] += first[q - 1];
+        std::vector<uint32_t> at(first.begin(), first.end() - 1);
+        for (uint64_t i = 0; i < n; ++i) order[at[hits[i].q]++] = (uint32_t)i;
+    } else {
+        for (uint64_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return hits[a].q < hits[b].q; });
+    }
+    std::vector<uint32_t> grp, count((size_t)n_splits);
+    std::vector<uint8_t> drop;                                   // allocated only when some (query, split) exceeds top_k
+    uint64_t no = 0, nc = 0;
     for (uint64_t a = 0; a < n;) {
-        uint64_t b = a;
-        while (b < n && hits[order[b]].q == hits[order[a]].q) ++b;
-        for (int32_t sp = 0; sp < n_splits; ++sp) {
-            grp.clear();
-            for (uint64_t k = a; k < b; ++k)
-                if ((int32_t)(hits[order[k]].t % (uint32_t)n_splits) == sp) grp.push_back(k);
-            if (grp.size() > (size_t)top_k) {
-                std::sort(grp.begin(), grp.end(), [&](uint64_t u, uint64_t v) {
-                    const pep_hit &x = hits[order[u]], &y = hits[order[v]];
+        uint64_t b = a + 1;
+        bool sorted = true;
+        const uint32_t q = hits[order[a]].q;
+        while (b < n && hits[order[b]].q == q) { sorted = sorted && !by_t(order[b], order[b - 1]); ++b; }
+        if (!sorted) std::sort(order.begin() + a, order.begin() + b, by_t);
+        bool over = false;
+        if (b - a > (uint64_t)top_k) {
+            std::fill(count.begin(), count.end(), 0u);
+            for (uint64_t k = a; k < b; ++k) over = (++count[hits[order[k]].t % (uint32_t)n_splits] > (uint32_t)top_k) || over;
+        }
+        if (over) {
+            // the reference's `-k` per database split (uberBlast.py:546-552): best score first, then target order
+            if (drop.empty()) drop.assign((size_t)n, 0);
+            for (int32_t sp = 0; sp < n_splits; ++sp) {
+                if (count[sp] <= (uint32_t)top_k) continue;
+                grp.clear();
+                for (uint64_t k = a; k < b; ++k)
+                    if ((int32_t)(hits[order[k]].t % (uint32_t)n_splits) == sp) grp.push_back(order[k]);
+                std::sort(grp.begin(), grp.end(), [&](uint32_t u, uint32_t v) {
+                    const pep_hit &x = hits[u], &y = hits[v];
                     if (x.score != y.score) return x.score > y.score;
-                    if (x.t != y.t) return x.t < y.t;
-                    return x.bin < y.bin;
+                    return by_t(u, v);
                 });
-                grp.resize((size_t)top_k);
+                for (size_t k = (size_t)top_k; k < grp.size(); ++k) drop[grp[k]] = 1;
             }
-            for (uint64_t k : grp) keep[k] = 1;
+        }
+        for (uint64_t k = a; k < b; ++k) {
+            const uint32_t i = order[k];
+            if (over && drop[i]) continue;
+            pep_hit h = hits[i];
+            if (h.cigar_runs) memcpy(out_cigar + nc, cigar + h.cigar_off, (size_t)h.cigar_runs * sizeof(uint32_t));
+            h.cigar_off = nc;
+            nc += h.cigar_runs;
+            out_hits[no++] = h;
         }
         a = b;
-    }
-    uint64_t no = 0, nc = 0;
-    for (uint64_t k = 0; k < n; ++k) {
-        if (!keep[k]) continue;
-        pep_hit h = hits[order[k]];
-        if (h.cigar_runs) memcpy(out_cigar + nc, cigar + h.cigar_off, (size_t)h.cigar_runs * sizeof(uint32_t));
-        h.cigar_off = nc;
-        nc += h.cigar_runs;
-        out_hits[no++] = h;
     }
     *n_out = no; *n_cigar_out = nc;
     return PEP_OK;

@@ -218,7 +218,14 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
     const uint32_t n = coarse_cnt[c];
     __syncthreads();                                           // wave_sum is used again below
     if (c == n_coarse - 1 && threadIdx.x == 0) start[(size_t)n_coarse << fine_bits] = lo + n;
-    if (n > PART_CAP) { if (threadIdx.x == 0) counters[3] = 1u; return; }                                       // host falls back to count -> scan -> fill
+    if (n > PART_CAP) {
+        // the host falls back to count -> scan -> fill, but the matcher of THIS attempt still runs: leave it well-formed (empty) buckets and
+        // filter words instead of whatever the buffers held before
+        if (threadIdx.x == 0) counters[3] = 1u;
+        for (uint32_t x = threadIdx.x; x < n_fine; x += 256) start[((size_t)c << fine_bits) + x] = lo;
+        for (uint32_t x = threadIdx.x; x < (n_fine >> FILTER_SHIFT); x += 256) filter[((size_t)c << (fine_bits - FILTER_SHIFT)) + x] = 0ull;
+        return;
+    }
     for (uint32_t x = threadIdx.x; x < n_fine; x += 256) pos[x] = 0;
     for (uint32_t x = threadIdx.x; x < (n_fine >> FILTER_SHIFT); x += 256) fw[x] = 0;
     __syncthreads();

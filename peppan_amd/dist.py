@@ -46,31 +46,73 @@ def grid_shape(world):
     return r, world // r
 
 
-def _all_gather_bytes(payload, group, device):
-    """all-gather of one variable-length uint8 array per rank -> list of arrays in rank order (counts first, then padded payloads)"""
+class _Staging(object):
+    """byte buffers of one exchange, kept between steps and grown geometrically: page-locked host memory + device memory when the
+    group runs over RCCL, plain host tensors under gloo.  A step then costs no allocation and no page faults."""
+
+    def __init__(self, device):
+        import torch
+        self.device = device if device is not None else torch.device('cpu')
+        self.on_gpu = self.device.type == 'cuda'
+        self.bufs = {}
+
+    def get(self, name, nbytes, host):
+        import torch
+        t = self.bufs.get(name)
+        if t is None or t.numel() < nbytes:
+            cap = max(1 << 16, int(nbytes * 1.5))
+            if host:
+                t = torch.empty(cap, dtype=torch.uint8, pin_memory=self.on_gpu)
+            else:
+                t = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            self.bufs[name] = t
+        return t[:nbytes]
+
+
+_staging = {}
+
+
+def _staging_for(device):
+    key = str(device)
+    if key not in _staging:
+        _staging[key] = _Staging(device)
+    return _staging[key]
+
+
+def _all_gather_bytes(fill, nbytes, group, device, stage=None):
+    """all-gather of one variable-length byte string per rank: `fill(view)` writes this rank's `nbytes` bytes into a uint8 numpy view of
+    the send buffer.  Returns (flat uint8 numpy view of the receive buffer, slot size, per-rank byte counts); rank r's bytes are
+    flat[r * slot : r * slot + counts[r]].  Two collectives: the byte counts, then the payloads padded to the largest."""
     import torch
     import torch.distributed as dist
+    st = stage if stage is not None else _staging_for(device)
     world = dist.get_world_size(group)
-    n = torch.tensor([payload.size], dtype=torch.int64, device=device)
-    counts = torch.empty(world, dtype=torch.int64, device=device)
+    n = torch.tensor([nbytes], dtype=torch.int64, device=st.device)
+    counts = torch.empty(world, dtype=torch.int64, device=st.device)
     dist.all_gather_into_tensor(counts, n, group=group)
     counts = counts.cpu().numpy()
-    slot = int(counts.max())
+    slot = (int(counts.max()) + 255) & ~255
     if slot == 0:
-        return [np.zeros(0, dtype=np.uint8) for _ in range(world)]
-    buf = np.zeros(slot, dtype=np.uint8)
-    buf[:payload.size] = payload
-    out = torch.empty(slot * world, dtype=torch.uint8, device=device)
-    dist.all_gather_into_tensor(out, torch.from_numpy(buf).to(device), group=group)
-    flat = out.cpu().numpy()
-    return [flat[r * slot:r * slot + int(counts[r])] for r in range(world)]
+        return np.zeros(0, dtype=np.uint8), 0, counts
+    send = st.get('send', slot, host=True)
+    fill(send.numpy()[:nbytes])
+    recv = st.get('recv', slot * world, host=True)
+    if st.on_gpu:
+        d_send, d_recv = st.get('d_send', slot, host=False), st.get('d_recv', slot * world, host=False)
+        d_send.copy_(send, non_blocking=True)
+        dist.all_gather_into_tensor(d_recv, d_send, group=group)
+        recv.copy_(d_recv, non_blocking=True)
+        torch.cuda.current_stream(st.device).synchronize()
+    else:
+        dist.all_gather_into_tensor(recv, send, group=group)
+    return recv.numpy(), slot, counts
 
 
-def allgather_hits(hits, cigar, q_base, t_base=0, group=None, device=None):
+def allgather_hits(hits, cigar, q_base, t_base=0, group=None, device=None, out=None):
     """hits: structured array (peppan_amd._native.HIT_DTYPE) with shard-local q / t indices; cigar: uint32 arena.
     Returns the concatenated (hits, cigar) of all ranks in rank order with global indices and re-based cigar offsets.
-    Collectives: one all-gather of the payload sizes, one of a padded payload (hit records + arena)."""
-    import torch
+    Collectives: one all-gather of the payload sizes, one of a padded payload (8-byte hit count + hit records + arena).
+    `out`: optional dict that keeps the output arrays between calls (the result is then only valid until the next call)."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         if q_base or t_base:
@@ -78,23 +120,40 @@ def allgather_hits(hits, cigar, q_base, t_base=0, group=None, device=None):
             hits['q'] += q_base
             hits['t'] += t_base
         return hits, cigar
-    dev = device if device is not None else torch.device('cpu')
-    mine = hits.copy()
-    mine['q'] += q_base
-    mine['t'] += t_base
-    rec = mine.dtype.itemsize
-    head = np.array([len(mine)], dtype=np.uint64).view(np.uint8)
-    payload = np.concatenate([head, mine.view(np.uint8).reshape(-1), np.ascontiguousarray(cigar, dtype=np.uint32).view(np.uint8)])
-    out_h, out_c, coff = [], [], 0
-    for part in _all_gather_bytes(payload, group, dev):
-        nh = int(part[:8].view(np.uint64)[0])
-        h = part[8:8 + nh * rec].view(mine.dtype).copy()
-        c = part[8 + nh * rec:].view(np.uint32)
-        h['cigar_off'] += coff
-        coff += len(c)
-        out_h.append(h)
-        out_c.append(c)
-    return np.concatenate(out_h), np.concatenate(out_c)
+    rec, nh, nc = hits.dtype.itemsize, len(hits), len(cigar)
+
+    def fill(view):
+        view[:8].view(np.uint64)[0] = nh
+        mine = view[8:8 + nh * rec].view(hits.dtype)
+        mine[:] = hits
+        mine['q'] += q_base
+        mine['t'] += t_base
+        view[8 + nh * rec:].view(np.uint32)[:] = cigar
+
+    flat, slot, counts = _all_gather_bytes(fill, 8 + nh * rec + 4 * nc, group, device)
+    parts, tot_h, tot_c = [], 0, 0
+    for r in range(len(counts)):
+        part = flat[r * slot:r * slot + int(counts[r])]
+        n_r = int(part[:8].view(np.uint64)[0])
+        h, c = part[8:8 + n_r * rec].view(hits.dtype), part[8 + n_r * rec:].view(np.uint32)
+        parts.append((h, c))
+        tot_h, tot_c = tot_h + n_r, tot_c + len(c)
+    if out is None:
+        all_h, all_c = np.empty(tot_h, dtype=hits.dtype), np.empty(tot_c, dtype=np.uint32)
+    else:
+        if len(out.get('h', ())) < tot_h:
+            out['h'] = np.empty(int(tot_h * 1.5) + 64, dtype=hits.dtype)
+        if len(out.get('c', ())) < tot_c:
+            out['c'] = np.empty(int(tot_c * 1.5) + 64, dtype=np.uint32)
+        all_h, all_c = out['h'][:tot_h], out['c'][:tot_c]
+    ph = pc = 0
+    for h, c in parts:
+        dst = all_h[ph:ph + len(h)]
+        dst[:] = h
+        dst['cigar_off'] += pc
+        all_c[pc:pc + len(c)] = c
+        ph, pc = ph + len(h), pc + len(c)
+    return all_h, all_c
 
 
 class ShardedSearch(object):
@@ -127,18 +186,27 @@ class ShardedSearch(object):
             # what K1 made of every column's genes: the number of targets in front of this column and the global target -> gene map
             import torch
             dev = device if device is not None else torch.device('cpu')
-            parts = _all_gather_bytes(local_gene.view(np.uint8), group, dev)
-            cols = [parts[c].view(np.uint32) for c in range(self.C)]          # row 0 holds one rank per column, in column order
+            raw = local_gene.view(np.uint8)
+            flat, slot, counts = _all_gather_bytes(lambda view: view.__setitem__(slice(None), raw), raw.size, group, dev)
+            cols = [flat[c * slot:c * slot + int(counts[c])].view(np.uint32).copy() for c in range(self.C)]   # row 0 holds one rank per column, in column order
             self.t_base = int(sum(len(x) for x in cols[:self.c]))
             self.gene_of_target = np.concatenate(cols)
         self.params.t_index_base = self.t_base
+        self._scratch, self._merged = {}, {}
 
     def search(self, retranslate=False, copy=True):
+        import time
+        t0 = time.perf_counter()
         if retranslate:
             self.ctx.translate(force=True)
         hits, cigar, stats = self.ctx.search(self.params, copy=(copy and self.world == 1))
-        allh, allc = allgather_hits(hits, cigar, self.q0, self.t_base, group=self.group, device=self.device)
+        t1 = time.perf_counter()
+        keep = None if copy else self._scratch            # copy=False: the arrays of the previous step are overwritten
+        allh, allc = allgather_hits(hits, cigar, self.q0, self.t_base, group=self.group, device=self.device, out=keep)
+        t2 = time.perf_counter()
         if self.C > 1:
             from . import _native as N
-            allh, allc = N.merge_hits(allh, allc, self.params.top_k, self.params.n_splits)
+            allh, allc = N.merge_hits(allh, allc, self.params.top_k, self.params.n_splits, out=None if copy else self._merged)
+        # host wall time of the three parts of a step (the device phases are in the pep_search_stats fields)
+        stats = dict(stats, ms_host_search=(t1 - t0) * 1e3, ms_host_exchange=(t2 - t1) * 1e3, ms_host_merge=(time.perf_counter() - t2) * 1e3)
         return allh, allc, stats
