@@ -173,7 +173,7 @@ def _grid_worker(rank, world, port, grid, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,grid', [(2, (1, 2)), (2, (2, 1)), (4, (2, 2)), (4, None)])
+@pytest.mark.parametrize('world,grid', [(2, (1, 2)), (2, (2, 1)), (4, (2, 2)), (4, None), (8, None)])
 def test_sharded_all_vs_all_equals_single_process(world, grid):
     """queries x reference shards on a 2-D grid of gloo ranks (oracle-backed contexts): after the all-gather and pep_merge_hits every
     rank holds exactly the table of the unsharded search - every field, every CIGAR run - and the same target -> gene map"""
