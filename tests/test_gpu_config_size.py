@@ -153,3 +153,67 @@ def test_all_vs_all_50k_bit_exact_vs_oracle(ctx):
     assert np.array_equal(gc, oc)
     for k in ('candidates', 'pairs', 'cells', 'tracebacks'):
         assert st[k] == ost[k], k
+
+
+def test_chromosome_longer_than_the_sequence_limit(tmp_path, monkeypatch):
+    """the nucleotide tool on a 10.6 Mbp contig (> PEP_MAX_SEQ_LEN = 8.39 Mbp: runBlast searches it as three overlapping windows, nothing
+    patched): 300 genes planted on both strands, some of them right across the window boundaries at 4 194 304 and 8 388 608, all come
+    back at their coordinates; the same genes on a second, short contig are found as well"""
+    from peppan_amd import _native as N, synth, uberBlast as UB
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(99)
+    names, seqs = synth.make_genes(400, 0, seed=41)
+    genes = [s for s in seqs if 300 <= len(s) <= 3000][:300]
+    B = np.frombuffer(b'ACGT', dtype=np.uint8)
+    comp = np.zeros(256, dtype=np.uint8)
+    comp[list(b'ACGT')] = list(b'TGCA')
+    total = 10600000
+    assert total > N.MAX_SEQ_LEN
+    chrom = B[rng.integers(0, 4, total)]
+    # planted (gene, start, strand): one gene right across every window boundary - the windows of the forward strand meet at 4 194 304 and
+    # 8 388 608, those of the reverse strand at the same offsets from the other end - with the midpoint 100 / 500 nt to either side,
+    # neighbours a few kb away on both sides (inside the halos), the rest spread out; no two planted genes overlap
+    H = UB._TILE_HOME
+    edges = [(H, 0, -100), (2 * H, 0, 500), (total - H, 1, 100), (total - 2 * H, 1, -500)]
+    planted, gi = [], 0
+    for b, strand, shift in edges:
+        for off in (0, -4000, 4000):
+            g = genes[gi]
+            planted.append((gi, b + (shift if off == 0 else off) - len(g) // 2, strand))
+            gi += 1
+    for pos in np.linspace(50000, total - 50000, len(genes) - gi + 60).astype(int):
+        if gi >= len(genes):
+            break
+        if any(abs(int(pos) - b) < 20000 for b, _, _ in edges):
+            continue
+        planted.append((gi, int(pos), gi % 2))
+        gi += 1
+    ann = []
+    for gi_, pos, strand in planted:
+        s = np.frombuffer(genes[gi_], dtype=np.uint8).copy()
+        m = rng.random(s.size) < 0.02
+        s[m] = B[rng.integers(0, 4, int(m.sum()))]
+        chrom[pos:pos + s.size] = comp[s[::-1]] if strand else s
+        ann.append((gi_, pos + 1, pos + s.size, strand))
+    with open('q.fa', 'w') as f:
+        for i in range(len(planted)):
+            f.write('>%d\n%s\n' % (i, genes[i].decode()))
+    small = np.concatenate([chrom[p0 - 1:p1] for _, p0, p1, _ in ann[:20]])
+    with open('r.fa', 'w') as f:
+        f.write('>chr\n%s\n>small\n%s\n' % (chrom.tobytes().decode(), small.tobytes().decode()))
+    argv = '-r r.fa -q q.fa --blastn -s 1 --min_id 0.6 --min_cov 50 --min_ratio 0.2 -e 0,3 -f -m'.split()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stderr(io.StringIO()):
+        tab = UB.uberBlast(argv)
+    print('10.6 Mbp chromosome, %d queries: %.2f s, %d rows' % (len(planted), time.perf_counter() - t0, tab.shape[0]))
+    on_chr = {}
+    for r in tab:
+        if r[1] == 'chr' and r[2] >= 0.95:
+            on_chr.setdefault(int(r[0]), []).append((min(r[8], r[9]), max(r[8], r[9]), r[8] > r[9], r[6], r[7]))
+    for gi_, p0, p1, strand in ann:
+        hits = on_chr.get(gi_, [])
+        assert any(abs(lo - p0) <= 3 and abs(hi - p1) <= 3 and rev == bool(strand) for lo, hi, rev, qs, qe in hits), (gi_, p0, p1, strand, hits[:3])
+    assert sum(1 for r in tab if r[1] == 'small' and r[2] >= 0.95) >= 20
+    # no duplicates from the overlapping halos: one row per (query, locus)
+    for gi_, hits in on_chr.items():
+        assert len({(lo, hi) for lo, hi, rev, qs, qe in hits}) == len(hits)
