@@ -1,5 +1,6 @@
 // C ABI of libpeppan_hip.so (declared in include/peppan_hip.h): context, inputs, orchestration of K1..K8.
 #include "common.h"
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -84,9 +85,31 @@ int pep_read_back(pep_ctx *ctx, void *dst, const void *d_src, size_t n)
     return PEP_OK;
 }
 
+hipError_t pep_event_wait(hipEvent_t ev)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int spin = 0; spin < 64; ++spin) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q != hipErrorNotReady) return q;
+            __builtin_ia32_pause();
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1500)) break;      // long waits sleep
+    }
+    return hipEventSynchronize(ev);
+}
+
+hipError_t pep_stream_wait(pep_ctx *ctx)
+{
+    if (!ctx->wait_event && hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming) != hipSuccess) return hipStreamSynchronize(ctx->stream);
+    const hipError_t r = hipEventRecord(ctx->wait_event, ctx->stream);
+    if (r != hipSuccess) return hipStreamSynchronize(ctx->stream);
+    return pep_event_wait(ctx->wait_event);
+}
+
 int pep_sync_reads(pep_ctx *ctx)
 {
-    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    const hipError_t e = pep_stream_wait(ctx);
     if (e == hipSuccess)
         for (int i = 0; i < ctx->n_pending; ++i) memcpy(ctx->pending[i].dst, ctx->pin_small.p + ctx->pending[i].off, ctx->pending[i].n);
     ctx->n_pending = 0;
@@ -360,6 +383,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_k1q.p) (void)hipHostFree(ctx->pin_k1q.p);
     if (ctx->pin_k1n.p) (void)hipHostFree(ctx->pin_k1n.p);
     if (ctx->k1_event) (void)hipEventDestroy(ctx->k1_event);
+    if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
     if (ctx->pin_ms.p) (void)hipHostFree(ctx->pin_ms.p);
     DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq};
@@ -578,7 +602,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         rc = pep_extend(ctx, d_cands, n_cands, min_score.data(), res);
     }
     pep_timer_end(ctx, TM_TOTAL);
-    const hipError_t se = hipStreamSynchronize(ctx->stream);
+    const hipError_t se = pep_stream_wait(ctx);
     if (rc == PEP_OK && se != hipSuccess) rc = pep_fail(ctx, PEP_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
     if (rc != PEP_OK) { delete res; return rc; }
     pep_timers_resolve(ctx);

@@ -80,6 +80,7 @@ struct pep_ctx {
     int n_pending = 0;
     PinBuf pin_k1, pin_k1q, pin_k1n;        // grow-only: K1 descriptors of the reference / of the queries, the target count
     hipEvent_t k1_event = nullptr;          // the point of the stream where the reference side's downloads have arrived
+    hipEvent_t wait_event = nullptr;        // pep_stream_wait: marks the point of the stream the host is waiting for
     bool k1_count_pending = false;
     PinBuf pin_stage;                       // grow-only: the hit table of the newest search
     PinBuf pin_ms;                          // grow-only: per-query score thresholds on their way to the device
@@ -166,6 +167,11 @@ int pep_fail(pep_ctx *ctx, int code, const std::string &msg);
 // waits for the stream and stores the values
 int pep_read_back(pep_ctx *ctx, void *dst, const void *d_src, size_t n);
 int pep_sync_reads(pep_ctx *ctx);
+// Waits until everything queued on the context's stream so far has finished - by polling an event for up to a few hundred microseconds
+// before falling back to a blocking wait: the searches are chains of short kernels with a handful of host decisions in between, and a
+// sleeping host thread adds tens of microseconds of wake-up latency to each of them.
+hipError_t pep_stream_wait(pep_ctx *ctx);
+hipError_t pep_event_wait(hipEvent_t ev);
 int pin_reserve(pep_ctx *ctx, PinBuf &b, size_t bytes);
 void pep_materialise_staged(pep_ctx *ctx);
 int dev_reserve(pep_ctx *ctx, DevBuf &b, size_t bytes);

@@ -335,7 +335,7 @@ PackDesc *stage_desc(pep_ctx *ctx, PinBuf &pin, uint64_t n)
 
 int k1_ref_finish(pep_ctx *ctx)
 {
-    PEP_HIP(ctx, hipEventSynchronize(ctx->k1_event));
+    PEP_HIP(ctx, pep_event_wait(ctx->k1_event));
     const uint32_t n_targets = ctx->k1_count_pending ? *reinterpret_cast<const uint32_t *>(ctx->pin_k1n.p) : 0u;
     ctx->k1_count_pending = false;
     const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1.p);
@@ -375,7 +375,7 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
     }
     if (phase == 1) return PEP_OK;
     const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1q.p);
-    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PEP_HIP(ctx, pep_stream_wait(ctx));
     ctx->q_meta.resize(n);
     for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, desc[i].frame, desc[i].len, (uint32_t)(nt.h_off[i + 1] - nt.h_off[i])};
     return finish_layout(ctx, desc, n, ctx->q);

@@ -64,6 +64,6 @@ int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const u
     hipLaunchKernelGGL(uf_flatten, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, label, n_nodes);
     PEP_HIP(ctx, hipGetLastError());
     PEP_HIP(ctx, hipMemcpyAsync(h_label, label, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PEP_HIP(ctx, pep_stream_wait(ctx));
     return PEP_OK;
 }
