@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void seed_fill(SeedShape sh, const uint8_t *__
 // bucket = coarse << F | fine, C + F = bucket_bits.  A coarse bucket that does not fit LDS (pathologically repetitive input) raises
 // a flag and the host rebuilds with the count -> scan -> fill kernels.
 constexpr int PART_TILES = 16;                 // 256-position tiles per block in the two partition passes (more for large query sets: <= 2048 blocks)
-constexpr int PART_CAP = 5632;                 // entries of one coarse bucket that fit LDS next to 4096 fine counters
+constexpr int PART_CAP = 5632;                 // capacity of one coarse bucket's slab (an overflow falls back to the plain build)
 
 // One pass over the query positions: a block takes `tiles` tiles in chunks of PART_TILES, keeps the chunk's entries in registers, counts
 // them per coarse bucket in LDS, reserves its share of every bucket's slab (PART_CAP entries per coarse bucket) with one global atomic
@@ -159,14 +159,22 @@ __global__ __launch_bounds__(256) void idx_slab(SeedShape sh, const uint8_t *__r
     for (int t0 = 0; t0 < tiles; t0 += PART_TILES) {
         for (uint32_t x = threadIdx.x; x < n_coarse; x += 256) h[x] = 0;
         uint64_t ent[PART_TILES];
-        uint32_t cb[PART_TILES];
+        uint32_t cb[PART_TILES], fetched[PART_TILES];
+        // the residues of the whole chunk are fetched up front (16 loads in flight): a block walks its tiles one after the other with two
+        // barriers each, and only ~3 blocks fit a CU's share of the grid - every tile used to start with an exposed memory latency
+#pragma unroll
+        for (int t = 0; t < PART_TILES; ++t) {
+            const uint64_t tile = (uint64_t)blockIdx.x * tiles + t0 + t;
+            fetched[t] = (t0 + t < tiles && tile * TILE < total) ? fetch_tile(res, tile, total) : 0u;
+        }
 #pragma unroll
         for (int t = 0; t < PART_TILES; ++t) {
             const uint64_t base = ((uint64_t)blockIdx.x * tiles + t0 + t) * TILE;
             ent[t] = ~0ull; cb[t] = 0;
             __syncthreads();
             if (t0 + t < tiles && base < total) {           // block-uniform
-                stage_reduced(sh, res, base, total, red);
+                red[threadIdx.x] = reduce_letter(sh, fetched[t]);
+                if (threadIdx.x < TILE_HALO) red[TILE + threadIdx.x] = reduce_letter(sh, fetched[t] >> 8);
                 __syncthreads();
                 const uint64_t p = base + threadIdx.x;
                 uint64_t key;
@@ -178,13 +186,20 @@ __global__ __launch_bounds__(256) void idx_slab(SeedShape sh, const uint8_t *__r
             }
         }
         __syncthreads();
-        for (uint32_t x = threadIdx.x; x < n_coarse; x += 256) {
-            const uint32_t c = h[x];
-            if (c) {
-                const uint32_t at = atomicAdd(&coarse_cnt[x], c);
-                if (at + c > (uint32_t)PART_CAP) counters[3] = 1u;
-                h[x] = at;
-            }
+        // slab space of this chunk: one returning global atomic per coarse bucket - eight of a thread's are in flight together (issued one
+        // by one, each waiting for its answer, they were a third of the kernel)
+        for (uint32_t x0 = threadIdx.x; x0 < n_coarse; x0 += 8 * 256) {
+            uint32_t c8[8], at8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const uint32_t x = x0 + 256u * k; c8[k] = x < n_coarse ? h[x] : 0u; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) at8[k] = x0 + 256u * k < n_coarse ? atomicAdd(&coarse_cnt[x0 + 256u * k], c8[k]) : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c8[k]) {
+                    if (at8[k] + c8[k] > (uint32_t)PART_CAP) counters[3] = 1u;
+                    h[x0 + 256u * k] = at8[k];
+                }
         }
         __syncthreads();
 #pragma unroll
@@ -204,7 +219,6 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
                                                   unsigned long long *__restrict__ filter, uint32_t *__restrict__ counters)
 {
     __shared__ uint32_t pos[4096];
-    __shared__ uint64_t ents[PART_CAP];
     __shared__ unsigned long long fw[4096 >> FILTER_SHIFT];
     __shared__ uint32_t wave_sum[4];
     const uint32_t c = blockIdx.x, n_coarse = 1u << (bucket_bits - fine_bits), n_fine = 1u << fine_bits;
@@ -230,9 +244,10 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
     for (uint32_t x = threadIdx.x; x < (n_fine >> FILTER_SHIFT); x += 256) fw[x] = 0;
     __syncthreads();
     const uint32_t fmask = n_fine - 1;
+    // the slab is read twice (count, place) from the L2 instead of being staged: 45 KiB of LDS less, four times the resident blocks
+    const uint64_t *slab = part + (uint64_t)c * PART_CAP;
     for (uint32_t x = threadIdx.x; x < n; x += 256) {
-        const uint64_t e = part[(uint64_t)c * PART_CAP + x];
-        ents[x] = e;
+        const uint64_t e = slab[x];
         atomicAdd(&pos[hash_u64(e >> POS_BITS, bucket_bits) & fmask], 1u);
         uint32_t word;
         const uint64_t m = filter_mask(e >> POS_BITS, bucket_bits, word);
@@ -253,14 +268,17 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
     for (uint32_t k = 0; k < per; ++k) {
         const uint32_t f = threadIdx.x * per + k, cnt = pos[f];
         pos[f] = run;
-        start[((size_t)c << fine_bits) + f] = lo + run;
         run += cnt;
     }
+    __syncthreads();
+    // start[] of this coarse bucket from the scanned counters, one coalesced pass (a thread writing its own `per` consecutive words
+    // touches every 64-byte line of the slice `per` times)
+    for (uint32_t x = threadIdx.x; x < n_fine; x += 256) start[((size_t)c << fine_bits) + x] = lo + pos[x];
     // this coarse bucket's slice of the filter: 2^(fine_bits - 5) words
     for (uint32_t x = threadIdx.x; x < (n_fine >> FILTER_SHIFT); x += 256) filter[((size_t)c << (fine_bits - FILTER_SHIFT)) + x] = fw[x];
     __syncthreads();
     for (uint32_t x = threadIdx.x; x < n; x += 256) {
-        const uint64_t e = ents[x];
+        const uint64_t e = slab[x];
         const uint32_t slot = atomicAdd(&pos[hash_u64(e >> POS_BITS, bucket_bits) & fmask], 1u);
         entries[lo + slot] = e;
     }
