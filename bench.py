@@ -197,6 +197,7 @@ def main():
         # ungapped pre-filter in front of it is stricter (threshold 55 instead of 45: 39 % fewer candidates, identical hit table - DESIGN.md
         # section 2).  For comparison across rounds the same timed loop is run once more with the round-1 threshold.
         p45 = N.default_params(min_id, min_qcov, 10, 5, ungapped_min=45)
+        p45.stage1_min = 0                                  # (round 1 had no first stage either)
         keep = shard.params
         shard.params = p45
         step(); step()

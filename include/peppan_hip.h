@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 2
+#define PEP_ABI_VERSION 3
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -83,6 +83,10 @@ typedef struct {
     int32_t t_index_base;         /* index of this context's target 0 in the WHOLE reference set when the targets are one shard of it (multi-GPU
                                      target sharding, peppan_amd/dist.py): split membership is (t + t_index_base) mod n_splits, so a shard ranks
                                      its hits exactly as the unsharded search would; 0 otherwise.  Ignored with pep_set_target_groups. */
+    int32_t stage1_min;           /* first stage of the ungapped pre-filter (only with ungapped_min > 0): the extension to the right of a seed hit must
+                                     have reached this score after its first 16 residues - the seed and a few residues behind it - or the hit is
+                                     dropped before the rest of its windows is fetched (chance hits of the reduced alphabet); 0 = off */
+    int32_t reserved2;            /* 0 */
 } pep_search_params;
 
 /* one alignment; coordinates are 1-based, inclusive, in residues of the query / target protein */

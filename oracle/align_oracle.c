@@ -44,6 +44,7 @@
 #define BIN_W 64
 #define BAND 128
 #define BAND_LEAD 32
+#define STAGE1_LEN 16
 
 typedef struct {
     int32_t gap_open;      /* 11 */
@@ -66,6 +67,8 @@ typedef struct {
                               1: every band of (q, t) that reaches min_score, minus duplicates (same end cell: keep the
                                  higher score, then the lower bin) - the nucleotide tool, where a subject can carry several copies */
     int32_t t_base;        /* index of target 0 in the whole reference set when the targets are one shard of it: split = (t + t_base) mod n_splits */
+    int32_t stage1_min;    /* first stage of the pre-filter: the right extension must have reached this after its first STAGE1_LEN residues (0 = off) */
+    int32_t pad0;
 } oracle_params;
 
 typedef struct {
@@ -140,7 +143,7 @@ void oracle_default_params(oracle_params *p)
         p->weight[s] = w;
     }
     p->min_id_pct = 0.; p->min_qcov_pct = 0.; p->top_k = 10; p->n_splits = 5;
-    p->ungapped_min = 55; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24;
+    p->ungapped_min = 55; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24; p->stage1_min = 24; p->pad0 = 0;
 }
 
 /* smallest raw score whose e-value m*n*K*exp(-lambda*S) is <= max_evalue
@@ -195,12 +198,16 @@ static int seed_key(const oracle_params *p, int sh, const uint8_t *s, uint32_t l
  * each part stops at the sequence end, after `ext` residues, or once the running sum falls more than xdrop below its best */
 static int32_t ungapped_score(const oracle_params *p, const uint8_t *q, int32_t Lq, int32_t qpos, const uint8_t *t, int32_t Lt, int32_t tpos)
 {
-    int32_t s = 0, br = 0, bl = 0;
-    for (int32_t k = 0; k < p->ext_right && qpos + k < Lq && tpos + k < Lt; ++k) {
+    int32_t s = 0, br = 0, bl = 0, k = 0;
+    for (; k < p->ext_right && qpos + k < Lq && tpos + k < Lt; ++k) {
+        /* stage 1: a hit whose right extension has not reached stage1_min within its first STAGE1_LEN residues - the seed itself and a
+         * few residues behind it - is a chance hit of the reduced alphabet and is dropped before the rest is looked at */
+        if (k == STAGE1_LEN && br < p->stage1_min) return -1;
         s += p->sub[(q[qpos + k] & 31) * 32 + (t[tpos + k] & 31)];
         if (s > br) br = s;
         else if (br - s > p->xdrop) break;
     }
+    if (br < p->stage1_min) return -1;          /* (the extension ended inside the first STAGE1_LEN residues) */
     s = 0;
     for (int32_t k = 1; k <= p->ext_left && qpos - k >= 0 && tpos - k >= 0; ++k) {
         s += p->sub[(q[qpos - k] & 31) * 32 + (t[tpos - k] & 31)];

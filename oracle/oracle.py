@@ -25,7 +25,7 @@ class Params(C.Structure):
                 ('weight', C.c_int32 * 4), ('offs', (C.c_int32 * 32) * 4), ('reduce', C.c_uint8 * 32),
                 ('sub', C.c_int8 * 1024), ('min_id_pct', C.c_double), ('min_qcov_pct', C.c_double),
                 ('top_k', C.c_int32), ('n_splits', C.c_int32), ('ungapped_min', C.c_int32), ('xdrop', C.c_int32),
-                ('ext_right', C.c_int32), ('ext_left', C.c_int32), ('hsp_mode', C.c_int32), ('t_base', C.c_int32)]
+                ('ext_right', C.c_int32), ('ext_left', C.c_int32), ('hsp_mode', C.c_int32), ('t_base', C.c_int32), ('stage1_min', C.c_int32), ('pad0', C.c_int32)]
 
 
 class Hit(C.Structure):
@@ -81,6 +81,7 @@ def params_from(native):
     for f in ('gap_open', 'gap_ext', 'n_shapes', 'base', 'min_id_pct', 'min_qcov_pct', 'top_k', 'n_splits', 'ungapped_min', 'xdrop', 'ext_right', 'ext_left', 'hsp_mode'):
         setattr(p, f, getattr(native, f))
     p.t_base = getattr(native, 't_index_base', 0)
+    p.stage1_min = getattr(native, 'stage1_min', 0)
     for i in range(4):
         p.weight[i] = native.weight[i]
         for j in range(32):

@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
@@ -26,7 +26,7 @@ class SearchParams(C.Structure):
                 ('sub', C.c_int8 * 1024), ('min_id_pct', C.c_double), ('min_qcov_pct', C.c_double),
                 ('top_k', C.c_int32), ('n_splits', C.c_int32), ('dbsize', C.c_double), ('max_evalue', C.c_double),
                 ('use_lds', C.c_int32), ('ungapped_min', C.c_int32), ('xdrop', C.c_int32), ('ext_right', C.c_int32),
-                ('ext_left', C.c_int32), ('reserved', C.c_int32 * 3), ('ka_lambda', C.c_double), ('ka_k', C.c_double), ('hsp_mode', C.c_int32), ('t_index_base', C.c_int32)]
+                ('ext_left', C.c_int32), ('reserved', C.c_int32 * 3), ('ka_lambda', C.c_double), ('ka_k', C.c_double), ('hsp_mode', C.c_int32), ('t_index_base', C.c_int32), ('stage1_min', C.c_int32), ('reserved2', C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -130,6 +130,7 @@ def nucleotide_params(min_id_pct=0., min_qcov_pct=0., top_k=1000, dbsize=5e6, ma
         for b in range(32):
             p.sub[a * 32 + b] = (2 if a == b else -3) if (a < 4 and b < 4) else (-3 if (a < 5 and b < 5) else -64)
     p.ungapped_min, p.xdrop, p.ext_right, p.ext_left = 40, 16, 40, 24
+    p.stage1_min = 0                     # (an exact 17-mer scores 32 over its first 16 bases: the first stage has nothing to reject here)
     p.ka_lambda, p.ka_k = 0.625, 0.41
     p.hsp_mode = 1                       # blastn reports every HSP of a subject; a contig can carry several copies of a gene
     return p

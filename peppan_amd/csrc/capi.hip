@@ -329,7 +329,7 @@ void pep_default_params(pep_search_params *p)
     p->min_id_pct = 0.; p->min_qcov_pct = 0.; p->top_k = 10; p->n_splits = 5;
     p->dbsize = 5e6; p->max_evalue = 1.;
     p->use_lds = 1;
-    p->ungapped_min = 55; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24;
+    p->ungapped_min = 55; p->xdrop = 12; p->ext_right = 40; p->ext_left = 24; p->stage1_min = 24; p->reserved2 = 0;
     p->ka_lambda = 0.267; p->ka_k = 0.041;
 }
 
@@ -555,6 +555,8 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         }
         if (params->t_index_base < 0) return pep_fail(ctx, PEP_ERR_ARG, "t_index_base must not be negative");
         if (params->hsp_mode != 0 && params->hsp_mode != 1) return pep_fail(ctx, PEP_ERR_ARG, "hsp_mode must be 0 or 1");
+        if (params->stage1_min < 0 || (params->ungapped_min > 0 && params->stage1_min > params->ungapped_min))
+            return pep_fail(ctx, PEP_ERR_ARG, "stage1_min must lie between 0 and ungapped_min");
         if (!(params->ka_lambda > 0.) || !(params->ka_k > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "invalid Karlin-Altschul parameters");
         if (!(params->dbsize > 0.) || !(params->max_evalue > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "dbsize and max_evalue must be positive");
         if (params->xdrop < 0 || params->xdrop > 48 || params->ext_right < 1 || params->ext_right > 48 || params->ext_left < 0 || params->ext_left > 48)

@@ -314,7 +314,7 @@ struct JoinArgs {
     unsigned long long *stats;   // [0] = target seeds, [1] = seed hits, [2] = seed hits passing the ungapped filter
     const uint8_t *q_res;
     const int8_t *sub;       // 32x32 substitution scores (global; staged in LDS by the kernel)
-    int ungapped_min, xdrop, ext_right, ext_left;
+    int ungapped_min, xdrop, ext_right, ext_left, stage1_min;
     uint64_t *hits;          // raw seed hits (qpos << 32 | tpos)
     unsigned long long *hit_count;
     uint64_t hit_cap;
@@ -353,20 +353,18 @@ __device__ __forceinline__ bool set_contains(const JoinArgs &a, uint64_t k)
 
 // ungapped x-drop score of the diagonal through a seed hit, on PACKED positions: the >= 16 padding bytes around every
 // sequence score -64, which ends an extension exactly where the sequence ends (x-drop < 64), so no bounds are needed
-// Returns as soon as the threshold is reached (only the outcome score >= ungapped_min is used).  The two 48-byte
-// windows per side are fetched with unaligned 16-byte loads up front, so a hit costs one memory latency instead of
-// one per residue; the loops are fully unrolled so that the windows stay in registers.
+// Returns as soon as the threshold is reached (only the outcome score >= ungapped_min is used).  The windows are fetched with
+// unaligned 16-byte loads, a piece at a time; the loops are fully unrolled so that the windows stay in registers.
 __device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *sub, uint32_t qp, uint64_t tp)
 {
-    // The windows are fetched in 16-byte pieces, and only as far as an extension gets: the first 32 residues to the right and the first
-    // 16 to the left up front (one memory latency for nearly every hit), the rest inside the wave-uniform blocks below and only by the
-    // lanes that are still extending.  A chance hit of the reduced alphabet - most of what arrives here once the gene set is large -
-    // dies inside the first pieces, so it costs 96 window bytes instead of 192 (seed_extend is bound by these scattered line fetches).
+    // seed_extend is bound by the NUMBER of these scattered fetches, and most of what arrives here once the gene set is large is a chance
+    // hit of the reduced alphabet.  Stage 1 (pep_search_params.stage1_min; oracle: ungapped_score) therefore looks at the first 16
+    // residues to the right only - two fetches: the seed and a few residues behind it; a hit whose extension has not reached stage1_min
+    // by then is dropped.  Only the survivors fetch the second piece to the right and the first to the left (four more fetches), the
+    // rest inside the wave-uniform blocks below, by the lanes that are still extending.
     uint32_t qr[12], tr[12], ql[12], tl[12];
-    __builtin_memcpy(qr, a.q_res + qp, 32);
-    __builtin_memcpy(tr, a.t_res + tp, 32);
-    __builtin_memcpy(ql + 8, a.q_res + qp - 16, 16);
-    __builtin_memcpy(tl + 8, a.t_res + tp - 16, 16);
+    __builtin_memcpy(qr, a.q_res + qp, 16);
+    __builtin_memcpy(tr, a.t_res + tp, 16);
     int s = 0, br = 0, bl = 0;
     bool live = true, pass = false;
     // Straight-line predicated code costs its full length as long as ONE lane of the wave is still extending; most extensions
@@ -374,6 +372,16 @@ __device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *s
     // residues whether anybody is left and skips the rest of the window otherwise.
 #pragma unroll
     for (int blk8 = 0; blk8 < 6; ++blk8) {
+        if (blk8 == 2) {
+            if (pass) return true;
+            if (br < a.stage1_min) return false;                      // stage 1 (an extension that ended earlier is judged by what it reached)
+            if (live && 16 < a.ext_right) {                           // residues 16..31: second piece of the right windows
+                __builtin_memcpy(qr + 4, a.q_res + qp + 16, 16);
+                __builtin_memcpy(tr + 4, a.t_res + tp + 16, 16);
+            }
+            __builtin_memcpy(ql + 8, a.q_res + qp - 16, 16);          // first piece of the left windows
+            __builtin_memcpy(tl + 8, a.t_res + tp - 16, 16);
+        }
         if (__ballot(live && blk8 * 8 < a.ext_right)) {
             if (blk8 == 4 && live && 32 < a.ext_right) {             // residues 32..47: third piece of the right windows
                 __builtin_memcpy(qr + 8, a.q_res + qp + 32, 16);
@@ -762,7 +770,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             a.table = ctx->ws[3].as<uint64_t>(); a.table_bits = table_bits;
             a.counters = counters; a.stats = stats;
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
-            a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
+            a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.stage1_min = P.stage1_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
             PEP_HIP(ctx, hipMemsetAsync(hit_count, 0, 16, ctx->stream));        // hit_count and n_runs (counters[12..15]) in one fill
             pep_timer_begin(ctx, TM_MATCH0 + s);
@@ -772,6 +780,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             hipLaunchKernelGGL(seed_extend, dim3(256u * 16u), dim3(256), 0, ctx->stream, a, (const uint64_t *)run_first, (const uint32_t *)run_len,
                                (const uint64_t *)run_key, (const unsigned long long *)n_runs);
             PEP_HIP(ctx, hipGetLastError());
+            if (getenv("PEP_DEBUG_RUNS")) { unsigned long long hc[2]; hipMemcpy(hc, hit_count, 16, hipMemcpyDeviceToHost); unsigned long long st3[3]; hipMemcpy(st3, stats, 24, hipMemcpyDeviceToHost); fprintf(stderr, "shape %d: raw hits (cum) %llu runs %llu passed(cum) %llu\n", s, hc[0], hc[1], st3[2]); }
             PEP_TRY(pep_read_back(ctx, &h_nseed[s], start + n_buckets, sizeof(uint32_t)));
         }
         // field widths of the dense key form (see keys_pack)

@@ -105,6 +105,7 @@ def test_default_params_and_min_score_match_oracle():
     assert [list(x) for x in p.offs] == [list(x) for x in o.offs]
     assert (p.gap_open, p.gap_ext, p.top_k, p.n_splits) == (o.gap_open, o.gap_ext, o.top_k, o.n_splits)
     assert (p.ungapped_min, p.xdrop, p.ext_right, p.ext_left) == (o.ungapped_min, o.xdrop, o.ext_right, o.ext_left) == (55, 12, 40, 24)
+    assert p.stage1_min == o.stage1_min == 24
     for L in (1, 30, 100, 334, 1000, 3164, 50000):
         assert N.min_score(L) == O.min_score(L)
     assert N.min_score(334) == 68          # ~63/68/72 for 100/334/1000-aa queries
