@@ -780,7 +780,6 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             hipLaunchKernelGGL(seed_extend, dim3(256u * 16u), dim3(256), 0, ctx->stream, a, (const uint64_t *)run_first, (const uint32_t *)run_len,
                                (const uint64_t *)run_key, (const unsigned long long *)n_runs);
             PEP_HIP(ctx, hipGetLastError());
-            if (getenv("PEP_DEBUG_RUNS")) { unsigned long long hc[2]; hipMemcpy(hc, hit_count, 16, hipMemcpyDeviceToHost); unsigned long long st3[3]; hipMemcpy(st3, stats, 24, hipMemcpyDeviceToHost); fprintf(stderr, "shape %d: raw hits (cum) %llu runs %llu passed(cum) %llu\n", s, hc[0], hc[1], st3[2]); }
             PEP_TRY(pep_read_back(ctx, &h_nseed[s], start + n_buckets, sizeof(uint32_t)));
         }
         // field widths of the dense key form (see keys_pack)
