@@ -79,23 +79,10 @@ def _staging_for(device):
     return _staging[key]
 
 
-def _all_gather_bytes(fill, nbytes, group, device, stage=None):
-    """all-gather of one variable-length byte string per rank: `fill(view)` writes this rank's `nbytes` bytes into a uint8 numpy view of
-    the send buffer.  Returns (flat uint8 numpy view of the receive buffer, slot size, per-rank byte counts); rank r's bytes are
-    flat[r * slot : r * slot + counts[r]].  Two collectives: the byte counts, then the payloads padded to the largest."""
+def _exchange(st, send, slot, world, group):
+    """all-gather of one `slot`-byte block per rank through the staging buffers -> uint8 numpy view of world * slot bytes"""
     import torch
     import torch.distributed as dist
-    st = stage if stage is not None else _staging_for(device)
-    world = dist.get_world_size(group)
-    n = torch.tensor([nbytes], dtype=torch.int64, device=st.device)
-    counts = torch.empty(world, dtype=torch.int64, device=st.device)
-    dist.all_gather_into_tensor(counts, n, group=group)
-    counts = counts.cpu().numpy()
-    slot = (int(counts.max()) + 255) & ~255
-    if slot == 0:
-        return np.zeros(0, dtype=np.uint8), 0, counts
-    send = st.get('send', slot, host=True)
-    fill(send.numpy()[:nbytes])
     recv = st.get('recv', slot * world, host=True)
     if st.on_gpu:
         d_send, d_recv = st.get('d_send', slot, host=False), st.get('d_recv', slot * world, host=False)
@@ -105,14 +92,51 @@ def _all_gather_bytes(fill, nbytes, group, device, stage=None):
         torch.cuda.current_stream(st.device).synchronize()
     else:
         dist.all_gather_into_tensor(recv, send, group=group)
-    return recv.numpy(), slot, counts
+    return recv.numpy()
 
 
-def allgather_hits(hits, cigar, q_base, t_base=0, group=None, device=None, out=None):
+def _all_gather_bytes(fill, nbytes, group, device, stage=None, hint=None):
+    """all-gather of one variable-length byte string per rank: `fill(view)` writes this rank's `nbytes` bytes into a uint8 numpy view of
+    the send buffer.  Returns (flat uint8 numpy view of the receive buffer, slot size, offset of the payload inside a slot, per-rank byte
+    counts); rank r's bytes are flat[r * slot + offset : r * slot + offset + counts[r]].
+    Two collectives in general - the byte counts, then the payloads padded to the largest.  With `hint` (a dict the caller keeps between
+    calls) ONE: every rank sends a slot of the size that was enough last time (+ 25 %), its byte count in front; only when some rank's
+    payload does not fit - every rank sees that in the gathered counts - the exchange is repeated the two-step way."""
+    import torch
+    import torch.distributed as dist
+    st = stage if stage is not None else _staging_for(device)
+    world = dist.get_world_size(group)
+    if hint is not None and hint.get('slot', 0) >= 16:
+        slot = int(hint['slot'])
+        send = st.get('send', slot, host=True)
+        view = send.numpy()
+        view[:8].view(np.uint64)[0] = nbytes
+        if 8 + nbytes <= slot:
+            fill(view[8:8 + nbytes])
+        flat = _exchange(st, send, slot, world, group)
+        counts = np.array([int(flat[r * slot:r * slot + 8].view(np.uint64)[0]) for r in range(world)], dtype=np.int64)
+        if int(counts.max()) + 8 <= slot:
+            return flat, slot, 8, counts
+    n = torch.tensor([nbytes], dtype=torch.int64, device=st.device)
+    counts = torch.empty(world, dtype=torch.int64, device=st.device)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts = counts.cpu().numpy()
+    slot = (int(counts.max()) + 255) & ~255
+    if hint is not None:
+        hint['slot'] = ((int(counts.max()) * 5 // 4 + 8 + 255) & ~255)
+    if slot == 0:
+        return np.zeros(0, dtype=np.uint8), 0, 0, counts
+    send = st.get('send', slot, host=True)
+    fill(send.numpy()[:nbytes])
+    return _exchange(st, send, slot, world, group), slot, 0, counts
+
+
+def allgather_hits(hits, cigar, q_base, t_base=0, group=None, device=None, out=None, hint=None):
     """hits: structured array (peppan_amd._native.HIT_DTYPE) with shard-local q / t indices; cigar: uint32 arena.
     Returns the concatenated (hits, cigar) of all ranks in rank order with global indices and re-based cigar offsets.
     Collectives: one all-gather of the payload sizes, one of a padded payload (8-byte hit count + hit records + arena).
-    `out`: optional dict that keeps the output arrays between calls (the result is then only valid until the next call)."""
+    `out`: optional dict that keeps the output arrays between calls (the result is then only valid until the next call).
+    `hint`: optional dict kept between calls: repeated exchanges of similar size then need ONE collective (_all_gather_bytes)."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         if q_base or t_base:
@@ -130,10 +154,10 @@ def allgather_hits(hits, cigar, q_base, t_base=0, group=None, device=None, out=N
         mine['t'] += t_base
         view[8 + nh * rec:].view(np.uint32)[:] = cigar
 
-    flat, slot, counts = _all_gather_bytes(fill, 8 + nh * rec + 4 * nc, group, device)
+    flat, slot, at, counts = _all_gather_bytes(fill, 8 + nh * rec + 4 * nc, group, device, hint=hint)
     parts, tot_h, tot_c = [], 0, 0
     for r in range(len(counts)):
-        part = flat[r * slot:r * slot + int(counts[r])]
+        part = flat[r * slot + at:r * slot + at + int(counts[r])]
         n_r = int(part[:8].view(np.uint64)[0])
         h, c = part[8:8 + n_r * rec].view(hits.dtype), part[8 + n_r * rec:].view(np.uint32)
         parts.append((h, c))
@@ -187,12 +211,12 @@ class ShardedSearch(object):
             import torch
             dev = device if device is not None else torch.device('cpu')
             raw = local_gene.view(np.uint8)
-            flat, slot, counts = _all_gather_bytes(lambda view: view.__setitem__(slice(None), raw), raw.size, group, dev)
-            cols = [flat[c * slot:c * slot + int(counts[c])].view(np.uint32).copy() for c in range(self.C)]   # row 0 holds one rank per column, in column order
+            flat, slot, at, counts = _all_gather_bytes(lambda view: view.__setitem__(slice(None), raw), raw.size, group, dev)
+            cols = [flat[c * slot + at:c * slot + at + int(counts[c])].view(np.uint32).copy() for c in range(self.C)]   # row 0 holds one rank per column, in column order
             self.t_base = int(sum(len(x) for x in cols[:self.c]))
             self.gene_of_target = np.concatenate(cols)
         self.params.t_index_base = self.t_base
-        self._scratch, self._merged = {}, {}
+        self._scratch, self._merged, self._hint = {}, {}, {}
 
     def search(self, retranslate=False, copy=True):
         import time
@@ -202,7 +226,7 @@ class ShardedSearch(object):
         hits, cigar, stats = self.ctx.search(self.params, copy=(copy and self.world == 1))
         t1 = time.perf_counter()
         keep = None if copy else self._scratch            # copy=False: the arrays of the previous step are overwritten
-        allh, allc = allgather_hits(hits, cigar, self.q0, self.t_base, group=self.group, device=self.device, out=keep)
+        allh, allc = allgather_hits(hits, cigar, self.q0, self.t_base, group=self.group, device=self.device, out=keep, hint=self._hint)
         t2 = time.perf_counter()
         if self.C > 1:
             from . import _native as N

@@ -38,6 +38,26 @@ def _worker(rank, world, port, lengths, out_q):
     b = pdist.shard_bounds(lengths, world)
     hits, cig = _fake_hits(b[rank], b[rank + 1], seed=100 + rank)
     allh, allc = pdist.allgather_hits(hits, cig, b[rank])
+    # repeated exchanges with a size hint: the second takes the one-collective path, the third (one rank's table four times as large)
+    # does not fit the hinted slot and falls back; all three must deliver the same as the plain exchange
+    hint, calls = {}, []
+    real = dist.all_gather_into_tensor
+
+    def counted(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    dist.all_gather_into_tensor = counted
+    for rep in range(3):
+        h2, c2 = (hits, cig) if rep < 2 or rank == 0 else (np.concatenate([hits] * 4), cig)
+        n0 = len(calls)
+        gh, gc = pdist.allgather_hits(h2, c2, b[rank], hint=hint)
+        used = len(calls) - n0
+        assert used == (2, 1, 3)[rep], (rep, used)
+        if rep < 2:
+            assert gh.tobytes() == allh.tobytes() and gc.tobytes() == allc.tobytes()
+        else:
+            assert len(gh) == len(allh) + 3 * (len(allh) - len(_fake_hits(b[0], b[1], seed=100)[0]))
+    dist.all_gather_into_tensor = real
     out_q.put((rank, b, allh.tobytes(), allc.tobytes()))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,4 +1,4 @@
-"""What one exchange step costs on a GPU box besides the wire: the two collectives of peppan_amd.dist._all_gather_bytes on a
+"""What one exchange step costs on a GPU box besides the wire: the collectives of peppan_amd.dist._all_gather_bytes on a
 one-rank RCCL group (staging copies, launches, synchronisation - everything except the xGMI transfer itself) and the host merge
 (pep_merge_hits) of a table of the bench workload's size.  python3 tools/exchange_cost.py [n_hits]"""
 import os
@@ -34,7 +34,9 @@ def main():
 
     def fill(view):
         view[:] = raw
-    for name, fn in (('all-gather of %.2f MB through the staging buffers (1-rank RCCL group)' % (raw.size / 1e6), lambda: pdist._all_gather_bytes(fill, raw.size, None, dev)),
+    hint = {}
+    for name, fn in (('all-gather of %.2f MB through the staging buffers (1-rank RCCL group), counts + payload' % (raw.size / 1e6), lambda: pdist._all_gather_bytes(fill, raw.size, None, dev)),
+                     ('the same with a size hint: one collective', lambda: pdist._all_gather_bytes(fill, raw.size, None, dev, hint=hint)),
                      ('pep_merge_hits of %d hits from 2 reference shards' % n, lambda: N.merge_hits(allh, cig, 10, 5, out=keep))):
         keep = {}
         for _ in range(3):
