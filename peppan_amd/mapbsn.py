@@ -15,7 +15,6 @@ import io
 import queue
 import threading
 import os
-import re
 import sys
 import zipfile
 

@@ -14,7 +14,7 @@ from operator import itemgetter
 import numpy as np
 
 from .clust import getClust
-from .configure import logger, readFasta, uopen
+from .configure import logger, readFasta
 from .uberBlast import uberBlast, get_context
 
 

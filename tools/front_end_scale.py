@@ -2,7 +2,6 @@
 pan-genome (default 5 M = 10 000 genes x 500 genomes).  usage: python tools/front_end_scale.py [n_genes] [copies]"""
 import contextlib, io, os, resource, sys, tempfile, time
 sys.path.insert(0, '.')
-import numpy as np
 from peppan_amd import pipeline as PL, synth, _native as N
 n_base = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 copies = int(sys.argv[2]) if len(sys.argv) > 2 else 500

@@ -7,7 +7,7 @@ Prints the algorithmic byte counts of each stage (SURVEY.md 8d style) so that th
 import contextlib, io, os, sys, tempfile, time
 sys.path.insert(0, '.')
 import numpy as np
-from peppan_amd import _native as N, synth, uberBlast as UB, pipeline as PL, mapbsn
+from peppan_amd import synth, uberBlast as UB, mapbsn
 
 _start_dir = os.getcwd()
 os.chdir(tempfile.mkdtemp())
