@@ -280,7 +280,8 @@ def main():
         line = {
             'metric': 'gene_pairs_aligned_per_s', 'value': total_pairs / dt, 'unit': 'gene-pairs/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': dt / K * 1e3,
-            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic',
+            'dtype_note': 'both Smith-Waterman passes run in packed 16-bit integers (v_pk_*_i16) whenever the scores of a pair fit, which is every pair of this workload; 32-bit integer kernels otherwise; seed keys are 64-bit integers',
             'config': {'workload': 'synthgenes-v1 seed 355: %d genes x %d nt, all-vs-all (BASELINE configs[2] search stage), '
                                    'min_id 0.45 min_ratio 0.25 top-k 10 x 5 splits' % (args.genes, args.gene_len),
                        'queries_per_rank': shard.q1 - shard.q0, 'reference_genes_per_rank': shard.g1 - shard.g0,
