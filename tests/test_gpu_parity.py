@@ -931,7 +931,7 @@ def test_k9_gapped_verification_and_context_state(ctx):
         ctx.search(p)
 
 
-@pytest.mark.parametrize('seed', [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('seed', [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_search_parameter_fuzz(ctx, seed):
     """random gap costs, ungapped-filter settings, top-k / splits, HSP mode and thresholds: GPU == oracle on every field;
     then the packed 16-bit passes against the 32-bit passes of the GPU itself on a larger set"""
@@ -942,7 +942,8 @@ def test_search_parameter_fuzz(ctx, seed):
     p = N.default_params(float(rng.choice([0., 30., 60.])), float(rng.choice([0., 20., 70.])), int(rng.choice([1, 3, 10])), int(rng.choice([1, 5])),
                          ungapped_min=int(rng.choice([0, 30, 45, 60])))
     p.gap_open, p.gap_ext = int(rng.integers(5, 15)), int(rng.integers(1, 4))
-    p.xdrop, p.ext_right, p.ext_left = int(rng.integers(8, 21)), int(rng.integers(20, 49)), int(rng.integers(0, 41))
+    p.xdrop, p.ext_right, p.ext_left = int(rng.integers(8, 21)), int(rng.integers(8, 49)), int(rng.integers(0, 41))      # (ext_right below 16: the first filter stage judges a shorter extension)
+    p.stage1_min = min(int(rng.choice([0, 10, 24, 40])), p.ungapped_min) if p.ungapped_min else int(rng.choice([0, 24]))
     p.hsp_mode = int(rng.integers(0, 2))
     p.max_evalue = float(rng.choice([1., 1e-3, 10.]))
     if seed % 3 == 0:                            # a steeper substitution table (x3): the 16-bit passes must size their eligibility from it
