@@ -46,6 +46,19 @@ def grid_shape(world):
     return r, world // r
 
 
+GRID_MIN_REF_NT = 20000000     # reference nucleotides from which the reference side is split as well (choose_grid)
+
+
+def choose_grid(world, ref_nt_total):
+    """The grid a sharded search uses by default.  Splitting the reference shrinks the part of a search that grows with it (the streaming
+    of six frames per gene through the seed index) but costs the top-k merge after the exchange (0.3 ms for 35 k hits); below about
+    20 Mnt of reference - measured per-rank cells of the 10 k-gene workload: 2x4 1.37 ms, 8x1 1.39 ms, 1x8 1.25 ms, all of it fixed cost -
+    the merge is the larger of the two, and the queries alone are sharded (no merge: the tables concatenate)."""
+    if ref_nt_total < GRID_MIN_REF_NT:
+        return world, 1
+    return grid_shape(world)
+
+
 class _Staging(object):
     """byte buffers of one exchange, kept between steps and grown geometrically: page-locked host memory + device memory when the
     group runs over RCCL, plain host tensors under gloo.  A step then costs no allocation and no page faults."""
@@ -192,7 +205,7 @@ class ShardedSearch(object):
 
     def __init__(self, ctx, query_nt, ref_nt, params, rank=0, world=1, frames=6, gtable=11, grid=None, group=None, device=None):
         self.ctx, self.params, self.rank, self.world, self.group, self.device = ctx, params, rank, world, group, device
-        self.R, self.C = grid if grid is not None else grid_shape(world)
+        self.R, self.C = grid if grid is not None else choose_grid(world, sum(len(x) for x in ref_nt))
         if self.R * self.C != world:
             raise ValueError('grid %dx%d does not match world size %d' % (self.R, self.C, world))
         self.r, self.c = divmod(rank, self.C)

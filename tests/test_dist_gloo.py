@@ -193,7 +193,7 @@ def _grid_worker(rank, world, port, grid, out_q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,grid', [(2, (1, 2)), (2, (2, 1)), (4, (2, 2)), (4, None), (8, None)])
+@pytest.mark.parametrize('world,grid', [(2, (1, 2)), (2, (2, 1)), (4, (2, 2)), (4, None), (8, None), (8, (2, 4))])
 def test_sharded_all_vs_all_equals_single_process(world, grid):
     """queries x reference shards on a 2-D grid of gloo ranks (oracle-backed contexts): after the all-gather and pep_merge_hits every
     rank holds exactly the table of the unsharded search - every field, every CIGAR run - and the same target -> gene map"""
@@ -216,7 +216,7 @@ def test_sharded_all_vs_all_equals_single_process(world, grid):
         assert p.exitcode == 0
     cells = [r[1] for r in res]
     assert len(set(cells)) == world                                   # every rank owns a different (query range, reference range) cell
-    if (grid or pdist.grid_shape(world))[1] > 1:
+    if (grid or pdist.choose_grid(world, sum(len(x) for x in seqs)))[1] > 1:
         assert any(c[4] > 0 for c in cells)                           # some column really starts at a non-zero target index
     for rank, cell, hb, cb, gb in res:
         assert np.array_equal(np.frombuffer(hb, dtype=N.HIT_DTYPE), want_h), rank
@@ -227,3 +227,5 @@ def test_sharded_all_vs_all_equals_single_process(world, grid):
 def test_grid_shape():
     from peppan_amd import dist as pdist
     assert [pdist.grid_shape(w) for w in (1, 2, 3, 4, 6, 8, 16)] == [(1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (2, 4), (4, 4)]
+    # small references are not split (the merge would cost more than the split saves), large ones are
+    assert pdist.choose_grid(8, 10 ** 7) == (8, 1) and pdist.choose_grid(8, 5 * 10 ** 7) == (2, 4) and pdist.choose_grid(1, 10) == (1, 1)
