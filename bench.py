@@ -285,7 +285,7 @@ def main():
             'config': {'workload': 'synthgenes-v1 seed 355: %d genes x %d nt, all-vs-all (BASELINE configs[2] search stage), '
                                    'min_id 0.45 min_ratio 0.25 top-k 10 x 5 splits' % (args.genes, args.gene_len),
                        'queries_per_rank': shard.q1 - shard.q0, 'reference_genes_per_rank': shard.g1 - shard.g0,
-                       'parallelism': 'grid %d query shards x %d reference shards, all-gather + top-k merge of the hit tables' % (shard.R, shard.C)},
+                       'parallelism': 'grid %d query shards x %d reference shards, one all-gather of the hit tables%s' % (shard.R, shard.C, ' + exact top-k merge' if shard.C > 1 else ' (query shards only: the tables concatenate)')},
             'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3) if acc['ms_sw'] else None,
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
             'hits_per_step': float(len(allh)), 'clusters': int(len(np.unique(labels))), 'candidates_per_step': acc['candidates'] / K,
