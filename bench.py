@@ -97,8 +97,8 @@ def _profile_tables():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=50)      # (a step is 3 ms: ten of them are at the mercy of one stall of the runtime)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--genes', type=int, default=10000)
     ap.add_argument('--gene-len', type=int, default=1002)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -152,12 +152,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # host hygiene before anything is timed: with torch imported the interpreter holds a few million objects, and a full collection of
+    # the cyclic garbage collector would take milliseconds - more than a step.  Everything allocated so far is moved out of the collector's
+    # reach; the steps' own garbage is still collected.
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     sync()
     t0 = time.perf_counter()
     keys = ('candidates', 'cells', 'cells_swept', 'cells_swept_trace', 'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total',
-            'hits', 'dir_bytes', 'tracebacks', 'seed_hits', 'target_residues', 'query_residues', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')
+            'hits', 'dir_bytes', 'tracebacks', 'seed_hits', 'target_residues', 'query_residues', 'ms_host_translate', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')
     acc = dict.fromkeys(keys, 0.0)
     t_uf = 0.0
     for _ in range(args.steps):
@@ -292,7 +298,7 @@ def main():
             'value_definition': 'candidate (query, target-frame, band) pairs entering gapped Smith-Waterman per second of step wall time (SURVEY.md 8d-i); '
                                 'the pre-filter in front of that stage decides how many there are - see same_unit_as_round1',
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
-            'host_phase_ms_rank0': dict({k: acc[k] / K for k in ('ms_host_search', 'ms_host_exchange', 'ms_host_merge')}, ms_host_union_find=t_uf / K),
+            'host_phase_ms_rank0': dict({k: acc[k] / K for k in ('ms_host_translate', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')}, ms_host_union_find=t_uf / K),
             'roofline': top, 'roofline_kernels': rl,
             'cpu_baseline': cpu_line if world == 1 else None,
             'parity_check': parity,

@@ -81,6 +81,7 @@ struct pep_ctx {
     PinBuf pin_k1, pin_k1q, pin_k1n;        // grow-only: K1 descriptors of the reference / of the queries, the target count
     hipEvent_t k1_event = nullptr;          // the point of the stream where the reference side's downloads have arrived
     hipEvent_t wait_event = nullptr;        // pep_stream_wait: marks the point of the stream the host is waiting for
+    hipEvent_t k1_t0 = nullptr, k1_t1 = nullptr;   // pep_translate's timing pair (created once)
     bool k1_count_pending = false;
     PinBuf pin_stage;                       // grow-only: the hit table of the newest search
     PinBuf pin_ms;                          // grow-only: per-query score thresholds on their way to the device
@@ -133,6 +134,8 @@ struct pep_result {
 
 // HIP-event stopwatch on one stream (the kernel times bench.py reports are taken with it, inside the library,
 // on the stream the kernels are launched on); destroys its events on every exit path
+hipError_t pep_event_wait(hipEvent_t ev);      // polls before it sleeps (capi.hip)
+
 struct EventTimer {
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
@@ -145,7 +148,7 @@ struct EventTimer {
     float stop()                      // records the end event, waits for it, returns milliseconds (0 on failure)
     {
         float ms = 0.f;
-        if (a && b && hipEventRecord(b, st) == hipSuccess && hipEventSynchronize(b) == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
+        if (a && b && hipEventRecord(b, st) == hipSuccess && pep_event_wait(b) == hipSuccess) (void)hipEventElapsedTime(&ms, a, b);
         return ms;
     }
     ~EventTimer()

@@ -788,11 +788,12 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         const int tb = std::max(1, ilog2_ceil(T.n)), qb = std::max(1, ilog2_ceil(Q.n)), bb = std::max(1, ilog2_ceil((uint64_t)bin_max - bin_min + 1));
         hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256 * COMPACT_ROUNDS)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ws[3].as<uint64_t>(), cap,
                            ctx->ws[4].as<uint64_t>(), list_cap, counters);
-        uint32_t h_counters[4];
-        unsigned long long h_stats[3];
-        PEP_TRY(pep_read_back(ctx, h_counters, counters, sizeof(h_counters)));
-        PEP_TRY(pep_read_back(ctx, h_stats, stats, sizeof(h_stats)));
+        struct { uint32_t counters[4]; unsigned long long stats[3]; } h_all;        // counters[0..3] and the three statistics words behind them: one copy
+        static_assert(sizeof(h_all) == 40, "layout of the counter block");
+        PEP_TRY(pep_read_back(ctx, &h_all, counters, sizeof(h_all)));
         PEP_TRY(pep_sync_reads(ctx));
+        const uint32_t *h_counters = h_all.counters;
+        const unsigned long long *h_stats = h_all.stats;
         if (h_counters[3]) { use_partition = false; continue; }       // a coarse index bucket did not fit LDS: rebuild the plain way
         if (h_counters[2]) { hit_cap *= 4; continue; }                // raw hit buffer too small: retry 4x larger
         if (h_counters[1] || h_counters[0] > list_cap) { table_bits += 2; continue; }     // set too small: retry 4x larger

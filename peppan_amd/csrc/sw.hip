@@ -795,13 +795,13 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     if (trace) {
         // the traceback area is sized from the block total, so the host has to see it before the launch; the score pass needs neither
         // the per-candidate offsets nor the totals up front (they reach the statistics with the next synchronisation, see pep_extend)
-        uint64_t total_blk = 0;
-        unsigned long long h_cells = 0;
-        PEP_TRY(pep_read_back(ctx, &h_cells, cells, 8));
-        PEP_TRY(pep_read_back(ctx, &total_blk, cells + 1, 8));
-        PEP_TRY(pep_read_back(ctx, &n_long, cells + 3, 8));
+        unsigned long long h_tot[4] = {0, 0, 0, 0};            // cells, 16-step blocks, (work-queue counter), candidates above nb_limit: one copy
+        PEP_TRY(pep_read_back(ctx, h_tot, cells, sizeof(h_tot)));
         PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
         PEP_TRY(pep_sync_reads(ctx));
+        const unsigned long long h_cells = h_tot[0];
+        const uint64_t total_blk = h_tot[1];
+        n_long = h_tot[3];
         ctx->stats.cells_trace += h_cells;
         ctx->stats.cells_swept_trace += total_blk * 16 * 64;
         ctx->stats.dir_bytes += total_blk * 512;

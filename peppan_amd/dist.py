@@ -236,6 +236,7 @@ class ShardedSearch(object):
         t0 = time.perf_counter()
         if retranslate:
             self.ctx.translate(force=True)
+        t_k1 = time.perf_counter()
         hits, cigar, stats = self.ctx.search(self.params, copy=(copy and self.world == 1))
         t1 = time.perf_counter()
         keep = None if copy else self._scratch            # copy=False: the arrays of the previous step are overwritten
@@ -245,5 +246,5 @@ class ShardedSearch(object):
             from . import _native as N
             allh, allc = N.merge_hits(allh, allc, self.params.top_k, self.params.n_splits, out=None if copy else self._merged)
         # host wall time of the three parts of a step (the device phases are in the pep_search_stats fields)
-        stats = dict(stats, ms_host_search=(t1 - t0) * 1e3, ms_host_exchange=(t2 - t1) * 1e3, ms_host_merge=(time.perf_counter() - t2) * 1e3)
+        stats = dict(stats, ms_host_translate=(t_k1 - t0) * 1e3, ms_host_search=(t1 - t0) * 1e3, ms_host_exchange=(t2 - t1) * 1e3, ms_host_merge=(time.perf_counter() - t2) * 1e3)
         return allh, allc, stats
