@@ -16,6 +16,12 @@ import subprocess
 import sys
 import time
 
+# Copies go through blit kernels instead of the SDMA engines in this process (set before anything initialises the runtime): after every
+# torch.cuda.synchronize() - which the timed region is bracketed by - the runtime spends 5.6 ms, once, some nine to eighteen steps later,
+# on its copy queues; with twenty timed steps that is +0.28 ms per step in nine runs out of ten.  Without SDMA a
+# step costs 0.13 ms more and every step costs the same.  A library user who never calls a device-wide synchronisation keeps the default.
+os.environ.setdefault('HSA_ENABLE_SDMA', '0')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
@@ -97,11 +103,8 @@ def _profile_tables():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # a step is 3 ms.  With torch loaded in the process the HIP runtime spends 5.6 ms on some one-time housekeeping somewhere in the first
-    # hundred steps: the default warm-up leaves that behind, and the default timed region is long enough not to hinge on
-    # one step
     ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=150)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--genes', type=int, default=10000)
     ap.add_argument('--gene-len', type=int, default=1002)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -298,6 +301,7 @@ def main():
             'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3) if acc['ms_sw'] else None,
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
             'hits_per_step': float(len(allh)), 'clusters': int(len(np.unique(labels))), 'candidates_per_step': acc['candidates'] / K,
+            'runtime_env': {'HSA_ENABLE_SDMA': os.environ.get('HSA_ENABLE_SDMA')},
             'value_definition': 'candidate (query, target-frame, band) pairs entering gapped Smith-Waterman per second of step wall time (SURVEY.md 8d-i); '
                                 'the pre-filter in front of that stage decides how many there are - see same_unit_as_round1',
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},

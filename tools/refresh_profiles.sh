@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/.."
 R=${1:-r02}
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e   (MI355X; tools/rocpd_summary.py over the rocpd database)"; cat gpurun_out/final_stats.txt; } > profiles/${R}_final_kernel_stats.txt
-{ echo "# python bench.py  (MI355X; default flags: 1 GPU, 50 steps, 150 warmup, cpu baseline = oracle C port with OpenMP on every host thread, whole workload)"; cat gpurun_out/bench_line.txt; } > profiles/${R}_bench_line.txt
+{ echo "# python bench.py  (MI355X; default flags: 1 GPU, 50 steps, 5 warmup, cpu baseline = oracle C port with OpenMP on every host thread, whole workload)"; cat gpurun_out/bench_line.txt; } > profiles/${R}_bench_line.txt
 cp gpurun_out/counters.json profiles/${R}_counters.json
 { echo "# tools/micro/valu_rate (MI355X, gfx950): issue rate of the instructions the Smith-Waterman passes are made of; see the header of tools/micro/valu_rate.hip for the method"; cat gpurun_out/valu_rate.txt; } > profiles/${R}_valu_rate.txt
 { echo "# rocprofv3 --kernel-trace --pmc <one pass per line below> -- python3 tools/one_search.py   (10k genes x 1002 nt all-vs-all, 2 searches per pass; MI355X)"
