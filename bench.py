@@ -16,12 +16,6 @@ import subprocess
 import sys
 import time
 
-# Copies go through blit kernels instead of the SDMA engines in this process (set before anything initialises the runtime): after every
-# torch.cuda.synchronize() - which the timed region is bracketed by - the runtime spends 5.6 ms, once, some nine to eighteen steps later,
-# on its copy queues; with twenty timed steps that is +0.28 ms per step in nine runs out of ten.  Without SDMA a
-# step costs 0.13 ms more and every step costs the same.  A library user who never calls a device-wide synchronisation keeps the default.
-os.environ.setdefault('HSA_ENABLE_SDMA', '0')
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
@@ -167,6 +161,16 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    # After a device-wide synchronisation the HIP runtime re-establishes its SDMA copy queues, once, about a thousand submitted commands
+    # later: 5.6 ms in the middle of some step - with twenty timed steps +0.28 ms per step in nine runs out of ten.
+    # A burst of tiny SYNCHRONOUS library calls (a union-find over eight nodes each: two uploads, three kernels, one download; 20 ms in all)
+    # between the synchronisation and the start of the clock gets the runtime past that point; the device is idle again when the clock
+    # starts, and no step is run here.
+    settle_a, settle_b = np.array([0, 1, 2, 3], dtype=np.uint32), np.array([1, 2, 3, 4], dtype=np.uint32)
+    for _ in range(500):
+        ctx.components(8, settle_a, settle_b)
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     keys = ('candidates', 'cells', 'cells_swept', 'cells_swept_trace', 'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total',
             'hits', 'dir_bytes', 'tracebacks', 'seed_hits', 'target_residues', 'query_residues', 'ms_host_translate', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')
@@ -301,7 +305,6 @@ def main():
             'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3) if acc['ms_sw'] else None,
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
             'hits_per_step': float(len(allh)), 'clusters': int(len(np.unique(labels))), 'candidates_per_step': acc['candidates'] / K,
-            'runtime_env': {'HSA_ENABLE_SDMA': os.environ.get('HSA_ENABLE_SDMA')},
             'value_definition': 'candidate (query, target-frame, band) pairs entering gapped Smith-Waterman per second of step wall time (SURVEY.md 8d-i); '
                                 'the pre-filter in front of that stage decides how many there are - see same_unit_as_round1',
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
