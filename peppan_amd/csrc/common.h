@@ -110,6 +110,8 @@ struct pep_ctx {
     DevBuf ws[24];
     DevBuf sub_lds;                         // replicated substitution table image (32 KiB)
     DevBuf d_params;                        // device copy of seed params
+    int8_t d_params_host[1024] = {};        // what d_params holds (uploaded again only when the substitution table changes)
+    bool d_params_valid = false;
     // phase timers: events recorded on the stream, read once after the search's final synchronisation (waiting for an end event in
     // the middle of a search costs a host round trip with the GPU idle, and lets nothing be queued behind a running SW pass)
     hipEvent_t tm_a[12] = {}, tm_b[12] = {};

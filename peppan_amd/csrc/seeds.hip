@@ -15,6 +15,7 @@
 //                           already in the device hash set, or ungapped x-drop extension of its hits until one passes -> insert.
 //  The candidate set is compacted and radix-sorted (sort.hip) so every later stage is order-deterministic.
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -686,7 +687,12 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     uint32_t *counters = ctx->ws[6].as<uint32_t>();
     unsigned long long *stats = reinterpret_cast<unsigned long long *>(counters + 4);
     PEP_TRY(dev_reserve(ctx, ctx->d_params, 1024));
-    PEP_HIP(ctx, hipMemcpyAsync(ctx->d_params.p, P.sub, 1024, hipMemcpyHostToDevice, ctx->stream));
+    if (!ctx->d_params_valid || memcmp(ctx->d_params_host, P.sub, 1024) != 0) {
+        // (a copy out of pageable memory makes the host wait for the stream: only when the table really changed)
+        PEP_HIP(ctx, hipMemcpyAsync(ctx->d_params.p, P.sub, 1024, hipMemcpyHostToDevice, ctx->stream));
+        memcpy(ctx->d_params_host, P.sub, 1024);
+        ctx->d_params_valid = true;
+    }
 
     // candidate set: start near 64 slots per query (chance hits grow with |Q| x |T|), grow x4 on overflow
     int table_bits = std::max(20, std::min(28, ilog2_ceil(64ull * Q.n)));
