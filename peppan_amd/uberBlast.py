@@ -225,34 +225,56 @@ class RunBlast(object):
     # ---------------------------------------------------------------------------------------------- driver
     def run(self, ref, qry, methods, min_id, min_cov, min_ratio, table_id=11, n_thread=8, useProcess=False, re_score=0,
             filter=[False, 0.9, 0.], linear_merge=[False, 300., 1.2], return_overlap=[True, 300, 0.6], fix_end=[6., 6.]):
-        tools = dict(blastn=self.runBlast, diamond=self.runDiamond, diamondself=self.runDiamondSELF, gpu=self.runDiamond)
         self.min_id, self.min_cov, self.min_ratio = min_id, min_cov, min_ratio
         self.table_id, self.n_thread = table_id, n_thread
         self.pool = useProcess            # accepted for signature compatibility; the GPU path does not fan out
-        tables = []
-        try:
-            for method in methods:
-                if method.lower() in tools:
-                    tables.append(_as_table(tools[method.lower()](ref, qry)))
-        except N.PepError as e:
-            if 'PEP_ERR_LIMIT' in str(e) or '(-3)' in str(e):
-                raise                     # an input beyond a documented limit must not silently cost a whole tool's hits
-            import traceback
-            traceback.print_exc()
-        except Exception:
-            # same convention as the reference (uberBlast.py:347-349): report, keep what the other tools produced
-            import traceback
-            traceback.print_exc()
+        tables = self._run_tools(methods, ref, qry)
         return self._post(tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end)
+
+    def _tool_table(self):
+        """tool name -> callable(ref, qry).  Inside run() the built-in tools hand over the numeric HitTable (no Python object per cell);
+        the PUBLIC runBlast / runDiamond / runDiamondSELF keep the reference's plug-in contract - ndarray(object)[n, 15] (uberBlast.py:327,
+        343-353) - and a subclass that overrides one of them is called through its override (its rows are converted on entry)."""
+        cls = type(self)
+        pick = lambda public, internal: internal if getattr(cls, public) is _BUILTIN_TOOLS[public] else getattr(self, public)
+        return dict(blastn=pick('runBlast', self._runBlast_table), diamond=pick('runDiamond', self._runDiamond_table),
+                    diamondself=pick('runDiamondSELF', lambda ref, qry: self._runDiamond_table(ref, qry, nhits=200, frames='F')),
+                    gpu=pick('runDiamond', self._runDiamond_table))
+
+    def _run_tools(self, methods, ref, qry):
+        """the tools of one run in the order given.  A tool that fails is reported and the other tools' tables are kept - the reference's
+        convention (uberBlast.py:347-349) - but never silently: `failed_tools` lists (tool, message) of this run, and a PEP_ERR_LIMIT
+        (an input beyond a documented limit) is raised instead of costing a whole table."""
+        tools = self._tool_table()
+        tables, self.failed_tools = [], []
+        for method in methods:
+            if method.lower() not in tools:
+                continue
+            try:
+                tables.append(_as_table(tools[method.lower()](ref, qry)))
+            except N.PepError as e:
+                if 'PEP_ERR_LIMIT' in str(e) or '(-3)' in str(e):
+                    raise                     # an input beyond a documented limit must not silently cost a whole tool's hits
+                import traceback
+                traceback.print_exc()
+                self.failed_tools.append((method, str(e)))
+                break                         # (the reference's try block ends with the first failure, uberBlast.py:343-349)
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                self.failed_tools.append((method, repr(e)))
+                break
+        if self.failed_tools:
+            logger('WARNING: {0} of {1} search tools failed: {2}'.format(len(self.failed_tools), len(methods), ', '.join(m for m, _ in self.failed_tools)))
+        return tables
 
     def _post(self, tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end):
         """everything RunBlast.run does after the tools returned (uberBlast.py:352-376), on the numeric table; the object rows the
         caller gets are made at the very end"""
         T = HitTable.concat(tables)
         if len(T) == 0:
-            if return_overlap[0]:
-                return np.empty([0, 16], dtype=object), np.empty([0, 3], dtype=int)
-            return np.empty([0, 16], dtype=object)
+            none = HitTable.empty() if self._as_tables else np.empty([0, 16], dtype=object)
+            return (none, np.empty([0, 3], dtype=int)) if return_overlap[0] else none
         T.rid = np.arange(len(T), dtype=np.int64)
         if re_score:
             T = self._rescore_table(ref, qry, T, re_score, self.min_id, self.table_id)
@@ -294,7 +316,6 @@ class RunBlast(object):
 
     def _run_one_batch(self, refs, qry, methods, min_id, min_cov, min_ratio, table_id, n_thread, useProcess, re_score,
                        filter, linear_merge, return_overlap, fix_end):
-        tools = dict(blastn=self.runBlast, diamond=self.runDiamond, diamondself=self.runDiamondSELF, gpu=self.runDiamond)
         self.min_id, self.min_cov, self.min_ratio = min_id, min_cov, min_ratio
         self.table_id, self.n_thread, self.pool = table_id, n_thread, useProcess
         self.qrySeq = _read_cached(qry)
@@ -309,19 +330,7 @@ class RunBlast(object):
                 groups.append(g)
         self.refSeq, self._batch = combined, (names, groups)
         genome_of = dict(zip(names, groups))
-        tables = []
-        try:
-            for method in methods:
-                if method.lower() in tools:
-                    tables.append(_as_table(tools[method.lower()](None, None)))
-        except N.PepError as e:
-            if 'PEP_ERR_LIMIT' in str(e) or '(-3)' in str(e):
-                raise
-            import traceback
-            traceback.print_exc()
-        except Exception:
-            import traceback
-            traceback.print_exc()
+        tables = self._run_tools(methods, None, None)
         # rows of every tool's table by genome (the reference set of row's reference sequence), table order kept inside a genome
         split = []
         for T in tables:
@@ -367,10 +376,18 @@ class RunBlast(object):
         return s if isinstance(s, (str, bytes)) else ''.join('ACNGT'[int(x)] for x in s)
 
     # ---------------------------------------------------------------------------------------------- tools
+    # The three public tools keep the reference's plug-in contract (uberBlast.py:327): method(ref, qry) -> ndarray(object)[n, 15], names as
+    # str, CIGAR as [[n, op], ...] in nucleotides, rows in any order - what the reference's own run() loop vstacks (uberBlast.py:343-354).
     def runDiamondSELF(self, ref, qry):
-        return self.runDiamond(ref, qry, nhits=200, frames='F')
+        return self._runDiamond_table(ref, qry, nhits=200, frames='F').to_rows(with_rid=False)
 
     def runDiamond(self, ref, qry, nhits=10, frames='7'):
+        return self._runDiamond_table(ref, qry, nhits, frames).to_rows(with_rid=False)
+
+    def runBlast(self, ref, qry):
+        return self._runBlast_table(ref, qry).to_rows(with_rid=False)
+
+    def _runDiamond_table(self, ref, qry, nhits=10, frames='7'):
         """translated search on the GPU: K1 translate/pack, K2-K4 seeds, K5/K6 banded Smith-Waterman + traceback,
         K8 filters/top-k; thresholds as on the reference's diamond command line (uberBlast.py:550)"""
         logger('Run diamond starts')
@@ -388,7 +405,7 @@ class RunBlast(object):
         logger('Run diamond finishes. Got {0} alignments'.format(len(table)))
         return table
 
-    def runBlast(self, ref, qry):
+    def _runBlast_table(self, ref, qry):
         """nucleotide search on the same GPU engine, configured like the reference's blastn call (uberBlast.py:294):
         exact 17-mer seeds, +2/-3, gap 6+2k, e-value 1e-2 at dbsize 5e6, both strands of the reference, the
         -perc_identity / -qcov_hsp_perc cuts, then parseBlast's filters (uberBlast.py:283).  hsp_mode 1: every
@@ -519,6 +536,9 @@ class RunBlast(object):
         for col, vals in ((6, T.qs), (7, T.qe), (8, T.ss), (9, T.se)):
             blastab[:, col] = vals.tolist()
         blastab[:, 14] = T.cigar_strings()
+
+
+_BUILTIN_TOOLS = {name: getattr(RunBlast, name) for name in ('runBlast', 'runDiamond', 'runDiamondSELF')}     # as defined above: run() bypasses their object rows
 
 
 def _as_table(x):
