@@ -129,6 +129,7 @@ void pep_materialise_staged(pep_ctx *ctx)
     r->hits.assign(r->st_hits, r->st_hits + r->n_hits);
     r->cigar.assign(r->st_cigar, r->st_cigar + r->n_cigar);
     r->st_hits = nullptr; r->st_cigar = nullptr;
+    r->ctx = nullptr;                    // a result that owns its table needs the context no more (it may outlive it: pep_result_free after pep_ctx_destroy)
     ctx->staged_result = nullptr;
 }
 
@@ -375,9 +376,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     for (int id = 0; id < TM_COUNT; ++id) { if (ctx->tm_a[id]) (void)hipEventDestroy(ctx->tm_a[id]); if (ctx->tm_b[id]) (void)hipEventDestroy(ctx->tm_b[id]); }
     if (ctx->staged_result) {
         // the result outlives the context (freeing it afterwards is allowed): it takes its own copy and forgets the context
-        pep_result *r = ctx->staged_result;
         pep_materialise_staged(ctx);
-        r->ctx = nullptr;
     }
     if (ctx->pin_small.p) (void)hipHostFree(ctx->pin_small.p);
     if (ctx->pin_stage.p) (void)hipHostFree(ctx->pin_stage.p);
@@ -618,6 +617,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     pep_timers_resolve(ctx);
     res->stats = ctx->stats;
     if (res->st_hits || res->st_cigar) ctx->staged_result = res;
+    else res->ctx = nullptr;             // owns its (possibly empty) table from the start: nothing ties it to the context
     *out = res;
     return PEP_OK;
 }

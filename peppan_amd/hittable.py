@@ -169,6 +169,8 @@ class HitTable(object):
         fwd = self.se > self.ss
         d = np.where((head > 0) & (head <= se_lim), np.where(fwd, np.minimum(head, self.ss - 1), np.minimum(head, self.sl - self.ss)), 0)
         e = np.where((tail > 0) & (tail <= ee_lim), np.where(fwd, np.minimum(tail, self.sl - self.se), np.minimum(tail, self.se - 1)), 0)
+        if (self.c_runs[(d != 0) | (e != 0)] <= 0).any():
+            raise IndexError('fix_end: a row without CIGAR runs cannot be extended (the reference fails on cigar[0] here, uberBlast.py:468)')
         self.qs = self.qs - d
         self.ss = self.ss + np.where(fwd, -d, d)
         self.qe = self.qe + e
