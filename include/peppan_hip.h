@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 3
+#define PEP_ABI_VERSION 4
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -127,6 +127,7 @@ typedef struct {
     uint64_t sw_launches;
     uint64_t cells_trace;         /* DP cells recomputed by the traceback pass (selected pairs only) */
     uint64_t cells_swept_trace;   /* 64 lanes x steps executed by the traceback pass */
+    uint64_t tracebacks_gapless;  /* of `tracebacks`: pairs whose alignment is one ungapped run, settled without a traceback sweep (rule 5a) */
     double ms_seed, ms_sw, ms_trace, ms_total;   /* HIP-event times on the context's stream; ms_sw = score pass kernel */
     double ms_k1, ms_sw_trace;                   /* ms_sw_trace = traceback-pass kernel (selected pairs only) */
     double ms_seed_match;                        /* seed_match kernel, summed over the seed shapes (one launch per shape) */

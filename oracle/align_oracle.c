@@ -386,8 +386,27 @@ static void traceback(const sw_out *o, const uint8_t *q, const uint8_t *t, int32
  * maximum stays below T) is traced in the full band, from the full band's first maximal cell.  Either way the reported alignment has
  * score T; the rule only fixes WHICH optimal alignment is reported and lets the traceback pass sweep half the cells. */
 #define SUB_BAND 64
-static uint64_t g_traced = 0, g_full_band = 0;      /* how often the sub-band was enough (oracle_trace_counts) */
-void oracle_trace_counts(uint64_t *out, int reset) { out[0] = g_traced; out[1] = g_full_band; if (reset) g_traced = g_full_band = 0; }
+static uint64_t g_traced = 0, g_full_band = 0, g_gapless = 0;      /* how often the sub-band was enough / no DP was needed (oracle_trace_counts) */
+void oracle_trace_counts(uint64_t *out, int reset) { out[0] = g_traced; out[1] = g_full_band; out[2] = g_gapless; if (reset) g_traced = g_full_band = g_gapless = 0; }
+
+/* Gapless shortcut (rule 5a).  T = the band's score, d = one diagonal of the band.  If an UNGAPPED segment of d
+ * scores T, the alignment that ends in the segment's last cell is that segment and nothing else: H >= the running ungapped sum in every
+ * cell of d, so an H above the sum anywhere inside the segment would carry on to an H above T at its end - impossible, T is the band's
+ * maximum - hence H == h (the diagonal move, which has priority in the traceback) in every cell of the segment and H == 0 in front of
+ * it.  The scan is Kadane's: the running sum restarts AFTER a cell that brings it to <= 0 (so every prefix of the reported segment is
+ * positive) and the first cell at which it equals T ends the segment.  Returns 1 and the segment [is, ie] x [js, je], else 0. */
+static int gapless_segment(const oracle_params *p, const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt, int32_t d, int32_t T,
+                           int32_t *is, int32_t *ie)
+{
+    int32_t i0 = d < 0 ? -d : 0, i1 = Lq - 1 < Lt - 1 - d ? Lq - 1 : Lt - 1 - d;
+    int32_t run = 0, start = i0;
+    for (int32_t i = i0; i <= i1; ++i) {
+        run += p->sub[(q[i] & 31) * 32 + (t[i + d] & 31)];
+        if (run <= 0) { run = 0; start = i + 1; continue; }
+        if (run == T) { *is = start; *ie = i; return 1; }
+    }
+    return 0;
+}
 static void band_align(const oracle_params *p, const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt, int32_t dlo,
                        sw_out *o, runbuf *rb, int32_t *is, int32_t *js, uint32_t *nid, uint32_t *al)
 {
@@ -397,6 +416,22 @@ static void band_align(const oracle_params *p, const uint8_t *q, int32_t Lq, con
     if (wide.score <= 0) return;
     #pragma omp atomic
     ++g_traced;
+    /* rule 5a: the two diagonals of the lowest diagonal pair that holds the score (lower diagonal first) are tried for an ungapped
+     * segment with that score; the first one found IS the reported alignment - one M run, no second pass over the band */
+    for (int32_t x = 0; x < 2; ++x) {
+        const int32_t d = dlo + 2 * wide.end_lane + x;
+        int32_t gs, ge;
+        if (gapless_segment(p, q, Lq, t, Lt, d, wide.score, &gs, &ge)) {
+            rb->n = 0;
+            for (int32_t i = gs; i <= ge; ++i) push_op(rb, 0);
+            *is = gs; *js = gs + d; *al = (uint32_t)(ge - gs + 1); *nid = 0;
+            for (int32_t i = gs; i <= ge; ++i) *nid += q[i] == t[i + d];
+            o->iend = ge; o->jend = ge + d;
+            #pragma omp atomic
+            ++g_gapless;
+            return;
+        }
+    }
     int32_t L0 = wide.end_lane - SUB_BAND / 4;
     if (L0 < 0) L0 = 0;
     if (L0 > (BAND - SUB_BAND) / 2) L0 = (BAND - SUB_BAND) / 2;

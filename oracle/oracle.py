@@ -154,6 +154,13 @@ def align_one(q, t, bin_, params=None):
     return h, cig[:h.cigar_runs].copy()
 
 
+def trace_counts(reset=False):
+    """how the reported alignments were obtained since the last reset: (traced, needed the full band, gapless shortcut - rule 5a)"""
+    out = np.zeros(3, dtype=np.uint64)
+    lib().oracle_trace_counts(out.ctypes.data_as(C.c_void_p), C.c_int(1 if reset else 0))
+    return dict(traced=int(out[0]), full_band=int(out[1]), gapless=int(out[2]))
+
+
 def rescore_counts(q_codes, r_codes, qs, rs, re_, cigar):
     """mode-1 integer counts (nMatch, nMismatch, nGap, bGap, mGap); uberBlast.py:226-249, 412"""
     out = np.zeros(5, dtype=np.int64)

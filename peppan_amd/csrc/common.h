@@ -192,8 +192,9 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase = 0);
 int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase = 0);
 // ---- seeds.hip  (K2-K4)
 int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands);
+int pep_upload_sub_table(pep_ctx *ctx);       // ctx->params.sub -> ctx->d_params (1 KiB, uploaded when it changed)
 // ---- sw.hip / trace.hip (K5, K6, K8)
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known = nullptr, const int32_t *d_end_lane = nullptr);   // kernel time: phase timers TM_SW / TM_SW_TRACE
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known = nullptr, const int32_t *d_end_lane = nullptr, const int32_t *d_skip_mode = nullptr);   // kernel time: phase timers TM_SW / TM_SW_TRACE
 int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n_cands, const int32_t *h_min_score, pep_result *res);
 int pep_selftest_dpp(pep_ctx *ctx);
 // ---- rescore.hip (K7)

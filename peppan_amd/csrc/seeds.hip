@@ -657,6 +657,21 @@ int ilog2_ceil(uint64_t x)
 
 }  // namespace
 
+// the plain 32 x 32 substitution table of the current parameters in device memory (ctx->d_params): the ungapped extension of the seed
+// stage and the gapless shortcut of the traceback stage read it
+int pep_upload_sub_table(pep_ctx *ctx)
+{
+    const pep_search_params &P = ctx->params;
+    PEP_TRY(dev_reserve(ctx, ctx->d_params, 1024));
+    if (!ctx->d_params_valid || memcmp(ctx->d_params_host, P.sub, 1024) != 0) {
+        // (a copy out of pageable memory makes the host wait for the stream: only when the table really changed)
+        PEP_HIP(ctx, hipMemcpyAsync(ctx->d_params.p, P.sub, 1024, hipMemcpyHostToDevice, ctx->stream));
+        memcpy(ctx->d_params_host, P.sub, 1024);
+        ctx->d_params_valid = true;
+    }
+    return PEP_OK;
+}
+
 // workspace slots used here: ws[0] cnt, ws[1] start, ws[2] entries, ws[3] table, ws[4] list, ws[5] list tmp (sort),
 // ws[6] counters+stats, ws[7] scan scratch, ws[8] raw seed hits, ws[10..12] runs of hits (the sort histogram reuses ws[0])
 int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
@@ -686,13 +701,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     uint64_t *entries = ctx->ws[2].as<uint64_t>();
     uint32_t *counters = ctx->ws[6].as<uint32_t>();
     unsigned long long *stats = reinterpret_cast<unsigned long long *>(counters + 4);
-    PEP_TRY(dev_reserve(ctx, ctx->d_params, 1024));
-    if (!ctx->d_params_valid || memcmp(ctx->d_params_host, P.sub, 1024) != 0) {
-        // (a copy out of pageable memory makes the host wait for the stream: only when the table really changed)
-        PEP_HIP(ctx, hipMemcpyAsync(ctx->d_params.p, P.sub, 1024, hipMemcpyHostToDevice, ctx->stream));
-        memcpy(ctx->d_params_host, P.sub, 1024);
-        ctx->d_params_valid = true;
-    }
+    PEP_TRY(pep_upload_sub_table(ctx));
 
     // candidate set: start near 64 slots per query (chance hits grow with |Q| x |T|), grow x4 on overflow
     int table_bits = std::max(20, std::min(28, ilog2_ceil(64ull * Q.n)));

@@ -654,7 +654,8 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
                                                const uint32_t *__restrict__ t_len, uint32_t *__restrict__ nblk, uint64_t *__restrict__ nblk64,
                                                unsigned long long *__restrict__ cells_total,           // [0] cells, [1] 16-step blocks, [3] candidates above nb_limit
                                                uint32_t *__restrict__ len_hist,                        // [LEN_BUCKETS] candidates per length bucket
-                                               uint32_t nb_limit)
+                                               uint32_t nb_limit,
+                                               const int32_t *__restrict__ skip_mode)                  // traceback pass: candidates settled without a sweep (mode -2, gapless_check) take no part
 {
     __shared__ uint32_t lh[LEN_BUCKETS];
     for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) lh[x] = 0;
@@ -662,7 +663,8 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long cells = 0, blocks = 0;
     bool is_long = false;
-    if (c < n) {
+    if (c < n && skip_mode && skip_mode[c] == -2) { nblk[c] = 0; nblk64[c] = 0; }
+    else if (c < n) {
         const uint64_t key = cands[c];
         const uint32_t q = (uint32_t)(key >> 43), t = (uint32_t)((key >> 18) & ((1u << 25) - 1));
         const int bin = (int)(key & ((1u << 18) - 1));
@@ -685,8 +687,11 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
         is_long = nb > nb_limit;
         atomicAdd(&lh[len_bucket(nb)], 1u);
     }
+    const bool active = c < n && !(skip_mode && skip_mode[c] == -2);
     const int longs = __syncthreads_count(is_long);
+    const int actives = __syncthreads_count(active);
     if (threadIdx.x == 0 && longs) atomicAdd(&cells_total[3], (unsigned long long)longs);
+    if (threadIdx.x == 0 && actives) atomicAdd(&cells_total[5], (unsigned long long)actives);      // candidates that enter the order (and the sweep)
     // totals: one pair of atomics per block (every wavefront adding to the same two words serialises in the L2)
     __shared__ unsigned long long tot[2][4];
     for (int d = 32; d > 0; d >>= 1) { cells += __shfl_down(cells, d, 64); blocks += __shfl_down(blocks, d, 64); }
@@ -703,7 +708,7 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
 // atomics hand out - results are per candidate, so it does not matter).  Equal lengths side by side keep both halves of a packed
 // wavefront busy to the end; longest first keeps the tail of the launch short.
 __global__ __launch_bounds__(256) void sw_order(const uint32_t *__restrict__ nblk, uint64_t n, const uint32_t *__restrict__ len_hist,
-                                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ order)
+                                                uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, const int32_t *__restrict__ skip_mode)
 {
     __shared__ uint32_t start[LEN_BUCKETS], lh[LEN_BUCKETS], base[LEN_BUCKETS], part[256];
     // start[b] = candidates in longer buckets: every block rebuilds the (tiny) scan
@@ -724,11 +729,12 @@ __global__ __launch_bounds__(256) void sw_order(const uint32_t *__restrict__ nbl
     for (int k = 0; k < LEN_BUCKETS / 256; ++k) { start[LEN_BUCKETS - 1 - (threadIdx.x * (LEN_BUCKETS / 256) + k)] = run; run += mine[k]; }
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t b = 0, rank = 0;
-    if (c < n) { b = len_bucket(nblk[c]); rank = atomicAdd(&lh[b], 1u); }
+    const bool active = c < n && !(skip_mode && skip_mode[c] == -2);
+    if (active) { b = len_bucket(nblk[c]); rank = atomicAdd(&lh[b], 1u); }
     __syncthreads();
     for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) if (lh[x]) base[x] = atomicAdd(&cursor[x], lh[x]);
     __syncthreads();
-    if (c < n) order[start[b] + base[b] + rank] = (uint32_t)c;
+    if (active) order[start[b] + base[b] + rank] = (uint32_t)c;
 }
 
 __global__ void dpp_probe(int *out)
@@ -756,7 +762,7 @@ int pep_selftest_dpp(pep_ctx *ctx)
 
 // Runs K5 over `n` candidate keys.  trace = false: score pass (ws[12] <- score / end cell / a0 per candidate).
 // trace = true: same DP plus traceback codes (ws[11] dir_off u64[n+1], ws[13] dirs).  ws[10] nblk, ws[14] scan input.
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known, const int32_t *d_end_lane)
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known, const int32_t *d_end_lane, const int32_t *d_skip_mode)
 {
     const pep_search_params &P = ctx->params;
     if (n == 0) return PEP_OK;
@@ -788,26 +794,28 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     uint32_t *len_hist = reinterpret_cast<uint32_t *>(ctx->ws[15].as<unsigned char>() + 64), *cursor = len_hist + LEN_BUCKETS, *order = cursor + LEN_BUCKETS;
     PEP_HIP(ctx, hipMemsetAsync(cells, 0, 64 + 2 * hist_bytes, ctx->stream));
     hipLaunchKernelGGL(sw_prep, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_cands, n, ctx->q.len.as<const uint32_t>(),
-                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist, nb_limit);
+                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist, nb_limit, trace ? d_skip_mode : nullptr);
     hipLaunchKernelGGL(sw_order, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[10].as<const uint32_t>(), n,
-                       (const uint32_t *)len_hist, cursor, order);
+                       (const uint32_t *)len_hist, cursor, order, trace ? d_skip_mode : nullptr);
     unsigned long long n_long = 0;
+    uint64_t n_active = n;                  // candidates in `order` (traceback pass: those the gapless shortcut did not settle)
     if (trace) {
         // the traceback area is sized from the block total, so the host has to see it before the launch; the score pass needs neither
         // the per-candidate offsets nor the totals up front (they reach the statistics with the next synchronisation, see pep_extend)
-        unsigned long long h_tot[4] = {0, 0, 0, 0};            // cells, 16-step blocks, (work-queue counter), candidates above nb_limit: one copy
+        unsigned long long h_tot[6] = {0, 0, 0, 0, 0, 0};      // cells, 16-step blocks, (work-queue counter), candidates above nb_limit, (queue), candidates in the order: one copy
         PEP_TRY(pep_read_back(ctx, h_tot, cells, sizeof(h_tot)));
         PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
         PEP_TRY(pep_sync_reads(ctx));
         const unsigned long long h_cells = h_tot[0];
         const uint64_t total_blk = h_tot[1];
         n_long = h_tot[3];
+        n_active = h_tot[5];
         ctx->stats.cells_trace += h_cells;
         ctx->stats.cells_swept_trace += total_blk * 16 * 64;
         ctx->stats.dir_bytes += total_blk * 512;
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 512 + 512));
         PEP_TRY(dev_reserve(ctx, ctx->d_trace_mode, (n + 1) * sizeof(int32_t)));
-        if (!pk16) n_long = n;
+        if (!pk16) n_long = n_active;
     } else {
         PEP_TRY(pep_read_back(ctx, ctx->sw_totals, cells, 16));
         ctx->sw_totals_pending = true;
@@ -840,8 +848,8 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
         const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16 / WAVES_PER_BLOCK, (160 * 1024) / std::max<size_t>(smem, 1)));
         struct { uint64_t first, count; int span; unsigned int *queue; } part[2] = {
-            {0, (uint64_t)std::min<unsigned long long>(n_long, n), 1, reinterpret_cast<unsigned int *>(cells + 2)},          // too long for the staging area: one per wavefront
-            {(uint64_t)std::min<unsigned long long>(n_long, n), n - (uint64_t)std::min<unsigned long long>(n_long, n), 4, reinterpret_cast<unsigned int *>(cells + 4)}};
+            {0, (uint64_t)std::min<unsigned long long>(n_long, n_active), 1, reinterpret_cast<unsigned int *>(cells + 2)},          // too long for the staging area: one per wavefront
+            {(uint64_t)std::min<unsigned long long>(n_long, n_active), n_active - (uint64_t)std::min<unsigned long long>(n_long, n_active), 4, reinterpret_cast<unsigned int *>(cells + 4)}};
         for (const auto &pt : part) {
             if (pt.count == 0) continue;
             a.item_first = pt.first; a.item_count = pt.count; a.item_span = pt.span; a.queue = pt.queue;

@@ -67,6 +67,69 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
     run_cap[pos[c]] = 2ull * min(q_len[key_q(k)], t_len[key_t(k)]) + 2;
 }
 
+// Rule 5a (oracle: gapless_segment / band_align): before any traceback sweep, the two diagonals of the lowest lane
+// that met the band's score T in the score pass are scanned for an UNGAPPED segment scoring T.  Such a segment IS the alignment that ends
+// in its last cell (H equals the running ungapped sum all along it - anything larger would end above T - and the diagonal move has
+// priority), so the pair is settled as one M run: mode -2, no codes, no walk.  One wavefront per pair; a diagonal is taken 64 cells at a
+// time: P = inclusive prefix sum, M = inclusive prefix minimum of P (with the 0 in front), run = P - M is Kadane's running sum with its
+// restart after every cell that brings it to <= 0; the first cell with run == T ends the segment, the last restart before it starts it.
+__global__ __launch_bounds__(256) void gapless_check(uint64_t n_sel, const uint64_t *__restrict__ cands, const int32_t *__restrict__ known,
+                                                     const int32_t *__restrict__ end_lane, const uint8_t *__restrict__ q_res, const uint32_t *__restrict__ q_off,
+                                                     const uint32_t *__restrict__ q_len, const uint8_t *__restrict__ t_res, const uint32_t *__restrict__ t_off,
+                                                     const uint32_t *__restrict__ t_len, const int8_t *__restrict__ sub_g, int4 *__restrict__ out,
+                                                     int32_t *__restrict__ mode, uint32_t *__restrict__ n_gapless)
+{
+    __shared__ int8_t sub[1024];
+    reinterpret_cast<uint32_t *>(sub)[threadIdx.x] = reinterpret_cast<const uint32_t *>(sub_g)[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n_sel) return;                                     // (whole wavefronts leave together)
+    const uint64_t key = cands[s];
+    const uint32_t q = key_q(key), t = key_t(key);
+    const int T = known[s];
+    const int Lq = (int)q_len[q], Lt = (int)t_len[t];
+    const uint8_t *qs = q_res + q_off[q], *ts = t_res + t_off[t];
+    int found_is = -1, found_ie = -1, found_d = 0;
+    for (int x = 0; x < 2 && found_is < 0 && T > 0; ++x) {
+        const int d = key_dlo(key) + 2 * end_lane[s] + x;
+        const int i0 = max(0, -d), i1 = min(Lq - 1, Lt - 1 - d);
+        int carry_p = 0, carry_m = 0, last_reset = -1;          // in cells of this diagonal: cell k is (i0 + k, i0 + k + d)
+        for (int base = 0; base <= i1 - i0; base += 64) {       // wave-uniform trip count
+            const int k = base + lane;
+            const bool valid = i0 + k <= i1;
+            int v = valid ? (int)sub[(qs[i0 + k] & 31) * 32 + (ts[i0 + k + d] & 31)] : 0;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(v, sh, 64); if (lane >= sh) v += o; }
+            const int P = carry_p + v;
+            int m = P;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(m, sh, 64); if (lane >= sh) m = min(m, o); }
+            const int M = min(m, carry_m);
+            const int run = P - M;
+            const unsigned long long hit = __ballot(valid && run == T);
+            const unsigned long long resets = __ballot(valid && run == 0);
+            if (hit) {
+                const int l = __builtin_ctzll(hit);
+                const unsigned long long before = resets & ((1ull << l) - 1ull);
+                const int start_k = before ? base + (63 - __builtin_clzll(before)) + 1 : last_reset + 1;
+                found_is = i0 + start_k; found_ie = i0 + base + l; found_d = d;
+                break;
+            }
+            if (resets) last_reset = base + (63 - __builtin_clzll(resets));
+            carry_p = __shfl(P, 63, 64);
+            carry_m = __shfl(M, 63, 64);
+        }
+    }
+    if (lane == 0) {
+        if (found_is >= 0) {
+            out[s] = make_int4(T, found_ie, found_ie + found_d, found_ie - found_is + 1);       // score, end cell, run length
+            mode[s] = -2;
+            atomicAdd(n_gapless, 1u);
+        } else mode[s] = -1;
+    }
+}
+
 // One THREAD per selected pair.  The walk is a serial chain of tiny decisions; spread over a wavefront (one alignment per wave, as the
 // first version did) every decision costs an issue slot of the whole CU - vector or scalar unit alike - and 40 k alignments took
 // 0.48 ms.  One alignment per lane instead; with all 64 lanes of a wave in use there are too few waves to hide the load latency
@@ -87,6 +150,15 @@ __global__ __launch_bounds__(WALK_LANES) void walk(uint64_t n_sel, SelInfo *__re
     // the codes cover the full band (64 lanes, mode -1) or the sub-band that starts at lane mode[] (32 lanes): the row of one 16-step
     // block holds 2 dwords per lane
     const int md = mode[info.cand];
+    if (md == -2) {
+        // settled by the gapless shortcut (gapless_check): sw[] holds score, end cell and the length of the one M run
+        const int4 g = sw[info.cand];
+        info.iend = g.y; info.jend = g.z; info.istart = g.y - g.w + 1; info.jstart = g.z - g.w + 1;
+        info.n_runs = 1; info.aln_len = (uint32_t)g.w;
+        runs[run_off[s]] = ((uint32_t)g.w << 2);
+        sel[s] = info;
+        return;
+    }
     const int dlo = key_dlo(key) + (md > 0 ? 2 * md : 0);
     const size_t row = md < 0 ? 128 : 64;
     const int4 cell = sw[info.cand];
@@ -355,9 +427,20 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
                            ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known, end_lane);
         PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_sel, ctx->ws[7]));
         uint64_t total_runs = 0;
+        uint32_t n_gapless = 0;
         PEP_TRY(pep_read_back(ctx, &total_runs, run_off + n_sel, 8));       // arrives with the synchronisation inside pep_sw_run (block total)
-        // ---- pass 2: the same DP with traceback codes, selected pairs only (overwrites the pass-1 per-candidate arrays)
-        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, known, end_lane));
+        // ---- rule 5a: pairs whose alignment is one ungapped run are settled without a sweep (the score-pass results in ws[12] have been
+        // consumed by gather_sel: the slots of the selected pairs are written from here on)
+        PEP_TRY(dev_reserve(ctx, ctx->d_trace_mode, ((size_t)n_sel + 1) * sizeof(int32_t)));
+        PEP_TRY(pep_upload_sub_table(ctx));                                 // (K9 drives this stage without the seed stage in front)
+        hipLaunchKernelGGL(gapless_check, dim3((unsigned)ceil_div(n_sel, 4)), dim3(256), 0, st, (uint64_t)n_sel, (const uint64_t *)sel_keys, (const int32_t *)known,
+                           (const int32_t *)end_lane, ctx->q.res.as<const uint8_t>(), ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(),
+                           ctx->t.res.as<const uint8_t>(), ctx->t.off.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), ctx->d_params.as<const int8_t>(),
+                           ctx->ws[12].as<int4>(), ctx->d_trace_mode.as<int32_t>(), counters + 1);
+        PEP_TRY(pep_read_back(ctx, &n_gapless, counters + 1, 4));
+        // ---- pass 2: the same DP with traceback codes, the remaining selected pairs only
+        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, known, end_lane, ctx->d_trace_mode.as<const int32_t>()));
+        ctx->stats.tracebacks_gapless = n_gapless;
         const int4 *sw2 = ctx->ws[12].as<const int4>();
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
         uint32_t *runs = ctx->ws[21].as<uint32_t>();

@@ -69,8 +69,9 @@ def make_genes(n_genes, fixed_len=1002, seed=355, family=4):
     return names, seqs
 
 
-def make_proteins(n, length=300, seed=1, family=3, sub=0.2):
-    """random protein families as residue-code arrays (letter - 'A'), for kernel-level tests"""
+def make_proteins(n, length=300, seed=1, family=3, sub=0.2, indel=0.7):
+    """random protein families as residue-code arrays (letter - 'A'), for kernel-level tests; indel = probability that a member carries one
+    insertion or deletion of 1-8 residues"""
     rng = np.random.default_rng(seed)
     aa = np.frombuffer(b'ARNDCQEGHILKMFPSTWYV', dtype=np.uint8) - 65
     out = []
@@ -82,7 +83,7 @@ def make_proteins(n, length=300, seed=1, family=3, sub=0.2):
             m = root.copy()
             pos = rng.random(L) < sub
             m[pos] = aa[rng.integers(0, 20, int(pos.sum()))]
-            if L > 60 and rng.random() < 0.7:
+            if L > 60 and rng.random() < indel:
                 p = int(rng.integers(20, L - 30)); k = int(rng.integers(1, 9))
                 m = np.concatenate([m[:p], m[p + k:]]) if rng.random() < 0.5 else np.concatenate([m[:p], aa[rng.integers(0, 20, k)], m[p:]])
             out.append(m)

@@ -38,6 +38,40 @@ def test_search_protein_families(ctx, use_lds, min_id, min_qcov, top_k):
     assert len(gh) > 300
 
 
+def test_gapless_shortcut_counts_and_parity(ctx):
+    """rule 5a: pairs whose alignment is one ungapped run are settled without a traceback sweep - the same pairs in the kernel and in the
+    oracle (counted on both sides), and the table stays bit-exact.  Families without indels (most pairs gapless), with indels, the 32-bit
+    passes, the nucleotide configuration (hsp_mode 1, long pairs one per wavefront) and sequences that start / end inside the run."""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    for kw, forced32 in ((dict(sub=0.2, indel=0.), False), (dict(sub=0.25), False), (dict(sub=0.2, indel=0.), True)):
+        prots = synth.make_proteins(300, length=(40, 500), seed=23, family=5, **kw)
+        prots[5] = prots[6][7:]                 # a member that is a suffix / prefix of another: runs that touch row 0 / column 0 / the last cell
+        prots[11] = prots[10][:-9]
+        ctx.set_query_aa(prots)
+        ctx.set_ref_aa(prots)
+        p = N.default_params(30., 10., 10, 5)
+        p.reserved[1] = 1 if forced32 else 0
+        gh, gc, st = ctx.search(p)
+        O.trace_counts(True)
+        oh, oc, ost = O.search(prots, prots, O.default_params(30., 10., 10, 5))
+        tc = O.trace_counts()
+        _cmp_hits(gh, gc, oh, oc)
+        assert st['tracebacks'] == tc['traced'] and st['tracebacks_gapless'] == tc['gapless'], (st['tracebacks'], st['tracebacks_gapless'], tc)
+        assert tc['gapless'] >= 300 and (kw.get('indel', 1) != 0. or tc['gapless'] > 0.8 * tc['traced'])
+    names, seqs = synth.make_genes(120, 0, seed=4)
+    codes = [O.nt_codes(s.decode()) for s in seqs]
+    rc = [(3 - c[::-1]).astype(np.uint8) for c in codes]
+    ctx.set_query_aa(codes)
+    ctx.set_ref_aa(codes + rc)
+    gh, gc, st = ctx.search(N.nucleotide_params(60., 20.))
+    O.trace_counts(True)
+    oh, oc, ost = O.search(codes, codes + rc, O.params_from(N.nucleotide_params(60., 20.)))
+    tc = O.trace_counts()
+    _cmp_hits(gh, gc, oh, oc)
+    assert st['tracebacks'] == tc['traced'] and st['tracebacks_gapless'] == tc['gapless'] >= 120
+
+
 def test_search_ragged_and_empty(ctx):
     from peppan_amd import _native as N, synth
     from oracle import oracle as O
