@@ -118,6 +118,7 @@ struct pep_ctx {
     int tm_state[12] = {};                   // 0 idle, 1 begun, 2 ended (waiting to be read)
     unsigned long long sw_totals[2] = {};   // score pass: cells / 16-step blocks, read back with the next synchronisation
     bool sw_totals_pending = false;
+    uint64_t trace_swept = 0;               // pairs the last traceback pass swept (the rest were settled by the gapless shortcut)
     struct ScanState { DevBuf buf; uint32_t epoch = 0, ticket_base = 0; };
     ScanState scan_state[2];                // single-launch scans (u32, u64): ticket counter + one status word per tile (scan.hip)
     // stats of the last search

@@ -810,6 +810,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
         const uint64_t total_blk = h_tot[1];
         n_long = h_tot[3];
         n_active = h_tot[5];
+        ctx->trace_swept = n_active;
         ctx->stats.cells_trace += h_cells;
         ctx->stats.cells_swept_trace += total_blk * 16 * 64;
         ctx->stats.dir_bytes += total_blk * 512;

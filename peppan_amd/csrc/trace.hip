@@ -70,14 +70,30 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
 // Rule 5a (oracle: gapless_segment / band_align): before any traceback sweep, the two diagonals of the lowest lane
 // that met the band's score T in the score pass are scanned for an UNGAPPED segment scoring T.  Such a segment IS the alignment that ends
 // in its last cell (H equals the running ungapped sum all along it - anything larger would end above T - and the diagonal move has
-// priority), so the pair is settled as one M run: mode -2, no codes, no walk.  One wavefront per pair; a diagonal is taken 64 cells at a
-// time: P = inclusive prefix sum, M = inclusive prefix minimum of P (with the 0 in front), run = P - M is Kadane's running sum with its
-// restart after every cell that brings it to <= 0; the first cell with run == T ends the segment, the last restart before it starts it.
+// priority), so the pair is settled as one M run: mode -2, no codes, no walk.
+// One wavefront per pair; a diagonal is taken 512 cells at a time, eight consecutive cells per lane (two unaligned 8-byte loads - the
+// packed sets carry >= 16 bytes of padding behind every sequence - and eight independent table reads).  With P = prefix sum of the
+// scores and M = prefix minimum of P (the 0 in front included), run = P - M is Kadane's running sum with its restart after every cell
+// that brings it to <= 0: lane sums and lane minima are scanned across the wavefront with DPP moves (no LDS round trips: a first
+// version built on __shfl_up spent 165 us in dependent ds_bpermute chains), then every lane replays its eight cells.  The first cell
+// with run == T ends the segment, the last restart before it starts it.
+template <class Op>
+__device__ __forceinline__ int wave_scan_incl(int v, const int identity, Op op)
+{
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false));      // row_shr:1
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false));      // row_shr:2
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false));      // row_shr:4
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false));      // row_shr:8
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false));      // row_bcast:15 -> rows 1, 3
+    v = op(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false));      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 __global__ __launch_bounds__(256) void gapless_check(uint64_t n_sel, const uint64_t *__restrict__ cands, const int32_t *__restrict__ known,
                                                      const int32_t *__restrict__ end_lane, const uint8_t *__restrict__ q_res, const uint32_t *__restrict__ q_off,
                                                      const uint32_t *__restrict__ q_len, const uint8_t *__restrict__ t_res, const uint32_t *__restrict__ t_off,
                                                      const uint32_t *__restrict__ t_len, const int8_t *__restrict__ sub_g, int4 *__restrict__ out,
-                                                     int32_t *__restrict__ mode, uint32_t *__restrict__ n_gapless)
+                                                     int32_t *__restrict__ mode)
 {
     __shared__ int8_t sub[1024];
     reinterpret_cast<uint32_t *>(sub)[threadIdx.x] = reinterpret_cast<const uint32_t *>(sub_g)[threadIdx.x];
@@ -90,42 +106,60 @@ __global__ __launch_bounds__(256) void gapless_check(uint64_t n_sel, const uint6
     const int T = known[s];
     const int Lq = (int)q_len[q], Lt = (int)t_len[t];
     const uint8_t *qs = q_res + q_off[q], *ts = t_res + t_off[t];
+    constexpr int INF = 0x3fffffff;
+    auto add = [](int a, int b) { return a + b; };
+    auto mn = [](int a, int b) { return min(a, b); };
     int found_is = -1, found_ie = -1, found_d = 0;
     for (int x = 0; x < 2 && found_is < 0 && T > 0; ++x) {
         const int d = key_dlo(key) + 2 * end_lane[s] + x;
-        const int i0 = max(0, -d), i1 = min(Lq - 1, Lt - 1 - d);
-        int carry_p = 0, carry_m = 0, last_reset = -1;          // in cells of this diagonal: cell k is (i0 + k, i0 + k + d)
-        for (int base = 0; base <= i1 - i0; base += 64) {       // wave-uniform trip count
-            const int k = base + lane;
-            const bool valid = i0 + k <= i1;
-            int v = valid ? (int)sub[(qs[i0 + k] & 31) * 32 + (ts[i0 + k + d] & 31)] : 0;
+        const int i0 = max(0, -d), n = min(Lq - 1, Lt - 1 - d) - i0 + 1;        // cell k of the diagonal is (i0 + k, i0 + k + d)
+        int carry_p = 0, carry_m = 0, last_reset = -1;
+        for (int base = 0; base < n; base += 512) {             // wave-uniform trip count
+            const int k0 = base + lane * 8;
+            uint32_t qw[2] = {0u, 0u}, tw[2] = {0u, 0u};
+            if (k0 < n) { __builtin_memcpy(qw, qs + i0 + k0, 8); __builtin_memcpy(tw, ts + i0 + k0 + d, 8); }
+            int sc[8], S = 0, lmin = INF;
 #pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(v, sh, 64); if (lane >= sh) v += o; }
-            const int P = carry_p + v;
-            int m = P;
+            for (int u = 0; u < 8; ++u) {
+                const int qc = (qw[u >> 2] >> ((u & 3) * 8)) & 31, tc = (tw[u >> 2] >> ((u & 3) * 8)) & 31;
+                sc[u] = k0 + u < n ? (int)sub[qc * 32 + tc] : 0;
+            }
 #pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) { const int o = __shfl_up(m, sh, 64); if (lane >= sh) m = min(m, o); }
-            const int M = min(m, carry_m);
-            const int run = P - M;
-            const unsigned long long hit = __ballot(valid && run == T);
-            const unsigned long long resets = __ballot(valid && run == 0);
+            for (int u = 0; u < 8; ++u) { S += sc[u]; lmin = min(lmin, S); }
+            const int p_start = carry_p + wave_scan_incl(S, 0, add) - S;
+            const int m_incl = wave_scan_incl(p_start + lmin, INF, mn);
+            const int m_start = min(carry_m, __builtin_amdgcn_update_dpp(INF, m_incl, 0x138, 0xf, 0xf, false));      // lane l <- lane l - 1
+            int P = p_start, M = m_start, first = -1, reset = -1;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                P += sc[u]; M = min(M, P);
+                const bool live = k0 + u < n && first < 0;
+                if (live && P - M == T) first = u;
+                if (live && P == M) reset = u;
+            }
+            const unsigned long long hit = __ballot(first >= 0);
+            const unsigned long long resets = __ballot(reset >= 0);
             if (hit) {
                 const int l = __builtin_ctzll(hit);
-                const unsigned long long before = resets & ((1ull << l) - 1ull);
-                const int start_k = before ? base + (63 - __builtin_clzll(before)) + 1 : last_reset + 1;
-                found_is = i0 + start_k; found_ie = i0 + base + l; found_d = d;
+                const int f = __builtin_amdgcn_readlane(first, l), r_own = __builtin_amdgcn_readlane(reset, l);
+                int start_k = last_reset + 1;
+                if (r_own >= 0) start_k = base + l * 8 + r_own + 1;
+                else {
+                    const unsigned long long before = resets & ((1ull << l) - 1ull);
+                    if (before) { const int r = 63 - __builtin_clzll(before); start_k = base + r * 8 + __builtin_amdgcn_readlane(reset, r) + 1; }
+                }
+                found_is = i0 + start_k; found_ie = i0 + base + l * 8 + f; found_d = d;
                 break;
             }
-            if (resets) last_reset = base + (63 - __builtin_clzll(resets));
-            carry_p = __shfl(P, 63, 64);
-            carry_m = __shfl(M, 63, 64);
+            if (resets) { const int r = 63 - __builtin_clzll(resets); last_reset = base + r * 8 + __builtin_amdgcn_readlane(reset, r); }
+            carry_p = __builtin_amdgcn_readlane(P, 63);
+            carry_m = __builtin_amdgcn_readlane(M, 63);
         }
     }
     if (lane == 0) {
         if (found_is >= 0) {
             out[s] = make_int4(T, found_ie, found_ie + found_d, found_ie - found_is + 1);       // score, end cell, run length
             mode[s] = -2;
-            atomicAdd(n_gapless, 1u);
         } else mode[s] = -1;
     }
 }
@@ -427,7 +461,6 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
                            ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known, end_lane);
         PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_sel, ctx->ws[7]));
         uint64_t total_runs = 0;
-        uint32_t n_gapless = 0;
         PEP_TRY(pep_read_back(ctx, &total_runs, run_off + n_sel, 8));       // arrives with the synchronisation inside pep_sw_run (block total)
         // ---- rule 5a: pairs whose alignment is one ungapped run are settled without a sweep (the score-pass results in ws[12] have been
         // consumed by gather_sel: the slots of the selected pairs are written from here on)
@@ -436,11 +469,10 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         hipLaunchKernelGGL(gapless_check, dim3((unsigned)ceil_div(n_sel, 4)), dim3(256), 0, st, (uint64_t)n_sel, (const uint64_t *)sel_keys, (const int32_t *)known,
                            (const int32_t *)end_lane, ctx->q.res.as<const uint8_t>(), ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(),
                            ctx->t.res.as<const uint8_t>(), ctx->t.off.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), ctx->d_params.as<const int8_t>(),
-                           ctx->ws[12].as<int4>(), ctx->d_trace_mode.as<int32_t>(), counters + 1);
-        PEP_TRY(pep_read_back(ctx, &n_gapless, counters + 1, 4));
+                           ctx->ws[12].as<int4>(), ctx->d_trace_mode.as<int32_t>());
         // ---- pass 2: the same DP with traceback codes, the remaining selected pairs only
         PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, known, end_lane, ctx->d_trace_mode.as<const int32_t>()));
-        ctx->stats.tracebacks_gapless = n_gapless;
+        ctx->stats.tracebacks_gapless = n_sel - ctx->trace_swept;           // (counted by the pass's set-up kernel: the pairs that entered the sweep)
         const int4 *sw2 = ctx->ws[12].as<const int4>();
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
         uint32_t *runs = ctx->ws[21].as<uint32_t>();
