@@ -30,6 +30,8 @@
  *   pep_ovl_filter          RunBlast.ovlFilter (host C++)                    uberBlast.py:417-452
  *   pep_linear_merge        RunBlast.linearMerge + _linearMerge (host C++)   uberBlast.py:100-218, 453-460
  *   pep_alleles             aligned-allele strings + base-5 packing of iter_map_bsn   PEPPAN.py:812-835, 846-848
+ *   pep_similar_scan / pep_pair_support / pep_similar_resolve   the pass of get_similar_pairs over the all-vs-all table and its
+ *                           get_similar (host state machine, K14 on the GPU, host dictionary)   PEPPAN.py:195-224, 231-276, 294
  */
 #ifndef PEPPAN_HIP_H
 #define PEPPAN_HIP_H
@@ -232,6 +234,48 @@ typedef struct {
 int pep_alleles(pep_ctx *ctx, const uint8_t *nt, const uint64_t *nt_off, uint32_t n_contigs, uint64_t n_rows, const pep_locus *rows,
                 const uint32_t *cigar, uint64_t n_cigar, uint32_t n_groups, const uint64_t *grp_off, const uint32_t *grp_qlen, int gtable,
                 int64_t *in_frame, int64_t *orf, uint8_t *packed, uint64_t packed_cap);
+
+/* K14 and its two host passes: the consumer of the all-vs-all table (get_similar_pairs, PEPPAN.py:194-294).
+ *
+ * pep_similar_scan (host, no context): ONE ordered pass over the table as RunBlast.run returns it (sorted by query, reference, score).
+ *   q / r: gene codes in [0, n_genes) that keep the order of the gene ids.  action[k]: the row-local classification of PEPPAN.py:246-260
+ *   (PEP_ROW_*), forward[k] = column 8 < column 9, iden4[k] = int(identity * 10000).  The pass keeps the reference's state - genes absorbed
+ *   by a near-identical partner or found repetitive are dead from then on, forward rows of one (q, r) pair are collected until a row of
+ *   another pair survives - and reports: alive[g] (0 = absorbed / repetitive), seen_as_query[g], the absorbed edges (kept, dropped, iden4)
+ *   in order, and the events that write ortho_pairs, in order: PEP_EVENT_CONFLICT (pair a < b gets -2, PEPPAN.py:249) or
+ *   PEP_EVENT_SUPPORT (pair a < b is to be judged by get_similar over rows ev_rows[ev_row_off[e] .. ev_row_off[e+1]), PEPPAN.py:268-276).
+ *   Capacities: absorbed 3 n, ev_* n + 1 (ev_row_off n + 2), ev_rows n.
+ * pep_pair_support (K14): get_similar (PEPPAN.py:195-224) for many groups of forward alignments at once.  Group g = rows
+ *   [grp_off[g], grp_off[g+1]) in table order, all of one (query, reference) pair of lengths grp_qlen / grp_rlen.  value[g] =
+ *   PEP_SUPPORT_NONE (no decision), 0 (similar but too short a support) or int(mean identity * 10000), with the mean taken over the
+ *   covered query positions exactly as numpy.mean takes it (pairwise summation in first-cover order).  At most 255 rows per group.
+ * pep_similar_resolve (host, no context): the dictionary ortho_pairs from the events and the values K14 returned for them (ev_value[e]
+ *   is ignored for conflicts): out = (a, b, value) triples with value != 0 in first-insertion order (capacity 3 n_events). */
+#define PEP_ROW_ORDINARY 0
+#define PEP_ROW_CONFLICT 1
+#define PEP_ROW_ABSORB_QUERY 2
+#define PEP_ROW_ABSORB_REF 3
+#define PEP_EVENT_CONFLICT 0
+#define PEP_EVENT_SUPPORT 1
+#define PEP_SUPPORT_NONE (-2147483647 - 1)
+typedef struct {
+    uint32_t q_start, r_start;    /* columns 6 and 8: 1-based first query / reference nucleotide (forward alignments only) */
+    uint32_t cigar_runs, pad;
+    uint64_t cigar_off;           /* runs of (len << 2 | op) in nucleotides, op 0=M 1=I 2=D */
+    double identity;              /* column 2 */
+} pep_support_row;
+typedef struct {
+    double match_len[3], match_prop[3];   /* params match_len, match_len1, match_len2 / match_prop, match_prop1, match_prop2 (PEPPAN.py:211, 214-216) */
+    double identity_x1e4;                 /* params match_identity * 10000 (PEPPAN.py:213) */
+    int32_t any_frame, pad;               /* 'f' in params incompleteCDS (PEPPAN.py:205) */
+} pep_support_limits;
+int pep_similar_scan(uint64_t n, const int64_t *q, const int64_t *r, const uint8_t *action, const uint8_t *forward, const int32_t *iden4, uint64_t n_genes,
+                     uint8_t *alive, uint8_t *seen_as_query, int64_t *absorbed, uint64_t *n_absorbed,
+                     uint8_t *ev_kind, int64_t *ev_a, int64_t *ev_b, uint64_t *ev_row_off, uint64_t *ev_rows, uint64_t *n_events);
+int pep_pair_support(pep_ctx *ctx, uint64_t n_rows, const pep_support_row *rows, const uint32_t *cigar, uint64_t n_cigar, uint64_t n_groups,
+                     const uint64_t *grp_off, const uint32_t *grp_qlen, const uint32_t *grp_rlen, const pep_support_limits *lim, int32_t *value);
+int pep_similar_resolve(uint64_t n_events, const uint8_t *ev_kind, const int64_t *ev_a, const int64_t *ev_b, const int32_t *ev_value,
+                        int64_t *out, uint64_t *n_out);
 
 /* K13: exact-duplicate collapse of gene instances (front end of the clustering path).
  * pep_sha1: digest[20*i..] = SHA-1 of sequence i (bytes[off[i]..off[i+1])), big-endian bytes as hashlib.sha1(seq).digest();

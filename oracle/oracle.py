@@ -361,3 +361,34 @@ def overlaps_sweep(contig, start, end, row_id, ovl_l, ovl_p):
             if ovl >= need or ovl >= ovl_p * (end[j] - start[j] + 1):
                 out.append((row_id[i], row_id[j], ovl))
     return np.array(out, dtype=np.int64).reshape(-1, 3)
+
+
+def pair_support(rows, q_len, r_len, lim):
+    """get_similar of PEPPAN.py:195-224 for the forward alignments of ONE (query, reference) pair, restated with the reference's own
+    dictionary (query nucleotide position -> identity of the last alignment that covered it; np.mean over the values in insertion order).
+    rows: [(q_start, r_start, identity, [(n, op), ...])] in table order, op 0 = M, 1 = I, 2 = D (nucleotides);
+    lim: dict(match_len=[3], match_prop=[3], identity_x1e4, any_frame).  -> None (no decision) | 0 | int(mean identity * 10000)"""
+    if min(q_len, r_len) * 20 <= max(q_len, r_len):                                  # PEPPAN.py:199-200
+        return None
+    matched = {}
+    for q_start, r_start, ident, runs in rows:
+        s_i, s_j = int(q_start), int(r_start)
+        for n, op in runs:
+            n = int(n)
+            if op == 0:
+                frame_i, frame_j = s_i % 3, s_j % 3
+                if frame_i == frame_j or lim['any_frame']:                           # PEPPAN.py:205-206
+                    matched.update({(s_i + x): ident for x in range((3 - (frame_i - 1)) % 3, n)})
+                s_i += n
+                s_j += n
+                if len(matched) * 3 >= min(lim['match_len']) and len(matched) * 3 >= min(lim['match_prop']) * q_len:      # PEPPAN.py:211
+                    ave = int(np.mean(list(matched.values())) * 10000)
+                    if ave >= lim['identity_x1e4']:
+                        shorter = min(q_len, r_len)
+                        need = min(max(l, p * shorter) for l, p in zip(lim['match_len'], lim['match_prop']))
+                        return ave if len(matched) * 3 >= need else 0                # PEPPAN.py:214-219
+            elif op == 1:
+                s_i += n
+            else:
+                s_j += n
+    return None

@@ -13,7 +13,8 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_stats', 'pep_result_free',
-           'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup']
+           'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve']
 
 
 class PepError(RuntimeError):
@@ -46,6 +47,26 @@ NT_HIT_DTYPE = np.dtype([('q', '<u4'), ('r', '<u4'), ('qs', '<u4'), ('qe', '<u4'
 
 LOCUS_DTYPE = np.dtype([('contig', '<u4'), ('q_start', '<u4'), ('rs', '<u4'), ('re', '<u4'), ('cigar_runs', '<u4'), ('group', '<u4'),
                         ('cigar_off', '<u8')])
+
+SUPPORT_ROW_DTYPE = np.dtype([('q_start', '<u4'), ('r_start', '<u4'), ('cigar_runs', '<u4'), ('pad', '<u4'), ('cigar_off', '<u8'), ('identity', '<f8')])
+SUPPORT_NONE = -2 ** 31
+ROW_ORDINARY, ROW_CONFLICT, ROW_ABSORB_QUERY, ROW_ABSORB_REF = 0, 1, 2, 3
+EVENT_CONFLICT, EVENT_SUPPORT = 0, 1
+
+
+class SupportLimits(C.Structure):
+    _fields_ = [('match_len', C.c_double * 3), ('match_prop', C.c_double * 3), ('identity_x1e4', C.c_double), ('any_frame', C.c_int32), ('pad', C.c_int32)]
+
+
+def support_limits(params):
+    """the thresholds of get_similar (PEPPAN.py:205-216) from PEPPAN's parameter dictionary"""
+    lim = SupportLimits()
+    for k, (l, p) in enumerate((('match_len', 'match_prop'), ('match_len1', 'match_prop1'), ('match_len2', 'match_prop2'))):
+        lim.match_len[k], lim.match_prop[k] = float(params[l]), float(params[p])
+    lim.identity_x1e4 = params['match_identity'] * 10000
+    lim.any_frame = 1 if 'f' in params['incompleteCDS'] else 0
+    return lim
+
 
 _lib = None
 
@@ -210,6 +231,44 @@ def linear_merge(q, r, iden, qs, qe, ss, se, score, ql, sl, rid, gap_dist, len_d
                     ids[:n_ids.value])
         keep_cap, ids_cap = n_keep.value + 16, n_ids.value + 16
     raise PepError('pep_linear_merge: inconsistent sizes')
+
+
+def similar_scan(q, r, action, forward, iden4, n_genes):
+    """pep_similar_scan: the ordered pass of get_similar_pairs (PEPPAN.py:231-276) over numeric columns -> dict(alive, seen_as_query,
+    absorbed int64[m, 3], ev_kind, ev_a, ev_b, ev_row_off, ev_rows)"""
+    lib = load_library()
+    n = len(q)
+    q, r = np.ascontiguousarray(q, dtype=np.int64), np.ascontiguousarray(r, dtype=np.int64)
+    action, forward = np.ascontiguousarray(action, dtype=np.uint8), np.ascontiguousarray(forward, dtype=np.uint8)
+    iden4 = np.ascontiguousarray(iden4, dtype=np.int32)
+    alive, seen = np.zeros(max(n_genes, 1), dtype=np.uint8), np.zeros(max(n_genes, 1), dtype=np.uint8)
+    absorbed = np.zeros((n + 1, 3), dtype=np.int64)
+    ev_kind, ev_a, ev_b = np.zeros(n + 1, dtype=np.uint8), np.zeros(n + 1, dtype=np.int64), np.zeros(n + 1, dtype=np.int64)
+    ev_row_off, ev_rows = np.zeros(n + 2, dtype=np.uint64), np.zeros(n + 1, dtype=np.uint64)
+    na, ne = C.c_uint64(), C.c_uint64()
+    rc_ = lib.pep_similar_scan(C.c_uint64(n), _ptr(q), _ptr(r), _ptr(action), _ptr(forward), _ptr(iden4), C.c_uint64(n_genes), _ptr(alive), _ptr(seen),
+                               _ptr(absorbed), C.byref(na), _ptr(ev_kind), _ptr(ev_a), _ptr(ev_b), _ptr(ev_row_off), _ptr(ev_rows), C.byref(ne))
+    if rc_ != 0:
+        raise PepError('pep_similar_scan failed (%d)' % rc_)
+    ne, na = ne.value, na.value
+    off = ev_row_off[:ne + 1].astype(np.int64)
+    return dict(alive=alive[:n_genes], seen_as_query=seen[:n_genes], absorbed=absorbed[:na], ev_kind=ev_kind[:ne], ev_a=ev_a[:ne], ev_b=ev_b[:ne],
+                ev_row_off=off, ev_rows=ev_rows[:int(off[-1])].astype(np.int64))
+
+
+def similar_resolve(ev_kind, ev_a, ev_b, ev_value):
+    """pep_similar_resolve: ortho_pairs as the reference's dictionary builds it -> int64[m, 3] (a, b, value), value != 0, insertion order"""
+    lib = load_library()
+    n = len(ev_kind)
+    ev_kind = np.ascontiguousarray(ev_kind, dtype=np.uint8)
+    ev_a, ev_b = np.ascontiguousarray(ev_a, dtype=np.int64), np.ascontiguousarray(ev_b, dtype=np.int64)
+    ev_value = np.ascontiguousarray(ev_value, dtype=np.int32)
+    out = np.zeros((n + 1, 3), dtype=np.int64)
+    no = C.c_uint64()
+    rc_ = lib.pep_similar_resolve(C.c_uint64(n), _ptr(ev_kind), _ptr(ev_a), _ptr(ev_b), _ptr(ev_value), _ptr(out), C.byref(no))
+    if rc_ != 0:
+        raise PepError('pep_similar_resolve failed (%d)' % rc_)
+    return out[:no.value]
 
 
 def merge_hits(hits, cigar, top_k, n_splits, out=None):
@@ -377,6 +436,23 @@ class Context(object):
             cg = cigar if len(cigar) else np.zeros(1, np.uint32)
             self._check(self._lib.pep_rescore_nt(self._h, C.c_uint64(len(nt_hits)), _ptr(nt_hits), _ptr(cg), C.c_uint64(len(cigar)), _ptr(out)), 'pep_rescore_nt')
         return out
+
+    # ---- K14
+    def pair_support(self, rows, cigar, grp_off, grp_qlen, grp_rlen, limits):
+        """get_similar (PEPPAN.py:195-224) for groups of forward alignments: rows SUPPORT_ROW_DTYPE, group g = rows [grp_off[g], grp_off[g+1])
+        -> int32 per group: SUPPORT_NONE | 0 | int(mean identity * 10000)"""
+        rows = np.ascontiguousarray(rows, dtype=SUPPORT_ROW_DTYPE)
+        cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+        grp_off = np.ascontiguousarray(grp_off, dtype=np.uint64)
+        grp_qlen, grp_rlen = np.ascontiguousarray(grp_qlen, dtype=np.uint32), np.ascontiguousarray(grp_rlen, dtype=np.uint32)
+        ng = len(grp_qlen)
+        value = np.full(max(ng, 1), SUPPORT_NONE, dtype=np.int32)
+        if ng:
+            cg = cigar if len(cigar) else np.zeros(1, np.uint32)
+            rr = rows if len(rows) else np.zeros(1, SUPPORT_ROW_DTYPE)
+            self._check(self._lib.pep_pair_support(self._h, C.c_uint64(len(rows)), _ptr(rr), _ptr(cg), C.c_uint64(len(cigar)), C.c_uint64(ng), _ptr(grp_off),
+                                                   _ptr(grp_qlen), _ptr(grp_rlen), C.byref(limits), _ptr(value)), 'pep_pair_support')
+        return value[:ng]
 
     # ---- K9
     def linclust(self, seqs, min_id, min_cov, base=4, k=17, m=20):

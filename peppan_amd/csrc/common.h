@@ -213,6 +213,9 @@ int pep_k12_alleles(pep_ctx *ctx, const uint8_t *h_nt, const uint64_t *h_nt_off,
 // ---- dedup.hip (K13)
 int pep_k13_sha1(pep_ctx *ctx, const uint8_t *h_bytes, const uint64_t *h_off, uint32_t n, uint8_t *h_digest);
 int pep_k13_dedup(pep_ctx *ctx, uint32_t n, const uint32_t *h_len, const uint8_t *h_digest, uint32_t *h_rep);
+// ---- similar.hip (K14)
+int pep_k14_pair_support(pep_ctx *ctx, uint64_t n_rows, const pep_support_row *h_rows, const uint32_t *h_cigar, uint64_t n_cigar, uint64_t n_groups,
+                         const uint64_t *h_grp_off, const uint32_t *h_qlen, const uint32_t *h_rlen, const pep_support_limits *lim, int32_t *h_value);
 // ---- linclust.hip (K9)
 int pep_k9_linclust(pep_ctx *ctx, const uint8_t *h_res, const uint64_t *h_off, uint32_t n, int base, int k, int m, double min_id, double min_cov,
                     uint32_t *h_rep, uint64_t *h_stats);

@@ -13,9 +13,10 @@ from operator import itemgetter
 
 import numpy as np
 
+from . import _native as N
 from .clust import getClust
 from .configure import logger, readFasta
-from .uberBlast import uberBlast, get_context
+from .uberBlast import uberBlast, get_context, _as_table
 
 
 def gene_hashes(seqs, ctx=None):
@@ -82,82 +83,22 @@ def iterClust(prefix, genes, geneGroup, params):
 
 
 # ---- the decision pass over the all-vs-all table (PEPPAN.py:194-294; behaviour spec: SURVEY.md appendix A.4) -----------------
-ORDINARY, CONFLICT, ABSORB_QUERY, ABSORB_REF = 0, 1, 2, 3
-_CIGAR_RUN = re.compile(r'(\d+)([A-Z])')
-
-
-class _SupportLimits(object):
-    """the thresholds of the ortholog-support test, derived once from the parameter dict"""
-
-    def __init__(self, params):
-        self.lens = (params['match_len'], params['match_len1'], params['match_len2'])
-        self.props = (params['match_prop'], params['match_prop1'], params['match_prop2'])
-        self.identity = params['match_identity'] * 10000
-        self.any_frame = 'f' in params['incompleteCDS']
-
-    def enough_to_decide(self, n_nt, q_len):
-        return n_nt >= min(self.lens) and n_nt >= min(self.props) * q_len
-
-    def full_support(self, n_nt, shorter):
-        return n_nt >= min(max(l, p * shorter) for l, p in zip(self.lens, self.props))
-
-
-def _pair_support(hits, lim):
-    """Ortholog support of one (query, reference) pair from its forward hits in table order.
-    A coverage map over the query's nucleotide positions records, for every position inside an in-frame M run (counted from the
-    first position of the run that starts a codon of the query), the identity of the LAST hit that covered it; positions are remembered in the
-    order they were first covered, because the mean is taken over that sequence.  After every M run: once enough positions
-    are covered the mean identity is tested - passing ends the walk with the mean (full support) or 0 (partial support);
-    failing lets later runs and hits add positions.  -> None (no decision) | 0 | int(mean identity * 1e4)"""
-    q_len, r_len = int(hits[0][12]), int(hits[0][13])
-    if 20 * min(q_len, r_len) <= max(q_len, r_len):
-        return None
-    parsed = [(int(h[6]), int(h[8]), h[2], [(int(n), op) for n, op in _CIGAR_RUN.findall(h[14])]) for h in hits]
-    size = max(q0 + sum(n for n, op in runs if op in 'MI') for q0, _, _, runs in parsed) + 1
-    covered = np.zeros(size, dtype=bool)
-    ident_at = np.zeros(size, dtype=np.float64)
-    first_cover_order, n_cov = [], 0
-    for qpos, rpos, ident, runs in parsed:
-        for n, op in runs:
-            if op == 'I':
-                qpos += n
-            elif op != 'M':
-                rpos += n
-            else:
-                lo, hi = qpos + (1 - qpos) % 3, qpos + n
-                if lo < hi and (lim.any_frame or qpos % 3 == rpos % 3):
-                    fresh = np.flatnonzero(~covered[lo:hi]) + lo
-                    first_cover_order.append(fresh)
-                    n_cov += fresh.size
-                    covered[lo:hi] = True
-                    ident_at[lo:hi] = ident
-                qpos += n
-                rpos += n
-                if lim.enough_to_decide(3 * n_cov, q_len):
-                    mean = int(np.mean(ident_at[np.concatenate(first_cover_order)]) * 10000)
-                    if mean >= lim.identity:
-                        return mean if lim.full_support(3 * n_cov, min(q_len, r_len)) else 0
-    return None
-
-
-def _classify_rows(table, priorities, near_identity, cover):
-    """order-independent part of the decision, for all rows at once -> (action code per row, forward flag per row)"""
-    num = lambda c: table[:, c].astype(np.float64)
-    q, r = table[:, 0].astype(np.int64), table[:, 1].astype(np.int64)
-    iden, qs, qe, ss, se, ql, sl = num(2), num(6), num(7), num(8), num(9), num(12), num(13)
-    rank_q = np.array([priorities[g][0] for g in q.tolist()])
-    rank_r = np.array([priorities[g][0] for g in r.tolist()])
+def _classify_rows(T, rank_q, rank_r, q, r, near_identity, cover):
+    """the row-local tests of PEPPAN.py:244-263 for all rows of the numeric table at once -> (action code per row, forward flag per row,
+    int(identity * 10000) per row).  Arithmetic in float64 exactly as the reference's float() conversions make it."""
+    f = lambda a: a.astype(np.float64)
+    iden, qs, qe, ss, se, ql, sl = T.iden, f(T.qs), f(T.qe), f(T.ss), f(T.se), f(T.ql), f(T.sl)
     q_span, r_span = qe - qs + 1, np.abs(se - ss) + 1
     near = (q != r) & (iden >= near_identity)
     same_head, same_tail = (qs % 3 == ss % 3), ((ql - qe) % 3 == (sl - se) % 3)
     off_frame = (ss > se) | (~same_head & same_tail)                              # reverse strand, or shifted at the head only
     in_frame = ~off_frame & (ss < se) & same_head & same_tail
     root = np.sqrt(cover)
-    action = np.full(len(table), ORDINARY, dtype=np.int8)
-    action[near & off_frame & ((q_span >= cover * ql) | (r_span >= cover * sl))] = CONFLICT
-    action[near & in_frame & (ql <= sl) & (q_span >= root * sl) & (rank_q >= rank_r)] = ABSORB_QUERY
-    action[near & in_frame & (ql > sl) & (r_span >= root * ql) & (rank_q <= rank_r)] = ABSORB_REF
-    return q.tolist(), r.tolist(), action.tolist(), (ss < se).tolist(), (iden * 10000.).astype(np.int64).tolist()
+    action = np.full(len(T), N.ROW_ORDINARY, dtype=np.uint8)
+    action[near & off_frame & ((q_span >= cover * ql) | (r_span >= cover * sl))] = N.ROW_CONFLICT
+    action[near & in_frame & (ql <= sl) & (q_span >= root * sl) & (rank_q >= rank_r)] = N.ROW_ABSORB_QUERY
+    action[near & in_frame & (ql > sl) & (r_span >= root * ql) & (rank_q <= rank_r)] = N.ROW_ABSORB_REF
+    return action, (ss < se).astype(np.uint8), (iden * 10000.).astype(np.int64).astype(np.int32)
 
 
 def _self_search(clust, params, pool):
@@ -165,66 +106,63 @@ def _self_search(clust, params, pool):
     argv = ['-r', clust, '-q', clust] + tools.split() + ['--min_id', str(params['match_identity'] - 0.05), '--min_cov', str(params['match_frag_len']),
                                                         '-t', str(params['n_thread']), '--min_ratio', str(params['match_frag_prop']), '-e', '3,3', '-p',
                                                         '--gtable', str(params['gtable'])]
-    return uberBlast(argv, pool)
+    return uberBlast(argv, pool, as_table=True)
 
 
-def get_similar_pairs(clust, priorities, params, pool=None):
-    """All-vs-all search of the exemplars, then ONE ordered pass over its table (rows sorted by query, reference, score with
-    the names compared as strings) deciding which exemplars are absorbed by a near-identical in-frame partner, which pairs
-    conflict (-2) and which are ortholog-like (mean identity * 1e4).  The row-local tests are evaluated for all rows at once
-    (_classify_rows); only the state that makes the pass order-dependent is walked row by row:
-      alive[g]   0 once g was absorbed or found repetitive; rows touching a dead gene are ignored from then on
-      pending    the forward rows of the current (query, reference) pair; the pair is settled when the NEXT surviving row
-                 belongs to another pair (or at the end) - not earlier, rows in between still see the old state
+def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=None):
+    """All-vs-all search of the exemplars, then the reference's ONE ordered pass over its table (rows sorted by query, reference, score with
+    the names compared as strings) deciding which exemplars are absorbed by a near-identical in-frame partner, which pairs conflict (-2)
+    and which are ortholog-like (mean identity * 1e4).  Nothing here walks rows in Python and no row ever becomes a Python object:
+      * the search hands over its numeric HitTable (columns + CIGAR arena);
+      * the row-local tests are numpy expressions over the columns (_classify_rows);
+      * the order-dependent state - alive[g] (0 once g was absorbed or found repetitive; rows touching a dead gene are ignored from then
+        on) and the pending forward rows of the current (query, reference) pair, settled when the NEXT surviving row belongs to another
+        pair - is one pass of host C++ inside the library (pep_similar_scan); it does not depend on what get_similar returns, so
+      * get_similar itself (PEPPAN.py:195-224) runs afterwards for all settled pairs at once on the GPU (K14, pep_pair_support), and
+      * pep_similar_resolve replays the dictionary writes in order.
     Side effects as in the reference: the exemplar FASTA loses the dead genes, absorbed pairs are added to clust.npy."""
-    table = _self_search(clust, params, pool)
-    if len(table):
-        table.T[:2] = table.T[:2].astype(int)
-    q, r, action, forward, iden4 = _classify_rows(table, priorities, params['clust_identity'], params['clust_match_prop']) if len(table) else ([], [], [], [], [])
-    lim = _SupportLimits(params)
-    alive, verdict, absorbed, pending = {}, {}, [], []
-
-    def settle(rows):
-        a, b = q[rows[0]], r[rows[0]]
-        if len(rows) >= 50:
-            alive[b] = 0                                   # fifty or more hits between two genes: the reference gene is a repeat
-        elif a != b and (min(a, b), max(a, b)) not in verdict:
-            value = _pair_support([table[k] for k in rows], lim)
-            if value is not None:
-                verdict[(min(a, b), max(a, b))] = value
-
-    for k in range(len(table)):
-        a, b = q[k], r[k]
-        if alive.setdefault(a, 1) == 0 or alive.get(b, 1) == 0:
-            continue
-        if action[k] == CONFLICT:
-            verdict[(min(a, b), max(a, b))] = -2
-        elif action[k] == ABSORB_QUERY:
-            absorbed.append([b, a, iden4[k]])
-            alive[a] = 0
-        elif action[k] == ABSORB_REF:
-            absorbed.append([a, b, iden4[k]])
-            alive[b] = 0
-        elif forward[k]:
-            if pending and (q[pending[0]], r[pending[0]]) != (a, b):
-                settle(pending)
-                pending = []
-            pending.append(k)
-    if pending:
-        settle(pending)
-
-    _drop_dead_exemplars(params['clust'], alive)
+    import time
+    t0 = time.perf_counter()
+    T = _as_table(_self_search(clust, params, pool))
+    t1 = time.perf_counter()
+    pairs = np.array([], dtype=int)
+    alive_ids, absorbed = set(), []
+    if len(T):
+        q_gene = np.array([int(x) for x in T.q_tab], dtype=np.int64)[T.qi]            # the reference casts both name columns to int (PEPPAN.py:231)
+        r_gene = np.array([int(x) for x in T.r_tab], dtype=np.int64)[T.ri]
+        genes = np.unique(np.concatenate([q_gene, r_gene]))                           # sorted: codes keep the order of the ids
+        q, r = np.searchsorted(genes, q_gene), np.searchsorted(genes, r_gene)
+        rank = np.array([priorities[g][0] for g in genes.tolist()])
+        action, forward, iden4 = _classify_rows(T, rank[q], rank[r], q, r, params['clust_identity'], params['clust_match_prop'])
+        sc = N.similar_scan(q, r, action, forward, iden4, len(genes))
+        rows_of = sc['ev_rows']
+        sup = np.zeros(len(rows_of), dtype=N.SUPPORT_ROW_DTYPE)
+        sup['q_start'], sup['r_start'], sup['identity'] = T.qs[rows_of], T.ss[rows_of], T.iden[rows_of]
+        sup['cigar_off'], sup['cigar_runs'] = T.c_off[rows_of], T.c_runs[rows_of]
+        off = sc['ev_row_off']
+        # lengths of a group's two genes from its first row (conflict events carry no rows: any row will do, they are not judged)
+        first = rows_of[np.minimum(off[:-1], len(rows_of) - 1)] if len(rows_of) else np.zeros(len(off) - 1, dtype=np.int64)
+        value = (ctx or get_context()).pair_support(sup, T.arena, off, T.ql[first], T.sl[first], N.support_limits(params))
+        res = N.similar_resolve(sc['ev_kind'], sc['ev_a'], sc['ev_b'], value)
+        if len(res):
+            pairs = np.column_stack([genes[res[:, 0]], genes[res[:, 1]], res[:, 2]]).astype(int)
+        alive_ids = set(genes[(sc['alive'] > 0) & (sc['seen_as_query'] > 0)].tolist())
+        ab = sc['absorbed']
+        absorbed = np.column_stack([genes[ab[:, 0]], genes[ab[:, 1]], ab[:, 2]]).tolist() if len(ab) else []
+    _drop_dead_exemplars(params['clust'], alive_ids)
     if absorbed:
         npy = params['clust'].rsplit('.', 1)[0] + '.npy'
         edges = np.vstack([np.load(npy, allow_pickle=True), absorbed])
         np.save(npy, edges[np.argsort(-edges.T[2])])
-    return np.array([[a, b, v] for (a, b), v in verdict.items() if v != 0], dtype=int)
+    if timing is not None:
+        timing.update(search_ms=(t1 - t0) * 1e3, decide_ms=(time.perf_counter() - t1) * 1e3, rows=len(T))
+    return pairs
 
 
-def _drop_dead_exemplars(fasta, alive):
+def _drop_dead_exemplars(fasta, alive_ids):
     """rewrite the exemplar FASTA in place, keeping the records of genes that appeared as a query and are still alive"""
     from .clust import read_blocks
-    keep = [blk.text for blk in read_blocks(fasta) if alive.get(int(blk.name), 0) > 0]
+    keep = [blk.text for blk in read_blocks(fasta) if int(blk.name) in alive_ids]
     with open(fasta, 'w') as fout:
         fout.writelines(keep)
 

@@ -598,14 +598,20 @@ def _run_arguments(a):
     return [name for name, on in wanted if on], kw
 
 
-def uberBlast(args, extPool=None):
-    """command-line style entry point (reference: uberBlast.py:564): list of flags -> hit table, or (table, overlaps) with -O"""
+def uberBlast(args, extPool=None, as_table=False):
+    """command-line style entry point (reference: uberBlast.py:564): list of flags -> hit table, or (table, overlaps) with -O.
+    as_table (not in the reference): the table comes as the numeric HitTable - same rows, same order, no Python object per cell - for
+    callers inside this package that work on the columns (pipeline.get_similar_pairs)."""
     a = _parser('Similarity search of query sequences against a reference on an MI355X; table format of PEPPAN uberBlast.', True).parse_args(args)
     methods, kw = _run_arguments(a)
-    data = RunBlast(a.device).run(a.reference, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread,
-                                  extPool if extPool is not None else a.process, **kw)
+    rb = RunBlast(a.device)
+    rb._as_tables = bool(as_table)
+    data = rb.run(a.reference, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread,
+                  extPool if extPool is not None else a.process, **kw)
     if a.output:
         rows = data[0] if a.return_overlap else data
+        if as_table:
+            rows = rows.to_rows(cigar='str')
         text = ''.join('\t'.join(map(str, row)) + '\n' for row in rows)
         if a.output.upper() == 'STDOUT':
             sys.stdout.write(text)

@@ -90,6 +90,19 @@ class OracleContext(object):
                                       arena[int(h['cigar_off'][k]):int(h['cigar_off'][k]) + int(h['cigar_runs'][k])])
         return out
 
+    def pair_support(self, rows, cigar, grp_off, grp_qlen, grp_rlen, limits):
+        lim = dict(match_len=list(limits.match_len), match_prop=list(limits.match_prop), identity_x1e4=limits.identity_x1e4, any_frame=bool(limits.any_frame))
+        out = np.full(len(grp_qlen), N.SUPPORT_NONE, dtype=np.int32)
+        for g in range(len(grp_qlen)):
+            rr = []
+            for k in range(int(grp_off[g]), int(grp_off[g + 1])):
+                o, c = int(rows['cigar_off'][k]), int(rows['cigar_runs'][k])
+                rr.append((int(rows['q_start'][k]), int(rows['r_start'][k]), float(rows['identity'][k]), [(int(x) >> 2, int(x) & 3) for x in cigar[o:o + c]]))
+            v = O.pair_support(rr, int(grp_qlen[g]), int(grp_rlen[g]), lim) if rr else None
+            if v is not None:
+                out[g] = v
+        return out
+
     def components(self, n, a, b):
         return O.components(n, a, b)
 

@@ -378,6 +378,84 @@ def test_public_tools_keep_the_reference_plugin_contract_on_gpu(tmp_path, monkey
     assert a.tolist() == b.tolist() and a_ovl.tolist() == b_ovl.tolist() and len(a) >= 200
 
 
+def _random_support_groups(rng, n_groups, long_group=False):
+    """groups of forward alignments of one gene pair each, as get_similar meets them: overlapping rows, all three frames, gaps, short and
+    long genes; identities with three decimals"""
+    from peppan_amd import _native as N
+    rows, cigar, off, gq, gr = [], [], [0], [], []
+    for g in range(n_groups):
+        ql = int(rng.choice([90, 300, 1002, 2400, 9000])) + int(rng.integers(0, 30))
+        if long_group and g == 0:
+            ql = 120000                                          # more than 32 768 covered positions: the serial leaf path of the summation
+        rl = max(30, int(ql * rng.choice([1., 1., 0.9, 1.3, 0.04])))
+        n_rows = int(rng.choice([1, 1, 2, 2, 3, 6])) if g % 37 else 49
+        for _ in range(n_rows):
+            qs = int(rng.integers(1, max(2, ql // 3)))
+            rs = qs + int(rng.choice([0, 0, 0, 3, 1, 2, 30]))
+            runs, qpos = [], qs
+            while qpos < ql - 12 and len(runs) < 40:
+                m = int(min(ql - qpos, rng.integers(3, max(4, ql // 2))))
+                runs.append((m << 2) | 0)
+                qpos += m
+                if rng.random() < 0.7 and qpos < ql - 12:
+                    gl = int(rng.integers(1, 8))
+                    op = int(rng.integers(1, 3))
+                    runs.append((gl << 2) | op)
+                    if op == 1:
+                        qpos += gl
+                if rng.random() < 0.15:
+                    break
+            rows.append((qs, rs, len(runs), 0, len(cigar), round(float(rng.uniform(0.45, 1.0)), 3)))
+            cigar += runs
+        off.append(len(rows)); gq.append(ql); gr.append(rl)
+    return (np.array(rows, dtype=N.SUPPORT_ROW_DTYPE), np.array(cigar, dtype=np.uint32), np.array(off, dtype=np.uint64),
+            np.array(gq, dtype=np.uint32), np.array(gr, dtype=np.uint32))
+
+
+def test_pair_support_kernel_equals_get_similar(ctx):
+    """K14 (pep_pair_support) == the reference's get_similar restated with its own dictionary and np.mean (oracle.pair_support,
+    PEPPAN.py:195-224): every group value, including the last bit of numpy's pairwise mean before int() truncates it"""
+    from peppan_amd import _native as N
+    from oracle_context import OracleContext
+    rng = np.random.default_rng(14)
+    base = dict(match_identity=0.5, incompleteCDS='', match_len=250., match_len1=100., match_len2=400., match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+    seen = set()
+    for k, params in enumerate((base, dict(base, incompleteCDS='sife'), dict(base, match_identity=0.8, match_len1=30., match_prop2=0.1))):
+        rows, cigar, off, gq, gr = _random_support_groups(rng, 700, long_group=(k == 0))
+        lim = N.support_limits(params)
+        got = ctx.pair_support(rows, cigar, off, gq, gr, lim)
+        want = OracleContext().pair_support(rows, cigar, off, gq, gr, lim)
+        assert np.array_equal(got, want), np.flatnonzero(got != want)[:10]
+        seen |= {'none' if v == N.SUPPORT_NONE else ('zero' if v == 0 else 'mean') for v in got.tolist()}
+        assert (got > 0).sum() > 100
+    assert seen == {'none', 'zero', 'mean'}
+    # nothing to judge / empty groups
+    e = ctx.pair_support(rows[:0], cigar[:0], np.zeros(3, np.uint64), gq[:2], gr[:2], lim)
+    assert e.tolist() == [N.SUPPORT_NONE, N.SUPPORT_NONE]
+    with pytest.raises(N.PepError):
+        ctx.pair_support(np.zeros(300, N.SUPPORT_ROW_DTYPE), cigar, np.array([0, 300], np.uint64), gq[:1], gr[:1], lim)      # > 255 rows in one group
+
+
+def test_get_similar_pairs_golden_on_gpu(tmp_path, monkeypatch):
+    """golden G10 (the reference's own get_similar_pairs on a canned table: returned pairs, rewritten exemplar file, clust.npy) through the
+    product path proper: numeric table, host scan, K14 on the GPU, resolve"""
+    import copy
+    from peppan_amd import pipeline as PL
+    g = load_golden('g10_pairs.json')
+    for params_in, exp in ((g['params'], g), (g['variant_sife']['params'], g['variant_sife'])):
+        cl = tmp_path / 'p.clust.exemplar'
+        cl.write_text(g['exemplar_in'])
+        np.save(str(tmp_path / 'p.clust.npy'), np.array(g['clust_npy_in'], dtype=int))
+        tab = np.empty([len(g['table']), 16], dtype=object)
+        for i, r in enumerate(g['table']):
+            for j, v in enumerate(r):
+                tab[i, j] = v
+        monkeypatch.setattr(PL, 'uberBlast', lambda argv, pool=None, as_table=False: copy.deepcopy(tab))
+        res = PL.get_similar_pairs(str(cl), {int(k): v for k, v in g['priorities'].items()}, dict(params_in, clust=str(cl)))
+        assert res.tolist() == exp['pairs'] and cl.read_text() == exp['exemplar_out']
+        assert np.load(str(tmp_path / 'p.clust.npy'), allow_pickle=True).tolist() == exp['clust_npy_out']
+
+
 @pytest.mark.parametrize('nucl', [False, True])
 def test_config1_1k_genes_cluster_membership_bit_exact(tmp_path, monkeypatch, nucl):
     """BASELINE configs[1]: 1k synthetic 1 kb genes, all-vs-all on one MI355X, cluster membership bit-exact vs the CPU path.

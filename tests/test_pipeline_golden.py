@@ -81,10 +81,13 @@ def test_get_similar_pairs(tmp_path, monkeypatch):
             for j, v in enumerate(r):
                 tab[i, j] = v
         calls = []
-        monkeypatch.setattr(PL, 'uberBlast', lambda argv, pool=None: (calls.append(argv), copy.deepcopy(tab))[1])
+        # the canned table arrives as the reference's object rows; the product converts it to its numeric form on entry.  get_similar
+        # itself (K14 on the GPU) is served by the oracle's restatement here; tests/test_gpu_parity.py runs this very case over the kernel
+        monkeypatch.setattr(PL, 'uberBlast', lambda argv, pool=None, as_table=False: (calls.append(argv), copy.deepcopy(tab))[1])
         params = dict(params_in, clust=str(cl))
         prio = {int(k): v for k, v in g['priorities'].items()}
-        res = PL.get_similar_pairs(str(cl), prio, params)
+        from oracle_context import OracleContext
+        res = PL.get_similar_pairs(str(cl), prio, params, ctx=OracleContext())
         assert res.tolist() == exp['pairs']
         assert cl.read_text() == exp['exemplar_out']
         assert np.load(str(tmp_path / 'p.clust.npy'), allow_pickle=True).tolist() == exp['clust_npy_out']
