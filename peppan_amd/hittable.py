@@ -7,7 +7,27 @@ the layout the GPU hands over - and the 16/17-column object rows the callers exp
 RunBlast.run (`to_rows`).  `from_rows` is the way back in: tables that arrive as object rows (the reference's tool plug-in
 contract, canned tables in the tests) take the same numeric chain.
 """
+import ctypes as C
+import os
+
 import numpy as np
+
+_PYROWS = None
+
+
+def _pyrows():
+    """the C pass that builds the object rows (csrc/pyrows.c -> _pyrows.so, through the CPython API with the GIL held)"""
+    global _PYROWS
+    if _PYROWS is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_pyrows.so')
+        if not os.path.exists(path):
+            raise RuntimeError('peppan_amd/_pyrows.so is not built (run `python -c "import __graft_entry__ as g; g.build()"` or `make -C peppan_amd/csrc`)')
+        lib = C.PyDLL(path)
+        lib.pep_rows_fill.restype = C.c_int
+        lib.pep_rows_fill.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.py_object, C.py_object] + [C.c_void_p] * 12 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        _PYROWS = lib
+    return _PYROWS
+
 
 _OPS = np.array(['M', 'I', 'D'])
 _OP_BYTES = np.frombuffer(b'MID', dtype=np.uint8)
@@ -228,28 +248,27 @@ class HitTable(object):
         return [pairs[o:o + r] for o, r in zip(self.c_off.tolist(), self.c_runs.tolist())]
 
     def to_rows(self, cigar='list', with_rid=True):
-        """ndarray(object)[n, 15 | 16 | 17]: Python scalars per cell, CIGAR as lists ('list') or as text ('str')"""
+        """ndarray(object)[n, 15 | 16 | 17]: Python scalars per cell, CIGAR as lists ('list') or as text ('str').  One C pass over the
+        columns (csrc/pyrows.c); only column 16 after -m (lists of Python objects per merged group) is filled from here."""
         n = len(self)
         width = 15 + (1 if with_rid else 0) + (1 if (self.has_merge() and with_rid) else 0)
         out = np.empty([n, width], dtype=object)
         if n == 0:
             return out
-        q_tab, r_tab = self.q_tab, self.r_tab
-        score = self.score.astype(np.int64).tolist() if self.score_is_int else self.score.tolist()
-        cols = [[q_tab[i] for i in self.qi.tolist()], [r_tab[i] for i in self.ri.tolist()], self.iden.tolist(), self.aln.tolist(), self.mis.tolist(),
-                self.gap.tolist(), self.qs.tolist(), self.qe.tolist(), self.ss.tolist(), self.se.tolist(), self.evalue.tolist(), score,
-                self.ql.tolist(), self.sl.tolist(), self.cigar_strings() if cigar == 'str' else None]
-        for j, c in enumerate(cols):
-            if c is not None:
-                out[:, j] = c
-        if cigar != 'str':
-            col = out[:, 14]
-            for k, v in enumerate(self.cigar_lists()):
+        q_tab, r_tab = (self.q_tab if isinstance(self.q_tab, list) else list(self.q_tab)), (self.r_tab if isinstance(self.r_tab, list) else list(self.r_tab))
+        cols = [np.ascontiguousarray(a, dtype=dt) for a, dt in ((self.qi, np.int64), (self.ri, np.int64), (self.iden, np.float64), (self.aln, np.int64),
+                (self.mis, np.int64), (self.gap, np.int64), (self.qs, np.int64), (self.qe, np.int64), (self.ss, np.int64), (self.se, np.int64),
+                (self.evalue, np.float64), (self.score, np.float64))]
+        tail = [np.ascontiguousarray(a, dtype=dt) for a, dt in ((self.ql, np.int64), (self.sl, np.int64), (self.arena if len(self.arena) else np.zeros(1, np.uint32), np.uint32),
+                (self.c_off, np.int64), (self.c_runs, np.int64))]
+        rid = np.ascontiguousarray(self.rid, dtype=np.int64) if with_rid else None
+        ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+        rc = _pyrows().pep_rows_fill(C.c_void_p(out.ctypes.data), n, width, q_tab, r_tab, *[ptr(a) for a in cols], 1 if self.score_is_int else 0,
+                                     *[ptr(a) for a in tail], 1 if cigar == 'str' else 2, ptr(rid) if rid is not None else None)
+        if rc != 0:
+            raise RuntimeError('pep_rows_fill failed')
+        if with_rid and self.has_merge():
+            col = out[:, 16]
+            for k, v in enumerate(self.merge_lists()):
                 col[k] = v
-        if with_rid:
-            out[:, 15] = self.rid.tolist()
-            if self.has_merge():
-                col = out[:, 16]
-                for k, v in enumerate(self.merge_lists()):
-                    col[k] = v
         return out
