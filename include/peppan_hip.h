@@ -155,6 +155,13 @@ int pep_set_query_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, ui
 int pep_set_ref_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n);
 /* run K1 for the sides given as nucleotides (idempotent until the inputs change; force != 0 re-runs it) */
 int pep_translate(pep_ctx *ctx, int force);
+/* The nucleotide search (the reference's blastn call, uberBlast.py:294, 482-509) on device-resident inputs: the nucleotide sets given to
+ * pep_set_query_nt / pep_set_ref_nt THEMSELVES become the residue sets of the following searches, as base codes A0 C1 G2 T3 (anything
+ * else 4), packed on the GPU - queries forward; the reference, per reference set (pep_set_target_groups, else the whole list), all
+ * forward strands followed (strands = 2) by all reverse complements.  Target meta: seq = reference sequence, frame 1 forward / 4 reverse.
+ * Stays in force until the next pep_translate or pep_set_*: pep_search does not run K1 in between, and a translated search afterwards
+ * needs pep_translate first.  PEP_ERR_LIMIT for a sequence beyond PEP_MAX_SEQ_LEN (the caller then windows it, peppan_amd/uberBlast.py). */
+int pep_use_nt_as_residues(pep_ctx *ctx, int strands);
 int pep_query_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues);
 int pep_target_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues);
 int pep_get_query_meta(pep_ctx *ctx, pep_query_meta *out, uint32_t cap);

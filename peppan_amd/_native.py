@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 ABI_VERSION = 4
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
-           'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate',
+           'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_stats', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
@@ -364,6 +364,11 @@ class Context(object):
         """groups: one non-decreasing id per reference sequence (None / empty clears): batch of reference sets in one search"""
         g = np.ascontiguousarray(groups if groups is not None else [], dtype=np.uint32)
         self._check(self._lib.pep_set_target_groups(self._h, _ptr(g) if len(g) else None, C.c_uint32(len(g))), 'pep_set_target_groups')
+
+    def use_nt_as_residues(self, strands=2):
+        """the device-resident nucleotide sets themselves become the residue sets (base codes; reference: forward strands, then reverse
+        complements, per target group) - the inputs of the nucleotide search.  Until the next translate() / set_*."""
+        self._check(self._lib.pep_use_nt_as_residues(self._h, C.c_int(strands)), 'pep_use_nt_as_residues')
 
     def translate(self, force=False):
         self._check(self._lib.pep_translate(self._h, C.c_int(1 if force else 0)), 'pep_translate')

@@ -403,7 +403,7 @@ int pep_set_query_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint3
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     if (n > PEP_MAX_QUERIES) return pep_fail(ctx, PEP_ERR_LIMIT, "too many queries");
     PEP_TRY(upload_nt(ctx, ctx->q_nt, nt, off, n));
-    ctx->q_from_nt = true; ctx->q_gtable = gtable; ctx->q_ready = false;
+    ctx->q_from_nt = true; ctx->q_gtable = gtable; ctx->q_ready = false; ctx->resid_from_nucl = false;
     return PEP_OK;
 }
 
@@ -413,7 +413,7 @@ int pep_set_ref_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint32_
     if (frames != 3 && frames != 6) return pep_fail(ctx, PEP_ERR_ARG, "frames must be 3 or 6");
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     PEP_TRY(upload_nt(ctx, ctx->r_nt, nt, off, n));
-    ctx->t_from_nt = true; ctx->t_gtable = gtable; ctx->t_frames = frames; ctx->t_ready = false; ctx->k1_base_frames = 0;
+    ctx->t_from_nt = true; ctx->t_gtable = gtable; ctx->t_frames = frames; ctx->t_ready = false; ctx->k1_base_frames = 0; ctx->resid_from_nucl = false;
     ctx->group_of_seq.clear(); ctx->t_class_ready = false;
     return PEP_OK;
 }
@@ -425,7 +425,7 @@ int pep_set_query_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, ui
     PEP_TRY(upload_aa(ctx, ctx->q, codes, off, n, PEP_MAX_QUERIES));
     ctx->q_meta.resize(n);
     for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, 0u, ctx->q.h_len[i], 0u};
-    ctx->q_from_nt = false; ctx->q_ready = true;
+    ctx->q_from_nt = false; ctx->q_ready = true; ctx->resid_from_nucl = false;
     return PEP_OK;
 }
 
@@ -436,7 +436,7 @@ int pep_set_ref_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint
     PEP_TRY(upload_aa(ctx, ctx->t, codes, off, n, PEP_MAX_TARGETS));
     ctx->t_meta.resize(n);
     for (uint32_t i = 0; i < n; ++i) ctx->t_meta[i] = pep_target_meta{i, 0u, 0u, ctx->t.h_len[i]};
-    ctx->t_from_nt = false; ctx->t_ready = true;
+    ctx->t_from_nt = false; ctx->t_ready = true; ctx->resid_from_nucl = false;
     ctx->group_of_seq.clear(); ctx->t_class_ready = false;
     return PEP_OK;
 }
@@ -449,6 +449,7 @@ int pep_translate(pep_ctx *ctx, int force)
     if (!ctx->k1_t0 && (hipEventCreate(&ctx->k1_t0) != hipSuccess || hipEventCreate(&ctx->k1_t1) != hipSuccess)) { ctx->k1_t0 = ctx->k1_t1 = nullptr; }
     if (ctx->k1_t0) (void)hipEventRecord(ctx->k1_t0, ctx->stream);
     // both sides are queued first (reference, then queries); the reference's host-side tables are built while the query kernels run
+    ctx->resid_from_nucl = false;           // (pep_use_nt_as_residues left q_ready / t_ready false: K1 runs again)
     const bool do_q = ctx->q_from_nt && (force || !ctx->q_ready), do_t = ctx->t_from_nt && (force || !ctx->t_ready);
     if (do_t) PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable, 1));
     if (do_q) PEP_TRY(pep_k1_query(ctx, ctx->q_gtable, 1));
@@ -460,9 +461,24 @@ int pep_translate(pep_ctx *ctx, int force)
     return PEP_OK;
 }
 
+int pep_use_nt_as_residues(pep_ctx *ctx, int strands)
+{
+    if (!ctx) return PEP_ERR_ARG;
+    if (strands != 1 && strands != 2) return pep_fail(ctx, PEP_ERR_ARG, "strands must be 1 or 2");
+    if (!ctx->q_from_nt || !ctx->t_from_nt) return pep_fail(ctx, PEP_ERR_STATE, "pep_use_nt_as_residues needs pep_set_query_nt and pep_set_ref_nt first");
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    pep_materialise_staged(ctx);
+    ctx->q_ready = ctx->t_ready = false;      // the packed protein sets are gone: a later pep_translate runs K1 again
+    ctx->resid_from_nucl = false;
+    ctx->t_class_ready = false;
+    PEP_TRY(pep_nucl_sets(ctx, strands));
+    ctx->resid_from_nucl = true;
+    return PEP_OK;
+}
+
 int pep_query_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues)
 {
-    if (!ctx || !ctx->q_ready) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
+    if (!ctx || !(ctx->q_ready || ctx->resid_from_nucl)) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
     if (n) *n = ctx->q.n;
     if (residues) *residues = ctx->q.residues;
     return PEP_OK;
@@ -470,7 +486,7 @@ int pep_query_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues)
 
 int pep_target_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues)
 {
-    if (!ctx || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
+    if (!ctx || !(ctx->t_ready || ctx->resid_from_nucl)) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
     if (n) *n = ctx->t.n;
     if (residues) *residues = ctx->t.residues;
     return PEP_OK;
@@ -478,7 +494,7 @@ int pep_target_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues)
 
 int pep_get_query_meta(pep_ctx *ctx, pep_query_meta *out, uint32_t cap)
 {
-    if (!ctx || !ctx->q_ready) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
+    if (!ctx || !(ctx->q_ready || ctx->resid_from_nucl)) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
     if (cap < ctx->q_meta.size()) return pep_fail(ctx, PEP_ERR_ARG, "output buffer too small");
     if (!ctx->q_meta.empty()) memcpy(out, ctx->q_meta.data(), ctx->q_meta.size() * sizeof(pep_query_meta));
     return PEP_OK;
@@ -486,7 +502,7 @@ int pep_get_query_meta(pep_ctx *ctx, pep_query_meta *out, uint32_t cap)
 
 int pep_get_target_meta(pep_ctx *ctx, pep_target_meta *out, uint32_t cap)
 {
-    if (!ctx || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
+    if (!ctx || !(ctx->t_ready || ctx->resid_from_nucl)) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
     if (cap < ctx->t_meta.size()) return pep_fail(ctx, PEP_ERR_ARG, "output buffer too small");
     if (!ctx->t_meta.empty()) memcpy(out, ctx->t_meta.data(), ctx->t_meta.size() * sizeof(pep_target_meta));
     return PEP_OK;
@@ -494,14 +510,14 @@ int pep_get_target_meta(pep_ctx *ctx, pep_target_meta *out, uint32_t cap)
 
 int pep_get_query_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off)
 {
-    if (!ctx || !ctx->q_ready) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
+    if (!ctx || !(ctx->q_ready || ctx->resid_from_nucl)) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     return download_aa(ctx, ctx->q, codes, cap, off);
 }
 
 int pep_get_target_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off)
 {
-    if (!ctx || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
+    if (!ctx || !(ctx->t_ready || ctx->resid_from_nucl)) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     return download_aa(ctx, ctx->t, codes, cap, off);
 }
@@ -575,8 +591,10 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         if (memcmp(ctx->params.sub, params->sub, sizeof(params->sub)) != 0) ctx->sub_ready = false;      // the LDS image follows the table only
         ctx->params = *params;
     }
-    PEP_TRY(pep_translate(ctx, 0));
-    if (!ctx->q_ready || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "pep_search before both sequence sets were given");
+    if (!ctx->resid_from_nucl) {
+        PEP_TRY(pep_translate(ctx, 0));
+        if (!ctx->q_ready || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "pep_search before both sequence sets were given");
+    }
     if (!ctx->sub_ready) { PEP_TRY(upload_sub_image(ctx)); ctx->sub_ready = true; }
     PEP_TRY(build_t_class(ctx));
 

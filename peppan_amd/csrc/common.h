@@ -95,6 +95,7 @@ struct pep_ctx {
     std::vector<pep_target_meta> t_meta;    // (seq, frame, chunk offset, length) per target (K1)
     bool q_from_nt = false, t_from_nt = false;
     bool q_ready = false, t_ready = false, sub_ready = false, codon_ready = false;
+    bool resid_from_nucl = false;           // ctx->q / ctx->t hold base codes made by pep_use_nt_as_residues (until the next pep_translate / pep_set_*)
     int q_gtable = 11, t_gtable = 11, t_frames = 6;
     // K1 reference side: chunk-slot prefix per (sequence, frame), a function of the input lengths only - kept between translations
     DevBuf d_k1_base;
@@ -191,6 +192,7 @@ int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, in
 // ---- translate.hip  (K1)
 int pep_k1_query(pep_ctx *ctx, int gtable, int phase = 0);
 int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase = 0);
+int pep_nucl_sets(pep_ctx *ctx, int strands);      // the nucleotide sets themselves as residue sets (base codes; reference: forward strands + reverse complements)
 // ---- seeds.hip  (K2-K4)
 int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands);
 int pep_upload_sub_table(pep_ctx *ctx);       // ctx->params.sub -> ctx->d_params (1 KiB, uploaded when it changed)

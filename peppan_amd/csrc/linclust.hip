@@ -266,6 +266,7 @@ int k9_gapped(pep_ctx *ctx, const uint8_t *h_res, const uint64_t *h_off, int bas
     int rc = pep_upload_sub(ctx);
     // the sequence sets of the context are taken over: a later pep_search needs its inputs again (nucleotide inputs are re-translated)
     ctx->q_ready = ctx->t_ready = false;
+    ctx->resid_from_nucl = false;
     ctx->t_class_ready = false;
     const uint64_t BYTES = 200ull << 20;                 // packed bytes per side and batch
     size_t at = 0;

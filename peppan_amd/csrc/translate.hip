@@ -224,6 +224,45 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
     for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = s;
 }
 
+// ---- nucleotide sets as residue sets (the blastn-equivalent tool, uberBlast.py:294, 482-509): base codes A0 C1 G2 T3, anything else 4;
+// a reverse-strand target is the reverse complement.  One wavefront per packed sequence, eight consecutive bytes per lane (one unaligned
+// 8-byte load where the whole window lies inside the sequence, byte loads at its two ends), padding and block -> sequence map as k1_pack.
+struct NuclDesc { uint32_t seq, rev; };
+__global__ __launch_bounds__(256) void nucl_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, const NuclDesc *__restrict__ desc,
+                                                 const uint32_t *__restrict__ pk_off, uint32_t n_packed, uint8_t *__restrict__ res, uint32_t *__restrict__ blk2seq)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n_packed == 0) {
+        if (s == 0) for (uint32_t x = lane; x < pk_off[0]; x += 64) res[x] = (uint8_t)PEP_PAD_CODE;
+        return;
+    }
+    if (s >= n_packed) return;
+    const NuclDesc d = desc[s];
+    const uint32_t start = pk_off[s], next = pk_off[s + 1];
+    const uint8_t *src = nt + nt_off[d.seq];
+    const int64_t L = (int64_t)(nt_off[d.seq + 1] - nt_off[d.seq]);
+    if (s == 0) for (uint32_t x = lane; x < start; x += 64) res[x] = (uint8_t)PEP_PAD_CODE;          // leading pad
+    for (uint32_t x0 = 8 * lane; x0 < next - start; x0 += 512) {
+        uint32_t word[2] = {0, 0};
+        uint8_t raw[8];
+        const bool whole = (int64_t)x0 + 8 <= L;
+        if (whole) __builtin_memcpy(raw, d.rev ? src + (L - 8 - x0) : src + x0, 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t c = PEP_PAD_CODE;
+            if ((int64_t)x0 + k < L) {
+                const uint8_t ch = whole ? raw[d.rev ? 7 - k : k] : (d.rev ? src[L - 1 - x0 - k] : src[x0 + k]);
+                const int v = base2(ch);
+                c = v < 0 ? 4u : (uint32_t)(d.rev ? 3 - v : v);
+            }
+            word[k >> 2] |= c << (8 * (k & 3));
+        }
+        *reinterpret_cast<uint2 *>(res + start + x0) = make_uint2(word[0], word[1]);                 // starts and paddings are multiples of 16: whole words
+    }
+    for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = s;
+}
+
 void fill_codon_table(uint8_t tab[2][64])
 {
     static const char *aa = "KNKNTTTTRSRSIIMIQHQHPPPPRRRRLLLLEDEDAAAAGGGGVVVVXYXYSSSSXCWCLFLF";
@@ -449,4 +488,64 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     PEP_HIP(ctx, hipEventRecord(ctx->k1_event, ctx->stream));
     if (phase == 1) return PEP_OK;
     return k1_ref_finish(ctx);
+}
+
+// the packed residue set of one side from its nucleotide set: `order` lists (sequence, strand) per packed sequence
+static int nucl_build(pep_ctx *ctx, const NtSet &nt, const std::vector<NuclDesc> &order, uint32_t max_n, SeqSet &out)
+{
+    const uint32_t n = (uint32_t)order.size();
+    if (n > max_n) return pep_fail(ctx, PEP_ERR_LIMIT, "too many sequences");
+    out.n = n;
+    out.h_off.assign((size_t)n + 1, 0);
+    out.h_len.assign(n, 0);
+    uint64_t pos = PEP_END_PAD, residues = 0;
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t len = nt.h_off[order[i].seq + 1] - nt.h_off[order[i].seq];
+        if (len > PEP_MAX_SEQ_LEN) return pep_fail(ctx, PEP_ERR_LIMIT, "sequence longer than PEP_MAX_SEQ_LEN");
+        out.h_off[i] = (uint32_t)pos; out.h_len[i] = (uint32_t)len;
+        residues += len; max_len = std::max(max_len, (uint32_t)len);
+        pos += (len + 15) / 16 * 16 + PEP_SEQ_GAP;
+        if (pos > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "packed sequence set exceeds 2^29 bytes");
+    }
+    pos += PEP_END_PAD;
+    out.h_off[n] = (uint32_t)pos;
+    out.total = pos; out.residues = residues; out.max_len = max_len;
+    PEP_TRY(dev_reserve(ctx, out.res, pos + 64));
+    PEP_TRY(dev_reserve(ctx, out.off, ((size_t)n + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, out.len, ((size_t)n + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, out.blk2seq, (pos / 16 + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[2], ((size_t)n + 1) * sizeof(NuclDesc)));
+    PEP_HIP(ctx, hipMemcpyAsync(out.off.p, out.h_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n) PEP_HIP(ctx, hipMemcpyAsync(out.len.p, out.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n) PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[2].p, order.data(), (size_t)n * sizeof(NuclDesc), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(nucl_pack, dim3((unsigned)ceil_div((uint64_t)n + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(),
+                       ctx->ws[2].as<const NuclDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>());
+    PEP_HIP(ctx, hipGetLastError());
+    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (the descriptor vector is the caller's)
+    return PEP_OK;
+}
+
+int pep_nucl_sets(pep_ctx *ctx, int strands)
+{
+    std::vector<NuclDesc> qo(ctx->q_nt.n), to;
+    for (uint32_t i = 0; i < ctx->q_nt.n; ++i) qo[i] = NuclDesc{i, 0u};
+    PEP_TRY(nucl_build(ctx, ctx->q_nt, qo, PEP_MAX_QUERIES, ctx->q));
+    ctx->q_meta.resize(ctx->q_nt.n);
+    for (uint32_t i = 0; i < ctx->q_nt.n; ++i) ctx->q_meta[i] = pep_query_meta{i, 1u, ctx->q.h_len[i], ctx->q.h_len[i]};
+    // targets: per reference set (pep_set_target_groups; one set otherwise) all forward strands, then all reverse complements
+    const uint32_t nr = ctx->r_nt.n;
+    const bool grouped = ctx->group_of_seq.size() == nr && nr > 0;
+    to.reserve((size_t)nr * strands);
+    for (uint32_t a = 0; a < nr;) {
+        uint32_t b = a + 1;
+        while (b < nr && (!grouped || ctx->group_of_seq[b] == ctx->group_of_seq[a])) ++b;
+        for (int rev = 0; rev < strands; ++rev)
+            for (uint32_t i = a; i < b; ++i) to.push_back(NuclDesc{i, (uint32_t)rev});
+        a = b;
+    }
+    PEP_TRY(nucl_build(ctx, ctx->r_nt, to, PEP_MAX_TARGETS, ctx->t));
+    ctx->t_meta.resize(to.size());
+    for (size_t i = 0; i < to.size(); ++i) ctx->t_meta[i] = pep_target_meta{to[i].seq, to[i].rev ? 4u : 1u, 0u, ctx->t.h_len[i]};
+    return PEP_OK;
 }

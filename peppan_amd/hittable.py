@@ -46,7 +46,7 @@ def _name_codes(names, idx):
 
 class HitTable(object):
     __slots__ = ('q_tab', 'r_tab', 'qi', 'ri', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'score_is_int',
-                 'ql', 'sl', 'arena', 'c_off', 'c_runs', 'rid', 'merge', 'm_score', 'm_iden', 'm_span', 'm_start', 'm_len', 'm_ids')
+                 'ql', 'sl', 'arena', 'c_off', 'c_runs', 'rid', 'merge', 'm_score', 'm_iden', 'm_span', 'm_start', 'm_len', 'm_ids', 'q_sorted', 'r_sorted')
     _ROW_COLS = ('qi', 'ri', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'ql', 'sl', 'c_off', 'c_runs', 'rid')
     # column 16 after -m in numeric form: per row the group's score / identity / span (span < 0: the row has no group and shows the
     # reference's shared empty list) and the slice [m_start, m_start + m_len) of m_ids that holds the group's row ids
@@ -66,6 +66,7 @@ class HitTable(object):
         self.merge = merge                      # column 16 after -m as Python lists, one per row (made on demand from the m_* arrays)
         self.m_score = self.m_iden = self.m_span = self.m_start = self.m_len = self.m_ids = None
         self.score_is_int = score_is_int
+        self.q_sorted = self.r_sorted = False   # True: the name table is a list of str in ascending code-point order (row codes = indices)
 
     def __len__(self):
         return len(self.qi)
@@ -154,6 +155,17 @@ class HitTable(object):
             return HitTable.empty()
         if len(tables) == 1:
             return tables[0]
+        if all(t.q_tab is tables[0].q_tab and t.r_tab is tables[0].r_tab for t in tables):
+            # the tools of one run share their name tables: columns one after the other, arenas side by side
+            base = np.cumsum([0] + [len(t.arena) for t in tables[:-1]])
+            cols = {f: np.concatenate([getattr(t, f) for t in tables]) for f in HitTable._ROW_COLS if f != 'c_off'}
+            first = tables[0]
+            out = HitTable(first.q_tab, first.r_tab, cols['qi'], cols['ri'], cols['iden'], cols['aln'], cols['mis'], cols['gap'], cols['qs'], cols['qe'], cols['ss'], cols['se'],
+                           cols['evalue'], cols['score'], cols['ql'], cols['sl'], np.concatenate([t.arena for t in tables]),
+                           np.concatenate([t.c_off + b for t, b in zip(tables, base.tolist())]), cols['c_runs'], rid=cols['rid'],
+                           score_is_int=all(t.score_is_int for t in tables))
+            out.q_sorted, out.r_sorted = all(t.q_sorted for t in tables), all(t.r_sorted for t in tables)
+            return out
         q_of, r_of, parts = {}, {}, {f: [] for f in HitTable._ROW_COLS}
         arena, base = [], 0
         for t in tables:
@@ -174,10 +186,10 @@ class HitTable(object):
 
     # ------------------------------------------------------------------------------------------------ pieces of the chain
     def q_codes(self):
-        return _name_codes(self.q_tab, self.qi)
+        return self.qi if self.q_sorted else _name_codes(self.q_tab, self.qi)
 
     def r_codes(self):
-        return _name_codes(self.r_tab, self.ri)
+        return self.ri if self.r_sorted else _name_codes(self.r_tab, self.ri)
 
     def fix_end(self, se_lim, ee_lim):
         """RunBlast.fixEnd (uberBlast.py:462-480): stretch an alignment over an unaligned query head of at most se_lim bases / tail of at

@@ -160,11 +160,22 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
 
 
 def _drop_dead_exemplars(fasta, alive_ids):
-    """rewrite the exemplar FASTA in place, keeping the records of genes that appeared as a query and are still alive"""
-    from .clust import read_blocks
-    keep = [blk.text for blk in read_blocks(fasta) if int(blk.name) in alive_ids]
-    with open(fasta, 'w') as fout:
-        fout.writelines(keep)
+    """rewrite the exemplar FASTA in place, keeping the records (header line and the lines behind it, byte for byte) of genes that appeared as
+    a query and are still alive (PEPPAN.py:278-288).  The file is cut at its header lines in one pass; it is left alone when every record stays."""
+    with open(fasta, 'rb') as fin:
+        data = fin.read()
+    parts = data.split(b'\n>')                     # a record starts at a '>' that opens a line
+    kept, dropped = [], False
+    for k, rec in enumerate(parts):
+        text = (rec if k == 0 else b'>' + rec) + (b'\n' if k + 1 < len(parts) else b'')
+        name = text[1:].split(b'\n', 1)[0].split() if text.startswith(b'>') else []
+        if name and int(name[0]) in alive_ids:
+            kept.append(text)
+        else:
+            dropped = True
+    if dropped:
+        with open(fasta, 'wb') as fout:
+            fout.write(b''.join(kept))
 
 
 def _edges(cluFile, bsnFile):

@@ -71,6 +71,11 @@ def get_context(device=None):
 # ------------------------------------------------------------------------------------------------------------
 # GPU hits -> the reference's table rows (coordinate algebra of parseDiamond, uberBlast.py:25-58)
 # ------------------------------------------------------------------------------------------------------------
+def _str_table(names):
+    """a name table as a list of str; a list that is one already is passed on as it is (tables that share it concatenate without a remap)"""
+    return names if isinstance(names, list) and all(type(x) is str for x in names[:4]) and all(type(x) is str for x in names[-4:]) else [str(x) for x in names]
+
+
 def hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
     """hits/cigar: output of Context.search for a translated search.  q_len / r_len: nucleotide lengths per sequence index.
     Returns the numeric HitTable of the rows parseDiamond would keep (coordinate algebra and filters of uberBlast.py:25-58)."""
@@ -100,7 +105,7 @@ def hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, m
     gap_open = np.bincount(owner, weights=(runs_op != 0), minlength=n).astype(np.int64)
     mismatch = (variation - gap_nt).astype(np.int64)
     idx = np.nonzero(keep)[0]
-    return HitTable([str(x) for x in q_names], [str(x) for x in r_names], qseq[idx], rseq[idx], iden[idx], cl[idx], mismatch[idx], gap_open[idx],
+    return HitTable(_str_table(q_names), _str_table(r_names), qseq[idx], rseq[idx], iden[idx], cl[idx], mismatch[idx], gap_open[idx],
                     qs_nt[idx], qe_nt[idx], rs_nt[idx], re_nt[idx], np.zeros(len(idx)), hits['score'][idx], ql[idx], rl[idx],
                     ((runs_len << 2) | runs_op).astype(np.uint32), hits['cigar_off'][idx], hits['cigar_runs'][idx])
 
@@ -108,6 +113,20 @@ def hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, m
 def hits_to_blastab(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
     """the same as the reference's row format: ndarray(object)[n, 15], CIGAR as [[n, op], ...] in nucleotides"""
     return hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio).to_rows(with_rid=False)
+
+
+def _three_decimals(v):
+    """float('%.3f' % x) for every element (blastn prints pident with three decimals, uberBlast.py:282): the decimal string is the
+    correctly rounded 3-digit decimal of the double, and float() of it is the double nearest to that decimal - np.round(v, 3) gives the
+    same value except when x * 1000 sits within an ulp of a tie, so those few go through the string"""
+    v = np.asarray(v, dtype=np.float64)
+    scaled = v * 1000.
+    out = np.round(v, 3)
+    frac = np.abs(scaled - np.floor(scaled) - 0.5)
+    near = np.flatnonzero(frac < 1e-6)
+    if len(near):
+        out[near] = [float('%.3f' % x) for x in v[near].tolist()]
+    return out
 
 
 _NT_CODE = np.full(256, 4, dtype=np.uint8)
@@ -148,7 +167,7 @@ def blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len, min_id, min
         in_home = (mid >= home_lo[ti]) & (mid < home_hi[ti])
     ss, se = np.where(rev, sl - ts + 1, ts), np.where(rev, sl - te + 1, te)
     aln, ident = hits['aln_len'].astype(np.int64), hits['n_ident'].astype(np.int64)
-    iden = np.array([float('%.3f' % v) for v in (100. * ident / aln).tolist()]) / 100.
+    iden = _three_decimals(100. * ident / aln) / 100.
     runs_len, runs_op = (cigar >> 2).astype(np.int64), (cigar & 3).astype(np.int64)
     owner = np.repeat(np.arange(n), hits['cigar_runs'].astype(np.int64))
     gap_cols = np.bincount(owner, weights=runs_len * (runs_op != 0), minlength=n).astype(np.int64)
@@ -157,7 +176,7 @@ def blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len, min_id, min
     evalue = params.ka_k * ql * params.dbsize * np.exp(-params.ka_lambda * score)
     keep = (iden >= min_id) & (qe - qs + 1 >= min_cov) & (qe - qs + 1 >= min_ratio * ql) & in_home
     idx = np.nonzero(keep)[0]
-    return HitTable([str(x) for x in q_names], [str(x) for x in r_names], qi[idx], ri[idx], iden[idx], aln[idx], (aln - ident - gap_cols)[idx], gap_open[idx],
+    return HitTable(_str_table(q_names), _str_table(r_names), qi[idx], ri[idx], iden[idx], aln[idx], (aln - ident - gap_cols)[idx], gap_open[idx],
                     qs[idx], qe[idx], ss[idx], se[idx], evalue[idx], score[idx], ql[idx], sl[idx], np.array(cigar, dtype=np.uint32), hits['cigar_off'][idx], hits['cigar_runs'][idx])
 
 
@@ -366,6 +385,12 @@ class RunBlast(object):
         self.r_names = sorted(self.refSeq) if self._batch is None else list(self._batch[0])
         self.q_index = {n: i for i, n in enumerate(self.q_names)}
         self.r_index = {n: i for i, n in enumerate(self.r_names)}
+        # the name tables every HitTable of this run shares (same list objects: concat and the final sort recognise them)
+        self._q_tab, self._r_tab = [str(x) for x in self.q_names], [str(x) for x in self.r_names]
+        self._q_sorted = all(isinstance(x, str) for x in self.q_names)               # sorted(): code-point order when the keys are strings
+        self._r_sorted = self._batch is None and all(isinstance(x, str) for x in self.r_names)
+        self._q_len = np.fromiter((len(self.qrySeq[n]) for n in self.q_names), dtype=np.int64, count=len(self.q_names))
+        self._r_len = np.fromiter((len(self.refSeq[n]) for n in self.r_names), dtype=np.int64, count=len(self.r_names))
         ctx.set_query_nt([self._text(self.qrySeq[n]) for n in self.q_names], self.table_id)
         ctx.set_ref_nt([self._text(self.refSeq[n]) for n in self.r_names], frames, self.table_id)
         ctx.set_target_groups(None if self._batch is None else self._batch[1])
@@ -396,11 +421,11 @@ class RunBlast(object):
         self._ensure_nt(ctx, 6 if frames == '7' else 3)
         params = N.default_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100., top_k=nhits, n_splits=5,
                                   dbsize=5000000., max_evalue=1., sensitive=os.environ.get('PEPPAN_HIP_SENSITIVE') == '1')
+        ctx.translate()                                                # (K1; a nucleotide search before this one left base codes in the packed sets)
         hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
-        q_len = [len(self.qrySeq[n]) for n in self.q_names]
-        r_len = [len(self.refSeq[n]) for n in self.r_names]
-        table = hits_to_table(hits, cigar, ctx.query_meta(), ctx.target_meta(), self.q_names, self.r_names, q_len, r_len,
+        table = hits_to_table(hits, cigar, ctx.query_meta(), ctx.target_meta(), self._q_tab, self._r_tab, self._q_len, self._r_len,
                               self.min_id, self.min_cov, self.min_ratio)
+        table.q_sorted, table.r_sorted = self._q_sorted, self._r_sorted
         self.last_stats = stats
         logger('Run diamond finishes. Got {0} alignments'.format(len(table)))
         return table
@@ -413,6 +438,19 @@ class RunBlast(object):
         logger('Run BLASTn starts')
         self._load(ref, qry)
         ctx = get_context(self.device)
+        params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100.)
+        if max(map(len, self.refSeq.values()), default=0) <= N.MAX_SEQ_LEN:
+            # the usual case: the nucleotide sets that K1 and K7 read on the device are packed THERE into the base-code residue sets of this
+            # search (forward strands, then reverse complements, per reference set) - no encoding, concatenation or upload on the host
+            self._ensure_nt(ctx)
+            ctx.use_nt_as_residues(2)
+            hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
+            tm = ctx.target_meta()
+            table = blast_hits_to_table(hits, cigar, self._q_tab, self._r_tab, self._q_len, self._r_len, self.min_id, self.min_cov, self.min_ratio, params,
+                                        tm['seq'].astype(np.int64), tm['frame'] > 3)
+            table.q_sorted, table.r_sorted = self._q_sorted, self._r_sorted
+            logger('Run BLASTn finishes. Got {0} alignments'.format(len(table)))
+            return table
         q_names = sorted(self.qrySeq)
         r_names = sorted(self.refSeq) if self._batch is None else list(self._batch[0])
         groups = [0] * len(r_names) if self._batch is None else list(self._batch[1])
@@ -469,7 +507,6 @@ class RunBlast(object):
         ctx.set_ref_aa((np.concatenate(parts) if parts else np.zeros(0, np.uint8), t_off))
         ctx.set_target_groups(None if self._batch is None else t_grp)
         self._nt_loaded = None                      # the packed protein sets of a previous translated search are gone
-        params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100.)
         hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
         table = blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len,
                                     self.min_id, self.min_cov, self.min_ratio, params, np.array(t_seq, dtype=np.int64), np.array(t_rev, dtype=bool),

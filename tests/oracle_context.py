@@ -11,6 +11,7 @@ class OracleContext(object):
         self.q_nt = [s.decode() if isinstance(s, bytes) else s for s in seqs]
         self.q_table = gtable
         self._direct = False
+        self.q_aa_given = False
 
     def set_ref_nt(self, seqs, frames=6, gtable=11):
         self.r_nt = [s.decode() if isinstance(s, bytes) else s for s in seqs]
@@ -26,6 +27,7 @@ class OracleContext(object):
     def set_query_aa(self, seqs):
         self.q_aa = self._unpack(seqs)
         self._direct = True
+        self.q_aa_given = True
 
     def set_ref_aa(self, seqs):
         self.t_aa = self._unpack(seqs)
@@ -43,7 +45,23 @@ class OracleContext(object):
     def set_target_groups(self, groups):
         assert groups is None or len(groups) == 0, 'the oracle searches one reference set at a time'
 
+    def use_nt_as_residues(self, strands=2):
+        """pep_use_nt_as_residues: base codes of the nucleotide sets; reference = all forward strands, then all reverse complements"""
+        self.q_aa = [O.nt_codes(s.upper()) for s in self.q_nt]
+        fwd = [O.nt_codes(s.upper()) for s in self.r_nt]
+        rc = [np.where(c < 4, 3 - c, 4).astype(np.uint8)[::-1] for c in fwd]
+        self.t_aa = fwd + (rc if strands == 2 else [])
+        n = len(fwd)
+        self._qm = np.array([(i, 1, len(c), len(c)) for i, c in enumerate(self.q_aa)], dtype=N.QUERY_META_DTYPE).reshape(-1)
+        self._tm = np.array([(i % n, 1 if i < n else 4, 0, len(c)) for i, c in enumerate(self.t_aa)], dtype=N.TARGET_META_DTYPE).reshape(-1)
+        self._direct = True
+
     def translate(self, force=False):
+        if hasattr(self, 'q_nt') and hasattr(self, 'r_nt') and getattr(self, 'q_aa_given', False) is False:
+            self._direct = False            # (K1 again: a nucleotide search may have left base codes in the packed sets)
+        self._translate_now()
+
+    def _translate_now(self):
         if getattr(self, '_direct', False):
             return
         qm, self.q_aa = [], []
@@ -68,7 +86,7 @@ class OracleContext(object):
         return self._tm
 
     def search(self, params=None, copy=True):
-        self.translate()
+        self._translate_now()
         p = O.params_from(params)
         ms = np.array([O.min_score(len(s), params.dbsize, params.max_evalue, params.ka_lambda, params.ka_k) for s in self.q_aa], dtype=np.int32)
         h, c, st = O.search(self.q_aa, self.t_aa, p, min_scores=ms)
