@@ -307,6 +307,7 @@ class Context(object):
         self._h = h
         self._view = None
         self.upload_generation = 0           # bumped by every call that replaces a device-resident sequence set (see RunBlast._ensure_nt)
+        self.q_nt_token = self.r_nt_token = None     # what the nucleotide sets on the device were made from (set by RunBlast._ensure_nt, cleared by any set_*)
         if rc != 0:
             msg = self._lib.pep_last_error(h).decode() if h else 'pep_ctx_create failed'
             if h:
@@ -342,21 +343,25 @@ class Context(object):
     # ---- inputs
     def set_query_nt(self, seqs, gtable=11):
         self.upload_generation += 1
+        self.q_nt_token = None
         nt, off = _pack(seqs)
         self._check(self._lib.pep_set_query_nt(self._h, _ptr(nt), _ptr(off), C.c_uint32(_count(seqs)), C.c_int(gtable)), 'pep_set_query_nt')
 
     def set_ref_nt(self, seqs, frames=6, gtable=11):
         self.upload_generation += 1
+        self.r_nt_token = None
         nt, off = _pack(seqs)
         self._check(self._lib.pep_set_ref_nt(self._h, _ptr(nt), _ptr(off), C.c_uint32(_count(seqs)), C.c_int(frames), C.c_int(gtable)), 'pep_set_ref_nt')
 
     def set_query_aa(self, seqs):
         self.upload_generation += 1
+        self.q_nt_token = None
         aa, off = _pack(seqs)
         self._check(self._lib.pep_set_query_aa(self._h, _ptr(aa), _ptr(off), C.c_uint32(_count(seqs))), 'pep_set_query_aa')
 
     def set_ref_aa(self, seqs):
         self.upload_generation += 1
+        self.r_nt_token = None
         aa, off = _pack(seqs)
         self._check(self._lib.pep_set_ref_aa(self._h, _ptr(aa), _ptr(off), C.c_uint32(_count(seqs))), 'pep_set_ref_aa')
 

@@ -186,10 +186,10 @@ class HitTable(object):
 
     # ------------------------------------------------------------------------------------------------ pieces of the chain
     def q_codes(self):
-        return self.qi if self.q_sorted else _name_codes(self.q_tab, self.qi)
+        return self.qi if self.q_sorted and type(self.q_tab[0]) is str else _name_codes(self.q_tab, self.qi)
 
     def r_codes(self):
-        return self.ri if self.r_sorted else _name_codes(self.r_tab, self.ri)
+        return self.ri if self.r_sorted and type(self.r_tab[0]) is str else _name_codes(self.r_tab, self.ri)
 
     def fix_end(self, se_lim, ee_lim):
         """RunBlast.fixEnd (uberBlast.py:462-480): stretch an alignment over an unaligned query head of at most se_lim bases / tail of at

@@ -331,6 +331,7 @@ def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=Non
         from .uberBlast import get_context
         ctx = get_context()
     T.q_tab, T.r_tab = [int(x) for x in T.q_tab], [int(x) for x in T.r_tab]
+    T.q_sorted = T.r_sorted = False           # (integer names order numerically from here on)
     T = _with_known(T, old_prediction)
     n = len(T)
     n_id = int(T.rid.max()) + 1

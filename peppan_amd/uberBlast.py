@@ -44,17 +44,38 @@ _CTX = {}
 _FASTA_CACHE = {}
 
 
-def _read_cached(path):
+def _read_cached(path, with_key=False):
     """sequences of a FASTA/FASTQ file, re-parsed only when the file changed: PEPPAN maps the SAME gene file against
-    every genome (PEPPAN.py:768-772), one uberBlast call per genome"""
+    every genome (PEPPAN.py:768-772), one uberBlast call per genome.  with_key: also the cache key (path, mtime, size) that identifies
+    this content - the prepared form of a side (_prepare_side) and what a context holds on the device are remembered under it."""
     st = os.stat(path)
     key = (os.path.abspath(path), st.st_mtime_ns, st.st_size)
     hit = _FASTA_CACHE.get(key)
     if hit is None:
         if len(_FASTA_CACHE) >= 4:
             _FASTA_CACHE.clear()
+            _SIDE_CACHE.clear()
         hit = _FASTA_CACHE[key] = readFastq(path, with_qual=False)[0]
-    return dict(hit)         # callers may mutate their copy (the reference's reScore does, uberBlast.py:402-405)
+    seqs = dict(hit)         # callers may mutate their copy (the reference's reScore does, uberBlast.py:402-405)
+    return (seqs, key) if with_key else seqs
+
+
+_SIDE_CACHE = {}
+
+
+def _prepare_side(seqs, key, names=None):
+    """one side of a search ready for the device: names in the reference's FASTA order (sorted, uberBlast.py:527, 537; or as given), the
+    shared str name table, nucleotide lengths, and the packed (bytes, offsets) pair Context.set_*_nt takes.  Remembered per file."""
+    side = _SIDE_CACHE.get(key) if (key is not None and names is None) else None
+    if side is None:
+        order = sorted(seqs) if names is None else list(names)
+        texts = [RunBlast._text(seqs[n]) for n in order]
+        side = dict(names=order, index={n: i for i, n in enumerate(order)}, tab=[str(x) for x in order],
+                    sorted=names is None and all(isinstance(x, str) for x in order),
+                    lens=np.fromiter(map(len, texts), dtype=np.int64, count=len(texts)), packed=N._pack(texts))
+        if key is not None and names is None:
+            _SIDE_CACHE[key] = side
+    return side
 
 
 def get_context(device=None):
@@ -236,6 +257,7 @@ def cigar2score(data):
 class RunBlast(object):
     def __init__(self, device=None):
         self.qrySeq = self.refSeq = None
+        self._q_key = self._r_key = None    # cache keys of the files the sequences came from (None: handed over by the caller)
         self.device = device
         self._nt_loaded = None
         self._batch = None                  # (reference names genome-major, genome id per name) in run_batch
@@ -337,7 +359,8 @@ class RunBlast(object):
                        filter, linear_merge, return_overlap, fix_end):
         self.min_id, self.min_cov, self.min_ratio = min_id, min_cov, min_ratio
         self.table_id, self.n_thread, self.pool = table_id, n_thread, useProcess
-        self.qrySeq = _read_cached(qry)
+        self.qrySeq, self._q_key = _read_cached(qry, with_key=True)
+        self._r_key = None
         combined, names, groups = {}, [], []
         for g, path in enumerate(refs):
             rs = _read_cached(path)
@@ -368,9 +391,9 @@ class RunBlast(object):
         if self._batch is not None:
             return                          # run_batch filled qrySeq / refSeq itself
         if not self.qrySeq:
-            self.qrySeq, self.qryQual = _read_cached(qry), None
+            (self.qrySeq, self._q_key), self.qryQual = _read_cached(qry, with_key=True), None
         if not self.refSeq:
-            self.refSeq, self.refQual = _read_cached(ref), None
+            (self.refSeq, self._r_key), self.refQual = _read_cached(ref, with_key=True), None
 
     def _ensure_nt(self, ctx, frames=None):
         """this instance's nucleotide sets on the device (K1 and K7 read them there).  sorted(name) order is the order in which the
@@ -381,18 +404,20 @@ class RunBlast(object):
         if self._nt_loaded is not None and self._nt_loaded[2] == gen and self._nt_loaded[1] == self.table_id and frames in (None, self._nt_loaded[0]):
             return
         frames = frames or 6
-        self.q_names = sorted(self.qrySeq)
-        self.r_names = sorted(self.refSeq) if self._batch is None else list(self._batch[0])
-        self.q_index = {n: i for i, n in enumerate(self.q_names)}
-        self.r_index = {n: i for i, n in enumerate(self.r_names)}
-        # the name tables every HitTable of this run shares (same list objects: concat and the final sort recognise them)
-        self._q_tab, self._r_tab = [str(x) for x in self.q_names], [str(x) for x in self.r_names]
-        self._q_sorted = all(isinstance(x, str) for x in self.q_names)               # sorted(): code-point order when the keys are strings
-        self._r_sorted = self._batch is None and all(isinstance(x, str) for x in self.r_names)
-        self._q_len = np.fromiter((len(self.qrySeq[n]) for n in self.q_names), dtype=np.int64, count=len(self.q_names))
-        self._r_len = np.fromiter((len(self.refSeq[n]) for n in self.r_names), dtype=np.int64, count=len(self.r_names))
-        ctx.set_query_nt([self._text(self.qrySeq[n]) for n in self.q_names], self.table_id)
-        ctx.set_ref_nt([self._text(self.refSeq[n]) for n in self.r_names], frames, self.table_id)
+        q = _prepare_side(self.qrySeq, getattr(self, '_q_key', None))
+        r = _prepare_side(self.refSeq, getattr(self, '_r_key', None), names=None if self._batch is None else self._batch[0])
+        self.q_names, self.q_index, self._q_tab, self._q_sorted, self._q_len = q['names'], q['index'], q['tab'], q['sorted'], q['lens']
+        self.r_names, self.r_index, self._r_tab, self._r_len = r['names'], r['index'], r['tab'], r['lens']
+        self._r_sorted = r['sorted'] and self._batch is None
+        # a side the context still holds from an earlier call on the same file (PEPPAN maps one gene file against every genome) is not sent again
+        q_token = (getattr(self, '_q_key', None), self.table_id) if getattr(self, '_q_key', None) is not None else None
+        r_token = (getattr(self, '_r_key', None), frames, self.table_id) if getattr(self, '_r_key', None) is not None else None
+        if q_token is None or getattr(ctx, 'q_nt_token', None) != q_token:
+            ctx.set_query_nt(q['packed'], self.table_id)
+            ctx.q_nt_token = q_token
+        if r_token is None or getattr(ctx, 'r_nt_token', None) != r_token:
+            ctx.set_ref_nt(r['packed'], frames, self.table_id)
+            ctx.r_nt_token = r_token
         ctx.set_target_groups(None if self._batch is None else self._batch[1])
         self._nt_loaded = (frames, self.table_id, getattr(ctx, 'upload_generation', 0))
 

@@ -7,14 +7,21 @@ from peppan_amd import _native as N
 
 
 class OracleContext(object):
+    @staticmethod
+    def _texts(seqs):
+        if isinstance(seqs, tuple) and len(seqs) == 2:                       # (bytes, offsets), the packed form Context.set_*_nt also takes
+            buf, off = np.asarray(seqs[0], dtype=np.uint8).tobytes().decode('ascii'), np.asarray(seqs[1], dtype=np.int64)
+            return [buf[off[i]:off[i + 1]] for i in range(len(off) - 1)]
+        return [s.decode() if isinstance(s, bytes) else s for s in seqs]
+
     def set_query_nt(self, seqs, gtable=11):
-        self.q_nt = [s.decode() if isinstance(s, bytes) else s for s in seqs]
+        self.q_nt = self._texts(seqs)
         self.q_table = gtable
         self._direct = False
         self.q_aa_given = False
 
     def set_ref_nt(self, seqs, frames=6, gtable=11):
-        self.r_nt = [s.decode() if isinstance(s, bytes) else s for s in seqs]
+        self.r_nt = self._texts(seqs)
         self.r_frames, self.r_table = frames, gtable
 
     @staticmethod
