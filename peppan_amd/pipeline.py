@@ -128,10 +128,10 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
     pairs = np.array([], dtype=int)
     alive_ids, absorbed = set(), []
     if len(T):
-        q_gene = np.array([int(x) for x in T.q_tab], dtype=np.int64)[T.qi]            # the reference casts both name columns to int (PEPPAN.py:231)
-        r_gene = np.array([int(x) for x in T.r_tab], dtype=np.int64)[T.ri]
-        genes = np.unique(np.concatenate([q_gene, r_gene]))                           # sorted: codes keep the order of the ids
-        q, r = np.searchsorted(genes, q_gene), np.searchsorted(genes, r_gene)
+        q_ids = np.array([int(x) for x in T.q_tab], dtype=np.int64)                   # the reference casts both name columns to int (PEPPAN.py:231)
+        r_ids = q_ids if T.r_tab is T.q_tab else np.array([int(x) for x in T.r_tab], dtype=np.int64)
+        genes = np.unique(np.concatenate([q_ids[np.unique(T.qi)], r_ids[np.unique(T.ri)]]))      # sorted: codes keep the order of the ids
+        q, r = np.searchsorted(genes, q_ids)[T.qi], np.searchsorted(genes, r_ids)[T.ri]
         rank = np.array([priorities[g][0] for g in genes.tolist()])
         action, forward, iden4 = _classify_rows(T, rank[q], rank[r], q, r, params['clust_identity'], params['clust_match_prop'])
         sc = N.similar_scan(q, r, action, forward, iden4, len(genes))
@@ -159,23 +159,35 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
     return pairs
 
 
+_HEADER_LINE = re.compile(rb'^>([^\n]*)', re.M)
+
+
 def _drop_dead_exemplars(fasta, alive_ids):
     """rewrite the exemplar FASTA in place, keeping the records (header line and the lines behind it, byte for byte) of genes that appeared as
-    a query and are still alive (PEPPAN.py:278-288).  The file is cut at its header lines in one pass; it is left alone when every record stays."""
+    a query and are still alive (PEPPAN.py:278-288).  The header lines are located in one pass over the file's bytes and the kept stretches
+    are written straight from that buffer; the file is left alone when every record stays."""
     with open(fasta, 'rb') as fin:
         data = fin.read()
-    parts = data.split(b'\n>')                     # a record starts at a '>' that opens a line
-    kept, dropped = [], False
-    for k, rec in enumerate(parts):
-        text = (rec if k == 0 else b'>' + rec) + (b'\n' if k + 1 < len(parts) else b'')
-        name = text[1:].split(b'\n', 1)[0].split() if text.startswith(b'>') else []
-        if name and int(name[0]) in alive_ids:
-            kept.append(text)
-        else:
-            dropped = True
-    if dropped:
-        with open(fasta, 'wb') as fout:
-            fout.write(b''.join(kept))
+    starts, keep = [], []
+    for m in _HEADER_LINE.finditer(data):
+        name = m.group(1).split()
+        starts.append(m.start())
+        keep.append(bool(name) and int(name[0]) in alive_ids)
+    if all(keep) and (not starts or starts[0] == 0):
+        return
+    starts.append(len(data))
+    view = memoryview(data)
+    with open(fasta, 'wb') as fout:
+        k, n = 0, len(keep)
+        while k < n:
+            if not keep[k]:
+                k += 1
+                continue
+            j = k
+            while j < n and keep[j]:
+                j += 1
+            fout.write(view[starts[k]:starts[j]])          # a run of kept records in one piece
+            k = j
 
 
 def _edges(cluFile, bsnFile):
