@@ -144,7 +144,10 @@ def main():
 
     def step():
         allh, allc, st = shard.search(retranslate=True, copy=False)           # views of the pinned staging area at N = 1: consumed within the step
-        labels = ctx.components_of_hits(len(nts), allh, shard.gene_of_target)   # edges (q, gene of t) straight from the table
+        if world == 1:
+            labels = ctx.components_of_search(len(nts), shard.gene_of_target)   # edges (q, gene of t) straight from the table's device copy
+        else:
+            labels = ctx.components_of_hits(len(nts), allh, shard.gene_of_target)   # the gathered table
         return st, allh, allc, labels
 
     def sync():

@@ -185,6 +185,10 @@ int pep_result_copy(const pep_result *r, pep_hit *hits, uint32_t *cigar);
  * whichever comes first: they point into the context's pinned staging area, which such calls may re-use or re-allocate
  * (use pep_result_copy for anything that must outlive that) */
 int pep_result_data(const pep_result *r, const pep_hit **hits, const uint32_t **cigar);
+/* device copy of the table (same records, same order), for callers that go on working on the GPU - an all-gather from device memory, K10:
+ * pointers into the context's workspace, valid (PEP_OK) only while r is its context's NEWEST result and nothing has reused that workspace
+ * (the next pep_search / pep_linclust does); PEP_ERR_STATE and null pointers otherwise */
+int pep_result_device(const pep_result *r, const pep_hit **d_hits, const uint32_t **d_cigar);
 int pep_result_stats(const pep_result *r, pep_stats *stats);
 void pep_result_free(pep_result *r);
 
@@ -206,6 +210,11 @@ int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint3
  * the table of the all-vs-all search (PEPPAN.py:1598-1607), without building the two edge columns on the caller's side */
 int pep_components_of_hits(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_hits, const pep_hit *hits, uint32_t q_base,
                            const uint32_t *node_of_target, uint64_t n_targets, uint32_t *label);
+
+/* the same for a search result: while r is the context's newest result its device copy is read in place (no edge columns are built or
+ * uploaded; node_of_target is uploaded only when it changed since the last call), otherwise as pep_components_of_hits */
+int pep_components_of_result(pep_ctx *ctx, const pep_result *r, uint32_t n_nodes, uint32_t q_base, const uint32_t *node_of_target, uint64_t n_targets,
+                             uint32_t *label);
 
 /* K9: linear-time clustering.  codes: residue codes (< base are valid k-mer letters), concatenated, off[n+1].
  * rep[i] = index of sequence i's representative (rep[i] == i for representatives).  stats (may be NULL):

@@ -12,7 +12,7 @@ MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequenc
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
-           'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_stats', 'pep_result_free',
+           'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
            'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve']
 
@@ -544,6 +544,19 @@ class Context(object):
             nn = node_of_target if len(node_of_target) else np.zeros(1, np.uint32)
             self._check(self._lib.pep_components_of_hits(self._h, C.c_uint32(n_nodes), C.c_uint64(len(hits)), _ptr(hh), C.c_uint32(q_base), _ptr(nn),
                                                          C.c_uint64(len(node_of_target)), _ptr(lab)), 'pep_components_of_hits')
+        return lab
+
+    def components_of_search(self, n_nodes, node_of_target, q_base=0):
+        """labels of the graph with one edge (hit.q + q_base, node_of_target[hit.t]) per hit of the NEWEST search(copy=False) on this context,
+        read from the table's device copy (pep_components_of_result)"""
+        if self._view is None:
+            raise PepError('components_of_search: no search result is held (call search(copy=False) first)')
+        node_of_target = np.ascontiguousarray(node_of_target, dtype=np.uint32)
+        lab = np.zeros(n_nodes, dtype=np.uint32)
+        if n_nodes:
+            nn = node_of_target if len(node_of_target) else np.zeros(1, np.uint32)
+            self._check(self._lib.pep_components_of_result(self._h, self._view, C.c_uint32(n_nodes), C.c_uint32(q_base), _ptr(nn), C.c_uint64(len(node_of_target)),
+                                                           _ptr(lab)), 'pep_components_of_result')
         return lab
 
     def components(self, n_nodes, a, b):

@@ -74,6 +74,16 @@ void pep_timers_resolve(pep_ctx *ctx)
     ctx->stats.ms_seed_match = match[0] + match[1] + match[2] + match[3];
 }
 
+int pep_zero_block(pep_ctx *ctx, int which, size_t offset, size_t bytes, void **out)
+{
+    PEP_TRY(dev_reserve(ctx, ctx->d_zero, PEP_ZERO_TOTAL));
+    char *p = ctx->d_zero.as<char>() + offset;
+    if (!ctx->zero_ok[which]) PEP_HIP(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
+    ctx->zero_ok[which] = false;
+    *out = p;
+    return PEP_OK;
+}
+
 int pep_read_back(pep_ctx *ctx, void *dst, const void *d_src, size_t n)
 {
     const size_t n8 = (n + 7) & ~size_t(7);
@@ -120,6 +130,14 @@ int pep_sync_reads(pep_ctx *ctx)
     return PEP_OK;
 }
 
+// the device copy of a result's table is about to be overwritten (or its context to go away)
+void pep_drop_dev_result(pep_ctx *ctx)
+{
+    pep_result *r = ctx->dev_result;
+    ctx->dev_result = nullptr;
+    if (r && ctx->staged_result != r) r->ctx = nullptr;      // nothing ties it to the context any more
+}
+
 // the hit table of the newest search lives in the context's pinned staging area until it is copied out; before that area is
 // reused (next search, K1) a result that is still alive takes its own copy
 void pep_materialise_staged(pep_ctx *ctx)
@@ -129,7 +147,7 @@ void pep_materialise_staged(pep_ctx *ctx)
     r->hits.assign(r->st_hits, r->st_hits + r->n_hits);
     r->cigar.assign(r->st_cigar, r->st_cigar + r->n_cigar);
     r->st_hits = nullptr; r->st_cigar = nullptr;
-    r->ctx = nullptr;                    // a result that owns its table needs the context no more (it may outlive it: pep_result_free after pep_ctx_destroy)
+    if (ctx->dev_result != r) r->ctx = nullptr;      // a result that owns its table and has no device copy needs the context no more (it may outlive it)
     ctx->staged_result = nullptr;
 }
 
@@ -374,6 +392,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     for (auto &b : ctx->ws) dev_release(b);
     for (int id = 0; id < TM_COUNT; ++id) { if (ctx->tm_a[id]) (void)hipEventDestroy(ctx->tm_a[id]); if (ctx->tm_b[id]) (void)hipEventDestroy(ctx->tm_b[id]); }
+    pep_drop_dev_result(ctx);
     if (ctx->staged_result) {
         // the result outlives the context (freeing it afterwards is allowed): it takes its own copy and forgets the context
         pep_materialise_staged(ctx);
@@ -389,7 +408,8 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
     if (ctx->pin_ms.p) (void)hipHostFree(ctx->pin_ms.p);
     DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
-                      &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq};
+                      &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq,
+                      &ctx->sort_state, &ctx->sort_hist, &ctx->d_set, &ctx->d_zero};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -634,8 +654,9 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     if (rc != PEP_OK) { delete res; return rc; }
     pep_timers_resolve(ctx);
     res->stats = ctx->stats;
+    ctx->dev_result = res->d_hits ? res : nullptr;
     if (res->st_hits || res->st_cigar) ctx->staged_result = res;
-    else res->ctx = nullptr;             // owns its (possibly empty) table from the start: nothing ties it to the context
+    else if (!res->d_hits) res->ctx = nullptr;             // owns its (possibly empty) table from the start: nothing ties it to the context
     *out = res;
     return PEP_OK;
 }
@@ -676,7 +697,27 @@ int pep_result_stats(const pep_result *r, pep_stats *stats)
 void pep_result_free(pep_result *r)
 {
     if (r && r->ctx && r->ctx->staged_result == r) r->ctx->staged_result = nullptr;
+    if (r && r->ctx && r->ctx->dev_result == r) r->ctx->dev_result = nullptr;
     delete r;
+}
+
+int pep_result_device(const pep_result *r, const pep_hit **d_hits, const uint32_t **d_cigar)
+{
+    if (!r) return PEP_ERR_ARG;
+    const bool live = r->ctx && r->ctx->dev_result == r;
+    if (d_hits) *d_hits = live ? r->d_hits : nullptr;
+    if (d_cigar) *d_cigar = live ? r->d_cigar : nullptr;
+    return live ? PEP_OK : PEP_ERR_STATE;
+}
+
+int pep_components_of_result(pep_ctx *ctx, const pep_result *r, uint32_t n_nodes, uint32_t q_base, const uint32_t *node_of_target, uint64_t n_targets, uint32_t *label)
+{
+    if (!ctx || !r || (n_nodes && !label) || (n_targets && !node_of_target)) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    if (r->ctx == ctx && ctx->dev_result == r && n_targets >= ctx->t.n)
+        return pep_k10_components_dev(ctx, n_nodes, r->n_hits, r->d_hits, q_base, node_of_target, n_targets, label);
+    const pep_hit *h = r->st_hits ? r->st_hits : r->hits.data();
+    return pep_components_of_hits(ctx, n_nodes, r->n_hits, h, q_base, node_of_target, n_targets, label);
 }
 
 int pep_merge_hits(uint64_t n, const pep_hit *hits, const uint32_t *cigar, uint64_t n_cigar, int32_t top_k, int32_t n_splits,

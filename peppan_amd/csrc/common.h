@@ -122,6 +122,15 @@ struct pep_ctx {
     uint64_t trace_swept = 0;               // pairs the last traceback pass swept (the rest were settled by the gapless shortcut)
     struct ScanState { DevBuf buf; uint32_t epoch = 0, ticket_base = 0; };
     ScanState scan_state[2];                // single-launch scans (u32, u64): ticket counter + one status word per tile (scan.hip)
+    DevBuf sort_state, sort_hist;           // one-launch-per-pass radix sort (sort.hip): ticket + status words per (tile, digit); its own histograms
+    uint32_t sort_epoch = 0, sort_ticket_base = 0;
+    DevBuf d_set;                           // candidate hash set of the seed stage (seeds.hip); set_compact leaves every slot it read EMPTY again
+    uint64_t set_clean_slots = 0;           // leading slots of d_set known to be EMPTY (0 while a search is using it)
+    DevBuf uf_nodes;                        // K10 over a device-resident hit table: node of every target (uploaded when it changes)
+    std::vector<uint32_t> uf_nodes_host;
+    pep_result *dev_result = nullptr;       // the result whose hit table is still intact on the device (ws[23]): the newest search's, until the workspace is reused
+    DevBuf d_zero;                          // the small counters of one search, cleared by ONE fill when it starts (layout: PEP_ZERO_* below)
+    bool zero_ok[4] = {false, false, false, false};     // which consumer regions of d_zero are still untouched since that fill (PEP_ZC_*)
     // stats of the last search
     pep_stats stats;
 };
@@ -133,6 +142,8 @@ struct pep_result {
     const pep_hit *st_hits = nullptr;       // while staged: views into ctx->pin_stage
     const uint32_t *st_cigar = nullptr;
     uint64_t n_hits = 0, n_cigar = 0;
+    const pep_hit *d_hits = nullptr;        // device copy (context workspace), valid while ctx->dev_result == this
+    const uint32_t *d_cigar = nullptr;
     pep_stats stats;
 };
 
@@ -181,14 +192,34 @@ hipError_t pep_stream_wait(pep_ctx *ctx);
 hipError_t pep_event_wait(hipEvent_t ev);
 int pin_reserve(pep_ctx *ctx, PinBuf &b, size_t bytes);
 void pep_materialise_staged(pep_ctx *ctx);
+void pep_drop_dev_result(pep_ctx *ctx);
 int dev_reserve(pep_ctx *ctx, DevBuf &b, size_t bytes);
 void dev_release(DevBuf &b);
+
+// Layout of pep_ctx::d_zero: every small counter block a search needs starts from zero, and one fill at the start of the search clears
+// them all (each used to be a fill of its own in front of its kernel: eleven tiny launches per search).  A stage that runs without the
+// seed stage in front (K9 drives the alignment stage alone) finds its flag in zero_ok unset and clears its own block.
+#define PEP_ZERO_SEED 0                                         // 64 B: list length, overflow flags, statistics (seeds.hip)
+#define PEP_ZERO_SHAPE (PEP_ZERO_SEED + 64)                     // 4 x 16 B: raw-hit and run counters per seed shape
+#define PEP_ZERO_COARSE (PEP_ZERO_SHAPE + 64)                   // 4 x 8192 x 4 B: coarse-bucket counts of the query index per seed shape
+#define PEP_ZERO_SORT (PEP_ZERO_COARSE + 4 * 8192 * 4)          // 8 x 2048 x 4 B: digit histograms of the candidate sort
+#define PEP_ZERO_SW_BYTES (64 + 2 * 1024 * 4)                   // totals + length histogram + scatter cursors of one Smith-Waterman pass (sw.hip)
+#define PEP_ZERO_SW_SCORE (PEP_ZERO_SORT + 8 * 2048 * 4)
+#define PEP_ZERO_SW_TRACE (PEP_ZERO_SW_SCORE + PEP_ZERO_SW_BYTES)
+#define PEP_ZERO_SELECT (PEP_ZERO_SW_TRACE + PEP_ZERO_SW_BYTES)  // 256 B: counters of the selection stage (trace.hip)
+#define PEP_ZERO_TOTAL (PEP_ZERO_SELECT + 256)
+enum { PEP_ZC_SW_SCORE = 0, PEP_ZC_SW_TRACE, PEP_ZC_SELECT, PEP_ZC_SORT };
+// the block of consumer `which` (PEP_ZC_*), zeroed: taken from the search's one fill when it is still untouched, cleared here otherwise
+int pep_zero_block(pep_ctx *ctx, int which, size_t offset, size_t bytes, void **out);
 
 // ---- scan.hip
 int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp);   // exclusive; d_out[n] = total (n+1 outputs)
 int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp);
 // ---- sort.hip
-int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, int bits, DevBuf &hist);   // result in d_keys
+// the dense candidate-key form q | t | bin - bin_min (tb / bb bits for t / bin) <-> q:21 | t:25 | bin:18 (seeds.hip); on = 0: keys pass unchanged
+struct pep_key_unpack { int on, tb, bb; uint32_t bin_min; };
+int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, const uint32_t *d_n, uint64_t n_bound, int bits, uint32_t *d_hist_zeroed,
+                 const pep_key_unpack *unpack);   // result in d_keys
 // ---- translate.hip  (K1)
 int pep_k1_query(pep_ctx *ctx, int gtable, int phase = 0);
 int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase = 0);
@@ -204,6 +235,8 @@ int pep_selftest_dpp(pep_ctx *ctx);
 int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uint32_t *h_cigar, uint64_t n_cigar, int64_t *h_out);
 // ---- unionfind.hip (K10)
 int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *h_a, const uint32_t *h_b, uint32_t *h_label);
+int pep_k10_components_dev(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_hits, const pep_hit *d_hits, uint32_t q_base, const uint32_t *h_node_of_target,
+                           uint64_t n_targets, uint32_t *h_label);
 
 // ---- overlaps.hip (K11)
 int pep_k11_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *h_contig, const int64_t *h_start, const int64_t *h_end, const int64_t *h_rid,

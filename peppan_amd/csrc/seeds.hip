@@ -599,8 +599,11 @@ __global__ __launch_bounds__(256) void seed_extend(JoinArgs a, const uint64_t *_
 // hash set -> dense list (arbitrary order; sorted afterwards).  One global atomic per block and per COMPACT_ROUNDS x 256 slots:
 // the single counter word sustains ~90 atomics/us, so 4096 blocks with one atomic each spent 45 us waiting for it.
 constexpr int COMPACT_ROUNDS = 16;
-__global__ __launch_bounds__(256) void set_compact(const uint64_t *__restrict__ table, uint64_t cap, uint64_t *__restrict__ list, uint32_t list_cap,
-                                                   uint32_t *__restrict__ counters)
+// The keys leave in the dense form q | t | bin - bin_min (only as many bits per field as this search needs: the radix sort then runs over
+// ~36 instead of 64 bits; its last pass restores q:21 | t:25 | bin:18), and every slot that held a key is EMPTY again afterwards: the
+// next search finds the set clean instead of filling 8 MB in front of its first kernel.
+__global__ __launch_bounds__(256) void set_compact(uint64_t *__restrict__ table, uint64_t cap, uint64_t *__restrict__ list, uint32_t list_cap,
+                                                   uint32_t *__restrict__ counters, int tb, int bb, uint32_t bin_min)
 {
     __shared__ uint32_t wave_cnt[4], blk_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256) void set_compact(const uint64_t *__restrict__ 
     for (int r = 0; r < COMPACT_ROUNDS; ++r) {
         const uint64_t i = ((uint64_t)blockIdx.x * COMPACT_ROUNDS + r) * 256 + threadIdx.x;
         k[r] = i < cap ? table[i] : EMPTY;
-        mine += k[r] != EMPTY ? 1u : 0u;
+        if (k[r] != EMPTY) { ++mine; table[i] = EMPTY; }
     }
     // exclusive prefix of `mine` over the block
     uint32_t incl = mine;
@@ -626,26 +629,11 @@ __global__ __launch_bounds__(256) void set_compact(const uint64_t *__restrict__ 
     for (int w = 0; w < wave; ++w) idx += wave_cnt[w];
 #pragma unroll
     for (int r = 0; r < COMPACT_ROUNDS; ++r)
-        if (k[r] != EMPTY) { if (idx < list_cap) list[idx] = k[r]; else counters[1] = 1u; ++idx; }
-}
-
-// candidate keys q:21 | t:25 | bin:18 <-> the dense form q | t | bin - bin_min with only as many bits per field as this search
-// needs: the radix sort then runs over ~36 instead of 64 bits (each of its 8-bit passes is five small launches)
-__global__ __launch_bounds__(256) void keys_pack(uint64_t *__restrict__ keys, const uint32_t *__restrict__ n_ptr, int tb, int bb, uint32_t bin_min)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= *n_ptr) return;
-    const uint64_t k = keys[i];
-    const uint64_t q = k >> 43, t = (k >> 18) & ((1u << 25) - 1), bin = (k & ((1u << 18) - 1)) - bin_min;
-    keys[i] = (q << (tb + bb)) | (t << bb) | bin;
-}
-__global__ __launch_bounds__(256) void keys_unpack(uint64_t *__restrict__ keys, uint64_t n, int tb, int bb, uint32_t bin_min)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = keys[i];
-    const uint64_t q = k >> (tb + bb), t = (k >> bb) & ((1ull << tb) - 1), bin = (k & ((1ull << bb) - 1)) + bin_min;
-    keys[i] = (q << 43) | (t << 18) | bin;
+        if (k[r] != EMPTY) {
+            const uint64_t q = k[r] >> 43, t = (k[r] >> 18) & ((1u << 25) - 1), bin = (k[r] & ((1u << 18) - 1)) - bin_min;
+            if (idx < list_cap) list[idx] = (q << (tb + bb)) | (t << bb) | bin; else counters[1] = 1u;
+            ++idx;
+        }
 }
 
 int ilog2_ceil(uint64_t x)
@@ -694,19 +682,20 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     PEP_TRY(dev_reserve(ctx, ctx->ws[0], (n_buckets + 1) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_buckets + 2) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[2], (Q.total + 1) * sizeof(uint64_t)));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[6], 64));
+    PEP_TRY(dev_reserve(ctx, ctx->d_zero, PEP_ZERO_TOTAL));
     PEP_TRY(dev_reserve(ctx, ctx->ws[9], ((n_buckets >> FILTER_SHIFT) + 2) * 8));
     unsigned long long *filter = ctx->ws[9].as<unsigned long long>();
     uint32_t *cnt = ctx->ws[0].as<uint32_t>(), *start = ctx->ws[1].as<uint32_t>();
     uint64_t *entries = ctx->ws[2].as<uint64_t>();
-    uint32_t *counters = ctx->ws[6].as<uint32_t>();
+    char *zero = ctx->d_zero.as<char>();
+    uint32_t *counters = reinterpret_cast<uint32_t *>(zero + PEP_ZERO_SEED);
     unsigned long long *stats = reinterpret_cast<unsigned long long *>(counters + 4);
     PEP_TRY(pep_upload_sub_table(ctx));
 
     // candidate set: start near 64 slots per query (chance hits grow with |Q| x |T|), grow x4 on overflow
     int table_bits = std::max(20, std::min(28, ilog2_ceil(64ull * Q.n)));
     uint64_t hit_cap = std::max<uint64_t>(1ull << 22, 2 * T.total);
-    unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(counters + 12);
+    if (P.n_shapes > 4) return pep_fail(ctx, PEP_ERR_ARG, "more than 4 seed shapes");
     // query index build: by partition when the bucket count splits into <= 2^13 coarse x <= 2^12 fine buckets (reserved[2] != 0 forces the
     // count -> scan -> fill build, as does a coarse bucket that overflows LDS)
     const int fine_bits = std::min(12, bucket_bits - 8);
@@ -718,14 +707,19 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         PEP_TRY(dev_reserve(ctx, ctx->ws[12], hit_cap * 4 + 64));
         uint64_t *run_first = ctx->ws[10].as<uint64_t>(), *run_key = ctx->ws[11].as<uint64_t>();
         uint32_t *run_len = ctx->ws[12].as<uint32_t>();
-        unsigned long long *n_runs = reinterpret_cast<unsigned long long *>(counters + 14);
         const uint64_t cap = 1ull << table_bits;
         const uint32_t list_cap = (uint32_t)(cap >> 1);
-        PEP_TRY(dev_reserve(ctx, ctx->ws[3], cap * sizeof(uint64_t)));
+        // the candidate set lives in a buffer of its own: set_compact hands every slot back EMPTY, so only a new (or larger, or abandoned)
+        // table is filled here
+        if (cap * sizeof(uint64_t) > ctx->d_set.cap) ctx->set_clean_slots = 0;
+        PEP_TRY(dev_reserve(ctx, ctx->d_set, cap * sizeof(uint64_t)));
+        if (ctx->set_clean_slots < cap) PEP_HIP(ctx, hipMemsetAsync(ctx->d_set.p, 0xFF, cap * sizeof(uint64_t), ctx->stream));
+        ctx->set_clean_slots = 0;                               // in use until set_compact below has been queued
         PEP_TRY(dev_reserve(ctx, ctx->ws[4], (uint64_t)list_cap * sizeof(uint64_t)));
         PEP_TRY(dev_reserve(ctx, ctx->ws[5], (uint64_t)list_cap * sizeof(uint64_t)));
-        PEP_HIP(ctx, hipMemsetAsync(ctx->ws[3].p, 0xFF, cap * sizeof(uint64_t), ctx->stream));
-        PEP_HIP(ctx, hipMemsetAsync(counters, 0, 64, ctx->stream));
+        // ONE fill for every small counter block of the search (seed stage, candidate sort, both Smith-Waterman passes, selection)
+        PEP_HIP(ctx, hipMemsetAsync(zero, 0, PEP_ZERO_TOTAL, ctx->stream));
+        for (bool &f : ctx->zero_ok) f = true;
         uint64_t q_seeds = 0;
         uint32_t h_nseed[4] = {0, 0, 0, 0};
         for (int s = 0; s < P.n_shapes; ++s) {
@@ -766,9 +760,9 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
                 const size_t lds = (size_t)n_coarse * 4 + TILE + TILE_HALO;
                 PEP_TRY(dev_reserve(ctx, ctx->ws[13], (uint64_t)n_coarse * PART_CAP * sizeof(uint64_t)));
                 uint64_t *part = ctx->ws[13].as<uint64_t>();
-                PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (size_t)n_coarse * sizeof(uint32_t), ctx->stream));
-                PEP_SEED_DISPATCH_LDS(idx_slab, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, cnt, part, tiles, counters);
-                hipLaunchKernelGGL(idx_finish, dim3(n_coarse), dim3(256), 0, ctx->stream, (const uint64_t *)part, (const uint32_t *)cnt, bucket_bits, fine_bits,
+                uint32_t *coarse = reinterpret_cast<uint32_t *>(zero + PEP_ZERO_COARSE) + (size_t)s * 8192;       // (cleared by the search's one fill)
+                PEP_SEED_DISPATCH_LDS(idx_slab, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, coarse, part, tiles, counters);
+                hipLaunchKernelGGL(idx_finish, dim3(n_coarse), dim3(256), 0, ctx->stream, (const uint64_t *)part, (const uint32_t *)coarse, bucket_bits, fine_bits,
                                    start, entries, filter, counters);
             } else {
                 PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
@@ -782,12 +776,12 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             JoinArgs a;
             a.t_res = T.res.as<const uint8_t>(); a.t_total = T.total; a.t_off = T.off.as<const uint32_t>(); a.nt = T.n;
             a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint32_t>(); a.t_blk2seq = T.blk2seq.as<const uint32_t>(); a.start = start; a.entries = entries; a.filter = filter; a.bucket_bits = bucket_bits;
-            a.table = ctx->ws[3].as<uint64_t>(); a.table_bits = table_bits;
+            a.table = ctx->d_set.as<uint64_t>(); a.table_bits = table_bits;
             a.counters = counters; a.stats = stats;
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
             a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.stage1_min = P.stage1_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
+            unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(zero + PEP_ZERO_SHAPE) + 2 * s, *n_runs = hit_count + 1;      // per shape, cleared by the one fill
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
-            PEP_HIP(ctx, hipMemsetAsync(hit_count, 0, 16, ctx->stream));        // hit_count and n_runs (counters[12..15]) in one fill
             pep_timer_begin(ctx, TM_MATCH0 + s);
             PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 8u)), sh, a);
             pep_timer_end(ctx, TM_MATCH0 + s);
@@ -801,8 +795,9 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         const uint32_t bin_min = (uint32_t)(((1 << 23) - (int)std::max<uint32_t>(Q.max_len, 1u) + 1) >> 6);
         const uint32_t bin_max = (uint32_t)(((1 << 23) + (int)std::max<uint32_t>(T.max_len, 1u) - 1) >> 6);
         const int tb = std::max(1, ilog2_ceil(T.n)), qb = std::max(1, ilog2_ceil(Q.n)), bb = std::max(1, ilog2_ceil((uint64_t)bin_max - bin_min + 1));
-        hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256 * COMPACT_ROUNDS)), dim3(256), 0, ctx->stream, (const uint64_t *)ctx->ws[3].as<uint64_t>(), cap,
-                           ctx->ws[4].as<uint64_t>(), list_cap, counters);
+        hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256 * COMPACT_ROUNDS)), dim3(256), 0, ctx->stream, ctx->d_set.as<uint64_t>(), cap,
+                           ctx->ws[4].as<uint64_t>(), list_cap, counters, tb, bb, bin_min);
+        ctx->set_clean_slots = cap;
         struct { uint32_t counters[4]; unsigned long long stats[3]; } h_all;        // counters[0..3] and the three statistics words behind them: one copy
         static_assert(sizeof(h_all) == 40, "layout of the counter block");
         PEP_TRY(pep_read_back(ctx, &h_all, counters, sizeof(h_all)));
@@ -819,9 +814,11 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         ctx->stats.seed_hits_passed = h_stats[2];
         const uint64_t n = h_counters[0];
         if (n) {
-            hipLaunchKernelGGL(keys_pack, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[4].as<uint64_t>(), (const uint32_t *)counters, tb, bb, bin_min);
-            PEP_TRY(pep_sort_u64(ctx, ctx->ws[4].as<uint64_t>(), ctx->ws[5].as<uint64_t>(), n, qb + tb + bb, ctx->ws[0]));
-            hipLaunchKernelGGL(keys_unpack, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[4].as<uint64_t>(), n, tb, bb, bin_min);
+            pep_key_unpack up;
+            up.on = 1; up.tb = tb; up.bb = bb; up.bin_min = bin_min;
+            void *sort_hist = nullptr;
+            PEP_TRY(pep_zero_block(ctx, PEP_ZC_SORT, PEP_ZERO_SORT, 8 * 2048 * 4, &sort_hist));
+            PEP_TRY(pep_sort_u64(ctx, ctx->ws[4].as<uint64_t>(), ctx->ws[5].as<uint64_t>(), nullptr, n, qb + tb + bb, reinterpret_cast<uint32_t *>(sort_hist), &up));
         }
         *d_cands = ctx->ws[4].as<uint64_t>();
         *n_cands = n;

@@ -786,13 +786,16 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
         nb_limit = entries > SUB_LANES + 16 + 8 ? (uint32_t)((entries - SUB_LANES - 16) / 8 - 1) : 0;     // (the sub-band may need one block more than the band)
         nb_limit = std::min<uint32_t>(nb_limit, LEN_BUCKETS - 2);
     }
-    // ws[15]: [0..63] totals (cells, 16-step blocks, work-queue counters, candidates above nb_limit), [64..) length histogram, then the
-    // scatter cursors, then the order itself
+    // counter block of this pass (d_zero): [0..63] totals (cells, 16-step blocks, work-queue counters, candidates above nb_limit, candidates in
+    // the order), [64..) length histogram, then the scatter cursors; ws[15]: the order itself
     const size_t hist_bytes = LEN_BUCKETS * sizeof(uint32_t);
-    PEP_TRY(dev_reserve(ctx, ctx->ws[15], 64 + 2 * hist_bytes + (n + 1) * sizeof(uint32_t)));
-    unsigned long long *cells = ctx->ws[15].as<unsigned long long>();
-    uint32_t *len_hist = reinterpret_cast<uint32_t *>(ctx->ws[15].as<unsigned char>() + 64), *cursor = len_hist + LEN_BUCKETS, *order = cursor + LEN_BUCKETS;
-    PEP_HIP(ctx, hipMemsetAsync(cells, 0, 64 + 2 * hist_bytes, ctx->stream));
+    static_assert(PEP_ZERO_SW_BYTES == 64 + 2 * LEN_BUCKETS * sizeof(uint32_t), "counter block of a Smith-Waterman pass");
+    void *zb = nullptr;
+    PEP_TRY(pep_zero_block(ctx, trace ? PEP_ZC_SW_TRACE : PEP_ZC_SW_SCORE, trace ? PEP_ZERO_SW_TRACE : PEP_ZERO_SW_SCORE, PEP_ZERO_SW_BYTES, &zb));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[15], (n + 1) * sizeof(uint32_t)));
+    unsigned long long *cells = reinterpret_cast<unsigned long long *>(zb);
+    uint32_t *len_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(zb) + 64), *cursor = len_hist + LEN_BUCKETS, *order = ctx->ws[15].as<uint32_t>();
+    (void)hist_bytes;
     hipLaunchKernelGGL(sw_prep, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_cands, n, ctx->q.len.as<const uint32_t>(),
                        ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist, nb_limit, trace ? d_skip_mode : nullptr);
     hipLaunchKernelGGL(sw_order, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[10].as<const uint32_t>(), n,

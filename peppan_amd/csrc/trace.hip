@@ -409,6 +409,7 @@ __global__ __launch_bounds__(256) void emit(uint64_t n_sel, const SelInfo *__res
 int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t *h_min_score, pep_result *res)
 {
     const pep_search_params &P = ctx->params;
+    pep_drop_dev_result(ctx);                     // ws[23] is about to be rewritten
     res->hits.clear();
     res->cigar.clear();
     ctx->stats.candidates = n;
@@ -432,10 +433,10 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     PEP_TRY(dev_reserve(ctx, ctx->ws[16], (n + 1) * 4));
     PEP_TRY(dev_reserve(ctx, ctx->ws[17], (n + 2) * 4));
     PEP_TRY(dev_reserve(ctx, ctx->ws[18], (n + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[9], 256));
     uint32_t *flag = ctx->ws[16].as<uint32_t>(), *pos = ctx->ws[17].as<uint32_t>(), *best_idx = ctx->ws[18].as<uint32_t>();
-    uint32_t *counters = ctx->ws[9].as<uint32_t>();
-    PEP_HIP(ctx, hipMemsetAsync(counters, 0, 256, st));
+    void *zb = nullptr;
+    PEP_TRY(pep_zero_block(ctx, PEP_ZC_SELECT, PEP_ZERO_SELECT, 256, &zb));
+    uint32_t *counters = reinterpret_cast<uint32_t *>(zb);
     const unsigned gb = (unsigned)ceil_div(n, 256);
     hipLaunchKernelGGL(select_best, dim3(gb), dim3(256), 0, st, d_cands, n, sw, dms.as<const int32_t>(), flag, best_idx, counters, P.hsp_mode);
     PEP_TRY(pep_scan_u32(ctx, flag, pos, n, ctx->ws[7]));
@@ -523,6 +524,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
                 if (n_cig) PEP_HIP(ctx, hipMemcpyAsync(res->cigar.data(), d_cig, n_cig * 4, hipMemcpyDeviceToHost, st));
             }
             res->n_hits = n_hits; res->n_cigar = n_cig;
+            res->d_hits = d_hits; res->d_cigar = d_cig;
         }
     }
     pep_timer_end(ctx, TM_TRACE);

@@ -4,6 +4,7 @@
 // its smallest node id whatever the execution order; a second kernel flattens.  HBM-bound: 8 B per edge read,
 // 4 B per node written; parent look-ups are random 4-byte reads.
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -36,6 +37,21 @@ __global__ __launch_bounds__(256) void uf_union(uint32_t *parent, const uint32_t
     }
 }
 
+// the same over the edges of a hit table that is still on the device: (hit.q + q_base, node_of_target[hit.t])
+__global__ __launch_bounds__(256) void uf_union_hits(uint32_t *parent, const pep_hit *__restrict__ hits, uint64_t m, uint32_t q_base, const uint32_t *__restrict__ node_of_target)
+{
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= m) return;
+    uint32_t x = hits[e].q + q_base, y = node_of_target[hits[e].t];
+    for (;;) {
+        x = uf_root(parent, x);
+        y = uf_root(parent, y);
+        if (x == y) return;
+        if (x < y) { const uint32_t t = x; x = y; y = t; }
+        if (atomicCAS(&parent[x], x, y) == x) return;
+    }
+}
+
 __global__ __launch_bounds__(256) void uf_flatten(uint32_t *parent, uint32_t *__restrict__ label, uint32_t n)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -61,6 +77,31 @@ int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const u
         hipLaunchKernelGGL(uf_union, dim3((unsigned)ceil_div(n_edges, 256)), dim3(256), 0, ctx->stream, parent, ctx->ws[2].as<const uint32_t>(),
                            ctx->ws[3].as<const uint32_t>(), n_edges);
     }
+    hipLaunchKernelGGL(uf_flatten, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, label, n_nodes);
+    PEP_HIP(ctx, hipGetLastError());
+    PEP_HIP(ctx, hipMemcpyAsync(h_label, label, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PEP_HIP(ctx, pep_stream_wait(ctx));
+    return PEP_OK;
+}
+
+// K10 straight from the device copy of the newest search's hit table (d_hits: ws[23], still intact) - no edge columns built or uploaded.
+// The node map is uploaded only when it differs from the one the context already holds.
+int pep_k10_components_dev(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_hits, const pep_hit *d_hits, uint32_t q_base, const uint32_t *h_node_of_target,
+                           uint64_t n_targets, uint32_t *h_label)
+{
+    if (n_nodes == 0) return PEP_OK;
+    if (ctx->uf_nodes_host.size() != n_targets || (n_targets && memcmp(ctx->uf_nodes_host.data(), h_node_of_target, n_targets * 4) != 0)) {
+        for (uint64_t t = 0; t < n_targets; ++t)
+            if (h_node_of_target[t] >= n_nodes) return pep_fail(ctx, PEP_ERR_ARG, "pep_components_of_result: node of a target out of range");
+        ctx->uf_nodes_host.assign(h_node_of_target, h_node_of_target + n_targets);
+        PEP_TRY(dev_reserve(ctx, ctx->uf_nodes, (n_targets + 1) * 4));
+        if (n_targets) PEP_HIP(ctx, hipMemcpyAsync(ctx->uf_nodes.p, ctx->uf_nodes_host.data(), n_targets * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    PEP_TRY(dev_reserve(ctx, ctx->ws[0], (size_t)n_nodes * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[1], (size_t)n_nodes * 4));
+    uint32_t *parent = ctx->ws[0].as<uint32_t>(), *label = ctx->ws[1].as<uint32_t>();
+    hipLaunchKernelGGL(uf_init, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, n_nodes);
+    if (n_hits) hipLaunchKernelGGL(uf_union_hits, dim3((unsigned)ceil_div(n_hits, 256)), dim3(256), 0, ctx->stream, parent, d_hits, n_hits, q_base, ctx->uf_nodes.as<const uint32_t>());
     hipLaunchKernelGGL(uf_flatten, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, label, n_nodes);
     PEP_HIP(ctx, hipGetLastError());
     PEP_HIP(ctx, hipMemcpyAsync(h_label, label, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -551,6 +551,12 @@ def test_full_size_10k_properties(ctx):
     lab = ctx.components(10000, h1['q'], genes_t)
     assert np.array_equal(ctx.components_of_hits(10000, h1, tm['seq']), lab)          # the same graph straight from the hit table
     assert np.array_equal(ctx.components_of_hits(10004, h1, tm['seq'] + 4, q_base=4)[4:], lab + 4)
+    # ... and from the table's DEVICE copy (pep_components_of_result): the newest search's, held through search(copy=False)
+    h3, c3, s3 = ctx.search(p, copy=False)
+    assert np.array_equal(np.array(h3), h1)
+    assert np.array_equal(ctx.components_of_search(10000, tm['seq']), lab)
+    assert np.array_equal(ctx.components_of_search(10004, tm['seq'] + 4, q_base=4)[4:], lab + 4)
+    assert np.array_equal(ctx.components_of_search(10000, tm['seq']), lab)              # (node map changed back: uploaded again)
     assert np.array_equal(lab[lab], lab) and (lab <= np.arange(10000)).all()
     assert np.array_equal(ctx.components(10000, np.arange(10000), lab), lab)
     assert (lab // 4 == np.arange(10000) // 4).all()
