@@ -169,8 +169,7 @@ int sort_passes(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, const uint32_t 
     }
     HistArgs ha;
     ha.passes = 0;
-    for (int p = 0; p < passes; ++p)
-        if (p * DB < bits && p * DB < 64) ha.shift[ha.passes++] = p * DB;
+    for (int p = 0; p < passes; ++p) ha.shift[ha.passes++] = p * DB;        // (a pass beyond the key width sees digit 0 everywhere: a stable copy)
     hipLaunchKernelGGL(sort_hist_all<DB>, dim3(std::min<uint32_t>(nb, 1024u)), dim3(ST), (size_t)ha.passes * R * 4, ctx->stream, (const uint64_t *)d_keys, d_n, n_bound, hist, ha);
     uint64_t *src = d_keys, *dst = d_tmp;
     int real = 0;
@@ -179,10 +178,7 @@ int sort_passes(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, const uint32_t 
     for (int p = 0; p < passes; ++p) {
         const int shift = p * DB;
         const bool last = p == passes - 1;
-        if (shift >= bits || shift >= 64) {  // padding pass beyond the key width (keeps the pass count even): plain copy
-            if (last && unpack && unpack->on) return pep_fail(ctx, PEP_ERR_INTERNAL, "pep_sort_u64: the pass that unpacks the keys must be a real one");
-            PEP_HIP(ctx, hipMemcpyAsync(dst, src, n_bound * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
-        } else {
+        {
             ctx->sort_epoch = (ctx->sort_epoch + 1) & ((1u << 29) - 1);
             if (ctx->sort_epoch == 0) { clear = true; ctx->sort_epoch = 1; }          // wrapped: forget every old word
             if (clear) { PEP_HIP(ctx, hipMemsetAsync(S.p, 0, S.cap, ctx->stream)); ctx->sort_ticket_base = 0; clear = false; }
@@ -212,6 +208,7 @@ int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, const uint32_t
     while ((bits + passes - 1) / passes > MAX_DIGIT_BITS) passes += 2;
     if (passes > MAX_PASSES) return pep_fail(ctx, PEP_ERR_INTERNAL, "pep_sort_u64: too many passes");
     const int db = std::max(8, (bits + passes - 1) / passes);
+    if ((passes - 1) * db >= 64) return pep_fail(ctx, PEP_ERR_INTERNAL, "pep_sort_u64: pass beyond 64 bits");
     switch (db) {
         case 8: return sort_passes<8>(ctx, d_keys, d_tmp, d_n, n_bound, bits, passes, d_hist_zeroed, unpack);
         case 9: return sort_passes<9>(ctx, d_keys, d_tmp, d_n, n_bound, bits, passes, d_hist_zeroed, unpack);
