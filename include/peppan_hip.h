@@ -176,6 +176,10 @@ int pep_get_target_aa(pep_ctx *ctx, uint8_t *codes, uint64_t cap, uint64_t *off)
  * reference sequences are set; a new pep_set_ref_* clears it. */
 int pep_set_target_groups(pep_ctx *ctx, const uint32_t *group, uint32_t n);
 
+/* on_device != 0: the searches of this context leave their hit table on the device (pep_result_device) and skip the copy to the host at
+ * the end of pep_search; pep_result_copy / pep_result_data then fetch it on demand, while the result is still the context's newest
+ * (PEP_ERR_STATE afterwards).  For callers that go on working on the GPU: the all-gather of a multi-GPU search, K10. */
+int pep_set_result_mode(pep_ctx *ctx, int on_device);
 /* K2..K8: seeds, candidates, banded Smith-Waterman, traceback, filters, top-k.  Hits ordered by (q, t). */
 int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out);
 int pep_result_size(const pep_result *r, uint64_t *n_hits, uint64_t *n_cigar);

@@ -12,7 +12,7 @@ MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequenc
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
-           'pep_get_target_aa', 'pep_set_target_groups', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
+           'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
            'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve']
 
@@ -436,6 +436,37 @@ class Context(object):
             if r is not None:
                 self._lib.pep_result_free(r)
         return hits, cig, {n: getattr(st, n) for n, _ in Stats._fields_}
+
+    def search_on_device(self, params=None):
+        """the search with its hit table LEFT ON THE DEVICE: -> (n_hits, n_cigar, stats dict, (address of the hit records, address of the
+        CIGAR arena)).  The addresses point into the context's workspace and stay valid until the next search / linclust on this context;
+        result_to_host() fetches the table afterwards if somebody wants it after all."""
+        if self._view is not None:
+            self._lib.pep_result_free(self._view)
+            self._view = None
+        self._check(self._lib.pep_set_result_mode(self._h, C.c_int(1)), 'pep_set_result_mode')
+        r = C.c_void_p()
+        try:
+            self._check(self._lib.pep_search(self._h, C.byref(params) if params is not None else None, C.byref(r)), 'pep_search')
+        finally:
+            self._lib.pep_set_result_mode(self._h, C.c_int(0))
+        nh, nc = C.c_uint64(), C.c_uint64()
+        st = Stats()
+        ph, pc = C.c_void_p(), C.c_void_p()
+        self._view = r
+        self._check(self._lib.pep_result_size(r, C.byref(nh), C.byref(nc)), 'pep_result_size')
+        self._check(self._lib.pep_result_stats(r, C.byref(st)), 'pep_result_stats')
+        if nh.value:
+            self._check(self._lib.pep_result_device(r, C.byref(ph), C.byref(pc)), 'pep_result_device')
+        return nh.value, nc.value, {n: getattr(st, n) for n, _ in Stats._fields_}, (ph.value or 0, pc.value or 0)
+
+    def result_to_host(self):
+        """(hits, cigar) of the result search_on_device() is holding"""
+        nh, nc = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.pep_result_size(self._view, C.byref(nh), C.byref(nc)), 'pep_result_size')
+        hits, cig = np.empty(nh.value, dtype=HIT_DTYPE), np.empty(nc.value, dtype=np.uint32)
+        self._check(self._lib.pep_result_copy(self._view, _ptr(hits), _ptr(cig)), 'pep_result_copy')
+        return hits, cig
 
     # ---- K7
     def rescore_nt(self, nt_hits, cigar):

@@ -661,6 +661,29 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     return PEP_OK;
 }
 
+int pep_set_result_mode(pep_ctx *ctx, int on_device)
+{
+    if (!ctx) return PEP_ERR_ARG;
+    ctx->device_results = on_device != 0;
+    return PEP_OK;
+}
+
+// the host copy of a result that was left on the device (pep_set_result_mode): fetched once, on demand
+static int pep_fetch_result(const pep_result *cr)
+{
+    pep_result *r = const_cast<pep_result *>(cr);
+    if (r->st_hits || r->n_hits == 0 || !r->hits.empty()) return PEP_OK;
+    pep_ctx *ctx = r->ctx;
+    if (!ctx || ctx->dev_result != r) return PEP_ERR_STATE;         // its device copy has been overwritten
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    r->hits.resize(r->n_hits);
+    r->cigar.resize(r->n_cigar);
+    PEP_HIP(ctx, hipMemcpyAsync(r->hits.data(), r->d_hits, r->n_hits * sizeof(pep_hit), hipMemcpyDeviceToHost, ctx->stream));
+    if (r->n_cigar) PEP_HIP(ctx, hipMemcpyAsync(r->cigar.data(), r->d_cigar, r->n_cigar * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PEP_OK;
+}
+
 int pep_result_size(const pep_result *r, uint64_t *n_hits, uint64_t *n_cigar)
 {
     if (!r) return PEP_ERR_ARG;
@@ -672,6 +695,7 @@ int pep_result_size(const pep_result *r, uint64_t *n_hits, uint64_t *n_cigar)
 int pep_result_copy(const pep_result *r, pep_hit *hits, uint32_t *cigar)
 {
     if (!r) return PEP_ERR_ARG;
+    PEP_TRY(pep_fetch_result(r));
     const pep_hit *h = r->st_hits ? r->st_hits : r->hits.data();
     const uint32_t *c = r->st_cigar ? r->st_cigar : r->cigar.data();
     if (hits && r->n_hits) memcpy(hits, h, r->n_hits * sizeof(pep_hit));
@@ -682,6 +706,7 @@ int pep_result_copy(const pep_result *r, pep_hit *hits, uint32_t *cigar)
 int pep_result_data(const pep_result *r, const pep_hit **hits, const uint32_t **cigar)
 {
     if (!r) return PEP_ERR_ARG;
+    PEP_TRY(pep_fetch_result(r));
     if (hits) *hits = r->st_hits ? r->st_hits : r->hits.data();
     if (cigar) *cigar = r->st_cigar ? r->st_cigar : r->cigar.data();
     return PEP_OK;
@@ -716,6 +741,7 @@ int pep_components_of_result(pep_ctx *ctx, const pep_result *r, uint32_t n_nodes
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     if (r->ctx == ctx && ctx->dev_result == r && n_targets >= ctx->t.n)
         return pep_k10_components_dev(ctx, n_nodes, r->n_hits, r->d_hits, q_base, node_of_target, n_targets, label);
+    PEP_TRY(pep_fetch_result(r));
     const pep_hit *h = r->st_hits ? r->st_hits : r->hits.data();
     return pep_components_of_hits(ctx, n_nodes, r->n_hits, h, q_base, node_of_target, n_targets, label);
 }

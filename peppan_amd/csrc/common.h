@@ -128,6 +128,7 @@ struct pep_ctx {
     uint64_t set_clean_slots = 0;           // leading slots of d_set known to be EMPTY (0 while a search is using it)
     DevBuf uf_nodes;                        // K10 over a device-resident hit table: node of every target (uploaded when it changes)
     std::vector<uint32_t> uf_nodes_host;
+    bool device_results = false;            // pep_set_result_mode: searches leave their table on the device; the host copy is fetched on demand
     pep_result *dev_result = nullptr;       // the result whose hit table is still intact on the device (ws[23]): the newest search's, until the workspace is reused
     DevBuf d_zero;                          // the small counters of one search, cleared by ONE fill when it starts (layout: PEP_ZERO_* below)
     bool zero_ok[4] = {false, false, false, false};     // which consumer regions of d_zero are still untouched since that fill (PEP_ZC_*)

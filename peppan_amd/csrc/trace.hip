@@ -512,8 +512,10 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
                                ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig);
             PEP_HIP(ctx, hipGetLastError());
             // the table goes to the context's pinned staging area (DMA speed, no page faults); pep_result_copy reads it from there.
-            // If the host refuses that much pinned memory the result owns ordinary vectors instead.
-            if (pin_reserve(ctx, ctx->pin_stage, hb + (n_cig + 1) * 4) == PEP_OK) {
+            // If the host refuses that much pinned memory the result owns ordinary vectors instead.  In device-result mode
+            // (pep_set_result_mode) nothing is copied here: whoever wants the host copy fetches it later (pep_fetch_result).
+            if (ctx->device_results) {
+            } else if (pin_reserve(ctx, ctx->pin_stage, hb + (n_cig + 1) * 4) == PEP_OK) {
                 PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_stage.p, d_hits, hb + n_cig * 4, hipMemcpyDeviceToHost, st));       // hits and arena are adjacent in ws[23]
                 res->st_hits = reinterpret_cast<const pep_hit *>(ctx->pin_stage.p);
                 res->st_cigar = reinterpret_cast<const uint32_t *>(ctx->pin_stage.p + hb);

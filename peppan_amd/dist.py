@@ -93,13 +93,15 @@ def _staging_for(device):
 
 
 def _exchange(st, send, slot, world, group):
-    """all-gather of one `slot`-byte block per rank through the staging buffers -> uint8 numpy view of world * slot bytes"""
+    """all-gather of one `slot`-byte block per rank through the staging buffers -> uint8 numpy view of world * slot bytes.
+    send: this rank's block in the page-locked send buffer, or None when it has been written into the DEVICE send buffer already"""
     import torch
     import torch.distributed as dist
     recv = st.get('recv', slot * world, host=True)
     if st.on_gpu:
         d_send, d_recv = st.get('d_send', slot, host=False), st.get('d_recv', slot * world, host=False)
-        d_send.copy_(send, non_blocking=True)
+        if send is not None:
+            d_send.copy_(send, non_blocking=True)
         dist.all_gather_into_tensor(d_recv, d_send, group=group)
         recv.copy_(d_recv, non_blocking=True)
         torch.cuda.current_stream(st.device).synchronize()
@@ -108,24 +110,37 @@ def _exchange(st, send, slot, world, group):
     return recv.numpy()
 
 
-def _all_gather_bytes(fill, nbytes, group, device, stage=None, hint=None):
+def _all_gather_bytes(fill, nbytes, group, device, stage=None, hint=None, fill_dev=None):
     """all-gather of one variable-length byte string per rank: `fill(view)` writes this rank's `nbytes` bytes into a uint8 numpy view of
     the send buffer.  Returns (flat uint8 numpy view of the receive buffer, slot size, offset of the payload inside a slot, per-rank byte
     counts); rank r's bytes are flat[r * slot + offset : r * slot + offset + counts[r]].
     Two collectives in general - the byte counts, then the payloads padded to the largest.  With `hint` (a dict the caller keeps between
     calls) ONE: every rank sends a slot of the size that was enough last time (+ 25 %), its byte count in front; only when some rank's
-    payload does not fit - every rank sees that in the gathered counts - the exchange is repeated the two-step way."""
+    payload does not fit - every rank sees that in the gathered counts - the exchange is repeated the two-step way.
+    fill_dev (RCCL groups only): `fill_dev(tensor)` writes the payload into a uint8 DEVICE tensor instead - the payload is on the GPU
+    already (a hit table left there by the search) and goes from device memory straight into the collective, without the round trip
+    through the host that `fill` implies."""
     import torch
     import torch.distributed as dist
     st = stage if stage is not None else _staging_for(device)
     world = dist.get_world_size(group)
+    on_dev = fill_dev is not None and st.on_gpu
     if hint is not None and hint.get('slot', 0) >= 16:
         slot = int(hint['slot'])
-        send = st.get('send', slot, host=True)
-        view = send.numpy()
-        view[:8].view(np.uint64)[0] = nbytes
-        if 8 + nbytes <= slot:
-            fill(view[8:8 + nbytes])
+        if on_dev:
+            head = st.get('head', 8, host=True)
+            head.numpy().view(np.uint64)[0] = nbytes
+            d_send = st.get('d_send', slot, host=False)
+            d_send[:8].copy_(head, non_blocking=True)
+            if 8 + nbytes <= slot:
+                fill_dev(d_send[8:8 + nbytes])
+            send = None
+        else:
+            send = st.get('send', slot, host=True)
+            view = send.numpy()
+            view[:8].view(np.uint64)[0] = nbytes
+            if 8 + nbytes <= slot:
+                fill(view[8:8 + nbytes])
         flat = _exchange(st, send, slot, world, group)
         counts = np.array([int(flat[r * slot:r * slot + 8].view(np.uint64)[0]) for r in range(world)], dtype=np.int64)
         if int(counts.max()) + 8 <= slot:
@@ -139,47 +154,86 @@ def _all_gather_bytes(fill, nbytes, group, device, stage=None, hint=None):
         hint['slot'] = ((int(counts.max()) * 5 // 4 + 8 + 255) & ~255)
     if slot == 0:
         return np.zeros(0, dtype=np.uint8), 0, 0, counts
+    if on_dev:
+        fill_dev(st.get('d_send', slot, host=False)[:nbytes])
+        return _exchange(st, None, slot, world, group), slot, 0, counts
     send = st.get('send', slot, host=True)
     fill(send.numpy()[:nbytes])
     return _exchange(st, send, slot, world, group), slot, 0, counts
 
 
-def allgather_hits(hits, cigar, q_base, t_base=0, group=None, device=None, out=None, hint=None):
+class _DeviceBytes(object):
+    """raw device memory as something torch.as_tensor understands (the library hands out plain addresses, include/peppan_hip.h)"""
+
+    def __init__(self, address, nbytes):
+        self.__cuda_array_interface__ = dict(shape=(int(nbytes),), typestr='|u1', data=(int(address), False), version=2)
+
+
+def allgather_hits(hits, cigar, q_base, t_base=0, group=None, device=None, out=None, hint=None, on_device=None, force=False):
     """hits: structured array (peppan_amd._native.HIT_DTYPE) with shard-local q / t indices; cigar: uint32 arena.
     Returns the concatenated (hits, cigar) of all ranks in rank order with global indices and re-based cigar offsets.
     Collectives: one all-gather of the payload sizes, one of a padded payload (8-byte hit count + hit records + arena).
     `out`: optional dict that keeps the output arrays between calls (the result is then only valid until the next call).
-    `hint`: optional dict kept between calls: repeated exchanges of similar size then need ONE collective (_all_gather_bytes)."""
+    `hint`: optional dict kept between calls: repeated exchanges of similar size then need ONE collective (_all_gather_bytes).
+    `on_device`: (n_hits, n_cigar, address of the hit records, address of the arena) of a table the search left ON THE GPU
+    (Context.search_on_device) - hits / cigar are then not looked at: the payload is assembled in device memory (record copy, q / t
+    re-based by two strided adds) and handed to the collective from there.
+    `force`: run the collectives even in a one-rank group (tests and tools on a one-GPU box)."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        if on_device is not None:
+            raise ValueError('allgather_hits: on_device needs an initialised process group')
         if q_base or t_base:
             hits = hits.copy()
             hits['q'] += q_base
             hits['t'] += t_base
         return hits, cigar
-    rec, nh, nc = hits.dtype.itemsize, len(hits), len(cigar)
+    from . import _native as N
+    rec = N.HIT_DTYPE.itemsize
+    nh, nc = (len(hits), len(cigar)) if on_device is None else (int(on_device[0]), int(on_device[1]))
 
     def fill(view):
         view[:8].view(np.uint64)[0] = nh
-        mine = view[8:8 + nh * rec].view(hits.dtype)
+        mine = view[8:8 + nh * rec].view(N.HIT_DTYPE)
         mine[:] = hits
         mine['q'] += q_base
         mine['t'] += t_base
         view[8 + nh * rec:].view(np.uint32)[:] = cigar
 
-    flat, slot, at, counts = _all_gather_bytes(fill, 8 + nh * rec + 4 * nc, group, device, hint=hint)
+    fill_dev = None
+    if on_device is not None:
+        import torch
+        st = _staging_for(device)
+        if not st.on_gpu:
+            raise ValueError('allgather_hits: on_device needs an RCCL group (device tensors)')
+
+        def fill_dev(t):
+            head = st.get('nh', 8, host=True)
+            head.numpy().view(np.uint64)[0] = nh
+            t[:8].copy_(head, non_blocking=True)
+            if nh:
+                t[8:8 + nh * rec].copy_(torch.as_tensor(_DeviceBytes(on_device[2], nh * rec), device=st.device))
+                cols = t[8:8 + nh * rec].view(torch.int32).view(nh, rec // 4)          # q and t are the first two 32-bit fields of a record
+                if q_base:
+                    cols[:, 0] += int(q_base)
+                if t_base:
+                    cols[:, 1] += int(t_base)
+            if nc:
+                t[8 + nh * rec:8 + nh * rec + 4 * nc].copy_(torch.as_tensor(_DeviceBytes(on_device[3], 4 * nc), device=st.device))
+
+    flat, slot, at, counts = _all_gather_bytes(fill, 8 + nh * rec + 4 * nc, group, device, hint=hint, fill_dev=fill_dev)
     parts, tot_h, tot_c = [], 0, 0
     for r in range(len(counts)):
         part = flat[r * slot + at:r * slot + at + int(counts[r])]
         n_r = int(part[:8].view(np.uint64)[0])
-        h, c = part[8:8 + n_r * rec].view(hits.dtype), part[8 + n_r * rec:].view(np.uint32)
+        h, c = part[8:8 + n_r * rec].view(N.HIT_DTYPE), part[8 + n_r * rec:].view(np.uint32)
         parts.append((h, c))
         tot_h, tot_c = tot_h + n_r, tot_c + len(c)
     if out is None:
-        all_h, all_c = np.empty(tot_h, dtype=hits.dtype), np.empty(tot_c, dtype=np.uint32)
+        all_h, all_c = np.empty(tot_h, dtype=N.HIT_DTYPE), np.empty(tot_c, dtype=np.uint32)
     else:
         if len(out.get('h', ())) < tot_h:
-            out['h'] = np.empty(int(tot_h * 1.5) + 64, dtype=hits.dtype)
+            out['h'] = np.empty(int(tot_h * 1.5) + 64, dtype=N.HIT_DTYPE)
         if len(out.get('c', ())) < tot_c:
             out['c'] = np.empty(int(tot_c * 1.5) + 64, dtype=np.uint32)
         all_h, all_c = out['h'][:tot_h], out['c'][:tot_c]
@@ -237,10 +291,17 @@ class ShardedSearch(object):
         if retranslate:
             self.ctx.translate(force=True)
         t_k1 = time.perf_counter()
-        hits, cigar, stats = self.ctx.search(self.params, copy=(copy and self.world == 1))
-        t1 = time.perf_counter()
         keep = None if copy else self._scratch            # copy=False: the arrays of the previous step are overwritten
-        allh, allc = allgather_hits(hits, cigar, self.q0, self.t_base, group=self.group, device=self.device, out=keep, hint=self._hint)
+        if self.world > 1 and self.device is not None and getattr(self.device, 'type', '') == 'cuda' and hasattr(self.ctx, 'search_on_device'):
+            # RCCL: the table never leaves the GPU before the collective (no copy to the host at the end of the search, none back up)
+            nh, nc, stats, ptrs = self.ctx.search_on_device(self.params)
+            t1 = time.perf_counter()
+            allh, allc = allgather_hits(None, None, self.q0, self.t_base, group=self.group, device=self.device, out=keep, hint=self._hint,
+                                        on_device=(nh, nc) + tuple(ptrs))
+        else:
+            hits, cigar, stats = self.ctx.search(self.params, copy=(copy and self.world == 1))
+            t1 = time.perf_counter()
+            allh, allc = allgather_hits(hits, cigar, self.q0, self.t_base, group=self.group, device=self.device, out=keep, hint=self._hint)
         t2 = time.perf_counter()
         if self.C > 1:
             from . import _native as N
