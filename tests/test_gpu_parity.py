@@ -357,49 +357,16 @@ def test_uberblast_dropin_blastn_and_diamond(tmp_path, monkeypatch):
     assert n_self >= 2 * 160 - 5            # blastn and diamond rows of the same pair coexist (uberBlast.py:343-346, 353)
 
 
-def test_allgather_from_device_memory_over_rccl(ctx):
+def test_allgather_from_device_memory_over_rccl():
     """the exchange step with the table left on the GPU (Context.search_on_device -> dist.allgather_hits(on_device=...)): payload assembled
     in device memory, RCCL all-gather (a one-rank group is all a one-GPU box offers: every copy, launch and synchronisation except the
-    xGMI transfer), result == the host-staged exchange == the table itself with re-based indices; then K10 and the lazy host copy"""
-    import torch
-    import torch.distributed as dist
-    from peppan_amd import _native as N, synth, dist as pdist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29541')
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-    torch.cuda.set_device(0)
-    dev = torch.device('cuda', 0)
-    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
-    try:
-        names, seqs = synth.make_genes(600, 0, seed=8)
-        ctx.set_query_nt(seqs, 11)
-        ctx.set_ref_nt(seqs, 6, 11)
-        p = N.default_params(45., 25., 10, 5)
-        h, c, st = ctx.search(p)
-        want = h.copy()
-        want['q'] += 5
-        want['t'] += 7
-        hint, hint2 = {}, {}
-        for rep in range(3):                                  # first call: two collectives (sizes, payload); then one (size hint)
-            nh, nc, st2, ptrs = ctx.search_on_device(p)
-            assert (nh, nc) == (len(h), len(c)) and ptrs[0] and ptrs[1]
-            gh, gc = pdist.allgather_hits(None, None, 5, 7, device=dev, hint=hint, on_device=(nh, nc) + tuple(ptrs), force=True)
-            assert np.array_equal(gh, want) and np.array_equal(gc, c)
-            hh, hc = pdist.allgather_hits(h, c, 5, 7, device=dev, hint=hint2, force=True)                       # the host-staged path
-            assert np.array_equal(hh, want) and np.array_equal(hc, c)
-        assert hint.get('slot', 0) >= 8 + len(h) * 64 + 4 * len(c)
-        # the table is still on the device: K10 reads it there, and the host copy can be had after all
-        lab = ctx.components_of_search(len(seqs), ctx.target_meta()['seq'])
-        assert np.array_equal(lab, ctx.components_of_hits(len(seqs), h, ctx.target_meta()['seq']))
-        fh, fc = ctx.result_to_host()
-        assert np.array_equal(fh, h) and np.array_equal(fc, c)
-        # an empty table travels too
-        ctx.set_query_nt([b'ACGT' * 30], 11)
-        nh, nc, st3, ptrs = ctx.search_on_device(p)
-        gh, gc = pdist.allgather_hits(None, None, 0, 0, device=dev, hint={}, on_device=(nh, nc) + tuple(ptrs), force=True)
-        assert nh == 0 and len(gh) == 0 and len(gc) == 0
-    finally:
-        dist.destroy_process_group()
+    xGMI transfer), result == the host-staged exchange == the table itself with re-based indices; then K10 and the lazy host copy.
+    In a process of its own: torch has to be imported before the library is loaded (its wheel carries its own HIP runtime)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'exchange_device_check.py')], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')))
+    assert r.returncode == 0 and 'exchange from device memory: ok' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 def test_public_tools_keep_the_reference_plugin_contract_on_gpu(tmp_path, monkeypatch):
