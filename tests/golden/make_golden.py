@@ -31,6 +31,9 @@ Fixture index:
   g14_mapbsn.json        iter_map_bsn / compare_prediction / decodeSeq (PEPPAN.py:318-324, 759-905)
   g15_getmapbsn.json     get_map_bsn -> MapBsn stores   (PEPPAN.py:27-114, 907-989)
   g16_real.json (+ g16_real_genes.fa.gz, g16_real_contig.fa.gz)  real genes of the reference's examples/ through its own front end
+  g17_examples.json (+ g17_examples_genes.fa.gz)  BASELINE configs[0] at full size: ALL CDS of the four example GFFs through the reference's
+                         readGFF -> encodeNames -> load_priority -> writeGenes (PEPPAN.py:117-191, 746-751, 1023-1039, 1766-1775, 1844-1849):
+                         the 11 696 unique genes of its <prefix>.genes with their priorities; instance hashes and duplicate groups
 """
 import json, os, sys, stat, tempfile, shutil, io, contextlib, copy
 
@@ -1113,7 +1116,44 @@ def g16_real():
     print('g16: %d gene instances, %d unique, %d duplicate pairs' % (len(genes), len(unique_order), len(groups)))
 
 
+# ----------------------------------------------------------------------------- G17 the whole example data set (BASELINE configs[0])
+def g17_examples():
+    """every CDS of the reference's four example genomes through the steps PEPPAN.ortho() takes before the first external call
+    (PEPPAN.py:1844-1849, 1880): readGFF (iter_readGFF per file; its worker pool replaced by a plain map), encodeNames, load_priority
+    (default: no priority list), writeGenes.  Recorded: the unique genes exactly as the reference wrote <prefix>.genes (integer names),
+    the priority of every one of them, and - for the duplicate collapse - (name, length, sha1 code, priority) of every gene instance with
+    the reference's duplicate groups."""
+    import gzip, glob
+
+    class _Serial(object):
+        def imap_unordered(self, fn, jobs):
+            return map(fn, jobs)
+    PEP.pool = _Serial()
+    PEP.params = dict(min_cds=120, incompleteCDS='')
+    files = sorted(glob.glob(os.path.join(REF, 'examples', '*.gff.gz')))
+    genomes, genes = PEP.readGFF(files, 'CDS', 11)
+    d = fake_dir()
+    n_cds = len(genes)
+    genomes, genes, encodes = PEP.encodeNames(genomes, genes, '', os.path.join(d, 'ex.encode.csv'), False)
+    priorities = PEP.load_priority('', genes, encodes)
+    n_with_seq = sum(1 for g in genes.values() if len(g[6]))
+    fn, groups = PEP.writeGenes(os.path.join(d, 'ex.genes'), genes, priorities)
+    unique = [int(l[1:]) for l in open(fn) if l.startswith('>')]
+    with open(fn) as fin, gzip.open(os.path.join(HERE, 'g17_examples_genes.fa.gz'), 'wt', compresslevel=9) as f:
+        f.write(fin.read())
+    inst = sorted(n for n, g in genes.items() if len(g[6]))
+    dump('g17_examples.json', dict(n_cds=n_cds, n_instances=n_with_seq, n_unique=len(unique),
+                                   priority={g: [priorities[g][0], priorities[g][1], str(priorities[g][2])] for g in unique},
+                                   instances=[[g, len(genes[g][6]), '%040x' % genes[g][5], priorities[g][0]] for g in inst],
+                                   groups=groups, nt_total=sum(len(genes[g][6]) for g in unique)))
+    print('g17: %d CDS, %d instances with a sequence, %d unique genes, %d duplicate pairs' % (n_cds, n_with_seq, len(unique), len(groups)))
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'g17':
+        g17_examples()
+        shutil.rmtree(SHIM, ignore_errors=True)
+        sys.exit(0)
     g13()
     g01()
     genes, refs, rel = g02()
@@ -1126,4 +1166,5 @@ if __name__ == '__main__':
     g10_g11_g12()
     g14_g15()
     g16_real()
+    g17_examples()
     shutil.rmtree(SHIM, ignore_errors=True)

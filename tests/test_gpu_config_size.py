@@ -29,11 +29,14 @@ def _cmp_tables(a, b):
     assert a.tolist() == b.tolist()
 
 
-def test_map_bsn_10k_exemplars_x_64_genomes(tmp_path, monkeypatch):
+@pytest.mark.parametrize('n_genomes', [64, 500])
+def test_map_bsn_10k_exemplars_x_genomes(tmp_path, monkeypatch, n_genomes):
+    """BASELINE configs[2] mapping stage: 10 000 exemplars against 64 genomes, and at the configuration's FULL size - 500 genomes, 1.07 Gnt -
+    through get_map_bsn; every planted allele found, stores consistent, sampled genomes equal to the oracle-driven host code row for row"""
     from peppan_amd import mapbsn, synth, uberBlast as UB
     from oracle_context import OracleContext
     monkeypatch.chdir(tmp_path)
-    n_genomes, sample = 64, (3, 40)
+    sample = (3, 40)
     names, seqs = synth.make_genes(10000, 0, seed=355)
     with open('m.clust.exemplar', 'w') as f:
         for i, s in enumerate(seqs):
@@ -75,7 +78,7 @@ def test_map_bsn_10k_exemplars_x_64_genomes(tmp_path, monkeypatch):
         for k, s, e, strand in ann:
             planted += 1
             assert (k, 900000 + g) in found, (g, k)
-    assert planted > 64 * 1500
+    assert planted > n_genomes * 1500
     # the sampled genomes: whole tables equal to the same host code over the CPU oracle (one uberBlast call per genome)
     octx = OracleContext()
     monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
@@ -89,15 +92,17 @@ def test_map_bsn_10k_exemplars_x_64_genomes(tmp_path, monkeypatch):
         assert o_tab.shape[0] > 5000
 
 
-def test_front_end_one_million_gene_instances(ctx, tmp_path, monkeypatch):
-    """writeGenes (K13 sha1 + duplicate collapse) and the 11-level iterClust (K9) on 1 M instances of 4 000 genes"""
+@pytest.mark.parametrize('n_base,copies', [(4000, 250), (10000, 500)])
+def test_front_end_gene_instances_at_size(ctx, tmp_path, monkeypatch, n_base, copies):
+    """writeGenes (K13 sha1 + duplicate collapse) and the 11-level iterClust (K9) on 1 M instances of 4 000 genes, and at BASELINE
+    configs[2]'s full size: 5 M instances of 10 000 genes (10 000 genes x 500 genomes, 4.45 Gnt)"""
     from peppan_amd import pipeline as PL
     monkeypatch.chdir(tmp_path)
     t0 = time.perf_counter()
     from peppan_amd import synth
-    seqs = synth.make_instances(4000, 250, seed=8)
+    seqs = synth.make_instances(n_base, copies, seed=8)
     n = len(seqs)
-    assert n == 1000000
+    assert n == n_base * copies
     t1 = time.perf_counter()
     hashes = PL.gene_hashes(seqs, ctx=ctx)
     t2 = time.perf_counter()
@@ -109,18 +114,18 @@ def test_front_end_one_million_gene_instances(ctx, tmp_path, monkeypatch):
     fn, groups = PL.writeGenes('big.genes', genes, prio, ctx=ctx)
     t3 = time.perf_counter()
     n_unique = sum(1 for line in open(fn) if line.startswith('>'))
-    assert n_unique + len(groups) == n and 4000 <= n_unique <= 7 * 5 * 4000     # identical alleles collapse inside a length run: at most 5 alleles x 7 file ranks per gene (PEPPAN.py:1032-1033)
+    assert n_unique + len(groups) == n and n_base <= n_unique <= 7 * 5 * n_base     # identical alleles collapse inside a length run: at most 5 alleles x 7 file ranks per gene (PEPPAN.py:1032-1033)
     with contextlib.redirect_stderr(io.StringIO()):
         ex = PL.iterClust('big', fn, groups, dict(identity=0.9, coverage=0.8, n_thread=1, translate=False))
     t4 = time.perf_counter()
     n_ex = sum(1 for line in open(ex) if line.startswith('>'))
     clu = np.load('big.clust.npy')
-    assert 2500 <= n_ex <= 4000                               # the alleles of a gene end up under one exemplar; of the four members of a family the two closest (0 / 5 % substitutions) merge at 0.9
+    assert 0.6 * n_base <= n_ex <= n_base                     # the alleles of a gene end up under one exemplar; of the four members of a family the two closest (0 / 5 % substitutions) merge at 0.9
     assert clu.shape[0] >= n - n_ex - 12 * 11                 # (every level loses the first line of its table, PEPPAN.py:1786)
     rss = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6
-    print('1 M instances: generate %.1f s, sha1 %.1f s, writeGenes %.1f s, iterClust %.1f s; %d unique, %d exemplars; peak RSS %.1f GB'
-          % (t1 - t0, t2 - t1, t3 - t2, t4 - t3, n_unique, n_ex, rss))
-    assert (t2 - t1) + (t3 - t2) + (t4 - t3) < 240 and rss < 24
+    print('%d instances: generate %.1f s, sha1 %.1f s, writeGenes %.1f s, iterClust %.1f s; %d unique, %d exemplars; peak RSS %.1f GB'
+          % (n, t1 - t0, t2 - t1, t3 - t2, t4 - t3, n_unique, n_ex, rss))
+    assert (t2 - t1) + (t3 - t2) + (t4 - t3) < 240 and rss < 40
 
 
 def test_all_vs_all_50k_bit_exact_vs_oracle(ctx):
@@ -217,3 +222,64 @@ def test_chromosome_longer_than_the_sequence_limit(tmp_path, monkeypatch):
     # no duplicates from the overlapping halos: one row per (query, locus)
     for gi_, hits in on_chr.items():
         assert len({(lo, hi) for lo, hi, rev, qs, qe in hits}) == len(hits)
+
+
+def test_example_genomes_full_pipeline_vs_oracle(ctx, tmp_path, monkeypatch):
+    """BASELINE configs[0] / [1] on REAL genes at full size (golden G17: every CDS of the reference's four example genomes, 8 441 unique genes
+    after its own writeGenes): sha1 (K13) == the reference's codes, writeGenes == its file and duplicate pairs, then the whole hot path
+    iterClust (K9) -> get_similar_pairs (K1..K8 x 2 tools, K7, K14) -> get_gene_group / K10 on the GPU == the same host code over the CPU oracle"""
+    import gzip, shutil
+    from conftest import load_golden
+    from peppan_amd import uberBlast as UB, pipeline as PL, clust as CL
+    from oracle import oracle as O
+    from oracle_context import OracleContext
+    g = load_golden('g17_examples.json')
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g17_examples_genes.fa.gz'), 'rt') as f:
+        text = f.read()
+    seqs = {}
+    for rec in text.split('>')[1:]:
+        name, seq = rec.split('\n', 1)
+        seqs[int(name)] = seq.strip()
+    code = {name: int(c, 16) for name, length, c, rank in g['instances']}
+    ids = sorted(seqs)
+    assert len(ids) == 8441 and PL.gene_hashes([seqs[i] for i in ids], ctx=ctx) == [code[i] for i in ids]
+    genes = {name: ['f', '', 0, 0, '+', int(c, 16), seqs.get(name, 'N' * length)] for name, length, c, rank in g['instances']}
+    prio_all = {name: [rank, -length, int(c, 16)] for name, length, c, rank in g['instances']}
+    monkeypatch.chdir(tmp_path)
+    fn, groups = PL.writeGenes('ex.genes', genes, prio_all, ctx=ctx)
+    assert open(fn).read() == text and groups == g['groups']
+    prio = {int(k): [v[0], v[1], int(v[2])] for k, v in g['priority'].items()}
+    params = dict(noDiamond=False, match_identity=0.5, match_frag_len=50, n_thread=2, match_frag_prop=0.25, gtable=11,
+                  clust_identity=0.9, clust_match_prop=0.8, incompleteCDS='', match_len=250., match_len1=100., match_len2=400.,
+                  match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+
+    def oracle_fn(fasta, identity, coverage, n_thread):
+        recs = CL.readFasta(fasta)
+        rep, _ = O.linclust([O.nt_codes(s) for _, s in recs], float(identity), float(coverage))
+        return [(recs[r][0], recs[i][0]) for i, r in enumerate(rep.tolist())]
+
+    results, took = {}, {}
+    for tag in ('gpu', 'ora'):
+        d = tmp_path / tag
+        d.mkdir()
+        monkeypatch.chdir(d)
+        shutil.copy(str(tmp_path / 'ex.genes'), 'p.genes')
+        if tag == 'ora':
+            octx = OracleContext()
+            monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
+            monkeypatch.setattr(PL, 'get_context', lambda device=None: octx)
+        t0 = time.perf_counter()
+        with contextlib.redirect_stderr(io.StringIO()):
+            ex = PL.iterClust('p', 'p.genes', [list(x) for x in groups], dict(identity=0.9, coverage=0.8, n_thread=2, translate=False,
+                                                                               cluster_fn=oracle_fn if tag == 'ora' else None))
+            t1 = time.perf_counter()
+            pairs = PL.get_similar_pairs(ex, prio, dict(params, clust=ex))
+        t2 = time.perf_counter()
+        np.save('p.self_bsn.npy', pairs)
+        grp = PL.get_gene_group(ex, 'p.self_bsn.npy')
+        took[tag] = (t1 - t0, t2 - t1)
+        results[tag] = (open(ex).read(), np.load('p.clust.npy').tolist(), pairs.tolist(), [[int(k), [int(x) for x in v]] for k, v in grp.items()])
+    print('example genomes, 8 441 genes: iterClust %.1f s, get_similar_pairs %.2f s on the GPU; %.1f s / %.1f s over the CPU oracle; %d pairs, %d groups'
+          % (took['gpu'] + took['ora'] + (len(results['gpu'][2]), len(results['gpu'][3]))))
+    assert results['gpu'] == results['ora']
+    assert len(results['gpu'][2]) > 500 and len(results['gpu'][3]) > 200

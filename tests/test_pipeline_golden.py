@@ -149,3 +149,35 @@ def test_real_genes_front_end(tmp_path):
     fn, groups = PL.writeGenes(str(tmp_path / 'real.genes'), genes, prio, ctx=OracleContext())
     assert groups == g['groups'] and len(groups) == 343
     assert [int(l[1:]) for l in open(fn) if l.startswith('>')] == g['unique_order']
+
+
+def _example_set():
+    """golden G17: every CDS of the reference's four example genomes (BASELINE configs[0]) as its own front end left them"""
+    import gzip
+    g = load_golden('g17_examples.json')
+    with gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g17_examples_genes.fa.gz'), 'rt') as f:
+        text = f.read()
+    seqs = {}
+    for rec in text.split('>')[1:]:
+        name, seq = rec.split('\n', 1)
+        seqs[int(name)] = seq.strip()
+    return g, text, seqs
+
+
+def test_example_genomes_front_end_at_full_size(tmp_path):
+    """all 19 490 gene instances of the four example genomes through writeGenes: the unique-gene FASTA is byte for byte the file the
+    reference's writeGenes wrote (order included - the lexsort over the priority columns is its sorted()) and the 11 049 duplicate pairs
+    are its pairs.  (A duplicate's sequence is not part of the fixture - only its length and sha1 code, which is all writeGenes looks at.)"""
+    from oracle_context import OracleContext
+    g, text, seqs = _example_set()
+    assert (g['n_cds'], g['n_instances'], g['n_unique'], len(seqs)) == (20915, 19490, 8441, 8441)
+    genes, prio = {}, {}
+    for name, length, code, rank in g['instances']:
+        genes[name] = ['f', '', 0, 0, '+', int(code, 16), seqs.get(name, 'N' * length)]
+        assert len(genes[name][6]) == length
+        prio[name] = [rank, -length, int(code, 16)]
+    fn, groups = PL.writeGenes(str(tmp_path / 'ex.genes'), genes, prio, ctx=OracleContext())
+    assert open(fn).read() == text
+    assert groups == g['groups'] and len(groups) == 11049
+    ids = sorted(seqs)[:400]
+    assert PL.gene_hashes([seqs[i] for i in ids], ctx=OracleContext()) == [genes[i][5] for i in ids]
