@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
-PROFILE_COUNTERS = os.path.join(ROOT, 'profiles', 'r02_counters.json')     # rocprofv3 PMC passes of this workload (tools/profile_round.sh)
-PROFILE_VALU = os.path.join(ROOT, 'profiles', 'r02_valu_rate.txt')         # tools/micro/valu_rate on the same GPU
+PROFILE_COUNTERS = os.path.join(ROOT, 'profiles', 'r03_counters.json')     # rocprofv3 PMC passes of this workload (tools/profile_round.sh)
+PROFILE_VALU = os.path.join(ROOT, 'profiles', 'r03_valu_rate.txt')         # tools/micro/valu_rate on the same GPU
 
 
 def cpu_baseline(nts, n_sample, min_id, min_qcov):
@@ -81,6 +81,57 @@ def spawn_ranks(args, argv):
     return 0
 
 
+def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup):
+    """The genes -> genomes mapping (BASELINE configs "x 500 / x 2000 genomes"; PEPPAN.py:907-989) as a bench workload: every rank maps ITS OWN
+    n_genomes synthetic genomes (10 000 exemplar genes, 2.2 Mb per genome) - batched GPU search for both tools, -f / -m / -O chain, K7, K12,
+    build_bsn - per step.  Genomes are the independent unit of this path: they shard over the ranks with no data-path collective (weak
+    scaling), which is what can scale on an 8-GPU node where the 3 ms all-vs-all step cannot."""
+    import contextlib
+    import io
+    import tempfile
+    from peppan_amd import mapbsn, synth, uberBlast as UB
+    names, seqs = synth.make_genes(args.genes, 0, seed=355)
+    params = dict(noDiamond=False, match_identity=0.65, match_frag_len=50, match_frag_prop=0.25, link_gap=600, link_diff=1.5, gtable=11,
+                  match_len=250., match_len1=100., match_len2=400., match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+    tmp = tempfile.mkdtemp(prefix='pep_map_%d_' % rank)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        with open('m.clust.exemplar', 'w') as f:
+            for i, s in enumerate(seqs):
+                f.write('>%d\n%s\n' % (i, s.decode()))
+        worlds = synth.make_genomes(seqs, n_genomes, seed=355 + 1000 * rank)
+        jobs, nt = [], 0
+        with mapbsn.MapBsn('m.old_prediction.npz', 'w') as op:
+            for g, (gname, contig, ann) in enumerate(worlds):
+                jobs.append((g, 900000 + g, [[100000 + g, contig.decode()]]))
+                nt += len(contig)
+                op.save(100000 + g, np.array([[k, a, b, st, 1] for k, a, b, st in ann[::2]], dtype=object))
+        og = np.array([[0, 1, 9000], [4, 5, -2]], dtype=int)
+        UB._CTX.clear()
+        os.environ['PEPPAN_HIP_DEVICE'] = str(local_rank)
+
+        def step():
+            groups = rows = 0
+            for job, (tab, ovl) in zip(jobs, mapbsn._gpu_search('m', 'm.clust.exemplar', jobs, params, genomes_per_batch=n_genomes)):
+                bsn, o = mapbsn.build_bsn(tab, ovl, job[2], og, 'm.old_prediction.npz', params)
+                groups += bsn.shape[0]
+                rows += len(tab)
+            return groups, rows
+        with contextlib.redirect_stderr(io.StringIO()):
+            for _ in range(warmup):
+                step()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                groups, rows = step()
+            dt = time.perf_counter() - t0
+    finally:
+        os.chdir(cwd)
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return dict(seconds=dt, genomes=n_genomes * steps, genome_nt=nt, groups_per_step=groups, hit_rows_per_step=rows)
+
+
 def _profile_tables():
     """tracked evidence the line refers to: per-kernel PMC counters of this workload and the measured VALU issue rates"""
     counters, cyc4 = {}, None
@@ -94,6 +145,38 @@ def _profile_tables():
     return counters, cyc4
 
 
+def main_map(args, rank, local_rank, world):
+    import torch
+    import torch.distributed as dist
+    steps = args.steps if '--steps' in sys.argv else 2
+    warmup = args.warmup if '--warmup' in sys.argv else 1
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        dist.barrier()
+    torch.cuda.synchronize()
+    r = map_workload(args, rank, world, local_rank, args.map_genomes, steps, warmup)
+    torch.cuda.synchronize()
+    dt = r['seconds']
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device('cuda', local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({'metric': 'genomes_mapped_per_s', 'value': world * r['genomes'] / dt, 'unit': 'genomes/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+                          'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic',
+                          'config': {'workload': 'synthgenes-v1: %d exemplar genes (log-normal lengths) x %d genomes per rank and step (%.1f Mnt per rank), the genes -> genomes mapping of '
+                                                 'BASELINE configs[2..4] (PEPPAN.py:907-989): --blastn --diamond -f -m -O -s 1, build_bsn' % (args.genes, args.map_genomes, r['genome_nt'] / 1e6),
+                                     'parallelism': 'genomes sharded over %d rank(s), no data-path collective' % world},
+                          'groups_per_step_rank0': r['groups_per_step'], 'hit_rows_per_step_rank0': r['hit_rows_per_step'],
+                          'roofline': None, 'cpu_baseline': None,
+                          'note': 'secondary workload (the BASELINE metric is --workload search): host-bound - the GPU is busy for a few per cent of a step (DESIGN.md section 4)'}))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -104,6 +187,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-e2e', action='store_true', help='skip the extras after the timed region (round-1 pre-filter comparison loop, H2D-inclusive step, the real uberBlast() call)')
     ap.add_argument('--cpu-sample', type=int, default=10000, help='leading queries of the workload the CPU baseline runs (all host cores)')
+    ap.add_argument('--workload', choices=('search', 'map'), default='search', help='search: the all-vs-all step (the BASELINE metric); map: the genes -> genomes '
+                    'mapping, genomes sharded over the ranks (weak scaling, no collective) - default 2 timed steps of --map-genomes genomes per rank')
+    ap.add_argument('--map-genomes', type=int, default=16, help='genomes per rank and step of --workload map')
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
@@ -111,6 +197,8 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.workload == 'map':
+        return main_map(args, rank, local_rank, world)
     # the workload, and (rank 0) the CPU oracle run: the cpu_baseline figure at N = 1, the identity check of the gathered table at any N
     # (run first: its OpenMP team is idle while the GPU steps are timed)
     from peppan_amd import synth
@@ -176,7 +264,7 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     keys = ('candidates', 'cells', 'cells_swept', 'cells_swept_trace', 'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total',
-            'hits', 'dir_bytes', 'tracebacks', 'seed_hits', 'target_residues', 'query_residues', 'ms_host_translate', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')
+            'hits', 'dir_bytes', 'tracebacks', 'tracebacks_gapless', 'seed_hits', 'target_residues', 'query_residues', 'ms_host_translate', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')
     acc = dict.fromkeys(keys, 0.0)
     t_uf = 0.0
     for _ in range(args.steps):
@@ -211,6 +299,15 @@ def main():
         cpu_line.update(gpu_hits_identical=bool(same), hits_compared=int(len(o_hits)))
 
     extras = {}
+    if world == 1 and rank == 0:
+        # what a caller sees who synchronises the whole device and then searches: the same K steps right behind a torch.cuda.synchronize(),
+        # WITHOUT the settle burst in front - the runtime's one-time 5.6 ms copy-queue stall lands in here if it occurs
+        torch.cuda.synchronize()
+        t9 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        extras['ms_per_step_after_device_sync'] = (time.perf_counter() - t9) / args.steps * 1e3
     if world == 1 and rank == 0 and not args.no_e2e:
         # the SAME unit of work as round 1's line: `value` counts the candidate pairs that enter gapped Smith-Waterman, and since round 2 the
         # ungapped pre-filter in front of it is stricter (threshold 55 instead of 45: 39 % fewer candidates, identical hit table - DESIGN.md
@@ -259,6 +356,37 @@ def main():
                 tab = UB.uberBlast(argv)
                 extras['uberblast_e2e_ms'] = (time.perf_counter() - t2) * 1e3
             extras['uberblast_e2e_rows'] = int(tab.shape[0])
+            # (c) the consumer of that table, PEPPAN's get_similar_pairs (PEPPAN.py:194-294), through the product's own entry point: numeric table,
+            # host scan (C++), get_similar as K14 on the GPU, resolve, exemplar file rewritten - `decide` is everything behind the search
+            import shutil
+            from peppan_amd import pipeline as PL
+            try:
+                prio = {int(names[i]): [0, -len(seqs[i]), int(names[i])] for i in order}
+            except ValueError:
+                prio = None                                     # (gene names that are not integers: PEPPAN encodes them first, PEPPAN.py:1766-1775)
+            if prio is not None:
+                params_gs = dict(noDiamond=False, match_identity=0.5, match_frag_len=50, n_thread=1, match_frag_prop=0.25, gtable=11, clust_identity=0.9, clust_match_prop=0.8,
+                                 incompleteCDS='', match_len=250., match_len1=100., match_len2=400., match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+                ex = os.path.join(tmp, 'p.clust.exemplar')
+                np.save(os.path.join(tmp, 'p.clust.npy'), np.zeros((0, 3), dtype=int))
+                best = None
+                for _ in range(3):
+                    shutil.copy(fa, ex)
+                    tm = {}
+                    with contextlib.redirect_stderr(io.StringIO()):
+                        pairs = PL.get_similar_pairs(ex, prio, dict(params_gs, clust=ex), timing=tm)
+                    if best is None or tm['decide_ms'] < best['decide_ms']:
+                        best = dict(tm, pairs=int(len(pairs)))
+                extras['get_similar_pairs_ms'] = best['decide_ms']
+                extras['get_similar_pairs'] = {'decide_ms': best['decide_ms'], 'search_ms': best['search_ms'], 'rows': best['rows'], 'pairs': best['pairs'],
+                                               'note': 'decide = classification + host scan + K14 + resolve + exemplar rewrite; search = the uberBlast call in front of it (numeric table, FASTA re-read because the exemplar file was rewritten)'}
+        # (d) the genes -> genomes mapping at N = 1 (bench.py --workload map is the same thing per rank): genomes/s on this GPU
+        try:
+            mr = map_workload(args, 0, 1, local_rank, 16, 1, 1)
+            extras['map_workload'] = {'genomes_per_s': mr['genomes'] / mr['seconds'], 'genomes': mr['genomes'], 'genome_nt': mr['genome_nt'], 'groups_per_step': mr['groups_per_step'],
+                                      'note': 'python bench.py --workload map --gpus N: genomes sharded over the ranks, weak scaling, no collective'}
+        except Exception as e:                                  # never lose the headline over the secondary leg
+            extras['map_workload'] = {'error': repr(e)}
 
     if rank == 0:
         K = args.steps
@@ -271,10 +399,17 @@ def main():
         def entry(kernel, what, ms, alg_bytes, insts_key=None):
             achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             prof = counters.get(kernel, {}) if headline else {}
+            # the tracked counters describe THIS kernel only while it still takes what it took when they were collected: its duration in the
+            # PMC passes must agree with the live HIP-event time within 10 %, else the figures are withheld (stale: regenerate with tools/profile_round.sh)
+            prof_us = prof.get('avg_us_in_pmc_passes') or []
+            stale = bool(prof_us) and ms > 0 and abs(min(prof_us) / 1e3 - ms) > 0.10 * ms and abs(sum(prof_us) / len(prof_us) / 1e3 - ms) > 0.10 * ms
+            if stale:
+                prof = {}
             traffic = (2 * prof['FETCH_SIZE'] + prof['WRITE_SIZE']) * 1024.0 if 'FETCH_SIZE' in prof and 'WRITE_SIZE' in prof else None
             e = {'kernel': kernel, 'what': what, 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-                 'ms_per_launch': ms, 'algorithmic_bytes': alg_bytes, 'traffic': traffic,
-                 'traffic_source': 'profiles/r02_counters.json: 2 x FETCH_SIZE + WRITE_SIZE of the same kernel on this workload (separate rocprofv3 --pmc passes; '
+                 'ms_per_launch': ms, 'algorithmic_bytes': alg_bytes, 'traffic': traffic, 'counters_stale': stale,
+                 'ms_per_launch_in_pmc_passes': (sum(prof_us) / len(prof_us) / 1e3) if prof_us else None,
+                 'traffic_source': 'profiles/r03_counters.json: 2 x FETCH_SIZE + WRITE_SIZE of the same kernel on this workload (separate rocprofv3 --pmc passes; '
                                    'x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)' if traffic is not None else None}
             if traffic:
                 e['traffic_over_algorithmic'] = traffic / alg_bytes if alg_bytes else None
@@ -282,13 +417,13 @@ def main():
                 # integer-VALU bound kernels: wave-instructions per launch (PMC) x measured cycles per instruction of the packed-16 / DPP / add3
                 # class (tools/micro/valu_rate.hip) against 1024 SIMDs at the 2.4 GHz peak clock for the launch's live duration
                 e['valu_issue_frac'] = prof['SQ_INSTS_VALU'] * cyc4 / (1024 * 2.4e9 * ms * 1e-3)
-                e['valu_issue_source'] = 'SQ_INSTS_VALU from profiles/r02_counters.json x %.3f cycles/instruction from profiles/r02_valu_rate.txt' % cyc4
+                e['valu_issue_source'] = 'SQ_INSTS_VALU from profiles/r03_counters.json x %.3f cycles/instruction from profiles/r03_valu_rate.txt' % cyc4
             return e
 
         ms_sw, ms_tr, ms_match = acc['ms_sw'] / K, acc['ms_sw_trace'] / K, acc['ms_seed_match'] / K / max(1, n_shapes)
         # algorithmic bytes per launch, SURVEY.md 8(d): SW = sum over pairs of (Lq + Lr) residue bytes + 64 B per reported hit;
         # seed join = 1 B + 8 B index entry per target residue + 8 B per raw seed hit
-        rl = [entry('sw_trace_kernel', 'K5 traceback pass: sub-band SW + 4-bit codes over the selected pairs, four per wavefront', ms_tr, (acc['tracebacks'] / K) * 2 * Lq + hits_step * 64, 'v'),
+        rl = [entry('sw_trace_kernel', 'K5 traceback pass: sub-band SW + 4-bit codes over the selected pairs that are not one ungapped run (rule 5a), four per wavefront', ms_tr, ((acc['tracebacks'] - acc['tracebacks_gapless']) / K) * 2 * Lq + hits_step * 64, 'v'),
               entry('sw_score_kernel', 'K5 score pass: banded SW over all candidate pairs', ms_sw, (acc['candidates'] / K) * 2 * Lq + hits_step * 64, 'v'),
               entry('seed_match<10>', 'K4a: target seeds streamed through the query index (one launch per seed shape)', ms_match,
                     9.0 * acc['target_residues'] / K + 8.0 * acc['seed_hits'] / K / max(1, n_shapes))]
@@ -308,8 +443,14 @@ def main():
             'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3) if acc['ms_sw'] else None,
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
             'hits_per_step': float(len(allh)), 'clusters': int(len(np.unique(labels))), 'candidates_per_step': acc['candidates'] / K,
+            # units that do not move with internal filters (value counts the candidates the pre-filter lets through):
+            'hits_per_s': float(len(allh)) * K / dt, 'gene_pairs_all_vs_all_per_s': float(args.genes) * float(args.genes) * K / dt,
+            'tracebacks_per_step': acc['tracebacks'] / K, 'tracebacks_gapless_per_step': acc['tracebacks_gapless'] / K,
+            'steady_state': True, 'settle_calls': 500,
             'value_definition': 'candidate (query, target-frame, band) pairs entering gapped Smith-Waterman per second of step wall time (SURVEY.md 8d-i); '
-                                'the pre-filter in front of that stage decides how many there are - see same_unit_as_round1',
+                                'the pre-filter in front of that stage decides how many there are - see same_unit_as_round1; hits_per_s and '
+                                'gene_pairs_all_vs_all_per_s (query genes x reference genes per second) do not depend on it. ms_per_step is a steady-state figure: '
+                                '500 tiny library calls run between the device-wide synchronisation and the clock (settle_calls); ms_per_step_after_device_sync is the same loop without them',
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
             'host_phase_ms_rank0': dict({k: acc[k] / K for k in ('ms_host_translate', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')}, ms_host_union_find=t_uf / K),
             'roofline': top, 'roofline_kernels': rl,

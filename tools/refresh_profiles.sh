@@ -2,7 +2,7 @@
 # after `gpurun -- 'bash tools/profile_round.sh'`: copy the summaries from gpurun_out/ into profiles/ with their header lines
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r02}
+R=${1:-r03}
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e   (MI355X; tools/rocpd_summary.py over the rocpd database)"; cat gpurun_out/final_stats.txt; } > profiles/${R}_final_kernel_stats.txt
 { echo "# python bench.py  (MI355X; default flags: 1 GPU, 50 steps, 5 warmup, cpu baseline = oracle C port with OpenMP on every host thread, whole workload)"; cat gpurun_out/bench_line.txt; } > profiles/${R}_bench_line.txt
 cp gpurun_out/counters.json profiles/${R}_counters.json
