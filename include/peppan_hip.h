@@ -88,7 +88,9 @@ typedef struct {
     int32_t stage1_min;           /* first stage of the ungapped pre-filter (only with ungapped_min > 0): the extension to the right of a seed hit must
                                      have reached this score after its first 16 residues - the seed and a few residues behind it - or the hit is
                                      dropped before the rest of its windows is fetched (chance hits of the reduced alphabet); 0 = off */
-    int32_t reserved2;            /* 0 */
+    int32_t reserved2;            /* test switch, 0 in production: 1 makes the alignment stage synchronise with the host after its selection step and size
+                                     the traceback buffers exactly (what it does by itself when its upper bounds would cost too much memory) instead of
+                                     running from the candidate count to the result sizes without a host round trip */
 } pep_search_params;
 
 /* one alignment; coordinates are 1-based, inclusive, in residues of the query / target protein */

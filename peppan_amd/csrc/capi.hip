@@ -11,7 +11,6 @@ int pep_fail(pep_ctx *ctx, int code, const std::string &msg)
     if (ctx) {
         ctx->err = msg;
         ctx->n_pending = 0;              // queued read-backs point at the failing caller's locals: drop them
-        ctx->sw_totals_pending = false;
         ctx->pin_small_used = 0;
     }
     return code;
@@ -263,6 +262,7 @@ int upload_aa(pep_ctx *ctx, SeqSet &s, const uint8_t *codes, const uint64_t *off
 {
     if (n && (!codes || !off)) return pep_fail(ctx, PEP_ERR_ARG, "null sequence buffer");
     if (n > max_n) return pep_fail(ctx, PEP_ERR_LIMIT, "too many sequences");
+    if (&s == &ctx->t) ctx->t_tables_lazy = false;          // the host tables are built right here
     s.n = n;
     s.h_off.assign(n + 1, 0);
     s.h_len.assign(n, 0);
@@ -300,6 +300,7 @@ int upload_aa(pep_ctx *ctx, SeqSet &s, const uint8_t *codes, const uint64_t *off
 int download_aa(pep_ctx *ctx, const SeqSet &s, uint8_t *codes, uint64_t cap, uint64_t *off)
 {
     if (s.residues > cap) return pep_fail(ctx, PEP_ERR_ARG, "output buffer too small");
+    if (&s == &ctx->t) PEP_TRY(pep_k1_host_tables(ctx));
     std::vector<uint8_t> img(s.total);
     if (s.total) PEP_HIP(ctx, hipMemcpy(img.data(), s.res.p, s.total, hipMemcpyDeviceToHost));
     uint64_t pos = 0;
@@ -401,7 +402,6 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_stage.p) (void)hipHostFree(ctx->pin_stage.p);
     if (ctx->pin_k1.p) (void)hipHostFree(ctx->pin_k1.p);
     if (ctx->pin_k1q.p) (void)hipHostFree(ctx->pin_k1q.p);
-    if (ctx->pin_k1n.p) (void)hipHostFree(ctx->pin_k1n.p);
     if (ctx->k1_event) (void)hipEventDestroy(ctx->k1_event);
     if (ctx->k1_t0) (void)hipEventDestroy(ctx->k1_t0);
     if (ctx->k1_t1) (void)hipEventDestroy(ctx->k1_t1);
@@ -467,10 +467,11 @@ int pep_translate(pep_ctx *ctx, int force)
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     // (the two timing events live as long as the context)
     if (!ctx->k1_t0 && (hipEventCreate(&ctx->k1_t0) != hipSuccess || hipEventCreate(&ctx->k1_t1) != hipSuccess)) { ctx->k1_t0 = ctx->k1_t1 = nullptr; }
-    if (ctx->k1_t0) (void)hipEventRecord(ctx->k1_t0, ctx->stream);
-    // both sides are queued first (reference, then queries); the reference's host-side tables are built while the query kernels run
+    // both sides are queued first (reference, then queries); the reference's summary is taken while the query kernels run
     ctx->resid_from_nucl = false;           // (pep_use_nt_as_residues left q_ready / t_ready false: K1 runs again)
     const bool do_q = ctx->q_from_nt && (force || !ctx->q_ready), do_t = ctx->t_from_nt && (force || !ctx->t_ready);
+    if (!do_q && !do_t) return PEP_OK;       // nothing to translate (pep_search calls this every time): no events, no waiting
+    if (ctx->k1_t0) (void)hipEventRecord(ctx->k1_t0, ctx->stream);
     if (do_t) PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable, 1));
     if (do_q) PEP_TRY(pep_k1_query(ctx, ctx->q_gtable, 1));
     if (do_t) { PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable, 2)); ctx->t_ready = true; }
@@ -523,6 +524,7 @@ int pep_get_query_meta(pep_ctx *ctx, pep_query_meta *out, uint32_t cap)
 int pep_get_target_meta(pep_ctx *ctx, pep_target_meta *out, uint32_t cap)
 {
     if (!ctx || !(ctx->t_ready || ctx->resid_from_nucl)) return pep_fail(ctx, PEP_ERR_STATE, "targets not set / not translated");
+    PEP_TRY(pep_k1_host_tables(ctx));
     if (cap < ctx->t_meta.size()) return pep_fail(ctx, PEP_ERR_ARG, "output buffer too small");
     if (!ctx->t_meta.empty()) memcpy(out, ctx->t_meta.data(), ctx->t_meta.size() * sizeof(pep_target_meta));
     return PEP_OK;
@@ -559,6 +561,7 @@ static int build_t_class(pep_ctx *ctx)
     if (ctx->group_of_seq.empty()) return PEP_OK;
     const uint32_t n_seq = ctx->t_from_nt ? ctx->r_nt.n : ctx->t.n;
     if (ctx->group_of_seq.size() != n_seq) return pep_fail(ctx, PEP_ERR_ARG, "pep_set_target_groups: one group per reference sequence expected");
+    PEP_TRY(pep_k1_host_tables(ctx));
     const uint32_t nt = ctx->t.n, ns = (uint32_t)ctx->params.n_splits;
     std::vector<uint32_t> cls(nt + 1, 0u);
     uint32_t cur = 0xFFFFFFFFu, local = 0;

@@ -78,11 +78,12 @@ struct pep_ctx {
     size_t pin_small_used = 0;
     struct PendingRead { void *dst; size_t off, n; } pending[32];
     int n_pending = 0;
-    PinBuf pin_k1, pin_k1q, pin_k1n;        // grow-only: K1 descriptors of the reference / of the queries, the target count
+    PinBuf pin_k1, pin_k1q;                 // grow-only: K1 descriptors (+ the set's summary behind them) of the reference / of the queries
     hipEvent_t k1_event = nullptr;          // the point of the stream where the reference side's downloads have arrived
     hipEvent_t wait_event = nullptr;        // pep_stream_wait: marks the point of the stream the host is waiting for
     hipEvent_t k1_t0 = nullptr, k1_t1 = nullptr;   // pep_translate's timing pair (created once)
-    bool k1_count_pending = false;
+    uint32_t k1_desc_cap = 0;               // descriptor slots of the reference side's last K1 (the summary sits behind them in pin_k1)
+    bool t_tables_lazy = false;             // the reference side's host tables (t_meta, h_off, h_len) have not been built from pin_k1 yet (pep_k1_host_tables)
     PinBuf pin_stage;                       // grow-only: the hit table of the newest search
     PinBuf pin_ms;                          // grow-only: per-query score thresholds on their way to the device
     pep_result *staged_result = nullptr;    // the result whose hits still live in pin_stage (materialised before it is overwritten)
@@ -117,8 +118,6 @@ struct pep_ctx {
     // the middle of a search costs a host round trip with the GPU idle, and lets nothing be queued behind a running SW pass)
     hipEvent_t tm_a[12] = {}, tm_b[12] = {};
     int tm_state[12] = {};                   // 0 idle, 1 begun, 2 ended (waiting to be read)
-    unsigned long long sw_totals[2] = {};   // score pass: cells / 16-step blocks, read back with the next synchronisation
-    bool sw_totals_pending = false;
     uint64_t trace_swept = 0;               // pairs the last traceback pass swept (the rest were settled by the gapless shortcut)
     struct ScanState { DevBuf buf; uint32_t epoch = 0, ticket_base = 0; };
     ScanState scan_state[2];                // single-launch scans (u32, u64): ticket counter + one status word per tile (scan.hip)
@@ -214,8 +213,9 @@ enum { PEP_ZC_SW_SCORE = 0, PEP_ZC_SW_TRACE, PEP_ZC_SELECT, PEP_ZC_SORT };
 int pep_zero_block(pep_ctx *ctx, int which, size_t offset, size_t bytes, void **out);
 
 // ---- scan.hip
-int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp);   // exclusive; d_out[n] = total (n+1 outputs)
-int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp);
+// exclusive; d_out[n] = total (n+1 outputs); d_total (optional): a second place the total is written to (a counter block the host reads in one copy)
+int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp, uint32_t *d_total = nullptr);
+int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp, uint64_t *d_total = nullptr);
 // ---- sort.hip
 // the dense candidate-key form q | t | bin - bin_min (tb / bb bits for t / bin) <-> q:21 | t:25 | bin:18 (seeds.hip); on = 0: keys pass unchanged
 struct pep_key_unpack { int on, tb, bb; uint32_t bin_min; };
@@ -224,12 +224,14 @@ int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, const uint32_t
 // ---- translate.hip  (K1)
 int pep_k1_query(pep_ctx *ctx, int gtable, int phase = 0);
 int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase = 0);
+int pep_k1_host_tables(pep_ctx *ctx);      // builds the reference side's per-sequence host tables if its last K1 left them to be built on demand
 int pep_nucl_sets(pep_ctx *ctx, int strands);      // the nucleotide sets themselves as residue sets (base codes; reference: forward strands + reverse complements)
 // ---- seeds.hip  (K2-K4)
 int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands);
 int pep_upload_sub_table(pep_ctx *ctx);       // ctx->params.sub -> ctx->d_params (1 KiB, uploaded when it changed)
 // ---- sw.hip / trace.hip (K5, K6, K8)
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known = nullptr, const int32_t *d_end_lane = nullptr, const int32_t *d_skip_mode = nullptr);   // kernel time: phase timers TM_SW / TM_SW_TRACE
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known = nullptr, const int32_t *d_end_lane = nullptr, const int32_t *d_skip_mode = nullptr,
+               const uint32_t *d_n = nullptr, uint64_t dir_blocks_bound = 0, unsigned long long **d_hdr = nullptr);   // kernel time: phase timers TM_SW / TM_SW_TRACE
 int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n_cands, const int32_t *h_min_score, pep_result *res);
 int pep_selftest_dpp(pep_ctx *ctx);
 // ---- rescore.hip (K7)

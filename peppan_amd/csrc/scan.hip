@@ -109,7 +109,8 @@ template <> struct ScanWord<uint32_t> { static constexpr int VB = 32; static con
 template <> struct ScanWord<uint64_t> { static constexpr int VB = 48; static constexpr uint32_t EPOCH_MASK = (1u << 14) - 1; };
 
 template <class T>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_lookback(const T *in, T *out, uint64_t n, uint32_t nb, uint64_t *state, uint32_t ticket_base, uint64_t epoch)
+__global__ __launch_bounds__(SCAN_THREADS) void scan_lookback(const T *in, T *out, uint64_t n, uint32_t nb, uint64_t *state, uint32_t ticket_base, uint64_t epoch,
+                                                              T *total_out)
 {
     constexpr int VB = ScanWord<T>::VB;
     constexpr uint64_t VMASK = (1ull << VB) - 1;
@@ -161,11 +162,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_lookback(const T *in, T *ou
         if (base + k < n) out[base + k] = ex;
         ex += v[k];
     }
-    if (tile == nb - 1 && threadIdx.x == SCAN_THREADS - 1) out[n] = ex;
+    if (tile == nb - 1 && threadIdx.x == SCAN_THREADS - 1) { out[n] = ex; if (total_out) *total_out = ex; }
 }
 
 template <class T>
-int scan_onepass(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n)
+int scan_onepass(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n, T *d_total)
 {
     const uint64_t nb = ceil_div(n, SCAN_TILE);
     pep_ctx::ScanState &S = ctx->scan_state[sizeof(T) == 8];       // one state area per width: the two word layouts must never meet
@@ -182,17 +183,18 @@ int scan_onepass(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n)
         S.ticket_base = 0;
     }
     hipLaunchKernelGGL(scan_lookback<T>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, n, (uint32_t)nb, S.buf.as<uint64_t>(), S.ticket_base,
-                       (uint64_t)S.epoch);
+                       (uint64_t)S.epoch, d_total);
     S.ticket_base += (uint32_t)nb;
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }
 
 template <class T>
-int scan_impl(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n, DevBuf &tmp)
+int scan_impl(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n, DevBuf &tmp, T *d_total)
 {
     if (n == 0) {
         PEP_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(T), ctx->stream));
+        if (d_total) PEP_HIP(ctx, hipMemsetAsync(d_total, 0, sizeof(T), ctx->stream));
         return PEP_OK;
     }
     const uint64_t nb = ceil_div(n, SCAN_TILE);
@@ -201,22 +203,23 @@ int scan_impl(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n, DevBuf &tmp)
     hipLaunchKernelGGL(scan_reduce<T>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_in, partial, n);
     hipLaunchKernelGGL(scan_partials<T>, dim3(1), dim3(SCAN_THREADS), 0, ctx->stream, partial, nb);
     hipLaunchKernelGGL(scan_apply<T>, dim3((unsigned)nb), dim3(SCAN_THREADS), 0, ctx->stream, d_in, d_out, (const T *)partial, n, nb);
+    if (d_total) PEP_HIP(ctx, hipMemcpyAsync(d_total, d_out + n, sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }
 
 }  // namespace
 
-int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp)
+int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp, uint32_t *d_total)
 {
-    if (n == 0 || n >= (1ull << 40)) return scan_impl<uint32_t>(ctx, d_in, d_out, n, tmp);
-    return scan_onepass<uint32_t>(ctx, d_in, d_out, n);
+    if (n == 0 || n >= (1ull << 40)) return scan_impl<uint32_t>(ctx, d_in, d_out, n, tmp, d_total);
+    return scan_onepass<uint32_t>(ctx, d_in, d_out, n, d_total);
 }
 
 // the single launch carries 48-bit sums; callers whose totals could pass 2^48 say so (none does: the u64 scans add up block, run and
 // CIGAR counts of one search)
-int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp)
+int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp, uint64_t *d_total)
 {
-    if (n == 0 || n >= (1ull << 40)) return scan_impl<uint64_t>(ctx, d_in, d_out, n, tmp);
-    return scan_onepass<uint64_t>(ctx, d_in, d_out, n);
+    if (n == 0 || n >= (1ull << 40)) return scan_impl<uint64_t>(ctx, d_in, d_out, n, tmp, d_total);
+    return scan_onepass<uint64_t>(ctx, d_in, d_out, n, d_total);
 }

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void idx_slab(SeedShape sh, const uint8_t *__r
 // start[c << F .. (c + 1) << F), filter slice
 __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ part, const uint32_t *__restrict__ coarse_cnt, int bucket_bits,
                                                   int fine_bits, uint32_t *__restrict__ start, uint64_t *__restrict__ entries,
-                                                  unsigned long long *__restrict__ filter, uint32_t *__restrict__ counters)
+                                                  unsigned long long *__restrict__ filter, uint32_t *__restrict__ counters, uint32_t *__restrict__ n_entries_out)
 {
     __shared__ uint32_t pos[4096];
     __shared__ unsigned long long fw[4096 >> FILTER_SHIFT];
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
     const uint32_t lo = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
     const uint32_t n = coarse_cnt[c];
     __syncthreads();                                           // wave_sum is used again below
-    if (c == n_coarse - 1 && threadIdx.x == 0) start[(size_t)n_coarse << fine_bits] = lo + n;
+    if (c == n_coarse - 1 && threadIdx.x == 0) { start[(size_t)n_coarse << fine_bits] = lo + n; *n_entries_out = lo + n; }      // (the second copy: read back with the search's counters)
     if (n > PART_CAP) {
         // the host falls back to count -> scan -> fill, but the matcher of THIS attempt still runs: leave it well-formed (empty) buckets and
         // filter words instead of whatever the buffers held before
@@ -287,9 +287,10 @@ __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ p
 
 // the filter for an index built the plain way (count -> scan -> fill): every entry sets its two bits (filter zeroed by the caller)
 __global__ __launch_bounds__(256) void filter_fill(const uint64_t *__restrict__ entries, const uint32_t *__restrict__ n_entries, int bucket_bits,
-                                                   unsigned long long *__restrict__ filter)
+                                                   unsigned long long *__restrict__ filter, uint32_t *__restrict__ n_entries_out)
 {
     const uint32_t n = *n_entries;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_entries_out = n;
     for (uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (uint64_t)gridDim.x * 256) {
         uint32_t word;
         const uint64_t m = filter_mask(entries[e] >> POS_BITS, bucket_bits, word);
@@ -721,7 +722,6 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         PEP_HIP(ctx, hipMemsetAsync(zero, 0, PEP_ZERO_TOTAL, ctx->stream));
         for (bool &f : ctx->zero_ok) f = true;
         uint64_t q_seeds = 0;
-        uint32_t h_nseed[4] = {0, 0, 0, 0};
         for (int s = 0; s < P.n_shapes; ++s) {
             SeedShape sh;
             sh.weight = P.weight[s];
@@ -763,7 +763,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
                 uint32_t *coarse = reinterpret_cast<uint32_t *>(zero + PEP_ZERO_COARSE) + (size_t)s * 8192;       // (cleared by the search's one fill)
                 PEP_SEED_DISPATCH_LDS(idx_slab, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, coarse, part, tiles, counters);
                 hipLaunchKernelGGL(idx_finish, dim3(n_coarse), dim3(256), 0, ctx->stream, (const uint64_t *)part, (const uint32_t *)coarse, bucket_bits, fine_bits,
-                                   start, entries, filter, counters);
+                                   start, entries, filter, counters, counters + 10 + s);
             } else {
                 PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
                 PEP_SEED_DISPATCH(seed_count, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, cnt, bucket_bits);
@@ -771,7 +771,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
                 PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
                 PEP_SEED_DISPATCH(seed_fill, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, (const uint32_t *)start, cnt, entries, bucket_bits);
                 PEP_HIP(ctx, hipMemsetAsync(filter, 0, (n_buckets >> FILTER_SHIFT) * 8, ctx->stream));
-                hipLaunchKernelGGL(filter_fill, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)entries, (const uint32_t *)(start + n_buckets), bucket_bits, filter);
+                hipLaunchKernelGGL(filter_fill, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)entries, (const uint32_t *)(start + n_buckets), bucket_bits, filter, counters + 10 + s);
             }
             JoinArgs a;
             a.t_res = T.res.as<const uint8_t>(); a.t_total = T.total; a.t_off = T.off.as<const uint32_t>(); a.nt = T.n;
@@ -789,7 +789,6 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
             hipLaunchKernelGGL(seed_extend, dim3(256u * 16u), dim3(256), 0, ctx->stream, a, (const uint64_t *)run_first, (const uint32_t *)run_len,
                                (const uint64_t *)run_key, (const unsigned long long *)n_runs);
             PEP_HIP(ctx, hipGetLastError());
-            PEP_TRY(pep_read_back(ctx, &h_nseed[s], start + n_buckets, sizeof(uint32_t)));
         }
         // field widths of the dense key form (see keys_pack)
         const uint32_t bin_min = (uint32_t)(((1 << 23) - (int)std::max<uint32_t>(Q.max_len, 1u) + 1) >> 6);
@@ -798,8 +797,8 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256 * COMPACT_ROUNDS)), dim3(256), 0, ctx->stream, ctx->d_set.as<uint64_t>(), cap,
                            ctx->ws[4].as<uint64_t>(), list_cap, counters, tb, bb, bin_min);
         ctx->set_clean_slots = cap;
-        struct { uint32_t counters[4]; unsigned long long stats[3]; } h_all;        // counters[0..3] and the three statistics words behind them: one copy
-        static_assert(sizeof(h_all) == 40, "layout of the counter block");
+        struct { uint32_t counters[4]; unsigned long long stats[3]; uint32_t n_entries[4]; } h_all;     // counters[0..3], the three statistics words and the index sizes per shape: one copy
+        static_assert(sizeof(h_all) == 56 && sizeof(h_all) <= 64, "layout of the counter block");
         PEP_TRY(pep_read_back(ctx, &h_all, counters, sizeof(h_all)));
         PEP_TRY(pep_sync_reads(ctx));
         const uint32_t *h_counters = h_all.counters;
@@ -807,7 +806,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         if (h_counters[3]) { use_partition = false; continue; }       // a coarse index bucket did not fit LDS: rebuild the plain way
         if (h_counters[2]) { hit_cap *= 4; continue; }                // raw hit buffer too small: retry 4x larger
         if (h_counters[1] || h_counters[0] > list_cap) { table_bits += 2; continue; }     // set too small: retry 4x larger
-        for (int s = 0; s < P.n_shapes; ++s) q_seeds += h_nseed[s];
+        for (int s = 0; s < P.n_shapes; ++s) q_seeds += h_all.n_entries[s];
         ctx->stats.query_seeds = q_seeds;
         ctx->stats.target_seeds = h_stats[0];
         ctx->stats.seed_hits = h_stats[1];

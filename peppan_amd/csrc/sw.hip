@@ -48,10 +48,8 @@ struct SwArgs {
     const uint32_t *order;         // candidates by decreasing length (sw_order): item w of a launch is order[w] (order[2w], order[2w+1] packed)
     const int32_t *end_lane;       // traceback pass: per candidate the lowest lane (diagonal pair) of the score pass that reached the score
     int32_t *mode;                 // traceback pass, out: first lane L0 of the 64-diagonal sub-band the codes were written for, -1 = the full band
-    unsigned int *queue;           // traceback pass: next item to hand out (the resident wavefronts pull their work from this counter)
-    uint64_t item_first;           // traceback pass: this launch covers order[item_first .. item_first + item_count), item_span candidates per item
-    uint64_t item_count;
-    int item_span;                 // 4: packed sub-band sweep of four candidates, 1: one candidate per wavefront (pairs too long for the staging area)
+    unsigned long long *counts;    // traceback pass: the pass's counter block, filled by sw_prep - [3] candidates too long for the four-candidate sweep (a prefix of
+                                   // the order), [5] candidates in the order; [2] and [4] are the work queues of the two parts (the resident wavefronts pull their items from them)
 };
 
 // The traceback of a band is taken in the 64-diagonal sub-band around the lane in which the score pass met the band's score (lanes
@@ -600,57 +598,68 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
     // With one item per wavefront and a block per eight items the 80 KB of LDS a block holds came free only when its slowest
     // wavefront was done: 2.8 of 4 wavefronts per SIMD on average and 64 % VALU utilisation (SQ_WAVE_CYCLES / SQ_INSTS_VALU,
     // profiles/r02_pmc_counters.txt).  The items are sorted by decreasing length, so the tail of the queue is its shortest work.
-    const uint64_t n_items = (a.item_count + a.item_span - 1) / a.item_span;
-    for (;;) {
-        unsigned int wq = 0;
-        if (lane == 0) wq = atomicAdd(a.queue, 1u);
-        const uint64_t w = (uint64_t)__builtin_amdgcn_readfirstlane((int)wq);
-        if (w >= n_items) break;
-        uint64_t cc[4];
-        int n_own = 0;                                       // candidates of this item (the last item may hold fewer than four)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const uint64_t k = (uint64_t)a.item_span * w + x;
-            const bool own = x < a.item_span && k < a.item_count;
-            cc[x] = a.order[a.item_first + min(k, a.item_count - 1)];
-            n_own += own ? 1 : 0;
-        }
-        bool packed = a.pk16 && a.known && a.end_lane && n_own == 4;
-        SubGeom gg[4];
-        int L0[4];
-        if (packed) {
-            int nb = 0;
+    // The counts live on the device (sw_prep wrote them): the host queues this launch without having seen them.  Part 0 = the prefix of the
+    // order that is too long for the staging area, one candidate per item; part 1 = the rest, four candidates per item.
+    const uint64_t n_active = a.counts[5];
+    const uint64_t n_long = a.pk16 ? min((uint64_t)a.counts[3], n_active) : n_active;
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+        const uint64_t item_first = part ? n_long : 0, item_count = part ? n_active - n_long : n_long;
+        const int item_span = part ? 4 : 1;
+        unsigned int *queue = reinterpret_cast<unsigned int *>(a.counts + (part ? 4 : 2));
+        if (item_count == 0) continue;
+        const uint64_t n_items = (item_count + item_span - 1) / item_span;
+        for (;;) {
+            unsigned int wq = 0;
+            if (lane == 0) wq = atomicAdd(queue, 1u);
+            const uint64_t w = (uint64_t)__builtin_amdgcn_readfirstlane((int)wq);
+            if (w >= n_items) break;
+            uint64_t cc[4];
+            int n_own = 0;                                       // candidates of this item (the last item may hold fewer than four)
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                const CandGeom g = cand_geom(a, cc[x]);
-                L0[x] = sub_band_first_lane(a.end_lane[cc[x]]);
-                gg[x] = sub_geom(g, L0[x]);
-                nb = max(nb, gg[x].nblk);
-                packed = packed && fits16(g, a.max_sub) && a.known[cc[x]] > 0;
+                const uint64_t k = (uint64_t)item_span * w + x;
+                const bool own = x < item_span && k < item_count;
+                cc[x] = a.order[item_first + min(k, item_count - 1)];
+                n_own += own ? 1 : 0;
             }
-            packed = packed && 8 * 2 * ((8 * nb + SUB_LANES + 16 + 7) & ~7) <= a.lds_res_bytes && nb < 2040;
-        }
-        if (packed) {
-            bool ok[4];
-            sw_four_pk16_trace(a, cc, gg, L0, ok, smem, lds_res, lane);
-#pragma unroll 1
-            for (int x = 0; x < 4; ++x)
-                if (!ok[x]) {                                // left its sub-band: once more in the full band
-                    const uint64_t c = cc[x];
-                    const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
-                    if (need1 <= a.lds_res_bytes) sw_one<true, true>(a, c, smem, lds_res, lane, -1);
-                    else sw_one<false, true>(a, c, smem, lds_res, lane, -1);
-                    if (lane == 0) a.mode[c] = -1;
+            bool packed = a.pk16 && a.known && a.end_lane && n_own == 4;
+            SubGeom gg[4];
+            int L0[4];
+            if (packed) {
+                int nb = 0;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const CandGeom g = cand_geom(a, cc[x]);
+                    L0[x] = sub_band_first_lane(a.end_lane[cc[x]]);
+                    gg[x] = sub_geom(g, L0[x]);
+                    nb = max(nb, gg[x].nblk);
+                    packed = packed && fits16(g, a.max_sub) && a.known[cc[x]] > 0;
                 }
-        } else {
+                packed = packed && 8 * 2 * ((8 * nb + SUB_LANES + 16 + 7) & ~7) <= a.lds_res_bytes && nb < 2040;
+            }
+            if (packed) {
+                bool ok[4];
+                sw_four_pk16_trace(a, cc, gg, L0, ok, smem, lds_res, lane);
 #pragma unroll 1
-            for (int x = 0; x < n_own; ++x) one(cc[x]);
+                for (int x = 0; x < 4; ++x)
+                    if (!ok[x]) {                                // left its sub-band: once more in the full band
+                        const uint64_t c = cc[x];
+                        const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
+                        if (need1 <= a.lds_res_bytes) sw_one<true, true>(a, c, smem, lds_res, lane, -1);
+                        else sw_one<false, true>(a, c, smem, lds_res, lane, -1);
+                        if (lane == 0) a.mode[c] = -1;
+                    }
+            } else {
+#pragma unroll 1
+                for (int x = 0; x < n_own; ++x) one(cc[x]);
+            }
         }
     }
 }
 
 // per candidate: number of 8-step blocks and the exact count of in-band in-matrix cells
-__global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cands, uint64_t n, const uint32_t *__restrict__ q_len,
+__global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cands, uint64_t n_host, const uint32_t *__restrict__ d_n, const uint32_t *__restrict__ q_len,
                                                const uint32_t *__restrict__ t_len, uint32_t *__restrict__ nblk, uint64_t *__restrict__ nblk64,
                                                unsigned long long *__restrict__ cells_total,           // [0] cells, [1] 16-step blocks, [3] candidates above nb_limit
                                                uint32_t *__restrict__ len_hist,                        // [LEN_BUCKETS] candidates per length bucket
@@ -660,6 +669,7 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
     __shared__ uint32_t lh[LEN_BUCKETS];
     for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) lh[x] = 0;
     __syncthreads();
+    const uint64_t n = d_n ? (uint64_t)*d_n : n_host;          // (the grid is sized from n_host, an upper bound, when the count lives on the device)
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     unsigned long long cells = 0, blocks = 0;
     bool is_long = false;
@@ -707,7 +717,7 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
 // candidates in the order of decreasing length bucket (counting sort over sw_prep's histogram; the order inside a bucket is whatever the
 // atomics hand out - results are per candidate, so it does not matter).  Equal lengths side by side keep both halves of a packed
 // wavefront busy to the end; longest first keeps the tail of the launch short.
-__global__ __launch_bounds__(256) void sw_order(const uint32_t *__restrict__ nblk, uint64_t n, const uint32_t *__restrict__ len_hist,
+__global__ __launch_bounds__(256) void sw_order(const uint32_t *__restrict__ nblk, uint64_t n_host, const uint32_t *__restrict__ d_n, const uint32_t *__restrict__ len_hist,
                                                 uint32_t *__restrict__ cursor, uint32_t *__restrict__ order, const int32_t *__restrict__ skip_mode)
 {
     __shared__ uint32_t start[LEN_BUCKETS], lh[LEN_BUCKETS], base[LEN_BUCKETS], part[256];
@@ -727,6 +737,7 @@ __global__ __launch_bounds__(256) void sw_order(const uint32_t *__restrict__ nbl
     uint32_t run = part[threadIdx.x] - sum;
 #pragma unroll
     for (int k = 0; k < LEN_BUCKETS / 256; ++k) { start[LEN_BUCKETS - 1 - (threadIdx.x * (LEN_BUCKETS / 256) + k)] = run; run += mine[k]; }
+    const uint64_t n = d_n ? (uint64_t)*d_n : n_host;
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     uint32_t b = 0, rank = 0;
     const bool active = c < n && !(skip_mode && skip_mode[c] == -2);
@@ -762,9 +773,15 @@ int pep_selftest_dpp(pep_ctx *ctx)
 
 // Runs K5 over `n` candidate keys.  trace = false: score pass (ws[12] <- score / end cell / a0 per candidate).
 // trace = true: same DP plus traceback codes (ws[11] dir_off u64[n+1], ws[13] dirs).  ws[10] nblk, ws[14] scan input.
-int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known, const int32_t *d_end_lane, const int32_t *d_skip_mode)
+// d_n (traceback pass, optional): the number of candidates lives on the device and `n` is an upper bound of it (grids and buffers are
+// sized from the bound).  dir_blocks_bound (traceback pass, optional): an upper bound of the pass's 16-step blocks - with it the traceback
+// area is sized without the host ever seeing the totals (no synchronisation in here; the caller reads the counter block *d_hdr -
+// [0] cells, [1] 16-step blocks, [3] long candidates, [5] candidates swept - whenever it synchronises next); 0 = read them here.
+int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known, const int32_t *d_end_lane, const int32_t *d_skip_mode,
+               const uint32_t *d_n, uint64_t dir_blocks_bound, unsigned long long **d_hdr)
 {
     const pep_search_params &P = ctx->params;
+    if (d_hdr) *d_hdr = nullptr;
     if (n == 0) return PEP_OK;
     PEP_TRY(dev_reserve(ctx, ctx->ws[10], (n + 1) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[11], (n + 2) * sizeof(uint64_t)));
@@ -788,41 +805,33 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     }
     // counter block of this pass (d_zero): [0..63] totals (cells, 16-step blocks, work-queue counters, candidates above nb_limit, candidates in
     // the order), [64..) length histogram, then the scatter cursors; ws[15]: the order itself
-    const size_t hist_bytes = LEN_BUCKETS * sizeof(uint32_t);
     static_assert(PEP_ZERO_SW_BYTES == 64 + 2 * LEN_BUCKETS * sizeof(uint32_t), "counter block of a Smith-Waterman pass");
     void *zb = nullptr;
     PEP_TRY(pep_zero_block(ctx, trace ? PEP_ZC_SW_TRACE : PEP_ZC_SW_SCORE, trace ? PEP_ZERO_SW_TRACE : PEP_ZERO_SW_SCORE, PEP_ZERO_SW_BYTES, &zb));
     PEP_TRY(dev_reserve(ctx, ctx->ws[15], (n + 1) * sizeof(uint32_t)));
     unsigned long long *cells = reinterpret_cast<unsigned long long *>(zb);
+    if (d_hdr) *d_hdr = cells;
     uint32_t *len_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(zb) + 64), *cursor = len_hist + LEN_BUCKETS, *order = ctx->ws[15].as<uint32_t>();
-    (void)hist_bytes;
-    hipLaunchKernelGGL(sw_prep, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_cands, n, ctx->q.len.as<const uint32_t>(),
+    hipLaunchKernelGGL(sw_prep, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_cands, n, trace ? d_n : nullptr, ctx->q.len.as<const uint32_t>(),
                        ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist, nb_limit, trace ? d_skip_mode : nullptr);
-    hipLaunchKernelGGL(sw_order, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[10].as<const uint32_t>(), n,
+    hipLaunchKernelGGL(sw_order, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[10].as<const uint32_t>(), n, trace ? d_n : nullptr,
                        (const uint32_t *)len_hist, cursor, order, trace ? d_skip_mode : nullptr);
-    unsigned long long n_long = 0;
-    uint64_t n_active = n;                  // candidates in `order` (traceback pass: those the gapless shortcut did not settle)
     if (trace) {
-        // the traceback area is sized from the block total, so the host has to see it before the launch; the score pass needs neither
-        // the per-candidate offsets nor the totals up front (they reach the statistics with the next synchronisation, see pep_extend)
-        unsigned long long h_tot[6] = {0, 0, 0, 0, 0, 0};      // cells, 16-step blocks, (work-queue counter), candidates above nb_limit, (queue), candidates in the order: one copy
-        PEP_TRY(pep_read_back(ctx, h_tot, cells, sizeof(h_tot)));
         PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
-        PEP_TRY(pep_sync_reads(ctx));
-        const unsigned long long h_cells = h_tot[0];
-        const uint64_t total_blk = h_tot[1];
-        n_long = h_tot[3];
-        n_active = h_tot[5];
-        ctx->trace_swept = n_active;
-        ctx->stats.cells_trace += h_cells;
-        ctx->stats.cells_swept_trace += total_blk * 16 * 64;
-        ctx->stats.dir_bytes += total_blk * 512;
+        uint64_t total_blk = dir_blocks_bound;
+        if (!dir_blocks_bound) {
+            // the traceback area is sized from the block total: the host has to see it before the launch
+            unsigned long long h_tot[6] = {0, 0, 0, 0, 0, 0};      // cells, 16-step blocks, (work-queue counter), candidates above nb_limit, (queue), candidates in the order: one copy
+            PEP_TRY(pep_read_back(ctx, h_tot, cells, sizeof(h_tot)));
+            PEP_TRY(pep_sync_reads(ctx));
+            total_blk = h_tot[1];
+            ctx->trace_swept = h_tot[5];
+            ctx->stats.cells_trace += h_tot[0];
+            ctx->stats.cells_swept_trace += total_blk * 16 * 64;
+            ctx->stats.dir_bytes += total_blk * 512;
+        }
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 512 + 512));
         PEP_TRY(dev_reserve(ctx, ctx->d_trace_mode, (n + 1) * sizeof(int32_t)));
-        if (!pk16) n_long = n_active;
-    } else {
-        PEP_TRY(pep_read_back(ctx, ctx->sw_totals, cells, 16));
-        ctx->sw_totals_pending = true;
     }
 
     SwArgs a;
@@ -838,7 +847,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     a.known = trace ? d_known : nullptr;
     a.end_lane = trace ? d_end_lane : nullptr;
     a.mode = trace ? ctx->d_trace_mode.as<int32_t>() : nullptr;
-    a.queue = nullptr; a.item_first = 0; a.item_count = 0; a.item_span = 4;
+    a.counts = cells;
     a.order = order;
     a.max_sub = 1;
     for (int x = 0; x < 32 * 32; ++x) a.max_sub = std::max(a.max_sub, (int)P.sub[x]);
@@ -846,21 +855,14 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
     pep_timer_begin(ctx, trace ? TM_SW_TRACE : TM_SW);
     if (trace) {
-        // resident blocks only: every wavefront pulls its next item from a counter.  160 KB of LDS and four wavefronts per SIMD (the
-        // kernel's launch bound) per CU
+        // resident blocks only: every wavefront pulls its next item from a counter, first the candidates that are too long for the
+        // four-candidate sweep (one per wavefront), then the rest; the counts are read from the pass's counter block on the device.
+        // 160 KB of LDS and four wavefronts per SIMD (the kernel's launch bound) per CU
         int n_cu = 256;
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
         const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16 / WAVES_PER_BLOCK, (160 * 1024) / std::max<size_t>(smem, 1)));
-        struct { uint64_t first, count; int span; unsigned int *queue; } part[2] = {
-            {0, (uint64_t)std::min<unsigned long long>(n_long, n_active), 1, reinterpret_cast<unsigned int *>(cells + 2)},          // too long for the staging area: one per wavefront
-            {(uint64_t)std::min<unsigned long long>(n_long, n_active), n_active - (uint64_t)std::min<unsigned long long>(n_long, n_active), 4, reinterpret_cast<unsigned int *>(cells + 4)}};
-        for (const auto &pt : part) {
-            if (pt.count == 0) continue;
-            a.item_first = pt.first; a.item_count = pt.count; a.item_span = pt.span; a.queue = pt.queue;
-            const uint64_t items = ceil_div(ceil_div(pt.count, (uint64_t)pt.span), WAVES_PER_BLOCK);
-            const unsigned grid = (unsigned)std::min<uint64_t>(items, (uint64_t)n_cu * per_cu);
-            hipLaunchKernelGGL(sw_trace_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
-        }
+        const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(n, WAVES_PER_BLOCK), (uint64_t)n_cu * per_cu);        // (one candidate per item at worst)
+        hipLaunchKernelGGL(sw_trace_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     } else {
         // one item (a packed candidate pair, or one candidate) per wavefront: the hardware's block dispatcher balances the load better than a
         // grid-stride loop inside fewer blocks (score pass 0.82 -> 0.80 ms on the benchmark), and the 16 KiB table load per block comes out

@@ -50,9 +50,12 @@ __global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__
                                                   const uint32_t *__restrict__ best_idx, const int4 *__restrict__ sw,
                                                   const uint64_t *__restrict__ cands, const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len,
                                                   SelInfo *__restrict__ sel, uint64_t *__restrict__ run_cap, uint64_t *__restrict__ sel_keys,
-                                                  int32_t *__restrict__ known, int32_t *__restrict__ end_lane)
+                                                  int32_t *__restrict__ known, int32_t *__restrict__ end_lane, uint64_t n_bound)
 {
     const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    // the arrays of the selected pairs are sized from n_bound >= pos[n] (the host may not have seen the count): the scan over run_cap runs
+    // over n_bound entries, so the ones behind the last selected pair are zero
+    if (c < n_bound && c >= pos[n]) run_cap[c] = 0;
     if (c >= n || !flag[c]) return;
     const uint32_t b = best_idx[c];
     SelInfo s;
@@ -89,7 +92,7 @@ __device__ __forceinline__ int wave_scan_incl(int v, const int identity, Op op)
     return v;
 }
 
-__global__ __launch_bounds__(256) void gapless_check(uint64_t n_sel, const uint64_t *__restrict__ cands, const int32_t *__restrict__ known,
+__global__ __launch_bounds__(256) void gapless_check(const uint32_t *__restrict__ d_n_sel, const uint64_t *__restrict__ cands, const int32_t *__restrict__ known,
                                                      const int32_t *__restrict__ end_lane, const uint8_t *__restrict__ q_res, const uint32_t *__restrict__ q_off,
                                                      const uint32_t *__restrict__ q_len, const uint8_t *__restrict__ t_res, const uint32_t *__restrict__ t_off,
                                                      const uint32_t *__restrict__ t_len, const int8_t *__restrict__ sub_g, int4 *__restrict__ out,
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void gapless_check(uint64_t n_sel, const uint6
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= n_sel) return;                                     // (whole wavefronts leave together)
+    if (s >= *d_n_sel) return;                                  // (whole wavefronts leave together; the grid is sized from an upper bound)
     const uint64_t key = cands[s];
     const uint32_t q = key_q(key), t = key_t(key);
     const int T = known[s];
@@ -173,12 +176,12 @@ __global__ __launch_bounds__(256) void gapless_check(uint64_t n_sel, const uint6
 // iterations does not work: rotating the word registers reads them, which makes the compiler wait for every outstanding load.)
 #define WALK_AHEAD 8
 #define WALK_LANES 64         // alignments per wavefront: few, so that many wavefronts overlap their load latencies (see above)
-__global__ __launch_bounds__(WALK_LANES) void walk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
+__global__ __launch_bounds__(WALK_LANES) void walk(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
                                            const uint64_t *__restrict__ dir_off, const uint32_t *__restrict__ dirs, const int32_t *__restrict__ mode,
                                            const uint64_t *__restrict__ run_off, uint32_t *__restrict__ runs)
 {
     const uint64_t s = (uint64_t)blockIdx.x * WALK_LANES + threadIdx.x;
-    if (s >= n_sel) return;
+    if (s >= *d_n_sel) return;
     SelInfo info = sel[s];
     const uint64_t key = cands[info.cand];
     // the codes cover the full band (64 lanes, mode -1) or the sub-band that starts at lane mode[] (32 lanes): the row of one 16-step
@@ -279,14 +282,14 @@ __global__ __launch_bounds__(WALK_LANES) void walk(uint64_t n_sel, SelInfo *__re
 // 38 k wavefronts that each lived for a chain of dependent loads: 0.039 ms; two pairs per wavefront: 0.031 ms, four: 0.030 ms but
 // slower once alignments are long)
 constexpr int FIN_LANES = 32;
-__global__ __launch_bounds__(256) void finalize(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands,
+__global__ __launch_bounds__(256) void finalize(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands,
                                                 const uint8_t *__restrict__ q_res, const uint32_t *__restrict__ q_off, const uint32_t *__restrict__ q_len,
                                                 const uint8_t *__restrict__ t_res, const uint32_t *__restrict__ t_off,
                                                 const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ runs, double min_id_pct, double min_qcov_pct)
 {
     const int lane = threadIdx.x & (FIN_LANES - 1);
     const uint64_t s = (uint64_t)blockIdx.x * (256 / FIN_LANES) + threadIdx.x / FIN_LANES;
-    if (s >= n_sel) return;                                   // (whole lane groups leave together)
+    if (s >= *d_n_sel) return;                                // (whole lane groups leave together)
     const SelInfo info = sel[s];
     const uint64_t key = cands[info.cand];
     const uint32_t q = key_q(key), t = key_t(key);
@@ -315,8 +318,9 @@ __global__ __launch_bounds__(256) void finalize(uint64_t n_sel, SelInfo *__restr
 
 // hsp_mode 1: two bands of one (q, t) that end in the same cell found the same alignment: keep the higher score, then the
 // lower bin (= lower index, sel is ordered by (q, t, bin)); the decision ignores whether the other one survives its filters
-__global__ __launch_bounds__(256) void dedupe_bands(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands)
+__global__ __launch_bounds__(256) void dedupe_bands(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands)
 {
+    const uint64_t n_sel = *d_n_sel;
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n_sel) return;
     const SelInfo me = sel[s];
@@ -332,20 +336,30 @@ __global__ __launch_bounds__(256) void dedupe_bands(uint64_t n_sel, SelInfo *__r
     if (dead) sel[s].pad = 1u;
 }
 
-__global__ __launch_bounds__(256) void apply_dedupe(uint64_t n_sel, SelInfo *__restrict__ sel)
+__global__ __launch_bounds__(256) void apply_dedupe(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel)
 {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s < n_sel && sel[s].pad) sel[s].pass = 0u;
+    if (s < *d_n_sel && sel[s].pad) sel[s].pass = 0u;
 }
 
 // rank inside (query, target mod n_splits): score desc, target asc, band asc.  sel is ordered by (q, t, bin).
 // t_class (optional): competition class of every target = group * n_splits + (index inside the group) % n_splits, so that a
 // batch of reference sets (genomes) searched at once ranks exactly as if each had been searched alone
-__global__ __launch_bounds__(256) void topk(uint64_t n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int top_k, int n_splits, uint32_t t_base,
-                                            const uint32_t *__restrict__ t_class, uint32_t *__restrict__ keep_flag, uint64_t *__restrict__ keep_runs)
+__global__ __launch_bounds__(256) void topk(const uint32_t *__restrict__ d_n_sel, uint64_t n_bound, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int top_k, int n_splits, uint32_t t_base,
+                                            const uint32_t *__restrict__ t_class, uint32_t *__restrict__ keep_flag, uint64_t *__restrict__ keep_runs,
+                                            const unsigned long long *__restrict__ score_hdr, const unsigned long long *__restrict__ trace_hdr, unsigned long long *__restrict__ mail)
 {
+    const uint64_t n_sel = *d_n_sel;
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= n_sel) return;
+    if (s == 0) {
+        // the totals of the two Smith-Waterman passes into the block the host reads with its last synchronisation (one copy for everything)
+        mail[4] = score_hdr[0]; mail[5] = score_hdr[1];
+        mail[6] = trace_hdr ? trace_hdr[0] : 0ull; mail[7] = trace_hdr ? trace_hdr[1] : 0ull; mail[8] = trace_hdr ? trace_hdr[5] : 0ull;
+    }
+    if (s >= n_sel) {
+        if (s < n_bound) { keep_flag[s] = 0; keep_runs[s] = 0; }      // the scans below run over n_bound entries
+        return;
+    }
     const SelInfo me = sel[s];
     uint32_t keep = 0;
     if (me.pass) {
@@ -406,6 +420,13 @@ __global__ __launch_bounds__(256) void emit(uint64_t n_sel, const SelInfo *__res
 
 // workspace slots: ws[16] flag, ws[17] pos, ws[18] best_idx, ws[19] sel, ws[20] run_cap/run_off (u64 x2) + selected keys,
 //                  ws[21] runs, ws[22] keep arrays, ws[23] output hits + cigar, ws[9] small counters
+//
+// Host round trips.  Between the seed stage's count of candidates and the sizes of the result (hits, CIGAR runs) the host does not need
+// to see anything: the number of selected pairs stays on the device (every kernel behind the selection reads it there and is launched on
+// a grid sized for all n candidates), the traceback area and the run arena are sized from upper bounds (every candidate selected, every
+// pair as long as the longest), and the statistics ride on the one read-back at the end.  When those bounds would cost more memory than
+// is sensible (FAST_DIR_BYTES / FAST_RUN_BYTES: long sequences times many candidates - searches that are long enough not to care about
+// two host round trips), or with params.reserved2 = 1 (tests), the stage synchronises after the selection and sizes everything exactly.
 int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t *h_min_score, pep_result *res)
 {
     const pep_search_params &P = ctx->params;
@@ -425,7 +446,8 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     PEP_TRY(pin_reserve(ctx, ctx->pin_ms, (size_t)(ctx->q.n + 1) * 4));
     std::memcpy(ctx->pin_ms.p, h_min_score, (size_t)ctx->q.n * 4);
     PEP_HIP(ctx, hipMemcpyAsync(dms.p, ctx->pin_ms.p, (size_t)ctx->q.n * 4, hipMemcpyHostToDevice, st));
-    PEP_TRY(pep_sw_run(ctx, d_cands, n, false));                   // (the pass times come from the context's phase timers, read after the search)
+    unsigned long long *score_hdr = nullptr, *trace_hdr = nullptr;
+    PEP_TRY(pep_sw_run(ctx, d_cands, n, false, nullptr, nullptr, nullptr, nullptr, 0, &score_hdr));      // (the pass times come from the context's phase timers, read after the search)
 
     pep_timer_begin(ctx, TM_TRACE);
 
@@ -434,100 +456,129 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     PEP_TRY(dev_reserve(ctx, ctx->ws[17], (n + 2) * 4));
     PEP_TRY(dev_reserve(ctx, ctx->ws[18], (n + 1) * 4));
     uint32_t *flag = ctx->ws[16].as<uint32_t>(), *pos = ctx->ws[17].as<uint32_t>(), *best_idx = ctx->ws[18].as<uint32_t>();
+    // the block the host reads: u32 [0] (q, t) pairs, [1] selected pairs, [2] hits; u64 [2] CIGAR runs of the hits, [3] run capacity of the selected
+    // pairs, [4] [5] cells / 16-step blocks of the score pass, [6] [7] [8] cells / blocks / swept pairs of the traceback pass
     void *zb = nullptr;
     PEP_TRY(pep_zero_block(ctx, PEP_ZC_SELECT, PEP_ZERO_SELECT, 256, &zb));
     uint32_t *counters = reinterpret_cast<uint32_t *>(zb);
+    unsigned long long *mail = reinterpret_cast<unsigned long long *>(zb);
+    const uint32_t *d_n_sel = counters + 1;
+    struct { uint32_t n_pairs, n_sel, n_hits, pad; unsigned long long n_cig, run_cap, score_cells, score_blocks, trace_cells, trace_blocks, trace_swept; } h_mail;
+    static_assert(sizeof(h_mail) == 72, "layout of the selection stage's counter block");
+    std::memset(&h_mail, 0, sizeof(h_mail));
     const unsigned gb = (unsigned)ceil_div(n, 256);
     hipLaunchKernelGGL(select_best, dim3(gb), dim3(256), 0, st, d_cands, n, sw, dms.as<const int32_t>(), flag, best_idx, counters, P.hsp_mode);
-    PEP_TRY(pep_scan_u32(ctx, flag, pos, n, ctx->ws[7]));
-    uint32_t n_sel = 0, n_pairs = 0;
-    PEP_TRY(pep_read_back(ctx, &n_sel, pos + n, 4));
-    PEP_TRY(pep_read_back(ctx, &n_pairs, counters, 4));
-    PEP_TRY(pep_sync_reads(ctx));
-    if (ctx->sw_totals_pending) {                // the score pass's totals arrived with this synchronisation
-        ctx->stats.cells += ctx->sw_totals[0];
-        ctx->stats.cells_swept += ctx->sw_totals[1] * 16 * 64;
-        ctx->sw_totals_pending = false;
+    PEP_TRY(pep_scan_u32(ctx, flag, pos, n, ctx->ws[7], counters + 1));
+    // upper bounds for the buffers of the traceback stage
+    constexpr uint64_t FAST_DIR_BYTES = 8ull << 30, FAST_RUN_BYTES = 2ull << 30;
+    const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 16 + 3;
+    const uint64_t dir_blocks_bound = n * max_blk, run_bound = n * (2ull * std::min(ctx->q.max_len, ctx->t.max_len) + 2);
+    const bool fast = P.reserved2 == 0 && dir_blocks_bound * 512 <= FAST_DIR_BYTES && run_bound * 4 <= FAST_RUN_BYTES;
+    uint64_t n_b = n;                            // what the buffers and grids behind the selection are sized for
+    if (!fast) {
+        PEP_TRY(pep_read_back(ctx, &h_mail, mail, 8));
+        PEP_TRY(pep_sync_reads(ctx));
+        n_b = h_mail.n_sel;
     }
-    ctx->stats.pairs = n_pairs;
-    ctx->stats.tracebacks = n_sel;
-    if (n_sel) {
-        PEP_TRY(dev_reserve(ctx, ctx->ws[19], (size_t)n_sel * sizeof(SelInfo)));
-        PEP_TRY(dev_reserve(ctx, ctx->ws[20], ((size_t)n_sel + 2) * 8 * 3));
-        PEP_TRY(dev_reserve(ctx, ctx->ws[8], ((size_t)n_sel + 2) * 4 * 2));      // ws[8]: raw seed hits of K4, free again
-        int32_t *known = ctx->ws[8].as<int32_t>(), *end_lane = known + n_sel + 2;
-        SelInfo *sel = ctx->ws[19].as<SelInfo>();
-        uint64_t *run_cap = ctx->ws[20].as<uint64_t>(), *run_off = run_cap + n_sel + 2, *sel_keys = run_off + n_sel + 2;
+    uint32_t n_hits = 0;
+    uint64_t n_cig = 0;
+    SelInfo *sel = nullptr;
+    uint64_t *run_off = nullptr, *sel_keys = nullptr, *cig_pos = nullptr;
+    uint32_t *runs = nullptr, *keep_flag = nullptr, *hit_pos = nullptr;
+    if (n_b) {
+        PEP_TRY(dev_reserve(ctx, ctx->ws[19], (size_t)n_b * sizeof(SelInfo)));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[20], ((size_t)n_b + 2) * 8 * 3));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[8], ((size_t)n_b + 2) * 4 * 2));      // ws[8]: raw seed hits of K4, free again
+        int32_t *known = ctx->ws[8].as<int32_t>(), *end_lane = known + n_b + 2;
+        sel = ctx->ws[19].as<SelInfo>();
+        uint64_t *run_cap = ctx->ws[20].as<uint64_t>();
+        run_off = run_cap + n_b + 2; sel_keys = run_off + n_b + 2;
         hipLaunchKernelGGL(gather_sel, dim3(gb), dim3(256), 0, st, n, (const uint32_t *)flag, (const uint32_t *)pos, (const uint32_t *)best_idx, sw, d_cands,
-                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known, end_lane);
-        PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_sel, ctx->ws[7]));
-        uint64_t total_runs = 0;
-        PEP_TRY(pep_read_back(ctx, &total_runs, run_off + n_sel, 8));       // arrives with the synchronisation inside pep_sw_run (block total)
+                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known, end_lane, n_b);
+        PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_b, ctx->ws[7], reinterpret_cast<uint64_t *>(mail + 3)));
+        uint64_t total_runs = run_bound;
+        if (!fast) PEP_TRY(pep_read_back(ctx, &total_runs, mail + 3, 8));         // arrives with the synchronisation inside pep_sw_run (block total)
         // ---- rule 5a: pairs whose alignment is one ungapped run are settled without a sweep (the score-pass results in ws[12] have been
         // consumed by gather_sel: the slots of the selected pairs are written from here on)
-        PEP_TRY(dev_reserve(ctx, ctx->d_trace_mode, ((size_t)n_sel + 1) * sizeof(int32_t)));
+        PEP_TRY(dev_reserve(ctx, ctx->d_trace_mode, ((size_t)n_b + 1) * sizeof(int32_t)));
         PEP_TRY(pep_upload_sub_table(ctx));                                 // (K9 drives this stage without the seed stage in front)
-        hipLaunchKernelGGL(gapless_check, dim3((unsigned)ceil_div(n_sel, 4)), dim3(256), 0, st, (uint64_t)n_sel, (const uint64_t *)sel_keys, (const int32_t *)known,
+        hipLaunchKernelGGL(gapless_check, dim3((unsigned)ceil_div(n_b, 4)), dim3(256), 0, st, d_n_sel, (const uint64_t *)sel_keys, (const int32_t *)known,
                            (const int32_t *)end_lane, ctx->q.res.as<const uint8_t>(), ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(),
                            ctx->t.res.as<const uint8_t>(), ctx->t.off.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), ctx->d_params.as<const int8_t>(),
                            ctx->ws[12].as<int4>(), ctx->d_trace_mode.as<int32_t>());
         // ---- pass 2: the same DP with traceback codes, the remaining selected pairs only
-        PEP_TRY(pep_sw_run(ctx, sel_keys, n_sel, true, known, end_lane, ctx->d_trace_mode.as<const int32_t>()));
-        ctx->stats.tracebacks_gapless = n_sel - ctx->trace_swept;           // (counted by the pass's set-up kernel: the pairs that entered the sweep)
+        PEP_TRY(pep_sw_run(ctx, sel_keys, n_b, true, known, end_lane, ctx->d_trace_mode.as<const int32_t>(), d_n_sel, fast ? dir_blocks_bound : 0, &trace_hdr));
         const int4 *sw2 = ctx->ws[12].as<const int4>();
         PEP_TRY(dev_reserve(ctx, ctx->ws[21], (total_runs + 1) * 4));
-        uint32_t *runs = ctx->ws[21].as<uint32_t>();
-        const unsigned gw = (unsigned)ceil_div(n_sel, 4);
-        const unsigned gfin = (unsigned)ceil_div(n_sel, 256 / FIN_LANES);
-        hipLaunchKernelGGL(walk, dim3((unsigned)ceil_div(n_sel, WALK_LANES)), dim3(WALK_LANES), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, sw2, ctx->ws[11].as<const uint64_t>(),
+        runs = ctx->ws[21].as<uint32_t>();
+        const unsigned gfin = (unsigned)ceil_div(n_b, 256 / FIN_LANES);
+        hipLaunchKernelGGL(walk, dim3((unsigned)ceil_div(n_b, WALK_LANES)), dim3(WALK_LANES), 0, st, d_n_sel, sel, (const uint64_t *)sel_keys, sw2, ctx->ws[11].as<const uint64_t>(),
                            ctx->ws[13].as<const uint32_t>(), ctx->d_trace_mode.as<const int32_t>(), (const uint64_t *)run_off, runs);
-        hipLaunchKernelGGL(finalize, dim3(gfin), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
+        hipLaunchKernelGGL(finalize, dim3(gfin), dim3(256), 0, st, d_n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
                            ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(),
                            ctx->t.off.as<const uint32_t>(), (const uint64_t *)run_off, (const uint32_t *)runs, P.min_id_pct, P.min_qcov_pct);
         if (P.hsp_mode == 1) {
-            hipLaunchKernelGGL(dedupe_bands, dim3((unsigned)ceil_div(n_sel, 256)), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys);
-            hipLaunchKernelGGL(apply_dedupe, dim3((unsigned)ceil_div(n_sel, 256)), dim3(256), 0, st, (uint64_t)n_sel, sel);
+            hipLaunchKernelGGL(dedupe_bands, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, sel, (const uint64_t *)sel_keys);
+            hipLaunchKernelGGL(apply_dedupe, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, sel);
         }
         // top-k, then compaction of hits and CIGAR runs
-        PEP_TRY(dev_reserve(ctx, ctx->ws[22], ((size_t)n_sel + 2) * (4 + 4 + 8 + 8)));
-        uint32_t *keep_flag = ctx->ws[22].as<uint32_t>(), *hit_pos = keep_flag + n_sel + 2;
-        uint64_t *keep_runs = reinterpret_cast<uint64_t *>(hit_pos + n_sel + 2), *cig_pos = keep_runs + n_sel + 2;
-        hipLaunchKernelGGL(topk, dim3((unsigned)ceil_div(n_sel, 256)), dim3(256), 0, st, (uint64_t)n_sel, sel, (const uint64_t *)sel_keys, P.top_k, P.n_splits,
-                           (uint32_t)(P.t_index_base % P.n_splits), ctx->t_class_ready ? ctx->d_t_class.as<const uint32_t>() : (const uint32_t *)nullptr, keep_flag, keep_runs);
-        PEP_TRY(pep_scan_u32(ctx, keep_flag, hit_pos, n_sel, ctx->ws[7]));
-        PEP_TRY(pep_scan_u64(ctx, keep_runs, cig_pos, n_sel, ctx->ws[7]));
-        uint32_t n_hits = 0;
-        uint64_t n_cig = 0;
-        PEP_TRY(pep_read_back(ctx, &n_hits, hit_pos + n_sel, 4));
-        PEP_TRY(pep_read_back(ctx, &n_cig, cig_pos + n_sel, 8));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[22], ((size_t)n_b + 2) * (4 + 4 + 8 + 8)));
+        keep_flag = ctx->ws[22].as<uint32_t>(); hit_pos = keep_flag + n_b + 2;
+        uint64_t *keep_runs = reinterpret_cast<uint64_t *>(hit_pos + n_b + 2);
+        cig_pos = keep_runs + n_b + 2;
+        hipLaunchKernelGGL(topk, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, n_b, sel, (const uint64_t *)sel_keys, P.top_k, P.n_splits,
+                           (uint32_t)(P.t_index_base % P.n_splits), ctx->t_class_ready ? ctx->d_t_class.as<const uint32_t>() : (const uint32_t *)nullptr, keep_flag, keep_runs,
+                           (const unsigned long long *)score_hdr, (const unsigned long long *)trace_hdr, mail);
+        PEP_TRY(pep_scan_u32(ctx, keep_flag, hit_pos, n_b, ctx->ws[7], counters + 2));
+        PEP_TRY(pep_scan_u64(ctx, keep_runs, cig_pos, n_b, ctx->ws[7], reinterpret_cast<uint64_t *>(mail + 2)));
+        PEP_TRY(pep_read_back(ctx, &h_mail, mail, sizeof(h_mail)));
         PEP_TRY(pep_sync_reads(ctx));
-        ctx->stats.hits = n_hits;
-        if (n_hits) {
-            const size_t hb = (size_t)n_hits * sizeof(pep_hit);
-            PEP_TRY(dev_reserve(ctx, ctx->ws[23], hb + (n_cig + 1) * 4));
-            pep_hit *d_hits = ctx->ws[23].as<pep_hit>();
-            uint32_t *d_cig = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctx->ws[23].p) + hb);
-            hipLaunchKernelGGL(emit, dim3(gw), dim3(256), 0, st, (uint64_t)n_sel, (const SelInfo *)sel, (const uint64_t *)sel_keys, (const uint32_t *)keep_flag,
-                               (const uint32_t *)hit_pos, (const uint64_t *)cig_pos, (const uint64_t *)run_off, (const uint32_t *)runs,
-                               ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig);
-            PEP_HIP(ctx, hipGetLastError());
-            // the table goes to the context's pinned staging area (DMA speed, no page faults); pep_result_copy reads it from there.
-            // If the host refuses that much pinned memory the result owns ordinary vectors instead.  In device-result mode
-            // (pep_set_result_mode) nothing is copied here: whoever wants the host copy fetches it later (pep_fetch_result).
-            if (ctx->device_results) {
-            } else if (pin_reserve(ctx, ctx->pin_stage, hb + (n_cig + 1) * 4) == PEP_OK) {
-                PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_stage.p, d_hits, hb + n_cig * 4, hipMemcpyDeviceToHost, st));       // hits and arena are adjacent in ws[23]
-                res->st_hits = reinterpret_cast<const pep_hit *>(ctx->pin_stage.p);
-                res->st_cigar = reinterpret_cast<const uint32_t *>(ctx->pin_stage.p + hb);
-            } else {
-                res->hits.resize(n_hits);
-                res->cigar.resize(n_cig);
-                PEP_HIP(ctx, hipMemcpyAsync(res->hits.data(), d_hits, hb, hipMemcpyDeviceToHost, st));
-                if (n_cig) PEP_HIP(ctx, hipMemcpyAsync(res->cigar.data(), d_cig, n_cig * 4, hipMemcpyDeviceToHost, st));
-            }
-            res->n_hits = n_hits; res->n_cigar = n_cig;
-            res->d_hits = d_hits; res->d_cigar = d_cig;
+        n_hits = h_mail.n_hits; n_cig = h_mail.n_cig;
+        ctx->stats.cells += h_mail.score_cells;
+        ctx->stats.cells_swept += h_mail.score_blocks * 16 * 64;
+        if (fast) {                                  // (the exactly sized pass has added its totals itself)
+            ctx->stats.cells_trace += h_mail.trace_cells;
+            ctx->stats.cells_swept_trace += h_mail.trace_blocks * 16 * 64;
+            ctx->stats.dir_bytes += h_mail.trace_blocks * 512;
+            ctx->trace_swept = h_mail.trace_swept;
         }
+        ctx->stats.tracebacks_gapless = h_mail.n_sel - ctx->trace_swept;   // (counted by the pass's set-up kernel: the pairs that entered the sweep)
+    } else {
+        unsigned long long h_score[2] = {0, 0};
+        PEP_TRY(pep_read_back(ctx, h_score, score_hdr, sizeof(h_score)));
+        PEP_TRY(pep_sync_reads(ctx));
+        ctx->stats.cells += h_score[0];
+        ctx->stats.cells_swept += h_score[1] * 16 * 64;
+    }
+    ctx->stats.pairs = h_mail.n_pairs;
+    ctx->stats.tracebacks = h_mail.n_sel;
+    ctx->stats.hits = n_hits;
+    if (n_hits) {
+        const uint32_t n_sel = h_mail.n_sel;
+        const size_t hb = (size_t)n_hits * sizeof(pep_hit);
+        PEP_TRY(dev_reserve(ctx, ctx->ws[23], hb + (n_cig + 1) * 4));
+        pep_hit *d_hits = ctx->ws[23].as<pep_hit>();
+        uint32_t *d_cig = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctx->ws[23].p) + hb);
+        hipLaunchKernelGGL(emit, dim3((unsigned)ceil_div(n_sel, 4)), dim3(256), 0, st, (uint64_t)n_sel, (const SelInfo *)sel, (const uint64_t *)sel_keys, (const uint32_t *)keep_flag,
+                           (const uint32_t *)hit_pos, (const uint64_t *)cig_pos, (const uint64_t *)run_off, (const uint32_t *)runs,
+                           ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig);
+        PEP_HIP(ctx, hipGetLastError());
+        // the table goes to the context's pinned staging area (DMA speed, no page faults); pep_result_copy reads it from there.
+        // If the host refuses that much pinned memory the result owns ordinary vectors instead.  In device-result mode
+        // (pep_set_result_mode) nothing is copied here: whoever wants the host copy fetches it later (pep_fetch_result).
+        if (ctx->device_results) {
+        } else if (pin_reserve(ctx, ctx->pin_stage, hb + (n_cig + 1) * 4) == PEP_OK) {
+            PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_stage.p, d_hits, hb + n_cig * 4, hipMemcpyDeviceToHost, st));       // hits and arena are adjacent in ws[23]
+            res->st_hits = reinterpret_cast<const pep_hit *>(ctx->pin_stage.p);
+            res->st_cigar = reinterpret_cast<const uint32_t *>(ctx->pin_stage.p + hb);
+        } else {
+            res->hits.resize(n_hits);
+            res->cigar.resize(n_cig);
+            PEP_HIP(ctx, hipMemcpyAsync(res->hits.data(), d_hits, hb, hipMemcpyDeviceToHost, st));
+            if (n_cig) PEP_HIP(ctx, hipMemcpyAsync(res->cigar.data(), d_cig, n_cig * 4, hipMemcpyDeviceToHost, st));
+        }
+        res->n_hits = n_hits; res->n_cigar = n_cig;
+        res->d_hits = d_hits; res->d_cigar = d_cig;
     }
     pep_timer_end(ctx, TM_TRACE);
     PEP_HIP(ctx, hipGetLastError());

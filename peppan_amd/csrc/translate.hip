@@ -282,12 +282,22 @@ int upload_codon_table(pep_ctx *ctx)
 
 __device__ __forceinline__ uint32_t padded_len(uint32_t len) { return (len + 15u) / 16u * 16u + PEP_SEQ_GAP; }
 
+// What the host needs of a packed set before it can queue a search: computed on the device (k1_offsets) and downloaded behind the
+// descriptors (two descriptor slots), so that the host does not have to walk 60 k descriptors while the GPU waits for its next kernel -
+// the per-sequence tables (h_off, h_len, the meta records) are built from the downloaded descriptors only when somebody asks for them.
+struct K1Summary {
+    unsigned long long residues, total;
+    uint32_t n, max_len;
+    uint32_t pad[2];
+};
+static_assert(sizeof(K1Summary) == 2 * 16, "the summary takes two descriptor slots");
+
 // query side: one packed sequence per gene, the chosen frame from its start
 __global__ void k1_query_desc(uint32_t n, const uint32_t *__restrict__ frame, const uint32_t *__restrict__ len, PackDesc *__restrict__ desc,
-                              uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, uint32_t *__restrict__ n_out)
+                              uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, uint32_t *__restrict__ n_out, K1Summary *__restrict__ sum)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *n_out = n;
+    if (i == 0) { *n_out = n; sum->residues = 0ull; sum->max_len = 0u; }       // (k1_offsets accumulates into it)
     if (i >= n) return;
     desc[i] = PackDesc{i, frame[i], 0u, len[i]};
     padded[i] = padded_len(len[i]);
@@ -297,9 +307,10 @@ __global__ void k1_query_desc(uint32_t n, const uint32_t *__restrict__ frame, co
 // reference side: the chunks of (sequence, frame) w become packed sequences first[w] .. first[w] + cnt[w] - 1
 __global__ void k1_ref_desc(uint64_t nw, int n_frames, const uint64_t *__restrict__ chunk_base, const uint32_t *__restrict__ chunk_cnt,
                             const uint32_t *__restrict__ first, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_len,
-                            PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out)
+                            PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, K1Summary *__restrict__ sum)
 {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w == 0) { sum->residues = 0ull; sum->max_len = 0u; }
     if (w >= nw) return;
     const uint32_t g = (uint32_t)(w / n_frames), f = (uint32_t)(w % n_frames) + 1;
     const uint64_t base = chunk_base[w];
@@ -311,12 +322,19 @@ __global__ void k1_ref_desc(uint64_t nw, int n_frames, const uint64_t *__restric
     }
 }
 
-// pk_off[i] = start of packed sequence i; entries n .. cap hold the layout's total size (sentinel of the owner search)
-__global__ void k1_offsets(const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ scan, uint32_t cap, uint32_t *__restrict__ pk_off)
+// pk_off[i] = start of packed sequence i; entries n .. cap hold the layout's total size (sentinel of the owner search).
+// Also the set's summary: number of sequences, layout size, residues, longest sequence.
+__global__ void k1_offsets(const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ scan, uint32_t cap, uint32_t *__restrict__ pk_off,
+                           const uint32_t *__restrict__ len, K1Summary *__restrict__ sum)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > cap) return;
-    pk_off[i] = i < *n_ptr ? scan[i] + PEP_END_PAD : scan[cap] + 2 * PEP_END_PAD;
+    const uint32_t n = *n_ptr;
+    if (i <= cap) pk_off[i] = i < n ? scan[i] + PEP_END_PAD : scan[cap] + 2 * PEP_END_PAD;
+    uint32_t L = i < n ? len[i] : 0u, m = L;
+    unsigned long long s = L;
+    for (int d = 32; d > 0; d >>= 1) { s += __shfl_xor(s, d, 64); m = max(m, (uint32_t)__shfl_xor((int)m, d, 64)); }
+    if ((threadIdx.x & 63) == 0 && m) { atomicAdd(&sum->residues, s); atomicMax(&sum->max_len, m); }
+    if (i == 0) { sum->n = n; sum->total = (unsigned long long)scan[cap] + 2ull * PEP_END_PAD; }
 }
 
 int reserve_packed(pep_ctx *ctx, SeqSet &out, uint32_t cap, uint64_t upper)
@@ -336,51 +354,51 @@ int layout_and_pack(pep_ctx *ctx, const NtSet &nt, int tab, const PackDesc *d_de
 {
     PEP_TRY(dev_reserve(ctx, d_scan, ((size_t)cap + 2) * 4));
     PEP_TRY(pep_scan_u32(ctx, d_padded, d_scan.as<uint32_t>(), cap, tmp));
-    hipLaunchKernelGGL(k1_offsets, dim3((unsigned)ceil_div((uint64_t)cap + 1, 256)), dim3(256), 0, ctx->stream, d_n, d_scan.as<const uint32_t>(), cap, out.off.as<uint32_t>());
+    K1Summary *d_sum = reinterpret_cast<K1Summary *>(const_cast<PackDesc *>(d_desc) + cap);        // behind the descriptors: one download brings both
+    hipLaunchKernelGGL(k1_offsets, dim3((unsigned)ceil_div((uint64_t)cap + 1, 256)), dim3(256), 0, ctx->stream, d_n, d_scan.as<const uint32_t>(), cap, out.off.as<uint32_t>(),
+                       out.len.as<const uint32_t>(), d_sum);
     hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div((uint64_t)cap + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
                        d_desc, out.off.as<const uint32_t>(), d_n, cap, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>());
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }
 
-// host mirrors of a packed set from its downloaded descriptors (same arithmetic as k1_offsets)
-int finish_layout(pep_ctx *ctx, const PackDesc *desc, uint32_t n, SeqSet &out)
+// the eager part of a finished K1 side: the set's summary (computed by k1_offsets, downloaded behind the descriptors)
+int take_summary(pep_ctx *ctx, const PackDesc *desc, uint32_t cap, SeqSet &out)
 {
-    out.n = n;
+    const K1Summary *sum = reinterpret_cast<const K1Summary *>(desc + cap);
+    if (sum->total > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "packed protein set exceeds 2^29 bytes");
+    if (sum->max_len > PEP_MAX_SEQ_LEN) return pep_fail(ctx, PEP_ERR_LIMIT, "protein longer than PEP_MAX_SEQ_LEN");
+    out.n = sum->n; out.total = sum->total; out.residues = sum->residues; out.max_len = sum->max_len;
+    return PEP_OK;
+}
+
+// host mirrors of a packed set from its downloaded descriptors (same arithmetic as k1_offsets)
+void finish_layout(const PackDesc *desc, uint32_t n, SeqSet &out)
+{
     out.h_off.resize((size_t)n + 1);
     out.h_len.resize(n);
-    uint64_t pos = PEP_END_PAD, residues = 0;
-    uint32_t max_len = 0;
+    uint64_t pos = PEP_END_PAD;
     for (uint32_t i = 0; i < n; ++i) {
         out.h_off[i] = (uint32_t)pos;
         out.h_len[i] = desc[i].len;
-        residues += desc[i].len;
-        max_len = std::max(max_len, desc[i].len);
         pos += ((uint64_t)desc[i].len + 15) / 16 * 16 + PEP_SEQ_GAP;
     }
-    pos += PEP_END_PAD;
-    if (pos > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "packed protein set exceeds 2^29 bytes");
-    out.h_off[n] = (uint32_t)pos;
-    out.total = pos; out.residues = residues; out.max_len = max_len;
-    if (max_len > PEP_MAX_SEQ_LEN) return pep_fail(ctx, PEP_ERR_LIMIT, "protein longer than PEP_MAX_SEQ_LEN");
-    return PEP_OK;
+    out.h_off[n] = (uint32_t)(pos + PEP_END_PAD);
 }
 
 PackDesc *stage_desc(pep_ctx *ctx, PinBuf &pin, uint64_t n)
 {
-    if (pin_reserve(ctx, pin, (n + 1) * sizeof(PackDesc)) != PEP_OK) return nullptr;
+    if (pin_reserve(ctx, pin, (n + 3) * sizeof(PackDesc)) != PEP_OK) return nullptr;
     return reinterpret_cast<PackDesc *>(pin.p);
 }
 
 int k1_ref_finish(pep_ctx *ctx)
 {
     PEP_HIP(ctx, pep_event_wait(ctx->k1_event));
-    const uint32_t n_targets = ctx->k1_count_pending ? *reinterpret_cast<const uint32_t *>(ctx->pin_k1n.p) : 0u;
-    ctx->k1_count_pending = false;
-    const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1.p);
-    ctx->t_meta.resize(n_targets);
-    for (uint32_t i = 0; i < n_targets; ++i) ctx->t_meta[i] = pep_target_meta{desc[i].seq, desc[i].frame, desc[i].aa_off, desc[i].len};
-    return finish_layout(ctx, desc, n_targets, ctx->t);
+    PEP_TRY(take_summary(ctx, reinterpret_cast<const PackDesc *>(ctx->pin_k1.p), ctx->k1_desc_cap, ctx->t));
+    ctx->t_tables_lazy = true;               // t_meta, h_off, h_len: pep_k1_host_tables, when somebody needs them
+    return PEP_OK;
 }
 
 }  // namespace
@@ -398,7 +416,7 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
         DevBuf *W = ctx->ws;
         PEP_TRY(dev_reserve(ctx, W[0], ((size_t)n + 1) * 4));
         PEP_TRY(dev_reserve(ctx, W[1], ((size_t)n + 1) * 4));
-        PEP_TRY(dev_reserve(ctx, W[2], ((size_t)n + 1) * sizeof(PackDesc)));
+        PEP_TRY(dev_reserve(ctx, W[2], ((size_t)n + 3) * sizeof(PackDesc)));       // + the summary behind the descriptors
         PEP_TRY(dev_reserve(ctx, W[3], ((size_t)n + 1) * 4));
         PEP_TRY(dev_reserve(ctx, W[5], 16));
         const uint64_t upper = 2 * PEP_END_PAD + (nt.total + 2 * (uint64_t)n) / 3 + (uint64_t)n * (16 + PEP_SEQ_GAP);
@@ -406,18 +424,34 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
         if (n) hipLaunchKernelGGL(k1_query_frames, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, tab,
                                   W[0].as<uint32_t>(), W[1].as<uint32_t>());
         hipLaunchKernelGGL(k1_query_desc, dim3((unsigned)ceil_div((uint64_t)n + 1, 256)), dim3(256), 0, ctx->stream, n, W[0].as<const uint32_t>(), W[1].as<const uint32_t>(),
-                           W[2].as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>());
+                           W[2].as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>(), reinterpret_cast<K1Summary *>(W[2].as<PackDesc>() + n));
         PEP_TRY(layout_and_pack(ctx, nt, tab, W[2].as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6]));
         PackDesc *desc = stage_desc(ctx, ctx->pin_k1q, n);
         if (!desc) return PEP_ERR_HIP;
-        if (n) PEP_HIP(ctx, hipMemcpyAsync(desc, W[2].p, (size_t)n * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
+        PEP_HIP(ctx, hipMemcpyAsync(desc, W[2].p, ((size_t)n + 2) * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
     }
     if (phase == 1) return PEP_OK;
     const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1q.p);
     PEP_HIP(ctx, pep_stream_wait(ctx));
+    PEP_TRY(take_summary(ctx, desc, n, ctx->q));
+    // the query side's tables are small and the search wants the lengths (score thresholds): built at once
     ctx->q_meta.resize(n);
     for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, desc[i].frame, desc[i].len, (uint32_t)(nt.h_off[i + 1] - nt.h_off[i])};
-    return finish_layout(ctx, desc, n, ctx->q);
+    finish_layout(desc, n, ctx->q);
+    return PEP_OK;
+}
+
+// the per-sequence host tables of the reference side (meta records, offsets, lengths) from the descriptors its last K1 downloaded
+int pep_k1_host_tables(pep_ctx *ctx)
+{
+    if (!ctx->t_tables_lazy) return PEP_OK;
+    const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1.p);
+    const uint32_t n = ctx->t.n;
+    ctx->t_meta.resize(n);
+    for (uint32_t i = 0; i < n; ++i) ctx->t_meta[i] = pep_target_meta{desc[i].seq, desc[i].frame, desc[i].aa_off, desc[i].len};
+    finish_layout(desc, n, ctx->t);
+    ctx->t_tables_lazy = false;
+    return PEP_OK;
 }
 
 int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
@@ -456,7 +490,7 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     PEP_TRY(dev_reserve(ctx, W[1], (nw + 1) * 4));
     PEP_TRY(dev_reserve(ctx, W[2], (slots + 1) * 4));
     PEP_TRY(dev_reserve(ctx, W[3], (slots + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, W[4], (slots + 1) * sizeof(PackDesc)));
+    PEP_TRY(dev_reserve(ctx, W[4], (slots + 3) * sizeof(PackDesc)));             // + the summary behind the descriptors
     PEP_TRY(dev_reserve(ctx, W[5], (nw + 2) * 4));
     PEP_TRY(dev_reserve(ctx, W[6], (slots + 1) * 4));
     PEP_TRY(reserve_packed(ctx, ctx->t, (uint32_t)slots, upper));
@@ -470,20 +504,18 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
         PEP_TRY(pep_scan_u32(ctx, W[1].as<const uint32_t>(), W[5].as<uint32_t>(), nw, W[8]));          // W[5][nw] = number of targets
         hipLaunchKernelGGL(k1_ref_desc, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, ctx->stream, nw, nf, d_base, W[1].as<const uint32_t>(),
                            W[5].as<const uint32_t>(), W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), W[4].as<PackDesc>(), W[6].as<uint32_t>(),
-                           ctx->t.len.as<uint32_t>());
+                           ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(W[4].as<PackDesc>() + slots));
         PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
                                 W[7], W[8]));
-        // the count and the descriptors travel through pinned memory; an event marks the point of the stream where both have arrived
-        PEP_TRY(pin_reserve(ctx, ctx->pin_k1n, 64));
-        PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_k1n.p, W[5].as<const uint32_t>() + nw, 4, hipMemcpyDeviceToHost, ctx->stream));
-        PEP_HIP(ctx, hipMemcpyAsync(desc, W[4].p, slots * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
-        ctx->k1_count_pending = true;
     } else {
         PEP_HIP(ctx, hipMemsetAsync(W[5].p, 0, 8, ctx->stream));
         PEP_HIP(ctx, hipMemsetAsync(W[6].p, 0, 4, ctx->stream));
+        PEP_HIP(ctx, hipMemsetAsync(W[4].p, 0, 3 * sizeof(PackDesc), ctx->stream));            // (the summary's accumulators)
         PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), 0, W[5].as<const uint32_t>(), upper, ctx->t, W[7], W[8]));
-        ctx->k1_count_pending = false;
     }
+    // the descriptors and the summary behind them travel through pinned memory in one copy; an event marks the point of the stream where they have arrived
+    PEP_HIP(ctx, hipMemcpyAsync(desc, W[4].p, (slots + 2) * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->k1_desc_cap = (uint32_t)slots;
     if (!ctx->k1_event && hipEventCreateWithFlags(&ctx->k1_event, hipEventDisableTiming) != hipSuccess) return pep_fail(ctx, PEP_ERR_HIP, "hipEventCreate failed");
     PEP_HIP(ctx, hipEventRecord(ctx->k1_event, ctx->stream));
     if (phase == 1) return PEP_OK;
@@ -545,6 +577,7 @@ int pep_nucl_sets(pep_ctx *ctx, int strands)
         a = b;
     }
     PEP_TRY(nucl_build(ctx, ctx->r_nt, to, PEP_MAX_TARGETS, ctx->t));
+    ctx->t_tables_lazy = false;
     ctx->t_meta.resize(to.size());
     for (size_t i = 0; i < to.size(); ++i) ctx->t_meta[i] = pep_target_meta{to[i].seq, to[i].rev ? 4u : 1u, 0u, ctx->t.h_len[i]};
     return PEP_OK;

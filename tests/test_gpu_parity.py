@@ -1236,3 +1236,48 @@ def test_sensitive_mode_four_shapes_vs_oracle(ctx):
     oh, oc, ost = O.search(q_aa, t_aa, O.params_from(p))
     _cmp_hits(gh, gc, oh, oc)
     assert st['candidates'] == ost['candidates'] and st['candidates'] >= base_st['candidates'] and len(gh) >= len(base_h) > 3000
+
+
+def test_alignment_stage_without_host_round_trips_equals_exactly_sized_stage(ctx):
+    """the alignment stage runs from the candidate count to the result sizes without a host round trip (the number of selected pairs stays
+    on the device, buffers sized from upper bounds); params.reserved2 = 1 makes it synchronise after the selection and size everything
+    exactly.  Both give the same table and the same statistics - protein families, the nucleotide configuration (hsp_mode 1, long
+    pairs), the 32-bit passes, a search whose candidates all die at the score cut, and K1 with its host tables built on demand"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    keys = ('candidates', 'pairs', 'tracebacks', 'tracebacks_gapless', 'hits', 'cells', 'cells_swept', 'cells_trace', 'cells_swept_trace', 'dir_bytes')
+    prots = synth.make_proteins(300, length=(40, 500), seed=23, family=5, sub=0.25)
+    names, seqs = synth.make_genes(120, 0, seed=4)
+    codes = [O.nt_codes(s.decode()) for s in seqs]
+    rc = [(3 - c[::-1]).astype(np.uint8) for c in codes]
+    rng = np.random.default_rng(5)
+    aa = np.frombuffer(b'ARNDCQEGHILKMFPSTWYV', dtype=np.uint8) - 65
+    noise = [aa[rng.integers(0, 20, 150)] for _ in range(40)]
+    cases = [(prots, prots, N.default_params(30., 10., 10, 5), 300), (codes, codes + rc, N.nucleotide_params(60., 20.), 120),
+             (noise, noise[::-1], N.default_params(0., 0., 10, 5, max_evalue=1e-30), 0)]
+    p32 = N.default_params(30., 10., 3, 5)
+    p32.reserved[1] = 1
+    cases.append((prots, prots, p32, 300))
+    for qs, ts, p, least in cases:
+        ctx.set_query_aa(qs); ctx.set_ref_aa(ts)
+        out = []
+        for flag in (0, 1):
+            p.reserved2 = flag
+            h, c, st = ctx.search(p)
+            out.append((h.tobytes(), c.tobytes(), tuple(st[k] for k in keys)))
+        assert out[0] == out[1], (out[0][2], out[1][2])
+        assert len(out[0][0]) >= 64 * least
+    names, seqs = synth.make_genes(900, 0, seed=77)
+    ctx.set_query_nt(seqs[:400], 11); ctx.set_ref_nt(seqs, 6, 11)
+    out = []
+    for flag in (0, 1):
+        p = N.default_params(45., 25., 10, 5)
+        p.reserved2 = flag
+        h, c, st = ctx.search(p)
+        tm = ctx.target_meta()
+        out.append((h.tobytes(), c.tobytes(), tuple(st[k] for k in keys), tm.tobytes()))
+    assert out[0] == out[1] and len(out[0][0]) > 64 * 400
+    qa, qo = ctx.query_aa()
+    ta, to = ctx.target_aa()
+    oh, oc, ost = O.search([qa[qo[i]:qo[i + 1]] for i in range(len(qo) - 1)], [ta[to[i]:to[i + 1]] for i in range(len(to) - 1)], O.default_params(45., 25., 10, 5))
+    _cmp_hits(np.frombuffer(out[0][0], dtype=N.HIT_DTYPE), np.frombuffer(out[0][1], dtype=np.uint32), oh, oc)
