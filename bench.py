@@ -262,6 +262,10 @@ def main():
         ctx.components(8, settle_a, settle_b)
     if world > 1:
         dist.barrier()
+    # phase timers: HIP events on the search's stream cost about 6 us of idle GPU each (profiles/r03_step_timeline.txt), sixteen per search with
+    # every phase timed.  The timed region keeps the pair around the dominant kernel (the score pass: the roofline's live duration) and nothing
+    # else; the other phases are measured in a loop of their own behind it (phase_timers below)
+    ctx.set_timing(1)
     t0 = time.perf_counter()
     keys = ('candidates', 'cells', 'cells_swept', 'cells_swept_trace', 'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total',
             'hits', 'dir_bytes', 'tracebacks', 'tracebacks_gapless', 'seed_hits', 'target_residues', 'query_residues', 'ms_host_translate', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')
@@ -275,6 +279,18 @@ def main():
             acc[k] += st[k]
     sync()
     dt = time.perf_counter() - t0
+    # the same K steps once more with every phase timer on (outside the timed region)
+    ctx.set_timing(2)
+    step()
+    sync()
+    t_ph = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()[0]
+        for k in ('ms_sw_trace', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total'):
+            acc[k] += st[k]
+    sync()
+    ms_step_all_timers = (time.perf_counter() - t_ph) / args.steps * 1e3
+    ctx.set_timing(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -452,6 +468,10 @@ def main():
                                 'gene_pairs_all_vs_all_per_s (query genes x reference genes per second) do not depend on it. ms_per_step is a steady-state figure: '
                                 '500 tiny library calls run between the device-wide synchronisation and the clock (settle_calls); ms_per_step_after_device_sync is the same loop without them',
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
+            'phase_timers': {'in_timed_region': ['ms_sw'], 'ms_per_step_with_every_phase_timer': ms_step_all_timers,
+                             'note': 'pep_set_timing: the timed region records the two HIP events around the score pass (the roofline kernel) only; the other phase_ms '
+                                     'entries and the durations of the second and third roofline_kernels come from a loop of the same K steps behind it with all '
+                                     'sixteen events per search on - each costs about 6 us of idle GPU between the kernels it separates'},
             'host_phase_ms_rank0': dict({k: acc[k] / K for k in ('ms_host_translate', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')}, ms_host_union_find=t_uf / K),
             'roofline': top, 'roofline_kernels': rl,
             'cpu_baseline': cpu_line if world == 1 else None,

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 4
+#define PEP_ABI_VERSION 5
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -182,6 +182,10 @@ int pep_set_target_groups(pep_ctx *ctx, const uint32_t *group, uint32_t n);
  * the end of pep_search; pep_result_copy / pep_result_data then fetch it on demand, while the result is still the context's newest
  * (PEP_ERR_STATE afterwards).  For callers that go on working on the GPU: the all-gather of a multi-GPU search, K10. */
 int pep_set_result_mode(pep_ctx *ctx, int on_device);
+/* Phase timers of the searches of this context (the ms_* fields of pep_stats): HIP events recorded on the search's stream, each of which
+ * leaves the GPU idle for about 6 us between the two kernels it separates.  level 0 (the default): none, the fields stay 0;
+ * 1: the Smith-Waterman score pass only (ms_sw); 2: every phase (sixteen events per search).  ms_k1 (pep_translate) follows the same switch. */
+int pep_set_timing(pep_ctx *ctx, int level);
 /* K2..K8: seeds, candidates, banded Smith-Waterman, traceback, filters, top-k.  Hits ordered by (q, t). */
 int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out);
 int pep_result_size(const pep_result *r, uint64_t *n_hits, uint64_t *n_cigar);

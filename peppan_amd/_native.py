@@ -7,12 +7,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
-           'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
+           'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
            'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve']
 
@@ -374,6 +374,11 @@ class Context(object):
         """the device-resident nucleotide sets themselves become the residue sets (base codes; reference: forward strands, then reverse
         complements, per target group) - the inputs of the nucleotide search.  Until the next translate() / set_*."""
         self._check(self._lib.pep_use_nt_as_residues(self._h, C.c_int(strands)), 'pep_use_nt_as_residues')
+
+    def set_timing(self, level):
+        """phase timers of the searches (the ms_* statistics): 0 none (default), 1 the score pass only, 2 every phase - each HIP event costs
+        the GPU about 6 us of idle time between two kernels"""
+        self._check(self._lib.pep_set_timing(self._h, C.c_int(level)), 'pep_set_timing')
 
     def translate(self, force=False):
         self._check(self._lib.pep_translate(self._h, C.c_int(1 if force else 0)), 'pep_translate')

@@ -51,6 +51,7 @@ int pin_reserve(pep_ctx *ctx, PinBuf &b, size_t bytes)
 
 void pep_timer_begin(pep_ctx *ctx, int id)
 {
+    if (ctx->timing_level < (id == TM_SW ? 1 : 2)) return;        // (an event between two kernels costs about 6 us of idle GPU: pep_set_timing)
     if (!ctx->tm_a[id] && (hipEventCreate(&ctx->tm_a[id]) != hipSuccess || hipEventCreate(&ctx->tm_b[id]) != hipSuccess)) { ctx->tm_a[id] = nullptr; return; }
     ctx->tm_state[id] = hipEventRecord(ctx->tm_a[id], ctx->stream) == hipSuccess ? 1 : 0;
 }
@@ -263,6 +264,7 @@ int upload_aa(pep_ctx *ctx, SeqSet &s, const uint8_t *codes, const uint64_t *off
     if (n && (!codes || !off)) return pep_fail(ctx, PEP_ERR_ARG, "null sequence buffer");
     if (n > max_n) return pep_fail(ctx, PEP_ERR_LIMIT, "too many sequences");
     if (&s == &ctx->t) ctx->t_tables_lazy = false;          // the host tables are built right here
+    if (&s == &ctx->q) ctx->q_tables_lazy = false;
     s.n = n;
     s.h_off.assign(n + 1, 0);
     s.h_len.assign(n, 0);
@@ -300,7 +302,7 @@ int upload_aa(pep_ctx *ctx, SeqSet &s, const uint8_t *codes, const uint64_t *off
 int download_aa(pep_ctx *ctx, const SeqSet &s, uint8_t *codes, uint64_t cap, uint64_t *off)
 {
     if (s.residues > cap) return pep_fail(ctx, PEP_ERR_ARG, "output buffer too small");
-    if (&s == &ctx->t) PEP_TRY(pep_k1_host_tables(ctx));
+    PEP_TRY(pep_k1_host_tables(ctx));
     std::vector<uint8_t> img(s.total);
     if (s.total) PEP_HIP(ctx, hipMemcpy(img.data(), s.res.p, s.total, hipMemcpyDeviceToHost));
     uint64_t pos = 0;
@@ -402,6 +404,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_stage.p) (void)hipHostFree(ctx->pin_stage.p);
     if (ctx->pin_k1.p) (void)hipHostFree(ctx->pin_k1.p);
     if (ctx->pin_k1q.p) (void)hipHostFree(ctx->pin_k1q.p);
+    if (ctx->pin_labels.p) (void)hipHostFree(ctx->pin_labels.p);
     if (ctx->k1_event) (void)hipEventDestroy(ctx->k1_event);
     if (ctx->k1_t0) (void)hipEventDestroy(ctx->k1_t0);
     if (ctx->k1_t1) (void)hipEventDestroy(ctx->k1_t1);
@@ -471,13 +474,14 @@ int pep_translate(pep_ctx *ctx, int force)
     ctx->resid_from_nucl = false;           // (pep_use_nt_as_residues left q_ready / t_ready false: K1 runs again)
     const bool do_q = ctx->q_from_nt && (force || !ctx->q_ready), do_t = ctx->t_from_nt && (force || !ctx->t_ready);
     if (!do_q && !do_t) return PEP_OK;       // nothing to translate (pep_search calls this every time): no events, no waiting
-    if (ctx->k1_t0) (void)hipEventRecord(ctx->k1_t0, ctx->stream);
+    const bool timed = ctx->timing_level >= 2 && ctx->k1_t0;
+    if (timed) (void)hipEventRecord(ctx->k1_t0, ctx->stream);
     if (do_t) PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable, 1));
     if (do_q) PEP_TRY(pep_k1_query(ctx, ctx->q_gtable, 1));
     if (do_t) { PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable, 2)); ctx->t_ready = true; }
     if (do_q) { PEP_TRY(pep_k1_query(ctx, ctx->q_gtable, 2)); ctx->q_ready = true; }
     float ms = 0.f;
-    if (ctx->k1_t0 && ctx->k1_t1 && hipEventRecord(ctx->k1_t1, ctx->stream) == hipSuccess && pep_event_wait(ctx->k1_t1) == hipSuccess) (void)hipEventElapsedTime(&ms, ctx->k1_t0, ctx->k1_t1);
+    if (timed && ctx->k1_t1 && hipEventRecord(ctx->k1_t1, ctx->stream) == hipSuccess && pep_event_wait(ctx->k1_t1) == hipSuccess) (void)hipEventElapsedTime(&ms, ctx->k1_t0, ctx->k1_t1);
     ctx->stats.ms_k1 = ms;
     return PEP_OK;
 }
@@ -516,6 +520,7 @@ int pep_target_count(pep_ctx *ctx, uint32_t *n, uint64_t *residues)
 int pep_get_query_meta(pep_ctx *ctx, pep_query_meta *out, uint32_t cap)
 {
     if (!ctx || !(ctx->q_ready || ctx->resid_from_nucl)) return pep_fail(ctx, PEP_ERR_STATE, "queries not set / not translated");
+    PEP_TRY(pep_k1_host_tables_q(ctx));
     if (cap < ctx->q_meta.size()) return pep_fail(ctx, PEP_ERR_ARG, "output buffer too small");
     if (!ctx->q_meta.empty()) memcpy(out, ctx->q_meta.data(), ctx->q_meta.size() * sizeof(pep_query_meta));
     return PEP_OK;
@@ -633,24 +638,31 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     for (int id = 0; id < TM_COUNT; ++id) ctx->tm_state[id] = 0;
     pep_timer_begin(ctx, TM_SEED); pep_timer_begin(ctx, TM_TOTAL);
     uint64_t *d_cands = nullptr, n_cands = 0;
-    int rc = pep_find_candidates(ctx, &d_cands, &n_cands);
-    pep_timer_end(ctx, TM_SEED);
-    if (rc == PEP_OK) {
-        std::vector<int32_t> min_score(ctx->q.n + 1);
+    // host work that only the alignment stage needs - the query side's tables, the score thresholds and their upload - is done while the
+    // seed stage's kernels run (between its last launch and its synchronisation)
+    auto prepare_thresholds = [](pep_ctx *c) -> int {
+        PEP_TRY(pep_k1_host_tables_q(c));
+        PEP_TRY(dev_reserve(c, c->d_min_score, (size_t)(c->q.n + 1) * 4));
+        PEP_TRY(pin_reserve(c, c->pin_ms, (size_t)(c->q.n + 1) * 4));
+        int32_t *ms = reinterpret_cast<int32_t *>(c->pin_ms.p);
         // the threshold depends on the length only and lengths repeat: one logarithm per distinct length (direct-mapped memo)
         uint32_t memo_len[1024];
         int32_t memo_val[1024];
         for (int i = 0; i < 1024; ++i) memo_len[i] = 0xFFFFFFFFu;
-        for (uint32_t i = 0; i < ctx->q.n; ++i) {
-            const uint32_t L = ctx->q.h_len[i], slot = L & 1023u;
+        for (uint32_t i = 0; i < c->q.n; ++i) {
+            const uint32_t L = c->q.h_len[i], slot = L & 1023u;
             if (memo_len[slot] != L) {
                 memo_len[slot] = L;
-                memo_val[slot] = pep_min_score_ka(L, ctx->params.dbsize, ctx->params.max_evalue, ctx->params.ka_lambda, ctx->params.ka_k);
+                memo_val[slot] = pep_min_score_ka(L, c->params.dbsize, c->params.max_evalue, c->params.ka_lambda, c->params.ka_k);
             }
-            min_score[i] = memo_val[slot];
+            ms[i] = memo_val[slot];
         }
-        rc = pep_extend(ctx, d_cands, n_cands, min_score.data(), res);
-    }
+        if (c->q.n) PEP_HIP(c, hipMemcpyAsync(c->d_min_score.p, c->pin_ms.p, (size_t)c->q.n * 4, hipMemcpyHostToDevice, c->stream));
+        return PEP_OK;
+    };
+    int rc = pep_find_candidates(ctx, &d_cands, &n_cands, prepare_thresholds);
+    pep_timer_end(ctx, TM_SEED);
+    if (rc == PEP_OK) rc = pep_extend(ctx, d_cands, n_cands, nullptr, res);
     pep_timer_end(ctx, TM_TOTAL);
     const hipError_t se = pep_stream_wait(ctx);
     if (rc == PEP_OK && se != hipSuccess) rc = pep_fail(ctx, PEP_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
@@ -661,6 +673,13 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     if (res->st_hits || res->st_cigar) ctx->staged_result = res;
     else if (!res->d_hits) res->ctx = nullptr;             // owns its (possibly empty) table from the start: nothing ties it to the context
     *out = res;
+    return PEP_OK;
+}
+
+int pep_set_timing(pep_ctx *ctx, int level)
+{
+    if (!ctx || level < 0 || level > 2) return PEP_ERR_ARG;
+    ctx->timing_level = level;
     return PEP_OK;
 }
 

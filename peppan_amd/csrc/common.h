@@ -83,7 +83,7 @@ struct pep_ctx {
     hipEvent_t wait_event = nullptr;        // pep_stream_wait: marks the point of the stream the host is waiting for
     hipEvent_t k1_t0 = nullptr, k1_t1 = nullptr;   // pep_translate's timing pair (created once)
     uint32_t k1_desc_cap = 0;               // descriptor slots of the reference side's last K1 (the summary sits behind them in pin_k1)
-    bool t_tables_lazy = false;             // the reference side's host tables (t_meta, h_off, h_len) have not been built from pin_k1 yet (pep_k1_host_tables)
+    bool t_tables_lazy = false, q_tables_lazy = false;   // a side's host tables (meta records, h_off, h_len) have not been built from its pinned descriptors yet (pep_k1_host_tables)
     PinBuf pin_stage;                       // grow-only: the hit table of the newest search
     PinBuf pin_ms;                          // grow-only: per-query score thresholds on their way to the device
     pep_result *staged_result = nullptr;    // the result whose hits still live in pin_stage (materialised before it is overwritten)
@@ -118,6 +118,8 @@ struct pep_ctx {
     // the middle of a search costs a host round trip with the GPU idle, and lets nothing be queued behind a running SW pass)
     hipEvent_t tm_a[12] = {}, tm_b[12] = {};
     int tm_state[12] = {};                   // 0 idle, 1 begun, 2 ended (waiting to be read)
+    int timing_level = 0;                    // pep_set_timing: 0 no phase timers, 1 the score pass only, 2 all of them
+    PinBuf pin_labels;                       // grow-only: K10's labels on their way to the caller
     uint64_t trace_swept = 0;               // pairs the last traceback pass swept (the rest were settled by the gapless shortcut)
     struct ScanState { DevBuf buf; uint32_t epoch = 0, ticket_base = 0; };
     ScanState scan_state[2];                // single-launch scans (u32, u64): ticket counter + one status word per tile (scan.hip)
@@ -224,14 +226,17 @@ int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, const uint32_t
 // ---- translate.hip  (K1)
 int pep_k1_query(pep_ctx *ctx, int gtable, int phase = 0);
 int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase = 0);
-int pep_k1_host_tables(pep_ctx *ctx);      // builds the reference side's per-sequence host tables if its last K1 left them to be built on demand
+int pep_k1_host_tables(pep_ctx *ctx);      // builds the per-sequence host tables of both sides if their last K1 left them to be built on demand
+int pep_k1_host_tables_q(pep_ctx *ctx);    // the query side only (the search needs the query lengths for its score thresholds)
 int pep_nucl_sets(pep_ctx *ctx, int strands);      // the nucleotide sets themselves as residue sets (base codes; reference: forward strands + reverse complements)
 // ---- seeds.hip  (K2-K4)
-int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands);
+// before_sync (optional): host work to do once every kernel of the stage is queued, while the GPU runs them (the stage ends with a synchronisation)
+int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int (*before_sync)(pep_ctx *) = nullptr);
 int pep_upload_sub_table(pep_ctx *ctx);       // ctx->params.sub -> ctx->d_params (1 KiB, uploaded when it changed)
 // ---- sw.hip / trace.hip (K5, K6, K8)
 int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known = nullptr, const int32_t *d_end_lane = nullptr, const int32_t *d_skip_mode = nullptr,
                const uint32_t *d_n = nullptr, uint64_t dir_blocks_bound = 0, unsigned long long **d_hdr = nullptr);   // kernel time: phase timers TM_SW / TM_SW_TRACE
+// h_min_score: score threshold per query; nullptr = ctx->d_min_score holds them already (pep_search uploads them while the seed stage runs)
 int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n_cands, const int32_t *h_min_score, pep_result *res);
 int pep_selftest_dpp(pep_ctx *ctx);
 // ---- rescore.hip (K7)

@@ -663,7 +663,7 @@ int pep_upload_sub_table(pep_ctx *ctx)
 
 // workspace slots used here: ws[0] cnt, ws[1] start, ws[2] entries, ws[3] table, ws[4] list, ws[5] list tmp (sort),
 // ws[6] counters+stats, ws[7] scan scratch, ws[8] raw seed hits, ws[10..12] runs of hits (the sort histogram reuses ws[0])
-int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
+int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int (*before_sync)(pep_ctx *))
 {
     const pep_search_params &P = ctx->params;
     SeqSet &Q = ctx->q, &T = ctx->t;
@@ -671,7 +671,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
     *n_cands = 0;
     *d_cands = nullptr;
     ctx->stats.query_seeds = ctx->stats.target_seeds = ctx->stats.seed_hits = 0;
-    if (Q.n == 0 || T.n == 0) return PEP_OK;
+    if (Q.n == 0 || T.n == 0) return before_sync ? before_sync(ctx) : PEP_OK;
 
     // two buckets per query position, except that up to 40 M positions stay at 2^25 buckets (the average coarse bucket then holds 4 900
     // of the 5 632 entries a slab takes; 100k genes x 100k genes: 103 -> 94 ms per pass): that is the largest index the partition
@@ -800,6 +800,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands)
         struct { uint32_t counters[4]; unsigned long long stats[3]; uint32_t n_entries[4]; } h_all;     // counters[0..3], the three statistics words and the index sizes per shape: one copy
         static_assert(sizeof(h_all) == 56 && sizeof(h_all) <= 64, "layout of the counter block");
         PEP_TRY(pep_read_back(ctx, &h_all, counters, sizeof(h_all)));
+        if (before_sync) { PEP_TRY(before_sync(ctx)); before_sync = nullptr; }      // (once, also when the stage is repeated with larger buffers)
         PEP_TRY(pep_sync_reads(ctx));
         const uint32_t *h_counters = h_all.counters;
         const unsigned long long *h_stats = h_all.stats;

@@ -442,10 +442,12 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     // per-query score thresholds: uploaded from pinned memory BEFORE the score pass is queued (a copy from pageable memory makes the
     // host wait for everything queued ahead of it - behind the score pass that was the whole pass)
     DevBuf &dms = ctx->d_min_score;
-    PEP_TRY(dev_reserve(ctx, dms, (size_t)(ctx->q.n + 1) * 4));
-    PEP_TRY(pin_reserve(ctx, ctx->pin_ms, (size_t)(ctx->q.n + 1) * 4));
-    std::memcpy(ctx->pin_ms.p, h_min_score, (size_t)ctx->q.n * 4);
-    PEP_HIP(ctx, hipMemcpyAsync(dms.p, ctx->pin_ms.p, (size_t)ctx->q.n * 4, hipMemcpyHostToDevice, st));
+    if (h_min_score) {                            // (nullptr: the caller has uploaded them already)
+        PEP_TRY(dev_reserve(ctx, dms, (size_t)(ctx->q.n + 1) * 4));
+        PEP_TRY(pin_reserve(ctx, ctx->pin_ms, (size_t)(ctx->q.n + 1) * 4));
+        std::memcpy(ctx->pin_ms.p, h_min_score, (size_t)ctx->q.n * 4);
+        PEP_HIP(ctx, hipMemcpyAsync(dms.p, ctx->pin_ms.p, (size_t)ctx->q.n * 4, hipMemcpyHostToDevice, st));
+    }
     unsigned long long *score_hdr = nullptr, *trace_hdr = nullptr;
     PEP_TRY(pep_sw_run(ctx, d_cands, n, false, nullptr, nullptr, nullptr, nullptr, 0, &score_hdr));      // (the pass times come from the context's phase timers, read after the search)
 

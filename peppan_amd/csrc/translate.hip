@@ -330,10 +330,18 @@ __global__ void k1_offsets(const uint32_t *__restrict__ n_ptr, const uint32_t *_
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = *n_ptr;
     if (i <= cap) pk_off[i] = i < n ? scan[i] + PEP_END_PAD : scan[cap] + 2 * PEP_END_PAD;
+    // residues and longest sequence: one pair of atomics per block (a thousand wavefronts adding to the same two words took 18 us)
+    __shared__ unsigned long long blk_s[4];
+    __shared__ uint32_t blk_m[4];
     uint32_t L = i < n ? len[i] : 0u, m = L;
     unsigned long long s = L;
     for (int d = 32; d > 0; d >>= 1) { s += __shfl_xor(s, d, 64); m = max(m, (uint32_t)__shfl_xor((int)m, d, 64)); }
-    if ((threadIdx.x & 63) == 0 && m) { atomicAdd(&sum->residues, s); atomicMax(&sum->max_len, m); }
+    if ((threadIdx.x & 63) == 0) { blk_s[threadIdx.x >> 6] = s; blk_m[threadIdx.x >> 6] = m; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t bm = max(max(blk_m[0], blk_m[1]), max(blk_m[2], blk_m[3]));
+        if (bm) { atomicAdd(&sum->residues, blk_s[0] + blk_s[1] + blk_s[2] + blk_s[3]); atomicMax(&sum->max_len, bm); }
+    }
     if (i == 0) { sum->n = n; sum->total = (unsigned long long)scan[cap] + 2ull * PEP_END_PAD; }
 }
 
@@ -434,23 +442,35 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
     const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1q.p);
     PEP_HIP(ctx, pep_stream_wait(ctx));
     PEP_TRY(take_summary(ctx, desc, n, ctx->q));
-    // the query side's tables are small and the search wants the lengths (score thresholds): built at once
-    ctx->q_meta.resize(n);
-    for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, desc[i].frame, desc[i].len, (uint32_t)(nt.h_off[i + 1] - nt.h_off[i])};
-    finish_layout(desc, n, ctx->q);
+    ctx->q_tables_lazy = true;               // q_meta, h_off, h_len: pep_k1_host_tables (the search builds them while its seed stage runs)
     return PEP_OK;
 }
 
-// the per-sequence host tables of the reference side (meta records, offsets, lengths) from the descriptors its last K1 downloaded
+// the per-sequence host tables of both sides (meta records, offsets, lengths) from the descriptors their last K1 downloaded
 int pep_k1_host_tables(pep_ctx *ctx)
 {
-    if (!ctx->t_tables_lazy) return PEP_OK;
-    const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1.p);
-    const uint32_t n = ctx->t.n;
-    ctx->t_meta.resize(n);
-    for (uint32_t i = 0; i < n; ++i) ctx->t_meta[i] = pep_target_meta{desc[i].seq, desc[i].frame, desc[i].aa_off, desc[i].len};
-    finish_layout(desc, n, ctx->t);
-    ctx->t_tables_lazy = false;
+    if (ctx->t_tables_lazy) {
+        const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1.p);
+        const uint32_t n = ctx->t.n;
+        ctx->t_meta.resize(n);
+        for (uint32_t i = 0; i < n; ++i) ctx->t_meta[i] = pep_target_meta{desc[i].seq, desc[i].frame, desc[i].aa_off, desc[i].len};
+        finish_layout(desc, n, ctx->t);
+        ctx->t_tables_lazy = false;
+    }
+    return pep_k1_host_tables_q(ctx);
+}
+
+int pep_k1_host_tables_q(pep_ctx *ctx)
+{
+    if (ctx->q_tables_lazy) {
+        const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1q.p);
+        const NtSet &nt = ctx->q_nt;
+        const uint32_t n = ctx->q.n;
+        ctx->q_meta.resize(n);
+        for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, desc[i].frame, desc[i].len, (uint32_t)(nt.h_off[i + 1] - nt.h_off[i])};
+        finish_layout(desc, n, ctx->q);
+        ctx->q_tables_lazy = false;
+    }
     return PEP_OK;
 }
 
@@ -563,6 +583,7 @@ int pep_nucl_sets(pep_ctx *ctx, int strands)
     std::vector<NuclDesc> qo(ctx->q_nt.n), to;
     for (uint32_t i = 0; i < ctx->q_nt.n; ++i) qo[i] = NuclDesc{i, 0u};
     PEP_TRY(nucl_build(ctx, ctx->q_nt, qo, PEP_MAX_QUERIES, ctx->q));
+    ctx->q_tables_lazy = false;
     ctx->q_meta.resize(ctx->q_nt.n);
     for (uint32_t i = 0; i < ctx->q_nt.n; ++i) ctx->q_meta[i] = pep_query_meta{i, 1u, ctx->q.h_len[i], ctx->q.h_len[i]};
     // targets: per reference set (pep_set_target_groups; one set otherwise) all forward strands, then all reverse complements

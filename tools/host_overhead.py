@@ -4,6 +4,7 @@ import numpy as np
 from peppan_amd import _native as N, synth, dist as pdist
 names, seqs = synth.make_genes(10000, 1002, seed=355)
 ctx = N.Context(0)
+ctx.set_timing(2)
 ctx.set_query_nt(seqs, 11); ctx.set_ref_nt(seqs, 6, 11)
 p = N.default_params(45., 25., 10, 5)
 gene_of_target = None

@@ -6,6 +6,7 @@ from peppan_amd import _native as N, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 names, seqs = synth.make_genes(n, 1002, seed=355)
 ctx = N.Context(0)
+ctx.set_timing(2)
 ctx.set_query_nt(seqs, 11); ctx.set_ref_nt(seqs, 6, 11)
 for stage in (1, 2, 3, 0):
     p = N.default_params(45., 25., 10, 5)
