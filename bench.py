@@ -394,7 +394,7 @@ def main():
                     if best is None or tm['decide_ms'] < best['decide_ms']:
                         best = dict(tm, pairs=int(len(pairs)))
                 extras['get_similar_pairs_ms'] = best['decide_ms']
-                extras['get_similar_pairs'] = {'decide_ms': best['decide_ms'], 'search_ms': best['search_ms'], 'rows': best['rows'], 'pairs': best['pairs'],
+                extras['get_similar_pairs'] = {'decide_ms': best['decide_ms'], 'search_ms': best['search_ms'], 'decide_parts_ms': best.get('decide_parts_ms'), 'rows': best['rows'], 'pairs': best['pairs'],
                                                'note': 'decide = classification + host scan + K14 + resolve + exemplar rewrite; search = the uberBlast call in front of it (numeric table, FASTA re-read because the exemplar file was rewritten)'}
         # (d) the genes -> genomes mapping at N = 1 (bench.py --workload map is the same thing per rank): genomes/s on this GPU
         try:

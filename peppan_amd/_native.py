@@ -502,13 +502,14 @@ class Context(object):
 
     # ---- K9
     def linclust(self, seqs, min_id, min_cov, base=4, k=17, m=20):
-        """seqs: list of uint8 code arrays -> (uint32 representative index per sequence, stats dict)"""
+        """seqs: list of uint8 code arrays, or their (concatenation, uint64 offsets[n + 1]) -> (uint32 representative index per sequence, stats dict)"""
         codes, off = _pack(seqs)
+        n = _count(seqs)
         self.upload_generation += 1                     # the gapped stage takes over the packed sequence sets
-        rep = np.zeros(len(seqs), dtype=np.uint32)
+        rep = np.zeros(n, dtype=np.uint32)
         stats = np.zeros(3, dtype=np.uint64)
-        if len(seqs):
-            self._check(self._lib.pep_linclust(self._h, _ptr(codes), _ptr(off), C.c_uint32(len(seqs)), C.c_int(base), C.c_int(k), C.c_int(m),
+        if n:
+            self._check(self._lib.pep_linclust(self._h, _ptr(codes), _ptr(off), C.c_uint32(n), C.c_int(base), C.c_int(k), C.c_int(m),
                                                C.c_double(min_id), C.c_double(min_cov), _ptr(rep), _ptr(stats)), 'pep_linclust')
         return rep, dict(selected=int(stats[0]), verified=int(stats[1]), accepted=int(stats[2]))
 

@@ -151,17 +151,17 @@ void pep_materialise_staged(pep_ctx *ctx)
     ctx->staged_result = nullptr;
 }
 
-// block -> sequence map of a packed set (host build from the offsets, then upload)
+// block -> (sequence, start of the sequence) map of a packed set (host build from the offsets, then upload)
 int pep_upload_blk2seq(pep_ctx *ctx, SeqSet &s)
 {
     const uint64_t nblk = s.total / 16 + 1;
-    std::vector<uint32_t> m(nblk, 0u);
+    std::vector<uint2> m(nblk, make_uint2(0u, 0u));
     for (uint32_t i = 0; i < s.n; ++i) {
         const uint64_t b0 = s.h_off[i] / 16, b1 = ((uint64_t)s.h_off[i] + s.h_len[i] + 15) / 16;
-        for (uint64_t b = b0; b < b1 && b < nblk; ++b) m[b] = i;
+        for (uint64_t b = b0; b < b1 && b < nblk; ++b) m[b] = make_uint2(i, s.h_off[i]);
     }
-    PEP_TRY(dev_reserve(ctx, s.blk2seq, nblk * 4));
-    PEP_HIP(ctx, hipMemcpy(s.blk2seq.p, m.data(), nblk * 4, hipMemcpyHostToDevice));
+    PEP_TRY(dev_reserve(ctx, s.blk2seq, nblk * sizeof(uint2)));
+    PEP_HIP(ctx, hipMemcpy(s.blk2seq.p, m.data(), nblk * sizeof(uint2), hipMemcpyHostToDevice));
     return PEP_OK;
 }
 

@@ -305,7 +305,7 @@ struct JoinArgs {
     uint32_t nt;
     const uint32_t *q_off;
     uint32_t nq;
-    const uint32_t *q_blk2seq, *t_blk2seq;
+    const uint2 *q_blk2seq, *t_blk2seq;      // (sequence, its start) per 16-byte block of the packed sets
     const uint32_t *start;
     const uint64_t *entries;
     const unsigned long long *filter;     // filter_mask(): two bits per key in one 64-bit word (2 MiB for 2^23 buckets: stays in L2, unlike start[])
@@ -504,7 +504,7 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
 // equal candidate keys inside a wavefront becomes ONE work item (first hit, length, key) unless the candidate is in the set already.
 // No extension here: in the first version the extension code ran in this loop with one to three active lanes per wavefront
 // (the leaders of new runs) and cost its full instruction stream each time - 0.27 ms per shape, 53 % scalar-unit utilisation.
-constexpr int RUN_BUF = 1024;
+constexpr int RUN_BUF = 1024;       // >= RUN_BUF / 2 + 256 * RUN_UNROLL entries (seed_runs)
 __global__ __launch_bounds__(256) void seed_runs(JoinArgs a, uint64_t *__restrict__ run_first, uint32_t *__restrict__ run_len, uint64_t *__restrict__ run_key,
                                                  unsigned long long *__restrict__ n_runs)
 {
@@ -519,37 +519,63 @@ __global__ __launch_bounds__(256) void seed_runs(JoinArgs a, uint64_t *__restric
     unsigned long long n_hits = *a.hit_count;
     if (n_hits > a.hit_cap) n_hits = a.hit_cap;
     const int lane = threadIdx.x & 63;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t b0 = (uint64_t)blockIdx.x * 256; b0 < n_hits; b0 += stride) {      // block-uniform trip count
-        const uint64_t h = b0 + threadIdx.x;
-        const bool valid = h < n_hits;
-        uint64_t ck = ~0ull;
-        if (valid) {
-            const uint64_t hit = a.hits[h];
-            const uint32_t qp = (uint32_t)(hit >> 32), p = (uint32_t)hit;
-            const uint32_t t = a.t_blk2seq[p >> 4], q = a.q_blk2seq[qp >> 4];
-            const int32_t diag = (int32_t)(p - a.t_off[t]) - (int32_t)(qp - a.q_off[q]);
-            const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
-            ck = ((uint64_t)q << 43) | ((uint64_t)t << 18) | (uint64_t)bin;
+    // RUN_UNROLL rounds of 256 hits per trip: the loads of a round (hit, two block look-ups, up to two probes of the set) are a chain of
+    // dependent latencies and a trip ends in a barrier - with one round per trip a block spent ~7 us per 256 hits waiting for them one
+    // after the other; the rounds of a trip are independent, so their chains overlap
+    constexpr int RUN_UNROLL = 2;
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * RUN_UNROLL;
+    for (uint64_t b0 = (uint64_t)blockIdx.x * 256 * RUN_UNROLL; b0 < n_hits; b0 += stride) {      // block-uniform trip count
+        uint64_t hh[RUN_UNROLL], ck[RUN_UNROLL];
+        bool valid[RUN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RUN_UNROLL; ++u) {
+            hh[u] = b0 + (uint64_t)u * 256 + threadIdx.x;
+            valid[u] = hh[u] < n_hits;
         }
-        const uint32_t lo = (uint32_t)ck, hi = (uint32_t)(ck >> 32);
-        const uint32_t lo_prev = __shfl_up(lo, 1, 64), hi_prev = __shfl_up(hi, 1, 64);     // unconditional: every lane must take part in the shuffles
-        const bool leader = valid && !(a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi);
-        const unsigned long long leaders = __ballot(leader);
-        const unsigned long long valid_m = __ballot(valid);
-        const unsigned long long above = lane == 63 ? 0ull : (leaders & (~0ull << (lane + 1)));          // next run starts at its lowest set bit
-        const int next = above ? __builtin_ctzll(above) : __popcll(valid_m);                              // valid lanes are a prefix
+        uint64_t hit[RUN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RUN_UNROLL; ++u) hit[u] = valid[u] ? a.hits[hh[u]] : 0ull;
+#pragma unroll
+        for (int u = 0; u < RUN_UNROLL; ++u) {
+            ck[u] = ~0ull;
+            if (valid[u]) {
+                const uint32_t qp = (uint32_t)(hit[u] >> 32), p = (uint32_t)hit[u];
+                const uint2 tb = a.t_blk2seq[p >> 4], qb = a.q_blk2seq[qp >> 4];          // one look-up per side (sequence and its start together: not two dependent ones)
+                const int32_t diag = (int32_t)(p - tb.y) - (int32_t)(qp - qb.y);
+                const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
+                ck[u] = ((uint64_t)qb.x << 43) | ((uint64_t)tb.x << 18) | (uint64_t)bin;
+            }
+        }
+        bool leader[RUN_UNROLL], need_probe[RUN_UNROLL];
+        int run_len_u[RUN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RUN_UNROLL; ++u) {
+            const uint32_t lo = (uint32_t)ck[u], hi = (uint32_t)(ck[u] >> 32);
+            const uint32_t lo_prev = __shfl_up(lo, 1, 64), hi_prev = __shfl_up(hi, 1, 64);     // unconditional: every lane must take part in the shuffles
+            leader[u] = valid[u] && !(a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi);
+            const unsigned long long leaders = __ballot(leader[u]);
+            const unsigned long long valid_m = __ballot(valid[u]);
+            const unsigned long long above = lane == 63 ? 0ull : (leaders & (~0ull << (lane + 1)));          // next run starts at its lowest set bit
+            const int next = above ? __builtin_ctzll(above) : __popcll(valid_m);                              // valid lanes are a prefix
+            run_len_u[u] = next - lane;
+            need_probe[u] = leader[u] && run_len_u[u] > 1;
+        }
         // a run of ONE hit is almost always a chance hit of the reduced alphabet whose candidate is in no set: it goes straight to the
         // extension (which decides) instead of paying a scattered probe of the set here and another one there; longer runs - homologous
         // diagonals - are dropped here when their candidate is established already (an earlier run, shape or launch)
-        const bool emit_run = leader && (next - lane == 1 || !set_contains(a, ck));
-        const unsigned long long emit_m = __ballot(emit_run);
-        uint32_t off = 0;
-        if (lane == 0 && emit_m) off = atomicAdd(&s_n, (uint32_t)__popcll(emit_m));
-        off = (uint32_t)__shfl((int)off, 0, 64);
-        if (emit_run) {
-            const uint32_t slot = off + (uint32_t)__popcll(emit_m & ((1ull << lane) - 1ull));           // < RUN_BUF: flushed above RUN_BUF / 2, <= 256 per round
-            s_first[slot] = h; s_len[slot] = (uint32_t)(next - lane); s_key[slot] = ck;
+        bool emit_run[RUN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < RUN_UNROLL; ++u) emit_run[u] = leader[u] && (!need_probe[u] || !set_contains(a, ck[u]));
+#pragma unroll
+        for (int u = 0; u < RUN_UNROLL; ++u) {
+            const unsigned long long emit_m = __ballot(emit_run[u]);
+            uint32_t off = 0;
+            if (lane == 0 && emit_m) off = atomicAdd(&s_n, (uint32_t)__popcll(emit_m));
+            off = (uint32_t)__shfl((int)off, 0, 64);
+            if (emit_run[u]) {
+                const uint32_t slot = off + (uint32_t)__popcll(emit_m & ((1ull << lane) - 1ull));       // < RUN_BUF: flushed above RUN_BUF / 2, <= 256 * RUN_UNROLL per trip
+                s_first[slot] = hh[u]; s_len[slot] = (uint32_t)run_len_u[u]; s_key[slot] = ck[u];
+            }
         }
         __syncthreads();
         const uint32_t cnt = s_n;                    // block-uniform after the barrier
@@ -775,7 +801,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             }
             JoinArgs a;
             a.t_res = T.res.as<const uint8_t>(); a.t_total = T.total; a.t_off = T.off.as<const uint32_t>(); a.nt = T.n;
-            a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint32_t>(); a.t_blk2seq = T.blk2seq.as<const uint32_t>(); a.start = start; a.entries = entries; a.filter = filter; a.bucket_bits = bucket_bits;
+            a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint2>(); a.t_blk2seq = T.blk2seq.as<const uint2>(); a.start = start; a.entries = entries; a.filter = filter; a.bucket_bits = bucket_bits;
             a.table = ctx->d_set.as<uint64_t>(); a.table_bits = table_bits;
             a.counters = counters; a.stats = stats;
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();

@@ -151,7 +151,7 @@ struct PackDesc {          // one per packed sequence: where its residues come f
 // the 20 M reference residues, bound by the latency of that search.)
 __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, int tab,
                                                const PackDesc *__restrict__ desc, const uint32_t *__restrict__ pk_off, const uint32_t *__restrict__ n_ptr, uint32_t cap,
-                                               uint8_t *__restrict__ res, uint32_t *__restrict__ blk2seq)
+                                               uint8_t *__restrict__ res, uint2 *__restrict__ blk2seq)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
         }
         __builtin_amdgcn_wave_barrier();                                 // the next chunk overwrites the staging area
     }
-    for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = s;
+    for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = make_uint2(s, start);
 }
 
 // ---- nucleotide sets as residue sets (the blastn-equivalent tool, uberBlast.py:294, 482-509): base codes A0 C1 G2 T3, anything else 4;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
 // 8-byte load where the whole window lies inside the sequence, byte loads at its two ends), padding and block -> sequence map as k1_pack.
 struct NuclDesc { uint32_t seq, rev; };
 __global__ __launch_bounds__(256) void nucl_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, const NuclDesc *__restrict__ desc,
-                                                 const uint32_t *__restrict__ pk_off, uint32_t n_packed, uint8_t *__restrict__ res, uint32_t *__restrict__ blk2seq)
+                                                 const uint32_t *__restrict__ pk_off, uint32_t n_packed, uint8_t *__restrict__ res, uint2 *__restrict__ blk2seq)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void nucl_pack(const uint8_t *__restrict__ nt,
         }
         *reinterpret_cast<uint2 *>(res + start + x0) = make_uint2(word[0], word[1]);                 // starts and paddings are multiples of 16: whole words
     }
-    for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = s;
+    for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = make_uint2(s, start);
 }
 
 void fill_codon_table(uint8_t tab[2][64])
@@ -351,7 +351,7 @@ int reserve_packed(pep_ctx *ctx, SeqSet &out, uint32_t cap, uint64_t upper)
     PEP_TRY(dev_reserve(ctx, out.res, upper + 64));
     PEP_TRY(dev_reserve(ctx, out.off, ((size_t)cap + 2) * 4));
     PEP_TRY(dev_reserve(ctx, out.len, ((size_t)cap + 2) * 4));
-    PEP_TRY(dev_reserve(ctx, out.blk2seq, (upper / 16 + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, out.blk2seq, (upper / 16 + 2) * sizeof(uint2)));
     return PEP_OK;
 }
 
@@ -366,7 +366,7 @@ int layout_and_pack(pep_ctx *ctx, const NtSet &nt, int tab, const PackDesc *d_de
     hipLaunchKernelGGL(k1_offsets, dim3((unsigned)ceil_div((uint64_t)cap + 1, 256)), dim3(256), 0, ctx->stream, d_n, d_scan.as<const uint32_t>(), cap, out.off.as<uint32_t>(),
                        out.len.as<const uint32_t>(), d_sum);
     hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div((uint64_t)cap + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
-                       d_desc, out.off.as<const uint32_t>(), d_n, cap, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>());
+                       d_desc, out.off.as<const uint32_t>(), d_n, cap, out.res.as<uint8_t>(), out.blk2seq.as<uint2>());
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }
@@ -566,13 +566,13 @@ static int nucl_build(pep_ctx *ctx, const NtSet &nt, const std::vector<NuclDesc>
     PEP_TRY(dev_reserve(ctx, out.res, pos + 64));
     PEP_TRY(dev_reserve(ctx, out.off, ((size_t)n + 2) * 4));
     PEP_TRY(dev_reserve(ctx, out.len, ((size_t)n + 2) * 4));
-    PEP_TRY(dev_reserve(ctx, out.blk2seq, (pos / 16 + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, out.blk2seq, (pos / 16 + 2) * sizeof(uint2)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[2], ((size_t)n + 1) * sizeof(NuclDesc)));
     PEP_HIP(ctx, hipMemcpyAsync(out.off.p, out.h_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     if (n) PEP_HIP(ctx, hipMemcpyAsync(out.len.p, out.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     if (n) PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[2].p, order.data(), (size_t)n * sizeof(NuclDesc), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(nucl_pack, dim3((unsigned)ceil_div((uint64_t)n + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(),
-                       ctx->ws[2].as<const NuclDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), out.blk2seq.as<uint32_t>());
+                       ctx->ws[2].as<const NuclDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), out.blk2seq.as<uint2>());
     PEP_HIP(ctx, hipGetLastError());
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (the descriptor vector is the caller's)
     return PEP_OK;

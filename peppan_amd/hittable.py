@@ -25,6 +25,8 @@ def _pyrows():
         lib = C.PyDLL(path)
         lib.pep_rows_fill.restype = C.c_int
         lib.pep_rows_fill.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.py_object, C.py_object] + [C.c_void_p] * 12 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
+        lib.pep_genes_scan.restype = C.c_ssize_t
+        lib.pep_genes_scan.argtypes = [C.py_object, C.py_object, C.py_object] + [C.c_void_p] * 5 + [C.c_ssize_t]
         _PYROWS = lib
     return _PYROWS
 

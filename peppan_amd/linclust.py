@@ -25,8 +25,18 @@ def looks_like_protein(seqs):
 def linclust_file(fasta, identity, coverage, device=None):
     recs = readFasta(fasta)
     names = [n for n, _ in recs]
-    protein = looks_like_protein([s for _, s in recs])
-    codes = [encode(s, protein) for _, s in recs]
+    seqs = [s for _, s in recs]
+    protein = looks_like_protein(seqs)
+    # all sequences encoded in one table look-up over their concatenation (an array per sequence cost a second per 300 k genes)
+    try:
+        text = ''.join(seqs).encode('ascii')
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs)))
+        codes = ((_AA if protein else _NT)[np.frombuffer(text, dtype=np.uint8)] if len(text) else np.zeros(1, np.uint8), off)
+        n = len(seqs)
+    except UnicodeEncodeError:
+        codes = [encode(s, protein) for s in seqs]
+        n = len(codes)
     base, k = (20, 7) if protein else (4, 17)
-    rep, _ = get_context(device).linclust(codes, float(identity), float(coverage), base=base, k=k, m=20)
+    rep, _ = get_context(device).linclust(codes, float(identity), float(coverage), base=base, k=k, m=20) if n else (np.zeros(0, np.uint32), None)
     return [(names[r], names[i]) for i, r in enumerate(rep.tolist())]

@@ -26,6 +26,23 @@ def gene_hashes(seqs, ctx=None):
     return [int.from_bytes(d.tobytes(), 'big') for d in ctx.sha1(seqs)]
 
 
+def _lexsort_priority(a0, a1, code):
+    """order of the rows under (a0, a1, 160-bit code as 20 big-endian bytes), stable: what sorted(..., key=itemgetter(1)) gives for PEPPAN's
+    priorities [file rank, -length, sha1 code] (PEPPAN.py:746-751, 1027)"""
+    h0 = np.ascontiguousarray(code[:, 0:8]).view('>u8').ravel().astype(np.uint64)
+    h1 = np.ascontiguousarray(code[:, 8:16]).view('>u8').ravel().astype(np.uint64)
+    h2 = np.ascontiguousarray(code[:, 16:20]).view('>u4').ravel().astype(np.uint64)
+    keys = [h2, h1, h0]
+    # the two small integers in one column when their ranges allow it (one stable pass less over five million rows)
+    lo0, lo1 = int(a0.min()), int(a1.min())
+    r0, r1 = int(a0.max()) - lo0 + 1, int(a1.max()) - lo1 + 1
+    if r0 * r1 < (1 << 62):
+        keys.append((a0 - lo0) * r1 + (a1 - lo1))
+    else:
+        keys += [a1, a0]
+    return np.lexsort(keys)
+
+
 def _priority_order(names, priority):
     """the names in the order sorted(priority.items(), key=itemgetter(1)) visits them (PEPPAN.py:1027): PEPPAN's priorities are
     [file rank, -length, sha1 code] (PEPPAN.py:746-751) - three integers, the last one of 160 bits - and a stable lexsort over the
@@ -41,39 +58,62 @@ def _priority_order(names, priority):
         if any(type(v[0]) is not int or type(v[1]) is not int for v in vals[:64]):
             raise TypeError
         code = np.frombuffer(b''.join([int(v[2]).to_bytes(20, 'big') for v in vals]), dtype=np.uint8).reshape(m, 20)
-        h0 = np.ascontiguousarray(code[:, 0:8]).view('>u8').ravel().astype(np.uint64)
-        h1 = np.ascontiguousarray(code[:, 8:16]).view('>u8').ravel().astype(np.uint64)
-        h2 = np.ascontiguousarray(code[:, 16:20]).view('>u4').ravel().astype(np.uint64)
-        return np.lexsort((h2, h1, h0, a1, a0))
+        return _lexsort_priority(a0, a1, code)
     except (TypeError, ValueError, OverflowError, AttributeError):
         return np.array(sorted(range(m), key=lambda i: vals[i]), dtype=np.int64)
+
+
+def _scan_genes(genes, priority):
+    """names (dictionary order of `priority`, genes with a non-empty sequence only), their priority order, sequence lengths and sha1 digests
+    in ONE C pass over the two dictionaries (csrc/pyrows.c pep_genes_scan) -> (names, order index, lengths uint32, digests uint8[n, 20]),
+    or None when the values are not PEPPAN's [int, int, 160-bit int] / plain dicts (the caller then goes the Python way)"""
+    import ctypes as C
+    from .hittable import _pyrows
+    if type(genes) is not dict or type(priority) is not dict:
+        return None
+    cap = len(priority)
+    p0, p1, seq_len = np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.int64)
+    code, digest = np.empty((cap, 20), np.uint8), np.empty((cap, 20), np.uint8)
+    names = []
+    n = _pyrows().pep_genes_scan(priority, genes, names, *[C.c_void_p(a.ctypes.data) for a in (p0, p1, code, seq_len, digest)], cap)
+    if n < 0:
+        return None
+    if n == 0:
+        return names, np.zeros(0, np.int64), np.zeros(0, np.uint32), np.zeros((0, 20), np.uint8)
+    idx = _lexsort_priority(p0[:n], p1[:n], code[:n])
+    return names, idx, seq_len[:n][idx].astype(np.uint32), np.ascontiguousarray(digest[:n][idx])
 
 
 def writeGenes(fname, genes, priority, ctx=None):
     """genes in priority order; a gene whose (length, sha1) equals an already written one of the SAME length run is
     reported as its duplicate.  The reference rebuilds its seen-table whenever a length not currently in it shows up
     (PEPPAN.py:1032-1033), so duplicates are only found while one length is 'open'.  The collapse itself runs on the GPU
-    (K13 `pep_dedup`: smallest priority index per (length run, digest)); the priority order is a lexsort over numeric columns and the
-    FASTA leaves in one write."""
+    (K13 `pep_dedup`: smallest priority index per (length run, digest)); the two dictionaries are read in one C pass (names, priorities,
+    lengths, digests as columns), the priority order is a lexsort over those columns and the FASTA leaves in one write."""
     ctx = ctx or get_context()
-    names = [n for n in priority if n in genes and len(genes[n][6])]          # dictionary order: ties of the sort keep it (sorted() is stable)
-    idx = _priority_order(names, priority)
-    order = [names[i] for i in idx.tolist()]
-    lengths = np.fromiter((len(genes[n][6]) for n in order), dtype=np.int64, count=len(order)).astype(np.uint32)
-    digests = np.frombuffer(b''.join([int(genes[n][5]).to_bytes(20, 'big') for n in order]), dtype=np.uint8).reshape(-1, 20)
+    scanned = _scan_genes(genes, priority)
+    if scanned is not None:
+        names, idx, lengths, digests = scanned
+        order = np.array(names, dtype=object)[idx] if len(names) else np.zeros(0, dtype=object)
+    else:
+        names = [n for n in priority if n in genes and len(genes[n][6])]          # dictionary order: ties of the sort keep it (sorted() is stable)
+        idx = _priority_order(names, priority)
+        order = np.array([names[i] for i in idx.tolist()], dtype=object) if len(names) else np.zeros(0, dtype=object)
+        lengths = np.fromiter((len(genes[n][6]) for n in order), dtype=np.int64, count=len(order)).astype(np.uint32)
+        digests = np.frombuffer(b''.join([int(genes[n][5]).to_bytes(20, 'big') for n in order]), dtype=np.uint8).reshape(-1, 20)
     rep = ctx.dedup(lengths, digests).astype(np.int64)
     own = rep == np.arange(len(rep))
     with open(fname, 'w') as fout:
-        fout.write(''.join(['>{0}\n{1}\n'.format(order[i], genes[order[i]][6]) for i in np.flatnonzero(own).tolist()]))
+        fout.write(''.join(['>{0}\n{1}\n'.format(n, genes[n][6]) for n in order[own].tolist()]))
     dup = np.flatnonzero(~own)
-    if len(dup) and all(type(n) is int for n in order[:64]) and all(type(order[i]) is int for i in dup[:64].tolist()):
+    head = order[:64].tolist() + order[dup[:64]].tolist()
+    if len(dup) and all(type(n) is int for n in head):
         try:
-            ids = np.array(order, dtype=np.int64)
+            ids = order.astype(np.int64)
             return fname, np.column_stack([ids[rep[dup]], ids[dup], np.full(len(dup), 10000, dtype=np.int64)]).tolist()
         except (OverflowError, TypeError, ValueError):
             pass
-    rep_l = rep.tolist()
-    return fname, [[order[rep_l[i]], order[i], 10000] for i in dup.tolist()]
+    return fname, [[a, b, 10000] for a, b in zip(order[rep[dup]].tolist(), order[dup].tolist())]
 
 
 def identity_schedule(target):
@@ -157,6 +197,8 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
     t1 = time.perf_counter()
     pairs = np.array([], dtype=int)
     alive_ids, absorbed = set(), []
+    marks = [('search', t1)]
+    mark = lambda what: marks.append((what, time.perf_counter()))
     if len(T):
         q_ids = np.array([int(x) for x in T.q_tab], dtype=np.int64)                   # the reference casts both name columns to int (PEPPAN.py:231)
         r_ids = q_ids if T.r_tab is T.q_tab else np.array([int(x) for x in T.r_tab], dtype=np.int64)
@@ -164,7 +206,9 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
         q, r = np.searchsorted(genes, q_ids)[T.qi], np.searchsorted(genes, r_ids)[T.ri]
         rank = np.array([priorities[g][0] for g in genes.tolist()])
         action, forward, iden4 = _classify_rows(T, rank[q], rank[r], q, r, params['clust_identity'], params['clust_match_prop'])
+        mark('classify')
         sc = N.similar_scan(q, r, action, forward, iden4, len(genes))
+        mark('scan')
         rows_of = sc['ev_rows']
         sup = np.zeros(len(rows_of), dtype=N.SUPPORT_ROW_DTYPE)
         sup['q_start'], sup['r_start'], sup['identity'] = T.qs[rows_of], T.ss[rows_of], T.iden[rows_of]
@@ -173,35 +217,43 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
         # lengths of a group's two genes from its first row (conflict events carry no rows: any row will do, they are not judged)
         first = rows_of[np.minimum(off[:-1], len(rows_of) - 1)] if len(rows_of) else np.zeros(len(off) - 1, dtype=np.int64)
         value = (ctx or get_context()).pair_support(sup, T.arena, off, T.ql[first], T.sl[first], N.support_limits(params))
+        mark('pair_support')
         res = N.similar_resolve(sc['ev_kind'], sc['ev_a'], sc['ev_b'], value)
         if len(res):
             pairs = np.column_stack([genes[res[:, 0]], genes[res[:, 1]], res[:, 2]]).astype(int)
         alive_ids = set(genes[(sc['alive'] > 0) & (sc['seen_as_query'] > 0)].tolist())
         ab = sc['absorbed']
         absorbed = np.column_stack([genes[ab[:, 0]], genes[ab[:, 1]], ab[:, 2]]).tolist() if len(ab) else []
+        mark('resolve')
     _drop_dead_exemplars(params['clust'], alive_ids)
+    mark('rewrite')
     if absorbed:
         npy = params['clust'].rsplit('.', 1)[0] + '.npy'
         edges = np.vstack([np.load(npy, allow_pickle=True), absorbed])
         np.save(npy, edges[np.argsort(-edges.T[2])])
     if timing is not None:
-        timing.update(search_ms=(t1 - t0) * 1e3, decide_ms=(time.perf_counter() - t1) * 1e3, rows=len(T))
+        timing.update(search_ms=(t1 - t0) * 1e3, decide_ms=(time.perf_counter() - t1) * 1e3, rows=len(T),
+                      decide_parts_ms={b[0]: (b[1] - a[1]) * 1e3 for a, b in zip(marks, marks[1:])})
     return pairs
-
-
-_HEADER_LINE = re.compile(rb'^>([^\n]*)', re.M)
 
 
 def _drop_dead_exemplars(fasta, alive_ids):
     """rewrite the exemplar FASTA in place, keeping the records (header line and the lines behind it, byte for byte) of genes that appeared as
-    a query and are still alive (PEPPAN.py:278-288).  The header lines are located in one pass over the file's bytes and the kept stretches
-    are written straight from that buffer; the file is left alone when every record stays."""
+    a query and are still alive (PEPPAN.py:278-288).  The header lines are located with bytes.find over the file's buffer (a regular
+    expression over the 10 MB of 10 000 exemplars took twelve times as long) and the kept stretches are written straight from that
+    buffer; the file is left alone when every record stays."""
     with open(fasta, 'rb') as fin:
         data = fin.read()
-    starts, keep = [], []
-    for m in _HEADER_LINE.finditer(data):
-        name = m.group(1).split()
-        starts.append(m.start())
+    find = data.find
+    starts = [0] if data[:1] == b'>' else []
+    p = find(b'\n>')
+    while p >= 0:
+        starts.append(p + 1)
+        p = find(b'\n>', p + 2)
+    keep = []
+    for s in starts:
+        e = find(b'\n', s)
+        name = data[s + 1:e if e >= 0 else len(data)].split()
         keep.append(bool(name) and int(name[0]) in alive_ids)
     if all(keep) and (not starts or starts[0] == 0):
         return

@@ -41,6 +41,7 @@ def main():
                     pr.disable()
                 dt = time.perf_counter() - t
             print('get_similar_pairs: %.1f ms total (search %.1f ms, decision pass %.1f ms), %d rows -> %d pairs' % (dt * 1e3, tm['search_ms'], tm['decide_ms'], tm['rows'], len(pairs)))
+            print('   decision pass by part (ms):', {k: round(v, 2) for k, v in tm.get('decide_parts_ms', {}).items()})
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(30)
     print(s.getvalue())
