@@ -26,6 +26,53 @@ def gene_hashes(seqs, ctx=None):
     return [int.from_bytes(d.tobytes(), 'big') for d in ctx.sha1(seqs)]
 
 
+class EdgeTable:
+    """The duplicate pairs writeGenes returns - rows [kept gene, duplicate, 10000] - as ONE int64[n, 3] block instead of n Python lists of
+    three Python integers (4.7 M rows at BASELINE configs[2]: the lists alone cost four seconds to build and three more to turn back into
+    the array iterClust saves).  It answers what PEPPAN does with the value (PEPPAN.py:1880-1884, 1790-1791): append() of further rows,
+    np.array(table, dtype=int), len(), iteration, indexing, comparison with a list of rows; tolist() gives the plain list."""
+
+    def __init__(self, block):
+        self._block = np.ascontiguousarray(block, dtype=np.int64).reshape(-1, 3)
+        self._extra = []
+
+    def append(self, row):
+        self._extra.append(row)
+
+    def extend(self, rows):
+        self._extra.extend(rows)
+
+    def __len__(self):
+        return len(self._block) + len(self._extra)
+
+    def __iter__(self):
+        yield from self._block.tolist()
+        yield from self._extra
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return self.tolist()[i]
+        n = len(self._block)
+        if i < 0:
+            i += len(self)
+        return self._block[i].tolist() if i < n else self._extra[i - n]
+
+    def __array__(self, dtype=None, copy=None):
+        out = self._block if not self._extra else np.vstack([self._block, np.array(self._extra, dtype=dtype or np.int64).reshape(-1, 3)])
+        return out.astype(dtype) if dtype is not None and out.dtype != np.dtype(dtype) else (out.copy() if copy else out)
+
+    def tolist(self):
+        return self._block.tolist() + list(self._extra)
+
+    def __eq__(self, other):
+        if isinstance(other, EdgeTable):
+            other = other.tolist()
+        return self.tolist() == other
+
+    def __repr__(self):
+        return 'EdgeTable(%d rows)' % len(self)
+
+
 def _lexsort_priority(a0, a1, code):
     """order of the rows under (a0, a1, 160-bit code as 20 big-endian bytes), stable: what sorted(..., key=itemgetter(1)) gives for PEPPAN's
     priorities [file rank, -length, sha1 code] (PEPPAN.py:746-751, 1027)"""
@@ -110,7 +157,8 @@ def writeGenes(fname, genes, priority, ctx=None):
     if len(dup) and all(type(n) is int for n in head):
         try:
             ids = order.astype(np.int64)
-            return fname, np.column_stack([ids[rep[dup]], ids[dup], np.full(len(dup), 10000, dtype=np.int64)]).tolist()
+            pairs = np.column_stack([ids[rep[dup]], ids[dup], np.full(len(dup), 10000, dtype=np.int64)])
+            return fname, (EdgeTable(pairs) if len(pairs) > 100000 else pairs.tolist())      # (small tables stay plain lists)
         except (OverflowError, TypeError, ValueError):
             pass
     return fname, [[a, b, 10000] for a, b in zip(order[rep[dup]].tolist(), order[dup].tolist())]
@@ -200,8 +248,13 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
     marks = [('search', t1)]
     mark = lambda what: marks.append((what, time.perf_counter()))
     if len(T):
-        q_ids = np.array([int(x) for x in T.q_tab], dtype=np.int64)                   # the reference casts both name columns to int (PEPPAN.py:231)
-        r_ids = q_ids if T.r_tab is T.q_tab else np.array([int(x) for x in T.r_tab], dtype=np.int64)
+        def as_ids(tab):                                                                # the reference casts both name columns to int (PEPPAN.py:231)
+            try:
+                return np.array(tab).astype(np.int64)                                   # (one C conversion of the whole column)
+            except (ValueError, TypeError, OverflowError):
+                return np.array([int(x) for x in tab], dtype=np.int64)
+        q_ids = as_ids(T.q_tab)
+        r_ids = q_ids if T.r_tab is T.q_tab else as_ids(T.r_tab)
         genes = np.unique(np.concatenate([q_ids[np.unique(T.qi)], r_ids[np.unique(T.ri)]]))      # sorted: codes keep the order of the ids
         q, r = np.searchsorted(genes, q_ids)[T.qi], np.searchsorted(genes, r_ids)[T.ri]
         rank = np.array([priorities[g][0] for g in genes.tolist()])
@@ -240,8 +293,8 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
 def _drop_dead_exemplars(fasta, alive_ids):
     """rewrite the exemplar FASTA in place, keeping the records (header line and the lines behind it, byte for byte) of genes that appeared as
     a query and are still alive (PEPPAN.py:278-288).  The header lines are located with bytes.find over the file's buffer (a regular
-    expression over the 10 MB of 10 000 exemplars took twelve times as long) and the kept stretches are written straight from that
-    buffer; the file is left alone when every record stays."""
+    expression over the 10 MB of 10 000 exemplars took twelve times as long), the names are tested against the alive set as one integer
+    column, and the kept stretches are written straight from that buffer; the file is left alone when every record stays."""
     with open(fasta, 'rb') as fin:
         data = fin.read()
     find = data.find
@@ -250,26 +303,29 @@ def _drop_dead_exemplars(fasta, alive_ids):
     while p >= 0:
         starts.append(p + 1)
         p = find(b'\n>', p + 2)
-    keep = []
-    for s in starts:
-        e = find(b'\n', s)
-        name = data[s + 1:e if e >= 0 else len(data)].split()
-        keep.append(bool(name) and int(name[0]) in alive_ids)
-    if all(keep) and (not starts or starts[0] == 0):
+    n = len(starts)
+    heads = [data[s + 1:s + 65] for s in starts]                  # enough for the name: the first token of the header line
+    try:
+        names = [h.split(None, 1)[0] if h[:1] not in b' \t\r\n' else b'' for h in heads]
+        if any(len(h) == 64 and len(t) == 64 for h, t in zip(heads, names)):
+            raise ValueError                                       # a name longer than the window: the plain way below
+        ids = np.array(names, dtype='S64').astype(np.int64) if n else np.zeros(0, np.int64)
+        keep = np.isin(ids, np.fromiter(alive_ids, dtype=np.int64, count=len(alive_ids)))
+    except (ValueError, IndexError, OverflowError):
+        keep = np.zeros(n, dtype=bool)
+        for k, s in enumerate(starts):
+            e = find(b'\n', s)
+            name = data[s + 1:e if e >= 0 else len(data)].split()
+            keep[k] = bool(name) and int(name[0]) in alive_ids
+    if keep.all() and (not starts or starts[0] == 0):
         return
     starts.append(len(data))
     view = memoryview(data)
+    # runs of kept records, each written in one piece
+    edge = np.flatnonzero(np.diff(np.concatenate([[False], keep, [False]]).astype(np.int8)))
     with open(fasta, 'wb') as fout:
-        k, n = 0, len(keep)
-        while k < n:
-            if not keep[k]:
-                k += 1
-                continue
-            j = k
-            while j < n and keep[j]:
-                j += 1
-            fout.write(view[starts[k]:starts[j]])          # a run of kept records in one piece
-            k = j
+        for k, j in zip(edge[0::2].tolist(), edge[1::2].tolist()):
+            fout.write(view[starts[k]:starts[j]])
 
 
 def _edges(cluFile, bsnFile):
