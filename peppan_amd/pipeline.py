@@ -255,9 +255,12 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
                 return np.array([int(x) for x in tab], dtype=np.int64)
         q_ids = as_ids(T.q_tab)
         r_ids = q_ids if T.r_tab is T.q_tab else as_ids(T.r_tab)
-        genes = np.unique(np.concatenate([q_ids[np.unique(T.qi)], r_ids[np.unique(T.ri)]]))      # sorted: codes keep the order of the ids
+        seen_q, seen_r = np.zeros(len(q_ids), dtype=bool), np.zeros(len(r_ids), dtype=bool)
+        seen_q[T.qi] = True
+        seen_r[T.ri] = True
+        genes = np.unique(np.concatenate([q_ids[seen_q], r_ids[seen_r]]))      # sorted: codes keep the order of the ids
         q, r = np.searchsorted(genes, q_ids)[T.qi], np.searchsorted(genes, r_ids)[T.ri]
-        rank = np.array([priorities[g][0] for g in genes.tolist()])
+        rank = np.array(list(map(itemgetter(0), map(priorities.__getitem__, genes.tolist()))))
         action, forward, iden4 = _classify_rows(T, rank[q], rank[r], q, r, params['clust_identity'], params['clust_match_prop'])
         mark('classify')
         sc = N.similar_scan(q, r, action, forward, iden4, len(genes))
@@ -323,9 +326,8 @@ def _drop_dead_exemplars(fasta, alive_ids):
     view = memoryview(data)
     # runs of kept records, each written in one piece
     edge = np.flatnonzero(np.diff(np.concatenate([[False], keep, [False]]).astype(np.int8)))
-    with open(fasta, 'wb') as fout:
-        for k, j in zip(edge[0::2].tolist(), edge[1::2].tolist()):
-            fout.write(view[starts[k]:starts[j]])
+    with open(fasta, 'wb') as fout:                                # (one write: a call per run of records cost more than the copy)
+        fout.write(b''.join([view[starts[k]:starts[j]] for k, j in zip(edge[0::2].tolist(), edge[1::2].tolist())]))
 
 
 def _edges(cluFile, bsnFile):
