@@ -302,6 +302,10 @@ int pep_pair_support(pep_ctx *ctx, uint64_t n_rows, const pep_support_row *rows,
                      const uint64_t *grp_off, const uint32_t *grp_qlen, const uint32_t *grp_rlen, const pep_support_limits *lim, int32_t *value);
 int pep_similar_resolve(uint64_t n_events, const uint8_t *ev_kind, const int64_t *ev_a, const int64_t *ev_b, const int32_t *ev_value,
                         int64_t *out, uint64_t *n_out);
+/* the exemplar rewrite at the end of get_similar_pairs (PEPPAN.py:278-288; host, no context): the FASTA file `path` keeps the records whose
+ * name (first token of the header line, a decimal integer) is in ids[0..n_ids) (sorted ascending), verbatim; the file is not touched when
+ * every record stays.  PEP_ERR_ARG (file untouched) when a name is not a plain decimal integer: the caller then applies its own rules. */
+int pep_fasta_keep(const char *path, const int64_t *ids, uint64_t n_ids, uint64_t *n_records, uint64_t *n_kept);
 
 /* K13: exact-duplicate collapse of gene instances (front end of the clustering path).
  * pep_sha1: digest[20*i..] = SHA-1 of sequence i (bytes[off[i]..off[i+1])), big-endian bytes as hashlib.sha1(seq).digest();

@@ -14,7 +14,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve']
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep']
 
 
 class PepError(RuntimeError):
@@ -254,6 +254,20 @@ def similar_scan(q, r, action, forward, iden4, n_genes):
     off = ev_row_off[:ne + 1].astype(np.int64)
     return dict(alive=alive[:n_genes], seen_as_query=seen[:n_genes], absorbed=absorbed[:na], ev_kind=ev_kind[:ne], ev_a=ev_a[:ne], ev_b=ev_b[:ne],
                 ev_row_off=off, ev_rows=ev_rows[:int(off[-1])].astype(np.int64))
+
+
+def fasta_keep(path, ids):
+    """pep_fasta_keep: rewrite the FASTA file so that only records named by one of the integers `ids` stay -> (records, kept), or None when
+    a record's name is not a plain decimal integer (file untouched: the caller goes its own way)"""
+    lib = load_library()
+    ids = np.unique(np.asarray(ids, dtype=np.int64))
+    nr, nk = C.c_uint64(), C.c_uint64()
+    rc_ = lib.pep_fasta_keep(os.fsencode(path), _ptr(ids if len(ids) else np.zeros(1, np.int64)), C.c_uint64(len(ids)), C.byref(nr), C.byref(nk))
+    if rc_ == -2:                                   # PEP_ERR_ARG: a name that is not a plain integer, or no such file
+        return None
+    if rc_ != 0:
+        raise PepError('pep_fasta_keep failed (%d)' % rc_)
+    return nr.value, nk.value
 
 
 def similar_resolve(ev_kind, ev_a, ev_b, ev_value):

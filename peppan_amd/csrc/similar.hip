@@ -20,6 +20,9 @@
 // division give the same bits on the GPU as in numpy (tests/test_gpu_parity.py compares with np.mean itself through the oracle).
 #include "common.h"
 #include <algorithm>
+#include <climits>
+#include <cstdio>
+#include <cstring>
 #include <unordered_map>
 
 namespace {
@@ -336,6 +339,64 @@ int pep_similar_resolve(uint64_t n_events, const uint8_t *ev_kind, const int64_t
     for (size_t x = 0; x < ent.size(); x += 3)
         if (ent[x + 2] != 0) { out[3 * no] = ent[x]; out[3 * no + 1] = ent[x + 1]; out[3 * no + 2] = ent[x + 2]; ++no; }
     *n_out = no;
+    return PEP_OK;
+}
+
+// The last step of get_similar_pairs (PEPPAN.py:278-288): the exemplar FASTA keeps only the records of genes in `ids` (sorted ascending) -
+// header line and every line behind it, byte for byte; what precedes the first header goes.  Host code, one read and (when something
+// goes) one write of the file: as Python over the file's buffer this was 10 of the 17 ms the whole decision pass took.
+// A record's name is the first blank-delimited token of its header line and has to be a decimal integer ([+-]digits, as PEPPAN's encoded
+// gene names are); anything else -> PEP_ERR_ARG with the file untouched, and the caller applies its own (Python int()) rules.
+int pep_fasta_keep(const char *path, const int64_t *ids, uint64_t n_ids, uint64_t *n_records, uint64_t *n_kept)
+{
+    if (!path || (n_ids && !ids)) return PEP_ERR_ARG;
+    FILE *f = fopen(path, "rb");
+    if (!f) return PEP_ERR_ARG;
+    std::vector<char> data;
+    if (fseek(f, 0, SEEK_END) == 0) { const long sz = ftell(f); if (sz > 0) data.resize((size_t)sz); }
+    rewind(f);
+    const size_t got = data.empty() ? 0 : fread(data.data(), 1, data.size(), f);
+    fclose(f);
+    if (got != data.size()) return PEP_ERR_INTERNAL;
+    const char *d = data.data();
+    const size_t n = data.size();
+    std::vector<size_t> start;
+    std::vector<char> keep;
+    for (size_t p = 0; p < n;) {
+        if (d[p] == '>') {
+            size_t x = p + 1;
+            bool neg = false;
+            if (x < n && (d[x] == '+' || d[x] == '-')) { neg = d[x] == '-'; ++x; }
+            const size_t first_digit = x;
+            int64_t v = 0;
+            while (x < n && d[x] >= '0' && d[x] <= '9') {
+                if (v > (INT64_MAX - 9) / 10) return PEP_ERR_ARG;
+                v = v * 10 + (d[x] - '0');
+                ++x;
+            }
+            if (x == first_digit || (x < n && d[x] != ' ' && d[x] != '\t' && d[x] != '\n' && d[x] != '\r' && d[x] != '\f' && d[x] != '\v')) return PEP_ERR_ARG;
+            if (neg) v = -v;
+            start.push_back(p);
+            keep.push_back(std::binary_search(ids, ids + n_ids, v) ? 1 : 0);
+        }
+        const void *nl = memchr(d + p, '\n', n - p);
+        if (!nl) break;
+        p = (size_t)((const char *)nl - d) + 1;
+    }
+    uint64_t kept = 0;
+    for (char k : keep) kept += k;
+    if (n_records) *n_records = start.size();
+    if (n_kept) *n_kept = kept;
+    if (kept == start.size() && (start.empty() || start[0] == 0)) return PEP_OK;       // every record stays: the file is left alone
+    start.push_back(n);
+    std::vector<char> out;
+    out.reserve(n);
+    for (size_t k = 0; k + 1 < start.size(); ++k)
+        if (keep[k]) out.insert(out.end(), d + start[k], d + start[k + 1]);
+    f = fopen(path, "wb");
+    if (!f) return PEP_ERR_INTERNAL;
+    const size_t put = out.empty() ? 0 : fwrite(out.data(), 1, out.size(), f);
+    if (fclose(f) != 0 || put != out.size()) return PEP_ERR_INTERNAL;
     return PEP_OK;
 }
 
