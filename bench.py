@@ -230,10 +230,13 @@ def main():
     ctx = N.Context(local_rank)
     shard = pdist.ShardedSearch(ctx, nts, nts, params, rank, world, device=dev if world > 1 else None)
 
+    if world == 1:
+        ctx.set_grouping(len(nts), shard.gene_of_target)    # single linkage (K10) as the tail of the search: edges (q, gene of t) straight from the table's device copy
+
     def step():
         allh, allc, st = shard.search(retranslate=True, copy=False)           # views of the pinned staging area at N = 1: consumed within the step
         if world == 1:
-            labels = ctx.components_of_search(len(nts), shard.gene_of_target)   # edges (q, gene of t) straight from the table's device copy
+            labels = ctx.labels
         else:
             labels = ctx.components_of_hits(len(nts), allh, shard.gene_of_target)   # the gathered table
         return st, allh, allc, labels

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 5
+#define PEP_ABI_VERSION 6
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -223,6 +223,12 @@ int pep_components_of_hits(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_hits, cons
 
 /* the same for a search result: while r is the context's newest result its device copy is read in place (no edge columns are built or
  * uploaded; node_of_target is uploaded only when it changed since the last call), otherwise as pep_components_of_hits */
+/* single linkage as the tail of every search of this context (the north-star path: all-vs-all search + grouping, PEPPAN.py:229-230 +
+ * 1598-1607): with n_nodes > 0 pep_search ends with K10 over the edges (hit.q + q_base, node_of_target[hit.t]) of the table it has just
+ * produced - same stream, no second call, no second wait - and pep_result_labels hands out label[g] = smallest node of g's component.
+ * node_of_target needs an entry for every target of the searches that follow (else they fail with PEP_ERR_STATE); n_nodes = 0 switches it off. */
+int pep_set_grouping(pep_ctx *ctx, uint32_t n_nodes, uint32_t q_base, const uint32_t *node_of_target, uint64_t n_targets);
+int pep_result_labels(const pep_result *r, uint32_t *label, uint32_t n_nodes);
 int pep_components_of_result(pep_ctx *ctx, const pep_result *r, uint32_t n_nodes, uint32_t q_base, const uint32_t *node_of_target, uint64_t n_targets,
                              uint32_t *label);
 

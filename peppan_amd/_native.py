@@ -7,12 +7,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
-           'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
+           'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
            'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep']
 
@@ -320,6 +320,7 @@ class Context(object):
         rc = self._lib.pep_ctx_create(int(device), C.byref(h))
         self._h = h
         self._view = None
+        self._grouping, self.labels = 0, None           # set_grouping: K10 as the tail of every search
         self.upload_generation = 0           # bumped by every call that replaces a device-resident sequence set (see RunBlast._ensure_nt)
         self.q_nt_token = self.r_nt_token = None     # what the nucleotide sets on the device were made from (set by RunBlast._ensure_nt, cleared by any set_*)
         if rc != 0:
@@ -394,6 +395,20 @@ class Context(object):
         the GPU about 6 us of idle time between two kernels"""
         self._check(self._lib.pep_set_timing(self._h, C.c_int(level)), 'pep_set_timing')
 
+    def set_grouping(self, n_nodes, node_of_target=None, q_base=0):
+        """every search of this context ends with single linkage (K10) over its own hit table: edges (hit.q + q_base, node_of_target[hit.t]);
+        the labels of the newest search are in self.labels afterwards.  n_nodes = 0 switches it off."""
+        nn = np.ascontiguousarray(node_of_target if node_of_target is not None else [], dtype=np.uint32)
+        self._check(self._lib.pep_set_grouping(self._h, C.c_uint32(n_nodes), C.c_uint32(q_base), _ptr(nn) if len(nn) else None, C.c_uint64(len(nn))), 'pep_set_grouping')
+        self._grouping = int(n_nodes)
+        self.labels = None
+
+    def _take_labels(self, r):
+        if getattr(self, '_grouping', 0):
+            lab = np.empty(self._grouping, dtype=np.uint32)
+            self._check(self._lib.pep_result_labels(r, _ptr(lab), C.c_uint32(self._grouping)), 'pep_result_labels')
+            self.labels = lab
+
     def translate(self, force=False):
         self._check(self._lib.pep_translate(self._h, C.c_int(1 if force else 0)), 'pep_translate')
 
@@ -441,6 +456,7 @@ class Context(object):
             self._check(self._lib.pep_result_size(r, C.byref(nh), C.byref(nc)), 'pep_result_size')
             st = Stats()
             self._check(self._lib.pep_result_stats(r, C.byref(st)), 'pep_result_stats')
+            self._take_labels(r)
             if copy or nh.value == 0:
                 hits = np.empty(nh.value, dtype=HIT_DTYPE)
                 cig = np.empty(nc.value, dtype=np.uint32)

@@ -662,12 +662,22 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     };
     int rc = pep_find_candidates(ctx, &d_cands, &n_cands, prepare_thresholds);
     pep_timer_end(ctx, TM_SEED);
-    if (rc == PEP_OK) rc = pep_extend(ctx, d_cands, n_cands, nullptr, res);
+    if (rc == PEP_OK) rc = pep_extend(ctx, d_cands, n_cands, nullptr, res, true);
+    const bool grouped = rc == PEP_OK && ctx->grp_nodes != 0;
+    if (grouped)                                  // single linkage over the table that was just emitted, same stream, same wait
+        rc = ctx->ext.pending ? pep_k10_queue(ctx, ctx->ext.n_bound, reinterpret_cast<const pep_hit *>(ctx->ext.d_hits), ctx->ext.d_n_hits)
+                              : pep_k10_queue(ctx, res->n_hits, res->d_hits);
     pep_timer_end(ctx, TM_TOTAL);
     const hipError_t se = pep_stream_wait(ctx);
     if (rc == PEP_OK && se != hipSuccess) rc = pep_fail(ctx, PEP_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
+    if (rc == PEP_OK) rc = pep_extend_finish(ctx);      // (a result that left through pack_out: its sizes and statistics are in the staging area now)
+    ctx->ext.pending = false;
     if (rc != PEP_OK) { delete res; return rc; }
     pep_timers_resolve(ctx);
+    if (grouped) {
+        const uint32_t *lab = reinterpret_cast<const uint32_t *>(ctx->pin_labels.p);
+        res->labels.assign(lab, lab + ctx->grp_nodes);
+    }
     res->stats = ctx->stats;
     ctx->dev_result = res->d_hits ? res : nullptr;
     if (res->st_hits || res->st_cigar) ctx->staged_result = res;
@@ -680,6 +690,21 @@ int pep_set_timing(pep_ctx *ctx, int level)
 {
     if (!ctx || level < 0 || level > 2) return PEP_ERR_ARG;
     ctx->timing_level = level;
+    return PEP_OK;
+}
+
+int pep_set_grouping(pep_ctx *ctx, uint32_t n_nodes, uint32_t q_base, const uint32_t *node_of_target, uint64_t n_targets)
+{
+    if (!ctx || (n_nodes && n_targets && !node_of_target)) return PEP_ERR_ARG;
+    PEP_HIP(ctx, hipSetDevice(ctx->device));
+    return pep_k10_set_grouping(ctx, n_nodes, q_base, node_of_target, n_targets);
+}
+
+int pep_result_labels(const pep_result *r, uint32_t *label, uint32_t n_nodes)
+{
+    if (!r || (n_nodes && !label)) return PEP_ERR_ARG;
+    if (r->labels.size() != n_nodes) return PEP_ERR_STATE;          // the search ran without pep_set_grouping (or with another node count)
+    if (n_nodes) memcpy(label, r->labels.data(), (size_t)n_nodes * 4);
     return PEP_OK;
 }
 

@@ -130,6 +130,9 @@ struct pep_ctx {
     uint64_t set_clean_slots = 0;           // leading slots of d_set known to be EMPTY (0 while a search is using it)
     DevBuf uf_nodes;                        // K10 over a device-resident hit table: node of every target (uploaded when it changes)
     std::vector<uint32_t> uf_nodes_host;
+    struct { bool pending = false; pep_result *res = nullptr; const void *d_hits = nullptr, *d_cig = nullptr; const uint32_t *d_n_hits = nullptr; uint64_t n_bound = 0; } ext;
+                                            // a search whose result left through pack_out and whose host half (sizes, statistics, views) is still to be done (pep_extend_finish)
+    uint32_t grp_nodes = 0, grp_q_base = 0;  // pep_set_grouping: the searches of this context end with K10 over their own hit table (0 = off)
     bool device_results = false;            // pep_set_result_mode: searches leave their table on the device; the host copy is fetched on demand
     pep_result *dev_result = nullptr;       // the result whose hit table is still intact on the device (ws[23]): the newest search's, until the workspace is reused
     DevBuf d_zero;                          // the small counters of one search, cleared by ONE fill when it starts (layout: PEP_ZERO_* below)
@@ -148,6 +151,7 @@ struct pep_result {
     const pep_hit *d_hits = nullptr;        // device copy (context workspace), valid while ctx->dev_result == this
     const uint32_t *d_cigar = nullptr;
     pep_stats stats;
+    std::vector<uint32_t> labels;           // pep_set_grouping: the partition of the search's hit graph (one label per node)
 };
 
 // HIP-event stopwatch on one stream (the kernel times bench.py reports are taken with it, inside the library,
@@ -238,7 +242,9 @@ int pep_upload_sub_table(pep_ctx *ctx);       // ctx->params.sub -> ctx->d_param
 int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known = nullptr, const int32_t *d_end_lane = nullptr, const int32_t *d_skip_mode = nullptr,
                const uint32_t *d_n = nullptr, uint64_t dir_blocks_bound = 0, unsigned long long **d_hdr = nullptr);   // kernel time: phase timers TM_SW / TM_SW_TRACE
 // h_min_score: score threshold per query; nullptr = ctx->d_min_score holds them already (pep_search uploads them while the seed stage runs)
-int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n_cands, const int32_t *h_min_score, pep_result *res);
+// defer: the caller waits for the stream itself and calls pep_extend_finish afterwards (pep_search: one wait for everything)
+int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n_cands, const int32_t *h_min_score, pep_result *res, bool defer = false);
+int pep_extend_finish(pep_ctx *ctx);
 int pep_selftest_dpp(pep_ctx *ctx);
 // ---- rescore.hip (K7)
 int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uint32_t *h_cigar, uint64_t n_cigar, int64_t *h_out);
@@ -246,6 +252,9 @@ int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uin
 int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *h_a, const uint32_t *h_b, uint32_t *h_label);
 int pep_k10_components_dev(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_hits, const pep_hit *d_hits, uint32_t q_base, const uint32_t *h_node_of_target,
                            uint64_t n_targets, uint32_t *h_label);
+
+int pep_k10_queue(pep_ctx *ctx, uint64_t n_hits, const pep_hit *d_hits, const uint32_t *d_n_hits = nullptr);   // d_n_hits: the count lives on the device, n_hits bounds it       // K10 behind a search, labels -> ctx->pin_labels (no wait)
+int pep_k10_set_grouping(pep_ctx *ctx, uint32_t n_nodes, uint32_t q_base, const uint32_t *h_node_of_target, uint64_t n_targets);
 
 // ---- overlaps.hip (K11)
 int pep_k11_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *h_contig, const int64_t *h_start, const int64_t *h_end, const int64_t *h_rid,

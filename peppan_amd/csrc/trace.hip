@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void topk(const uint32_t *__restrict__ d_n_sel
     keep_runs[s] = keep ? me.n_runs : 0;
 }
 
-__global__ __launch_bounds__(256) void emit(uint64_t n_sel, const SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands,
+__global__ __launch_bounds__(256) void emit(const uint32_t *__restrict__ d_n_sel, const SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands,
                                             const uint32_t *__restrict__ keep_flag, const uint32_t *__restrict__ hit_pos, const uint64_t *__restrict__ cig_pos,
                                             const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ runs, const uint32_t *__restrict__ nblk,
                                             const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len,
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void emit(uint64_t n_sel, const SelInfo *__res
 {
     const int lane = threadIdx.x & 63;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s >= n_sel || !keep_flag[s]) return;
+    if (s >= *d_n_sel || !keep_flag[s]) return;
     const SelInfo info = sel[s];
     const uint64_t key = cands[info.cand];
     const uint64_t co = cig_pos[s];
@@ -416,6 +416,29 @@ __global__ __launch_bounds__(256) void emit(uint64_t n_sel, const SelInfo *__res
     (void)nblk;
 }
 
+// The result on its way to the host WITHOUT the host knowing its size: the counter block (72 bytes: hits, CIGAR runs, statistics), the
+// hit records and the CIGAR arena are written into the context's pinned staging area by this kernel - header (PACK_HEADER bytes), hits,
+// arena back to back - so that the search needs no synchronisation between its candidate count and its end.  A staging area that is too
+// small (the first search of a context, a result that grew) gets the header only, with the overflow word set: the host then sizes it
+// and copies the classic way.
+constexpr size_t PACK_HEADER = 128;
+__global__ __launch_bounds__(256) void pack_out(const unsigned long long *__restrict__ mail, const pep_hit *__restrict__ hits, const uint32_t *__restrict__ cigar,
+                                                unsigned char *__restrict__ pinned, unsigned long long cap)
+{
+    const uint32_t n_hits = reinterpret_cast<const uint32_t *>(mail)[2];
+    const unsigned long long n_cig = mail[2];
+    const bool fits = PACK_HEADER + (unsigned long long)n_hits * sizeof(pep_hit) + n_cig * 4 <= cap;
+    unsigned long long *head = reinterpret_cast<unsigned long long *>(pinned);
+    if (blockIdx.x == 0 && threadIdx.x < 16) head[threadIdx.x] = threadIdx.x < 9 ? mail[threadIdx.x] : (threadIdx.x == 15 ? (fits ? 0ull : 1ull) : 0ull);
+    if (!fits) return;
+    const uint64_t stride = (uint64_t)gridDim.x * 256, t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint4 *src = reinterpret_cast<const uint4 *>(hits);
+    uint4 *dst = reinterpret_cast<uint4 *>(pinned + PACK_HEADER);
+    for (uint64_t x = t0; x < (uint64_t)n_hits * (sizeof(pep_hit) / 16); x += stride) dst[x] = src[x];
+    uint32_t *cdst = reinterpret_cast<uint32_t *>(pinned + PACK_HEADER + (size_t)n_hits * sizeof(pep_hit));
+    for (uint64_t x = t0; x < n_cig; x += stride) cdst[x] = cigar[x];
+}
+
 }  // namespace
 
 // workspace slots: ws[16] flag, ws[17] pos, ws[18] best_idx, ws[19] sel, ws[20] run_cap/run_off (u64 x2) + selected keys,
@@ -427,7 +450,56 @@ __global__ __launch_bounds__(256) void emit(uint64_t n_sel, const SelInfo *__res
 // pair as long as the longest), and the statistics ride on the one read-back at the end.  When those bounds would cost more memory than
 // is sensible (FAST_DIR_BYTES / FAST_RUN_BYTES: long sequences times many candidates - searches that are long enough not to care about
 // two host round trips), or with params.reserved2 = 1 (tests), the stage synchronises after the selection and sizes everything exactly.
-int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t *h_min_score, pep_result *res)
+struct HostMail { uint32_t n_pairs, n_sel, n_hits, pad; unsigned long long n_cig, run_cap, score_cells, score_blocks, trace_cells, trace_blocks, trace_swept; };
+static_assert(sizeof(HostMail) == 72, "layout of the selection stage's counter block");
+
+// the host's half of a search whose result left through pack_out: sizes, statistics and the views of the staging area - called once the
+// stream has been waited for (by pep_search behind its one final wait, or by pep_extend itself when the caller wants the result at once)
+int pep_extend_finish(pep_ctx *ctx)
+{
+    if (!ctx->ext.pending) return PEP_OK;
+    ctx->ext.pending = false;
+    pep_result *res = ctx->ext.res;
+    HostMail h;
+    std::memcpy(&h, ctx->pin_stage.p, sizeof(h));
+    const bool overflow = reinterpret_cast<const unsigned long long *>(ctx->pin_stage.p)[15] != 0;
+    ctx->stats.cells += h.score_cells;
+    ctx->stats.cells_swept += h.score_blocks * 16 * 64;
+    ctx->stats.cells_trace += h.trace_cells;
+    ctx->stats.cells_swept_trace += h.trace_blocks * 16 * 64;
+    ctx->stats.dir_bytes += h.trace_blocks * 512;
+    ctx->trace_swept = h.trace_swept;
+    ctx->stats.tracebacks_gapless = h.n_sel - h.trace_swept;
+    ctx->stats.pairs = h.n_pairs;
+    ctx->stats.tracebacks = h.n_sel;
+    ctx->stats.hits = h.n_hits;
+    if (h.n_hits == 0) return PEP_OK;
+    const size_t hb = (size_t)h.n_hits * sizeof(pep_hit);
+    const pep_hit *d_hits = reinterpret_cast<const pep_hit *>(ctx->ext.d_hits);
+    const uint32_t *d_cig = reinterpret_cast<const uint32_t *>(ctx->ext.d_cig);
+    if (!overflow) {
+        res->st_hits = reinterpret_cast<const pep_hit *>(ctx->pin_stage.p + PACK_HEADER);
+        res->st_cigar = reinterpret_cast<const uint32_t *>(ctx->pin_stage.p + PACK_HEADER + hb);
+    } else if (pin_reserve(ctx, ctx->pin_stage, PACK_HEADER + hb + (h.n_cig + 1) * 4) == PEP_OK) {
+        // the staging area was too small for this result (now it is not: the next search of this size goes through pack_out)
+        PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_stage.p + PACK_HEADER, d_hits, hb, hipMemcpyDeviceToHost, ctx->stream));
+        if (h.n_cig) PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_stage.p + PACK_HEADER + hb, d_cig, h.n_cig * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PEP_HIP(ctx, pep_stream_wait(ctx));
+        res->st_hits = reinterpret_cast<const pep_hit *>(ctx->pin_stage.p + PACK_HEADER);
+        res->st_cigar = reinterpret_cast<const uint32_t *>(ctx->pin_stage.p + PACK_HEADER + hb);
+    } else {
+        res->hits.resize(h.n_hits);
+        res->cigar.resize(h.n_cig);
+        PEP_HIP(ctx, hipMemcpyAsync(res->hits.data(), d_hits, hb, hipMemcpyDeviceToHost, ctx->stream));
+        if (h.n_cig) PEP_HIP(ctx, hipMemcpyAsync(res->cigar.data(), d_cig, h.n_cig * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    res->n_hits = h.n_hits; res->n_cigar = h.n_cig;
+    res->d_hits = d_hits; res->d_cigar = d_cig;
+    return PEP_OK;
+}
+
+int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t *h_min_score, pep_result *res, bool defer)
 {
     const pep_search_params &P = ctx->params;
     pep_drop_dev_result(ctx);                     // ws[23] is about to be rewritten
@@ -465,9 +537,9 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     uint32_t *counters = reinterpret_cast<uint32_t *>(zb);
     unsigned long long *mail = reinterpret_cast<unsigned long long *>(zb);
     const uint32_t *d_n_sel = counters + 1;
-    struct { uint32_t n_pairs, n_sel, n_hits, pad; unsigned long long n_cig, run_cap, score_cells, score_blocks, trace_cells, trace_blocks, trace_swept; } h_mail;
-    static_assert(sizeof(h_mail) == 72, "layout of the selection stage's counter block");
+    HostMail h_mail;
     std::memset(&h_mail, 0, sizeof(h_mail));
+    ctx->ext.pending = false;
     const unsigned gb = (unsigned)ceil_div(n, 256);
     hipLaunchKernelGGL(select_best, dim3(gb), dim3(256), 0, st, d_cands, n, sw, dms.as<const int32_t>(), flag, best_idx, counters, P.hsp_mode);
     PEP_TRY(pep_scan_u32(ctx, flag, pos, n, ctx->ws[7], counters + 1));
@@ -533,6 +605,25 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
                            (const unsigned long long *)score_hdr, (const unsigned long long *)trace_hdr, mail);
         PEP_TRY(pep_scan_u32(ctx, keep_flag, hit_pos, n_b, ctx->ws[7], counters + 2));
         PEP_TRY(pep_scan_u64(ctx, keep_runs, cig_pos, n_b, ctx->ws[7], reinterpret_cast<uint64_t *>(mail + 2)));
+        if (fast && !ctx->device_results && pin_reserve(ctx, ctx->pin_stage, PACK_HEADER) == PEP_OK) {
+            // the result leaves through pack_out: output buffers from the same upper bounds, no look at the sizes, no synchronisation here
+            const size_t hb_bound = (size_t)n_b * sizeof(pep_hit);
+            PEP_TRY(dev_reserve(ctx, ctx->ws[23], hb_bound + (run_bound + 1) * 4));
+            pep_hit *d_hits = ctx->ws[23].as<pep_hit>();
+            uint32_t *d_cig = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctx->ws[23].p) + hb_bound);
+            hipLaunchKernelGGL(emit, dim3((unsigned)ceil_div(n_b, 4)), dim3(256), 0, st, d_n_sel, (const SelInfo *)sel, (const uint64_t *)sel_keys, (const uint32_t *)keep_flag,
+                               (const uint32_t *)hit_pos, (const uint64_t *)cig_pos, (const uint64_t *)run_off, (const uint32_t *)runs,
+                               ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig);
+            hipLaunchKernelGGL(pack_out, dim3(1024), dim3(256), 0, st, (const unsigned long long *)mail, (const pep_hit *)d_hits, (const uint32_t *)d_cig,
+                               ctx->pin_stage.p, (unsigned long long)ctx->pin_stage.cap);
+            PEP_HIP(ctx, hipGetLastError());
+            ctx->ext.pending = true; ctx->ext.res = res; ctx->ext.d_hits = d_hits; ctx->ext.d_cig = d_cig;
+            ctx->ext.d_n_hits = counters + 2; ctx->ext.n_bound = n_b;
+            pep_timer_end(ctx, TM_TRACE);
+            if (defer) return PEP_OK;
+            PEP_HIP(ctx, pep_stream_wait(ctx));
+            return pep_extend_finish(ctx);
+        }
         PEP_TRY(pep_read_back(ctx, &h_mail, mail, sizeof(h_mail)));
         PEP_TRY(pep_sync_reads(ctx));
         n_hits = h_mail.n_hits; n_cig = h_mail.n_cig;
@@ -561,7 +652,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         PEP_TRY(dev_reserve(ctx, ctx->ws[23], hb + (n_cig + 1) * 4));
         pep_hit *d_hits = ctx->ws[23].as<pep_hit>();
         uint32_t *d_cig = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctx->ws[23].p) + hb);
-        hipLaunchKernelGGL(emit, dim3((unsigned)ceil_div(n_sel, 4)), dim3(256), 0, st, (uint64_t)n_sel, (const SelInfo *)sel, (const uint64_t *)sel_keys, (const uint32_t *)keep_flag,
+        hipLaunchKernelGGL(emit, dim3((unsigned)ceil_div(n_sel, 4)), dim3(256), 0, st, d_n_sel, (const SelInfo *)sel, (const uint64_t *)sel_keys, (const uint32_t *)keep_flag,
                            (const uint32_t *)hit_pos, (const uint64_t *)cig_pos, (const uint64_t *)run_off, (const uint32_t *)runs,
                            ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig);
         PEP_HIP(ctx, hipGetLastError());

@@ -307,11 +307,13 @@ __global__ void k1_query_desc(uint32_t n, const uint32_t *__restrict__ frame, co
 // reference side: the chunks of (sequence, frame) w become packed sequences first[w] .. first[w] + cnt[w] - 1
 __global__ void k1_ref_desc(uint64_t nw, int n_frames, const uint64_t *__restrict__ chunk_base, const uint32_t *__restrict__ chunk_cnt,
                             const uint32_t *__restrict__ first, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_len,
-                            PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, K1Summary *__restrict__ sum)
+                            PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, K1Summary *__restrict__ sum, uint64_t slots)
 {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w == 0) { sum->residues = 0ull; sum->max_len = 0u; }
     if (w >= nw) return;
+    // the slots behind the last packed sequence count as empty in the layout scan (this used to be a fill of the whole array in front of the chain)
+    for (uint64_t x = (uint64_t)first[nw] + w; x <= slots; x += nw) padded[x] = 0u;
     const uint32_t g = (uint32_t)(w / n_frames), f = (uint32_t)(w % n_frames) + 1;
     const uint64_t base = chunk_base[w];
     const uint32_t at = first[w];
@@ -518,13 +520,12 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     if (!desc) return PEP_ERR_HIP;
     const uint64_t *d_base = ctx->d_k1_base.as<const uint64_t>();
     if (nw) {
-        PEP_HIP(ctx, hipMemsetAsync(W[6].p, 0, (slots + 1) * 4, ctx->stream));
         hipLaunchKernelGGL(k1_ref_chunks, dim3((unsigned)ceil_div(nw, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, nf, tab,
                            d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>());
         PEP_TRY(pep_scan_u32(ctx, W[1].as<const uint32_t>(), W[5].as<uint32_t>(), nw, W[8]));          // W[5][nw] = number of targets
         hipLaunchKernelGGL(k1_ref_desc, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, ctx->stream, nw, nf, d_base, W[1].as<const uint32_t>(),
                            W[5].as<const uint32_t>(), W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), W[4].as<PackDesc>(), W[6].as<uint32_t>(),
-                           ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(W[4].as<PackDesc>() + slots));
+                           ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(W[4].as<PackDesc>() + slots), slots);
         PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
                                 W[7], W[8]));
     } else {

@@ -38,8 +38,10 @@ __global__ __launch_bounds__(256) void uf_union(uint32_t *parent, const uint32_t
 }
 
 // the same over the edges of a hit table that is still on the device: (hit.q + q_base, node_of_target[hit.t])
-__global__ __launch_bounds__(256) void uf_union_hits(uint32_t *parent, const pep_hit *__restrict__ hits, uint64_t m, uint32_t q_base, const uint32_t *__restrict__ node_of_target)
+__global__ __launch_bounds__(256) void uf_union_hits(uint32_t *parent, const pep_hit *__restrict__ hits, uint64_t m, uint32_t q_base, const uint32_t *__restrict__ node_of_target,
+                                                     const uint32_t *__restrict__ d_m = nullptr)
 {
+    if (d_m) m = *d_m;                       // (the grid is sized from an upper bound then)
     const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= m) return;
     uint32_t x = hits[e].q + q_base, y = node_of_target[hits[e].t];
@@ -120,5 +122,43 @@ int pep_k10_components_dev(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_hits, cons
         PEP_HIP(ctx, hipMemcpyAsync(h_label, label, (size_t)n_nodes * 4, hipMemcpyDeviceToHost, ctx->stream));
         PEP_HIP(ctx, pep_stream_wait(ctx));
     }
+    return PEP_OK;
+}
+
+// K10 as the tail of a search (pep_set_grouping): queued behind `emit` on the search's stream, BEFORE the search's final synchronisation -
+// no second call, no second wait, and uf_flatten writes the labels straight into pinned host memory (no blit behind it).  The labels are
+// in ctx->pin_labels once the stream has been waited for.
+int pep_k10_queue(pep_ctx *ctx, uint64_t n_hits, const pep_hit *d_hits, const uint32_t *d_n_hits)
+{
+    const uint32_t n_nodes = ctx->grp_nodes;
+    if (n_nodes == 0) return PEP_OK;
+    if (ctx->uf_nodes_host.size() < ctx->t.n) return pep_fail(ctx, PEP_ERR_STATE, "pep_set_grouping: fewer node entries than the search has targets");
+    if ((uint64_t)ctx->q.n + ctx->grp_q_base > n_nodes) return pep_fail(ctx, PEP_ERR_STATE, "pep_set_grouping: query nodes beyond n_nodes");
+    PEP_TRY(dev_reserve(ctx, ctx->ws[0], (size_t)n_nodes * 4));
+    PEP_TRY(pin_reserve(ctx, ctx->pin_labels, (size_t)n_nodes * 4));
+    uint32_t *parent = ctx->ws[0].as<uint32_t>();
+    hipLaunchKernelGGL(uf_init, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, n_nodes);
+    if (n_hits) hipLaunchKernelGGL(uf_union_hits, dim3((unsigned)ceil_div(n_hits, 256)), dim3(256), 0, ctx->stream, parent, d_hits, n_hits, ctx->grp_q_base, ctx->uf_nodes.as<const uint32_t>(), d_n_hits);
+    hipLaunchKernelGGL(uf_flatten, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, reinterpret_cast<uint32_t *>(ctx->pin_labels.p), n_nodes);
+    PEP_HIP(ctx, hipGetLastError());
+    return PEP_OK;
+}
+
+int pep_k10_set_grouping(pep_ctx *ctx, uint32_t n_nodes, uint32_t q_base, const uint32_t *h_node_of_target, uint64_t n_targets)
+{
+    ctx->grp_nodes = 0;
+    if (n_nodes == 0) return PEP_OK;
+    if (ctx->uf_nodes_host.size() != n_targets || (n_targets && memcmp(ctx->uf_nodes_host.data(), h_node_of_target, n_targets * 4) != 0)) {
+        for (uint64_t t = 0; t < n_targets; ++t)
+            if (h_node_of_target[t] >= n_nodes) return pep_fail(ctx, PEP_ERR_ARG, "pep_set_grouping: node of a target out of range");
+        ctx->uf_nodes_host.assign(h_node_of_target, h_node_of_target + n_targets);
+        PEP_TRY(dev_reserve(ctx, ctx->uf_nodes, (n_targets + 1) * 4));
+        if (n_targets) PEP_HIP(ctx, hipMemcpy(ctx->uf_nodes.p, ctx->uf_nodes_host.data(), n_targets * 4, hipMemcpyHostToDevice));
+    } else {
+        for (uint64_t t = 0; t < n_targets; ++t)
+            if (h_node_of_target[t] >= n_nodes) return pep_fail(ctx, PEP_ERR_ARG, "pep_set_grouping: node of a target out of range");
+    }
+    ctx->grp_nodes = n_nodes;
+    ctx->grp_q_base = q_base;
     return PEP_OK;
 }

@@ -569,6 +569,26 @@ def test_full_size_10k_properties(ctx):
     assert np.array_equal(ctx.components_of_search(10000, tm['seq']), lab)
     assert np.array_equal(ctx.components_of_search(10004, tm['seq'] + 4, q_base=4)[4:], lab + 4)
     assert np.array_equal(ctx.components_of_search(10000, tm['seq']), lab)              # (node map changed back: uploaded again)
+    # ... and as the tail of the search itself (pep_set_grouping): same labels, with and without a host copy of the table, with a node offset,
+    # for a search without hits; switched off again afterwards (a later search carries no labels)
+    try:
+        ctx.set_grouping(10000, tm['seq'])
+        for copy in (False, True):
+            h4, c4, s4 = ctx.search(p, copy=copy)
+            assert np.array_equal(np.array(h4), h1) and np.array_equal(ctx.labels, lab)
+        ctx.set_grouping(10004, tm['seq'] + 4, q_base=4)
+        ctx.search(p, copy=False)
+        assert np.array_equal(ctx.labels[4:], lab + 4) and np.array_equal(ctx.labels[:4], np.arange(4))
+        with pytest.raises(Exception):
+            ctx.set_grouping(100, tm['seq'])                                             # a node beyond n_nodes
+        ctx.set_grouping(10000, tm['seq'])
+        strict = N.default_params(45., 25., 10, 5, max_evalue=1e-300)
+        h5, c5, s5 = ctx.search(strict)
+        assert len(h5) == 0 and np.array_equal(ctx.labels, np.arange(10000))
+    finally:
+        ctx.set_grouping(0)
+    ctx.search(p, copy=False)
+    assert ctx.labels is None
     assert np.array_equal(lab[lab], lab) and (lab <= np.arange(10000)).all()
     assert np.array_equal(ctx.components(10000, np.arange(10000), lab), lab)
     assert (lab // 4 == np.arange(10000) // 4).all()
