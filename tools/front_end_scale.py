@@ -15,12 +15,23 @@ with N.Context(0) as ctx:
     t2 = time.perf_counter()
     genes = {i: ['f', '', 0, 0, '+', hashes[i], seqs[i]] for i in range(n)}
     prio = {i: [i % 7, -len(seqs[i]), hashes[i]] for i in range(n)}
+    prof = None
+    if os.environ.get('FRONT_END_PROFILE'):
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     fn, groups = PL.writeGenes('big.genes', genes, prio, ctx=ctx)
     t3 = time.perf_counter()
     n_unique = sum(1 for line in open(fn) if line.startswith('>'))
     with contextlib.redirect_stderr(io.StringIO()):
         ex = PL.iterClust('big', fn, groups, dict(identity=0.9, coverage=0.8, n_thread=1, translate=False))
     t4 = time.perf_counter()
+    if prof is not None:
+        import pstats
+        prof.disable()
+        sio = io.StringIO()
+        pstats.Stats(prof, stream=sio).sort_stats('tottime').print_stats(28)
+        print(sio.getvalue())
 n_ex = sum(1 for line in open(ex) if line.startswith('>'))
 print('%d instances (%.2f Gnt): generate %.1f s, sha1 on the GPU %.1f s, writeGenes %.1f s, iterClust %.1f s; %d unique, %d exemplars; peak RSS %.1f GB'
       % (n, sum(map(len, seqs)) / 1e9, t1 - t0, t2 - t1, t3 - t2, t4 - t3, n_unique, n_ex, resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6))
