@@ -157,6 +157,10 @@ int pep_set_query_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, ui
 int pep_set_ref_aa(pep_ctx *ctx, const uint8_t *codes, const uint64_t *off, uint32_t n);
 /* run K1 for the sides given as nucleotides (idempotent until the inputs change; force != 0 re-runs it) */
 int pep_translate(pep_ctx *ctx, int force);
+/* the protein sets made from nucleotide inputs are stale: the next pep_search translates again (K1), inside the search - both sides queued
+ * at once and the seed stage's first kernels behind them, so that the GPU does not wait for the host between K1 and the search as it does
+ * with a pep_translate(force) call in front */
+int pep_invalidate_translation(pep_ctx *ctx);
 /* The nucleotide search (the reference's blastn call, uberBlast.py:294, 482-509) on device-resident inputs: the nucleotide sets given to
  * pep_set_query_nt / pep_set_ref_nt THEMSELVES become the residue sets of the following searches, as base codes A0 C1 G2 T3 (anything
  * else 4), packed on the GPU - queries forward; the reference, per reference set (pep_set_target_groups, else the whole list), all

@@ -12,7 +12,7 @@ MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequenc
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
-           'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
+           'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
            'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep']
 
@@ -408,6 +408,10 @@ class Context(object):
             lab = np.empty(self._grouping, dtype=np.uint32)
             self._check(self._lib.pep_result_labels(r, _ptr(lab), C.c_uint32(self._grouping)), 'pep_result_labels')
             self.labels = lab
+
+    def invalidate_translation(self):
+        """the next search() runs K1 again, inside the search (cheaper than translate(force=True) in front of it: no host wait between K1 and the search)"""
+        self._check(self._lib.pep_invalidate_translation(self._h), 'pep_invalidate_translation')
 
     def translate(self, force=False):
         self._check(self._lib.pep_translate(self._h, C.c_int(1 if force else 0)), 'pep_translate')

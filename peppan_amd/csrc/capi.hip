@@ -406,6 +406,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_k1q.p) (void)hipHostFree(ctx->pin_k1q.p);
     if (ctx->pin_labels.p) (void)hipHostFree(ctx->pin_labels.p);
     if (ctx->k1_event) (void)hipEventDestroy(ctx->k1_event);
+    if (ctx->k1q_event) (void)hipEventDestroy(ctx->k1q_event);
     if (ctx->k1_t0) (void)hipEventDestroy(ctx->k1_t0);
     if (ctx->k1_t1) (void)hipEventDestroy(ctx->k1_t1);
     if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
@@ -483,6 +484,14 @@ int pep_translate(pep_ctx *ctx, int force)
     float ms = 0.f;
     if (timed && ctx->k1_t1 && hipEventRecord(ctx->k1_t1, ctx->stream) == hipSuccess && pep_event_wait(ctx->k1_t1) == hipSuccess) (void)hipEventElapsedTime(&ms, ctx->k1_t0, ctx->k1_t1);
     ctx->stats.ms_k1 = ms;
+    return PEP_OK;
+}
+
+int pep_invalidate_translation(pep_ctx *ctx)
+{
+    if (!ctx) return PEP_ERR_ARG;
+    if (ctx->q_from_nt) ctx->q_ready = false;
+    if (ctx->t_from_nt) ctx->t_ready = false;
     return PEP_OK;
 }
 
@@ -619,15 +628,34 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         if (memcmp(ctx->params.sub, params->sub, sizeof(params->sub)) != 0) ctx->sub_ready = false;      // the LDS image follows the table only
         ctx->params = *params;
     }
+    ctx->k1_t_deferred = false;
     if (!ctx->resid_from_nucl) {
-        PEP_TRY(pep_translate(ctx, 0));
-        if (!ctx->q_ready || !ctx->t_ready) return pep_fail(ctx, PEP_ERR_STATE, "pep_search before both sequence sets were given");
+        const bool do_q = ctx->q_from_nt && !ctx->q_ready, do_t = ctx->t_from_nt && !ctx->t_ready;
+        if ((do_q || do_t) && ctx->timing_level < 2 && ctx->group_of_seq.empty()) {
+            // K1 inside the search (sets given or invalidated since the last one): both sides are queued, queries first, and only the query
+            // side is waited for here - the reference side's summary is picked up after the first index build has been queued behind it
+            // (pep_find_candidates' need_targets), so the GPU runs from K1 into the seed stage without waiting for the host
+            if (do_q) PEP_TRY(pep_k1_query(ctx, ctx->q_gtable, 1));
+            if (do_t) PEP_TRY(pep_k1_ref(ctx, ctx->t_frames, ctx->t_gtable, 1));
+            if (do_q) { PEP_TRY(pep_k1_query(ctx, ctx->q_gtable, 2)); ctx->q_ready = true; }
+            ctx->k1_t_deferred = do_t;
+            ctx->stats.ms_k1 = 0.;
+        } else PEP_TRY(pep_translate(ctx, 0));
+        if (!ctx->q_ready || !(ctx->t_ready || ctx->k1_t_deferred)) { ctx->k1_t_deferred = false; return pep_fail(ctx, PEP_ERR_STATE, "pep_search before both sequence sets were given"); }
     }
-    if (!ctx->sub_ready) { PEP_TRY(upload_sub_image(ctx)); ctx->sub_ready = true; }
-    PEP_TRY(build_t_class(ctx));
+    auto finish_targets = [](pep_ctx *c) -> int {
+        if (!c->k1_t_deferred) return PEP_OK;
+        c->k1_t_deferred = false;
+        PEP_TRY(pep_k1_ref(c, c->t_frames, c->t_gtable, 2));
+        c->t_ready = true;
+        c->stats.target_residues = c->t.residues;
+        return PEP_OK;
+    };
+    if (!ctx->sub_ready) { const int rc0 = upload_sub_image(ctx); if (rc0 != PEP_OK) { ctx->k1_t_deferred = false; return rc0; } ctx->sub_ready = true; }
+    { const int rc0 = build_t_class(ctx); if (rc0 != PEP_OK) { ctx->k1_t_deferred = false; return rc0; } }
 
     pep_result *res = new (std::nothrow) pep_result();
-    if (!res) return pep_fail(ctx, PEP_ERR_INTERNAL, "out of host memory");
+    if (!res) { ctx->k1_t_deferred = false; return pep_fail(ctx, PEP_ERR_INTERNAL, "out of host memory"); }
     res->ctx = ctx;
     const double ms_k1 = ctx->stats.ms_k1;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
@@ -660,7 +688,9 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         if (c->q.n) PEP_HIP(c, hipMemcpyAsync(c->d_min_score.p, c->pin_ms.p, (size_t)c->q.n * 4, hipMemcpyHostToDevice, c->stream));
         return PEP_OK;
     };
-    int rc = pep_find_candidates(ctx, &d_cands, &n_cands, prepare_thresholds);
+    int rc = pep_find_candidates(ctx, &d_cands, &n_cands, prepare_thresholds, finish_targets);
+    if (rc == PEP_OK && ctx->k1_t_deferred) rc = finish_targets(ctx);
+    ctx->k1_t_deferred = false;                   // (after a failure the reference side simply is not ready: the next search translates again)
     pep_timer_end(ctx, TM_SEED);
     if (rc == PEP_OK) rc = pep_extend(ctx, d_cands, n_cands, nullptr, res, true);
     const bool grouped = rc == PEP_OK && ctx->grp_nodes != 0;

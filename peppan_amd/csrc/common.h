@@ -81,6 +81,9 @@ struct pep_ctx {
     int n_pending = 0;
     PinBuf pin_k1, pin_k1q;                 // grow-only: K1 descriptors (+ the set's summary behind them) of the reference / of the queries
     hipEvent_t k1_event = nullptr;          // the point of the stream where the reference side's downloads have arrived
+    hipEvent_t k1q_event = nullptr;         // ... and the query side's
+    bool k1q_event_set = false;
+    bool k1_t_deferred = false;             // pep_search: the reference side's K1 is queued, its summary not taken yet
     hipEvent_t wait_event = nullptr;        // pep_stream_wait: marks the point of the stream the host is waiting for
     hipEvent_t k1_t0 = nullptr, k1_t1 = nullptr;   // pep_translate's timing pair (created once)
     uint32_t k1_desc_cap = 0;               // descriptor slots of the reference side's last K1 (the summary sits behind them in pin_k1)
@@ -236,7 +239,7 @@ int pep_k1_host_tables_q(pep_ctx *ctx);    // the query side only (the search ne
 int pep_nucl_sets(pep_ctx *ctx, int strands);      // the nucleotide sets themselves as residue sets (base codes; reference: forward strands + reverse complements)
 // ---- seeds.hip  (K2-K4)
 // before_sync (optional): host work to do once every kernel of the stage is queued, while the GPU runs them (the stage ends with a synchronisation)
-int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int (*before_sync)(pep_ctx *) = nullptr);
+int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int (*before_sync)(pep_ctx *) = nullptr, int (*need_targets)(pep_ctx *) = nullptr);
 int pep_upload_sub_table(pep_ctx *ctx);       // ctx->params.sub -> ctx->d_params (1 KiB, uploaded when it changed)
 // ---- sw.hip / trace.hip (K5, K6, K8)
 int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, const int32_t *d_known = nullptr, const int32_t *d_end_lane = nullptr, const int32_t *d_skip_mode = nullptr,

@@ -689,15 +689,21 @@ int pep_upload_sub_table(pep_ctx *ctx)
 
 // workspace slots used here: ws[0] cnt, ws[1] start, ws[2] entries, ws[3] table, ws[4] list, ws[5] list tmp (sort),
 // ws[6] counters+stats, ws[7] scan scratch, ws[8] raw seed hits, ws[10..12] runs of hits (the sort histogram reuses ws[0])
-int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int (*before_sync)(pep_ctx *))
+// need_targets (optional): the target set may still be on its way (pep_search queues K1 for both sides and waits for the query side only);
+// the hook is called once, right before the first use of anything about the targets - after the first shape's index build has been queued,
+// so that the GPU goes from K1 into the index kernels while the host picks up the target side's summary.
+int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int (*before_sync)(pep_ctx *), int (*need_targets)(pep_ctx *))
 {
     const pep_search_params &P = ctx->params;
     SeqSet &Q = ctx->q, &T = ctx->t;
-    if (Q.total > PEP_MAX_RESIDUES || T.total > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "more than 2^29 packed residues on one side");
+    if (Q.total > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "more than 2^29 packed residues on one side");
     *n_cands = 0;
     *d_cands = nullptr;
     ctx->stats.query_seeds = ctx->stats.target_seeds = ctx->stats.seed_hits = 0;
-    if (Q.n == 0 || T.n == 0) return before_sync ? before_sync(ctx) : PEP_OK;
+    if (Q.n == 0) {
+        if (need_targets) PEP_TRY(need_targets(ctx));
+        return before_sync ? before_sync(ctx) : PEP_OK;
+    }
 
     // two buckets per query position, except that up to 40 M positions stay at 2^25 buckets (the average coarse bucket then holds 4 900
     // of the 5 632 entries a slab takes; 100k genes x 100k genes: 103 -> 94 ms per pass): that is the largest index the partition
@@ -721,19 +727,15 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
 
     // candidate set: start near 64 slots per query (chance hits grow with |Q| x |T|), grow x4 on overflow
     int table_bits = std::max(20, std::min(28, ilog2_ceil(64ull * Q.n)));
-    uint64_t hit_cap = std::max<uint64_t>(1ull << 22, 2 * T.total);
+    uint64_t hit_cap = 0;                          // raw seed hits: 2 x target bytes to start with (sized below, once the targets are known)
     if (P.n_shapes > 4) return pep_fail(ctx, PEP_ERR_ARG, "more than 4 seed shapes");
     // query index build: by partition when the bucket count splits into <= 2^13 coarse x <= 2^12 fine buckets (reserved[2] != 0 forces the
     // count -> scan -> fill build, as does a coarse bucket that overflows LDS)
     const int fine_bits = std::min(12, bucket_bits - 8);
     bool use_partition = P.reserved[2] == 0 && bucket_bits >= 16 && bucket_bits - fine_bits <= 13;
     for (int attempt = 0; attempt < 8; ++attempt) {
-        PEP_TRY(dev_reserve(ctx, ctx->ws[8], hit_cap * sizeof(uint64_t)));
-        PEP_TRY(dev_reserve(ctx, ctx->ws[10], hit_cap * 8));          // runs of equal candidate keys: first hit, key, length
-        PEP_TRY(dev_reserve(ctx, ctx->ws[11], hit_cap * 8));
-        PEP_TRY(dev_reserve(ctx, ctx->ws[12], hit_cap * 4 + 64));
-        uint64_t *run_first = ctx->ws[10].as<uint64_t>(), *run_key = ctx->ws[11].as<uint64_t>();
-        uint32_t *run_len = ctx->ws[12].as<uint32_t>();
+        uint64_t *run_first = nullptr, *run_key = nullptr;
+        uint32_t *run_len = nullptr;
         const uint64_t cap = 1ull << table_bits;
         const uint32_t list_cap = (uint32_t)(cap >> 1);
         // the candidate set lives in a buffer of its own: set_compact hands every slot back EMPTY, so only a new (or larger, or abandoned)
@@ -765,7 +767,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             for (int i = 0, pl = 1, ph = 1; i < sh.weight; ++i) {
                 if (i < sh.h1) { sh.pw[i] = (uint32_t)pl; pl *= sh.base; } else { sh.pw[i] = (uint32_t)ph; ph *= sh.base; }
             }
-            const unsigned qb = (unsigned)ceil_div(Q.total, 256), tb = (unsigned)ceil_div(T.total, 256);
+            const unsigned qb = (unsigned)ceil_div(Q.total, 256);
 #define PEP_SEED_DISPATCH(KERNEL, GRID, ...)                                                                          \
     do {                                                                                                              \
         if (sh.weight == 10) hipLaunchKernelGGL(KERNEL<10>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);            \
@@ -799,6 +801,20 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
                 PEP_HIP(ctx, hipMemsetAsync(filter, 0, (n_buckets >> FILTER_SHIFT) * 8, ctx->stream));
                 hipLaunchKernelGGL(filter_fill, dim3(2048), dim3(256), 0, ctx->stream, (const uint64_t *)entries, (const uint32_t *)(start + n_buckets), bucket_bits, filter, counters + 10 + s);
             }
+            if (s == 0) {
+                // everything about the targets from here on
+                if (need_targets) { PEP_TRY(need_targets(ctx)); need_targets = nullptr; }
+                if (T.total > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "more than 2^29 packed residues on one side");
+                if (T.n == 0) return before_sync ? before_sync(ctx) : PEP_OK;             // (the index kernels queued so far are harmless)
+                if (hit_cap == 0) hit_cap = std::max<uint64_t>(1ull << 22, 2 * T.total);
+                PEP_TRY(dev_reserve(ctx, ctx->ws[8], hit_cap * sizeof(uint64_t)));
+                PEP_TRY(dev_reserve(ctx, ctx->ws[10], hit_cap * 8));          // runs of equal candidate keys: first hit, key, length
+                PEP_TRY(dev_reserve(ctx, ctx->ws[11], hit_cap * 8));
+                PEP_TRY(dev_reserve(ctx, ctx->ws[12], hit_cap * 4 + 64));
+                run_first = ctx->ws[10].as<uint64_t>(); run_key = ctx->ws[11].as<uint64_t>();
+                run_len = ctx->ws[12].as<uint32_t>();
+            }
+            const unsigned tb = (unsigned)ceil_div(T.total, 256);
             JoinArgs a;
             a.t_res = T.res.as<const uint8_t>(); a.t_total = T.total; a.t_off = T.off.as<const uint32_t>(); a.nt = T.n;
             a.q_off = Q.off.as<const uint32_t>(); a.nq = Q.n; a.q_blk2seq = Q.blk2seq.as<const uint2>(); a.t_blk2seq = T.blk2seq.as<const uint2>(); a.start = start; a.entries = entries; a.filter = filter; a.bucket_bits = bucket_bits;

@@ -439,10 +439,16 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
         PackDesc *desc = stage_desc(ctx, ctx->pin_k1q, n);
         if (!desc) return PEP_ERR_HIP;
         PEP_HIP(ctx, hipMemcpyAsync(desc, W[2].p, ((size_t)n + 2) * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
+        // an event of its own: whoever waits for the query side must not wait for what was queued behind it (pep_search queues the reference side next)
+        ctx->k1q_event_set = false;
+        if (ctx->k1q_event || hipEventCreateWithFlags(&ctx->k1q_event, hipEventDisableTiming) == hipSuccess)
+            ctx->k1q_event_set = hipEventRecord(ctx->k1q_event, ctx->stream) == hipSuccess;
     }
     if (phase == 1) return PEP_OK;
     const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1q.p);
-    PEP_HIP(ctx, pep_stream_wait(ctx));
+    if (ctx->k1q_event_set) PEP_HIP(ctx, pep_event_wait(ctx->k1q_event));
+    else PEP_HIP(ctx, pep_stream_wait(ctx));
+    ctx->k1q_event_set = false;
     PEP_TRY(take_summary(ctx, desc, n, ctx->q));
     ctx->q_tables_lazy = true;               // q_meta, h_off, h_len: pep_k1_host_tables (the search builds them while its seed stage runs)
     return PEP_OK;

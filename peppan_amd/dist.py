@@ -289,7 +289,7 @@ class ShardedSearch(object):
         import time
         t0 = time.perf_counter()
         if retranslate:
-            self.ctx.translate(force=True)
+            self.ctx.invalidate_translation() if hasattr(self.ctx, 'invalidate_translation') else self.ctx.translate(force=True)
         t_k1 = time.perf_counter()
         keep = None if copy else self._scratch            # copy=False: the arrays of the previous step are overwritten
         if self.world > 1 and self.device is not None and getattr(self.device, 'type', '') == 'cuda' and hasattr(self.ctx, 'search_on_device'):
