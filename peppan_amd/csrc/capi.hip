@@ -413,7 +413,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_ms.p) (void)hipHostFree(ctx->pin_ms.p);
     DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq,
-                      &ctx->sort_state, &ctx->sort_hist, &ctx->d_set, &ctx->d_zero};
+                      &ctx->sort_state, &ctx->sort_hist, &ctx->d_set, &ctx->d_zero, &ctx->d_k1_desc_q, &ctx->d_k1_desc_t};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -666,10 +666,9 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     for (int id = 0; id < TM_COUNT; ++id) ctx->tm_state[id] = 0;
     pep_timer_begin(ctx, TM_SEED); pep_timer_begin(ctx, TM_TOTAL);
     uint64_t *d_cands = nullptr, n_cands = 0;
-    // host work that only the alignment stage needs - the query side's tables, the score thresholds and their upload - is done while the
+    // host work that only the alignment stage needs - the score thresholds (from the query lengths K1 left in pinned memory) and their upload - is done while the
     // seed stage's kernels run (between its last launch and its synchronisation)
     auto prepare_thresholds = [](pep_ctx *c) -> int {
-        PEP_TRY(pep_k1_host_tables_q(c));
         PEP_TRY(dev_reserve(c, c->d_min_score, (size_t)(c->q.n + 1) * 4));
         PEP_TRY(pin_reserve(c, c->pin_ms, (size_t)(c->q.n + 1) * 4));
         int32_t *ms = reinterpret_cast<int32_t *>(c->pin_ms.p);
@@ -685,7 +684,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
             }
             ms[i] = memo_val[slot];
         }
-        if (c->q.n) PEP_HIP(c, hipMemcpyAsync(c->d_min_score.p, c->pin_ms.p, (size_t)c->q.n * 4, hipMemcpyHostToDevice, c->stream));
+        PEP_TRY(pep_copy_from_pinned(c, c->d_min_score.p, c->pin_ms.p, c->q.n));
         return PEP_OK;
     };
     int rc = pep_find_candidates(ctx, &d_cands, &n_cands, prepare_thresholds, finish_targets);

@@ -79,7 +79,8 @@ struct pep_ctx {
     size_t pin_small_used = 0;
     struct PendingRead { void *dst; size_t off, n; } pending[32];
     int n_pending = 0;
-    PinBuf pin_k1, pin_k1q;                 // grow-only: K1 descriptors (+ the set's summary behind them) of the reference / of the queries
+    PinBuf pin_k1, pin_k1q;                 // grow-only: what K1's kernels write for the host - the set's summary (reference), summary + lengths (queries)
+    DevBuf d_k1_desc_q, d_k1_desc_t;        // K1's descriptors (+ the summary's accumulators behind them): fetched only when the host tables are asked for
     hipEvent_t k1_event = nullptr;          // the point of the stream where the reference side's downloads have arrived
     hipEvent_t k1q_event = nullptr;         // ... and the query side's
     bool k1q_event_set = false;
@@ -226,6 +227,7 @@ int pep_zero_block(pep_ctx *ctx, int which, size_t offset, size_t bytes, void **
 // exclusive; d_out[n] = total (n+1 outputs); d_total (optional): a second place the total is written to (a counter block the host reads in one copy)
 int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp, uint32_t *d_total = nullptr);
 int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp, uint64_t *d_total = nullptr);
+int pep_copy_from_pinned(pep_ctx *ctx, void *d_dst, const void *pinned_src, uint64_t n_words);     // a kernel instead of a copy command (scan.hip)
 // ---- sort.hip
 // the dense candidate-key form q | t | bin - bin_min (tb / bb bits for t / bin) <-> q:21 | t:25 | bin:18 (seeds.hip); on = 0: keys pass unchanged
 struct pep_key_unpack { int on, tb, bb; uint32_t bin_min; };

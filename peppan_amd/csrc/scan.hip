@@ -223,3 +223,21 @@ int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n
     if (n == 0 || n >= (1ull << 40)) return scan_impl<uint64_t>(ctx, d_in, d_out, n, tmp, d_total);
     return scan_onepass<uint64_t>(ctx, d_in, d_out, n, d_total);
 }
+
+// n 32-bit words from pinned host memory into device memory BY A KERNEL (the device reads the host buffer over the bus): between two
+// kernels a copy command costs the GPU about 10 us of idle time in front of it, a kernel none
+namespace {
+__global__ __launch_bounds__(256) void copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+
+int pep_copy_from_pinned(pep_ctx *ctx, void *d_dst, const void *pinned_src, uint64_t n_words)
+{
+    if (n_words == 0) return PEP_OK;
+    hipLaunchKernelGGL(copy_words, dim3((unsigned)std::min<uint64_t>(ceil_div(n_words, 256), 1024)), dim3(256), 0, ctx->stream, reinterpret_cast<uint32_t *>(d_dst),
+                       reinterpret_cast<const uint32_t *>(pinned_src), n_words);
+    PEP_HIP(ctx, hipGetLastError());
+    return PEP_OK;
+}

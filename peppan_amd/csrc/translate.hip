@@ -136,6 +136,16 @@ __global__ __launch_bounds__(256) void k1_ref_chunks(const uint8_t *__restrict__
     if (lane == 0) chunk_cnt[w] = cnt;
 }
 
+// What the host needs of a packed set before it can queue a search: computed on the device (k1_offsets) and downloaded behind the
+// descriptors (two descriptor slots), so that the host does not have to walk 60 k descriptors while the GPU waits for its next kernel -
+// the per-sequence tables (h_off, h_len, the meta records) are built from the downloaded descriptors only when somebody asks for them.
+struct K1Summary {
+    unsigned long long residues, total;
+    uint32_t n, max_len;
+    uint32_t pad[2];
+};
+static_assert(sizeof(K1Summary) == 2 * 16, "the summary takes two descriptor slots");
+
 struct PackDesc {          // one per packed sequence: where its residues come from
     uint32_t seq;
     uint32_t frame;
@@ -151,10 +161,13 @@ struct PackDesc {          // one per packed sequence: where its residues come f
 // the 20 M reference residues, bound by the latency of that search.)
 __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, int tab,
                                                const PackDesc *__restrict__ desc, const uint32_t *__restrict__ pk_off, const uint32_t *__restrict__ n_ptr, uint32_t cap,
-                                               uint8_t *__restrict__ res, uint2 *__restrict__ blk2seq)
+                                               uint8_t *__restrict__ res, uint2 *__restrict__ blk2seq, const K1Summary *__restrict__ d_sum, K1Summary *__restrict__ pin_sum)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the set's summary (k1_offsets finished it) goes to the host from here: a 32-byte store into pinned memory instead of a copy command,
+    // which would cost the GPU 10 us of idle time in front of it
+    if (blockIdx.x == 0 && threadIdx.x == 0) *pin_sum = *d_sum;
     // the count, the descriptor and the offsets are fetched together (slot s exists in all three arrays whether or not it is in use):
     // a wave lives for a chain of dependent loads, and this takes one link out of it
     const uint32_t n_packed = *n_ptr;
@@ -282,19 +295,10 @@ int upload_codon_table(pep_ctx *ctx)
 
 __device__ __forceinline__ uint32_t padded_len(uint32_t len) { return (len + 15u) / 16u * 16u + PEP_SEQ_GAP; }
 
-// What the host needs of a packed set before it can queue a search: computed on the device (k1_offsets) and downloaded behind the
-// descriptors (two descriptor slots), so that the host does not have to walk 60 k descriptors while the GPU waits for its next kernel -
-// the per-sequence tables (h_off, h_len, the meta records) are built from the downloaded descriptors only when somebody asks for them.
-struct K1Summary {
-    unsigned long long residues, total;
-    uint32_t n, max_len;
-    uint32_t pad[2];
-};
-static_assert(sizeof(K1Summary) == 2 * 16, "the summary takes two descriptor slots");
-
 // query side: one packed sequence per gene, the chosen frame from its start
 __global__ void k1_query_desc(uint32_t n, const uint32_t *__restrict__ frame, const uint32_t *__restrict__ len, PackDesc *__restrict__ desc,
-                              uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, uint32_t *__restrict__ n_out, K1Summary *__restrict__ sum)
+                              uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, uint32_t *__restrict__ n_out, K1Summary *__restrict__ sum,
+                              uint32_t *__restrict__ pin_len)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) { *n_out = n; sum->residues = 0ull; sum->max_len = 0u; }       // (k1_offsets accumulates into it)
@@ -302,6 +306,7 @@ __global__ void k1_query_desc(uint32_t n, const uint32_t *__restrict__ frame, co
     desc[i] = PackDesc{i, frame[i], 0u, len[i]};
     padded[i] = padded_len(len[i]);
     len_out[i] = len[i];
+    pin_len[i] = len[i];                     // the host's copy (pinned memory): the search derives its score thresholds from the lengths
 }
 
 // reference side: the chunks of (sequence, frame) w become packed sequences first[w] .. first[w] + cnt[w] - 1
@@ -360,7 +365,7 @@ int reserve_packed(pep_ctx *ctx, SeqSet &out, uint32_t cap, uint64_t upper)
 // Device-side layout + packing (after reserve_packed).  d_desc / d_padded hold up to `cap` entries (padded = 0 beyond the *d_n real ones); `upper` bounds the
 // layout's size.  Nothing is read back here: the caller downloads the descriptors once, after everything is queued.
 int layout_and_pack(pep_ctx *ctx, const NtSet &nt, int tab, const PackDesc *d_desc, const uint32_t *d_padded, uint32_t cap, const uint32_t *d_n,
-                    uint64_t upper, SeqSet &out, DevBuf &d_scan, DevBuf &tmp)
+                    uint64_t upper, SeqSet &out, DevBuf &d_scan, DevBuf &tmp, K1Summary *pin_sum)
 {
     PEP_TRY(dev_reserve(ctx, d_scan, ((size_t)cap + 2) * 4));
     PEP_TRY(pep_scan_u32(ctx, d_padded, d_scan.as<uint32_t>(), cap, tmp));
@@ -368,15 +373,15 @@ int layout_and_pack(pep_ctx *ctx, const NtSet &nt, int tab, const PackDesc *d_de
     hipLaunchKernelGGL(k1_offsets, dim3((unsigned)ceil_div((uint64_t)cap + 1, 256)), dim3(256), 0, ctx->stream, d_n, d_scan.as<const uint32_t>(), cap, out.off.as<uint32_t>(),
                        out.len.as<const uint32_t>(), d_sum);
     hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div((uint64_t)cap + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
-                       d_desc, out.off.as<const uint32_t>(), d_n, cap, out.res.as<uint8_t>(), out.blk2seq.as<uint2>());
+                       d_desc, out.off.as<const uint32_t>(), d_n, cap, out.res.as<uint8_t>(), out.blk2seq.as<uint2>(), (const K1Summary *)d_sum, pin_sum);
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
 }
 
 // the eager part of a finished K1 side: the set's summary (computed by k1_offsets, downloaded behind the descriptors)
-int take_summary(pep_ctx *ctx, const PackDesc *desc, uint32_t cap, SeqSet &out)
+int take_summary(pep_ctx *ctx, const void *pinned, SeqSet &out)
 {
-    const K1Summary *sum = reinterpret_cast<const K1Summary *>(desc + cap);
+    const K1Summary *sum = reinterpret_cast<const K1Summary *>(pinned);
     if (sum->total > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "packed protein set exceeds 2^29 bytes");
     if (sum->max_len > PEP_MAX_SEQ_LEN) return pep_fail(ctx, PEP_ERR_LIMIT, "protein longer than PEP_MAX_SEQ_LEN");
     out.n = sum->n; out.total = sum->total; out.residues = sum->residues; out.max_len = sum->max_len;
@@ -397,16 +402,10 @@ void finish_layout(const PackDesc *desc, uint32_t n, SeqSet &out)
     out.h_off[n] = (uint32_t)(pos + PEP_END_PAD);
 }
 
-PackDesc *stage_desc(pep_ctx *ctx, PinBuf &pin, uint64_t n)
-{
-    if (pin_reserve(ctx, pin, (n + 3) * sizeof(PackDesc)) != PEP_OK) return nullptr;
-    return reinterpret_cast<PackDesc *>(pin.p);
-}
-
 int k1_ref_finish(pep_ctx *ctx)
 {
     PEP_HIP(ctx, pep_event_wait(ctx->k1_event));
-    PEP_TRY(take_summary(ctx, reinterpret_cast<const PackDesc *>(ctx->pin_k1.p), ctx->k1_desc_cap, ctx->t));
+    PEP_TRY(take_summary(ctx, ctx->pin_k1.p, ctx->t));
     ctx->t_tables_lazy = true;               // t_meta, h_off, h_len: pep_k1_host_tables, when somebody needs them
     return PEP_OK;
 }
@@ -426,7 +425,11 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
         DevBuf *W = ctx->ws;
         PEP_TRY(dev_reserve(ctx, W[0], ((size_t)n + 1) * 4));
         PEP_TRY(dev_reserve(ctx, W[1], ((size_t)n + 1) * 4));
-        PEP_TRY(dev_reserve(ctx, W[2], ((size_t)n + 3) * sizeof(PackDesc)));       // + the summary behind the descriptors
+        DevBuf &D = ctx->d_k1_desc_q;              // the descriptors stay on the device (a buffer of their own): fetched when somebody asks for the host tables
+        PEP_TRY(dev_reserve(ctx, D, ((size_t)n + 3) * sizeof(PackDesc)));          // + the summary behind the descriptors
+        PEP_TRY(pin_reserve(ctx, ctx->pin_k1q, sizeof(K1Summary) + ((size_t)n + 1) * 4));
+        K1Summary *pin_sum = reinterpret_cast<K1Summary *>(ctx->pin_k1q.p);
+        uint32_t *pin_len = reinterpret_cast<uint32_t *>(ctx->pin_k1q.p + sizeof(K1Summary));
         PEP_TRY(dev_reserve(ctx, W[3], ((size_t)n + 1) * 4));
         PEP_TRY(dev_reserve(ctx, W[5], 16));
         const uint64_t upper = 2 * PEP_END_PAD + (nt.total + 2 * (uint64_t)n) / 3 + (uint64_t)n * (16 + PEP_SEQ_GAP);
@@ -434,23 +437,22 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
         if (n) hipLaunchKernelGGL(k1_query_frames, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, tab,
                                   W[0].as<uint32_t>(), W[1].as<uint32_t>());
         hipLaunchKernelGGL(k1_query_desc, dim3((unsigned)ceil_div((uint64_t)n + 1, 256)), dim3(256), 0, ctx->stream, n, W[0].as<const uint32_t>(), W[1].as<const uint32_t>(),
-                           W[2].as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>(), reinterpret_cast<K1Summary *>(W[2].as<PackDesc>() + n));
-        PEP_TRY(layout_and_pack(ctx, nt, tab, W[2].as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6]));
-        PackDesc *desc = stage_desc(ctx, ctx->pin_k1q, n);
-        if (!desc) return PEP_ERR_HIP;
-        PEP_HIP(ctx, hipMemcpyAsync(desc, W[2].p, ((size_t)n + 2) * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
+                           D.as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + n), pin_len);
+        PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6], pin_sum));
         // an event of its own: whoever waits for the query side must not wait for what was queued behind it (pep_search queues the reference side next)
         ctx->k1q_event_set = false;
         if (ctx->k1q_event || hipEventCreateWithFlags(&ctx->k1q_event, hipEventDisableTiming) == hipSuccess)
             ctx->k1q_event_set = hipEventRecord(ctx->k1q_event, ctx->stream) == hipSuccess;
     }
     if (phase == 1) return PEP_OK;
-    const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1q.p);
     if (ctx->k1q_event_set) PEP_HIP(ctx, pep_event_wait(ctx->k1q_event));
     else PEP_HIP(ctx, pep_stream_wait(ctx));
     ctx->k1q_event_set = false;
-    PEP_TRY(take_summary(ctx, desc, n, ctx->q));
-    ctx->q_tables_lazy = true;               // q_meta, h_off, h_len: pep_k1_host_tables (the search builds them while its seed stage runs)
+    PEP_TRY(take_summary(ctx, ctx->pin_k1q.p, ctx->q));
+    // the lengths are here already (k1_query_desc wrote them into the pinned buffer); q_meta and h_off wait for pep_k1_host_tables_q
+    const uint32_t *pin_len = reinterpret_cast<const uint32_t *>(ctx->pin_k1q.p + sizeof(K1Summary));
+    ctx->q.h_len.assign(pin_len, pin_len + n);
+    ctx->q_tables_lazy = true;
     return PEP_OK;
 }
 
@@ -458,8 +460,10 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
 int pep_k1_host_tables(pep_ctx *ctx)
 {
     if (ctx->t_tables_lazy) {
-        const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1.p);
         const uint32_t n = ctx->t.n;
+        std::vector<PackDesc> fetched((size_t)n + 1);
+        if (n) PEP_HIP(ctx, hipMemcpy(fetched.data(), ctx->d_k1_desc_t.p, (size_t)n * sizeof(PackDesc), hipMemcpyDeviceToHost));        // (waits for the stream)
+        const PackDesc *desc = fetched.data();
         ctx->t_meta.resize(n);
         for (uint32_t i = 0; i < n; ++i) ctx->t_meta[i] = pep_target_meta{desc[i].seq, desc[i].frame, desc[i].aa_off, desc[i].len};
         finish_layout(desc, n, ctx->t);
@@ -471,9 +475,11 @@ int pep_k1_host_tables(pep_ctx *ctx)
 int pep_k1_host_tables_q(pep_ctx *ctx)
 {
     if (ctx->q_tables_lazy) {
-        const PackDesc *desc = reinterpret_cast<const PackDesc *>(ctx->pin_k1q.p);
         const NtSet &nt = ctx->q_nt;
         const uint32_t n = ctx->q.n;
+        std::vector<PackDesc> fetched((size_t)n + 1);
+        if (n) PEP_HIP(ctx, hipMemcpy(fetched.data(), ctx->d_k1_desc_q.p, (size_t)n * sizeof(PackDesc), hipMemcpyDeviceToHost));
+        const PackDesc *desc = fetched.data();
         ctx->q_meta.resize(n);
         for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, desc[i].frame, desc[i].len, (uint32_t)(nt.h_off[i + 1] - nt.h_off[i])};
         finish_layout(desc, n, ctx->q);
@@ -518,30 +524,30 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     PEP_TRY(dev_reserve(ctx, W[1], (nw + 1) * 4));
     PEP_TRY(dev_reserve(ctx, W[2], (slots + 1) * 4));
     PEP_TRY(dev_reserve(ctx, W[3], (slots + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, W[4], (slots + 3) * sizeof(PackDesc)));             // + the summary behind the descriptors
+    DevBuf &D = ctx->d_k1_desc_t;                  // the descriptors stay on the device (a buffer of their own: ws[] is the seed stage's next)
+    PEP_TRY(dev_reserve(ctx, D, (slots + 3) * sizeof(PackDesc)));                 // + the summary behind the descriptors
+    PEP_TRY(pin_reserve(ctx, ctx->pin_k1, sizeof(K1Summary)));
+    K1Summary *pin_sum = reinterpret_cast<K1Summary *>(ctx->pin_k1.p);
     PEP_TRY(dev_reserve(ctx, W[5], (nw + 2) * 4));
     PEP_TRY(dev_reserve(ctx, W[6], (slots + 1) * 4));
     PEP_TRY(reserve_packed(ctx, ctx->t, (uint32_t)slots, upper));
-    PackDesc *desc = stage_desc(ctx, ctx->pin_k1, slots);
-    if (!desc) return PEP_ERR_HIP;
     const uint64_t *d_base = ctx->d_k1_base.as<const uint64_t>();
     if (nw) {
         hipLaunchKernelGGL(k1_ref_chunks, dim3((unsigned)ceil_div(nw, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, nf, tab,
                            d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>());
         PEP_TRY(pep_scan_u32(ctx, W[1].as<const uint32_t>(), W[5].as<uint32_t>(), nw, W[8]));          // W[5][nw] = number of targets
         hipLaunchKernelGGL(k1_ref_desc, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, ctx->stream, nw, nf, d_base, W[1].as<const uint32_t>(),
-                           W[5].as<const uint32_t>(), W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), W[4].as<PackDesc>(), W[6].as<uint32_t>(),
-                           ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(W[4].as<PackDesc>() + slots), slots);
-        PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
-                                W[7], W[8]));
+                           W[5].as<const uint32_t>(), W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), D.as<PackDesc>(), W[6].as<uint32_t>(),
+                           ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + slots), slots);
+        PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
+                                W[7], W[8], pin_sum));
     } else {
         PEP_HIP(ctx, hipMemsetAsync(W[5].p, 0, 8, ctx->stream));
         PEP_HIP(ctx, hipMemsetAsync(W[6].p, 0, 4, ctx->stream));
-        PEP_HIP(ctx, hipMemsetAsync(W[4].p, 0, 3 * sizeof(PackDesc), ctx->stream));            // (the summary's accumulators)
-        PEP_TRY(layout_and_pack(ctx, nt, tab, W[4].as<const PackDesc>(), W[6].as<const uint32_t>(), 0, W[5].as<const uint32_t>(), upper, ctx->t, W[7], W[8]));
+        PEP_HIP(ctx, hipMemsetAsync(D.p, 0, 3 * sizeof(PackDesc), ctx->stream));               // (the summary's accumulators)
+        PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[6].as<const uint32_t>(), 0, W[5].as<const uint32_t>(), upper, ctx->t, W[7], W[8], pin_sum));
     }
-    // the descriptors and the summary behind them travel through pinned memory in one copy; an event marks the point of the stream where they have arrived
-    PEP_HIP(ctx, hipMemcpyAsync(desc, W[4].p, (slots + 2) * sizeof(PackDesc), hipMemcpyDeviceToHost, ctx->stream));
+    // the summary has been written into pinned memory by k1_pack; an event marks the point of the stream where it is there
     ctx->k1_desc_cap = (uint32_t)slots;
     if (!ctx->k1_event && hipEventCreateWithFlags(&ctx->k1_event, hipEventDisableTiming) != hipSuccess) return pep_fail(ctx, PEP_ERR_HIP, "hipEventCreate failed");
     PEP_HIP(ctx, hipEventRecord(ctx->k1_event, ctx->stream));
