@@ -382,7 +382,7 @@ int pep_ctx_create(int device, pep_ctx **out)
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     pep_default_params(&ctx->params);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PEP_ERR_HIP; }
-    if (pin_reserve(ctx, ctx->pin_small, 4096) != PEP_OK) { *out = ctx; return PEP_ERR_HIP; }
+    if (pin_reserve(ctx, ctx->pin_small, 16384) != PEP_OK) { *out = ctx; return PEP_ERR_HIP; }
     int rc = pep_selftest_dpp(ctx);
     if (rc != PEP_OK) { *out = ctx; return rc; }      // caller can read the message, then destroy
     *out = ctx;

@@ -75,7 +75,7 @@ struct pep_result;
 struct pep_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    PinBuf pin_small;                       // 4 KiB: counters read back between kernels
+    PinBuf pin_small;                       // 16 KiB: counters read back between kernels
     size_t pin_small_used = 0;
     struct PendingRead { void *dst; size_t off, n; } pending[32];
     int n_pending = 0;
@@ -211,7 +211,10 @@ void dev_release(DevBuf &b);
 // them all (each used to be a fill of its own in front of its kernel: eleven tiny launches per search).  A stage that runs without the
 // seed stage in front (K9 drives the alignment stage alone) finds its flag in zero_ok unset and clears its own block.
 #define PEP_ZERO_SEED 0                                         // 64 B: list length, overflow flags, statistics (seeds.hip)
-#define PEP_ZERO_SHAPE (PEP_ZERO_SEED + 64)                     // 4 x 16 B: raw-hit and run counters per seed shape
+#define PEP_SORT_TOP_BITS 10                                    // two-level candidate sort (sort.hip): buckets by the top 10 bits of the key ...
+#define PEP_SORT_TOP_CAP 4096                                   // ... each sorted in LDS when none holds more keys than this
+#define PEP_ZERO_TOP (PEP_ZERO_SEED + 64)                       // 1024 x 4 B: candidates per top digit of the dense key (set_compact; read back WITH the 64 bytes in front)
+#define PEP_ZERO_SHAPE (PEP_ZERO_TOP + 4096)                    // 4 x 16 B: raw-hit and run counters per seed shape
 #define PEP_ZERO_COARSE (PEP_ZERO_SHAPE + 64)                   // 4 x 8192 x 4 B: coarse-bucket counts of the query index per seed shape
 #define PEP_ZERO_SORT (PEP_ZERO_COARSE + 4 * 8192 * 4)          // 8 x 2048 x 4 B: digit histograms of the candidate sort
 #define PEP_ZERO_SW_BYTES (64 + 2 * 1024 * 4)                   // totals + length histogram + scatter cursors of one Smith-Waterman pass (sw.hip)
@@ -233,6 +236,7 @@ int pep_copy_from_pinned(pep_ctx *ctx, void *d_dst, const void *pinned_src, uint
 struct pep_key_unpack { int on, tb, bb; uint32_t bin_min; };
 int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, const uint32_t *d_n, uint64_t n_bound, int bits, uint32_t *d_hist_zeroed,
                  const pep_key_unpack *unpack);   // result in d_keys
+int pep_sort_u64_two_level(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, int bits, const uint32_t *d_top_hist, const pep_key_unpack *unpack);
 // ---- translate.hip  (K1)
 int pep_k1_query(pep_ctx *ctx, int gtable, int phase = 0);
 int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase = 0);

@@ -574,7 +574,8 @@ __global__ __launch_bounds__(256) void seed_runs(JoinArgs a, uint64_t *__restric
             off = (uint32_t)__shfl((int)off, 0, 64);
             if (emit_run[u]) {
                 const uint32_t slot = off + (uint32_t)__popcll(emit_m & ((1ull << lane) - 1ull));       // < RUN_BUF: flushed above RUN_BUF / 2, <= 256 * RUN_UNROLL per trip
-                s_first[slot] = hh[u]; s_len[slot] = (uint32_t)run_len_u[u]; s_key[slot] = ck[u];
+                // (a run of one carries its hit itself - the extension then has no look-up into the hit buffer to do; longer runs the index of their first hit)
+                s_first[slot] = run_len_u[u] == 1 ? hit[u] : hh[u]; s_len[slot] = (uint32_t)run_len_u[u]; s_key[slot] = ck[u];
             }
         }
         __syncthreads();
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(256) void seed_extend(JoinArgs a, const uint64_t *_
         if (len > 1 && set_contains(a, ck)) { ++n_pass; continue; }          // (single hits: the extension is cheaper than the probe it would save)
         bool pass = a.ungapped_min <= 0;
         for (uint32_t x = 0; x < len && !pass; ++x) {
-            const uint64_t hit = a.hits[first + x];
+            const uint64_t hit = len == 1 ? first : a.hits[first + x];          // (seed_runs put the hit of a single-hit run into the run record)
             pass = ungapped_pass(a, sub, (uint32_t)(hit >> 32), (uint32_t)hit);
         }
         if (pass) { ++n_pass; set_insert(a, ck); }
@@ -630,9 +631,11 @@ constexpr int COMPACT_ROUNDS = 16;
 // ~36 instead of 64 bits; its last pass restores q:21 | t:25 | bin:18), and every slot that held a key is EMPTY again afterwards: the
 // next search finds the set clean instead of filling 8 MB in front of its first kernel.
 __global__ __launch_bounds__(256) void set_compact(uint64_t *__restrict__ table, uint64_t cap, uint64_t *__restrict__ list, uint32_t list_cap,
-                                                   uint32_t *__restrict__ counters, int tb, int bb, uint32_t bin_min)
+                                                   uint32_t *__restrict__ counters, int tb, int bb, uint32_t bin_min, uint32_t *__restrict__ top_hist, int top_shift)
 {
     __shared__ uint32_t wave_cnt[4], blk_base;
+    __shared__ uint32_t top[1 << PEP_SORT_TOP_BITS];          // keys of this block per top digit of the dense key (top_shift < 0: not wanted)
+    if (top_shift >= 0) for (int x = threadIdx.x; x < (1 << PEP_SORT_TOP_BITS); x += 256) top[x] = 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t k[COMPACT_ROUNDS];
     uint32_t mine = 0;
@@ -658,9 +661,15 @@ __global__ __launch_bounds__(256) void set_compact(uint64_t *__restrict__ table,
     for (int r = 0; r < COMPACT_ROUNDS; ++r)
         if (k[r] != EMPTY) {
             const uint64_t q = k[r] >> 43, t = (k[r] >> 18) & ((1u << 25) - 1), bin = (k[r] & ((1u << 18) - 1)) - bin_min;
-            if (idx < list_cap) list[idx] = (q << (tb + bb)) | (t << bb) | bin; else counters[1] = 1u;
+            const uint64_t dense = (q << (tb + bb)) | (t << bb) | bin;
+            if (idx < list_cap) list[idx] = dense; else counters[1] = 1u;
+            if (top_shift >= 0) atomicAdd(&top[(uint32_t)(dense >> top_shift) & ((1u << PEP_SORT_TOP_BITS) - 1)], 1u);
             ++idx;
         }
+    if (top_shift >= 0) {
+        __syncthreads();
+        for (int x = threadIdx.x; x < (1 << PEP_SORT_TOP_BITS); x += 256) if (top[x]) atomicAdd(&top_hist[x], top[x]);
+    }
 }
 
 int ilog2_ceil(uint64_t x)
@@ -836,11 +845,15 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
         const uint32_t bin_min = (uint32_t)(((1 << 23) - (int)std::max<uint32_t>(Q.max_len, 1u) + 1) >> 6);
         const uint32_t bin_max = (uint32_t)(((1 << 23) + (int)std::max<uint32_t>(T.max_len, 1u) - 1) >> 6);
         const int tb = std::max(1, ilog2_ceil(T.n)), qb = std::max(1, ilog2_ceil(Q.n)), bb = std::max(1, ilog2_ceil((uint64_t)bin_max - bin_min + 1));
+        // (the histogram of the keys' top digit rides along: the two-level sort below needs it, and the host decides from it)
+        const int key_bits = qb + tb + bb, top_shift = key_bits > PEP_SORT_TOP_BITS && key_bits <= 54 && P.reserved[2] == 0 ? key_bits - PEP_SORT_TOP_BITS : -1;
+        uint32_t *top_hist = reinterpret_cast<uint32_t *>(zero + PEP_ZERO_TOP);
         hipLaunchKernelGGL(set_compact, dim3((unsigned)ceil_div(cap, 256 * COMPACT_ROUNDS)), dim3(256), 0, ctx->stream, ctx->d_set.as<uint64_t>(), cap,
-                           ctx->ws[4].as<uint64_t>(), list_cap, counters, tb, bb, bin_min);
+                           ctx->ws[4].as<uint64_t>(), list_cap, counters, tb, bb, bin_min, top_hist, top_shift);
         ctx->set_clean_slots = cap;
-        struct { uint32_t counters[4]; unsigned long long stats[3]; uint32_t n_entries[4]; } h_all;     // counters[0..3], the three statistics words and the index sizes per shape: one copy
-        static_assert(sizeof(h_all) == 56 && sizeof(h_all) <= 64, "layout of the counter block");
+        struct { uint32_t counters[4]; unsigned long long stats[3]; uint32_t n_entries[4]; uint32_t pad[2]; uint32_t top[1 << PEP_SORT_TOP_BITS]; } h_all;
+        // counters[0..3], the three statistics words, the index sizes per shape and the top-digit histogram of the candidate keys: one copy
+        static_assert(sizeof(h_all) == 64 + 4096 && PEP_ZERO_TOP == PEP_ZERO_SEED + 64, "layout of the counter block");
         PEP_TRY(pep_read_back(ctx, &h_all, counters, sizeof(h_all)));
         if (before_sync) { PEP_TRY(before_sync(ctx)); before_sync = nullptr; }      // (once, also when the stage is repeated with larger buffers)
         PEP_TRY(pep_sync_reads(ctx));
@@ -859,6 +872,15 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             pep_key_unpack up;
             up.on = 1; up.tb = tb; up.bb = bb; up.bin_min = bin_min;
             void *sort_hist = nullptr;
+            uint32_t top_max = 0;
+            for (uint32_t v : h_all.top) top_max = std::max(top_max, v);
+            if (top_shift >= 0 && top_max <= PEP_SORT_TOP_CAP) {
+                // every bucket of the top digit fits LDS: partition + per-bucket sort, two launches
+                PEP_TRY(pep_sort_u64_two_level(ctx, ctx->ws[4].as<uint64_t>(), ctx->ws[5].as<uint64_t>(), n, key_bits, top_hist, &up));
+                *d_cands = ctx->ws[4].as<uint64_t>();
+                *n_cands = n;
+                return PEP_OK;
+            }
             PEP_TRY(pep_zero_block(ctx, PEP_ZC_SORT, PEP_ZERO_SORT, 8 * 2048 * 4, &sort_hist));
             PEP_TRY(pep_sort_u64(ctx, ctx->ws[4].as<uint64_t>(), ctx->ws[5].as<uint64_t>(), nullptr, n, qb + tb + bb, reinterpret_cast<uint32_t *>(sort_hist), &up));
         }

@@ -47,6 +47,47 @@ __global__ __launch_bounds__(ST) void sort_hist_all(const uint64_t *__restrict__
     for (uint32_t d = threadIdx.x; d < R * (uint32_t)a.passes; d += ST) if (h[d]) atomicAdd(&hist[d], h[d]);
 }
 
+// ---- two-level sort for UNIQUE keys (the candidate list of a search): one onesweep pass on the TOP 10 bits of the key, then every bucket of
+// that digit is sorted inside LDS by one block (bitonic) - two launches instead of five for the ~50 k keys of a search, whose sort is
+// bound by launches and barrier chains, not by bytes.  The histogram of the top digit comes from the kernel that produced the keys
+// (set_compact) and travels to the host with the search's counters: the host takes this path only when every bucket fits (TOP_CAP keys).
+__global__ __launch_bounds__(256) void sort_buckets(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, const uint32_t *__restrict__ top_hist, pep_key_unpack unpack)
+{
+    __shared__ uint64_t k[PEP_SORT_TOP_CAP];
+    __shared__ uint32_t s_part[4];
+    const uint32_t b = blockIdx.x, cnt = top_hist[b];
+    if (cnt == 0) return;                                    // (block-uniform)
+    // keys of the buckets in front of this one
+    uint32_t before = 0;
+    for (uint32_t d = threadIdx.x; d < b; d += 256) before += top_hist[d];
+    for (int x = 32; x > 0; x >>= 1) before += __shfl_xor(before, x, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = before;
+    __syncthreads();
+    const uint32_t start = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    uint32_t m = 1;
+    while (m < cnt) m <<= 1;
+    for (uint32_t x = threadIdx.x; x < m; x += 256) k[x] = x < cnt ? in[start + x] : ~0ull;
+    __syncthreads();
+    for (uint32_t size = 2; size <= m; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = threadIdx.x; t < (m >> 1); t += 256) {
+                const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;           // the pair (lo, hi) of this step
+                const bool up = (lo & size) == 0;
+                const uint64_t a = k[lo], c = k[hi];
+                if ((a > c) == up) { k[lo] = c; k[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (uint32_t x = threadIdx.x; x < cnt; x += 256) {
+        uint64_t v = k[x];
+        if (unpack.on) {
+            const uint64_t q = v >> (unpack.tb + unpack.bb), t = (v >> unpack.bb) & ((1ull << unpack.tb) - 1), bin = (v & ((1ull << unpack.bb) - 1)) + unpack.bin_min;
+            v = (q << 43) | (t << 18) | bin;
+        }
+        out[start + x] = v;
+    }
+}
+
 template <int DB>
 __global__ __launch_bounds__(ST) void sort_onesweep(const uint64_t *__restrict__ keys, uint64_t *__restrict__ out, const uint32_t *__restrict__ n_ptr, uint64_t n_host,
                                                     int shift, const uint32_t *__restrict__ hist /* [R] of this pass */, uint64_t *__restrict__ state,
@@ -215,4 +256,30 @@ int pep_sort_u64(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, const uint32_t
         case 10: return sort_passes<10>(ctx, d_keys, d_tmp, d_n, n_bound, bits, passes, d_hist_zeroed, unpack);
         default: return sort_passes<11>(ctx, d_keys, d_tmp, d_n, n_bound, bits, passes, d_hist_zeroed, unpack);
     }
+}
+
+// the two-level sort (see sort_buckets): n distinct keys of `bits` significant bits, d_top_hist = the histogram of their top
+// PEP_SORT_TOP_BITS bits (device memory), every count of which the caller has seen to be <= PEP_SORT_TOP_CAP.  Result in d_keys.
+int pep_sort_u64_two_level(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, int bits, const uint32_t *d_top_hist, const pep_key_unpack *unpack)
+{
+    if (n == 0) return PEP_OK;
+    if (bits <= PEP_SORT_TOP_BITS || n >= (1ull << 30)) return pep_fail(ctx, PEP_ERR_INTERNAL, "pep_sort_u64_two_level: key width / count");
+    constexpr int DB = PEP_SORT_TOP_BITS;
+    constexpr uint32_t R = 1u << DB;
+    const uint32_t nb = (uint32_t)ceil_div(n, STILE);
+    DevBuf &S = ctx->sort_state;
+    const size_t need = ((size_t)nb * R + 2) * sizeof(uint64_t);
+    bool clear = false;
+    if (need > S.cap) { PEP_TRY(dev_reserve(ctx, S, need)); clear = true; }
+    ctx->sort_epoch = (ctx->sort_epoch + 1) & ((1u << 29) - 1);
+    if (ctx->sort_epoch == 0) { clear = true; ctx->sort_epoch = 1; }
+    if (clear) { PEP_HIP(ctx, hipMemsetAsync(S.p, 0, S.cap, ctx->stream)); ctx->sort_ticket_base = 0; }
+    pep_key_unpack none;
+    none.on = 0; none.tb = none.bb = 0; none.bin_min = 0;
+    hipLaunchKernelGGL(sort_onesweep<DB>, dim3(nb), dim3(ST), 0, ctx->stream, (const uint64_t *)d_keys, d_tmp, (const uint32_t *)nullptr, n, bits - DB, d_top_hist,
+                       S.as<uint64_t>(), ctx->sort_ticket_base, (uint64_t)ctx->sort_epoch, none);
+    ctx->sort_ticket_base += nb;
+    hipLaunchKernelGGL(sort_buckets, dim3(R), dim3(256), 0, ctx->stream, (const uint64_t *)d_tmp, d_keys, d_top_hist, unpack ? *unpack : none);
+    PEP_HIP(ctx, hipGetLastError());
+    return PEP_OK;
 }

@@ -688,7 +688,15 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
             const int dstar = min(max(Lt - Lq, dl), dh);
             const int s_hi = 2 * min(Lq - 1, Lt - 1 - dstar) + dstar;
             steps = s_hi - s0 + 1;
-            for (int d = dl; d <= dh; ++d) cells += (unsigned long long)(min(Lq - 1, Lt - 1 - d) - max(0, -d) + 1);
+            // in-matrix cells of the diagonals dl .. dh: sum of min(Lq, Lt - d) + min(0, d), in closed form (a loop over the 128 diagonals of
+            // every candidate was most of this kernel's time)
+            auto tri = [](long long a, long long b) { return b < a ? 0ll : (a + b) * (b - a + 1) / 2; };      // a + (a + 1) + ... + b
+            const long long k = (long long)Lt - Lq;                       // min(Lq, Lt - d) = Lq for d <= k, Lt - d beyond
+            const long long flat_hi = min((long long)dh, k), slope_lo = max((long long)dl, k + 1);
+            long long total = (flat_hi >= dl ? (flat_hi - dl + 1) * (long long)Lq : 0ll);
+            if (slope_lo <= dh) total += (long long)(dh - slope_lo + 1) * Lt - tri(slope_lo, dh);
+            total += tri(dl, min((long long)dh, -1ll));                     // + d for the negative diagonals
+            cells += (unsigned long long)total;
         }
         const uint32_t nb = (uint32_t)((steps + 15) / 16);
         nblk[c] = nb;
