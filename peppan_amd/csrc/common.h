@@ -127,6 +127,7 @@ struct pep_ctx {
     PinBuf pin_labels;                       // grow-only: K10's labels on their way to the caller
     uint64_t trace_swept = 0;               // pairs the last traceback pass swept (the rest were settled by the gapless shortcut)
     struct ScanState { DevBuf buf; uint32_t epoch = 0, ticket_base = 0; };
+    ScanState fused_state[4];               // kernels that scan while they compute (lookback.h): select (count, run capacity), top-k (hits, CIGAR runs)
     ScanState scan_state[2];                // single-launch scans (u32, u64): ticket counter + one status word per tile (scan.hip)
     DevBuf sort_state, sort_hist;           // one-launch-per-pass radix sort (sort.hip): ticket + status words per (tile, digit); its own histograms
     uint32_t sort_epoch = 0, sort_ticket_base = 0;

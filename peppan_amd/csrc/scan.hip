@@ -5,6 +5,7 @@
 // u64: the same with 48-bit sums in the status word.  (n = 0 or n >= 2^40: per-tile reduce -> scan of the tile sums -> per-tile
 // scan + offset.)
 #include "common.h"
+#include "lookback.h"
 
 namespace {
 
@@ -239,5 +240,27 @@ int pep_copy_from_pinned(pep_ctx *ctx, void *d_dst, const void *pinned_src, uint
     hipLaunchKernelGGL(copy_words, dim3((unsigned)std::min<uint64_t>(ceil_div(n_words, 256), 1024)), dim3(256), 0, ctx->stream, reinterpret_cast<uint32_t *>(d_dst),
                        reinterpret_cast<const uint32_t *>(pinned_src), n_words);
     PEP_HIP(ctx, hipGetLastError());
+    return PEP_OK;
+}
+
+// (lookback.h) the state area, ticket base and epoch of one launch of a kernel that uses the look-back device functions
+int pep_lookback_begin(pep_ctx *ctx, pep_ctx::ScanState &S, uint64_t n_tiles, uint32_t epoch_mask, uint64_t **state, uint32_t *ticket_base, uint64_t *epoch)
+{
+    bool clear = false;
+    if ((n_tiles + 1) * sizeof(uint64_t) > S.buf.cap) {
+        // a new (or larger) state area starts from zeros: epoch 0 is never used, so no word of it can pass for a published one
+        PEP_TRY(dev_reserve(ctx, S.buf, (n_tiles + 1) * sizeof(uint64_t) * 2));
+        clear = true;
+    }
+    S.epoch = (S.epoch + 1) & epoch_mask;
+    if (S.epoch == 0) { clear = true; S.epoch = 1; }   // wrapped: forget every old word
+    if (clear) {
+        PEP_HIP(ctx, hipMemsetAsync(S.buf.p, 0, S.buf.cap, ctx->stream));
+        S.ticket_base = 0;
+    }
+    *state = S.buf.as<uint64_t>();
+    *ticket_base = S.ticket_base;
+    *epoch = S.epoch;
+    S.ticket_base += (uint32_t)n_tiles;
     return PEP_OK;
 }

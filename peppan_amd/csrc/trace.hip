@@ -2,6 +2,7 @@
 // run-length encode the CIGAR, count identities, apply the identity / query-cover filters and the
 // per-(query, split) top-k, and emit fixed-size hit records + a CIGAR arena ordered by (q, t).
 #include "common.h"
+#include "lookback.h"
 #include <cstring>
 
 namespace {
@@ -20,54 +21,68 @@ __device__ __forceinline__ uint32_t key_q(uint64_t k) { return (uint32_t)(k >> 4
 __device__ __forceinline__ uint32_t key_t(uint64_t k) { return (uint32_t)((k >> 18) & ((1u << 25) - 1)); }
 __device__ __forceinline__ int key_dlo(uint64_t k) { return (int)(k & ((1u << 18) - 1)) * 64 - (1 << 23) - 32; }
 
-// group heads pick the best band of their (q,t) group: score desc, then lowest bin (= first in sorted order)
-__global__ __launch_bounds__(256) void select_best(const uint64_t *__restrict__ cands, uint64_t n, const int4 *__restrict__ sw,
-                                                   const int32_t *__restrict__ min_score, uint32_t *__restrict__ flag, uint32_t *__restrict__ best_idx,
-                                                   uint32_t *__restrict__ n_pairs, int hsp_mode)
+// Selection (group heads pick the best band of their (q, t) group: score desc, then lowest bin = first in sorted order; hsp_mode 1: every band
+// that reaches the threshold), compaction and run slots in ONE launch (lookback.h): every thread judges its candidate, the tile scans two
+// values at once - selected pairs (their slot in the arrays of the selected) and their run capacity (the slot of their CIGAR runs) - finds
+// the totals of the tiles in front of it by look-back and writes the selected pairs' records straight to their slots.  Four launches of a
+// dependent chain before (about 5 us each for 50 k candidates).
+struct SelectState { uint64_t *count_state, *run_state; uint32_t ticket_base; uint64_t epoch_count, epoch_run; };
+__global__ __launch_bounds__(256) void select_gather(const uint64_t *__restrict__ cands, uint64_t n, const int4 *__restrict__ sw, const int32_t *__restrict__ min_score,
+                                                     int hsp_mode, const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len, SelInfo *__restrict__ sel,
+                                                     uint64_t *__restrict__ run_off, uint64_t *__restrict__ sel_keys, int32_t *__restrict__ known, int32_t *__restrict__ end_lane,
+                                                     uint32_t *__restrict__ counters /* [0] (q, t) groups, [1] selected pairs */, unsigned long long *__restrict__ total_runs,
+                                                     SelectState st)
 {
-    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint32_t s_tile, lds32[4];
+    __shared__ uint64_t lds64[4], s_pre[2];
+    const uint32_t tile = lb_take_tile(st.count_state, st.ticket_base, &s_tile);
+    const uint64_t c = (uint64_t)tile * 256 + threadIdx.x;
     const bool live = c < n;
     const uint64_t g = live ? cands[c] >> 18 : 0;
-    uint32_t f = 0;
     const bool head = live && (c == 0 || (cands[c - 1] >> 18) != g);
-    const int heads = __syncthreads_count(head);                 // (q, t) groups that start in this block: one atomic per block
-    if (threadIdx.x == 0 && heads) atomicAdd(n_pairs, (uint32_t)heads);
-    if (!live) return;
-    if (hsp_mode == 1) {
+    const int heads = __syncthreads_count(head);                 // (q, t) groups that start in this tile: one atomic per block
+    if (threadIdx.x == 0 && heads) atomicAdd(&counters[0], (uint32_t)heads);
+    uint32_t f = 0, b = (uint32_t)c;
+    if (live && hsp_mode == 1) {
         // every band that reaches the threshold is traced; duplicates are removed after the walk (dedupe_bands)
-        if (sw[c].x > 0 && sw[c].x >= min_score[key_q(cands[c])]) { f = 1; best_idx[c] = (uint32_t)c; }
+        if (sw[c].x > 0 && sw[c].x >= min_score[key_q(cands[c])]) f = 1;
     } else if (head) {
         int best = sw[c].x;
-        uint64_t bi = c;
         for (uint64_t x = c + 1; x < n && (cands[x] >> 18) == g; ++x)
-            if (sw[x].x > best) { best = sw[x].x; bi = x; }
-        if (best > 0 && best >= min_score[key_q(cands[c])]) { f = 1; best_idx[c] = (uint32_t)bi; }
+            if (sw[x].x > best) { best = sw[x].x; b = (uint32_t)x; }
+        if (best > 0 && best >= min_score[key_q(cands[c])]) f = 1;
     }
-    flag[c] = f;
-}
-
-__global__ __launch_bounds__(256) void gather_sel(uint64_t n, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos,
-                                                  const uint32_t *__restrict__ best_idx, const int4 *__restrict__ sw,
-                                                  const uint64_t *__restrict__ cands, const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len,
-                                                  SelInfo *__restrict__ sel, uint64_t *__restrict__ run_cap, uint64_t *__restrict__ sel_keys,
-                                                  int32_t *__restrict__ known, int32_t *__restrict__ end_lane, uint64_t n_bound)
-{
-    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    // the arrays of the selected pairs are sized from n_bound >= pos[n] (the host may not have seen the count): the scan over run_cap runs
-    // over n_bound entries, so the ones behind the last selected pair are zero
-    if (c < n_bound && c >= pos[n]) run_cap[c] = 0;
-    if (c >= n || !flag[c]) return;
-    const uint32_t b = best_idx[c];
-    SelInfo s;
-    s.cand = pos[c]; s.score = sw[b].x; s.iend = s.jend = -1;      // the end cell comes from the traceback pass
-    sel_keys[pos[c]] = cands[b];
-    known[pos[c]] = sw[b].x;            // the traceback pass looks for the first cell that reaches this score ...
-    end_lane[pos[c]] = sw[b].y;         // ... in the sub-band around the lane where the score pass met it
-    s.istart = s.jstart = 0; s.n_runs = s.aln_len = s.n_ident = 0; s.pass = s.keep = 0; s.pad = 0;
-    sel[pos[c]] = s;
-    // an alignment has at most 2*min(Lq,Lt)+1 runs (M runs consume a residue of both sequences)
-    const uint64_t k = cands[b];
-    run_cap[pos[c]] = 2ull * min(q_len[key_q(k)], t_len[key_t(k)]) + 2;
+    uint64_t key = 0, cap = 0;
+    int4 r = make_int4(0, 0, 0, 0);
+    if (f) {
+        key = cands[b]; r = sw[b];
+        cap = 2ull * min(q_len[key_q(key)], t_len[key_t(key)]) + 2;      // an alignment has at most 2 * min(Lq, Lt) + 1 runs (M runs consume a residue of both sequences)
+    }
+    uint32_t tot_f;
+    uint64_t tot_cap;
+    const uint32_t ex_f = block_excl_scan_256<uint32_t>(f, &tot_f, lds32);
+    const uint64_t ex_cap = block_excl_scan_256<uint64_t>(cap, &tot_cap, lds64);
+    if (threadIdx.x < 64) {
+        const uint64_t p0 = lb_tile_prefix<32>(st.count_state + 1, tile, tot_f, st.epoch_count, (int)threadIdx.x);
+        const uint64_t p1 = lb_tile_prefix<48>(st.run_state + 1, tile, tot_cap, st.epoch_run, (int)threadIdx.x);
+        if (threadIdx.x == 0) { s_pre[0] = p0; s_pre[1] = p1; }
+    }
+    __syncthreads();
+    if (f) {
+        const uint64_t slot = s_pre[0] + ex_f;
+        SelInfo s;
+        s.cand = (uint32_t)slot; s.score = r.x; s.iend = s.jend = -1;      // the end cell comes from the traceback pass
+        s.istart = s.jstart = 0; s.n_runs = s.aln_len = s.n_ident = 0; s.pass = s.keep = 0; s.pad = 0;
+        sel[slot] = s;
+        sel_keys[slot] = key;
+        known[slot] = r.x;              // the traceback pass looks for the first cell that reaches this score ...
+        end_lane[slot] = r.y;           // ... in the sub-band around the lane where the score pass met it
+        run_off[slot] = s_pre[1] + ex_cap;
+    }
+    if ((uint64_t)(tile + 1) * 256 >= n && threadIdx.x == 255) {      // the last tile: totals
+        counters[1] = (uint32_t)(s_pre[0] + tot_f);
+        *total_runs = s_pre[1] + tot_cap;
+    }
 }
 
 // Rule 5a (oracle: gapless_segment / band_align): before any traceback sweep, the two diagonals of the lowest lane
@@ -345,41 +360,64 @@ __global__ __launch_bounds__(256) void apply_dedupe(const uint32_t *__restrict__
 // rank inside (query, target mod n_splits): score desc, target asc, band asc.  sel is ordered by (q, t, bin).
 // t_class (optional): competition class of every target = group * n_splits + (index inside the group) % n_splits, so that a
 // batch of reference sets (genomes) searched at once ranks exactly as if each had been searched alone
-__global__ __launch_bounds__(256) void topk(const uint32_t *__restrict__ d_n_sel, uint64_t n_bound, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int top_k, int n_splits, uint32_t t_base,
-                                            const uint32_t *__restrict__ t_class, uint32_t *__restrict__ keep_flag, uint64_t *__restrict__ keep_runs,
-                                            const unsigned long long *__restrict__ score_hdr, const unsigned long long *__restrict__ trace_hdr, unsigned long long *__restrict__ mail)
+__global__ __launch_bounds__(256) void topk(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int top_k, int n_splits, uint32_t t_base,
+                                            const uint32_t *__restrict__ t_class, uint32_t *__restrict__ keep_flag, uint32_t *__restrict__ hit_pos, uint64_t *__restrict__ cig_pos,
+                                            const unsigned long long *__restrict__ score_hdr, const unsigned long long *__restrict__ trace_hdr, unsigned long long *__restrict__ mail,
+                                            SelectState st)
 {
+    // top-k decision per selected pair AND the two compactions behind it (slot of the hit record, slot of its CIGAR runs) in one launch:
+    // the tile scans (kept, runs of the kept) and finds the totals in front of it by look-back (lookback.h)
+    __shared__ uint32_t s_tile, lds32[4];
+    __shared__ uint64_t lds64[4], s_pre[2];
+    const uint32_t tile = lb_take_tile(st.count_state, st.ticket_base, &s_tile);
     const uint64_t n_sel = *d_n_sel;
-    const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t s = (uint64_t)tile * 256 + threadIdx.x;
     if (s == 0) {
         // the totals of the two Smith-Waterman passes into the block the host reads with its last synchronisation (one copy for everything)
         mail[4] = score_hdr[0]; mail[5] = score_hdr[1];
         mail[6] = trace_hdr ? trace_hdr[0] : 0ull; mail[7] = trace_hdr ? trace_hdr[1] : 0ull; mail[8] = trace_hdr ? trace_hdr[5] : 0ull;
     }
-    if (s >= n_sel) {
-        if (s < n_bound) { keep_flag[s] = 0; keep_runs[s] = 0; }      // the scans below run over n_bound entries
-        return;
-    }
-    const SelInfo me = sel[s];
     uint32_t keep = 0;
-    if (me.pass) {
-        const uint64_t key = cands[me.cand];
-        const uint32_t q = key_q(key), t = key_t(key), split = t_class ? t_class[t] : (t + t_base) % (uint32_t)n_splits;
-        uint32_t rank = 0;
-        for (int dir = -1; dir <= 1; dir += 2) {
-            for (int64_t x = (int64_t)s + dir; x >= 0 && x < (int64_t)n_sel; x += dir) {
-                const SelInfo o = sel[x];
-                const uint64_t ko = cands[o.cand];
-                if (key_q(ko) != q) break;
-                const uint32_t to = key_t(ko);
-                if (!o.pass || (t_class ? t_class[to] : (to + t_base) % (uint32_t)n_splits) != split) continue;
-                if (o.score > me.score || (o.score == me.score && (to < t || (to == t && x < (int64_t)s)))) ++rank;
+    uint64_t n_runs = 0;
+    if (s < n_sel) {
+        const SelInfo me = sel[s];
+        if (me.pass) {
+            const uint64_t key = cands[me.cand];
+            const uint32_t q = key_q(key), t = key_t(key), split = t_class ? t_class[t] : (t + t_base) % (uint32_t)n_splits;
+            uint32_t rank = 0;
+            for (int dir = -1; dir <= 1; dir += 2) {
+                for (int64_t x = (int64_t)s + dir; x >= 0 && x < (int64_t)n_sel; x += dir) {
+                    const SelInfo o = sel[x];
+                    const uint64_t ko = cands[o.cand];
+                    if (key_q(ko) != q) break;
+                    const uint32_t to = key_t(ko);
+                    if (!o.pass || (t_class ? t_class[to] : (to + t_base) % (uint32_t)n_splits) != split) continue;
+                    if (o.score > me.score || (o.score == me.score && (to < t || (to == t && x < (int64_t)s)))) ++rank;
+                }
             }
+            keep = rank < (uint32_t)top_k ? 1u : 0u;
         }
-        keep = rank < (uint32_t)top_k ? 1u : 0u;
+        n_runs = keep ? me.n_runs : 0;
     }
-    keep_flag[s] = keep;
-    keep_runs[s] = keep ? me.n_runs : 0;
+    uint32_t tot_k;
+    uint64_t tot_r;
+    const uint32_t ex_k = block_excl_scan_256<uint32_t>(keep, &tot_k, lds32);
+    const uint64_t ex_r = block_excl_scan_256<uint64_t>(n_runs, &tot_r, lds64);
+    if (threadIdx.x < 64) {
+        const uint64_t p0 = lb_tile_prefix<32>(st.count_state + 1, tile, tot_k, st.epoch_count, (int)threadIdx.x);
+        const uint64_t p1 = lb_tile_prefix<48>(st.run_state + 1, tile, tot_r, st.epoch_run, (int)threadIdx.x);
+        if (threadIdx.x == 0) { s_pre[0] = p0; s_pre[1] = p1; }
+    }
+    __syncthreads();
+    if (s < n_sel) {
+        keep_flag[s] = keep;
+        hit_pos[s] = (uint32_t)(s_pre[0] + ex_k);
+        cig_pos[s] = s_pre[1] + ex_r;
+    }
+    if (tile == gridDim.x - 1 && threadIdx.x == 255) {          // the last tile: number of hits, number of their CIGAR runs
+        reinterpret_cast<uint32_t *>(mail)[2] = (uint32_t)(s_pre[0] + tot_k);
+        mail[2] = s_pre[1] + tot_r;
+    }
 }
 
 __global__ __launch_bounds__(256) void emit(const uint32_t *__restrict__ d_n_sel, const SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands,
@@ -526,10 +564,6 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     pep_timer_begin(ctx, TM_TRACE);
 
     const int4 *sw = ctx->ws[12].as<const int4>();
-    PEP_TRY(dev_reserve(ctx, ctx->ws[16], (n + 1) * 4));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[17], (n + 2) * 4));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[18], (n + 1) * 4));
-    uint32_t *flag = ctx->ws[16].as<uint32_t>(), *pos = ctx->ws[17].as<uint32_t>(), *best_idx = ctx->ws[18].as<uint32_t>();
     // the block the host reads: u32 [0] (q, t) pairs, [1] selected pairs, [2] hits; u64 [2] CIGAR runs of the hits, [3] run capacity of the selected
     // pairs, [4] [5] cells / 16-step blocks of the score pass, [6] [7] [8] cells / blocks / swept pairs of the traceback pass
     void *zb = nullptr;
@@ -541,8 +575,24 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     std::memset(&h_mail, 0, sizeof(h_mail));
     ctx->ext.pending = false;
     const unsigned gb = (unsigned)ceil_div(n, 256);
-    hipLaunchKernelGGL(select_best, dim3(gb), dim3(256), 0, st, d_cands, n, sw, dms.as<const int32_t>(), flag, best_idx, counters, P.hsp_mode);
-    PEP_TRY(pep_scan_u32(ctx, flag, pos, n, ctx->ws[7], counters + 1));
+    // selection, compaction and the run slots of the selected pairs in one launch (select_gather); the arrays of the selected pairs are laid
+    // out for n entries (every candidate selected) whatever the count turns out to be
+    PEP_TRY(dev_reserve(ctx, ctx->ws[19], (size_t)n * sizeof(SelInfo)));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[20], ((size_t)n + 2) * 8 * 2));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[8], ((size_t)n + 2) * 4 * 2));      // ws[8]: raw seed hits of K4, free again
+    int32_t *known = ctx->ws[8].as<int32_t>(), *end_lane = known + n + 2;
+    SelInfo *sel = ctx->ws[19].as<SelInfo>();
+    uint64_t *run_off = ctx->ws[20].as<uint64_t>(), *sel_keys = run_off + n + 2;
+    {
+        SelectState ss;
+        uint64_t ep = 0;
+        uint32_t tb2 = 0;
+        PEP_TRY(pep_lookback_begin(ctx, ctx->fused_state[0], gb, (1u << 30) - 1, &ss.count_state, &ss.ticket_base, &ss.epoch_count));
+        PEP_TRY(pep_lookback_begin(ctx, ctx->fused_state[1], gb, (1u << 14) - 1, &ss.run_state, &tb2, &ep));
+        ss.epoch_run = ep;
+        hipLaunchKernelGGL(select_gather, dim3(gb), dim3(256), 0, st, d_cands, n, sw, dms.as<const int32_t>(), P.hsp_mode, ctx->q.len.as<const uint32_t>(),
+                           ctx->t.len.as<const uint32_t>(), sel, run_off, sel_keys, known, end_lane, counters, mail + 3, ss);
+    }
     // upper bounds for the buffers of the traceback stage
     constexpr uint64_t FAST_DIR_BYTES = 8ull << 30, FAST_RUN_BYTES = 2ull << 30;
     const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 16 + 3;
@@ -556,20 +606,9 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     }
     uint32_t n_hits = 0;
     uint64_t n_cig = 0;
-    SelInfo *sel = nullptr;
-    uint64_t *run_off = nullptr, *sel_keys = nullptr, *cig_pos = nullptr;
+    uint64_t *cig_pos = nullptr;
     uint32_t *runs = nullptr, *keep_flag = nullptr, *hit_pos = nullptr;
     if (n_b) {
-        PEP_TRY(dev_reserve(ctx, ctx->ws[19], (size_t)n_b * sizeof(SelInfo)));
-        PEP_TRY(dev_reserve(ctx, ctx->ws[20], ((size_t)n_b + 2) * 8 * 3));
-        PEP_TRY(dev_reserve(ctx, ctx->ws[8], ((size_t)n_b + 2) * 4 * 2));      // ws[8]: raw seed hits of K4, free again
-        int32_t *known = ctx->ws[8].as<int32_t>(), *end_lane = known + n_b + 2;
-        sel = ctx->ws[19].as<SelInfo>();
-        uint64_t *run_cap = ctx->ws[20].as<uint64_t>();
-        run_off = run_cap + n_b + 2; sel_keys = run_off + n_b + 2;
-        hipLaunchKernelGGL(gather_sel, dim3(gb), dim3(256), 0, st, n, (const uint32_t *)flag, (const uint32_t *)pos, (const uint32_t *)best_idx, sw, d_cands,
-                           ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), sel, run_cap, sel_keys, known, end_lane, n_b);
-        PEP_TRY(pep_scan_u64(ctx, run_cap, run_off, n_b, ctx->ws[7], reinterpret_cast<uint64_t *>(mail + 3)));
         uint64_t total_runs = run_bound;
         if (!fast) PEP_TRY(pep_read_back(ctx, &total_runs, mail + 3, 8));         // arrives with the synchronisation inside pep_sw_run (block total)
         // ---- rule 5a: pairs whose alignment is one ungapped run are settled without a sweep (the score-pass results in ws[12] have been
@@ -596,15 +635,21 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
             hipLaunchKernelGGL(apply_dedupe, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, sel);
         }
         // top-k, then compaction of hits and CIGAR runs
-        PEP_TRY(dev_reserve(ctx, ctx->ws[22], ((size_t)n_b + 2) * (4 + 4 + 8 + 8)));
+        PEP_TRY(dev_reserve(ctx, ctx->ws[22], ((size_t)n_b + 2) * (4 + 4 + 8)));
         keep_flag = ctx->ws[22].as<uint32_t>(); hit_pos = keep_flag + n_b + 2;
-        uint64_t *keep_runs = reinterpret_cast<uint64_t *>(hit_pos + n_b + 2);
-        cig_pos = keep_runs + n_b + 2;
-        hipLaunchKernelGGL(topk, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, n_b, sel, (const uint64_t *)sel_keys, P.top_k, P.n_splits,
-                           (uint32_t)(P.t_index_base % P.n_splits), ctx->t_class_ready ? ctx->d_t_class.as<const uint32_t>() : (const uint32_t *)nullptr, keep_flag, keep_runs,
-                           (const unsigned long long *)score_hdr, (const unsigned long long *)trace_hdr, mail);
-        PEP_TRY(pep_scan_u32(ctx, keep_flag, hit_pos, n_b, ctx->ws[7], counters + 2));
-        PEP_TRY(pep_scan_u64(ctx, keep_runs, cig_pos, n_b, ctx->ws[7], reinterpret_cast<uint64_t *>(mail + 2)));
+        cig_pos = reinterpret_cast<uint64_t *>(hit_pos + n_b + 2);
+        {
+            SelectState ts;
+            uint64_t ep = 0;
+            uint32_t tb2 = 0;
+            const uint64_t tiles = ceil_div(n_b, 256);
+            PEP_TRY(pep_lookback_begin(ctx, ctx->fused_state[2], tiles, (1u << 30) - 1, &ts.count_state, &ts.ticket_base, &ts.epoch_count));
+            PEP_TRY(pep_lookback_begin(ctx, ctx->fused_state[3], tiles, (1u << 14) - 1, &ts.run_state, &tb2, &ep));
+            ts.epoch_run = ep;
+            hipLaunchKernelGGL(topk, dim3((unsigned)tiles), dim3(256), 0, st, d_n_sel, sel, (const uint64_t *)sel_keys, P.top_k, P.n_splits,
+                               (uint32_t)(P.t_index_base % P.n_splits), ctx->t_class_ready ? ctx->d_t_class.as<const uint32_t>() : (const uint32_t *)nullptr, keep_flag, hit_pos, cig_pos,
+                               (const unsigned long long *)score_hdr, (const unsigned long long *)trace_hdr, mail, ts);
+        }
         if (fast && !ctx->device_results && pin_reserve(ctx, ctx->pin_stage, PACK_HEADER) == PEP_OK) {
             // the result leaves through pack_out: output buffers from the same upper bounds, no look at the sizes, no synchronisation here
             const size_t hb_bound = (size_t)n_b * sizeof(pep_hit);

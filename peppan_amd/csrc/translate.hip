@@ -54,12 +54,33 @@ __device__ __forceinline__ int64_t frame_len(int64_t L, int frame)
     return rem > 0 ? (rem + 2) / 3 : 0;
 }
 
-// one wavefront per query gene
+// What the host needs of a packed set before it can queue a search: computed on the device (k1_offsets) and downloaded behind the
+// descriptors (two descriptor slots), so that the host does not have to walk 60 k descriptors while the GPU waits for its next kernel -
+// the per-sequence tables (h_off, h_len, the meta records) are built from the downloaded descriptors only when somebody asks for them.
+struct K1Summary {
+    unsigned long long residues, total;
+    uint32_t n, max_len;
+    uint32_t pad[2];
+};
+static_assert(sizeof(K1Summary) == 2 * 16, "the summary takes two descriptor slots");
+
+struct PackDesc {          // one per packed sequence: where its residues come from
+    uint32_t seq;
+    uint32_t frame;
+    uint32_t aa_off;
+    uint32_t len;
+};
+
+__device__ __forceinline__ uint32_t padded_len(uint32_t len) { return (len + 15u) / 16u * 16u + PEP_SEQ_GAP; }
+
+// one wavefront per query gene; the gene's descriptor, padded length and (in pinned memory, for the host) length are written here too
 __global__ __launch_bounds__(256) void k1_query_frames(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ off, uint32_t n, int tab,
-                                                       uint32_t *__restrict__ frame_out, uint32_t *__restrict__ len_out)
+                                                       PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, uint32_t *__restrict__ n_out,
+                                                       K1Summary *__restrict__ sum, uint32_t *__restrict__ pin_len)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *n_out = n; sum->residues = 0ull; sum->max_len = 0u; }       // (k1_offsets accumulates into it)
     if (g >= n) return;
     const uint8_t *s = nt + off[g];
     const int64_t L = (int64_t)(off[g + 1] - off[g]);
@@ -92,7 +113,12 @@ __global__ __launch_bounds__(256) void k1_query_frames(const uint8_t *__restrict
     uint32_t best_cnt = x1, best_f = 1, best_len = (uint32_t)na1;
     if (x2 < best_cnt) { best_cnt = x2; best_f = 2; best_len = (uint32_t)na2; }
     if (x3 < best_cnt) { best_cnt = x3; best_f = 3; best_len = (uint32_t)na3; }
-    if (lane == 0) { frame_out[g] = best_f; len_out[g] = best_len; }
+    if (lane == 0) {
+        desc[g] = PackDesc{g, best_f, 0u, best_len};
+        padded[g] = padded_len(best_len);
+        len_out[g] = best_len;
+        pin_len[g] = best_len;                   // the host's copy (pinned memory): the search derives its score thresholds from the lengths
+    }
 }
 
 // one wavefront per (reference sequence, frame): chunk boundaries.  chunk_base[w] = first slot of this frame's chunk list.
@@ -135,23 +161,6 @@ __global__ __launch_bounds__(256) void k1_ref_chunks(const uint8_t *__restrict__
     }
     if (lane == 0) chunk_cnt[w] = cnt;
 }
-
-// What the host needs of a packed set before it can queue a search: computed on the device (k1_offsets) and downloaded behind the
-// descriptors (two descriptor slots), so that the host does not have to walk 60 k descriptors while the GPU waits for its next kernel -
-// the per-sequence tables (h_off, h_len, the meta records) are built from the downloaded descriptors only when somebody asks for them.
-struct K1Summary {
-    unsigned long long residues, total;
-    uint32_t n, max_len;
-    uint32_t pad[2];
-};
-static_assert(sizeof(K1Summary) == 2 * 16, "the summary takes two descriptor slots");
-
-struct PackDesc {          // one per packed sequence: where its residues come from
-    uint32_t seq;
-    uint32_t frame;
-    uint32_t aa_off;
-    uint32_t len;
-};
 
 // One wavefront per packed sequence: lanes stride over its residues (adjacent lanes read adjacent codons - 192 contiguous
 // nucleotide bytes per step - and store 64 contiguous residue bytes), then over the padding up to the next sequence, and fill
@@ -293,8 +302,6 @@ int upload_codon_table(pep_ctx *ctx)
     return PEP_OK;
 }
 
-__device__ __forceinline__ uint32_t padded_len(uint32_t len) { return (len + 15u) / 16u * 16u + PEP_SEQ_GAP; }
-
 // query side: one packed sequence per gene, the chosen frame from its start
 __global__ void k1_query_desc(uint32_t n, const uint32_t *__restrict__ frame, const uint32_t *__restrict__ len, PackDesc *__restrict__ desc,
                               uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, uint32_t *__restrict__ n_out, K1Summary *__restrict__ sum,
@@ -435,9 +442,9 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
         const uint64_t upper = 2 * PEP_END_PAD + (nt.total + 2 * (uint64_t)n) / 3 + (uint64_t)n * (16 + PEP_SEQ_GAP);
         PEP_TRY(reserve_packed(ctx, ctx->q, n, upper));
         if (n) hipLaunchKernelGGL(k1_query_frames, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, tab,
-                                  W[0].as<uint32_t>(), W[1].as<uint32_t>());
-        hipLaunchKernelGGL(k1_query_desc, dim3((unsigned)ceil_div((uint64_t)n + 1, 256)), dim3(256), 0, ctx->stream, n, W[0].as<const uint32_t>(), W[1].as<const uint32_t>(),
-                           D.as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + n), pin_len);
+                                  D.as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + n), pin_len);
+        else hipLaunchKernelGGL(k1_query_desc, dim3(1), dim3(64), 0, ctx->stream, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                D.as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + n), pin_len);
         PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6], pin_sum));
         // an event of its own: whoever waits for the query side must not wait for what was queued behind it (pep_search queues the reference side next)
         ctx->k1q_event_set = false;
