@@ -20,6 +20,7 @@
 // Integer DP in int32.  Algorithmic HBM bytes per candidate: Lq + Lt residues + 16 B result
 // (+ 32 B per anti-diagonal step of traceback codes).  VALU-bound by construction.
 #include "common.h"
+#include "lookback.h"
 
 namespace {
 
@@ -664,13 +665,17 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
                                                unsigned long long *__restrict__ cells_total,           // [0] cells, [1] 16-step blocks, [3] candidates above nb_limit
                                                uint32_t *__restrict__ len_hist,                        // [LEN_BUCKETS] candidates per length bucket
                                                uint32_t nb_limit,
-                                               const int32_t *__restrict__ skip_mode)                  // traceback pass: candidates settled without a sweep (mode -2, gapless_check) take no part
+                                               const int32_t *__restrict__ skip_mode,                  // traceback pass: candidates settled without a sweep (mode -2, gapless_check) take no part
+                                               uint64_t *__restrict__ dir_off,                         // traceback pass: start of every candidate's traceback codes (in 16-step blocks) = exclusive
+                                               uint64_t *__restrict__ lb_state, uint32_t lb_ticket_base, uint64_t lb_epoch)      //   scan of the block counts, taken in here (lookback.h)
 {
     __shared__ uint32_t lh[LEN_BUCKETS];
+    __shared__ uint32_t s_tile;
     for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) lh[x] = 0;
     __syncthreads();
     const uint64_t n = d_n ? (uint64_t)*d_n : n_host;          // (the grid is sized from n_host, an upper bound, when the count lives on the device)
-    const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t tile = lb_state ? lb_take_tile(lb_state, lb_ticket_base, &s_tile) : blockIdx.x;
+    const uint64_t c = (uint64_t)tile * 256 + threadIdx.x;
     unsigned long long cells = 0, blocks = 0;
     bool is_long = false;
     if (c < n && skip_mode && skip_mode[c] == -2) { nblk[c] = 0; nblk64[c] = 0; }
@@ -704,6 +709,17 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
         blocks = nb;
         is_long = nb > nb_limit;
         atomicAdd(&lh[len_bucket(nb)], 1u);
+    }
+    if (lb_state) {
+        __shared__ uint64_t lds64[4], s_pre;
+        uint64_t tot;
+        const uint64_t ex = block_excl_scan_256<uint64_t>(blocks, &tot, lds64);
+        if (threadIdx.x < 64) {
+            const uint64_t p = lb_tile_prefix<48>(lb_state + 1, tile, tot, lb_epoch, (int)threadIdx.x);
+            if (threadIdx.x == 0) s_pre = p;
+        }
+        __syncthreads();
+        if (c <= n) dir_off[c] = s_pre + ex;                    // (entry n: the total)
     }
     const bool active = c < n && !(skip_mode && skip_mode[c] == -2);
     const int longs = __syncthreads_count(is_long);
@@ -820,12 +836,16 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     unsigned long long *cells = reinterpret_cast<unsigned long long *>(zb);
     if (d_hdr) *d_hdr = cells;
     uint32_t *len_hist = reinterpret_cast<uint32_t *>(reinterpret_cast<unsigned char *>(zb) + 64), *cursor = len_hist + LEN_BUCKETS, *order = ctx->ws[15].as<uint32_t>();
-    hipLaunchKernelGGL(sw_prep, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_cands, n, trace ? d_n : nullptr, ctx->q.len.as<const uint32_t>(),
-                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist, nb_limit, trace ? d_skip_mode : nullptr);
+    uint64_t *lb_state = nullptr, lb_epoch = 0;
+    uint32_t lb_ticket = 0;
+    const uint64_t prep_tiles = ceil_div(n + (trace ? 1 : 0), 256);        // (the traceback pass writes one entry more: the total)
+    if (trace) PEP_TRY(pep_lookback_begin(ctx, ctx->scan_state[1], prep_tiles, (1u << 14) - 1, &lb_state, &lb_ticket, &lb_epoch));
+    hipLaunchKernelGGL(sw_prep, dim3((unsigned)prep_tiles), dim3(256), 0, ctx->stream, d_cands, n, trace ? d_n : nullptr, ctx->q.len.as<const uint32_t>(),
+                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist, nb_limit, trace ? d_skip_mode : nullptr,
+                       ctx->ws[11].as<uint64_t>(), lb_state, lb_ticket, lb_epoch);
     hipLaunchKernelGGL(sw_order, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[10].as<const uint32_t>(), n, trace ? d_n : nullptr,
                        (const uint32_t *)len_hist, cursor, order, trace ? d_skip_mode : nullptr);
     if (trace) {
-        PEP_TRY(pep_scan_u64(ctx, ctx->ws[14].as<uint64_t>(), ctx->ws[11].as<uint64_t>(), n, ctx->ws[7]));
         uint64_t total_blk = dir_blocks_bound;
         if (!dir_blocks_bound) {
             // the traceback area is sized from the block total: the host has to see it before the launch

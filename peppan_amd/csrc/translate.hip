@@ -8,6 +8,7 @@
 //                code 31 between sequences, 64 at both ends).          [translation: configure.py:160-194]
 // Byte-granular, HBM-bound: 3 nt bytes read per residue byte written.
 #include "common.h"
+#include "lookback.h"
 #include <algorithm>
 
 namespace {
@@ -317,36 +318,65 @@ __global__ void k1_query_desc(uint32_t n, const uint32_t *__restrict__ frame, co
 }
 
 // reference side: the chunks of (sequence, frame) w become packed sequences first[w] .. first[w] + cnt[w] - 1
-__global__ void k1_ref_desc(uint64_t nw, int n_frames, const uint64_t *__restrict__ chunk_base, const uint32_t *__restrict__ chunk_cnt,
-                            const uint32_t *__restrict__ first, const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_len,
-                            PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, K1Summary *__restrict__ sum, uint64_t slots)
+// look-back state of a K1 kernel that scans while it works (lookback.h)
+struct K1Scan { uint64_t *state; uint32_t ticket_base; uint64_t epoch; };
+
+// the chunks of (sequence, frame) w become packed sequences first[w] .. first[w] + cnt[w] - 1, first = exclusive scan of the chunk counts -
+// taken inside this kernel (tile totals by look-back) instead of by a scan launch in front of it; *n_targets = their number
+__global__ __launch_bounds__(256) void k1_ref_desc(uint64_t nw, int n_frames, const uint64_t *__restrict__ chunk_base, const uint32_t *__restrict__ chunk_cnt,
+                                                   const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_len,
+                                                   PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, K1Summary *__restrict__ sum,
+                                                   uint32_t *__restrict__ n_targets, K1Scan sc)
 {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_tile, lds[4];
+    __shared__ uint64_t s_pre;
+    const uint32_t tile = lb_take_tile(sc.state, sc.ticket_base, &s_tile);
+    const uint64_t w = (uint64_t)tile * 256 + threadIdx.x;
     if (w == 0) { sum->residues = 0ull; sum->max_len = 0u; }
+    const uint32_t cnt = w < nw ? chunk_cnt[w] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_256<uint32_t>(cnt, &tot, lds);
+    if (threadIdx.x < 64) {
+        const uint64_t p = lb_tile_prefix<32>(sc.state + 1, tile, tot, sc.epoch, (int)threadIdx.x);
+        if (threadIdx.x == 0) s_pre = p;
+    }
+    __syncthreads();
+    if (tile == gridDim.x - 1 && threadIdx.x == 255) *n_targets = (uint32_t)(s_pre + tot);
     if (w >= nw) return;
-    // the slots behind the last packed sequence count as empty in the layout scan (this used to be a fill of the whole array in front of the chain)
-    for (uint64_t x = (uint64_t)first[nw] + w; x <= slots; x += nw) padded[x] = 0u;
     const uint32_t g = (uint32_t)(w / n_frames), f = (uint32_t)(w % n_frames) + 1;
     const uint64_t base = chunk_base[w];
-    const uint32_t at = first[w];
-    for (uint32_t c = 0; c < chunk_cnt[w]; ++c) {
+    const uint32_t at = (uint32_t)s_pre + ex;
+    for (uint32_t c = 0; c < cnt; ++c) {
         desc[at + c] = PackDesc{g, f, chunk_off[base + c], chunk_len[base + c]};
         padded[at + c] = padded_len(chunk_len[base + c]);
         len_out[at + c] = chunk_len[base + c];
     }
 }
 
-// pk_off[i] = start of packed sequence i; entries n .. cap hold the layout's total size (sentinel of the owner search).
+// pk_off[i] = start of packed sequence i = END_PAD + exclusive scan of the padded lengths (taken inside this kernel by look-back; slots behind
+// the last sequence count as empty); entries n .. cap hold the layout's total size (sentinel of the owner search).
 // Also the set's summary: number of sequences, layout size, residues, longest sequence.
-__global__ void k1_offsets(const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ scan, uint32_t cap, uint32_t *__restrict__ pk_off,
-                           const uint32_t *__restrict__ len, K1Summary *__restrict__ sum)
+__global__ __launch_bounds__(256) void k1_offsets(const uint32_t *__restrict__ n_ptr, const uint32_t *__restrict__ padded, uint32_t cap, uint32_t *__restrict__ pk_off,
+                                                  const uint32_t *__restrict__ len, K1Summary *__restrict__ sum, K1Scan sc)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n = *n_ptr;
-    if (i <= cap) pk_off[i] = i < n ? scan[i] + PEP_END_PAD : scan[cap] + 2 * PEP_END_PAD;
-    // residues and longest sequence: one pair of atomics per block (a thousand wavefronts adding to the same two words took 18 us)
+    __shared__ uint32_t s_tile, lds[4];
+    __shared__ uint64_t s_pre;
     __shared__ unsigned long long blk_s[4];
     __shared__ uint32_t blk_m[4];
+    const uint32_t tile = lb_take_tile(sc.state, sc.ticket_base, &s_tile);
+    const uint32_t i = tile * 256 + threadIdx.x;
+    const uint32_t n = *n_ptr;
+    const uint32_t pad = i < n ? padded[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_256<uint32_t>(pad, &tot, lds);
+    if (threadIdx.x < 64) {
+        const uint64_t p = lb_tile_prefix<32>(sc.state + 1, tile, tot, sc.epoch, (int)threadIdx.x);
+        if (threadIdx.x == 0) s_pre = p;
+    }
+    __syncthreads();
+    const uint32_t at = (uint32_t)s_pre + ex;                // padded bytes in front of slot i (behind the last sequence: all of them)
+    if (i <= cap) pk_off[i] = i < n ? at + PEP_END_PAD : at + 2 * PEP_END_PAD;
+    // residues and longest sequence: one pair of atomics per block (a thousand wavefronts adding to the same two words took 18 us)
     uint32_t L = i < n ? len[i] : 0u, m = L;
     unsigned long long s = L;
     for (int d = 32; d > 0; d >>= 1) { s += __shfl_xor(s, d, 64); m = max(m, (uint32_t)__shfl_xor((int)m, d, 64)); }
@@ -356,7 +386,7 @@ __global__ void k1_offsets(const uint32_t *__restrict__ n_ptr, const uint32_t *_
         const uint32_t bm = max(max(blk_m[0], blk_m[1]), max(blk_m[2], blk_m[3]));
         if (bm) { atomicAdd(&sum->residues, blk_s[0] + blk_s[1] + blk_s[2] + blk_s[3]); atomicMax(&sum->max_len, bm); }
     }
-    if (i == 0) { sum->n = n; sum->total = (unsigned long long)scan[cap] + 2ull * PEP_END_PAD; }
+    if (i == cap) { sum->n = n; sum->total = (unsigned long long)at + 2ull * PEP_END_PAD; }
 }
 
 int reserve_packed(pep_ctx *ctx, SeqSet &out, uint32_t cap, uint64_t upper)
@@ -374,11 +404,12 @@ int reserve_packed(pep_ctx *ctx, SeqSet &out, uint32_t cap, uint64_t upper)
 int layout_and_pack(pep_ctx *ctx, const NtSet &nt, int tab, const PackDesc *d_desc, const uint32_t *d_padded, uint32_t cap, const uint32_t *d_n,
                     uint64_t upper, SeqSet &out, DevBuf &d_scan, DevBuf &tmp, K1Summary *pin_sum)
 {
-    PEP_TRY(dev_reserve(ctx, d_scan, ((size_t)cap + 2) * 4));
-    PEP_TRY(pep_scan_u32(ctx, d_padded, d_scan.as<uint32_t>(), cap, tmp));
-    K1Summary *d_sum = reinterpret_cast<K1Summary *>(const_cast<PackDesc *>(d_desc) + cap);        // behind the descriptors: one download brings both
-    hipLaunchKernelGGL(k1_offsets, dim3((unsigned)ceil_div((uint64_t)cap + 1, 256)), dim3(256), 0, ctx->stream, d_n, d_scan.as<const uint32_t>(), cap, out.off.as<uint32_t>(),
-                       out.len.as<const uint32_t>(), d_sum);
+    (void)d_scan; (void)tmp;
+    K1Summary *d_sum = reinterpret_cast<K1Summary *>(const_cast<PackDesc *>(d_desc) + cap);        // behind the descriptors
+    K1Scan sc;
+    const uint64_t tiles = ceil_div((uint64_t)cap + 1, 256);
+    PEP_TRY(pep_lookback_begin(ctx, ctx->scan_state[0], tiles, (1u << 30) - 1, &sc.state, &sc.ticket_base, &sc.epoch));
+    hipLaunchKernelGGL(k1_offsets, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, d_n, d_padded, cap, out.off.as<uint32_t>(), out.len.as<const uint32_t>(), d_sum, sc);
     hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div((uint64_t)cap + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
                        d_desc, out.off.as<const uint32_t>(), d_n, cap, out.res.as<uint8_t>(), out.blk2seq.as<uint2>(), (const K1Summary *)d_sum, pin_sum);
     PEP_HIP(ctx, hipGetLastError());
@@ -542,10 +573,14 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     if (nw) {
         hipLaunchKernelGGL(k1_ref_chunks, dim3((unsigned)ceil_div(nw, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, nf, tab,
                            d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>());
-        PEP_TRY(pep_scan_u32(ctx, W[1].as<const uint32_t>(), W[5].as<uint32_t>(), nw, W[8]));          // W[5][nw] = number of targets
-        hipLaunchKernelGGL(k1_ref_desc, dim3((unsigned)ceil_div(nw, 256)), dim3(256), 0, ctx->stream, nw, nf, d_base, W[1].as<const uint32_t>(),
-                           W[5].as<const uint32_t>(), W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), D.as<PackDesc>(), W[6].as<uint32_t>(),
-                           ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + slots), slots);
+        {
+            K1Scan sc;
+            const uint64_t tiles = ceil_div(nw, 256);
+            PEP_TRY(pep_lookback_begin(ctx, ctx->scan_state[0], tiles, (1u << 30) - 1, &sc.state, &sc.ticket_base, &sc.epoch));
+            hipLaunchKernelGGL(k1_ref_desc, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, nw, nf, d_base, W[1].as<const uint32_t>(),
+                               W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), D.as<PackDesc>(), W[6].as<uint32_t>(),
+                               ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + slots), W[5].as<uint32_t>() + nw, sc);         // W[5][nw] = number of targets
+        }
         PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
                                 W[7], W[8], pin_sum));
     } else {
