@@ -95,6 +95,18 @@ int pep_read_back(pep_ctx *ctx, void *dst, const void *d_src, size_t n)
     return PEP_OK;
 }
 
+int pep_read_back_with_upload(pep_ctx *ctx, void *dst, const void *d_src, size_t n, void *d_up_dst, const void *pinned_up_src, uint64_t n_up_words)
+{
+    const size_t n8 = (n + 7) & ~size_t(7);
+    if (n % 4) return pep_fail(ctx, PEP_ERR_INTERNAL, "pep_read_back_with_upload: size not a multiple of 4");
+    if (ctx->n_pending >= 32 || ctx->pin_small_used + n8 > ctx->pin_small.cap) PEP_TRY(pep_sync_reads(ctx));
+    if (n8 > ctx->pin_small.cap) return pep_fail(ctx, PEP_ERR_INTERNAL, "pep_read_back: value larger than the pinned page");
+    PEP_TRY(pep_exchange_pinned(ctx, d_up_dst, pinned_up_src, n_up_words, ctx->pin_small.p + ctx->pin_small_used, d_src, n / 4));
+    ctx->pending[ctx->n_pending++] = pep_ctx::PendingRead{dst, ctx->pin_small_used, n};
+    ctx->pin_small_used += n8;
+    return PEP_OK;
+}
+
 hipError_t pep_event_wait(hipEvent_t ev)
 {
     static const long spin_us = [] { const char *e = getenv("PEPPAN_HIP_SPIN_US"); return e ? atol(e) : 1500L; }();
@@ -684,7 +696,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
             }
             ms[i] = memo_val[slot];
         }
-        PEP_TRY(pep_copy_from_pinned(c, c->d_min_score.p, c->pin_ms.p, c->q.n));
+        c->upload.d_dst = c->d_min_score.p; c->upload.pinned_src = c->pin_ms.p; c->upload.n_words = c->q.n;      // (rides on the seed stage's read-back kernel)
         return PEP_OK;
     };
     int rc = pep_find_candidates(ctx, &d_cands, &n_cands, prepare_thresholds, finish_targets);

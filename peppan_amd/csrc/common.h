@@ -137,6 +137,7 @@ struct pep_ctx {
     std::vector<uint32_t> uf_nodes_host;
     struct { bool pending = false; pep_result *res = nullptr; const void *d_hits = nullptr, *d_cig = nullptr; const uint32_t *d_n_hits = nullptr; uint64_t n_bound = 0; } ext;
                                             // a search whose result left through pack_out and whose host half (sizes, statistics, views) is still to be done (pep_extend_finish)
+    struct { void *d_dst = nullptr; const void *pinned_src = nullptr; uint64_t n_words = 0; } upload;   // an upload out of pinned memory that rides on the next read-back kernel
     uint32_t grp_nodes = 0, grp_q_base = 0;  // pep_set_grouping: the searches of this context end with K10 over their own hit table (0 = off)
     bool device_results = false;            // pep_set_result_mode: searches leave their table on the device; the host copy is fetched on demand
     pep_result *dev_result = nullptr;       // the result whose hit table is still intact on the device (ws[23]): the newest search's, until the workspace is reused
@@ -232,6 +233,9 @@ int pep_zero_block(pep_ctx *ctx, int which, size_t offset, size_t bytes, void **
 int pep_scan_u32(pep_ctx *ctx, const uint32_t *d_in, uint32_t *d_out, uint64_t n, DevBuf &tmp, uint32_t *d_total = nullptr);
 int pep_scan_u64(pep_ctx *ctx, const uint64_t *d_in, uint64_t *d_out, uint64_t n, DevBuf &tmp, uint64_t *d_total = nullptr);
 int pep_copy_from_pinned(pep_ctx *ctx, void *d_dst, const void *pinned_src, uint64_t n_words);     // a kernel instead of a copy command (scan.hip)
+int pep_exchange_pinned(pep_ctx *ctx, void *d_up_dst, const void *pinned_up_src, uint64_t n_up_words, void *pinned_down_dst, const void *d_down_src, uint64_t n_down_words);
+// pep_read_back through a kernel that also carries an upload out of pinned memory (one launch for both directions; n a multiple of 4)
+int pep_read_back_with_upload(pep_ctx *ctx, void *dst, const void *d_src, size_t n, void *d_up_dst, const void *pinned_up_src, uint64_t n_up_words);
 // ---- sort.hip
 // the dense candidate-key form q | t | bin - bin_min (tb / bb bits for t / bin) <-> q:21 | t:25 | bin:18 (seeds.hip); on = 0: keys pass unchanged
 struct pep_key_unpack { int on, tb, bb; uint32_t bin_min; };

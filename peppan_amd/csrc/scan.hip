@@ -234,6 +234,27 @@ __global__ __launch_bounds__(256) void copy_words(uint32_t *__restrict__ dst, co
 }
 }  // namespace
 
+// both directions in one launch: n_up words from pinned host memory into device memory, n_down words from device memory into pinned host memory
+namespace {
+__global__ __launch_bounds__(256) void exchange_words(uint32_t *__restrict__ up_dst, const uint32_t *__restrict__ up_src, uint64_t n_up,
+                                                      uint32_t *__restrict__ down_dst, const uint32_t *__restrict__ down_src, uint64_t n_down)
+{
+    const uint64_t t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+    for (uint64_t i = t0; i < n_up; i += stride) up_dst[i] = up_src[i];
+    for (uint64_t i = t0; i < n_down; i += stride) down_dst[i] = down_src[i];
+}
+}  // namespace
+
+int pep_exchange_pinned(pep_ctx *ctx, void *d_up_dst, const void *pinned_up_src, uint64_t n_up_words, void *pinned_down_dst, const void *d_down_src, uint64_t n_down_words)
+{
+    if (n_up_words + n_down_words == 0) return PEP_OK;
+    hipLaunchKernelGGL(exchange_words, dim3((unsigned)std::min<uint64_t>(ceil_div(std::max(n_up_words, n_down_words), 256), 1024)), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<uint32_t *>(d_up_dst), reinterpret_cast<const uint32_t *>(pinned_up_src), n_up_words,
+                       reinterpret_cast<uint32_t *>(pinned_down_dst), reinterpret_cast<const uint32_t *>(d_down_src), n_down_words);
+    PEP_HIP(ctx, hipGetLastError());
+    return PEP_OK;
+}
+
 int pep_copy_from_pinned(pep_ctx *ctx, void *d_dst, const void *pinned_src, uint64_t n_words)
 {
     if (n_words == 0) return PEP_OK;

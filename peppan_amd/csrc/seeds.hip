@@ -711,7 +711,9 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
     ctx->stats.query_seeds = ctx->stats.target_seeds = ctx->stats.seed_hits = 0;
     if (Q.n == 0) {
         if (need_targets) PEP_TRY(need_targets(ctx));
-        return before_sync ? before_sync(ctx) : PEP_OK;
+        if (before_sync) PEP_TRY(before_sync(ctx));
+        ctx->upload.n_words = 0;                               // (nothing to align: the thresholds are not needed)
+        return PEP_OK;
     }
 
     // two buckets per query position, except that up to 40 M positions stay at 2^25 buckets (the average coarse bucket then holds 4 900
@@ -814,7 +816,11 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
                 // everything about the targets from here on
                 if (need_targets) { PEP_TRY(need_targets(ctx)); need_targets = nullptr; }
                 if (T.total > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "more than 2^29 packed residues on one side");
-                if (T.n == 0) return before_sync ? before_sync(ctx) : PEP_OK;             // (the index kernels queued so far are harmless)
+                if (T.n == 0) {                                                          // (the index kernels queued so far are harmless)
+                    if (before_sync) PEP_TRY(before_sync(ctx));
+                    ctx->upload.n_words = 0;
+                    return PEP_OK;
+                }
                 if (hit_cap == 0) hit_cap = std::max<uint64_t>(1ull << 22, 2 * T.total);
                 PEP_TRY(dev_reserve(ctx, ctx->ws[8], hit_cap * sizeof(uint64_t)));
                 PEP_TRY(dev_reserve(ctx, ctx->ws[10], hit_cap * 8));          // runs of equal candidate keys: first hit, key, length
@@ -854,8 +860,10 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
         struct { uint32_t counters[4]; unsigned long long stats[3]; uint32_t n_entries[4]; uint32_t pad[2]; uint32_t top[1 << PEP_SORT_TOP_BITS]; } h_all;
         // counters[0..3], the three statistics words, the index sizes per shape and the top-digit histogram of the candidate keys: one copy
         static_assert(sizeof(h_all) == 64 + 4096 && PEP_ZERO_TOP == PEP_ZERO_SEED + 64, "layout of the counter block");
-        PEP_TRY(pep_read_back(ctx, &h_all, counters, sizeof(h_all)));
         if (before_sync) { PEP_TRY(before_sync(ctx)); before_sync = nullptr; }      // (once, also when the stage is repeated with larger buffers)
+        // the counters go to the host and whatever before_sync wants on the device (the score thresholds) comes up, in ONE kernel over pinned memory
+        PEP_TRY(pep_read_back_with_upload(ctx, &h_all, counters, sizeof(h_all), ctx->upload.d_dst, ctx->upload.pinned_src, ctx->upload.n_words));
+        ctx->upload.n_words = 0;
         PEP_TRY(pep_sync_reads(ctx));
         const uint32_t *h_counters = h_all.counters;
         const unsigned long long *h_stats = h_all.stats;
