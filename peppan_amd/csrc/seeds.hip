@@ -462,17 +462,25 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
                 if (a.debug == 2) { n_hit += e1 - e0; e1 = e0; }
             }
         }
-        for (uint32_t e = e0; e < e1; ++e) {
-            const uint64_t ent = a.entries[e];
-            if ((ent >> POS_BITS) != key) continue;
-            ++n_hit;
-            if (a.debug == 3) continue;
-            const uint64_t hit = ((ent & POS_MASK) << 32) | p;
-            const uint32_t idx = atomicAdd(&nbuf, 1u);
-            if (idx < HIT_BUF) buf[idx] = hit;
-            else {                                   // staging buffer full: rare direct append
-                const unsigned long long g = atomicAdd(a.hit_count, 1ull);
-                if (g < a.hit_cap) a.hits[g] = hit; else a.counters[2] = 1u;
+        // two entries per trip (one unaligned 16-byte load): a bucket that holds the key usually holds one to four entries - the members of a
+        // gene family - and every trip of this loop is a dependent round trip to the L2 (the entry behind the bucket's last one is read and
+        // ignored; the array has a spare slot)
+        for (uint32_t e = e0; e < e1; e += 2) {
+            uint64_t pair[2];
+            __builtin_memcpy(pair, a.entries + e, 16);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint64_t ent = pair[k];
+                if (e + k >= e1 || (ent >> POS_BITS) != key) continue;
+                ++n_hit;
+                if (a.debug == 3) continue;
+                const uint64_t hit = ((ent & POS_MASK) << 32) | p;
+                const uint32_t idx = atomicAdd(&nbuf, 1u);
+                if (idx < HIT_BUF) buf[idx] = hit;
+                else {                                   // staging buffer full: rare direct append
+                    const unsigned long long g = atomicAdd(a.hit_count, 1ull);
+                    if (g < a.hit_cap) a.hits[g] = hit; else a.counters[2] = 1u;
+                }
             }
         }
         __syncthreads();
