@@ -135,13 +135,16 @@ struct pep_ctx {
     uint64_t set_clean_slots = 0;           // leading slots of d_set known to be EMPTY (0 while a search is using it)
     DevBuf uf_nodes;                        // K10 over a device-resident hit table: node of every target (uploaded when it changes)
     std::vector<uint32_t> uf_nodes_host;
-    struct { bool pending = false; pep_result *res = nullptr; const void *d_hits = nullptr, *d_cig = nullptr; const uint32_t *d_n_hits = nullptr; uint64_t n_bound = 0; } ext;
+    struct { bool pending = false; pep_result *res = nullptr; const void *d_hits = nullptr, *d_cig = nullptr; const uint32_t *d_n_hits = nullptr; uint64_t n_bound = 0; bool parent_ready = false; } ext;
                                             // a search whose result left through pack_out and whose host half (sizes, statistics, views) is still to be done (pep_extend_finish)
     struct { void *d_dst = nullptr; const void *pinned_src = nullptr; uint64_t n_words = 0; } upload;   // an upload out of pinned memory that rides on the next read-back kernel
     uint32_t grp_nodes = 0, grp_q_base = 0;  // pep_set_grouping: the searches of this context end with K10 over their own hit table (0 = off)
     bool device_results = false;            // pep_set_result_mode: searches leave their table on the device; the host copy is fetched on demand
     pep_result *dev_result = nullptr;       // the result whose hit table is still intact on the device (ws[23]): the newest search's, until the workspace is reused
     DevBuf d_zero;                          // the small counters of one search, cleared by ONE fill when it starts (layout: PEP_ZERO_* below)
+    bool zero_clean = false;                // the seed stage's part of d_zero is zero as of the end of what is queued (pack_out cleared all of d_zero): with every
+                                            // zero_ok flag still set the next search needs no fill
+    DevBuf d_mail_copy;                     // the alignment stage's counter block outside d_zero (trace.hip: emit -> pack_out, K10)
     bool zero_ok[4] = {false, false, false, false};     // which consumer regions of d_zero are still untouched since that fill (PEP_ZC_*)
     // stats of the last search
     pep_stats stats;

@@ -766,7 +766,11 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
         PEP_TRY(dev_reserve(ctx, ctx->ws[4], (uint64_t)list_cap * sizeof(uint64_t)));
         PEP_TRY(dev_reserve(ctx, ctx->ws[5], (uint64_t)list_cap * sizeof(uint64_t)));
         // ONE fill for every small counter block of the search (seed stage, candidate sort, both Smith-Waterman passes, selection)
-        PEP_HIP(ctx, hipMemsetAsync(zero, 0, PEP_ZERO_TOTAL, ctx->stream));
+        // (not even that when the previous search's last kernel has left all of them cleared and nothing has touched them since)
+        bool all_ok = ctx->zero_clean;
+        for (bool f : ctx->zero_ok) all_ok = all_ok && f;
+        if (!all_ok) PEP_HIP(ctx, hipMemsetAsync(zero, 0, PEP_ZERO_TOTAL, ctx->stream));
+        ctx->zero_clean = false;
         for (bool &f : ctx->zero_ok) f = true;
         uint64_t q_seeds = 0;
         for (int s = 0; s < P.n_shapes; ++s) {

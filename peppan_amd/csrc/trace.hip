@@ -424,10 +424,14 @@ __global__ __launch_bounds__(256) void emit(const uint32_t *__restrict__ d_n_sel
                                             const uint32_t *__restrict__ keep_flag, const uint32_t *__restrict__ hit_pos, const uint64_t *__restrict__ cig_pos,
                                             const uint64_t *__restrict__ run_off, const uint32_t *__restrict__ runs, const uint32_t *__restrict__ nblk,
                                             const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len,
-                                            pep_hit *__restrict__ hits, uint32_t *__restrict__ cigar)
+                                            pep_hit *__restrict__ hits, uint32_t *__restrict__ cigar,
+                                            const unsigned long long *__restrict__ mail = nullptr, unsigned long long *__restrict__ mail_copy = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the counter block of the stage (final since topk) once more, outside the search's zeroed region: pack_out and K10 read it there, so that
+    // pack_out may clear that region for the next search
+    if (mail_copy && blockIdx.x == 0 && threadIdx.x < 9) mail_copy[threadIdx.x] = mail[threadIdx.x];
     if (s >= *d_n_sel || !keep_flag[s]) return;
     const SelInfo info = sel[s];
     const uint64_t key = cands[info.cand];
@@ -460,9 +464,14 @@ __global__ __launch_bounds__(256) void emit(const uint32_t *__restrict__ d_n_sel
 // small (the first search of a context, a result that grew) gets the header only, with the overflow word set: the host then sizes it
 // and copies the classic way.
 constexpr size_t PACK_HEADER = 128;
+// Two chores ride along (a launch of their own costs 4 - 5 us each): the counters of the NEXT search are cleared (zero_words: the region every
+// search needs zeroed - this is its last reader), and the union-find that follows gets its parent array initialised (iota).
 __global__ __launch_bounds__(256) void pack_out(const unsigned long long *__restrict__ mail, const pep_hit *__restrict__ hits, const uint32_t *__restrict__ cigar,
-                                                unsigned char *__restrict__ pinned, unsigned long long cap)
+                                                unsigned char *__restrict__ pinned, unsigned long long cap, uint32_t *__restrict__ zero_words, uint32_t n_zero_words,
+                                                uint32_t *__restrict__ iota, uint32_t n_iota)
 {
+    for (uint32_t x = blockIdx.x * 256 + threadIdx.x; x < n_zero_words; x += gridDim.x * 256) zero_words[x] = 0u;
+    for (uint32_t x = blockIdx.x * 256 + threadIdx.x; x < n_iota; x += gridDim.x * 256) iota[x] = x;
     const uint32_t n_hits = reinterpret_cast<const uint32_t *>(mail)[2];
     const unsigned long long n_cig = mail[2];
     const bool fits = PACK_HEADER + (unsigned long long)n_hits * sizeof(pep_hit) + n_cig * 4 <= cap;
@@ -656,14 +665,22 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
             PEP_TRY(dev_reserve(ctx, ctx->ws[23], hb_bound + (run_bound + 1) * 4));
             pep_hit *d_hits = ctx->ws[23].as<pep_hit>();
             uint32_t *d_cig = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ctx->ws[23].p) + hb_bound);
+            PEP_TRY(dev_reserve(ctx, ctx->d_mail_copy, 128));
+            unsigned long long *mail_copy = ctx->d_mail_copy.as<unsigned long long>();
+            uint32_t *parent = nullptr;
+            if (ctx->grp_nodes) { PEP_TRY(dev_reserve(ctx, ctx->ws[0], (size_t)ctx->grp_nodes * 4)); parent = ctx->ws[0].as<uint32_t>(); }      // (K10 follows: pep_k10_queue)
             hipLaunchKernelGGL(emit, dim3((unsigned)ceil_div(n_b, 4)), dim3(256), 0, st, d_n_sel, (const SelInfo *)sel, (const uint64_t *)sel_keys, (const uint32_t *)keep_flag,
                                (const uint32_t *)hit_pos, (const uint64_t *)cig_pos, (const uint64_t *)run_off, (const uint32_t *)runs,
-                               ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig);
-            hipLaunchKernelGGL(pack_out, dim3(1024), dim3(256), 0, st, (const unsigned long long *)mail, (const pep_hit *)d_hits, (const uint32_t *)d_cig,
-                               ctx->pin_stage.p, (unsigned long long)ctx->pin_stage.cap);
+                               ctx->ws[10].as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), d_hits, d_cig,
+                               (const unsigned long long *)mail, mail_copy);
+            hipLaunchKernelGGL(pack_out, dim3(1024), dim3(256), 0, st, (const unsigned long long *)mail_copy, (const pep_hit *)d_hits, (const uint32_t *)d_cig,
+                               ctx->pin_stage.p, (unsigned long long)ctx->pin_stage.cap, ctx->d_zero.as<uint32_t>(), (uint32_t)(PEP_ZERO_TOTAL / 4), parent, ctx->grp_nodes);
             PEP_HIP(ctx, hipGetLastError());
             ctx->ext.pending = true; ctx->ext.res = res; ctx->ext.d_hits = d_hits; ctx->ext.d_cig = d_cig;
-            ctx->ext.d_n_hits = counters + 2; ctx->ext.n_bound = n_b;
+            ctx->ext.d_n_hits = reinterpret_cast<const uint32_t *>(mail_copy) + 2; ctx->ext.n_bound = n_b;
+            ctx->ext.parent_ready = parent != nullptr;
+            for (bool &f : ctx->zero_ok) f = true;   // as of this point of the stream every counter block is zero again (pack_out): whatever is queued
+            ctx->zero_clean = true;                  // behind it - the next search, K9's alignment stage - needs no fill
             pep_timer_end(ctx, TM_TRACE);
             if (defer) return PEP_OK;
             PEP_HIP(ctx, pep_stream_wait(ctx));

@@ -137,7 +137,8 @@ int pep_k10_queue(pep_ctx *ctx, uint64_t n_hits, const pep_hit *d_hits, const ui
     PEP_TRY(dev_reserve(ctx, ctx->ws[0], (size_t)n_nodes * 4));
     PEP_TRY(pin_reserve(ctx, ctx->pin_labels, (size_t)n_nodes * 4));
     uint32_t *parent = ctx->ws[0].as<uint32_t>();
-    hipLaunchKernelGGL(uf_init, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, n_nodes);
+    if (!(ctx->ext.pending && ctx->ext.parent_ready))          // (pack_out has initialised the parents on its way)
+        hipLaunchKernelGGL(uf_init, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, n_nodes);
     if (n_hits) hipLaunchKernelGGL(uf_union_hits, dim3((unsigned)ceil_div(n_hits, 256)), dim3(256), 0, ctx->stream, parent, d_hits, n_hits, ctx->grp_q_base, ctx->uf_nodes.as<const uint32_t>(), d_n_hits);
     hipLaunchKernelGGL(uf_flatten, dim3((unsigned)ceil_div(n_nodes, 256)), dim3(256), 0, ctx->stream, parent, reinterpret_cast<uint32_t *>(ctx->pin_labels.p), n_nodes);
     PEP_HIP(ctx, hipGetLastError());
