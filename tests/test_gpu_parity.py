@@ -1301,3 +1301,33 @@ def test_alignment_stage_without_host_round_trips_equals_exactly_sized_stage(ctx
     ta, to = ctx.target_aa()
     oh, oc, ost = O.search([qa[qo[i]:qo[i + 1]] for i in range(len(qo) - 1)], [ta[to[i]:to[i + 1]] for i in range(len(to) - 1)], O.default_params(45., 25., 10, 5))
     _cmp_hits(np.frombuffer(out[0][0], dtype=N.HIT_DTYPE), np.frombuffer(out[0][1], dtype=np.uint32), oh, oc)
+
+
+def test_candidate_sort_two_level_and_fallback(ctx):
+    """the candidate list is sorted in two levels (top 10 bits of the key, then every bucket inside LDS) unless a bucket holds more than
+    4 096 keys - then by four LSD passes; which one runs is decided from a histogram that set_compact computes.  A reference in which one
+    query family has 6 000 members overflows its bucket; a plain family set does not; both tables equal the oracle's, and params.reserved[2]
+    (LSD path forced) changes nothing"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(12)
+    base = synth.make_proteins(24, length=(150, 260), seed=31, family=1, sub=0.)
+    crowd = []
+    for k in range(6000):                                  # 6 000 mutants of protein 0: one query, thousands of candidates
+        p = base[0].copy()
+        idx = rng.integers(0, len(p), 6)
+        p[idx] = rng.integers(0, 20, 6).astype(np.uint8)
+        crowd.append(p)
+    for qs, ts, top_k in ((base, crowd + base, 50), (base, base, 10)):
+        ctx.set_query_aa(qs); ctx.set_ref_aa(ts)
+        out = []
+        for forced in (0, 1):
+            p = N.default_params(30., 10., top_k, 5)
+            p.reserved[2] = forced
+            h, c, st = ctx.search(p)
+            out.append((h.tobytes(), c.tobytes(), st['candidates'], st['pairs'], st['tracebacks']))
+        assert out[0] == out[1]
+        oh, oc, ost = O.search(qs, ts, O.default_params(30., 10., top_k, 5))
+        _cmp_hits(np.frombuffer(out[0][0], dtype=N.HIT_DTYPE), np.frombuffer(out[0][1], dtype=np.uint32), oh, oc)
+        assert out[0][2] == ost['candidates']
+    assert ost['candidates'] < 4096
