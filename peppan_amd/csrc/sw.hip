@@ -49,6 +49,7 @@ struct SwArgs {
     const uint32_t *order;         // candidates by decreasing length (sw_order): item w of a launch is order[w] (order[2w], order[2w+1] packed)
     const int32_t *end_lane;       // traceback pass: per candidate the lowest lane (diagonal pair) of the score pass that reached the score
     int32_t *mode;                 // traceback pass, out: first lane L0 of the 64-diagonal sub-band the codes were written for, -1 = the full band
+    int split_long;                // the pairs whose windows do not fit the staging area have a launch of their own (sw_*_kernel<true>: packed sweep in chunks of blocks)
     unsigned long long *counts;    // traceback pass: the pass's counter block, filled by sw_prep - [3] candidates too long for the four-candidate sweep (a prefix of
                                    // the order), [5] candidates in the order; [2] and [4] are the work queues of the two parts (the resident wavefronts pull their items from them)
 };
@@ -282,29 +283,26 @@ __device__ __forceinline__ CandGeom cand_geom(const SwArgs &a, uint64_t c)
 
 __device__ __forceinline__ bool fits16(const CandGeom &g, int max_sub) { return min(g.Lq, g.Lt) * max_sub + 64 + PK_BIAS < 32767; }
 
-__device__ __forceinline__ void stage_windows(const CandGeom &g, int nb, uint16_t *lq, uint16_t *lt, int lane)
+// the window entries that blocks [b0, b1) of a sweep read (8 per block + 72 of overlap / slack), stored from index 0: a pair whose windows do not
+// fit the staging area is swept in chunks of blocks, each staged on its own (the DP state stays in registers across chunks)
+__device__ __forceinline__ void stage_windows(const CandGeom &g, int b0, int b1, uint16_t *lq, uint16_t *lt, int lane)
 {
-    const int qlo = g.a0 - 64, tlo = g.a0 + g.dlo - 1, n = 8 * nb + 72;
+    const int qlo = g.a0 - 64 + 8 * b0, tlo = g.a0 + g.dlo - 1 + 8 * b0, n = 8 * (b1 - b0) + 72;
     for (int x = lane; x < n; x += 64) { const int p = qlo + x; lq[x] = q_addr_part(((unsigned)p < (unsigned)g.Lq) ? g.qg[p] : PEP_PAD_CODE); }
     for (int x = lane; x < n; x += 64) { const int p = tlo + x; lt[x] = t_addr_part(((unsigned)p < (unsigned)g.Lt) ? g.tg[p] : PEP_PAD_CODE); }
 }
 
+template <bool CHUNKED>          // false: the windows of the whole pair fit the staging area (one staging, the loop nest of the short pairs untouched)
 __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64_t c1, const CandGeom &g0, const CandGeom &g1,
                                             const unsigned char *lds_tab, uint16_t *lds_res, int lane)
 {
     const int nb = max(g0.nblk, g1.nblk);
-    const int win = (8 * nb + 80 + 7) & ~7;
+    // blocks per staging chunk: four windows of 8 * blocks + 80 entries in the wavefront's staging area (nucleotide pairs of 1 000 bases have
+    // 125 blocks and used to miss the packed sweep by seven: they went through the 32-bit one-candidate sweep at half the speed)
+    const int chunk = CHUNKED ? max(1, min(nb, (a.lds_res_bytes / 8 - 80) / 8)) : nb;
+    const int win = (8 * chunk + 80 + 7) & ~7;
     uint16_t *q0 = lds_res, *t0 = q0 + win, *q1 = t0 + win, *t1 = q1 + win;
-    stage_windows(g0, nb, q0, t0, lane);
-    stage_windows(g1, nb, q1, t1, lane);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    // per-lane read cursors: the A cell of step pair m is (a0 + m - lane, a0 + dlo + m + lane); window origins a0-64 / a0+dlo-1
-    // explicit LDS address space: through a generic volatile pointer hipcc emits flat_load_ushort instead of ds_read_u16
     typedef const volatile __attribute__((address_space(3))) uint16_t lds_cu16;
-    lds_cu16 *vq0 = (lds_cu16 *)(q0 + (64 - lane)), *vt0 = (lds_cu16 *)(t0 + (1 + lane));
-    lds_cu16 *vq1 = (lds_cu16 *)(q1 + (64 - lane)), *vt1 = (lds_cu16 *)(t1 + (1 + lane));
     const uint32_t tab = (uint32_t)(uintptr_t)(lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
     // every H / E / F below is the true value + PK_BIAS (the recurrences are shift-invariant; the floor 0 becomes PK_BIAS; band-edge
     // lanes read 0 = -PK_BIAS, still "never selected")
@@ -314,10 +312,26 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
     // one subtraction moves to the single place where max(E, F) meets H - one instruction less per step.  Every POSITIVE E / F (the
     // only ones that can reach H >= 0) is the same as in the plain recurrence.
     s16x2 HA = zero, EA = zero, FA = zero, HB = zero, EB = zero, FB = zero, best = zero;
+    int cb = 0;
+    do {
+    const int ce = CHUNKED ? min(nb, cb + chunk) : nb;
+    if (CHUNKED && cb) {                            // every lane is done with the windows of the chunk before
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    stage_windows(g0, cb, ce, q0, t0, lane);
+    stage_windows(g1, cb, ce, q1, t1, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // per-lane read cursors: the A cell of step pair m is (a0 + m - lane, a0 + dlo + m + lane); window origins a0-64 / a0+dlo-1
+    // explicit LDS address space: through a generic volatile pointer hipcc emits flat_load_ushort instead of ds_read_u16
+    lds_cu16 *vq0 = (lds_cu16 *)(q0 + (64 - lane)), *vt0 = (lds_cu16 *)(t0 + (1 + lane));
+    lds_cu16 *vq1 = (lds_cu16 *)(q1 + (64 - lane)), *vt1 = (lds_cu16 *)(t1 + (1 + lane));
     // the residue cursors run one step ahead of the table look-ups: the reads for the next step are issued right behind the two table
     // reads of this one, and the single s_waitcnt of diag_finish covers all four (the windows are staged with 8 entries of slack)
     int tv0 = vt0[0], tv1 = vt1[0], qv0 = vq0[0], qv1 = vq1[0];
-    for (int b = 0; b < nb; ++b) {
+    for (int b = cb; b < ce; ++b) {
 #pragma unroll 1
         for (int half = 0; half < 2; ++half, vq0 += 4, vq1 += 4, vt0 += 4, vt1 += 4)
 #pragma unroll
@@ -352,6 +366,8 @@ __device__ __forceinline__ void sw_two_pk16(const SwArgs &a, uint64_t c0, uint64
             tv0 = tn0; tv1 = tn1; qv0 = qn0; qv1 = qn1;
         }
     }
+    cb = ce;
+    } while (CHUNKED && cb < nb);
     int b0 = best.x - PK_BIAS, b1 = best.y - PK_BIAS;
     const int m0 = b0, m1 = b1;
 #pragma unroll
@@ -426,9 +442,10 @@ __device__ __forceinline__ SubGeom sub_geom(const CandGeom &g, int L0)
     band_geom(g.Lq, g.Lt, s.dlo, 2 * SUB_LANES, s.a0, s.nblk);
     return s;
 }
-__device__ __forceinline__ void stage_sub_windows(const SubGeom &g, int nb, uint16_t *lq, uint16_t *lt, int lane)
+// (the entries that blocks [b0, b1) read, stored from index 0: long pairs are swept in chunks of blocks, see stage_windows)
+__device__ __forceinline__ void stage_sub_windows(const SubGeom &g, int b0, int b1, uint16_t *lq, uint16_t *lt, int lane)
 {
-    const int qlo = g.a0 - SUB_LANES, tlo = g.a0 + g.dlo - 1, n = 8 * nb + SUB_LANES + 8;
+    const int qlo = g.a0 - SUB_LANES + 8 * b0, tlo = g.a0 + g.dlo - 1 + 8 * b0, n = 8 * (b1 - b0) + SUB_LANES + 8;
     for (int x = lane; x < n; x += 64) { const int p = qlo + x; lq[x] = q_addr_part(((unsigned)p < (unsigned)g.Lq) ? g.qg[p] : PEP_PAD_CODE); }
     for (int x = lane; x < n; x += 64) { const int p = tlo + x; lt[x] = t_addr_part(((unsigned)p < (unsigned)g.Lt) ? g.tg[p] : PEP_PAD_CODE); }
 }
@@ -438,21 +455,20 @@ __device__ __forceinline__ void stage_sub_windows(const SubGeom &g, int nb, uint
 // sweep (see above); the only additions are the AND masks that make lanes 0 / 31 of each half read the band boundary instead of the
 // other half's edge lane (v_and_b32 issues at twice the rate of the packed operations).  ok[x] = candidate x reached its known score
 // inside its sub-band (wave-uniform); a candidate that did not is traced again in its full band by the caller.
+template <bool CHUNKED>
 __device__ __forceinline__ void sw_four_pk16_trace(const SwArgs &a, const uint64_t cc[4], const SubGeom gg[4], const int L0[4], bool ok[4],
                                                    const unsigned char *lds_tab, uint16_t *lds_res, int lane)
 {
     const int nb = max(max(gg[0].nblk, gg[1].nblk), max(gg[2].nblk, gg[3].nblk));
-    const int win = (8 * nb + SUB_LANES + 16 + 7) & ~7;
+    // blocks per staging chunk: eight windows of 8 * blocks + 48 entries in the wavefront's staging area; pairs with more blocks (nucleotide
+    // alignments, long proteins) are swept chunk by chunk with the DP state kept in registers - they used to go one per wavefront through the 32-bit sweep
+    const int chunk = CHUNKED ? max(1, min(nb, (a.lds_res_bytes / 16 - (SUB_LANES + 16)) / 8)) : nb;
+    const int win = (8 * chunk + SUB_LANES + 16 + 7) & ~7;
     uint16_t *wq[4], *wt[4];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) { wq[x] = lds_res + (2 * x) * win; wt[x] = lds_res + (2 * x + 1) * win; stage_sub_windows(gg[x], nb, wq[x], wt[x], lane); }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int x = 0; x < 4; ++x) { wq[x] = lds_res + (2 * x) * win; wt[x] = lds_res + (2 * x + 1) * win; }
     const int hf = lane >> 5, ln = lane & (SUB_LANES - 1);      // which pair of candidates, which lane of the sub-band
     typedef const volatile __attribute__((address_space(3))) uint16_t lds_cu16;
-    lds_cu16 *vq0 = (lds_cu16 *)((hf ? wq[2] : wq[0]) + (SUB_LANES - ln)), *vt0 = (lds_cu16 *)((hf ? wt[2] : wt[0]) + (1 + ln));
-    lds_cu16 *vq1 = (lds_cu16 *)((hf ? wq[3] : wq[1]) + (SUB_LANES - ln)), *vt1 = (lds_cu16 *)((hf ? wt[3] : wt[1]) + (1 + ln));
     const uint32_t tab = (uint32_t)(uintptr_t)(lds_ci8 *)(reinterpret_cast<const signed char *>(lds_tab) + (lane & (PEP_TAB_REP - 1)) * 4);
     const uint64_t c0 = hf ? cc[2] : cc[0], c1 = hf ? cc[3] : cc[1];
     const int nb0 = hf ? gg[2].nblk : gg[0].nblk, nb1 = hf ? gg[3].nblk : gg[1].nblk;
@@ -469,8 +485,22 @@ __device__ __forceinline__ void sw_four_pk16_trace(const SwArgs &a, const uint64
     s16x2 HA = zero, EA = zero, FA = zero, HB = zero, EB = zero, FB = zero;
     u16x2 first = {0, 0};
     s16x2 best = zero;
+    int cb = 0;
+    do {
+    const int ce = CHUNKED ? min(nb, cb + chunk) : nb;
+    if (CHUNKED && cb) {                            // every lane is done with the windows of the chunk before
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) stage_sub_windows(gg[x], cb, ce, wq[x], wt[x], lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    lds_cu16 *vq0 = (lds_cu16 *)((hf ? wq[2] : wq[0]) + (SUB_LANES - ln)), *vt0 = (lds_cu16 *)((hf ? wt[2] : wt[0]) + (1 + ln));
+    lds_cu16 *vq1 = (lds_cu16 *)((hf ? wq[3] : wq[1]) + (SUB_LANES - ln)), *vt1 = (lds_cu16 *)((hf ? wt[3] : wt[1]) + (1 + ln));
     int tv0 = vt0[0], tv1 = vt1[0], qv0 = 0, qv1 = 0;
-    for (int b = 0; b < nb; ++b) {
+    for (int b = cb; b < ce; ++b) {
         u16x2 accA = {0, 0}, accB = {0, 0}, loA = {0, 0}, loB = {0, 0};
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
@@ -520,6 +550,8 @@ __device__ __forceinline__ void sw_four_pk16_trace(const SwArgs &a, const uint64
         if (b < nb0) dir0[(size_t)b * SUB_LANES + ln] = make_uint2(__builtin_amdgcn_perm(ha, la, 0x05040100u), __builtin_amdgcn_perm(hb, lb, 0x05040100u));
         if (b < nb1 && c1 != c0) dir1[(size_t)b * SUB_LANES + ln] = make_uint2(__builtin_amdgcn_perm(ha, la, 0x07060302u), __builtin_amdgcn_perm(hb, lb, 0x07060302u));
     }
+    cb = ce;
+    } while (CHUNKED && cb < nb);
     // end cell per candidate: earliest step with H == T in the lane, then min i, then min j over the 32 lanes of the half
     const int fk[2] = {(int)first.x, (int)first.y};
     const int TT[2] = {(int)T2.x, (int)T2.y};
@@ -552,22 +584,32 @@ __device__ __forceinline__ void sw_four_pk16_trace(const SwArgs &a, const uint64
 
 // score pass: wave w of the grid-stride loop takes the candidate pair (order[2w], order[2w+1]): neighbours in the length order, so the
 // two halves of the packed registers finish together, and the longest pairs start first
+// LONG = false: the pairs whose windows fit the staging area (and the ones the packed sweep cannot take at all); LONG = true: the pairs that the
+// packed sweep takes in chunks of blocks - a launch of its own, made only when the sequence lengths allow such pairs, because the chunked
+// sweep next to the plain one made both kernels a few per cent slower on short pairs (code size, register allocation)
+template <bool LONG>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint64_t n_pairs = (a.n + 1) / 2;
+    // the candidates with more blocks than the staging area takes at once are a prefix of the length order (sw_prep counted them): the pairs
+    // [0, w_long) belong to the LONG launch, the rest to the other
+    const uint64_t w_long = a.split_long ? min(n_pairs, ((uint64_t)a.counts[3] + 1) / 2) : 0;
+    if ((LONG ? 0 : w_long) + (uint64_t)blockIdx.x * WAVES_PER_BLOCK >= (LONG ? w_long : n_pairs)) return;      // nothing for this block (before it loads the table)
     uint32_t *lds_tab = reinterpret_cast<uint32_t *>(smem);
     for (int x = threadIdx.x; x < LDS_TABLE_BYTES / 4; x += blockDim.x) lds_tab[x] = a.sub_image[x];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t *lds_res = reinterpret_cast<uint16_t *>(smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes);
-    const uint64_t n_pairs = (a.n + 1) / 2;
-    for (uint64_t w = (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < n_pairs; w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
+    for (uint64_t w = (LONG ? 0 : w_long) + (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < (LONG ? w_long : n_pairs); w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
         const uint64_t c0 = a.order[2 * w], c1 = a.order[min(2 * w + 1, a.n - 1)];
         const CandGeom g0 = cand_geom(a, c0), g1 = cand_geom(a, c1);
-        const int nb = max(g0.nblk, g1.nblk);
-        const int need = 4 * 2 * ((8 * nb + 80 + 7) & ~7);
-        if (a.pk16 && fits16(g0, a.max_sub) && fits16(g1, a.max_sub) && need <= a.lds_res_bytes) {
-            sw_two_pk16(a, c0, c1, g0, g1, smem, lds_res, lane);
+        const int nbm = max(g0.nblk, g1.nblk);
+        const bool can_pack = a.pk16 && fits16(g0, a.max_sub) && fits16(g1, a.max_sub) && a.lds_res_bytes >= 4 * 2 * 88;
+        const bool fits = 4 * 2 * ((8 * nbm + 80 + 7) & ~7) <= a.lds_res_bytes;
+        if (LONG && can_pack) sw_two_pk16<LONG>(a, c0, c1, g0, g1, smem, lds_res, lane);
+        else if (!LONG && can_pack && fits) {
+            sw_two_pk16<false>(a, c0, c1, g0, g1, smem, lds_res, lane);
         } else {
             for (int x = 0; x < (c1 != c0 ? 2 : 1); ++x) {
                 const uint64_t c = x ? c1 : c0;
@@ -582,6 +624,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a
 // traceback pass over the pairs that survived best-per-(q,t) and the e-value cut: four candidates per wavefront in their sub-bands
 // (packed 16-bit), the 32-bit sweep for anything that does not fit (scores beyond 16 bits, windows beyond the LDS staging area), and the
 // full band for the few alignments that leave their sub-band
+template <bool LONG>            // true: the long candidates only (part 0 of the order), four per wavefront in chunks of blocks - see sw_score_kernel
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArgs a)      // 4 waves per SIMD is what the LDS budget allows: keep the VGPRs within that
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -604,9 +647,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
     const uint64_t n_active = a.counts[5];
     const uint64_t n_long = a.pk16 ? min((uint64_t)a.counts[3], n_active) : n_active;
 #pragma unroll 1
-    for (int part = 0; part < 2; ++part) {
+    for (int part = LONG ? 0 : (a.split_long ? 1 : 0); part < (LONG ? 1 : 2); ++part) {
         const uint64_t item_first = part ? n_long : 0, item_count = part ? n_active - n_long : n_long;
-        const int item_span = part ? 4 : 1;
+        const int item_span = (part || LONG) ? 4 : 1;
         unsigned int *queue = reinterpret_cast<unsigned int *>(a.counts + (part ? 4 : 2));
         if (item_count == 0) continue;
         const uint64_t n_items = (item_count + item_span - 1) / item_span;
@@ -637,11 +680,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
                     nb = max(nb, gg[x].nblk);
                     packed = packed && fits16(g, a.max_sub) && a.known[cc[x]] > 0;
                 }
-                packed = packed && 8 * 2 * ((8 * nb + SUB_LANES + 16 + 7) & ~7) <= a.lds_res_bytes && nb < 2040;
+                packed = packed && (LONG ? a.lds_res_bytes >= 8 * 2 * (SUB_LANES + 24) : 8 * 2 * ((8 * nb + SUB_LANES + 16 + 7) & ~7) <= a.lds_res_bytes) && nb < 2040;
             }
             if (packed) {
                 bool ok[4];
-                sw_four_pk16_trace(a, cc, gg, L0, ok, smem, lds_res, lane);
+                sw_four_pk16_trace<LONG>(a, cc, gg, L0, ok, smem, lds_res, lane);
 #pragma unroll 1
                 for (int x = 0; x < 4; ++x)
                     if (!ok[x]) {                                // left its sub-band: once more in the full band
@@ -822,6 +865,12 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     // traceback pass: the four-candidate sweep stages 8 windows of 8 * blocks + 48 entries; candidates with more 16-step blocks than fit
     // are swept one per wavefront.  The order below is by decreasing length, so they are a prefix of it.
     uint32_t nb_limit = 0;
+    const bool split_long = pk16 && (trace ? want4 : 2 * want) > (uint64_t)lds_res_bytes;
+    if (!trace && split_long) {
+        // score pass: the longest pair the packed sweep stages at once (four windows of 8 * blocks + 80 entries)
+        const int entries = lds_res_bytes / (4 * 2);
+        nb_limit = std::min<uint32_t>(entries > 88 ? (uint32_t)((entries - 87) / 8) : 0, LEN_BUCKETS - 2);
+    }
     if (trace && pk16) {
         const int entries = lds_res_bytes / (8 * 2);
         nb_limit = entries > SUB_LANES + 16 + 8 ? (uint32_t)((entries - SUB_LANES - 16) / 8 - 1) : 0;     // (the sub-band may need one block more than the band)
@@ -876,6 +925,8 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     a.end_lane = trace ? d_end_lane : nullptr;
     a.mode = trace ? ctx->d_trace_mode.as<int32_t>() : nullptr;
     a.counts = cells;
+    // (windows of the longest possible pair against the staging area: score pass 4 windows of 8 * blocks + 80 entries, traceback pass 8 of 8 * blocks + 48)
+    a.split_long = split_long ? 1 : 0;
     a.order = order;
     a.max_sub = 1;
     for (int x = 0; x < 32 * 32; ++x) a.max_sub = std::max(a.max_sub, (int)P.sub[x]);
@@ -890,14 +941,18 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
         (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
         const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16 / WAVES_PER_BLOCK, (160 * 1024) / std::max<size_t>(smem, 1)));
         const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(n, WAVES_PER_BLOCK), (uint64_t)n_cu * per_cu);        // (one candidate per item at worst)
-        hipLaunchKernelGGL(sw_trace_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+        // candidates with more blocks than the staging area takes at once exist only when the sequences are long enough: then they get a launch
+        // of their own (the packed sweep in chunks), in front - they are the longest work
+        if (a.split_long) hipLaunchKernelGGL(sw_trace_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+        hipLaunchKernelGGL(sw_trace_kernel<false>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     } else {
         // one item (a packed candidate pair, or one candidate) per wavefront: the hardware's block dispatcher balances the load better than a
         // grid-stride loop inside fewer blocks (score pass 0.82 -> 0.80 ms on the benchmark), and the 16 KiB table load per block comes out
         // of the L2
         const uint64_t items = ceil_div(a.pk16 ? (n + 1) / 2 : n, WAVES_PER_BLOCK);
         const unsigned grid = (unsigned)std::min<uint64_t>(items, 256ull * 256);
-        hipLaunchKernelGGL(sw_score_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+        if (a.split_long) hipLaunchKernelGGL(sw_score_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+        hipLaunchKernelGGL(sw_score_kernel<false>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     }
     pep_timer_end(ctx, trace ? TM_SW_TRACE : TM_SW);
     PEP_HIP(ctx, hipGetLastError());
