@@ -1331,3 +1331,42 @@ def test_candidate_sort_two_level_and_fallback(ctx):
         _cmp_hits(np.frombuffer(out[0][0], dtype=N.HIT_DTYPE), np.frombuffer(out[0][1], dtype=np.uint32), oh, oc)
         assert out[0][2] == ost['candidates']
     assert ost['candidates'] < 4096
+
+
+def test_k1_inside_the_search_equals_translate_in_front(ctx):
+    """pep_invalidate_translation: K1 runs inside the next search (both sides queued at once, the reference side's summary taken late, the
+    host tables built from descriptors that stay on the device) - same hit table, same statistics, same meta records and proteins as
+    translate(force=True) in front of the search; also when only one side changes, and several times in a row"""
+    from peppan_amd import _native as N, synth
+    names, seqs = synth.make_genes(700, 0, seed=5)
+    keys = ('candidates', 'pairs', 'tracebacks', 'hits', 'cells', 'query_residues', 'target_residues', 'query_seeds', 'target_seeds', 'seed_hits')
+    p = N.default_params(45., 25., 10, 5)
+    ctx.set_query_nt(seqs[:300], 11); ctx.set_ref_nt(seqs, 6, 11)
+    ctx.translate(force=True)
+    h0, c0, s0 = ctx.search(p)
+    qm0, tm0 = ctx.query_meta(), ctx.target_meta()
+    qa0, ta0 = ctx.query_aa(), ctx.target_aa()
+    for rep in range(3):
+        ctx.invalidate_translation()
+        h, c, st = ctx.search(p, copy=bool(rep % 2))
+        assert np.array(h).tobytes() == h0.tobytes() and np.array(c).tobytes() == c0.tobytes() and all(st[k] == s0[k] for k in keys), rep
+    assert ctx.query_meta().tobytes() == qm0.tobytes() and ctx.target_meta().tobytes() == tm0.tobytes()
+    qa, ta = ctx.query_aa(), ctx.target_aa()
+    assert all(np.array_equal(a, b) for a, b in zip(qa + ta, qa0 + ta0))
+    # only the query side is new: the reference side is not translated again, the result is that of a fresh context
+    ctx.set_query_nt(seqs[100:500], 11)
+    h1, c1, s1 = ctx.search(p)
+    with N.Context(0) as other:
+        other.set_query_nt(seqs[100:500], 11); other.set_ref_nt(seqs, 6, 11)
+        other.translate()
+        h2, c2, s2 = other.search(p)
+        tm2 = other.target_meta()
+    assert h1.tobytes() == h2.tobytes() and c1.tobytes() == c2.tobytes() and all(s1[k] == s2[k] for k in keys) and len(h1) > 400
+    assert ctx.target_meta().tobytes() == tm2.tobytes()
+    # an empty reference set / empty query set inside the search
+    ctx.set_ref_nt([], 6, 11)
+    h3, c3, s3 = ctx.search(p)
+    assert len(h3) == 0
+    ctx.set_query_nt([], 11); ctx.set_ref_nt(seqs[:50], 6, 11)
+    h4, c4, s4 = ctx.search(p)
+    assert len(h4) == 0 and len(ctx.target_meta()) >= 300
