@@ -213,6 +213,75 @@ __global__ __launch_bounds__(256) void idx_slab(SeedShape sh, const uint8_t *__r
     }
 }
 
+// MEASUREMENT ONLY (params.reserved[0] = 7, tools/partition_probe.py): the first pass of a PARTITIONED join - the target positions whose key
+// passes the filter are scattered into the coarse buckets of the query index, exactly as idx_slab scatters the query positions (same chunking,
+// same LDS counting, same slab reservation), 8 bytes (key << 29 | position) each.  Its duration against seed_match's is what decides whether a
+// partitioned join can pay; nothing reads what it writes.
+template <int W>
+__global__ __launch_bounds__(256) void tgt_slab_probe(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, int bucket_bits, int fine_bits,
+                                                      const unsigned long long *__restrict__ filter, uint32_t *__restrict__ coarse_cnt, uint64_t *__restrict__ part,
+                                                      uint32_t cap, int tiles, unsigned long long *__restrict__ kept)
+{
+    extern __shared__ uint32_t part_lds[];
+    uint32_t *h = part_lds;
+    const uint32_t n_coarse = 1u << (bucket_bits - fine_bits);
+    uint8_t *red = reinterpret_cast<uint8_t *>(h + n_coarse);
+    unsigned long long mine = 0;
+    for (int t0 = 0; t0 < tiles; t0 += PART_TILES) {
+        for (uint32_t x = threadIdx.x; x < n_coarse; x += 256) h[x] = 0;
+        uint64_t ent[PART_TILES];
+        uint32_t cb[PART_TILES], fetched[PART_TILES];
+#pragma unroll
+        for (int t = 0; t < PART_TILES; ++t) {
+            const uint64_t tile = (uint64_t)blockIdx.x * tiles + t0 + t;
+            fetched[t] = (t0 + t < tiles && tile * TILE < total) ? fetch_tile(res, tile, total) : 0u;
+        }
+#pragma unroll
+        for (int t = 0; t < PART_TILES; ++t) {
+            const uint64_t base = ((uint64_t)blockIdx.x * tiles + t0 + t) * TILE;
+            ent[t] = ~0ull; cb[t] = 0;
+            __syncthreads();
+            if (t0 + t < tiles && base < total) {
+                red[threadIdx.x] = reduce_letter(sh, fetched[t]);
+                if (threadIdx.x < TILE_HALO) red[TILE + threadIdx.x] = reduce_letter(sh, fetched[t] >> 8);
+                __syncthreads();
+                const uint64_t p = base + threadIdx.x;
+                uint64_t key;
+                if (p + 32 <= total && tile_key<W>(sh, red, threadIdx.x, key)) {
+                    uint32_t word;
+                    const uint64_t m = filter_mask(key, bucket_bits, word);
+                    if ((filter[word] & m) == m) {
+                        ent[t] = (key << POS_BITS) | p;
+                        cb[t] = hash_u64(key, bucket_bits) >> fine_bits;
+                        atomicAdd(&h[cb[t]], 1u);
+                        ++mine;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t x0 = threadIdx.x; x0 < n_coarse; x0 += 8 * 256) {
+            uint32_t c8[8], at8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const uint32_t x = x0 + 256u * k; c8[k] = x < n_coarse ? h[x] : 0u; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) at8[k] = x0 + 256u * k < n_coarse ? atomicAdd(&coarse_cnt[x0 + 256u * k], c8[k]) : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (c8[k]) h[x0 + 256u * k] = at8[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < PART_TILES; ++t)
+            if (ent[t] != ~0ull) {
+                const uint32_t slot = atomicAdd(&h[cb[t]], 1u);
+                if (slot < cap) part[(uint64_t)cb[t] * cap + slot] = ent[t];
+            }
+        __syncthreads();
+    }
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(kept, mine);
+}
+
 // one block per coarse bucket c: its slab -> entries[] ordered by fine bucket (dense: after the entries of the coarse buckets before it),
 // start[c << F .. (c + 1) << F), filter slice
 __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ part, const uint32_t *__restrict__ coarse_cnt, int bucket_bits,
@@ -854,6 +923,19 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             pep_timer_begin(ctx, TM_MATCH0 + s);
             PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 8u)), sh, a);
             pep_timer_end(ctx, TM_MATCH0 + s);
+            if (P.reserved[0] == 7 && use_partition && sh.weight == 10) {
+                // measurement only: the scatter pass of a partitioned join over the same targets, behind the matcher it would replace
+                static DevBuf probe_part, probe_cnt;
+                const uint32_t n_coarse = 1u << (bucket_bits - fine_bits), cap = 16384;
+                PEP_TRY(dev_reserve(ctx, probe_part, (uint64_t)n_coarse * cap * 8));
+                PEP_TRY(dev_reserve(ctx, probe_cnt, (uint64_t)n_coarse * 4 + 64));
+                PEP_HIP(ctx, hipMemsetAsync(probe_cnt.p, 0, (uint64_t)n_coarse * 4 + 64, ctx->stream));
+                const int tiles = (int)std::max<uint64_t>(PART_TILES, ceil_div(T.total, (uint64_t)TILE * 8192));
+                const unsigned pb = (unsigned)ceil_div(T.total, (uint64_t)tiles * TILE);
+                hipLaunchKernelGGL(tgt_slab_probe<10>, dim3(pb), dim3(256), (size_t)n_coarse * 4 + TILE + TILE_HALO, ctx->stream, sh, T.res.as<const uint8_t>(), T.total, bucket_bits, fine_bits,
+                                   (const unsigned long long *)filter, probe_cnt.as<uint32_t>(), probe_part.as<uint64_t>(), cap, tiles,
+                                   reinterpret_cast<unsigned long long *>(probe_cnt.as<uint32_t>() + n_coarse));
+            }
             hipLaunchKernelGGL(seed_runs, dim3(256u * 8u), dim3(256), 0, ctx->stream, a, run_first, run_len, run_key, n_runs);
             hipLaunchKernelGGL(seed_extend, dim3(256u * 16u), dim3(256), 0, ctx->stream, a, (const uint64_t *)run_first, (const uint32_t *)run_len,
                                (const uint64_t *)run_key, (const unsigned long long *)n_runs);
