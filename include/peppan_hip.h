@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 6
+#define PEP_ABI_VERSION 7
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -316,6 +316,13 @@ int pep_similar_resolve(uint64_t n_events, const uint8_t *ev_kind, const int64_t
  * name (first token of the header line, a decimal integer) is in ids[0..n_ids) (sorted ascending), verbatim; the file is not touched when
  * every record stays.  PEP_ERR_ARG (file untouched) when a name is not a plain decimal integer: the caller then applies its own rules. */
 int pep_fasta_keep(const char *path, const int64_t *ids, uint64_t n_ids, uint64_t *n_records, uint64_t *n_kept);
+/* the clusterer's input (the FASTA file clust.py:62-66 hands to `mmseqs createdb`; host, no context): the sequences of the FASTA text
+ * data[0..n) as codes[] = table[byte] with off[0 .. *n_records] the start of each record's codes.  A record starts at a '>' at the start of a
+ * line, its first line is the header; body lines starting with '#' are dropped, ASCII blanks removed.  codes must hold n bytes, off cap + 1
+ * entries; PEP_ERR_LIMIT when the text has more than cap records.  *non_ascii = 1 when a body holds a byte >= 0x80 (the caller then applies
+ * its own, Unicode-aware rules). */
+int pep_fasta_scan(const uint8_t *data, uint64_t n, const uint8_t *table, uint8_t *codes, uint64_t *off, uint64_t cap, uint64_t *n_records,
+                   int32_t *non_ascii);
 
 /* K13: exact-duplicate collapse of gene instances (front end of the clustering path).
  * pep_sha1: digest[20*i..] = SHA-1 of sequence i (bytes[off[i]..off[i+1])), big-endian bytes as hashlib.sha1(seq).digest();

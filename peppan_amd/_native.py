@@ -7,14 +7,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep']
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan']
 
 
 class PepError(RuntimeError):
@@ -268,6 +268,23 @@ def fasta_keep(path, ids):
     if rc_ != 0:
         raise PepError('pep_fasta_keep failed (%d)' % rc_)
     return nr.value, nk.value
+
+
+def fasta_scan(data, table, n_records):
+    """pep_fasta_scan: the sequences of FASTA text `data` (bytes) as (codes uint8[total], off uint64[n + 1]) with codes = table[byte], or None when
+    the text does not hold exactly n_records records or a sequence holds non-ASCII bytes (the caller then goes its own way)"""
+    lib = load_library()
+    table = np.ascontiguousarray(table, dtype=np.uint8)
+    assert len(table) == 256
+    codes = np.empty(max(len(data), 1), dtype=np.uint8)
+    off = np.zeros(n_records + 2, dtype=np.uint64)
+    nr, high = C.c_uint64(), C.c_int32()
+    rc_ = lib.pep_fasta_scan(C.c_char_p(data), C.c_uint64(len(data)), _ptr(table), _ptr(codes), _ptr(off), C.c_uint64(n_records), C.byref(nr), C.byref(high))
+    if rc_ == -3 or (rc_ == 0 and (nr.value != n_records or high.value)):          # PEP_ERR_LIMIT: more records than the caller counted
+        return None
+    if rc_ != 0:
+        raise PepError('pep_fasta_scan failed (%d)' % rc_)
+    return codes[:int(off[n_records])], off[:n_records + 1]
 
 
 def similar_resolve(ev_kind, ev_a, ev_b, ev_value):

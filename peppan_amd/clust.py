@@ -32,11 +32,14 @@ Block = collections.namedtuple('Block', 'name text')          # text: the header
 MAX_ROUNDS = 3
 
 
-def read_blocks(path):
-    """the records of a FASTA file as verbatim text blocks, file order; lines before the first header belong to nobody.
-    (One read and one split at the header marks: the per-line loop this replaces was a third of iterClust's time at 300 k genes.)"""
+def _read_text(path):
     with uopen(path) as fin:
-        data = fin.read()
+        return fin.read()
+
+
+def blocks_of(data):
+    """the records of FASTA text as verbatim text blocks, file order; lines before the first header belong to nobody.
+    (One split at the header marks: the per-line loop this replaces was a third of iterClust's time at 300 k genes.)"""
     if data[:1] != '>':
         at = data.find('\n>')
         if at < 0:
@@ -52,16 +55,22 @@ def read_blocks(path):
     return blocks
 
 
+def read_blocks(path):
+    return blocks_of(_read_text(path))
+
+
+def sequence_of(blk):
+    """a record's sequence: its non-comment lines without blanks, upper case"""
+    nl = blk.text.find('\n')
+    body = '' if nl < 0 else blk.text[nl + 1:]
+    if '#' in body:
+        body = ' '.join(line for line in body.split('\n') if not line.startswith('#'))
+    return ''.join(body.split()).upper()
+
+
 def readFasta(fasta):
-    """[[name, SEQUENCE], ...] in file order; sequence = the record's non-comment tokens joined, upper case"""
-    records = []
-    for blk in read_blocks(fasta):
-        nl = blk.text.find('\n')
-        body = '' if nl < 0 else blk.text[nl + 1:]
-        if '#' in body:
-            body = ' '.join(line for line in body.split('\n') if not line.startswith('#'))
-        records.append([blk.name, ''.join(body.split()).upper()])
-    return records
+    """[[name, SEQUENCE], ...] in file order"""
+    return [[blk.name, sequence_of(blk)] for blk in read_blocks(fasta)]
 
 
 def cluster_relation(fasta, identity, coverage, n_thread=1):
@@ -115,8 +124,17 @@ def getClust(prefix, genes, params):
         survivors_path = os.path.join(work, 'seq.ref')
         n_before = None
         for _ in range(MAX_ROUNDS):
-            link.update((str(member), str(rep)) for rep, member in cluster_fn(round_input, params['identity'], params['coverage'], params['n_thread']))
-            survivors, first_of = _one_round(read_blocks(round_input), link)
+            if cluster_fn is cluster_relation:             # the default clusterer takes the text this function reads anyway: one read per round
+                from . import linclust
+                text = _read_text(round_input)
+                blocks = blocks_of(text)
+                relation = linclust.linclust_text(text, blocks, params['identity'], params['coverage'])
+                del text
+            else:
+                relation = cluster_fn(round_input, params['identity'], params['coverage'], params['n_thread'])
+                blocks = read_blocks(round_input)
+            link.update((str(member), str(rep)) for rep, member in relation)
+            survivors, first_of = _one_round(blocks, link)
             for gene, label in link.items():               # every gene seen so far follows its cluster's exemplar
                 link[gene] = first_of.get(label, label)
             with open(survivors_path, 'w') as fout:

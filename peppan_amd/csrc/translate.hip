@@ -72,43 +72,65 @@ struct PackDesc {          // one per packed sequence: where its residues come f
     uint32_t len;
 };
 
+// where a packed sequence's nucleotides lie (one record per descriptor slot, written by the kernel that writes the descriptor): k1_pack
+// fetches it together with the descriptor instead of chasing nt_off[desc.seq] behind it - a wave of k1_pack lives for a chain of
+// dependent loads, and this takes a link out of it
+struct K1Src { uint64_t off; uint32_t L, pad; };
+static_assert(sizeof(K1Src) == sizeof(PackDesc), "source records lie behind the descriptors, in slots of the same size");
+__host__ __device__ __forceinline__ K1Src *k1_src_of(const PackDesc *desc, uint32_t cap) { return reinterpret_cast<K1Src *>(const_cast<PackDesc *>(desc) + cap + 3); }
+
 __device__ __forceinline__ uint32_t padded_len(uint32_t len) { return (len + 15u) / 16u * 16u + PEP_SEQ_GAP; }
 
-// one wavefront per query gene; the gene's descriptor, padded length and (in pinned memory, for the host) length are written here too
+// one wavefront per query gene; the gene's descriptor, source record, padded length and (in pinned memory, for the host) length are written here too
 __global__ __launch_bounds__(256) void k1_query_frames(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ off, uint32_t n, int tab,
                                                        PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, uint32_t *__restrict__ n_out,
-                                                       K1Summary *__restrict__ sum, uint32_t *__restrict__ pin_len)
+                                                       K1Summary *__restrict__ sum, uint32_t *__restrict__ pin_len, K1Src *__restrict__ src_of)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) { *n_out = n; sum->residues = 0ull; sum->max_len = 0u; }       // (k1_offsets accumulates into it)
     if (g >= n) return;
-    const uint8_t *s = nt + off[g];
-    const int64_t L = (int64_t)(off[g + 1] - off[g]);
-    // the three frames are walked together: codon a of frames 1, 2, 3 is bytes 3a .. 3a+4, five loads instead of nine, and two
-    // codon positions per lane and trip keep ten loads in flight (the kernel is bound by their latency, not by the bytes)
-    const int64_t na1 = frame_len(L, 1), na2 = frame_len(L, 2), na3 = frame_len(L, 3);
+    const uint64_t o = off[g];
+    const uint8_t *s = nt + o;
+    const int L = (int)(off[g + 1] - o);           // (upload_nt keeps a sequence below 2^31 - 256 nucleotides)
+    // Same geometry as k1_pack: the wavefront copies the 1536 + 2 nucleotide bytes behind 512 codon positions into LDS with aligned dword
+    // loads, then every lane looks at eight positions.  The three frames are walked together: codon a of frames 1, 2, 3 is bytes 3a .. 3a+4.
+    // The codon table sits in LDS too (one copy per wavefront): the first version read its bytes from global memory five at a time and
+    // looked the codons up in the constant array with per-lane indices, i.e. a chain of two global round trips per 128 positions.
+    __shared__ uint32_t stage_all[4][392];
+    __shared__ uint32_t codon_all[4][64];
+    uint32_t *stage = stage_all[threadIdx.x >> 6], *codon = codon_all[threadIdx.x >> 6];
+    const uint8_t *sb = reinterpret_cast<const uint8_t *>(stage);
+    codon[lane] = c_codon[tab][lane];
+    const int na1 = (int)frame_len(L, 1), na2 = (int)frame_len(L, 2), na3 = (int)frame_len(L, 3);
     uint32_t x1 = 0, x2 = 0, x3 = 0;
-    for (int64_t a0 = lane; a0 + 1 < na1; a0 += 128) {         // s[:-1] of every frame; frame 1 is the longest
-        int b[2][5];
+    for (int c0 = 0; c0 + 1 < na1; c0 += 512) {                // s[:-1] of every frame; frame 1 is the longest
+        const int lo = 3 * c0;
+        const uintptr_t A = reinterpret_cast<uintptr_t>(s + lo);
+        const int shift = (int)(A & 3u);
+        const uint32_t *al = reinterpret_cast<const uint32_t *>(A - shift);
+        const int n_dw = (min(1538, L - lo) + shift + 3) >> 2;            // <= 386; the buffer is padded by 64 bytes behind the last sequence
+        for (int x = lane; x < n_dw; x += 64) stage[x] = al[x];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        int b[26];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int k = 0; k < 26; ++k) { const int p = lo + 24 * lane + k; b[k] = p < L ? base2(sb[p - lo + shift]) : -1; }
+        const int lim[3] = {na1, na2, na3};
+        uint32_t *cnt[3] = {&x1, &x2, &x3};
 #pragma unroll
-            for (int k = 0; k < 5; ++k) { const int64_t p = 3 * (a0 + 64 * h) + k; b[h][k] = p < L ? base2(s[p]) : -1; }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int64_t a = a0 + 64 * h;
-            const int64_t lim[3] = {na1, na2, na3};
-            uint32_t *cnt[3] = {&x1, &x2, &x3};
+        for (int h = 0; h < 8; ++h) {
+            const int a = c0 + 8 * lane + h;
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
-                if (a + 1 >= lim[f]) continue;
-                const int u = b[h][f], v = b[h][f + 1], w = b[h][f + 2];
+                const int u = b[3 * h + f], v = b[3 * h + f + 1], w = b[3 * h + f + 2];
                 const bool gap = (u == -2) | (v == -2) | (w == -2);
-                const bool stop = !gap && ((u | v | w) < 0 || c_codon[tab][(u << 4) | (v << 2) | w] == 23);
-                *cnt[f] += stop ? 1u : 0u;
+                const bool stop = !gap && ((u | v | w) < 0 || codon[((u << 4) | (v << 2) | w) & 63] == 23u);
+                *cnt[f] += (a + 1 < lim[f] && stop) ? 1u : 0u;
             }
         }
+        __builtin_amdgcn_wave_barrier();                                 // the next chunk overwrites the staging area
     }
     for (int d = 32; d > 0; d >>= 1) { x1 += __shfl_xor(x1, d, 64); x2 += __shfl_xor(x2, d, 64); x3 += __shfl_xor(x3, d, 64); }
     uint32_t best_cnt = x1, best_f = 1, best_len = (uint32_t)na1;
@@ -116,6 +138,7 @@ __global__ __launch_bounds__(256) void k1_query_frames(const uint8_t *__restrict
     if (x3 < best_cnt) { best_cnt = x3; best_f = 3; best_len = (uint32_t)na3; }
     if (lane == 0) {
         desc[g] = PackDesc{g, best_f, 0u, best_len};
+        src_of[g] = K1Src{o, (uint32_t)L, 0u};
         padded[g] = padded_len(best_len);
         len_out[g] = best_len;
         pin_len[g] = best_len;                   // the host's copy (pinned memory): the search derives its score thresholds from the lengths
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(256) void k1_ref_chunks(const uint8_t *__restrict__
 // sized from a host upper bound and the surplus waves leave at once, so the host never waits for the chunk count.
 // (The first version ran one thread per 16-byte block of the layout with a 16-step binary search for the owner: 0.22 ms for
 // the 20 M reference residues, bound by the latency of that search.)
-__global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, int tab,
+__global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, const K1Src *__restrict__ src_of, int tab,
                                                const PackDesc *__restrict__ desc, const uint32_t *__restrict__ pk_off, const uint32_t *__restrict__ n_ptr, uint32_t cap,
                                                uint8_t *__restrict__ res, uint2 *__restrict__ blk2seq, const K1Summary *__restrict__ d_sum, K1Summary *__restrict__ pin_sum)
 {
@@ -183,14 +206,20 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
     const uint32_t n_packed = *n_ptr;
     const uint32_t sc = min(s, cap);                                   // (the last block's surplus waves stay inside the arrays)
     const PackDesc d = desc[sc];
+    const K1Src so = src_of[sc];
     const uint32_t start = pk_off[sc], next = pk_off[sc + 1];        // pk_off[n] = size of the whole layout (includes the trailing pad)
+    // the codon table in LDS, one copy per wavefront (no block-level barrier: waves leave early): a look-up in the constant array with a
+    // per-lane index is a vector load from global memory, one more link in the chain
+    __shared__ uint32_t codon_all[4][64];
+    uint32_t *codon = codon_all[threadIdx.x >> 6];
+    codon[lane] = c_codon[tab][lane];
     if (n_packed == 0) {                      // nothing but the two end pads
         if (s == 0) for (uint32_t x = lane; x < pk_off[0]; x += 64) res[x] = (uint8_t)PEP_PAD_CODE;
         return;
     }
     if (s >= n_packed) return;
-    const uint8_t *src = nt + nt_off[d.seq];
-    const int L = (int)(nt_off[d.seq + 1] - nt_off[d.seq]);
+    const uint8_t *src = nt + so.off;
+    const int L = (int)so.L;
     if (s == 0) for (uint32_t x = lane; x < start; x += 64) res[x] = (uint8_t)PEP_PAD_CODE;          // leading pad
     // Chunks of 512 residues: the wavefront copies the 1536 nucleotide bytes behind them into LDS with aligned dword loads (coalesced:
     // 256 contiguous bytes per instruction), then every lane translates eight residues out of LDS and stores 8 bytes.  Reading the
@@ -236,7 +265,7 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
                         b[j] = v;
                     }
                     const bool gap = (b[0] == -2) | (b[1] == -2) | (b[2] == -2);
-                    c = (gap || (b[0] | b[1] | b[2]) < 0) ? 23u : (uint32_t)c_codon[tab][(b[0] << 4) | (b[1] << 2) | b[2]];
+                    c = (gap || (b[0] | b[1] | b[2]) < 0) ? 23u : codon[(b[0] << 4) | (b[1] << 2) | b[2]];
                 }
                 word[k >> 2] |= c << (8 * (k & 3));
             }
@@ -326,7 +355,7 @@ struct K1Scan { uint64_t *state; uint32_t ticket_base; uint64_t epoch; };
 __global__ __launch_bounds__(256) void k1_ref_desc(uint64_t nw, int n_frames, const uint64_t *__restrict__ chunk_base, const uint32_t *__restrict__ chunk_cnt,
                                                    const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_len,
                                                    PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, K1Summary *__restrict__ sum,
-                                                   uint32_t *__restrict__ n_targets, K1Scan sc)
+                                                   uint32_t *__restrict__ n_targets, K1Scan sc, const uint64_t *__restrict__ nt_off, K1Src *__restrict__ src_of)
 {
     __shared__ uint32_t s_tile, lds[4];
     __shared__ uint64_t s_pre;
@@ -346,8 +375,11 @@ __global__ __launch_bounds__(256) void k1_ref_desc(uint64_t nw, int n_frames, co
     const uint32_t g = (uint32_t)(w / n_frames), f = (uint32_t)(w % n_frames) + 1;
     const uint64_t base = chunk_base[w];
     const uint32_t at = (uint32_t)s_pre + ex;
+    const uint64_t o = nt_off[g];
+    const K1Src so{o, (uint32_t)(nt_off[g + 1] - o), 0u};
     for (uint32_t c = 0; c < cnt; ++c) {
         desc[at + c] = PackDesc{g, f, chunk_off[base + c], chunk_len[base + c]};
+        src_of[at + c] = so;
         padded[at + c] = padded_len(chunk_len[base + c]);
         len_out[at + c] = chunk_len[base + c];
     }
@@ -410,7 +442,7 @@ int layout_and_pack(pep_ctx *ctx, const NtSet &nt, int tab, const PackDesc *d_de
     const uint64_t tiles = ceil_div((uint64_t)cap + 1, 256);
     PEP_TRY(pep_lookback_begin(ctx, ctx->scan_state[0], tiles, (1u << 30) - 1, &sc.state, &sc.ticket_base, &sc.epoch));
     hipLaunchKernelGGL(k1_offsets, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, d_n, d_padded, cap, out.off.as<uint32_t>(), out.len.as<const uint32_t>(), d_sum, sc);
-    hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div((uint64_t)cap + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), tab,
+    hipLaunchKernelGGL(k1_pack, dim3((unsigned)ceil_div((uint64_t)cap + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), (const K1Src *)k1_src_of(d_desc, cap), tab,
                        d_desc, out.off.as<const uint32_t>(), d_n, cap, out.res.as<uint8_t>(), out.blk2seq.as<uint2>(), (const K1Summary *)d_sum, pin_sum);
     PEP_HIP(ctx, hipGetLastError());
     return PEP_OK;
@@ -464,7 +496,7 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
         PEP_TRY(dev_reserve(ctx, W[0], ((size_t)n + 1) * 4));
         PEP_TRY(dev_reserve(ctx, W[1], ((size_t)n + 1) * 4));
         DevBuf &D = ctx->d_k1_desc_q;              // the descriptors stay on the device (a buffer of their own): fetched when somebody asks for the host tables
-        PEP_TRY(dev_reserve(ctx, D, ((size_t)n + 3) * sizeof(PackDesc)));          // + the summary behind the descriptors
+        PEP_TRY(dev_reserve(ctx, D, (2 * (size_t)n + 4) * sizeof(PackDesc)));      // + the summary and the source records behind the descriptors
         PEP_TRY(pin_reserve(ctx, ctx->pin_k1q, sizeof(K1Summary) + ((size_t)n + 1) * 4));
         K1Summary *pin_sum = reinterpret_cast<K1Summary *>(ctx->pin_k1q.p);
         uint32_t *pin_len = reinterpret_cast<uint32_t *>(ctx->pin_k1q.p + sizeof(K1Summary));
@@ -473,7 +505,8 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
         const uint64_t upper = 2 * PEP_END_PAD + (nt.total + 2 * (uint64_t)n) / 3 + (uint64_t)n * (16 + PEP_SEQ_GAP);
         PEP_TRY(reserve_packed(ctx, ctx->q, n, upper));
         if (n) hipLaunchKernelGGL(k1_query_frames, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, tab,
-                                  D.as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + n), pin_len);
+                                  D.as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + n), pin_len,
+                                  k1_src_of(D.as<const PackDesc>(), n));
         else hipLaunchKernelGGL(k1_query_desc, dim3(1), dim3(64), 0, ctx->stream, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
                                 D.as<PackDesc>(), W[3].as<uint32_t>(), ctx->q.len.as<uint32_t>(), W[5].as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + n), pin_len);
         PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6], pin_sum));
@@ -563,7 +596,7 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     PEP_TRY(dev_reserve(ctx, W[2], (slots + 1) * 4));
     PEP_TRY(dev_reserve(ctx, W[3], (slots + 1) * 4));
     DevBuf &D = ctx->d_k1_desc_t;                  // the descriptors stay on the device (a buffer of their own: ws[] is the seed stage's next)
-    PEP_TRY(dev_reserve(ctx, D, (slots + 3) * sizeof(PackDesc)));                 // + the summary behind the descriptors
+    PEP_TRY(dev_reserve(ctx, D, (2 * slots + 4) * sizeof(PackDesc)));             // + the summary and the source records behind the descriptors
     PEP_TRY(pin_reserve(ctx, ctx->pin_k1, sizeof(K1Summary)));
     K1Summary *pin_sum = reinterpret_cast<K1Summary *>(ctx->pin_k1.p);
     PEP_TRY(dev_reserve(ctx, W[5], (nw + 2) * 4));
@@ -579,7 +612,8 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
             PEP_TRY(pep_lookback_begin(ctx, ctx->scan_state[0], tiles, (1u << 30) - 1, &sc.state, &sc.ticket_base, &sc.epoch));
             hipLaunchKernelGGL(k1_ref_desc, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, nw, nf, d_base, W[1].as<const uint32_t>(),
                                W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), D.as<PackDesc>(), W[6].as<uint32_t>(),
-                               ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + slots), W[5].as<uint32_t>() + nw, sc);         // W[5][nw] = number of targets
+                               ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + slots), W[5].as<uint32_t>() + nw, sc,
+                               nt.off.as<const uint64_t>(), k1_src_of(D.as<const PackDesc>(), (uint32_t)slots));         // W[5][nw] = number of targets
         }
         PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
                                 W[7], W[8], pin_sum));

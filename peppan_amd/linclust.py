@@ -2,7 +2,8 @@
 "representative, member" over the sequences of a FASTA file (every sequence appears once as a member)."""
 import numpy as np
 
-from .clust import readFasta
+from . import _native as N
+from .clust import blocks_of, read_blocks, sequence_of, _read_text
 from .uberBlast import get_context
 
 _NT = np.full(256, 4, dtype=np.uint8)
@@ -10,7 +11,7 @@ for _c, _v in zip('ACGTacgt', (0, 1, 2, 3, 0, 1, 2, 3)):
     _NT[ord(_c)] = _v
 _AA = np.full(256, 20, dtype=np.uint8)
 for _i, _c in enumerate('ACDEFGHIKLMNPQRSTVWY'):
-    _AA[ord(_c)] = _i
+    _AA[ord(_c)] = _AA[ord(_c.lower())] = _i              # (sequences are upper-cased before they are encoded: the table does it)
 
 
 def encode(seq, protein=False):
@@ -23,20 +24,26 @@ def looks_like_protein(seqs):
 
 
 def linclust_file(fasta, identity, coverage, device=None):
-    recs = readFasta(fasta)
-    names = [n for n, _ in recs]
-    seqs = [s for _, s in recs]
-    protein = looks_like_protein(seqs)
-    # all sequences encoded in one table look-up over their concatenation (an array per sequence cost a second per 300 k genes)
+    text = _read_text(fasta)
+    return linclust_text(text, blocks_of(text), identity, coverage, device)
+
+
+def linclust_text(text, blocks, identity, coverage, device=None):
+    """the relation over the records `blocks` of the FASTA text `text` (clust.blocks_of).  The sequences become one code array + offsets in one
+    C pass over the text (pep_fasta_scan); a text it does not take (non-ASCII) goes record by record through clust.sequence_of."""
+    names = [blk.name for blk in blocks]
+    n = len(names)
+    protein = looks_like_protein([sequence_of(blk) for blk in blocks[:50]])
+    table = _AA if protein else _NT
+    codes = None
     try:
-        text = ''.join(seqs).encode('ascii')
-        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
-        off[1:] = np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs)))
-        codes = ((_AA if protein else _NT)[np.frombuffer(text, dtype=np.uint8)] if len(text) else np.zeros(1, np.uint8), off)
-        n = len(seqs)
+        codes = N.fasta_scan(text.encode('ascii'), table, n)
     except UnicodeEncodeError:
-        codes = [encode(s, protein) for s in seqs]
-        n = len(codes)
+        pass
+    if codes is None:
+        codes = [encode(sequence_of(blk), protein) for blk in blocks]
+    elif len(codes[0]) == 0:
+        codes = (np.zeros(1, np.uint8), codes[1])
     base, k = (20, 7) if protein else (4, 17)
     rep, _ = get_context(device).linclust(codes, float(identity), float(coverage), base=base, k=k, m=20) if n else (np.zeros(0, np.uint32), None)
     return [(names[r], names[i]) for i, r in enumerate(rep.tolist())]

@@ -33,36 +33,50 @@ class EdgeTable:
     np.array(table, dtype=int), len(), iteration, indexing, comparison with a list of rows; tolist() gives the plain list."""
 
     def __init__(self, block):
-        self._block = np.ascontiguousarray(block, dtype=np.int64).reshape(-1, 3)
-        self._extra = []
+        self._parts = [np.ascontiguousarray(block, dtype=np.int64).reshape(-1, 3)]          # int64 blocks and plain lists of rows, in order
 
     def append(self, row):
-        self._extra.append(row)
+        if not isinstance(self._parts[-1], list):
+            self._parts.append([])
+        self._parts[-1].append(row)
 
     def extend(self, rows):
-        self._extra.extend(rows)
+        if not isinstance(self._parts[-1], list):
+            self._parts.append([])
+        self._parts[-1].extend(rows)
+
+    def extend_block(self, block):
+        """rows as an int64[m, 3] block (iterClust's edges of one identity level)"""
+        self._parts.append(np.ascontiguousarray(block, dtype=np.int64).reshape(-1, 3))
 
     def __len__(self):
-        return len(self._block) + len(self._extra)
+        return sum(len(p) for p in self._parts)
 
     def __iter__(self):
-        yield from self._block.tolist()
-        yield from self._extra
+        for p in self._parts:
+            yield from (p if isinstance(p, list) else p.tolist())
 
     def __getitem__(self, i):
         if isinstance(i, slice):
             return self.tolist()[i]
-        n = len(self._block)
         if i < 0:
             i += len(self)
-        return self._block[i].tolist() if i < n else self._extra[i - n]
+        for p in self._parts:
+            if i < len(p):
+                return p[i] if isinstance(p, list) else p[i].tolist()
+            i -= len(p)
+        raise IndexError('EdgeTable index out of range')
 
     def __array__(self, dtype=None, copy=None):
-        out = self._block if not self._extra else np.vstack([self._block, np.array(self._extra, dtype=dtype or np.int64).reshape(-1, 3)])
+        parts = [p if not isinstance(p, list) else np.array(p, dtype=dtype or np.int64).reshape(-1, 3) for p in self._parts if len(p)]
+        out = parts[0] if len(parts) == 1 else (np.vstack(parts) if parts else self._parts[0])
         return out.astype(dtype) if dtype is not None and out.dtype != np.dtype(dtype) else (out.copy() if copy else out)
 
     def tolist(self):
-        return self._block.tolist() + list(self._extra)
+        out = []
+        for p in self._parts:
+            out += p if isinstance(p, list) else p.tolist()
+        return out
 
     def __eq__(self, other):
         if isinstance(other, EdgeTable):
@@ -169,17 +183,40 @@ def identity_schedule(target):
     return [float(x) for x in np.round(np.arange(1., target - 0.005, -0.01), 5)]
 
 
+_TWO_INT_COLUMNS = re.compile(r'(?:[+-]?\d+\t[+-]?\d+\n)*')
+
+
 def _tab_pairs_after_first_line(tab):
     """(gene, exemplar) rows of a clust.tab file WITHOUT its first line, columns typed the way a header-inferring CSV reader
     types them (all-integer column -> ints).  The reference reads the file with pandas' default header handling
-    (PEPPAN.py:1786), so the first gene of every table silently never reaches clust.npy; downstream results depend on it."""
+    (PEPPAN.py:1786), so the first gene of every table silently never reaches clust.npy; downstream results depend on it.
+    -> int64[n, 2] when both columns are integers that fit (what PEPPAN's encoded gene names give), else a list of tuples."""
     with open(tab) as fin:
-        rows = [line.rstrip('\n').split('\t')[:2] for line in fin][1:]
+        text = fin.read()
+    if _TWO_INT_COLUMNS.fullmatch(text):                   # one C pass instead of a regular expression per cell (a million of them per level)
+        try:
+            return np.array(text.split()).astype(np.int64).reshape(-1, 2)[1:]
+        except (OverflowError, ValueError):
+            pass
+    rows = [line.split('\t')[:2] for line in text.split('\n')[:-1 if text.endswith('\n') else None]][1:]
     cols = [[r[0] for r in rows], [r[1] for r in rows]]
     for c in cols:
         if c and all(re.fullmatch(r'[+-]?\d+', x) for x in c):
             c[:] = [int(x) for x in c]
     return list(zip(*cols))
+
+
+def _canonical_ints(names):
+    """the integers n with str(n) among the names"""
+    out = []
+    for x in names:
+        try:
+            v = int(x)
+        except ValueError:
+            continue
+        if str(v) == x and -(1 << 63) <= v < (1 << 63):
+            out.append(v)
+    return np.array(out, dtype=np.int64)
 
 
 def iterClust(prefix, genes, geneGroup, params):
@@ -193,7 +230,18 @@ def iterClust(prefix, genes, geneGroup, params):
         exemplars = readFasta(current, headOnly=True)
         logger('Iterative clustering. {0} exemplars left with identity = {1}'.format(len(exemplars), level))
         label = int(min(1., level + 0.005) * 10000)
-        for gene, other in _tab_pairs_after_first_line(tab):
+        pairs = _tab_pairs_after_first_line(tab)
+        if isinstance(pairs, np.ndarray):                  # integer names: the level's edges as one block
+            pairs = pairs[pairs[:, 0] != pairs[:, 1]]
+            first = np.isin(pairs[:, 0], _canonical_ints(exemplars))
+            block = np.column_stack([np.where(first, pairs[:, 0], pairs[:, 1]), np.where(first, pairs[:, 1], pairs[:, 0]),
+                                     np.full(len(pairs), label, dtype=np.int64)])
+            if hasattr(geneGroup, 'extend_block'):
+                geneGroup.extend_block(block)
+            else:
+                geneGroup.extend(block.tolist())
+            continue
+        for gene, other in pairs:
             if gene != other:
                 geneGroup.append([gene, other, label] if str(gene) in exemplars else [other, gene, label])
     np.save('{0}.clust.npy'.format(prefix), np.array(geneGroup, dtype=int))

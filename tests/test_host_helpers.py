@@ -90,3 +90,72 @@ def test_edge_table_behaves_like_the_list_peppan_expects():
     assert a.shape == (12, 3) and a.dtype == np.dtype(int) and a[-2].tolist() == [100, 101, 9950] and e[10] == [100, 101, 9950]
     assert e.tolist() == rows.tolist() + [[100, 101, 9950], [200, 201, 9900]] and e[1:3] == rows[1:3].tolist()
     assert np.array(EdgeTable(np.zeros((0, 3), dtype=np.int64)), dtype=int).shape == (0, 3)
+
+
+def test_fasta_scan_equals_the_python_reader():
+    """pep_fasta_scan (the clusterer's input in one C pass) against clust.blocks_of / sequence_of + the code table, on the shapes a FASTA
+    file takes: leading junk, comment lines, blank lines, CRLF, lower case, a header without body, no final newline, '>' inside a line"""
+    from peppan_amd import _native as N, clust as CL, linclust as LC
+    rng = np.random.default_rng(5)
+    texts = [
+        '',
+        'no header at all\nACGT\n',
+        'junk line\n>a desc\nACGT\nacgtn\n>b\n\n# a comment\nAC GT\tA\r\n#>not a header\n>c\n>d x y\nTTTT',
+        '>only',
+        '>x\nAC>GT\n>y\nA\x1cC\x0bG\n',
+        '\n>late\nACGT\n',
+        '>p1\nMKV LAW\n>p2\nmkvlaw*\n',
+    ]
+    recs = []
+    for i in range(300):
+        seq = ''.join(rng.choice(list('ACGTacgtN-'), size=int(rng.integers(0, 200))))
+        lines = [seq[j:j + 60] for j in range(0, len(seq), 60)]
+        if i % 7 == 0:
+            lines.insert(len(lines) // 2, '# remark')
+        recs.append('>g%d some text\n%s%s' % (i, '\n'.join(lines), '\n' if lines else ''))
+    texts.append(''.join(recs))
+    for text in texts:
+        blocks = CL.blocks_of(text)
+        for table, protein in ((LC._NT, False), (LC._AA, True)):
+            want = [LC.encode(CL.sequence_of(b), protein) for b in blocks]
+            got = N.fasta_scan(text.encode('ascii'), table, len(blocks))
+            assert got is not None, text[:40]
+            codes, off = got
+            assert len(off) == len(blocks) + 1 and off[0] == 0
+            for k, w in enumerate(want):
+                assert np.array_equal(codes[int(off[k]):int(off[k + 1])], w), (text[:40], k)
+            assert int(off[-1]) == sum(map(len, want))
+        # a record count that does not fit the text is refused, not truncated
+        assert N.fasta_scan(text.encode('ascii'), LC._NT, len(blocks) + 1) is None
+        if blocks:
+            assert N.fasta_scan(text.encode('ascii'), LC._NT, len(blocks) - 1) is None
+    # non-ASCII sequence bytes: the caller's own rules apply
+    assert N.fasta_scan('>a\nACéT\n'.encode('utf-8'), LC._NT, 1) is None
+
+
+def test_edge_table_blocks_and_the_tab_reader(tmp_path):
+    """EdgeTable.extend_block keeps the order of appends; the one-pass reader of clust.tab gives what the per-cell reader gives"""
+    from peppan_amd import pipeline as PL
+    e = PL.EdgeTable(np.array([[1, 2, 10000], [3, 4, 10000]]))
+    e.append([5, 6, 9900])
+    e.extend_block(np.array([[7, 8, 9800], [9, 10, 9800]]))
+    e.append([11, 12, 9700])
+    want = [[1, 2, 10000], [3, 4, 10000], [5, 6, 9900], [7, 8, 9800], [9, 10, 9800], [11, 12, 9700]]
+    assert e.tolist() == want and list(e) == want and len(e) == 6 and e == want
+    assert [e[i] for i in range(-6, 6)] == want + want and e[1:3] == want[1:3]
+    assert np.array_equal(np.array(e, dtype=int), np.array(want))
+    with pytest.raises(IndexError):
+        e[6]
+    tab = tmp_path / 'x.clust.tab'
+    for text, typed in (('1\t1\n10\t1\n-3\t+7\n', np.ndarray), ('1\t1\n10\ta\n3\t7\n', list), ('1\t1\n', np.ndarray), ('', np.ndarray),
+                        ('1\t1\n99999999999999999999\t1\n', list), ('1\t1\n2\t1', list), ('a\tb\nc\td\n', list)):
+        tab.write_text(text)
+        got = PL._tab_pairs_after_first_line(str(tab))
+        assert isinstance(got, typed), text
+        rows = [line.split('\t')[:2] for line in text.splitlines()][1:]
+        cols = [[r[0] for r in rows], [r[1] for r in rows]]
+        for c in cols:
+            if c and all(x.lstrip('+-').isdigit() for x in c):
+                c[:] = [int(x) for x in c]
+        assert [tuple(r) for r in (got.tolist() if isinstance(got, np.ndarray) else got)] == list(zip(*cols)), text
+    assert PL._canonical_ints(['12', '012', 'x', '-4', '+5', '7 ']).tolist() == [12, -4]
