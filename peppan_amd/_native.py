@@ -165,6 +165,15 @@ def _pack(seqs):
         return (res if res.size else np.zeros(1, dtype=np.uint8)), np.ascontiguousarray(off, dtype=np.uint64)
     n = len(seqs)
     off = np.zeros(n + 1, dtype=np.uint64)
+    if n >= 4096 and isinstance(seqs, list):                         # big lists of str / bytes: lengths and ONE copy of the bytes in two C loops
+        from .hittable import _pyrows
+        lens = np.zeros(n, dtype=np.int64)
+        total = _pyrows().pep_strs_measure(seqs, lens.ctypes.data)
+        if total >= 0:
+            res = np.empty(max(total, 1), dtype=np.uint8)
+            if _pyrows().pep_strs_pack(seqs, res.ctypes.data, total) == 0:
+                off[1:] = np.cumsum(lens)
+                return res, off
     if n and all(isinstance(s, str) for s in seqs):                  # one join + one buffer view instead of one array per sequence
         off[1:] = np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=n))
         res = np.frombuffer(''.join(seqs).encode('ascii'), dtype=np.uint8)

@@ -181,3 +181,59 @@ Py_ssize_t pep_genes_scan(PyObject *priority, PyObject *genes, PyObject *names_o
     }
     return n;
 }
+
+/* ---- the input of K13 (pep_sha1) and its output as PEPPAN wants it ------------------------------------------------------------------------
+ * pep_strs_measure: total number of bytes of a list of str (ASCII only) / bytes objects, lengths written to len_out[0 .. n); -2 when an
+ * element is something else (the caller then packs the plain way), -1 with an exception set.
+ * pep_strs_pack: their bytes, back to back, into out (one copy; ''.join(seqs).encode() makes two and holds both). */
+int64_t pep_strs_measure(PyObject *seqs, int64_t *len_out)
+{
+    if (!PyList_Check(seqs)) { PyErr_SetString(PyExc_TypeError, "pep_strs_measure: list expected"); return -1; }
+    const Py_ssize_t n = PyList_GET_SIZE(seqs);
+    int64_t total = 0;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *s = PyList_GET_ITEM(seqs, i);
+        Py_ssize_t L;
+        if (PyUnicode_Check(s)) {
+            if (PyUnicode_READY(s) < 0) return -1;
+            if (!PyUnicode_IS_ASCII(s)) return -2;
+            L = PyUnicode_GET_LENGTH(s);
+        } else if (PyBytes_Check(s)) L = PyBytes_GET_SIZE(s);
+        else return -2;
+        len_out[i] = (int64_t)L;
+        total += (int64_t)L;
+    }
+    return total;
+}
+
+int pep_strs_pack(PyObject *seqs, uint8_t *out, int64_t cap)
+{
+    if (!PyList_Check(seqs)) { PyErr_SetString(PyExc_TypeError, "pep_strs_pack: list expected"); return -1; }
+    const Py_ssize_t n = PyList_GET_SIZE(seqs);
+    int64_t at = 0;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *s = PyList_GET_ITEM(seqs, i);
+        const void *src;
+        Py_ssize_t L;
+        if (PyUnicode_Check(s) && PyUnicode_IS_ASCII(s)) { src = PyUnicode_DATA(s); L = PyUnicode_GET_LENGTH(s); }
+        else if (PyBytes_Check(s)) { src = PyBytes_AS_STRING(s); L = PyBytes_GET_SIZE(s); }
+        else return -2;
+        if (at + (int64_t)L > cap) { PyErr_SetString(PyExc_IndexError, "pep_strs_pack: output buffer too small"); return -1; }
+        memcpy(out + at, src, (size_t)L);
+        at += (int64_t)L;
+    }
+    return 0;
+}
+
+/* [int.from_bytes(digest[w * i : w * (i + 1)], 'big') for i in range(n)] in one C loop (five million 160-bit integers: 2 s as a comprehension) */
+PyObject *pep_digest_ints(const uint8_t *digest, Py_ssize_t n, Py_ssize_t width)
+{
+    PyObject *out = PyList_New(n);
+    if (!out) return NULL;
+    for (Py_ssize_t i = 0; i < n; ++i) {
+        PyObject *v = _PyLong_FromByteArray(digest + width * i, (size_t)width, 0, 0);
+        if (!v) { Py_DECREF(out); return NULL; }
+        PyList_SET_ITEM(out, i, v);
+    }
+    return out;
+}

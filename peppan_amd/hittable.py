@@ -27,6 +27,12 @@ def _pyrows():
         lib.pep_rows_fill.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.py_object, C.py_object] + [C.c_void_p] * 12 + [C.c_int] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p]
         lib.pep_genes_scan.restype = C.c_ssize_t
         lib.pep_genes_scan.argtypes = [C.py_object, C.py_object, C.py_object] + [C.c_void_p] * 5 + [C.c_ssize_t]
+        lib.pep_strs_measure.restype = C.c_int64
+        lib.pep_strs_measure.argtypes = [C.py_object, C.c_void_p]
+        lib.pep_strs_pack.restype = C.c_int
+        lib.pep_strs_pack.argtypes = [C.py_object, C.c_void_p, C.c_int64]
+        lib.pep_digest_ints.restype = C.py_object
+        lib.pep_digest_ints.argtypes = [C.c_void_p, C.c_ssize_t, C.c_ssize_t]
         _PYROWS = lib
     return _PYROWS
 

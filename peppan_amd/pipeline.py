@@ -23,7 +23,9 @@ def gene_hashes(seqs, ctx=None):
     """the integer PEPPAN stores per gene and breaks priority ties with: int(hashlib.sha1(seq).hexdigest(), 16)
     (PEPPAN.py:62, 1019), computed for the whole list on the GPU (K13 `pep_sha1`)"""
     ctx = ctx or get_context()
-    return [int.from_bytes(d.tobytes(), 'big') for d in ctx.sha1(seqs)]
+    digests = np.ascontiguousarray(ctx.sha1(seqs))
+    from .hittable import _pyrows
+    return _pyrows().pep_digest_ints(digests.ctypes.data, len(digests), 20)             # (one C loop; five million of them)
 
 
 class EdgeTable:

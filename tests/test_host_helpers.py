@@ -159,3 +159,25 @@ def test_edge_table_blocks_and_the_tab_reader(tmp_path):
                 c[:] = [int(x) for x in c]
         assert [tuple(r) for r in (got.tolist() if isinstance(got, np.ndarray) else got)] == list(zip(*cols)), text
     assert PL._canonical_ints(['12', '012', 'x', '-4', '+5', '7 ']).tolist() == [12, -4]
+
+
+def test_packing_of_big_lists_and_digest_integers():
+    """the C loops behind _pack (lists of >= 4096 str / bytes) and gene_hashes' integers against their Python statements"""
+    from peppan_amd import _native as N
+    from peppan_amd.hittable import _pyrows
+    rng = np.random.default_rng(11)
+    seqs = [''.join(rng.choice(list('ACGTN'), size=int(rng.integers(0, 40)))) for _ in range(5000)]
+    for lst in (seqs, [s.encode() for s in seqs], [s if i % 2 else s.encode() for i, s in enumerate(seqs)]):
+        res, off = N._pack(lst)
+        joined = b''.join(s if isinstance(s, bytes) else s.encode() for s in lst)
+        assert res[:len(joined)].tobytes() == joined and int(off[-1]) == len(joined)
+        assert np.array_equal(np.diff(off.astype(np.int64)), [len(s) for s in lst])
+    with pytest.raises(UnicodeEncodeError):
+        N._pack(seqs[:4999] + ['ACé'])
+    res, off = N._pack([''] * 5000)
+    assert int(off[-1]) == 0 and res.size >= 1
+    d = rng.integers(0, 256, (1000, 20), dtype=np.uint8)
+    d[0] = 0
+    d[1] = 255
+    assert _pyrows().pep_digest_ints(d.ctypes.data, len(d), 20) == [int.from_bytes(x.tobytes(), 'big') for x in d]
+    assert _pyrows().pep_digest_ints(d.ctypes.data, 0, 20) == []
