@@ -150,16 +150,22 @@ def main_map(args, rank, local_rank, world):
     import torch.distributed as dist
     steps = args.steps if '--steps' in sys.argv else 2
     warmup = args.warmup if '--warmup' in sys.argv else 1
+    share = os.environ.get('PEPPAN_BENCH_SHARE_GPU') == '1'          # test hook for a one-GPU box (see main): all ranks on device 0, gloo
+    if share:
+        local_rank = 0
     if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if share:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         dist.barrier()
     torch.cuda.synchronize()
     r = map_workload(args, rank, world, local_rank, args.map_genomes, steps, warmup)
     torch.cuda.synchronize()
     dt = r['seconds']
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=torch.device('cuda', local_rank))
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device('cpu') if share else torch.device('cuda', local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank == 0:
