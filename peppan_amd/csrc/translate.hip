@@ -25,6 +25,19 @@ __device__ __forceinline__ int base2(uint8_t ch)
     return ch == '-' ? -2 : -1;
 }
 
+// four characters at once (one per byte of w): their codes packed two bits each, first character (byte 0) in bits 7:6 - complemented when
+// `rev` - and a mask of the characters that are not A, C, G, T in either case, first character = bit 3.  Same rule as base2.
+__device__ __forceinline__ void nt4(uint32_t w, bool rev, uint32_t &pk, uint32_t &bad)
+{
+    const uint32_t u = w & 0xDFDFDFDFu;
+    uint32_t code = ((u >> 1) ^ (u >> 2)) & 0x03030303u;
+    const uint32_t diff = u ^ __builtin_amdgcn_perm(0u, 0x54474341u, code);            // byte i: the letter that code i stands for
+    const uint32_t nz = ((((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff) >> 7) & 0x01010101u;
+    if (rev) code ^= 0x03030303u;
+    pk = (code * 0x40100401u) >> 24;
+    bad = (nz * 0x08040201u) >> 24;
+}
+
 // residue `aa` of frame `frame` (1..6) of the sequence nt[0..L): returns code 0..25, X for ambiguous/partial codons;
 // *is_gap set when the codon contains '-' (the reference emits '-', which is not an 'X' for frame choice)
 __device__ __forceinline__ int translate_at(const uint8_t *__restrict__ nt, int L, int frame, int aa, int tab, bool *is_gap)
@@ -95,13 +108,12 @@ __global__ __launch_bounds__(256) void k1_query_frames(const uint8_t *__restrict
     const int L = (int)(off[g + 1] - o);           // (upload_nt keeps a sequence below 2^31 - 256 nucleotides)
     // Same geometry as k1_pack: the wavefront copies the 1536 + 2 nucleotide bytes behind 512 codon positions into LDS with aligned dword
     // loads, then every lane looks at eight positions.  The three frames are walked together: codon a of frames 1, 2, 3 is bytes 3a .. 3a+4.
-    // The codon table sits in LDS too (one copy per wavefront): the first version read its bytes from global memory five at a time and
-    // looked the codons up in the constant array with per-lane indices, i.e. a chain of two global round trips per 128 positions.
+    // The first version read its bytes from global memory five at a time and looked the codons up in the constant array with per-lane
+    // indices, i.e. a chain of two global round trips per 128 positions; the second judged the lane's 26 characters one by one (600 vector
+    // instructions per chunk).  Now: four characters per register (nt4), and "is this codon a stop" is a bit of a 64-bit mask.
     __shared__ uint32_t stage_all[4][392];
-    __shared__ uint32_t codon_all[4][64];
-    uint32_t *stage = stage_all[threadIdx.x >> 6], *codon = codon_all[threadIdx.x >> 6];
-    const uint8_t *sb = reinterpret_cast<const uint8_t *>(stage);
-    codon[lane] = c_codon[tab][lane];
+    uint32_t *stage = stage_all[threadIdx.x >> 6];
+    const unsigned long long stop_codon = __ballot(c_codon[tab][lane] == 23);
     const int na1 = (int)frame_len(L, 1), na2 = (int)frame_len(L, 2), na3 = (int)frame_len(L, 3);
     uint32_t x1 = 0, x2 = 0, x3 = 0;
     for (int c0 = 0; c0 + 1 < na1; c0 += 512) {                // s[:-1] of every frame; frame 1 is the longest
@@ -114,9 +126,27 @@ __global__ __launch_bounds__(256) void k1_query_frames(const uint8_t *__restrict
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        int b[26];
+        // the lane's characters 0 .. 27 (26 are used): codes two bits each (character j at bits 55-2j, 54-2j), one bit each for "not A, C, G, T"
+        // and for '-' (character j at bit 27-j)
+        uint32_t raw[8];
 #pragma unroll
-        for (int k = 0; k < 26; ++k) { const int p = lo + 24 * lane + k; b[k] = p < L ? base2(sb[p - lo + shift]) : -1; }
+        for (int k = 0; k < 8; ++k) raw[k] = stage[6 * lane + k];
+        unsigned long long codes = 0;
+        uint32_t bad = 0, gap = 0;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const uint32_t w = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)shift);
+            uint32_t pk, bd;
+            nt4(w, false, pk, bd);
+            const uint32_t g = w ^ 0x2D2D2D2Du;
+            const uint32_t is_gap = (~((((g & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | g)) >> 7) & 0x01010101u;
+            codes |= (unsigned long long)pk << (48 - 8 * k);
+            bad |= bd << (24 - 4 * k);
+            gap |= ((is_gap * 0x08040201u) >> 24) << (24 - 4 * k);
+        }
+        const int nv = min(max(L - (lo + 24 * lane), 0), 28);
+        bad |= (1u << (28 - nv)) - 1u;                                    // characters behind the sequence's end
+        gap &= ~((1u << (28 - nv)) - 1u);
         const int lim[3] = {na1, na2, na3};
         uint32_t *cnt[3] = {&x1, &x2, &x3};
 #pragma unroll
@@ -124,9 +154,10 @@ __global__ __launch_bounds__(256) void k1_query_frames(const uint8_t *__restrict
             const int a = c0 + 8 * lane + h;
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
-                const int u = b[3 * h + f], v = b[3 * h + f + 1], w = b[3 * h + f + 2];
-                const bool gap = (u == -2) | (v == -2) | (w == -2);
-                const bool stop = !gap && ((u | v | w) < 0 || codon[((u << 4) | (v << 2) | w) & 63] == 23u);
+                const int j = 3 * h + f;
+                const uint32_t idx = (uint32_t)(codes >> (50 - 2 * j)) & 63u;
+                const uint32_t b3 = (bad >> (25 - j)) & 7u, g3 = (gap >> (25 - j)) & 7u;
+                const bool stop = g3 == 0u && (b3 != 0u || ((stop_codon >> idx) & 1ull));
                 *cnt[f] += (a + 1 < lim[f] && stop) ? 1u : 0u;
             }
         }
@@ -225,49 +256,67 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
     // 256 contiguous bytes per instruction), then every lane translates eight residues out of LDS and stores 8 bytes.  Reading the
     // bytes straight from global memory (three byte loads per residue, 24 bytes apart from lane to lane) made every instruction touch
     // 24 cache lines: both sides of K1 ran at the same 230 G residues/s whatever their size.
+    // A lane's 24 characters are handled four to a register (nt4): character by character the kernel spent 850 vector instructions per
+    // chunk - at four cycles per wave64 instruction that, not memory, was its time.
     __shared__ uint32_t stage_all[4][392];
     uint32_t *stage = stage_all[threadIdx.x >> 6];
-    const uint8_t *sb = reinterpret_cast<const uint8_t *>(stage);
     const int frame = (int)d.frame;
     const bool fwd = frame <= 3;
     const int fo = fwd ? frame - 1 : frame - 4;
     for (uint32_t c0 = 0; c0 < next - start; c0 += 512) {
         const int P0 = fo + 3 * (int)(d.aa_off + c0);                    // first nucleotide position (in reading direction) of the chunk
-        // window of source bytes [lo, lo + 1536) that holds positions P0 .. P0 + 1535 (forward: as they are; reverse: mirrored)
-        const int lo = fwd ? P0 : max(0, L - 1 - (P0 + 1535));
+        // window of source bytes [lo, lo + 1536) that holds positions P0 .. P0 + 1535 (forward: as they are; reverse: mirrored - lo may
+        // lie in front of the sequence then: those bytes are not fetched and not used)
+        const int lo = fwd ? P0 : L - 1 - (P0 + 1535);
         int shift = 0;
-        if (c0 < d.len && lo < L) {
-            const uintptr_t A = reinterpret_cast<uintptr_t>(src + lo);
+        if (c0 < d.len && P0 < L) {
+            const uintptr_t A = reinterpret_cast<uintptr_t>(src) + (intptr_t)lo;
             shift = (int)(A & 3u);
             const uint32_t *al = reinterpret_cast<const uint32_t *>(A - shift);
+            const int first_dw = lo < 0 ? (-lo + shift) >> 2 : 0;         // (the dword that holds the sequence's first byte starts inside the buffer)
             const int n_dw = (min(1536, L - lo) + shift + 3) >> 2;        // <= 385; the buffer is padded by 64 bytes behind the last sequence
-            for (int x = lane; x < n_dw; x += 64) stage[x] = al[x];
+            for (int x = first_dw + lane; x < n_dw; x += 64) stage[x] = al[x];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const uint32_t x0 = c0 + 8 * lane;
         if (x0 < next - start) {
-            uint32_t word[2] = {0, 0};
+            // the lane's 24 characters in source order: seven dwords from LDS, shifted down by the window's misalignment
+            const int di = fwd ? 6 * lane : 378 - 6 * lane;
+            uint32_t raw[7], ch[6];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                uint32_t c = PEP_PAD_CODE;
-                if (x0 + k < d.len) {
-                    int b[3];
+            for (int k = 0; k < 7; ++k) raw[k] = stage[di + k];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        const int p = P0 + 3 * (8 * lane + k) + j;
-                        int v = -1;
-                        if (p < L) {
-                            v = base2(sb[(fwd ? p - lo : (L - 1 - p) - lo) + shift]);
-                            if (!fwd && v >= 0) v = 3 - v;
-                        }
-                        b[j] = v;
-                    }
-                    const bool gap = (b[0] == -2) | (b[1] == -2) | (b[2] == -2);
-                    c = (gap || (b[0] | b[1] | b[2]) < 0) ? 23u : codon[(b[0] << 4) | (b[1] << 2) | b[2]];
+            for (int k = 0; k < 6; ++k) ch[k] = __builtin_amdgcn_alignbyte(raw[k + 1], raw[k], (uint32_t)shift);
+            if (!fwd) {                                                   // reading direction = descending source order
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t lo_w = __builtin_bswap32(ch[5 - k]), hi_w = __builtin_bswap32(ch[k]);
+                    ch[k] = lo_w; ch[5 - k] = hi_w;
                 }
-                word[k >> 2] |= c << (8 * (k & 3));
+            }
+            const int n_valid = min(max(L - (P0 + 24 * lane), 0), 24);          // characters of the lane that lie inside the sequence
+            const int n_res = (int)min(max((int64_t)d.len - (int64_t)x0, (int64_t)0), (int64_t)8);
+            uint32_t word[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                                 // twelve characters = four codons
+                uint32_t pk[3], bad[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) nt4(ch[3 * h + k], !fwd, pk[k], bad[k]);
+                const uint32_t codes = (pk[0] << 16) | (pk[1] << 8) | pk[2];
+                uint32_t bad12 = (bad[0] << 8) | (bad[1] << 4) | bad[2];
+                const int nv = min(max(n_valid - 12 * h, 0), 12);
+                bad12 |= (1u << (12 - nv)) - 1u;                          // characters behind the sequence's end
+                uint32_t w = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    uint32_t c = codon[(codes >> (18 - 6 * k)) & 63u];
+                    if ((bad12 >> (9 - 3 * k)) & 7u) c = 23u;
+                    if (4 * h + k >= n_res) c = PEP_PAD_CODE;
+                    w |= c << (8 * k);
+                }
+                word[h] = w;
             }
             *reinterpret_cast<uint2 *>(res + start + x0) = make_uint2(word[0], word[1]);
         }
