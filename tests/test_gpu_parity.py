@@ -149,6 +149,39 @@ def test_k1_translation_golden_and_oracle(ctx):
         assert got == exp
 
 
+def test_k1_random_shapes_vs_oracle(ctx):
+    """K1 on shapes the byte-parallel translation has to get right: lengths 0 .. 40 and around the 512-codon chunk and the 1000-residue
+    cut, unaligned starts, lower case, N and '-' anywhere, the first sequence of the buffer read backwards (frames 4-6), both tables"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(41)
+    alphabet = np.array(list('ACGT' * 12 + 'acgt' * 3 + 'NnRY-'))
+    lengths = list(range(0, 41)) + [1533, 1534, 1535, 1536, 1537, 1538, 1539, 1540, 2999, 3000, 3001, 3002, 3003, 3004, 3073, 4611, 6150] + \
+        [int(x) for x in rng.integers(41, 5000, 60)]
+    seqs = [''.join(rng.choice(alphabet, size=n)).encode() for n in lengths]
+    clean = [bytes(rng.choice(np.frombuffer(b'ACGT', dtype=np.uint8), size=n)) for n in (7, 1536, 3001, 4000, 6200)]       # stop-free stretches are rare in random text:
+    seqs += [s.replace(b'TAA', b'TCA').replace(b'TAG', b'TCG').replace(b'TGA', b'TCA') for s in clean]                   # long frames without a cut
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    for table in (11, 4):
+        for frames in (6, 3):
+            ctx.set_query_nt(seqs, table)
+            ctx.set_ref_nt(seqs, frames, table)
+            ctx.translate()
+            qa, qo = ctx.query_aa()
+            qm = ctx.query_meta()
+            assert len(qm) == len(seqs)
+            for i, m in enumerate(qm):
+                f, aa = O.query_frame(seqs[i].decode(), table)
+                assert m['frame'] == f and ''.join(chr(65 + c) for c in qa[int(qo[i]):int(qo[i + 1])]) == aa.replace('-', 'X'), (table, i, len(seqs[i]))
+            ta, to = ctx.target_aa()
+            exp = []
+            for n, sq in enumerate(seqs):
+                for f, aa_ in zip(range(1, frames + 1), O.translate_frames(sq.decode(), range(1, frames + 1), table)):
+                    exp += [(n, f, o, c.replace('-', 'X')) for o, c in O.ref_chunks(aa_)]
+            got = [(int(m['seq']), int(m['frame']), int(m['chunk_off']), ''.join(chr(65 + c) for c in ta[int(to[i]):int(to[i + 1])])) for i, m in enumerate(ctx.target_meta())]
+            assert got == exp, (table, frames)
+
+
 def test_search_from_nucleotides_1k(ctx):
     """BASELINE config 1k synthetic 1 kb genes, all-vs-all, from nucleotides: K1..K8 against the oracle"""
     from peppan_amd import _native as N, synth
