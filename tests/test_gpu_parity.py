@@ -324,8 +324,10 @@ def test_k9_linclust_vs_oracle(ctx, min_id):
     assert np.array_equal(g_rep, o_rep) and g_st == o_st
 
 
-def test_getclust_and_iterclust_on_gpu(tmp_path, monkeypatch):
-    """clust.getClust / pipeline.iterClust with the GPU clusterer == the same host code over the oracle's relation"""
+@pytest.mark.parametrize('translate', [False, True])
+def test_getclust_and_iterclust_on_gpu(tmp_path, monkeypatch, translate):
+    """clust.getClust / pipeline.iterClust with the GPU clusterer == the same host code over the oracle's relation; translate = clust -a:
+    the first-frame proteins are clustered (base 20, k 7; lower-case and comment lines in the file on the nucleotide side)"""
     import io, contextlib
     from peppan_amd import clust as CL, pipeline as PL, linclust as LC, synth
     from oracle import oracle as O
@@ -333,18 +335,31 @@ def test_getclust_and_iterclust_on_gpu(tmp_path, monkeypatch):
     names, seqs = synth.make_genes(1200, 0, seed=31)
     names = [str(i) for i in range(len(seqs))]
     with open('genes.fa', 'w') as f:
-        for n, s in zip(names, seqs):
-            f.write('>%s\n%s\n' % (n, s.decode()))
+        f.write('text in front of the first record\n')
+        for k, (n, s) in enumerate(zip(names, seqs)):
+            t = s.decode()
+            if k % 5 == 0:
+                t = t.lower()
+            lines = [t[j:j + 70] for j in range(0, len(t), 70)]
+            if k % 11 == 0:
+                lines.insert(1, '# a remark')
+            f.write('>%s description\n%s\n' % (n, '\n'.join(lines)))
+    aa20 = np.full(256, 20, dtype=np.uint8)
+    for i, c in enumerate('ACDEFGHIKLMNPQRSTVWY'):
+        aa20[ord(c)] = i
 
     def oracle_fn(fasta, identity, coverage, n_thread):
         recs = CL.readFasta(fasta)
-        rep, _ = O.linclust([O.nt_codes(s) for _, s in recs], float(identity), float(coverage))
+        if translate:
+            rep, _ = O.linclust([aa20[np.frombuffer(s.encode(), dtype=np.uint8)] for _, s in recs], float(identity), float(coverage), base=20, k=7, m=20)
+        else:
+            rep, _ = O.linclust([O.nt_codes(s) for _, s in recs], float(identity), float(coverage))
         return [(recs[r][0], recs[i][0]) for i, r in enumerate(rep.tolist())]
     out = {}
     for tag, fn in (('gpu', None), ('ora', oracle_fn)):
         with contextlib.redirect_stderr(io.StringIO()):
             groups = [[0, 999999, 10000]]
-            ex = PL.iterClust(tag, 'genes.fa', groups, dict(identity=0.9, coverage=0.8, n_thread=1, translate=False, cluster_fn=fn))
+            ex = PL.iterClust(tag, 'genes.fa', groups, dict(identity=0.9, coverage=0.8, n_thread=1, translate=translate, cluster_fn=fn))
         out[tag] = (open(ex).read(), open(tag + '.clust.tab').read(), np.load(tag + '.clust.npy').tolist())
     assert out['gpu'] == out['ora']
     assert out['gpu'][0].count('>') < 1200 and len(out['gpu'][2]) > 50
