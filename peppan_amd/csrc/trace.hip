@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void gapless_check(const uint32_t *__restrict_
 // 4-byte loads is paid once per 8 * WALK_AHEAD cells of a diagonal run, not once per word.  (Keeping single loads in flight across
 // iterations does not work: rotating the word registers reads them, which makes the compiler wait for every outstanding load.)
 #define WALK_AHEAD 8
+#ifndef WALK_LANES               // (16 and 32 measured at the end of round 3 with -DWALK_LANES: no difference, tools/ab/variants.sh)
 #define WALK_LANES 64         // alignments per wavefront: few, so that many wavefronts overlap their load latencies (see above)
+#endif
 __global__ __launch_bounds__(WALK_LANES) void walk(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, const int4 *__restrict__ sw,
                                            const uint64_t *__restrict__ dir_off, const uint32_t *__restrict__ dirs, const int32_t *__restrict__ mode,
                                            const uint64_t *__restrict__ run_off, uint32_t *__restrict__ runs)
