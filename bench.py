@@ -276,7 +276,7 @@ def main():
     # else; the other phases are measured in a loop of their own behind it (phase_timers below)
     ctx.set_timing(1)
     t0 = time.perf_counter()
-    keys = ('candidates', 'cells', 'cells_swept', 'cells_swept_trace', 'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total',
+    keys = ('candidates', 'candidates_settled', 'cells', 'cells_settled', 'cells_swept', 'cells_swept_trace', 'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total',
             'hits', 'dir_bytes', 'tracebacks', 'tracebacks_gapless', 'seed_hits', 'target_residues', 'query_residues', 'ms_host_translate', 'ms_host_search', 'ms_host_exchange', 'ms_host_merge')
     acc = dict.fromkeys(keys, 0.0)
     t_uf = 0.0
@@ -304,11 +304,11 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tot = torch.tensor([acc['candidates'], acc['cells']], dtype=torch.float64, device=dev)
+        tot = torch.tensor([acc['candidates'], acc['cells'] - acc['cells_settled']], dtype=torch.float64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_pairs, total_cells = float(tot[0].item()), float(tot[1].item())
     else:
-        total_pairs, total_cells = float(acc['candidates']), float(acc['cells'])
+        total_pairs, total_cells = float(acc['candidates']), float(acc['cells'] - acc['cells_settled'])        # (cells the score pass sweeps)
 
     parity = None
     if rank == 0 and cpu_line is not None:
@@ -457,7 +457,7 @@ def main():
         # algorithmic bytes per launch, SURVEY.md 8(d): SW = sum over pairs of (Lq + Lr) residue bytes + 64 B per reported hit;
         # seed join = 1 B + 8 B index entry per target residue + 8 B per raw seed hit
         rl = [entry('sw_trace_kernel', 'K5 traceback pass: sub-band SW + 4-bit codes over the selected pairs that are not one ungapped run (rule 5a), four per wavefront', ms_tr, ((acc['tracebacks'] - acc['tracebacks_gapless']) / K) * 2 * Lq + hits_step * 64, 'v'),
-              entry('sw_score_kernel', 'K5 score pass: banded SW over all candidate pairs', ms_sw, (acc['candidates'] / K) * 2 * Lq + hits_step * 64, 'v'),
+              entry('sw_score_kernel', 'K5 score pass: banded SW over the candidate pairs that are not identical sequences (those are settled by comparison: candidates_settled)', ms_sw, ((acc['candidates'] - acc['candidates_settled']) / K) * 2 * Lq + hits_step * 64, 'v'),
               entry('seed_match<10>', 'K4a: target seeds streamed through the query index (one launch per seed shape)', ms_match,
                     9.0 * acc['target_residues'] / K + 8.0 * acc['seed_hits'] / K / max(1, n_shapes))]
         rl.sort(key=lambda e: -e['ms_per_launch'])
@@ -473,12 +473,13 @@ def main():
                                    'min_id 0.45 min_ratio 0.25 top-k 10 x 5 splits' % (args.genes, args.gene_len),
                        'queries_per_rank': shard.q1 - shard.q0, 'reference_genes_per_rank': shard.g1 - shard.g0,
                        'parallelism': 'grid %d query shards x %d reference shards, one all-gather of the hit tables%s' % (shard.R, shard.C, ' + exact top-k merge' if shard.C > 1 else ' (query shards only: the tables concatenate)')},
-            'sw_cell_updates_per_s_per_gpu': acc['cells'] / (acc['ms_sw'] * 1e-3) if acc['ms_sw'] else None,
+            'sw_cell_updates_per_s_per_gpu': (acc['cells'] - acc['cells_settled']) / (acc['ms_sw'] * 1e-3) if acc['ms_sw'] else None,
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
             'hits_per_step': float(len(allh)), 'clusters': int(len(np.unique(labels))), 'candidates_per_step': acc['candidates'] / K,
             # units that do not move with internal filters (value counts the candidates the pre-filter lets through):
             'hits_per_s': float(len(allh)) * K / dt, 'gene_pairs_all_vs_all_per_s': float(args.genes) * float(args.genes) * K / dt,
             'tracebacks_per_step': acc['tracebacks'] / K, 'tracebacks_gapless_per_step': acc['tracebacks_gapless'] / K,
+            'candidates_settled_per_step': acc['candidates_settled'] / K,      # identical pairs: scored by comparison, not swept (their cells are not in the cell rates)
             'steady_state': True, 'settle_calls': 500,
             'value_definition': 'candidate (query, target-frame, band) pairs entering gapped Smith-Waterman per second of step wall time (SURVEY.md 8d-i); '
                                 'the pre-filter in front of that stage decides how many there are - see same_unit_as_round1; hits_per_s and '

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 7
+#define PEP_ABI_VERSION 8
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -88,9 +88,11 @@ typedef struct {
     int32_t stage1_min;           /* first stage of the ungapped pre-filter (only with ungapped_min > 0): the extension to the right of a seed hit must
                                      have reached this score after its first 16 residues - the seed and a few residues behind it - or the hit is
                                      dropped before the rest of its windows is fetched (chance hits of the reduced alphabet); 0 = off */
-    int32_t reserved2;            /* test switch, 0 in production: 1 makes the alignment stage synchronise with the host after its selection step and size
-                                     the traceback buffers exactly (what it does by itself when its upper bounds would cost too much memory) instead of
-                                     running from the candidate count to the result sizes without a host round trip */
+    int32_t reserved2;            /* test switches (bits), 0 in production: bit 0 makes the alignment stage synchronise with the host after its selection
+                                     step and size the traceback buffers exactly (what it does by itself when its upper bounds would cost too much
+                                     memory) instead of running from the candidate count to the result sizes without a host round trip; bit 1 makes the
+                                     score pass sweep identical pairs like any other pair instead of settling them by comparison
+                                     (pep_stats.candidates_settled) */
 } pep_search_params;
 
 /* one alignment; coordinates are 1-based, inclusive, in residues of the query / target protein */
@@ -132,6 +134,9 @@ typedef struct {
     uint64_t cells_trace;         /* DP cells recomputed by the traceback pass (selected pairs only) */
     uint64_t cells_swept_trace;   /* 64 lanes x steps executed by the traceback pass */
     uint64_t tracebacks_gapless;  /* of `tracebacks`: pairs whose alignment is one ungapped run, settled without a traceback sweep (rule 5a) */
+    uint64_t candidates_settled;  /* of `candidates`: identical pairs the score pass settles without a sweep (same residues, band over diagonal 0, every
+                                     residue dominant in the score table: the optimum is the whole diagonal) */
+    uint64_t cells_settled;       /* of `cells`: the cells of those candidates (cells - cells_settled = cells the score pass sweeps) */
     double ms_seed, ms_sw, ms_trace, ms_total;   /* HIP-event times on the context's stream; ms_sw = score pass kernel */
     double ms_k1, ms_sw_trace;                   /* ms_sw_trace = traceback-pass kernel (selected pairs only) */
     double ms_seed_match;                        /* seed_match kernel, summed over the seed shapes (one launch per shape) */

@@ -7,7 +7,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
@@ -33,7 +33,7 @@ class SearchParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ('query_residues', 'target_residues', 'query_seeds', 'target_seeds', 'seed_hits',
                                            'seed_hits_passed', 'candidates', 'pairs', 'tracebacks', 'hits', 'cells', 'cells_swept', 'dir_bytes',
-                                           'sw_launches', 'cells_trace', 'cells_swept_trace', 'tracebacks_gapless')] + \
+                                           'sw_launches', 'cells_trace', 'cells_swept_trace', 'tracebacks_gapless', 'candidates_settled', 'cells_settled')] + \
                [(n, C.c_double) for n in ('ms_seed', 'ms_sw', 'ms_trace', 'ms_total', 'ms_k1', 'ms_sw_trace', 'ms_seed_match', 'ms_reserved0', 'ms_reserved1', 'ms_reserved2')]
 
 

@@ -591,7 +591,8 @@ template <bool LONG>
 __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint64_t n_pairs = (a.n + 1) / 2;
+    const uint64_t n_act = a.counts[5];                          // candidates in the order (sw_prep): all of them but the ones settled without a sweep
+    const uint64_t n_pairs = (n_act + 1) / 2;
     // the candidates with more blocks than the staging area takes at once are a prefix of the length order (sw_prep counted them): the pairs
     // [0, w_long) belong to the LONG launch, the rest to the other
     const uint64_t w_long = a.split_long ? min(n_pairs, ((uint64_t)a.counts[3] + 1) / 2) : 0;
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t *lds_res = reinterpret_cast<uint16_t *>(smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes);
     for (uint64_t w = (LONG ? 0 : w_long) + (uint64_t)blockIdx.x * WAVES_PER_BLOCK + wave; w < (LONG ? w_long : n_pairs); w += (uint64_t)gridDim.x * WAVES_PER_BLOCK) {
-        const uint64_t c0 = a.order[2 * w], c1 = a.order[min(2 * w + 1, a.n - 1)];
+        const uint64_t c0 = a.order[2 * w], c1 = a.order[min(2 * w + 1, n_act - 1)];
         const CandGeom g0 = cand_geom(a, c0), g1 = cand_geom(a, c1);
         const int nbm = max(g0.nblk, g1.nblk);
         const bool can_pack = a.pk16 && fits16(g0, a.max_sub) && fits16(g1, a.max_sub) && a.lds_res_bytes >= 4 * 2 * 88;
@@ -702,13 +703,68 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
     }
 }
 
+// Score pass without a sweep for IDENTICAL pairs (every gene of an all-vs-all against itself: a fifth of the candidates of the benchmark, more
+// on real exemplar sets, where most genes have few homologues).  One wavefront per candidate.  Residue classes, derived from the score table
+// of the search: r is DOMINANT if sub[r][r] > 0 and sub[r][x] < sub[r][r] for every other x, HARMLESS if no entry of its row is positive
+// (BLOSUM62: the twenty amino acids are dominant, X - which is what a stop codon becomes - is harmless, B / Z are neither).  If the two
+// sequences are the same string P + H - one or more dominant residues, then any number of harmless ones (the stop at the end of a gene) - and
+// the band contains diagonal 0, the banded optimum is diagonal 0 over P:
+//   * a path collects at most max_x sub[r_i][x] for every row i it touches and pays for its gaps, i.e. at most the sum S of sub[r][r] over
+//     the rows of P it touches (rows of H add nothing positive);
+//   * S over ALL of P needs every row of P, no gap, and equality in every row: a gap-free path through all rows of P lies on one diagonal k,
+//     k < 0 misses row 0, and k > 0 puts the last k rows of P against columns of H, where strict dominance makes it lose.
+// So the score is S, reached on diagonal 0 and on no other, i.e. in lane (-dlo) >> 1: exactly what the sweep writes (score, lowest lane that
+// met it, a0).  The traceback stage then settles the pair by rule 5a.  settled[c] = -2 (the sweep skips the candidate) or 0.
+struct IdentArgs { int8_t diag[32]; uint32_t dominant, harmless; };
+__global__ __launch_bounds__(256) void identical_check(const uint64_t *__restrict__ cands, uint64_t n, const uint8_t *__restrict__ q_res, const uint32_t *__restrict__ q_off,
+                                                       const uint32_t *__restrict__ q_len, const uint8_t *__restrict__ t_res, const uint32_t *__restrict__ t_off,
+                                                       const uint32_t *__restrict__ t_len, IdentArgs ia, int4 *__restrict__ out, int32_t *__restrict__ settled)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n) return;
+    const uint64_t key = cands[c];
+    const uint32_t q = (uint32_t)(key >> 43), t = (uint32_t)((key >> 18) & ((1u << 25) - 1));
+    const int bin = (int)(key & ((1u << 18) - 1));
+    const int dlo = bin * 64 - (1 << 23) - 32;
+    const int L = (int)q_len[q];
+    const int my_diag = ia.diag[lane & 31];                       // lane r holds sub[r][r]
+    bool same = L > 0 && L == (int)t_len[t] && dlo <= 0 && dlo + 127 >= 0;
+    bool tail = false;                                            // a harmless residue has been seen: only harmless ones may follow
+    int sum = 0;
+    if (same) {
+        const uint8_t *qg = q_res + q_off[q], *tg = t_res + t_off[t];
+        for (int x0 = 0; x0 < L; x0 += 64) {                        // (wave-uniform trip count: the look-up below is a shuffle)
+            const int x = x0 + lane;
+            const bool in = x < L;
+            const uint32_t qa = in ? qg[x] : 0u, ta = in ? tg[x] : 0u;
+            const int d = __shfl(my_diag, (int)(qa & 31u), 64);
+            const bool dom = in && qa < 32u && ((ia.dominant >> qa) & 1u), harm = in && qa < 32u && ((ia.harmless >> qa) & 1u);
+            const unsigned long long m_dom = __ballot(dom), m_harm = __ballot(harm);
+            const bool bad = __ballot(in && (qa != ta || !(dom || harm))) != 0ull                                    // differs, or a residue of neither class
+                             || (m_dom && (tail || (m_harm && (63 - __builtin_clzll(m_dom)) > (__builtin_ffsll((long long)m_harm) - 1))));      // dominant behind harmless
+            if (bad) { same = false; break; }
+            if (dom) sum += d;
+            tail = tail || m_harm != 0ull;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    same = same && sum > 0;
+    if (lane == 0) {
+        settled[c] = same ? -2 : 0;
+        if (same) out[c] = make_int4(sum, (-dlo) >> 1, -1, (-dlo) >> 1);       // (a0 of a band that holds diagonal 0 is the lane of diagonal 0: band_geom)
+    }
+}
+
 // per candidate: number of 8-step blocks and the exact count of in-band in-matrix cells
 __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cands, uint64_t n_host, const uint32_t *__restrict__ d_n, const uint32_t *__restrict__ q_len,
                                                const uint32_t *__restrict__ t_len, uint32_t *__restrict__ nblk, uint64_t *__restrict__ nblk64,
                                                unsigned long long *__restrict__ cells_total,           // [0] cells, [1] 16-step blocks, [3] candidates above nb_limit
                                                uint32_t *__restrict__ len_hist,                        // [LEN_BUCKETS] candidates per length bucket
                                                uint32_t nb_limit,
-                                               const int32_t *__restrict__ skip_mode,                  // traceback pass: candidates settled without a sweep (mode -2, gapless_check) take no part
+                                               const int32_t *__restrict__ skip_mode,                  // candidates settled without a sweep (mode -2: gapless_check, identical_check) take no part
+                                               int count_skipped,                                      // score pass: their cells still count in [0] (and, with their number, in [6] [7])
                                                uint64_t *__restrict__ dir_off,                         // traceback pass: start of every candidate's traceback codes (in 16-step blocks) = exclusive
                                                uint64_t *__restrict__ lb_state, uint32_t lb_ticket_base, uint64_t lb_epoch)      //   scan of the block counts, taken in here (lookback.h)
 {
@@ -719,9 +775,10 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
     const uint64_t n = d_n ? (uint64_t)*d_n : n_host;          // (the grid is sized from n_host, an upper bound, when the count lives on the device)
     const uint32_t tile = lb_state ? lb_take_tile(lb_state, lb_ticket_base, &s_tile) : blockIdx.x;
     const uint64_t c = (uint64_t)tile * 256 + threadIdx.x;
-    unsigned long long cells = 0, blocks = 0;
+    unsigned long long cells = 0, blocks = 0, cells_skipped = 0, n_skipped = 0;
     bool is_long = false;
-    if (c < n && skip_mode && skip_mode[c] == -2) { nblk[c] = 0; nblk64[c] = 0; }
+    const bool skipped = c < n && skip_mode && skip_mode[c] == -2;
+    if (skipped && !count_skipped) { nblk[c] = 0; nblk64[c] = 0; }
     else if (c < n) {
         const uint64_t key = cands[c];
         const uint32_t q = (uint32_t)(key >> 43), t = (uint32_t)((key >> 18) & ((1u << 25) - 1));
@@ -746,12 +803,15 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
             total += tri(dl, min((long long)dh, -1ll));                     // + d for the negative diagonals
             cells += (unsigned long long)total;
         }
-        const uint32_t nb = (uint32_t)((steps + 15) / 16);
-        nblk[c] = nb;
-        nblk64[c] = nb;
-        blocks = nb;
-        is_long = nb > nb_limit;
-        atomicAdd(&lh[len_bucket(nb)], 1u);
+        if (skipped) { nblk[c] = 0; nblk64[c] = 0; cells_skipped = cells; n_skipped = 1; }
+        else {
+            const uint32_t nb = (uint32_t)((steps + 15) / 16);
+            nblk[c] = nb;
+            nblk64[c] = nb;
+            blocks = nb;
+            is_long = nb > nb_limit;
+            atomicAdd(&lh[len_bucket(nb)], 1u);
+        }
     }
     if (lb_state) {
         __shared__ uint64_t lds64[4], s_pre;
@@ -770,13 +830,16 @@ __global__ __launch_bounds__(256) void sw_prep(const uint64_t *__restrict__ cand
     if (threadIdx.x == 0 && longs) atomicAdd(&cells_total[3], (unsigned long long)longs);
     if (threadIdx.x == 0 && actives) atomicAdd(&cells_total[5], (unsigned long long)actives);      // candidates that enter the order (and the sweep)
     // totals: one pair of atomics per block (every wavefront adding to the same two words serialises in the L2)
-    __shared__ unsigned long long tot[2][4];
-    for (int d = 32; d > 0; d >>= 1) { cells += __shfl_down(cells, d, 64); blocks += __shfl_down(blocks, d, 64); }
-    if ((threadIdx.x & 63) == 0) { tot[0][threadIdx.x >> 6] = cells; tot[1][threadIdx.x >> 6] = blocks; }
+    __shared__ unsigned long long tot[4][4];
+    for (int d = 32; d > 0; d >>= 1) {
+        cells += __shfl_down(cells, d, 64); blocks += __shfl_down(blocks, d, 64);
+        cells_skipped += __shfl_down(cells_skipped, d, 64); n_skipped += __shfl_down(n_skipped, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { tot[0][threadIdx.x >> 6] = cells; tot[1][threadIdx.x >> 6] = blocks; tot[2][threadIdx.x >> 6] = cells_skipped; tot[3][threadIdx.x >> 6] = n_skipped; }
     __syncthreads();
-    if (threadIdx.x < 2) {
+    if (threadIdx.x < 4) {
         const unsigned long long v = tot[threadIdx.x][0] + tot[threadIdx.x][1] + tot[threadIdx.x][2] + tot[threadIdx.x][3];
-        if (v) atomicAdd(&cells_total[threadIdx.x], v);
+        if (v) atomicAdd(&cells_total[threadIdx.x < 2 ? threadIdx.x : threadIdx.x + 4], v);          // [0] cells, [1] blocks, [6] cells settled without a sweep, [7] their number
     }
     for (int x = threadIdx.x; x < LEN_BUCKETS; x += 256) if (lh[x]) atomicAdd(&len_hist[x], lh[x]);
 }
@@ -889,11 +952,32 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     uint32_t lb_ticket = 0;
     const uint64_t prep_tiles = ceil_div(n + (trace ? 1 : 0), 256);        // (the traceback pass writes one entry more: the total)
     if (trace) PEP_TRY(pep_lookback_begin(ctx, ctx->scan_state[1], prep_tiles, (1u << 14) - 1, &lb_state, &lb_ticket, &lb_epoch));
+    // score pass: identical pairs are settled without a sweep (identical_check; params.reserved2 bit 1 switches it off for the tests)
+    const int32_t *skip = trace ? d_skip_mode : nullptr;
+    if (!trace && (P.reserved2 & 2) == 0) {
+        PEP_TRY(dev_reserve(ctx, ctx->ws[13], (n + 1) * sizeof(int32_t)));          // (the traceback codes' buffer: not in use before the traceback pass)
+        IdentArgs ia;
+        ia.dominant = ia.harmless = 0;
+        for (int r = 0; r < 32; ++r) {
+            ia.diag[r] = P.sub[r * 32 + r];
+            bool dom = P.sub[r * 32 + r] > 0, harm = true;
+            for (int x = 0; x < 32; ++x) {
+                if (x != r) dom = dom && P.sub[r * 32 + x] < P.sub[r * 32 + r];
+                harm = harm && P.sub[r * 32 + x] <= 0;
+            }
+            if (dom) ia.dominant |= 1u << r;
+            if (harm) ia.harmless |= 1u << r;
+        }
+        hipLaunchKernelGGL(identical_check, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_cands, n, ctx->q.res.as<const uint8_t>(), ctx->q.off.as<const uint32_t>(),
+                           ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(), ctx->t.off.as<const uint32_t>(), ctx->t.len.as<const uint32_t>(), ia,
+                           ctx->ws[12].as<int4>(), ctx->ws[13].as<int32_t>());
+        skip = ctx->ws[13].as<const int32_t>();
+    }
     hipLaunchKernelGGL(sw_prep, dim3((unsigned)prep_tiles), dim3(256), 0, ctx->stream, d_cands, n, trace ? d_n : nullptr, ctx->q.len.as<const uint32_t>(),
-                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist, nb_limit, trace ? d_skip_mode : nullptr,
+                       ctx->t.len.as<const uint32_t>(), ctx->ws[10].as<uint32_t>(), ctx->ws[14].as<uint64_t>(), cells, len_hist, nb_limit, skip, trace ? 0 : 1,
                        ctx->ws[11].as<uint64_t>(), lb_state, lb_ticket, lb_epoch);
     hipLaunchKernelGGL(sw_order, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ctx->stream, ctx->ws[10].as<const uint32_t>(), n, trace ? d_n : nullptr,
-                       (const uint32_t *)len_hist, cursor, order, trace ? d_skip_mode : nullptr);
+                       (const uint32_t *)len_hist, cursor, order, skip);
     if (trace) {
         uint64_t total_blk = dir_blocks_bound;
         if (!dir_blocks_bound) {

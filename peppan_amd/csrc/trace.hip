@@ -378,6 +378,8 @@ __global__ __launch_bounds__(256) void topk(const uint32_t *__restrict__ d_n_sel
         // the totals of the two Smith-Waterman passes into the block the host reads with its last synchronisation (one copy for everything)
         mail[4] = score_hdr[0]; mail[5] = score_hdr[1];
         mail[6] = trace_hdr ? trace_hdr[0] : 0ull; mail[7] = trace_hdr ? trace_hdr[1] : 0ull; mail[8] = trace_hdr ? trace_hdr[5] : 0ull;
+        mail[9] = score_hdr[6];                                                  // cells of the candidates the score pass settled without a sweep,
+        reinterpret_cast<uint32_t *>(mail)[3] = (uint32_t)score_hdr[7];          // their number
     }
     uint32_t keep = 0;
     uint64_t n_runs = 0;
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256) void emit(const uint32_t *__restrict__ d_n_sel
     const uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     // the counter block of the stage (final since topk) once more, outside the search's zeroed region: pack_out and K10 read it there, so that
     // pack_out may clear that region for the next search
-    if (mail_copy && blockIdx.x == 0 && threadIdx.x < 9) mail_copy[threadIdx.x] = mail[threadIdx.x];
+    if (mail_copy && blockIdx.x == 0 && threadIdx.x < 10) mail_copy[threadIdx.x] = mail[threadIdx.x];
     if (s >= *d_n_sel || !keep_flag[s]) return;
     const SelInfo info = sel[s];
     const uint64_t key = cands[info.cand];
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256) void pack_out(const unsigned long long *__rest
     const unsigned long long n_cig = mail[2];
     const bool fits = PACK_HEADER + (unsigned long long)n_hits * sizeof(pep_hit) + n_cig * 4 <= cap;
     unsigned long long *head = reinterpret_cast<unsigned long long *>(pinned);
-    if (blockIdx.x == 0 && threadIdx.x < 16) head[threadIdx.x] = threadIdx.x < 9 ? mail[threadIdx.x] : (threadIdx.x == 15 ? (fits ? 0ull : 1ull) : 0ull);
+    if (blockIdx.x == 0 && threadIdx.x < 16) head[threadIdx.x] = threadIdx.x < 10 ? mail[threadIdx.x] : (threadIdx.x == 15 ? (fits ? 0ull : 1ull) : 0ull);
     if (!fits) return;
     const uint64_t stride = (uint64_t)gridDim.x * 256, t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     const uint4 *src = reinterpret_cast<const uint4 *>(hits);
@@ -499,8 +501,8 @@ __global__ __launch_bounds__(256) void pack_out(const unsigned long long *__rest
 // pair as long as the longest), and the statistics ride on the one read-back at the end.  When those bounds would cost more memory than
 // is sensible (FAST_DIR_BYTES / FAST_RUN_BYTES: long sequences times many candidates - searches that are long enough not to care about
 // two host round trips), or with params.reserved2 = 1 (tests), the stage synchronises after the selection and sizes everything exactly.
-struct HostMail { uint32_t n_pairs, n_sel, n_hits, pad; unsigned long long n_cig, run_cap, score_cells, score_blocks, trace_cells, trace_blocks, trace_swept; };
-static_assert(sizeof(HostMail) == 72, "layout of the selection stage's counter block");
+struct HostMail { uint32_t n_pairs, n_sel, n_hits, n_settled; unsigned long long n_cig, run_cap, score_cells, score_blocks, trace_cells, trace_blocks, trace_swept, settled_cells; };
+static_assert(sizeof(HostMail) == 80, "layout of the selection stage's counter block");
 
 // the host's half of a search whose result left through pack_out: sizes, statistics and the views of the staging area - called once the
 // stream has been waited for (by pep_search behind its one final wait, or by pep_extend itself when the caller wants the result at once)
@@ -514,6 +516,8 @@ int pep_extend_finish(pep_ctx *ctx)
     const bool overflow = reinterpret_cast<const unsigned long long *>(ctx->pin_stage.p)[15] != 0;
     ctx->stats.cells += h.score_cells;
     ctx->stats.cells_swept += h.score_blocks * 16 * 64;
+    ctx->stats.candidates_settled += h.n_settled;
+    ctx->stats.cells_settled += h.settled_cells;
     ctx->stats.cells_trace += h.trace_cells;
     ctx->stats.cells_swept_trace += h.trace_blocks * 16 * 64;
     ctx->stats.dir_bytes += h.trace_blocks * 512;
@@ -557,6 +561,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     ctx->stats.candidates = n;
     ctx->stats.pairs = ctx->stats.tracebacks = ctx->stats.hits = 0;
     ctx->stats.cells = ctx->stats.cells_swept = ctx->stats.dir_bytes = 0;
+    ctx->stats.candidates_settled = ctx->stats.cells_settled = 0;
     if (n == 0) return PEP_OK;
     hipStream_t st = ctx->stream;
     // ---- pass 1: score-only banded SW over every candidate
@@ -608,7 +613,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
     constexpr uint64_t FAST_DIR_BYTES = 8ull << 30, FAST_RUN_BYTES = 2ull << 30;
     const uint64_t max_blk = ((uint64_t)ctx->q.max_len + ctx->t.max_len) / 16 + 3;
     const uint64_t dir_blocks_bound = n * max_blk, run_bound = n * (2ull * std::min(ctx->q.max_len, ctx->t.max_len) + 2);
-    const bool fast = P.reserved2 == 0 && dir_blocks_bound * 512 <= FAST_DIR_BYTES && run_bound * 4 <= FAST_RUN_BYTES;
+    const bool fast = (P.reserved2 & 1) == 0 && dir_blocks_bound * 512 <= FAST_DIR_BYTES && run_bound * 4 <= FAST_RUN_BYTES;
     uint64_t n_b = n;                            // what the buffers and grids behind the selection are sized for
     if (!fast) {
         PEP_TRY(pep_read_back(ctx, &h_mail, mail, 8));
@@ -693,6 +698,8 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         n_hits = h_mail.n_hits; n_cig = h_mail.n_cig;
         ctx->stats.cells += h_mail.score_cells;
         ctx->stats.cells_swept += h_mail.score_blocks * 16 * 64;
+        ctx->stats.candidates_settled += h_mail.n_settled;
+        ctx->stats.cells_settled += h_mail.settled_cells;
         if (fast) {                                  // (the exactly sized pass has added its totals itself)
             ctx->stats.cells_trace += h_mail.trace_cells;
             ctx->stats.cells_swept_trace += h_mail.trace_blocks * 16 * 64;
@@ -701,11 +708,13 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         }
         ctx->stats.tracebacks_gapless = h_mail.n_sel - ctx->trace_swept;   // (counted by the pass's set-up kernel: the pairs that entered the sweep)
     } else {
-        unsigned long long h_score[2] = {0, 0};
+        unsigned long long h_score[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         PEP_TRY(pep_read_back(ctx, h_score, score_hdr, sizeof(h_score)));
         PEP_TRY(pep_sync_reads(ctx));
         ctx->stats.cells += h_score[0];
         ctx->stats.cells_swept += h_score[1] * 16 * 64;
+        ctx->stats.cells_settled += h_score[6];
+        ctx->stats.candidates_settled += h_score[7];
     }
     ctx->stats.pairs = h_mail.n_pairs;
     ctx->stats.tracebacks = h_mail.n_sel;

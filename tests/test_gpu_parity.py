@@ -1381,6 +1381,64 @@ def test_candidate_sort_two_level_and_fallback(ctx):
     assert ost['candidates'] < 4096
 
 
+def test_identical_pairs_settled_without_a_sweep(ctx):
+    """the score pass settles identical pairs by comparison (identical_check): same table and statistics as with every pair swept
+    (params.reserved2 bit 1) and as the oracle, on sets built to tempt it - exact duplicates, duplicates with one residue changed at either
+    end or in the middle, sequences with X inside (swept) and at the end (the stop codon of a gene: settled), a protein that is a repeat of one short unit (the
+    band over diagonal 0 next to bands over the shifted copies), prefixes of other proteins, equal lengths with different residues; and
+    on the nucleotide configuration (N is not dominant)"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    base = synth.make_proteins(60, length=(40, 420), seed=9, family=3, sub=0.15)
+    extra = []
+    for k in (0, 7, 19, 33):
+        p = base[k].copy(); extra.append(p.copy())                                  # exact duplicate
+        for at in (0, len(p) // 2, len(p) - 1):
+            m = p.copy(); m[at] = (m[at] + 1 + rng.integers(0, 18)) % 20; extra.append(m)
+        x = p.copy(); x[len(x) // 3] = 23; extra.append(x); extra.append(x.copy())  # X inside: a duplicate pair that must be swept
+        extra.append(p[:len(p) - 7].copy()); extra.append(p[5:].copy())
+    for k, m in ((2, 1), (13, 3), (21, 1)):                                         # the stop at the end of a gene: X behind the last residue
+        y = np.concatenate([base[k], np.full(m, 23, dtype=np.uint8)]); extra.append(y); extra.append(y.copy())
+    extra.append(np.concatenate([base[2], np.array([23, 0], dtype=np.uint8)]))          # ... and a residue behind the X: swept
+    extra.append(np.full(40, 23, dtype=np.uint8))                                       # nothing but X
+    unit = base[3][:23]
+    extra.append(np.concatenate([unit] * 9)); extra.append(np.concatenate([unit] * 9))
+    shuffled = base[11].copy(); rng.shuffle(shuffled); extra.append(shuffled)         # same length and composition, other order
+    prots = base + extra
+    keys = ('candidates', 'pairs', 'tracebacks', 'tracebacks_gapless', 'hits', 'cells', 'cells_trace')
+    ctx.set_query_aa(prots); ctx.set_ref_aa(prots)
+    out = {}
+    for flag in (0, 2, 1, 3):
+        p = N.default_params(30., 10., 25, 5)
+        p.reserved2 = flag
+        h, c, st = ctx.search(p)
+        out[flag] = (h.tobytes(), c.tobytes(), tuple(st[k] for k in keys), st['candidates_settled'], st['cells_settled'], st['cells_swept'])
+    assert out[0][:3] == out[2][:3] == out[1][:3] == out[3][:3]
+    assert out[2][3] == 0 and out[2][4] == 0 and out[0][3] == out[1][3] >= 60 and 0 < out[0][4] < dict(zip(keys, out[0][2]))['cells']
+    assert out[0][5] < out[2][5]                                                    # fewer cells swept
+    oh, oc, ost = O.search(prots, prots, O.default_params(30., 10., 25, 5))
+    _cmp_hits(np.frombuffer(out[0][0], dtype=N.HIT_DTYPE), np.frombuffer(out[0][1], dtype=np.uint32), oh, oc)
+    assert ost['candidates'] == out[0][2][0] and ost['cells'] == dict(zip(keys, out[0][2]))['cells']
+    # nucleotide configuration: exact 17-mers, +2 / -3; sequences with N are swept
+    names, seqs = synth.make_genes(120, 0, seed=41)
+    codes = [O.nt_codes(x) for x in seqs]
+    codes += [codes[5].copy(), codes[9].copy()]
+    withn = codes[12].copy(); withn[30:33] = 4; codes += [withn, withn.copy()]
+    pn = N.nucleotide_params(70., 25.)
+    ms = np.array([O.min_score(len(x), pn.dbsize, pn.max_evalue, pn.ka_lambda, pn.ka_k) for x in codes], dtype=np.int32)
+    ctx.set_query_aa(codes); ctx.set_ref_aa(codes)
+    res = {}
+    for flag in (0, 2):
+        pn.reserved2 = flag
+        gh, gc, st = ctx.search(pn)
+        res[flag] = (gh.tobytes(), gc.tobytes(), st['candidates'], st['cells'], st['candidates_settled'])
+    assert res[0][:4] == res[2][:4] and res[2][4] == 0 and res[0][4] >= 100
+    pn.reserved2 = 0
+    oh, oc, ost = O.search(codes, codes, O.params_from(pn), min_scores=ms)
+    _cmp_hits(np.frombuffer(res[0][0], dtype=N.HIT_DTYPE), np.frombuffer(res[0][1], dtype=np.uint32), oh, oc)
+
+
 def test_k1_inside_the_search_equals_translate_in_front(ctx):
     """pep_invalidate_translation: K1 runs inside the next search (both sides queued at once, the reference side's summary taken late, the
     host tables built from descriptors that stay on the device) - same hit table, same statistics, same meta records and proteins as
