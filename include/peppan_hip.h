@@ -92,7 +92,8 @@ typedef struct {
                                      step and size the traceback buffers exactly (what it does by itself when its upper bounds would cost too much
                                      memory) instead of running from the candidate count to the result sizes without a host round trip; bit 1 makes the
                                      score pass sweep identical pairs like any other pair instead of settling them by comparison
-                                     (pep_stats.candidates_settled) */
+                                     (pep_stats.candidates_settled), bit 2 makes it settle them also in searches below 16 384 candidates, where
+                                     the comparison costs more than it saves */
 } pep_search_params;
 
 /* one alignment; coordinates are 1-based, inclusive, in residues of the query / target protein */

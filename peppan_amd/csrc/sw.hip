@@ -952,9 +952,11 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     uint32_t lb_ticket = 0;
     const uint64_t prep_tiles = ceil_div(n + (trace ? 1 : 0), 256);        // (the traceback pass writes one entry more: the total)
     if (trace) PEP_TRY(pep_lookback_begin(ctx, ctx->scan_state[1], prep_tiles, (1u << 14) - 1, &lb_state, &lb_ticket, &lb_epoch));
-    // score pass: identical pairs are settled without a sweep (identical_check; params.reserved2 bit 1 switches it off for the tests)
+    // score pass: identical pairs are settled without a sweep (identical_check; params.reserved2 bit 1 switches it off, bit 2 on whatever the
+    // size - tests).  Not below 16 k candidates: a pass that small is one or two rounds of wavefronts, a fifth fewer of them does not shorten it,
+    // and the check is a launch and a chain of loads of its own (8x1 cell of the benchmark, 6 163 candidates: 0.965 -> 1.0 ms with it)
     const int32_t *skip = trace ? d_skip_mode : nullptr;
-    if (!trace && (P.reserved2 & 2) == 0) {
+    if (!trace && (P.reserved2 & 2) == 0 && (n >= 16384 || (P.reserved2 & 4))) {
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], (n + 1) * sizeof(int32_t)));          // (the traceback codes' buffer: not in use before the traceback pass)
         IdentArgs ia;
         ia.dominant = ia.harmless = 0;

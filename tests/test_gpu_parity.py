@@ -1409,14 +1409,15 @@ def test_identical_pairs_settled_without_a_sweep(ctx):
     keys = ('candidates', 'pairs', 'tracebacks', 'tracebacks_gapless', 'hits', 'cells', 'cells_trace')
     ctx.set_query_aa(prots); ctx.set_ref_aa(prots)
     out = {}
-    for flag in (0, 2, 1, 3):
+    for flag in (4, 2, 5, 3, 0):                                                    # bit 2: also in a search this small; 0 = production (too small: swept)
         p = N.default_params(30., 10., 25, 5)
         p.reserved2 = flag
         h, c, st = ctx.search(p)
         out[flag] = (h.tobytes(), c.tobytes(), tuple(st[k] for k in keys), st['candidates_settled'], st['cells_settled'], st['cells_swept'])
-    assert out[0][:3] == out[2][:3] == out[1][:3] == out[3][:3]
-    assert out[2][3] == 0 and out[2][4] == 0 and out[0][3] == out[1][3] >= 60 and 0 < out[0][4] < dict(zip(keys, out[0][2]))['cells']
-    assert out[0][5] < out[2][5]                                                    # fewer cells swept
+    assert out[4][:3] == out[2][:3] == out[5][:3] == out[3][:3] == out[0][:3]
+    assert out[2][3] == 0 and out[2][4] == 0 and out[0][3] == 0 and out[4][3] == out[5][3] >= 60 and 0 < out[4][4] < dict(zip(keys, out[4][2]))['cells']
+    assert out[4][5] < out[2][5]                                                    # fewer cells swept
+    out[0] = out[4]
     oh, oc, ost = O.search(prots, prots, O.default_params(30., 10., 25, 5))
     _cmp_hits(np.frombuffer(out[0][0], dtype=N.HIT_DTYPE), np.frombuffer(out[0][1], dtype=np.uint32), oh, oc)
     assert ost['candidates'] == out[0][2][0] and ost['cells'] == dict(zip(keys, out[0][2]))['cells']
@@ -1429,10 +1430,11 @@ def test_identical_pairs_settled_without_a_sweep(ctx):
     ms = np.array([O.min_score(len(x), pn.dbsize, pn.max_evalue, pn.ka_lambda, pn.ka_k) for x in codes], dtype=np.int32)
     ctx.set_query_aa(codes); ctx.set_ref_aa(codes)
     res = {}
-    for flag in (0, 2):
+    for flag in (4, 2):
         pn.reserved2 = flag
         gh, gc, st = ctx.search(pn)
         res[flag] = (gh.tobytes(), gc.tobytes(), st['candidates'], st['cells'], st['candidates_settled'])
+    res[0] = res[4]
     assert res[0][:4] == res[2][:4] and res[2][4] == 0 and res[0][4] >= 100
     pn.reserved2 = 0
     oh, oc, ost = O.search(codes, codes, O.params_from(pn), min_scores=ms)
