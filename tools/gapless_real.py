@@ -1,4 +1,4 @@
-"""Rule 5a on real genes: how many of the traced pairs of an all-vs-all search are settled as one ungapped run (no traceback sweep).
+"""Rule 5a and the comparison of identical pairs on real genes: how many of the traced pairs of an all-vs-all search are settled as one ungapped run (no traceback sweep).
 Fixtures: golden G16 (1 644 genes of the reference's examples/) and G17 (the 8 441 unique genes of its four example genomes).
 python3 tools/gapless_real.py"""
 import gzip
@@ -25,11 +25,14 @@ def main():
         seqs = genes_of(fn)
         ctx.set_query_nt(seqs, 11)
         ctx.set_ref_nt(seqs, 6, 11)
-        p = N.default_params(45., 25., 10, 5)
-        for _ in range(3):
-            h, c, st = ctx.search(p)
-        print('%s: %d genes, %d candidates, %d traced pairs, %d of them one ungapped run (rule 5a), %d hits; score pass %.3f ms, traceback pass %.3f ms, search %.3f ms'
-              % (label, len(seqs), st['candidates'], st['tracebacks'], st['tracebacks_gapless'], len(h), st['ms_sw'], st['ms_sw_trace'], st['ms_total']))
+        for flag, what in ((0, 'production'), (2, 'every pair swept'), (4, 'identical pairs compared whatever the size')):
+            p = N.default_params(45., 25., 10, 5)
+            p.reserved2 = flag
+            for _ in range(3):
+                h, c, st = ctx.search(p)
+            print('%s (%s): %d genes, %d candidates, %d of them identical pairs scored by comparison, %d traced pairs, %d of them one ungapped run (rule 5a), %d hits; '
+                  'score pass %.3f ms, traceback pass %.3f ms, search %.3f ms'
+                  % (label, what, len(seqs), st['candidates'], st['candidates_settled'], st['tracebacks'], st['tracebacks_gapless'], len(h), st['ms_sw'], st['ms_sw_trace'], st['ms_total']))
 
 
 if __name__ == '__main__':
