@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
 // (BLOSUM62: the twenty amino acids are dominant, X - which is what a stop codon becomes - is harmless, B / Z are neither).  If the two
 // sequences are the same string P + H - one or more dominant residues, then any number of harmless ones (the stop at the end of a gene) - and
 // the band contains diagonal 0, the banded optimum is diagonal 0 over P:
-//   * a path collects at most max_x sub[r_i][x] for every row i it touches and pays for its gaps, i.e. at most the sum S of sub[r][r] over
+//   * a path collects at most max_x sub[r_i][x] for every row i it touches and pays for its gaps (every gap costs something: checked on the host), i.e. at most the sum S of sub[r][r] over
 //     the rows of P it touches (rows of H add nothing positive);
 //   * S over ALL of P needs every row of P, no gap, and equality in every row: a gap-free path through all rows of P lies on one diagonal k,
 //     k < 0 misses row 0, and k > 0 puts the last k rows of P against columns of H, where strict dominance makes it lose.
@@ -956,7 +956,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     // size - tests).  Not below 16 k candidates: a pass that small is one or two rounds of wavefronts, a fifth fewer of them does not shorten it,
     // and the check is a launch and a chain of loads of its own (8x1 cell of the benchmark, 6 163 candidates: 0.965 -> 1.0 ms with it)
     const int32_t *skip = trace ? d_skip_mode : nullptr;
-    if (!trace && (P.reserved2 & 2) == 0 && (n >= 16384 || (P.reserved2 & 4))) {
+    if (!trace && (P.reserved2 & 2) == 0 && (n >= 16384 || (P.reserved2 & 4)) && P.gap_ext >= 0 && P.gap_open + P.gap_ext > 0) {       // (the argument needs gaps that cost something)
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], (n + 1) * sizeof(int32_t)));          // (the traceback codes' buffer: not in use before the traceback pass)
         IdentArgs ia;
         ia.dominant = ia.harmless = 0;
