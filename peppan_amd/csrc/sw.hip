@@ -734,18 +734,23 @@ __global__ __launch_bounds__(256) void identical_check(const uint64_t *__restric
     int sum = 0;
     if (same) {
         const uint8_t *qg = q_res + q_off[q], *tg = t_res + t_off[t];
-        for (int x0 = 0; x0 < L; x0 += 64) {                        // (wave-uniform trip count: the look-up below is a shuffle)
-            const int x = x0 + lane;
-            const bool in = x < L;
-            const uint32_t qa = in ? qg[x] : 0u, ta = in ? tg[x] : 0u;
-            const int d = __shfl(my_diag, (int)(qa & 31u), 64);
-            const bool dom = in && qa < 32u && ((ia.dominant >> qa) & 1u), harm = in && qa < 32u && ((ia.harmless >> qa) & 1u);
-            const unsigned long long m_dom = __ballot(dom), m_harm = __ballot(harm);
-            const bool bad = __ballot(in && (qa != ta || !(dom || harm))) != 0ull                                    // differs, or a residue of neither class
-                             || (m_dom && (tail || (m_harm && (63 - __builtin_clzll(m_dom)) > (__builtin_ffsll((long long)m_harm) - 1))));      // dominant behind harmless
-            if (bad) { same = false; break; }
-            if (dom) sum += d;
-            tail = tail || m_harm != 0ull;
+        for (int x0 = 0; x0 < L && same; x0 += 256) {               // (wave-uniform trip count: the look-up below is a shuffle)
+            // four strips of 64 residues per trip, their eight loads in flight together: the kernel's time is the chain of these round trips
+            uint32_t qa[4], ta[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int x = x0 + 64 * k + lane; qa[k] = x < L ? qg[x] : 0u; ta[k] = x < L ? tg[x] : 0u; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool in = x0 + 64 * k + lane < L;
+                const int d = __shfl(my_diag, (int)(qa[k] & 31u), 64);
+                const bool dom = in && qa[k] < 32u && ((ia.dominant >> qa[k]) & 1u), harm = in && qa[k] < 32u && ((ia.harmless >> qa[k]) & 1u);
+                const unsigned long long m_dom = __ballot(dom), m_harm = __ballot(harm);
+                const bool bad = __ballot(in && (qa[k] != ta[k] || !(dom || harm))) != 0ull                               // differs, or a residue of neither class
+                                 || (m_dom && (tail || (m_harm && (63 - __builtin_clzll(m_dom)) > (__builtin_ffsll((long long)m_harm) - 1))));      // dominant behind harmless
+                if (bad) same = false;
+                if (dom) sum += d;
+                tail = tail || m_harm != 0ull;
+            }
         }
     }
 #pragma unroll
