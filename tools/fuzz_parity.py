@@ -1,7 +1,7 @@
 """Randomised parity of the whole search against the CPU oracle: random protein sets (families, exact duplicates, X and B at the ends and inside,
 repeats), random thresholds, score tables other than BLOSUM62 (ties on the diagonal, residues that are neither dominant nor harmless, cheap
 gaps), every combination of the test switches (exact sizing of the alignment stage, identical pairs compared / swept, 32-bit sweeps, LSD sort).
-python3 tools/fuzz_parity.py [cases] [seed]   - exits 1 on the first difference"""
+python3 tools/fuzz_parity.py [cases] [seed] [nucl]   - exits 1 on the first difference; nucl: the nucleotide configuration of the engine"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
@@ -31,10 +31,44 @@ def make_set(rng):
     return [out[i] for i in order]
 
 
+def nucleotide_cases(ctx, cases, rng):
+    """the blastn-like configuration (base-4 exact 17-mers, +2 / -3, gaps 6 + 2k, both strands): genes, duplicates, runs of N, fragments"""
+    rc = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    for case in range(cases):
+        names, seqs = synth.make_genes(int(rng.integers(30, 500)), 0, seed=int(rng.integers(1, 1 << 30)))
+        codes = [O.nt_codes(x) for x in seqs]
+        for _ in range(int(rng.integers(0, 20))):
+            c = codes[int(rng.integers(0, len(codes)))].copy()
+            kind = int(rng.integers(0, 4))
+            if kind == 1: c[int(rng.integers(0, len(c) - 5)):][:int(rng.integers(1, 5))] = 4
+            elif kind == 2: c = c[int(rng.integers(0, 30)):]
+            elif kind == 3: c[-1] = 4
+            codes.append(c); codes.append(c.copy())
+        targets = codes + [rc[c[::-1]] for c in codes]
+        p = N.nucleotide_params(float(rng.choice([70., 90.])), float(rng.choice([25., 50.])))
+        flags = int(rng.choice([0, 1, 2, 3, 4, 5]))
+        p.reserved2 = flags
+        p.reserved[1] = int(rng.integers(0, 4) == 0)
+        ctx.set_query_aa(codes); ctx.set_ref_aa(targets)
+        gh, gc, st = ctx.search(p)
+        ms = np.array([O.min_score(len(c), p.dbsize, p.max_evalue, p.ka_lambda, p.ka_k) for c in codes], dtype=np.int32)
+        oh, oc, ost = O.search(codes, targets, O.params_from(p), min_scores=ms)
+        bad = [f for f in FIELDS if len(gh) != len(oh) or not np.array_equal(gh[f], oh[f])]
+        bad += ['cigar arena'] if not np.array_equal(gc, oc) else []
+        bad += ['stat ' + k for k in ('candidates', 'pairs', 'cells', 'tracebacks') if st[k] != ost[k]]
+        print('nucleotide case %3d: %4d sequences x 2 strands, switches %d/%d: %6d candidates (%5d settled), %6d hits  %s'
+              % (case, len(codes), flags, p.reserved[1], st['candidates'], st['candidates_settled'], len(gh), 'ok' if not bad else 'DIFFERENT: ' + ', '.join(bad)), flush=True)
+        if bad:
+            sys.exit(1)
+    print('all %d nucleotide cases identical to the oracle' % cases)
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
     ctx = N.Context(0)
+    if len(sys.argv) > 3 and sys.argv[3] == 'nucl':
+        return nucleotide_cases(ctx, cases, rng)
     for case in range(cases):
         prots = make_set(rng)
         p = N.default_params(float(rng.choice([0., 30., 45., 70.])), float(rng.choice([0., 10., 25., 60.])), int(rng.choice([1, 2, 10, 50])), int(rng.choice([1, 5])))
