@@ -26,7 +26,7 @@ def test_struct_layouts_match_header(tmp_path):
     import subprocess
     from peppan_amd import _native as N
     probes = [('pep_search_params', 'min_id_pct'), ('pep_search_params', 'dbsize'), ('pep_search_params', 'ka_lambda'), ('pep_search_params', 'hsp_mode'),
-              ('pep_search_params', 't_index_base'), ('pep_stats', 'cells_swept_trace'), ('pep_stats', 'ms_seed'), ('pep_stats', 'ms_seed_match'),
+              ('pep_search_params', 't_index_base'), ('pep_stats', 'cells_swept_trace'), ('pep_stats', 'candidates_settled'), ('pep_stats', 'cells_settled'), ('pep_stats', 'ms_seed'), ('pep_stats', 'ms_seed_match'),
               ('pep_hit', 'cigar_off'), ('pep_hit', 'cells'), ('pep_nt_hit', 'cigar_off'), ('pep_locus', 'cigar_off')]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "peppan_hip.h"\nint main(void) {\n'
     for st in ('pep_search_params', 'pep_stats', 'pep_hit', 'pep_nt_hit', 'pep_locus', 'pep_query_meta', 'pep_target_meta'):
