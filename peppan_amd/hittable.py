@@ -229,7 +229,10 @@ class HitTable(object):
     def final_order(self):
         """the sort that ends RunBlast.run (uberBlast.py:375): by query name, reference name (as the column's values sort: strings
         lexicographically - '10' < '9'), then score; stable"""
-        return np.lexsort((self.score, self.r_codes(), self.q_codes()))
+        q, r = self.q_codes(), self.r_codes()
+        if len(q) and min(int(q.min()), int(r.min())) >= 0 and max(int(q.max()), int(r.max())) < (1 << 31):
+            return np.lexsort((self.score, (q.astype(np.int64) << 32) | r.astype(np.int64)))        # (one stable pass less: the two codes as one key)
+        return np.lexsort((self.score, r, q))
 
     # ------------------------------------------------------------------------------------------------ object rows
     def cigar_strings(self):
