@@ -22,6 +22,7 @@ Fixture index:
   g05_rescore.json       cigar2score / reScore          (uberBlast.py:221-269, 397-415)
   g06_fixend.json        fixEnd                         (uberBlast.py:462-480)
   g07_filters.json       ovlFilter/_linearMerge/returnOverlap (uberBlast.py:73-218, 378-460)
+  g18_filters_random.json.gz  200 random mapping tables through the reference's ovlFilter / linearMerge (uberBlast.py:100-218, 417-460)
   g08_run.json           RunBlast.run / uberBlast end to end with canned aligner output
   g09_clust.json         getClust / iterClust           (clust.py:34-111, PEPPAN.py:1777-1792)
   g10_pairs.json         get_similar_pairs              (PEPPAN.py:194-294)
@@ -621,6 +622,85 @@ def g07():
     dump('g07_filters.json', dict(cases=cases))
 
 
+# ----------------------------------------------------------------------------- G18 randomized -f / -m tables
+G18_COLS = ('q', 'r', 'iden', 'qs', 'qe', 'ss', 'se', 'score', 'ql', 'sl')
+
+
+def dense_filter_table(rng, n_gene, n_contig, per):
+    """many fragments per gene and contig, close together: chains, joined chains, contig-edge pairs, more than eight rows per query,
+    overlapping competitors.  Returns the ten defining columns; the other six of the 16-column row follow from them (expand_filter_table)."""
+    cols = []
+    for g in range(n_gene):
+        ql = int(rng.integers(600, 3000))
+        for c in range(n_contig):
+            sl = int(rng.integers(4000, 9000))
+            fwd = rng.random() < 0.5
+            r_at = int(rng.integers(1, 400)) if rng.random() < 0.5 else int(rng.integers(sl // 2, sl - 1500))
+            q_at = int(rng.integers(1, 40))
+            for h in range(int(rng.integers(1, per + 1))):
+                ln = int(rng.integers(60, 500))
+                qs, qe = q_at, min(ql, q_at + ln)
+                if qe - qs < 50:
+                    break
+                span = qe - qs + int(rng.integers(-6, 7))
+                lo, hi = r_at, min(sl, r_at + span)
+                if hi - lo < 40:
+                    break
+                if fwd:
+                    rec = [qs, qe, lo, hi]
+                else:
+                    rec = [ql - qe + 1, ql - qs + 1, hi, lo]
+                iden = round(float(rng.uniform(0.7, 1.0)), 3)
+                n_q = rec[1] - rec[0] + 1
+                score = float(int(n_q * (4 * iden - 1))) if rng.random() < 0.8 else float(int(n_q * 2))
+                cols.append([str(g), 'c%d' % c, iden] + rec + [score, ql, sl])
+                step = int(rng.integers(-30, 200))
+                q_at, r_at = q_at + ln + step, r_at + span + step + int(rng.integers(-20, 20))
+            if rng.random() < 0.3 and cols:                  # an overlapping competitor of the last hit
+                t = list(cols[-1])
+                t[7] = t[7] - int(rng.integers(-40, 40))
+                if t[5] < t[6]:
+                    t[5] += 3
+                if t[5] != t[6]:
+                    cols.append(t)
+    return cols
+
+
+def expand_filter_table(cols):
+    tab = np.empty([len(cols), 16], dtype=object)
+    for i, (q, r, iden, qs, qe, ss, se, score, ql, sl) in enumerate(cols):
+        for j, v in enumerate([q, r, iden, qe - qs + 1, 3, 0, qs, qe, ss, se, 0.0, score, ql, sl, [[qe - qs + 1, 'M']], i]):
+            tab[i, j] = v
+    return tab
+
+
+def g18():
+    """200 random mapping tables through the reference's own ovlFilter (three settings) and linearMerge (three settings): what the host C++
+    ports of -f / -m are held to beyond the crafted cases of G7.  Stored compactly: the ten defining columns of every input row; of every
+    output the row ids in output order (the filters pass the other columns through) and, for -m, column 16 of every row."""
+    rng = np.random.default_rng(1818)
+    cases = []
+    for k in range(200):
+        cols = dense_filter_table(rng, int(rng.integers(3, 9)), int(rng.integers(1, 4)), (2, 5, 12, 20)[k % 4])
+        tab = expand_filter_table(cols)
+        rb = uberBlast.RunBlast()
+        case = dict(cols=cols, ovl={}, merge={})
+        for cov, delta in ((0.9, 0.), (0.5, 10.), (0.2, -5.)):
+            f = rb.ovlFilter(copy.deepcopy(tab), [True, cov, delta])
+            assert all(list(r[:15]) == list(tab[r[15]][:15]) for r in f)          # pass-through of every other column
+            case['ovl']['%g_%g' % (cov, delta)] = [int(r[15]) for r in f]
+        for gap, diff in ((600., 1.5), (300., 1.2), (2000., 3.0)):
+            m = rb.linearMerge(copy.deepcopy(tab), [True, gap, diff])
+            assert all(list(r[:15]) == list(tab[r[15]][:15]) for r in m)
+            case['merge']['%g_%g' % (gap, diff)] = [[int(r[15]), r[16]] for r in m]
+        cases.append(case)
+    import gzip
+    with gzip.GzipFile(os.path.join(HERE, 'g18_filters_random.json.gz'), 'wb', mtime=0) as f:
+        f.write(json.dumps(jsonable(dict(columns=G18_COLS, cases=cases)), separators=(',', ':')).encode())
+    print('wrote g18_filters_random.json.gz', os.path.getsize(os.path.join(HERE, 'g18_filters_random.json.gz')), 'bytes;',
+          sum(len(c['cols']) for c in cases), 'rows;', sum(1 for c in cases for v in c['merge'].values() for r in v if len(r[1]) > 4), 'chained rows')
+
+
 # ----------------------------------------------------------------------------- G8 RunBlast.run end to end
 def g08(genes, refs, sam_text, bsn_text):
     out = []
@@ -1150,8 +1230,8 @@ def g17_examples():
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'g17':
-        g17_examples()
+    if len(sys.argv) > 1 and sys.argv[1] in ('g17', 'g18'):
+        {'g17': g17_examples, 'g18': g18}[sys.argv[1]]()
         shutil.rmtree(SHIM, ignore_errors=True)
         sys.exit(0)
     g13()
@@ -1161,6 +1241,7 @@ if __name__ == '__main__':
     bsn_text = g04(genes, refs, rel)
     g05_g06(genes, refs, sam_text, bsn_text)
     g07()
+    g18()
     g08(genes, refs, sam_text, bsn_text)
     g09()
     g10_g11_g12()

@@ -190,61 +190,34 @@ def test_map_filters(oracle_ctx):
         assert mapfilters.overlaps(_table(case['table']), 30, 0.1).tolist() == case['overlap_30_01_raw']
 
 
-def _dense_table(rng, n_gene, n_contig, per):
-    """many fragments per gene and contig, close together: chains, joined chains, contig-edge pairs, >8 rows per query"""
-    rows = []
-    for g in range(n_gene):
-        ql = int(rng.integers(600, 3000))
-        for c in range(n_contig):
-            sl = int(rng.integers(4000, 9000))
-            strand = 1 if rng.random() < 0.5 else -1
-            base = int(rng.integers(1, 400)) if rng.random() < 0.5 else int(rng.integers(sl // 2, sl - 1500))
-            q_at, r_at = int(rng.integers(1, 40)), base
-            for h in range(int(rng.integers(1, per + 1))):
-                ln = int(rng.integers(60, 500))
-                qs, qe = q_at, min(ql, q_at + ln)
-                if qe - qs < 50:
-                    break
-                span = qe - qs + int(rng.integers(-6, 7))
-                lo, hi = r_at, min(sl, r_at + span)
-                if hi - lo < 40:
-                    break
-                if strand > 0:
-                    ss, se = lo, hi
-                else:
-                    ss, se, qs, qe = hi, lo, ql - qe + 1, ql - qs + 1
-                iden = round(float(rng.uniform(0.7, 1.0)), 3)
-                score = float(int((qe - qs + 1) * (4 * iden - 1))) if rng.random() < 0.8 else int((qe - qs + 1) * 2)
-                rows.append([str(g) if g % 2 else g, 'c%d' % c, iden, qe - qs + 1, 3, 0, qs, qe, ss, se, 0.0, score, ql, sl, [[qe - qs + 1, 'M']], len(rows)])
-                step = int(rng.integers(-30, 200))
-                q_at, r_at = q_at + ln + step, r_at + span + step + int(rng.integers(-20, 20))
-            if rng.random() < 0.3 and rows:                      # an overlapping competitor of the last hit
-                t = list(rows[-1]); t[11] = t[11] - int(rng.integers(-40, 40)); t[8] += 3 * (1 if t[8] < t[9] else 0); t[15] = len(rows)
-                if t[8] != t[9]:
-                    rows.append(t)
-    for r in rows:
-        r[0] = str(r[0])
-    return _table(rows)
-
-
-def test_cpp_filters_equal_the_python_statement():
-    """pep_ovl_filter / pep_linear_merge (host C++) against the pure-Python statements that the golden vectors pin, on dense random tables"""
-    import copy
-    rng = np.random.default_rng(4242)
-    g = load_golden('g07_filters.json')
-    tables = [_table(c['table']) for c in g['cases']] + [_dense_table(rng, 30, 3, k) for k in (2, 5, 12, 20)]
-    chained = 0
-    for tab in tables:
-        for cov, delta in ((0.9, 0.), (0.5, 10.), (0.2, -5.)):
+def test_cpp_filters_equal_the_reference_on_random_tables():
+    """pep_ovl_filter / pep_linear_merge (host C++) against the reference's own ovlFilter / linearMerge on the 200 random tables of golden G18
+    (dense fragments: chains, joined chains, contig-edge pairs, more than eight rows per query, overlapping competitors)"""
+    import gzip
+    from conftest import GOLDEN
+    with gzip.open(os.path.join(GOLDEN, 'g18_filters_random.json.gz')) as f:
+        g = json.loads(f.read().decode())
+    assert len(g['cases']) == 200
+    chained = dropped = 0
+    for case in g['cases']:
+        rows = [[q, r, iden, qe - qs + 1, 3, 0, qs, qe, ss, se, 0.0, score, ql, sl, [[qe - qs + 1, 'M']], i]
+                for i, (q, r, iden, qs, qe, ss, se, score, ql, sl) in enumerate(case['cols'])]
+        tab = _table(rows)
+        for key, want in case['ovl'].items():
+            cov, delta = (float(x) for x in key.split('_'))
             a = mapfilters.ovl_filter(copy.deepcopy(tab), cov, delta)
-            b = mapfilters.ovl_filter_py(copy.deepcopy(tab), cov, delta)
-            assert a.tolist() == b.tolist()
-        for gap, diff in ((600., 1.5), (300., 1.2), (2000., 3.0)):
+            assert [int(r[15]) for r in a] == want, key
+            rows_equal([r[:15] for r in a], [rows[i][:15] for i in want])
+            dropped += len(rows) - len(want)
+        for key, want in case['merge'].items():
+            gap, diff = (float(x) for x in key.split('_'))
             a = mapfilters.linear_merge(copy.deepcopy(tab), gap, diff)
-            b = mapfilters.linear_merge_py(copy.deepcopy(tab), gap, diff)
-            assert a.tolist() == b.tolist()
-            chained += sum(1 for r in a if len(r[16]) > 4)
-    assert chained > 200
+            assert [int(r[15]) for r in a] == [w[0] for w in want], key
+            for r, (i, m) in zip(a, want):
+                assert list(r[:15]) == rows[i][:15]
+                assert json.loads(json.dumps(list(r[16]), default=lambda o: o.item())) == m, (key, i)
+            chained += sum(1 for w in want if len(w[1]) > 4)
+    assert chained > 10000 and dropped > 1000
     e = mapfilters.linear_merge(np.empty([0, 16], dtype=object), 600., 1.5)
     assert e.shape == (0, 17) and mapfilters.ovl_filter(np.empty([0, 16], dtype=object), 0.9, 0.).shape == (0, 16)
 
