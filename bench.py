@@ -81,7 +81,7 @@ def spawn_ranks(args, argv):
     return 0
 
 
-def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup):
+def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_stores=False):
     """The genes -> genomes mapping (BASELINE configs "x 500 / x 2000 genomes"; PEPPAN.py:907-989) as a bench workload: every rank maps ITS OWN
     n_genomes synthetic genomes (10 000 exemplar genes, 2.2 Mb per genome) - batched GPU search for both tools, -f / -m / -O chain, K7, K12,
     build_bsn - per step.  Genomes are the independent unit of this path: they shard over the ranks with no data-path collective (weak
@@ -108,16 +108,24 @@ def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup):
                 nt += len(contig)
                 op.save(100000 + g, np.array([[k, a, b, st, 1] for k, a, b, st in ann[::2]], dtype=object))
         og = np.array([[0, 1, 9000], [4, 5, -2]], dtype=int)
+        np.save('m.self_bsn.npy', og)
         UB._CTX.clear()
         os.environ['PEPPAN_HIP_DEVICE'] = str(local_rank)
+        ortho = mapbsn.OrthoRelation(og)
+        genomes = {100000 + g: [900000 + g, contig.decode()] for g, (gname, contig, ann) in enumerate(worlds)}
 
         def step():
             groups = rows = 0
             for job, (tab, ovl) in zip(jobs, mapbsn._gpu_search('m', 'm.clust.exemplar', jobs, params, genomes_per_batch=n_genomes)):
-                bsn, o = mapbsn.build_bsn(tab, ovl, job[2], og, 'm.old_prediction.npz', params)
-                groups += bsn.shape[0]
+                G = mapbsn.build_groups(tab, ovl, job[2], ortho, 'm.old_prediction.npz', params)
+                groups += len(G)
                 rows += len(tab)
             return groups, rows
+
+        def step_with_stores():
+            """the same genomes through get_map_bsn with the reference's four stores written (PEPPAN.py:907-989; .seq included)"""
+            with mapbsn.MapBsn('t.npz', 'w') as c0, mapbsn.MapBsn('s.npz', 'w') as c1, mapbsn.MapBsn('a.npz', 'w') as c2, mapbsn.MapBsn('c.npz', 'w') as c3:
+                mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params, genomes_per_round=n_genomes)
         with contextlib.redirect_stderr(io.StringIO()):
             for _ in range(warmup):
                 step()
@@ -125,11 +133,18 @@ def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup):
             for _ in range(steps):
                 groups, rows = step()
             dt = time.perf_counter() - t0
+            dt_stores = None
+            if with_stores:
+                step_with_stores()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step_with_stores()
+                dt_stores = time.perf_counter() - t0
     finally:
         os.chdir(cwd)
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
-    return dict(seconds=dt, genomes=n_genomes * steps, genome_nt=nt, groups_per_step=groups, hit_rows_per_step=rows)
+    return dict(seconds=dt, seconds_with_stores=dt_stores, genomes=n_genomes * steps, genome_nt=nt, groups_per_step=groups, hit_rows_per_step=rows)
 
 
 def _profile_tables():
@@ -415,8 +430,9 @@ def main():
                                                'note': 'decide = classification + host scan + K14 + resolve + exemplar rewrite; search = the uberBlast call in front of it (numeric table, FASTA re-read because the exemplar file was rewritten)'}
         # (d) the genes -> genomes mapping at N = 1 (bench.py --workload map is the same thing per rank): genomes/s on this GPU
         try:
-            mr = map_workload(args, 0, 1, local_rank, 16, 1, 1)
-            extras['map_workload'] = {'genomes_per_s': mr['genomes'] / mr['seconds'], 'genomes': mr['genomes'], 'genome_nt': mr['genome_nt'], 'groups_per_step': mr['groups_per_step'],
+            mr = map_workload(args, 0, 1, local_rank, 16, 1, 1, with_stores=True)
+            extras['map_workload'] = {'genomes_per_s': mr['genomes'] / mr['seconds'], 'genomes_per_s_with_stores': mr['genomes'] / mr['seconds_with_stores'],
+                                      'genomes': mr['genomes'], 'genome_nt': mr['genome_nt'], 'groups_per_step': mr['groups_per_step'],
                                       'note': 'python bench.py --workload map --gpus N: genomes sharded over the ranks, weak scaling, no collective'}
         except Exception as e:                                  # never lose the headline over the secondary leg
             extras['map_workload'] = {'error': repr(e)}

@@ -30,6 +30,8 @@
  *   pep_ovl_filter          RunBlast.ovlFilter (host C++)                    uberBlast.py:417-452
  *   pep_linear_merge        RunBlast.linearMerge + _linearMerge (host C++)   uberBlast.py:100-218, 453-460
  *   pep_alleles             aligned-allele strings + base-5 packing of iter_map_bsn   PEPPAN.py:812-835, 846-848
+ *   pep_store_mat_member / pep_store_seq_member   the 1000-group members of the .mat / .seq stores get_map_bsn writes (host C++:
+ *                           the .npy pickle stream emitted from the numeric hit table)   PEPPAN.py:950-966
  *   pep_similar_scan / pep_pair_support / pep_similar_resolve   the pass of get_similar_pairs over the all-vs-all table and its
  *                           get_similar (host state machine, K14 on the GPU, host dictionary)   PEPPAN.py:195-224, 231-276, 294
  */
@@ -40,7 +42,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 8
+#define PEP_ABI_VERSION 9
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -361,6 +363,30 @@ int pep_linear_merge(uint64_t n, const int64_t *q, const int64_t *r, const doubl
                      const int64_t *se, const double *score, const int64_t *ql, const int64_t *sl, const int64_t *rid, double gap_dist, double len_diff,
                      int64_t *keep_seq, uint64_t keep_cap, uint64_t *n_keep, uint64_t *query_off, uint8_t *query_ascending, uint64_t *n_query,
                      double *grp_score, double *grp_iden, int64_t *grp_span, uint64_t *grp_ids_off, int64_t *grp_ids, uint64_t ids_cap, uint64_t *n_ids);
+
+/* Members of the genome-mapping stores (PEPPAN.py:950-966: 1000 groups per member of <prefix>.mat.npz / <prefix>.seq.npz), emitted as
+ * the pickle stream numpy writes for an object array, straight from numeric columns - no Python object is made for a stored row.
+ * Host C++, no context.
+ *   pep_store_mat_member: the stream of ndarray(object)[n_groups] whose element g is ndarray(object)[row_off[g+1] - row_off[g], 16]
+ *     of the hit rows [row_off[g], row_off[g+1]) of `cols`: columns 0-15 of the reference's table with q / r
+ *     as integers (PEPPAN's encoded names), the CIGAR as text ("150M3D150M", uberBlast.py:480), score as int when score_is_int.
+ *   pep_store_seq_member: ndarray(object)[n_groups] of ndarray(uint8) = packed[pack_off[g] .. pack_off[g+1]) (the base-5 packed
+ *     alleles, PEPPAN.py:846-848).
+ * recon_module: the module that holds numpy's `_reconstruct` ("numpy._core.multiarray" / "numpy.core.multiarray").
+ * Both return the length of the stream; when it exceeds `cap` the buffer holds nothing usable and the caller calls again with a
+ * larger one (cap = 0 measures).  Negative: PEP_ERR_ARG. */
+typedef struct pep_mat_cols {
+    const int64_t *q, *r;
+    const double *iden;
+    const int64_t *aln, *mis, *gap, *qs, *qe, *ss, *se;
+    const double *evalue, *score;
+    const int64_t *ql, *sl;
+    const uint32_t *arena;          /* CIGAR runs len << 2 | op (0 M, 1 I, 2 D), nucleotide units */
+    const int64_t *c_off, *c_runs, *rid;
+    int32_t score_is_int, reserved;
+} pep_mat_cols;
+int64_t pep_store_mat_member(const pep_mat_cols *cols, const int64_t *row_off, int64_t n_groups, const char *recon_module, uint8_t *out, int64_t cap);
+int64_t pep_store_seq_member(const uint8_t *packed, const int64_t *pack_off, int64_t n_groups, const char *recon_module, uint8_t *out, int64_t cap);
 
 #ifdef __cplusplus
 }

@@ -7,14 +7,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan']
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member']
 
 
 class PepError(RuntimeError):
@@ -240,6 +240,73 @@ def linear_merge(q, r, iden, qs, qe, ss, se, score, ql, sl, rid, gap_dist, len_d
                     ids[:n_ids.value])
         keep_cap, ids_cap = n_keep.value + 16, n_ids.value + 16
     raise PepError('pep_linear_merge: inconsistent sizes')
+
+
+class MatCols(C.Structure):
+    """pep_mat_cols (include/peppan_hip.h): the sixteen stored columns of the hit table as pointers"""
+    _fields_ = [(n, C.c_void_p) for n in ('q', 'r', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'ql', 'sl', 'arena', 'c_off', 'c_runs', 'rid')] + \
+               [('score_is_int', C.c_int32), ('reserved', C.c_int32)]
+
+
+_RECON_MODULE = None
+
+
+def _recon_module():
+    """the module numpy's own pickles name for `_reconstruct` (numpy._core.multiarray since numpy 2, numpy.core.multiarray before)"""
+    global _RECON_MODULE
+    if _RECON_MODULE is None:
+        _RECON_MODULE = np.empty(0).__reduce__()[0].__module__.encode()
+    return _RECON_MODULE
+
+
+def _npy_object_header(n):
+    """the .npy header of a 1-D object array of n elements (what np.lib.format.write_array puts in front of the pickle)"""
+    import io
+    buf = io.BytesIO()
+    np.lib.format.write_array_header_1_0(buf, {'descr': '|O', 'fortran_order': False, 'shape': (int(n),)})
+    return buf.getvalue()
+
+
+def store_mat_member(cols, row_off, score_is_int):
+    """pep_store_mat_member: the complete .npy member (header + pickle stream) of one chunk of the .mat store (PEPPAN.py:959-966).
+    cols: the 18 arrays of MatCols in field order (q and r as int64 names per row); row_off int64[n_groups + 1]."""
+    lib = load_library()
+    lib.pep_store_mat_member.restype = C.c_int64
+    keep = [np.ascontiguousarray(a, dtype=dt) for a, dt in zip(cols, (np.int64, np.int64, np.float64) + (np.int64,) * 7 + (np.float64, np.float64, np.int64, np.int64,
+                                                                                                                       np.uint32, np.int64, np.int64, np.int64))]
+    mc = MatCols(*[a.ctypes.data for a in keep], int(bool(score_is_int)), 0)
+    row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+    n_groups = len(row_off) - 1
+    n_rows = int(row_off[-1] - row_off[0]) if n_groups else 0
+    head = _npy_object_header(n_groups)
+    cap = 256 + 64 * n_groups + 200 * n_rows + 12 * int(keep[16][row_off[0]:row_off[-1]].sum() if n_rows else 0)
+    for _ in range(2):
+        buf = np.empty(len(head) + cap, dtype=np.uint8)
+        need = lib.pep_store_mat_member(C.byref(mc), _ptr(row_off), C.c_int64(n_groups), C.c_char_p(_recon_module()), C.c_void_p(buf.ctypes.data + len(head)), C.c_int64(cap))
+        if need < 0:
+            raise PepError('pep_store_mat_member failed (%d)' % need)
+        if need <= cap:
+            buf[:len(head)] = np.frombuffer(head, dtype=np.uint8)
+            return buf[:len(head) + need].tobytes()
+        cap = int(need)
+    raise PepError('pep_store_mat_member: inconsistent sizes')
+
+
+def store_seq_member(packed, pack_off):
+    """pep_store_seq_member: the complete .npy member of one chunk of the .seq store (PEPPAN.py:950-957): object array of uint8 arrays"""
+    lib = load_library()
+    lib.pep_store_seq_member.restype = C.c_int64
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    pack_off = np.ascontiguousarray(pack_off, dtype=np.int64)
+    n_groups = len(pack_off) - 1
+    head = _npy_object_header(n_groups)
+    cap = 256 + 64 * n_groups + (int(pack_off[-1] - pack_off[0]) if n_groups else 0)
+    buf = np.empty(len(head) + cap, dtype=np.uint8)
+    need = lib.pep_store_seq_member(_ptr(packed), _ptr(pack_off), C.c_int64(n_groups), C.c_char_p(_recon_module()), C.c_void_p(buf.ctypes.data + len(head)), C.c_int64(cap))
+    if need < 0 or need > cap:
+        raise PepError('pep_store_seq_member failed (%d)' % need)
+    buf[:len(head)] = np.frombuffer(head, dtype=np.uint8)
+    return buf[:len(head) + need].tobytes()
 
 
 def similar_scan(q, r, action, forward, iden4, n_genes):

@@ -1,0 +1,177 @@
+// Members of the genome-mapping stores straight from numeric columns (host C++, no GPU work, no context).
+//
+// get_map_bsn (PEPPAN.py:950-966) keeps, per group of merged hits, the group's 16-column hit rows (store .mat) and its packed allele
+// (store .seq), 1000 groups per member; a member is one .npy file holding an OBJECT array whose elements are arrays - which numpy
+// writes as a pickle.  Making 12 000 x 16 Python objects per genome only to have the pickler walk them again was the floor of the
+// mapping path (18 ms of 84 per genome).  Here the pickle stream itself is emitted from the columns of the hit table: the same
+// value and Python type per cell the object rows held (int, float, str), one inner ndarray(object)[k, 16] per group, protocol-3
+// opcodes only, the two globals / the b'b' argument / the dtype objects shared through the memo exactly as numpy's own pickles
+// share them.  np.load(..., allow_pickle=True) - how PEPPAN reads its stores (PEPPAN.py:40-42, 1931) - returns equal arrays.
+//
+// The callers pass the module that holds `_reconstruct` in the running numpy ("numpy._core.multiarray" in numpy 2,
+// "numpy.core.multiarray" before), so a store is written the way the numpy at hand would write it.
+#include "../../include/peppan_hip.h"
+#include <cstdint>
+#include <cstring>
+
+namespace {
+
+struct Stream {
+    uint8_t *p;
+    int64_t cap, n;
+    void bytes(const void *src, int64_t len)
+    {
+        if (n + len <= cap) memcpy(p + n, src, (size_t)len);
+        n += len;                                        // (keeps counting past the end: the caller learns the size it needs)
+    }
+    void byte(uint8_t b) { bytes(&b, 1); }
+    void text(const char *s) { bytes(s, (int64_t)strlen(s)); }
+    void u32(uint32_t v) { uint8_t b[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)}; bytes(b, 4); }
+    void integer(int64_t v)
+    {
+        if (v >= 0 && v < 256) { byte('K'); byte((uint8_t)v); }
+        else if (v >= 0 && v < 65536) { byte('M'); byte((uint8_t)v); byte((uint8_t)(v >> 8)); }
+        else if (v >= INT32_MIN && v <= INT32_MAX) { byte('J'); u32((uint32_t)(int32_t)v); }
+        else {                                           // LONG1: little-endian two's complement, as few bytes as hold the sign
+            int len = 8;
+            while (len > 1) {
+                const uint8_t top = (uint8_t)((uint64_t)v >> (8 * (len - 1))), below = (uint8_t)((uint64_t)v >> (8 * (len - 2)));
+                if ((top == 0x00 && !(below & 0x80)) || (top == 0xFF && (below & 0x80))) --len; else break;
+            }
+            byte(0x8a); byte((uint8_t)len);
+            for (int k = 0; k < len; ++k) byte((uint8_t)((uint64_t)v >> (8 * k)));
+        }
+    }
+    void real(double v)
+    {
+        uint64_t b;
+        memcpy(&b, &v, 8);
+        byte('G');
+        for (int k = 7; k >= 0; --k) byte((uint8_t)(b >> (8 * k)));
+    }
+    void unicode(const char *s, uint32_t len) { byte('X'); u32(len); bytes(s, len); }
+    void get(uint8_t slot) { byte('h'); byte(slot); }
+    void put(uint8_t slot) { byte('q'); byte(slot); }
+};
+
+// memo slots
+enum { M_RECON = 0, M_NDARRAY = 1, M_B = 2, M_DTYPE_FN = 3, M_BAR = 4, M_OBJ_DTYPE = 5, M_U1_DTYPE = 6 };
+
+// numpy.dtype(code, False, True) + its state (3, '|', None, None, None, -1, -1, flags); slot = where the finished dtype is remembered
+void emit_dtype(Stream &s, const char *code, int flags, uint8_t slot, bool first_dtype)
+{
+    if (first_dtype) { s.text("cnumpy\ndtype\n"); s.put(M_DTYPE_FN); } else s.get(M_DTYPE_FN);
+    s.unicode(code, 2);
+    s.byte(0x89); s.byte(0x88); s.byte(0x87); s.byte('R'); s.put(slot);
+    s.byte('('); s.byte('K'); s.byte(3);
+    if (first_dtype) { s.unicode("|", 1); s.put(M_BAR); } else s.get(M_BAR);
+    s.byte('N'); s.byte('N'); s.byte('N'); s.byte('J'); s.u32(0xFFFFFFFFu); s.byte('J'); s.u32(0xFFFFFFFFu); s.byte('K'); s.byte((uint8_t)flags);
+    s.byte('t'); s.byte('b');
+}
+
+// _reconstruct(ndarray, (0,), b'b'): an empty array for BUILD to fill
+void emit_blank(Stream &s, const char *recon_module, bool first)
+{
+    if (first) {
+        s.byte('c'); s.text(recon_module); s.text("\n_reconstruct\n"); s.put(M_RECON);
+        s.text("cnumpy\nndarray\n"); s.put(M_NDARRAY);
+        s.byte('K'); s.byte(0); s.byte(0x85);
+        s.byte('C'); s.byte(1); s.byte('b'); s.put(M_B);
+    } else {
+        s.get(M_RECON); s.get(M_NDARRAY); s.byte('K'); s.byte(0); s.byte(0x85); s.get(M_B);
+    }
+    s.byte(0x87); s.byte('R');
+}
+
+// the outer array: ndarray(object)[n]; afterwards the stream stands inside its element list
+void open_outer(Stream &s, const char *recon_module, int64_t n)
+{
+    s.byte(0x80); s.byte(3);
+    emit_blank(s, recon_module, true);
+    s.byte('('); s.byte('K'); s.byte(1);
+    s.integer(n); s.byte(0x85);
+    emit_dtype(s, "O8", 63, M_OBJ_DTYPE, true);
+    s.byte(0x89); s.byte(']'); s.byte('(');
+}
+
+void close_outer(Stream &s)
+{
+    s.byte('e'); s.byte('t'); s.byte('b'); s.byte('.');
+}
+
+uint32_t cigar_text(char *dst, const uint32_t *runs, int64_t n)
+{
+    uint32_t len = 0;
+    for (int64_t x = 0; x < n; ++x) {
+        uint32_t v = runs[x] >> 2;
+        char tmp[12];
+        int d = 0;
+        do { tmp[d++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (d) dst[len++] = tmp[--d];
+        dst[len++] = "MID?"[runs[x] & 3u];
+    }
+    return len;
+}
+
+}  // namespace
+
+extern "C" int64_t pep_store_mat_member(const pep_mat_cols *c, const int64_t *row_off, int64_t n_groups, const char *recon_module, uint8_t *out, int64_t cap)
+{
+    if (!c || !row_off || !recon_module || n_groups < 0 || (cap > 0 && !out)) return PEP_ERR_ARG;
+    Stream s{out, cap, 0};
+    open_outer(s, recon_module, n_groups);
+    char small[256];
+    char *text = small;
+    int64_t text_cap = sizeof(small);
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int64_t lo = row_off[g], hi = row_off[g + 1];
+        if (hi < lo) { if (text != small) delete[] text; return PEP_ERR_ARG; }
+        emit_blank(s, recon_module, false);
+        s.byte('('); s.byte('K'); s.byte(1);
+        s.integer(hi - lo); s.integer(16); s.byte(0x86);
+        s.get(M_OBJ_DTYPE);
+        s.byte(0x89); s.byte(']'); s.byte('(');
+        for (int64_t k = lo; k < hi; ++k) {
+            s.integer(c->q[k]); s.integer(c->r[k]); s.real(c->iden[k]);
+            s.integer(c->aln[k]); s.integer(c->mis[k]); s.integer(c->gap[k]);
+            s.integer(c->qs[k]); s.integer(c->qe[k]); s.integer(c->ss[k]); s.integer(c->se[k]);
+            s.real(c->evalue[k]);
+            if (c->score_is_int) s.integer((int64_t)c->score[k]); else s.real(c->score[k]);
+            s.integer(c->ql[k]); s.integer(c->sl[k]);
+            const int64_t need = c->c_runs[k] * 12 + 1;
+            if (need > text_cap) {
+                if (text != small) delete[] text;
+                text_cap = need * 2;
+                text = new char[(size_t)text_cap];
+            }
+            const uint32_t len = cigar_text(text, c->arena + c->c_off[k], c->c_runs[k]);
+            s.unicode(text, len);
+            s.integer(c->rid[k]);
+        }
+        s.byte('e'); s.byte('t'); s.byte('b');
+    }
+    if (text != small) delete[] text;
+    close_outer(s);
+    return s.n;
+}
+
+extern "C" int64_t pep_store_seq_member(const uint8_t *packed, const int64_t *pack_off, int64_t n_groups, const char *recon_module, uint8_t *out, int64_t cap)
+{
+    if (!pack_off || !recon_module || n_groups < 0 || (cap > 0 && !out)) return PEP_ERR_ARG;
+    Stream s{out, cap, 0};
+    open_outer(s, recon_module, n_groups);
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int64_t lo = pack_off[g], len = pack_off[g + 1] - lo;
+        if (len < 0 || (len > 0 && !packed)) return PEP_ERR_ARG;
+        emit_blank(s, recon_module, false);
+        s.byte('('); s.byte('K'); s.byte(1);
+        s.integer(len); s.byte(0x85);
+        if (g == 0) emit_dtype(s, "u1", 0, M_U1_DTYPE, false); else s.get(M_U1_DTYPE);
+        s.byte(0x89);
+        if (len < 256) { s.byte('C'); s.byte((uint8_t)len); } else { s.byte('B'); s.u32((uint32_t)len); }
+        s.bytes(packed + lo, len);
+        s.byte('t'); s.byte('b');
+    }
+    close_outer(s);
+    return s.n;
+}

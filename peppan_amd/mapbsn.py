@@ -16,13 +16,14 @@ import queue
 import threading
 import os
 import sys
+import time
 import zipfile
 
 import numpy as np
 
 from .configure import logger
 
-__all__ = ['MapBsn', 'decodeSeq', 'encodeSeq', 'compare_prediction', 'build_bsn', 'iter_map_bsn', 'get_map_bsn']
+__all__ = ['MapBsn', 'decodeSeq', 'encodeSeq', 'compare_prediction', 'GenomeGroups', 'OrthoRelation', 'build_groups', 'build_bsn', 'iter_map_bsn', 'get_map_bsn']
 
 
 def _npy_bytes(val):
@@ -67,6 +68,8 @@ class MapBsn(object):
                     return
                 db, key, data = item
                 if self._error is None:
+                    if callable(data):
+                        data = data()               # a member whose bytes are made here, off the caller's thread (C emitters: no GIL held)
                     # members are read back whole either way; deflating a few hundred bytes costs more than it saves (zlib set-up per member)
                     db.writestr(key, data, compress_type=zipfile.ZIP_STORED if len(data) < 4096 else None)
             except BaseException as e:              # reported by the next _flush() on the owning thread
@@ -135,13 +138,16 @@ class MapBsn(object):
         os.replace(tmp, self.fname)
         self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
 
-    def _save(self, db, key, val):
-        data = _npy_bytes(val)                      # serialised here: the caller may change `val` afterwards
+    def _enqueue(self, db, key, data):
+        """data: the member's bytes, or a callable that returns them (run by the writer thread)"""
         if self._thread is None:
             self._queue = queue.Queue(maxsize=256)
             self._thread = threading.Thread(target=self._writer, daemon=True)
             self._thread.start()
         self._queue.put((db, key, data))
+
+    def _save(self, db, key, val):
+        self._enqueue(db, key, _npy_bytes(val))     # serialised here: the caller may change `val` afterwards
 
     def save(self, key, val):
         key = str(key)
@@ -149,26 +155,37 @@ class MapBsn(object):
         self._save(self.conn, key, val)
         self.namelist.add(key)
 
+    def save_member(self, key, make_bytes):
+        """save() for a member that arrives as ready-made .npy bytes (or a callable producing them on the writer thread)"""
+        key = str(key)
+        self.delete_real(key)
+        self._enqueue(self.conn, key, make_bytes)
+        self.namelist.add(key)
+
     def update(self, dataset):
-        """merge a list of 2-D arrays, each keyed by its [0][0], into the store (rows appended to what the key holds)"""
-        tmp_name = self.fname[:-4] + '.tmp.npz'
-        seen = set()
-        with zipfile.ZipFile(tmp_name, mode='w', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as tmp:
-            for d in dataset:
-                key = str(d[0][0])
-                seen.add(key)
-                old = self.get(key)
-                self._save(tmp, key, np.vstack([old, d]) if len(old) else d)
-            for key in list(self.keys()):
-                if key not in seen:
-                    data = self.get(key)
-                    if len(data):
-                        seen.add(key)
-                        self._save(tmp, key, data)
+        """Rows for many keys at once (PEPPAN.py:91-113): every 2-D array of `dataset` belongs to the key in its first cell and is
+        appended to what the store holds under that key; members that are not mentioned stay (empty ones are dropped).  The archive
+        is rebuilt beside the old one and swapped in, as zip members cannot grow in place."""
+        incoming = {}
+        for rows in dataset:
+            incoming[str(rows[0][0])] = rows                       # (a key named twice: the later array counts)
+        self._flush()
+        side = self.fname[:-4] + '.tmp.npz'
+        listed = set()
+        with zipfile.ZipFile(side, mode='w', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as fresh:
+            for key in list(incoming) + sorted(self.namelist.difference(incoming)):
+                have, more = self.get(key), incoming.get(key)
+                if more is not None and len(have):
+                    more = np.vstack([have, more])
+                elif more is None:
+                    more = have
+                if len(more):
+                    self._save(fresh, key, more)
+                    listed.add(key)
             self._flush()
         self.conn.close()
-        self.namelist = seen
-        os.rename(tmp_name, self.fname)
+        os.replace(side, self.fname)
+        self.namelist = listed
         self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
 
 
@@ -313,11 +330,86 @@ def _passes_all(length, ql, params):
             (length >= np.maximum(params['match_prop2'] * ql, params['match_len2'])))
 
 
-def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=None):
-    """(17-column table with merge groups, int[m,3] overlaps) of ONE genome -> (bsn object[n,7], ovl int[k,3]).
-    bsn row = [gene, contig, score, identity, packed allele, group id, rows(object[k,16])].  PEPPAN.py:773-866.
-    `blastab` is the HitTable the search chain ends with (the product path: no Python row is touched before the rows that are
-    stored get made) or the same thing as object rows.  The per-hit allele strings, their in-frame / stop-free lengths and the
+class GenomeGroups(object):
+    """The groups of merged hits of ONE genome as columns: what the reference's `bsn` table holds per row - [gene, contig, score,
+    identity, packed allele, group id, hit rows] (PEPPAN.py:836-866) - before any Python object is made for it.
+      gene / contig   int64[n]    names of the group's leading hit
+      score / iden    float64[n]
+      packed, pack_off            the base-5 packed alleles back to back, group g = packed[pack_off[g]:pack_off[g+1]]
+      rows, row_off               HitTable of the hit rows of all groups, group g = rows [row_off[g], row_off[g+1])
+      ovl             int64[k, 3] pairs of groups (local ids) that overlap on the genome, with their relation class"""
+    __slots__ = ('gene', 'contig', 'score', 'iden', 'packed', 'pack_off', 'rows', 'row_off', 'ovl')
+
+    def __init__(self, gene, contig, score, iden, packed, pack_off, rows, row_off, ovl):
+        self.gene, self.contig, self.score, self.iden = gene, contig, score, iden
+        self.packed, self.pack_off, self.rows, self.row_off, self.ovl = packed, pack_off, rows, row_off, ovl
+
+    def __len__(self):
+        return len(self.gene)
+
+    @classmethod
+    def none(cls):
+        z = np.zeros(0, dtype=np.int64)
+        return cls(z, z, np.zeros(0), np.zeros(0), np.zeros(0, np.uint8), np.zeros(1, np.int64), None, np.zeros(1, np.int64), np.zeros([0, 3], dtype=np.int64))
+
+    def as_bsn(self):
+        """the reference's object table [n, 7] (what iter_map_bsn stores in <prefix>.<id>.bsn.npz, PEPPAN.py:866)"""
+        n = len(self)
+        bsn = np.empty([n, 7], dtype=object)
+        if n == 0:
+            return bsn
+        rows16 = self.rows.to_rows(cigar='str')
+        gene, contig, iden = self.gene.tolist(), self.contig.tolist(), self.iden.tolist()
+        r_lo, p_lo = self.row_off.tolist(), self.pack_off.tolist()
+        for g in range(n):
+            row = bsn[g]
+            row[0], row[1], row[2], row[3], row[4], row[5], row[6] = gene[g], contig[g], self.score[g], iden[g], self.packed[p_lo[g]:p_lo[g + 1]], g, rows16[r_lo[g]:r_lo[g + 1]]
+        return bsn
+
+
+class OrthoRelation(object):
+    """the relation of two genes in the all-vs-all result (rows [gene, gene, value] of <prefix>.self_bsn.npy): +1 ortholog-like
+    (value > 0), -1 conflict (value < 0), 2 when the pair is not listed; a gene with itself is 0.  The reference builds a dictionary
+    of both orientations for every genome (PEPPAN.py:856-862: first every pair as listed, then every pair reversed, later entries
+    replacing earlier ones); here it is ONE sorted key array per run and a binary search per question."""
+
+    def __init__(self, ortho):
+        og = np.load(ortho, allow_pickle=True) if isinstance(ortho, str) else np.asarray(ortho)
+        og = og[og.T[2] != 0] if len(og) else np.zeros([0, 3], dtype=np.int64)
+        a, b = og.T[0].astype(np.int64), og.T[1].astype(np.int64)
+        sign = np.where(og.T[2].astype(np.int64) > 0, 1, -1)
+        self._wide = len(og) > 0 and (min(a.min(), b.min()) < 0 or max(a.max(), b.max()) >= (1 << 31))
+        if self._wide:                                           # (names beyond 31 bits: PEPPAN's encoded ids never are)
+            self._table = {}
+            for x, y, v in list(zip(a.tolist(), b.tolist(), sign.tolist())) + list(zip(b.tolist(), a.tolist(), sign.tolist())):
+                self._table[(x, y)] = v
+            return
+        key = np.concatenate([(a << 32) | b, (b << 32) | a])
+        val = np.concatenate([sign, sign])
+        order = np.argsort(key, kind='stable')
+        key, val = key[order], val[order]
+        last = np.concatenate([key[1:] != key[:-1], [True]]) if len(key) else np.zeros(0, dtype=bool)        # of equal keys the latest entry counts
+        self._key, self._val = key[last], val[last]
+
+    def between(self, m, k):
+        m, k = np.asarray(m, dtype=np.int64), np.asarray(k, dtype=np.int64)
+        if self._wide:
+            return np.array([0 if x == y else self._table.get((x, y), 2) for x, y in zip(m.tolist(), k.tolist())], dtype=np.int64)
+        out = np.full(len(m), 2, dtype=np.int64)
+        if len(self._key) and len(m):
+            narrow = (m >= 0) & (k >= 0) & (m < (1 << 31)) & (k < (1 << 31))
+            q = (m << 32) | k
+            at = np.minimum(np.searchsorted(self._key, q), len(self._key) - 1)
+            hit = narrow & (self._key[at] == q)
+            out[hit] = self._val[at[hit]]
+        out[m == k] = 0
+        return out
+
+
+def build_groups(blastab, overlap, seq, ortho, old_prediction, params, ctx=None):
+    """(17-column table with merge groups, int[m, 3] overlaps) of ONE genome -> GenomeGroups.  PEPPAN.py:773-866.
+    `blastab` is the HitTable the search chain ends with (the product path: no Python row is made at all) or the same thing as object
+    rows; `ortho` an OrthoRelation (or what it is built from).  The per-hit allele strings, their in-frame / stop-free lengths and the
     packing run on the GPU (K12, `ctx.alleles`).
 
     Groups, in the reference's order: first every row that stands for itself - a row whose merge group is just itself, or a member
@@ -326,7 +418,7 @@ def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=Non
     from .hittable import HitTable
     T = blastab if isinstance(blastab, HitTable) else HitTable.from_rows(blastab)
     if len(T) == 0:
-        return np.empty([0, 7], dtype=object), np.zeros([0, 3], dtype=np.int64)
+        return GenomeGroups.none()
     if ctx is None:
         from .uberBlast import get_context
         ctx = get_context()
@@ -363,7 +455,7 @@ def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=Non
     n_groups = len(n_rows)
     overlap = overlap[kept[overlap.T[0]] & kept[overlap.T[1]], :2]
     if n_groups == 0:
-        return np.empty([0, 7], dtype=object), np.zeros([0, 3], dtype=np.int64)
+        return GenomeGroups.none()
     grp_off = np.concatenate([[0], np.cumsum(n_rows)]).astype(np.uint64)
     first = grp_off[:-1].astype(np.int64)
     head_row = np.concatenate([single, np.array(chain_first, dtype=np.int64)]).astype(np.int64)      # the row a group takes gene / contig / group score from
@@ -389,52 +481,52 @@ def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=Non
     r = np.sqrt(sc.astype(np.float64) / ql * known)
     msc = (sc * iden) * np.sqrt(sc * r)
     amsc = msc / qspan
-    pack_off = np.concatenate([[0], np.cumsum((ql[first] + 2) // 3)])
-    # ---- assemble
+    pack_off = np.concatenate([[0], np.cumsum((ql[first] + 2) // 3)]).astype(np.int64)
+    # ---- group scores: a single row's own; the fragments of a chain that overlap on the query give way to the stronger neighbour first
+    score = msc[first].astype(np.float64)
+    row_off = grp_off.astype(np.int64)
+    for gid in np.flatnonzero(n_rows > 1).tolist():
+        lo, hi = int(row_off[gid]), int(row_off[gid + 1])
+        spans = [[q_lo[k], q_hi[k], amsc[k], msc[k]] for k in range(lo, hi)]
+        for prev, cur in zip(spans[:-1], spans[1:]):
+            if cur[0] < prev[1]:
+                if cur[2] > prev[2]:
+                    prev[1] = cur[0] - 1
+                    prev[3] = prev[2] * (prev[1] - prev[0] + 1)
+                else:
+                    cur[0] = prev[1] + 1
+                    cur[3] = cur[2] * (cur[1] - cur[0] + 1)
+        score[gid] = np.sum([c[3] for c in spans])
+    # group identity: the merge group's for a lone row and for a chain, the row's own for a chain member standing alone
+    g_iden = np.where(is_lone_group | (n_rows > 1), T.m_iden[head_row], T.iden[head_row])
+    q_names, r_names = np.asarray(T.q_tab, dtype=np.int64), np.asarray(T.r_tab, dtype=np.int64)
+    g_gene, g_contig = q_names[T.qi[head_row]], r_names[T.ri[head_row]]
+    # ---- overlaps between groups: a row id may stand in a group of its own and in a chain
     as_single, as_chain = np.full(n_id, -1, dtype=np.int64), np.full(n_id, -1, dtype=np.int64)
     gid_of_row = loci['group'].astype(np.int64)
     multi = np.repeat(n_rows > 1, n_rows)
     rid_flat = T.rid[flat]
     as_single[rid_flat[~multi]] = gid_of_row[~multi]
     as_chain[rid_flat[multi]] = gid_of_row[multi]
-    rows16 = T.take(flat).to_rows(cigar='str')[:, :16]              # the object rows the .mat store keeps, made once
-    g_gene, g_contig = [T.q_tab[i] for i in T.qi[head_row].tolist()], [T.r_tab[i] for i in T.ri[head_row].tolist()]
-    # group score / identity: the merge group's for a lone row and for a chain, the row's own for a chain member standing alone
-    g_iden = np.where(is_lone_group | (n_rows > 1), T.m_iden[head_row], T.iden[head_row]).tolist()
-    bsn = np.empty([n_groups, 7], dtype=object)
-    lo_l, hi_l = grp_off[:-1].astype(np.int64).tolist(), grp_off[1:].astype(np.int64).tolist()
-    for gid in range(n_groups):
-        lo, hi = lo_l[gid], hi_l[gid]
-        if hi - lo == 1:
-            score = msc[lo]
-        else:
-            spans = [[q_lo[k], q_hi[k], amsc[k], msc[k]] for k in range(lo, hi)]
-            for prev, cur in zip(spans[:-1], spans[1:]):          # fragments overlapping on the query: the weaker one is trimmed
-                if cur[0] < prev[1]:
-                    if cur[2] > prev[2]:
-                        prev[1] = cur[0] - 1
-                        prev[3] = prev[2] * (prev[1] - prev[0] + 1)
-                    else:
-                        cur[0] = prev[1] + 1
-                        cur[3] = cur[2] * (cur[1] - cur[0] + 1)
-            score = np.sum([c[3] for c in spans])
-        row = bsn[gid]
-        row[0], row[1], row[2], row[3], row[4], row[5], row[6] = g_gene[gid], g_contig[gid], score, g_iden[gid], packed[pack_off[gid]:pack_off[gid + 1]], gid, rows16[lo:hi]
     a0, c0, a1, c1 = as_single[overlap.T[0]], as_chain[overlap.T[0]], as_single[overlap.T[1]], as_chain[overlap.T[1]]
-    overlap = np.vstack([np.vstack([m, k]).T[(m >= 0) & (k >= 0)] for m in (a0, c0) for k in (a1, c1)] +
-                        [np.vstack([as_single, as_chain]).T[(as_single >= 0) & (as_chain >= 0)]])
-    if overlap.shape[0]:
-        og = np.load(orthoGroup, allow_pickle=True) if isinstance(orthoGroup, str) else orthoGroup
-        rel = {}
-        for g in og[og.T[2] != 0]:
-            rel[(g[0], g[1])] = 1 if g[2] > 0 else -1
-        for g in og[og.T[2] != 0]:
-            rel[(g[1], g[0])] = 1 if g[2] > 0 else -1
-        score = np.array([0 if m == k else rel.get((m, k), 2) for m, k in zip(bsn[overlap.T[0], 0], bsn[overlap.T[1], 0])], dtype=np.int64)
-        overlap = np.hstack([overlap, score[:, np.newaxis]])[score >= 0]
+    pairs = np.vstack([np.vstack([m, k]).T[(m >= 0) & (k >= 0)] for m in (a0, c0) for k in (a1, c1)] +
+                      [np.vstack([as_single, as_chain]).T[(as_single >= 0) & (as_chain >= 0)]])
+    if pairs.shape[0]:
+        rel = ortho if isinstance(ortho, OrthoRelation) else OrthoRelation(ortho)
+        cls = rel.between(g_gene[pairs.T[0]], g_gene[pairs.T[1]])
+        pairs = np.hstack([pairs, cls[:, np.newaxis]])[cls >= 0]
     else:
-        overlap = np.zeros([0, 3], dtype=np.int64)
-    return bsn, overlap
+        pairs = np.zeros([0, 3], dtype=np.int64)
+    rows = T.take(flat)
+    rows.merge = rows.m_span = None                     # (the stored rows are the 16 columns: no merge lists to build)
+    return GenomeGroups(g_gene, g_contig, score, g_iden, packed, pack_off, rows, row_off, pairs)
+
+
+def build_bsn(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx=None):
+    """build_groups in the reference's form: (bsn object[n, 7], ovl int[k, 3]) with bsn row = [gene, contig, score, identity,
+    packed allele, group id, rows(object[k, 16])] (PEPPAN.py:773-866)"""
+    G = build_groups(blastab, overlap, seq, orthoGroup, old_prediction, params, ctx)
+    return G.as_bsn(), G.ovl
 
 
 def _map_argv(clust, params):
@@ -471,31 +563,27 @@ def iter_map_bsn(data):
 # ------------------------------------------------------------------------------------------------ all genomes
 CHUNK = 1000          # arrays per member of the .seq / .mat stores (PEPPAN.py:953, 962)
 BLOCK = 30000         # group ids per member of the .conflicts store (PEPPAN.py:934-947)
+TABLE_EVERY = 500     # genomes between two updates of the gene table store (PEPPAN.py:972)
 
 
 def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
-    """yield (blastab, overlap) per genome, `genomes_per_batch` genomes per GPU search"""
+    """yield (blastab, overlap) per genome, `genomes_per_batch` genomes per GPU search.  The genomes go to the search as they are -
+    the reference writes every genome to <prefix>.<id>.genome for its uberBlast call to read back (PEPPAN.py:763-766)"""
     from .uberBlast import uberBlastBatch
     argv = _map_argv(clust, params)
     for lo in range(0, len(jobs), genomes_per_batch):
-        files = [_write_genome(prefix, id, seq) for id, taxon, seq in jobs[lo:lo + genomes_per_batch]]
-        try:
-            results = uberBlastBatch(files, argv, as_tables=True)        # (HitTable, overlaps) per genome: build_bsn works on the columns
-        finally:
-            for f in files:
-                os.unlink(f)
-        for r in results:
+        for r in uberBlastBatch([seq for id, taxon, seq in jobs[lo:lo + genomes_per_batch]], argv, as_tables=True):        # (HitTable, overlaps) per genome
             yield r
 
 
-def _all_bsn(prefix, clust, jobs, og, old_prediction, params, search, ctx, group, per_round):
-    """(job, (bsn, ovl)) for every genome in job order.  With torch.distributed initialised the genomes are dealt to the ranks in
+def _all_groups(prefix, clust, jobs, ortho, old_prediction, params, search, ctx, group, per_round):
+    """(job, GenomeGroups) for every genome in job order.  With torch.distributed initialised the genomes are dealt to the ranks in
     blocks of `per_round` (independent units, no data-path collective); every rank maps its block on its own GPU and rank 0
-    gathers the finished per-genome objects - only rank 0 yields, the others just take part."""
+    gathers the finished per-genome columns - only rank 0 yields, the others just take part."""
     def local(mine):
         out = []
         for (id, taxon, seq), (blastab, overlap) in zip(mine, search(prefix, clust, mine, params) if mine else ()):
-            out.append(build_bsn(blastab, overlap, seq, og, old_prediction, params, ctx))
+            out.append(build_groups(blastab, overlap, seq, ortho, old_prediction, params, ctx))
         return out
     world, rank = 1, 0
     dist = sys.modules.get('torch.distributed')            # only a caller that set up a process group has imported it
@@ -503,7 +591,7 @@ def _all_bsn(prefix, clust, jobs, og, old_prediction, params, search, ctx, group
         world, rank = dist.get_world_size(group), dist.get_rank(group)
     if world == 1:
         for job, (blastab, overlap) in zip(jobs, search(prefix, clust, jobs, params)):
-            yield job, build_bsn(blastab, overlap, job[2], og, old_prediction, params, ctx)
+            yield job, build_groups(blastab, overlap, job[2], ortho, old_prediction, params, ctx)
         return
     n_rounds = -(-len(jobs) // (per_round * world))
     for k in range(n_rounds):
@@ -518,8 +606,170 @@ def _all_bsn(prefix, clust, jobs, og, old_prediction, params, search, ctx, group
                     yield job, out
 
 
+class _ConflictBlocks(object):
+    """The .conflicts store (PEPPAN.py:934-947, 983-986): for every block of BLOCK consecutive group ids one member holding a CSR -
+    BLOCK + 1 offsets (into the member itself, so they start at BLOCK + 1) followed by one value per conflict, partner id * 10 + class -
+    listing, per group of the block, the groups it overlaps on its genome, both directions of every pair.
+    Conflicts never cross genomes and group ids grow genome by genome, so the entries arrive ordered by block and a block is complete
+    as soon as the group counter has passed its end; what is pending is a list of (group id, value) column pairs."""
+
+    def __init__(self, store):
+        self.store, self.pending = store, []
+
+    def add(self, pairs):
+        """pairs int[k, 3] = (group, group, class) with store-wide group ids"""
+        if len(pairs) == 0:
+            return
+        src = np.concatenate([pairs[:, 0], pairs[:, 1]])
+        val = np.concatenate([pairs[:, 1], pairs[:, 0]]) * 10 + np.concatenate([pairs[:, 2], pairs[:, 2]])
+        order = np.argsort(src)                     # (the sort the reference applies to the doubled list: equal ids keep ITS order of ties)
+        self.pending.append((src[order], val[order]))
+
+    def write(self, below=None):
+        """every block that ends at or before group id `below` (None: everything that is left)"""
+        if not self.pending:
+            return
+        src, val = (np.concatenate(c) for c in zip(*self.pending))
+        block = src // BLOCK
+        done = len(src) if below is None else int(np.searchsorted(block, below // BLOCK))
+        if done == 0:
+            return
+        starts = np.concatenate([[0], np.flatnonzero(np.diff(block[:done])) + 1, [done]])
+        for a, b in zip(starts[:-1].tolist(), starts[1:].tolist()):
+            per_group = np.bincount(src[a:b] - block[a] * BLOCK, minlength=BLOCK)
+            self.store.save(int(block[a]), np.concatenate([np.concatenate([[0], np.cumsum(per_group)]) + (BLOCK + 1), val[a:b]]))
+        self.pending = [(src[done:], val[done:])] if done < len(src) else []
+
+
+class _MemberQueue(object):
+    """Groups waiting to become members of CHUNK consecutive groups each (the .seq and .mat stores, PEPPAN.py:950-966): a list of
+    per-genome column blocks with the range of groups still unwritten; a member is cut as soon as CHUNK groups are there and handed to
+    the store's writer thread as a closure, which emits the .npy bytes from the columns (pep_store_*_member) and deflates them."""
+
+    def __init__(self, store, emit):
+        self.store, self.emit, self.parts, self.waiting, self.members = store, emit, [], 0, 0
+
+    def add(self, block, n_groups):
+        self.parts.append([block, 0, n_groups])
+        self.waiting += n_groups
+        while self.waiting >= CHUNK:
+            self._cut(CHUNK)
+
+    def close(self):
+        if self.waiting:
+            self._cut(self.waiting)
+
+    def _cut(self, want):
+        take, need = [], want
+        while need:
+            block, lo, hi = self.parts[0]
+            n = min(need, hi - lo)
+            take.append((block, lo, lo + n))
+            need -= n
+            if lo + n == hi:
+                self.parts.pop(0)
+            else:
+                self.parts[0][1] = lo + n
+        self.waiting -= want
+        emit = self.emit
+        self.store.save_member(self.members, lambda: emit(take))
+        self.members += 1
+
+
+def _mat_block(G):
+    """the stored columns of a genome's hit rows, CIGAR runs gathered into an arena of their own (the search's arena is shared by a
+    whole batch of genomes)"""
+    R = G.rows
+    runs = R.c_runs
+    start = np.concatenate([[0], np.cumsum(runs)]).astype(np.int64)
+    src = np.repeat(R.c_off - start[:-1], runs) + np.arange(int(start[-1]))
+    q, r = np.asarray(R.q_tab, dtype=np.int64)[R.qi], np.asarray(R.r_tab, dtype=np.int64)[R.ri]
+    cols = [q, r, R.iden, R.aln, R.mis, R.gap, R.qs, R.qe, R.ss, R.se, R.evalue, R.score, R.ql, R.sl]
+    return dict(cols=cols, arena=R.arena[src], run_off=start, rid=R.rid, row_off=G.row_off, score_is_int=R.score_is_int)
+
+
+def _emit_mat(take):
+    from . import _native as N
+    cols, arenas, c_off, c_runs, rids, offs = [[] for _ in range(14)], [], [], [], [], [np.zeros(1, np.int64)]
+    runs_before = rows_before = 0
+    as_int = True
+    for block, lo, hi in take:
+        a, b = int(block['row_off'][lo]), int(block['row_off'][hi])
+        for k, c in enumerate(block['cols']):
+            cols[k].append(c[a:b])
+        ra, rb = int(block['run_off'][a]), int(block['run_off'][b])
+        arenas.append(block['arena'][ra:rb])
+        c_off.append(block['run_off'][a:b] - ra + runs_before)
+        c_runs.append(np.diff(block['run_off'][a:b + 1]))
+        rids.append(block['rid'][a:b])
+        offs.append(block['row_off'][lo + 1:hi + 1] - a + rows_before)
+        runs_before, rows_before = runs_before + (rb - ra), rows_before + (b - a)
+        as_int = as_int and block['score_is_int']
+    cat = lambda parts, dt: np.concatenate(parts).astype(dt, copy=False) if parts else np.zeros(0, dt)
+    arena = cat(arenas, np.uint32)
+    return N.store_mat_member([cat(c, np.float64 if k in (2, 10, 11) else np.int64) for k, c in enumerate(cols)] +
+                              [arena if len(arena) else np.zeros(1, np.uint32), cat(c_off, np.int64), cat(c_runs, np.int64), cat(rids, np.int64)],
+                              cat(offs, np.int64), as_int)
+
+
+def _emit_seq(take):
+    from . import _native as N
+    data, offs, before = [], [np.zeros(1, np.int64)], 0
+    for (packed, pack_off), lo, hi in take:
+        a, b = int(pack_off[lo]), int(pack_off[hi])
+        data.append(packed[a:b])
+        offs.append(pack_off[lo + 1:hi + 1] - a + before)
+        before += b - a
+    return N.store_seq_member(np.concatenate(data) if before else np.zeros(1, np.uint8), np.concatenate(offs))
+
+
+class _StoreWriter(object):
+    """what get_map_bsn keeps between genomes: the group counter and the unwritten parts of the four stores"""
+
+    def __init__(self, conn, seq_conn, mat_conn, clf_conn, save_seq):
+        self.conn = conn
+        self.n_group, self.table = 0, []
+        self.conflicts = _ConflictBlocks(clf_conn)
+        self.seqs = _MemberQueue(seq_conn, _emit_seq) if save_seq else None
+        self.mats = _MemberQueue(mat_conn, _emit_mat)
+
+    def add(self, G, taxon):
+        n, first = len(G), self.n_group
+        self.n_group += n
+        if len(G.ovl):
+            pairs = G.ovl.astype(np.int64)
+            pairs[:, :2] += first
+            self.conflicts.add(pairs)
+            self.conflicts.write(below=self.n_group)
+        if self.seqs is not None:
+            self.seqs.add((G.packed, G.pack_off), n)
+        self.mats.add(_mat_block(G), n)
+        # the gene table's rows [gene, taxon, score, identity, identity, group id, fragments] x 1e4 where fractional, best score first
+        s4 = G.score * 10000
+        order = np.argsort(-s4.astype(object))       # (as the reference sorts its object column: the same order among equal scores)
+        i4 = (G.iden * 10000).astype(np.int64)
+        rows = np.stack([G.gene, np.full(n, taxon, dtype=np.int64), s4.astype(np.int64), i4, i4, np.arange(first, first + n, dtype=np.int64),
+                         np.diff(G.row_off).astype(np.uint8).astype(np.int64)], axis=1)
+        self.table.append(rows[order])
+
+    def write_table(self):
+        if not self.table:
+            return
+        tab = np.vstack(self.table)
+        tab = tab[np.argsort(tab[:, 0], kind='stable')]
+        self.conn.update(np.split(tab, np.flatnonzero(np.diff(tab[:, 0])) + 1))
+        self.table = []
+
+    def close(self):
+        self.write_table()
+        if self.seqs is not None:
+            self.seqs.close()
+        self.mats.close()
+        self.conflicts.write()
+
+
 def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_conn, mat_conn, clf_conn, saveSeq, params, search=None, ctx=None,
-                group=None, genomes_per_round=64):
+                group=None, genomes_per_round=64, timing=None):
     """genomes: {contig id: [taxon id, sequence]} -> fills the four MapBsn stores like PEPPAN.py:907-989:
       conn      gene id -> int rows [gene, taxon, score*1e4, ident*1e4, ident*1e4, group id, n fragments], best score first
       seq_conn  chunk no -> object array of packed alleles (only with saveSeq)
@@ -527,70 +777,63 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
       clf_conn  block no -> CSR [30001 offsets + 30001, partner*10 + class] of group-overlap conflicts
     `search(prefix, clust, jobs, params)` yields (blastab, overlap) per genome in job order (default: batched GPU search).
     Under torch.distributed (one process per GPU) the genomes are sharded over the ranks in blocks of `genomes_per_round`; rank 0
-    writes the stores (the other ranks pass None for them), whose contents do not depend on the number of ranks."""
+    writes the stores (the other ranks pass None for them), whose contents do not depend on the number of ranks.
+    No Python object is made for a stored hit row: the groups of a genome stay columns (GenomeGroups) and the members of the .mat /
+    .seq stores are emitted from them as .npy pickle streams by host C++ on the stores' writer threads."""
     if len(genomes) == 0:
         raise ValueError('get_map_bsn: no genome to map against')
     taxa = {}
     for g, s in genomes.items():
         taxa.setdefault(s[0], []).append([g, s[1]])
     jobs = [(id, taxon, seq) for id, (taxon, seq) in enumerate(taxa.items())]
-    og = np.load(orthoGroup, allow_pickle=True)
-    n_group = 0
-    seqs, seq_cnt = [], 0
-    mats, mat_cnt = [], 0
-    tabs, conflicts = [], {}
-
-    def flush_conflicts(block):
-        ovl = np.vstack(conflicts.pop(block))
-        clf_conn.save(block, np.concatenate([np.cumsum(np.concatenate([[0], np.bincount(ovl.T[0], minlength=BLOCK)])) + BLOCK + 1, ovl.T[1]]))
-
+    ortho = OrthoRelation(orthoGroup)
     per_round = max(1, int(genomes_per_round))
     searcher = search or (lambda *a: _gpu_search(*a, genomes_per_batch=per_round))
-    for (id, taxon, seq), (bsn, ovl) in _all_bsn(prefix, clust, jobs, og, old_prediction, params, searcher, ctx, group, per_round):
-        bId = id
-        last = bId == len(jobs) - 1
-        if bsn.shape[0]:
-            bsn.T[5] += n_group
-            ovl[:, :2] += n_group
-            first, n_group = n_group, n_group + bsn.shape[0]
-            bsn.T[1] = genomes.get(bsn[0, 1], [-1])[0]
-            if ovl.shape[0]:
-                for block in np.unique((ovl[:, :2] / BLOCK).astype(int)):
-                    conflicts.setdefault(block, [])
-                ovl = np.vstack([ovl, ovl[:, (1, 0, 2)]])
-                ovl = ovl[np.argsort(ovl.T[0])]
-                ovl = np.hstack([(ovl[:, :1] / BLOCK).astype(int), ovl[:, :1] % BLOCK, ovl[:, 1:2] * 10 + ovl[:, 2:]])
-                for part in np.split(ovl, np.cumsum(np.unique(ovl.T[0], return_counts=True)[1])[:-1]):
-                    conflicts[part[0, 0]].append(part[:, 1:])
-                for block in np.arange(int(first / BLOCK), int(n_group / BLOCK)):
-                    if block in conflicts:
-                        flush_conflicts(block)
-            if saveSeq:
-                seqs = np.concatenate([seqs, bsn.T[4]])
-                pieces = np.split(seqs, np.arange(CHUNK, seqs.shape[0], CHUNK))
-                seqs = pieces[-1]
-                for s in pieces[:-1]:
-                    seq_conn.save(seq_cnt, s)
-                    seq_cnt += 1
-            bsn.T[4] = bsn.T[3]
-            mats = np.concatenate([mats, bsn.T[6]])
-            pieces = np.split(mats, np.arange(CHUNK, mats.shape[0], CHUNK))
-            mats = pieces[-1]
-            for m in pieces[:-1]:
-                mat_conn.save(mat_cnt, m)
-                mat_cnt += 1
-            bsn.T[6] = np.array([len(b) for b in bsn.T[6]], dtype=np.uint8)
-            bsn.T[2:5] = bsn.T[2:5] * 10000
-            tabs.append(bsn[np.argsort(-bsn.T[2])].astype(int))
-        logger('Merged {0}.{1}'.format(prefix, id))
-        if (bId % 500 == 499 or last) and len(tabs):
-            tab = np.vstack(tabs)
-            tab = tab[np.argsort(tab.T[0], kind='mergesort')]
-            conn.update(np.split(tab, np.cumsum(np.unique(tab.T[0], return_counts=True)[1])[:-1]))
-            tabs = []
-    if saveSeq and len(seqs):
-        seq_conn.save(seq_cnt, seqs)
-    if len(mats):
-        mat_conn.save(mat_cnt, mats)
-    for block in list(conflicts.keys()):
-        flush_conflicts(block)
+    stores = _StoreWriter(conn, seq_conn, mat_conn, clf_conn, saveSeq)
+    clock = time.perf_counter
+    spent = dict(stores=0., gene_table=0.)
+    # The stores are fed by a thread of their own, genome by genome in job order: the caller's thread goes straight back to the next
+    # genome's search / filters / K12 and never waits for an archive (handing a genome to the stores took 16 ms of a 44 ms genome while
+    # it shared a thread with them: queues filling up behind the deflating writers).  At most two rounds of genomes wait in the queue.
+    inbox, failure = queue.Queue(maxsize=2 * per_round), []
+
+    def keeper():
+        while True:
+            item = inbox.get()
+            if item is None:
+                return
+            if failure:
+                continue                            # (keep draining so that the producer never blocks on a full queue)
+            try:
+                id, G = item
+                t0 = clock()
+                if len(G):
+                    stores.add(G, genomes.get(int(G.contig[0]), [-1])[0])
+                logger('Merged {0}.{1}'.format(prefix, id))
+                t1 = clock()
+                if id % TABLE_EVERY == TABLE_EVERY - 1:
+                    stores.write_table()
+                spent['stores'] += t1 - t0
+                spent['gene_table'] += clock() - t1
+            except BaseException as e:
+                failure.append(e)
+
+    worker = threading.Thread(target=keeper, daemon=True)
+    worker.start()
+    t_start = clock()
+    try:
+        for (id, taxon, seq), G in _all_groups(prefix, clust, jobs, ortho, old_prediction, params, searcher, ctx, group, per_round):
+            if failure:
+                break
+            inbox.put((id, G))
+    finally:
+        t_groups = clock()
+        inbox.put(None)
+        worker.join()
+    if failure:
+        raise failure[0]
+    t0 = clock()
+    stores.close()
+    if timing is not None:      # seconds: search + filters + build_groups on the caller's thread; then, on the stores' thread and overlapped with it,
+        #                         handing groups to the stores and the gene table updates; what was left to wait for at the end
+        timing.update(groups=t_groups - t_start, stores=spent['stores'], gene_table=spent['gene_table'], drain=clock() - t_groups)

@@ -60,6 +60,20 @@ def _read_cached(path, with_key=False):
     return (seqs, key) if with_key else seqs
 
 
+def _reference_seqs(ref):
+    """the sequences of one reference of a batch: a FASTA / FASTQ path, or the sequences themselves - a dict or a list of (name, sequence)
+    pairs, read as a FASTA file of those records would be (names as text, first token; upper case; no white space) without the file"""
+    if isinstance(ref, (str, bytes, os.PathLike)):
+        return _read_cached(ref)
+    out = {}
+    for n, s in (ref.items() if isinstance(ref, dict) else ref):
+        codes = np.frombuffer(s.encode('ascii', 'replace'), dtype=np.uint8)
+        if len(codes) and (codes.min() <= 32 or codes.max() >= 97):               # white space or lower case somewhere: as readFasta would read it
+            s = ''.join(s.split()).upper()
+        out[str(n).split()[0]] = s
+    return out
+
+
 _SIDE_CACHE = {}
 
 
@@ -341,7 +355,8 @@ class RunBlast(object):
         GPU-native form of PEPPAN's per-genome fan-out (PEPPAN.py:907-922, iter_map_bsn :759-772): the query index is
         shared and no worker process ever touches the device.  Genomes are grouped into sub-batches of at most
         MAX_BATCH_NT nucleotides so that a packed reference set stays inside the library's 2^29-byte limit."""
-        sizes = [sum(len(v) for v in _read_cached(p).values()) for p in refs]
+        refs = [_reference_seqs(p) for p in refs]                  # (paths are read once, here)
+        sizes = [sum(len(v) for v in rs.values()) for rs in refs]
         out, start = [], 0
         while start < len(refs):
             stop, tot = start, 0
@@ -362,8 +377,9 @@ class RunBlast(object):
         self.qrySeq, self._q_key = _read_cached(qry, with_key=True)
         self._r_key = None
         combined, names, groups = {}, [], []
-        for g, path in enumerate(refs):
-            rs = _read_cached(path)
+        for g, rs in enumerate(refs):
+            if not isinstance(rs, dict):
+                rs = _reference_seqs(rs)
             for n in sorted(rs):
                 if n in combined:
                     raise ValueError('run_batch: reference sequence name {0} occurs in more than one file'.format(n))
@@ -684,7 +700,8 @@ def uberBlast(args, extPool=None, as_table=False):
 
 
 def uberBlastBatch(references, args, device=None, as_tables=False):
-    """uberBlast for a LIST of reference files and one query file: `args` are uberBlast's flags without -r/-o.
+    """uberBlast for a LIST of reference files (or in-memory references: dicts / lists of (name, sequence), see _reference_seqs) and one
+    query file: `args` are uberBlast's flags without -r/-o.
     Returns one result per reference, each identical to uberBlast(['-r', ref] + args).  One GPU search per tool.
     as_tables: the hit tables come as numeric HitTables (same rows, same order) instead of object rows - for callers like
     mapbsn.build_bsn that work on the columns."""

@@ -117,3 +117,97 @@ def test_get_map_bsn(world, tmp_path, save_seq):
         with mapbsn.MapBsn(fn) as c:
             got = {k: plain(c.get(k)) for k in sorted(c.keys())}
         assert got == exp[x], x
+
+
+def _random_groups(rng, genome, n_groups, n_genes):
+    """GenomeGroups of one made-up genome: 1-3 hit rows per group, random conflicts between its groups"""
+    from peppan_amd.hittable import HitTable
+    n_rows = rng.integers(1, 4, size=n_groups)
+    row_off = np.concatenate([[0], np.cumsum(n_rows)]).astype(np.int64)
+    n = int(row_off[-1])
+    runs = rng.integers(1, 4, size=n)
+    arena = ((rng.integers(1, 900, size=int(runs.sum())) << 2) | rng.integers(0, 3, size=int(runs.sum()))).astype(np.uint32)
+    c_off = np.concatenate([[0], np.cumsum(runs)[:-1]])
+    genes = list(range(n_genes))
+    qi = rng.integers(0, n_genes, size=n)
+    T = HitTable(genes, [1000 + genome], qi, np.zeros(n, dtype=int), rng.integers(600, 1000, size=n) / 1000., rng.integers(50, 900, size=n), rng.integers(0, 9, size=n),
+                 rng.integers(0, 3, size=n), rng.integers(1, 50, size=n), rng.integers(60, 900, size=n), rng.integers(1, 10 ** 6, size=n), rng.integers(1, 10 ** 6, size=n),
+                 rng.random(n), rng.integers(50, 3000, size=n).astype(float), rng.integers(900, 1200, size=n), np.full(n, 10 ** 6), arena, c_off, runs,
+                 rid=rng.permutation(n))
+    pack_len = rng.integers(0, 40, size=n_groups)
+    pack_off = np.concatenate([[0], np.cumsum(pack_len)]).astype(np.int64)
+    k = int(rng.integers(0, 2 * n_groups)) if n_groups else 0
+    ovl = np.stack([rng.integers(0, n_groups, size=k), rng.integers(0, n_groups, size=k), rng.integers(0, 3, size=k)], axis=1) if k else np.zeros([0, 3], dtype=np.int64)
+    score = rng.integers(1, 10 ** 7, size=n_groups) / 1000.
+    if n_groups > 3:
+        score[1] = score[3]                                   # equal scores: the order among them is the object sort's
+    return mapbsn.GenomeGroups(np.asarray(genes)[qi[row_off[:-1]]], np.full(n_groups, 1000 + genome), score, rng.integers(650, 1000, size=n_groups) / 1000.,
+                               rng.integers(0, 125, size=int(pack_off[-1])).astype(np.uint8), pack_off, T, row_off, ovl)
+
+
+@pytest.mark.parametrize('save_seq', [True, False])
+def test_store_writer_against_the_definition_of_the_stores(tmp_path, monkeypatch, save_seq):
+    """the four stores for 23 made-up genomes with small member sizes, so that members are cut inside and across genomes, conflict blocks
+    close in the middle of a genome and the gene table is updated several times - against the stores' definition stated over ALL groups at once"""
+    monkeypatch.setattr(mapbsn, 'CHUNK', 7)
+    monkeypatch.setattr(mapbsn, 'BLOCK', 16)
+    rng = np.random.default_rng(99)
+    world = [_random_groups(rng, g, int(rng.integers(0, 30)) if g != 4 else 0, 9) for g in range(23)]
+    names = [str(tmp_path / ('w.%s.npz' % x)) for x in ('tab', 'seq', 'mat', 'conflicts')]
+    with mapbsn.MapBsn(names[0], 'w') as c0, mapbsn.MapBsn(names[1], 'w') as c1, mapbsn.MapBsn(names[2], 'w') as c2, mapbsn.MapBsn(names[3], 'w') as c3:
+        w = mapbsn._StoreWriter(c0, c1, c2, c3, save_seq)
+        for g, G in enumerate(world):
+            if len(G):
+                w.add(G, 500 + g)
+            if g % 5 == 4:
+                w.write_table()
+        w.close()
+    # ---- the definition
+    groups, first = [], []
+    for g, G in enumerate(world):
+        first.append(len(groups))
+        bsn = G.as_bsn()
+        for k in range(len(G)):
+            groups.append((g, k, bsn[k]))
+    with mapbsn.MapBsn(names[2]) as c:
+        assert sorted(c.keys(), key=int) == [str(i) for i in range(-(-len(groups) // 7))]
+        for i in range(-(-len(groups) // 7)):
+            got = c.get(i)
+            assert got.dtype == object and got.shape == (len(groups[7 * i:7 * i + 7]),)
+            for x, (g, k, row) in zip(got, groups[7 * i:7 * i + 7]):
+                assert x.dtype == object and plain(x) == plain(row[6])
+                assert [type(v) for v in x[0]] == [type(v) for v in row[6][0]]
+    with mapbsn.MapBsn(names[1]) as c:
+        if not save_seq:
+            assert c.size() == 0
+        else:
+            for i in range(-(-len(groups) // 7)):
+                got = c.get(i)
+                assert [x.tolist() for x in got] == [row[4].tolist() for g, k, row in groups[7 * i:7 * i + 7]] and all(x.dtype == np.uint8 for x in got)
+    want = {}
+    for g, G in enumerate(world):
+        for a, b, cls in G.ovl.tolist():
+            want.setdefault(first[g] + a, []).append((first[g] + b) * 10 + cls)
+            want.setdefault(first[g] + b, []).append((first[g] + a) * 10 + cls)
+    with mapbsn.MapBsn(names[3]) as c:
+        assert sorted(c.keys(), key=int) == [str(b) for b in sorted({k // 16 for k in want})]
+        for key in c.keys():
+            m = c.get(key)
+            off, b = m[:17] - 17, int(key)
+            assert off[0] == 0 and off[16] == len(m) - 17
+            for local in range(16):
+                assert sorted(m[17 + off[local]:17 + off[local + 1]].tolist()) == sorted(want.get(16 * b + local, []))
+    with mapbsn.MapBsn(names[0]) as c:
+        per_gene = {}
+        for g, G in enumerate(world):
+            order = sorted(range(len(G)), key=lambda k: -G.score[k])                  # best score first (equal scores: either order)
+            for k in order:
+                per_gene.setdefault(int(G.gene[k]), []).append([int(G.gene[k]), 500 + g, int(G.score[k] * 10000), int(G.iden[k] * 10000), int(G.iden[k] * 10000),
+                                                                 first[g] + k, int(G.row_off[k + 1] - G.row_off[k])])
+        assert sorted(c.keys(), key=int) == [str(k) for k in sorted(per_gene)]
+        for gene, rows in per_gene.items():
+            got = c.get(gene).tolist()
+            assert sorted(got) == sorted(rows)
+            assert [r[1] for r in got] == sorted(r[1] for r in got)                   # genome order inside a gene
+            for r0, r1 in zip(got[:-1], got[1:]):
+                assert r0[1] != r1[1] or r0[2] >= r1[2]                               # and best score first inside a genome

@@ -26,10 +26,14 @@ for rep in range(2):
     t0 = time.perf_counter()
     with contextlib.redirect_stderr(io.StringIO()):
         with mapbsn.MapBsn('t.npz', 'w') as c0, mapbsn.MapBsn('s.npz', 'w') as c1, mapbsn.MapBsn('m.npz', 'w') as c2, mapbsn.MapBsn('c.npz', 'w') as c3:
-            pr.enable()
+            tm = {}
+            if rep: pr.enable()
             mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params,
-                               search=lambda *a: mapbsn._gpu_search(*a, genomes_per_batch=per))
-            pr.disable()
+                               search=lambda *a: mapbsn._gpu_search(*a, genomes_per_batch=per), timing=tm)
+            if rep: pr.disable()
+            t_in = time.perf_counter() - t0
     dt = time.perf_counter() - t0
-    print('rep', rep, 'seconds %.2f  -> %.1f genomes/s' % (dt, nG / dt))
-pstats.Stats(pr).sort_stats("tottime").print_stats(40)
+    print('rep', rep, 'seconds %.2f  -> %.1f genomes/s' % (dt, nG / dt), 'inside %.2f, closing the archives %.2f;' % (t_in, dt - t_in), {k: round(v, 2) for k, v in tm.items()})
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(40)
+st.print_callers("acquire")
