@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <time.h>
 
 #define NEG (-(1 << 28))
 #define DIAG_OFF (1 << 23)
@@ -223,6 +224,12 @@ static inline uint64_t cand_key(uint32_t q, uint32_t t, int32_t bin)
 }
 
 /* candidates: sorted unique keys (q:21 | t:25 | bin:18) */
+/* phase clocks of oracle_search (bench.py's cpu_baseline reports them): wall seconds of the seed stage and of the alignment stage, and the
+ * thread-seconds the alignment stage spent in score-only sweeps and in band_align (traceback sweeps, rule 5a, walks) */
+static double g_phase[4];
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+void oracle_phase_seconds(double *out, int reset) { for (int k = 0; k < 4; ++k) { out[k] = g_phase[k]; if (reset) g_phase[k] = 0.; } }
+
 static uint64_t *find_candidates(const oracle_params *p,
                                  const uint8_t *qr, const uint64_t *qo, uint32_t nq,
                                  const uint8_t *tr, const uint64_t *to, uint32_t nt, uint64_t *n_out)
@@ -395,6 +402,9 @@ void oracle_trace_counts(uint64_t *out, int reset) { out[0] = g_traced; out[1] =
  * maximum - hence H == h (the diagonal move, which has priority in the traceback) in every cell of the segment and H == 0 in front of
  * it.  The scan is Kadane's: the running sum restarts AFTER a cell that brings it to <= 0 (so every prefix of the reported segment is
  * positive) and the first cell at which it equals T ends the segment.  Returns 1 and the segment [is, ie] x [js, je], else 0. */
+/* test switch: 0 = every reported alignment comes from the traceback (the definition before rule 5a was added); the tests hold the two equal */
+static int g_rule5a = 1;
+void oracle_set_rule5a(int on) { g_rule5a = on; }
 static int gapless_segment(const oracle_params *p, const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt, int32_t d, int32_t T,
                            int32_t *is, int32_t *ie)
 {
@@ -418,7 +428,7 @@ static void band_align(const oracle_params *p, const uint8_t *q, int32_t Lq, con
     ++g_traced;
     /* rule 5a: the two diagonals of the lowest diagonal pair that holds the score (lower diagonal first) are tried for an ungapped
      * segment with that score; the first one found IS the reported alignment - one M run, no second pass over the band */
-    for (int32_t x = 0; x < 2; ++x) {
+    for (int32_t x = 0; x < 2 && g_rule5a; ++x) {
         const int32_t d = dlo + 2 * wide.end_lane + x;
         int32_t gs, ge;
         if (gapless_segment(p, q, Lq, t, Lt, d, wide.score, &gs, &ge)) {
@@ -499,6 +509,7 @@ static void align_group(const oracle_params *p, const uint64_t *cand, uint64_t g
                         const int32_t *min_score, group_out *r)
 {
     runbuf rb = {0};
+    double t_score = 0., t_trace = 0., t0;
     {
         uint32_t q = (uint32_t)(cand[g0] >> 43), t = (uint32_t)((cand[g0] >> 18) & ((1u << 25) - 1));
         const uint8_t *qs = q_res + q_off[q], *ts = t_res + t_off[t];
@@ -508,7 +519,9 @@ static void align_group(const oracle_params *p, const uint64_t *cand, uint64_t g
             int32_t bin = (int32_t)(cand[g] & ((1u << 18) - 1));
             int32_t dlo = bin * BIN_W - DIAG_OFF - BAND_LEAD;
             sw_out o;
+            t0 = now_s();
             banded_sw(p, qs, Lq, ts, Lt, dlo, BAND, 0, &o);
+            t_score += now_s() - t0;
             r->cells += o.cells;
             if (o.score > best) { best = o.score; best_bin = bin; }
         }
@@ -517,7 +530,9 @@ static void align_group(const oracle_params *p, const uint64_t *cand, uint64_t g
                 int32_t dlo = best_bin * BIN_W - DIAG_OFF - BAND_LEAD;
                 sw_out o;
                 int32_t is, js; uint32_t nid, al;
+                t0 = now_s();
                 band_align(p, qs, Lq, ts, Lt, dlo, &o, &rb, &is, &js, &nid, &al);
+                t_trace += now_s() - t0;
                 ++r->traced;
                 double idp = (double)nid * 100.0 / (double)al;
                 double qcov = (double)(o.iend - is + 1) * 100.0 / (double)Lq;
@@ -568,6 +583,10 @@ static void align_group(const oracle_params *p, const uint64_t *cand, uint64_t g
         }
     }
     free(rb.runs);
+    #pragma omp atomic
+    g_phase[2] += t_score;
+    #pragma omp atomic
+    g_phase[3] += t_trace;
 }
 
 /* full search.  q_off/t_off have n+1 entries (plain concatenation, no padding).
@@ -580,7 +599,10 @@ int oracle_search(const oracle_params *p,
                   uint64_t *stats /* [0]=candidates [1]=cells over all candidates [2]=(q,t) pairs [3]=tracebacks */)
 {
     uint64_t nc = 0;
+    const double t_begin = now_s();
     uint64_t *cand = find_candidates(p, q_res, q_off, nq, t_res, t_off, nt, &nc);
+    const double t_seeded = now_s();
+    g_phase[0] += t_seeded - t_begin;
     /* (q, t) groups of candidates are independent: aligned in parallel, results appended in group order */
     uint64_t n_grp = 0;
     uint64_t *grp = malloc((nc + 2) * sizeof(uint64_t));
@@ -591,6 +613,7 @@ int oracle_search(const oracle_params *p,
     #pragma omp parallel for schedule(dynamic, 16)
     for (uint64_t k = 0; k < n_grp; ++k)
         align_group(p, cand, grp[k], grp[k + 1], q_res, q_off, t_res, t_off, min_score, &res[k]);
+    g_phase[1] += now_s() - t_seeded;
     uint64_t nh = 0, ncig = 0, cells_all = 0, traced = 0;
     const uint64_t pairs = n_grp;
     for (uint64_t k = 0; k < n_grp; ++k) { nh += res[k].nh; ncig += res[k].ncig; }

@@ -154,6 +154,19 @@ def align_one(q, t, bin_, params=None):
     return h, cig[:h.cigar_runs].copy()
 
 
+def phase_seconds(reset=False):
+    """clocks of the searches since the last reset: wall seconds of the seed stage and of the alignment stage; thread-seconds of the score-only
+    sweeps and of band_align (traceback sweeps, walks) inside the alignment stage (the protein configuration, hsp_mode 0)"""
+    out = np.zeros(4, dtype=np.float64)
+    lib().oracle_phase_seconds(out.ctypes.data_as(C.c_void_p), C.c_int(1 if reset else 0))
+    return dict(seed_s=float(out[0]), align_s=float(out[1]), score_thread_s=float(out[2]), trace_thread_s=float(out[3]))
+
+
+def set_rule5a(on):
+    """test switch: False = no gapless shortcut, every alignment is traced (align_oracle.c: oracle_set_rule5a)"""
+    lib().oracle_set_rule5a(C.c_int(1 if on else 0))
+
+
 def trace_counts(reset=False):
     """how the reported alignments were obtained since the last reset: (traced, needed the full band, gapless shortcut - rule 5a)"""
     out = np.zeros(3, dtype=np.uint64)

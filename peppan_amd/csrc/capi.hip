@@ -12,6 +12,15 @@ int pep_fail(pep_ctx *ctx, int code, const std::string &msg)
         ctx->err = msg;
         ctx->n_pending = 0;              // queued read-backs point at the failing caller's locals: drop them
         ctx->pin_small_used = 0;
+        // A failure between "tickets taken on the host" and "kernel queued" (a reservation that fails between two pep_lookback_begin calls,
+        // a launch that is never made) leaves the host's ticket bases ahead of the device counters, and counter blocks half used: whatever
+        // runs next on this context starts from cleared state areas and a filled counter block instead of trusting any of it.
+        for (auto &st : ctx->fused_state) st.dirty = true;
+        for (auto &st : ctx->scan_state) st.dirty = true;
+        ctx->sort_dirty = true;
+        ctx->zero_clean = false;
+        for (bool &f : ctx->zero_ok) f = false;
+        ctx->set_clean_slots = 0;
     }
     return code;
 }

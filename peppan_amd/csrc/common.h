@@ -126,11 +126,12 @@ struct pep_ctx {
     int timing_level = 0;                    // pep_set_timing: 0 no phase timers, 1 the score pass only, 2 all of them
     PinBuf pin_labels;                       // grow-only: K10's labels on their way to the caller
     uint64_t trace_swept = 0;               // pairs the last traceback pass swept (the rest were settled by the gapless shortcut)
-    struct ScanState { DevBuf buf; uint32_t epoch = 0, ticket_base = 0; };
+    struct ScanState { DevBuf buf; uint32_t epoch = 0, ticket_base = 0; bool dirty = false; };     // dirty: a failure may have left host and device ticket counts apart - next use starts from a cleared area (pep_fail)
     ScanState fused_state[4];               // kernels that scan while they compute (lookback.h): select (count, run capacity), top-k (hits, CIGAR runs)
     ScanState scan_state[2];                // single-launch scans (u32, u64): ticket counter + one status word per tile (scan.hip)
     DevBuf sort_state, sort_hist;           // one-launch-per-pass radix sort (sort.hip): ticket + status words per (tile, digit); its own histograms
     uint32_t sort_epoch = 0, sort_ticket_base = 0;
+    bool sort_dirty = false;
     DevBuf d_set;                           // candidate hash set of the seed stage (seeds.hip); set_compact leaves every slot it read EMPTY again
     uint64_t set_clean_slots = 0;           // leading slots of d_set known to be EMPTY (0 while a search is using it)
     DevBuf uf_nodes;                        // K10 over a device-resident hit table: node of every target (uploaded when it changes)

@@ -177,6 +177,7 @@ int scan_onepass(pep_ctx *ctx, const T *d_in, T *d_out, uint64_t n, T *d_total)
         PEP_TRY(dev_reserve(ctx, S.buf, (nb + 1) * sizeof(uint64_t) * 2));
         clear = true;
     }
+    if (S.dirty) { clear = true; S.dirty = false; }
     S.epoch = (S.epoch + 1) & ScanWord<T>::EPOCH_MASK;
     if (S.epoch == 0) { clear = true; S.epoch = 1; }   // wrapped: forget every old word
     if (clear) {
@@ -273,6 +274,7 @@ int pep_lookback_begin(pep_ctx *ctx, pep_ctx::ScanState &S, uint64_t n_tiles, ui
         PEP_TRY(dev_reserve(ctx, S.buf, (n_tiles + 1) * sizeof(uint64_t) * 2));
         clear = true;
     }
+    if (S.dirty) { clear = true; S.dirty = false; }
     S.epoch = (S.epoch + 1) & epoch_mask;
     if (S.epoch == 0) { clear = true; S.epoch = 1; }   // wrapped: forget every old word
     if (clear) {

@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void idx_slab(SeedShape sh, const uint8_t *__r
     }
 }
 
-// MEASUREMENT ONLY (params.reserved[0] = 7, tools/partition_probe.py): the first pass of a PARTITIONED join - the target positions whose key
+#ifdef PEP_PROBES
+// MEASUREMENT ONLY, compiled with -DPEP_PROBES (make PROBES=1; params.reserved[0] = 7, tools/partition_probe.py): the first pass of a PARTITIONED join - the target positions whose key
 // passes the filter are scattered into the coarse buckets of the query index, exactly as idx_slab scatters the query positions (same chunking,
 // same LDS counting, same slab reservation), 8 bytes (key << 29 | position) each.  Its duration against seed_match's is what decides whether a
 // partitioned join can pay; nothing reads what it writes.
@@ -281,6 +282,7 @@ __global__ __launch_bounds__(256) void tgt_slab_probe(SeedShape sh, const uint8_
     for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(kept, mine);
 }
+#endif  // PEP_PROBES
 
 // one block per coarse bucket c: its slab -> entries[] ordered by fine bucket (dense: after the entries of the coarse buckets before it),
 // start[c << F .. (c + 1) << F), filter slice
@@ -923,6 +925,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             pep_timer_begin(ctx, TM_MATCH0 + s);
             PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 8u)), sh, a);
             pep_timer_end(ctx, TM_MATCH0 + s);
+#ifdef PEP_PROBES
             if (P.reserved[0] == 7 && use_partition && sh.weight == 10) {
                 // measurement only: the scatter pass of a partitioned join over the same targets, behind the matcher it would replace
                 static DevBuf probe_part, probe_cnt;
@@ -936,6 +939,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
                                    (const unsigned long long *)filter, probe_cnt.as<uint32_t>(), probe_part.as<uint64_t>(), cap, tiles,
                                    reinterpret_cast<unsigned long long *>(probe_cnt.as<uint32_t>() + n_coarse));
             }
+#endif
             hipLaunchKernelGGL(seed_runs, dim3(256u * 8u), dim3(256), 0, ctx->stream, a, run_first, run_len, run_key, n_runs);
             hipLaunchKernelGGL(seed_extend, dim3(256u * 16u), dim3(256), 0, ctx->stream, a, (const uint64_t *)run_first, (const uint32_t *)run_len,
                                (const uint64_t *)run_key, (const unsigned long long *)n_runs);

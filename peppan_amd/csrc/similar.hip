@@ -42,6 +42,7 @@ struct SupportArgs {
     uint8_t *val_row;                    // scratch: last_row of seq[k]
     int32_t *value;
     uint64_t n_groups;
+    uint64_t g_base;                     // first group of this launch (the groups go out in batches bounded by a scratch budget)
     pep_support_limits lim;
 };
 
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(64) void k14_pair_support(SupportArgs a)
     __shared__ double leaf_sum[LEAF_MAX];
     __shared__ double iden[ROW_MAX + 1];
     const int lane = threadIdx.x;
-    const uint64_t g = blockIdx.x;
+    const uint64_t g = a.g_base + blockIdx.x;
     if (g >= a.n_groups) return;
     const uint64_t r0 = a.grp_off[g], r1 = a.grp_off[g + 1];
     const int ql = (int)a.grp_qlen[g], sl = (int)a.grp_rlen[g];
@@ -211,18 +212,30 @@ int pep_k14_pair_support(pep_ctx *ctx, uint64_t n_rows, const pep_support_row *h
     if (n_groups == 0) return PEP_OK;
     if (n_groups > 0x7FFFFFFFull) return pep_fail(ctx, PEP_ERR_LIMIT, "pep_pair_support: more than 2^31 - 1 groups");
     if (h_grp_off[0] != 0 || h_grp_off[n_groups] != n_rows) return pep_fail(ctx, PEP_ERR_ARG, "pep_pair_support: grp_off must run from 0 to n_rows");
-    std::vector<uint64_t> scr(n_groups + 1, 0);
+    // scratch (query length + 2 entries of 6 bytes) only for the groups the kernel works on - those with rows whose two genes pass the length test of
+    // PEPPAN.py:199-200 - and in batches of at most SCR_BUDGET entries: a self search with millions of settled pairs of kb-long genes would otherwise
+    // ask for tens of GB in one reservation.  scr[g] = offset of group g inside ITS batch; a batch is a run of consecutive groups.
+    constexpr uint64_t SCR_BUDGET = 160ull << 20;                     // entries: 1 GiB of scratch
+    std::vector<uint64_t> scr(n_groups + 1, 0), batch_end;
+    uint64_t used = 0, cap = 0;
     for (uint64_t g = 0; g < n_groups; ++g) {
         if (h_grp_off[g + 1] < h_grp_off[g]) return pep_fail(ctx, PEP_ERR_ARG, "pep_pair_support: grp_off must be non-decreasing");
         if (h_grp_off[g + 1] - h_grp_off[g] > (uint64_t)ROW_MAX) return pep_fail(ctx, PEP_ERR_LIMIT, "pep_pair_support: more than 255 alignments in one group");
-        scr[g + 1] = scr[g] + (((uint64_t)h_qlen[g] + 2 + 3) & ~3ull);
+        const uint64_t ql = h_qlen[g], sl = h_rlen[g];
+        const bool works = h_grp_off[g + 1] > h_grp_off[g] && 20ull * std::min(ql, sl) > std::max(ql, sl);
+        const uint64_t need = works ? ((ql + 2 + 3) & ~3ull) : 0;
+        if (used && used + need > SCR_BUDGET) { batch_end.push_back(g); used = 0; }
+        scr[g] = used;
+        used += need;
+        cap = std::max(cap, used);
         for (uint64_t x = h_grp_off[g]; x < h_grp_off[g + 1]; ++x) {
             const pep_support_row &r = h_rows[x];
             if (r.cigar_off + r.cigar_runs > n_cigar) return pep_fail(ctx, PEP_ERR_ARG, "pep_pair_support: CIGAR slice out of range");
             if (r.q_start < 1) return pep_fail(ctx, PEP_ERR_ARG, "pep_pair_support: coordinates are 1-based");
         }
     }
-    const uint64_t total = scr[n_groups];
+    batch_end.push_back(n_groups);
+    const uint64_t total = cap;
     // ws[0] rows, ws[1] cigar, ws[2] groups (off u64, scr u64, qlen u32, rlen u32, value i32), ws[3] scratch bytes x2, ws[4] scratch u32
     PEP_TRY(dev_reserve(ctx, ctx->ws[0], (n_rows + 1) * sizeof(pep_support_row)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_cigar + 1) * 4));
@@ -245,7 +258,10 @@ int pep_k14_pair_support(pep_ctx *ctx, uint64_t n_rows, const pep_support_row *h
     a.grp_off = d_off; a.grp_qlen = d_ql; a.grp_rlen = d_rl; a.scr_off = d_scr;
     a.last_row = ctx->ws[3].as<uint8_t>(); a.val_row = a.last_row + total; a.seq = ctx->ws[4].as<uint32_t>();
     a.value = d_val; a.n_groups = n_groups; a.lim = *lim;
-    hipLaunchKernelGGL(k14_pair_support, dim3((unsigned)n_groups), dim3(64), 0, st, a);
+    for (uint64_t b = 0, g0 = 0; b < batch_end.size(); g0 = batch_end[b++]) {             // (one launch unless the scratch budget splits the groups)
+        a.g_base = g0;
+        hipLaunchKernelGGL(k14_pair_support, dim3((unsigned)(batch_end[b] - g0)), dim3(64), 0, st, a);
+    }
     PEP_HIP(ctx, hipGetLastError());
     PEP_HIP(ctx, hipMemcpyAsync(h_value, d_val, n_groups * 4, hipMemcpyDeviceToHost, st));
     PEP_HIP(ctx, hipStreamSynchronize(st));

@@ -220,6 +220,7 @@ int sort_passes(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, const uint32_t 
         const int shift = p * DB;
         const bool last = p == passes - 1;
         {
+            if (ctx->sort_dirty) { clear = true; ctx->sort_dirty = false; }
             ctx->sort_epoch = (ctx->sort_epoch + 1) & ((1u << 29) - 1);
             if (ctx->sort_epoch == 0) { clear = true; ctx->sort_epoch = 1; }          // wrapped: forget every old word
             if (clear) { PEP_HIP(ctx, hipMemsetAsync(S.p, 0, S.cap, ctx->stream)); ctx->sort_ticket_base = 0; clear = false; }
@@ -271,6 +272,7 @@ int pep_sort_u64_two_level(pep_ctx *ctx, uint64_t *d_keys, uint64_t *d_tmp, uint
     const size_t need = ((size_t)nb * R + 2) * sizeof(uint64_t);
     bool clear = false;
     if (need > S.cap) { PEP_TRY(dev_reserve(ctx, S, need)); clear = true; }
+    if (ctx->sort_dirty) { clear = true; ctx->sort_dirty = false; }
     ctx->sort_epoch = (ctx->sort_epoch + 1) & ((1u << 29) - 1);
     if (ctx->sort_epoch == 0) { clear = true; ctx->sort_epoch = 1; }
     if (clear) { PEP_HIP(ctx, hipMemsetAsync(S.p, 0, S.cap, ctx->stream)); ctx->sort_ticket_base = 0; }

@@ -883,7 +883,8 @@ __global__ __launch_bounds__(256) void sw_order(const uint32_t *__restrict__ nbl
     if (active) order[start[b] + base[b] + rank] = (uint32_t)c;
 }
 
-__global__ void dpp_probe(int *out)
+// one wavefront of the context's start-up self-test (pep_selftest_dpp): the lane semantics of the two DPP shifts every sweep relies on
+__global__ void dpp_selftest(int *out)
 {
     const int lane = threadIdx.x;
     out[lane] = shr1(-1, lane);
@@ -895,7 +896,7 @@ __global__ void dpp_probe(int *out)
 int pep_selftest_dpp(pep_ctx *ctx)
 {
     PEP_TRY(dev_reserve(ctx, ctx->ws[9], 128 * sizeof(int)));
-    hipLaunchKernelGGL(dpp_probe, dim3(1), dim3(64), 0, ctx->stream, ctx->ws[9].as<int>());
+    hipLaunchKernelGGL(dpp_selftest, dim3(1), dim3(64), 0, ctx->stream, ctx->ws[9].as<int>());
     int h[128];
     PEP_HIP(ctx, hipMemcpyAsync(h, ctx->ws[9].p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));

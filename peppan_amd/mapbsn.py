@@ -18,6 +18,7 @@ import os
 import sys
 import time
 import zipfile
+import zlib
 
 import numpy as np
 
@@ -32,6 +33,51 @@ def _npy_bytes(val):
     return buf.getvalue()
 
 
+# ---- archive members, deflated off the writer's thread -------------------------------------------------------------------------------------
+# zipfile deflates inside ZipFile.writestr, under the archive's lock: one member at a time per archive, 13 ms for the 0.5 MB of hit rows a
+# genome adds to the .mat store - the store's writer thread then is what the whole mapping waits for.  Members are therefore made and
+# deflated by a small pool shared by all stores (zlib releases the GIL) and the writer thread only appends finished payloads, in order:
+# local header + payload at the archive's end, and the entry for the central directory that ZipFile.close() writes.
+_PACKERS = None
+
+
+def _packers():
+    global _PACKERS
+    if _PACKERS is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _PACKERS = ThreadPoolExecutor(max_workers=max(2, min(6, (os.cpu_count() or 4) // 2)), thread_name_prefix='mapbsn-pack')
+    return _PACKERS
+
+
+def _pack_member(data):
+    """data (bytes, or a callable returning them) -> (payload, crc, size, method).  Members are read back whole either way; deflating
+    a few hundred bytes costs more than it saves (zlib set-up per member)"""
+    if callable(data):
+        data = data()               # a member whose bytes are made here, off the caller's thread (C emitters: no GIL held)
+    if len(data) < 4096:
+        return data, zlib.crc32(data), len(data), zipfile.ZIP_STORED
+    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+    return co.compress(data) + co.flush(), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
+
+
+def _append_member(zf, name, packed):
+    """one finished member into an archive that is open for writing: what ZipFile.writestr does after its own compression"""
+    payload, crc, size, method = packed
+    zi = zipfile.ZipInfo(name, date_time=time.localtime(time.time())[:6])
+    zi.compress_type, zi.external_attr = method, 0o600 << 16
+    zi.CRC, zi.compress_size, zi.file_size = crc, len(payload), size
+    with zf._lock:
+        zf._writecheck(zi)
+        zf._didModify = True
+        zf.fp.seek(zf.start_dir)
+        zi.header_offset = zf.fp.tell()
+        zf.fp.write(zi.FileHeader(zip64=None))
+        zf.fp.write(payload)
+        zf.start_dir = zf.fp.tell()
+        zf.filelist.append(zi)
+        zf.NameToInfo[zi.filename] = zi
+
+
 class MapBsn(object):
     """dict-like store: zip member `str(key)` holds one array in .npy format (object arrays pickled).  Readable by
     `np.load(fname, allow_pickle=True)` like the reference's files (PEPPAN.py:1931)."""
@@ -40,8 +86,7 @@ class MapBsn(object):
         self.fname, self.mode = fname, mode
         self.conn = zipfile.ZipFile(fname, mode=mode, compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
         self.namelist = set(self.conn.namelist())
-        # writes go through ONE background thread per store, in order: deflate releases the GIL, so the compression of a genome's
-        # tables overlaps with the Python bookkeeping of the next one (a third of get_map_bsn's time was spent inside zlib)
+        # writes go through ONE background thread per store, in order; the members it appends are made and deflated by a shared pool
         self._queue = self._thread = self._error = None
 
     def __enter__(self):
@@ -66,12 +111,9 @@ class MapBsn(object):
             try:
                 if item is None:
                     return
-                db, key, data = item
+                db, key, packed = item
                 if self._error is None:
-                    if callable(data):
-                        data = data()               # a member whose bytes are made here, off the caller's thread (C emitters: no GIL held)
-                    # members are read back whole either way; deflating a few hundred bytes costs more than it saves (zlib set-up per member)
-                    db.writestr(key, data, compress_type=zipfile.ZIP_STORED if len(data) < 4096 else None)
+                    _append_member(db, key, packed.result())
             except BaseException as e:              # reported by the next _flush() on the owning thread
                 self._error = e
             finally:
@@ -144,7 +186,7 @@ class MapBsn(object):
             self._queue = queue.Queue(maxsize=256)
             self._thread = threading.Thread(target=self._writer, daemon=True)
             self._thread.start()
-        self._queue.put((db, key, data))
+        self._queue.put((db, key, _packers().submit(_pack_member, data)))
 
     def _save(self, db, key, val):
         self._enqueue(db, key, _npy_bytes(val))     # serialised here: the caller may change `val` afterwards

@@ -84,7 +84,7 @@ def _prepare_side(seqs, key, names=None):
     if side is None:
         order = sorted(seqs) if names is None else list(names)
         texts = [RunBlast._text(seqs[n]) for n in order]
-        side = dict(names=order, index={n: i for i, n in enumerate(order)}, tab=[str(x) for x in order],
+        side = dict(names=order, index={n: i for i, n in enumerate(order)}, tab=_NameTable(str(x) for x in order),
                     sorted=names is None and all(isinstance(x, str) for x in order),
                     lens=np.fromiter(map(len, texts), dtype=np.int64, count=len(texts)), packed=N._pack(texts))
         if key is not None and names is None:
@@ -106,9 +106,15 @@ def get_context(device=None):
 # ------------------------------------------------------------------------------------------------------------
 # GPU hits -> the reference's table rows (coordinate algebra of parseDiamond, uberBlast.py:25-58)
 # ------------------------------------------------------------------------------------------------------------
+class _NameTable(list):
+    """a name table this module built: every entry is a str (tables that share one concatenate without a remap)"""
+    __slots__ = ()
+
+
 def _str_table(names):
-    """a name table as a list of str; a list that is one already is passed on as it is (tables that share it concatenate without a remap)"""
-    return names if isinstance(names, list) and all(type(x) is str for x in names[:4]) and all(type(x) is str for x in names[-4:]) else [str(x) for x in names]
+    """a name table as a list of str.  Only a table built here (_prepare_side) is passed on as it is; anything a caller hands in is coerced
+    entry by entry - PEPPAN's encoded gene ids are integers, and a mixed list must not reach the row builder"""
+    return names if isinstance(names, _NameTable) else _NameTable(str(x) for x in names)
 
 
 def hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
@@ -290,11 +296,20 @@ class RunBlast(object):
         """tool name -> callable(ref, qry).  Inside run() the built-in tools hand over the numeric HitTable (no Python object per cell);
         the PUBLIC runBlast / runDiamond / runDiamondSELF keep the reference's plug-in contract - ndarray(object)[n, 15] (uberBlast.py:327,
         343-353) - and a subclass that overrides one of them is called through its override (its rows are converted on entry)."""
-        cls = type(self)
-        pick = lambda public, internal: internal if getattr(cls, public) is _BUILTIN_TOOLS[public] else getattr(self, public)
-        return dict(blastn=pick('runBlast', self._runBlast_table), diamond=pick('runDiamond', self._runDiamond_table),
-                    diamondself=pick('runDiamondSELF', lambda ref, qry: self._runDiamond_table(ref, qry, nhits=200, frames='F')),
-                    gpu=pick('runDiamond', self._runDiamond_table))
+        def builtin(public):
+            """is the tool this INSTANCE would call still the one defined here?  (the reference builds its dictionary from bound instance
+            attributes, uberBlast.py:327: a subclass method and an attribute set on the instance both count)"""
+            f = getattr(self, public)
+            return getattr(f, '__func__', f) is _BUILTIN_TOOLS[public]
+        blastn = self._runBlast_table if builtin('runBlast') else self.runBlast
+        diamond = self._runDiamond_table if builtin('runDiamond') else self.runDiamond
+        if not builtin('runDiamondSELF'):
+            diamondself = self.runDiamondSELF
+        elif builtin('runDiamond'):
+            diamondself = lambda ref, qry: self._runDiamond_table(ref, qry, nhits=200, frames='F')
+        else:                                   # the reference's runDiamondSELF goes through self.runDiamond (uberBlast.py:511): so does an override of it
+            diamondself = lambda ref, qry: self.runDiamond(ref, qry, nhits=200, frames='F')
+        return dict(blastn=blastn, diamond=diamond, diamondself=diamondself, gpu=diamond)
 
     def _run_tools(self, methods, ref, qry):
         """the tools of one run in the order given.  A tool that fails is reported and the other tools' tables are kept - the reference's
@@ -445,7 +460,7 @@ class RunBlast(object):
     # The three public tools keep the reference's plug-in contract (uberBlast.py:327): method(ref, qry) -> ndarray(object)[n, 15], names as
     # str, CIGAR as [[n, op], ...] in nucleotides, rows in any order - what the reference's own run() loop vstacks (uberBlast.py:343-354).
     def runDiamondSELF(self, ref, qry):
-        return self._runDiamond_table(ref, qry, nhits=200, frames='F').to_rows(with_rid=False)
+        return self.runDiamond(ref, qry, nhits=200, frames='F')                 # (through self.runDiamond, like uberBlast.py:511)
 
     def runDiamond(self, ref, qry, nhits=10, frames='7'):
         return self._runDiamond_table(ref, qry, nhits, frames).to_rows(with_rid=False)

@@ -34,7 +34,9 @@ Fixture index:
   g16_real.json (+ g16_real_genes.fa.gz, g16_real_contig.fa.gz)  real genes of the reference's examples/ through its own front end
   g17_examples.json (+ g17_examples_genes.fa.gz)  BASELINE configs[0] at full size: ALL CDS of the four example GFFs through the reference's
                          readGFF -> encodeNames -> load_priority -> writeGenes (PEPPAN.py:117-191, 746-751, 1023-1039, 1766-1775, 1844-1849):
-                         the 11 696 unique genes of its <prefix>.genes with their priorities; instance hashes and duplicate groups
+                         the 8 441 unique genes (7.80 Mnt) of its <prefix>.genes with their priorities; instance hashes and duplicate groups.
+                         (SURVEY.md 8a quotes 11 696 genes / 10.65 Mnt for this set from an earlier probe; the reference's writeGenes, run here, collapses
+                         the 19 490 instances to 8 441 - there are exactly 8 441 distinct (length, sha1) among them)
 """
 import json, os, sys, stat, tempfile, shutil, io, contextlib, copy
 

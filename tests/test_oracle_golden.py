@@ -1,4 +1,6 @@
 """Pins the CPU oracle (oracle/) against golden vectors captured from the reference's Python."""
+import os
+
 import numpy as np
 import pytest
 from conftest import load_golden
@@ -139,3 +141,42 @@ def test_linclust_gapped_verification():
     assert rep2[6] == 2                                 # ... which is enough at coverage 0.4
     rep3, st3 = O.linclust([centre, seqs[3]], 0.95, 0.9)
     assert rep3.tolist() == [0, 0] and st3['accepted'] == 1          # substitutions only: accepted on the diagonal, no gaps needed
+
+
+def test_rule_5a_changes_no_reported_alignment():
+    """Rule 5a (the gapless shortcut) came into the oracle together with its GPU counterpart.  With the oracle's switch off every
+    alignment is traced as before the rule existed: the tables must be the same - protein families with indels and duplicates, the nucleotide
+    configuration on both strands, and real genes (golden G16) - while the shortcut settles a good part of the pairs"""
+    import gzip
+    from conftest import GOLDEN
+    from peppan_amd import synth
+
+    def both(q, t, p):
+        out = []
+        for on in (True, False):
+            O.set_rule5a(on)
+            O.trace_counts(reset=True)
+            h, c, st = O.search(q, t, p)
+            out.append((h, c, O.trace_counts()))
+        O.set_rule5a(True)
+        return out
+    fields = ('q', 't', 'q_start', 'q_end', 't_start', 't_end', 'score', 'nm', 'n_ident', 'aln_len', 'cigar_runs', 'bin')
+    cases = []
+    for seed in (0, 1):
+        prots = synth.make_proteins(300, length=(60, 400), seed=seed, family=4, sub=0.25, indel=0.7)
+        cases.append((prots + prots[:20], prots, O.default_params(30., 20., 10, 5)))
+    names, genes = synth.make_genes(120, 0, seed=5)
+    from peppan_amd import _native as N
+    nt = [O.nt_codes(s.decode()) for s in genes]
+    cases.append((nt, nt + [(3 - x[::-1]).astype(np.uint8) for x in nt], O.params_from(N.nucleotide_params(70., 20.))))
+    with gzip.open(os.path.join(GOLDEN, 'g16_real_genes.fa.gz'), 'rt') as f:
+        real = [s.split('\n', 1)[1].replace('\n', '') for s in f.read().split('>')[1:]][:250]
+    q_aa = [O.aa_codes(O.query_frame(s, 11)[1]) for s in real]
+    cases.append((q_aa, q_aa, O.default_params(45., 25., 10, 5)))
+    settled = 0
+    for q, t, p in cases:
+        (h1, c1, k1), (h0, c0, k0) = both(q, t, p)
+        assert k0['gapless'] == 0 and k1['traced'] == k0['traced']
+        assert len(h1) == len(h0) and all(np.array_equal(h1[f], h0[f]) for f in fields) and np.array_equal(c1, c0)
+        settled += k1['gapless']
+    assert settled > 800

@@ -65,6 +65,25 @@ def test_subclass_tool_override_and_failed_tools(tmp_path, monkeypatch):
         plug = WithPlugin().run(fa, fa, ['diamond'], 0.4, 40., 0.25, return_overlap=[False, 300, 0.6])
     assert calls == ['plugin'] and plug.tolist() == plain.tolist() and len(plain) > 20
 
+    # diamondSELF goes through the instance's runDiamond (uberBlast.py:511): a subclass that overrides runDiamond only is not bypassed ...
+    del calls[:]
+    with contextlib.redirect_stderr(io.StringIO()):
+        plain_self = UB.RunBlast().run(fa, fa, ['diamondSELF'], 0.4, 40., 0.25, return_overlap=[False, 300, 0.6])
+        plug_self = WithPlugin().run(fa, fa, ['diamondSELF'], 0.4, 40., 0.25, return_overlap=[False, 300, 0.6])
+    assert calls == ['plugin'] and plug_self.tolist() == plain_self.tolist() and len(plain_self) >= 24
+    # ... and neither is a tool set on the INSTANCE (the reference's dictionary holds bound instance attributes, uberBlast.py:327)
+    rb = UB.RunBlast()
+    seen = []
+
+    def my_blast(ref, qry):
+        seen.append((ref, qry))
+        return UB.RunBlast.runBlast(rb, ref, qry)
+    rb.runBlast = my_blast
+    with contextlib.redirect_stderr(io.StringIO()):
+        inst = rb.run(fa, fa, ['blastn'], 0.4, 40., 0.25, return_overlap=[False, 300, 0.6])
+        ref_b = UB.RunBlast().run(fa, fa, ['blastn'], 0.4, 40., 0.25, return_overlap=[False, 300, 0.6])
+    assert seen == [(fa, fa)] and inst.tolist() == ref_b.tolist()
+
     class Broken(UB.RunBlast):
         def runDiamond(self, ref, qry, nhits=10, frames='7'):
             raise RuntimeError('tool fell over')
