@@ -20,16 +20,107 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
-PROFILE_COUNTERS = os.path.join(ROOT, 'profiles', 'r03_counters.json')     # rocprofv3 PMC passes of this workload (tools/profile_round.sh)
-PROFILE_VALU = os.path.join(ROOT, 'profiles', 'r03_valu_rate.txt')         # tools/micro/valu_rate on the same GPU
+PROFILE_COUNTERS = os.path.join(ROOT, 'profiles', 'r04_counters.json')          # rocprofv3 PMC passes of the headline workload (tools/profile_round.sh)
+PROFILE_COUNTERS_50K = os.path.join(ROOT, 'profiles', 'r04_counters_50k.json')  # the same passes over the 50 000-gene all-vs-all (the `workloads` block)
+PROFILE_VALU = os.path.join(ROOT, 'profiles', 'r04_valu_rate.txt')              # tools/micro/valu_rate on the same GPU
 
 
-def cpu_baseline(nts, n_sample, min_id, min_qcov):
-    """CPU oracle (C port, OpenMP over targets in the seed phase and over (query, target) pairs in the alignment phase, all host
-    cores) timed on a bounded sample of the same workload: the first n_sample queries against the whole reference.
-    Reported beside the GPU number, never the target."""
+REFERENCE_TOOLS = ('diamond', 'blastn', 'makeblastdb', 'mmseqs')
+
+
+def probe_reference_tools():
+    """which of the binaries the reference shells out to exist on this machine (its bundled copies are stripped,
+    .MISSING_LARGE_BLOBS), and what CPU this is"""
+    import shutil
+    found = {t: shutil.which(t) for t in REFERENCE_TOOLS}
+    model = None
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return found, model
+
+
+def reference_cpu_path(found, names, nts, min_id, min_ratio, threads):
+    """The reference's own CPU path on the same genes, when its binaries are installed: the IDENTICAL command lines of uberBlast.py:531, 550
+    (diamond makedb + 5 x blastp on the 5 round-robin splits of the translated reference), uberBlast.py:492, 294 (makeblastdb + one blastn per
+    query shard, `threads` shards side by side) and clust.py:62-66 (mmseqs createdb / linclust / createtsv), timed with time.perf_counter.
+    Inputs are the files the reference itself would write (qryAA / refAA.0-4 text: oracle.diamond_fasta, pinned to golden G2)."""
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    out = {}
+    run = lambda cmd, **kw: subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, **kw)
+    with tempfile.TemporaryDirectory() as d:
+        genes = {n: s.decode() for n, s in zip(names, nts)}
+        if found.get('diamond'):
+            q_txt, r_txt = O.diamond_fasta(genes, genes, '7', 11)
+            qry, ref, hit = os.path.join(d, 'qryAA'), os.path.join(d, 'refAA'), os.path.join(d, 'aaMatch')
+            open(qry, 'w').write(q_txt)
+            t0 = time.perf_counter()
+            run('{0} makedb --db {1} --in {1}'.format(found['diamond'], qry).split())
+            n_rec = 0
+            for i in range(5):
+                open('%s.%d' % (ref, i), 'w').write(r_txt[i])
+                run('{diamond} blastp --no-self-hits --threads {n_thread} --db {refAA} --query {qryAA} --out {aaMatch} --id {min_id} --query-cover {min_ratio} --evalue 1 -k {nhits} --dbsize 5000000 --outfmt 101'.format(
+                    diamond=found['diamond'], refAA='%s.%d' % (ref, i), qryAA=qry, aaMatch='%s.%d' % (hit, i), n_thread=threads, min_id=min_id, nhits=10, min_ratio=min_ratio).split())
+                if os.path.exists('%s.%d' % (hit, i)):
+                    n_rec += sum(1 for line in open('%s.%d' % (hit, i)) if not line.startswith('@'))
+            out['diamond'] = dict(seconds=time.perf_counter() - t0, records=n_rec, version=subprocess.run([found['diamond'], 'version'], capture_output=True, text=True).stdout.strip())
+        if found.get('blastn') and found.get('makeblastdb'):
+            ref = os.path.join(d, 'refNA')
+            with open(ref, 'w') as f:
+                for n, s in genes.items():
+                    f.write('>{0}\n{1}\n'.format(n, s))
+            t0 = time.perf_counter()
+            run('{0} -dbtype nucl -in {1} -out {1}'.format(found['makeblastdb'], ref).split())
+            order = sorted(genes.items(), key=lambda kv: -len(kv[1]))
+            shards = [os.path.join(d, 'qryNA.%d' % i) for i in range(min(len(order), threads))]
+            for i, q in enumerate(shards):
+                with open(q, 'w') as f:
+                    for n, s in order[i::threads]:
+                        f.write('>{0}\n{1}\n'.format(n, s))
+            cmd = ('{blastn} -db {refDb} -query {qry} -word_size 17 -out {qry}.bsn -perc_identity {min_id} -outfmt "6 qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue score qlen slen qseq sseq" '
+                   '-qcov_hsp_perc {min_ratio} -num_alignments 1000 -task blastn -evalue 1e-2 -dbsize 5000000 -reward 2 -penalty -3 -gapopen 6 -gapextend 2')
+            with ThreadPoolExecutor(max_workers=threads) as pool:
+                list(pool.map(lambda q: run(cmd.format(blastn=found['blastn'], refDb=ref, qry=q, min_id=min_id, min_ratio=min_ratio), shell=True), shards))
+            out['blastn'] = dict(seconds=time.perf_counter() - t0, records=sum(sum(1 for _ in open(q + '.bsn')) for q in shards if os.path.exists(q + '.bsn')))
+        if found.get('mmseqs'):
+            fa, db, lc, tmp, tab = (os.path.join(d, x) for x in ('genes.fa', 'seq.db', 'seq.lc', 'tmp', 'clust.tab'))
+            with open(fa, 'w') as f:
+                for n, s in genes.items():
+                    f.write('>{0}\n{1}\n'.format(n, s))
+            os.makedirs(tmp)
+            t0 = time.perf_counter()
+            run('{0} createdb {2} {1} -v 0'.format(found['mmseqs'], db, fa).split())
+            run('{0} linclust {1} {2} {3} --min-seq-id {4} -c {5} --threads {6} -v 0'.format(found['mmseqs'], db, lc, tmp, 0.9, 0.9, threads).split())
+            run('{0} createtsv {1} {1} {2} {3}'.format(found['mmseqs'], db, lc, tab).split())
+            out['mmseqs'] = dict(seconds=time.perf_counter() - t0, records=sum(1 for _ in open(tab)) if os.path.exists(tab) else 0)
+    return out
+
+
+def cpu_baseline(names, nts, n_sample, min_id, min_qcov):
+    """The CPU figure beside the GPU line.  The reference's binaries are probed for first (and timed with the reference's own command lines when
+    they exist: kind "reference"); on a machine without them - the GPU boxes of this pool - it is the CPU oracle (C port: seed phase parallel
+    over targets, alignment phase over (query, target) pairs, OpenMP on every host core) on a bounded sample of the same workload: the first
+    n_sample queries against the whole reference, with its phase split, plus the rate a VECTORISED Smith-Waterman reaches on the same CPU
+    (oracle/full_sw.c: 32 targets per query side by side, all cores) - the port is deliberately plain scalar code and says nothing about what
+    DIAMOND or a SIMD aligner would do.  Reported beside the GPU number, never the target."""
     from oracle import oracle as O
     from peppan_amd.configure import transeq          # numpy translation (pinned to the same golden vectors as the oracle's)
+    found, cpu_model = probe_reference_tools()
+    cores = len(os.sched_getaffinity(0))
+    have = sorted(t for t, path in found.items() if path)
+    sys.stderr.write('bench.py: reference binaries on PATH: %s; CPU: %s, %d hardware threads available\n' % (', '.join('%s=%s' % (t, found[t]) for t in have) or 'none', cpu_model, cores))
+    reference = None
+    if have:
+        try:
+            reference = reference_cpu_path(found, names, nts, min_id, min_qcov, cores)
+        except Exception as e:                          # a broken installation must not cost the line
+            reference = {'error': repr(e)}
     q_aa = []
     for n, frames in transeq([[i, s.decode()] for i, s in enumerate(nts[:n_sample])], frame='F', transl_table=11):
         q_aa.append(O.aa_codes(min((f[:-1].count('X'), k, f) for k, f in enumerate(frames))[2].replace('-', 'X')))
@@ -37,17 +128,42 @@ def cpu_baseline(nts, n_sample, min_id, min_qcov):
     for n, frames in transeq([[i, s.decode()] for i, s in enumerate(nts)], frame='7', transl_table=11):
         for aa in frames:
             t_aa += [O.aa_codes(c.replace('-', 'X')) for o, c in O.ref_chunks(aa)]
-    cores = len(os.sched_getaffinity(0))
     O.lib().oracle_set_threads(cores)
+    O.phase_seconds(reset=True)
     t0 = time.perf_counter()
     hits, cig, st = O.search(q_aa, t_aa, O.default_params(min_id, min_qcov, 10, 5))
     dt = time.perf_counter() - t0
-    return dict(value=st['candidates'] / dt, unit='gene-pairs/s', cores=cores, kind='port',
-                sample='first %d of %d queries vs all %d genes x 6 frames; %.1f s on %d threads; %d candidates, %.3g SW cells (%.3g cells/s); '
-                       'reference binaries (diamond/blastn/mmseqs) are absent, so this is the oracle C port (scalar code, OpenMP) - its ratio '
-                       'to the GPU figure says nothing about DIAMOND'
+    ph = O.phase_seconds()
+    # a vectorised CPU Smith-Waterman on the same residues: every (query, target frame) pair of a slice of the workload, full matrix, score only
+    vec = None
+    try:
+        from oracle import full_sw as F
+        nq_v, nt_v = min(64, len(q_aa)), min(len(t_aa), 12000)
+        t1 = time.perf_counter()
+        F.score_matrix(q_aa[:nq_v], t_aa[:nt_v], O.default_params(min_id, min_qcov, 10, 5), threads=cores)
+        dv = time.perf_counter() - t1
+        cells_v = float(sum(len(x) for x in q_aa[:nq_v])) * float(sum(len(x) for x in t_aa[:nt_v]))
+        vec = dict(cells_per_s=cells_v / dv, seconds=dv, sample='%d queries x %d target frames, full matrices, score only, %d threads (oracle/full_sw.c, 32 targets per query in SIMD lanes)' % (nq_v, nt_v, cores))
+    except Exception as e:
+        vec = {'error': repr(e)}
+    line = dict(value=st['candidates'] / dt, unit='gene-pairs/s', cores=cores, kind='port', cpu_model=cpu_model,
+                reference_binaries={t: found[t] for t in REFERENCE_TOOLS}, reference_cpu_path=reference,
+                sample='first %d of %d queries vs all %d genes x 6 frames; %.1f s on %d threads; %d candidates, %.3g SW cells (%.3g cells/s)'
                        % (n_sample, len(nts), len(nts), dt, cores, st['candidates'], st['cells'], st['cells'] / dt),
-                seconds=dt, sw_cells_per_s=st['cells'] / dt, _hits=(hits, cig, n_sample))
+                seconds=dt, sw_cells_per_s=st['cells'] / dt,
+                phase_s=dict(seed=ph['seed_s'], align=ph['align_s'], other=max(0., dt - ph['seed_s'] - ph['align_s']),
+                             score_pass_share_of_align=ph['score_thread_s'] / max(1e-12, ph['score_thread_s'] + ph['trace_thread_s']),
+                             traceback_share_of_align=ph['trace_thread_s'] / max(1e-12, ph['score_thread_s'] + ph['trace_thread_s'])),
+                sw_cells_per_s_vectorised=vec.get('cells_per_s') if vec else None, vectorised_sw=vec,
+                note='kind "port": the reference\'s binaries (diamond / blastn / mmseqs) are absent from this machine (probed: reference_binaries), so the figure is the '
+                     'oracle C port - scalar banded code under OpenMP; sw_cells_per_s_vectorised is what a SIMD Smith-Waterman sustains on the same cores. With the '
+                     'binaries on PATH the same run times the reference\'s own command lines (reference_cpu_path) and reports kind "reference"',
+                _hits=(hits, cig, n_sample))
+    if reference and reference.get('diamond', {}).get('seconds'):
+        d = reference['diamond']
+        line.update(kind='reference', value=float(len(nts)) * float(len(nts)) / d['seconds'], unit='gene pairs of the all-vs-all/s (diamond makedb + 5 x blastp, wall)', cores=cores,
+                    sample='all %d genes, the reference\'s diamond command lines (uberBlast.py:531, 550), %d threads, %.1f s, %d SAM records' % (len(nts), cores, d['seconds'], d['records']))
+    return line
 
 
 def spawn_ranks(args, argv):
@@ -81,7 +197,7 @@ def spawn_ranks(args, argv):
     return 0
 
 
-def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_stores=False):
+def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_stores=False, gene_set=None, presence=None, timing=None, search_log=None):
     """The genes -> genomes mapping (BASELINE configs "x 500 / x 2000 genomes"; PEPPAN.py:907-989) as a bench workload: every rank maps ITS OWN
     n_genomes synthetic genomes (10 000 exemplar genes, 2.2 Mb per genome) - batched GPU search for both tools, -f / -m / -O chain, K7, K12,
     build_bsn - per step.  Genomes are the independent unit of this path: they shard over the ranks with no data-path collective (weak
@@ -90,7 +206,7 @@ def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_s
     import io
     import tempfile
     from peppan_amd import mapbsn, synth, uberBlast as UB
-    names, seqs = synth.make_genes(args.genes, 0, seed=355)
+    names, seqs = gene_set or synth.make_genes(args.genes, 0, seed=355)
     params = dict(noDiamond=False, match_identity=0.65, match_frag_len=50, match_frag_prop=0.25, link_gap=600, link_diff=1.5, gtable=11,
                   match_len=250., match_len1=100., match_len2=400., match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
     tmp = tempfile.mkdtemp(prefix='pep_map_%d_' % rank)
@@ -100,7 +216,7 @@ def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_s
         with open('m.clust.exemplar', 'w') as f:
             for i, s in enumerate(seqs):
                 f.write('>%d\n%s\n' % (i, s.decode()))
-        worlds = synth.make_genomes(seqs, n_genomes, seed=355 + 1000 * rank)
+        worlds = synth.make_genomes(seqs, n_genomes, seed=355 + 1000 * rank, presence=presence)
         jobs, nt = [], 0
         with mapbsn.MapBsn('m.old_prediction.npz', 'w') as op:
             for g, (gname, contig, ann) in enumerate(worlds):
@@ -111,6 +227,17 @@ def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_s
         np.save('m.self_bsn.npy', og)
         UB._CTX.clear()
         os.environ['PEPPAN_HIP_DEVICE'] = str(local_rank)
+        if search_log is not None:
+            # every search of the drop-in's context with all phase timers on, its statistics appended to the caller's list
+            sctx = UB.get_context()
+            sctx.set_timing(2)
+            plain_search = sctx.search
+
+            def recorded(*a, **k):
+                r = plain_search(*a, **k)
+                search_log.append(r[2])
+                return r
+            sctx.search = recorded
         ortho = mapbsn.OrthoRelation(og)
         genomes = {100000 + g: [900000 + g, contig.decode()] for g, (gname, contig, ann) in enumerate(worlds)}
 
@@ -125,7 +252,7 @@ def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_s
         def step_with_stores():
             """the same genomes through get_map_bsn with the reference's four stores written (PEPPAN.py:907-989; .seq included)"""
             with mapbsn.MapBsn('t.npz', 'w') as c0, mapbsn.MapBsn('s.npz', 'w') as c1, mapbsn.MapBsn('a.npz', 'w') as c2, mapbsn.MapBsn('c.npz', 'w') as c3:
-                mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params, genomes_per_round=n_genomes)
+                mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params, genomes_per_round=n_genomes, timing=timing)
         with contextlib.redirect_stderr(io.StringIO()):
             for _ in range(warmup):
                 step()
@@ -147,11 +274,190 @@ def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_s
     return dict(seconds=dt, seconds_with_stores=dt_stores, genomes=n_genomes * steps, genome_nt=nt, groups_per_step=groups, hit_rows_per_step=rows)
 
 
-def _profile_tables():
+def map_strong(args, rank, world, local_rank, n_total):
+    """BASELINE configs[3] / [4], mapping stage, as STRONG scaling: ONE fixed set of n_total synthetic genomes against the exemplar genes through
+    get_map_bsn (PEPPAN.py:907-989) - the genomes dealt to the ranks in blocks of 32 (each rank searches its blocks on its own GPU: batched search of
+    both tools, -f / -m / -O, K7, K12, build_groups), rank 0 gathers the per-genome columns and writes the four stores.  No data-path collective."""
+    import contextlib
+    import io
+    import tempfile
+    from peppan_amd import mapbsn, synth, uberBlast as UB
+    names, seqs = synth.make_genes(args.genes, 0, seed=355)
+    params = dict(noDiamond=False, match_identity=0.65, match_frag_len=50, match_frag_prop=0.25, link_gap=600, link_diff=1.5, gtable=11,
+                  match_len=250., match_len1=100., match_len2=400., match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+    tmp = tempfile.mkdtemp(prefix='pep_maps_%d_' % rank)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        with open('m.clust.exemplar', 'w') as f:
+            for i, s in enumerate(seqs):
+                f.write('>%d\n%s\n' % (i, s.decode()))
+        worlds = synth.make_genomes(seqs, n_total, seed=355)                # the same set on every rank
+        genomes, nt = {}, 0
+        with mapbsn.MapBsn('m.old_prediction.npz', 'w') as op:
+            for g, (gname, contig, ann) in enumerate(worlds):
+                genomes[100000 + g] = [900000 + g, contig.decode()]
+                nt += len(contig)
+                op.save(100000 + g, np.array([[k, a, b, st, 1] for k, a, b, st in ann[::2]], dtype=object))
+        np.save('m.self_bsn.npy', np.array([[0, 1, 9000], [4, 5, -2]], dtype=int))
+        UB._CTX.clear()
+        os.environ['PEPPAN_HIP_DEVICE'] = str(local_rank)
+        tm = {}
+
+        def once():
+            import torch.distributed as dist
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            with contextlib.ExitStack() as es:
+                stores = [es.enter_context(mapbsn.MapBsn('s%d.npz' % k, 'w')) for k in range(4)] if rank == 0 else [None] * 4
+                mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', stores[0], stores[1], stores[2], stores[3], True, params,
+                                   genomes_per_round=32, timing=tm)
+            if world > 1:
+                dist.barrier()
+            return time.perf_counter() - t0
+        with contextlib.redirect_stderr(io.StringIO()):
+            once() if args.warmup and '--warmup' in sys.argv else None
+            dt = once()
+    finally:
+        os.chdir(cwd)
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return dict(seconds=dt, genomes=n_total, genome_nt=nt, phase_s_rank0=tm)
+
+
+def configs4_workloads(local_rank, min_id, min_qcov, torch, steps=5):
+    """BASELINE configs[4] at the size ONE GPU holds, behind the headline (the `workloads` block of the line):
+      search_50k   the 50 000 x 50 000 gene all-vs-all step (K1 .. K10, the headline's step at 25 x the gene pairs): ms per step, phase split,
+                   the three largest kernels with their rooflines (traffic from profiles/r04_counters_50k.json)
+      map_50k      50 000 exemplar genes mapped onto 8 genomes of a 50 000-gene pan-genome (6 500 genes, 7 Mb each: synth.PAN_GENOME_PRESENCE)
+                   through the batched mapping path - search of both tools, -f / -m / -O, K7, K12, build_groups - and through get_map_bsn with
+                   the four stores written; phase split, the time the GPU spends inside the searches, the largest search kernel's roofline"""
+    from peppan_amd import _native as N, dist as pdist, synth, uberBlast as UB
+    out = {}
+    names, seqs = synth.make_genes(50000, 1002, seed=355)
+    order = sorted(range(len(names)), key=lambda i: names[i])
+    nts = [seqs[i] for i in order]
+    params = N.default_params(min_id, min_qcov, 10, 5)
+    keys = ('candidates', 'candidates_settled', 'cells', 'cells_settled', 'hits', 'tracebacks', 'tracebacks_gapless', 'seed_hits', 'target_residues', 'query_residues',
+            'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total')
+    cyc4 = _profile_tables()[1]
+    with N.Context(local_rank) as ctx:
+        shard = pdist.ShardedSearch(ctx, nts, nts, params, 0, 1)
+        ctx.set_grouping(len(nts), shard.gene_of_target)
+        for _ in range(2):
+            shard.search(retranslate=True, copy=False)
+        torch.cuda.synchronize()
+        ctx.set_timing(0)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            allh, allc, st = shard.search(retranslate=True, copy=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_hits, n_clusters = int(len(allh)), int(len(np.unique(ctx.labels)))
+        ctx.set_timing(2)
+        shard.search(retranslate=True, copy=False)
+        acc = dict.fromkeys(keys, 0.0)
+        for _ in range(steps):
+            st = shard.search(retranslate=True, copy=False)[2]
+            for k in keys:
+                acc[k] += st[k]
+        ctx.set_timing(0)
+        per = {k: acc[k] / steps for k in keys}
+        rl = roofline_kernels(_profile_tables(PROFILE_COUNTERS_50K)[0], cyc4, os.path.basename(PROFILE_COUNTERS_50K), per, 334, params.n_shapes)
+        rl.sort(key=lambda e: -e['ms_per_launch'])
+        out['search_50k'] = {'workload': 'synthgenes-v1 seed 355: 50000 genes x 1002 nt, all-vs-all on one GPU (BASELINE configs[4] search stage)', 'steps': steps,
+                             'ms_per_step': dt / steps * 1e3, 'gene_pairs_all_vs_all_per_s': 2.5e9 * steps / dt, 'candidates_per_step': per['candidates'], 'hits_per_step': n_hits,
+                             'clusters': n_clusters, 'value_gene_pairs_aligned_per_s': per['candidates'] * steps / dt,
+                             'sw_cell_updates_per_s_per_gpu': (per['cells'] - per['cells_settled']) / (per['ms_sw'] * 1e-3) if per['ms_sw'] else None,
+                             'phase_ms': {k: per[k] for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
+                             'roofline': rl[0], 'roofline_kernels': rl}
+    # ---- the mapping leg: the search context of the drop-in (uberBlast.get_context), every search's statistics recorded
+    class A(object):
+        genes = 50000
+    log, tm = [], {}
+    n_genomes = 8
+    mr = map_workload(A, 0, 1, local_rank, n_genomes, 1, 1, with_stores=True, gene_set=(names, seqs), presence=synth.PAN_GENOME_PRESENCE, timing=tm, search_log=log)
+    # the log holds the searches of: one warm-up step, the timed step, one warm-up with stores, the timed step with stores - equal quarters
+    n_per = len(log) // 4
+    step_log = log[n_per:2 * n_per]
+    per = {k: float(sum(st[k] for st in step_log)) for k in keys}
+    launches = {'sw_trace_kernel': sum(1 for st in step_log if st['ms_sw_trace'] > 0), 'sw_score_kernel': sum(1 for st in step_log if st['ms_sw'] > 0),
+                'seed_match<10>': sum(1 for st in step_log if st['ms_seed_match'] > 0)}
+    rl = roofline_kernels({}, cyc4, '', per, max(1., per['query_residues'] / max(1, n_per) / 50000.), 1)
+    for e in rl:
+        e['launches_per_step'] = launches.get(e['kernel'], 0)
+        e['ms_per_step'] = e.pop('ms_per_launch')
+        e['note'] = 'summed over the searches of one mapping step (nucleotide tool + translated tool per sub-batch of genomes); lengths differ per pair: algorithmic bytes use the mean query length'
+    rl.sort(key=lambda e: -e['ms_per_step'])
+    wall = mr['seconds']
+    out['map_50k'] = {'workload': 'synthgenes-v1: 50000 exemplar genes x 1002 nt mapped onto %d genomes of a 50000-gene pan-genome (%.1f Mnt per genome): --blastn --diamond -f -m -O -s 1, K7, K12, '
+                                  'build_groups; then the same through get_map_bsn with the four stores (BASELINE configs[4] mapping stage on one GPU)' % (n_genomes, mr['genome_nt'] / n_genomes / 1e6),
+                      'genomes_per_s': mr['genomes'] / wall, 'genomes_per_s_with_stores': mr['genomes'] / mr['seconds_with_stores'], 'ms_per_genome': wall / mr['genomes'] * 1e3,
+                      'groups_per_genome': mr['groups_per_step'] / n_genomes, 'hit_rows_per_genome': mr['hit_rows_per_step'] / n_genomes,
+                      'searches_per_step': n_per, 'gpu_ms_in_searches_per_step': per['ms_total'], 'gpu_busy_frac': per['ms_total'] * 1e-3 / wall,
+                      'gpu_busy_note': 'HIP-event time of the searches (K1 .. K8) over the step wall clock; K7 / K11 / K12 run besides (a few per cent more: profiles/r04_map_kernel_stats.txt)',
+                      'phase_ms_searches': {k: per[k] for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
+                      'phase_s_with_stores': tm, 'roofline': rl[0], 'roofline_kernels': rl}
+    return out
+
+
+def _ranks_seen(dist, torch, world, share, local_rank):
+    """how many ranks the collective library really connects: a sum of ones over the process group - on the GPU through RCCL (backend nccl),
+    which is what `rccl_ranks_seen` in the line says; None in a one-rank run without a group"""
+    if world == 1:
+        return None
+    t = torch.ones(1, dtype=torch.int32, device=torch.device('cpu') if share else torch.device('cuda', local_rank))
+    dist.all_reduce(t)
+    return int(t.item())
+
+
+def roofline_entry(counters, cyc4, source, kernel, what, ms, alg_bytes, valu=False):
+    """one roofline record: algorithmic bytes over the kernel's LIVE duration against the 8 TB/s HBM roof, plus the tracked PMC
+    traffic of the same kernel on the same workload (`counters`: per-kernel figures of a rocprofv3 --pmc run kept under profiles/)"""
+    achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    prof = counters.get(kernel) or counters.get(kernel + '<false>') or {}      # (the Smith-Waterman kernels are templates: <false> = the launch of the pairs that fit the staging area)
+    # the tracked counters describe THIS kernel only while it still takes what it took when they were collected: its duration in the
+    # PMC passes must agree with the live HIP-event time within 10 %, else the figures are withheld (stale: regenerate with tools/profile_round.sh)
+    prof_us = prof.get('avg_us_in_pmc_passes') or []
+    stale = bool(prof_us) and ms > 0 and abs(min(prof_us) / 1e3 - ms) > 0.10 * ms and abs(sum(prof_us) / len(prof_us) / 1e3 - ms) > 0.10 * ms
+    if stale:
+        prof = {}
+    traffic = (2 * prof['FETCH_SIZE'] + prof['WRITE_SIZE']) * 1024.0 if 'FETCH_SIZE' in prof and 'WRITE_SIZE' in prof else None
+    e = {'kernel': kernel, 'what': what, 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
+         'ms_per_launch': ms, 'algorithmic_bytes': alg_bytes, 'traffic': traffic, 'counters_stale': stale,
+         'ms_per_launch_in_pmc_passes': (sum(prof_us) / len(prof_us) / 1e3) if prof_us else None,
+         'traffic_source': ('profiles/%s: 2 x FETCH_SIZE + WRITE_SIZE of the same kernel on this workload (separate rocprofv3 --pmc passes; '
+                            'x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)' % source) if traffic is not None else None}
+    if traffic:
+        e['traffic_over_algorithmic'] = traffic / alg_bytes if alg_bytes else None
+    if valu and cyc4 and 'SQ_INSTS_VALU' in prof and ms > 0:
+        # integer-VALU bound kernels: wave-instructions per launch (PMC) x measured cycles per instruction of the packed-16 / DPP / add3
+        # class (tools/micro/valu_rate.hip) against 1024 SIMDs at the 2.4 GHz peak clock for the launch's live duration
+        e['valu_issue_frac'] = prof['SQ_INSTS_VALU'] * cyc4 / (1024 * 2.4e9 * ms * 1e-3)
+        e['valu_issue_source'] = 'SQ_INSTS_VALU from profiles/%s x %.3f cycles/instruction from profiles/%s' % (source, cyc4, os.path.basename(PROFILE_VALU))
+    return e
+
+
+def roofline_kernels(counters, cyc4, source, per_step, Lq, n_shapes):
+    """the three kernels a search spends most of its time in.  per_step: the search statistics per step (phase times in ms, counts).
+    Algorithmic bytes per launch, SURVEY.md 8(d): SW = sum over pairs of (Lq + Lr) residue bytes + 64 B per reported hit;
+    seed join = 1 B + 8 B index entry per target residue + 8 B per raw seed hit"""
+    p = per_step
+    return [roofline_entry(counters, cyc4, source, 'sw_trace_kernel', 'K5 traceback pass: sub-band SW + 4-bit codes over the selected pairs that are not one ungapped run (rule 5a), four per wavefront',
+                           p['ms_sw_trace'], (p['tracebacks'] - p['tracebacks_gapless']) * 2 * Lq + p['hits'] * 64, True),
+            roofline_entry(counters, cyc4, source, 'sw_score_kernel', 'K5 score pass: banded SW over the candidate pairs that are not identical sequences (those are settled by comparison: candidates_settled)',
+                           p['ms_sw'], (p['candidates'] - p['candidates_settled']) * 2 * Lq + p['hits'] * 64, True),
+            roofline_entry(counters, cyc4, source, 'seed_match<10>', 'K4a: target seeds streamed through the query index (one launch per seed shape)', p['ms_seed_match'] / max(1, n_shapes),
+                           9.0 * p['target_residues'] + 8.0 * p['seed_hits'] / max(1, n_shapes))]
+
+
+def _profile_tables(path=None):
     """tracked evidence the line refers to: per-kernel PMC counters of this workload and the measured VALU issue rates"""
     counters, cyc4 = {}, None
-    if os.path.exists(PROFILE_COUNTERS):
-        counters = json.load(open(PROFILE_COUNTERS)).get('kernels', {})
+    path = path or PROFILE_COUNTERS
+    if os.path.exists(path):
+        counters = json.load(open(path)).get('kernels', {})
     if os.path.exists(PROFILE_VALU):
         for line in open(PROFILE_VALU):
             f = line.split()
@@ -176,6 +482,28 @@ def main_map(args, rank, local_rank, world):
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         dist.barrier()
     torch.cuda.synchronize()
+    ranks_seen = _ranks_seen(dist, torch, world, share, local_rank)
+    if args.map_scaling == 'strong':
+        n_total = args.map_genomes if '--map-genomes' in sys.argv else 500
+        r = map_strong(args, rank, world, local_rank, n_total)
+        torch.cuda.synchronize()
+        dt = r['seconds']
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=torch.device('cpu') if share else torch.device('cuda', local_rank))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            print(json.dumps({'metric': 'genomes_mapped_per_s', 'value': r['genomes'] / dt, 'unit': 'genomes/s', 'n_gpus': world, 'steps': 1, 'warmup': 0, 'ms_per_step': dt * 1e3,
+                              'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic', 'rccl_ranks_seen': ranks_seen,
+                              'config': {'workload': 'synthgenes-v1: %d exemplar genes (log-normal lengths) x ONE fixed set of %d genomes (%.2f Gnt), get_map_bsn with the four stores written by rank 0 '
+                                                     '(BASELINE configs[3]/[4] mapping stage, PEPPAN.py:907-989)' % (args.genes, r['genomes'], r['genome_nt'] / 1e9),
+                                         'parallelism': 'genomes dealt to %d rank(s) in blocks of 32, gather_object of the per-genome columns to rank 0, no data-path collective' % world},
+                              'phase_s_rank0': r['phase_s_rank0'], 'roofline': None, 'cpu_baseline': None}))
+            sys.stdout.flush()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     r = map_workload(args, rank, world, local_rank, args.map_genomes, steps, warmup)
     torch.cuda.synchronize()
     dt = r['seconds']
@@ -185,7 +513,7 @@ def main_map(args, rank, local_rank, world):
         dt = float(t.item())
     if rank == 0:
         print(json.dumps({'metric': 'genomes_mapped_per_s', 'value': world * r['genomes'] / dt, 'unit': 'genomes/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
-                          'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic',
+                          'ms_per_step': dt / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic', 'rccl_ranks_seen': ranks_seen,
                           'config': {'workload': 'synthgenes-v1: %d exemplar genes (log-normal lengths) x %d genomes per rank and step (%.1f Mnt per rank), the genes -> genomes mapping of '
                                                  'BASELINE configs[2..4] (PEPPAN.py:907-989): --blastn --diamond -f -m -O -s 1, build_bsn' % (args.genes, args.map_genomes, r['genome_nt'] / 1e6),
                                      'parallelism': 'genomes sharded over %d rank(s), no data-path collective' % world},
@@ -201,7 +529,7 @@ def main_map(args, rank, local_rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--steps', type=int, default=250, help='timed steps (default 250: a timed region of about 0.55 s)')
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--genes', type=int, default=10000)
     ap.add_argument('--gene-len', type=int, default=1002)
@@ -210,7 +538,11 @@ def main():
     ap.add_argument('--cpu-sample', type=int, default=10000, help='leading queries of the workload the CPU baseline runs (all host cores)')
     ap.add_argument('--workload', choices=('search', 'map'), default='search', help='search: the all-vs-all step (the BASELINE metric); map: the genes -> genomes '
                     'mapping, genomes sharded over the ranks (weak scaling, no collective) - default 2 timed steps of --map-genomes genomes per rank')
-    ap.add_argument('--map-genomes', type=int, default=16, help='genomes per rank and step of --workload map')
+    ap.add_argument('--map-genomes', type=int, default=16, help='genomes per rank and step of --workload map (weak scaling); with --map-scaling strong: the size of the FIXED genome set')
+    ap.add_argument('--map-scaling', choices=('weak', 'strong'), default='weak', help='strong: ONE fixed set of --map-genomes genomes (default 500 then) through get_map_bsn, '
+                    'sharded over the ranks in blocks, rank 0 writes the four stores (BASELINE configs[3]/[4] mapping stage)')
+    ap.add_argument('--grid', default=None, help='RxC: query shards x reference shards of the all-vs-all (default: peppan_amd.dist.choose_grid); R*C must equal --gpus')
+    ap.add_argument('--no-workloads', action='store_true', help='skip the configs[4] legs behind the headline (50k x 50k search step, 50k-exemplar mapping step)')
     args = ap.parse_args()
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
@@ -229,7 +561,7 @@ def main():
     min_id, min_qcov = 45.0, 25.0                                  # PEPPAN.py:229-230 with defaults (match_identity 0.5 - 0.05, match_frag_prop 0.25)
     cpu_line = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu_line = cpu_baseline(nts, min(args.cpu_sample, len(nts)), min_id, min_qcov)
+        cpu_line = cpu_baseline([names[i] for i in order], nts, min(args.cpu_sample, len(nts)), min_id, min_qcov)
 
     import torch
     import torch.distributed as dist
@@ -245,11 +577,17 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     dev = torch.device('cpu') if (share and world > 1) else torch.device('cuda', local_rank)
+    ranks_seen = _ranks_seen(dist, torch, world, share, local_rank)
 
     from peppan_amd import _native as N, dist as pdist
     params = N.default_params(min_id, min_qcov, 10, 5)
     ctx = N.Context(local_rank)
-    shard = pdist.ShardedSearch(ctx, nts, nts, params, rank, world, device=dev if world > 1 else None)
+    grid = None
+    if args.grid:
+        grid = tuple(int(x) for x in args.grid.lower().split('x'))
+        if len(grid) != 2 or grid[0] * grid[1] != world:
+            sys.exit('bench.py: --grid %s does not describe %d rank(s)' % (args.grid, world))
+    shard = pdist.ShardedSearch(ctx, nts, nts, params, rank, world, grid=grid, device=dev if world > 1 else None)
 
     if world == 1:
         ctx.set_grouping(len(nts), shard.gene_of_target)    # single linkage (K10) as the tail of the search: edges (q, gene of t) straight from the table's device copy
@@ -276,16 +614,6 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    # After a device-wide synchronisation the HIP runtime re-establishes its SDMA copy queues, once, about a thousand submitted commands
-    # later: 5.6 ms in the middle of some step - with twenty timed steps +0.28 ms per step in nine runs out of ten.
-    # A burst of tiny SYNCHRONOUS library calls (a union-find over eight nodes each: two uploads, three kernels, one download; 20 ms in all)
-    # between the synchronisation and the start of the clock gets the runtime past that point; the device is idle again when the clock
-    # starts, and no step is run here.
-    settle_a, settle_b = np.array([0, 1, 2, 3], dtype=np.uint32), np.array([1, 2, 3, 4], dtype=np.uint32)
-    for _ in range(500):
-        ctx.components(8, settle_a, settle_b)
-    if world > 1:
-        dist.barrier()
     # phase timers: HIP events on the search's stream cost about 6 us of idle GPU each (profiles/r03_step_timeline.txt), sixteen per search with
     # every phase timed.  The timed region keeps the pair around the dominant kernel (the score pass: the roofline's live duration) and nothing
     # else; the other phases are measured in a loop of their own behind it (phase_timers below)
@@ -338,10 +666,11 @@ def main():
         parity = dict(gpu_hits_identical=bool(same), hits_compared=int(len(o_hits)), against='oracle C port (align_oracle.c), same queries and reference')
         cpu_line.update(gpu_hits_identical=bool(same), hits_compared=int(len(o_hits)))
 
+    hits_last, clusters_last = float(len(allh)), int(len(np.unique(labels)))      # (allh / labels are views of the context's pinned staging area)
     extras = {}
     if world == 1 and rank == 0:
         # what a caller sees who synchronises the whole device and then searches: the same K steps right behind a torch.cuda.synchronize(),
-        # WITHOUT the settle burst in front - the runtime's one-time 5.6 ms copy-queue stall lands in here if it occurs
+        # once more (the runtime's one-time 5.6 ms copy-queue stall behind a device-wide synchronisation, DESIGN.md section 6, lands in one of the two loops if it occurs)
         torch.cuda.synchronize()
         t9 = time.perf_counter()
         for _ in range(args.steps):
@@ -436,6 +765,14 @@ def main():
                                       'note': 'python bench.py --workload map --gpus N: genomes sharded over the ranks, weak scaling, no collective'}
         except Exception as e:                                  # never lose the headline over the secondary leg
             extras['map_workload'] = {'error': repr(e)}
+    if rank == 0 and world == 1 and not args.no_e2e and not args.no_workloads and args.genes == 10000:
+        # (e) BASELINE configs[4] at the size one GPU holds: the 50k x 50k search step and a 50k-exemplar mapping step
+        try:
+            ctx.close()                                         # (the headline's context: its workspaces go back before the large legs allocate theirs)
+            extras['workloads'] = configs4_workloads(local_rank, min_id, min_qcov, torch)
+        except Exception as e:
+            import traceback
+            extras['workloads'] = {'error': repr(e), 'traceback': traceback.format_exc()[-1500:]}
 
     if rank == 0:
         K = args.steps
@@ -445,37 +782,7 @@ def main():
         hits_step = acc['hits'] / K
         n_shapes = params.n_shapes
 
-        def entry(kernel, what, ms, alg_bytes, insts_key=None):
-            achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            prof = (counters.get(kernel) or counters.get(kernel + '<false>') or {}) if headline else {}      # (the Smith-Waterman kernels are templates: <false> = the launch of the pairs that fit the staging area, all of this workload)
-            # the tracked counters describe THIS kernel only while it still takes what it took when they were collected: its duration in the
-            # PMC passes must agree with the live HIP-event time within 10 %, else the figures are withheld (stale: regenerate with tools/profile_round.sh)
-            prof_us = prof.get('avg_us_in_pmc_passes') or []
-            stale = bool(prof_us) and ms > 0 and abs(min(prof_us) / 1e3 - ms) > 0.10 * ms and abs(sum(prof_us) / len(prof_us) / 1e3 - ms) > 0.10 * ms
-            if stale:
-                prof = {}
-            traffic = (2 * prof['FETCH_SIZE'] + prof['WRITE_SIZE']) * 1024.0 if 'FETCH_SIZE' in prof and 'WRITE_SIZE' in prof else None
-            e = {'kernel': kernel, 'what': what, 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-                 'ms_per_launch': ms, 'algorithmic_bytes': alg_bytes, 'traffic': traffic, 'counters_stale': stale,
-                 'ms_per_launch_in_pmc_passes': (sum(prof_us) / len(prof_us) / 1e3) if prof_us else None,
-                 'traffic_source': 'profiles/r03_counters.json: 2 x FETCH_SIZE + WRITE_SIZE of the same kernel on this workload (separate rocprofv3 --pmc passes; '
-                                   'x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)' if traffic is not None else None}
-            if traffic:
-                e['traffic_over_algorithmic'] = traffic / alg_bytes if alg_bytes else None
-            if insts_key and cyc4 and 'SQ_INSTS_VALU' in prof and ms > 0:
-                # integer-VALU bound kernels: wave-instructions per launch (PMC) x measured cycles per instruction of the packed-16 / DPP / add3
-                # class (tools/micro/valu_rate.hip) against 1024 SIMDs at the 2.4 GHz peak clock for the launch's live duration
-                e['valu_issue_frac'] = prof['SQ_INSTS_VALU'] * cyc4 / (1024 * 2.4e9 * ms * 1e-3)
-                e['valu_issue_source'] = 'SQ_INSTS_VALU from profiles/r03_counters.json x %.3f cycles/instruction from profiles/r03_valu_rate.txt' % cyc4
-            return e
-
-        ms_sw, ms_tr, ms_match = acc['ms_sw'] / K, acc['ms_sw_trace'] / K, acc['ms_seed_match'] / K / max(1, n_shapes)
-        # algorithmic bytes per launch, SURVEY.md 8(d): SW = sum over pairs of (Lq + Lr) residue bytes + 64 B per reported hit;
-        # seed join = 1 B + 8 B index entry per target residue + 8 B per raw seed hit
-        rl = [entry('sw_trace_kernel', 'K5 traceback pass: sub-band SW + 4-bit codes over the selected pairs that are not one ungapped run (rule 5a), four per wavefront', ms_tr, ((acc['tracebacks'] - acc['tracebacks_gapless']) / K) * 2 * Lq + hits_step * 64, 'v'),
-              entry('sw_score_kernel', 'K5 score pass: banded SW over the candidate pairs that are not identical sequences (those are settled by comparison: candidates_settled)', ms_sw, ((acc['candidates'] - acc['candidates_settled']) / K) * 2 * Lq + hits_step * 64, 'v'),
-              entry('seed_match<10>', 'K4a: target seeds streamed through the query index (one launch per seed shape)', ms_match,
-                    9.0 * acc['target_residues'] / K + 8.0 * acc['seed_hits'] / K / max(1, n_shapes))]
+        rl = roofline_kernels(counters if headline else {}, cyc4, os.path.basename(PROFILE_COUNTERS), {k: acc[k] / K for k in acc}, Lq, n_shapes)
         rl.sort(key=lambda e: -e['ms_per_launch'])
         top = dict(rl[0])
         top['note'] = ('dominant kernel by live HIP-event time; the SW passes are integer-VALU bound by construction (SURVEY 8d): valu_issue_frac is '
@@ -483,6 +790,7 @@ def main():
         line = {
             'metric': 'gene_pairs_aligned_per_s', 'value': total_pairs / dt, 'unit': 'gene-pairs/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': dt / K * 1e3,
+            'rccl_ranks_seen': ranks_seen, 'collective_backend': None if world == 1 else ('gloo (PEPPAN_BENCH_SHARE_GPU test hook)' if share else 'nccl = RCCL'),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic',
             'dtype_note': 'both Smith-Waterman passes run in packed 16-bit integers (v_pk_*_i16) whenever the scores of a pair fit, which is every pair of this workload; 32-bit integer kernels otherwise; seed keys are 64-bit integers',
             'config': {'workload': 'synthgenes-v1 seed 355: %d genes x %d nt, all-vs-all (BASELINE configs[2] search stage), '
@@ -491,16 +799,15 @@ def main():
                        'parallelism': 'grid %d query shards x %d reference shards, one all-gather of the hit tables%s' % (shard.R, shard.C, ' + exact top-k merge' if shard.C > 1 else ' (query shards only: the tables concatenate)')},
             'sw_cell_updates_per_s_per_gpu': (acc['cells'] - acc['cells_settled']) / (acc['ms_sw'] * 1e-3) if acc['ms_sw'] else None,
             'sw_cell_updates_per_s_per_gpu_wall': total_cells / dt / world,
-            'hits_per_step': float(len(allh)), 'clusters': int(len(np.unique(labels))), 'candidates_per_step': acc['candidates'] / K,
+            'hits_per_step': hits_last, 'clusters': clusters_last, 'candidates_per_step': acc['candidates'] / K,
             # units that do not move with internal filters (value counts the candidates the pre-filter lets through):
-            'hits_per_s': float(len(allh)) * K / dt, 'gene_pairs_all_vs_all_per_s': float(args.genes) * float(args.genes) * K / dt,
+            'hits_per_s': hits_last * K / dt, 'gene_pairs_all_vs_all_per_s': float(args.genes) * float(args.genes) * K / dt,
             'tracebacks_per_step': acc['tracebacks'] / K, 'tracebacks_gapless_per_step': acc['tracebacks_gapless'] / K,
             'candidates_settled_per_step': acc['candidates_settled'] / K,      # identical pairs: scored by comparison, not swept (their cells are not in the cell rates)
-            'steady_state': True, 'settle_calls': 500,
             'value_definition': 'candidate (query, target-frame, band) pairs entering gapped Smith-Waterman per second of step wall time (SURVEY.md 8d-i); '
                                 'the pre-filter in front of that stage decides how many there are - see same_unit_as_round1; hits_per_s and '
-                                'gene_pairs_all_vs_all_per_s (query genes x reference genes per second) do not depend on it. ms_per_step is a steady-state figure: '
-                                '500 tiny library calls run between the device-wide synchronisation and the clock (settle_calls); ms_per_step_after_device_sync is the same loop without them',
+                                'gene_pairs_all_vs_all_per_s (query genes x reference genes per second) do not depend on it. The timed region starts right behind the barrier + '
+                                'torch.cuda.synchronize() the contract asks for (no settle calls in between since round 4); ms_per_step_after_device_sync is a second such loop',
             'phase_ms': {k: acc[k] / K for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
             'phase_timers': {'in_timed_region': ['ms_sw'], 'ms_per_step_with_every_phase_timer': ms_step_all_timers,
                              'note': 'pep_set_timing: the timed region records the two HIP events around the score pass (the roofline kernel) only; the other phase_ms '

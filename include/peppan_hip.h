@@ -152,6 +152,9 @@ int pep_ctx_create(int device, pep_ctx **out);
 void pep_ctx_destroy(pep_ctx *ctx);
 const char *pep_last_error(const pep_ctx *ctx);
 void pep_default_params(pep_search_params *p);
+/* sensitivity of the translated search: 0 = DIAMOND's two default-mode seed shapes (what the reference's command line runs, uberBlast.py:550),
+ * 1 = four shapes (recall 0.93 -> 0.985 between 0.45 and 0.7 identity at twice the seed-stage cost).  Rewrites n_shapes / weight / offs. */
+int pep_set_sensitivity(pep_search_params *p, int level);
 /* smallest raw score passing the e-value cut for a query of qlen residues */
 int32_t pep_min_score(uint32_t qlen, double dbsize, double max_evalue);
 int32_t pep_min_score_ka(uint32_t qlen, double dbsize, double max_evalue, double ka_lambda, double ka_k);

@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
 ABI_VERSION = 9
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
-EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params',
+EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params', 'pep_set_sensitivity',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
@@ -99,6 +99,7 @@ def load_library():
     return lib
 
 
+DEFAULT_SHAPES = ('111101110111', '111011010010111')          # DIAMOND's two default-sensitivity shapes (weight 10)
 SENSITIVE_SHAPES = ('110010011111011', '10111110011011')      # two more weight-10 shapes for the sensitive mode (see default_params)
 
 
@@ -118,7 +119,7 @@ def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5, dbsize=
     """the protein search configured like the reference's diamond call (uberBlast.py:550).  sensitive: four seed shapes instead of DIAMOND's
     two default-mode shapes - against exhaustive Smith-Waterman the recall between 0.45 and 0.7 identity rises from 0.93 to 0.985 on the
     1 000-gene configuration (above 0.7 it is 1.0 either way) at twice the seed-stage cost; the reference itself runs diamond at its default
-    sensitivity, so this is an option (PEPPAN_HIP_SENSITIVE=1 for the drop-in), not the default"""
+    sensitivity, so this is an option (RunBlast(sensitive=True) / uberBlast's --sensitive flag / pep_set_sensitivity in the C ABI), not the default"""
     p = SearchParams()
     load_library().pep_default_params(C.byref(p))
     if ungapped_min is not None:
@@ -126,7 +127,8 @@ def default_params(min_id_pct=0., min_qcov_pct=0., top_k=10, n_splits=5, dbsize=
     p.min_id_pct, p.min_qcov_pct, p.top_k, p.n_splits = float(min_id_pct), float(min_qcov_pct), int(top_k), int(n_splits)
     p.dbsize, p.max_evalue, p.use_lds = float(dbsize), float(max_evalue), int(use_lds)
     if sensitive:
-        set_shapes(p, ['111101110111', '111011010010111'] + list(SENSITIVE_SHAPES))
+        if load_library().pep_set_sensitivity(C.byref(p), 1) != 0:
+            raise PepError('pep_set_sensitivity failed')
     return p
 
 

@@ -113,7 +113,7 @@ class MapBsn(object):
                     return
                 db, key, packed = item
                 if self._error is None:
-                    _append_member(db, key, packed.result())
+                    _append_member(db, key, packed if isinstance(packed, tuple) else packed.result())
             except BaseException as e:              # reported by the next _flush() on the owning thread
                 self._error = e
             finally:
@@ -186,7 +186,11 @@ class MapBsn(object):
             self._queue = queue.Queue(maxsize=256)
             self._thread = threading.Thread(target=self._writer, daemon=True)
             self._thread.start()
-        self._queue.put((db, key, _packers().submit(_pack_member, data)))
+        if not callable(data) and len(data) < 4096:
+            packed = _pack_member(data)             # a few hundred bytes, stored as they are: not worth a trip through the pool
+        else:
+            packed = _packers().submit(_pack_member, data)
+        self._queue.put((db, key, packed))
 
     def _save(self, db, key, val):
         self._enqueue(db, key, _npy_bytes(val))     # serialised here: the caller may change `val` afterwards

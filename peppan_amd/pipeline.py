@@ -274,6 +274,8 @@ def _self_search(clust, params, pool):
     argv = ['-r', clust, '-q', clust] + tools.split() + ['--min_id', str(params['match_identity'] - 0.05), '--min_cov', str(params['match_frag_len']),
                                                         '-t', str(params['n_thread']), '--min_ratio', str(params['match_frag_prop']), '-e', '3,3', '-p',
                                                         '--gtable', str(params['gtable'])]
+    if params.get('sensitive'):                    # (not a PEPPAN parameter: four seed shapes in the translated search, see uberBlast --sensitive)
+        argv.append('--sensitive')
     return uberBlast(argv, pool, as_table=True)
 
 

@@ -90,13 +90,19 @@ def make_proteins(n, length=300, seed=1, family=3, sub=0.2, indel=0.7):
     return [np.ascontiguousarray(x, dtype=np.uint8) for x in out[:n]]
 
 
-def make_genomes(gene_seqs, n_genomes, seed=355, family=4):
+PAN_GENOME_PRESENCE = ((0.99, 0.5, 0.05), (0.40, 0.22, 0.38))    # (presence probabilities, shares of the families): core / shell / cloud of a
+#                                                                    50 000-gene pan-genome (12 500 families) whose genomes carry about 6 500 genes, 7 Mb, each (BASELINE configs[4], "Salmonella-scale")
+
+
+def make_genomes(gene_seqs, n_genomes, seed=355, family=4, presence=None):
     """synthgenes-v1 genomes: a family is present with p = 0.99 (70 % of families), 0.5 (20 %) or 0.05
-    (10 %); the allele is one family member with a per-genome substitution rate U(0, 0.02); one contig, random strand,
-    50-300 nt random spacers.  Returns [(genome name, contig bytes, [(gene index, start, end, strand), ...]), ...]"""
+    (10 %) - or with the probabilities / shares given as presence = ((p...), (share...)), e.g. PAN_GENOME_PRESENCE; the allele is one
+    family member with a per-genome substitution rate U(0, 0.02); one contig, random strand, 50-300 nt random spacers.
+    Returns [(genome name, contig bytes, [(gene index, start, end, strand), ...]), ...]"""
     rng = np.random.default_rng(seed + 1)
     n_fam = (len(gene_seqs) + family - 1) // family
-    p_present = rng.choice([0.99, 0.5, 0.05], size=n_fam, p=[0.7, 0.2, 0.1])
+    probs, shares = presence or ((0.99, 0.5, 0.05), (0.7, 0.2, 0.1))
+    p_present = rng.choice(list(probs), size=n_fam, p=list(shares))
     comp = np.zeros(256, dtype=np.uint8)
     comp[list(b'ACGT')] = list(b'TGCA')
     out = []

@@ -275,7 +275,8 @@ def cigar2score(data):
 
 
 class RunBlast(object):
-    def __init__(self, device=None):
+    def __init__(self, device=None, sensitive=False):
+        self.sensitive = bool(sensitive)    # four seed shapes in the translated search (pep_set_sensitivity level 1); default: the reference's diamond call (level 0)
         self.qrySeq = self.refSeq = None
         self._q_key = self._r_key = None    # cache keys of the files the sequences came from (None: handed over by the caller)
         self.device = device
@@ -378,7 +379,7 @@ class RunBlast(object):
             while stop < len(refs) and (stop == start or tot + sizes[stop] <= self.MAX_BATCH_NT):
                 tot += sizes[stop]
                 stop += 1
-            sub = RunBlast(self.device) if (start, stop) != (0, len(refs)) else self
+            sub = RunBlast(self.device, sensitive=self.sensitive) if (start, stop) != (0, len(refs)) else self
             sub._as_tables = self._as_tables
             out += sub._run_one_batch(refs[start:stop], qry, methods, min_id, min_cov, min_ratio, table_id, n_thread, useProcess, re_score,
                                       filter, linear_merge, return_overlap, fix_end)
@@ -476,7 +477,7 @@ class RunBlast(object):
         ctx = get_context(self.device)
         self._ensure_nt(ctx, 6 if frames == '7' else 3)
         params = N.default_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100., top_k=nhits, n_splits=5,
-                                  dbsize=5000000., max_evalue=1., sensitive=os.environ.get('PEPPAN_HIP_SENSITIVE') == '1')
+                                  dbsize=5000000., max_evalue=1., sensitive=self.sensitive)
         ctx.translate()                                                # (K1; a nucleotide search before this one left base codes in the packed sets)
         hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
         table = hits_to_table(hits, cigar, ctx.query_meta(), ctx.target_meta(), self._q_tab, self._r_tab, self._q_len, self._r_len,
@@ -646,6 +647,8 @@ _TOOL_FLAGS = (
     (('--diamond',), dict(action='store_true', default=False, help='run the translated search (6 reference frames, BLOSUM62) on the GPU')),
     (('--diamondSELF',), dict(action='store_true', default=False, help='translated search against the 3 forward frames only, 200 targets per query')),
     (('--gpu',), dict(action='store_true', default=False, help='same as --diamond')),
+    (('--sensitive',), dict(action='store_true', default=False, help='translated search with four seed shapes instead of two (not a flag of the reference: recall between 0.45 and 0.7 '
+                                                                      'identity 0.93 -> 0.985 at twice the seed-stage cost; the default matches the reference\'s diamond call, which runs at default sensitivity)')),
 )
 _SEARCH_FLAGS = (
     (('--gtable',), dict(type=int, default=11, help='translation table: 11 (bacteria) or 4 (Mycoplasma, TGA codes W) [11]')),
@@ -697,7 +700,7 @@ def uberBlast(args, extPool=None, as_table=False):
     callers inside this package that work on the columns (pipeline.get_similar_pairs)."""
     a = _parser('Similarity search of query sequences against a reference on an MI355X; table format of PEPPAN uberBlast.', True).parse_args(args)
     methods, kw = _run_arguments(a)
-    rb = RunBlast(a.device)
+    rb = RunBlast(a.device, sensitive=a.sensitive)
     rb._as_tables = bool(as_table)
     data = rb.run(a.reference, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread,
                   extPool if extPool is not None else a.process, **kw)
@@ -722,7 +725,7 @@ def uberBlastBatch(references, args, device=None, as_tables=False):
     mapbsn.build_bsn that work on the columns."""
     a = _parser('uberBlast over many reference files with one search per tool.', False).parse_args(args)
     methods, kw = _run_arguments(a)
-    rb = RunBlast(device)
+    rb = RunBlast(device, sensitive=a.sensitive)
     rb._as_tables = bool(as_tables)
     return rb.run_batch(references, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread, a.process, **kw)
 

@@ -48,7 +48,7 @@ def protein_sets(nt_seqs, table=11):
     return q_aa, t_aa, np.array(t_gene)
 
 
-def report(q_seqs, t_seqs, params, min_scores, q_idx=None, threads=0):
+def report(q_seqs, t_seqs, params, min_scores, q_idx=None, threads=0, sensitive_shapes=None):
     """q_seqs / t_seqs: residue-code arrays; params: oracle Params with the cuts set; q_idx: the queries to evaluate (all targets
     are always searched).  Returns a dict of counts (see module docstring)."""
     from oracle import oracle as O, full_sw as F
@@ -69,6 +69,14 @@ def report(q_seqs, t_seqs, params, min_scores, q_idx=None, threads=0):
         key = (int(h['q'][k]), int(h['t'][k]))
         if key not in found or h['score'][k] > found[key]:
             found[key] = int(h['score'][k])
+    # the SENSITIVE mode of the translated search (four seed shapes instead of two: pep_set_sensitivity level 1), same cuts
+    found_s, st_s = None, None
+    if getattr(params, 'base', 0) != 4 and sensitive_shapes:
+        from peppan_amd import _native as N
+        ps = copy.copy(p)
+        N.set_shapes(ps, list(sensitive_shapes))
+        hs, _, st_s = O.search(qs, t_seqs, ps, min_scores=ms)
+        found_s = set(zip(hs['q'].tolist(), hs['t'].tolist()))
     # the same without the ungapped pre-filter: separates what seeding loses from what the filter loses
     p0 = copy.copy(p)
     p0.ungapped_min = 0
@@ -94,6 +102,8 @@ def report(q_seqs, t_seqs, params, min_scores, q_idx=None, threads=0):
             truth.add(key)
             b = out['bins'][_bin_of(ident)]
             b['truth'] += 1
+            if found_s is not None and key in found_s:
+                b['found_sensitive'] = b.get('found_sensitive', 0) + 1
             if key in found:
                 b['found'] += 1
             else:
@@ -106,6 +116,12 @@ def report(q_seqs, t_seqs, params, min_scores, q_idx=None, threads=0):
     out['reported_not_in_truth'] = sum(1 for k in found if k not in truth)   # e.g. a band-limited alignment that passes a cut its full version fails
     for b in out['bins'].values():
         b['recall'] = round(b['found'] / b['truth'], 4) if b['truth'] else None
+        if found_s is not None:
+            b['found_sensitive'] = b.get('found_sensitive', 0)
+            b['recall_sensitive'] = round(b['found_sensitive'] / b['truth'], 4) if b['truth'] else None
+    if found_s is not None:
+        out['sensitive'] = dict(shapes=list(sensitive_shapes), reported_pairs=len(found_s), candidates=st_s['candidates'], found_of_truth=sum(1 for k in truth if k in found_s),
+                                recall=round(sum(1 for k in truth if k in found_s) / max(1, len(truth)), 4))
     out['recall'] = round(out['found_of_truth'] / max(1, len(truth)), 4)
     out['missed_examples(ident,score,min_score,Lq,Lt,cols)'] = sorted(missed, reverse=True)[:8]
     return out
@@ -156,6 +172,7 @@ def workload(name):
 if __name__ == '__main__':
     for w in sys.argv[1:] or ['protein1k_sample']:
         q, t, p, ms, q_idx, desc = workload(w)
-        r = report(q, t, p, ms, q_idx)
+        from peppan_amd import _native as N
+        r = report(q, t, p, ms, q_idx, sensitive_shapes=N.DEFAULT_SHAPES + N.SENSITIVE_SHAPES)
         r['workload'] = desc
         print(json.dumps(r))

@@ -33,15 +33,27 @@ def _cmp_tables(a, b):
 def test_map_bsn_10k_exemplars_x_genomes(tmp_path, monkeypatch, n_genomes):
     """BASELINE configs[2] mapping stage: 10 000 exemplars against 64 genomes, and at the configuration's FULL size - 500 genomes, 1.07 Gnt -
     through get_map_bsn; every planted allele found, stores consistent, sampled genomes equal to the oracle-driven host code row for row"""
+    _map_bsn_at_size(tmp_path, monkeypatch, 10000, 0, n_genomes, None, (3, 40), 1500)
+
+
+def test_map_bsn_50k_exemplars_x_32_genomes(tmp_path, monkeypatch):
+    """BASELINE configs[4] mapping stage at the size one GPU holds: 50 000 exemplar genes (log-normal lengths, 45 Mnt) against 32 genomes of a
+    50 000-gene pan-genome (about 6 500 genes / 7 Mb per genome: synth.PAN_GENOME_PRESENCE) through get_map_bsn (PEPPAN.py:759-772, 907-989);
+    every planted allele found, stores consistent, one sampled genome equal to the oracle-driven host code row for row"""
+    from peppan_amd import synth
+    # (identity floor 0.90 here: with 210 000 planted alleles a 147-base gene now and then collects eight substitutions at the nominal 2 %)
+    _map_bsn_at_size(tmp_path, monkeypatch, 50000, 0, 32, synth.PAN_GENOME_PRESENCE, (5,), 5000, min_iden4=9000)
+
+
+def _map_bsn_at_size(tmp_path, monkeypatch, n_genes, gene_len, n_genomes, presence, sample, planted_per_genome, min_iden4=9500):
     from peppan_amd import mapbsn, synth, uberBlast as UB
     from oracle_context import OracleContext
     monkeypatch.chdir(tmp_path)
-    sample = (3, 40)
-    names, seqs = synth.make_genes(10000, 0, seed=355)
+    names, seqs = synth.make_genes(n_genes, gene_len, seed=355)
     with open('m.clust.exemplar', 'w') as f:
         for i, s in enumerate(seqs):
             f.write('>%d\n%s\n' % (i, s.decode()))
-    worlds = synth.make_genomes(seqs, n_genomes, seed=355)
+    worlds = synth.make_genomes(seqs, n_genomes, seed=355, presence=presence)
     genomes = {}
     with mapbsn.MapBsn('m.old_prediction.npz', 'w') as op:
         for g, (gname, contig, ann) in enumerate(worlds):
@@ -71,13 +83,13 @@ def test_map_bsn_10k_exemplars_x_genomes(tmp_path, monkeypatch, n_genomes):
     # one row per group, group ids dense, one hit-row block per group
     assert tab.shape[0] == n_mat and sorted(tab.T[5].tolist()) == list(range(tab.shape[0]))
     # every planted allele (<= 2 % substitutions, full length) is found in its genome with identity >= 0.95
-    found = {(int(r[0]), int(r[1])) for r in tab if r[3] >= 9500}
+    found = {(int(r[0]), int(r[1])) for r in tab if r[3] >= min_iden4}
     planted = 0
     for g, (gname, contig, ann) in enumerate(worlds):
         for k, s, e, strand in ann:
             planted += 1
             assert (k, 900000 + g) in found, (g, k)
-    assert planted > n_genomes * 1500
+    assert planted > n_genomes * planted_per_genome
     # the sampled genomes: whole tables equal to the same host code over the CPU oracle (one uberBlast call per genome)
     octx = OracleContext()
     monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
@@ -88,14 +100,19 @@ def test_map_bsn_10k_exemplars_x_genomes(tmp_path, monkeypatch, n_genomes):
             o_tab, o_ovl = UB.uberBlast(['-r', gfile] + mapbsn._map_argv('m.clust.exemplar', params))
         _cmp_tables(seen[id][0], o_tab)
         assert seen[id][1].tolist() == o_ovl.tolist()
-        assert o_tab.shape[0] > 5000
+        assert o_tab.shape[0] > 3 * planted_per_genome
 
 
-@pytest.mark.parametrize('n_base,copies', [(4000, 250), (10000, 500)])
+@pytest.mark.parametrize('n_base,copies', [(4000, 250), (10000, 500), (50000, 400)])
 def test_front_end_gene_instances_at_size(ctx, tmp_path, monkeypatch, n_base, copies):
-    """writeGenes (K13 sha1 + duplicate collapse) and the 11-level iterClust (K9) on 1 M instances of 4 000 genes, and at BASELINE
-    configs[2]'s full size: 5 M instances of 10 000 genes (10 000 genes x 500 genomes, 4.45 Gnt)"""
+    """writeGenes (K13 sha1 + duplicate collapse) and the 11-level iterClust (K9) on 1 M instances of 4 000 genes, at BASELINE
+    configs[2]'s full size - 5 M instances of 10 000 genes (10 000 genes x 500 genomes, 4.45 Gnt) - and on 20 M instances of 50 000 genes
+    (18 Gnt: a fifth of configs[4]'s 100 M, what one host of this pool holds comfortably; PEPPAN.py:1023-1039, 1777-1792)"""
     from peppan_amd import pipeline as PL
+    if n_base * copies > 5000000:
+        import psutil
+        if psutil.virtual_memory().available < 100e9:
+            pytest.skip('20 M gene instances need about 40 GB of host memory; %.0f GB available' % (psutil.virtual_memory().available / 1e9))
     monkeypatch.chdir(tmp_path)
     t0 = time.perf_counter()
     from peppan_amd import synth
