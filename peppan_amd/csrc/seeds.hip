@@ -424,77 +424,8 @@ __device__ __forceinline__ bool set_contains(const JoinArgs &a, uint64_t k)
     return false;
 }
 
-// ungapped x-drop score of the diagonal through a seed hit, on PACKED positions: the >= 16 padding bytes around every
-// sequence score -64, which ends an extension exactly where the sequence ends (x-drop < 64), so no bounds are needed
-// Returns as soon as the threshold is reached (only the outcome score >= ungapped_min is used).  The windows are fetched with
-// unaligned 16-byte loads, a piece at a time; the loops are fully unrolled so that the windows stay in registers.
-__device__ __forceinline__ bool ungapped_pass(const JoinArgs &a, const int8_t *sub, uint32_t qp, uint64_t tp)
-{
-    // seed_extend is bound by the NUMBER of these scattered fetches, and most of what arrives here once the gene set is large is a chance
-    // hit of the reduced alphabet.  Stage 1 (pep_search_params.stage1_min; oracle: ungapped_score) therefore looks at the first 16
-    // residues to the right only - two fetches: the seed and a few residues behind it; a hit whose extension has not reached stage1_min
-    // by then is dropped.  Only the survivors fetch the second piece to the right and the first to the left (four more fetches), the
-    // rest inside the wave-uniform blocks below, by the lanes that are still extending.
-    uint32_t qr[12], tr[12], ql[12], tl[12];
-    __builtin_memcpy(qr, a.q_res + qp, 16);
-    __builtin_memcpy(tr, a.t_res + tp, 16);
-    int s = 0, br = 0, bl = 0;
-    bool live = true, pass = false;
-    // Straight-line predicated code costs its full length as long as ONE lane of the wave is still extending; most extensions
-    // end within a dozen residues (x-drop on a chance hit, threshold reached on a true one), so the wave checks every 8
-    // residues whether anybody is left and skips the rest of the window otherwise.
-#pragma unroll
-    for (int blk8 = 0; blk8 < 6; ++blk8) {
-        if (blk8 == 2) {
-            if (pass) return true;
-            if (br < a.stage1_min) return false;                      // stage 1 (an extension that ended earlier is judged by what it reached)
-            if (live && 16 < a.ext_right) {                           // residues 16..31: second piece of the right windows
-                __builtin_memcpy(qr + 4, a.q_res + qp + 16, 16);
-                __builtin_memcpy(tr + 4, a.t_res + tp + 16, 16);
-            }
-            __builtin_memcpy(ql + 8, a.q_res + qp - 16, 16);          // first piece of the left windows
-            __builtin_memcpy(tl + 8, a.t_res + tp - 16, 16);
-        }
-        if (__ballot(live && blk8 * 8 < a.ext_right)) {
-            if (blk8 == 4 && live && 32 < a.ext_right) {             // residues 32..47: third piece of the right windows
-                __builtin_memcpy(qr + 8, a.q_res + qp + 32, 16);
-                __builtin_memcpy(tr + 8, a.t_res + tp + 32, 16);
-            }
-#pragma unroll
-            for (int k = blk8 * 8; k < blk8 * 8 + 8; ++k) {
-                if (live && k < a.ext_right) {
-                    const int qc = (qr[k >> 2] >> ((k & 3) * 8)) & 31, tc = (tr[k >> 2] >> ((k & 3) * 8)) & 31;
-                    s += sub[qc * 32 + tc];
-                    if (s > br) { br = s; if (br >= a.ungapped_min) { pass = true; live = false; } }
-                    else if (br - s > a.xdrop) live = false;
-                }
-            }
-        }
-    }
-    if (pass) return true;
-    s = 0; live = true;
-#pragma unroll
-    for (int blk8 = 0; blk8 < 6; ++blk8) {
-        if (__ballot(live && blk8 * 8 + 1 <= a.ext_left)) {
-            if ((blk8 == 2 || blk8 == 4) && live && blk8 * 8 + 1 <= a.ext_left) {      // residues 17..32 / 33..48 to the left: the next piece down
-                const int w = blk8 == 2 ? 4 : 0;
-                __builtin_memcpy(ql + w, a.q_res + qp - 48 + 4 * w, 16);
-                __builtin_memcpy(tl + w, a.t_res + tp - 48 + 4 * w, 16);
-            }
-#pragma unroll
-            for (int k = blk8 * 8 + 1; k <= blk8 * 8 + 8; ++k) {
-                if (live && k <= a.ext_left) {
-                    const int b = 48 - k;                    // byte index inside the left window
-                    const int qc = (ql[b >> 2] >> ((b & 3) * 8)) & 31, tc = (tl[b >> 2] >> ((b & 3) * 8)) & 31;
-                    s += sub[qc * 32 + tc];
-                    if (s > bl) { bl = s; if (br + bl >= a.ungapped_min) { pass = true; live = false; } }
-                    else if (bl - s > a.xdrop) live = false;
-                }
-            }
-        }
-    }
-    return pass;
-}
+// (the ungapped x-drop extension itself - BLOSUM62 along the diagonal through a seed hit, on PACKED positions: the >= 16 padding bytes around every
+// sequence score -64, which ends an extension exactly where the sequence ends (x-drop < 64), so no bounds are needed - lives in seed_extend below)
 
 // Phase 1 of the join (persistent, grid-stride over 256-position tiles): target seed keys are looked up in the
 // query index and every equal-key pair is appended as a raw seed hit (qpos << 32 | tpos).  Hits are staged in an
@@ -671,31 +602,118 @@ __global__ __launch_bounds__(256) void seed_runs(JoinArgs a, uint64_t *__restric
     }
 }
 
-// Phase 2b: one thread per run, every lane busy with a different candidate.  A candidate needs ONE hit whose ungapped x-drop
-// extension reaches the threshold: the hits of the run are tried in order until one passes (true homologues pass at the first or
-// second, chance runs are one or two hits long); the first passer inserts the key.  The set is order-independent, so the result
-// does not depend on scheduling.
+// Phase 2b: the ungapped x-drop extensions.  A candidate needs ONE hit whose extension reaches the threshold: the hits of a run are tried in
+// order until one passes (true homologues pass at the first or second, chance runs are one or two hits long); the first passer inserts the
+// key.  The set is order-independent, so the result does not depend on scheduling.
+//
+// Execution (round 4): every lane holds one extension in flight and every ROUND of the wavefront advances all of them by one block of eight
+// residues, whichever side and block each is in - the window piece of the block is fetched for it (8 bytes per sequence; the lines are the
+// ones the blocks before touched).  A lane whose extension is decided takes the next run of its block's share of the run list in the same
+// round.  Before, a thread walked its run through 96 unrolled, predicated residues: as long as ONE lane of a wavefront was still extending,
+// all of it was issued - 1 100 scalar and 650 vector instructions per wavefront and run list slice (SQ_INSTS_SALU 44.6 M against
+// SQ_INSTS_VALU 26.2 M per launch at 10 k genes: the one scalar unit of a CU was what the kernel waited for), most of them for the one or
+// two lanes whose extension went beyond its first sixteen residues.
+struct XDrop { int s, best, live, pass; };      // live / pass: 0 or 1
+// one residue pair, for every lane and without a branch: the state of a lane that is not extending (on = 0) does not change.
+//   s = running score, best = its maximum so far, base = what the other side of the seed has secured (0 on the right side)
+//   pass: base + best reached the threshold;  an extension ends when it passes or falls more than xdrop below its best
+__device__ __forceinline__ void xdrop_step(XDrop &x, int sc, int on, int base, int thr, int xdrop)
+{
+    const int act = x.live & on;
+    const int s2 = x.s + sc;
+    const int up = s2 > x.best ? 1 : 0;
+    const int nb = up ? s2 : x.best;
+    const int p = up & (base + nb >= thr ? 1 : 0);
+    const int d = (up ^ 1) & (x.best - s2 > xdrop ? 1 : 0);
+    x.s = act ? s2 : x.s;
+    x.best = act ? nb : x.best;
+    x.pass |= act & p;
+    x.live &= (act & (p | d)) ^ 1;
+}
+
 __global__ __launch_bounds__(256) void seed_extend(JoinArgs a, const uint64_t *__restrict__ run_first, const uint32_t *__restrict__ run_len,
                                                    const uint64_t *__restrict__ run_key, const unsigned long long *__restrict__ n_runs)
 {
     __shared__ int8_t sub[1024];
     __shared__ uint32_t blk_pass;
+    __shared__ unsigned long long cursor;
     reinterpret_cast<uint32_t *>(sub)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.sub)[threadIdx.x];
-    if (threadIdx.x == 0) blk_pass = 0;
-    __syncthreads();
     const unsigned long long n = *n_runs;
+    // this block's share of the run list: a contiguous slice (neighbouring runs come from neighbouring target positions: their windows share lines)
+    const unsigned long long per = (n + gridDim.x - 1) / gridDim.x, c0 = min(n, per * blockIdx.x), c1 = min(n, c0 + per);
+    if (threadIdx.x == 0) { blk_pass = 0; cursor = c0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
     uint32_t n_pass = 0;
-    for (uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x; r < n; r += (uint64_t)gridDim.x * 256) {
-        const uint64_t ck = run_key[r];
-        const uint64_t first = run_first[r];
-        const uint32_t len = run_len[r];
-        if (len > 1 && set_contains(a, ck)) { ++n_pass; continue; }          // (single hits: the extension is cheaper than the probe it would save)
-        bool pass = a.ungapped_min <= 0;
-        for (uint32_t x = 0; x < len && !pass; ++x) {
-            const uint64_t hit = len == 1 ? first : a.hits[first + x];          // (seed_runs put the hit of a single-hit run into the run record)
-            pass = ungapped_pass(a, sub, (uint32_t)(hit >> 32), (uint32_t)hit);
+    // the extension a lane has in flight
+    int busy = 0, side = 0, k = 0, br = 0;
+    XDrop X = {0, 0, 0, 0};
+    uint64_t ck = 0, first = 0;
+    uint32_t len = 0, h = 0, qp = 0, tp = 0;
+    for (;;) {
+        // ---- idle lanes take the next runs of the slice (one LDS atomic per wavefront and round)
+        const unsigned long long idle = __ballot(!busy);
+        if (idle) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&cursor, (unsigned long long)__popcll(idle));
+            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            const unsigned long long r = base + (unsigned long long)__popcll(idle & ((1ull << lane) - 1ull));
+            if (!busy && r < c1) {
+                ck = run_key[r]; first = run_first[r]; len = run_len[r];
+                if (len > 1 && set_contains(a, ck)) ++n_pass;                 // established already (single hits: the extension is cheaper than the probe it would save)
+                else if (a.ungapped_min <= 0) { ++n_pass; set_insert(a, ck); }
+                else {
+                    const uint64_t hit = len == 1 ? first : a.hits[first];    // (seed_runs put the hit of a single-hit run into the run record)
+                    qp = (uint32_t)(hit >> 32); tp = (uint32_t)hit; h = 0;
+                    busy = 1; side = 0; k = 0; X = XDrop{0, 0, 1, 0};
+                }
+            }
+            if (!__ballot(busy) && base >= c1) break;                         // nothing in flight and nothing left to take (runs that turn out to be
+                                                                              // established leave a lane idle: the next round takes more)
         }
-        if (pass) { ++n_pass; set_insert(a, ck); }
+        // ---- one block of XB residues for every extension in flight: right side block k = residues XB k .. XB k + XB - 1 from the seed start,
+        // left side block k = residues XB k + 1 .. XB k + XB before it (read from the seed outwards).  XB = 16: the first block IS stage 1.
+        constexpr int XB = 16;
+        uint32_t qw[XB / 4], tw[XB / 4];
+#pragma unroll
+        for (int w = 0; w < XB / 4; ++w) qw[w] = tw[w] = 0;
+        if (busy) {
+            const int off = side ? -XB * (k + 1) : XB * k;
+            __builtin_memcpy(qw, a.q_res + (int64_t)qp + off, XB);
+            __builtin_memcpy(tw, a.t_res + (int64_t)tp + off, XB);
+            if (side) {                                                        // left side: nearest residue first
+                uint32_t q[XB / 4], t[XB / 4];
+#pragma unroll
+                for (int w = 0; w < XB / 4; ++w) { q[w] = __builtin_bswap32(qw[XB / 4 - 1 - w]); t[w] = __builtin_bswap32(tw[XB / 4 - 1 - w]); }
+#pragma unroll
+                for (int w = 0; w < XB / 4; ++w) { qw[w] = q[w]; tw[w] = t[w]; }
+            }
+        }
+        const int r0 = side ? XB * k + 1 : XB * k, lim = side ? a.ext_left + 1 : a.ext_right, base_score = side ? br : 0;
+#pragma unroll
+        for (int j = 0; j < XB; ++j) {
+            const int qc = (int)((qw[j >> 2] >> ((j & 3) * 8)) & 31u), tc = (int)((tw[j >> 2] >> ((j & 3) * 8)) & 31u);
+            xdrop_step(X, sub[qc * 32 + tc], busy & (r0 + j < lim ? 1 : 0), base_score, a.ungapped_min, a.xdrop);
+        }
+        // ---- where the extension stands after the block
+        if (busy) {
+            ++k;
+            bool next_hit = false;
+            if (X.pass) { ++n_pass; set_insert(a, ck); busy = 0; }
+            else if (side == 0) {
+                // stage 1: after sixteen residues to the right (or wherever the extension ended before) it must have reached stage1_min
+                const bool over = !X.live || XB * k >= a.ext_right;
+                if (k == 1 && X.best < a.stage1_min) next_hit = true;
+                else if (over) { side = 1; k = 0; br = X.best; X = XDrop{0, 0, 1, 0}; }
+            } else if (!X.live || XB * k + 1 > a.ext_left) next_hit = true;
+            if (next_hit) {
+                if (++h < len) {
+                    const uint64_t hit = a.hits[first + h];
+                    qp = (uint32_t)(hit >> 32); tp = (uint32_t)hit;
+                    side = 0; k = 0; X = XDrop{0, 0, 1, 0};
+                } else busy = 0;
+            }
+        }
     }
     for (int d = 32; d > 0; d >>= 1) n_pass += __shfl_down(n_pass, d, 64);
     if ((threadIdx.x & 63) == 0) atomicAdd(&blk_pass, n_pass);
