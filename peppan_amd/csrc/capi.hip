@@ -175,11 +175,12 @@ void pep_materialise_staged(pep_ctx *ctx)
 // block -> (sequence, start of the sequence) map of a packed set (host build from the offsets, then upload)
 int pep_upload_blk2seq(pep_ctx *ctx, SeqSet &s)
 {
-    const uint64_t nblk = s.total / 16 + 1;
+    const uint64_t nblk = s.total / 32 + 2;
     std::vector<uint2> m(nblk, make_uint2(0u, 0u));
     for (uint32_t i = 0; i < s.n; ++i) {
-        const uint64_t b0 = s.h_off[i] / 16, b1 = ((uint64_t)s.h_off[i] + s.h_len[i] + 15) / 16;
-        for (uint64_t b = b0; b < b1 && b < nblk; ++b) m[b] = make_uint2(i, s.h_off[i]);
+        if (s.h_len[i] == 0) continue;
+        const uint64_t b0 = s.h_off[i] / 32, b1 = ((uint64_t)s.h_off[i] + s.h_len[i] - 1) / 32;          // the 32-byte blocks that hold residues of sequence i
+        for (uint64_t b = b0; b <= b1 && b < nblk; ++b) m[b] = make_uint2(i, s.h_off[i]);
     }
     PEP_TRY(dev_reserve(ctx, s.blk2seq, nblk * sizeof(uint2)));
     PEP_HIP(ctx, hipMemcpy(s.blk2seq.p, m.data(), nblk * sizeof(uint2), hipMemcpyHostToDevice));

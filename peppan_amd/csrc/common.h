@@ -47,7 +47,7 @@ struct SeqSet {
     DevBuf res;                  // u8
     DevBuf off;                  // u32[n+1]  (off[n] = total, sentinel for binary search)
     DevBuf len;                  // u32[n]
-    DevBuf blk2seq;              // uint2[total/16]: (sequence owning each 16-byte block, start of that sequence) - starts are 16-aligned, gaps >= 16; one look-up
+    DevBuf blk2seq;              // uint2[total/32]: (sequence whose residues a 32-byte block holds, start of that sequence) - starts are 16-aligned, gaps >= 16, so never two; one look-up
                                  // turns a packed position into (sequence, position inside it)
     // host mirrors
     std::vector<uint32_t> h_off, h_len;

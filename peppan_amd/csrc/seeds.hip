@@ -376,7 +376,8 @@ struct JoinArgs {
     uint32_t nt;
     const uint32_t *q_off;
     uint32_t nq;
-    const uint2 *q_blk2seq, *t_blk2seq;      // (sequence, its start) per 16-byte block of the packed sets
+    const uint2 *q_blk2seq, *t_blk2seq;      // (sequence, its start) per 32-byte block of the packed sets (half the table of round 3: 4.2 MiB instead of 8.4 at 50 000 genes -
+                                             // seed_runs is bound by the misses of exactly this look-up, profiles/r04_seed_counters_50k.txt)
     const uint32_t *start;
     const uint64_t *entries;
     const unsigned long long *filter;     // filter_mask(): two bits per key in one 64-bit word (2 MiB for 2^23 buckets: stays in L2, unlike start[])
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(256) void seed_runs(JoinArgs a, uint64_t *__restric
             ck[u] = ~0ull;
             if (valid[u]) {
                 const uint32_t qp = (uint32_t)(hit[u] >> 32), p = (uint32_t)hit[u];
-                const uint2 tb = a.t_blk2seq[p >> 4], qb = a.q_blk2seq[qp >> 4];          // one look-up per side (sequence and its start together: not two dependent ones)
+                const uint2 tb = a.t_blk2seq[p >> 5], qb = a.q_blk2seq[qp >> 5];          // one look-up per side (sequence and its start together: not two dependent ones)
                 const int32_t diag = (int32_t)(p - tb.y) - (int32_t)(qp - qb.y);
                 const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
                 ck[u] = ((uint64_t)qb.x << 43) | ((uint64_t)tb.x << 18) | (uint64_t)bin;

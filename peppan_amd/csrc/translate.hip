@@ -322,7 +322,9 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
         }
         __builtin_amdgcn_wave_barrier();                                 // the next chunk overwrites the staging area
     }
-    for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = make_uint2(s, start);
+    // (sequence, start) per 32-byte block that holds residues of this sequence: [start, next - 16) - the gap in front of `next` is at least 16 bytes of
+    // padding, so a block never holds residues of two sequences; the block that `next` starts in the middle of belongs to the next sequence
+    for (uint32_t b = (start >> 5) + lane, last = ((next & 31u) == 16u) ? ((next - 16u) >> 5) - 1u : (next - 17u) >> 5; b <= last && last != ~0u; b += 64) blk2seq[b] = make_uint2(s, start);
 }
 
 // ---- nucleotide sets as residue sets (the blastn-equivalent tool, uberBlast.py:294, 482-509): base codes A0 C1 G2 T3, anything else 4;
@@ -361,7 +363,9 @@ __global__ __launch_bounds__(256) void nucl_pack(const uint8_t *__restrict__ nt,
         }
         *reinterpret_cast<uint2 *>(res + start + x0) = make_uint2(word[0], word[1]);                 // starts and paddings are multiples of 16: whole words
     }
-    for (uint32_t b = (start >> 4) + lane; b < (next >> 4); b += 64) blk2seq[b] = make_uint2(s, start);
+    // (sequence, start) per 32-byte block that holds residues of this sequence: [start, next - 16) - the gap in front of `next` is at least 16 bytes of
+    // padding, so a block never holds residues of two sequences; the block that `next` starts in the middle of belongs to the next sequence
+    for (uint32_t b = (start >> 5) + lane, last = ((next & 31u) == 16u) ? ((next - 16u) >> 5) - 1u : (next - 17u) >> 5; b <= last && last != ~0u; b += 64) blk2seq[b] = make_uint2(s, start);
 }
 
 void fill_codon_table(uint8_t tab[2][64])
@@ -476,7 +480,7 @@ int reserve_packed(pep_ctx *ctx, SeqSet &out, uint32_t cap, uint64_t upper)
     PEP_TRY(dev_reserve(ctx, out.res, upper + 64));
     PEP_TRY(dev_reserve(ctx, out.off, ((size_t)cap + 2) * 4));
     PEP_TRY(dev_reserve(ctx, out.len, ((size_t)cap + 2) * 4));
-    PEP_TRY(dev_reserve(ctx, out.blk2seq, (upper / 16 + 2) * sizeof(uint2)));
+    PEP_TRY(dev_reserve(ctx, out.blk2seq, (upper / 32 + 2) * sizeof(uint2)));
     return PEP_OK;
 }
 
@@ -704,7 +708,7 @@ static int nucl_build(pep_ctx *ctx, const NtSet &nt, const std::vector<NuclDesc>
     PEP_TRY(dev_reserve(ctx, out.res, pos + 64));
     PEP_TRY(dev_reserve(ctx, out.off, ((size_t)n + 2) * 4));
     PEP_TRY(dev_reserve(ctx, out.len, ((size_t)n + 2) * 4));
-    PEP_TRY(dev_reserve(ctx, out.blk2seq, (pos / 16 + 2) * sizeof(uint2)));
+    PEP_TRY(dev_reserve(ctx, out.blk2seq, (pos / 32 + 2) * sizeof(uint2)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[2], ((size_t)n + 1) * sizeof(NuclDesc)));
     PEP_HIP(ctx, hipMemcpyAsync(out.off.p, out.h_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     if (n) PEP_HIP(ctx, hipMemcpyAsync(out.len.p, out.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
