@@ -10,9 +10,10 @@
 //  seed_match             : persistent blocks stream the packed target bytes tile by tile; every position that passes the
 //                           filter compares its key with the bucket's entries; equal keys are raw seed hits
 //                           (qpos << 32 | tpos), staged in LDS and flushed with one global atomic per ~1.5 k hits.
-//  seed_runs / seed_extend: neighbouring hits of one diagonal share their candidate key q:21 | t:25 | bin:18; seed_runs turns
-//                           the raw hits into runs of equal keys (one per wave and key), seed_extend takes one run per thread:
-//                           already in the device hash set, or ungapped x-drop extension of its hits until one passes -> insert.
+//  seed_runs_extend       : neighbouring hits of one diagonal share their candidate key q:21 | t:25 | bin:18; every wavefront turns its
+//                           slice of the raw hits into runs of equal keys and works them off: already in the device hash set, or
+//                           ungapped x-drop extension of the run's hits until one passes -> insert.  All lanes advance their own
+//                           extension by sixteen residues per round (no per-residue branching, no runs in global memory).
 //  The candidate set is compacted and radix-sorted (sort.hip) so every later stage is order-deterministic.
 #include "common.h"
 #include <cstring>
@@ -510,110 +511,23 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
     if (threadIdx.x < 2 && blk_stats[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)blk_stats[threadIdx.x]);
 }
 
-// Phase 2a: one thread per raw seed hit, fully converged.  (q, t, diagonal bin) from the block->sequence maps.  Neighbouring hits
-// of the buffer usually come from neighbouring positions of one diagonal, i.e. they nominate the same candidate: every run of
-// equal candidate keys inside a wavefront becomes ONE work item (first hit, length, key) unless the candidate is in the set already.
-// No extension here: in the first version the extension code ran in this loop with one to three active lanes per wavefront
-// (the leaders of new runs) and cost its full instruction stream each time - 0.27 ms per shape, 53 % scalar-unit utilisation.
-constexpr int RUN_BUF = 1024;       // >= RUN_BUF / 2 + 256 * RUN_UNROLL entries (seed_runs)
-__global__ __launch_bounds__(256) void seed_runs(JoinArgs a, uint64_t *__restrict__ run_first, uint32_t *__restrict__ run_len, uint64_t *__restrict__ run_key,
-                                                 unsigned long long *__restrict__ n_runs)
-{
-    // work items are staged in LDS and appended with ONE global atomic per flush: a single counter word sustains only ~90
-    // atomics/us, and one atomic per wavefront and round (90 k per launch) made this kernel take a millisecond
-    __shared__ uint64_t s_first[RUN_BUF], s_key[RUN_BUF];
-    __shared__ uint32_t s_len[RUN_BUF];
-    __shared__ uint32_t s_n;
-    __shared__ unsigned long long s_base;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    unsigned long long n_hits = *a.hit_count;
-    if (n_hits > a.hit_cap) n_hits = a.hit_cap;
-    const int lane = threadIdx.x & 63;
-    // RUN_UNROLL rounds of 256 hits per trip: the loads of a round (hit, two block look-ups, up to two probes of the set) are a chain of
-    // dependent latencies and a trip ends in a barrier - with one round per trip a block spent ~7 us per 256 hits waiting for them one
-    // after the other; the rounds of a trip are independent, so their chains overlap
-    constexpr int RUN_UNROLL = 2;
-    const uint64_t stride = (uint64_t)gridDim.x * 256 * RUN_UNROLL;
-    for (uint64_t b0 = (uint64_t)blockIdx.x * 256 * RUN_UNROLL; b0 < n_hits; b0 += stride) {      // block-uniform trip count
-        uint64_t hh[RUN_UNROLL], ck[RUN_UNROLL];
-        bool valid[RUN_UNROLL];
-#pragma unroll
-        for (int u = 0; u < RUN_UNROLL; ++u) {
-            hh[u] = b0 + (uint64_t)u * 256 + threadIdx.x;
-            valid[u] = hh[u] < n_hits;
-        }
-        uint64_t hit[RUN_UNROLL];
-#pragma unroll
-        for (int u = 0; u < RUN_UNROLL; ++u) hit[u] = valid[u] ? a.hits[hh[u]] : 0ull;
-#pragma unroll
-        for (int u = 0; u < RUN_UNROLL; ++u) {
-            ck[u] = ~0ull;
-            if (valid[u]) {
-                const uint32_t qp = (uint32_t)(hit[u] >> 32), p = (uint32_t)hit[u];
-                const uint2 tb = a.t_blk2seq[p >> 5], qb = a.q_blk2seq[qp >> 5];          // one look-up per side (sequence and its start together: not two dependent ones)
-                const int32_t diag = (int32_t)(p - tb.y) - (int32_t)(qp - qb.y);
-                const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
-                ck[u] = ((uint64_t)qb.x << 43) | ((uint64_t)tb.x << 18) | (uint64_t)bin;
-            }
-        }
-        bool leader[RUN_UNROLL], need_probe[RUN_UNROLL];
-        int run_len_u[RUN_UNROLL];
-#pragma unroll
-        for (int u = 0; u < RUN_UNROLL; ++u) {
-            const uint32_t lo = (uint32_t)ck[u], hi = (uint32_t)(ck[u] >> 32);
-            const uint32_t lo_prev = __shfl_up(lo, 1, 64), hi_prev = __shfl_up(hi, 1, 64);     // unconditional: every lane must take part in the shuffles
-            leader[u] = valid[u] && !(a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi);
-            const unsigned long long leaders = __ballot(leader[u]);
-            const unsigned long long valid_m = __ballot(valid[u]);
-            const unsigned long long above = lane == 63 ? 0ull : (leaders & (~0ull << (lane + 1)));          // next run starts at its lowest set bit
-            const int next = above ? __builtin_ctzll(above) : __popcll(valid_m);                              // valid lanes are a prefix
-            run_len_u[u] = next - lane;
-            need_probe[u] = leader[u] && run_len_u[u] > 1;
-        }
-        // a run of ONE hit is almost always a chance hit of the reduced alphabet whose candidate is in no set: it goes straight to the
-        // extension (which decides) instead of paying a scattered probe of the set here and another one there; longer runs - homologous
-        // diagonals - are dropped here when their candidate is established already (an earlier run, shape or launch)
-        bool emit_run[RUN_UNROLL];
-#pragma unroll
-        for (int u = 0; u < RUN_UNROLL; ++u) emit_run[u] = leader[u] && (!need_probe[u] || !set_contains(a, ck[u]));
-#pragma unroll
-        for (int u = 0; u < RUN_UNROLL; ++u) {
-            const unsigned long long emit_m = __ballot(emit_run[u]);
-            uint32_t off = 0;
-            if (lane == 0 && emit_m) off = atomicAdd(&s_n, (uint32_t)__popcll(emit_m));
-            off = (uint32_t)__shfl((int)off, 0, 64);
-            if (emit_run[u]) {
-                const uint32_t slot = off + (uint32_t)__popcll(emit_m & ((1ull << lane) - 1ull));       // < RUN_BUF: flushed above RUN_BUF / 2, <= 256 * RUN_UNROLL per trip
-                // (a run of one carries its hit itself - the extension then has no look-up into the hit buffer to do; longer runs the index of their first hit)
-                s_first[slot] = run_len_u[u] == 1 ? hit[u] : hh[u]; s_len[slot] = (uint32_t)run_len_u[u]; s_key[slot] = ck[u];
-            }
-        }
-        __syncthreads();
-        const uint32_t cnt = s_n;                    // block-uniform after the barrier
-        if (cnt > RUN_BUF / 2 || b0 + stride >= n_hits) {
-            if (threadIdx.x == 0) s_base = cnt ? atomicAdd(n_runs, (unsigned long long)cnt) : 0ull;
-            __syncthreads();
-            const unsigned long long g = s_base;
-            for (uint32_t x = threadIdx.x; x < cnt; x += 256) { run_first[g + x] = s_first[x]; run_len[g + x] = s_len[x]; run_key[g + x] = s_key[x]; }
-            __syncthreads();
-            if (threadIdx.x == 0) s_n = 0;
-            __syncthreads();
-        }
-    }
-}
-
-// Phase 2b: the ungapped x-drop extensions.  A candidate needs ONE hit whose extension reaches the threshold: the hits of a run are tried in
-// order until one passes (true homologues pass at the first or second, chance runs are one or two hits long); the first passer inserts the
-// key.  The set is order-independent, so the result does not depend on scheduling.
+// Phase 2: raw seed hits -> runs of one candidate -> ungapped x-drop extensions -> candidate set, in ONE kernel (round 4; seed_runs + seed_extend
+// before, with the runs written to and read back from global memory in between: 20 bytes per run, 2 GB per shape at 50 000 genes).
 //
-// Execution (round 4): every lane holds one extension in flight and every ROUND of the wavefront advances all of them by one block of eight
-// residues, whichever side and block each is in - the window piece of the block is fetched for it (8 bytes per sequence; the lines are the
-// ones the blocks before touched).  A lane whose extension is decided takes the next run of its block's share of the run list in the same
-// round.  Before, a thread walked its run through 96 unrolled, predicated residues: as long as ONE lane of a wavefront was still extending,
-// all of it was issued - 1 100 scalar and 650 vector instructions per wavefront and run list slice (SQ_INSTS_SALU 44.6 M against
-// SQ_INSTS_VALU 26.2 M per launch at 10 k genes: the one scalar unit of a CU was what the kernel waited for), most of them for the one or
-// two lanes whose extension went beyond its first sixteen residues.
+// Runs.  Neighbouring hits of the buffer usually come from neighbouring positions of one diagonal, i.e. they nominate the same candidate
+// (q, t, diagonal bin; q / t / the diagonal from the block -> sequence maps): every run of equal candidate keys inside a wavefront's 64 hits
+// is ONE work item.  A candidate needs one hit whose extension reaches the threshold: the hits of a run are tried in order until one passes
+// (true homologues pass at the first or second, chance runs are one or two hits long); the first passer inserts the key.  The set is
+// order-independent, so the result does not depend on scheduling.
+//
+// Execution.  Every wavefront works for itself - no block-level barrier anywhere.  It turns RUN_TRIP x 64 hits into runs, kept in its own
+// strip of LDS, and then advances extensions in ROUNDS: every lane holds one extension in flight and a round moves all of them on by one
+// block of sixteen residues, whichever side and block each is in (the piece of the two windows is fetched for it: 16 bytes per sequence; the
+// first block is stage 1).  A lane whose extension is decided takes the next run of the strip in the same round; when the strip is empty the
+// wavefront makes the next one while the extensions still in flight keep their state.  Before, a thread walked its run through 96 unrolled,
+// predicated residues: as long as ONE lane of a wavefront was extending all of it was issued - 1 100 scalar and 650 vector instructions
+// per wavefront and slice (SQ_INSTS_SALU 44.6 M against SQ_INSTS_VALU 26.2 M per launch at 10 k genes), most of them for the one or two
+// lanes whose extension went beyond its first sixteen residues.
 struct XDrop { int s, best, live, pass; };      // live / pass: 0 or 1
 // one residue pair, for every lane and without a branch: the state of a lane that is not extending (on = 0) does not change.
 //   s = running score, best = its maximum so far, base = what the other side of the seed has secured (0 on the right side)
@@ -632,19 +546,32 @@ __device__ __forceinline__ void xdrop_step(XDrop &x, int sc, int on, int base, i
     x.live &= (act & (p | d)) ^ 1;
 }
 
-__global__ __launch_bounds__(256) void seed_extend(JoinArgs a, const uint64_t *__restrict__ run_first, const uint32_t *__restrict__ run_len,
-                                                   const uint64_t *__restrict__ run_key, const unsigned long long *__restrict__ n_runs)
+constexpr int RUN_TRIP = 2;                     // rounds of 64 hits a wavefront turns into runs at a time (their look-up chains overlap)
+constexpr int RUN_STRIP = 64 * RUN_TRIP;        // runs a wavefront's strip holds (a run per hit at most)
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ __launch_bounds__(256) void seed_runs_extend(JoinArgs a)
 {
     __shared__ int8_t sub[1024];
     __shared__ uint32_t blk_pass;
-    __shared__ unsigned long long cursor;
+    __shared__ uint64_t s_first[4][RUN_STRIP], s_key[4][RUN_STRIP];
+    __shared__ uint32_t s_len[4][RUN_STRIP];
     reinterpret_cast<uint32_t *>(sub)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.sub)[threadIdx.x];
-    const unsigned long long n = *n_runs;
-    // this block's share of the run list: a contiguous slice (neighbouring runs come from neighbouring target positions: their windows share lines)
-    const unsigned long long per = (n + gridDim.x - 1) / gridDim.x, c0 = min(n, per * blockIdx.x), c1 = min(n, c0 + per);
-    if (threadIdx.x == 0) { blk_pass = 0; cursor = c0; }
+    if (threadIdx.x == 0) blk_pass = 0;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t *q_first = s_first[wave], *q_key = s_key[wave];
+    uint32_t *q_len = s_len[wave];
+    unsigned long long n_hits = *a.hit_count;
+    if (n_hits > a.hit_cap) n_hits = a.hit_cap;
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * RUN_TRIP;
+    uint64_t next_hits = ((uint64_t)blockIdx.x * 4 + wave) * 64 * RUN_TRIP;      // this wavefront's next slice of the hit buffer
+    uint32_t q_n = 0, q_take = 0;                                                // the strip: runs made, runs taken (wave-uniform)
     uint32_t n_pass = 0;
     // the extension a lane has in flight
     int busy = 0, side = 0, k = 0, br = 0;
@@ -652,28 +579,74 @@ __global__ __launch_bounds__(256) void seed_extend(JoinArgs a, const uint64_t *_
     uint64_t ck = 0, first = 0;
     uint32_t len = 0, h = 0, qp = 0, tp = 0;
     for (;;) {
-        // ---- idle lanes take the next runs of the slice (one LDS atomic per wavefront and round)
+        // ---- the strip is empty: the next RUN_TRIP x 64 hits become runs
+        if (q_take == q_n && next_hits < n_hits) {
+            wave_sync_lds();                                                     // (every lane has read what it took from the strip)
+            q_n = q_take = 0;
+            uint64_t hh[RUN_TRIP], key[RUN_TRIP], hit[RUN_TRIP];
+            bool valid[RUN_TRIP];
+#pragma unroll
+            for (int u = 0; u < RUN_TRIP; ++u) {
+                hh[u] = next_hits + (uint64_t)u * 64 + lane;
+                valid[u] = hh[u] < n_hits;
+                hit[u] = valid[u] ? a.hits[hh[u]] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < RUN_TRIP; ++u) {
+                key[u] = ~0ull;
+                if (valid[u]) {
+                    const uint32_t hq = (uint32_t)(hit[u] >> 32), p = (uint32_t)hit[u];
+                    const uint2 tb = a.t_blk2seq[p >> 5], qb = a.q_blk2seq[hq >> 5];          // one look-up per side (sequence and its start together: not two dependent ones)
+                    const int32_t diag = (int32_t)(p - tb.y) - (int32_t)(hq - qb.y);
+                    const uint32_t bin = (uint32_t)(diag + (1 << 23)) >> 6;
+                    key[u] = ((uint64_t)qb.x << 43) | ((uint64_t)tb.x << 18) | (uint64_t)bin;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RUN_TRIP; ++u) {
+                const uint32_t lo = (uint32_t)key[u], hi = (uint32_t)(key[u] >> 32);
+                const uint32_t lo_prev = __shfl_up(lo, 1, 64), hi_prev = __shfl_up(hi, 1, 64);     // unconditional: every lane must take part in the shuffles
+                const bool leader = valid[u] && !(a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi);
+                const unsigned long long leaders = __ballot(leader), valid_m = __ballot(valid[u]);
+                const unsigned long long above = lane == 63 ? 0ull : (leaders & (~0ull << (lane + 1)));          // the next run starts at its lowest set bit
+                const int nxt = above ? __builtin_ctzll(above) : __popcll(valid_m);                               // valid lanes are a prefix
+                if (leader) {
+                    const uint32_t slot = q_n + (uint32_t)__popcll(leaders & ((1ull << lane) - 1ull));
+                    // (a run of one carries its hit itself - no look-up into the hit buffer later; longer runs the index of their first hit)
+                    q_first[slot] = nxt - lane == 1 ? hit[u] : hh[u]; q_len[slot] = (uint32_t)(nxt - lane); q_key[slot] = key[u];
+                }
+                q_n += (uint32_t)__popcll(leaders);
+            }
+            next_hits += stride;
+            wave_sync_lds();
+        }
+        // ---- idle lanes take the next runs of the strip
         const unsigned long long idle = __ballot(!busy);
-        if (idle) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&cursor, (unsigned long long)__popcll(idle));
-            base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            const unsigned long long r = base + (unsigned long long)__popcll(idle & ((1ull << lane) - 1ull));
-            if (!busy && r < c1) {
-                ck = run_key[r]; first = run_first[r]; len = run_len[r];
-                if (len > 1 && set_contains(a, ck)) ++n_pass;                 // established already (single hits: the extension is cheaper than the probe it would save)
+        if (idle && q_take < q_n) {
+            const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), r = q_take + rank;
+            if (!busy && r < q_n) {
+                ck = q_key[r]; first = q_first[r]; len = q_len[r];
+                // a run of ONE hit is almost always a chance hit of the reduced alphabet whose candidate is in no set: it goes straight to the
+                // extension (which decides) instead of paying a scattered probe of the set; longer runs - homologous diagonals - are dropped
+                // when their candidate is established already (an earlier run, shape or launch)
+                if (len > 1 && set_contains(a, ck)) ++n_pass;
                 else if (a.ungapped_min <= 0) { ++n_pass; set_insert(a, ck); }
                 else {
-                    const uint64_t hit = len == 1 ? first : a.hits[first];    // (seed_runs put the hit of a single-hit run into the run record)
+                    const uint64_t hit = len == 1 ? first : a.hits[first];
                     qp = (uint32_t)(hit >> 32); tp = (uint32_t)hit; h = 0;
                     busy = 1; side = 0; k = 0; X = XDrop{0, 0, 1, 0};
                 }
             }
-            if (!__ballot(busy) && base >= c1) break;                         // nothing in flight and nothing left to take (runs that turn out to be
-                                                                              // established leave a lane idle: the next round takes more)
+            q_take = min(q_n, q_take + (uint32_t)__popcll(idle));
+        }
+        if (!__ballot(busy)) {
+            if (q_take == q_n && next_hits >= n_hits) break;                     // nothing in flight, nothing in the strip, no hits left
+            continue;
         }
         // ---- one block of XB residues for every extension in flight: right side block k = residues XB k .. XB k + XB - 1 from the seed start,
-        // left side block k = residues XB k + 1 .. XB k + XB before it (read from the seed outwards).  XB = 16: the first block IS stage 1.
+        // left side block k = residues XB k + 1 .. XB k + XB before it (read from the seed outwards).  XB = 16: the first block IS stage 1
+        // (pep_search_params.stage1_min; oracle: ungapped_score).  Padding bytes (>= 16 around every sequence) score -64, which ends an
+        // extension exactly where the sequence ends (x-drop < 64): no bounds are needed.
         constexpr int XB = 16;
         uint32_t qw[XB / 4], tw[XB / 4];
 #pragma unroll
@@ -843,8 +816,6 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
     const int fine_bits = std::min(12, bucket_bits - 8);
     bool use_partition = P.reserved[2] == 0 && bucket_bits >= 16 && bucket_bits - fine_bits <= 13;
     for (int attempt = 0; attempt < 8; ++attempt) {
-        uint64_t *run_first = nullptr, *run_key = nullptr;
-        uint32_t *run_len = nullptr;
         const uint64_t cap = 1ull << table_bits;
         const uint32_t list_cap = (uint32_t)(cap >> 1);
         // the candidate set lives in a buffer of its own: set_compact hands every slot back EMPTY, so only a new (or larger, or abandoned)
@@ -925,11 +896,6 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
                 }
                 if (hit_cap == 0) hit_cap = std::max<uint64_t>(1ull << 22, 2 * T.total);
                 PEP_TRY(dev_reserve(ctx, ctx->ws[8], hit_cap * sizeof(uint64_t)));
-                PEP_TRY(dev_reserve(ctx, ctx->ws[10], hit_cap * 8));          // runs of equal candidate keys: first hit, key, length
-                PEP_TRY(dev_reserve(ctx, ctx->ws[11], hit_cap * 8));
-                PEP_TRY(dev_reserve(ctx, ctx->ws[12], hit_cap * 4 + 64));
-                run_first = ctx->ws[10].as<uint64_t>(); run_key = ctx->ws[11].as<uint64_t>();
-                run_len = ctx->ws[12].as<uint32_t>();
             }
             const unsigned tb = (unsigned)ceil_div(T.total, 256);
             JoinArgs a;
@@ -939,7 +905,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             a.counters = counters; a.stats = stats;
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
             a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.stage1_min = P.stage1_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
-            unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(zero + PEP_ZERO_SHAPE) + 2 * s, *n_runs = hit_count + 1;      // per shape, cleared by the one fill
+            unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(zero + PEP_ZERO_SHAPE) + 2 * s;      // per shape, cleared by the one fill
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
             pep_timer_begin(ctx, TM_MATCH0 + s);
             PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 8u)), sh, a);
@@ -959,9 +925,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
                                    reinterpret_cast<unsigned long long *>(probe_cnt.as<uint32_t>() + n_coarse));
             }
 #endif
-            hipLaunchKernelGGL(seed_runs, dim3(256u * 8u), dim3(256), 0, ctx->stream, a, run_first, run_len, run_key, n_runs);
-            hipLaunchKernelGGL(seed_extend, dim3(256u * 16u), dim3(256), 0, ctx->stream, a, (const uint64_t *)run_first, (const uint32_t *)run_len,
-                               (const uint64_t *)run_key, (const unsigned long long *)n_runs);
+            hipLaunchKernelGGL(seed_runs_extend, dim3(256u * 8u), dim3(256), 0, ctx->stream, a);
             PEP_HIP(ctx, hipGetLastError());
         }
         // field widths of the dense key form (see keys_pack)
