@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rocprofv3 PMC databases (one per counter pass) -> profiles/rNN_counters.json: per kernel the per-dispatch average of every counter
 (raw counter unit: FETCH_SIZE / WRITE_SIZE in KiB) and the average duration of the kernel in that pass.
-    python tools/pmc_to_json.py out.json pass1_results.db pass2_results.db ..."""
+    python tools/pmc_to_json.py out.json n_genes pass1_results.db pass2_results.db ..."""
 import json
 import sqlite3
 import sys
@@ -11,7 +11,7 @@ def short(n):
     return str(n).replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0]
 
 
-def main(out, *dbs):
+def main(out, n_genes, *dbs):
     kernels = {}
     for path in dbs:
         c = sqlite3.connect(path)
@@ -21,7 +21,7 @@ def main(out, *dbs):
             k = kernels.setdefault(short(name), {})
             k.setdefault('avg_us_in_pmc_passes', []).append(round(avg / 1e3, 2))
             k['dispatches_per_pass'] = n
-    json.dump({'workload': '10000 genes x 1002 nt all-vs-all (tools/one_search.py: 2 searches per pass)',
+    json.dump({'workload': '%s genes x 1002 nt all-vs-all (tools/one_search.py: 2 searches per pass)' % n_genes,
                'unit': 'per-dispatch average of the raw counter (FETCH_SIZE / WRITE_SIZE: KiB; SQ_* cycle counters: quad-cycles summed over all SIMDs; '
                        'GRBM_GUI_ACTIVE: summed over the 8 XCDs)',
                'kernels': kernels}, open(out, 'w'), indent=1, sort_keys=True)
