@@ -546,7 +546,7 @@ __device__ __forceinline__ void xdrop_step(XDrop &x, int sc, int on, int base, i
     x.live &= (act & (p | d)) ^ 1;
 }
 
-constexpr int RUN_TRIP = 2;                     // rounds of 64 hits a wavefront turns into runs at a time (their look-up chains overlap)
+constexpr int RUN_TRIP = 4;                     // rounds of 64 hits a wavefront turns into runs at a time (their look-up chains overlap)
 constexpr int RUN_STRIP = 64 * RUN_TRIP;        // runs a wavefront's strip holds (a run per hit at most)
 __device__ __forceinline__ void wave_sync_lds()
 {
@@ -925,7 +925,8 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
                                    reinterpret_cast<unsigned long long *>(probe_cnt.as<uint32_t>() + n_coarse));
             }
 #endif
-            hipLaunchKernelGGL(seed_runs_extend, dim3(256u * 8u), dim3(256), 0, ctx->stream, a);
+            // (same-box A/B, tools/ab/phase2_ab.sh: four trips of 64 hits per strip; 8 blocks per CU at 10 k genes - 122 us against 126 with 16 -, 16 at 50 k - 1.71 ms against 1.86)
+            hipLaunchKernelGGL(seed_runs_extend, dim3(256u * (T.total > (48ull << 20) ? 16u : 8u)), dim3(256), 0, ctx->stream, a);
             PEP_HIP(ctx, hipGetLastError());
         }
         // field widths of the dense key form (see keys_pack)
