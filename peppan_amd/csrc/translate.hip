@@ -331,6 +331,9 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
 // a reverse-strand target is the reverse complement.  One wavefront per packed sequence, eight consecutive bytes per lane (one unaligned
 // 8-byte load where the whole window lies inside the sequence, byte loads at its two ends), padding and block -> sequence map as k1_pack.
 struct NuclDesc { uint32_t seq, rev; };
+// one wavefront per (sequence, slice of NUCL_SLICE packed bytes): blockIdx.y is the slice.  (One wavefront per SEQUENCE until round 4: fine for genes,
+// but a genome's contig of 2 Mb was packed by a single wavefront - 4 - 8 ms per mapping batch, the largest kernel of the mapping path's trace.)
+constexpr uint32_t NUCL_SLICE = 32768;
 __global__ __launch_bounds__(256) void nucl_pack(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ nt_off, const NuclDesc *__restrict__ desc,
                                                  const uint32_t *__restrict__ pk_off, uint32_t n_packed, uint8_t *__restrict__ res, uint2 *__restrict__ blk2seq)
 {
@@ -345,8 +348,10 @@ __global__ __launch_bounds__(256) void nucl_pack(const uint8_t *__restrict__ nt,
     const uint32_t start = pk_off[s], next = pk_off[s + 1];
     const uint8_t *src = nt + nt_off[d.seq];
     const int64_t L = (int64_t)(nt_off[d.seq + 1] - nt_off[d.seq]);
-    if (s == 0) for (uint32_t x = lane; x < start; x += 64) res[x] = (uint8_t)PEP_PAD_CODE;          // leading pad
-    for (uint32_t x0 = 8 * lane; x0 < next - start; x0 += 512) {
+    const uint32_t x_lo = blockIdx.y * NUCL_SLICE, x_hi = min(next - start, x_lo + NUCL_SLICE);       // (slices are multiples of 512: whole trips)
+    if (x_lo >= next - start) return;
+    if (s == 0 && blockIdx.y == 0) for (uint32_t x = lane; x < start; x += 64) res[x] = (uint8_t)PEP_PAD_CODE;          // leading pad
+    for (uint32_t x0 = x_lo + 8 * lane; x0 < x_hi; x0 += 512) {
         uint32_t word[2] = {0, 0};
         uint8_t raw[8];
         const bool whole = (int64_t)x0 + 8 <= L;
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(256) void nucl_pack(const uint8_t *__restrict__ nt,
     }
     // (sequence, start) per 32-byte block that holds residues of this sequence: [start, next - 16) - the gap in front of `next` is at least 16 bytes of
     // padding, so a block never holds residues of two sequences; the block that `next` starts in the middle of belongs to the next sequence
-    for (uint32_t b = (start >> 5) + lane, last = ((next & 31u) == 16u) ? ((next - 16u) >> 5) - 1u : (next - 17u) >> 5; b <= last && last != ~0u; b += 64) blk2seq[b] = make_uint2(s, start);
+    for (uint32_t b = ((start + x_lo) >> 5) + lane, last = min(((next & 31u) == 16u) ? ((next - 16u) >> 5) - 1u : (next - 17u) >> 5, (start + x_hi - 1u) >> 5); b <= last && last != ~0u; b += 64)
+        blk2seq[b] = make_uint2(s, start);       // (this slice's part of the map)
 }
 
 void fill_codon_table(uint8_t tab[2][64])
@@ -713,7 +719,7 @@ static int nucl_build(pep_ctx *ctx, const NtSet &nt, const std::vector<NuclDesc>
     PEP_HIP(ctx, hipMemcpyAsync(out.off.p, out.h_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     if (n) PEP_HIP(ctx, hipMemcpyAsync(out.len.p, out.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     if (n) PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[2].p, order.data(), (size_t)n * sizeof(NuclDesc), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(nucl_pack, dim3((unsigned)ceil_div((uint64_t)n + 1, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(),
+    hipLaunchKernelGGL(nucl_pack, dim3((unsigned)ceil_div((uint64_t)n + 1, 4), (unsigned)ceil_div((uint64_t)max_len + 15 + PEP_SEQ_GAP, NUCL_SLICE) + 1), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(),
                        ctx->ws[2].as<const NuclDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), out.blk2seq.as<uint2>());
     PEP_HIP(ctx, hipGetLastError());
     PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (the descriptor vector is the caller's)
