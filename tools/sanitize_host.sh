@@ -1,11 +1,12 @@
 #!/bin/bash
-# AddressSanitizer + UBSan over the host-only code (GPU sanitizers are not available on the pool): the oracle and the C++ -f / -m filters.
+# AddressSanitizer + UBSan over the host-only code (GPU sanitizers are not available on the pool): the oracle, the C++ -f / -m filters and the
+# store-member emitters (csrc/stores.hip).
 # usage: tools/sanitize_host.sh      (CPU only; prints one line per check)
 set -e
 cd "$(dirname "$0")/.."
 make -s -C oracle asan
 g++ -x c++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -fPIC \
-    peppan_amd/csrc/mapfilters.hip -o /tmp/libmf_asan.so
+    peppan_amd/csrc/mapfilters.hip peppan_amd/csrc/stores.hip -o /tmp/libmf_asan.so
 ASAN=$(gcc -print-file-name=libasan.so)
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0 python - <<'PY'
 import sys, os, ctypes as C, copy
@@ -18,15 +19,37 @@ class Host:                       # only the two host entry points are needed
     def __init__(self): self.a = C.CDLL('/tmp/libmf_asan.so')
     def __getattr__(self, k): return getattr(self.a, k)
 N._lib = Host()
+import gzip, json, io
+from conftest import GOLDEN
+g = json.loads(gzip.open(os.path.join(GOLDEN, 'g18_filters_random.json.gz')).read().decode())
 import test_host_golden as T
+ok, n_tab = True, 0
+for case in g['cases'][::4]:
+    rows = [[q, r, iden, qe - qs + 1, 3, 0, qs, qe, ss, se, 0.0, score, ql, sl, [[qe - qs + 1, 'M']], i] for i, (q, r, iden, qs, qe, ss, se, score, ql, sl) in enumerate(case['cols'])]
+    tab = T._table(rows)
+    for key, want in case['ovl'].items():
+        cov, delta = (float(x) for x in key.split('_'))
+        ok &= [int(r[15]) for r in mapfilters.ovl_filter(copy.deepcopy(tab), cov, delta)] == want
+    for key, want in case['merge'].items():
+        gap, diff = (float(x) for x in key.split('_'))
+        ok &= [int(r[15]) for r in mapfilters.linear_merge(copy.deepcopy(tab), gap, diff)] == [w[0] for w in want]
+    n_tab += 1
+print('host C++ filters == the reference on %d random tables of G18 under ASAN/UBSAN:' % n_tab, ok)
+# the store-member emitters: pickle streams from columns, read back by numpy
 rng = np.random.default_rng(7)
-ok = True
-for tab in [T._dense_table(rng, 40, 3, k) for k in (2, 6, 15, 25)]:
-    for cov, delta in ((0.9, 0.), (0.5, 10.)):
-        ok &= mapfilters.ovl_filter(copy.deepcopy(tab), cov, delta).tolist() == mapfilters.ovl_filter_py(copy.deepcopy(tab), cov, delta).tolist()
-    for gap, diff in ((600., 1.5), (2000., 3.0)):
-        ok &= mapfilters.linear_merge(copy.deepcopy(tab), gap, diff).tolist() == mapfilters.linear_merge_py(copy.deepcopy(tab), gap, diff).tolist()
-print('host C++ filters == Python statement under ASAN/UBSAN:', ok)
+row_off = np.concatenate([[0], np.cumsum(rng.integers(0, 4, size=500))]); n = int(row_off[-1])
+runs = rng.integers(0, 5, size=n); c_off = np.concatenate([[0], np.cumsum(runs)[:-1]])
+arena = ((rng.integers(1, 70000, size=max(1, int(runs.sum()))) << 2) | rng.integers(0, 3, size=max(1, int(runs.sum())))).astype(np.uint32)
+cols = [rng.integers(-2 ** 40, 2 ** 40, size=n) for _ in range(2)] + [rng.random(n)] + [rng.integers(0, 70000, size=n) for _ in range(7)] + [rng.random(n), rng.integers(0, 5000, size=n).astype(float)] + \
+       [rng.integers(0, 300, size=n), rng.integers(0, 10 ** 7, size=n), arena, c_off, runs, rng.integers(0, 20000, size=n)]
+lib = N._lib.a
+lib.pep_store_mat_member.restype = lib.pep_store_seq_member.restype = C.c_int64
+member = N.store_mat_member(cols, row_off, True)
+back = np.lib.format.read_array(io.BytesIO(member), allow_pickle=True)
+print('pep_store_mat_member under ASAN/UBSAN: %d bytes, %d groups read back,' % (len(member), len(back)), all(back[k].shape == (row_off[k + 1] - row_off[k], 16) for k in range(500)))
+po = np.concatenate([[0], np.cumsum(rng.integers(0, 700, size=300))]); pk = rng.integers(0, 125, size=int(po[-1])).astype(np.uint8)
+sb = np.lib.format.read_array(io.BytesIO(N.store_seq_member(pk, po)), allow_pickle=True)
+print('pep_store_seq_member under ASAN/UBSAN:', all(np.array_equal(sb[k], pk[po[k]:po[k + 1]]) for k in range(300)))
 prots = synth.make_proteins(120, length=(40, 400), seed=5, family=3, sub=0.2)
 for mode in (0, 1):
     p = O.default_params(30., 20., 3, 5); p.hsp_mode = mode
