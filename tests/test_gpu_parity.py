@@ -736,6 +736,21 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert l1['n_gpus'] == 1 and l1['cpu_baseline']['gpu_hits_identical'] is True and l1['hits_per_step'] == line['hits_per_step']
     assert l1['clusters'] == line['clusters'] and l1['uberblast_e2e_ms'] > 0 and l1['ms_per_step_incl_h2d'] > 0
     assert len(l1['roofline_kernels']) == 3 and l1['roofline']['kernel'] == l1['roofline_kernels'][0]['kernel']
+    assert l1['cpu_baseline']['kind'] == 'port' and set(l1['cpu_baseline']['reference_binaries']) == {'diamond', 'blastn', 'makeblastdb', 'mmseqs'}
+    assert l1['cpu_baseline']['phase_s']['seed'] > 0 and l1['cpu_baseline']['sw_cells_per_s_vectorised'] > l1['cpu_baseline']['sw_cells_per_s']
+    # --grid: the reference side split too, so that the exact top-k merge runs behind the exchange; the line says how many ranks the collective connected
+    grid = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--grid', '1x2', '--genes', '400', '--steps', '2', '--warmup', '1', '--no-e2e'],
+                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert grid.returncode == 0, grid.stderr.decode()[-2000:]
+    lg = json.loads([l for l in grid.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert lg['rccl_ranks_seen'] == 2 and 'grid 1 query shards x 2 reference shards' in lg['config']['parallelism']
+    assert lg['parity_check']['gpu_hits_identical'] is True and lg['hits_per_step'] == line['hits_per_step'] and lg['clusters'] == line['clusters']
+    # the mapping stage as strong scaling: ONE fixed set of genomes dealt to the two ranks, rank 0 writes the stores
+    ms = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'map', '--map-scaling', 'strong', '--genes', '600', '--map-genomes', '5'],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert ms.returncode == 0, ms.stderr.decode()[-2000:]
+    lm = json.loads([l for l in ms.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert lm['n_gpus'] == 2 and lm['scaling'] == 'strong' and lm['value'] > 0 and lm['rccl_ranks_seen'] == 2 and '5 genomes' in lm['config']['workload']
 
 
 def test_multiple_hsps_per_subject(ctx):
