@@ -43,11 +43,32 @@ _OP_CODE = {'M': 0, 'I': 1, 'D': 2}
 _INT_TYPES = (int, np.integer)
 
 
+_INT_TABLES = {}         # id(name table) -> (the table, its int64 array): the genomes of a mapping batch share one 10 000-entry table of gene ids
+
+
+def int_name_array(names, register=None):
+    """the int64 array of a name table of integers, remembered per table OBJECT (None when the table holds anything else).  register: the
+    array of a table the caller has just converted itself"""
+    hit = _INT_TABLES.get(id(names))
+    if hit is not None and hit[0] is names:
+        return hit[1]
+    if register is None:
+        if not (len(names) and all(isinstance(v, _INT_TYPES) for v in names)):
+            return None
+        register = np.asarray(names, dtype=np.int64)
+    if len(names) >= 256:
+        if len(_INT_TABLES) >= 16:
+            _INT_TABLES.clear()
+        _INT_TABLES[id(names)] = (names, register)
+    return register
+
+
 def _name_codes(names, idx):
     """integer code of every row's name in the order a sort of the column orders the names: numeric when every name is an integer,
     code-point order of the strings otherwise (what pandas / numpy do with an object column of that content)"""
-    if len(names) and all(isinstance(v, _INT_TYPES) for v in names):
-        return np.asarray(names, dtype=np.int64)[idx]
+    num = int_name_array(names)
+    if num is not None:
+        return num[idx]
     rank = np.unique(np.array([str(v) for v in names], dtype=str), return_inverse=True)[1].astype(np.int64) if len(names) else np.zeros(0, np.int64)
     return rank[idx]
 

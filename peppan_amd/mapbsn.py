@@ -11,6 +11,7 @@ genomes to one GPU search (`uberBlastBatch`, pep_set_target_groups keeps the per
 same per-genome bookkeeping, in genome order, so the stores are those of the reference's in-order `map` variant
 (PEPPAN.py:923).  Everything below the search is host logic pinned by tests/golden/g14_mapbsn.json / g15_getmapbsn.json.
 """
+import contextlib
 import io
 import queue
 import threading
@@ -296,7 +297,7 @@ def _known_fraction(T, old_prediction):
     f1 = np.where(fwd, head % 3 + 1, (-head) % 3 - 1)
     f2 = np.where(fwd, (tail + 1) % 3 + 1, (-(tail - 1)) % 3 - 1)
     bounds = np.concatenate([[0], np.flatnonzero(np.diff(ri)) + 1, [n]])
-    with MapBsn(old_prediction) as op:
+    with (contextlib.nullcontext(old_prediction) if isinstance(old_prediction, MapBsn) else MapBsn(old_prediction)) as op:       # (an open store is read as it is)
         for a, b in zip(bounds[:-1].tolist(), bounds[1:].tolist()):
             genes = op.get(T.r_tab[ri[a]])
             if len(genes) == 0:
@@ -452,6 +453,23 @@ class OrthoRelation(object):
         return out
 
 
+_INT_NAMES = {}
+
+
+def _int_names(tab):
+    """a name table as a list of Python ints, remembered per table object: the genomes of a batch share their tables (10 000 gene ids), and every
+    sort of the chain asks for the numeric form"""
+    from .hittable import int_name_array
+    hit = _INT_NAMES.get(id(tab))
+    if hit is None or hit[0] is not tab:
+        if len(_INT_NAMES) >= 16:
+            _INT_NAMES.clear()
+        ints = [int(x) for x in tab]
+        int_name_array(ints, register=np.asarray(ints, dtype=np.int64))
+        hit = _INT_NAMES[id(tab)] = (tab, ints)
+    return hit[1]
+
+
 def build_groups(blastab, overlap, seq, ortho, old_prediction, params, ctx=None):
     """(17-column table with merge groups, int[m, 3] overlaps) of ONE genome -> GenomeGroups.  PEPPAN.py:773-866.
     `blastab` is the HitTable the search chain ends with (the product path: no Python row is made at all) or the same thing as object
@@ -468,7 +486,7 @@ def build_groups(blastab, overlap, seq, ortho, old_prediction, params, ctx=None)
     if ctx is None:
         from .uberBlast import get_context
         ctx = get_context()
-    T.q_tab, T.r_tab = [int(x) for x in T.q_tab], [int(x) for x in T.r_tab]
+    T.q_tab, T.r_tab = _int_names(T.q_tab), _int_names(T.r_tab)
     T.q_sorted = T.r_sorted = False           # (integer names order numerically from here on)
     T = _with_known(T, old_prediction)
     n = len(T)
@@ -545,7 +563,8 @@ def build_groups(blastab, overlap, seq, ortho, old_prediction, params, ctx=None)
         score[gid] = np.sum([c[3] for c in spans])
     # group identity: the merge group's for a lone row and for a chain, the row's own for a chain member standing alone
     g_iden = np.where(is_lone_group | (n_rows > 1), T.m_iden[head_row], T.iden[head_row])
-    q_names, r_names = np.asarray(T.q_tab, dtype=np.int64), np.asarray(T.r_tab, dtype=np.int64)
+    from .hittable import int_name_array
+    q_names, r_names = int_name_array(T.q_tab), np.asarray(T.r_tab, dtype=np.int64)
     g_gene, g_contig = q_names[T.qi[head_row]], r_names[T.ri[head_row]]
     # ---- overlaps between groups: a row id may stand in a group of its own and in a chain
     as_single, as_chain = np.full(n_id, -1, dtype=np.int64), np.full(n_id, -1, dtype=np.int64)
@@ -729,7 +748,9 @@ def _mat_block(G):
     runs = R.c_runs
     start = np.concatenate([[0], np.cumsum(runs)]).astype(np.int64)
     src = np.repeat(R.c_off - start[:-1], runs) + np.arange(int(start[-1]))
-    q, r = np.asarray(R.q_tab, dtype=np.int64)[R.qi], np.asarray(R.r_tab, dtype=np.int64)[R.ri]
+    from .hittable import int_name_array
+    q_num = int_name_array(R.q_tab)
+    q, r = (q_num if q_num is not None else np.asarray(R.q_tab, dtype=np.int64))[R.qi], np.asarray(R.r_tab, dtype=np.int64)[R.ri]
     cols = [q, r, R.iden, R.aln, R.mis, R.gap, R.qs, R.qe, R.ss, R.se, R.evalue, R.score, R.ql, R.sl]
     return dict(cols=cols, arena=R.arena[src], run_off=start, rid=R.rid, row_off=G.row_off, score_is_int=R.score_is_int)
 
@@ -833,6 +854,8 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         taxa.setdefault(s[0], []).append([g, s[1]])
     jobs = [(id, taxon, seq) for id, (taxon, seq) in enumerate(taxa.items())]
     ortho = OrthoRelation(orthoGroup)
+    if isinstance(old_prediction, str):
+        old_prediction = MapBsn(old_prediction)            # opened once, read by every genome (the reference opens it per genome, PEPPAN.py:870)
     per_round = max(1, int(genomes_per_round))
     searcher = search or (lambda *a: _gpu_search(*a, genomes_per_batch=per_round))
     stores = _StoreWriter(conn, seq_conn, mat_conn, clf_conn, saveSeq)

@@ -244,8 +244,8 @@ def test_run_end_to_end_with_canned_aligner_output(tmp_path, monkeypatch, oracle
     made = []
     orig_init = UB.RunBlast.__init__
 
-    def init(self, device=None):
-        orig_init(self, device)
+    def init(self, device=None, **kw):
+        orig_init(self, device, **kw)
         oracle_ctx['ctx'] = OracleCtx(self)
         self._nt_loaded = None
         made.append(self)
