@@ -602,20 +602,35 @@ __global__ __launch_bounds__(256) void seed_runs_extend(JoinArgs a)
                     key[u] = ((uint64_t)qb.x << 43) | ((uint64_t)tb.x << 18) | (uint64_t)bin;
                 }
             }
+            bool leader[RUN_TRIP];
+            int rlen[RUN_TRIP];
+            uint64_t seen[RUN_TRIP];
 #pragma unroll
             for (int u = 0; u < RUN_TRIP; ++u) {
                 const uint32_t lo = (uint32_t)key[u], hi = (uint32_t)(key[u] >> 32);
                 const uint32_t lo_prev = __shfl_up(lo, 1, 64), hi_prev = __shfl_up(hi, 1, 64);     // unconditional: every lane must take part in the shuffles
-                const bool leader = valid[u] && !(a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi);
-                const unsigned long long leaders = __ballot(leader), valid_m = __ballot(valid[u]);
+                leader[u] = valid[u] && !(a.debug != 9 && lane > 0 && lo_prev == lo && hi_prev == hi);
+                const unsigned long long leaders = __ballot(leader[u]), valid_m = __ballot(valid[u]);
                 const unsigned long long above = lane == 63 ? 0ull : (leaders & (~0ull << (lane + 1)));          // the next run starts at its lowest set bit
-                const int nxt = above ? __builtin_ctzll(above) : __popcll(valid_m);                               // valid lanes are a prefix
-                if (leader) {
-                    const uint32_t slot = q_n + (uint32_t)__popcll(leaders & ((1ull << lane) - 1ull));
+                rlen[u] = (above ? __builtin_ctzll(above) : __popcll(valid_m)) - lane;                            // valid lanes are a prefix
+            }
+            // a run of ONE hit is almost always a chance hit of the reduced alphabet whose candidate is in no set: it goes straight to the
+            // extension (which decides) instead of paying a scattered probe of the set; longer runs - homologous diagonals - are dropped HERE
+            // when their candidate is established already (an earlier run, shape or launch).  The first probes of the whole trip are in flight
+            // together; only a slot that holds another key sends a lane down the probe sequence.
+#pragma unroll
+            for (int u = 0; u < RUN_TRIP; ++u) seen[u] = (leader[u] && rlen[u] > 1) ? a.table[hash_u64(key[u], a.table_bits)] : EMPTY;
+#pragma unroll
+            for (int u = 0; u < RUN_TRIP; ++u) {
+                bool queue = leader[u];
+                if (leader[u] && rlen[u] > 1 && (seen[u] == key[u] || (seen[u] != EMPTY && set_contains(a, key[u])))) { queue = false; ++n_pass; }
+                const unsigned long long queued = __ballot(queue);
+                if (queue) {
+                    const uint32_t slot = q_n + (uint32_t)__popcll(queued & ((1ull << lane) - 1ull));
                     // (a run of one carries its hit itself - no look-up into the hit buffer later; longer runs the index of their first hit)
-                    q_first[slot] = nxt - lane == 1 ? hit[u] : hh[u]; q_len[slot] = (uint32_t)(nxt - lane); q_key[slot] = key[u];
+                    q_first[slot] = rlen[u] == 1 ? hit[u] : hh[u]; q_len[slot] = (uint32_t)rlen[u]; q_key[slot] = key[u];
                 }
-                q_n += (uint32_t)__popcll(leaders);
+                q_n += (uint32_t)__popcll(queued);
             }
             next_hits += stride;
             wave_sync_lds();
@@ -626,11 +641,7 @@ __global__ __launch_bounds__(256) void seed_runs_extend(JoinArgs a)
             const uint32_t rank = (uint32_t)__popcll(idle & ((1ull << lane) - 1ull)), r = q_take + rank;
             if (!busy && r < q_n) {
                 ck = q_key[r]; first = q_first[r]; len = q_len[r];
-                // a run of ONE hit is almost always a chance hit of the reduced alphabet whose candidate is in no set: it goes straight to the
-                // extension (which decides) instead of paying a scattered probe of the set; longer runs - homologous diagonals - are dropped
-                // when their candidate is established already (an earlier run, shape or launch)
-                if (len > 1 && set_contains(a, ck)) ++n_pass;
-                else if (a.ungapped_min <= 0) { ++n_pass; set_insert(a, ck); }
+                if (a.ungapped_min <= 0) { ++n_pass; set_insert(a, ck); }
                 else {
                     const uint64_t hit = len == 1 ? first : a.hits[first];
                     qp = (uint32_t)(hit >> 32); tp = (uint32_t)hit; h = 0;
