@@ -27,9 +27,10 @@ def test_struct_layouts_match_header(tmp_path):
     from peppan_amd import _native as N
     probes = [('pep_search_params', 'min_id_pct'), ('pep_search_params', 'dbsize'), ('pep_search_params', 'ka_lambda'), ('pep_search_params', 'hsp_mode'),
               ('pep_search_params', 't_index_base'), ('pep_stats', 'cells_swept_trace'), ('pep_stats', 'candidates_settled'), ('pep_stats', 'cells_settled'), ('pep_stats', 'ms_seed'), ('pep_stats', 'ms_seed_match'),
-              ('pep_hit', 'cigar_off'), ('pep_hit', 'cells'), ('pep_nt_hit', 'cigar_off'), ('pep_locus', 'cigar_off')]
+              ('pep_hit', 'cigar_off'), ('pep_hit', 'cells'), ('pep_nt_hit', 'cigar_off'), ('pep_locus', 'cigar_off'),
+              ('pep_mat_cols', 'iden'), ('pep_mat_cols', 'arena'), ('pep_mat_cols', 'rid'), ('pep_mat_cols', 'score_is_int')]
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "peppan_hip.h"\nint main(void) {\n'
-    for st in ('pep_search_params', 'pep_stats', 'pep_hit', 'pep_nt_hit', 'pep_locus', 'pep_query_meta', 'pep_target_meta'):
+    for st in ('pep_search_params', 'pep_stats', 'pep_hit', 'pep_nt_hit', 'pep_locus', 'pep_query_meta', 'pep_target_meta', 'pep_mat_cols'):
         src += '  printf("%s %%zu\\n", sizeof(%s));\n' % (st, st)
     for st, f in probes:
         src += '  printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (st, f, st, f)
@@ -40,10 +41,10 @@ def test_struct_layouts_match_header(tmp_path):
     got = {k: int(v) for k, v in got.items()}
     assert got['pep_search_params'] == C.sizeof(N.SearchParams) and got['pep_stats'] == C.sizeof(N.Stats)
     assert got['pep_hit'] == N.HIT_DTYPE.itemsize == 64 and got['pep_nt_hit'] == N.NT_HIT_DTYPE.itemsize == 40
-    assert got['pep_locus'] == N.LOCUS_DTYPE.itemsize == 32
+    assert got['pep_locus'] == N.LOCUS_DTYPE.itemsize == 32 and got['pep_mat_cols'] == C.sizeof(N.MatCols)
     assert got['pep_query_meta'] == N.QUERY_META_DTYPE.itemsize == 16 and got['pep_target_meta'] == N.TARGET_META_DTYPE.itemsize == 16
     for st, f in probes:
-        mirror = {'pep_search_params': N.SearchParams, 'pep_stats': N.Stats}.get(st)
+        mirror = {'pep_search_params': N.SearchParams, 'pep_stats': N.Stats, 'pep_mat_cols': N.MatCols}.get(st)
         if mirror is not None:
             assert got[st + '.' + f] == getattr(mirror, f).offset, (st, f)
         else:
