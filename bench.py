@@ -274,10 +274,13 @@ def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_s
     return dict(seconds=dt, seconds_with_stores=dt_stores, genomes=n_genomes * steps, genome_nt=nt, groups_per_step=groups, hit_rows_per_step=rows)
 
 
-def map_strong(args, rank, world, local_rank, n_total):
+def map_strong(args, rank, world, local_rank, n_total, workers=0, warm=False):
     """BASELINE configs[3] / [4], mapping stage, as STRONG scaling: ONE fixed set of n_total synthetic genomes against the exemplar genes through
     get_map_bsn (PEPPAN.py:907-989) - the genomes dealt to the ranks in blocks of 32 (each rank searches its blocks on its own GPU: batched search of
-    both tools, -f / -m / -O, K7, K12, build_groups), rank 0 gathers the per-genome columns and writes the four stores.  No data-path collective."""
+    both tools, -f / -m / -O, K7, K12, build_groups), rank 0 gathers the per-genome columns and writes the four stores.  No data-path collective.
+    `workers` > 1: every rank deals its genomes to that many worker processes on its GPU (peppan_amd.mapworkers, the reference's pool of forked
+    workers, PEPPAN.py:922) and only keeps the stores; the pool's start-up is inside the measured time unless `warm` (then the set is mapped twice
+    by the same pool and the second pass is the one reported, with the first as `first_pass_s`)."""
     import contextlib
     import io
     import tempfile
@@ -302,28 +305,40 @@ def map_strong(args, rank, world, local_rank, n_total):
         np.save('m.self_bsn.npy', np.array([[0, 1, 9000], [4, 5, -2]], dtype=int))
         UB._CTX.clear()
         os.environ['PEPPAN_HIP_DEVICE'] = str(local_rank)
-        tm = {}
+        tm, extra = {}, {}
 
-        def once():
+        def once(pool):
             import torch.distributed as dist
             if world > 1:
                 dist.barrier()
             t0 = time.perf_counter()
             with contextlib.ExitStack() as es:
                 stores = [es.enter_context(mapbsn.MapBsn('s%d.npz' % k, 'w')) for k in range(4)] if rank == 0 else [None] * 4
+                if workers > 1 and pool is None:
+                    from peppan_amd.mapworkers import MapWorkers
+                    pool = es.enter_context(MapWorkers(workers, device=local_rank))
+                    extra['workers_startup_s'] = time.perf_counter() - t0
                 mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', stores[0], stores[1], stores[2], stores[3], True, params,
-                                   genomes_per_round=32, timing=tm)
+                                   genomes_per_round=32, timing=tm, workers=pool if workers > 1 else 0)
             if world > 1:
                 dist.barrier()
             return time.perf_counter() - t0
         with contextlib.redirect_stderr(io.StringIO()):
-            once() if args.warmup and '--warmup' in sys.argv else None
-            dt = once()
+            if workers > 1 and warm:
+                from peppan_amd.mapworkers import MapWorkers
+                t0 = time.perf_counter()
+                with MapWorkers(workers, device=local_rank) as pool:
+                    extra['workers_startup_s'] = time.perf_counter() - t0
+                    extra['first_pass_s'] = once(pool)
+                    dt = once(pool)
+            else:
+                once(None) if args.warmup and '--warmup' in sys.argv else None
+                dt = once(None)
     finally:
         os.chdir(cwd)
         import shutil
         shutil.rmtree(tmp, ignore_errors=True)
-    return dict(seconds=dt, genomes=n_total, genome_nt=nt, phase_s_rank0=tm)
+    return dict(seconds=dt, genomes=n_total, genome_nt=nt, phase_s_rank0=tm, workers=workers, **extra)
 
 
 def configs4_workloads(local_rank, min_id, min_qcov, torch, steps=5):
@@ -485,7 +500,7 @@ def main_map(args, rank, local_rank, world):
     ranks_seen = _ranks_seen(dist, torch, world, share, local_rank)
     if args.map_scaling == 'strong':
         n_total = args.map_genomes if '--map-genomes' in sys.argv else 500
-        r = map_strong(args, rank, world, local_rank, n_total)
+        r = map_strong(args, rank, world, local_rank, n_total, workers=args.map_workers)
         torch.cuda.synchronize()
         dt = r['seconds']
         if world > 1:
@@ -497,8 +512,9 @@ def main_map(args, rank, local_rank, world):
                               'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'int16', 'data': 'synthetic', 'rccl_ranks_seen': ranks_seen,
                               'config': {'workload': 'synthgenes-v1: %d exemplar genes (log-normal lengths) x ONE fixed set of %d genomes (%.2f Gnt), get_map_bsn with the four stores written by rank 0 '
                                                      '(BASELINE configs[3]/[4] mapping stage, PEPPAN.py:907-989)' % (args.genes, r['genomes'], r['genome_nt'] / 1e9),
-                                         'parallelism': 'genomes dealt to %d rank(s) in blocks of 32, gather_object of the per-genome columns to rank 0, no data-path collective' % world},
-                              'phase_s_rank0': r['phase_s_rank0'], 'roofline': None, 'cpu_baseline': None}))
+                                         'parallelism': 'genomes dealt to %d rank(s) in blocks of 32, gather_object of the per-genome columns to rank 0, no data-path collective' % world
+                                                        + ('; every rank deals its block to %d worker processes on its GPU (start-up inside the time)' % r['workers'] if r['workers'] > 1 else '')},
+                              'phase_s_rank0': r['phase_s_rank0'], 'workers_per_rank': r['workers'], 'workers_startup_s': r.get('workers_startup_s'), 'roofline': None, 'cpu_baseline': None}))
             sys.stdout.flush()
         if world > 1:
             dist.barrier()
@@ -541,6 +557,7 @@ def main():
     ap.add_argument('--map-genomes', type=int, default=16, help='genomes per rank and step of --workload map (weak scaling); with --map-scaling strong: the size of the FIXED genome set')
     ap.add_argument('--map-scaling', choices=('weak', 'strong'), default='weak', help='strong: ONE fixed set of --map-genomes genomes (default 500 then) through get_map_bsn, '
                     'sharded over the ranks in blocks, rank 0 writes the four stores (BASELINE configs[3]/[4] mapping stage)')
+    ap.add_argument('--map-workers', type=int, default=0, help='--workload map --map-scaling strong: worker processes per rank (peppan_amd.mapworkers; 0 = the rank maps its genomes itself)')
     ap.add_argument('--grid', default=None, help='RxC: query shards x reference shards of the all-vs-all (default: peppan_amd.dist.choose_grid); R*C must equal --gpus')
     ap.add_argument('--no-workloads', action='store_true', help='skip the configs[4] legs behind the headline (50k x 50k search step, 50k-exemplar mapping step)')
     args = ap.parse_args()
@@ -763,8 +780,15 @@ def main():
             extras['map_workload'] = {'genomes_per_s': mr['genomes'] / mr['seconds'], 'genomes_per_s_with_stores': mr['genomes'] / mr['seconds_with_stores'],
                                       'genomes': mr['genomes'], 'genome_nt': mr['genome_nt'], 'groups_per_step': mr['groups_per_step'],
                                       'note': 'python bench.py --workload map --gpus N: genomes sharded over the ranks, weak scaling, no collective'}
+            # the same path with the reference's pool of workers (PEPPAN.py:922): 8 worker processes share this GPU, this process keeps the stores
+            n_pool, n_set = min(8, max(2, (os.cpu_count() or 2) - 1)), 256
+            ps = map_strong(args, 0, 1, local_rank, n_set, workers=n_pool, warm=True)
+            extras['map_workload']['worker_pool'] = {'workers': n_pool, 'genomes': n_set, 'genomes_per_s_with_stores': n_set / ps['seconds'], 'seconds': ps['seconds'],
+                                                     'first_pass_s': ps['first_pass_s'], 'workers_startup_s': ps['workers_startup_s'], 'phase_s': ps['phase_s_rank0'],
+                                                     'note': 'get_map_bsn(..., workers=8) over ONE set of 256 genomes, four stores written; second pass of a started pool '
+                                                             '(first_pass_s: the first one, with every worker\'s first search). python bench.py --workload map --map-scaling strong --map-workers 8'}
         except Exception as e:                                  # never lose the headline over the secondary leg
-            extras['map_workload'] = {'error': repr(e)}
+            extras.setdefault('map_workload', {})['error'] = repr(e)
     if rank == 0 and world == 1 and not args.no_e2e and not args.no_workloads and args.genes == 10000:
         # (e) BASELINE configs[4] at the size one GPU holds: the 50k x 50k search step and a 50k-exemplar mapping step
         try:

@@ -32,6 +32,7 @@
  *   pep_alleles             aligned-allele strings + base-5 packing of iter_map_bsn   PEPPAN.py:812-835, 846-848
  *   pep_store_mat_member / pep_store_seq_member   the 1000-group members of the .mat / .seq stores get_map_bsn writes (host C++:
  *                           the .npy pickle stream emitted from the numeric hit table)   PEPPAN.py:950-966
+ *   pep_store_tab_members   all members of the .tab store (gene -> int rows) as finished zip entries, host threads   PEPPAN.py:91-113, 972-975
  *   pep_similar_scan / pep_pair_support / pep_similar_resolve   the pass of get_similar_pairs over the all-vs-all table and its
  *                           get_similar (host state machine, K14 on the GPU, host dictionary)   PEPPAN.py:195-224, 231-276, 294
  */
@@ -42,7 +43,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 9
+#define PEP_ABI_VERSION 10
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -390,6 +391,16 @@ typedef struct pep_mat_cols {
 } pep_mat_cols;
 int64_t pep_store_mat_member(const pep_mat_cols *cols, const int64_t *row_off, int64_t n_groups, const char *recon_module, uint8_t *out, int64_t cap);
 int64_t pep_store_seq_member(const uint8_t *packed, const int64_t *pack_off, int64_t n_groups, const char *recon_module, uint8_t *out, int64_t cap);
+
+/* The gene table store <prefix>.tab.npz (PEPPAN.py:972-975 through MapBsn.update, PEPPAN.py:91-113) written into an EMPTY archive: the
+ * complete zip entries - local file header + payload - of all members back to back in `out`, made by up to `threads` host threads.
+ * Member m is the .npy file of int64[off[m+1] - off[m], n_cols] = rows [off[m], off[m+1]) of the row-major table, named by the decimal
+ * key[m]; stored below 4 KiB, raw deflate (level 1) from there on - what MapBsn writes member by member.  crc / csize / usize / at[m]
+ * (offset of the entry in `out`) are what the archive's central directory needs; the caller appends `out` to the archive and lists
+ * the entries.  Returns the length of `out`'s content; when it exceeds `cap` nothing usable was written and the caller calls again
+ * with that much room.  Negative: PEP_ERR_ARG. */
+int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
+                              int32_t threads, uint8_t *out, int64_t cap, uint32_t *crc, int64_t *csize, int64_t *usize, int64_t *at);
 
 #ifdef __cplusplus
 }

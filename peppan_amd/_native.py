@@ -7,14 +7,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params', 'pep_set_sensitivity',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member']
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members']
 
 
 class PepError(RuntimeError):
@@ -309,6 +309,34 @@ def store_seq_member(packed, pack_off):
         raise PepError('pep_store_seq_member failed (%d)' % need)
     buf[:len(head)] = np.frombuffer(head, dtype=np.uint8)
     return buf[:len(head) + need].tobytes()
+
+
+def store_tab_members(rows, off, keys, date_time, threads=None):
+    """pep_store_tab_members: the finished zip entries of all members of the .tab store (PEPPAN.py:91-113, 972-975) ->
+    (bytes of all entries, crc uint32[m], compressed size int64[m], size int64[m], offset of the entry int64[m])"""
+    lib = load_library()
+    lib.pep_store_tab_members.restype = C.c_int64
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    off, keys = np.ascontiguousarray(off, dtype=np.int64), np.ascontiguousarray(keys, dtype=np.int64)
+    m = len(keys)
+    if rows.ndim != 2 or len(off) != m + 1:
+        raise ValueError('store_tab_members: rows int64[n, c], off int64[m + 1], keys int64[m]')
+    crc, csize, usize, at = np.empty(m, np.uint32), np.empty(m, np.int64), np.empty(m, np.int64), np.empty(m, np.int64)
+    y, mo, d, h, mi, sec = date_time
+    dos_date, dos_time = (y - 1980) << 9 | mo << 5 | d, h << 11 | mi << 5 | (sec // 2)
+    if threads is None:
+        threads = max(1, min(16, (os.cpu_count() or 4) // 2))
+    cap = rows.nbytes // 2 + 256 * m + 4096
+    for _ in range(2):
+        buf = np.empty(cap, dtype=np.uint8)
+        need = lib.pep_store_tab_members(_ptr(rows), C.c_int64(rows.shape[1]), _ptr(off), _ptr(keys), C.c_int64(m), C.c_uint32(dos_time), C.c_uint32(dos_date), C.c_int32(threads),
+                                         _ptr(buf), C.c_int64(cap), _ptr(crc), _ptr(csize), _ptr(usize), _ptr(at))
+        if need < 0:
+            raise PepError('pep_store_tab_members failed (%d)' % need)
+        if need <= cap:
+            return buf[:need], crc, csize, usize, at
+        cap = int(need)
+    raise PepError('pep_store_tab_members: the entries did not fit the size it had asked for')
 
 
 def similar_scan(q, r, action, forward, iden4, n_genes):

@@ -175,3 +175,104 @@ extern "C" int64_t pep_store_seq_member(const uint8_t *packed, const int64_t *pa
     close_outer(s);
     return s.n;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The gene table store (.tab): one member per gene, int64 rows.  MapBsn.update (PEPPAN.py:91-113) writes them one by one - at 10 000 genes
+// that is 10 000 trips through numpy's header writer, zlib and zipfile, a second of interpreter time per update.  When the archive is EMPTY
+// (the usual case: the table is kept in memory and written once) every member's complete zip entry - local file header, .npy header, rows,
+// raw-deflated at level 1 from 4 KiB on - is made here, the members dealt to a few threads, and the caller writes the lot with one write()
+// and lists the entries in the archive's directory.
+#include <zlib.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+void put16(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)x); v.push_back((uint8_t)(x >> 8)); }
+void put32(std::vector<uint8_t> &v, uint32_t x) { put16(v, x & 0xFFFFu); put16(v, x >> 16); }
+
+struct TabJob {
+    const int64_t *rows, *off, *key;
+    int64_t n_cols, lo, hi;
+    uint32_t dos_time, dos_date;
+    uint32_t *crc;
+    int64_t *csize, *usize, *at;            // at[]: relative to the job's buffer until the pieces are put together
+    std::vector<uint8_t> buf;
+    bool ok = true;
+};
+
+void tab_members(TabJob *j)
+{
+    std::vector<uint8_t> npy, packed;
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    bool z_open = false;
+    for (int64_t m = j->lo; m < j->hi; ++m) {
+        const int64_t k = j->off[m + 1] - j->off[m];
+        // .npy, format 1.0: magic, version, header length, the dictionary padded with blanks to a multiple of 64 and closed by a newline
+        char dict[128];
+        const int dl = snprintf(dict, sizeof dict, "{'descr': '<i8', 'fortran_order': False, 'shape': (%lld, %lld), }", (long long)k, (long long)j->n_cols);
+        const int hlen = ((10 + dl + 1 + 63) / 64) * 64 - 10;
+        const int64_t body = k * j->n_cols * 8;
+        npy.resize((size_t)(10 + hlen + body));
+        memcpy(npy.data(), "\x93NUMPY\x01\x00", 8);
+        npy[8] = (uint8_t)hlen; npy[9] = (uint8_t)(hlen >> 8);
+        memcpy(npy.data() + 10, dict, (size_t)dl);
+        memset(npy.data() + 10 + dl, ' ', (size_t)(hlen - dl - 1));
+        npy[10 + hlen - 1] = '\n';
+        memcpy(npy.data() + 10 + hlen, j->rows + j->off[m] * j->n_cols, (size_t)body);
+        const uint32_t crc = (uint32_t)crc32(0L, npy.data(), (uInt)npy.size());
+        const uint8_t *payload = npy.data();
+        int64_t plen = (int64_t)npy.size();
+        int method = 0;
+        if (plen >= 4096) {
+            if (!z_open) { if (deflateInit2(&z, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { j->ok = false; return; } z_open = true; }
+            else deflateReset(&z);
+            packed.resize((size_t)deflateBound(&z, (uLong)npy.size()));
+            z.next_in = npy.data(); z.avail_in = (uInt)npy.size();
+            z.next_out = packed.data(); z.avail_out = (uInt)packed.size();
+            if (deflate(&z, Z_FINISH) != Z_STREAM_END) { j->ok = false; break; }
+            payload = packed.data(); plen = (int64_t)z.total_out; method = 8;
+        }
+        const std::string name = std::to_string((long long)j->key[m]);
+        j->crc[m] = crc; j->csize[m] = plen; j->usize[m] = (int64_t)npy.size(); j->at[m] = (int64_t)j->buf.size();
+        std::vector<uint8_t> &b = j->buf;
+        put32(b, 0x04034b50u); put16(b, 20); put16(b, 0); put16(b, (uint32_t)method); put16(b, j->dos_time); put16(b, j->dos_date);
+        put32(b, crc); put32(b, (uint32_t)plen); put32(b, (uint32_t)npy.size()); put16(b, (uint32_t)name.size()); put16(b, 0);
+        b.insert(b.end(), name.begin(), name.end());
+        b.insert(b.end(), payload, payload + plen);
+    }
+    if (z_open) deflateEnd(&z);
+}
+
+}   // namespace
+
+extern "C" int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
+                                         int32_t threads, uint8_t *out, int64_t cap, uint32_t *crc, int64_t *csize, int64_t *usize, int64_t *at)
+{
+    if (n_members < 0 || n_cols < 1 || !off || (n_members && (!rows || !key || !crc || !csize || !usize || !at)) || (cap > 0 && !out)) return PEP_ERR_ARG;
+    for (int64_t m = 0; m < n_members; ++m)
+        if (off[m + 1] < off[m] || (off[m + 1] - off[m]) * n_cols * 8 > (int64_t)0x7FFFFF00) return PEP_ERR_ARG;       // (a member stays below 2 GiB: no zip64 entry)
+    const int64_t T = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(threads, 64), (n_members + 255) / 256));
+    std::vector<TabJob> jobs((size_t)T);
+    std::vector<std::thread> pool;
+    for (int64_t t = 0; t < T; ++t) {
+        TabJob &j = jobs[(size_t)t];
+        j.rows = rows; j.off = off; j.key = key; j.n_cols = n_cols; j.lo = n_members * t / T; j.hi = n_members * (t + 1) / T;
+        j.dos_time = dos_time; j.dos_date = dos_date; j.crc = crc; j.csize = csize; j.usize = usize; j.at = at;
+        if (t + 1 < T) pool.emplace_back(tab_members, &j);
+    }
+    tab_members(&jobs[(size_t)T - 1]);
+    for (auto &th : pool) th.join();
+    int64_t total = 0;
+    for (auto &j : jobs) { if (!j.ok) return PEP_ERR_ARG; total += (int64_t)j.buf.size(); }
+    if (total > cap) return total;                       // (the caller calls again with a buffer of this size)
+    int64_t base = 0;
+    for (auto &j : jobs) {
+        memcpy(out + base, j.buf.data(), j.buf.size());
+        for (int64_t m = j.lo; m < j.hi; ++m) at[m] += base;
+        base += (int64_t)j.buf.size();
+    }
+    return total;
+}

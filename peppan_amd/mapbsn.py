@@ -46,18 +46,19 @@ def _packers():
     global _PACKERS
     if _PACKERS is None:
         from concurrent.futures import ThreadPoolExecutor
-        _PACKERS = ThreadPoolExecutor(max_workers=max(2, min(6, (os.cpu_count() or 4) // 2)), thread_name_prefix='mapbsn-pack')
+        _PACKERS = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 2)), thread_name_prefix='mapbsn-pack')
     return _PACKERS
 
 
-def _pack_member(data):
+def _pack_member(data, strategy=zlib.Z_DEFAULT_STRATEGY):
     """data (bytes, or a callable returning them) -> (payload, crc, size, method).  Members are read back whole either way; deflating
-    a few hundred bytes costs more than it saves (zlib set-up per member)"""
+    a few hundred bytes costs more than it saves (zlib set-up per member).  strategy: zlib's - Z_HUFFMAN_ONLY for members known to hold no
+    repeats (the packed alleles of the .seq store: entropy coding alone gives 0.75 at 120 MB/s where level 1's match search gives 0.77 at 30)"""
     if callable(data):
         data = data()               # a member whose bytes are made here, off the caller's thread (C emitters: no GIL held)
     if len(data) < 4096:
         return data, zlib.crc32(data), len(data), zipfile.ZIP_STORED
-    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+    co = zlib.compressobj(1, zlib.DEFLATED, -15, 8, strategy)
     return co.compress(data) + co.flush(), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
 
 
@@ -181,16 +182,19 @@ class MapBsn(object):
         os.replace(tmp, self.fname)
         self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
 
-    def _enqueue(self, db, key, data):
-        """data: the member's bytes, or a callable that returns them (run by the writer thread)"""
+    def _start_writer(self):
         if self._thread is None:
             self._queue = queue.Queue(maxsize=256)
             self._thread = threading.Thread(target=self._writer, daemon=True)
             self._thread.start()
+
+    def _enqueue(self, db, key, data, strategy=zlib.Z_DEFAULT_STRATEGY):
+        """data: the member's bytes, or a callable that returns them (run by the writer thread)"""
+        self._start_writer()
         if not callable(data) and len(data) < 4096:
             packed = _pack_member(data)             # a few hundred bytes, stored as they are: not worth a trip through the pool
         else:
-            packed = _packers().submit(_pack_member, data)
+            packed = _packers().submit(_pack_member, data, strategy)
         self._queue.put((db, key, packed))
 
     def _save(self, db, key, val):
@@ -202,11 +206,19 @@ class MapBsn(object):
         self._save(self.conn, key, val)
         self.namelist.add(key)
 
-    def save_member(self, key, make_bytes):
+    def save_member(self, key, make_bytes, strategy=zlib.Z_DEFAULT_STRATEGY):
         """save() for a member that arrives as ready-made .npy bytes (or a callable producing them on the writer thread)"""
         key = str(key)
         self.delete_real(key)
-        self._enqueue(self.conn, key, make_bytes)
+        self._enqueue(self.conn, key, make_bytes, strategy)
+        self.namelist.add(key)
+
+    def save_packed(self, key, packed):
+        """save() for a member that is finished already: (payload, crc, size, method) as _pack_member returns it (made by a worker process)"""
+        key = str(key)
+        self.delete_real(key)
+        self._start_writer()
+        self._queue.put((self.conn, key, tuple(packed)))
         self.namelist.add(key)
 
     def update(self, dataset):
@@ -234,6 +246,37 @@ class MapBsn(object):
         os.replace(side, self.fname)
         self.namelist = listed
         self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
+
+
+    def update_table(self, tab):
+        """update() for an int64 table sorted by its first column: the rows of every key appended to what the store holds under it.  Into an
+        EMPTY store - the usual case, the table being kept in memory until the end - all members are made as finished zip entries by host
+        threads of the library (pep_store_tab_members) and written with one write(); 10 000 members one by one cost a second"""
+        tab = np.ascontiguousarray(tab, dtype=np.int64)
+        if len(tab) == 0:
+            return
+        starts = np.concatenate([[0], np.flatnonzero(np.diff(tab[:, 0])) + 1, [len(tab)]]).astype(np.int64)
+        if self.namelist or self.conn.filelist or self.mode == 'r':
+            return self.update([tab[a:b] for a, b in zip(starts[:-1].tolist(), starts[1:].tolist())])
+        from . import _native
+        self._flush()
+        keys = tab[starts[:-1], 0]
+        stamp = time.localtime(time.time())[:6]
+        blob, crc, csize, usize, at = _native.store_tab_members(tab, starts, keys, stamp)
+        zf = self.conn
+        with zf._lock:
+            zf._didModify = True
+            zf.fp.seek(zf.start_dir)
+            base = zf.fp.tell()
+            zf.fp.write(memoryview(blob))
+            zf.start_dir = zf.fp.tell()
+            for name, c, cs, us, off in zip(map(str, keys.tolist()), crc.tolist(), csize.tolist(), usize.tolist(), at.tolist()):
+                zi = zipfile.ZipInfo(name, date_time=stamp)
+                zi.compress_type, zi.external_attr = zipfile.ZIP_DEFLATED if cs != us else zipfile.ZIP_STORED, 0o600 << 16
+                zi.CRC, zi.compress_size, zi.file_size, zi.header_offset = c, cs, us, base + off
+                zf.filelist.append(zi)
+                zf.NameToInfo[name] = zi
+                self.namelist.add(name)
 
 
 # ------------------------------------------------------------------------------------------------ allele strings
@@ -628,7 +671,9 @@ def iter_map_bsn(data):
 # ------------------------------------------------------------------------------------------------ all genomes
 CHUNK = 1000          # arrays per member of the .seq / .mat stores (PEPPAN.py:953, 962)
 BLOCK = 30000         # group ids per member of the .conflicts store (PEPPAN.py:934-947)
-TABLE_EVERY = 500     # genomes between two updates of the gene table store (PEPPAN.py:972)
+TABLE_ROWS = 8 << 20  # gene-table rows kept in memory between two updates of the .tab store (7 x int64 each: 470 MB).  The reference updates every
+#                       500 genomes (PEPPAN.py:972) to bound ITS memory - object rows; an update rewrites the whole archive, and the store's content
+#                       does not depend on how often that happens
 
 
 def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
@@ -641,20 +686,31 @@ def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
             yield r
 
 
-def _all_groups(prefix, clust, jobs, ortho, old_prediction, params, search, ctx, group, per_round):
+def _dist_world(group):
+    dist = sys.modules.get('torch.distributed')            # only a caller that set up a process group has imported it
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return dist, dist.get_world_size(group), dist.get_rank(group)
+    return None, 1, 0
+
+
+def _all_groups(prefix, clust, jobs, ortho, old_prediction, params, search, ctx, group, per_round, pool=None):
     """(job, GenomeGroups) for every genome in job order.  With torch.distributed initialised the genomes are dealt to the ranks in
     blocks of `per_round` (independent units, no data-path collective); every rank maps its block on its own GPU and rank 0
-    gathers the finished per-genome columns - only rank 0 yields, the others just take part."""
+    gathers the finished per-genome columns - only rank 0 yields, the others just take part.  With a pool of worker processes
+    (mapworkers.MapWorkers) a rank's genomes are dealt to its workers instead of being mapped by the rank itself."""
     def local(mine):
+        if pool is not None:
+            return [G for job, G in pool.rounds(mine, max(1, min(per_round, -(-len(mine) // pool.n))))] if mine else []
         out = []
         for (id, taxon, seq), (blastab, overlap) in zip(mine, search(prefix, clust, mine, params) if mine else ()):
             out.append(build_groups(blastab, overlap, seq, ortho, old_prediction, params, ctx))
         return out
-    world, rank = 1, 0
-    dist = sys.modules.get('torch.distributed')            # only a caller that set up a process group has imported it
-    if dist is not None and dist.is_available() and dist.is_initialized():
-        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dist, world, rank = _dist_world(group)
     if world == 1:
+        if pool is not None:
+            for job, G in pool.rounds(jobs, per_round):     # (form 'members': the jobs of a round, what the stores take from it)
+                yield job, G
+            return
         for job, (blastab, overlap) in zip(jobs, search(prefix, clust, jobs, params)):
             yield job, build_groups(blastab, overlap, job[2], ortho, old_prediction, params, ctx)
         return
@@ -681,14 +737,10 @@ class _ConflictBlocks(object):
     def __init__(self, store):
         self.store, self.pending = store, []
 
-    def add(self, pairs):
-        """pairs int[k, 3] = (group, group, class) with store-wide group ids"""
-        if len(pairs) == 0:
-            return
-        src = np.concatenate([pairs[:, 0], pairs[:, 1]])
-        val = np.concatenate([pairs[:, 1], pairs[:, 0]]) * 10 + np.concatenate([pairs[:, 2], pairs[:, 2]])
-        order = np.argsort(src)                     # (the sort the reference applies to the doubled list: equal ids keep ITS order of ties)
-        self.pending.append((src[order], val[order]))
+    def add_sorted(self, src, val):
+        """a genome's conflicts as the doubled list group -> partner * 10 + class, sorted by group, store-wide group ids (StoreBlock)"""
+        if len(src):
+            self.pending.append((src, val))
 
     def write(self, below=None):
         """every block that ends at or before group id `below` (None: everything that is left)"""
@@ -711,14 +763,24 @@ class _MemberQueue(object):
     per-genome column blocks with the range of groups still unwritten; a member is cut as soon as CHUNK groups are there and handed to
     the store's writer thread as a closure, which emits the .npy bytes from the columns (pep_store_*_member) and deflates them."""
 
-    def __init__(self, store, emit):
-        self.store, self.emit, self.parts, self.waiting, self.members = store, emit, [], 0, 0
+    def __init__(self, store, emit, strategy=zlib.Z_DEFAULT_STRATEGY):
+        self.store, self.emit, self.parts, self.waiting, self.members, self.strategy = store, emit, [], 0, 0, strategy
 
     def add(self, block, n_groups):
         self.parts.append([block, 0, n_groups])
         self.waiting += n_groups
         while self.waiting >= CHUNK:
             self._cut(CHUNK)
+
+    def add_finished(self, first_member, packed):
+        """whole members made elsewhere (a worker process): (payload, crc, size, method) each, numbered from `first_member`"""
+        if not packed:
+            return
+        if self.waiting or self.members != first_member:
+            raise RuntimeError('store members out of step: %d groups waiting, member %d expected, %d delivered' % (self.waiting, self.members, first_member))
+        for p in packed:
+            self.store.save_packed(self.members, p)
+            self.members += 1
 
     def close(self):
         if self.waiting:
@@ -737,7 +799,7 @@ class _MemberQueue(object):
                 self.parts[0][1] = lo + n
         self.waiting -= want
         emit = self.emit
-        self.store.save_member(self.members, lambda: emit(take))
+        self.store.save_member(self.members, lambda: emit(take), self.strategy)
         self.members += 1
 
 
@@ -790,42 +852,161 @@ def _emit_seq(take):
     return N.store_seq_member(np.concatenate(data) if before else np.zeros(1, np.uint8), np.concatenate(offs))
 
 
+def _slice_mat(block, lo, hi):
+    """groups [lo, hi) of a _mat_block as a block of their own"""
+    a, b = int(block['row_off'][lo]), int(block['row_off'][hi])
+    ra, rb = int(block['run_off'][a]), int(block['run_off'][b])
+    return dict(cols=[c[a:b] for c in block['cols']], arena=block['arena'][ra:rb], run_off=block['run_off'][a:b + 1] - ra, rid=block['rid'][a:b],
+                row_off=block['row_off'][lo:hi + 1] - a, score_is_int=block['score_is_int'])
+
+
+def _slice_seq(part, lo, hi):
+    packed, pack_off = part
+    a, b = int(pack_off[lo]), int(pack_off[hi])
+    return packed[a:b], pack_off[lo:hi + 1] - a
+
+
+def round_members(blocks, taxa, first, save_seq):
+    """What the stores take from a ROUND of genomes whose first group has the store-wide id `first` (blocks: the genomes' StoreBlocks in
+    job order, taxa: their taxon ids), made where the round was mapped - a worker process:
+      n, first        groups of the round, id of its first
+      table           int64[n, 7] gene-table rows, ids store-wide, taxon filled in
+      c_src, c_val    the conflicts, ids store-wide
+      mat, seq        per member store: head - column blocks [(block, groups)] of the ids in front of the round's first member boundary (they
+                      complete the member that is open in front of the round) -, first_member + members - every member that lies inside the round,
+                      FINISHED (payload, crc, size, method: pickle stream emitted, deflated) -, tail - the ids behind the last boundary"""
+    n_each = [B.n for B in blocks]
+    end = first + sum(n_each)
+    b0 = min(end, -(-first // CHUNK) * CHUNK)
+    b1 = max(b0, end // CHUNK * CHUNK)
+    base = np.concatenate([[first], first + np.cumsum(n_each)]).tolist()
+
+    def takes(parts, a, b):
+        out = []
+        for part, lo_id, n in zip(parts, base, n_each):
+            lo, hi = max(a, lo_id), min(b, lo_id + n)
+            if lo < hi:
+                out.append((part, lo - lo_id, hi - lo_id))
+        return out
+
+    def store(parts, cut, emit, strategy):
+        jobs = [_packers().submit(_pack_member, (lambda take: lambda: emit(take))(takes(parts, m, m + CHUNK)), strategy) for m in range(b0, b1, CHUNK)]
+        return dict(head=[(cut(part, lo, hi), hi - lo) for part, lo, hi in takes(parts, first, b0)], first_member=b0 // CHUNK,
+                    members=[j.result() for j in jobs], tail=[(cut(part, lo, hi), hi - lo) for part, lo, hi in takes(parts, b1, end)])
+    rows, src, val = [], [], []
+    for B, taxon, lo_id in zip(blocks, taxa, base):
+        if B.n == 0:
+            continue
+        B.table[:, 1] = taxon
+        B.table[:, 5] += lo_id
+        rows.append(B.table)
+        src.append(B.c_src + lo_id)
+        val.append(B.c_val + 10 * lo_id)
+    z = np.zeros(0, dtype=np.int64)
+    return dict(n=end - first, first=first, table=np.vstack(rows) if rows else np.zeros([0, 7], dtype=np.int64), c_src=np.concatenate(src) if src else z, c_val=np.concatenate(val) if val else z,
+                mat=store([B.mat for B in blocks], _slice_mat, _emit_mat, zlib.Z_DEFAULT_STRATEGY),
+                seq=store([(B.packed, B.pack_off) for B in blocks], _slice_seq, _emit_seq, zlib.Z_HUFFMAN_ONLY) if save_seq else None)
+
+
+class StoreBlock(object):
+    """What the four stores take from ONE genome, with group ids still local to the genome (0 .. n-1): everything about a genome's groups
+    that does not depend on the genomes in front of it.  Made where the groups are made - by a worker process when there are workers - so
+    that the process that keeps the stores only adds the genome's first group id and cuts members:
+      table             int64[n, 7]   the gene table's rows [gene, taxon (filled in by the keeper), score, identity, identity, LOCAL group id,
+                                      fragments], x 1e4 where fractional, best score first in the order the reference's object sort gives
+      mat               columns of the stored hit rows (_mat_block)
+      packed, pack_off  the packed alleles
+      c_src, c_val      the conflicts as the doubled, sorted list: group -> partner * 10 + class, both LOCAL"""
+    __slots__ = ('n', 'contig', 'table', 'mat', 'packed', 'pack_off', 'c_src', 'c_val')
+
+    def __init__(self, G):
+        n = self.n = len(G)
+        self.contig = int(G.contig[0]) if n else -1
+        self.packed, self.pack_off = G.packed, G.pack_off
+        self.mat = _mat_block(G) if n else None
+        s4 = G.score * 10000
+        order = np.argsort(-s4.astype(object))       # (as the reference sorts its object column: the same order among equal scores)
+        i4 = (G.iden * 10000).astype(np.int64)
+        rows = np.stack([G.gene, np.zeros(n, dtype=np.int64), s4.astype(np.int64), i4, i4, np.arange(n, dtype=np.int64),
+                         np.diff(G.row_off).astype(np.uint8).astype(np.int64)], axis=1)
+        self.table = rows[order]
+        pairs = np.asarray(G.ovl, dtype=np.int64)
+        src = np.concatenate([pairs[:, 0], pairs[:, 1]])
+        val = np.concatenate([pairs[:, 1], pairs[:, 0]]) * 10 + np.concatenate([pairs[:, 2], pairs[:, 2]])
+        order = np.argsort(src)                      # (the sort the reference applies to the doubled list: equal ids keep ITS order of ties)
+        self.c_src, self.c_val = src[order], val[order]
+
+    def __getstate__(self):
+        return tuple(getattr(self, k) for k in self.__slots__)
+
+    def __setstate__(self, state):
+        for k, v in zip(self.__slots__, state):
+            setattr(self, k, v)
+
+
 class _StoreWriter(object):
     """what get_map_bsn keeps between genomes: the group counter and the unwritten parts of the four stores"""
 
     def __init__(self, conn, seq_conn, mat_conn, clf_conn, save_seq):
         self.conn = conn
-        self.n_group, self.table = 0, []
+        self.n_group, self.table, self.table_rows, self.t_table = 0, [], 0, 0.
         self.conflicts = _ConflictBlocks(clf_conn)
-        self.seqs = _MemberQueue(seq_conn, _emit_seq) if save_seq else None
+        self.seqs = _MemberQueue(seq_conn, _emit_seq, zlib.Z_HUFFMAN_ONLY) if save_seq else None
         self.mats = _MemberQueue(mat_conn, _emit_mat)
 
     def add(self, G, taxon):
-        n, first = len(G), self.n_group
+        """the next genome's groups: a StoreBlock, or the GenomeGroups one is made from"""
+        B = G if isinstance(G, StoreBlock) else StoreBlock(G)
+        n, first = B.n, self.n_group
+        if n == 0:
+            return
         self.n_group += n
-        if len(G.ovl):
-            pairs = G.ovl.astype(np.int64)
-            pairs[:, :2] += first
-            self.conflicts.add(pairs)
+        if len(B.c_src):
+            self.conflicts.add_sorted(B.c_src + first, B.c_val + 10 * first)
             self.conflicts.write(below=self.n_group)
         if self.seqs is not None:
-            self.seqs.add((G.packed, G.pack_off), n)
-        self.mats.add(_mat_block(G), n)
-        # the gene table's rows [gene, taxon, score, identity, identity, group id, fragments] x 1e4 where fractional, best score first
-        s4 = G.score * 10000
-        order = np.argsort(-s4.astype(object))       # (as the reference sorts its object column: the same order among equal scores)
-        i4 = (G.iden * 10000).astype(np.int64)
-        rows = np.stack([G.gene, np.full(n, taxon, dtype=np.int64), s4.astype(np.int64), i4, i4, np.arange(first, first + n, dtype=np.int64),
-                         np.diff(G.row_off).astype(np.uint8).astype(np.int64)], axis=1)
-        self.table.append(rows[order])
+            self.seqs.add((B.packed, B.pack_off), n)
+        self.mats.add(B.mat, n)
+        rows = B.table
+        rows[:, 1] = taxon
+        rows[:, 5] += first
+        self.table.append(rows)
+        self.table_rows += n
+        if self.table_rows >= TABLE_ROWS:
+            self.write_table()
+
+    def add_round(self, P):
+        """the next round of genomes as round_members made it"""
+        if P['first'] != self.n_group:
+            raise RuntimeError('a round of genomes starts at group %d, the stores are at %d' % (P['first'], self.n_group))
+        if P['n'] == 0:
+            return
+        self.n_group += P['n']
+        if len(P['c_src']):
+            self.conflicts.add_sorted(P['c_src'], P['c_val'])
+            self.conflicts.write(below=self.n_group)
+        for q, part in ((self.seqs, P['seq']), (self.mats, P['mat'])):
+            if q is None:
+                continue
+            for block, n in part['head']:
+                q.add(block, n)
+            q.add_finished(part['first_member'], part['members'])
+            for block, n in part['tail']:
+                q.add(block, n)
+        self.table.append(P['table'])
+        self.table_rows += P['n']
+        if self.table_rows >= TABLE_ROWS:
+            self.write_table()
 
     def write_table(self):
         if not self.table:
             return
+        t0 = time.perf_counter()
         tab = np.vstack(self.table)
         tab = tab[np.argsort(tab[:, 0], kind='stable')]
-        self.conn.update(np.split(tab, np.flatnonzero(np.diff(tab[:, 0])) + 1))
-        self.table = []
+        self.conn.update_table(tab)
+        self.table, self.table_rows = [], 0
+        self.t_table += time.perf_counter() - t0
 
     def close(self):
         self.write_table()
@@ -836,7 +1017,7 @@ class _StoreWriter(object):
 
 
 def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_conn, mat_conn, clf_conn, saveSeq, params, search=None, ctx=None,
-                group=None, genomes_per_round=64, timing=None):
+                group=None, genomes_per_round=64, timing=None, workers=None):
     """genomes: {contig id: [taxon id, sequence]} -> fills the four MapBsn stores like PEPPAN.py:907-989:
       conn      gene id -> int rows [gene, taxon, score*1e4, ident*1e4, ident*1e4, group id, n fragments], best score first
       seq_conn  chunk no -> object array of packed alleles (only with saveSeq)
@@ -846,7 +1027,13 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
     Under torch.distributed (one process per GPU) the genomes are sharded over the ranks in blocks of `genomes_per_round`; rank 0
     writes the stores (the other ranks pass None for them), whose contents do not depend on the number of ranks.
     No Python object is made for a stored hit row: the groups of a genome stay columns (GenomeGroups) and the members of the .mat /
-    .seq stores are emitted from them as .npy pickle streams by host C++ on the stores' writer threads."""
+    .seq stores are emitted from them as .npy pickle streams by host C++ on the stores' writer threads.
+    `workers`: a number of worker processes or an open mapworkers.MapWorkers - the reference's pool of forked workers (PEPPAN.py:922):
+    rounds of genomes are searched and grouped by the workers, each with a HIP context of its own on this process's device; they also make
+    the .mat / .seq members that lie inside their rounds, and this process only appends to the stores.  A mapped genome costs ten times
+    more host than GPU time: eight workers map five times as many genomes per second on one GPU.  Default (None): min(8, params['n_thread'])
+    workers - the size of the reference's pool - from 64 genomes on when the caller's params carry `n_thread`, otherwise everything in
+    this process (0 / 1 say so explicitly)."""
     if len(genomes) == 0:
         raise ValueError('get_map_bsn: no genome to map against')
     taxa = {}
@@ -858,9 +1045,25 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         old_prediction = MapBsn(old_prediction)            # opened once, read by every genome (the reference opens it per genome, PEPPAN.py:870)
     per_round = max(1, int(genomes_per_round))
     searcher = search or (lambda *a: _gpu_search(*a, genomes_per_batch=per_round))
+    pool, own_pool = None, False
+    if workers is None and search is None and len(jobs) >= 64:
+        workers = min(8, int(params.get('n_thread', 0) or 0))          # the reference's pool has n_thread workers (PEPPAN.py:1841); a GPU feeds about eight
+    if workers is not None and not (isinstance(workers, int) and workers <= 1):
+        from .mapworkers import MapWorkers
+        pool, own_pool = (workers, False) if isinstance(workers, MapWorkers) else (MapWorkers(int(workers)), True)
+        per_round = max(min(4, per_round), min(per_round, -(-len(jobs) // (4 * pool.n))))      # four rounds per worker or more: the last ones even the load out
+        try:
+            from . import _native
+            pool.setup(prefix, clust, orthoGroup, old_prediction, params, search=search, per_batch=per_round,
+                       ctx_class=None if ctx is None or isinstance(ctx, _native.Context) else type(ctx), save_seq=saveSeq,
+                       form='members' if _dist_world(group)[1] == 1 else 'stores')     # (under torch.distributed a rank does not know its rounds' first ids)
+        except BaseException:
+            if own_pool:
+                pool.close()
+            raise
     stores = _StoreWriter(conn, seq_conn, mat_conn, clf_conn, saveSeq)
     clock = time.perf_counter
-    spent = dict(stores=0., gene_table=0.)
+    spent = dict(stores=0.)
     # The stores are fed by a thread of their own, genome by genome in job order: the caller's thread goes straight back to the next
     # genome's search / filters / K12 and never waits for an archive (handing a genome to the stores took 16 ms of a 44 ms genome while
     # it shared a thread with them: queues filling up behind the deflating writers).  At most two rounds of genomes wait in the queue.
@@ -876,14 +1079,16 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
             try:
                 id, G = item
                 t0 = clock()
-                if len(G):
-                    stores.add(G, genomes.get(int(G.contig[0]), [-1])[0])
-                logger('Merged {0}.{1}'.format(prefix, id))
-                t1 = clock()
-                if id % TABLE_EVERY == TABLE_EVERY - 1:
-                    stores.write_table()
-                spent['stores'] += t1 - t0
-                spent['gene_table'] += clock() - t1
+                if isinstance(G, dict):             # a round of genomes whose members the workers made: id = the round's jobs
+                    stores.add_round(G)
+                    for job in id:
+                        logger('Merged {0}.{1}'.format(prefix, job[0]))
+                else:
+                    B = G if isinstance(G, StoreBlock) else StoreBlock(G)
+                    if B.n:
+                        stores.add(B, genomes.get(B.contig, [-1])[0])
+                    logger('Merged {0}.{1}'.format(prefix, id))
+                spent['stores'] += clock() - t0
             except BaseException as e:
                 failure.append(e)
 
@@ -891,18 +1096,20 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
     worker.start()
     t_start = clock()
     try:
-        for (id, taxon, seq), G in _all_groups(prefix, clust, jobs, ortho, old_prediction, params, searcher, ctx, group, per_round):
+        for job, G in _all_groups(prefix, clust, jobs, ortho, old_prediction, params, searcher, ctx, group, per_round, pool):
             if failure:
                 break
-            inbox.put((id, G))
+            inbox.put((job, G) if isinstance(G, dict) else (job[0], G))
     finally:
         t_groups = clock()
         inbox.put(None)
         worker.join()
+        if own_pool:
+            pool.close()
     if failure:
         raise failure[0]
     t0 = clock()
     stores.close()
     if timing is not None:      # seconds: search + filters + build_groups on the caller's thread; then, on the stores' thread and overlapped with it,
         #                         handing groups to the stores and the gene table updates; what was left to wait for at the end
-        timing.update(groups=t_groups - t_start, stores=spent['stores'], gene_table=spent['gene_table'], drain=clock() - t_groups)
+        timing.update(groups=t_groups - t_start, stores=spent['stores'], gene_table=stores.t_table, drain=clock() - t_groups)

@@ -1,0 +1,253 @@
+"""Worker processes for the genes -> genomes mapping: the reference's `pool.imap_unordered(iter_map_bsn, ...)` over its forked
+workers (PEPPAN.py:907-923), for a path whose search runs on the GPU.
+
+One genome costs about 1.5 ms of GPU time and ten times that of host bookkeeping (filters, overlaps, `build_groups`): ONE process keeps
+an MI355X busy for a tenth of the time.  `MapWorkers(n)` starts n processes that each own a HIP context (stream, work space) on the same
+device; rounds of genomes are dealt to whichever worker is free, every worker runs the batched search and `build_groups` for its round,
+and the caller gets the per-genome columns (`GenomeGroups`) back IN JOB ORDER - what the stores need (PEPPAN.py:923, the in-order
+variant).  The stores do not depend on the number of workers: a genome's groups do not depend on which other genomes shared its search
+(tests/test_gpu_parity.py::test_get_map_bsn_batched_equals_per_genome_workers, ::test_map_workers_write_the_same_stores).
+
+The workers are started as `python -m peppan_amd.mapworkers <socket>` (not forked: the parent may hold a HIP context; not through
+multiprocessing's spawn either, which would import the caller's main module a second time) and talk over a unix socket with
+multiprocessing.connection's pickled messages:
+    parent -> worker   ('setup', {...})        ('round', k, jobs)                          ('emit', k, first group id) | ('drop', k)     ('stop',)
+    worker -> parent   ('ready', pid)          ('done', k, [GenomeGroups or StoreBlock])   ('error', k, traceback text)
+                                               ('counts', k, groups per genome)  - form 'members' only, answered by 'emit' / 'drop' -
+                                               ('done', k, what the stores take from the round: mapbsn.round_members)
+
+Form 'members' moves the stores' work to the workers as well.  The .mat / .seq stores hold 1 000 consecutive groups per member, groups
+numbered through all genomes - a round's first id is known once every round in front of it has been mapped.  So a worker reports its
+round's group counts, is told the round's first id as soon as the rounds in front have reported theirs, and then makes every member that
+lies inside its round completely (pickle stream, deflate, CRC: mapbsn.round_members); only the groups in front of its first and behind its
+last member boundary travel as columns.  The keeping process appends finished payloads: 1.5 ms per genome instead of 7.
+"""
+import os
+import pickle
+import subprocess
+import sys
+import tempfile
+import threading
+import traceback
+from multiprocessing.connection import Client, Listener
+
+__all__ = ['MapWorkers']
+
+
+def _serve(address, authkey):
+    """the worker's life: set-ups and rounds until 'stop' or until the parent goes away"""
+    conn = Client(address, family='AF_UNIX', authkey=authkey)
+    state = {}
+    while True:
+        try:
+            msg = conn.recv()
+        except EOFError:
+            return
+        if msg[0] == 'stop':
+            return
+        if msg[0] == 'setup':
+            try:
+                from . import mapbsn
+                a = msg[1]
+                old = a['old_prediction']
+                if state.get('old_is_mine'):
+                    state['old'].close()
+                state.update(a, ortho=mapbsn.OrthoRelation(a['orthoGroup']), old=mapbsn.MapBsn(old) if isinstance(old, str) else old,
+                             old_is_mine=isinstance(old, str), ctx=a['ctx_class']() if a['ctx_class'] is not None else None)
+                conn.send(('ready', os.getpid()))
+            except BaseException:
+                conn.send(('error', -1, traceback.format_exc()))
+            continue
+        if msg[0] != 'round':
+            continue                                # (an 'emit' / 'drop' for a round that failed here: nothing is waiting for it)
+        k, jobs = msg[1], msg[2]
+        try:
+            from . import mapbsn
+            search = state['search'] or (lambda *a: mapbsn._gpu_search(*a, genomes_per_batch=state['per_batch']))
+            out = []
+            for (id, taxon, seq), (blastab, overlap) in zip(jobs, search(state['prefix'], state['clust'], jobs, state['params'])):
+                G = mapbsn.build_groups(blastab, overlap, seq, state['ortho'], state['old'], state['params'], state['ctx'])
+                out.append(G if state['form'] == 'groups' else mapbsn.StoreBlock(G))
+            if len(out) != len(jobs):
+                raise RuntimeError('the search returned %d tables for %d genomes' % (len(out), len(jobs)))
+            if state['form'] == 'members':
+                conn.send(('counts', k, [B.n for B in out]))
+                reply = conn.recv()
+                if reply[0] == 'stop':
+                    return
+                out = mapbsn.round_members(out, [job[1] for job in jobs], reply[2], state['save_seq']) if reply[0] == 'emit' else None
+            conn.send(('done', k, out))
+        except EOFError:
+            return
+        except BaseException:
+            conn.send(('error', k, traceback.format_exc()))
+
+
+class MapWorkers(object):
+    """n worker processes on one device.
+
+        with MapWorkers(8) as pool:
+            get_map_bsn(..., workers=pool)          # or workers=8: a pool for the length of that call
+    """
+
+    def __init__(self, n, device=None):
+        self.n = int(n)
+        if self.n < 1:
+            raise ValueError('MapWorkers: at least one worker')
+        self._dir = tempfile.mkdtemp(prefix='pep_workers_')
+        address = os.path.join(self._dir, 's')
+        authkey = os.urandom(16)
+        self._listener = Listener(address, family='AF_UNIX', authkey=authkey)
+        env = dict(os.environ, PEPPAN_WORKER_KEY=authkey.hex(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        if device is not None:
+            env['PEPPAN_HIP_DEVICE'] = str(int(device))
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env['PYTHONPATH'] = os.pathsep.join([root] + [p for p in sys.path if p] + [env.get('PYTHONPATH', '')])     # a search function of the caller's must be importable
+        self._procs, self._conns = [], []
+        try:
+            for _ in range(self.n):
+                self._procs.append(subprocess.Popen([sys.executable, '-m', 'peppan_amd.mapworkers', address], env=env, stdin=subprocess.DEVNULL,
+                                                    stdout=sys.stderr.fileno() if hasattr(sys.stderr, 'fileno') and self._has_fd(sys.stderr) else subprocess.DEVNULL))
+            self._listener._listener._socket.settimeout(120.)
+            for _ in range(self.n):
+                self._conns.append(self._listener.accept())
+        except BaseException:
+            self.close()
+            raise
+
+    @staticmethod
+    def _has_fd(stream):
+        try:
+            stream.fileno()
+            return True
+        except Exception:
+            return False
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def close(self):
+        for c in self._conns:
+            try:
+                c.send(('stop',))
+                c.close()
+            except Exception:
+                pass
+        for p in self._procs:
+            try:
+                p.wait(timeout=20)
+            except Exception:
+                p.kill()
+        self._conns, self._procs = [], []
+        if self._listener is not None:
+            self._listener.close()
+            self._listener = None
+        try:
+            os.rmdir(self._dir)
+        except OSError:
+            pass
+
+    def setup(self, prefix, clust, orthoGroup, old_prediction, params, search=None, per_batch=32, ctx_class=None, form='groups', save_seq=True):
+        """what every round of one get_map_bsn call shares.  `search` must be None (the batched GPU search) or a function the workers can
+        import (a module-level function: it is sent by reference); `ctx_class`: None (every worker uses its own HIP context) or an
+        importable class whose instances stand in for one (the CPU tests' oracle-backed context); `form`: 'groups' - the workers return
+        GenomeGroups -, 'stores' - they return what the stores take from a genome (mapbsn.StoreBlock), made on their side - or 'members'
+        (module docstring; `save_seq`: whether there is a .seq store)"""
+        if search is not None:
+            try:
+                pickle.dumps(search)
+            except Exception:
+                raise ValueError('MapWorkers: search must be None or a module-level function (it is sent to the workers by reference)')
+        if not isinstance(old_prediction, str):
+            old_prediction = getattr(old_prediction, 'fname', old_prediction)        # an open MapBsn is reopened by every worker
+        msg = ('setup', dict(prefix=prefix, clust=clust, orthoGroup=orthoGroup, old_prediction=old_prediction, params=dict(params), search=search, per_batch=int(per_batch), ctx_class=ctx_class, form=form, save_seq=bool(save_seq)))
+        self.form = form
+        for c in self._conns:
+            c.send(msg)
+        for c in self._conns:
+            r = c.recv()
+            if r[0] != 'ready':
+                raise RuntimeError('MapWorkers: a worker failed to set up:\n' + r[2])
+
+    def rounds(self, jobs, per_round, first=0):
+        """In job order: (job, GenomeGroups or StoreBlock) for every job - forms 'groups' / 'stores' - or (the round's jobs, what the stores
+        take from the round) for every round - form 'members', `first` being the id of the first group of the first round.  Rounds of
+        `per_round` jobs go to whichever worker is free; at most two rounds per worker are in flight or waiting to be taken."""
+        per_round = max(1, int(per_round))
+        n_rounds = -(-len(jobs) // per_round)
+        members = getattr(self, 'form', 'groups') == 'members'
+        cond = threading.Condition()
+        slots = threading.Semaphore(2 * self.n)
+        state = dict(next=0, stop=False)
+        results, counts, first_of = {}, {}, {0: int(first)}
+
+        def feeder(conn):
+            while True:
+                slots.acquire()
+                with cond:
+                    k = state['next']
+                    if k >= n_rounds or state['stop']:
+                        slots.release()
+                        return
+                    state['next'] = k + 1
+                try:
+                    conn.send(('round', k, jobs[k * per_round:(k + 1) * per_round]))
+                    msg = conn.recv()
+                    if msg[0] == 'counts':
+                        with cond:
+                            counts[k] = sum(msg[2])
+                            j = k
+                            while j in counts and j in first_of:            # (every round whose predecessors have all reported now knows its first id)
+                                first_of[j + 1] = first_of[j] + counts[j]
+                                j += 1
+                            cond.notify_all()
+                            while k not in first_of and not state['stop']:
+                                cond.wait()
+                            go = ('emit', k, first_of[k]) if k in first_of else ('drop', k)
+                        conn.send(go)
+                        msg = conn.recv()
+                        if go[0] == 'drop':
+                            msg = ('dropped', k, None)
+                except (EOFError, OSError) as e:
+                    msg = ('error', k, 'a mapping worker went away: %r' % (e,))
+                with cond:
+                    results[k] = msg
+                    if msg[0] != 'done':
+                        state['stop'] = True                                # (rounds behind a failed one will never learn their first id)
+                    cond.notify_all()
+                if msg[0] != 'done':
+                    return
+
+        threads = [threading.Thread(target=feeder, args=(c,), daemon=True) for c in self._conns[:max(1, min(self.n, n_rounds))]]
+        for t in threads:
+            t.start()
+        try:
+            for k in range(n_rounds):
+                with cond:
+                    while k not in results:
+                        cond.wait()
+                    msg = results.pop(k)
+                if msg[0] != 'done':
+                    raise RuntimeError('MapWorkers: round %d failed in a worker:\n%s' % (k, msg[2]))
+                mine = jobs[k * per_round:(k + 1) * per_round]
+                if members:
+                    yield mine, msg[2]
+                else:
+                    for job, G in zip(mine, msg[2]):
+                        yield job, G
+                slots.release()
+        finally:
+            with cond:
+                state['stop'] = True
+                cond.notify_all()
+            for _ in threads:
+                slots.release()                 # (a feeder waiting for a slot sees the flag and leaves)
+            for t in threads:
+                t.join()
+
+
+if __name__ == '__main__':
+    _serve(sys.argv[1], bytes.fromhex(os.environ.pop('PEPPAN_WORKER_KEY')))

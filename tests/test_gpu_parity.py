@@ -963,6 +963,60 @@ def test_get_map_bsn_batched_equals_per_genome_workers(tmp_path, monkeypatch):
             assert hits and max(hits) >= 0.9
 
 
+def test_map_workers_write_the_same_stores(tmp_path, monkeypatch):
+    """the reference's pool of workers (PEPPAN.py:907-923) on one GPU: worker processes with HIP contexts of their own map rounds of genomes and
+    make the stores' members; the four stores are those of the process mapping everything itself - whatever the number of workers and the size
+    of a round (members of 1 000 groups are made inside rounds, completed across rounds, and left open at the end)"""
+    import io, contextlib
+    from peppan_amd import mapbsn, synth
+    from peppan_amd.mapworkers import MapWorkers
+    monkeypatch.chdir(tmp_path)
+    names, seqs = synth.make_genes(1500, 0, seed=29, family=3)
+    _write_fasta('m.clust.exemplar', [str(i) for i in range(len(seqs))], seqs)
+    worlds = synth.make_genomes(seqs, 11, seed=78)
+    genomes = {}
+    with mapbsn.MapBsn('m.old_prediction.npz', 'w') as op:
+        for g, (gname, contig, ann) in enumerate(worlds):
+            genomes[5000 + g] = [900 + g, contig.decode()]
+            op.save(5000 + g, np.array([[k, s, e, strand, 1] for k, s, e, strand in ann[::2]], dtype=object))
+    np.save('m.self_bsn.npy', np.array([[0, 1, 9000], [4, 5, -2], [8, 9, 0]], dtype=int))
+    params = dict(noDiamond=False, match_identity=0.65, match_frag_len=50, match_frag_prop=0.25, link_gap=600, link_diff=1.5, gtable=11,
+                  match_len=250., match_len1=100., match_len2=400., match_prop=0.5, match_prop1=0.8, match_prop2=0.4)
+
+    def run(tag, save_seq, **kw):
+        fn = ['%s.%s.npz' % (tag, x) for x in ('tab', 'seq', 'mat', 'conflicts')]
+        with contextlib.redirect_stderr(io.StringIO()):
+            with mapbsn.MapBsn(fn[0], 'w') as c0, mapbsn.MapBsn(fn[1], 'w') as c1, mapbsn.MapBsn(fn[2], 'w') as c2, mapbsn.MapBsn(fn[3], 'w') as c3:
+                mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, save_seq, params, **kw)
+        out = {}
+        for x, f in zip(('tab', 'seq', 'mat', 'conflicts'), fn):
+            with mapbsn.MapBsn(f) as c:
+                out[x] = {k: c.get(k) for k in sorted(c.keys())}
+        return out
+
+    def same(a, b):
+        assert {x: sorted(v) for x, v in a.items()} == {x: sorted(v) for x, v in b.items()}
+        for x in a:
+            for k in a[x]:
+                u, v = a[x][k], b[x][k]
+                if u.dtype != object:
+                    assert u.dtype == v.dtype and np.array_equal(u, v), (x, k)
+                else:
+                    assert len(u) == len(v)
+                    for p, q in zip(u, v):
+                        assert p.dtype == q.dtype and p.shape == q.shape and p.tolist() == q.tolist(), (x, k)
+    want = run('self', True)
+    assert sum(len(v) for v in want['mat'].values()) > 3000 and len(want['mat']) >= 4            # several members of 1 000 groups
+    with MapWorkers(3) as pool:
+        same(want, run('w3', True, workers=pool, genomes_per_round=2))
+        same(want, run('w3b', True, workers=pool, genomes_per_round=64))          # one round
+        no_seq = run('w3c', False, workers=pool, genomes_per_round=3)
+        assert no_seq['seq'] == {}
+        same({k: v for k, v in want.items() if k != 'seq'}, {k: v for k, v in no_seq.items() if k != 'seq'})
+    same(want, run('w2', True, workers=2, genomes_per_round=1))
+
+
+
 def _random_loci(rng, n_groups, contig_len=20000, n_contigs=3):
     """random K12 input: contigs with N runs and planted stops, groups of 1-3 rows with indels, both strands"""
     from peppan_amd import _native as N

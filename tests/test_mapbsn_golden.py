@@ -59,6 +59,36 @@ def test_store_roundtrip(tmp_path):
     assert z['5'].tolist() == [[5, 1, 1], [5, 2, 2], [5, 3, 3]]
 
 
+def test_gene_table_written_by_the_library_reads_like_update(tmp_path):
+    """MapBsn.update_table into an empty archive (all members made as zip entries by pep_store_tab_members) against MapBsn.update
+    (PEPPAN.py:91-113) member by member: same keys, same arrays, through MapBsn, numpy and a plain zipfile check; then a second table on
+    top of the first (members grow, new ones appear)"""
+    import zipfile
+    rng = np.random.default_rng(3)
+    sizes = np.concatenate([rng.integers(1, 40, size=700), [600, 1, 2000]])                  # members below and above the 4 KiB where deflating starts
+    keys = np.sort(rng.choice(10 ** 6, size=len(sizes), replace=False))
+    tab = np.concatenate([np.column_stack([np.full(k, key), rng.integers(-10 ** 12, 10 ** 12, size=[k, 6])]) for key, k in zip(keys, sizes)]).astype(np.int64)
+    more = np.concatenate([np.column_stack([np.full(3, key), rng.integers(0, 99, size=[3, 6])]) for key in list(keys[::50]) + [10 ** 6 + 5]]).astype(np.int64)
+    more = more[np.argsort(more[:, 0], kind='stable')]
+    split = lambda t: np.split(t, np.flatnonzero(np.diff(t[:, 0])) + 1)
+    a, b = str(tmp_path / 'a.npz'), str(tmp_path / 'b.npz')
+    with mapbsn.MapBsn(a, 'w') as fast, mapbsn.MapBsn(b, 'w') as slow:
+        fast.update_table(tab)
+        slow.update(split(tab))
+        assert fast.keys() == slow.keys() == {str(k) for k in keys}
+        for k in keys[::17]:
+            assert np.array_equal(fast.get(k), slow.get(k)) and fast.get(k).dtype == np.int64
+        fast.update_table(more)
+        slow.update(split(more))
+    za, zb = dict(np.load(a)), dict(np.load(b))
+    assert sorted(za) == sorted(zb) and len(za) == len(keys) + 1
+    for k in za:
+        assert za[k].dtype == zb[k].dtype == np.int64 and np.array_equal(za[k], zb[k]), k
+    assert len(za[str(keys[0])]) == sizes[0] + 3
+    with zipfile.ZipFile(a) as z:
+        assert z.testzip() is None
+
+
 def test_decode_encode():
     g = load_golden('g14_mapbsn.json')
     seqs = np.array(g['decodeSeq_in'], dtype=np.uint8)
@@ -119,6 +149,33 @@ def test_get_map_bsn(world, tmp_path, save_seq):
         assert got == exp[x], x
 
 
+def test_get_map_bsn_with_worker_processes(world, tmp_path):
+    """the reference's pool of workers (PEPPAN.py:907-923): two worker processes, one genome per round, the rounds finishing in any
+    order - the stores are G15's.  The workers import the canned search and the oracle-backed context by reference."""
+    from map_pool_helpers import canned_search
+    from peppan_amd.mapworkers import MapWorkers
+    g, old_fn, bsn_fn = world
+    want = load_golden('g15_getmapbsn.json')
+    genomes = {int(c): [want['genomes'][c], s] for case in g['cases'] for c, s in case['contigs'].items()}
+    with MapWorkers(2) as pool:
+        for rep, workers in enumerate((pool, pool, 2)):                   # a pool serves several calls; a number makes one for the call
+            names = [str(tmp_path / ('w%d.%s.npz' % (rep, x))) for x in ('tab', 'seq', 'mat', 'conflicts')]
+            with mapbsn.MapBsn(names[0], 'w') as c0, mapbsn.MapBsn(names[1], 'w') as c1, mapbsn.MapBsn(names[2], 'w') as c2, mapbsn.MapBsn(names[3], 'w') as c3:
+                mapbsn.get_map_bsn(str(tmp_path / 'm'), 'CL', genomes, bsn_fn, old_fn, c0, c1, c2, c3, True, dict(g['params']), search=canned_search, ctx=OracleContext(),
+                                   genomes_per_round=1, workers=workers)
+            exp = want['stores']['saveSeq_1']
+            for x, fn in zip(('tab', 'seq', 'mat', 'conflicts'), names):
+                with mapbsn.MapBsn(fn) as c:
+                    assert {k: plain(c.get(k)) for k in sorted(c.keys())} == exp[x], (rep, x)
+        # a search that cannot be sent to the workers, and a round that fails in a worker, are errors of the call - not a hang
+        with pytest.raises(ValueError, match='module-level'):
+            pool.setup('m', 'CL', bsn_fn, old_fn, dict(g['params']), search=lambda *a: iter(()))
+        pool.setup(str(tmp_path / 'm'), 'CL', bsn_fn, old_fn, dict(g['params']), search=canned_search, ctx_class=OracleContext)
+        with pytest.raises(RuntimeError, match='failed in a worker'):
+            list(pool.rounds([(7, 0, [])], 1))                            # no such genome in the canned search
+        assert [j[0] for j, G in pool.rounds([(i, 0, [[int(c), s] for c, s in g['cases'][i]['contigs'].items()]) for i in (2, 0)], 1)] == [2, 0]    # still alive and in step
+
+
 def _random_groups(rng, genome, n_groups, n_genes):
     """GenomeGroups of one made-up genome: 1-3 hit rows per group, random conflicts between its groups"""
     from peppan_amd.hittable import HitTable
@@ -145,8 +202,8 @@ def _random_groups(rng, genome, n_groups, n_genes):
                                rng.integers(0, 125, size=int(pack_off[-1])).astype(np.uint8), pack_off, T, row_off, ovl)
 
 
-@pytest.mark.parametrize('save_seq', [True, False])
-def test_store_writer_against_the_definition_of_the_stores(tmp_path, monkeypatch, save_seq):
+@pytest.mark.parametrize('save_seq,by_round', [(True, 0), (False, 0), (True, 3), (False, 5), (True, 1)])
+def test_store_writer_against_the_definition_of_the_stores(tmp_path, monkeypatch, save_seq, by_round):
     """the four stores for 23 made-up genomes with small member sizes, so that members are cut inside and across genomes, conflict blocks
     close in the middle of a genome and the gene table is updated several times - against the stores' definition stated over ALL groups at once"""
     monkeypatch.setattr(mapbsn, 'CHUNK', 7)
@@ -156,11 +213,21 @@ def test_store_writer_against_the_definition_of_the_stores(tmp_path, monkeypatch
     names = [str(tmp_path / ('w.%s.npz' % x)) for x in ('tab', 'seq', 'mat', 'conflicts')]
     with mapbsn.MapBsn(names[0], 'w') as c0, mapbsn.MapBsn(names[1], 'w') as c1, mapbsn.MapBsn(names[2], 'w') as c2, mapbsn.MapBsn(names[3], 'w') as c3:
         w = mapbsn._StoreWriter(c0, c1, c2, c3, save_seq)
-        for g, G in enumerate(world):
-            if len(G):
-                w.add(G, 500 + g)
-            if g % 5 == 4:
-                w.write_table()
+        import pickle
+        if by_round:
+            # rounds of genomes as the worker processes deliver them: the members inside a round finished, the groups around them as columns
+            for lo in range(0, len(world), by_round):
+                P = mapbsn.round_members([mapbsn.StoreBlock(G) for G in world[lo:lo + by_round]], [500 + g for g in range(lo, lo + by_round)], w.n_group, save_seq)
+                assert all(isinstance(m, tuple) and len(m) == 4 for m in P['mat']['members'])
+                w.add_round(pickle.loads(pickle.dumps(P)))
+                if lo % 2:
+                    w.write_table()
+        else:
+            for g, G in enumerate(world):
+                if len(G):
+                    w.add(G if g % 2 else pickle.loads(pickle.dumps(mapbsn.StoreBlock(G))), 500 + g)      # (what a worker process sends / what the process itself makes)
+                if g % 5 == 4:
+                    w.write_table()
         w.close()
     # ---- the definition
     groups, first = [], []

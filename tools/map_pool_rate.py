@@ -1,0 +1,12 @@
+"""get_map_bsn with worker processes on one GPU: genomes per second of a started pool (second pass over the same set) by number of workers.
+usage: python tools/map_pool_rate.py [genomes] [workers ...]"""
+import sys, argparse
+sys.path.insert(0, '.')
+import bench
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+ws = [int(x) for x in sys.argv[2:]] or [4, 8, 16]
+args = argparse.Namespace(genes=10000, warmup=0)
+for w in ws:
+    r = bench.map_strong(args, 0, 1, 0, n, workers=w, warm=True)
+    print('workers %2d: %d genomes in %.2f s = %.1f genomes/s (first pass %.2f s, start-up %.2f s)  %s' % (
+        w, n, r['seconds'], n / r['seconds'], r['first_pass_s'], r['workers_startup_s'], {k: round(v, 2) for k, v in r['phase_s_rank0'].items()}), flush=True)
