@@ -52,8 +52,9 @@ def _packers():
 
 def _pack_member(data, strategy=zlib.Z_DEFAULT_STRATEGY):
     """data (bytes, or a callable returning them) -> (payload, crc, size, method).  Members are read back whole either way; deflating
-    a few hundred bytes costs more than it saves (zlib set-up per member).  strategy: zlib's - Z_HUFFMAN_ONLY for members known to hold no
-    repeats (the packed alleles of the .seq store: entropy coding alone gives 0.75 at 120 MB/s where level 1's match search gives 0.77 at 30)"""
+    a few hundred bytes costs more than it saves (zlib set-up per member).  strategy: zlib's.  (Z_HUFFMAN_ONLY was tried for the packed alleles
+    of the .seq store: four times as fast and as small on the alleles of ONE gene set, but a genome's groups repeat a locus once per paralogous
+    exemplar it matches, and level 1's match search makes 0.66 of such members where entropy coding alone makes 0.81: the default stays.)"""
     if callable(data):
         data = data()               # a member whose bytes are made here, off the caller's thread (C emitters: no GIL held)
     if len(data) < 4096:
@@ -905,7 +906,7 @@ def round_members(blocks, taxa, first, save_seq):
     z = np.zeros(0, dtype=np.int64)
     return dict(n=end - first, first=first, table=np.vstack(rows) if rows else np.zeros([0, 7], dtype=np.int64), c_src=np.concatenate(src) if src else z, c_val=np.concatenate(val) if val else z,
                 mat=store([B.mat for B in blocks], _slice_mat, _emit_mat, zlib.Z_DEFAULT_STRATEGY),
-                seq=store([(B.packed, B.pack_off) for B in blocks], _slice_seq, _emit_seq, zlib.Z_HUFFMAN_ONLY) if save_seq else None)
+                seq=store([(B.packed, B.pack_off) for B in blocks], _slice_seq, _emit_seq, zlib.Z_DEFAULT_STRATEGY) if save_seq else None)
 
 
 class StoreBlock(object):
@@ -944,6 +945,18 @@ class StoreBlock(object):
             setattr(self, k, v)
 
 
+def _stable_order_of_ids(ids):
+    """np.argsort(ids, kind='stable') for non-negative integer ids: numpy sorts 16-bit keys by radix (stable, linear) - one pass below
+    2^16, two below 2^32 (low half, then high half), against a merge sort of the 64-bit column that takes six times as long"""
+    top = int(ids.max()) if len(ids) else 0
+    if len(ids) == 0 or int(ids.min()) < 0 or top >= 1 << 32:
+        return np.argsort(ids, kind='stable')
+    order = np.argsort((ids & 0xFFFF).astype(np.uint16), kind='stable')
+    if top >= 1 << 16:
+        order = order[np.argsort((ids[order] >> 16).astype(np.uint16), kind='stable')]
+    return order
+
+
 class _StoreWriter(object):
     """what get_map_bsn keeps between genomes: the group counter and the unwritten parts of the four stores"""
 
@@ -951,7 +964,7 @@ class _StoreWriter(object):
         self.conn = conn
         self.n_group, self.table, self.table_rows, self.t_table = 0, [], 0, 0.
         self.conflicts = _ConflictBlocks(clf_conn)
-        self.seqs = _MemberQueue(seq_conn, _emit_seq, zlib.Z_HUFFMAN_ONLY) if save_seq else None
+        self.seqs = _MemberQueue(seq_conn, _emit_seq) if save_seq else None
         self.mats = _MemberQueue(mat_conn, _emit_mat)
 
     def add(self, G, taxon):
@@ -1003,7 +1016,7 @@ class _StoreWriter(object):
             return
         t0 = time.perf_counter()
         tab = np.vstack(self.table)
-        tab = tab[np.argsort(tab[:, 0], kind='stable')]
+        tab = tab[_stable_order_of_ids(tab[:, 0])]
         self.conn.update_table(tab)
         self.table, self.table_rows = [], 0
         self.t_table += time.perf_counter() - t0

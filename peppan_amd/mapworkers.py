@@ -36,14 +36,20 @@ __all__ = ['MapWorkers']
 
 def _serve(address, authkey):
     """the worker's life: set-ups and rounds until 'stop' or until the parent goes away"""
+    import time
     conn = Client(address, family='AF_UNIX', authkey=authkey)
     state = {}
+    clock, spent = time.perf_counter, dict(recv=0., search=0., groups=0., wait_first=0., members=0., send=0., genomes=0)
     while True:
         try:
+            t0 = clock()
             msg = conn.recv()
+            spent['recv'] += clock() - t0
         except EOFError:
             return
         if msg[0] == 'stop':
+            if os.environ.get('PEPPAN_WORKERS_TIMING'):             # seconds this worker spent where (a line per worker on stderr)
+                sys.stderr.write('mapping worker %d: %s\n' % (os.getpid(), ' '.join('%s %.2f' % kv for kv in spent.items())))
             return
         if msg[0] == 'setup':
             try:
@@ -64,19 +70,30 @@ def _serve(address, authkey):
         try:
             from . import mapbsn
             search = state['search'] or (lambda *a: mapbsn._gpu_search(*a, genomes_per_batch=state['per_batch']))
-            out = []
+            out, t0 = [], clock()
             for (id, taxon, seq), (blastab, overlap) in zip(jobs, search(state['prefix'], state['clust'], jobs, state['params'])):
+                t1 = clock()
                 G = mapbsn.build_groups(blastab, overlap, seq, state['ortho'], state['old'], state['params'], state['ctx'])
                 out.append(G if state['form'] == 'groups' else mapbsn.StoreBlock(G))
+                t2 = clock()
+                spent['search'] += t1 - t0
+                spent['groups'] += t2 - t1
+                t0 = t2
+            spent['genomes'] += len(out)
             if len(out) != len(jobs):
                 raise RuntimeError('the search returned %d tables for %d genomes' % (len(out), len(jobs)))
             if state['form'] == 'members':
                 conn.send(('counts', k, [B.n for B in out]))
                 reply = conn.recv()
+                t1 = clock()
                 if reply[0] == 'stop':
                     return
                 out = mapbsn.round_members(out, [job[1] for job in jobs], reply[2], state['save_seq']) if reply[0] == 'emit' else None
+                spent['wait_first'] += t1 - t0
+                spent['members'] += clock() - t1
+            t0 = clock()
             conn.send(('done', k, out))
+            spent['send'] += clock() - t0
         except EOFError:
             return
         except BaseException:
