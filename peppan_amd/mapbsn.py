@@ -1063,7 +1063,7 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         workers = min(8, int(params.get('n_thread', 0) or 0))          # the reference's pool has n_thread workers (PEPPAN.py:1841); a GPU feeds about eight
     if workers is not None and not (isinstance(workers, int) and workers <= 1):
         from .mapworkers import MapWorkers
-        pool, own_pool = (workers, False) if isinstance(workers, MapWorkers) else (MapWorkers(int(workers)), True)
+        pool, own_pool = (workers, False) if isinstance(workers, MapWorkers) else (MapWorkers(int(workers), device=getattr(ctx, 'device', None)), True)     # (the workers' contexts: on the caller's device)
         per_round = max(min(4, per_round), min(per_round, -(-len(jobs) // (4 * pool.n))))      # four rounds per worker or more: the last ones even the load out
         try:
             from . import _native
