@@ -339,15 +339,18 @@ class RunBlast(object):
             logger('WARNING: {0} of {1} search tools failed: {2}'.format(len(self.failed_tools), len(methods), ', '.join(m for m, _ in self.failed_tools)))
         return tables
 
-    def _post(self, tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end):
+    def _post(self, tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end, rescored=False):
         """everything RunBlast.run does after the tools returned (uberBlast.py:352-376), on the numeric table; the object rows the
-        caller gets are made at the very end"""
+        caller gets are made at the very end.  rescored: the tables carry the rescored identity / score already (run_batch does K7 for all
+        genomes of a batch at once) and only the identity cut is left"""
         T = HitTable.concat(tables)
         if len(T) == 0:
             none = HitTable.empty() if self._as_tables else np.empty([0, 16], dtype=object)
             return (none, np.empty([0, 3], dtype=int)) if return_overlap[0] else none
         T.rid = np.arange(len(T), dtype=np.int64)
-        if re_score:
+        if re_score and rescored:
+            T = T.take(T.iden >= self.min_id)
+        elif re_score:
             T = self._rescore_table(ref, qry, T, re_score, self.min_id, self.table_id)
         if filter[0]:
             T = mapfilters.ovl_filter_table(T, filter[1], filter[2])
@@ -405,6 +408,12 @@ class RunBlast(object):
         self.refSeq, self._batch = combined, (names, groups)
         genome_of = dict(zip(names, groups))
         tables = self._run_tools(methods, None, None)
+        # mode-1 rescoring is a function of the row alone: K7 once per tool over the rows of ALL genomes (a launch and a round trip per genome
+        # otherwise: 84 us of GPU and a synchronisation each, sixteen times per batch), the identity cut stays with the genome's table (_post)
+        batch_rescore = re_score == 1
+        if batch_rescore:
+            for T in tables:
+                self._rescore_table(None, None, T, 1, None, table_id, cut=False)
         # rows of every tool's table by genome (the reference set of row's reference sequence), table order kept inside a genome
         split = []
         for T in tables:
@@ -415,7 +424,7 @@ class RunBlast(object):
         out = []
         for g in range(len(refs)):
             part = [T.take(order[cuts[g]:cuts[g + 1]]) for T, order, cuts in split]
-            out.append(self._post(part, None, None, re_score, filter, linear_merge, return_overlap, fix_end))
+            out.append(self._post(part, None, None, re_score, filter, linear_merge, return_overlap, fix_end, rescored=batch_rescore))
         return out
 
     # ---------------------------------------------------------------------------------------------- inputs
@@ -579,9 +588,9 @@ class RunBlast(object):
             return blastab
         return self._rescore_table(ref, qry, HitTable.from_rows(blastab), mode, min_id, table_id).to_rows()
 
-    def _rescore_table(self, ref, qry, T, mode, min_id, table_id=11):
+    def _rescore_table(self, ref, qry, T, mode, min_id, table_id=11, cut=True):
         """Mode 1: integer counts on the GPU (K7), float arithmetic and np.round in float64 here.  Modes 2 / 3 (amino-acid / codon-position
-        scoring, not used by PEPPAN's calls) walk the rows on the host."""
+        scoring, not used by PEPPAN's calls) walk the rows on the host.  cut=False: identity and score are replaced in place and every row stays"""
         self._load(ref, qry)
         if len(T) == 0:
             return T
@@ -608,7 +617,7 @@ class RunBlast(object):
             iden, score = np.array(vals, dtype=np.float64).T
         T.iden, T.score = np.round(iden, 3), np.round(score, 3)
         T.score_is_int = False
-        return T.take(T.iden >= min_id)
+        return T.take(T.iden >= min_id) if cut else T
 
     def ovlFilter(self, blastab, params):
         return mapfilters.ovl_filter(blastab, params[1], params[2])
