@@ -622,6 +622,24 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK) void sw_score_kernel(SwArgs a
     }
 }
 
+// The traceback kernel's rare paths - the 32-bit sweep for a candidate the packed sweep cannot take, the full band for an alignment that
+// left its sub-band - as ONE function that is NOT inlined: inlined, their live ranges sat in the kernel's register allocation next to the
+// packed sweep's (128 VGPRs at the 4 waves per SIMD the LDS budget allows, 55 vector + 47 scalar spills, 96 B of scratch).  The arguments
+// are read from the kernel-argument segment (a reference to the by-value kernel parameter would put a copy of it into private memory).
+__device__ __attribute__((noinline)) void trace_slow_path(const SwArgs *ka, uint64_t c, const unsigned char *smem, uint16_t *lds_res, int lane, int full_band)
+{
+    const SwArgs &a = *ka;
+    const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
+    if (full_band) {
+        if (need1 <= a.lds_res_bytes) sw_one<true, true>(a, c, smem, lds_res, lane, -1);
+        else sw_one<false, true>(a, c, smem, lds_res, lane, -1);
+        if (lane == 0) a.mode[c] = -1;
+    } else {
+        if (need1 <= a.lds_res_bytes) trace_one<true>(a, c, smem, lds_res, lane);
+        else trace_one<false>(a, c, smem, lds_res, lane);
+    }
+}
+
 // traceback pass over the pairs that survived best-per-(q,t) and the e-value cut: four candidates per wavefront in their sub-bands
 // (packed 16-bit), the 32-bit sweep for anything that does not fit (scores beyond 16 bits, windows beyond the LDS staging area), and the
 // full band for the few alignments that leave their sub-band
@@ -634,11 +652,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint16_t *lds_res = reinterpret_cast<uint16_t *>(smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes);
-    auto one = [&](uint64_t c) {
-        const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
-        if (need1 <= a.lds_res_bytes) trace_one<true>(a, c, smem, lds_res, lane);
-        else trace_one<false>(a, c, smem, lds_res, lane);
-    };
+    const SwArgs *ka = (const SwArgs *)__builtin_amdgcn_kernarg_segment_ptr();      // (the kernel's only argument)
     // The grid is only as large as the chip holds at once and every wavefront PULLS its next item (four candidates) from a counter.
     // With one item per wavefront and a block per eight items the 80 KB of LDS a block holds came free only when its slowest
     // wavefront was done: 2.8 of 4 wavefronts per SIMD on average and 64 % VALU utilisation (SQ_WAVE_CYCLES / SQ_INSTS_VALU,
@@ -688,16 +702,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
                 sw_four_pk16_trace<LONG>(a, cc, gg, L0, ok, smem, lds_res, lane);
 #pragma unroll 1
                 for (int x = 0; x < 4; ++x)
-                    if (!ok[x]) {                                // left its sub-band: once more in the full band
-                        const uint64_t c = cc[x];
-                        const int need1 = 2 * 2 * ((8 * (int)a.nblk[c] + 72 + 7) & ~7);
-                        if (need1 <= a.lds_res_bytes) sw_one<true, true>(a, c, smem, lds_res, lane, -1);
-                        else sw_one<false, true>(a, c, smem, lds_res, lane, -1);
-                        if (lane == 0) a.mode[c] = -1;
-                    }
+                    if (!ok[x]) trace_slow_path(ka, cc[x], smem, lds_res, lane, 1);          // left its sub-band: once more in the full band
             } else {
 #pragma unroll 1
-                for (int x = 0; x < n_own; ++x) one(cc[x]);
+                for (int x = 0; x < n_own; ++x) trace_slow_path(ka, cc[x], smem, lds_res, lane, 0);
             }
         }
     }
