@@ -695,6 +695,39 @@ def main():
         torch.cuda.synchronize()
         extras['ms_per_step_after_device_sync'] = (time.perf_counter() - t9) / args.steps * 1e3
     if world == 1 and rank == 0 and not args.no_e2e:
+        # Independent searches in flight together (NOT the headline: `value` is one search at a time).  A second context - stream and work space of
+        # its own - runs the same step from a second host thread: the seed stage waits for memory (VALU issue 0.2) while the alignment passes wait for
+        # nothing but the VALU (0.9), so two searches overlap.  This is what the mapping path's worker processes get out of one GPU.
+        try:
+            import threading
+            ctx2 = N.Context(local_rank)
+            shard2 = pdist.ShardedSearch(ctx2, nts, nts, N.default_params(min_id, min_qcov, 10, 5), 0, 1)
+            ctx2.set_grouping(len(nts), shard2.gene_of_target)
+            for _ in range(3):
+                shard2.search(retranslate=True, copy=False)
+            n_each = max(1, args.steps // 2)
+            go = threading.Barrier(3)
+
+            def runner(sh):
+                go.wait()
+                for _ in range(n_each):
+                    sh.search(retranslate=True, copy=False)
+                go.wait()
+            th = [threading.Thread(target=runner, args=(sh,)) for sh in (shard, shard2)]
+            for t in th:
+                t.start()
+            torch.cuda.synchronize()
+            go.wait()
+            t7 = time.perf_counter()
+            go.wait()
+            torch.cuda.synchronize()
+            extras['two_searches_in_flight'] = {'ms_per_step': (time.perf_counter() - t7) / (2 * n_each) * 1e3, 'steps': 2 * n_each, 'contexts': 2,
+                                                'note': 'two contexts (streams) on this GPU, one host thread each, the same step; throughput of independent searches, not the headline'}
+            for t in th:
+                t.join()
+            ctx2.close()
+        except Exception as e:
+            extras['two_searches_in_flight'] = {'error': repr(e)}
         # the SAME unit of work as round 1's line: `value` counts the candidate pairs that enter gapped Smith-Waterman, and since round 2 the
         # ungapped pre-filter in front of it is stricter (threshold 55 instead of 45: 39 % fewer candidates, identical hit table - DESIGN.md
         # section 2).  For comparison across rounds the same timed loop is run once more with the round-1 threshold.

@@ -125,7 +125,10 @@ class MapWorkers(object):
             for _ in range(self.n):
                 self._procs.append(subprocess.Popen([sys.executable, '-m', 'peppan_amd.mapworkers', address], env=env, stdin=subprocess.DEVNULL,
                                                     stdout=sys.stderr.fileno() if hasattr(sys.stderr, 'fileno') and self._has_fd(sys.stderr) else subprocess.DEVNULL))
-            self._listener._listener._socket.settimeout(120.)
+            try:
+                self._listener._listener._socket.settimeout(120.)      # (a worker that dies before it connects must not leave accept() waiting for ever)
+            except AttributeError:
+                pass
             for _ in range(self.n):
                 self._conns.append(self._listener.accept())
         except BaseException:
