@@ -112,9 +112,12 @@ def cpu_baseline(names, nts, n_sample, min_id, min_qcov):
     from oracle import oracle as O
     from peppan_amd.configure import transeq          # numpy translation (pinned to the same golden vectors as the oracle's)
     found, cpu_model = probe_reference_tools()
-    cores = len(os.sched_getaffinity(0))
+    from peppan_amd.configure import effective_cpus
+    visible = len(os.sched_getaffinity(0))
+    cores = effective_cpus()                          # (the control group's CPU allowance counts: 256 threads on 16 CPUs' worth of time are 16 cores)
     have = sorted(t for t, path in found.items() if path)
-    sys.stderr.write('bench.py: reference binaries on PATH: %s; CPU: %s, %d hardware threads available\n' % (', '.join('%s=%s' % (t, found[t]) for t in have) or 'none', cpu_model, cores))
+    sys.stderr.write('bench.py: reference binaries on PATH: %s; CPU: %s, %d hardware threads visible, %d CPUs granted to this container\n' % (
+        ', '.join('%s=%s' % (t, found[t]) for t in have) or 'none', cpu_model, visible, cores))
     reference = None
     if have:
         try:
@@ -146,7 +149,7 @@ def cpu_baseline(names, nts, n_sample, min_id, min_qcov):
         vec = dict(cells_per_s=cells_v / dv, seconds=dv, sample='%d queries x %d target frames, full matrices, score only, %d threads (oracle/full_sw.c, 32 targets per query in SIMD lanes)' % (nq_v, nt_v, cores))
     except Exception as e:
         vec = {'error': repr(e)}
-    line = dict(value=st['candidates'] / dt, unit='gene-pairs/s', cores=cores, kind='port', cpu_model=cpu_model,
+    line = dict(value=st['candidates'] / dt, unit='gene-pairs/s', cores=cores, hardware_threads_visible=visible, kind='port', cpu_model=cpu_model,
                 reference_binaries={t: found[t] for t in REFERENCE_TOOLS}, reference_cpu_path=reference,
                 sample='first %d of %d queries vs all %d genes x 6 frames; %.1f s on %d threads; %d candidates, %.3g SW cells (%.3g cells/s)'
                        % (n_sample, len(nts), len(nts), dt, cores, st['candidates'], st['cells'], st['cells'] / dt),
@@ -274,6 +277,15 @@ def map_workload(args, rank, world, local_rank, n_genomes, steps, warmup, with_s
     return dict(seconds=dt, seconds_with_stores=dt_stores, genomes=n_genomes * steps, genome_nt=nt, groups_per_step=groups, hit_rows_per_step=rows)
 
 
+def _container_cpu():
+    """(CPU seconds used by this container so far, periods in which it was throttled) from the control group, or None"""
+    try:
+        d = dict(l.split() for l in open('/sys/fs/cgroup/cpu.stat'))
+        return int(d['usage_usec']) / 1e6, int(d.get('nr_throttled', 0))
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def map_strong(args, rank, world, local_rank, n_total, workers=0, warm=False):
     """BASELINE configs[3] / [4], mapping stage, as STRONG scaling: ONE fixed set of n_total synthetic genomes against the exemplar genes through
     get_map_bsn (PEPPAN.py:907-989) - the genomes dealt to the ranks in blocks of 32 (each rank searches its blocks on its own GPU: batched search of
@@ -319,7 +331,7 @@ def map_strong(args, rank, world, local_rank, n_total, workers=0, warm=False):
                     pool = es.enter_context(MapWorkers(workers, device=local_rank))
                     extra['workers_startup_s'] = time.perf_counter() - t0
                 mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', stores[0], stores[1], stores[2], stores[3], True, params,
-                                   genomes_per_round=32, timing=tm, workers=pool if workers > 1 else 0)
+                                   genomes_per_round=int(os.environ.get('PEPPAN_BENCH_MAP_ROUND', 32)), timing=tm, workers=pool if workers > 1 else 0)
             if world > 1:
                 dist.barrier()
             return time.perf_counter() - t0
@@ -330,7 +342,12 @@ def map_strong(args, rank, world, local_rank, n_total, workers=0, warm=False):
                 with MapWorkers(workers, device=local_rank) as pool:
                     extra['workers_startup_s'] = time.perf_counter() - t0
                     extra['first_pass_s'] = once(pool)
+                    c0, p0 = _container_cpu(), time.process_time()
                     dt = once(pool)
+                    c1 = _container_cpu()
+                    extra['keeper_process_cpu_s'] = time.process_time() - p0         # (this process alone, all its threads)
+                    if c0 and c1:                      # CPU seconds the whole container (this process, its workers) used over the timed pass; times it hit its allowance
+                        extra['container_cpu_s'], extra['throttled_periods'] = c1[0] - c0[0], c1[1] - c0[1]
             else:
                 once(None) if args.warmup and '--warmup' in sys.argv else None
                 dt = once(None)
@@ -814,10 +831,12 @@ def main():
                                       'genomes': mr['genomes'], 'genome_nt': mr['genome_nt'], 'groups_per_step': mr['groups_per_step'],
                                       'note': 'python bench.py --workload map --gpus N: genomes sharded over the ranks, weak scaling, no collective'}
             # the same path with the reference's pool of workers (PEPPAN.py:922): 8 worker processes share this GPU, this process keeps the stores
-            n_pool, n_set = min(8, max(2, (os.cpu_count() or 2) - 1)), 256
+            from peppan_amd.configure import effective_cpus
+            n_pool, n_set = min(8, max(2, effective_cpus() // 2)), 256
             ps = map_strong(args, 0, 1, local_rank, n_set, workers=n_pool, warm=True)
             extras['map_workload']['worker_pool'] = {'workers': n_pool, 'genomes': n_set, 'genomes_per_s_with_stores': n_set / ps['seconds'], 'seconds': ps['seconds'],
                                                      'first_pass_s': ps['first_pass_s'], 'workers_startup_s': ps['workers_startup_s'], 'phase_s': ps['phase_s_rank0'],
+                                                     'container_cpu_s': ps.get('container_cpu_s'), 'cpu_throttled_periods': ps.get('throttled_periods'), 'cpus_granted': effective_cpus(),
                                                      'note': 'get_map_bsn(..., workers=8) over ONE set of 256 genomes, four stores written; second pass of a started pool '
                                                              '(first_pass_s: the first one, with every worker\'s first search). python bench.py --workload map --map-scaling strong --map-workers 8'}
         except Exception as e:                                  # never lose the headline over the secondary leg

@@ -325,7 +325,8 @@ def store_tab_members(rows, off, keys, date_time, threads=None):
     y, mo, d, h, mi, sec = date_time
     dos_date, dos_time = (y - 1980) << 9 | mo << 5 | d, h << 11 | mi << 5 | (sec // 2)
     if threads is None:
-        threads = max(1, min(16, (os.cpu_count() or 4) // 2))
+        from .configure import effective_cpus
+        threads = max(1, min(16, effective_cpus()))
     cap = rows.nbytes // 2 + 256 * m + 4096
     for _ in range(2):
         buf = np.empty(cap, dtype=np.uint8)

@@ -25,6 +25,29 @@ def logger(log, pipe=sys.stderr):
     pipe.flush()
 
 
+def effective_cpus():
+    """CPUs this process may actually use: the affinity mask, cut down to the control group's CPU allowance when there is one (a container
+    that shows 256 hardware threads and grants 16 CPUs' worth of time runs 256 threads no faster than 16 - and polling threads steal from
+    working ones).  Not part of the reference: its pools are sized by --n_thread."""
+    import math
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:                         # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:      # cgroup v1
+                quota, period = int(f.read()), int(g.read())
+            if quota > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 class uopen(object):
     """context manager over a plain or gzipped text file ('r' or 'w')"""
 

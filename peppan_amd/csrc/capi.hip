@@ -116,9 +116,20 @@ int pep_read_back_with_upload(pep_ctx *ctx, void *dst, const void *d_src, size_t
     return PEP_OK;
 }
 
-hipError_t pep_event_wait(hipEvent_t ev)
+// PEPPAN_HIP_SPIN_US: how long a wait for the GPU polls before it sleeps (default 1.5 ms: a search's waits are shorter than a sleep's wake-up).  0 =
+// never poll - the events are created for blocking waits and the thread sleeps until the interrupt: what the mapping path's worker processes
+// use, which share a GPU and a machine's CPU allowance (peppan_amd/mapworkers.py)
+static long pep_spin_us()
 {
     static const long spin_us = [] { const char *e = getenv("PEPPAN_HIP_SPIN_US"); return e ? atol(e) : 1500L; }();
+    return spin_us;
+}
+
+unsigned pep_wait_event_flags() { return hipEventDisableTiming | (pep_spin_us() <= 0 ? hipEventBlockingSync : 0u); }
+
+hipError_t pep_event_wait(hipEvent_t ev)
+{
+    const long spin_us = pep_spin_us();
     if (spin_us <= 0) return hipEventSynchronize(ev);
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -134,7 +145,7 @@ hipError_t pep_event_wait(hipEvent_t ev)
 
 hipError_t pep_stream_wait(pep_ctx *ctx)
 {
-    if (!ctx->wait_event && hipEventCreateWithFlags(&ctx->wait_event, hipEventDisableTiming) != hipSuccess) return hipStreamSynchronize(ctx->stream);
+    if (!ctx->wait_event && hipEventCreateWithFlags(&ctx->wait_event, pep_wait_event_flags()) != hipSuccess) return hipStreamSynchronize(ctx->stream);
     const hipError_t r = hipEventRecord(ctx->wait_event, ctx->stream);
     if (r != hipSuccess) return hipStreamSynchronize(ctx->stream);
     return pep_event_wait(ctx->wait_event);
@@ -421,7 +432,9 @@ int pep_ctx_create(int device, pep_ctx **out)
     ctx->device = device;
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     pep_default_params(&ctx->params);
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PEP_ERR_HIP; }
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return PEP_ERR_HIP; }
+    if (pep_spin_us() <= 0) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);      // (every stream synchronisation of this process sleeps instead of polling)
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PEP_ERR_HIP; }
     if (pin_reserve(ctx, ctx->pin_small, 16384) != PEP_OK) { *out = ctx; return PEP_ERR_HIP; }
     int rc = pep_selftest_dpp(ctx);
     if (rc != PEP_OK) { *out = ctx; return rc; }      // caller can read the message, then destroy

@@ -167,6 +167,7 @@ struct pep_result {
 // HIP-event stopwatch on one stream (the kernel times bench.py reports are taken with it, inside the library,
 // on the stream the kernels are launched on); destroys its events on every exit path
 hipError_t pep_event_wait(hipEvent_t ev);      // polls before it sleeps (capi.hip)
+unsigned pep_wait_event_flags();               // flags of an event that is only ever waited for (blocking when PEPPAN_HIP_SPIN_US=0)
 
 struct EventTimer {
     hipEvent_t a = nullptr, b = nullptr;

@@ -571,7 +571,7 @@ int pep_k1_query(pep_ctx *ctx, int gtable, int phase)
         PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[3].as<const uint32_t>(), n, W[5].as<const uint32_t>(), upper, ctx->q, W[4], W[6], pin_sum));
         // an event of its own: whoever waits for the query side must not wait for what was queued behind it (pep_search queues the reference side next)
         ctx->k1q_event_set = false;
-        if (ctx->k1q_event || hipEventCreateWithFlags(&ctx->k1q_event, hipEventDisableTiming) == hipSuccess)
+        if (ctx->k1q_event || hipEventCreateWithFlags(&ctx->k1q_event, pep_wait_event_flags()) == hipSuccess)
             ctx->k1q_event_set = hipEventRecord(ctx->k1q_event, ctx->stream) == hipSuccess;
     }
     if (phase == 1) return PEP_OK;
@@ -684,7 +684,7 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     }
     // the summary has been written into pinned memory by k1_pack; an event marks the point of the stream where it is there
     ctx->k1_desc_cap = (uint32_t)slots;
-    if (!ctx->k1_event && hipEventCreateWithFlags(&ctx->k1_event, hipEventDisableTiming) != hipSuccess) return pep_fail(ctx, PEP_ERR_HIP, "hipEventCreate failed");
+    if (!ctx->k1_event && hipEventCreateWithFlags(&ctx->k1_event, pep_wait_event_flags()) != hipSuccess) return pep_fail(ctx, PEP_ERR_HIP, "hipEventCreate failed");
     PEP_HIP(ctx, hipEventRecord(ctx->k1_event, ctx->stream));
     if (phase == 1) return PEP_OK;
     return k1_ref_finish(ctx);

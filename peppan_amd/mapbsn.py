@@ -23,7 +23,7 @@ import zlib
 
 import numpy as np
 
-from .configure import logger
+from .configure import logger, effective_cpus
 
 __all__ = ['MapBsn', 'decodeSeq', 'encodeSeq', 'compare_prediction', 'GenomeGroups', 'OrthoRelation', 'build_groups', 'build_bsn', 'iter_map_bsn', 'get_map_bsn']
 
@@ -46,15 +46,13 @@ def _packers():
     global _PACKERS
     if _PACKERS is None:
         from concurrent.futures import ThreadPoolExecutor
-        _PACKERS = ThreadPoolExecutor(max_workers=max(2, min(16, (os.cpu_count() or 4) // 2)), thread_name_prefix='mapbsn-pack')
+        _PACKERS = ThreadPoolExecutor(max_workers=int(os.environ.get('PEPPAN_PACK_THREADS', 0)) or max(2, min(16, effective_cpus() // 2)), thread_name_prefix='mapbsn-pack')
     return _PACKERS
 
 
 def _pack_member(data, strategy=zlib.Z_DEFAULT_STRATEGY):
     """data (bytes, or a callable returning them) -> (payload, crc, size, method).  Members are read back whole either way; deflating
-    a few hundred bytes costs more than it saves (zlib set-up per member).  strategy: zlib's.  (Z_HUFFMAN_ONLY was tried for the packed alleles
-    of the .seq store: four times as fast and as small on the alleles of ONE gene set, but a genome's groups repeat a locus once per paralogous
-    exemplar it matches, and level 1's match search makes 0.66 of such members where entropy coding alone makes 0.81: the default stays.)"""
+    a few hundred bytes costs more than it saves (zlib set-up per member).  strategy: zlib's (SEQ_STRATEGY for the .seq store)."""
     if callable(data):
         data = data()               # a member whose bytes are made here, off the caller's thread (C emitters: no GIL held)
     if len(data) < 4096:
@@ -670,6 +668,12 @@ def iter_map_bsn(data):
 
 
 # ------------------------------------------------------------------------------------------------ all genomes
+SEQ_STRATEGY = zlib.Z_HUFFMAN_ONLY      # how the members of the .seq store are deflated.  Packed alleles are all but incompressible by matching (a byte
+#                       holds three bases of three different thirds of an allele): entropy coding alone makes 0.75 of a gene set's alleles at 120 MB/s where
+#                       level 1's match search makes 0.77 at 30 MB/s, and those 50 ms of CPU per genome were two thirds of what a mapped genome costs on the
+#                       host (16 CPUs granted to a GPU box: 148 -> 197 genomes/s with eight workers).  Where a genome's groups repeat a locus - once per
+#                       paralogous exemplar it matches, identical spans only - matching does find something: 0.66 against 0.81 on the synthetic genomes, whose
+#                       family members all have the same length.  zlib.Z_DEFAULT_STRATEGY brings that back.
 CHUNK = 1000          # arrays per member of the .seq / .mat stores (PEPPAN.py:953, 962)
 BLOCK = 30000         # group ids per member of the .conflicts store (PEPPAN.py:934-947)
 TABLE_ROWS = 8 << 20  # gene-table rows kept in memory between two updates of the .tab store (7 x int64 each: 470 MB).  The reference updates every
@@ -906,7 +910,7 @@ def round_members(blocks, taxa, first, save_seq):
     z = np.zeros(0, dtype=np.int64)
     return dict(n=end - first, first=first, table=np.vstack(rows) if rows else np.zeros([0, 7], dtype=np.int64), c_src=np.concatenate(src) if src else z, c_val=np.concatenate(val) if val else z,
                 mat=store([B.mat for B in blocks], _slice_mat, _emit_mat, zlib.Z_DEFAULT_STRATEGY),
-                seq=store([(B.packed, B.pack_off) for B in blocks], _slice_seq, _emit_seq, zlib.Z_DEFAULT_STRATEGY) if save_seq else None)
+                seq=store([(B.packed, B.pack_off) for B in blocks], _slice_seq, _emit_seq, SEQ_STRATEGY) if save_seq else None)
 
 
 class StoreBlock(object):
@@ -964,7 +968,7 @@ class _StoreWriter(object):
         self.conn = conn
         self.n_group, self.table, self.table_rows, self.t_table = 0, [], 0, 0.
         self.conflicts = _ConflictBlocks(clf_conn)
-        self.seqs = _MemberQueue(seq_conn, _emit_seq) if save_seq else None
+        self.seqs = _MemberQueue(seq_conn, _emit_seq, SEQ_STRATEGY) if save_seq else None
         self.mats = _MemberQueue(mat_conn, _emit_mat)
 
     def add(self, G, taxon):
@@ -1060,7 +1064,7 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
     searcher = search or (lambda *a: _gpu_search(*a, genomes_per_batch=per_round))
     pool, own_pool = None, False
     if workers is None and search is None and len(jobs) >= 64:
-        workers = min(8, int(params.get('n_thread', 0) or 0))          # the reference's pool has n_thread workers (PEPPAN.py:1841); a GPU feeds about eight
+        workers = min(8, int(params.get('n_thread', 0) or 0), effective_cpus() // 2)     # the reference's pool has n_thread workers (PEPPAN.py:1841); a GPU feeds about eight, a worker wants two CPUs
     if workers is not None and not (isinstance(workers, int) and workers <= 1):
         from .mapworkers import MapWorkers
         pool, own_pool = (workers, False) if isinstance(workers, MapWorkers) else (MapWorkers(int(workers), device=getattr(ctx, 'device', None)), True)     # (the workers' contexts: on the caller's device)

@@ -10,8 +10,10 @@ variant).  The stores do not depend on the number of workers: a genome's groups 
 
 The workers are started as `python -m peppan_amd.mapworkers <socket>` (not forked: the parent may hold a HIP context; not through
 multiprocessing's spawn either, which would import the caller's main module a second time) and talk over a unix socket with
-multiprocessing.connection's pickled messages:
-    parent -> worker   ('setup', {...})        ('round', k, jobs)                          ('emit', k, first group id) | ('drop', k)     ('stop',)
+multiprocessing.connection's pickled messages (form 'members': the BULK - the genomes' sequences out, gene-table rows and finished members
+back - goes through files in a memory-backed scratch directory, one write and one read each, instead of being pickled through the
+sockets by the keeping process's threads):
+    parent -> worker   ('setup', {...})        ('round', k, jobs[, file])                  ('emit', k, first group id, file) | ('drop', k)     ('stop',)
     worker -> parent   ('ready', pid)          ('done', k, [GenomeGroups or StoreBlock])   ('error', k, traceback text)
                                                ('counts', k, groups per genome)  - form 'members' only, answered by 'emit' / 'drop' -
                                                ('done', k, what the stores take from the round: mapbsn.round_members)
@@ -34,12 +36,93 @@ from multiprocessing.connection import Client, Listener
 __all__ = ['MapWorkers']
 
 
+def _scratch_root():
+    """where the bulk of the traffic between the processes lives for a moment: memory-backed if the machine offers it"""
+    shm = '/dev/shm'
+    return shm if os.path.isdir(shm) and os.access(shm, os.W_OK | os.X_OK) else None
+
+
+def _jobs_to_file(path, jobs):
+    """the sequences of a round's genomes back to back in `path`; returns what is left of the jobs (ids, lengths).  A sequence that is
+    not text stays in the message"""
+    meta = []
+    with open(path, 'wb', buffering=0) as f:
+        for id, taxon, seq in jobs:
+            contigs = []
+            for name, s in seq:
+                if isinstance(s, str):
+                    s = s.encode('ascii')
+                if isinstance(s, (bytes, bytearray)):
+                    f.write(s)
+                    contigs.append((name, len(s), None))
+                else:
+                    contigs.append((name, -1, s))
+            meta.append((id, taxon, contigs))
+    return meta
+
+
+def _jobs_from_file(path, meta):
+    with open(path, 'rb', buffering=0) as f:
+        data = f.read()
+    os.unlink(path)
+    jobs, at = [], 0
+    for id, taxon, contigs in meta:
+        seq = []
+        for name, n, other in contigs:
+            if n < 0:
+                seq.append([name, other])
+            else:
+                seq.append([name, data[at:at + n].decode('ascii')])
+                at += n
+        jobs.append((id, taxon, seq))
+    return jobs
+
+
+def _members_to_file(path, P):
+    """the bulk of a round's result - gene-table rows, finished members - into `path`; the message keeps offsets"""
+    with open(path, 'wb', buffering=0) as f:
+        tab = P['table']
+        f.write(memoryview(tab).cast('B') if tab.size else b'')
+        at = tab.nbytes
+        P['table'] = ('file', 0, int(tab.shape[0]), int(tab.shape[1]))
+        for kind in ('mat', 'seq'):
+            if P[kind] is None:
+                continue
+            refs = []
+            for payload, crc, size, method in P[kind]['members']:
+                f.write(payload)
+                refs.append((at, len(payload), crc, size, method))
+                at += len(payload)
+            P[kind]['members'] = refs
+    P['blob'] = path
+    return P
+
+
+def _members_from_file(P):
+    import numpy as np
+    path = P.pop('blob')
+    with open(path, 'rb', buffering=0) as f:
+        data = f.read()
+    os.unlink(path)
+    view = memoryview(data)
+    _, at, rows, cols = P['table']
+    P['table'] = np.frombuffer(data, dtype=np.int64, count=rows * cols, offset=at).reshape(rows, cols).copy()      # (the keeper adds to it in place)
+    for kind in ('mat', 'seq'):
+        if P[kind] is not None:
+            P[kind]['members'] = [(view[at:at + n], crc, size, method) for at, n, crc, size, method in P[kind]['members']]
+    return P
+
+
 def _serve(address, authkey):
     """the worker's life: set-ups and rounds until 'stop' or until the parent goes away"""
     import time
     conn = Client(address, family='AF_UNIX', authkey=authkey)
     state = {}
     clock, spent = time.perf_counter, dict(recv=0., search=0., groups=0., wait_first=0., members=0., send=0., genomes=0)
+    profile = None
+    if os.environ.get('PEPPAN_WORKERS_PROFILE'):                    # cProfile over this worker's rounds, its top functions on stderr at the end
+        import cProfile
+        profile = cProfile.Profile()
     while True:
         try:
             t0 = clock()
@@ -50,6 +133,9 @@ def _serve(address, authkey):
         if msg[0] == 'stop':
             if os.environ.get('PEPPAN_WORKERS_TIMING'):             # seconds this worker spent where (a line per worker on stderr)
                 sys.stderr.write('mapping worker %d: %s\n' % (os.getpid(), ' '.join('%s %.2f' % kv for kv in spent.items())))
+            if profile is not None:
+                import pstats
+                pstats.Stats(profile, stream=sys.stderr).sort_stats('tottime').print_stats(25)
             return
         if msg[0] == 'setup':
             try:
@@ -67,8 +153,12 @@ def _serve(address, authkey):
         if msg[0] != 'round':
             continue                                # (an 'emit' / 'drop' for a round that failed here: nothing is waiting for it)
         k, jobs = msg[1], msg[2]
+        if profile is not None:
+            profile.enable()
         try:
             from . import mapbsn
+            if len(msg) > 3 and msg[3] is not None:
+                jobs = _jobs_from_file(msg[3], jobs)
             search = state['search'] or (lambda *a: mapbsn._gpu_search(*a, genomes_per_batch=state['per_batch']))
             out, t0 = [], clock()
             for (id, taxon, seq), (blastab, overlap) in zip(jobs, search(state['prefix'], state['clust'], jobs, state['params'])):
@@ -89,8 +179,12 @@ def _serve(address, authkey):
                 if reply[0] == 'stop':
                     return
                 out = mapbsn.round_members(out, [job[1] for job in jobs], reply[2], state['save_seq']) if reply[0] == 'emit' else None
+                if out is not None and len(reply) > 3 and reply[3] is not None:
+                    out = _members_to_file(reply[3], out)
                 spent['wait_first'] += t1 - t0
                 spent['members'] += clock() - t1
+            if profile is not None:
+                profile.disable()
             t0 = clock()
             conn.send(('done', k, out))
             spent['send'] += clock() - t0
@@ -112,10 +206,12 @@ class MapWorkers(object):
         if self.n < 1:
             raise ValueError('MapWorkers: at least one worker')
         self._dir = tempfile.mkdtemp(prefix='pep_workers_')
+        self._bulk = tempfile.mkdtemp(prefix='pep_workers_', dir=_scratch_root())      # sequences out, members back: files, not messages
         address = os.path.join(self._dir, 's')
         authkey = os.urandom(16)
         self._listener = Listener(address, family='AF_UNIX', authkey=authkey)
         env = dict(os.environ, PEPPAN_WORKER_KEY=authkey.hex(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env.setdefault('PEPPAN_HIP_SPIN_US', '0')           # the workers sleep while they wait for the GPU they share: polling would eat the CPU time the others need
         if device is not None:
             env['PEPPAN_HIP_DEVICE'] = str(int(device))
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -165,6 +261,8 @@ class MapWorkers(object):
         if self._listener is not None:
             self._listener.close()
             self._listener = None
+        import shutil
+        shutil.rmtree(self._bulk, ignore_errors=True)
         try:
             os.rmdir(self._dir)
         except OSError:
@@ -204,17 +302,31 @@ class MapWorkers(object):
         state = dict(next=0, stop=False)
         results, counts, first_of = {}, {}, {0: int(first)}
 
+        def hand_out(conn):
+            """the next round into the worker's queue (None when there is none, or the call is being given up)"""
+            slots.acquire()
+            with cond:
+                k = state['next']
+                if k >= n_rounds or state['stop']:
+                    slots.release()
+                    return None
+                state['next'] = k + 1
+            mine = jobs[k * per_round:(k + 1) * per_round]
+            if members:
+                j_path = os.path.join(self._bulk, 'j%d' % k)
+                conn.send(('round', k, _jobs_to_file(j_path, mine), j_path))
+            else:
+                conn.send(('round', k, mine))
+            return k
+
         def feeder(conn):
-            while True:
-                slots.acquire()
-                with cond:
-                    k = state['next']
-                    if k >= n_rounds or state['stop']:
-                        slots.release()
-                        return
-                    state['next'] = k + 1
-                try:
-                    conn.send(('round', k, jobs[k * per_round:(k + 1) * per_round]))
+            # form 'members': while the worker makes the members of round k, the next round is in its queue already (its sequences written, the
+            # message sent) - the worker never waits for this thread between two rounds
+            k = ahead = None
+            try:
+                k = hand_out(conn)
+                while k is not None:
+                    ahead = None
                     msg = conn.recv()
                     if msg[0] == 'counts':
                         with cond:
@@ -226,20 +338,38 @@ class MapWorkers(object):
                             cond.notify_all()
                             while k not in first_of and not state['stop']:
                                 cond.wait()
-                            go = ('emit', k, first_of[k]) if k in first_of else ('drop', k)
+                            go = ('emit', k, first_of[k], os.path.join(self._bulk, 'r%d' % k)) if k in first_of else ('drop', k)
                         conn.send(go)
+                        if go[0] == 'emit':
+                            ahead = hand_out(conn)
                         msg = conn.recv()
                         if go[0] == 'drop':
                             msg = ('dropped', k, None)
-                except (EOFError, OSError) as e:
-                    msg = ('error', k, 'a mapping worker went away: %r' % (e,))
-                with cond:
-                    results[k] = msg
+                        elif msg[0] == 'done' and msg[2] is not None and 'blob' in msg[2]:
+                            msg = ('done', k, _members_from_file(msg[2]))
+                    with cond:
+                        results[k] = msg
+                        if msg[0] != 'done':
+                            state['stop'] = True                            # (rounds behind a failed one will never learn their first id)
+                        cond.notify_all()
                     if msg[0] != 'done':
-                        state['stop'] = True                                # (rounds behind a failed one will never learn their first id)
+                        break
+                    k, ahead = (ahead, None) if members else (hand_out(conn), None)
+                if ahead is not None:                                       # a round was handed out ahead of one that failed: take it back, in step with the worker
+                    m = conn.recv()
+                    if m[0] == 'counts':
+                        conn.send(('drop', ahead))
+                        conn.recv()
+                    with cond:
+                        results[ahead] = ('dropped', ahead, None)
+                        cond.notify_all()
+            except (EOFError, OSError) as e:
+                with cond:
+                    for r in (k, ahead):
+                        if r is not None and r not in results:
+                            results[r] = ('error', r, 'a mapping worker went away: %r' % (e,))
+                    state['stop'] = True
                     cond.notify_all()
-                if msg[0] != 'done':
-                    return
 
         threads = [threading.Thread(target=feeder, args=(c,), daemon=True) for c in self._conns[:max(1, min(self.n, n_rounds))]]
         for t in threads:

@@ -173,7 +173,16 @@ def test_get_map_bsn_with_worker_processes(world, tmp_path):
         pool.setup(str(tmp_path / 'm'), 'CL', bsn_fn, old_fn, dict(g['params']), search=canned_search, ctx_class=OracleContext)
         with pytest.raises(RuntimeError, match='failed in a worker'):
             list(pool.rounds([(7, 0, [])], 1))                            # no such genome in the canned search
-        assert [j[0] for j, G in pool.rounds([(i, 0, [[int(c), s] for c, s in g['cases'][i]['contigs'].items()]) for i in (2, 0)], 1)] == [2, 0]    # still alive and in step
+        job = lambda i: (i, 0, [[int(c), s] for c, s in g['cases'][i]['contigs'].items()])
+        assert [j[0] for j, G in pool.rounds([job(i) for i in (2, 0)], 1)] == [2, 0]              # still alive and in step
+        # a failing round in the middle of many, with rounds handed out ahead of it and behind it: the rounds in front arrive, the call fails, the pool stays in step
+        pool.setup(str(tmp_path / 'm'), 'CL', bsn_fn, old_fn, dict(g['params']), search=canned_search, ctx_class=OracleContext, form='members')
+        got = []
+        with pytest.raises(RuntimeError, match='round 2 failed in a worker'):
+            for jobs_k, P in pool.rounds([job(0), job(1), (7, 0, []), job(2), job(0), job(1), job(2)], 1):
+                got.append(jobs_k[0][0])
+        assert got == [0, 1]
+        assert [jobs_k[0][0] for jobs_k, P in pool.rounds([job(2), job(1), job(0), job(2)], 1)] == [2, 1, 0, 2]
 
 
 def _random_groups(rng, genome, n_groups, n_genes):
