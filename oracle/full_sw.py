@@ -42,7 +42,8 @@ def _sub(params):
 def score_matrix(q_seqs, t_seqs, params, threads=0):
     """best local score of every pair: int32[len(q_seqs), len(t_seqs)].  params: any block with sub / gap_open / gap_ext"""
     L = lib()
-    L.fullsw_set_threads(C.c_int(threads))
+    from .oracle import granted_cpus
+    L.fullsw_set_threads(C.c_int(threads if threads > 0 else granted_cpus()))
     qr, qo = _pack(q_seqs)
     tr, to = _pack(t_seqs)
     out = np.zeros((len(q_seqs), len(t_seqs)), dtype=np.int32)

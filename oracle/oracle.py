@@ -46,6 +46,20 @@ def build():
     subprocess.check_call(['make', '-C', HERE, '-s'])
 
 
+def granted_cpus():
+    """CPUs the process may use: the affinity mask cut down to the control group's allowance (a container that shows 256 hardware threads
+    and grants 16 CPUs runs an OpenMP team of 256 slower than one of 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -54,6 +68,7 @@ def lib():
         _lib = C.CDLL(LIB)
         _lib.oracle_min_score.restype = C.c_int32
         _lib.oracle_min_score.argtypes = [C.c_uint32, C.c_double, C.c_double]
+        _lib.oracle_set_threads(granted_cpus())
     return _lib
 
 

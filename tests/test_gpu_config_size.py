@@ -163,7 +163,7 @@ def test_all_vs_all_50k_bit_exact_vs_oracle(ctx):
     ta, to = ctx.target_aa()
     q_aa = [qa[qo[i]:qo[i + 1]] for i in range(len(qo) - 1)]
     t_aa = [ta[to[i]:to[i + 1]] for i in range(len(to) - 1)]
-    O.lib().oracle_set_threads(0)
+    O.lib().oracle_set_threads(O.granted_cpus())
     t0 = time.perf_counter()
     oh, oc, ost = O.search(q_aa, t_aa, O.default_params(45., 25., 10, 5))
     t_cpu = time.perf_counter() - t0

@@ -660,7 +660,7 @@ def test_full_size_10k_bit_exact_vs_oracle(ctx, gene_len):
     ta, to = ctx.target_aa()
     q_aa = [qa[qo[i]:qo[i + 1]] for i in range(len(qo) - 1)]
     t_aa = [ta[to[i]:to[i + 1]] for i in range(len(to) - 1)]
-    O.lib().oracle_set_threads(0)                # all host cores (the results do not depend on the thread count)
+    O.lib().oracle_set_threads(O.granted_cpus())                # all CPUs the box grants (the results do not depend on the thread count)
     oh, oc, ost = O.search(q_aa, t_aa, O.default_params(45., 25., 10, 5))
     _cmp_hits(gh, gc, oh, oc)
     assert len(gh) > 30000
