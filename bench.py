@@ -346,6 +346,7 @@ def map_strong(args, rank, world, local_rank, n_total, workers=0, warm=False):
                     dt = once(pool)
                     c1 = _container_cpu()
                     extra['keeper_process_cpu_s'] = time.process_time() - p0         # (this process alone, all its threads)
+                    extra['keeper_feeders_s'] = dict(pool.spent)
                     if c0 and c1:                      # CPU seconds the whole container (this process, its workers) used over the timed pass; times it hit its allowance
                         extra['container_cpu_s'], extra['throttled_periods'] = c1[0] - c0[0], c1[1] - c0[1]
             else:

@@ -1090,6 +1090,7 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         while True:
             item = inbox.get()
             if item is None:
+                spent['keeper_cpu'] = time.thread_time()
                 return
             if failure:
                 continue                            # (keep draining so that the producer never blocks on a full queue)
@@ -1111,7 +1112,7 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
 
     worker = threading.Thread(target=keeper, daemon=True)
     worker.start()
-    t_start = clock()
+    t_start, main_cpu0 = clock(), time.thread_time()
     try:
         for job, G in _all_groups(prefix, clust, jobs, ortho, old_prediction, params, searcher, ctx, group, per_round, pool):
             if failure:
@@ -1129,4 +1130,4 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
     stores.close()
     if timing is not None:      # seconds: search + filters + build_groups on the caller's thread; then, on the stores' thread and overlapped with it,
         #                         handing groups to the stores and the gene table updates; what was left to wait for at the end
-        timing.update(groups=t_groups - t_start, stores=spent['stores'], gene_table=stores.t_table, drain=clock() - t_groups)
+        timing.update(groups=t_groups - t_start, stores=spent['stores'], keeper_thread_cpu=spent.get('keeper_cpu', 0.), main_thread_cpu=time.thread_time() - main_cpu0, gene_table=stores.t_table, drain=clock() - t_groups)

@@ -30,6 +30,7 @@ import subprocess
 import sys
 import tempfile
 import threading
+import time
 import traceback
 from multiprocessing.connection import Client, Listener
 
@@ -217,6 +218,7 @@ class MapWorkers(object):
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env['PYTHONPATH'] = os.pathsep.join([root] + [p for p in sys.path if p] + [env.get('PYTHONPATH', '')])     # a search function of the caller's must be importable
         self._procs, self._conns = [], []
+        self.spent = dict(sequences_to_files=0., members_from_files=0.)        # seconds of this process's feeder threads (all of them together)
         try:
             for _ in range(self.n):
                 self._procs.append(subprocess.Popen([sys.executable, '-m', 'peppan_amd.mapworkers', address], env=env, stdin=subprocess.DEVNULL,
@@ -314,7 +316,10 @@ class MapWorkers(object):
             mine = jobs[k * per_round:(k + 1) * per_round]
             if members:
                 j_path = os.path.join(self._bulk, 'j%d' % k)
-                conn.send(('round', k, _jobs_to_file(j_path, mine), j_path))
+                t0 = time.perf_counter()
+                meta = _jobs_to_file(j_path, mine)
+                self.spent['sequences_to_files'] += time.perf_counter() - t0
+                conn.send(('round', k, meta, j_path))
             else:
                 conn.send(('round', k, mine))
             return k
@@ -346,7 +351,9 @@ class MapWorkers(object):
                         if go[0] == 'drop':
                             msg = ('dropped', k, None)
                         elif msg[0] == 'done' and msg[2] is not None and 'blob' in msg[2]:
+                            t0 = time.perf_counter()
                             msg = ('done', k, _members_from_file(msg[2]))
+                            self.spent['members_from_files'] += time.perf_counter() - t0
                     with cond:
                         results[k] = msg
                         if msg[0] != 'done':
@@ -363,6 +370,7 @@ class MapWorkers(object):
                     with cond:
                         results[ahead] = ('dropped', ahead, None)
                         cond.notify_all()
+                self.spent['feeder_threads_cpu'] = self.spent.get('feeder_threads_cpu', 0.) + time.thread_time()
             except (EOFError, OSError) as e:
                 with cond:
                     for r in (k, ahead):

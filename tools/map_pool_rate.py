@@ -12,6 +12,6 @@ for w in ws:
     r = bench.map_strong(args, 0, 1, 0, n, workers=w, warm=True)
     if 'container_cpu_s' in r:
         print('   container CPU over the timed pass: %.1f s = %.0f ms per mapped genome, %.1f CPUs busy on average, throttled in %d periods of 100 ms; the keeping process alone %.2f s' % (
-            r['container_cpu_s'], r['container_cpu_s'] / n * 1e3, r['container_cpu_s'] / r['seconds'], r['throttled_periods'], r['keeper_process_cpu_s']))
+            r['container_cpu_s'], r['container_cpu_s'] / n * 1e3, r['container_cpu_s'] / r['seconds'], r['throttled_periods'], r['keeper_process_cpu_s']), r.get('keeper_feeders_s'))
     print('workers %2d: %d genomes in %.2f s = %.1f genomes/s (first pass %.2f s, start-up %.2f s)  %s' % (
         w, n, r['seconds'], n / r['seconds'], r['first_pass_s'], r['workers_startup_s'], {k: round(v, 2) for k, v in r['phase_s_rank0'].items()}), flush=True)
