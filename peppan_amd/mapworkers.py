@@ -314,14 +314,21 @@ class MapWorkers(object):
                     return None
                 state['next'] = k + 1
             mine = jobs[k * per_round:(k + 1) * per_round]
-            if members:
-                j_path = os.path.join(self._bulk, 'j%d' % k)
-                t0 = time.perf_counter()
-                meta = _jobs_to_file(j_path, mine)
-                self.spent['sequences_to_files'] += time.perf_counter() - t0
-                conn.send(('round', k, meta, j_path))
-            else:
-                conn.send(('round', k, mine))
+            try:
+                if members:
+                    j_path = os.path.join(self._bulk, 'j%d' % k)
+                    t0 = time.perf_counter()
+                    meta = _jobs_to_file(j_path, mine)
+                    self.spent['sequences_to_files'] += time.perf_counter() - t0
+                    conn.send(('round', k, meta, j_path))
+                else:
+                    conn.send(('round', k, mine))
+            except (EOFError, OSError) as e:                    # the round has a number already: the call must hear about it
+                with cond:
+                    results[k] = ('error', k, 'a mapping worker went away: %r' % (e,))
+                    state['stop'] = True
+                    cond.notify_all()
+                raise
             return k
 
         def feeder(conn):

@@ -185,6 +185,22 @@ def test_get_map_bsn_with_worker_processes(world, tmp_path):
         assert [jobs_k[0][0] for jobs_k, P in pool.rounds([job(2), job(1), job(0), job(2)], 1)] == [2, 1, 0, 2]
 
 
+def test_a_worker_that_dies_fails_the_call(world, tmp_path):
+    """a mapping worker that goes away (killed, out of memory) is an error of the call that was using it - reported, not waited for"""
+    from map_pool_helpers import canned_search
+    from peppan_amd.mapworkers import MapWorkers
+    g, old_fn, bsn_fn = world
+    job = lambda i: (i, 0, [[int(c), s] for c, s in g['cases'][i]['contigs'].items()])
+    with MapWorkers(2) as pool:
+        pool.setup(str(tmp_path / 'm'), 'CL', bsn_fn, old_fn, dict(g['params']), search=canned_search, ctx_class=OracleContext, form='members')
+        assert len(list(pool.rounds([job(0), job(1)], 1))) == 2
+        for p in pool._procs:
+            p.kill()
+            p.wait()
+        with pytest.raises(RuntimeError, match='went away'):
+            list(pool.rounds([job(0), job(1), job(2)], 1))
+
+
 def _random_groups(rng, genome, n_groups, n_genes):
     """GenomeGroups of one made-up genome: 1-3 hit rows per group, random conflicts between its groups"""
     from peppan_amd.hittable import HitTable
