@@ -73,7 +73,7 @@ def _jobs_from_file(path, meta):
             if n < 0:
                 seq.append([name, other])
             else:
-                seq.append([name, data[at:at + n].decode('ascii')])
+                seq.append([name, data[at:at + n]])                   # bytes: the search and K12 take them as they are (no decode, no second encode)
                 at += n
         jobs.append((id, taxon, seq))
     return jobs

@@ -67,9 +67,10 @@ def _reference_seqs(ref):
         return _read_cached(ref)
     out = {}
     for n, s in (ref.items() if isinstance(ref, dict) else ref):
-        codes = np.frombuffer(s.encode('ascii', 'replace'), dtype=np.uint8)
+        raw = isinstance(s, (bytes, bytearray))                                     # (ASCII bytes are taken as they are: the mapping workers pass them)
+        codes = np.frombuffer(s if raw else s.encode('ascii', 'replace'), dtype=np.uint8)
         if len(codes) and (codes.min() <= 32 or codes.max() >= 97):               # white space or lower case somewhere: as readFasta would read it
-            s = ''.join(s.split()).upper()
+            s = b''.join(bytes(s).split()).upper() if raw else ''.join(s.split()).upper()
         out[str(n).split()[0]] = s
     return out
 
