@@ -394,12 +394,13 @@ int64_t pep_store_seq_member(const uint8_t *packed, const int64_t *pack_off, int
 
 /* The gene table store <prefix>.tab.npz (PEPPAN.py:972-975 through MapBsn.update, PEPPAN.py:91-113) written into an EMPTY archive: the
  * complete zip entries - local file header + payload - of all members back to back in `out`, made by up to `threads` host threads.
- * Member m is the .npy file of int64[off[m+1] - off[m], n_cols] = rows [off[m], off[m+1]) of the row-major table, named by the decimal
+ * Member m is the .npy file of int64[off[m+1] - off[m], n_cols] = rows [off[m], off[m+1]) of the row-major table - of the table taken in the
+ * order `order` when that is not NULL (row i of the sorted table = row order[i] of `rows`: the gather happens here, by the threads) -, named by the decimal
  * key[m]; stored below 4 KiB, raw deflate (level 1) from there on - what MapBsn writes member by member.  crc / csize / usize / at[m]
  * (offset of the entry in `out`) are what the archive's central directory needs; the caller appends `out` to the archive and lists
  * the entries.  Returns the length of `out`'s content; when it exceeds `cap` nothing usable was written and the caller calls again
  * with that much room.  Negative: PEP_ERR_ARG. */
-int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
+int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
                               int32_t threads, uint8_t *out, int64_t cap, uint32_t *crc, int64_t *csize, int64_t *usize, int64_t *at);
 
 #ifdef __cplusplus

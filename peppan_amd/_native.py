@@ -311,13 +311,14 @@ def store_seq_member(packed, pack_off):
     return buf[:len(head) + need].tobytes()
 
 
-def store_tab_members(rows, off, keys, date_time, threads=None):
+def store_tab_members(rows, off, keys, date_time, threads=None, order=None):
     """pep_store_tab_members: the finished zip entries of all members of the .tab store (PEPPAN.py:91-113, 972-975) ->
     (bytes of all entries, crc uint32[m], compressed size int64[m], size int64[m], offset of the entry int64[m])"""
     lib = load_library()
     lib.pep_store_tab_members.restype = C.c_int64
     rows = np.ascontiguousarray(rows, dtype=np.int64)
     off, keys = np.ascontiguousarray(off, dtype=np.int64), np.ascontiguousarray(keys, dtype=np.int64)
+    order = None if order is None else np.ascontiguousarray(order, dtype=np.int64)
     m = len(keys)
     if rows.ndim != 2 or len(off) != m + 1:
         raise ValueError('store_tab_members: rows int64[n, c], off int64[m + 1], keys int64[m]')
@@ -330,7 +331,7 @@ def store_tab_members(rows, off, keys, date_time, threads=None):
     cap = rows.nbytes // 2 + 256 * m + 4096
     for _ in range(2):
         buf = np.empty(cap, dtype=np.uint8)
-        need = lib.pep_store_tab_members(_ptr(rows), C.c_int64(rows.shape[1]), _ptr(off), _ptr(keys), C.c_int64(m), C.c_uint32(dos_time), C.c_uint32(dos_date), C.c_int32(threads),
+        need = lib.pep_store_tab_members(_ptr(rows), C.c_int64(rows.shape[1]), None if order is None else _ptr(order), _ptr(off), _ptr(keys), C.c_int64(m), C.c_uint32(dos_time), C.c_uint32(dos_date), C.c_int32(threads),
                                          _ptr(buf), C.c_int64(cap), _ptr(crc), _ptr(csize), _ptr(usize), _ptr(at))
         if need < 0:
             raise PepError('pep_store_tab_members failed (%d)' % need)

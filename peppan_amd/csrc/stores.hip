@@ -193,7 +193,7 @@ void put16(std::vector<uint8_t> &v, uint32_t x) { v.push_back((uint8_t)x); v.pus
 void put32(std::vector<uint8_t> &v, uint32_t x) { put16(v, x & 0xFFFFu); put16(v, x >> 16); }
 
 struct TabJob {
-    const int64_t *rows, *off, *key;
+    const int64_t *rows, *order, *off, *key;
     int64_t n_cols, lo, hi;
     uint32_t dos_time, dos_date;
     uint32_t *crc;
@@ -221,7 +221,10 @@ void tab_members(TabJob *j)
         memcpy(npy.data() + 10, dict, (size_t)dl);
         memset(npy.data() + 10 + dl, ' ', (size_t)(hlen - dl - 1));
         npy[10 + hlen - 1] = '\n';
-        memcpy(npy.data() + 10 + hlen, j->rows + j->off[m] * j->n_cols, (size_t)body);
+        if (j->order) {                              // the table is not sorted: row i of the member is row order[off[m] + i] of it
+            uint8_t *dst = npy.data() + 10 + hlen;
+            for (int64_t i = 0; i < k; ++i) memcpy(dst + i * j->n_cols * 8, j->rows + j->order[j->off[m] + i] * j->n_cols, (size_t)j->n_cols * 8);
+        } else memcpy(npy.data() + 10 + hlen, j->rows + j->off[m] * j->n_cols, (size_t)body);
         const uint32_t crc = (uint32_t)crc32(0L, npy.data(), (uInt)npy.size());
         const uint8_t *payload = npy.data();
         int64_t plen = (int64_t)npy.size();
@@ -248,7 +251,7 @@ void tab_members(TabJob *j)
 
 }   // namespace
 
-extern "C" int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
+extern "C" int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
                                          int32_t threads, uint8_t *out, int64_t cap, uint32_t *crc, int64_t *csize, int64_t *usize, int64_t *at)
 {
     if (n_members < 0 || n_cols < 1 || !off || (n_members && (!rows || !key || !crc || !csize || !usize || !at)) || (cap > 0 && !out)) return PEP_ERR_ARG;
@@ -259,7 +262,7 @@ extern "C" int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, co
     std::vector<std::thread> pool;
     for (int64_t t = 0; t < T; ++t) {
         TabJob &j = jobs[(size_t)t];
-        j.rows = rows; j.off = off; j.key = key; j.n_cols = n_cols; j.lo = n_members * t / T; j.hi = n_members * (t + 1) / T;
+        j.rows = rows; j.order = order; j.off = off; j.key = key; j.n_cols = n_cols; j.lo = n_members * t / T; j.hi = n_members * (t + 1) / T;
         j.dos_time = dos_time; j.dos_date = dos_date; j.crc = crc; j.csize = csize; j.usize = usize; j.at = at;
         if (t + 1 < T) pool.emplace_back(tab_members, &j);
     }

@@ -247,21 +247,25 @@ class MapBsn(object):
         self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
 
 
-    def update_table(self, tab):
-        """update() for an int64 table sorted by its first column: the rows of every key appended to what the store holds under it.  Into an
-        EMPTY store - the usual case, the table being kept in memory until the end - all members are made as finished zip entries by host
-        threads of the library (pep_store_tab_members) and written with one write(); 10 000 members one by one cost a second"""
+    def update_table(self, tab, order=None):
+        """update() for an int64 table sorted by its first column - or sorted by it when taken in the order `order` -: the rows of every key
+        appended to what the store holds under it.  Into an EMPTY store - the usual case, the table being kept in memory until the end - all
+        members are made as finished zip entries by host threads of the library (pep_store_tab_members: they gather the rows, too) and
+        written with one write(); 10 000 members one by one cost a second"""
         tab = np.ascontiguousarray(tab, dtype=np.int64)
         if len(tab) == 0:
             return
-        starts = np.concatenate([[0], np.flatnonzero(np.diff(tab[:, 0])) + 1, [len(tab)]]).astype(np.int64)
+        ids = tab[:, 0] if order is None else tab[:, 0][order]
+        starts = np.concatenate([[0], np.flatnonzero(np.diff(ids)) + 1, [len(tab)]]).astype(np.int64)
         if self.namelist or self.conn.filelist or self.mode == 'r':
+            if order is not None:
+                tab = tab[order]
             return self.update([tab[a:b] for a, b in zip(starts[:-1].tolist(), starts[1:].tolist())])
         from . import _native
         self._flush()
-        keys = tab[starts[:-1], 0]
+        keys = ids[starts[:-1]]
         stamp = time.localtime(time.time())[:6]
-        blob, crc, csize, usize, at = _native.store_tab_members(tab, starts, keys, stamp)
+        blob, crc, csize, usize, at = _native.store_tab_members(tab, starts, keys, stamp, order=order)
         zf = self.conn
         with zf._lock:
             zf._didModify = True
@@ -1020,17 +1024,16 @@ class _StoreWriter(object):
             return
         t0 = time.perf_counter()
         tab = np.vstack(self.table)
-        tab = tab[_stable_order_of_ids(tab[:, 0])]
-        self.conn.update_table(tab)
+        self.conn.update_table(tab, order=_stable_order_of_ids(tab[:, 0]))
         self.table, self.table_rows = [], 0
         self.t_table += time.perf_counter() - t0
 
     def close(self):
-        self.write_table()
-        if self.seqs is not None:
+        if self.seqs is not None:           # (the last, partial members first: they are deflated and appended by the stores' threads while the gene table is made)
             self.seqs.close()
         self.mats.close()
         self.conflicts.write()
+        self.write_table()
 
 
 def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_conn, mat_conn, clf_conn, saveSeq, params, search=None, ctx=None,
