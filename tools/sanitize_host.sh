@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 make -s -C oracle asan
 g++ -x c++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -shared -fPIC \
-    peppan_amd/csrc/mapfilters.hip peppan_amd/csrc/stores.hip -o /tmp/libmf_asan.so
+    peppan_amd/csrc/mapfilters.hip peppan_amd/csrc/stores.hip -o /tmp/libmf_asan.so -lz -lpthread
 ASAN=$(gcc -print-file-name=libasan.so)
 LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0 python - <<'PY'
 import sys, os, ctypes as C, copy
@@ -50,6 +50,18 @@ print('pep_store_mat_member under ASAN/UBSAN: %d bytes, %d groups read back,' % 
 po = np.concatenate([[0], np.cumsum(rng.integers(0, 700, size=300))]); pk = rng.integers(0, 125, size=int(po[-1])).astype(np.uint8)
 sb = np.lib.format.read_array(io.BytesIO(N.store_seq_member(pk, po)), allow_pickle=True)
 print('pep_store_seq_member under ASAN/UBSAN:', all(np.array_equal(sb[k], pk[po[k]:po[k + 1]]) for k in range(300)))
+# the gene table's members as finished zip entries (threads, zlib), sorted and through an order
+import zipfile, tempfile
+sizes = np.concatenate([rng.integers(1, 40, size=600), [900, 1, 3000]]); keys = np.sort(rng.choice(10 ** 6, size=len(sizes), replace=False))
+tab = np.concatenate([np.column_stack([np.full(k, key), rng.integers(-10 ** 12, 10 ** 12, size=[k, 6])]) for key, k in zip(keys, sizes)]).astype(np.int64)
+shuffle = rng.permutation(len(tab)); order = np.argsort(tab[shuffle, 0], kind='stable')
+from peppan_amd import mapbsn
+d = tempfile.mkdtemp()
+with mapbsn.MapBsn(d + '/a.npz', 'w') as a, mapbsn.MapBsn(d + '/b.npz', 'w') as b:
+    a.update_table(tab); b.update_table(tab[shuffle], order=order)
+za, zb = dict(np.load(d + '/a.npz')), dict(np.load(d + '/b.npz'))
+print('pep_store_tab_members under ASAN/UBSAN: %d members,' % len(za), sorted(za) == sorted(zb) == sorted(str(k) for k in keys) and all(np.array_equal(np.sort(za[k], axis=0), np.sort(zb[k], axis=0)) and len(za[k]) == n for k, n in zip(map(str, keys), sizes)),
+      zipfile.ZipFile(d + '/a.npz').testzip() is None)
 prots = synth.make_proteins(120, length=(40, 400), seed=5, family=3, sub=0.2)
 for mode in (0, 1):
     p = O.default_params(30., 20., 3, 5); p.hsp_mode = mode
