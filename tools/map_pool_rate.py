@@ -6,8 +6,6 @@ import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 ws = [int(x) for x in sys.argv[2:]] or [4, 8, 16]
 args = argparse.Namespace(genes=10000, warmup=0)
-import os
-per_round = int(os.environ.get('ROUND', 32))
 for w in ws:
     r = bench.map_strong(args, 0, 1, 0, n, workers=w, warm=True)
     if 'container_cpu_s' in r:
