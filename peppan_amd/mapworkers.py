@@ -22,7 +22,9 @@ Form 'members' moves the stores' work to the workers as well.  The .mat / .seq s
 numbered through all genomes - a round's first id is known once every round in front of it has been mapped.  So a worker reports its
 round's group counts, is told the round's first id as soon as the rounds in front have reported theirs, and then makes every member that
 lies inside its round completely (pickle stream, deflate, CRC: mapbsn.round_members); only the groups in front of its first and behind its
-last member boundary travel as columns.  The keeping process appends finished payloads: 1.5 ms per genome instead of 7.
+last member boundary travel as columns.  The keeping process appends finished payloads: 0.5 ms per genome instead of 7.  While a worker
+makes the members of one round the next round is in its queue already, and a worker sleeps while it waits for the GPU it shares
+(PEPPAN_HIP_SPIN_US=0).  Measured: DESIGN.md section 5, tools/map_pool_rate.py.
 """
 import os
 import pickle
