@@ -1336,6 +1336,41 @@ def test_many_searches_on_one_context(ctx):
     assert h.tobytes() == h0.tobytes() and c.tobytes() == c0.tobytes()
 
 
+def test_searches_in_flight_together_on_contexts_of_their_own(ctx):
+    """two host threads, a context (stream, work space, counters) each, searching different sets at the same time: every result equals the one the
+    context produces alone - nothing of a search lives outside its context (what bench.py's `two_searches_in_flight` and a caller with
+    several independent searches rely on)"""
+    import threading
+    from peppan_amd import _native as N, synth
+    sets = [synth.make_genes(n, 0, seed=sd)[1] for n, sd in ((700, 5), (1100, 6))]
+    p = N.default_params(45., 25., 10, 5)
+    ctxs, alone = [ctx, N.Context(0)], []
+    try:
+        for c, nts in zip(ctxs, sets):
+            c.set_query_nt(nts, 11); c.set_ref_nt(nts, 6, 11)
+            h, cg, st = c.search(p)
+            alone.append((h.tobytes(), cg.tobytes()))
+            assert len(h) > 1000
+        assert alone[0] != alone[1]
+        bad, go = [], threading.Barrier(2)
+
+        def run(k):
+            go.wait()
+            for it in range(40):
+                ctxs[k].invalidate_translation()              # K1 inside the search, like the bench step
+                h, cg, st = ctxs[k].search(p, copy=False)
+                if (h.tobytes(), cg.tobytes()) != alone[k]:
+                    bad.append((k, it))
+        th = [threading.Thread(target=run, args=(k,)) for k in (0, 1)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not bad, bad
+    finally:
+        ctxs[1].close()
+
+
 def test_query_index_partition_build_equals_plain_build(ctx):
     """the query seed index built by partition (coarse buckets in LDS, per-bucket LDS sort) gives the same search as the count -> scan
     -> fill build (params.reserved[2] = 1), also when a coarse bucket overflows LDS and the library falls back by itself"""
