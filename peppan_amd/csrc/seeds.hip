@@ -30,6 +30,9 @@ struct SeedShape {
     uint32_t pw[32];        // weight of letter i inside its half: base^i (i < h1), base^(i - h1) otherwise
 };
 
+// every shape of a search: the index kernels build all shapes' indices in ONE launch each (blockIdx.y = shape)
+struct SeedShapeSet { SeedShape s[4]; };
+
 constexpr int TILE = 256, TILE_HALO = 32;
 constexpr int FILTER_SHIFT = 5;              // one 64-bit filter word per 2^FILTER_SHIFT buckets: 5 = 2 bits per bucket (2 MiB at 2^23 buckets, L2-resident); 4 bits per bucket lets 3 % instead of 12 % of the foreign keys through but no longer fits the 4 MiB L2 of an XCD beside the rest: seed_match 0.53 -> 0.59 ms
 
@@ -151,10 +154,15 @@ constexpr int PART_CAP = 5632;                 // capacity of one coarse bucket'
 // per non-empty bucket, and writes the entries there.  (The first version counted in one launch, scanned the [coarse][block] table in a
 // second and scattered in a third: 0.035 + 0.025 + 0.052 ms per shape.)  A slab that overflows raises counters[3]: plain build.
 template <int W>
-__global__ __launch_bounds__(256) void idx_slab(SeedShape sh, const uint8_t *__restrict__ res, uint64_t total, int bucket_bits, int fine_bits,
-                                                uint32_t *__restrict__ coarse_cnt, uint64_t *__restrict__ part, int tiles, uint32_t *__restrict__ counters)
+__global__ __launch_bounds__(256) void idx_slab(SeedShapeSet shs, const uint8_t *__restrict__ res, uint64_t total, int bucket_bits, int fine_bits,
+                                                uint32_t *__restrict__ coarse_cnt, uint64_t *__restrict__ part, uint64_t part_stride, int tiles, uint32_t *__restrict__ counters)
 {
     extern __shared__ uint32_t part_lds[];
+    // blockIdx.y = shape: one shape's 800 blocks (10 000 genes) are three per CU and wait for memory most of the time - the shapes' builds side by side
+    // take the time of one (2 x 0.081 -> 0.10 ms for index build at 10 000 genes)
+    const SeedShape &sh = shs.s[blockIdx.y];
+    coarse_cnt += (size_t)blockIdx.y * 8192;
+    part += (size_t)blockIdx.y * part_stride;
     uint32_t *h = part_lds;                                  // 2^C counters, then write cursors inside the slabs
     const uint32_t n_coarse = 1u << (bucket_bits - fine_bits);
     uint8_t *red = reinterpret_cast<uint8_t *>(h + n_coarse);
@@ -289,9 +297,16 @@ __global__ __launch_bounds__(256) void tgt_slab_probe(SeedShape sh, const uint8_
 // start[c << F .. (c + 1) << F), filter slice
 __global__ __launch_bounds__(256) void idx_finish(const uint64_t *__restrict__ part, const uint32_t *__restrict__ coarse_cnt, int bucket_bits,
                                                   int fine_bits, uint32_t *__restrict__ start, uint64_t *__restrict__ entries,
-                                                  unsigned long long *__restrict__ filter, uint32_t *__restrict__ counters, uint32_t *__restrict__ n_entries_out)
+                                                  unsigned long long *__restrict__ filter, uint32_t *__restrict__ counters, uint32_t *__restrict__ n_entries_out,
+                                                  uint64_t part_stride, uint64_t start_stride, uint64_t entries_stride, uint64_t filter_stride)
 {
     __shared__ uint32_t pos[4096];
+    part += (size_t)blockIdx.y * part_stride;                  // blockIdx.y = shape (see idx_slab)
+    coarse_cnt += (size_t)blockIdx.y * 8192;
+    start += (size_t)blockIdx.y * start_stride;
+    entries += (size_t)blockIdx.y * entries_stride;
+    filter += (size_t)blockIdx.y * filter_stride;
+    n_entries_out += blockIdx.y;
     __shared__ unsigned long long fw[4096 >> FILTER_SHIFT];
     __shared__ uint32_t wave_sum[4];
     const uint32_t c = blockIdx.x, n_coarse = 1u << (bucket_bits - fine_bits), n_fine = 1u << fine_bits;
@@ -805,14 +820,20 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
     int bucket_bits = std::max(10, std::min(28, ilog2_ceil(2 * Q.total)));
     if (bucket_bits > 25 && Q.total <= 40000000ull && P.reserved[2] == 0) bucket_bits = 25;
     const uint64_t n_buckets = 1ull << bucket_bits;
+    // every shape has an index of its own (start[], entries, filter): the partition build makes all of them in one launch per kernel
+    // (blockIdx.y = shape), and the matcher of shape s then reads copy s.  Shapes of different weights (no caller has them) share copy 0, one after the other.
+    bool same_weight = true;
+    for (int s = 1; s < P.n_shapes && s < 4; ++s) same_weight = same_weight && P.weight[s] == P.weight[0];
+    const int n_idx = same_weight ? std::max(1, std::min<int>(P.n_shapes, 4)) : 1;
+    const uint64_t start_stride = (n_buckets + 2 + 15) & ~15ull, entries_stride = (Q.total + 1 + 7) & ~7ull, filter_stride = ((n_buckets >> FILTER_SHIFT) + 2 + 7) & ~7ull;
     PEP_TRY(dev_reserve(ctx, ctx->ws[0], (n_buckets + 1) * sizeof(uint32_t)));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_buckets + 2) * sizeof(uint32_t)));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[2], (Q.total + 1) * sizeof(uint64_t)));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[1], n_idx * start_stride * sizeof(uint32_t)));
+    PEP_TRY(dev_reserve(ctx, ctx->ws[2], n_idx * entries_stride * sizeof(uint64_t)));
     PEP_TRY(dev_reserve(ctx, ctx->d_zero, PEP_ZERO_TOTAL));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[9], ((n_buckets >> FILTER_SHIFT) + 2) * 8));
-    unsigned long long *filter = ctx->ws[9].as<unsigned long long>();
-    uint32_t *cnt = ctx->ws[0].as<uint32_t>(), *start = ctx->ws[1].as<uint32_t>();
-    uint64_t *entries = ctx->ws[2].as<uint64_t>();
+    PEP_TRY(dev_reserve(ctx, ctx->ws[9], n_idx * filter_stride * 8));
+    unsigned long long *filter0 = ctx->ws[9].as<unsigned long long>();
+    uint32_t *cnt = ctx->ws[0].as<uint32_t>(), *start0 = ctx->ws[1].as<uint32_t>();
+    uint64_t *entries0 = ctx->ws[2].as<uint64_t>();
     char *zero = ctx->d_zero.as<char>();
     uint32_t *counters = reinterpret_cast<uint32_t *>(zero + PEP_ZERO_SEED);
     unsigned long long *stats = reinterpret_cast<unsigned long long *>(counters + 4);
@@ -845,7 +866,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
         ctx->zero_clean = false;
         for (bool &f : ctx->zero_ok) f = true;
         uint64_t q_seeds = 0;
-        for (int s = 0; s < P.n_shapes; ++s) {
+        auto make_shape = [&](int s) {
             SeedShape sh;
             sh.weight = P.weight[s];
             sh.base = P.base;
@@ -862,6 +883,15 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             for (int i = 0, pl = 1, ph = 1; i < sh.weight; ++i) {
                 if (i < sh.h1) { sh.pw[i] = (uint32_t)pl; pl *= sh.base; } else { sh.pw[i] = (uint32_t)ph; ph *= sh.base; }
             }
+            return sh;
+        };
+        const bool fused_build = use_partition && n_idx > 1;                   // all shapes' indices by the first trip through the loop
+        for (int s = 0; s < P.n_shapes; ++s) {
+            const SeedShape sh = make_shape(s);
+            const int copy = n_idx > 1 ? s : 0;
+            uint32_t *start = start0 + copy * start_stride;
+            uint64_t *entries = entries0 + copy * entries_stride;
+            unsigned long long *filter = filter0 + copy * filter_stride;
             const unsigned qb = (unsigned)ceil_div(Q.total, 256);
 #define PEP_SEED_DISPATCH(KERNEL, GRID, ...)                                                                          \
     do {                                                                                                              \
@@ -881,12 +911,18 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
                 const unsigned pb = (unsigned)ceil_div(Q.total, (uint64_t)tiles * TILE);
                 const uint32_t n_coarse = 1u << (bucket_bits - fine_bits);
                 const size_t lds = (size_t)n_coarse * 4 + TILE + TILE_HALO;
-                PEP_TRY(dev_reserve(ctx, ctx->ws[13], (uint64_t)n_coarse * PART_CAP * sizeof(uint64_t)));
+                const uint64_t part_stride = (uint64_t)n_coarse * PART_CAP;
+                PEP_TRY(dev_reserve(ctx, ctx->ws[13], (fused_build ? n_idx : 1) * part_stride * sizeof(uint64_t)));
                 uint64_t *part = ctx->ws[13].as<uint64_t>();
                 uint32_t *coarse = reinterpret_cast<uint32_t *>(zero + PEP_ZERO_COARSE) + (size_t)s * 8192;       // (cleared by the search's one fill)
-                PEP_SEED_DISPATCH_LDS(idx_slab, dim3(pb), lds, sh, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, coarse, part, tiles, counters);
-                hipLaunchKernelGGL(idx_finish, dim3(n_coarse), dim3(256), 0, ctx->stream, (const uint64_t *)part, (const uint32_t *)coarse, bucket_bits, fine_bits,
-                                   start, entries, filter, counters, counters + 10 + s);
+                if (!fused_build || s == 0) {
+                    SeedShapeSet shs;
+                    const unsigned ny = fused_build ? (unsigned)n_idx : 1u;
+                    for (unsigned y = 0; y < 4; ++y) shs.s[y] = make_shape(fused_build ? (int)std::min<unsigned>(y, ny - 1) : s);
+                    PEP_SEED_DISPATCH_LDS(idx_slab, dim3(pb, ny), lds, shs, Q.res.as<const uint8_t>(), Q.total, bucket_bits, fine_bits, coarse, part, part_stride, tiles, counters);
+                    hipLaunchKernelGGL(idx_finish, dim3(n_coarse, ny), dim3(256), 0, ctx->stream, (const uint64_t *)part, (const uint32_t *)coarse, bucket_bits, fine_bits,
+                                       start, entries, filter, counters, counters + 10 + s, part_stride, start_stride, entries_stride, filter_stride);
+                }
             } else {
                 PEP_HIP(ctx, hipMemsetAsync(cnt, 0, (n_buckets + 1) * sizeof(uint32_t), ctx->stream));
                 PEP_SEED_DISPATCH(seed_count, dim3(qb), sh, Q.res.as<const uint8_t>(), Q.total, cnt, bucket_bits);
