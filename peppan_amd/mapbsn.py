@@ -57,6 +57,9 @@ def _pack_member(data, strategy=zlib.Z_DEFAULT_STRATEGY):
         data = data()               # a member whose bytes are made here, off the caller's thread (C emitters: no GIL held)
     if len(data) < 4096:
         return data, zlib.crc32(data), len(data), zipfile.ZIP_STORED
+    if strategy == zlib.Z_HUFFMAN_ONLY:          # the library's own literal-only coder: the sizes of zlib's Z_HUFFMAN_ONLY at 590 instead of 130 MB/s
+        from ._native import deflate_literals
+        return deflate_literals(data), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
     co = zlib.compressobj(1, zlib.DEFLATED, -15, 8, strategy)
     return co.compress(data) + co.flush(), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
 
@@ -673,7 +676,7 @@ def iter_map_bsn(data):
 
 # ------------------------------------------------------------------------------------------------ all genomes
 SEQ_STRATEGY = zlib.Z_HUFFMAN_ONLY      # how the members of the .seq store are deflated.  Packed alleles are all but incompressible by matching (a byte
-#                       holds three bases of three different thirds of an allele): entropy coding alone makes 0.75 of a gene set's alleles at 120 MB/s where
+#                       holds three bases of three different thirds of an allele): entropy coding alone (pep_deflate_literals, 590 MB/s; zlib's Z_HUFFMAN_ONLY: 130) makes 0.75 of a gene set's alleles where
 #                       level 1's match search makes 0.77 at 30 MB/s, and those 50 ms of CPU per genome were two thirds of what a mapped genome costs on the
 #                       host (16 CPUs granted to a GPU box: 148 -> 197 genomes/s with eight workers).  Where a genome's groups repeat a locus - once per
 #                       paralogous exemplar it matches, identical spans only - matching does find something: 0.66 against 0.81 on the synthetic genomes, whose

@@ -89,6 +89,28 @@ def test_gene_table_written_by_the_library_reads_like_update(tmp_path):
         assert z.testzip() is None
 
 
+def test_literal_only_deflate_is_read_by_zlib():
+    """pep_deflate_literals (the .seq members' coder): raw DEFLATE streams of dynamic-Huffman blocks holding literals only - zlib inflates every one of
+    them to the input, and the sizes are those of zlib's own Z_HUFFMAN_ONLY mode (blocks of 128 KiB: several per large input)"""
+    import os
+    import zlib
+    from peppan_amd import _native as N
+    rng = np.random.default_rng(11)
+    cases = [b'', b'a', b'abab' * 3, bytes(5000), os.urandom(70000), bytes(rng.integers(0, 125, size=300001).astype(np.uint8)),
+             bytes(rng.choice([0, 1, 2, 200], p=[0.97, 0.01, 0.01, 0.01], size=400000).astype(np.uint8)),                  # a very skewed alphabet
+             bytes((np.arange(262144 + 5) % 251).astype(np.uint8)),                                                      # flat, across a block boundary
+             bytes(np.minimum(rng.geometric(0.002, size=300000), 255).astype(np.uint8)),                                   # many rare symbols: the 15-bit limit
+             bytes(np.concatenate([np.full(1 << 17, 7), np.arange(256), np.full(1000, 9)]).astype(np.uint8))]              # one-symbol block, then all symbols
+    for d in cases:
+        z = N.deflate_literals(d)
+        assert zlib.decompress(z, -15) == d
+        co = zlib.compressobj(1, zlib.DEFLATED, -15, 8, zlib.Z_HUFFMAN_ONLY)
+        ref = co.compress(d) + co.flush()
+        assert len(z) <= len(ref) * 1.01 + 160 * (1 + len(d) // (128 << 10)), (len(d), len(z), len(ref))
+    packed, crc, size, method = mapbsn._pack_member(cases[5], zlib.Z_HUFFMAN_ONLY)
+    assert method == 8 and size == len(cases[5]) and crc == zlib.crc32(cases[5]) and zlib.decompress(packed, -15) == cases[5]
+
+
 def test_decode_encode():
     g = load_golden('g14_mapbsn.json')
     seqs = np.array(g['decodeSeq_in'], dtype=np.uint8)

@@ -62,6 +62,12 @@ with mapbsn.MapBsn(d + '/a.npz', 'w') as a, mapbsn.MapBsn(d + '/b.npz', 'w') as 
 za, zb = dict(np.load(d + '/a.npz')), dict(np.load(d + '/b.npz'))
 print('pep_store_tab_members under ASAN/UBSAN: %d members,' % len(za), sorted(za) == sorted(zb) == sorted(str(k) for k in keys) and all(np.array_equal(np.sort(za[k], axis=0), np.sort(zb[k], axis=0)) and len(za[k]) == n for k, n in zip(map(str, keys), sizes)),
       zipfile.ZipFile(d + '/a.npz').testzip() is None)
+import zlib
+lib.pep_deflate_literals.restype = C.c_int64
+ok = True
+for d in (b'', b'x', bytes(9000), os.urandom(300000), bytes(rng.integers(0, 125, size=400001).astype(np.uint8)), bytes(np.minimum(rng.geometric(0.002, size=300000), 255).astype(np.uint8))):
+    ok &= zlib.decompress(N.deflate_literals(d), -15) == d
+print('pep_deflate_literals under ASAN/UBSAN: inflates to the input,', ok)
 prots = synth.make_proteins(120, length=(40, 400), seed=5, family=3, sub=0.2)
 for mode in (0, 1):
     p = O.default_params(30., 20., 3, 5); p.hsp_mode = mode
