@@ -405,9 +405,11 @@ def _with_known(T, old_prediction):
     """the table in the order compare_prediction returns it - (query, contig, score), stable on top of the (contig, position) walk -
     with column 10 replaced"""
     order, known = _known_fraction(T, old_prediction)
-    T = T.take(order)
-    T.evalue = known
-    return T.take(np.lexsort((T.score, T.r_codes(), T.q_codes())))
+    # (the second sort is stable on top of the first order: sorted over the three key columns taken in that order, the table itself is gathered once)
+    again = np.lexsort((T.score[order], T.r_codes()[order], T.q_codes()[order]))
+    T = T.take(order[again])
+    T.evalue = known[again]
+    return T
 
 
 def compare_prediction(blastab, old_prediction):
@@ -937,7 +939,9 @@ class StoreBlock(object):
         self.packed, self.pack_off = G.packed, G.pack_off
         self.mat = _mat_block(G) if n else None
         s4 = G.score * 10000
-        order = np.argsort(-s4.astype(object))       # (as the reference sorts its object column: the same order among equal scores)
+        order = np.argsort(-s4, kind='stable')
+        if n > 1 and (np.diff(s4[order]) == 0).any():
+            order = np.argsort(-s4.astype(object))   # equal scores: the order among them is the one the reference's sort of its OBJECT column gives (3 ms for 6 600 Python floats)
         i4 = (G.iden * 10000).astype(np.int64)
         rows = np.stack([G.gene, np.zeros(n, dtype=np.int64), s4.astype(np.int64), i4, i4, np.arange(n, dtype=np.int64),
                          np.diff(G.row_off).astype(np.uint8).astype(np.int64)], axis=1)

@@ -415,16 +415,17 @@ class RunBlast(object):
         if batch_rescore:
             for T in tables:
                 self._rescore_table(None, None, T, 1, None, table_id, cut=False)
-        # rows of every tool's table by genome (the reference set of row's reference sequence), table order kept inside a genome
-        split = []
-        for T in tables:
-            owner = np.array([genome_of[r] for r in T.r_tab], dtype=np.int64)[T.ri] if len(T) else np.zeros(0, np.int64)
+        # rows by genome (the reference set of a row's reference sequence): the tools' tables are put one behind the other ONCE per batch - their
+        # name tables are the same objects, their arenas end up side by side - and a genome takes its rows of every tool, in tool and table order, with one
+        # gather (a gather per tool and a concatenation per genome copied both tools' whole CIGAR arenas sixteen times per batch)
+        T = HitTable.concat(tables)
+        if len(T):
+            owner = np.array([genome_of[r] for r in T.r_tab], dtype=np.int64)[T.ri]
             order = np.argsort(owner, kind='stable')
             cuts = np.searchsorted(owner[order], np.arange(len(refs) + 1))
-            split.append((T, order, cuts))
         out = []
         for g in range(len(refs)):
-            part = [T.take(order[cuts[g]:cuts[g + 1]]) for T, order, cuts in split]
+            part = [T.take(order[cuts[g]:cuts[g + 1]])] if len(T) else []
             out.append(self._post(part, None, None, re_score, filter, linear_merge, return_overlap, fix_end, rescored=batch_rescore))
         return out
 
