@@ -403,6 +403,12 @@ int64_t pep_store_seq_member(const uint8_t *packed, const int64_t *pack_off, int
 int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
                               int32_t threads, uint8_t *out, int64_t cap, uint32_t *crc, int64_t *csize, int64_t *usize, int64_t *at);
 
+/* The same members as a COMPLETE archive: entries, central directory, end record - what <prefix>.tab.npz is when it is written once (no zipfile
+ * object is needed for a store that is then closed).  Plain zip: PEP_ERR_LIMIT from 65 535 members or 4 GiB on (the caller then writes member-wise).
+ * Returns the archive's length; when it exceeds `cap` nothing usable was written. */
+int64_t pep_store_tab_archive(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
+                              int32_t threads, uint8_t *out, int64_t cap);
+
 /* A raw DEFLATE stream (RFC 1951; what a zip member of method 8 holds) of `src` made of dynamic-Huffman blocks with literals only - entropy
  * coding without a match search, for the members of <prefix>.seq.npz (packed alleles: nothing to match).  Host C++, no context, any inflate
  * reads it.  Returns the stream's length; when it exceeds `cap` nothing usable was written (n + n / 64 + 512 always suffices).  Negative: PEP_ERR_ARG. */

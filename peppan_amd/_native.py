@@ -14,7 +14,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_deflate_literals']
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals']
 
 
 class PepError(RuntimeError):
@@ -352,6 +352,34 @@ def store_tab_members(rows, off, keys, date_time, threads=None, order=None):
             return buf[:need], crc, csize, usize, at
         cap = int(need)
     raise PepError('pep_store_tab_members: the entries did not fit the size it had asked for')
+
+
+def store_tab_archive(rows, off, keys, date_time, threads=None, order=None):
+    """pep_store_tab_archive: the .tab store as one complete zip archive (uint8 array), or None when it would need zip64 (>= 65 535 members, >= 4 GiB)"""
+    lib = load_library()
+    lib.pep_store_tab_archive.restype = C.c_int64
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    off, keys = np.ascontiguousarray(off, dtype=np.int64), np.ascontiguousarray(keys, dtype=np.int64)
+    order = None if order is None else np.ascontiguousarray(order, dtype=np.int64)
+    m = len(keys)
+    y, mo, d, h, mi, sec = date_time
+    dos_date, dos_time = (y - 1980) << 9 | mo << 5 | d, h << 11 | mi << 5 | (sec // 2)
+    if threads is None:
+        from .configure import effective_cpus
+        threads = max(1, min(16, effective_cpus()))
+    cap = rows.nbytes // 2 + 320 * m + 4096
+    for _ in range(2):
+        buf = np.empty(cap, dtype=np.uint8)
+        need = lib.pep_store_tab_archive(_ptr(rows), C.c_int64(rows.shape[1]), None if order is None else _ptr(order), _ptr(off), _ptr(keys), C.c_int64(m), C.c_uint32(dos_time),
+                                         C.c_uint32(dos_date), C.c_int32(threads), _ptr(buf), C.c_int64(cap))
+        if need == -3:
+            return None
+        if need < 0:
+            raise PepError('pep_store_tab_archive failed (%d)' % need)
+        if need <= cap:
+            return buf[:need]
+        cap = int(need)
+    raise PepError('pep_store_tab_archive: the archive did not fit the size it had asked for')
 
 
 def similar_scan(q, r, action, forward, iden4, n_genes):

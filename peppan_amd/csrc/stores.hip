@@ -198,6 +198,7 @@ struct TabJob {
     uint32_t dos_time, dos_date;
     uint32_t *crc;
     int64_t *csize, *usize, *at;            // at[]: relative to the job's buffer until the pieces are put together
+    uint8_t *method;                        // (optional) 0 stored / 8 deflated per member
     std::vector<uint8_t> buf;
     bool ok = true;
 };
@@ -240,6 +241,7 @@ void tab_members(TabJob *j)
         }
         const std::string name = std::to_string((long long)j->key[m]);
         j->crc[m] = crc; j->csize[m] = plen; j->usize[m] = (int64_t)npy.size(); j->at[m] = (int64_t)j->buf.size();
+        if (j->method) j->method[m] = (uint8_t)method;
         std::vector<uint8_t> &b = j->buf;
         put32(b, 0x04034b50u); put16(b, 20); put16(b, 0); put16(b, (uint32_t)method); put16(b, j->dos_time); put16(b, j->dos_date);
         put32(b, crc); put32(b, (uint32_t)plen); put32(b, (uint32_t)npy.size()); put16(b, (uint32_t)name.size()); put16(b, 0);
@@ -251,8 +253,8 @@ void tab_members(TabJob *j)
 
 }   // namespace
 
-extern "C" int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
-                                         int32_t threads, uint8_t *out, int64_t cap, uint32_t *crc, int64_t *csize, int64_t *usize, int64_t *at)
+static int64_t tab_entries(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
+                           int32_t threads, uint8_t *out, int64_t cap, uint32_t *crc, int64_t *csize, int64_t *usize, int64_t *at, uint8_t *method)
 {
     if (n_members < 0 || n_cols < 1 || !off || (n_members && (!rows || !key || !crc || !csize || !usize || !at)) || (cap > 0 && !out)) return PEP_ERR_ARG;
     for (int64_t m = 0; m < n_members; ++m)
@@ -263,7 +265,7 @@ extern "C" int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, co
     for (int64_t t = 0; t < T; ++t) {
         TabJob &j = jobs[(size_t)t];
         j.rows = rows; j.order = order; j.off = off; j.key = key; j.n_cols = n_cols; j.lo = n_members * t / T; j.hi = n_members * (t + 1) / T;
-        j.dos_time = dos_time; j.dos_date = dos_date; j.crc = crc; j.csize = csize; j.usize = usize; j.at = at;
+        j.dos_time = dos_time; j.dos_date = dos_date; j.crc = crc; j.csize = csize; j.usize = usize; j.at = at; j.method = method;
         if (t + 1 < T) pool.emplace_back(tab_members, &j);
     }
     tab_members(&jobs[(size_t)T - 1]);
@@ -402,4 +404,44 @@ extern "C" int64_t pep_deflate_literals(const uint8_t *src, int64_t n, uint8_t *
     }
     s.finish();
     return s.n;
+}
+
+extern "C" int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
+                                         int32_t threads, uint8_t *out, int64_t cap, uint32_t *crc, int64_t *csize, int64_t *usize, int64_t *at)
+{
+    return tab_entries(rows, n_cols, order, off, key, n_members, dos_time, dos_date, threads, out, cap, crc, csize, usize, at, nullptr);
+}
+
+// The whole <prefix>.tab.npz in one piece: the entries as above, then the archive's central directory and end record - a store that is written
+// once and closed needs no zipfile object at all (10 000 ZipInfo objects made and walked again by ZipFile.close(): 0.2 s; 50 000: 1 s).
+// Plain zip only: fewer than 65 535 members and less than 4 GiB, else PEP_ERR_LIMIT (the caller takes the member-wise way).
+extern "C" int64_t pep_store_tab_archive(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
+                                         int32_t threads, uint8_t *out, int64_t cap)
+{
+    if (n_members < 0) return PEP_ERR_ARG;
+    if (n_members >= 65535) return PEP_ERR_LIMIT;
+    std::vector<uint32_t> crc((size_t)n_members + 1);
+    std::vector<int64_t> csize((size_t)n_members + 1), usize((size_t)n_members + 1), at((size_t)n_members + 1);
+    std::vector<uint8_t> method((size_t)n_members + 1);
+    std::vector<uint8_t> dir;
+    // the directory's size is known before the entries are made: 46 bytes + the name per member, 22 for the end record
+    int64_t dir_bytes = 22;
+    for (int64_t m = 0; m < n_members; ++m) dir_bytes += 46 + (int64_t)std::to_string((long long)key[m]).size();
+    const int64_t room = cap > dir_bytes ? cap - dir_bytes : 0;
+    const int64_t body = tab_entries(rows, n_cols, order, off, key, n_members, dos_time, dos_date, threads, out, room, crc.data(), csize.data(), usize.data(), at.data(), method.data());
+    if (body < 0) return body;
+    if (body + dir_bytes >= (int64_t)0xFFFFFFFFll) return PEP_ERR_LIMIT;
+    if (body > room) return body + dir_bytes;                 // (nothing usable written: call again with this much)
+    dir.reserve((size_t)dir_bytes);
+    for (int64_t m = 0; m < n_members; ++m) {
+        const std::string name = std::to_string((long long)key[m]);
+        put32(dir, 0x02014b50u); put16(dir, 20 | (3u << 8)); put16(dir, 20); put16(dir, 0); put16(dir, method[(size_t)m]); put16(dir, dos_time); put16(dir, dos_date);
+        put32(dir, crc[(size_t)m]); put32(dir, (uint32_t)csize[(size_t)m]); put32(dir, (uint32_t)usize[(size_t)m]); put16(dir, (uint32_t)name.size()); put16(dir, 0); put16(dir, 0);
+        put16(dir, 0); put16(dir, 0); put32(dir, 0600u << 16); put32(dir, (uint32_t)at[(size_t)m]);
+        dir.insert(dir.end(), name.begin(), name.end());
+    }
+    const uint32_t cd_size = (uint32_t)dir.size();
+    put32(dir, 0x06054b50u); put16(dir, 0); put16(dir, 0); put16(dir, (uint32_t)n_members); put16(dir, (uint32_t)n_members); put32(dir, cd_size); put32(dir, (uint32_t)body); put16(dir, 0);
+    memcpy(out + body, dir.data(), dir.size());
+    return body + (int64_t)dir.size();
 }

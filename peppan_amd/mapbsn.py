@@ -82,6 +82,28 @@ def _append_member(zf, name, packed):
         zf.NameToInfo[zi.filename] = zi
 
 
+class _LazyZip(object):
+    """an archive on disk that is opened for appending (zipfile reads its whole directory then) only when something is asked of it"""
+
+    def __init__(self, fname):
+        self.__dict__['_fname'], self.__dict__['_zf'] = fname, None
+
+    def _open(self):
+        if self._zf is None:
+            self.__dict__['_zf'] = zipfile.ZipFile(self._fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
+        return self._zf
+
+    def __getattr__(self, name):
+        return getattr(self._open(), name)
+
+    def __setattr__(self, name, value):
+        setattr(self._open(), name, value)
+
+    def close(self):
+        if self._zf is not None:
+            self._zf.close()
+
+
 class MapBsn(object):
     """dict-like store: zip member `str(key)` holds one array in .npy format (object arrays pickled).  Readable by
     `np.load(fname, allow_pickle=True)` like the reference's files (PEPPAN.py:1931)."""
@@ -268,6 +290,15 @@ class MapBsn(object):
         self._flush()
         keys = ids[starts[:-1]]
         stamp = time.localtime(time.time())[:6]
+        whole = _native.store_tab_archive(tab, starts, keys, stamp, order=order) if self.mode == 'w' else None
+        if whole is not None:
+            # the complete archive, directory included, from the library: no zipfile object is made for it unless the store is used again
+            self.conn.close()
+            with open(self.fname, 'wb') as f:
+                f.write(memoryview(whole))
+            self.conn = _LazyZip(self.fname)
+            self.namelist = set(map(str, keys.tolist()))
+            return
         blob, crc, csize, usize, at = _native.store_tab_members(tab, starts, keys, stamp, order=order)
         zf = self.conn
         with zf._lock:
