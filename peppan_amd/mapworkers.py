@@ -42,7 +42,14 @@ __all__ = ['MapWorkers']
 def _scratch_root():
     """where the bulk of the traffic between the processes lives for a moment: memory-backed if the machine offers it"""
     shm = '/dev/shm'
-    return shm if os.path.isdir(shm) and os.access(shm, os.W_OK | os.X_OK) else None
+    try:
+        if os.path.isdir(shm) and os.access(shm, os.W_OK | os.X_OK):
+            st = os.statvfs(shm)
+            if st.f_bavail * st.f_frsize >= 4 << 30:          # (a round of 16 genomes is ~70 MB there and back, two rounds per worker: a container's default 64 MB will not do)
+                return shm
+    except OSError:
+        pass
+    return None
 
 
 def _jobs_to_file(path, jobs):
@@ -327,7 +334,7 @@ class MapWorkers(object):
                     conn.send(('round', k, mine))
             except (EOFError, OSError) as e:                    # the round has a number already: the call must hear about it
                 with cond:
-                    results[k] = ('error', k, 'a mapping worker went away: %r' % (e,))
+                    results[k] = ('error', k, 'round %d could not be handed to a worker (worker gone, or no room in %s): %r' % (k, self._bulk, e))
                     state['stop'] = True
                     cond.notify_all()
                 raise
