@@ -100,7 +100,7 @@ def test_allgather_hits_two_ranks_gloo():
     assert len(exp_h) > 20
 
 
-def _map_worker(rank, world, port, tmp, out_q):
+def _map_worker(rank, world, port, tmp, out_q, workers=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import copy
@@ -130,36 +130,42 @@ def _map_worker(rank, world, port, tmp, out_q):
     def search(prefix, clust, jobs, params):              # every rank is handed only its own genomes
         seen.extend(j[0] for j in jobs)
         return iter([canned[j[0]] for j in jobs])
+    kw = {}
+    if workers:                                           # every rank deals its genomes to worker processes of its own (the search must be importable by them)
+        from map_pool_helpers import canned_search
+        search, kw = canned_search, dict(workers=workers)
     if rank == 0:
         names = [os.path.join(tmp, 'mm.%s.npz' % x) for x in ('tab', 'seq', 'mat', 'conflicts')]
         with mapbsn.MapBsn(names[0], 'w') as c0, mapbsn.MapBsn(names[1], 'w') as c1, mapbsn.MapBsn(names[2], 'w') as c2, mapbsn.MapBsn(names[3], 'w') as c3:
             mapbsn.get_map_bsn(os.path.join(tmp, 'm'), 'CL', genomes, bsn_fn, old_fn, c0, c1, c2, c3, True, dict(g['params']), search=search,
-                               ctx=OracleContext(), genomes_per_round=1)
+                               ctx=OracleContext(), genomes_per_round=1, **kw)
     else:
         mapbsn.get_map_bsn(os.path.join(tmp, 'm'), 'CL', genomes, bsn_fn, old_fn, None, None, None, None, True, dict(g['params']), search=search,
-                           ctx=OracleContext(), genomes_per_round=1)
+                           ctx=OracleContext(), genomes_per_round=1, **kw)
     out_q.put((rank, seen))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_get_map_bsn_sharded_over_two_ranks(tmp_path):
+@pytest.mark.parametrize('workers', [0, 2])
+def test_get_map_bsn_sharded_over_two_ranks(tmp_path, workers):
     """genomes dealt to two gloo ranks (PEPPAN.py:907-989 with one process per GPU instead of one forked worker per genome): rank 0's
-    stores are exactly the single-process stores of golden G15, and each rank searched only its own genomes"""
+    stores are exactly the single-process stores of golden G15, and each rank searched only its own genomes.  workers = 2: every rank
+    deals ITS genomes to two worker processes of its own (peppan_amd.mapworkers), rank 0 still cuts the stores' members"""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from conftest import load_golden
     from peppan_amd import mapbsn
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_map_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    procs = [ctx.Process(target=_map_worker, args=(r, world, port, str(tmp_path), q, workers)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got[0] == [0, 2] and got[1] == [1]
+    assert workers or (got[0] == [0, 2] and got[1] == [1])
     want = load_golden('g15_getmapbsn.json')['stores']['saveSeq_1']
 
     def plain(x):
