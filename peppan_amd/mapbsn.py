@@ -716,9 +716,11 @@ SEQ_STRATEGY = zlib.Z_HUFFMAN_ONLY      # how the members of the .seq store are 
 #                       family members all have the same length.  zlib.Z_DEFAULT_STRATEGY brings that back.
 CHUNK = 1000          # arrays per member of the .seq / .mat stores (PEPPAN.py:953, 962)
 BLOCK = 30000         # group ids per member of the .conflicts store (PEPPAN.py:934-947)
-TABLE_ROWS = 8 << 20  # gene-table rows kept in memory between two updates of the .tab store (7 x int64 each: 470 MB).  The reference updates every
-#                       500 genomes (PEPPAN.py:972) to bound ITS memory - object rows; an update rewrites the whole archive, and the store's content
-#                       does not depend on how often that happens
+TABLE_ROWS = 48 << 20 # gene-table rows kept in memory between two updates of the .tab store (7 x int64 each: 2.7 GB; 2 000 genomes x 6 600 groups are 13 M rows).  The
+#                       reference updates every 500 genomes (PEPPAN.py:972) to bound the memory of ITS rows - Python objects; an update of a store that holds
+#                       something already rewrites the whole archive member by member (5 s for 10 000 genes: measured when the limit was 8 M rows and a
+#                       2 000-genome run crossed it), the first one is a single call into the library (0.2 - 0.8 s), and the store's content does not depend
+#                       on how often that happens
 
 
 def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
