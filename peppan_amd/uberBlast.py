@@ -183,7 +183,8 @@ def _encode_nt(texts):
     off = np.zeros(len(texts) + 1, dtype=np.uint64)
     if texts:
         off[1:] = np.cumsum(np.fromiter(map(len, texts), dtype=np.int64, count=len(texts)))
-    return _NT_CODE[np.frombuffer(''.join(texts).encode('ascii'), dtype=np.uint8)], off
+    raw = b''.join(t if isinstance(t, (bytes, bytearray)) else t.encode('ascii') for t in texts)      # (str or ASCII bytes: the mapping workers pass bytes)
+    return _NT_CODE[np.frombuffer(raw, dtype=np.uint8)], off
 
 
 def blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev, windows=None):

@@ -238,6 +238,10 @@ def test_chromosome_longer_than_the_sequence_limit(tmp_path, monkeypatch):
     # no duplicates from the overlapping halos: one row per (query, locus)
     for gi_, hits in on_chr.items():
         assert len({(lo, hi) for lo, hi, rev, qs, qe in hits}) == len(hits)
+    # the same reference handed over in memory as ASCII bytes (what the mapping workers pass: no FASTA file, no str) through the batch entry point
+    with contextlib.redirect_stderr(io.StringIO()):
+        (batch,), = [UB.uberBlastBatch([[('chr', chrom.tobytes()), ('small', small.tobytes())]], argv[2:])]
+    assert batch.tolist() == tab.tolist()
 
 
 def test_example_genomes_full_pipeline_vs_oracle(ctx, tmp_path, monkeypatch):

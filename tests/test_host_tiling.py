@@ -46,6 +46,11 @@ def test_tiled_nucleotide_search_equals_untiled(tmp_path, monkeypatch):
         tiled, tiled_ovl = UB.uberBlast(argv)
     assert whole.shape[0] >= 3 * len(genes) and any(r[8] > r[9] for r in whole)          # both strands, every copy
     assert tiled.tolist() == whole.tolist() and tiled_ovl.tolist() == whole_ovl.tolist()
+    # references handed over in memory as ASCII bytes (what the mapping workers pass) take the same road: text and bytes encode alike
+    codes, off = UB._encode_nt([contig[:700], contig[700:900].encode(), ''])
+    both, off2 = UB._encode_nt([contig[:700], contig[700:900], ''])
+    assert codes.tolist() == both.tolist() and off.tolist() == off2.tolist() == [0, 700, 900, 900]
+    assert UB._reference_seqs([('chr x', contig[:50].lower().encode()), (7, b'AC GT')]) == {'chr': contig[:50].encode(), '7': b'ACGT'}
     # queries too long for the windows are a loud error, not a silently empty table
     monkeypatch.setattr(N, 'MAX_SEQ_LEN', 3000)
     import pytest
