@@ -729,7 +729,8 @@ def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
     from .uberBlast import uberBlastBatch
     argv = _map_argv(clust, params)
     for lo in range(0, len(jobs), genomes_per_batch):
-        for r in uberBlastBatch([seq for id, taxon, seq in jobs[lo:lo + genomes_per_batch]], argv, as_tables=True):        # (HitTable, overlaps) per genome
+        # (strict: a search tool that fails fails the mapping - stores made of one tool's hits only would look like results)
+        for r in uberBlastBatch([seq for id, taxon, seq in jobs[lo:lo + genomes_per_batch]], argv, as_tables=True, strict=True):        # (HitTable, overlaps) per genome
             yield r
 
 

@@ -378,7 +378,7 @@ class RunBlast(object):
         MAX_BATCH_NT nucleotides so that a packed reference set stays inside the library's 2^29-byte limit."""
         refs = [_reference_seqs(p) for p in refs]                  # (paths are read once, here)
         sizes = [sum(len(v) for v in rs.values()) for rs in refs]
-        out, start = [], 0
+        out, start, failed = [], 0, []
         while start < len(refs):
             stop, tot = start, 0
             while stop < len(refs) and (stop == start or tot + sizes[stop] <= self.MAX_BATCH_NT):
@@ -388,7 +388,9 @@ class RunBlast(object):
             sub._as_tables = self._as_tables
             out += sub._run_one_batch(refs[start:stop], qry, methods, min_id, min_cov, min_ratio, table_id, n_thread, useProcess, re_score,
                                       filter, linear_merge, return_overlap, fix_end)
+            failed += sub.failed_tools
             start = stop
+        self.failed_tools = failed               # (of every sub-batch)
         return out
 
     def _run_one_batch(self, refs, qry, methods, min_id, min_cov, min_ratio, table_id, n_thread, useProcess, re_score,
@@ -729,17 +731,21 @@ def uberBlast(args, extPool=None, as_table=False):
     return data
 
 
-def uberBlastBatch(references, args, device=None, as_tables=False):
+def uberBlastBatch(references, args, device=None, as_tables=False, strict=False):
     """uberBlast for a LIST of reference files (or in-memory references: dicts / lists of (name, sequence), see _reference_seqs) and one
     query file: `args` are uberBlast's flags without -r/-o.
     Returns one result per reference, each identical to uberBlast(['-r', ref] + args).  One GPU search per tool.
     as_tables: the hit tables come as numeric HitTables (same rows, same order) instead of object rows - for callers like
-    mapbsn.build_bsn that work on the columns."""
+    mapbsn.build_bsn that work on the columns.  strict: a tool that fails raises instead of being reported and left out (the reference's
+    convention, uberBlast.py:347-349, is the default; a caller that writes stores from the result does not want half of it)."""
     a = _parser('uberBlast over many reference files with one search per tool.', False).parse_args(args)
     methods, kw = _run_arguments(a)
     rb = RunBlast(device, sensitive=a.sensitive)
     rb._as_tables = bool(as_tables)
-    return rb.run_batch(references, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread, a.process, **kw)
+    out = rb.run_batch(references, a.query, methods, a.min_id, a.min_cov, a.min_ratio, a.gtable, a.n_thread, a.process, **kw)
+    if strict and rb.failed_tools:
+        raise RuntimeError('uberBlastBatch: %s' % '; '.join('%s failed: %s' % ft for ft in rb.failed_tools))
+    return out
 
 
 if __name__ == '__main__':

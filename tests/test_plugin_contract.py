@@ -96,3 +96,26 @@ def test_subclass_tool_override_and_failed_tools(tmp_path, monkeypatch):
     assert [m for m, _ in rb.failed_tools] == ['diamond'] and 'tool fell over' in err.getvalue()
     assert only_blast.tolist() == ref_blast.tolist() and len(ref_blast) >= 24
     assert UB.RunBlast().run(fa, fa, ['blastn'], 0.4, 40., 0.25) is not None and rb.failed_tools
+
+
+def test_batch_entry_point_can_be_strict_about_failed_tools(tmp_path, monkeypatch):
+    """uberBlastBatch(strict=True) - what the genome mapping calls - raises when a tool fails instead of returning the other tools' hits: stores
+    written from half a search would pass for results.  Without it the reference's convention holds (reported, left out)."""
+    import pytest
+    from oracle_context import OracleContext
+    from peppan_amd import uberBlast as UB
+    fa = _write_inputs(tmp_path, 12)
+    octx = OracleContext()
+    monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
+
+    def broken(self, ref, qry):
+        raise TypeError('a tool that falls over')
+    monkeypatch.setattr(UB.RunBlast, '_runBlast_table', broken)
+    monkeypatch.setitem(UB._BUILTIN_TOOLS, 'runBlast', None)                     # (run() then goes through the method)
+    argv = ('-q %s --blastn -s 1 --min_id 0.6 --min_cov 50 --min_ratio 0.2 -e 0,3' % fa).split()
+    refs = [[('c1', 'ACGT' * 200)]]
+    with contextlib.redirect_stderr(io.StringIO()):
+        lenient = UB.uberBlastBatch(refs, argv)
+        assert len(lenient) == 1 and len(lenient[0]) == 0
+        with pytest.raises(RuntimeError, match='blastn failed'):
+            UB.uberBlastBatch(refs, argv, strict=True)
