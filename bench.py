@@ -833,12 +833,12 @@ def main():
                                       'note': 'python bench.py --workload map --gpus N: genomes sharded over the ranks, weak scaling, no collective'}
             # the same path with the reference's pool of workers (PEPPAN.py:922): 8 worker processes share this GPU, this process keeps the stores
             from peppan_amd.configure import effective_cpus
-            n_pool, n_set = min(8, max(2, effective_cpus() // 2)), 256
+            n_pool, n_set = min(8, max(2, effective_cpus() // 2)), 512          # (BASELINE configs[2]/[3]: 10 000 genes x 500 genomes)
             ps = map_strong(args, 0, 1, local_rank, n_set, workers=n_pool, warm=True)
             extras['map_workload']['worker_pool'] = {'workers': n_pool, 'genomes': n_set, 'genomes_per_s_with_stores': n_set / ps['seconds'], 'seconds': ps['seconds'],
                                                      'first_pass_s': ps['first_pass_s'], 'workers_startup_s': ps['workers_startup_s'], 'phase_s': ps['phase_s_rank0'],
                                                      'container_cpu_s': ps.get('container_cpu_s'), 'cpu_throttled_periods': ps.get('throttled_periods'), 'cpus_granted': effective_cpus(),
-                                                     'note': 'get_map_bsn(..., workers=8) over ONE set of 256 genomes, four stores written; second pass of a started pool '
+                                                     'note': 'get_map_bsn(..., workers=8) over ONE set of 512 genomes, four stores written; second pass of a started pool '
                                                              '(first_pass_s: the first one, with every worker\'s first search). python bench.py --workload map --map-scaling strong --map-workers 8'}
         except Exception as e:                                  # never lose the headline over the secondary leg
             extras.setdefault('map_workload', {})['error'] = repr(e)
