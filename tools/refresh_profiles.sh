@@ -18,5 +18,5 @@ for s in "" _50k; do
   for t in pmc_f pmc_w pmc_sq pmc_grbm pmc_tcc; do echo "## $t$s"; sed -n '/^counters/,$p' gpurun_out/$t$s.txt | tail -n +2; done; } > profiles/${R}_pmc_counters$s.txt
 done
 { echo "# one step of bench.py on the GPU timeline (tools/rocpd_gaps.py over the same trace as ${R}_final_kernel_stats.txt): start offset, duration, idle gap before each launch"; cat gpurun_out/final_gaps.txt; } > profiles/${R}_step_timeline.txt
-{ echo "# tools/map_pool_rate.py 512 4 8 (MI355X box: 256 hardware threads visible, 16 CPUs granted): get_map_bsn with worker processes, 10 000 exemplars x 512 genomes of 2.2 Mb, four stores written; second pass of a started pool"; cat gpurun_out/map_pool_rate.txt; grep -A99 "^# tools/map_pool_rate.py 2000 8 (a run of its own)" profiles/${R}_map_pool_rate.txt 2>/dev/null; } > profiles/${R}_map_pool_rate.txt.new && mv profiles/${R}_map_pool_rate.txt.new profiles/${R}_map_pool_rate.txt
+{ echo "# tools/map_pool_rate.py 512 4 8 (MI355X box: 256 hardware threads visible, 16 CPUs granted): get_map_bsn with worker processes, 10 000 exemplars x 512 genomes of 2.2 Mb, four stores written; second pass of a started pool"; cat gpurun_out/map_pool_rate.txt; } > profiles/${R}_map_pool_rate.txt
 { echo "# tools/ab/concurrent_searches.py 10000 200 (MI355X): T host threads with a context (stream, work space) each run the 10 000-gene all-vs-all (log-normal lengths) side by side"; cat gpurun_out/concurrent_searches.txt; } > profiles/${R}_concurrent_searches.txt
