@@ -307,7 +307,7 @@ def map_strong(args, rank, world, local_rank, n_total, workers=0, warm=False):
         with open('m.clust.exemplar', 'w') as f:
             for i, s in enumerate(seqs):
                 f.write('>%d\n%s\n' % (i, s.decode()))
-        worlds = synth.make_genomes(seqs, n_total, seed=355)                # the same set on every rank
+        worlds = synth.make_genomes(seqs, n_total, seed=355, presence=getattr(args, 'presence', None))                # the same set on every rank
         genomes, nt = {}, 0
         with mapbsn.MapBsn('m.old_prediction.npz', 'w') as op:
             for g, (gname, contig, ann) in enumerate(worlds):

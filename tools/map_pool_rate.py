@@ -1,12 +1,14 @@
 """get_map_bsn with worker processes on one GPU: genomes per second of a started pool (second pass over the same set) by number of workers.
-usage: [GENES=50000] python tools/map_pool_rate.py [genomes] [workers ...]"""
+usage: [GENES=50000 [PRESENCE=pan]] python tools/map_pool_rate.py [genomes] [workers ...]"""
 import sys, argparse
 sys.path.insert(0, '.')
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 ws = [int(x) for x in sys.argv[2:]] or [4, 8, 16]          # (0 = one process, no pool: a single cold pass)
 import os
-args = argparse.Namespace(genes=int(os.environ.get('GENES', 10000)), warmup=0)       # GENES=50000: BASELINE configs[4]'s exemplar count
+from peppan_amd import synth
+args = argparse.Namespace(genes=int(os.environ.get('GENES', 10000)), warmup=0,       # GENES=50000: BASELINE configs[4]'s exemplar count
+                          presence=synth.PAN_GENOME_PRESENCE if os.environ.get('PRESENCE') == 'pan' else None)      # PRESENCE=pan: genomes of ~6 500 of the 50 000 genes (7.7 Mb)
 for w in ws:
     r = bench.map_strong(args, 0, 1, 0, n, workers=w, warm=True)
     if 'container_cpu_s' in r:

@@ -30,7 +30,7 @@ done
 python3 tools/sensitive_cost.py 10000 50000 > gpurun_out/sensitive_cost.txt 2>&1
 python3 tools/map_pool_rate.py 512 4 8 2>&1 | grep '^workers\|container CPU' > gpurun_out/map_pool_rate.txt
 { echo "# tools/map_pool_rate.py 2000 8: BASELINE configs[4]'s genome count at 10 000 exemplars on ONE GPU"; python3 tools/map_pool_rate.py 2000 8 2>&1 | grep '^workers\|container CPU'; } >> gpurun_out/map_pool_rate.txt
-{ echo "# GENES=50000 tools/map_pool_rate.py 96 4 8: 50 000 exemplars, genomes of 9.6 Mb (beyond the 8.39 Mbp sequence limit: the nucleotide tool's window path)"; GENES=50000 python3 tools/map_pool_rate.py 96 4 8 2>&1 | grep '^workers'; } >> gpurun_out/map_pool_rate.txt
+{ echo "# GENES=50000 PRESENCE=pan tools/map_pool_rate.py 128 0 4 8: BASELINE configs[4]'s exemplar count - 50 000 genes, genomes of ~6 500 of them (7.7 Mb) -, one process (cold) and 4 / 8 workers"; GENES=50000 PRESENCE=pan python3 tools/map_pool_rate.py 128 0 4 8 2>&1 | grep '^workers\|container CPU'; } >> gpurun_out/map_pool_rate.txt
 python3 tools/ab/concurrent_searches.py 10000 200 2>&1 | grep '^threads' > gpurun_out/concurrent_searches.txt
 python3 bench.py > gpurun_out/bench_line.txt 2> gpurun_out/bench_err.txt
 tail -c 1500 gpurun_out/bench_line.txt
