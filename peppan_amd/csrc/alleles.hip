@@ -192,6 +192,6 @@ int pep_k12_alleles(pep_ctx *ctx, const uint8_t *h_nt, const uint64_t *h_nt_off,
         PEP_HIP(ctx, hipMemcpyAsync(h_orf, d_orf, n * 8, hipMemcpyDeviceToHost, st));
     }
     PEP_HIP(ctx, hipMemcpyAsync(h_packed, W[10].p, pack_off[n_groups], hipMemcpyDeviceToHost, st));
-    PEP_HIP(ctx, hipStreamSynchronize(st));
+    PEP_HIP(ctx, pep_stream_wait(ctx));
     return PEP_OK;
 }

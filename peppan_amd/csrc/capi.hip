@@ -1,6 +1,7 @@
 // C ABI of libpeppan_hip.so (declared in include/peppan_hip.h): context, inputs, orchestration of K1..K8.
 #include "common.h"
 #include <chrono>
+#include <time.h>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -116,21 +117,40 @@ int pep_read_back_with_upload(pep_ctx *ctx, void *dst, const void *d_src, size_t
     return PEP_OK;
 }
 
-// PEPPAN_HIP_SPIN_US: how long a wait for the GPU polls before it sleeps (default 1.5 ms: a search's waits are shorter than a sleep's wake-up).  0 =
-// never poll - the events are created for blocking waits and the thread sleeps until the interrupt: what the mapping path's worker processes
-// use, which share a GPU and a machine's CPU allowance (peppan_amd/mapworkers.py)
+// PEPPAN_HIP_SPIN_US: how long a wait for the GPU polls before it gives the CPU up (default 1.5 ms: a search's waits are shorter than a sleep's wake-up).
+// 0 = never spin: the wait asks the event and naps (20 us growing to 200 us) in between - what the mapping path's worker processes use, which share a
+// GPU and a machine's CPU allowance (peppan_amd/mapworkers.py).  Naps, not blocking events: a wait that depends on an interrupt was seen to turn a
+// 2 s mapping into 218 s on one box of the pool (profiles/r04_map_pool_rate.txt), and asking costs a few per cent of a CPU.
 static long pep_spin_us()
 {
     static const long spin_us = [] { const char *e = getenv("PEPPAN_HIP_SPIN_US"); return e ? atol(e) : 1500L; }();
     return spin_us;
 }
 
-unsigned pep_wait_event_flags() { return hipEventDisableTiming | (pep_spin_us() <= 0 ? hipEventBlockingSync : 0u); }
+unsigned pep_wait_event_flags() { return hipEventDisableTiming; }
 
 hipError_t pep_event_wait(hipEvent_t ev)
 {
     const long spin_us = pep_spin_us();
-    if (spin_us <= 0) return hipEventSynchronize(ev);
+    if (spin_us <= 0) {
+        // (most waits of the small per-genome calls end within a few tens of microseconds: asked for without a nap first)
+        const auto t0 = std::chrono::steady_clock::now();
+        do {
+            for (int spin = 0; spin < 32; ++spin) {
+                const hipError_t q = hipEventQuery(ev);
+                if (q != hipErrorNotReady) return q;
+                __builtin_ia32_pause();
+            }
+        } while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(60));
+        long nap_ns = 20000;
+        for (;;) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q != hipErrorNotReady) return q;
+            struct timespec ts = {0, nap_ns};
+            nanosleep(&ts, nullptr);
+            if (nap_ns < 200000) nap_ns += nap_ns / 2;
+        }
+    }
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         for (int spin = 0; spin < 64; ++spin) {
@@ -433,7 +453,6 @@ int pep_ctx_create(int device, pep_ctx **out)
     memset(&ctx->stats, 0, sizeof(ctx->stats));
     pep_default_params(&ctx->params);
     if (hipSetDevice(device) != hipSuccess) { delete ctx; return PEP_ERR_HIP; }
-    if (pep_spin_us() <= 0) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);      // (every stream synchronisation of this process sleeps instead of polling)
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return PEP_ERR_HIP; }
     if (pin_reserve(ctx, ctx->pin_small, 16384) != PEP_OK) { *out = ctx; return PEP_ERR_HIP; }
     int rc = pep_selftest_dpp(ctx);

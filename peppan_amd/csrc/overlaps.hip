@@ -70,13 +70,13 @@ int pep_k11_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *h_contig, const in
     PEP_TRY(pep_scan_u64(ctx, W[4].as<uint64_t>(), W[5].as<uint64_t>(), n, W[7]));
     uint64_t total = 0;
     PEP_HIP(ctx, hipMemcpyAsync(&total, W[5].as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    PEP_HIP(ctx, hipStreamSynchronize(st));
+    PEP_HIP(ctx, pep_stream_wait(ctx));
     *n_pairs = total;
     if (total == 0 || total > cap) return PEP_OK;          // caller re-calls with a buffer of *n_pairs triples
     PEP_TRY(dev_reserve(ctx, W[6], total * 24));
     hipLaunchKernelGGL(ovl_sweep<true>, dim3(g), dim3(256), 0, st, a, (uint64_t *)nullptr, (const uint64_t *)W[5].as<uint64_t>(), W[6].as<int64_t>());
     PEP_HIP(ctx, hipGetLastError());
     PEP_HIP(ctx, hipMemcpyAsync(h_out, W[6].p, total * 24, hipMemcpyDeviceToHost, st));
-    PEP_HIP(ctx, hipStreamSynchronize(st));
+    PEP_HIP(ctx, pep_stream_wait(ctx));
     return PEP_OK;
 }

@@ -92,6 +92,6 @@ int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uin
                        ctx->ws[2].as<long long>());
     PEP_HIP(ctx, hipGetLastError());
     PEP_HIP(ctx, hipMemcpyAsync(h_out, ctx->ws[2].p, n * 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
-    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PEP_HIP(ctx, pep_stream_wait(ctx));
     return PEP_OK;
 }

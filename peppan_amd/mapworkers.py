@@ -23,8 +23,8 @@ numbered through all genomes - a round's first id is known once every round in f
 round's group counts, is told the round's first id as soon as the rounds in front have reported theirs, and then makes every member that
 lies inside its round completely (pickle stream, deflate, CRC: mapbsn.round_members); only the groups in front of its first and behind its
 last member boundary travel as columns.  The keeping process appends finished payloads: 0.5 ms per genome instead of 7.  While a worker
-makes the members of one round the next round is in its queue already, and a worker sleeps while it waits for the GPU it shares
-(PEPPAN_HIP_SPIN_US=0).  Measured: DESIGN.md section 5, tools/map_pool_rate.py.
+makes the members of one round the next round is in its queue already, and a worker naps while it waits for the GPU it shares
+(PEPPAN_HIP_SPIN_US=0: pep_event_wait).  Measured: DESIGN.md section 5, tools/map_pool_rate.py.
 """
 import os
 import pickle
@@ -221,7 +221,7 @@ class MapWorkers(object):
         authkey = os.urandom(16)
         self._listener = Listener(address, family='AF_UNIX', authkey=authkey)
         env = dict(os.environ, PEPPAN_WORKER_KEY=authkey.hex(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
-        env.setdefault('PEPPAN_HIP_SPIN_US', '0')           # the workers sleep while they wait for the GPU they share: polling would eat the CPU time the others need
+        env.setdefault('PEPPAN_HIP_SPIN_US', '0')           # the workers nap while they wait for the GPU they share: spinning would eat the CPU time the others need
         if device is not None:
             env['PEPPAN_HIP_DEVICE'] = str(int(device))
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
