@@ -751,6 +751,12 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert ms.returncode == 0, ms.stderr.decode()[-2000:]
     lm = json.loads([l for l in ms.stdout.decode().splitlines() if l.startswith('{')][0])
     assert lm['n_gpus'] == 2 and lm['scaling'] == 'strong' and lm['value'] > 0 and lm['rccl_ranks_seen'] == 2 and '5 genomes' in lm['config']['workload']
+    # ... and with every rank dealing ITS genomes to two worker processes of its own (each with a HIP context on the rank's device)
+    mw = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--workload', 'map', '--map-scaling', 'strong', '--genes', '600', '--map-genomes', '9', '--map-workers', '2'],
+                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert mw.returncode == 0, mw.stderr.decode()[-2000:]
+    lw = json.loads([l for l in mw.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert lw['n_gpus'] == 2 and lw['workers_per_rank'] == 2 and lw['value'] > 0 and '9 genomes' in lw['config']['workload']
 
 
 def test_multiple_hsps_per_subject(ctx):
