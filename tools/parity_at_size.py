@@ -30,7 +30,7 @@ bad = [f for f in ('q', 't', 'q_start', 'q_end', 't_start', 't_end', 'score', 'n
        if len(gh) != len(oh) or not np.array_equal(gh[f], oh[f])]
 bad += ['cigar arena'] if not np.array_equal(gc, oc) else []
 bad += ['stat ' + k for k in ('candidates', 'pairs', 'cells', 'tracebacks') if st[k] != ost[k]]
-print('%d genes x %s nt all-vs-all: GPU search %.1f ms (K1 inside: no), oracle %.1f s on every host thread; %d candidates (%d identical pairs scored by comparison), '
+print('%d genes x %s nt all-vs-all: GPU search %.1f ms (K1 inside: no), oracle %.1f s on the CPUs the box grants; %d candidates (%d identical pairs scored by comparison), '
       '%d traced pairs (%d one ungapped run), %d hits, %d CIGAR runs: %s'
       % (n, gene_len or 'log-normal', t_gpu * 1e3, t_cpu, st['candidates'], st['candidates_settled'], st['tracebacks'], st['tracebacks_gapless'], len(gh), len(gc),
          'IDENTICAL to the oracle in every field' if not bad else 'DIFFERENT: ' + ', '.join(bad)))
