@@ -341,7 +341,7 @@ def store_tab_members(rows, off, keys, date_time, threads=None, order=None):
     if threads is None:
         from .configure import effective_cpus
         threads = max(1, min(16, effective_cpus()))
-    cap = rows.nbytes // 2 + 256 * m + 4096
+    cap = rows.nbytes + rows.nbytes // 512 + 512 * m + 4096         # an upper bound (deflateBound + .npy header + entry header per member): one call; untouched pages cost nothing
     for _ in range(2):
         buf = np.empty(cap, dtype=np.uint8)
         need = lib.pep_store_tab_members(_ptr(rows), C.c_int64(rows.shape[1]), None if order is None else _ptr(order), _ptr(off), _ptr(keys), C.c_int64(m), C.c_uint32(dos_time), C.c_uint32(dos_date), C.c_int32(threads),
@@ -367,7 +367,7 @@ def store_tab_archive(rows, off, keys, date_time, threads=None, order=None):
     if threads is None:
         from .configure import effective_cpus
         threads = max(1, min(16, effective_cpus()))
-    cap = rows.nbytes // 2 + 320 * m + 4096
+    cap = rows.nbytes + rows.nbytes // 512 + 640 * m + 4096         # an upper bound, as above, plus the directory: one call
     for _ in range(2):
         buf = np.empty(cap, dtype=np.uint8)
         need = lib.pep_store_tab_archive(_ptr(rows), C.c_int64(rows.shape[1]), None if order is None else _ptr(order), _ptr(off), _ptr(keys), C.c_int64(m), C.c_uint32(dos_time),

@@ -431,7 +431,7 @@ extern "C" int64_t pep_store_tab_archive(const int64_t *rows, int64_t n_cols, co
     const int64_t body = tab_entries(rows, n_cols, order, off, key, n_members, dos_time, dos_date, threads, out, room, crc.data(), csize.data(), usize.data(), at.data(), method.data());
     if (body < 0) return body;
     if (body + dir_bytes >= (int64_t)0xFFFFFFFFll) return PEP_ERR_LIMIT;
-    if (body > room) return body + dir_bytes;                 // (nothing usable written: call again with this much)
+    if (body > room || cap < body + dir_bytes || !out) return body + dir_bytes;      // (nothing usable written: call again with this much - also for an archive without members and no room for its end record)
     dir.reserve((size_t)dir_bytes);
     for (int64_t m = 0; m < n_members; ++m) {
         const std::string name = std::to_string((long long)key[m]);

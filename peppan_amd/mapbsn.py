@@ -64,9 +64,34 @@ def _pack_member(data, strategy=zlib.Z_DEFAULT_STRATEGY):
     return co.compress(data) + co.flush(), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
 
 
-def _append_member(zf, name, packed):
+_FAST_APPEND = None
+
+
+def _fast_append_ok():
+    """The fast way below writes through zipfile's private fields (_lock, _writecheck, _didModify, start_dir, filelist, NameToInfo).  A
+    CPython that changed them would damage archives silently, so the first use in a process makes one archive in memory that way - a stored
+    and a deflated member -, reopens it and has zipfile check it; if anything is off every member goes through ZipFile.writestr instead."""
+    global _FAST_APPEND
+    if _FAST_APPEND is None:
+        try:
+            buf, big = io.BytesIO(), bytes(range(256)) * 40
+            with zipfile.ZipFile(buf, mode='w', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as zf:
+                _append_member(zf, 'a', _pack_member(b'abc'), checked=True)
+                _append_member(zf, 'b', _pack_member(big), checked=True)
+                zf.writestr('c', b'xyz')
+            with zipfile.ZipFile(io.BytesIO(buf.getvalue())) as zf:
+                _FAST_APPEND = zf.testzip() is None and zf.namelist() == ['a', 'b', 'c'] and zf.read('a') == b'abc' and zf.read('b') == big and zf.read('c') == b'xyz'
+        except Exception:
+            _FAST_APPEND = False
+    return _FAST_APPEND
+
+
+def _append_member(zf, name, packed, checked=False):
     """one finished member into an archive that is open for writing: what ZipFile.writestr does after its own compression"""
     payload, crc, size, method = packed
+    if not checked and not _fast_append_ok():
+        zf.writestr(name, bytes(payload) if method == zipfile.ZIP_STORED else zlib.decompress(bytes(payload), -15))
+        return
     zi = zipfile.ZipInfo(name, date_time=time.localtime(time.time())[:6])
     zi.compress_type, zi.external_attr = method, 0o600 << 16
     zi.CRC, zi.compress_size, zi.file_size = crc, len(payload), size
@@ -282,7 +307,7 @@ class MapBsn(object):
             return
         ids = tab[:, 0] if order is None else tab[:, 0][order]
         starts = np.concatenate([[0], np.flatnonzero(np.diff(ids)) + 1, [len(tab)]]).astype(np.int64)
-        if self.namelist or self.conn.filelist or self.mode == 'r':
+        if self.namelist or self.conn.filelist or self.mode == 'r' or not _fast_append_ok():
             if order is not None:
                 tab = tab[order]
             return self.update([tab[a:b] for a, b in zip(starts[:-1].tolist(), starts[1:].tolist())])
@@ -309,7 +334,7 @@ class MapBsn(object):
             zf.start_dir = zf.fp.tell()
             for name, c, cs, us, off in zip(map(str, keys.tolist()), crc.tolist(), csize.tolist(), usize.tolist(), at.tolist()):
                 zi = zipfile.ZipInfo(name, date_time=stamp)
-                zi.compress_type, zi.external_attr = zipfile.ZIP_DEFLATED if cs != us else zipfile.ZIP_STORED, 0o600 << 16
+                zi.compress_type, zi.external_attr = zipfile.ZIP_DEFLATED if us >= 4096 else zipfile.ZIP_STORED, 0o600 << 16      # (the library's rule, csrc/stores.hip tab_members: members of 4 KiB and more are deflated - whatever size came out)
                 zi.CRC, zi.compress_size, zi.file_size, zi.header_offset = c, cs, us, base + off
                 zf.filelist.append(zi)
                 zf.NameToInfo[name] = zi
@@ -771,7 +796,10 @@ def _all_groups(prefix, clust, jobs, ortho, old_prediction, params, search, ctx,
         if rank == 0:
             for r in range(world):
                 lo_r = (k * world + r) * per_round
-                for job, out in zip(jobs[lo_r:lo_r + per_round], gathered[r]):
+                block = jobs[lo_r:lo_r + per_round]
+                if len(gathered[r]) != len(block):          # (a rank that dealt by another unit: stores made of this would lose or repeat genomes)
+                    raise RuntimeError('get_map_bsn: rank %d returned %d genomes for a block of %d (genomes_per_round must be the same on every rank)' % (r, len(gathered[r]), len(block)))
+                for job, out in zip(block, gathered[r]):
                     yield job, out
 
 
@@ -1102,7 +1130,8 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         taxa.setdefault(s[0], []).append([g, s[1]])
     jobs = [(id, taxon, seq) for id, (taxon, seq) in enumerate(taxa.items())]
     ortho = OrthoRelation(orthoGroup)
-    if isinstance(old_prediction, str):
+    old_is_mine = isinstance(old_prediction, str)
+    if old_is_mine:
         old_prediction = MapBsn(old_prediction)            # opened once, read by every genome (the reference opens it per genome, PEPPAN.py:870)
     per_round = max(1, int(genomes_per_round))
     searcher = search or (lambda *a: _gpu_search(*a, genomes_per_batch=per_round))
@@ -1112,7 +1141,9 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
     if workers is not None and not (isinstance(workers, int) and workers <= 1):
         from .mapworkers import MapWorkers
         pool, own_pool = (workers, False) if isinstance(workers, MapWorkers) else (MapWorkers(int(workers), device=getattr(ctx, 'device', None)), True)     # (the workers' contexts: on the caller's device)
-        per_round = max(min(4, per_round), min(per_round, -(-len(jobs) // (4 * pool.n))))      # four rounds per worker or more: the last ones even the load out
+        if _dist_world(group)[1] == 1:     # (under torch.distributed `per_round` is the dealing unit of the RANKS - block k*world + rank, the number of gathers -
+            #                                 and must be the same on every rank whatever CPUs each was granted: the caller's value stays)
+            per_round = max(min(4, per_round), min(per_round, -(-len(jobs) // (4 * pool.n))))      # four rounds per worker or more: the last ones even the load out
         try:
             from . import _native
             pool.setup(prefix, clust, orthoGroup, old_prediction, params, search=search, per_batch=per_round,
@@ -1121,6 +1152,8 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         except BaseException:
             if own_pool:
                 pool.close()
+            if old_is_mine:
+                old_prediction.close()
             raise
     stores = _StoreWriter(conn, seq_conn, mat_conn, clf_conn, saveSeq)
     clock = time.perf_counter
@@ -1168,6 +1201,8 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         worker.join()
         if own_pool:
             pool.close()
+        if old_is_mine:
+            old_prediction.close()
     if failure:
         raise failure[0]
     t0 = clock()

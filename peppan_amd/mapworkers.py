@@ -127,6 +127,7 @@ def _serve(address, authkey):
     """the worker's life: set-ups and rounds until 'stop' or until the parent goes away"""
     import time
     conn = Client(address, family='AF_UNIX', authkey=authkey)
+    conn.send(('hello', os.getpid()))                               # (which of the processes the pool started is behind this connection)
     state = {}
     clock, spent = time.perf_counter, dict(recv=0., search=0., groups=0., wait_first=0., members=0., send=0., genomes=0)
     profile = None
@@ -204,20 +205,35 @@ def _serve(address, authkey):
             conn.send(('error', k, traceback.format_exc()))
 
 
+class _Hung(Exception):
+    """a worker did not answer within its round's deadline"""
+
+
 class MapWorkers(object):
     """n worker processes on one device.
 
         with MapWorkers(8) as pool:
             get_map_bsn(..., workers=pool)          # or workers=8: a pool for the length of that call
+
+    `round_deadline` = (seconds, seconds per genome of the round): how long ONE answer of a worker may take.  A worker that DIES is noticed
+    through its socket; one that HANGS (a GPU wait that never returns, a dead-locked library) would leave the call waiting for ever: it is
+    killed, a FRESH child process is started in its place (never a restart of the process that held the GPU) and takes the round once
+    more; a round that exceeds the deadline twice fails the call.  None: no deadline.  Default 120 s + 2 s per genome - a round of 16
+    genomes takes a third of a second, a worker's first one a few seconds - or PEPPAN_WORKER_DEADLINE="seconds,seconds per genome".
     """
 
-    def __init__(self, n, device=None):
+    def __init__(self, n, device=None, round_deadline='default'):
         self.n = int(n)
         if self.n < 1:
             raise ValueError('MapWorkers: at least one worker')
+        if round_deadline == 'default':
+            txt = os.environ.get('PEPPAN_WORKER_DEADLINE', '120,2')
+            round_deadline = None if txt.strip().lower() in ('', 'none', '0') else tuple(float(x) for x in (txt.split(',') + ['0'])[:2])
+        self.round_deadline = round_deadline
+        self.replaced = 0                                   # workers killed for exceeding the deadline and replaced, over the pool's life
         self._dir = tempfile.mkdtemp(prefix='pep_workers_')
         self._bulk = tempfile.mkdtemp(prefix='pep_workers_', dir=_scratch_root())      # sequences out, members back: files, not messages
-        address = os.path.join(self._dir, 's')
+        self._address = address = os.path.join(self._dir, 's')
         authkey = os.urandom(16)
         self._listener = Listener(address, family='AF_UNIX', authkey=authkey)
         env = dict(os.environ, PEPPAN_WORKER_KEY=authkey.hex(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
@@ -226,21 +242,38 @@ class MapWorkers(object):
             env['PEPPAN_HIP_DEVICE'] = str(int(device))
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env['PYTHONPATH'] = os.pathsep.join([root] + [p for p in sys.path if p] + [env.get('PYTHONPATH', '')])     # a search function of the caller's must be importable
-        self._procs, self._conns = [], []
+        self._env = env
+        self._procs, self._conns, started = [], [], {}
+        self._setup_msg, self._spawn_lock = None, threading.Lock()
         self.spent = dict(sequences_to_files=0., members_from_files=0.)        # seconds of this process's feeder threads (all of them together)
         try:
-            for _ in range(self.n):
-                self._procs.append(subprocess.Popen([sys.executable, '-m', 'peppan_amd.mapworkers', address], env=env, stdin=subprocess.DEVNULL,
-                                                    stdout=sys.stderr.fileno() if hasattr(sys.stderr, 'fileno') and self._has_fd(sys.stderr) else subprocess.DEVNULL))
             try:
                 self._listener._listener._socket.settimeout(120.)      # (a worker that dies before it connects must not leave accept() waiting for ever)
             except AttributeError:
                 pass
             for _ in range(self.n):
-                self._conns.append(self._listener.accept())
+                p = self._spawn()
+                started[p.pid] = p
+            for _ in range(self.n):
+                conn = self._listener.accept()
+                self._conns.append(conn)
+                self._procs.append(started.pop(self._hello(conn)))        # connections arrive in any order: _procs[i] is the process behind _conns[i]
         except BaseException:
+            self._procs += list(started.values())
             self.close()
             raise
+            self.close()
+            raise
+
+    def _spawn(self):
+        return subprocess.Popen([sys.executable, '-m', 'peppan_amd.mapworkers', self._address], env=self._env, stdin=subprocess.DEVNULL,
+                                stdout=sys.stderr.fileno() if hasattr(sys.stderr, 'fileno') and self._has_fd(sys.stderr) else subprocess.DEVNULL)
+
+    @staticmethod
+    def _hello(conn):
+        if not conn.poll(120.):
+            raise RuntimeError('MapWorkers: a worker connected and did not say who it is')
+        return conn.recv()[1]
 
     @staticmethod
     def _has_fd(stream):
@@ -293,7 +326,7 @@ class MapWorkers(object):
         if not isinstance(old_prediction, str):
             old_prediction = getattr(old_prediction, 'fname', old_prediction)        # an open MapBsn is reopened by every worker
         msg = ('setup', dict(prefix=prefix, clust=clust, orthoGroup=orthoGroup, old_prediction=old_prediction, params=dict(params), search=search, per_batch=int(per_batch), ctx_class=ctx_class, form=form, save_seq=bool(save_seq)))
-        self.form = form
+        self.form, self._setup_msg = form, msg
         for c in self._conns:
             c.send(msg)
         for c in self._conns:
@@ -301,10 +334,38 @@ class MapWorkers(object):
             if r[0] != 'ready':
                 raise RuntimeError('MapWorkers: a worker failed to set up:\n' + r[2])
 
+    def _replace(self, i):
+        """worker i is given up: killed, and a fresh child process - started by this process like the first ones, set up like them - takes its place"""
+        with self._spawn_lock:                          # (one at a time: the process started here is the one accepted here)
+            old = self._procs[i]
+            try:
+                old.kill()
+                old.wait(timeout=20)
+            except Exception:
+                pass
+            try:
+                self._conns[i].close()
+            except Exception:
+                pass
+            self._procs[i] = self._spawn()
+            conn = self._conns[i] = self._listener.accept()
+            if self._hello(conn) != self._procs[i].pid:
+                raise RuntimeError('MapWorkers: an unknown process connected in place of the replacement worker')
+            self.replaced += 1
+        conn.send(self._setup_msg)
+        if not conn.poll(120.):
+            raise RuntimeError('the replacement of a hung mapping worker did not come up')
+        r = conn.recv()
+        if r[0] != 'ready':
+            raise RuntimeError('the replacement of a hung mapping worker failed to set up:\n' + r[2])
+        return conn
+
     def rounds(self, jobs, per_round, first=0):
         """In job order: (job, GenomeGroups or StoreBlock) for every job - forms 'groups' / 'stores' - or (the round's jobs, what the stores
         take from the round) for every round - form 'members', `first` being the id of the first group of the first round.  Rounds of
-        `per_round` jobs go to whichever worker is free; at most two rounds per worker are in flight or waiting to be taken."""
+        `per_round` jobs go to whichever worker is free; at most two rounds per worker are in flight or waiting to be taken.
+        Whatever goes wrong in the threads that talk to the workers - a worker gone or hung, a sequence that cannot be written, a job that
+        cannot be pickled - reaches the caller as RuntimeError for the first round concerned: no round is left waiting."""
         per_round = max(1, int(per_round))
         n_rounds = -(-len(jobs) // per_round)
         members = getattr(self, 'form', 'groups') == 'members'
@@ -312,9 +373,10 @@ class MapWorkers(object):
         slots = threading.Semaphore(2 * self.n)
         state = dict(next=0, stop=False)
         results, counts, first_of = {}, {}, {0: int(first)}
+        again = set()                                   # rounds that have been given to a replacement worker already
 
-        def hand_out(conn):
-            """the next round into the worker's queue (None when there is none, or the call is being given up)"""
+        def take_number():
+            """the number of the next round (None when there is none, or the call is being given up)"""
             slots.acquire()
             with cond:
                 k = state['next']
@@ -322,87 +384,132 @@ class MapWorkers(object):
                     slots.release()
                     return None
                 state['next'] = k + 1
-            mine = jobs[k * per_round:(k + 1) * per_round]
-            try:
-                if members:
-                    j_path = os.path.join(self._bulk, 'j%d' % k)
-                    t0 = time.perf_counter()
-                    meta = _jobs_to_file(j_path, mine)
-                    self.spent['sequences_to_files'] += time.perf_counter() - t0
-                    conn.send(('round', k, meta, j_path))
-                else:
-                    conn.send(('round', k, mine))
-            except (EOFError, OSError) as e:                    # the round has a number already: the call must hear about it
-                with cond:
-                    results[k] = ('error', k, 'round %d could not be handed to a worker (worker gone, or no room in %s): %r' % (k, self._bulk, e))
-                    state['stop'] = True
-                    cond.notify_all()
-                raise
             return k
 
-        def feeder(conn):
+        def send_round(i, k):
+            mine = jobs[k * per_round:(k + 1) * per_round]
+            if members:
+                j_path = os.path.join(self._bulk, 'j%d' % k)
+                t0 = time.perf_counter()
+                meta = _jobs_to_file(j_path, mine)
+                self.spent['sequences_to_files'] += time.perf_counter() - t0
+                self._conns[i].send(('round', k, meta, j_path))
+            else:
+                self._conns[i].send(('round', k, mine))
+
+        def answer(i, k):
+            """the worker's next message about round k - within the round's deadline"""
+            conn = self._conns[i]
+            if self.round_deadline is not None:
+                limit = self.round_deadline[0] + self.round_deadline[1] * len(jobs[k * per_round:(k + 1) * per_round])
+                if not conn.poll(limit):
+                    raise _Hung('no answer about round %d within %.0f s' % (k, limit))
+            return conn.recv()
+
+        def one_round(i, k, held, resend):
+            """round k (in worker i's queue already) to its end -> the message for the caller.  Form 'members': the next round is handed
+            out (held[1]; `resend`: the round that was held ahead when the worker had to be replaced) while the worker makes k's members"""
+            msg = answer(i, k)
+            if msg[0] == 'counts':
+                with cond:
+                    counts[k] = sum(msg[2])
+                    j = k
+                    while j in counts and j in first_of:            # (every round whose predecessors have all reported now knows its first id)
+                        first_of[j + 1] = first_of[j] + counts[j]
+                        j += 1
+                    cond.notify_all()
+                    while k not in first_of and not state['stop']:
+                        cond.wait()
+                    go = ('emit', k, first_of[k], os.path.join(self._bulk, 'r%d' % k)) if k in first_of else ('drop', k)
+                self._conns[i].send(go)
+                if go[0] == 'emit':
+                    held[1] = resend if resend is not None else take_number()
+                    if held[1] is not None:
+                        send_round(i, held[1])
+                msg = answer(i, k)
+                if go[0] == 'drop':
+                    msg = ('dropped', k, None)
+                elif msg[0] == 'done' and msg[2] is not None and 'blob' in msg[2]:
+                    t0 = time.perf_counter()
+                    msg = ('done', k, _members_from_file(msg[2]))
+                    self.spent['members_from_files'] += time.perf_counter() - t0
+            return msg
+
+        def feeder(i):
             # form 'members': while the worker makes the members of round k, the next round is in its queue already (its sequences written, the
             # message sent) - the worker never waits for this thread between two rounds
-            k = ahead = None
+            held = [None, None]                     # the round this thread is waiting for, the round handed out ahead of its end
+            resend = None
             try:
-                k = hand_out(conn)
-                while k is not None:
-                    ahead = None
-                    msg = conn.recv()
-                    if msg[0] == 'counts':
-                        with cond:
-                            counts[k] = sum(msg[2])
-                            j = k
-                            while j in counts and j in first_of:            # (every round whose predecessors have all reported now knows its first id)
-                                first_of[j + 1] = first_of[j] + counts[j]
-                                j += 1
-                            cond.notify_all()
-                            while k not in first_of and not state['stop']:
-                                cond.wait()
-                            go = ('emit', k, first_of[k], os.path.join(self._bulk, 'r%d' % k)) if k in first_of else ('drop', k)
-                        conn.send(go)
-                        if go[0] == 'emit':
-                            ahead = hand_out(conn)
-                        msg = conn.recv()
-                        if go[0] == 'drop':
-                            msg = ('dropped', k, None)
-                        elif msg[0] == 'done' and msg[2] is not None and 'blob' in msg[2]:
-                            t0 = time.perf_counter()
-                            msg = ('done', k, _members_from_file(msg[2]))
-                            self.spent['members_from_files'] += time.perf_counter() - t0
+                held[0] = take_number()
+                if held[0] is not None:
+                    send_round(i, held[0])
+                while held[0] is not None:
+                    k = held[0]
+                    try:
+                        msg = one_round(i, k, held, resend)
+                    except _Hung as e:
+                        mine = [r for r in held if r is not None]
+                        if again.intersection(mine):
+                            try:
+                                self._replace(i)            # (the pool stays usable: the process that hangs is not left behind in it)
+                            except Exception:
+                                pass
+                            raise RuntimeError('a mapping worker hung twice: %s' % (e,))
+                        again.update(mine)
+                        sys.stderr.write('MapWorkers: %s - the worker (pid %d) is killed, a fresh process takes the round once more\n' % (e, self._procs[i].pid))
+                        self._replace(i)
+                        resend, held[1] = (held[1] if held[1] is not None else resend), None
+                        send_round(i, k)
+                        continue
+                    resend = None
                     with cond:
                         results[k] = msg
                         if msg[0] != 'done':
                             state['stop'] = True                            # (rounds behind a failed one will never learn their first id)
                         cond.notify_all()
                     if msg[0] != 'done':
+                        held[0] = None
                         break
-                    k, ahead = (ahead, None) if members else (hand_out(conn), None)
-                if ahead is not None:                                       # a round was handed out ahead of one that failed: take it back, in step with the worker
-                    m = conn.recv()
+                    if members:
+                        held[0], held[1] = held[1], None
+                    else:
+                        held[0] = take_number()
+                        if held[0] is not None:
+                            send_round(i, held[0])
+                if held[1] is not None:                                     # a round was handed out ahead of one that failed: take it back, in step with the worker
+                    ahead = held[1]
+                    m = answer(i, ahead)
                     if m[0] == 'counts':
-                        conn.send(('drop', ahead))
-                        conn.recv()
+                        self._conns[i].send(('drop', ahead))
+                        answer(i, ahead)
                     with cond:
                         results[ahead] = ('dropped', ahead, None)
+                        held[1] = None
                         cond.notify_all()
                 self.spent['feeder_threads_cpu'] = self.spent.get('feeder_threads_cpu', 0.) + time.thread_time()
-            except (EOFError, OSError) as e:
+            except BaseException as e:              # (EOFError / OSError: the worker went away; anything else - a sequence that is not ASCII, a job
+                #                                      that cannot be pickled, no memory for a round's members: the rounds this thread holds have
+                #                                      numbers already and the caller waits for them - it must hear)
+                gone = isinstance(e, (EOFError, OSError))
+                text = ('a mapping worker went away: %r' % (e,)) if gone else traceback.format_exc()
                 with cond:
-                    for r in (k, ahead):
+                    for r in held:
                         if r is not None and r not in results:
-                            results[r] = ('error', r, 'a mapping worker went away: %r' % (e,))
+                            results[r] = ('error', r, text)
                     state['stop'] = True
                     cond.notify_all()
 
-        threads = [threading.Thread(target=feeder, args=(c,), daemon=True) for c in self._conns[:max(1, min(self.n, n_rounds))]]
+        threads = [threading.Thread(target=feeder, args=(i,), daemon=True) for i in range(max(1, min(self.n, n_rounds)))]
         for t in threads:
             t.start()
         try:
             for k in range(n_rounds):
                 with cond:
                     while k not in results:
-                        cond.wait()
+                        if not any(t.is_alive() for t in threads):          # (cannot happen - every thread reports what it holds - but a call that waits for ever is the worst outcome)
+                            raise RuntimeError('MapWorkers: round %d was lost (no thread is working on it)' % k)
+                        cond.wait(5.)
                     msg = results.pop(k)
                 if msg[0] != 'done':
                     raise RuntimeError('MapWorkers: round %d failed in a worker:\n%s' % (k, msg[2]))

@@ -2,6 +2,7 @@
 iter_map_bsn / compare_prediction / get_map_bsn / MapBsn (tests/golden/make_golden.py g14_g15; PEPPAN.py:27-114, 759-989)."""
 import copy
 import os
+import time
 
 import numpy as np
 import pytest
@@ -221,6 +222,49 @@ def test_a_worker_that_dies_fails_the_call(world, tmp_path):
             p.wait()
         with pytest.raises(RuntimeError, match='went away|worker gone'):
             list(pool.rounds([job(0), job(1), job(2)], 1))
+
+
+@pytest.mark.parametrize('form', ['members', 'groups'])
+def test_a_worker_that_hangs_is_replaced_once_then_the_call_fails(world, tmp_path, form):
+    """a worker that does not answer within the round's deadline is killed, a FRESH child process takes its round once more (the stores
+    do not notice); a round that exceeds the deadline again fails the call - nothing waits for ever (the 218 s stall of round 4)"""
+    from map_pool_helpers import sleepy_search
+    from peppan_amd.mapworkers import MapWorkers
+    g, old_fn, bsn_fn = world
+    job = lambda i: (i, 0, [[int(c), s] for c, s in g['cases'][i]['contigs'].items()])
+    prefix = str(tmp_path / 'm')
+    ids = lambda out: [(j[0][0] if form == 'members' else j[0]) for j, G in out]
+    with MapWorkers(2, round_deadline=(4., 0.5)) as pool:
+        pool.setup(prefix, 'CL', bsn_fn, old_fn, dict(g['params']), search=sleepy_search, ctx_class=OracleContext, form=form)
+        assert ids(pool.rounds([job(0), job(1), job(2)], 1)) == [0, 1, 2] and pool.replaced == 0
+        first = {p.pid for p in pool._procs}
+        open(prefix + '.hang_once', 'w').close()
+        t0 = time.time()
+        assert ids(pool.rounds([job(2), job(0), job(1), job(2), job(0)], 1)) == [2, 0, 1, 2, 0]
+        assert pool.replaced == 1 and time.time() - t0 < 40
+        assert len(first & {p.pid for p in pool._procs}) == 1              # one of the two is a new process
+        open(prefix + '.hang_always', 'w').close()
+        with pytest.raises(RuntimeError, match='hung twice'):
+            list(pool.rounds([job(0), job(1)], 1))
+        os.unlink(prefix + '.hang_always')
+
+
+def test_a_job_that_cannot_be_handed_out_fails_the_call(world, tmp_path):
+    """whatever goes wrong in the threads that feed the workers reaches the caller (review, round 4: a sequence with a non-ASCII character
+    raised in the feeder thread and the call waited for ever)"""
+    from map_pool_helpers import canned_search
+    from peppan_amd.mapworkers import MapWorkers
+    g, old_fn, bsn_fn = world
+    job = lambda i: (i, 0, [[int(c), s] for c, s in g['cases'][i]['contigs'].items()])
+    bad = (1, 0, [[5, 'ACGT\u00e9ACGT']])
+    with MapWorkers(2) as pool:
+        pool.setup(str(tmp_path / 'm'), 'CL', bsn_fn, old_fn, dict(g['params']), search=canned_search, ctx_class=OracleContext, form='members')
+        with pytest.raises(RuntimeError, match='UnicodeEncodeError'):
+            list(pool.rounds([job(0), bad, job(2)], 1))
+        pool.setup(str(tmp_path / 'm'), 'CL', bsn_fn, old_fn, dict(g['params']), search=canned_search, ctx_class=OracleContext, form='groups')
+        with pytest.raises(RuntimeError, match='pickle|Pickl'):
+            list(pool.rounds([job(0), (1, 0, [[5, (lambda: 0)]]), job(2)], 1))
+        assert [j[0] for j, G in pool.rounds([job(2), job(0)], 1)] == [2, 0]              # the pool is still in step
 
 
 def _random_groups(rng, genome, n_groups, n_genes):
