@@ -74,43 +74,46 @@ class uopen(object):
         self.fstream.close()
 
 
+def _record_text(lines):
+    """the lines of one record's body -> its sequence: blanks inside and between the lines dropped, upper case"""
+    return ''.join(''.join(lines).split()).upper()
+
+
 def readFasta(fasta, headOnly=False):
-    """name (first token of the header) -> upper-cased sequence; '#' lines ignored"""
-    names, chunks = [], {}
+    """FASTA file -> {name: sequence}: the name is the first word of a header line, the sequence everything up to the next header
+    without its white space, upper-cased; lines that start with '#' are comments; of two records with one name the later counts
+    (configure.py:118-128).  The file is read in one piece and cut at the headers."""
     with uopen(fasta) as fin:
-        cur = None
-        for line in fin:
-            if line.startswith('>'):
-                cur = line[1:].strip().split()[0]
-                chunks[cur] = []
-                names.append(cur)
-            elif len(line) > 0 and not line.startswith('#') and not headOnly:
-                chunks[cur].extend(line.strip().split())
-    return {n: ''.join(chunks[n]).upper() for n in chunks}
+        text = fin.read()
+    records = {}
+    for block in re.split(r'^>', text, flags=re.MULTILINE)[1:]:             # (what stands in front of the first header belongs to no record)
+        header, _, body = block.partition('\n')
+        records[header.split()[0]] = '' if headOnly else _record_text([ln for ln in body.splitlines() if not ln.startswith('#')])
+    return records
+
+
+_PSEUDO_QUALITY = bytes(ord('I') if chr(c) in 'ACGTacgt' else ord('!') for c in range(256))
 
 
 def readFastq(fastq, with_qual=True):
-    """FASTQ or FASTA -> (sequences, qualities); FASTA input gets 'I'/'!' pseudo-qualities like the reference.
-    with_qual=False skips building them (nothing on the search path reads qualities; they cost more than the search)."""
+    """FASTQ file -> ({name: sequence}, {name: quality string}), four lines per read, the name being the first word behind the '@'.
+    A file that does not start with '@' is taken as FASTA and every sequence gets a made-up quality: 'I' under A, C, G, T and '!' under
+    anything else (configure.py:129-147).  with_qual=False leaves the made-up qualities out (nothing on the search path reads them, and
+    for a genome they cost more than its search)."""
     with uopen(fastq) as fin:
-        first = fin.readline()
-    if not first.startswith('@'):
+        text = fin.read()
+    if not text.startswith('@'):
         seq = readFasta(fastq)
         if not with_qual:
             return seq, None
-        return seq, {n: re.sub(r'[^!]', 'I', re.sub(r'[^ACGTacgt]', '!', s)) for n, s in seq.items()}
+        return seq, {name: s.encode('latin-1', 'replace').translate(_PSEUDO_QUALITY).decode('ascii') for name, s in seq.items()}
+    lines = text.splitlines()
+    lines += [''] * (-len(lines) % 4)
     seq, qual = {}, {}
-    with uopen(fastq) as fin:
-        for k, line in enumerate(fin):
-            m = k % 4
-            if m == 0:
-                name = line[1:].strip().split()[0]
-                seq[name], qual[name] = [], []
-            elif m == 1:
-                seq[name].extend(line.strip().split())
-            elif m == 3:
-                qual[name].extend(line.strip().split())
-    return {n: ''.join(s).upper() for n, s in seq.items()}, {n: ''.join(q) for n, q in qual.items()}
+    for header, bases, _, scores in zip(lines[0::4], lines[1::4], lines[2::4], lines[3::4]):
+        name = header[1:].split()[0]
+        seq[name], qual[name] = _record_text([bases]), ''.join(scores.split())
+    return seq, qual
 
 
 _COMP = str.maketrans('ACGTN', 'TGCAN')
@@ -161,29 +164,30 @@ def _translate_codes(codes, tab):
     return ''.join(aa.tolist())
 
 
+_FRAME_SETS = {'F': (1, 2, 3), 'R': (4, 5, 6), '7': (1, 2, 3, 4, 5, 6)}
+
+
+def _frame_list(frame):
+    """'F' | 'R' | '7' (any case; 7 as a number too) or a comma list of frame numbers 1..6"""
+    key = str(frame).upper()
+    return _FRAME_SETS[key] if key in _FRAME_SETS else tuple(int(f) for f in key.split(','))
+
+
+def _proteins(nt, frames, tab):
+    """the translations of one nucleotide string in the asked frames (4..6: the reverse strand, complemented)"""
+    fw = _NT[np.frombuffer(nt.upper().encode('ascii'), dtype=np.uint8)]
+    rv = np.where(fw >= 0, 3 - fw, fw)[::-1] if max(frames) > 3 else None
+    return [_translate_codes(fw[f - 1:] if f <= 3 else rv[f - 4:], tab) for f in frames]
+
+
 def transeq(seq, frame=7, transl_table=None, markStarts=False):
     """dict name->nt (or list of [name, nt]) -> dict name->[protein per frame] (or list of [name, [..]]).
     frame: 'F' (1,2,3), 'R' (4,5,6), '7' (all six) or a comma list; stops and ambiguous codons are 'X',
-    codons containing '-' are '-', a trailing partial codon is 'X'; transl_table 4 reads TGA as W."""
-    frames = {'F': [1, 2, 3], 'R': [4, 5, 6], '7': [1, 2, 3, 4, 5, 6]}.get(str(frame).upper())
-    if frames is None:
-        frames = [int(f) for f in str(frame).split(',')]
-    tab = _codon_table(transl_table, markStarts)
-    items = seq.items() if isinstance(seq, dict) else seq
-    out = []
-    for name, s in items:
-        fw = _NT[np.frombuffer(s.upper().encode('ascii'), dtype=np.uint8)]
-        rv = None
-        prots = []
-        for f in frames:
-            if f <= 3:
-                prots.append(_translate_codes(fw[f - 1:], tab))
-            else:
-                if rv is None:
-                    rv = np.where(fw >= 0, 3 - fw, fw)[::-1]
-                prots.append(_translate_codes(rv[f - 4:], tab))
-        out.append([name, prots])
-    return dict(out) if isinstance(seq, dict) else out
+    codons containing '-' are '-', a trailing partial codon is 'X'; transl_table 4 reads TGA as W (configure.py:160-194)."""
+    frames, tab = _frame_list(frame), _codon_table(transl_table, markStarts)
+    if isinstance(seq, dict):
+        return {name: _proteins(nt, frames, tab) for name, nt in seq.items()}
+    return [[name, _proteins(nt, frames, tab)] for name, nt in seq]
 
 
 # ---------------------------------------------------------------------------------------------- BLOSUM62

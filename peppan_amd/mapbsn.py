@@ -64,6 +64,11 @@ def _pack_member(data, strategy=zlib.Z_DEFAULT_STRATEGY):
     return co.compress(data) + co.flush(), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
 
 
+def _archive(where, mode):
+    """a store's zip archive: deflate level 1, zip64 when it grows that far"""
+    return zipfile.ZipFile(where, mode=mode, compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
+
+
 _FAST_APPEND = None
 
 
@@ -75,7 +80,7 @@ def _fast_append_ok():
     if _FAST_APPEND is None:
         try:
             buf, big = io.BytesIO(), bytes(range(256)) * 40
-            with zipfile.ZipFile(buf, mode='w', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as zf:
+            with _archive(buf, 'w') as zf:
                 _append_member(zf, 'a', _pack_member(b'abc'), checked=True)
                 _append_member(zf, 'b', _pack_member(big), checked=True)
                 zf.writestr('c', b'xyz')
@@ -115,7 +120,7 @@ class _LazyZip(object):
 
     def _open(self):
         if self._zf is None:
-            self.__dict__['_zf'] = zipfile.ZipFile(self._fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
+            self.__dict__['_zf'] = _archive(self._fname, 'a')
         return self._zf
 
     def __getattr__(self, name):
@@ -135,7 +140,7 @@ class MapBsn(object):
 
     def __init__(self, fname, mode='r'):
         self.fname, self.mode = fname, mode
-        self.conn = zipfile.ZipFile(fname, mode=mode, compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
+        self.conn = _archive(fname, mode)
         self.namelist = set(self.conn.namelist())
         # writes go through ONE background thread per store, in order; the members it appends are made and deflated by a shared pool
         self._queue = self._thread = self._error = None
@@ -224,12 +229,12 @@ class MapBsn(object):
         self.namelist.discard(key)
         self.conn.close()
         tmp = self.fname + '.rewrite'
-        with zipfile.ZipFile(self.fname) as src, zipfile.ZipFile(tmp, 'w', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as dst:
+        with zipfile.ZipFile(self.fname) as src, _archive(tmp, 'w') as dst:
             for name in src.namelist():
                 if name != key:
                     dst.writestr(name, src.read(name))
         os.replace(tmp, self.fname)
-        self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
+        self.conn = _archive(self.fname, 'a')
 
     def _start_writer(self):
         if self._thread is None:
@@ -270,32 +275,33 @@ class MapBsn(object):
         self._queue.put((self.conn, key, tuple(packed)))
         self.namelist.add(key)
 
-    def update(self, dataset):
-        """Rows for many keys at once (PEPPAN.py:91-113): every 2-D array of `dataset` belongs to the key in its first cell and is
-        appended to what the store holds under that key; members that are not mentioned stay (empty ones are dropped).  The archive
-        is rebuilt beside the old one and swapped in, as zip members cannot grow in place."""
-        incoming = {}
-        for rows in dataset:
-            incoming[str(rows[0][0])] = rows                       # (a key named twice: the later array counts)
-        self._flush()
+    def _swap_in(self, members):
+        """the archive rebuilt from (key, array) pairs beside the old one, then put in its place (zip members cannot grow where they are)"""
         side = self.fname[:-4] + '.tmp.npz'
         listed = set()
-        with zipfile.ZipFile(side, mode='w', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1) as fresh:
-            for key in list(incoming) + sorted(self.namelist.difference(incoming)):
-                have, more = self.get(key), incoming.get(key)
-                if more is not None and len(have):
-                    more = np.vstack([have, more])
-                elif more is None:
-                    more = have
-                if len(more):
-                    self._save(fresh, key, more)
-                    listed.add(key)
+        with _archive(side, 'w') as fresh:
+            for key, val in members:
+                self._save(fresh, key, val)
+                listed.add(key)
             self._flush()
         self.conn.close()
         os.replace(side, self.fname)
         self.namelist = listed
-        self.conn = zipfile.ZipFile(self.fname, mode='a', compression=zipfile.ZIP_DEFLATED, allowZip64=True, compresslevel=1)
+        self.conn = _archive(self.fname, 'a')
 
+    def update(self, dataset):
+        """Rows for many keys at once (PEPPAN.py:91-113): every 2-D array of `dataset` belongs to the key in its first cell and is
+        appended to what the store holds under that key; members that are not mentioned stay, empty ones are dropped."""
+        incoming = {str(rows[0][0]): rows for rows in dataset}         # (a key named twice: the later array counts)
+        self._flush()
+
+        def grown():
+            for key, rows in incoming.items():
+                have = self.get(key)
+                yield key, np.vstack([have, rows]) if len(have) else rows
+            for key in sorted(self.namelist.difference(incoming)):
+                yield key, self.get(key)
+        self._swap_in((key, val) for key, val in grown() if len(val))
 
     def update_table(self, tab, order=None):
         """update() for an int64 table sorted by its first column - or sorted by it when taken in the order `order` -: the rows of every key

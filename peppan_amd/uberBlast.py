@@ -231,50 +231,86 @@ def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, m
 # ------------------------------------------------------------------------------------------------------------
 # rescoring (cigar2score, uberBlast.py:221-269)
 # ------------------------------------------------------------------------------------------------------------
-def cigar2score(data):
-    """(cigar, rSeq, qSeq, frame, mode, gapOpen, gapExtend, table_id) -> (identity, score); host version of all
-    three modes on encoded sequences (A0 C1 G3 T4 other 2).  Mode 1 is what RunBlast.reScore runs on the GPU."""
-    cigar, r_seq, q_seq, frame, mode, gap_open, gap_ext, table_id = data
-    gt = gtable
-    if table_id == 4:
-        gt = gtable.copy()
-        gt[56] = 22            # TGA -> W; the reference patches its module table in place (uberBlast.py:223-224)
-    phase = (frame - 1) % 3
-    gaps, q_cols, r_cols = [], [], []
-    qi = ri = 0
-    for n, op in cigar:
-        if op == 'M':
-            q_cols.append(q_seq[qi:qi + n]); r_cols.append(r_seq[ri:ri + n])
-            qi += n; ri += n
-        elif op == 'D':
-            gaps.append(n); ri += n
-        elif op == 'I':
-            gaps.append(n)
-            if mode > 1:
-                q_cols.append(q_seq[qi:qi + n]); r_cols.append(np.full(n, -1, dtype=int))
-            qi += n
-    n_gap, b_gap = len(gaps), int(np.sum(gaps)) if gaps else 0
-    m_gap = int(np.sum([g for g in gaps if g > 3])) if gaps else 0
-    qa, ra = np.concatenate(q_cols), np.concatenate(r_cols)
-    gap_cost = n_gap * (gap_open - gap_ext) + b_gap * gap_ext
+_CODON_WEIGHT = (9. / 7., 9. / 7., 3. / 7.)        # what a match is worth at the three codon positions in mode 3 (uberBlast.py:256)
+
+
+def rescore_alignments(run_len, run_op, run_owner, q_cat, q_at, r_cat, r_at, first_base, mode, gap_open=6, gap_extend=1, table_id=11):
+    """Identity and score of MANY alignments at once, all three modes of the reference's cigar2score (uberBlast.py:221-269).
+
+    The alignments' CIGAR runs lie back to back - `run_len`, `run_op` (0 M, 1 I = query only, 2 D = reference only), `run_owner` = the
+    alignment a run belongs to, ascending -; `q_cat` / `r_cat` hold the aligned stretches of all queries / references back to back in
+    the rescoring alphabet (A 0, C 1, G 3, T 4, other 2; the reference strand already turned), alignment a starting at `q_at[a]` /
+    `r_at[a]`; `first_base[a]` is its 1-based first query base (the codon phase of modes 2 / 3).
+    Every column of every alignment becomes one element of flat arrays and every count is one np.bincount over them; the floating-point
+    expressions keep the reference's order of operations (golden G5 holds the three modes to the last bit).
+      mode 1  columns = M runs; identical bases, 3 / -1 per column, affine gaps
+      mode 3  columns = M and I runs (an I column never matches) cut to whole codons from the query's phase on; matches weighted by position
+      mode 2  the same columns as codons without an I column -> amino acids (table 11, or 4: TGA = W) -> identical residues, BLOSUM62
+    -> (identity float64[n], score float64[n])"""
+    n = len(q_at)
+    run_len, run_op, run_owner = (np.asarray(x, dtype=np.int64) for x in (run_len, run_op, run_owner))
+    gap = run_op != 0
+    n_gap = np.bincount(run_owner, weights=gap, minlength=n)                             # float64 counts: exact, and what the formulas below take
+    b_gap = np.bincount(run_owner, weights=run_len * gap, minlength=n)
+    m_gap = np.bincount(run_owner, weights=run_len * (gap & (run_len > 3)), minlength=n)
+    gap_cost_open, gap_cost_len = n_gap * (gap_open - gap_extend), b_gap * gap_extend
+    # where every run starts inside its alignment's two stretches: exclusive sums of the bases it consumes, restarted per alignment
+    first_run = np.searchsorted(run_owner, np.arange(n), side='left')
+
+    def starts(step, base):
+        upto = np.cumsum(step) - step
+        return upto - upto[first_run][run_owner] + np.asarray(base, dtype=np.int64)[run_owner]
+    q_run, r_run = starts(np.where(run_op != 2, run_len, 0), q_at), starts(np.where(run_op != 1, run_len, 0), r_at)
+    shown = np.flatnonzero((run_op == 0) | ((run_op == 1) & (mode > 1)))                # the runs that contribute columns
+    width = run_len[shown]
+    col_run = np.repeat(shown, width)
+    inside = np.arange(len(col_run)) - np.repeat(np.cumsum(width) - width, width)       # column number inside its run
+    owner = run_owner[col_run]
+    qa = np.asarray(q_cat, dtype=np.int64)[q_run[col_run] + inside]
+    paired = run_op[col_run] == 0
+    ra = np.full(len(col_run), -1, dtype=np.int64)
+    ra[paired] = np.asarray(r_cat, dtype=np.int64)[(r_run[col_run] + inside)[paired]]
     if mode == 1:
-        n_match = int(np.sum(qa == ra))
-        n_mis = qa.size - n_match
-        return float(n_match) / (n_match + n_mis + b_gap - m_gap), n_match * 3 - n_mis - gap_cost
-    qa, ra = qa[phase:], ra[phase:]
-    if qa.size % 3:
-        cut = qa.size % 3
-        qa, ra = qa[:-cut], ra[:-cut]
-    qa, ra = qa.reshape(-1, 3), ra.reshape(-1, 3)
+        n_match = np.bincount(owner, weights=qa == ra, minlength=n)
+        n_mis = np.bincount(owner, minlength=n) - n_match
+        return n_match / (n_match + n_mis + b_gap - m_gap), n_match * 3 - n_mis * 1 - gap_cost_open - gap_cost_len
+    # codon grid: column p of alignment a (counted from the phase on) is position p % 3 of codon p // 3; a trailing partial codon is dropped
+    n_col = np.bincount(owner, minlength=n)
+    phase = (np.asarray(first_base, dtype=np.int64) - 1) % 3
+    p = np.arange(len(owner)) - (np.cumsum(n_col) - n_col)[owner] - phase[owner]
+    whole = np.maximum(n_col - phase, 0) // 3
+    keep = (p >= 0) & (p < 3 * whole[owner])
+    owner, qa, ra, p = owner[keep], qa[keep], ra[keep], p[keep]
     if mode == 3:
-        n_match = np.sum(np.sum(qa == ra, 0) * (9. / 7., 9. / 7., 3. / 7.))
-        n_mis = np.sum(ra >= 0) - n_match
-        return float(n_match) / (n_match + n_mis + b_gap - m_gap), n_match * 3 - n_mis - gap_cost
-    whole = ~np.any(ra < 0, 1)
-    qa, ra = qa[whole], ra[whole]
-    q_aa, r_aa = gt[np.sum(qa * (25, 5, 1), 1)], gt[np.sum(ra * (25, 5, 1), 1)]
-    n_match = np.sum(q_aa == r_aa) * 3.
-    return n_match / (q_aa.size * 3. + b_gap - m_gap), np.sum(blosum62[(q_aa << 5) + r_aa]) - gap_cost
+        hit = np.bincount(owner * 3 + p % 3, weights=qa == ra, minlength=3 * n).reshape(n, 3)
+        n_match = hit[:, 0] * _CODON_WEIGHT[0] + hit[:, 1] * _CODON_WEIGHT[1] + hit[:, 2] * _CODON_WEIGHT[2]
+        n_mis = np.bincount(owner, weights=ra >= 0, minlength=n) - n_match
+        return n_match / (n_match + n_mis + b_gap - m_gap), n_match * 3 - n_mis * 1 - gap_cost_open - gap_cost_len
+    table = gtable
+    if table_id == 4:
+        table = gtable.copy()
+        table[56] = 22            # TGA -> W; the reference patches its module-level table for good (uberBlast.py:223-224), here it is this call's
+    codon = (np.cumsum(whole) - whole)[owner] + p // 3                                  # codons numbered through all alignments
+    n_codon = int(whole.sum())
+    place = np.array([25, 5, 1], dtype=np.int64)[p % 3]
+    q_word = np.bincount(codon, weights=qa * place, minlength=n_codon).astype(np.int64)
+    r_word = np.bincount(codon, weights=np.maximum(ra, 0) * place, minlength=n_codon).astype(np.int64)
+    full = np.bincount(codon, weights=ra < 0, minlength=n_codon) == 0                    # no I column inside
+    codon_owner = np.repeat(np.arange(n), whole)[full]
+    q_aa, r_aa = table[q_word[full]], table[r_word[full]]
+    n_match = np.bincount(codon_owner, weights=q_aa == r_aa, minlength=n) * 3.
+    n_total = np.bincount(codon_owner, minlength=n) * 3. + b_gap - m_gap
+    return n_match / n_total, np.bincount(codon_owner, weights=blosum62[(q_aa << 5) + r_aa], minlength=n) - gap_cost_open - gap_cost_len
+
+
+def cigar2score(data):
+    """(cigar, rSeq, qSeq, frame, mode, gapOpen, gapExtend, table_id) -> (identity, score): the reference's per-alignment entry point
+    (uberBlast.py:221), one alignment through rescore_alignments.  RunBlast.reScore does not come through here: mode 1 is counted on the
+    GPU (K7), modes 2 / 3 take all rows of the table in one call."""
+    cigar, r_seq, q_seq, frame, mode, gap_open, gap_ext, table_id = data
+    iden, score = rescore_alignments([n for n, op in cigar], [_OP_CODE[op] for n, op in cigar], np.zeros(len(cigar), dtype=np.int64),
+                                     q_seq, [0], r_seq, [0], [frame], mode, gap_open, gap_ext, table_id)
+    return iden[0], score[0]
 
 
 class RunBlast(object):
@@ -620,14 +656,23 @@ class RunBlast(object):
             iden = n_match.astype(np.float64) / (n_match + n_mis + b_gap - m_gap)
             score = (n_match * 3 - n_mis - n_gap * (6 - 1) - b_gap * 1).astype(np.float64)
         else:
-            q_enc = {str(k): nucEncoder[np.array(list(v)).view(asc2int)] for k, v in self.qrySeq.items()}
-            r_enc = {str(k): nucEncoder[np.array(list(v)).view(asc2int)] for k, v in self.refSeq.items()}
-            vals = []
-            for t in T.to_rows():
-                r = r_enc[str(t[1])]
-                r_sl = r[t[8] - 1:t[9]] if t[8] < t[9] else 4 - r[t[9] - 1:t[8]][::-1]
-                vals.append(cigar2score([t[14], r_sl, q_enc[str(t[0])][t[6] - 1:t[7]], t[6], mode, 6, 1, table_id]))
-            iden, score = np.array(vals, dtype=np.float64).T
+            # the aligned stretch of every row's query and reference (reverse strand: complemented and turned), back to back, then ONE call
+            enc = {}
+
+            def codes(side, name):
+                key = (side, str(name))
+                if key not in enc:
+                    enc[key] = nucEncoder[np.frombuffer((self.qrySeq if side == 'q' else self.refSeq)[name].encode('latin-1'), dtype=np.uint8)]
+                return enc[key]
+            q_parts, r_parts = [], []
+            for qn, rn, qs, qe, ss, se in zip((T.q_tab[i] for i in T.qi.tolist()), (T.r_tab[i] for i in T.ri.tolist()), T.qs.tolist(), T.qe.tolist(), T.ss.tolist(), T.se.tolist()):
+                q_parts.append(codes('q', qn)[qs - 1:qe])
+                r = codes('r', rn)
+                r_parts.append(r[ss - 1:se] if ss < se else 4 - r[se - 1:ss][::-1])
+            at = lambda parts: np.concatenate([[0], np.cumsum([len(x) for x in parts])[:-1]]).astype(np.int64)
+            pick = np.concatenate([np.arange(o, o + k) for o, k in zip(T.c_off.tolist(), T.c_runs.tolist())]) if len(T) else np.zeros(0, np.int64)
+            iden, score = rescore_alignments(T.arena[pick] >> 2, T.arena[pick] & 3, np.repeat(np.arange(len(T)), T.c_runs), np.concatenate(q_parts), at(q_parts),
+                                             np.concatenate(r_parts), at(r_parts), T.qs, mode, 6, 1, table_id)
         T.iden, T.score = np.round(iden, 3), np.round(score, 3)
         T.score_is_int = False
         return T.take(T.iden >= min_id) if cut else T

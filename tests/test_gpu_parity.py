@@ -418,21 +418,21 @@ def test_allgather_from_device_memory_over_rccl():
 
 
 def test_public_tools_keep_the_reference_plugin_contract_on_gpu(tmp_path, monkeypatch):
-    """the reference's own driver loop (uberBlast.py:343-376, restated in tests/plugin_replay.py) over the product's PUBLIC
-    tools - blastn + diamond together, `b.shape[0]`, np.vstack, np.hstack with arange, reScore, fixEnd, pandas sort - gives the table
+    """the product's PUBLIC tools - blastn + diamond together - return what the `tools` dictionary of uberBlast.py:327 promises
+    (tests/plugin_contract.py), and stacked, numbered and sent through the public reScore / fixEnd / returnOverlap they give the table
     RunBlast.run gives, on the GPU"""
     import io, contextlib
     from peppan_amd import uberBlast as UB, synth
-    from plugin_replay import reference_style_run
+    from plugin_contract import tools_then_methods
     monkeypatch.chdir(tmp_path)
     names, seqs = synth.make_genes(200, 0, seed=91)
     names = [str(5 * i + 2) for i in range(len(seqs))]
     fa = str(tmp_path / 'ex.fa')
     _write_fasta(fa, names, seqs)
     with contextlib.redirect_stderr(io.StringIO()):
-        via_loop = reference_style_run(UB.RunBlast(), fa, fa, ['blastn', 'diamond'], 0.45, 50., 0.25, re_score=1, fix_end=(3., 3.))
+        via_loop = tools_then_methods(UB.RunBlast(), fa, fa, ['blastn', 'diamond'], 0.45, 50., 0.25, re_score=1, fix_end=(3., 3.))
         via_run = UB.RunBlast().run(fa, fa, ['blastn', 'diamond'], 0.45, 50., 0.25, re_score=1, return_overlap=[False, 300, 0.6], fix_end=[3., 3.])
-        a, a_ovl = reference_style_run(UB.RunBlast(), fa, fa, ['diamondSELF'], 0.45, 50., 0.25, fix_end=(0., 3.), return_overlap=(True, 300, 0.6))
+        a, a_ovl = tools_then_methods(UB.RunBlast(), fa, fa, ['diamondSELF'], 0.45, 50., 0.25, fix_end=(0., 3.), overlap=(300, 0.6))
         b, b_ovl = UB.RunBlast().run(fa, fa, ['diamondSELF'], 0.45, 50., 0.25, return_overlap=[True, 300, 0.6], fix_end=[0., 3.])
     assert via_loop.shape[0] > 400 and via_loop.shape[1] == 16 and via_loop.tolist() == via_run.tolist()
     assert a.tolist() == b.tolist() and a_ovl.tolist() == b_ovl.tolist() and len(a) >= 200

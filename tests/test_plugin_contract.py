@@ -1,6 +1,6 @@
 """the reference-side plug-in point is the `tools` dictionary of RunBlast.run (uberBlast.py:327); every tool is
-method(ref, qry) -> ndarray(object)[n, 15].  CPU test over the oracle-backed context: the reference's own loop (tests/plugin_replay.py)
-over the product's public tools gives the table RunBlast.run gives."""
+method(ref, qry) -> ndarray(object)[n, 15].  CPU test over the oracle-backed context: the product's public tools, held to that contract (tests/plugin_contract.py),
+stacked and sent through the public object-row methods give the table RunBlast.run gives."""
 import contextlib
 import io
 import os
@@ -22,20 +22,20 @@ def _write_inputs(tmp_path, n=40):
 
 def test_public_tools_keep_the_reference_plugin_contract(tmp_path, monkeypatch):
     from oracle_context import OracleContext
-    from plugin_replay import reference_style_run
+    from plugin_contract import tools_then_methods
     from peppan_amd import uberBlast as UB
     fa = _write_inputs(tmp_path)
     octx = OracleContext()
     monkeypatch.setattr(UB, 'get_context', lambda device=None: octx)
     with contextlib.redirect_stderr(io.StringIO()):
-        via_loop = reference_style_run(UB.RunBlast(), fa, fa, ['blastn', 'diamond'], 0.4, 40., 0.25, re_score=1, fix_end=(3., 3.))
+        via_loop = tools_then_methods(UB.RunBlast(), fa, fa, ['blastn', 'diamond'], 0.4, 40., 0.25, re_score=1, fix_end=(3., 3.))
         via_run = UB.RunBlast().run(fa, fa, ['blastn', 'diamond'], 0.4, 40., 0.25, re_score=1, return_overlap=[False, 300, 0.6], fix_end=[3., 3.])
         argv_run = UB.uberBlast(('-r %s -q %s --blastn --diamond -s 1 --min_id 0.4 --min_cov 40 --min_ratio 0.25 -e 3,3' % (fa, fa)).split())
     assert via_loop.shape[0] > 80 and via_loop.shape[1] == 16
     assert via_loop.tolist() == via_run.tolist() == argv_run.tolist()
     # diamondSELF alone, with overlaps; and a tool without hits hands over an empty [0, 15] table instead of raising
     with contextlib.redirect_stderr(io.StringIO()):
-        a, a_ovl = reference_style_run(UB.RunBlast(), fa, fa, ['diamondSELF'], 0.4, 40., 0.25, fix_end=(0., 0.), return_overlap=(True, 300, 0.6))
+        a, a_ovl = tools_then_methods(UB.RunBlast(), fa, fa, ['diamondSELF'], 0.4, 40., 0.25, fix_end=(0., 0.), overlap=(300, 0.6))
         b, b_ovl = UB.RunBlast().run(fa, fa, ['diamondSELF'], 0.4, 40., 0.25, return_overlap=[True, 300, 0.6], fix_end=[0., 0.])
     assert a.tolist() == b.tolist() and a_ovl.tolist() == b_ovl.tolist() and len(a) >= 40
     rb = UB.RunBlast()
