@@ -6,6 +6,8 @@ names, seqs = synth.make_genes(n, 1002, seed=355)
 ctx = N.Context(0)
 ctx.set_query_nt(seqs, 11); ctx.set_ref_nt(seqs, 6, 11)
 p = N.default_params(45., 25., 10, 5)
-for rep in range(2):
+p.reserved2 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for rep in range(int(sys.argv[3]) if len(sys.argv) > 3 else 2):
+    ctx.invalidate_translation()
     h, c, st = ctx.search(p)
 print(st)
