@@ -20,9 +20,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
-PROFILE_COUNTERS = os.path.join(ROOT, 'profiles', 'r04_counters.json')          # rocprofv3 PMC passes of the headline workload (tools/profile_round.sh)
-PROFILE_COUNTERS_50K = os.path.join(ROOT, 'profiles', 'r04_counters_50k.json')  # the same passes over the 50 000-gene all-vs-all (the `workloads` block)
-PROFILE_VALU = os.path.join(ROOT, 'profiles', 'r04_valu_rate.txt')              # tools/micro/valu_rate on the same GPU
+PROFILE_COUNTERS = os.path.join(ROOT, 'profiles', 'r05_counters.json')          # rocprofv3 PMC passes of the headline workload (tools/profile_round.sh)
+PROFILE_COUNTERS_50K = os.path.join(ROOT, 'profiles', 'r05_counters_50k.json')  # the same passes over the 50 000-gene all-vs-all (the `workloads` block)
+PROFILE_COUNTERS_BLASTN = os.path.join(ROOT, 'profiles', 'r05_counters_blastn.json')   # ... over the nucleotide tool on the headline's genes (tools/one_search.py 10000 blastn)
+PROFILE_COUNTERS_MAP50K = os.path.join(ROOT, 'profiles', 'r05_counters_map50k.json')   # ... over one mapping step of the map_50k leg (tools/one_map_step.py)
+PROFILE_VALU = os.path.join(ROOT, 'profiles', 'r05_valu_rate.txt')              # tools/micro/valu_rate on the same GPU
 
 
 REFERENCE_TOOLS = ('diamond', 'blastn', 'makeblastdb', 'mmseqs')
@@ -398,7 +400,6 @@ def configs4_workloads(local_rank, min_id, min_qcov, torch, steps=5):
         ctx.set_timing(0)
         per = {k: acc[k] / steps for k in keys}
         rl = roofline_kernels(_profile_tables(PROFILE_COUNTERS_50K)[0], cyc4, os.path.basename(PROFILE_COUNTERS_50K), per, 334, params.n_shapes)
-        rl.sort(key=lambda e: -e['ms_per_launch'])
         out['search_50k'] = {'workload': 'synthgenes-v1 seed 355: 50000 genes x 1002 nt, all-vs-all on one GPU (BASELINE configs[4] search stage)', 'steps': steps,
                              'ms_per_step': dt / steps * 1e3, 'gene_pairs_all_vs_all_per_s': 2.5e9 * steps / dt, 'candidates_per_step': per['candidates'], 'hits_per_step': n_hits,
                              'clusters': n_clusters, 'value_gene_pairs_aligned_per_s': per['candidates'] * steps / dt,
@@ -415,23 +416,103 @@ def configs4_workloads(local_rank, min_id, min_qcov, torch, steps=5):
     n_per = len(log) // 4
     step_log = log[n_per:2 * n_per]
     per = {k: float(sum(st[k] for st in step_log)) for k in keys}
-    launches = {'sw_trace_kernel': sum(1 for st in step_log if st['ms_sw_trace'] > 0), 'sw_score_kernel': sum(1 for st in step_log if st['ms_sw'] > 0),
-                'seed_match<10>': sum(1 for st in step_log if st['ms_seed_match'] > 0)}
-    rl = roofline_kernels({}, cyc4, '', per, max(1., per['query_residues'] / max(1, n_per) / 50000.), 1)
-    for e in rl:
-        e['launches_per_step'] = launches.get(e['kernel'], 0)
-        e['ms_per_step'] = e.pop('ms_per_launch')
-        e['note'] = 'summed over the searches of one mapping step (nucleotide tool + translated tool per sub-batch of genomes); lengths differ per pair: algorithmic bytes use the mean query length'
-    rl.sort(key=lambda e: -e['ms_per_step'])
+    rl = map_step_rooflines(per, step_log, max(1., per['query_residues'] / max(1, n_per) / 50000.), cyc4)
     wall = mr['seconds']
     out['map_50k'] = {'workload': 'synthgenes-v1: 50000 exemplar genes x 1002 nt mapped onto %d genomes of a 50000-gene pan-genome (%.1f Mnt per genome): --blastn --diamond -f -m -O -s 1, K7, K12, '
                                   'build_groups; then the same through get_map_bsn with the four stores (BASELINE configs[4] mapping stage on one GPU)' % (n_genomes, mr['genome_nt'] / n_genomes / 1e6),
                       'genomes_per_s': mr['genomes'] / wall, 'genomes_per_s_with_stores': mr['genomes'] / mr['seconds_with_stores'], 'ms_per_genome': wall / mr['genomes'] * 1e3,
                       'groups_per_genome': mr['groups_per_step'] / n_genomes, 'hit_rows_per_genome': mr['hit_rows_per_step'] / n_genomes,
                       'searches_per_step': n_per, 'gpu_ms_in_searches_per_step': per['ms_total'], 'gpu_busy_frac': per['ms_total'] * 1e-3 / wall,
-                      'gpu_busy_note': 'HIP-event time of the searches (K1 .. K8) over the step wall clock; K7 / K11 / K12 run besides (a few per cent more: profiles/r04_map_kernel_stats.txt)',
+                      'gpu_busy_note': 'HIP-event time of the searches (K1 .. K8) over the step wall clock; K7 / K11 / K12 run besides (a few per cent more: profiles/r05_map_kernel_stats.txt)',
                       'phase_ms_searches': {k: per[k] for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
                       'phase_s_with_stores': tm, 'roofline': rl[0], 'roofline_kernels': rl}
+    return out
+
+
+def north_star_workloads(local_rank, names, order, seqs, nts, min_id, min_qcov, torch, steps=50):
+    """The call the reference makes (PEPPAN.py:229-230: uberBlast -r CL -q CL --blastn --diamond -s 1 -e 3,3 ...; uberBlast.py:597-599 runs both
+    tools) on the headline's genes, behind the headline:
+      search_10k_blastn   the nucleotide tool alone (uberBlast.py:294, 482-509 replaced): the resident nucleotide sets packed as base-code residue sets
+                          (both strands of the reference) + the search with exact 17-mers, +2 / -3, gap 6 + 2k, e-value 1e-2 - ms per step, phase split,
+                          its three largest kernels with rooflines (counters: profiles/r05_counters_blastn.json)
+      north_star_call     both tools back to back through the drop-in's own methods on the NUMERIC table - nucleotide search, translated search,
+                          the two tables joined, K7 rescoring (-s 1), fixEnd, the final order - without the object rows uberBlast() builds for its
+                          caller (uberblast_e2e_ms has those); what get_similar_pairs consumes"""
+    import contextlib
+    import io
+    import tempfile
+    from peppan_amd import _native as N, uberBlast as UB
+    out = {}
+    keys = ('candidates', 'candidates_settled', 'cells', 'cells_settled', 'hits', 'tracebacks', 'tracebacks_gapless', 'seed_hits', 'target_residues', 'query_residues',
+            'ms_sw_trace', 'ms_sw', 'ms_seed', 'ms_seed_match', 'ms_trace', 'ms_k1', 'ms_total')
+    cyc4 = _profile_tables()[1]
+    pn = N.nucleotide_params(min_id, min_qcov)
+    with N.Context(local_rank) as ctx:
+        ctx.set_query_nt(nts, 11)
+        ctx.set_ref_nt(nts, 6, 11)
+
+        def step():
+            ctx.use_nt_as_residues(2)                   # (the nucleotide tool's K1: both sets packed on the device, forward strands + reverse complements)
+            return ctx.search(pn, copy=False)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            h, c, st = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_hits = int(len(h))
+        ctx.set_timing(2)
+        step()
+        acc = dict.fromkeys(keys, 0.0)
+        for _ in range(steps):
+            st = step()[2]
+            for k in keys:
+                acc[k] += st[k]
+        ctx.set_timing(0)
+        per = {k: acc[k] / steps for k in keys}
+        Lq = per['query_residues'] / max(1, len(nts))
+        rl = roofline_kernels(_profile_tables(PROFILE_COUNTERS_BLASTN)[0], cyc4, os.path.basename(PROFILE_COUNTERS_BLASTN), per, Lq, 1, seed_weight=17)
+        out['search_10k_blastn'] = {'workload': 'synthgenes-v1 seed 355: %d genes x 1002 nt against themselves, nucleotide tool (the blastn call of uberBlast.py:294), both strands of the reference' % len(nts),
+                                    'steps': steps, 'ms_per_step': dt / steps * 1e3, 'candidates_per_step': per['candidates'], 'hits_per_step': n_hits,
+                                    'value_gene_pairs_aligned_per_s': per['candidates'] * steps / dt,
+                                    'sw_cell_updates_per_s_per_gpu': (per['cells'] - per['cells_settled']) / (per['ms_sw'] * 1e-3) if per['ms_sw'] else None,
+                                    'phase_ms': {k: per[k] for k in ('ms_k1', 'ms_seed', 'ms_seed_match', 'ms_sw', 'ms_sw_trace', 'ms_trace', 'ms_total')},
+                                    'phase_note': 'ms_k1 is 0 here: the nucleotide sets are packed by nucl_pack inside pep_use_nt_as_residues, in front of the search (inside ms_per_step, outside ms_total)',
+                                    'roofline': rl[0], 'roofline_kernels': rl}
+    with tempfile.TemporaryDirectory() as tmp:
+        fa = os.path.join(tmp, 'exemplar.fa')
+        with open(fa, 'w') as f:
+            for i in order:
+                f.write('>%s\n%s\n' % (names[i], seqs[i].decode()))
+        rb = UB.RunBlast()
+        rb._as_tables = True
+        clock = time.perf_counter
+
+        def call(parts=None):
+            rb.min_id, rb.min_cov, rb.min_ratio, rb.table_id, rb.n_thread = min_id / 100., 50., min_qcov / 100., 11, 1
+            t0 = clock()
+            tn = rb._runBlast_table(fa, fa)
+            t1 = clock()
+            td = rb._runDiamond_table(fa, fa)
+            t2 = clock()
+            T = rb._post([tn, td], fa, fa, 1, [False, 0.9, 0.], [False, 300., 1.2], [False, 300, 0.6], [3., 3.])
+            t3 = clock()
+            if parts is not None:
+                for k, v in (('nucleotide_search_ms', t1 - t0), ('translated_search_ms', t2 - t1), ('join_k7_fixend_order_ms', t3 - t2)):
+                    parts[k] = parts.get(k, 0.) + v * 1e3
+            return T
+        with contextlib.redirect_stderr(io.StringIO()):
+            call(); call()
+            reps, parts = 10, {}
+            t0 = clock()
+            for _ in range(reps):
+                T = call(parts)
+            dt = clock() - t0
+        out['north_star_call'] = {'north_star_call_ms': dt / reps * 1e3, 'rows': int(len(T)), 'parts_ms': {k: v / reps for k, v in parts.items()}, 'reps': reps,
+                                  'what': 'RunBlast: nucleotide tool + translated tool on the %d genes against themselves (FASTA read once and cached; sets resident on the GPU), tables joined, '
+                                          'K7 rescoring (-s 1), fixEnd 3,3, final order - the numeric HitTable, no object rows' % len(nts)}
     return out
 
 
@@ -445,44 +526,126 @@ def _ranks_seen(dist, torch, world, share, local_rank):
     return int(t.item())
 
 
-def roofline_entry(counters, cyc4, source, kernel, what, ms, alg_bytes, valu=False):
-    """one roofline record: algorithmic bytes over the kernel's LIVE duration against the 8 TB/s HBM roof, plus the tracked PMC
-    traffic of the same kernel on the same workload (`counters`: per-kernel figures of a rocprofv3 --pmc run kept under profiles/)"""
+VALU_PEAK_CLOCK = 2.4e9          # MI355X peak engine clock; 1024 SIMDs (256 CUs x 4)
+
+
+def _kernel_counters(counters, kernel):
+    """the tracked PMC record of a kernel; the Smith-Waterman kernels are templates (<false> = the launch of the pairs that fit the LDS staging area,
+    <true> = the long pairs): a name without its argument takes whichever instance the profile holds"""
+    for name in (kernel, kernel + '<false>', kernel + '<true>'):
+        if name in counters:
+            return counters[name]
+    return {}
+
+
+def roofline_entry(counters, cyc4, source, kernel, what, ms, alg_bytes, valu=False, scattered=False, launches_per_step=1):
+    """One roofline record.  HBM side: algorithmic bytes over the kernel's LIVE duration against the 8 TB/s roof, plus the tracked PMC
+    traffic of the same kernel on the same workload (`counters`: per-kernel figures of a rocprofv3 --pmc run kept under profiles/).
+    `scattered`: the kernel's reads are 8-byte requests to random lines - its traffic is TCC_EA0_RDREQ x 64 B (the lines that came over the fabric)
+    + WRITE_SIZE; the x 2 that MI355X_MICROARCH.md prescribes for FETCH_SIZE is calibrated for wide coalesced streams only and is applied to those.
+    `valu`: an integer-VALU bound kernel (the Smith-Waterman passes): the roof that binds is the issue rate of the 4-cycle instruction
+    class - `bound` says "valu", `frac` is the issue fraction, the HBM figures move to `hbm`."""
     achieved = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-    prof = counters.get(kernel) or counters.get(kernel + '<false>') or {}      # (the Smith-Waterman kernels are templates: <false> = the launch of the pairs that fit the staging area)
+    prof = _kernel_counters(counters, kernel)
     # the tracked counters describe THIS kernel only while it still takes what it took when they were collected: its duration in the
     # PMC passes must agree with the live HIP-event time within 10 %, else the figures are withheld (stale: regenerate with tools/profile_round.sh)
     prof_us = prof.get('avg_us_in_pmc_passes') or []
     stale = bool(prof_us) and ms > 0 and abs(min(prof_us) / 1e3 - ms) > 0.10 * ms and abs(sum(prof_us) / len(prof_us) / 1e3 - ms) > 0.10 * ms
     if stale:
         prof = {}
-    traffic = (2 * prof['FETCH_SIZE'] + prof['WRITE_SIZE']) * 1024.0 if 'FETCH_SIZE' in prof and 'WRITE_SIZE' in prof else None
-    e = {'kernel': kernel, 'what': what, 'bound': 'hbm', 'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0,
-         'ms_per_launch': ms, 'algorithmic_bytes': alg_bytes, 'traffic': traffic, 'counters_stale': stale,
-         'ms_per_launch_in_pmc_passes': (sum(prof_us) / len(prof_us) / 1e3) if prof_us else None,
-         'traffic_source': ('profiles/%s: 2 x FETCH_SIZE + WRITE_SIZE of the same kernel on this workload (separate rocprofv3 --pmc passes; '
-                            'x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md)' % source) if traffic is not None else None}
+    traffic = src = None
+    if scattered and 'TCC_EA0_RDREQ_sum' in prof and 'WRITE_SIZE' in prof:
+        traffic = prof['TCC_EA0_RDREQ_sum'] * 64.0 + prof['WRITE_SIZE'] * 1024.0
+        src = ('profiles/%s: TCC_EA0_RDREQ x 64 B + WRITE_SIZE of the same kernel on this workload (separate rocprofv3 --pmc passes); scattered 8-byte '
+               'requests, one 64-byte line each - no x 2, which MI355X_MICROARCH.md calibrates for wide coalesced streams' % source)
+    elif 'FETCH_SIZE' in prof and 'WRITE_SIZE' in prof:
+        traffic = (2 * prof['FETCH_SIZE'] + prof['WRITE_SIZE']) * 1024.0
+        src = ('profiles/%s: 2 x FETCH_SIZE + WRITE_SIZE of the same kernel on this workload (separate rocprofv3 --pmc passes; '
+               'x2 = the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md for wide coalesced reads)' % source)
+    hbm = {'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0}
+    e = {'kernel': kernel, 'what': what, 'bound': 'hbm', 'ms_per_launch': ms, 'launches_per_step': launches_per_step, 'ms_per_step': ms * launches_per_step,
+         'algorithmic_bytes': alg_bytes, 'traffic': traffic, 'counters_stale': stale,
+         'ms_per_launch_in_pmc_passes': (sum(prof_us) / len(prof_us) / 1e3) if prof_us else None, 'traffic_source': src}
+    e.update(hbm)
     if traffic:
         e['traffic_over_algorithmic'] = traffic / alg_bytes if alg_bytes else None
-    if valu and cyc4 and 'SQ_INSTS_VALU' in prof and ms > 0:
-        # integer-VALU bound kernels: wave-instructions per launch (PMC) x measured cycles per instruction of the packed-16 / DPP / add3
-        # class (tools/micro/valu_rate.hip) against 1024 SIMDs at the 2.4 GHz peak clock for the launch's live duration
-        e['valu_issue_frac'] = prof['SQ_INSTS_VALU'] * cyc4 / (1024 * 2.4e9 * ms * 1e-3)
-        e['valu_issue_source'] = 'SQ_INSTS_VALU from profiles/%s x %.3f cycles/instruction from profiles/%s' % (source, cyc4, os.path.basename(PROFILE_VALU))
+    if valu:
+        e['bound'] = 'valu'
+        e['hbm'] = hbm
+        peak = 1024 * VALU_PEAK_CLOCK / cyc4 / 1e9 if cyc4 else None          # G wave64-instructions / s the chip issues of this class
+        if cyc4 and 'SQ_INSTS_VALU' in prof and ms > 0:
+            # wave-instructions per launch (PMC) x measured cycles per instruction of the packed-16 / DPP / add3 class (tools/micro/valu_rate.hip)
+            # against 1024 SIMDs at the 2.4 GHz peak clock for the launch's live duration
+            rate = prof['SQ_INSTS_VALU'] / (ms * 1e-3) / 1e9
+            e.update(achieved=rate, peak=peak, unit='G wave64 VALU instructions/s', frac=rate / peak, valu_issue_frac=rate / peak,
+                     valu_issue_source='SQ_INSTS_VALU from profiles/%s x %.3f cycles/instruction from profiles/%s' % (source, cyc4, os.path.basename(PROFILE_VALU)))
+        else:
+            e.update(achieved=None, peak=peak, unit='G wave64 VALU instructions/s', frac=None, valu_issue_frac=None,
+                     valu_issue_source='no tracked SQ_INSTS_VALU for this kernel on this workload (or stale): the issue fraction is not stated; hbm holds the HBM side')
     return e
 
 
-def roofline_kernels(counters, cyc4, source, per_step, Lq, n_shapes):
-    """the three kernels a search spends most of its time in.  per_step: the search statistics per step (phase times in ms, counts).
-    Algorithmic bytes per launch, SURVEY.md 8(d): SW = sum over pairs of (Lq + Lr) residue bytes + 64 B per reported hit;
+def roofline_kernels(counters, cyc4, source, per_step, Lq, n_shapes, seed_weight=10):
+    """the three kernels a search spends most of its time in, largest share of the STEP first.  per_step: the search statistics per step (phase
+    times in ms, counts).  Algorithmic bytes per launch, SURVEY.md 8(d): SW = sum over pairs of (Lq + Lr) residue bytes + 64 B per reported hit;
     seed join = 1 B + 8 B index entry per target residue + 8 B per raw seed hit"""
     p = per_step
-    return [roofline_entry(counters, cyc4, source, 'sw_trace_kernel', 'K5 traceback pass: sub-band SW + 4-bit codes over the selected pairs that are not one ungapped run (rule 5a), four per wavefront',
-                           p['ms_sw_trace'], (p['tracebacks'] - p['tracebacks_gapless']) * 2 * Lq + p['hits'] * 64, True),
-            roofline_entry(counters, cyc4, source, 'sw_score_kernel', 'K5 score pass: banded SW over the candidate pairs that are not identical sequences (those are settled by comparison: candidates_settled)',
-                           p['ms_sw'], (p['candidates'] - p['candidates_settled']) * 2 * Lq + p['hits'] * 64, True),
-            roofline_entry(counters, cyc4, source, 'seed_match<10>', 'K4a: target seeds streamed through the query index (one launch per seed shape)', p['ms_seed_match'] / max(1, n_shapes),
-                           9.0 * p['target_residues'] + 8.0 * p['seed_hits'] / max(1, n_shapes))]
+    rl = [roofline_entry(counters, cyc4, source, 'sw_trace_kernel', 'K5 traceback pass: sub-band SW + 4-bit codes over the selected pairs that are not one ungapped run (rule 5a), four per wavefront',
+                         p['ms_sw_trace'], (p['tracebacks'] - p['tracebacks_gapless']) * 2 * Lq + p['hits'] * 64, valu=True),
+          roofline_entry(counters, cyc4, source, 'sw_score_kernel', 'K5 score pass: banded SW over the candidate pairs that are not identical sequences (those are settled by comparison: candidates_settled)',
+                         p['ms_sw'], (p['candidates'] - p['candidates_settled']) * 2 * Lq + p['hits'] * 64, valu=True),
+          roofline_entry(counters, cyc4, source, 'seed_match<%d>' % seed_weight, 'K4a: target seeds streamed through the query index (one launch per seed shape)', p['ms_seed_match'] / max(1, n_shapes),
+                         9.0 * p['target_residues'] + 8.0 * p['seed_hits'] / max(1, n_shapes), scattered=True, launches_per_step=max(1, n_shapes))]
+    rl.sort(key=lambda e: -e['ms_per_step'])
+    return rl
+
+
+def map_step_rooflines(per, step_log, Lq, cyc4):
+    """The kernel FAMILIES a mapping step spends its search time in - a step is several searches (nucleotide tool + translated tool per sub-batch of
+    genomes), so a family (all launches of sw_trace_kernel, of sw_score_kernel, of seed_match whatever their template argument) is summed over the
+    step: live HIP-event milliseconds per step from the searches' phase timers, algorithmic bytes from their statistics (lengths differ
+    per pair: the mean query length stands in), and the PMC traffic of the same launches from profiles/r05_counters_map50k.json (one mapping step of
+    the same workload under rocprofv3 --pmc: per instance the per-dispatch average x its dispatches per step)."""
+    path = PROFILE_COUNTERS_MAP50K
+    prof = json.load(open(path)) if os.path.exists(path) else {}
+    kernels, steps = prof.get('kernels', {}), max(1, int(prof.get('steps_per_pass', 1)))
+    src = os.path.basename(path)
+
+    def family(prefix, ms_step, alg, what, valu, scattered):
+        inst = {k: v for k, v in kernels.items() if k.split('<')[0] == prefix}
+        launches = sum(v.get('dispatches_per_pass', 0) for v in inst.values()) / steps
+        pmc_ms = sum(sum(v['avg_us_in_pmc_passes']) / len(v['avg_us_in_pmc_passes']) * v.get('dispatches_per_pass', 0) for v in inst.values() if v.get('avg_us_in_pmc_passes')) / steps / 1e3
+        stale = bool(inst) and ms_step > 0 and abs(pmc_ms - ms_step) > 0.15 * ms_step
+        traffic = insts = None
+        if inst and not stale:
+            if scattered and all('TCC_EA0_RDREQ_sum' in v and 'WRITE_SIZE' in v for v in inst.values()):
+                traffic = sum((v['TCC_EA0_RDREQ_sum'] * 64.0 + v['WRITE_SIZE'] * 1024.0) * v['dispatches_per_pass'] for v in inst.values()) / steps
+            elif all('FETCH_SIZE' in v and 'WRITE_SIZE' in v for v in inst.values()):
+                traffic = sum((2 * v['FETCH_SIZE'] + v['WRITE_SIZE']) * 1024.0 * v['dispatches_per_pass'] for v in inst.values()) / steps
+            if all('SQ_INSTS_VALU' in v for v in inst.values()):
+                insts = sum(v['SQ_INSTS_VALU'] * v['dispatches_per_pass'] for v in inst.values()) / steps
+        achieved = alg / (ms_step * 1e-3) / 1e9 if ms_step > 0 else 0.0
+        hbm = {'achieved': achieved, 'peak': 8000.0, 'unit': 'GB/s', 'frac': achieved / 8000.0}
+        e = {'kernel': prefix, 'instances': sorted(inst) or None, 'what': what, 'bound': 'hbm', 'ms_per_step': ms_step, 'launches_per_step': launches or None,
+             'algorithmic_bytes': alg, 'traffic': traffic, 'counters_stale': stale, 'ms_per_step_in_pmc_passes': pmc_ms or None,
+             'traffic_source': ('profiles/%s: %s, per instance x dispatches per step' % (src, 'TCC_EA0_RDREQ x 64 B + WRITE_SIZE (scattered requests)' if scattered else '2 x FETCH_SIZE + WRITE_SIZE')) if traffic is not None else None,
+             'note': 'summed over the searches of one mapping step (nucleotide tool + translated tool per sub-batch of genomes); lengths differ per pair: algorithmic bytes use the mean query length'}
+        e.update(hbm)
+        if traffic and alg:
+            e['traffic_over_algorithmic'] = traffic / alg
+        if valu:
+            peak = 1024 * VALU_PEAK_CLOCK / cyc4 / 1e9 if cyc4 else None
+            rate = insts / (ms_step * 1e-3) / 1e9 if insts and ms_step > 0 else None
+            e.update(bound='valu', hbm=hbm, achieved=rate, peak=peak, unit='G wave64 VALU instructions/s', frac=(rate / peak) if rate and peak else None,
+                     valu_issue_frac=(rate / peak) if rate and peak else None)
+        return e
+
+    n_tools = max(1, sum(1 for st in step_log if st['ms_seed_match'] > 0))
+    rl = [family('sw_trace_kernel', per['ms_sw_trace'], (per['tracebacks'] - per['tracebacks_gapless']) * 2 * Lq + per['hits'] * 64, 'K5 traceback pass of every search of the step', True, False),
+          family('sw_score_kernel', per['ms_sw'], (per['candidates'] - per['candidates_settled']) * 2 * Lq + per['hits'] * 64, 'K5 score pass of every search of the step', True, False),
+          family('seed_match', per['ms_seed_match'], 9.0 * per['target_residues'] + 8.0 * per['seed_hits'], 'K4a: the genomes streamed through the exemplar index, both tools (%d searches)' % n_tools, False, True)]
+    rl.sort(key=lambda e: -e['ms_per_step'])
+    return rl
 
 
 def _profile_tables(path=None):
@@ -843,13 +1006,17 @@ def main():
         except Exception as e:                                  # never lose the headline over the secondary leg
             extras.setdefault('map_workload', {})['error'] = repr(e)
     if rank == 0 and world == 1 and not args.no_e2e and not args.no_workloads and args.genes == 10000:
-        # (e) BASELINE configs[4] at the size one GPU holds: the 50k x 50k search step and a 50k-exemplar mapping step
+        # (e) the call the reference makes - both tools - on the headline's genes; then BASELINE configs[4] at the size one GPU holds: the 50k x 50k
+        # search step and a 50k-exemplar mapping step
         try:
             ctx.close()                                         # (the headline's context: its workspaces go back before the large legs allocate theirs)
-            extras['workloads'] = configs4_workloads(local_rank, min_id, min_qcov, torch)
+            ns = north_star_workloads(local_rank, names, order, seqs, nts, min_id, min_qcov, torch)
+            extras['north_star_call_ms'] = ns['north_star_call']['north_star_call_ms']
+            extras['workloads'] = dict(ns)
+            extras['workloads'].update(configs4_workloads(local_rank, min_id, min_qcov, torch))
         except Exception as e:
             import traceback
-            extras['workloads'] = {'error': repr(e), 'traceback': traceback.format_exc()[-1500:]}
+            extras.setdefault('workloads', {}).update(error=repr(e), traceback=traceback.format_exc()[-1500:])
 
     if rank == 0:
         K = args.steps
@@ -860,10 +1027,9 @@ def main():
         n_shapes = params.n_shapes
 
         rl = roofline_kernels(counters if headline else {}, cyc4, os.path.basename(PROFILE_COUNTERS), {k: acc[k] / K for k in acc}, Lq, n_shapes)
-        rl.sort(key=lambda e: -e['ms_per_launch'])
         top = dict(rl[0])
-        top['note'] = ('dominant kernel by live HIP-event time; the SW passes are integer-VALU bound by construction (SURVEY 8d): valu_issue_frac is '
-                       'the figure that bounds them, the HBM fraction is reported because the contract asks for it; roofline_kernels lists the top three')
+        top['note'] = ('the kernel with the largest share of the STEP (live HIP-event time x launches per step); the Smith-Waterman passes in roofline_kernels are '
+                       'integer-VALU bound (SURVEY 8d): their `bound` is "valu", their `frac` the issue fraction, their HBM side sits under `hbm`')
         line = {
             'metric': 'gene_pairs_aligned_per_s', 'value': total_pairs / dt, 'unit': 'gene-pairs/s',
             'n_gpus': world, 'steps': K, 'warmup': args.warmup, 'ms_per_step': dt / K * 1e3,

@@ -32,6 +32,8 @@
  *   pep_alleles             aligned-allele strings + base-5 packing of iter_map_bsn   PEPPAN.py:812-835, 846-848
  *   pep_store_mat_member / pep_store_seq_member   the 1000-group members of the .mat / .seq stores get_map_bsn writes (host C++:
  *                           the .npy pickle stream emitted from the numeric hit table)   PEPPAN.py:950-966
+ *   pep_table_from_hits / pep_cols_fix_end / pep_cols_order / pep_cols_gather   RunBlast.run's numeric chain between a search and the caller (host C++:
+ *                           parseDiamond / parseBlast columns, fixEnd, the final sort)   uberBlast.py:25-58, 275-290, 375, 462-480
  *   pep_store_tab_members   all members of the .tab store (gene -> int rows) as finished zip entries, host threads   PEPPAN.py:91-113, 972-975
  *   pep_similar_scan / pep_pair_support / pep_similar_resolve   the pass of get_similar_pairs over the all-vs-all table and its
  *                           get_similar (host state machine, K14 on the GPU, host dictionary)   PEPPAN.py:195-224, 231-276, 294
@@ -43,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 10
+#define PEP_ABI_VERSION 11
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -408,6 +410,45 @@ int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t
  * Returns the archive's length; when it exceeds `cap` nothing usable was written. */
 int64_t pep_store_tab_archive(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
                               int32_t threads, uint8_t *out, int64_t cap);
+
+/* ---- RunBlast.run's numeric chain between a search and the caller, host C++ (no GPU work, no context).  The columns of the reference's hit table
+ * ("blastab": SURVEY.md section 8) as flat arrays - every column int64 or double, one CIGAR arena of runs len << 2 | op in nucleotide units. */
+typedef struct pep_hit_cols {
+    int64_t *qi, *ri;               /* indices into the caller's query / reference name tables (columns 0, 1) */
+    double *iden;                   /* column 2 */
+    int64_t *aln, *mis, *gap, *qs, *qe, *ss, *se;    /* columns 3 - 9 */
+    double *evalue, *score;         /* columns 10, 11 */
+    int64_t *ql, *sl;               /* columns 12, 13 */
+    int64_t *c_off, *c_runs;        /* column 14: the row's runs in the arena */
+    int64_t *rid;                   /* column 15 (may be NULL where a function only fills it with -1) */
+} pep_hit_cols;
+
+/* Hit records of a search -> the rows the reference's parsers keep, as columns (room for n rows each); returns the number of rows, in hit order.
+ * tool 0, the translated search: parseDiamond's algebra (uberBlast.py:25-58) - names q:frame / r:frame:offset from q_meta / t_meta, CIGAR x 3
+ *   (arena_out takes all n_cigar runs, rewritten in nucleotides), identity 1 - round(3 NM / length, 3), coordinates on either strand of the
+ *   reference, the cuts qm * 3 >= min_cov, qm * 3 / ql >= min_ratio, identity >= min_id.  t_seq .. evalue unused (NULL).
+ * tool 1, the nucleotide search: parseBlast's columns (uberBlast.py:275-290): t_seq / t_rev = reference sequence and strand of every target, identity
+ *   with blastn's three printed decimals, mismatches = length - identities - gap columns, `evalue[i]` per HIT as the caller computed it, the cuts
+ *   identity >= min_id, aligned query span >= min_cov and >= min_ratio * ql; win_off / home_lo / home_hi (NULL or per target): targets that are
+ *   windows of a long strand - a hit is shifted to strand coordinates and kept by the window whose home stretch holds its midpoint.  q_meta / t_meta unused.
+ * q_len / r_len: nucleotide lengths per sequence.  Negative: PEP_ERR_ARG. */
+int64_t pep_table_from_hits(int32_t tool, uint64_t n, const pep_hit *hits, const uint32_t *cigar, uint64_t n_cigar, const pep_query_meta *q_meta,
+                            const pep_target_meta *t_meta, const int64_t *q_len, const int64_t *r_len, const int64_t *t_seq, const uint8_t *t_rev,
+                            const int64_t *win_off, const int64_t *home_lo, const int64_t *home_hi, const double *evalue, double min_id, double min_cov,
+                            double min_ratio, pep_hit_cols *out, uint32_t *arena_out);
+
+/* RunBlast.fixEnd (uberBlast.py:462-480) over all rows, in place: an alignment is stretched over an unaligned query head of at most se_lim / tail of
+ * at most ee_lim bases as far as the reference sequence allows, its first / last CIGAR run growing by the same amount.  The rows' runs are copied
+ * into arena_out (sum of c_runs words; rows may share runs in arena_in) and c_off is rewritten.  Returns the number of rows that changed;
+ * PEP_ERR_ARG also for a row without runs that would have to be extended (the reference fails there). */
+int64_t pep_cols_fix_end(uint64_t n, pep_hit_cols *cols, const uint32_t *arena_in, uint64_t n_arena_in, uint32_t *arena_out, double se_lim, double ee_lim);
+
+/* The sort that ends RunBlast.run (uberBlast.py:375: DataFrame.sort_values([0, 1, 11])): order[k] = the row that comes k-th by (q_code, r_code,
+ * score), stable; the codes are non-negative integers that sort like the names of columns 0 and 1 do (the caller ranks the name tables once). */
+int pep_cols_order(uint64_t n, const int64_t *q_code, const int64_t *r_code, const double *score, int64_t *order);
+
+/* dst[c][k] = src[c][idx[k]] for n_cols columns of 8-byte elements (n_src rows each): the rows `idx` of a whole table in one call */
+int pep_cols_gather(int32_t n_cols, const void *const *src, void *const *dst, const int64_t *idx, uint64_t n_idx, uint64_t n_src);
 
 /* A raw DEFLATE stream (RFC 1951; what a zip member of method 8 holds) of `src` made of dynamic-Huffman blocks with literals only - entropy
  * coding without a match search, for the members of <prefix>.seq.npz (packed alleles: nothing to match).  Host C++, no context, any inflate

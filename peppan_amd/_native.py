@@ -7,14 +7,15 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params', 'pep_set_sensitivity',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals']
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals',
+           'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather']
 
 
 class PepError(RuntimeError):
@@ -322,6 +323,98 @@ def deflate_literals(data):
     if n < 0 or n > cap:
         raise PepError('pep_deflate_literals failed (%d)' % n)
     return out[:n].tobytes()
+
+
+class HitCols(C.Structure):
+    """pep_hit_cols: pointers to the columns of a hit table"""
+    FIELDS = ('qi', 'ri', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'ql', 'sl', 'c_off', 'c_runs', 'rid')
+    FLOATS = ('iden', 'evalue', 'score')
+    _fields_ = [(f, C.c_void_p) for f in FIELDS]
+
+    @classmethod
+    def over(cls, arrays):
+        """the struct over a dict of contiguous int64 / float64 arrays (field -> array; a missing 'rid' is NULL)"""
+        c = cls()
+        for f in cls.FIELDS:
+            a = arrays.get(f)
+            if a is not None:
+                assert a.flags['C_CONTIGUOUS'] and a.dtype == (np.float64 if f in cls.FLOATS else np.int64), f
+                setattr(c, f, a.ctypes.data)
+        return c
+
+    @classmethod
+    def blank(cls, n):
+        """n uninitialised rows: field -> array"""
+        block = np.empty([len(cls.FIELDS), max(n, 1)], dtype=np.int64)
+        return {f: (block[k].view(np.float64) if f in cls.FLOATS else block[k]) for k, f in enumerate(cls.FIELDS)}
+
+
+def table_from_hits(tool, hits, cigar, q_len, r_len, min_id, min_cov, min_ratio, q_meta=None, t_meta=None, t_seq=None, t_rev=None, windows=None, evalue=None):
+    """pep_table_from_hits: hit records -> ({field: column[m]}, CIGAR arena in nucleotides).  tool 0 = translated search (q_meta / t_meta), tool 1 =
+    nucleotide search (t_seq / t_rev [, windows = (offset, home_lo, home_hi) per target], evalue per hit)"""
+    lib = load_library()
+    lib.pep_table_from_hits.restype = C.c_int64
+    n = len(hits)
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    cigar = np.ascontiguousarray(cigar, dtype=np.uint32)
+    arena = np.empty(max(len(cigar), 1), dtype=np.uint32)
+    cols = HitCols.blank(n)
+    i64 = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.int64)
+    q_len, r_len, t_seq = i64(q_len), i64(r_len), i64(t_seq)
+    t_rev = None if t_rev is None else np.ascontiguousarray(t_rev, dtype=np.uint8)
+    w = [i64(a) for a in windows] if windows is not None else [None, None, None]
+    evalue = None if evalue is None else np.ascontiguousarray(evalue, dtype=np.float64)
+    qm = None if q_meta is None else np.ascontiguousarray(q_meta, dtype=QUERY_META_DTYPE)
+    tm = None if t_meta is None else np.ascontiguousarray(t_meta, dtype=TARGET_META_DTYPE)
+    p = lambda a: None if a is None else _ptr(a)
+    hc = HitCols.over(cols)
+    m = lib.pep_table_from_hits(C.c_int32(tool), C.c_uint64(n), p(hits), p(cigar), C.c_uint64(len(cigar)), p(qm), p(tm), p(q_len), p(r_len), p(t_seq), p(t_rev),
+                                p(w[0]), p(w[1]), p(w[2]), p(evalue), C.c_double(min_id), C.c_double(min_cov), C.c_double(min_ratio), C.byref(hc), _ptr(arena))
+    if m < 0:
+        raise PepError('pep_table_from_hits failed (%d)' % m)
+    return {f: a[:m] for f, a in cols.items()}, arena[:len(cigar)]
+
+
+def cols_fix_end(cols, arena, se_lim, ee_lim):
+    """pep_cols_fix_end over {field: column} in place -> the rows' private arena (c_off rewritten)"""
+    lib = load_library()
+    lib.pep_cols_fix_end.restype = C.c_int64
+    n = len(cols['qs'])
+    out = np.empty(max(int(cols['c_runs'].sum()) if n else 0, 1), dtype=np.uint32)
+    hc = HitCols.over(cols)
+    arena = np.ascontiguousarray(arena, dtype=np.uint32)
+    rc_ = lib.pep_cols_fix_end(C.c_uint64(n), C.byref(hc), _ptr(arena) if len(arena) else None, C.c_uint64(len(arena)), _ptr(out), C.c_double(se_lim), C.c_double(ee_lim))
+    if rc_ < 0:
+        raise IndexError('fix_end: a row without CIGAR runs cannot be extended (the reference fails on cigar[0] here, uberBlast.py:468), or runs outside the arena')
+    return out[:int(cols['c_runs'].sum()) if n else 0]
+
+
+def cols_order(q_code, r_code, score):
+    """pep_cols_order: the row order of a stable sort by (q_code, r_code, score); codes non-negative"""
+    lib = load_library()
+    n = len(q_code)
+    q_code, r_code = np.ascontiguousarray(q_code, dtype=np.int64), np.ascontiguousarray(r_code, dtype=np.int64)
+    score = np.ascontiguousarray(score, dtype=np.float64)
+    order = np.empty(n, dtype=np.int64)
+    if n and lib.pep_cols_order(C.c_uint64(n), _ptr(q_code), _ptr(r_code), _ptr(score), _ptr(order)) != 0:
+        raise PepError('pep_cols_order failed (negative name codes?)')
+    return order
+
+
+def cols_gather(columns, idx):
+    """pep_cols_gather: [column[idx] for column in columns] for contiguous 8-byte columns of one length, in one call"""
+    lib = load_library()
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    k, n = len(columns), len(idx)
+    out = np.empty([max(k, 1), max(n, 1)], dtype=np.int64)
+    src = (C.c_void_p * max(k, 1))(*[a.ctypes.data for a in columns])
+    dst = (C.c_void_p * max(k, 1))(*[out[c].ctypes.data for c in range(k)])
+    for a in columns:
+        assert a.flags['C_CONTIGUOUS'] and a.dtype.itemsize == 8
+    n_src = len(columns[0]) if k else 0
+    if lib.pep_cols_gather(C.c_int32(k), src, dst, _ptr(idx) if n else None, C.c_uint64(n), C.c_uint64(n_src)) != 0:
+        raise IndexError('take: row index outside the table')
+    return [out[c][:n].view(a.dtype) for c, a in enumerate(columns)]
 
 
 def store_tab_members(rows, off, keys, date_time, threads=None, order=None):

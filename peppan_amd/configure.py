@@ -74,21 +74,23 @@ class uopen(object):
         self.fstream.close()
 
 
-def _record_text(lines):
-    """the lines of one record's body -> its sequence: blanks inside and between the lines dropped, upper case"""
-    return ''.join(''.join(lines).split()).upper()
+def _record_text(body):
+    """the text behind a record's header -> its sequence: comment lines (leading '#') left out, all white space dropped, upper case"""
+    if '#' in body:
+        body = ''.join(ln for ln in body.splitlines() if not ln.startswith('#'))
+    return ''.join(body.split()).upper()
 
 
 def readFasta(fasta, headOnly=False):
     """FASTA file -> {name: sequence}: the name is the first word of a header line, the sequence everything up to the next header
     without its white space, upper-cased; lines that start with '#' are comments; of two records with one name the later counts
-    (configure.py:118-128).  The file is read in one piece and cut at the headers."""
+    (configure.py:118-128).  The file is read in one piece and cut at the headers (a '>' at the start of a line)."""
     with uopen(fasta) as fin:
         text = fin.read()
     records = {}
-    for block in re.split(r'^>', text, flags=re.MULTILINE)[1:]:             # (what stands in front of the first header belongs to no record)
+    for block in ('\n' + text).split('\n>')[1:]:                           # (what stands in front of the first header belongs to no record)
         header, _, body = block.partition('\n')
-        records[header.split()[0]] = '' if headOnly else _record_text([ln for ln in body.splitlines() if not ln.startswith('#')])
+        records[header.split()[0]] = '' if headOnly else _record_text(body)
     return records
 
 
@@ -112,7 +114,7 @@ def readFastq(fastq, with_qual=True):
     seq, qual = {}, {}
     for header, bases, _, scores in zip(lines[0::4], lines[1::4], lines[2::4], lines[3::4]):
         name = header[1:].split()[0]
-        seq[name], qual[name] = _record_text([bases]), ''.join(scores.split())
+        seq[name], qual[name] = _record_text(bases), ''.join(scores.split())
     return seq, qual
 
 

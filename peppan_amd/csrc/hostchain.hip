@@ -1,0 +1,191 @@
+// Host-side C++ of RunBlast.run's numeric chain between the search and the caller (no GPU work, no context):
+//   pep_table_from_hits   hit records of a search -> the columns of the reference's table rows
+//                           translated tool: parseDiamond's coordinate algebra and filters        uberBlast.py:25-58
+//                           nucleotide tool: parseBlast's columns and filters                     uberBlast.py:275-290, 311-320
+//   pep_cols_fix_end      RunBlast.fixEnd over all rows                                           uberBlast.py:462-480
+//   pep_cols_order        the sort that ends RunBlast.run: query, reference, score - stable        uberBlast.py:375
+//   pep_cols_gather       rows picked from every column of a table in one pass
+// These were a chain of numpy expressions - some forty passes over 70 000 rows, 16 ms of the 31 ms the reference's hot call
+// (PEPPAN.py:229-230) took through the drop-in, and the per-genome bookkeeping of the mapping path.  Every float expression keeps the
+// operand order of the numpy form (IEEE double, no contraction): golden G3 / G4 / G6 / G8 hold the results to the last bit.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+// numpy.round(x, 3): multiply, round half to even, divide
+inline double round3(double x) { return std::nearbyint(x * 1000.0) / 1000.0; }
+
+// float('%.3f' % x) (blastn prints pident with three decimals, uberBlast.py:282): the correctly rounded 3-digit decimal of the double, read
+// back.  round3 gives the same value except when x * 1000 sits within an ulp of a tie: those go through the decimal string.
+inline double three_decimals(double v)
+{
+    const double scaled = v * 1000.0;
+    const double frac = std::fabs(scaled - std::floor(scaled) - 0.5);
+    if (frac < 1e-6) {
+        char buf[64];
+        snprintf(buf, sizeof buf, "%.3f", v);
+        return strtod(buf, nullptr);
+    }
+    return round3(v);
+}
+
+}   // namespace
+
+extern "C" {
+
+int64_t pep_table_from_hits(int32_t tool, uint64_t n, const pep_hit *hits, const uint32_t *cigar, uint64_t n_cigar, const pep_query_meta *q_meta,
+                            const pep_target_meta *t_meta, const int64_t *q_len, const int64_t *r_len, const int64_t *t_seq, const uint8_t *t_rev,
+                            const int64_t *win_off, const int64_t *home_lo, const int64_t *home_hi, const double *evalue, double min_id, double min_cov,
+                            double min_ratio, pep_hit_cols *out, uint32_t *arena_out)
+{
+    if ((n && (!hits || !out || !q_len || !r_len)) || (n_cigar && (!cigar || !arena_out))) return PEP_ERR_ARG;
+    if (tool == 0 && n && (!q_meta || !t_meta)) return PEP_ERR_ARG;
+    if (tool == 1 && n && (!t_seq || !t_rev)) return PEP_ERR_ARG;
+    if (tool != 0 && tool != 1) return PEP_ERR_ARG;
+    // the CIGAR arena in nucleotide units: the translated tool's runs count residues
+    if (tool == 0) for (uint64_t k = 0; k < n_cigar; ++k) arena_out[k] = ((cigar[k] >> 2) * 3u) << 2 | (cigar[k] & 3u);
+    else if (arena_out != cigar) memcpy(arena_out, cigar, n_cigar * sizeof(uint32_t));
+    int64_t m = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const pep_hit &h = hits[i];
+        if (h.cigar_off + h.cigar_runs > n_cigar) return PEP_ERR_ARG;
+        int64_t gap_cols = 0, gap_open = 0;
+        for (uint32_t k = 0; k < h.cigar_runs; ++k) {
+            const uint32_t run = cigar[h.cigar_off + k];
+            if (run & 3u) { gap_cols += run >> 2; ++gap_open; }
+        }
+        if (tool == 0) {
+            // parseDiamond: names q:frame / r:frame:offset, CIGAR x 3, identity from NM, coordinates back to nucleotides of either strand
+            const pep_query_meta &qm = q_meta[h.q];
+            const pep_target_meta &tm = t_meta[h.t];
+            const int64_t qseq = qm.seq, qf = qm.frame, rseq = tm.seq, rf = tm.frame, rx = tm.chunk_off;
+            const int64_t ql = q_len[qseq], rl = r_len[rseq];
+            const int64_t qs_aa = h.q_start, rs_aa = (int64_t)h.t_start + rx;
+            const int64_t qmatch = (int64_t)h.q_end - (int64_t)h.q_start + 1, rmatch = (int64_t)h.t_end - (int64_t)h.t_start + 1;
+            const int64_t cl = 3 * (int64_t)h.aln_len;
+            const double variation = 3.0 * (double)h.nm;
+            const double iden = 1.0 - round3(variation / (double)cl);
+            if (!((double)(qmatch * 3) >= min_cov && (double)qmatch * 3.0 / (double)ql >= min_ratio && iden >= min_id)) continue;
+            const bool fwd = rf <= 3;
+            out->qi[m] = qseq; out->ri[m] = rseq; out->iden[m] = iden; out->aln[m] = cl;
+            out->mis[m] = (int64_t)(variation - (double)(3 * gap_cols)); out->gap[m] = gap_open;
+            out->qs[m] = qs_aa * 3 + qf - 3; out->qe[m] = (qs_aa + qmatch - 1) * 3 + qf - 1;
+            out->ss[m] = fwd ? rs_aa * 3 + rf - 3 : rl - (rs_aa * 3 + rf - 6) + 1;
+            out->se[m] = fwd ? (rs_aa + rmatch - 1) * 3 + rf - 1 : rl - ((rs_aa + rmatch - 1) * 3 + rf - 4) + 1;
+            out->evalue[m] = 0.0; out->score[m] = (double)h.score; out->ql[m] = ql; out->sl[m] = rl;
+        } else {
+            // parseBlast: the subject strand from the target, identity with blastn's three printed decimals, e-value as given
+            const int64_t ri = t_seq[h.t];
+            const bool rev = t_rev[h.t] != 0;
+            const int64_t ql = q_len[h.q], sl = r_len[ri];
+            const int64_t qs = h.q_start, qe = h.q_end;
+            int64_t ts = h.t_start, te = h.t_end;
+            if (win_off) {
+                // targets that are windows of a long strand: back to strand coordinates; a hit belongs to the window whose home stretch holds its midpoint
+                ts += win_off[h.t]; te += win_off[h.t];
+                const int64_t mid = (ts + te - 2) / 2;           // (non-negative: floor division as in the numpy form)
+                if (!(mid >= home_lo[h.t] && mid < home_hi[h.t])) continue;
+            }
+            const double iden = three_decimals(100.0 * (double)h.n_ident / (double)h.aln_len) / 100.0;
+            const int64_t span = qe - qs + 1;
+            if (!(iden >= min_id && (double)span >= min_cov && (double)span >= min_ratio * (double)ql)) continue;
+            out->qi[m] = h.q; out->ri[m] = ri; out->iden[m] = iden; out->aln[m] = h.aln_len;
+            out->mis[m] = (int64_t)h.aln_len - (int64_t)h.n_ident - gap_cols; out->gap[m] = gap_open;
+            out->qs[m] = qs; out->qe[m] = qe;
+            out->ss[m] = rev ? sl - ts + 1 : ts; out->se[m] = rev ? sl - te + 1 : te;
+            out->evalue[m] = evalue ? evalue[i] : 0.0; out->score[m] = (double)h.score; out->ql[m] = ql; out->sl[m] = sl;
+        }
+        out->c_off[m] = (int64_t)h.cigar_off; out->c_runs[m] = h.cigar_runs;
+        if (out->rid) out->rid[m] = -1;
+        ++m;
+    }
+    return m;
+}
+
+// RunBlast.fixEnd for all rows: an alignment is stretched over an unaligned query head of at most se_lim bases / tail of at most ee_lim bases, as
+// far as the reference sequence allows; the first / last CIGAR run grows by the same amount whatever its operation is.  The rows' runs are
+// copied into a private arena (rows may share runs, and so may the caller's table): arena_out takes sum(c_runs) words, c_off is rewritten.
+// Returns the number of rows that changed, or PEP_ERR_ARG - also for a row without CIGAR runs that would have to be extended (the reference
+// fails on cigar[0] there, uberBlast.py:468).
+int64_t pep_cols_fix_end(uint64_t n, pep_hit_cols *c, const uint32_t *arena_in, uint64_t n_arena_in, uint32_t *arena_out, double se_lim, double ee_lim)
+{
+    if (n && (!c || !arena_out)) return PEP_ERR_ARG;
+    int64_t changed = 0, at = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const int64_t head = c->qs[i] - 1, tail = c->ql[i] - c->qe[i];
+        const bool fwd = c->se[i] > c->ss[i];
+        int64_t d = 0, e = 0;
+        if (head > 0 && (double)head <= se_lim) d = fwd ? std::min(head, c->ss[i] - 1) : std::min(head, c->sl[i] - c->ss[i]);
+        if (tail > 0 && (double)tail <= ee_lim) e = fwd ? std::min(tail, c->sl[i] - c->se[i]) : std::min(tail, c->se[i] - 1);
+        const int64_t runs = c->c_runs[i], off = c->c_off[i];
+        if ((d || e) && runs <= 0) return PEP_ERR_ARG;
+        if (runs < 0 || off < 0 || (uint64_t)(off + runs) > n_arena_in) return PEP_ERR_ARG;
+        memcpy(arena_out + at, arena_in + off, (size_t)runs * sizeof(uint32_t));
+        if (d || e) {
+            arena_out[at] += (uint32_t)(d << 2);
+            arena_out[at + runs - 1] += (uint32_t)(e << 2);
+            c->qs[i] -= d; c->ss[i] += fwd ? -d : d;
+            c->qe[i] += e; c->se[i] += fwd ? e : -e;
+            ++changed;
+        }
+        c->c_off[i] = at;
+        at += runs;
+    }
+    return changed;
+}
+
+// order[k] = the row that comes k-th when the table is sorted by (q_code, r_code, score), stable - the multi-column sort that ends RunBlast.run
+// with the names replaced by codes that sort like them.  Codes must be non-negative: two LSD radix passes per code as far as its range needs,
+// then the rows of one (query, reference) pair - a handful - by score.
+int pep_cols_order(uint64_t n, const int64_t *q_code, const int64_t *r_code, const double *score, int64_t *order)
+{
+    if (n && (!q_code || !r_code || !score || !order)) return PEP_ERR_ARG;
+    int64_t q_max = 0, r_max = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (q_code[i] < 0 || r_code[i] < 0) return PEP_ERR_ARG;
+        q_max = std::max(q_max, q_code[i]); r_max = std::max(r_max, r_code[i]);
+    }
+    std::vector<int64_t> tmp((size_t)n);
+    for (uint64_t i = 0; i < n; ++i) order[i] = (int64_t)i;
+    int64_t *src = order, *dst = tmp.data();
+    std::vector<uint64_t> cnt(65537);
+    auto pass = [&](const int64_t *code, int shift) {
+        std::fill(cnt.begin(), cnt.end(), 0);
+        for (uint64_t i = 0; i < n; ++i) ++cnt[(size_t)((code[src[i]] >> shift) & 0xFFFF) + 1];
+        for (int b = 0; b < 65536; ++b) cnt[(size_t)b + 1] += cnt[(size_t)b];
+        for (uint64_t i = 0; i < n; ++i) dst[cnt[(size_t)((code[src[i]] >> shift) & 0xFFFF)]++] = src[i];
+        std::swap(src, dst);
+    };
+    for (int shift = 0; shift < 64 && (r_max >> shift) != 0; shift += 16) pass(r_code, shift);
+    for (int shift = 0; shift < 64 && (q_max >> shift) != 0; shift += 16) pass(q_code, shift);
+    // rows of one pair by score (ascending; equal scores keep their order)
+    for (uint64_t a = 0; a < n;) {
+        uint64_t b = a + 1;
+        while (b < n && q_code[src[b]] == q_code[src[a]] && r_code[src[b]] == r_code[src[a]]) ++b;
+        if (b - a > 1) std::stable_sort(src + a, src + b, [&](int64_t x, int64_t y) { return score[x] < score[y]; });
+        a = b;
+    }
+    if (src != order) memcpy(order, src, (size_t)n * sizeof(int64_t));
+    return PEP_OK;
+}
+
+// dst[c][k] = src[c][idx[k]] for n_cols columns of 8-byte elements (every column of a hit table is int64 or double): HitTable.take in one call
+int pep_cols_gather(int32_t n_cols, const void *const *src, void *const *dst, const int64_t *idx, uint64_t n_idx, uint64_t n_src)
+{
+    if (n_cols < 0 || (n_cols && (!src || !dst)) || (n_idx && !idx)) return PEP_ERR_ARG;
+    for (uint64_t k = 0; k < n_idx; ++k)
+        if (idx[k] < 0 || (uint64_t)idx[k] >= n_src) return PEP_ERR_ARG;
+    for (int32_t c = 0; c < n_cols; ++c) {
+        const uint64_t *s = static_cast<const uint64_t *>(src[c]);
+        uint64_t *d = static_cast<uint64_t *>(dst[c]);
+        for (uint64_t k = 0; k < n_idx; ++k) d[k] = s[idx[k]];
+    }
+    return PEP_OK;
+}
+
+}   // extern "C"

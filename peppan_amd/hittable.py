@@ -167,11 +167,10 @@ class HitTable(object):
         t = HitTable.__new__(HitTable)
         for f in self.__slots__:
             setattr(t, f, getattr(self, f))
-        for f in self._ROW_COLS:
-            setattr(t, f, getattr(self, f)[idx])
-        if self.m_span is not None:
-            for f in self._MERGE_COLS:
-                setattr(t, f, getattr(self, f)[idx])
+        names = self._ROW_COLS + (self._MERGE_COLS if self.m_span is not None else ())
+        from ._native import cols_gather
+        for f, col in zip(names, cols_gather([np.ascontiguousarray(getattr(self, f)) for f in names], idx)):      # every column in one pass of host C++
+            setattr(t, f, col)
         if self.merge is not None:
             t.merge = [self.merge[i] for i in idx.tolist()]
         return t
@@ -226,33 +225,19 @@ class HitTable(object):
         operation is; identity, score and columns 3-5 stay.  All rows at once."""
         if not len(self):
             return
-        head, tail = self.qs - 1, self.ql - self.qe
-        fwd = self.se > self.ss
-        d = np.where((head > 0) & (head <= se_lim), np.where(fwd, np.minimum(head, self.ss - 1), np.minimum(head, self.sl - self.ss)), 0)
-        e = np.where((tail > 0) & (tail <= ee_lim), np.where(fwd, np.minimum(tail, self.sl - self.se), np.minimum(tail, self.se - 1)), 0)
-        if (self.c_runs[(d != 0) | (e != 0)] <= 0).any():
-            raise IndexError('fix_end: a row without CIGAR runs cannot be extended (the reference fails on cigar[0] here, uberBlast.py:468)')
-        self.qs = self.qs - d
-        self.ss = self.ss + np.where(fwd, -d, d)
-        self.qe = self.qe + e
-        self.se = self.se + np.where(fwd, e, -e)
-        if d.any() or e.any():
-            # the rows' runs are copied into a private arena first: rows may share runs (and so does the caller's table)
-            owner = np.repeat(np.arange(len(self)), self.c_runs)
-            start = np.concatenate([[0], np.cumsum(self.c_runs)[:-1]])
-            src = np.repeat(self.c_off - start, self.c_runs) + np.arange(len(owner))
-            arena = self.arena[src].astype(np.int64)
-            np.add.at(arena, start, d << 2)
-            np.add.at(arena, start + self.c_runs - 1, e << 2)
-            self.arena, self.c_off = arena.astype(np.uint32), start
-            del owner
+        from ._native import cols_fix_end
+        cols = {f: np.array(getattr(self, f)) for f in ('qs', 'qe', 'ss', 'se', 'c_off')}          # (the columns that change: private copies, rows may be shared with the caller's table)
+        cols.update({f: getattr(self, f) for f in ('ql', 'sl', 'c_runs')})
+        self.arena = cols_fix_end(cols, self.arena, se_lim, ee_lim)                                  # host C++; the rows' runs in a private arena
+        self.qs, self.qe, self.ss, self.se, self.c_off = (cols[f] for f in ('qs', 'qe', 'ss', 'se', 'c_off'))
 
     def final_order(self):
         """the sort that ends RunBlast.run (uberBlast.py:375): by query name, reference name (as the column's values sort: strings
         lexicographically - '10' < '9'), then score; stable"""
         q, r = self.q_codes(), self.r_codes()
-        if len(q) and min(int(q.min()), int(r.min())) >= 0 and max(int(q.max()), int(r.max())) < (1 << 31):
-            return np.lexsort((self.score, (q.astype(np.int64) << 32) | r.astype(np.int64)))        # (one stable pass less: the two codes as one key)
+        if len(q) and min(int(q.min()), int(r.min())) >= 0:
+            from ._native import cols_order
+            return cols_order(q, r, self.score)              # host C++: radix passes over the two codes, the rows of one pair by score
         return np.lexsort((self.score, r, q))
 
     # ------------------------------------------------------------------------------------------------ object rows

@@ -122,35 +122,11 @@ def _str_table(names):
 def hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
     """hits/cigar: output of Context.search for a translated search.  q_len / r_len: nucleotide lengths per sequence index.
     Returns the numeric HitTable of the rows parseDiamond would keep (coordinate algebra and filters of uberBlast.py:25-58)."""
-    n = len(hits)
-    if n == 0:
+    if len(hits) == 0:
         return HitTable.empty()
-    qi, ti = hits['q'].astype(np.int64), hits['t'].astype(np.int64)
-    qseq, qf = q_meta['seq'][qi].astype(np.int64), q_meta['frame'][qi].astype(np.int64)
-    rseq, rf, rx = t_meta['seq'][ti].astype(np.int64), t_meta['frame'][ti].astype(np.int64), t_meta['chunk_off'][ti].astype(np.int64)
-    ql, rl = np.asarray(q_len, dtype=np.int64)[qseq], np.asarray(r_len, dtype=np.int64)[rseq]
-    qs_aa, qe_aa = hits['q_start'].astype(np.int64), hits['q_end'].astype(np.int64)
-    rs_aa = hits['t_start'].astype(np.int64) + rx                       # POS + chunk offset
-    qm = qe_aa - qs_aa + 1                                              # aligned query residues = len(SEQ)
-    rm = hits['t_end'].astype(np.int64) - hits['t_start'].astype(np.int64) + 1
-    cl = 3 * hits['aln_len'].astype(np.int64)
-    variation = 3. * hits['nm'].astype(np.float64)
-    iden = 1 - np.round(variation / cl, 3)          # round() of a numpy float64 is numpy's round (uberBlast.py:38)
-    keep = (qm * 3 >= min_cov) & (qm * 3. / ql >= min_ratio) & (iden >= min_id)
-    fwd = rf <= 3
-    rs_nt = np.where(fwd, rs_aa * 3 + rf - 3, rl - (rs_aa * 3 + rf - 6) + 1)
-    re_nt = np.where(fwd, (rs_aa + rm - 1) * 3 + rf - 1, rl - ((rs_aa + rm - 1) * 3 + rf - 4) + 1)
-    qs_nt, qe_nt = qs_aa * 3 + qf - 3, (qs_aa + qm - 1) * 3 + qf - 1
-    runs_len = (cigar >> 2).astype(np.int64) * 3
-    runs_op = (cigar & 3).astype(np.int64)
-    owner = np.repeat(np.arange(n), hits['cigar_runs'].astype(np.int64))
-    gap_nt = np.bincount(owner, weights=runs_len * (runs_op != 0), minlength=n).astype(np.int64)
-    gap_open = np.bincount(owner, weights=(runs_op != 0), minlength=n).astype(np.int64)
-    mismatch = (variation - gap_nt).astype(np.int64)
-    idx = np.nonzero(keep)[0]
-    return HitTable(_str_table(q_names), _str_table(r_names), qseq[idx], rseq[idx], iden[idx], cl[idx], mismatch[idx], gap_open[idx],
-                    qs_nt[idx], qe_nt[idx], rs_nt[idx], re_nt[idx], np.zeros(len(idx)), hits['score'][idx], ql[idx], rl[idx],
-                    ((runs_len << 2) | runs_op).astype(np.uint32), hits['cigar_off'][idx], hits['cigar_runs'][idx])
+    c, arena = N.table_from_hits(0, hits, cigar, q_len, r_len, min_id, min_cov, min_ratio, q_meta=q_meta, t_meta=t_meta)      # host C++: one pass over the records
+    return HitTable(_str_table(q_names), _str_table(r_names), c['qi'], c['ri'], c['iden'], c['aln'], c['mis'], c['gap'], c['qs'], c['qe'], c['ss'], c['se'],
+                    c['evalue'], c['score'], c['ql'], c['sl'], arena, c['c_off'], c['c_runs'], rid=c['rid'])
 
 
 def hits_to_blastab(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
@@ -192,36 +168,13 @@ def blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len, min_id, min
     """nucleotide-search hits -> the rows parseBlast builds from blastn's outfmt 6 (uberBlast.py:275-290, 311-320), as a HitTable:
     t_seq / t_rev give the reference sequence and strand of every target (reverse strand: sstart > send); identity
     carries blastn's 3 printed decimals"""
-    n = len(hits)
-    if n == 0:
+    if len(hits) == 0:
         return HitTable.empty()
-    qi = hits['q'].astype(np.int64)
-    ti = hits['t'].astype(np.int64)
-    rev, ri = t_rev[ti], t_seq[ti]
-    ql, sl = np.asarray(q_len, dtype=np.int64)[qi], np.asarray(r_len, dtype=np.int64)[ri]
-    qs, qe = hits['q_start'].astype(np.int64), hits['q_end'].astype(np.int64)
-    ts, te = hits['t_start'].astype(np.int64), hits['t_end'].astype(np.int64)
-    in_home = True
-    if windows is not None:
-        # targets that are windows of a long strand (runBlast): back to strand coordinates; a hit belongs to the window whose home
-        # stretch holds its midpoint (the neighbouring window found the same alignment inside its halo)
-        w_off, home_lo, home_hi = windows
-        ts, te = ts + w_off[ti], te + w_off[ti]
-        mid = (ts + te - 2) // 2
-        in_home = (mid >= home_lo[ti]) & (mid < home_hi[ti])
-    ss, se = np.where(rev, sl - ts + 1, ts), np.where(rev, sl - te + 1, te)
-    aln, ident = hits['aln_len'].astype(np.int64), hits['n_ident'].astype(np.int64)
-    iden = _three_decimals(100. * ident / aln) / 100.
-    runs_len, runs_op = (cigar >> 2).astype(np.int64), (cigar & 3).astype(np.int64)
-    owner = np.repeat(np.arange(n), hits['cigar_runs'].astype(np.int64))
-    gap_cols = np.bincount(owner, weights=runs_len * (runs_op != 0), minlength=n).astype(np.int64)
-    gap_open = np.bincount(owner, weights=(runs_op != 0), minlength=n).astype(np.int64)
-    score = hits['score'].astype(np.int64)
-    evalue = params.ka_k * ql * params.dbsize * np.exp(-params.ka_lambda * score)
-    keep = (iden >= min_id) & (qe - qs + 1 >= min_cov) & (qe - qs + 1 >= min_ratio * ql) & in_home
-    idx = np.nonzero(keep)[0]
-    return HitTable(_str_table(q_names), _str_table(r_names), qi[idx], ri[idx], iden[idx], aln[idx], (aln - ident - gap_cols)[idx], gap_open[idx],
-                    qs[idx], qe[idx], ss[idx], se[idx], evalue[idx], score[idx], ql[idx], sl[idx], np.array(cigar, dtype=np.uint32), hits['cigar_off'][idx], hits['cigar_runs'][idx])
+    q_len = np.asarray(q_len, dtype=np.int64)
+    evalue = params.ka_k * q_len[hits['q'].astype(np.int64)] * params.dbsize * np.exp(-params.ka_lambda * hits['score'].astype(np.int64))
+    c, arena = N.table_from_hits(1, hits, cigar, q_len, r_len, min_id, min_cov, min_ratio, t_seq=t_seq, t_rev=t_rev, windows=windows, evalue=evalue)
+    return HitTable(_str_table(q_names), _str_table(r_names), c['qi'], c['ri'], c['iden'], c['aln'], c['mis'], c['gap'], c['qs'], c['qe'], c['ss'], c['se'],
+                    c['evalue'], c['score'], c['ql'], c['sl'], arena, c['c_off'], c['c_runs'], rid=c['rid'])
 
 
 def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev, windows=None):
@@ -647,8 +600,9 @@ class RunBlast(object):
             ctx = get_context(self.device)
             self._ensure_nt(ctx)
             h = np.zeros(len(T), dtype=N.NT_HIT_DTYPE)
-            h['q'] = np.array([self.q_index[str(x)] for x in T.q_tab], dtype=np.int64)[T.qi]
-            h['r'] = np.array([self.r_index[str(x)] for x in T.r_tab], dtype=np.int64)[T.ri]
+            # (a table of this instance's own tools carries the name tables the sides were prepared with: row codes ARE sequence indices)
+            h['q'] = T.qi if T.q_tab is self._q_tab else np.array([self.q_index[str(x)] for x in T.q_tab], dtype=np.int64)[T.qi]
+            h['r'] = T.ri if T.r_tab is self._r_tab else np.array([self.r_index[str(x)] for x in T.r_tab], dtype=np.int64)[T.ri]
             h['qs'], h['qe'], h['rs'], h['re'] = T.qs, T.qe, T.ss, T.se
             h['cigar_runs'], h['cigar_off'] = T.c_runs, T.c_off
             c = ctx.rescore_nt(h, T.arena).astype(np.int64)

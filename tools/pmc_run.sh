@@ -6,5 +6,5 @@ ctrs=()
 while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
 shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 240 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" -d gpurun_out/$tag -o $tag -- python3 "$@" > gpurun_out/$tag.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc "${ctrs[@]}" -d gpurun_out/$tag -o $tag -- python3 "$@" > gpurun_out/$tag.log 2>&1
 echo "rc=$?"

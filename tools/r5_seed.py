@@ -25,6 +25,6 @@ for n in [int(x) for x in sys.argv[1:]] or [10000, 50000]:
         ctx.set_timing(2)
         tabs[off] = (h.tobytes(), c.tobytes())
         print('%d genes, shortcut %s: step %.3f ms; ms_seed %.3f ms_seed_match %.3f ms_sw %.3f ms_total %.3f; seed_hits %d self %d target_seeds %d candidates %d hits %d'
-              % (n, 'off' if off else 'ON ', dt, st['ms_seed'], st['ms_seed_match'], st['ms_sw'], st['ms_total'], st['seed_hits'], st['seed_hits_self'], st['target_seeds'], st['candidates'], len(h)), flush=True)
+              % (n, 'off' if off else 'ON ', dt, st['ms_seed'], st['ms_seed_match'], st['ms_sw'], st['ms_total'], st['seed_hits'], st.get('seed_hits_self', 0), st['target_seeds'], st['candidates'], len(h)), flush=True)
     print('tables identical:', tabs[0] == tabs[8])
     ctx.close()
