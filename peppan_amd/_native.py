@@ -647,6 +647,7 @@ class Context(object):
     def use_nt_as_residues(self, strands=2):
         """the device-resident nucleotide sets themselves become the residue sets (base codes; reference: forward strands, then reverse
         complements, per target group) - the inputs of the nucleotide search.  Until the next translate() / set_*."""
+        self._drop_view()
         self._check(self._lib.pep_use_nt_as_residues(self._h, C.c_int(strands)), 'pep_use_nt_as_residues')
 
     def set_timing(self, level):
@@ -704,14 +705,17 @@ class Context(object):
     def target_aa(self):
         return self._get_aa(self._lib.pep_target_count, self._lib.pep_get_target_aa, 'pep_get_target_aa')
 
+    def _drop_view(self):
+        if self._view is not None:                      # the handle behind the previous zero-copy views: released first, so that
+            self._lib.pep_result_free(self._view)       # the library does not preserve a table nobody may look at any more
+            self._view = None
+
     # ---- search
     def search(self, params=None, copy=True):
         """returns (hits [HIT_DTYPE], cigar uint32 [len<<2|op], stats dict).
         copy=False: the arrays are views of the library's pinned staging memory - no 2 MB copy and no fresh pages - valid only
         until the next search on this context (for callers that consume the table at once, like hits_to_blastab)."""
-        if self._view is not None:                      # the handle behind the previous zero-copy views: released first, so that
-            self._lib.pep_result_free(self._view)       # the library does not preserve a table nobody may look at any more
-            self._view = None
+        self._drop_view()
         r = C.c_void_p()
         self._check(self._lib.pep_search(self._h, C.byref(params) if params is not None else None, C.byref(r)), 'pep_search')
         try:

@@ -485,7 +485,8 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_ms.p) (void)hipHostFree(ctx->pin_ms.p);
     DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->fused_state[0].buf, &ctx->fused_state[1].buf, &ctx->fused_state[2].buf, &ctx->fused_state[3].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq,
-                      &ctx->sort_state, &ctx->sort_hist, &ctx->d_set, &ctx->d_zero, &ctx->d_k1_desc_q, &ctx->d_k1_desc_t, &ctx->d_mail_copy};
+                      &ctx->sort_state, &ctx->sort_hist, &ctx->d_set, &ctx->d_zero, &ctx->d_k1_desc_q, &ctx->d_k1_desc_t, &ctx->d_mail_copy,
+                      &ctx->nucl_q.d_off, &ctx->nucl_q.d_len, &ctx->nucl_q.d_desc, &ctx->nucl_t.d_off, &ctx->nucl_t.d_len, &ctx->nucl_t.d_desc};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -499,6 +500,7 @@ int pep_set_query_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint3
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     if (n > PEP_MAX_QUERIES) return pep_fail(ctx, PEP_ERR_LIMIT, "too many queries");
     PEP_TRY(upload_nt(ctx, ctx->q_nt, nt, off, n));
+    ctx->nucl_valid = false;
     ctx->q_from_nt = true; ctx->q_gtable = gtable; ctx->q_ready = false; ctx->resid_from_nucl = false;
     return PEP_OK;
 }
@@ -509,6 +511,7 @@ int pep_set_ref_nt(pep_ctx *ctx, const uint8_t *nt, const uint64_t *off, uint32_
     if (frames != 3 && frames != 6) return pep_fail(ctx, PEP_ERR_ARG, "frames must be 3 or 6");
     PEP_HIP(ctx, hipSetDevice(ctx->device));
     PEP_TRY(upload_nt(ctx, ctx->r_nt, nt, off, n));
+    ctx->nucl_valid = false;
     ctx->t_from_nt = true; ctx->t_gtable = gtable; ctx->t_frames = frames; ctx->t_ready = false; ctx->k1_base_frames = 0; ctx->resid_from_nucl = false;
     ctx->group_of_seq.clear(); ctx->t_class_ready = false;
     return PEP_OK;
@@ -635,8 +638,10 @@ int pep_set_target_groups(pep_ctx *ctx, const uint32_t *group, uint32_t n)
     if (!ctx || (n && !group)) return PEP_ERR_ARG;
     for (uint32_t i = 1; i < n; ++i)
         if (group[i] < group[i - 1]) return pep_fail(ctx, PEP_ERR_ARG, "pep_set_target_groups: groups must be contiguous and non-decreasing");
+    if (ctx->group_of_seq.size() == n && (n == 0 || memcmp(ctx->group_of_seq.data(), group, (size_t)n * sizeof(uint32_t)) == 0)) return PEP_OK;      // (nothing changes: what was derived from the groups stays)
     ctx->group_of_seq.assign(group, group + n);
     ctx->t_class_ready = false;
+    ctx->nucl_valid = false;                    // (the nucleotide tool's targets are laid out group by group)
     return PEP_OK;
 }
 

@@ -108,6 +108,17 @@ struct pep_ctx {
     std::vector<uint64_t> k1_base;
     uint64_t k1_upper = 0;
     int k1_base_frames = 0;            // 0 = not computed for the current reference set
+    // what pep_use_nt_as_residues makes of the nucleotide sets apart from the residues themselves (translate.hip: pep_nucl_sets), kept per pair of uploads
+    struct NuclSide {
+        uint32_t n = 0, max_len = 0;
+        uint64_t total = 0, residues = 0;
+        std::vector<uint32_t> h_off, h_len;
+        std::vector<pep_query_meta> q_meta;
+        std::vector<pep_target_meta> t_meta;
+        DevBuf d_off, d_len, d_desc;
+    } nucl_q, nucl_t;
+    bool nucl_valid = false;
+    int nucl_strands = 0;
     DevBuf d_min_score;
     DevBuf d_trace_mode;                    // per traced pair: first lane of the sub-band its traceback codes cover, -1 = the full band (sw.hip)
     std::vector<uint32_t> group_of_seq;     // optional: competition group of every reference sequence (pep_set_target_groups)

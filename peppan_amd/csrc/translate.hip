@@ -690,64 +690,89 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     return k1_ref_finish(ctx);
 }
 
-// the packed residue set of one side from its nucleotide set: `order` lists (sequence, strand) per packed sequence
-static int nucl_build(pep_ctx *ctx, const NtSet &nt, const std::vector<NuclDesc> &order, uint32_t max_n, SeqSet &out)
+// The packed residue set of one side from its nucleotide set: `order` lists (sequence, strand) per packed sequence.  Everything but the residues
+// themselves - offsets, lengths, descriptors, the host mirrors - depends on the uploaded nucleotide sets (and the target groups) only and is kept
+// (NuclSide) between calls: PEPPAN's hot call runs the nucleotide tool and the translated tool in turn on the same sets, and K1 overwrites the packed
+// sets in between.  A repeat costs four small device-to-device copies and the two pack kernels, queued without a wait.
+static int nucl_build(pep_ctx *ctx, const NtSet &nt, const std::vector<NuclDesc> &order, uint32_t max_n, SeqSet &out, pep_ctx::NuclSide &keep)
 {
     const uint32_t n = (uint32_t)order.size();
     if (n > max_n) return pep_fail(ctx, PEP_ERR_LIMIT, "too many sequences");
-    out.n = n;
-    out.h_off.assign((size_t)n + 1, 0);
-    out.h_len.assign(n, 0);
+    keep.h_off.assign((size_t)n + 1, 0);
+    keep.h_len.assign(n, 0);
     uint64_t pos = PEP_END_PAD, residues = 0;
     uint32_t max_len = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const uint64_t len = nt.h_off[order[i].seq + 1] - nt.h_off[order[i].seq];
         if (len > PEP_MAX_SEQ_LEN) return pep_fail(ctx, PEP_ERR_LIMIT, "sequence longer than PEP_MAX_SEQ_LEN");
-        out.h_off[i] = (uint32_t)pos; out.h_len[i] = (uint32_t)len;
+        keep.h_off[i] = (uint32_t)pos; keep.h_len[i] = (uint32_t)len;
         residues += len; max_len = std::max(max_len, (uint32_t)len);
         pos += (len + 15) / 16 * 16 + PEP_SEQ_GAP;
         if (pos > PEP_MAX_RESIDUES) return pep_fail(ctx, PEP_ERR_LIMIT, "packed sequence set exceeds 2^29 bytes");
     }
     pos += PEP_END_PAD;
-    out.h_off[n] = (uint32_t)pos;
-    out.total = pos; out.residues = residues; out.max_len = max_len;
-    PEP_TRY(dev_reserve(ctx, out.res, pos + 64));
+    keep.h_off[n] = (uint32_t)pos;
+    keep.n = n; keep.total = pos; keep.residues = residues; keep.max_len = max_len;
+    PEP_TRY(dev_reserve(ctx, keep.d_off, ((size_t)n + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, keep.d_len, ((size_t)n + 2) * 4));
+    PEP_TRY(dev_reserve(ctx, keep.d_desc, ((size_t)n + 1) * sizeof(NuclDesc)));
+    PEP_HIP(ctx, hipMemcpyAsync(keep.d_off.p, keep.h_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n) PEP_HIP(ctx, hipMemcpyAsync(keep.d_len.p, keep.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (n) PEP_HIP(ctx, hipMemcpyAsync(keep.d_desc.p, order.data(), (size_t)n * sizeof(NuclDesc), hipMemcpyHostToDevice, ctx->stream));
+    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (the descriptor vector is the caller's; once per pair of uploads)
+    (void)out;
+    return PEP_OK;
+}
+
+// a kept side -> the context's packed set: offsets and lengths copied on the device, residues and the block map packed from the nucleotides
+static int nucl_apply(pep_ctx *ctx, const NtSet &nt, const pep_ctx::NuclSide &keep, SeqSet &out)
+{
+    const uint32_t n = keep.n;
+    out.n = n; out.total = keep.total; out.residues = keep.residues; out.max_len = keep.max_len;
+    out.h_off = keep.h_off; out.h_len = keep.h_len;
+    PEP_TRY(dev_reserve(ctx, out.res, keep.total + 64));
     PEP_TRY(dev_reserve(ctx, out.off, ((size_t)n + 2) * 4));
     PEP_TRY(dev_reserve(ctx, out.len, ((size_t)n + 2) * 4));
-    PEP_TRY(dev_reserve(ctx, out.blk2seq, (pos / 32 + 2) * sizeof(uint2)));
-    PEP_TRY(dev_reserve(ctx, ctx->ws[2], ((size_t)n + 1) * sizeof(NuclDesc)));
-    PEP_HIP(ctx, hipMemcpyAsync(out.off.p, out.h_off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (n) PEP_HIP(ctx, hipMemcpyAsync(out.len.p, out.h_len.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    if (n) PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[2].p, order.data(), (size_t)n * sizeof(NuclDesc), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(nucl_pack, dim3((unsigned)ceil_div((uint64_t)n + 1, 4), (unsigned)ceil_div((uint64_t)max_len + 15 + PEP_SEQ_GAP, NUCL_SLICE) + 1), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(),
-                       ctx->ws[2].as<const NuclDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), out.blk2seq.as<uint2>());
+    PEP_TRY(dev_reserve(ctx, out.blk2seq, (keep.total / 32 + 2) * sizeof(uint2)));
+    PEP_HIP(ctx, hipMemcpyAsync(out.off.p, keep.d_off.p, ((size_t)n + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (n) PEP_HIP(ctx, hipMemcpyAsync(out.len.p, keep.d_len.p, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(nucl_pack, dim3((unsigned)ceil_div((uint64_t)n + 1, 4), (unsigned)ceil_div((uint64_t)keep.max_len + 15 + PEP_SEQ_GAP, NUCL_SLICE) + 1), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(),
+                       keep.d_desc.as<const NuclDesc>(), out.off.as<const uint32_t>(), n, out.res.as<uint8_t>(), out.blk2seq.as<uint2>());
     PEP_HIP(ctx, hipGetLastError());
-    PEP_HIP(ctx, hipStreamSynchronize(ctx->stream));           // (the descriptor vector is the caller's)
     return PEP_OK;
 }
 
 int pep_nucl_sets(pep_ctx *ctx, int strands)
 {
-    std::vector<NuclDesc> qo(ctx->q_nt.n), to;
-    for (uint32_t i = 0; i < ctx->q_nt.n; ++i) qo[i] = NuclDesc{i, 0u};
-    PEP_TRY(nucl_build(ctx, ctx->q_nt, qo, PEP_MAX_QUERIES, ctx->q));
-    ctx->q_tables_lazy = false;
-    ctx->q_meta.resize(ctx->q_nt.n);
-    for (uint32_t i = 0; i < ctx->q_nt.n; ++i) ctx->q_meta[i] = pep_query_meta{i, 1u, ctx->q.h_len[i], ctx->q.h_len[i]};
-    // targets: per reference set (pep_set_target_groups; one set otherwise) all forward strands, then all reverse complements
-    const uint32_t nr = ctx->r_nt.n;
-    const bool grouped = ctx->group_of_seq.size() == nr && nr > 0;
-    to.reserve((size_t)nr * strands);
-    for (uint32_t a = 0; a < nr;) {
-        uint32_t b = a + 1;
-        while (b < nr && (!grouped || ctx->group_of_seq[b] == ctx->group_of_seq[a])) ++b;
-        for (int rev = 0; rev < strands; ++rev)
-            for (uint32_t i = a; i < b; ++i) to.push_back(NuclDesc{i, (uint32_t)rev});
-        a = b;
+    if (!ctx->nucl_valid || ctx->nucl_strands != strands) {
+        ctx->nucl_valid = false;
+        std::vector<NuclDesc> qo(ctx->q_nt.n), to;
+        for (uint32_t i = 0; i < ctx->q_nt.n; ++i) qo[i] = NuclDesc{i, 0u};
+        PEP_TRY(nucl_build(ctx, ctx->q_nt, qo, PEP_MAX_QUERIES, ctx->q, ctx->nucl_q));
+        // targets: per reference set (pep_set_target_groups; one set otherwise) all forward strands, then all reverse complements
+        const uint32_t nr = ctx->r_nt.n;
+        const bool grouped = ctx->group_of_seq.size() == nr && nr > 0;
+        to.reserve((size_t)nr * strands);
+        for (uint32_t a = 0; a < nr;) {
+            uint32_t b = a + 1;
+            while (b < nr && (!grouped || ctx->group_of_seq[b] == ctx->group_of_seq[a])) ++b;
+            for (int rev = 0; rev < strands; ++rev)
+                for (uint32_t i = a; i < b; ++i) to.push_back(NuclDesc{i, (uint32_t)rev});
+            a = b;
+        }
+        PEP_TRY(nucl_build(ctx, ctx->r_nt, to, PEP_MAX_TARGETS, ctx->t, ctx->nucl_t));
+        ctx->nucl_q.q_meta.resize(ctx->q_nt.n);
+        for (uint32_t i = 0; i < ctx->q_nt.n; ++i) ctx->nucl_q.q_meta[i] = pep_query_meta{i, 1u, ctx->nucl_q.h_len[i], ctx->nucl_q.h_len[i]};
+        ctx->nucl_t.t_meta.resize(to.size());
+        for (size_t i = 0; i < to.size(); ++i) ctx->nucl_t.t_meta[i] = pep_target_meta{to[i].seq, to[i].rev ? 4u : 1u, 0u, ctx->nucl_t.h_len[i]};
+        ctx->nucl_strands = strands;
+        ctx->nucl_valid = true;
     }
-    PEP_TRY(nucl_build(ctx, ctx->r_nt, to, PEP_MAX_TARGETS, ctx->t));
+    PEP_TRY(nucl_apply(ctx, ctx->q_nt, ctx->nucl_q, ctx->q));
+    PEP_TRY(nucl_apply(ctx, ctx->r_nt, ctx->nucl_t, ctx->t));
+    ctx->q_tables_lazy = false;
     ctx->t_tables_lazy = false;
-    ctx->t_meta.resize(to.size());
-    for (size_t i = 0; i < to.size(); ++i) ctx->t_meta[i] = pep_target_meta{to[i].seq, to[i].rev ? 4u : 1u, 0u, ctx->t.h_len[i]};
+    ctx->q_meta = ctx->nucl_q.q_meta;
+    ctx->t_meta = ctx->nucl_t.t_meta;
     return PEP_OK;
 }

@@ -340,10 +340,17 @@ class RunBlast(object):
             none = HitTable.empty() if self._as_tables else np.empty([0, 16], dtype=object)
             return (none, np.empty([0, 3], dtype=int)) if return_overlap[0] else none
         T.rid = np.arange(len(T), dtype=np.int64)
-        if re_score and rescored:
-            T = T.take(T.iden >= self.min_id)
-        elif re_score:
-            T = self._rescore_table(ref, qry, T, re_score, self.min_id, self.table_id)
+        plain = not (filter[0] or linear_merge[0] or return_overlap[0])
+        keep = None
+        if re_score and not rescored:
+            T = self._rescore_table(ref, qry, T, re_score, self.min_id, self.table_id, cut=not plain)
+        if re_score and (rescored or plain):
+            # the identity cut of reScore (uberBlast.py:414).  With nothing between it and the final sort that looks at other rows (-f, -m, -O), the
+            # cut rides on the sort's gather: fixEnd is row-local, one take instead of two
+            if plain:
+                keep = T.iden >= self.min_id
+            else:
+                T = T.take(T.iden >= self.min_id)
         if filter[0]:
             T = mapfilters.ovl_filter_table(T, filter[1], filter[2])
         if linear_merge[0]:
@@ -352,7 +359,8 @@ class RunBlast(object):
         overlap = None
         if return_overlap[0]:
             overlap = mapfilters.overlaps_table(T, return_overlap[1], return_overlap[2], sweep=get_context(self.device).overlaps)
-        T = T.take(T.final_order())
+        order = T.final_order()
+        T = T.take(order if keep is None else order[keep[order]])
         rows = T if self._as_tables else T.to_rows(cigar='str')
         return (rows, overlap) if return_overlap[0] else rows
 
@@ -692,9 +700,15 @@ _SEARCH_FLAGS = (
 )
 
 
+_PARSERS = {}
+
+
 def _parser(description, with_reference):
+    """the argument parser of uberBlast / uberBlastBatch, built once per process (PEPPAN calls uberBlast once per genome: a millisecond each time)"""
+    if (description, with_reference) in _PARSERS:
+        return _PARSERS[description, with_reference]
     import argparse
-    ap = argparse.ArgumentParser(description=description)
+    ap = _PARSERS[description, with_reference] = argparse.ArgumentParser(description=description)
     if with_reference:
         ap.add_argument('-r', '--reference', required=True, help='FASTA / FASTQ file searched against (gzip accepted)')
         ap.add_argument('-o', '--output', default=None, help='write the table as tab-separated text to this file, or STDOUT')
