@@ -120,6 +120,7 @@ struct pep_ctx {
     bool nucl_valid = false;
     int nucl_strands = 0;
     DevBuf d_min_score;
+    DevBuf d_trace_defer;                   // traceback pass: pairs that left their sub-band, waiting for their full-band sweep (sw.hip: run_deferred)
     DevBuf d_trace_mode;                    // per traced pair: first lane of the sub-band its traceback codes cover, -1 = the full band (sw.hip)
     std::vector<uint32_t> group_of_seq;     // optional: competition group of every reference sequence (pep_set_target_groups)
     DevBuf d_t_class;

@@ -43,6 +43,7 @@ struct SwArgs {
     int4 *out;                     // score, iend, jend, a0
     int oe, ext;
     int lds_res_bytes;             // per-wave residue staging capacity (0 = global path only)
+    uint32_t *defer;               // traceback pass: the pairs that left their sub-band (counts[6] of them; counts[7]: taken by sw_trace_retry_kernel)
     int pk16;                      // sweep two candidates per wavefront in packed 16-bit (score pass; traceback pass when `known` is set)
     const int32_t *known;          // traceback pass: the score of every candidate, from the score pass
     int max_sub;                   // largest table entry: bounds the scores of a pair for the 16-bit passes
@@ -700,14 +701,40 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
             if (packed) {
                 bool ok[4];
                 sw_four_pk16_trace<LONG>(a, cc, gg, L0, ok, smem, lds_res, lane);
+                // a pair whose alignment left its sub-band is swept once more in the full band, one pair per wavefront in 32 bits: the longest single
+                // piece of work of the pass (a millisecond for a pair of 1 000 bases).  It is not done here - a wavefront that met three of them held the
+                // whole launch up (nucleotide tool, 10 000 genes: 1 % of the pairs, 1.98 ms with 1.9 of 4 wavefronts per SIMD resident on average) - but
+                // put on a list that a launch of its own works off, one pair per wavefront over the whole chip (sw_trace_retry_kernel)
 #pragma unroll 1
                 for (int x = 0; x < 4; ++x)
-                    if (!ok[x]) trace_slow_path(ka, cc[x], smem, lds_res, lane, 1);          // left its sub-band: once more in the full band
+                    if (!ok[x] && lane == 0) a.defer[atomicAdd(a.counts + 6, 1ull)] = (uint32_t)cc[x];
             } else {
 #pragma unroll 1
                 for (int x = 0; x < n_own; ++x) trace_slow_path(ka, cc[x], smem, lds_res, lane, 0);
             }
         }
+    }
+}
+
+// The pairs whose alignment left its sub-band (sw_trace_kernel put them on a list: counts[6] of them), swept once more in the full band: one pair per
+// wavefront, every wavefront of the chip pulling from the list (counts[7] = pairs taken).
+__global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_retry_kernel(SwArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long n_list = a.counts[6];
+    if ((unsigned long long)blockIdx.x * WAVES_PER_BLOCK >= n_list) return;          // nothing for this block (before it loads the table)
+    uint32_t *lds_tab = reinterpret_cast<uint32_t *>(smem);
+    for (int x = threadIdx.x; x < LDS_TABLE_BYTES / 4; x += blockDim.x) lds_tab[x] = a.sub_image[x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint16_t *lds_res = reinterpret_cast<uint16_t *>(smem + LDS_TABLE_BYTES + (size_t)wave * a.lds_res_bytes);
+    const SwArgs *ka = (const SwArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    for (;;) {
+        unsigned long long w = 0;
+        if (lane == 0) w = atomicAdd(a.counts + 7, 1ull);
+        w = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)w);
+        if (w >= n_list) break;
+        trace_slow_path(ka, (uint64_t)a.defer[w], smem, lds_res, lane, 1);
     }
 }
 
@@ -1009,6 +1036,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
         }
         PEP_TRY(dev_reserve(ctx, ctx->ws[13], total_blk * 512 + 512));
         PEP_TRY(dev_reserve(ctx, ctx->d_trace_mode, (n + 1) * sizeof(int32_t)));
+        PEP_TRY(dev_reserve(ctx, ctx->d_trace_defer, (n + 1) * sizeof(uint32_t)));
     }
 
     SwArgs a;
@@ -1024,6 +1052,7 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     a.known = trace ? d_known : nullptr;
     a.end_lane = trace ? d_end_lane : nullptr;
     a.mode = trace ? ctx->d_trace_mode.as<int32_t>() : nullptr;
+    a.defer = trace ? ctx->d_trace_defer.as<uint32_t>() : nullptr;
     a.counts = cells;
     // (windows of the longest possible pair against the staging area: score pass 4 windows of 8 * blocks + 80 entries, traceback pass 8 of 8 * blocks + 48)
     a.split_long = split_long ? 1 : 0;
@@ -1032,6 +1061,13 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
     for (int x = 0; x < 32 * 32; ++x) a.max_sub = std::max(a.max_sub, (int)P.sub[x]);
     a.lds_res_bytes = lds_res_bytes;
     const size_t smem = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * a.lds_res_bytes;
+    // The score launch of the LONG candidates (the packed sweep in chunks of blocks: nucleotide alignments, long proteins) takes a SMALL staging area: a
+    // chunk is restaged every few hundred steps whatever its size, and 3 KiB per wavefront put four blocks - eight wavefronts per SIMD, which its
+    // 36 VGPRs allow - on a CU where the 6.5 KiB of the short pairs' launch put two: 1.09 -> 1.01 ms on the nucleotide tool's 10 000-gene search.  (The same
+    // for the traceback launch made it slower, 1.98 -> 2.37 ms: what held that kernel back was not occupancy - see the deferred full-band pairs there.)
+    SwArgs al = a;
+    al.lds_res_bytes = std::min(lds_res_bytes, 3072);
+    const size_t smem_long = LDS_TABLE_BYTES + (size_t)WAVES_PER_BLOCK * al.lds_res_bytes;
     pep_timer_begin(ctx, trace ? TM_SW_TRACE : TM_SW);
     if (trace) {
         // resident blocks only: every wavefront pulls its next item from a counter, first the candidates that are too long for the
@@ -1045,13 +1081,15 @@ int pep_sw_run(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, bool trace, co
         // of their own (the packed sweep in chunks), in front - they are the longest work
         if (a.split_long) hipLaunchKernelGGL(sw_trace_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
         hipLaunchKernelGGL(sw_trace_kernel<false>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+        // (the pairs that left their sub-band, in the full band: blocks beyond the list's length leave at once)
+        hipLaunchKernelGGL(sw_trace_retry_kernel, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     } else {
         // one item (a packed candidate pair, or one candidate) per wavefront: the hardware's block dispatcher balances the load better than a
         // grid-stride loop inside fewer blocks (score pass 0.82 -> 0.80 ms on the benchmark), and the 16 KiB table load per block comes out
         // of the L2
         const uint64_t items = ceil_div(a.pk16 ? (n + 1) / 2 : n, WAVES_PER_BLOCK);
         const unsigned grid = (unsigned)std::min<uint64_t>(items, 256ull * 256);
-        if (a.split_long) hipLaunchKernelGGL(sw_score_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
+        if (a.split_long) hipLaunchKernelGGL(sw_score_kernel<true>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem_long, ctx->stream, al);
         hipLaunchKernelGGL(sw_score_kernel<false>, dim3(grid), dim3(64 * WAVES_PER_BLOCK), smem, ctx->stream, a);
     }
     pep_timer_end(ctx, trace ? TM_SW_TRACE : TM_SW);
