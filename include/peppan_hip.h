@@ -455,6 +455,12 @@ int pep_cols_gather(int32_t n_cols, const void *const *src, void *const *dst, co
  * reads it.  Returns the stream's length; when it exceeds `cap` nothing usable was written (n + n / 64 + 512 always suffices).  Negative: PEP_ERR_ARG. */
 int64_t pep_deflate_literals(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap);
 
+/* A raw DEFLATE stream of `src` with matches found by ONE probe of a 4-byte hash per position (greedy; the matcher of the fastest levels of the
+ * modern deflate libraries) in dynamic-Huffman blocks of 64 KiB of input - for the members of <prefix>.mat.npz (PEPPAN.py:959-966; the reference deflates
+ * them at zlib's default level inside zipfile): about the size of zlib's level 1 at several times its rate.  Host C++, no context, any inflate reads
+ * it.  Returns the stream's length; when it exceeds `cap` nothing usable was written (n + n / 8 + 1024 always suffices).  Negative: PEP_ERR_ARG. */
+int64_t pep_deflate_fast(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,7 +14,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals',
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast',
            'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather']
 
 
@@ -322,6 +322,19 @@ def deflate_literals(data):
     n = lib.pep_deflate_literals(_ptr(src) if len(src) else None, C.c_int64(len(src)), _ptr(out), C.c_int64(cap))
     if n < 0 or n > cap:
         raise PepError('pep_deflate_literals failed (%d)' % n)
+    return out[:n].tobytes()
+
+
+def deflate_fast(data):
+    """pep_deflate_fast: bytes -> raw DEFLATE stream (zlib.decompress(x, -15) gives them back): single-probe matcher + dynamic Huffman blocks"""
+    lib = load_library()
+    lib.pep_deflate_fast.restype = C.c_int64
+    src = np.frombuffer(data, dtype=np.uint8)
+    cap = len(src) + len(src) // 8 + 1024
+    out = np.empty(cap, dtype=np.uint8)
+    n = lib.pep_deflate_fast(_ptr(src) if len(src) else None, C.c_int64(len(src)), _ptr(out), C.c_int64(cap))
+    if n < 0 or n > cap:
+        raise PepError('pep_deflate_fast failed (%d)' % n)
     return out[:n].tobytes()
 
 

@@ -406,6 +406,142 @@ extern "C" int64_t pep_deflate_literals(const uint8_t *src, int64_t n, uint8_t *
     return s.n;
 }
 
+// A raw DEFLATE stream with matches: one probe of a 4-byte hash per position (greedy, no chains, no lazy evaluation - the matcher of the "fastest"
+// levels of the modern deflate libraries), then dynamic-Huffman blocks over literals, lengths and distances.  For the members of the .mat store - the
+// .npy pickle stream of a thousand groups of hit rows: repeated opcodes, shared prefixes of numbers - zlib's level 1 gets 0.56 of the size at 39 MB/s on
+// a core of this container; this gets about the same size at several times the rate (the share of a mapped genome's CPU time that went into deflating
+// its hit rows was the largest single item left).  Any inflate reads the result.
+namespace {
+
+struct LenDistTables {
+    uint16_t len_sym[259];          // match length 3..258 -> literal/length symbol 257..285
+    uint8_t len_extra[29], dist_extra[30];
+    uint16_t len_base[29], dist_base[30];
+    LenDistTables()
+    {
+        static const uint16_t lb[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+        static const uint8_t le[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        static const uint16_t db[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+        static const uint8_t de[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+        for (int i = 0; i < 29; ++i) { len_base[i] = lb[i]; len_extra[i] = le[i]; }
+        for (int i = 0; i < 30; ++i) { dist_base[i] = db[i]; dist_extra[i] = de[i]; }
+        for (int l = 3; l <= 258; ++l) {
+            int k = 28;
+            while (lb[k] > l) --k;
+            if (l == 258) k = 28;
+            len_sym[l] = (uint16_t)(257 + k);
+        }
+    }
+    int dist_sym(uint32_t d) const           // distance 1..32768 -> symbol 0..29
+    {
+        if (d <= 4) return (int)d - 1;
+        const int b = 31 - __builtin_clz(d - 1);          // d - 1 in [2^b, 2^(b+1))
+        return 2 * b + (int)(((d - 1) >> (b - 1)) & 1u);
+    }
+};
+const LenDistTables g_ld;
+
+}   // namespace
+
+extern "C" int64_t pep_deflate_fast(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap)
+{
+    if (n < 0 || (n > 0 && !src) || (cap > 0 && !out)) return PEP_ERR_ARG;
+    BitSink s{out, cap, 0, 0, 0};
+    if (n == 0) { s.put(1, 1); s.put(1, 2); s.put(0, 7); s.finish(); return s.n; }
+    const int HASH_BITS = 15;
+    std::vector<int32_t> head((size_t)1 << HASH_BITS, -1);
+    const int64_t CHUNK = 64 << 10;
+    std::vector<uint32_t> tok((size_t)CHUNK + 8);                  // literal: the byte; match: 1 << 31 | length << 16 | distance - 1
+    auto load32 = [&](int64_t p) { uint32_t v; memcpy(&v, src + p, 4); return v; };
+    auto put_len4 = [&](int v) { uint32_t r = 0; for (int b = 0; b < 4; ++b) r = (r << 1) | ((v >> b) & 1); s.put(r, 4); };
+    int64_t pos = 0;
+    while (pos < n) {
+        const int64_t end = std::min(n, pos + CHUNK);
+        size_t nt = 0;
+        uint32_t f_lit[286] = {0}, f_dist[30] = {0};
+        uint32_t misses = 0;                                                 // positions in a row without a match: data that does not repeat is probed at every second, fourth ... position
+        while (pos < end) {
+            if (pos + 4 <= n && (misses < 32 || (pos & ((1u << std::min(6u, misses >> 5)) - 1u)) == 0)) {
+                const uint32_t v = load32(pos);
+                const uint32_t h = (v * 2654435761u) >> (32 - HASH_BITS);
+                const int32_t cand = head[h];
+                head[h] = (int32_t)(pos & 0x7FFFFFFF);
+                if (cand >= 0 && pos - cand <= 32768 && pos < 0x7FFFFFFF && load32(cand) == v) {
+                    int64_t len = 4;
+                    const int64_t lim = std::min<int64_t>(258, n - pos);
+                    while (len + 8 <= lim) {
+                        uint64_t a, b;
+                        memcpy(&a, src + pos + len, 8); memcpy(&b, src + cand + len, 8);
+                        if (a != b) { len += __builtin_ctzll(a ^ b) >> 3; goto matched; }
+                        len += 8;
+                    }
+                    while (len < lim && src[pos + len] == src[cand + len]) ++len;
+                matched:
+                    if (len > lim) len = lim;
+                    const uint32_t d = (uint32_t)(pos - cand);
+                    tok[nt++] = 0x80000000u | ((uint32_t)len << 16) | (d - 1u);
+                    ++f_lit[g_ld.len_sym[len]];
+                    ++f_dist[g_ld.dist_sym(d)];
+                    // (one more table entry inside the match keeps long repeats findable; every position would cost more than it finds)
+                    if (len >= 8 && pos + len + 4 <= n) { const uint32_t w = load32(pos + len - 4); head[(w * 2654435761u) >> (32 - HASH_BITS)] = (int32_t)(pos + len - 4); }
+                    pos += len;
+                    misses = 0;
+                    continue;
+                }
+            }
+            ++misses;
+            tok[nt++] = src[pos];
+            ++f_lit[src[pos]];
+            ++pos;
+        }
+        f_lit[256] = 1;
+        int n_dist_used = 0;
+        for (int i = 0; i < 30; ++i) n_dist_used += f_dist[i] ? 1 : 0;
+        if (n_dist_used < 2) { f_dist[0] += 1; f_dist[1] += 1; }            // (a complete distance code needs two symbols)
+        int n_lit_used = 0;
+        for (int i = 0; i < 286; ++i) n_lit_used += f_lit[i] ? 1 : 0;
+        if (n_lit_used < 2) f_lit[f_lit[0] ? 1 : 0] += 1;
+        uint8_t l_len[286], d_len[30];
+        uint16_t l_code[286], d_code[30];
+        huffman_lengths(f_lit, 286, l_len);
+        huffman_lengths(f_dist, 30, d_len);
+        canonical_codes(l_len, 286, l_code);
+        canonical_codes(d_len, 30, d_code);
+        static const uint8_t cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        s.put(pos >= n ? 1u : 0u, 1);                                        // BFINAL
+        s.put(2, 2);                                                         // BTYPE = dynamic Huffman
+        s.put(286 - 257, 5); s.put(30 - 1, 5); s.put(15, 4);                 // all 286 literal/length codes, all 30 distance codes, all 19 code-length codes listed
+        for (int k = 0; k < 19; ++k) s.put(cl_order[k] >= 16 ? 0u : 4u, 3);  // lengths 0..15 as the complete 4-bit code, no repeat codes (158 bytes per 64 KiB block)
+        for (int i = 0; i < 286; ++i) put_len4(l_len[i]);
+        for (int i = 0; i < 30; ++i) put_len4(d_len[i]);
+        uint32_t lit_pk[256];                                                // code | length << 16 per literal
+        for (int i = 0; i < 256; ++i) lit_pk[i] = (uint32_t)l_code[i] | ((uint32_t)l_len[i] << 16);
+        tok[nt] = 0x80000000u;                                               // (a sentinel behind the last token: the pairing below looks one ahead)
+        for (size_t k = 0; k < nt;) {
+            const uint32_t t = tok[k];
+            if (!(t & 0x80000000u)) {
+                const uint32_t a = lit_pk[t], u = tok[k + 1];
+                if (!(u & 0x80000000u)) {                                    // two literals (<= 30 bits) per trip through the sink
+                    const uint32_t b = lit_pk[u];
+                    const int la = (int)(a >> 16);
+                    s.put((a & 0xFFFFu) | ((b & 0xFFFFu) << la), la + (int)(b >> 16));
+                    k += 2;
+                } else { s.put(a & 0xFFFFu, (int)(a >> 16)); ++k; }
+                continue;
+            }
+            const uint32_t len = (t >> 16) & 0x1FFu, d = (t & 0xFFFFu) + 1u;
+            const int ls = g_ld.len_sym[len], li = ls - 257, ds = g_ld.dist_sym(d);
+            // length symbol + its extra bits (<= 20 bits), then distance symbol + its extra bits (<= 28 bits)
+            s.put((uint32_t)l_code[ls] | ((len - g_ld.len_base[li]) << l_len[ls]), l_len[ls] + g_ld.len_extra[li]);
+            s.put((uint32_t)d_code[ds] | ((d - g_ld.dist_base[ds]) << d_len[ds]), d_len[ds] + g_ld.dist_extra[ds]);
+            ++k;
+        }
+        s.put(l_code[256], l_len[256]);
+    }
+    s.finish();
+    return s.n;
+}
+
 extern "C" int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,
                                          int32_t threads, uint8_t *out, int64_t cap, uint32_t *crc, int64_t *csize, int64_t *usize, int64_t *at)
 {

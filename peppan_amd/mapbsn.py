@@ -50,6 +50,9 @@ def _packers():
     return _PACKERS
 
 
+FAST_DEFLATE = -1          # a "strategy" of _pack_member beside zlib's: the library's own coder with matches (csrc/stores.hip: pep_deflate_fast)
+
+
 def _pack_member(data, strategy=zlib.Z_DEFAULT_STRATEGY):
     """data (bytes, or a callable returning them) -> (payload, crc, size, method).  Members are read back whole either way; deflating
     a few hundred bytes costs more than it saves (zlib set-up per member).  strategy: zlib's (SEQ_STRATEGY for the .seq store)."""
@@ -60,6 +63,9 @@ def _pack_member(data, strategy=zlib.Z_DEFAULT_STRATEGY):
     if strategy == zlib.Z_HUFFMAN_ONLY:          # the library's own literal-only coder: the sizes of zlib's Z_HUFFMAN_ONLY at 590 instead of 130 MB/s
         from ._native import deflate_literals
         return deflate_literals(data), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
+    if strategy == FAST_DEFLATE:                 # the library's single-probe matcher (pep_deflate_fast): the sizes of zlib's level 1 at three times its rate
+        from ._native import deflate_fast
+        return deflate_fast(data), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
     co = zlib.compressobj(1, zlib.DEFLATED, -15, 8, strategy)
     return co.compress(data) + co.flush(), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
 
@@ -739,6 +745,7 @@ def iter_map_bsn(data):
 
 
 # ------------------------------------------------------------------------------------------------ all genomes
+MAT_STRATEGY = FAST_DEFLATE            # how the members of the .mat store are deflated: hit rows as a pickle stream - repeated opcodes, similar numbers; zlib's level 1 took 13 ms of CPU per mapped genome
 SEQ_STRATEGY = zlib.Z_HUFFMAN_ONLY      # how the members of the .seq store are deflated.  Packed alleles are all but incompressible by matching (a byte
 #                       holds three bases of three different thirds of an allele): entropy coding alone (pep_deflate_literals, 590 MB/s; zlib's Z_HUFFMAN_ONLY: 130) makes 0.75 of a gene set's alleles where
 #                       level 1's match search makes 0.77 at 30 MB/s, and those 50 ms of CPU per genome were two thirds of what a mapped genome costs on the
@@ -986,7 +993,7 @@ def round_members(blocks, taxa, first, save_seq):
         val.append(B.c_val + 10 * lo_id)
     z = np.zeros(0, dtype=np.int64)
     return dict(n=end - first, first=first, table=np.vstack(rows) if rows else np.zeros([0, 7], dtype=np.int64), c_src=np.concatenate(src) if src else z, c_val=np.concatenate(val) if val else z,
-                mat=store([B.mat for B in blocks], _slice_mat, _emit_mat, zlib.Z_DEFAULT_STRATEGY),
+                mat=store([B.mat for B in blocks], _slice_mat, _emit_mat, MAT_STRATEGY),
                 seq=store([(B.packed, B.pack_off) for B in blocks], _slice_seq, _emit_seq, SEQ_STRATEGY) if save_seq else None)
 
 
@@ -1048,7 +1055,7 @@ class _StoreWriter(object):
         self.n_group, self.table, self.table_rows, self.t_table = 0, [], 0, 0.
         self.conflicts = _ConflictBlocks(clf_conn)
         self.seqs = _MemberQueue(seq_conn, _emit_seq, SEQ_STRATEGY) if save_seq else None
-        self.mats = _MemberQueue(mat_conn, _emit_mat)
+        self.mats = _MemberQueue(mat_conn, _emit_mat, MAT_STRATEGY)
 
     def add(self, G, taxon):
         """the next genome's groups: a StoreBlock, or the GenomeGroups one is made from"""

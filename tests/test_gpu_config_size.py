@@ -36,16 +36,24 @@ def test_map_bsn_10k_exemplars_x_genomes(tmp_path, monkeypatch, n_genomes):
     _map_bsn_at_size(tmp_path, monkeypatch, 10000, 0, n_genomes, None, (3, 40), 1500)
 
 
-def test_map_bsn_50k_exemplars_x_32_genomes(tmp_path, monkeypatch):
-    """BASELINE configs[4] mapping stage at the size one GPU holds: 50 000 exemplar genes (log-normal lengths, 45 Mnt) against 32 genomes of a
+def test_map_bsn_10k_exemplars_x_2000_genomes_through_the_worker_pool(tmp_path, monkeypatch):
+    """BASELINE configs[4]'s genome count: 2 000 genomes (4.3 Gnt) against 10 000 exemplars through get_map_bsn with the reference's pool of
+    workers (PEPPAN.py:907-923) as eight processes that share the GPU; every planted allele found, stores consistent, sampled genomes searched
+    once more in this process and held to the oracle-driven host code row for row"""
+    _map_bsn_at_size(tmp_path, monkeypatch, 10000, 0, 2000, None, (7, 1234), 1500, workers=8)
+
+
+@pytest.mark.parametrize('n_genomes', [32, 128])
+def test_map_bsn_50k_exemplars_x_genomes(tmp_path, monkeypatch, n_genomes):
+    """BASELINE configs[4] mapping stage at the size one GPU holds: 50 000 exemplar genes (log-normal lengths, 45 Mnt) against 32 and 128 genomes of a
     50 000-gene pan-genome (about 6 500 genes / 7 Mb per genome: synth.PAN_GENOME_PRESENCE) through get_map_bsn (PEPPAN.py:759-772, 907-989);
     every planted allele found, stores consistent, one sampled genome equal to the oracle-driven host code row for row"""
     from peppan_amd import synth
     # (identity floor 0.90 here: with 210 000 planted alleles a 147-base gene now and then collects eight substitutions at the nominal 2 %)
-    _map_bsn_at_size(tmp_path, monkeypatch, 50000, 0, 32, synth.PAN_GENOME_PRESENCE, (5,), 5000, min_iden4=9000)
+    _map_bsn_at_size(tmp_path, monkeypatch, 50000, 0, n_genomes, synth.PAN_GENOME_PRESENCE, (5,), 5000, min_iden4=9000)
 
 
-def _map_bsn_at_size(tmp_path, monkeypatch, n_genes, gene_len, n_genomes, presence, sample, planted_per_genome, min_iden4=9500):
+def _map_bsn_at_size(tmp_path, monkeypatch, n_genes, gene_len, n_genomes, presence, sample, planted_per_genome, min_iden4=9500, workers=None):
     from peppan_amd import mapbsn, synth, uberBlast as UB
     from oracle_context import OracleContext
     monkeypatch.chdir(tmp_path)
@@ -73,8 +81,17 @@ def _map_bsn_at_size(tmp_path, monkeypatch, n_genes, gene_len, n_genomes, presen
     t0 = time.perf_counter()
     with contextlib.redirect_stderr(io.StringIO()):
         with mapbsn.MapBsn(fn[0], 'w') as c0, mapbsn.MapBsn(fn[1], 'w') as c1, mapbsn.MapBsn(fn[2], 'w') as c2, mapbsn.MapBsn(fn[3], 'w') as c3:
-            mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params, search=search)
+            if workers:
+                # (the pool's processes run the product's batched search themselves; the sample is searched once more here, below)
+                mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params, workers=workers)
+            else:
+                mapbsn.get_map_bsn('m', 'm.clust.exemplar', genomes, 'm.self_bsn.npy', 'm.old_prediction.npz', c0, c1, c2, c3, True, params, search=search)
     dt = time.perf_counter() - t0
+    if workers:
+        some = [(g, 900000 + g, [[100000 + g, genomes[100000 + g][1]]]) for g in sample]
+        with contextlib.redirect_stderr(io.StringIO()):
+            for job, res in zip(some, mapbsn._gpu_search('m', 'm.clust.exemplar', some, params, genomes_per_batch=len(some))):
+                seen[job[0]] = (res[0].to_rows(cigar='str'), res[1].copy())
     print('get_map_bsn: %d genomes in %.1f s = %.1f genomes/s' % (n_genomes, dt, n_genomes / dt))      # (a figure, not a condition: a slow host must not turn a parity suite red)
     with mapbsn.MapBsn(fn[0]) as c:
         tab = np.vstack([c.get(k) for k in c.keys()])
@@ -103,16 +120,23 @@ def _map_bsn_at_size(tmp_path, monkeypatch, n_genes, gene_len, n_genomes, presen
         assert o_tab.shape[0] > 3 * planted_per_genome
 
 
-@pytest.mark.parametrize('n_base,copies', [(4000, 250), (10000, 500), (50000, 400)])
+@pytest.mark.parametrize('n_base,copies', [(4000, 250), (10000, 500), (50000, 400), (50000, 1000)])
 def test_front_end_gene_instances_at_size(ctx, tmp_path, monkeypatch, n_base, copies):
     """writeGenes (K13 sha1 + duplicate collapse) and the 11-level iterClust (K9) on 1 M instances of 4 000 genes, at BASELINE
-    configs[2]'s full size - 5 M instances of 10 000 genes (10 000 genes x 500 genomes, 4.45 Gnt) - and on 20 M instances of 50 000 genes
-    (18 Gnt: a fifth of configs[4]'s 100 M, what one host of this pool holds comfortably; PEPPAN.py:1023-1039, 1777-1792)"""
+    configs[2]'s full size - 5 M instances of 10 000 genes (10 000 genes x 500 genomes, 4.45 Gnt) -, on 20 M and on 50 M instances of 50 000 genes
+    (18 / 45 Gnt: half of configs[4]'s 100 M instances in the suite; all 100 M: tools/front_end_scale.py, profiles/r05_front_end_scale.txt;
+    PEPPAN.py:1023-1039, 1777-1792)"""
     from peppan_amd import pipeline as PL
     if n_base * copies > 5000000:
         import psutil
-        if psutil.virtual_memory().available < 100e9:
-            pytest.skip('20 M gene instances need about 40 GB of host memory; %.0f GB available' % (psutil.virtual_memory().available / 1e9))
+        limit = psutil.virtual_memory().available
+        try:
+            limit = min(limit, int(open('/sys/fs/cgroup/memory.max').read()))       # (what the container grants, when that is less than the machine's)
+        except (OSError, ValueError):
+            pass
+        need = 5e9 * n_base * copies / 1e6 / 2.                                     # (measured: 21 GB peak at 20 M instances; twice that asked for)
+        if limit < need:
+            pytest.skip('%d M gene instances need about %.0f GB of host memory; %.0f GB available' % (n_base * copies // 1000000, need / 1e9, limit / 1e9))
     monkeypatch.chdir(tmp_path)
     t0 = time.perf_counter()
     from peppan_amd import synth
@@ -303,3 +327,32 @@ def test_example_genomes_full_pipeline_vs_oracle(ctx, tmp_path, monkeypatch):
           % (took['gpu'] + took['ora'] + (len(results['gpu'][2]), len(results['gpu'][3]))))
     assert results['gpu'] == results['ora']
     assert len(results['gpu'][2]) > 500 and len(results['gpu'][3]) > 200
+
+
+def test_linclust_1m_sequences_bit_exact_vs_oracle(ctx):
+    """K9 at the size the front end meets it: 1 M gene instances (4 000 genes x 250 alleles, 0.9 Gnt) through pep_linclust and through
+    oracle_linclust (OpenMP over the sequences since round 5) - the same representative for every sequence and the same counts of selected
+    k-mers, verified pairs and accepted edges.  (The at-size front-end tests above hold the 11-level schedule to properties; this holds one
+    level to the oracle.)"""
+    from peppan_amd import synth
+    from oracle import oracle as O
+    seqs = synth.make_instances(4000, 250, seed=8)
+    lut = np.full(256, 4, dtype=np.uint8)
+    for ch, v in zip('ACGT', (0, 1, 2, 3)):
+        lut[ord(ch)] = v
+    off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs)))
+    codes = lut[np.frombuffer(''.join(seqs).encode('ascii'), dtype=np.uint8)]
+    t0 = time.perf_counter()
+    rep, st = ctx.linclust((codes, off), 0.97, 0.8)
+    t1 = time.perf_counter()
+    import ctypes as C
+    o_rep = np.zeros(len(seqs), dtype=np.uint32)
+    o_stats = (C.c_uint64 * 3)()
+    O.lib().oracle_linclust(codes.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.c_uint32(len(seqs)), C.c_int(4), C.c_int(17), C.c_int(20),
+                            C.c_double(0.97), C.c_double(0.8), o_rep.ctypes.data_as(C.c_void_p), o_stats)
+    t2 = time.perf_counter()
+    print('linclust of %d sequences: GPU %.2f s, oracle %.1f s; %d clusters' % (len(seqs), t1 - t0, t2 - t1, len(np.unique(rep))))
+    assert (st['selected'], st['verified'], st['accepted']) == (int(o_stats[0]), int(o_stats[1]), int(o_stats[2]))
+    assert np.array_equal(rep, o_rep)
+    assert 3000 <= len(np.unique(rep)) <= 4000                 # (alleles under their gene; of a family's four genes the closest two are 5 % apart: not merged at 0.97)

@@ -112,6 +112,36 @@ def test_literal_only_deflate_is_read_by_zlib():
     assert method == 8 and size == len(cases[5]) and crc == zlib.crc32(cases[5]) and zlib.decompress(packed, -15) == cases[5]
 
 
+def test_fast_deflate_is_read_by_zlib():
+    """pep_deflate_fast (the .mat members' coder): raw DEFLATE streams with matches of a single-probe matcher in dynamic-Huffman blocks - zlib
+    inflates every one of them to the input: empty and tiny inputs, runs that chain maximal matches, distances up to the window, data that does
+    not repeat, inputs across several 64 KiB blocks, a few hundred random cases; a real member comes out near zlib's level-1 size"""
+    import os
+    import zlib
+    from peppan_amd import _native as N
+    rng = np.random.default_rng(12)
+    far = os.urandom(600)
+    cases = [b'', b'a', b'abc', b'abcd' * 2, b'a' * 100000, (b'x' * 258 + b'y') * 700, os.urandom(150000), bytes(rng.integers(0, 4, size=200001).astype(np.uint8)),
+             far + bytes(32768 - 600) + far + bytes(5) + far,                                         # a match at distance 32 768, one just beyond it
+             os.urandom(40000) * 4, bytes(range(256)) * 1200]
+    G = _random_groups(rng, 0, 1000, 10000)
+    member = mapbsn._emit_mat([(mapbsn.StoreBlock(G).mat, 0, 1000)])
+    cases.append(member)
+    for d in cases:
+        assert zlib.decompress(N.deflate_fast(d), -15) == d, len(d)
+    for k in range(300):
+        n = int(rng.integers(0, 70000 if k % 60 == 0 else 4000))
+        d = bytes(rng.integers(0, int(rng.integers(1, 256)), size=n).astype(np.uint8))
+        if k % 3 == 0 and n > 10:
+            d = d[:n // 3] * int(rng.integers(1, 8)) + d
+        assert zlib.decompress(N.deflate_fast(d), -15) == d
+    co = zlib.compressobj(1, zlib.DEFLATED, -15, 8)
+    ref = co.compress(member) + co.flush()
+    assert len(N.deflate_fast(member)) <= 1.08 * len(ref)
+    packed, crc, size, method = mapbsn._pack_member(member, mapbsn.FAST_DEFLATE)
+    assert method == 8 and size == len(member) and crc == zlib.crc32(member) and zlib.decompress(packed, -15) == member
+
+
 def test_decode_encode():
     g = load_golden('g14_mapbsn.json')
     seqs = np.array(g['decodeSeq_in'], dtype=np.uint8)
