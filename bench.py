@@ -490,27 +490,37 @@ def north_star_workloads(local_rank, names, order, seqs, nts, min_id, min_qcov, 
         rb._as_tables = True
         clock = time.perf_counter
 
-        def call(parts=None):
+        def call(parts=None, one_by_one=False):
             rb.min_id, rb.min_cov, rb.min_ratio, rb.table_id, rb.n_thread = min_id / 100., 50., min_qcov / 100., 11, 1
             t0 = clock()
-            tn = rb._runBlast_table(fa, fa)
-            t1 = clock()
-            td = rb._runDiamond_table(fa, fa)
+            if one_by_one:
+                tn = rb._runBlast_table(fa, fa)
+                t1 = clock()
+                tables = [tn, rb._runDiamond_table(fa, fa)]
+            else:
+                tables = rb._run_tools(['blastn', 'diamond'], fa, fa)          # (the way run() calls them: side by side, a HIP context each)
+                t1 = t0
             t2 = clock()
-            T = rb._post([tn, td], fa, fa, 1, [False, 0.9, 0.], [False, 300., 1.2], [False, 300, 0.6], [3., 3.])
+            T = rb._post(tables, fa, fa, 1, [False, 0.9, 0.], [False, 300., 1.2], [False, 300, 0.6], [3., 3.])
             t3 = clock()
             if parts is not None:
-                for k, v in (('nucleotide_search_ms', t1 - t0), ('translated_search_ms', t2 - t1), ('join_k7_fixend_order_ms', t3 - t2)):
+                for k, v in ((('nucleotide_search_ms', t1 - t0), ('translated_search_ms', t2 - t1)) if one_by_one else (('both_tools_side_by_side_ms', t2 - t0),)) + (('join_k7_fixend_order_ms', t3 - t2),):
                     parts[k] = parts.get(k, 0.) + v * 1e3
             return T
         with contextlib.redirect_stderr(io.StringIO()):
             call(); call()
-            reps, parts = 10, {}
+            reps, parts, seq_parts = 10, {}, {}
             t0 = clock()
             for _ in range(reps):
                 T = call(parts)
             dt = clock() - t0
+            call(one_by_one=True)
+            t0 = clock()
+            for _ in range(reps):
+                call(seq_parts, one_by_one=True)
+            dt_seq = clock() - t0
         out['north_star_call'] = {'north_star_call_ms': dt / reps * 1e3, 'rows': int(len(T)), 'parts_ms': {k: v / reps for k, v in parts.items()}, 'reps': reps,
+                                  'tools_one_after_the_other': {'ms': dt_seq / reps * 1e3, 'parts_ms': {k: v / reps for k, v in seq_parts.items()}},
                                   'what': 'RunBlast: nucleotide tool + translated tool on the %d genes against themselves (FASTA read once and cached; sets resident on the GPU), tables joined, '
                                           'K7 rescoring (-s 1), fixEnd 3,3, final order - the numeric HitTable, no object rows' % len(nts)}
     return out

@@ -105,6 +105,24 @@ def get_context(device=None):
     return _CTX[key]
 
 
+_plain_get_context = get_context
+
+
+def get_nucl_context(device=None):
+    """The context the nucleotide tool works in when a run asks for both tools (PEPPAN's calls do: --blastn --diamond, uberBlast.py:597-599): a second
+    HIP context - stream, work space, packed sets of its own - on the same device, so that the two searches of one run go side by side (one tool's
+    memory-bound seed stage under the other's Smith-Waterman passes, one tool's table being built while the other searches) and neither packs its
+    sets over the other's.  The SAME context as get_context when that function has been replaced (tests) or PEPPAN_ONE_CONTEXT=1."""
+    if get_context is not _plain_get_context or os.environ.get('PEPPAN_ONE_CONTEXT') == '1':
+        return get_context(device)
+    if device is None:
+        device = int(os.environ.get('PEPPAN_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+    key = (os.getpid(), device, 'nucl')
+    if key not in _CTX:
+        _CTX[key] = N.Context(device)
+    return _CTX[key]
+
+
 # ------------------------------------------------------------------------------------------------------------
 # GPU hits -> the reference's table rows (coordinate algebra of parseDiamond, uberBlast.py:25-58)
 # ------------------------------------------------------------------------------------------------------------
@@ -310,23 +328,53 @@ class RunBlast(object):
         (an input beyond a documented limit) is raised instead of costing a whole table."""
         tools = self._tool_table()
         tables, self.failed_tools = [], []
-        for method in methods:
-            if method.lower() not in tools:
-                continue
+        todo = [m for m in methods if m.lower() in tools]
+
+        def attempt(method):
+            """one tool -> ('ok', table) | ('limit', exception) | ('failed', method, message)"""
             try:
-                tables.append(_as_table(tools[method.lower()](ref, qry)))
+                return ('ok', _as_table(tools[method.lower()](ref, qry)))
             except N.PepError as e:
                 if 'PEP_ERR_LIMIT' in str(e) or '(-3)' in str(e):
-                    raise                     # an input beyond a documented limit must not silently cost a whole tool's hits
+                    return ('limit', e)           # an input beyond a documented limit must not silently cost a whole tool's hits
                 import traceback
                 traceback.print_exc()
-                self.failed_tools.append((method, str(e)))
-                break                         # (the reference's try block ends with the first failure, uberBlast.py:343-349)
+                return ('failed', method, str(e))
             except Exception as e:
                 import traceback
                 traceback.print_exc()
-                self.failed_tools.append((method, repr(e)))
+                return ('failed', method, repr(e))
+        # Both tools in one run, each in a context of its own (get_nucl_context): the nucleotide tool goes to a second thread, the translated tool(s) stay
+        # on this one; the outcomes are taken in the order the reference runs them.  Built-in tools only - a caller's override is called one after the other.
+        names = [m.lower() for m in todo]
+        plain = all(getattr(getattr(self, p), '__func__', getattr(self, p)) is _BUILTIN_TOOLS[p] for p in ('runBlast', 'runDiamond', 'runDiamondSELF'))
+        outcomes, side = {}, None
+        if self._batch is None and plain and 'blastn' in names and len(set(names)) > 1 and get_nucl_context(self.device) is not get_context(self.device):
+            import threading
+            self._load(ref, qry)
+            self._ensure_nt(get_context(self.device), 3 if set(names) <= {'blastn', 'diamondself'} else 6)       # (shared preparations first: the threads only read them)
+            self._ensure_nt(get_nucl_context(self.device))
+            k_side = names.index('blastn')
+            side = threading.Thread(target=lambda: outcomes.__setitem__(k_side, attempt(todo[k_side])))
+            side.start()
+        for k, method in enumerate(todo):
+            if side is None or k != k_side:
+                outcomes[k] = attempt(method)
+                if side is None and outcomes[k][0] != 'ok':
+                    break                         # (one after the other: nothing runs behind a failure)
+        if side is not None:
+            side.join()
+        for k in range(len(todo)):
+            o = outcomes.get(k)
+            if o is None:
                 break
+            if o[0] == 'ok':
+                tables.append(o[1])
+            elif o[0] == 'limit':
+                raise o[1]
+            else:
+                self.failed_tools.append((o[1], o[2]))
+                break                             # (the reference's try block ends with the first failure, uberBlast.py:343-349: what ran behind it does not count)
         if self.failed_tools:
             logger('WARNING: {0} of {1} search tools failed: {2}'.format(len(self.failed_tools), len(methods), ', '.join(m for m, _ in self.failed_tools)))
         return tables
@@ -445,7 +493,8 @@ class RunBlast(object):
         membership is reproduced.  The context is shared by every RunBlast of the process: what this instance uploaded is only
         still there while the context's upload generation is the one it left behind (frames None = any frame count will do)."""
         gen = getattr(ctx, 'upload_generation', 0)
-        if self._nt_loaded is not None and self._nt_loaded[2] == gen and self._nt_loaded[1] == self.table_id and frames in (None, self._nt_loaded[0]):
+        done = (self._nt_loaded or {}).get(id(ctx))
+        if done is not None and done[2] == gen and done[1] == self.table_id and frames in (None, done[0]):
             return
         frames = frames or 6
         q = _prepare_side(self.qrySeq, getattr(self, '_q_key', None))
@@ -463,7 +512,9 @@ class RunBlast(object):
             ctx.set_ref_nt(r['packed'], frames, self.table_id)
             ctx.r_nt_token = r_token
         ctx.set_target_groups(None if self._batch is None else self._batch[1])
-        self._nt_loaded = (frames, self.table_id, getattr(ctx, 'upload_generation', 0))
+        if self._nt_loaded is None:
+            self._nt_loaded = {}
+        self._nt_loaded[id(ctx)] = (frames, self.table_id, getattr(ctx, 'upload_generation', 0))
 
     @staticmethod
     def _text(s):
@@ -506,7 +557,7 @@ class RunBlast(object):
         64-diagonal band of a (query, subject strand) that reaches the score threshold yields an alignment."""
         logger('Run BLASTn starts')
         self._load(ref, qry)
-        ctx = get_context(self.device)
+        ctx = get_nucl_context(self.device) if self._batch is None else get_context(self.device)        # (a batch of genomes: one context, tool after tool)
         params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100.)
         if max(map(len, self.refSeq.values()), default=0) <= N.MAX_SEQ_LEN:
             # the usual case: the nucleotide sets that K1 and K7 read on the device are packed THERE into the base-code residue sets of this

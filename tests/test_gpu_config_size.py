@@ -40,7 +40,8 @@ def test_map_bsn_10k_exemplars_x_2000_genomes_through_the_worker_pool(tmp_path, 
     """BASELINE configs[4]'s genome count: 2 000 genomes (4.3 Gnt) against 10 000 exemplars through get_map_bsn with the reference's pool of
     workers (PEPPAN.py:907-923) as eight processes that share the GPU; every planted allele found, stores consistent, sampled genomes searched
     once more in this process and held to the oracle-driven host code row for row"""
-    _map_bsn_at_size(tmp_path, monkeypatch, 10000, 0, 2000, None, (7, 1234), 1500, workers=8)
+    # (identity floor 0.90: among 4 M planted alleles a 120-base gene now and then collects seven substitutions at the nominal 2 %)
+    _map_bsn_at_size(tmp_path, monkeypatch, 10000, 0, 2000, None, (7, 1234), 1500, min_iden4=9000, workers=8)
 
 
 @pytest.mark.parametrize('n_genomes', [32, 128])
@@ -355,4 +356,4 @@ def test_linclust_1m_sequences_bit_exact_vs_oracle(ctx):
     print('linclust of %d sequences: GPU %.2f s, oracle %.1f s; %d clusters' % (len(seqs), t1 - t0, t2 - t1, len(np.unique(rep))))
     assert (st['selected'], st['verified'], st['accepted']) == (int(o_stats[0]), int(o_stats[1]), int(o_stats[2]))
     assert np.array_equal(rep, o_rep)
-    assert 3000 <= len(np.unique(rep)) <= 4000                 # (alleles under their gene; of a family's four genes the closest two are 5 % apart: not merged at 0.97)
+    assert 3000 <= len(np.unique(rep)) <= 6000                 # (alleles under their gene - a short gene with three substitutions stays apart at 0.97; of a family's four genes the closest two are 5 % apart: not merged)
