@@ -4,6 +4,8 @@ sys.path.insert(0, '.')
 import numpy as np
 from peppan_amd import synth, uberBlast as UB, _native as N
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+if len(sys.argv) > 3:
+    sys.setswitchinterval(float(sys.argv[3]))
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 names, seqs = synth.make_genes(n, 1002, seed=355)
 order = sorted(range(len(names)), key=lambda i: names[i])
@@ -37,7 +39,7 @@ with tempfile.TemporaryDirectory() as tmp:
         from peppan_amd.hittable import HitTable
         for nm in ('to_rows', 'take', 'fix_end', 'final_order'):
             timed(HitTable, nm, 'HitTable.' + nm)
-        timed(UB.RunBlast, '_rescore_table'); timed(UB.RunBlast, '_runBlast_table'); timed(UB.RunBlast, '_runDiamond_table'); timed(UB.RunBlast, '_post')
+        timed(UB.RunBlast, '_rescore_table'); timed(UB.RunBlast, '_runBlast_table'); timed(UB.RunBlast, '_runDiamond_table'); timed(UB.RunBlast, '_post'); timed(UB.RunBlast, '_run_tools'); timed(UB.RunBlast, '_ensure_nt'); timed(UB.RunBlast, '_load'); timed(UB.RunBlast, 'run')
         t = time.perf_counter()
         for _ in range(reps):
             tab = UB.uberBlast(argv)
