@@ -169,10 +169,10 @@ int pep_k12_alleles(pep_ctx *ctx, const uint8_t *h_nt, const uint64_t *h_nt_off,
     PEP_TRY(dev_reserve(ctx, W[8], ((size_t)n_groups + 1) * 4));
     PEP_TRY(dev_reserve(ctx, W[9], ((size_t)n_groups + 1) * 8));
     PEP_TRY(dev_reserve(ctx, W[10], pack_off[n_groups] + 1));
-    PEP_HIP(ctx, hipMemcpyAsync(W[0].p, h_nt, nt_total, hipMemcpyHostToDevice, st));
+    PEP_TRY(pep_h2d(ctx, W[0].p, h_nt, nt_total));
     PEP_HIP(ctx, hipMemcpyAsync(W[1].p, h_nt_off, ((size_t)n_contigs + 1) * 8, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(W[2].p, h_rows, n * sizeof(pep_locus), hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(W[3].p, h_cigar, n_cigar * 4, hipMemcpyHostToDevice, st));
+    PEP_TRY(pep_h2d(ctx, W[2].p, h_rows, n * sizeof(pep_locus)));
+    PEP_TRY(pep_h2d(ctx, W[3].p, h_cigar, n_cigar * 4));
     PEP_HIP(ctx, hipMemcpyAsync(W[4].p, row_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
     PEP_HIP(ctx, hipMemcpyAsync(W[7].p, h_grp_off, ((size_t)n_groups + 1) * 8, hipMemcpyHostToDevice, st));
     PEP_HIP(ctx, hipMemcpyAsync(W[8].p, h_grp_qlen, (size_t)n_groups * 4, hipMemcpyHostToDevice, st));
@@ -188,10 +188,11 @@ int pep_k12_alleles(pep_ctx *ctx, const uint8_t *h_nt, const uint64_t *h_nt_off,
                        W[9].as<const uint64_t>(), W[2].as<const pep_locus>(), W[4].as<const uint64_t>(), W[5].as<const uint8_t>(), W[10].as<uint8_t>());
     PEP_HIP(ctx, hipGetLastError());
     if (n) {
-        PEP_HIP(ctx, hipMemcpyAsync(h_in_frame, d_frame, n * 8, hipMemcpyDeviceToHost, st));
-        PEP_HIP(ctx, hipMemcpyAsync(h_orf, d_orf, n * 8, hipMemcpyDeviceToHost, st));
+        PEP_TRY(pep_d2h_queue(ctx, h_in_frame, d_frame, n * 8));
+        PEP_TRY(pep_d2h_queue(ctx, h_orf, d_orf, n * 8));
     }
-    PEP_HIP(ctx, hipMemcpyAsync(h_packed, W[10].p, pack_off[n_groups], hipMemcpyDeviceToHost, st));
+    PEP_TRY(pep_d2h_queue(ctx, h_packed, W[10].p, pack_off[n_groups]));
     PEP_HIP(ctx, pep_stream_wait(ctx));
+    pep_d2h_finish(ctx);
     return PEP_OK;
 }

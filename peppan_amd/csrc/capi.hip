@@ -9,6 +9,7 @@
 
 int pep_fail(pep_ctx *ctx, int code, const std::string &msg)
 {
+    if (ctx) { ctx->n_down = 0; ctx->pin_down_used = 0; }          // (downloads that were on their way belong to the call that failed)
     if (ctx) {
         ctx->err = msg;
         ctx->n_pending = 0;              // queued read-backs point at the failing caller's locals: drop them
@@ -57,6 +58,59 @@ int pin_reserve(pep_ctx *ctx, PinBuf &b, size_t bytes)
     PEP_HIP(ctx, hipHostMalloc(reinterpret_cast<void **>(&b.p), want, hipHostMallocDefault));
     b.cap = want;
     return PEP_OK;
+}
+
+int pep_h2d(pep_ctx *ctx, void *d_dst, const void *h_src, size_t n)
+{
+    if (n == 0) return PEP_OK;
+    if (n < ((size_t)64 << 10) || n > ((size_t)256 << 20)) {          // small: the runtime's own staging does as well; huge: not worth a staging area of that size
+        PEP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, n, hipMemcpyHostToDevice, ctx->stream));
+        return PEP_OK;
+    }
+    const size_t need = (n + 255) & ~(size_t)255;
+    if (ctx->pin_up_used + need > ctx->pin_up.cap) {
+        // the area is full or too small: whatever was queued out of it must have left before it is used again (or replaced by a larger one)
+        if (ctx->up_event_set) { PEP_HIP(ctx, pep_event_wait(ctx->up_event)); ctx->up_event_set = false; }
+        ctx->pin_up_used = 0;
+        if (need > ctx->pin_up.cap) PEP_TRY(pin_reserve(ctx, ctx->pin_up, std::max(need, (size_t)32 << 20)));
+    }
+    memcpy(ctx->pin_up.p + ctx->pin_up_used, h_src, n);
+    PEP_HIP(ctx, hipMemcpyAsync(d_dst, ctx->pin_up.p + ctx->pin_up_used, n, hipMemcpyHostToDevice, ctx->stream));
+    ctx->pin_up_used += need;
+    if (!ctx->up_event && hipEventCreateWithFlags(&ctx->up_event, pep_wait_event_flags()) != hipSuccess) return pep_fail(ctx, PEP_ERR_HIP, "hipEventCreate failed");
+    PEP_HIP(ctx, hipEventRecord(ctx->up_event, ctx->stream));
+    ctx->up_event_set = true;
+    return PEP_OK;
+}
+
+int pep_d2h_queue(pep_ctx *ctx, void *h_dst, const void *d_src, size_t n)
+{
+    if (n == 0) return PEP_OK;
+    const size_t need = (n + 255) & ~(size_t)255;
+    if (n < ((size_t)64 << 10) || n > ((size_t)256 << 20) || ctx->n_down >= 16) {
+        PEP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
+        return PEP_OK;
+    }
+    if (ctx->pin_down_used + need > ctx->pin_down.cap) {
+        if (ctx->n_down) {                                       // (downloads are waiting in the area: it cannot be replaced under them)
+            PEP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
+            return PEP_OK;
+        }
+        PEP_HIP(ctx, pep_stream_wait(ctx));
+        PEP_TRY(pin_reserve(ctx, ctx->pin_down, std::max(need, (size_t)16 << 20)));
+        ctx->pin_down_used = 0;
+    }
+    PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_down.p + ctx->pin_down_used, d_src, n, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->down[ctx->n_down++] = pep_ctx::PendingDown{h_dst, ctx->pin_down_used, n};
+    ctx->pin_down_used += need;
+    return PEP_OK;
+}
+
+void pep_d2h_finish(pep_ctx *ctx)
+{
+    for (int k = 0; k < ctx->n_down; ++k) memcpy(ctx->down[k].dst, ctx->pin_down.p + ctx->down[k].off, ctx->down[k].n);
+    ctx->n_down = 0;
+    ctx->pin_down_used = 0;
 }
 
 void pep_timer_begin(pep_ctx *ctx, int id)
@@ -307,8 +361,8 @@ int upload_nt(pep_ctx *ctx, NtSet &s, const uint8_t *nt, const uint64_t *off, ui
     s.total = s.h_off[n];
     PEP_TRY(dev_reserve(ctx, s.nt, s.total + 64));
     PEP_TRY(dev_reserve(ctx, s.off, (size_t)(n + 1) * 8));
-    if (s.total) PEP_HIP(ctx, hipMemcpy(s.nt.p, nt, s.total, hipMemcpyHostToDevice));
-    PEP_HIP(ctx, hipMemcpy(s.off.p, s.h_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice));
+    if (s.total) PEP_TRY(pep_h2d(ctx, s.nt.p, nt, s.total));                  // (stream-ordered: K1, K7 and the nucleotide tool's packing are queued behind it)
+    PEP_TRY(pep_h2d(ctx, s.off.p, s.h_off.data(), (size_t)(n + 1) * 8));
     return PEP_OK;
 }
 
@@ -482,6 +536,9 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->k1_t0) (void)hipEventDestroy(ctx->k1_t0);
     if (ctx->k1_t1) (void)hipEventDestroy(ctx->k1_t1);
     if (ctx->wait_event) (void)hipEventDestroy(ctx->wait_event);
+    if (ctx->up_event) (void)hipEventDestroy(ctx->up_event);
+    if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
+    if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
     if (ctx->pin_ms.p) (void)hipHostFree(ctx->pin_ms.p);
     DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->fused_state[0].buf, &ctx->fused_state[1].buf, &ctx->fused_state[2].buf, &ctx->fused_state[3].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_trace_defer, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq,

@@ -89,6 +89,14 @@ struct pep_ctx {
     hipEvent_t k1_t0 = nullptr, k1_t1 = nullptr;   // pep_translate's timing pair (created once)
     uint32_t k1_desc_cap = 0;               // descriptor slots of the reference side's last K1 (the summary sits behind them in pin_k1)
     bool t_tables_lazy = false, q_tables_lazy = false;   // a side's host tables (meta records, h_off, h_len) have not been built from its pinned descriptors yet (pep_k1_host_tables)
+    PinBuf pin_up;                          // grow-only: staging area of uploads out of pageable memory (pep_h2d)
+    size_t pin_up_used = 0;
+    hipEvent_t up_event = nullptr;          // the point of the stream where the last upload out of pin_up has left it
+    bool up_event_set = false;
+    PinBuf pin_down;                        // grow-only: staging area of downloads into pageable memory (pep_d2h_queue / pep_d2h_finish)
+    size_t pin_down_used = 0;
+    struct PendingDown { void *dst; size_t off, n; } down[16];
+    int n_down = 0;
     PinBuf pin_stage;                       // grow-only: the hit table of the newest search
     PinBuf pin_ms;                          // grow-only: per-query score thresholds on their way to the device
     pep_result *staged_result = nullptr;    // the result whose hits still live in pin_stage (materialised before it is overwritten)
@@ -221,6 +229,16 @@ int pep_sync_reads(pep_ctx *ctx);
 hipError_t pep_stream_wait(pep_ctx *ctx);
 hipError_t pep_event_wait(hipEvent_t ev);
 int pin_reserve(pep_ctx *ctx, PinBuf &b, size_t bytes);
+// stream-ordered upload of caller memory: through the context's pinned staging area for anything of size (a copy command straight out of pageable
+// memory has the runtime pin the pages first - 15 ms for the 10 MB of a gene set it has not seen before, 0.2 ms the second time); the caller's buffer
+// is free on return
+int pep_h2d(pep_ctx *ctx, void *d_dst, const void *h_src, size_t n);
+// the way back: pep_d2h_queue queues a download into the pinned staging area (small ones go straight to their destination), pep_d2h_finish - called once
+// the stream has been waited for - copies what arrived to where the caller wants it.  A copy command straight into pageable memory makes the driver
+// register those pages; when the caller frees them (numpy arrays of a megabyte or more go back to the system at once) the driver evicts the process's
+// queues to drop the registration - the NEXT call on the GPU then takes 10 - 30 ms (found in round 5 behind the last gather of RunBlast.run)
+int pep_d2h_queue(pep_ctx *ctx, void *h_dst, const void *d_src, size_t n);
+void pep_d2h_finish(pep_ctx *ctx);
 void pep_materialise_staged(pep_ctx *ctx);
 void pep_drop_dev_result(pep_ctx *ctx);
 int dev_reserve(pep_ctx *ctx, DevBuf &b, size_t bytes);

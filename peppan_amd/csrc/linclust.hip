@@ -444,8 +444,9 @@ int pep_k9_linclust(pep_ctx *ctx, const uint8_t *h_res, const uint64_t *h_off, u
         PEP_HIP(ctx, hipStreamSynchronize(st));
         if (!h_flags[1]) break;
     }
-    PEP_HIP(ctx, hipMemcpyAsync(h_rep, rep, (uint64_t)n * 4, hipMemcpyDeviceToHost, st));
+    PEP_TRY(pep_d2h_queue(ctx, h_rep, rep, (uint64_t)n * 4));
     PEP_HIP(ctx, hipStreamSynchronize(st));
+    pep_d2h_finish(ctx);
     if (h_stats) {
         uint64_t tot = 0;
         for (uint32_t i = 0; i < n; ++i) tot += cnt[i];

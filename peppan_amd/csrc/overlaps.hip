@@ -76,7 +76,8 @@ int pep_k11_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *h_contig, const in
     PEP_TRY(dev_reserve(ctx, W[6], total * 24));
     hipLaunchKernelGGL(ovl_sweep<true>, dim3(g), dim3(256), 0, st, a, (uint64_t *)nullptr, (const uint64_t *)W[5].as<uint64_t>(), W[6].as<int64_t>());
     PEP_HIP(ctx, hipGetLastError());
-    PEP_HIP(ctx, hipMemcpyAsync(h_out, W[6].p, total * 24, hipMemcpyDeviceToHost, st));
+    PEP_TRY(pep_d2h_queue(ctx, h_out, W[6].p, total * 24));
     PEP_HIP(ctx, pep_stream_wait(ctx));
+    pep_d2h_finish(ctx);
     return PEP_OK;
 }

@@ -85,13 +85,14 @@ int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uin
     PEP_TRY(dev_reserve(ctx, ctx->ws[0], n * sizeof(pep_nt_hit)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[1], (n_cigar + 1) * 4));
     PEP_TRY(dev_reserve(ctx, ctx->ws[2], n * 5 * 8));
-    PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[0].p, h_hits, n * sizeof(pep_nt_hit), hipMemcpyHostToDevice, ctx->stream));
-    PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[1].p, h_cigar, n_cigar * 4, hipMemcpyHostToDevice, ctx->stream));
+    PEP_TRY(pep_h2d(ctx, ctx->ws[0].p, h_hits, n * sizeof(pep_nt_hit)));
+    PEP_TRY(pep_h2d(ctx, ctx->ws[1].p, h_cigar, n_cigar * 4));
     hipLaunchKernelGGL(k7_rescore, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, ctx->stream, n, ctx->ws[0].as<const pep_nt_hit>(), ctx->ws[1].as<const uint32_t>(),
                        ctx->q_nt.nt.as<const uint8_t>(), ctx->q_nt.off.as<const uint64_t>(), ctx->r_nt.nt.as<const uint8_t>(), ctx->r_nt.off.as<const uint64_t>(),
                        ctx->ws[2].as<long long>());
     PEP_HIP(ctx, hipGetLastError());
-    PEP_HIP(ctx, hipMemcpyAsync(h_out, ctx->ws[2].p, n * 5 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PEP_TRY(pep_d2h_queue(ctx, h_out, ctx->ws[2].p, n * 5 * 8));
     PEP_HIP(ctx, pep_stream_wait(ctx));
+    pep_d2h_finish(ctx);
     return PEP_OK;
 }

@@ -247,10 +247,10 @@ int pep_k14_pair_support(pep_ctx *ctx, uint64_t n_rows, const pep_support_row *h
     uint32_t *d_ql = reinterpret_cast<uint32_t *>(d_scr + n_groups + 1), *d_rl = d_ql + n_groups + 1;
     int32_t *d_val = reinterpret_cast<int32_t *>(d_rl + n_groups + 1);
     hipStream_t st = ctx->stream;
-    if (n_rows) PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[0].p, h_rows, n_rows * sizeof(pep_support_row), hipMemcpyHostToDevice, st));
-    if (n_cigar) PEP_HIP(ctx, hipMemcpyAsync(ctx->ws[1].p, h_cigar, n_cigar * 4, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(d_off, h_grp_off, (n_groups + 1) * 8, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(d_scr, scr.data(), (n_groups + 1) * 8, hipMemcpyHostToDevice, st));
+    if (n_rows) PEP_TRY(pep_h2d(ctx, ctx->ws[0].p, h_rows, n_rows * sizeof(pep_support_row)));
+    if (n_cigar) PEP_TRY(pep_h2d(ctx, ctx->ws[1].p, h_cigar, n_cigar * 4));
+    PEP_TRY(pep_h2d(ctx, d_off, h_grp_off, (n_groups + 1) * 8));
+    PEP_TRY(pep_h2d(ctx, d_scr, scr.data(), (n_groups + 1) * 8));
     PEP_HIP(ctx, hipMemcpyAsync(d_ql, h_qlen, n_groups * 4, hipMemcpyHostToDevice, st));
     PEP_HIP(ctx, hipMemcpyAsync(d_rl, h_rlen, n_groups * 4, hipMemcpyHostToDevice, st));
     SupportArgs a;
@@ -263,8 +263,9 @@ int pep_k14_pair_support(pep_ctx *ctx, uint64_t n_rows, const pep_support_row *h
         hipLaunchKernelGGL(k14_pair_support, dim3((unsigned)(batch_end[b] - g0)), dim3(64), 0, st, a);
     }
     PEP_HIP(ctx, hipGetLastError());
-    PEP_HIP(ctx, hipMemcpyAsync(h_value, d_val, n_groups * 4, hipMemcpyDeviceToHost, st));
+    PEP_TRY(pep_d2h_queue(ctx, h_value, d_val, n_groups * 4));
     PEP_HIP(ctx, hipStreamSynchronize(st));
+    pep_d2h_finish(ctx);
     return PEP_OK;
 }
 

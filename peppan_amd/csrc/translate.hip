@@ -592,7 +592,7 @@ int pep_k1_host_tables(pep_ctx *ctx)
     if (ctx->t_tables_lazy) {
         const uint32_t n = ctx->t.n;
         std::vector<PackDesc> fetched((size_t)n + 1);
-        if (n) PEP_HIP(ctx, hipMemcpy(fetched.data(), ctx->d_k1_desc_t.p, (size_t)n * sizeof(PackDesc), hipMemcpyDeviceToHost));        // (waits for the stream)
+        if (n) { PEP_TRY(pep_d2h_queue(ctx, fetched.data(), ctx->d_k1_desc_t.p, (size_t)n * sizeof(PackDesc))); PEP_HIP(ctx, pep_stream_wait(ctx)); pep_d2h_finish(ctx); }
         const PackDesc *desc = fetched.data();
         ctx->t_meta.resize(n);
         for (uint32_t i = 0; i < n; ++i) ctx->t_meta[i] = pep_target_meta{desc[i].seq, desc[i].frame, desc[i].aa_off, desc[i].len};
@@ -608,7 +608,7 @@ int pep_k1_host_tables_q(pep_ctx *ctx)
         const NtSet &nt = ctx->q_nt;
         const uint32_t n = ctx->q.n;
         std::vector<PackDesc> fetched((size_t)n + 1);
-        if (n) PEP_HIP(ctx, hipMemcpy(fetched.data(), ctx->d_k1_desc_q.p, (size_t)n * sizeof(PackDesc), hipMemcpyDeviceToHost));
+        if (n) { PEP_TRY(pep_d2h_queue(ctx, fetched.data(), ctx->d_k1_desc_q.p, (size_t)n * sizeof(PackDesc))); PEP_HIP(ctx, pep_stream_wait(ctx)); pep_d2h_finish(ctx); }
         const PackDesc *desc = fetched.data();
         ctx->q_meta.resize(n);
         for (uint32_t i = 0; i < n; ++i) ctx->q_meta[i] = pep_query_meta{i, desc[i].frame, desc[i].len, (uint32_t)(nt.h_off[i + 1] - nt.h_off[i])};
