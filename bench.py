@@ -473,7 +473,9 @@ def north_star_workloads(local_rank, names, order, seqs, nts, min_id, min_qcov, 
         ctx.set_timing(0)
         per = {k: acc[k] / steps for k in keys}
         Lq = per['query_residues'] / max(1, len(nts))
-        rl = roofline_kernels(_profile_tables(PROFILE_COUNTERS_BLASTN)[0], cyc4, os.path.basename(PROFILE_COUNTERS_BLASTN), per, Lq, 1, seed_weight=17)
+        # (the nucleotide tool's pairs are long: its passes are the <true> launches + the retry launch - kernel families, as for a mapping step)
+        rl = family_rooflines(PROFILE_COUNTERS_BLASTN, per, Lq, cyc4, 'one search of the nucleotide tool: both launches of a pass (pairs that fit the staging area / long pairs) summed',
+                              'K4a: both strands of the reference streamed through the query index (one shape of weight 17)')
         out['search_10k_blastn'] = {'workload': 'synthgenes-v1 seed 355: %d genes x 1002 nt against themselves, nucleotide tool (the blastn call of uberBlast.py:294), both strands of the reference' % len(nts),
                                     'steps': steps, 'ms_per_step': dt / steps * 1e3, 'candidates_per_step': per['candidates'], 'hits_per_step': n_hits,
                                     'value_gene_pairs_aligned_per_s': per['candidates'] * steps / dt,
@@ -610,19 +612,21 @@ def roofline_kernels(counters, cyc4, source, per_step, Lq, n_shapes, seed_weight
     return rl
 
 
-def map_step_rooflines(per, step_log, Lq, cyc4):
-    """The kernel FAMILIES a mapping step spends its search time in - a step is several searches (nucleotide tool + translated tool per sub-batch of
-    genomes), so a family (all launches of sw_trace_kernel, of sw_score_kernel, of seed_match whatever their template argument) is summed over the
-    step: live HIP-event milliseconds per step from the searches' phase timers, algorithmic bytes from their statistics (lengths differ
-    per pair: the mean query length stands in), and the PMC traffic of the same launches from profiles/r05_counters_map50k.json (one mapping step of
-    the same workload under rocprofv3 --pmc: per instance the per-dispatch average x its dispatches per step)."""
-    path = PROFILE_COUNTERS_MAP50K
+FAMILY_MEMBERS = {'sw_trace_kernel': ('sw_trace_kernel', 'sw_trace_retry_kernel')}     # (the pairs that left their sub-band are traced by a launch of their own inside the same phase)
+
+
+def family_rooflines(path, per, Lq, cyc4, note, seed_what):
+    """The kernel FAMILIES a step made of several launches per kernel spends its search time in - all launches of sw_trace_kernel (+ its retry
+    launch), of sw_score_kernel, of seed_match whatever their template argument, summed over the step: live HIP-event milliseconds per step from
+    the searches' phase timers, algorithmic bytes from their statistics (lengths differ per pair: the mean query length stands in),
+    and the PMC traffic of the same launches from the tracked counters at `path` (the same workload under rocprofv3 --pmc: per instance the
+    per-dispatch average x its dispatches per step)."""
     prof = json.load(open(path)) if os.path.exists(path) else {}
     kernels, steps = prof.get('kernels', {}), max(1, int(prof.get('steps_per_pass', 1)))
     src = os.path.basename(path)
 
     def family(prefix, ms_step, alg, what, valu, scattered):
-        inst = {k: v for k, v in kernels.items() if k.split('<')[0] == prefix}
+        inst = {k: v for k, v in kernels.items() if k.split('<')[0] in FAMILY_MEMBERS.get(prefix, (prefix,))}
         launches = sum(v.get('dispatches_per_pass', 0) for v in inst.values()) / steps
         pmc_ms = sum(sum(v['avg_us_in_pmc_passes']) / len(v['avg_us_in_pmc_passes']) * v.get('dispatches_per_pass', 0) for v in inst.values() if v.get('avg_us_in_pmc_passes')) / steps / 1e3
         stale = bool(inst) and ms_step > 0 and abs(pmc_ms - ms_step) > 0.15 * ms_step
@@ -639,7 +643,7 @@ def map_step_rooflines(per, step_log, Lq, cyc4):
         e = {'kernel': prefix, 'instances': sorted(inst) or None, 'what': what, 'bound': 'hbm', 'ms_per_step': ms_step, 'launches_per_step': launches or None,
              'algorithmic_bytes': alg, 'traffic': traffic, 'counters_stale': stale, 'ms_per_step_in_pmc_passes': pmc_ms or None,
              'traffic_source': ('profiles/%s: %s, per instance x dispatches per step' % (src, 'TCC_EA0_RDREQ x 64 B + WRITE_SIZE (scattered requests)' if scattered else '2 x FETCH_SIZE + WRITE_SIZE')) if traffic is not None else None,
-             'note': 'summed over the searches of one mapping step (nucleotide tool + translated tool per sub-batch of genomes); lengths differ per pair: algorithmic bytes use the mean query length'}
+             'note': note}
         e.update(hbm)
         if traffic and alg:
             e['traffic_over_algorithmic'] = traffic / alg
@@ -650,12 +654,19 @@ def map_step_rooflines(per, step_log, Lq, cyc4):
                      valu_issue_frac=(rate / peak) if rate and peak else None)
         return e
 
-    n_tools = max(1, sum(1 for st in step_log if st['ms_seed_match'] > 0))
-    rl = [family('sw_trace_kernel', per['ms_sw_trace'], (per['tracebacks'] - per['tracebacks_gapless']) * 2 * Lq + per['hits'] * 64, 'K5 traceback pass of every search of the step', True, False),
-          family('sw_score_kernel', per['ms_sw'], (per['candidates'] - per['candidates_settled']) * 2 * Lq + per['hits'] * 64, 'K5 score pass of every search of the step', True, False),
-          family('seed_match', per['ms_seed_match'], 9.0 * per['target_residues'] + 8.0 * per['seed_hits'], 'K4a: the genomes streamed through the exemplar index, both tools (%d searches)' % n_tools, False, True)]
+    rl = [family('sw_trace_kernel', per['ms_sw_trace'], (per['tracebacks'] - per['tracebacks_gapless']) * 2 * Lq + per['hits'] * 64, 'K5 traceback pass (every launch of the step, the retry launch included)', True, False),
+          family('sw_score_kernel', per['ms_sw'], (per['candidates'] - per['candidates_settled']) * 2 * Lq + per['hits'] * 64, 'K5 score pass (every launch of the step: pairs that fit the staging area and long pairs)', True, False),
+          family('seed_match', per['ms_seed_match'], 9.0 * per['target_residues'] + 8.0 * per['seed_hits'], seed_what, False, True)]
     rl.sort(key=lambda e: -e['ms_per_step'])
     return rl
+
+
+def map_step_rooflines(per, step_log, Lq, cyc4):
+    """family_rooflines over one mapping step (profiles/r05_counters_map50k.json: one mapping step of the same workload under rocprofv3 --pmc)"""
+    n_tools = max(1, sum(1 for st in step_log if st['ms_seed_match'] > 0))
+    return family_rooflines(PROFILE_COUNTERS_MAP50K, per, Lq, cyc4,
+                            'summed over the searches of one mapping step (nucleotide tool + translated tool per sub-batch of genomes); lengths differ per pair: algorithmic bytes use the mean query length',
+                            'K4a: the genomes streamed through the exemplar index, both tools (%d searches)' % n_tools)
 
 
 def _profile_tables(path=None):
