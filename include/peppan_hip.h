@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 11
+#define PEP_ABI_VERSION 12
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -337,6 +337,11 @@ int pep_fasta_keep(const char *path, const int64_t *ids, uint64_t n_ids, uint64_
  * its own, Unicode-aware rules). */
 int pep_fasta_scan(const uint8_t *data, uint64_t n, const uint8_t *table, uint8_t *codes, uint64_t *off, uint64_t cap, uint64_t *n_records,
                    int32_t *non_ascii);
+/* the same pass for the sequence reader of the search (readFasta, configure.py:118-128 of the reference, behind uberBlast.py:339-341): also the records' names -
+ * name_off[r] / name_len[r] = the first blank-delimited token of record r's header line inside data (length 0: a header without a name).
+ * name_off and name_len hold cap entries. */
+int pep_fasta_records(const uint8_t *data, uint64_t n, const uint8_t *table, uint8_t *codes, uint64_t *off, uint64_t *name_off, uint32_t *name_len,
+                      uint64_t cap, uint64_t *n_records, int32_t *non_ascii);
 
 /* K13: exact-duplicate collapse of gene instances (front end of the clustering path).
  * pep_sha1: digest[20*i..] = SHA-1 of sequence i (bytes[off[i]..off[i+1])), big-endian bytes as hashlib.sha1(seq).digest();

@@ -7,14 +7,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params', 'pep_set_sensitivity',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast',
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_fasta_records', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast',
            'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather']
 
 
@@ -540,6 +540,36 @@ def fasta_scan(data, table, n_records):
     if rc_ != 0:
         raise PepError('pep_fasta_scan failed (%d)' % rc_)
     return codes[:int(off[n_records])], off[:n_records + 1]
+
+
+_UPPER = np.frombuffer(bytes(range(256)).upper(), dtype=np.uint8)
+
+
+def fasta_records(data):
+    """pep_fasta_records: the records of FASTA text `data` (ASCII bytes without carriage returns) as (names, text, off): names = list of str (first word
+    of every header line), text = all sequences upper-cased and without blanks in one str, off = int64[n + 1] where each record's sequence starts in it.
+    None when a header has no name or a sequence holds non-ASCII bytes: the caller then goes its own way."""
+    lib = load_library()
+    codes = np.empty(max(len(data), 1), dtype=np.uint8)
+    nr, high = C.c_uint64(), C.c_int32()
+    cap = max(1024, len(data) // 128)                # (a guess; a file of shorter records is counted and scanned again)
+    while True:
+        off, name_off, name_len = np.empty(cap + 1, dtype=np.uint64), np.empty(cap, dtype=np.uint64), np.empty(cap, dtype=np.uint32)
+        rc_ = lib.pep_fasta_records(C.c_char_p(data), C.c_uint64(len(data)), _ptr(_UPPER), _ptr(codes), _ptr(off), _ptr(name_off), _ptr(name_len), C.c_uint64(cap),
+                                    C.byref(nr), C.byref(high))
+        if rc_ != -3 or cap >= len(data):            # PEP_ERR_LIMIT: more records than guessed
+            break
+        cap = data.count(b'>') + 1
+    if rc_ != 0:
+        raise PepError('pep_fasta_records failed (%d)' % rc_)
+    n = nr.value
+    if high.value or (n and int(name_len[:n].min()) == 0):
+        return None
+    a = name_off[:n].astype(np.int64)
+    b = a + name_len[:n]
+    names = [data[x:y].decode('ascii') for x, y in zip(a.tolist(), b.tolist())]
+    off = off[:n + 1].astype(np.int64)
+    return names, str(codes[:int(off[n])].data, 'ascii'), off
 
 
 def similar_resolve(ev_kind, ev_a, ev_b, ev_value):

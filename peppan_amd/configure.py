@@ -77,21 +77,43 @@ class uopen(object):
 def _record_text(body):
     """the text behind a record's header -> its sequence: comment lines (leading '#') left out, all white space dropped, upper case"""
     if '#' in body:
-        body = ''.join(ln for ln in body.splitlines() if not ln.startswith('#'))
+        body = ''.join(ln for ln in body.split('\n') if not ln.startswith('#'))      # (lines end at '\n' only, as for the reference's line iterator)
     return ''.join(body.split()).upper()
 
 
-def readFasta(fasta, headOnly=False):
-    """FASTA file -> {name: sequence}: the name is the first word of a header line, the sequence everything up to the next header
-    without its white space, upper-cased; lines that start with '#' are comments; of two records with one name the later counts
-    (configure.py:118-128).  The file is read in one piece and cut at the headers (a '>' at the start of a line)."""
-    with uopen(fasta) as fin:
-        text = fin.read()
+def _read_bytes(fname):
+    with (gzip.open(fname, 'rb') if fname.lower().endswith('gz') else open(fname, 'rb')) as fin:
+        return fin.read()
+
+
+def _fasta_text_records(text, headOnly=False):
+    """FASTA text -> {name: sequence}, record by record (any text: Unicode names and blanks, headers without a name raise as the reference's do)"""
     records = {}
     for block in ('\n' + text).split('\n>')[1:]:                           # (what stands in front of the first header belongs to no record)
         header, _, body = block.partition('\n')
         records[header.split()[0]] = '' if headOnly else _record_text(body)
     return records
+
+
+def _fasta_records(data, headOnly=False):
+    """FASTA file content (bytes) -> {name: sequence}.  Plain ASCII without carriage returns - every file PEPPAN writes for its own searches - is cut by
+    one pass of the library's host code (pep_fasta_records: names, and all sequences cleaned into one text that is sliced here); anything else is
+    decoded as the text-mode reader would and goes record by record."""
+    if not headOnly and data.isascii() and b'\r' not in data:
+        from . import _native
+        got = _native.fasta_records(data)
+        if got is not None:
+            names, text, off = got
+            cuts = off.tolist()
+            return dict(zip(names, map(text.__getitem__, map(slice, cuts[:-1], cuts[1:]))))
+    return _fasta_text_records(io.TextIOWrapper(io.BytesIO(data), encoding='utf-8').read(), headOnly)
+
+
+def readFasta(fasta, headOnly=False):
+    """FASTA file -> {name: sequence}: the name is the first word of a header line, the sequence everything up to the next header
+    without its white space, upper-cased; lines that start with '#' are comments; of two records with one name the later counts
+    (configure.py:118-128)."""
+    return _fasta_records(_read_bytes(fasta), headOnly)
 
 
 _PSEUDO_QUALITY = bytes(ord('I') if chr(c) in 'ACGTacgt' else ord('!') for c in range(256))
@@ -102,13 +124,13 @@ def readFastq(fastq, with_qual=True):
     A file that does not start with '@' is taken as FASTA and every sequence gets a made-up quality: 'I' under A, C, G, T and '!' under
     anything else (configure.py:129-147).  with_qual=False leaves the made-up qualities out (nothing on the search path reads them, and
     for a genome they cost more than its search)."""
-    with uopen(fastq) as fin:
-        text = fin.read()
-    if not text.startswith('@'):
-        seq = readFasta(fastq)
+    data = _read_bytes(fastq)
+    if not data.startswith(b'@'):
+        seq = _fasta_records(data)
         if not with_qual:
             return seq, None
         return seq, {name: s.encode('latin-1', 'replace').translate(_PSEUDO_QUALITY).decode('ascii') for name, s in seq.items()}
+    text = io.TextIOWrapper(io.BytesIO(data), encoding='utf-8').read()
     lines = text.splitlines()
     lines += [''] * (-len(lines) % 4)
     seq, qual = {}, {}

@@ -1138,6 +1138,7 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
     this process (0 / 1 say so explicitly)."""
     if len(genomes) == 0:
         raise ValueError('get_map_bsn: no genome to map against')
+    t_enter = time.perf_counter()
     taxa = {}
     for g, s in genomes.items():
         taxa.setdefault(s[0], []).append([g, s[1]])
@@ -1222,4 +1223,4 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
     stores.close()
     if timing is not None:      # seconds: search + filters + build_groups on the caller's thread; then, on the stores' thread and overlapped with it,
         #                         handing groups to the stores and the gene table updates; what was left to wait for at the end
-        timing.update(groups=t_groups - t_start, stores=spent['stores'], keeper_thread_cpu=spent.get('keeper_cpu', 0.), main_thread_cpu=time.thread_time() - main_cpu0, gene_table=stores.t_table, drain=clock() - t_groups)
+        timing.update(setup=t_start - t_enter, close=clock() - t0, groups=t_groups - t_start, stores=spent['stores'], keeper_thread_cpu=spent.get('keeper_cpu', 0.), main_thread_cpu=time.thread_time() - main_cpu0, gene_table=stores.t_table, drain=clock() - t_groups)

@@ -124,85 +124,158 @@ def _members_from_file(P):
 
 
 def _serve(address, authkey):
-    """the worker's life: set-ups and rounds until 'stop' or until the parent goes away"""
-    import time
+    """The worker's life: set-ups and rounds until 'stop' or until the parent goes away.
+
+    Three threads.  The one that reads the socket hands 'round' messages to the SEARCH thread (batched search of both tools, K7, the filters and K11
+    per genome) and 'emit' / 'drop' answers to the GROUPS thread (build_groups with K12 in a context of its own, the round's counts, its members, the
+    'done' message).  A worker shares the GPU with seven others, and at the rate the pool maps the GPU is half busy: a search waits about as long for
+    its turn as it computes, and those waits are where the round in front gets its groups and members made - the search thread sleeps inside the
+    library (no interpreter lock held) while the groups thread works.  Rounds leave the worker in the order they came."""
+    import queue
     conn = Client(address, family='AF_UNIX', authkey=authkey)
     conn.send(('hello', os.getpid()))                               # (which of the processes the pool started is behind this connection)
+    sys.setswitchinterval(1e-3)                                     # (two threads that hold the interpreter lock for a few hundred microseconds at a time)
     state = {}
     clock, spent = time.perf_counter, dict(recv=0., search=0., groups=0., wait_first=0., members=0., send=0., genomes=0)
-    profile = None
-    if os.environ.get('PEPPAN_WORKERS_PROFILE'):                    # cProfile over this worker's rounds, its top functions on stderr at the end
-        import cProfile
-        profile = cProfile.Profile()
+    todo, searched, replies = queue.Queue(), queue.Queue(maxsize=1), queue.Queue()
+    send_lock = threading.Lock()
+    profiles = []
+
+    def say(msg):
+        with send_lock:
+            conn.send(msg)
+
+    def profiled(f):
+        if not os.environ.get('PEPPAN_WORKERS_PROFILE'):            # cProfile over this worker's rounds (a profile per thread), top functions on stderr at the end
+            return f
+
+        def g():
+            import cProfile
+            pr = cProfile.Profile()
+            profiles.append(pr)
+            pr.enable()
+            try:
+                f()
+            finally:
+                pr.disable()
+        return g
+
+    def searcher():
+        while True:
+            msg = todo.get()
+            if msg is None:
+                searched.put(None)
+                return
+            k, jobs = msg[1], msg[2]
+            t0 = clock()
+            try:
+                from . import mapbsn
+                if len(msg) > 3 and msg[3] is not None:
+                    jobs = _jobs_from_file(msg[3], jobs)
+                search = state['search'] or (lambda *a: mapbsn._gpu_search(*a, genomes_per_batch=state['per_batch']))
+                found = list(search(state['prefix'], state['clust'], jobs, state['params']))
+                if len(found) != len(jobs):
+                    raise RuntimeError('the search returned %d tables for %d genomes' % (len(found), len(jobs)))
+                item = (k, jobs, found, None)
+            except BaseException:
+                item = (k, jobs, None, traceback.format_exc())
+            spent['search'] += clock() - t0
+            searched.put(item)
+
+    def answer_for(k):
+        """the parent's 'emit' / 'drop' for round k (answers for rounds that failed here are passed over); None: the worker is stopping"""
+        while True:
+            reply = replies.get()
+            if reply is None or reply[1] == k:
+                return reply
+
+    def grouper():
+        while True:
+            item = searched.get()
+            if item is None:
+                return
+            k, jobs, found, failed = item
+            try:
+                if failed is not None:
+                    say(('error', k, failed))
+                    continue
+                from . import mapbsn
+                t0 = clock()
+                out = []
+                for (id, taxon, seq), (blastab, overlap) in zip(jobs, found):
+                    G = mapbsn.build_groups(blastab, overlap, seq, state['ortho'], state['old'], state['params'], state['ctx'])
+                    out.append(G if state['form'] == 'groups' else mapbsn.StoreBlock(G))
+                del found, item
+                spent['groups'] += clock() - t0
+                spent['genomes'] += len(out)
+                if state['form'] == 'members':
+                    say(('counts', k, [B.n for B in out]))
+                    t0 = clock()
+                    reply = answer_for(k)
+                    t1 = clock()
+                    if reply is None:
+                        return
+                    out = mapbsn.round_members(out, [job[1] for job in jobs], reply[2], state['save_seq']) if reply[0] == 'emit' else None
+                    if out is not None and len(reply) > 3 and reply[3] is not None:
+                        out = _members_to_file(reply[3], out)
+                    spent['wait_first'] += t1 - t0
+                    spent['members'] += clock() - t1
+                t0 = clock()
+                say(('done', k, out))
+                spent['send'] += clock() - t0
+            except (EOFError, OSError):
+                os._exit(1)                             # (the parent is gone)
+            except BaseException:
+                try:
+                    say(('error', k, traceback.format_exc()))
+                except Exception:
+                    os._exit(1)
+
+    threads = [threading.Thread(target=profiled(searcher), daemon=True), threading.Thread(target=profiled(grouper), daemon=True)]
+    for t in threads:
+        t.start()
     while True:
         try:
             t0 = clock()
             msg = conn.recv()
             spent['recv'] += clock() - t0
         except EOFError:
-            return
+            os._exit(0)                                 # (the parent went away: nothing to finish, and the other threads may be inside the library)
         if msg[0] == 'stop':
+            todo.put(None)
+            replies.put(None)
+            for t in threads:
+                t.join(30.)
             if os.environ.get('PEPPAN_WORKERS_TIMING'):             # seconds this worker spent where (a line per worker on stderr)
                 sys.stderr.write('mapping worker %d: %s\n' % (os.getpid(), ' '.join('%s %.2f' % kv for kv in spent.items())))
-            if profile is not None:
+            if profiles:
                 import pstats
-                pstats.Stats(profile, stream=sys.stderr).sort_stats('tottime').print_stats(25)
+                st = pstats.Stats(profiles[0], stream=sys.stderr)
+                for pr in profiles[1:]:
+                    st.add(pr)
+                st.sort_stats('tottime').print_stats(30)
             return
-        if msg[0] == 'setup':
+        if msg[0] == 'setup':                           # (between two calls of the pool: both threads are idle)
             try:
                 from . import mapbsn
                 a = msg[1]
                 old = a['old_prediction']
                 if state.get('old_is_mine'):
                     state['old'].close()
+                ctx = a['ctx_class']() if a['ctx_class'] is not None else state.get('own_ctx')
+                if ctx is None:
+                    # the groups thread's K12 in a context of its own: the shared one (uberBlast.get_context) belongs to the search thread
+                    from . import _native
+                    ctx = state['own_ctx'] = _native.Context(int(os.environ.get('PEPPAN_HIP_DEVICE', os.environ.get('LOCAL_RANK', '0'))))
                 state.update(a, ortho=mapbsn.OrthoRelation(a['orthoGroup']), old=mapbsn.MapBsn(old) if isinstance(old, str) else old,
-                             old_is_mine=isinstance(old, str), ctx=a['ctx_class']() if a['ctx_class'] is not None else None)
-                conn.send(('ready', os.getpid()))
+                             old_is_mine=isinstance(old, str), ctx=ctx)
+                say(('ready', os.getpid()))
             except BaseException:
-                conn.send(('error', -1, traceback.format_exc()))
-            continue
-        if msg[0] != 'round':
-            continue                                # (an 'emit' / 'drop' for a round that failed here: nothing is waiting for it)
-        k, jobs = msg[1], msg[2]
-        if profile is not None:
-            profile.enable()
-        try:
-            from . import mapbsn
-            if len(msg) > 3 and msg[3] is not None:
-                jobs = _jobs_from_file(msg[3], jobs)
-            search = state['search'] or (lambda *a: mapbsn._gpu_search(*a, genomes_per_batch=state['per_batch']))
-            out, t0 = [], clock()
-            for (id, taxon, seq), (blastab, overlap) in zip(jobs, search(state['prefix'], state['clust'], jobs, state['params'])):
-                t1 = clock()
-                G = mapbsn.build_groups(blastab, overlap, seq, state['ortho'], state['old'], state['params'], state['ctx'])
-                out.append(G if state['form'] == 'groups' else mapbsn.StoreBlock(G))
-                t2 = clock()
-                spent['search'] += t1 - t0
-                spent['groups'] += t2 - t1
-                t0 = t2
-            spent['genomes'] += len(out)
-            if len(out) != len(jobs):
-                raise RuntimeError('the search returned %d tables for %d genomes' % (len(out), len(jobs)))
-            if state['form'] == 'members':
-                conn.send(('counts', k, [B.n for B in out]))
-                reply = conn.recv()
-                t1 = clock()
-                if reply[0] == 'stop':
-                    return
-                out = mapbsn.round_members(out, [job[1] for job in jobs], reply[2], state['save_seq']) if reply[0] == 'emit' else None
-                if out is not None and len(reply) > 3 and reply[3] is not None:
-                    out = _members_to_file(reply[3], out)
-                spent['wait_first'] += t1 - t0
-                spent['members'] += clock() - t1
-            if profile is not None:
-                profile.disable()
-            t0 = clock()
-            conn.send(('done', k, out))
-            spent['send'] += clock() - t0
-        except EOFError:
-            return
-        except BaseException:
-            conn.send(('error', k, traceback.format_exc()))
+                say(('error', -1, traceback.format_exc()))
+        elif msg[0] == 'round':
+            todo.put(msg)
+        elif msg[0] in ('emit', 'drop'):
+            replies.put(msg)
 
 
 class _Hung(Exception):
@@ -242,6 +315,8 @@ class MapWorkers(object):
             env['PEPPAN_HIP_DEVICE'] = str(int(device))
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         env['PYTHONPATH'] = os.pathsep.join([root] + [p for p in sys.path if p] + [env.get('PYTHONPATH', '')])     # a search function of the caller's must be importable
+        if os.environ.get('PEPPAN_POOL_GATE'):               # (experiment: at most that many workers inside their batched searches at once)
+            env['PEPPAN_GPU_GATE'] = '%s,%d' % (self._dir, int(os.environ['PEPPAN_POOL_GATE']))
         self._env = env
         self._procs, self._conns, started = [], [], {}
         self._setup_msg, self._spawn_lock = None, threading.Lock()
@@ -260,8 +335,6 @@ class MapWorkers(object):
                 self._procs.append(started.pop(self._hello(conn)))        # connections arrive in any order: _procs[i] is the process behind _conns[i]
         except BaseException:
             self._procs += list(started.values())
-            self.close()
-            raise
             self.close()
             raise
 
@@ -409,6 +482,20 @@ class MapWorkers(object):
         def one_round(i, k, held, resend):
             """round k (in worker i's queue already) to its end -> the message for the caller.  Form 'members': the next round is handed
             out (held[1]; `resend`: the round that was held ahead when the worker had to be replaced) while the worker makes k's members"""
+            if members and held[1] is None:                 # the round behind k goes into the worker's queue at once: its search runs while k's groups and members are made
+                ahead = resend if resend is not None else take_number()
+                if ahead is not None:
+                    try:
+                        send_round(i, ahead)
+                        held[1] = ahead
+                    except (EOFError, OSError):
+                        held[1] = ahead
+                        raise
+                    except BaseException:                   # a round that cannot be handed out (its sequences, its pickle) fails the call - and round k, which IS
+                        with cond:                          # in the worker, is still seen to its end: the pool stays in step
+                            results[ahead] = ('error', ahead, traceback.format_exc())
+                            state['stop'] = True
+                            cond.notify_all()
             msg = answer(i, k)
             if msg[0] == 'counts':
                 with cond:
@@ -422,10 +509,6 @@ class MapWorkers(object):
                         cond.wait()
                     go = ('emit', k, first_of[k], os.path.join(self._bulk, 'r%d' % k)) if k in first_of else ('drop', k)
                 self._conns[i].send(go)
-                if go[0] == 'emit':
-                    held[1] = resend if resend is not None else take_number()
-                    if held[1] is not None:
-                        send_round(i, held[1])
                 msg = answer(i, k)
                 if go[0] == 'drop':
                     msg = ('dropped', k, None)
@@ -500,6 +583,19 @@ class MapWorkers(object):
                     state['stop'] = True
                     cond.notify_all()
 
+        if os.environ.get('PEPPAN_KEEPER_PROFILE'):                           # cProfile of every thread that talks to a worker, merged, top functions appended to the file the variable names
+            import cProfile
+            import pstats
+            plain_feeder, profiles = feeder, []
+
+            def feeder(i):
+                pr = cProfile.Profile()
+                profiles.append(pr)
+                pr.enable()
+                try:
+                    plain_feeder(i)
+                finally:
+                    pr.disable()
         threads = [threading.Thread(target=feeder, args=(i,), daemon=True) for i in range(max(1, min(self.n, n_rounds)))]
         for t in threads:
             t.start()
@@ -528,6 +624,12 @@ class MapWorkers(object):
                 slots.release()                 # (a feeder waiting for a slot sees the flag and leaves)
             for t in threads:
                 t.join()
+            if os.environ.get('PEPPAN_KEEPER_PROFILE') and profiles:
+                with open(os.environ['PEPPAN_KEEPER_PROFILE'], 'a') as out:      # (the variable names the file)
+                    st = pstats.Stats(profiles[0], stream=out)
+                    for pr in profiles[1:]:
+                        st.add(pr)
+                    st.sort_stats('tottime').print_stats(25)
 
 
 if __name__ == '__main__':

@@ -94,6 +94,43 @@ def _prepare_side(seqs, key, names=None):
     return side
 
 
+class _gpu_gate(object):
+    """Worker processes of one pool share one GPU (mapworkers.py).  Their batched searches are chains of short launches with host round trips in
+    between; more than a few of them in flight at once and every one of them crawls (eight at once: 2 - 3 times a search's time alone).  The pool
+    therefore hands out PEPPAN_GPU_GATE="<directory>,<M>": a batch's searches run while the process holds one of M lock files - the other workers
+    do their host work (groups, members) meanwhile.  Nothing set: no gate."""
+
+    def __enter__(self):
+        self.f = None
+        spec = os.environ.get('PEPPAN_GPU_GATE')
+        if spec:
+            import fcntl
+            where, m = spec.rsplit(',', 1)
+            m = max(1, int(m))
+            files = [open(os.path.join(where, 'gate%d' % i), 'a') for i in range(m)]
+            first = os.getpid() % m
+            for k in range(m):
+                f = files[(first + k) % m]
+                try:
+                    fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
+                    self.f = f
+                    break
+                except OSError:
+                    pass
+            if self.f is None:
+                self.f = files[first]
+                fcntl.flock(self.f, fcntl.LOCK_EX)
+            for f in files:
+                if f is not self.f:
+                    f.close()
+        return self
+
+    def __exit__(self, *exc):
+        if self.f is not None:
+            self.f.close()                      # (closing gives the lock back)
+        return False
+
+
 def get_context(device=None):
     """one HIP context per (process, device), created lazily so that forked workers make their own
     (the reference forks pool workers before calling uberBlast, PEPPAN.py:922)"""
@@ -464,7 +501,8 @@ class RunBlast(object):
                 groups.append(g)
         self.refSeq, self._batch = combined, (names, groups)
         genome_of = dict(zip(names, groups))
-        tables = self._run_tools(methods, None, None)
+        with _gpu_gate():
+            tables = self._run_tools(methods, None, None)
         # mode-1 rescoring is a function of the row alone: K7 once per tool over the rows of ALL genomes (a launch and a round trip per genome
         # otherwise: 84 us of GPU and a synchronisation each, sixteen times per batch), the identity cut stays with the genome's table (_post)
         batch_rescore = re_score == 1

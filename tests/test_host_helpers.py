@@ -181,3 +181,53 @@ def test_packing_of_big_lists_and_digest_integers():
     d[1] = 255
     assert _pyrows().pep_digest_ints(d.ctypes.data, len(d), 20) == [int.from_bytes(x.tobytes(), 'big') for x in d]
     assert _pyrows().pep_digest_ints(d.ctypes.data, 0, 20) == []
+
+
+def test_read_fasta_through_the_library_equals_the_record_by_record_reader(tmp_path):
+    """configure.readFasta / readFastq cut a plain-ASCII file with one pass of host C++ (pep_fasta_records) and everything else record by record:
+    both give the reference's dictionary (configure.py:118-128: first word of the header, body lines not starting with '#', white space dropped,
+    upper case, the later of two records with one name) - on made-up files with every blank str.split knows, '#' and '>' inside lines, junk in
+    front of the first header, headers without a body, a last line without its newline, duplicate names"""
+    import gzip
+    import random
+    from peppan_amd import configure as CF
+    rnd = random.Random(7)
+    alpha = 'ACGTacgtNn \t\x0b\x0c\x1c\x1f#>xyz-*'
+    for case in range(600):
+        parts = []
+        if rnd.random() < 0.3:
+            parts.append(''.join(rnd.choice(alpha) for _ in range(rnd.randint(0, 8))) + '\n')
+        for r in range(rnd.randint(0, 6)):
+            parts.append('>' + rnd.choice(['', ' ', '\t']) + rnd.choice(['g%d' % rnd.randint(0, 4), 'name x', 'a\tb', 'x']) + rnd.choice(['', ' desc', '  ']) + '\n')
+            for _ in range(rnd.randint(0, 4)):
+                line = ''.join(rnd.choice(alpha) for _ in range(rnd.randint(0, 12)))
+                parts.append(('A' + line if line.startswith('>') else line) + ('\n' if rnd.random() < 0.95 else ''))
+                if not parts[-1].endswith('\n'):
+                    break
+            if not parts[-1].endswith('\n'):
+                break
+        text = ''.join(parts)
+        def outcome(f, x):
+            try:
+                d = f(x)
+                return list(d.items())
+            except IndexError:                      # (a header without a name: the reference fails on it the same way)
+                return 'no name'
+        assert outcome(CF._fasta_records, text.encode()) == outcome(CF._fasta_text_records, text), repr(text)
+    # many short records (more than the first guess of the record count), through the file readers, plain and gzipped
+    text = ''.join('>%d\nacgt\nNN\n' % (i % 4000) for i in range(5000))
+    fa, gz = str(tmp_path / 'a.fa'), str(tmp_path / 'a.fa.gz')
+    open(fa, 'w').write(text)
+    with gzip.open(gz, 'wt') as f:
+        f.write(text)
+    want = CF._fasta_text_records(text)
+    assert len(want) == 4000 and want['7'] == 'ACGTNN'
+    assert CF.readFasta(fa) == want and CF.readFasta(gz) == want and CF.readFastq(fa, with_qual=False)[0] == want
+    assert CF.readFastq(fa)[1]['7'] == 'IIII!!' and set(CF.readFasta(fa, headOnly=True).values()) == {''}
+    # what the library does not take goes the other way: carriage returns (the text reader's universal newlines), non-ASCII text, a header without a name
+    assert CF._fasta_records(b'>a x\r\nAC\r\nGT\r>b\rTT\n') == {'a': 'ACGT', 'b': 'TT'}
+    assert CF._fasta_records('>gène\nACGT\n'.encode()) == {'gène': 'ACGT'}
+    with pytest.raises(IndexError):
+        CF._fasta_records(b'>\nACGT\n')
+    with pytest.raises(IndexError):
+        CF._fasta_text_records('>\nACGT\n')
