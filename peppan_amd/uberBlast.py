@@ -337,8 +337,8 @@ class RunBlast(object):
         self.min_id, self.min_cov, self.min_ratio = min_id, min_cov, min_ratio
         self.table_id, self.n_thread = table_id, n_thread
         self.pool = useProcess            # accepted for signature compatibility; the GPU path does not fan out
-        tables = self._run_tools(methods, ref, qry)
-        return self._post(tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end)
+        tables = self._run_tools(methods, ref, qry, rescore=re_score)
+        return self._post(tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end, rescored=self._rescored_by_tools)
 
     def _tool_table(self):
         """tool name -> callable(ref, qry).  Inside run() the built-in tools hand over the numeric HitTable (no Python object per cell);
@@ -359,18 +359,28 @@ class RunBlast(object):
             diamondself = lambda ref, qry: self.runDiamond(ref, qry, nhits=200, frames='F')
         return dict(blastn=blastn, diamond=diamond, diamondself=diamondself, gpu=diamond)
 
-    def _run_tools(self, methods, ref, qry):
+    def _run_tools(self, methods, ref, qry, rescore=0):
         """the tools of one run in the order given.  A tool that fails is reported and the other tools' tables are kept - the reference's
         convention (uberBlast.py:347-349) - but never silently: `failed_tools` lists (tool, message) of this run, and a PEP_ERR_LIMIT
-        (an input beyond a documented limit) is raised instead of costing a whole table."""
+        (an input beyond a documented limit) is raised instead of costing a whole table.
+        rescore=1 (-s 1): when the tools run side by side, each rescores its own table (K7 is a function of the row alone, uberBlast.py:397-415)
+        in its own context while the other tool is still searching; `_rescored_by_tools` tells _post that only the identity cut is left."""
         tools = self._tool_table()
         tables, self.failed_tools = [], []
+        self._rescored_by_tools = False
         todo = [m for m in methods if m.lower() in tools]
 
         def attempt(method):
             """one tool -> ('ok', table) | ('limit', exception) | ('failed', method, message)"""
             try:
-                return ('ok', _as_table(tools[method.lower()](ref, qry)))
+                T = _as_table(tools[method.lower()](ref, qry))
+                if self._rescored_by_tools:
+                    try:
+                        ctx = get_nucl_context(self.device) if method.lower() == 'blastn' else get_context(self.device)
+                        T = self._rescore_table(ref, qry, T, 1, None, self.table_id, cut=False, ctx=ctx)
+                    except BaseException as e:    # (a failure of the rescoring is the run's, not the tool's: it is raised once both tools are back)
+                        return ('limit', e)
+                return ('ok', T)
             except N.PepError as e:
                 if 'PEP_ERR_LIMIT' in str(e) or '(-3)' in str(e):
                     return ('limit', e)           # an input beyond a documented limit must not silently cost a whole tool's hits
@@ -392,6 +402,7 @@ class RunBlast(object):
             self._ensure_nt(get_context(self.device), 3 if set(names) <= {'blastn', 'diamondself'} else 6)       # (shared preparations first: the threads only read them)
             self._ensure_nt(get_nucl_context(self.device))
             k_side = names.index('blastn')
+            self._rescored_by_tools = rescore == 1
             side = threading.Thread(target=lambda: outcomes.__setitem__(k_side, attempt(todo[k_side])))
             # (a thread that comes back from the library waits for the interpreter lock until the other one gives it up: at the default 5 ms
             # between such requests the two tools cost more side by side than one after the other - 30.5 against 29.1 ms per call; at 0.1 ms 24.0)
@@ -694,14 +705,14 @@ class RunBlast(object):
             return blastab
         return self._rescore_table(ref, qry, HitTable.from_rows(blastab), mode, min_id, table_id).to_rows()
 
-    def _rescore_table(self, ref, qry, T, mode, min_id, table_id=11, cut=True):
+    def _rescore_table(self, ref, qry, T, mode, min_id, table_id=11, cut=True, ctx=None):
         """Mode 1: integer counts on the GPU (K7), float arithmetic and np.round in float64 here.  Modes 2 / 3 (amino-acid / codon-position
         scoring, not used by PEPPAN's calls) walk the rows on the host.  cut=False: identity and score are replaced in place and every row stays"""
         self._load(ref, qry)
         if len(T) == 0:
             return T
         if mode == 1:
-            ctx = get_context(self.device)
+            ctx = ctx or get_context(self.device)
             self._ensure_nt(ctx)
             h = np.zeros(len(T), dtype=N.NT_HIT_DTYPE)
             # (a table of this instance's own tools carries the name tables the sides were prepared with: row codes ARE sequence indices)
