@@ -288,6 +288,74 @@ def _container_cpu():
         return None
 
 
+_BUSY_SAMPLER = r"""
+import glob, sys, time
+import os
+mine = [os.path.basename(r) for r in sorted(glob.glob('/dev/dri/renderD*')) if os.access(r, os.R_OK | os.W_OK)]        # the devices this job may open
+paths = []
+for r in mine:                                  # (render minor 128 + k belongs to card k; other jobs' cards are visible in sysfs too and are not this job's business)
+    for p in ('/sys/class/drm/%s/device/gpu_busy_percent' % r, '/sys/class/drm/card%d/device/gpu_busy_percent' % (int(r[7:]) - 128)):
+        if os.path.exists(p):
+            paths.append(p)
+            break
+out = open(sys.argv[1], 'w')
+out.write('# ' + ' '.join(paths) + '\n')
+while True:
+    vals = []
+    for p in paths:
+        try:
+            vals.append(open(p).read().strip())
+        except Exception:
+            vals.append('-1')
+    out.write('%.4f %s\n' % (time.time(), ' '.join(vals)))
+    out.flush()
+    time.sleep(0.01)
+"""
+
+
+class _GpuBusy(object):
+    """how busy the GPU is over an interval: the driver's gpu_busy_percent (sysfs) sampled every 10 ms by a process of its own (this process's threads
+    are what is being measured).  Only the render nodes this job may open are sampled; of several, the one that was busiest over the interval counts."""
+
+    def __enter__(self):
+        import subprocess, tempfile
+        self.path = tempfile.mktemp(prefix='pep_busy_')
+        try:
+            self.proc = subprocess.Popen([sys.executable, '-c', _BUSY_SAMPLER, self.path], stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:
+            self.proc = None
+        self.frac = self.samples = None
+        return self
+
+    def mark(self):
+        self.t0 = time.time()
+
+    def __exit__(self, *exc):
+        t1 = time.time()
+        if self.proc is None:
+            return False
+        self.proc.terminate()
+        try:
+            self.proc.wait(5)
+        except Exception:
+            self.proc.kill()
+        try:
+            rows = [l.split() for l in open(self.path) if not l.startswith('#')]
+            rows = [r for r in rows if len(r) > 1 and self.t0 <= float(r[0]) <= t1]
+            if rows:
+                cols = list(zip(*[[max(0, int(x)) for x in r[1:]] for r in rows]))
+                best = max(cols, key=sum)
+                self.frac, self.samples = sum(best) / (100.0 * len(best)), len(best)
+        except Exception:
+            pass
+        finally:
+            try:
+                os.remove(self.path)
+            except OSError:
+                pass
+        return False
+
+
 def map_strong(args, rank, world, local_rank, n_total, workers=0, warm=False):
     """BASELINE configs[3] / [4], mapping stage, as STRONG scaling: ONE fixed set of n_total synthetic genomes against the exemplar genes through
     get_map_bsn (PEPPAN.py:907-989) - the genomes dealt to the ranks in blocks of 32 (each rank searches its blocks on its own GPU: batched search of
@@ -353,8 +421,12 @@ def map_strong(args, rank, world, local_rank, n_total, workers=0, warm=False):
                     extra['workers_startup_s'] = time.perf_counter() - t0
                     extra['first_pass_s'] = once(pool)
                     c0, p0 = _container_cpu(), time.process_time()
-                    dt = once(pool)
+                    with _GpuBusy() as busy:
+                        time.sleep(0.05)                   # (the sampler's start-up)
+                        busy.mark()
+                        dt = once(pool)
                     c1 = _container_cpu()
+                    extra['gpu_busy_frac'], extra['gpu_busy_samples'] = busy.frac, busy.samples
                     extra['keeper_process_cpu_s'] = time.process_time() - p0         # (this process alone, all its threads)
                     extra['keeper_feeders_s'] = dict(pool.spent)
                     if c0 and c1:                      # CPU seconds the whole container (this process, its workers) used over the timed pass; times it hit its allowance
@@ -1030,6 +1102,9 @@ def main():
             extras['map_workload']['worker_pool'] = {'workers': n_pool, 'genomes': n_set, 'genomes_per_s_with_stores': n_set / ps['seconds'], 'seconds': ps['seconds'],
                                                      'first_pass_s': ps['first_pass_s'], 'workers_startup_s': ps['workers_startup_s'], 'phase_s': ps['phase_s_rank0'],
                                                      'container_cpu_s': ps.get('container_cpu_s'), 'cpu_throttled_periods': ps.get('throttled_periods'), 'cpus_granted': effective_cpus(),
+                                                     'gpu_busy_frac': ps.get('gpu_busy_frac'), 'gpu_busy_samples': ps.get('gpu_busy_samples'),
+                                                     'gpu_busy_note': "the driver's gpu_busy_percent (sysfs) sampled every 10 ms over the timed pass by a process of its own, setup and archive closes included",
+                                                     'rounds_genomes_per_s': n_set / ps['phase_s_rank0']['groups'] if ps['phase_s_rank0'].get('groups') else None,
                                                      'note': 'get_map_bsn(..., workers=8) over ONE set of 512 genomes, four stores written; second pass of a started pool '
                                                              '(first_pass_s: the first one, with every worker\'s first search). python bench.py --workload map --map-scaling strong --map-workers 8'}
         except Exception as e:                                  # never lose the headline over the secondary leg

@@ -14,5 +14,7 @@ for w in ws:
     if 'container_cpu_s' in r:
         print('   container CPU over the timed pass: %.1f s = %.0f ms per mapped genome, %.1f CPUs busy on average, throttled in %d periods of 100 ms; the keeping process alone %.2f s' % (
             r['container_cpu_s'], r['container_cpu_s'] / n * 1e3, r['container_cpu_s'] / r['seconds'], r['throttled_periods'], r['keeper_process_cpu_s']), r.get('keeper_feeders_s'))
+    if r.get('gpu_busy_frac') is not None:
+        print('   GPU busy over the timed pass: %.0f %% (%d samples of gpu_busy_percent)' % (100 * r['gpu_busy_frac'], r['gpu_busy_samples']))
     print('workers %2d: %d genomes in %.2f s = %.1f genomes/s (first pass %.2f s, start-up %.2f s)  %s' % (
         w, n, r['seconds'], n / r['seconds'], r.get('first_pass_s', float('nan')), r.get('workers_startup_s', 0.), {k: round(v, 2) for k, v in r['phase_s_rank0'].items()}), flush=True)
