@@ -86,7 +86,11 @@ typedef struct {
                                      of the packed 16-bit ones, [2] != 0 forces the count -> scan -> fill build of the query seed index */
     double ka_lambda, ka_k;       /* Karlin-Altschul parameters of the scoring system (protein default 0.267 / 0.041) */
     int32_t hsp_mode;             /* 0: one alignment per (q, t), its best band (diamond --max-hsps 1); 1: every band reaching the
-                                     score threshold, duplicates (same end cell) removed - several copies on one subject */
+                                     score threshold, duplicates (same end cell) removed - several copies on one subject; 2: BLAST's way with the
+                                     HSPs of a subject (blastn behind uberBlast.py:294): the bands of (q, t) in the order score descending, band ascending,
+                                     one dropped when an ACCEPTED one in front shares its start or its end cell or holds its query and subject ranges
+                                     inside its own; top_k counts subjects (the reference sequence a target is a strand / frame of), every alignment of
+                                     a kept subject stays.  Needs targets made by pep_translate / pep_use_nt_as_residues. */
     int32_t t_index_base;         /* index of this context's target 0 in the WHOLE reference set when the targets are one shard of it (multi-GPU
                                      target sharding, peppan_amd/dist.py): split membership is (t + t_index_base) mod n_splits, so a shard ranks
                                      its hits exactly as the unsharded search would; 0 otherwise.  Ignored with pep_set_target_groups. */

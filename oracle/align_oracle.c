@@ -66,7 +66,13 @@ typedef struct {
     int32_t ext_left;      /* max residues scored to the left of the seed's first position */
     int32_t hsp_mode;      /* 0: one alignment per (q, t) = its best band (diamond --max-hsps 1);
                               1: every band of (q, t) that reaches min_score, minus duplicates (same end cell: keep the
-                                 higher score, then the lower bin) - the nucleotide tool, where a subject can carry several copies */
+                                 higher score, then the lower bin) - the nucleotide tool, where a subject can carry several copies;
+                              2: BLAST's way with the HSPs of a subject (blastn behind uberBlast.py:294, `-num_alignments 1000`, no binary here to pin it
+                                 against: NCBI's published behaviour restated) - the bands of (q, t) that reach min_score are taken in the order score
+                                 descending, bin ascending, and one is dropped when an ACCEPTED one before it shares its start cell or its end cell
+                                 (Blast_HSPListPurgeHSPsWithCommonEndpoints) or holds its query range and its subject range inside its own (the interval-tree
+                                 containment test of the gapped stage); and top_k counts SUBJECTS (oracle_set_subjects: targets that are strands / frames of
+                                 one sequence), ranked by their best alignment - every alignment of a kept subject stays */
     int32_t t_base;        /* index of target 0 in the whole reference set when the targets are one shard of it: split = (t + t_base) mod n_splits */
     int32_t stage1_min;    /* first stage of the pre-filter: the right extension must have reached this after its first STAGE1_LEN residues (0 = off) */
     int32_t pad0;
@@ -473,6 +479,10 @@ static int cmp_hit_rank(const void *a, const void *b)
 
 typedef struct { int32_t bin, score, iend, jend, is, js; uint32_t nid, al, nruns; uint64_t cells; uint32_t *runs; int dead; } band_aln;
 
+/* hsp_mode 2: the subject (sequence) every target belongs to; NULL = every target is a subject of its own */
+static const uint32_t *g_subject = NULL;
+void oracle_set_subjects(const uint32_t *subject) { g_subject = subject; }
+
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -561,6 +571,26 @@ static void align_group(const oracle_params *p, const uint64_t *cand, uint64_t g
                     for (uint32_t x = 0; x < rb.n; ++x) b->runs[x] = rb.runs[rb.n - 1 - x];
                 }
             }
+            if (p->hsp_mode == 2) {
+                /* in rank order (score descending, bin ascending = position ascending): against the accepted ones in front */
+                uint64_t *ord = malloc((na + 1) * sizeof(uint64_t));
+                for (uint64_t x = 0; x < na; ++x) ord[x] = x;
+                for (uint64_t x = 1; x < na; ++x) {                       /* insertion sort: stable, al_ is in bin order */
+                    uint64_t v = ord[x], y = x;
+                    while (y > 0 && al_[ord[y - 1]].score < al_[v].score) { ord[y] = ord[y - 1]; --y; }
+                    ord[y] = v;
+                }
+                for (uint64_t a = 0; a < na; ++a) {
+                    band_aln *x = &al_[ord[a]];
+                    for (uint64_t b = 0; b < a && !x->dead; ++b) {
+                        const band_aln *y = &al_[ord[b]];
+                        if (y->dead) continue;
+                        if ((x->iend == y->iend && x->jend == y->jend) || (x->is == y->is && x->js == y->js) ||
+                            (y->is <= x->is && x->iend <= y->iend && y->js <= x->js && x->jend <= y->jend)) x->dead = 1;
+                    }
+                }
+                free(ord);
+            } else
             for (uint64_t x = 0; x < na; ++x)
                 for (uint64_t y = 0; y < na; ++y)
                     if (x != y && al_[x].iend == al_[y].iend && al_[x].jend == al_[y].jend &&
@@ -643,6 +673,19 @@ int oracle_search(const oracle_params *p,
             uint64_t m = 0;
             for (uint64_t k = a; k < b; ++k) if ((int)((hits[k].t + (uint32_t)(p->t_base % p->n_splits)) % (uint32_t)p->n_splits) == s) tmp[m++] = &hits[k];
             qsort(tmp, m, sizeof(*tmp), cmp_hit_rank);
+            if (p->hsp_mode == 2) {
+                /* the first alignment of a subject in rank order is its best: subjects are counted as they show up, every alignment of the first top_k stays */
+                uint64_t n_subj = 0;
+                uint32_t *seen = malloc((m + 1) * sizeof(uint32_t));
+                for (uint64_t k = 0; k < m; ++k) {
+                    const uint32_t sj = g_subject ? g_subject[tmp[k]->t] : tmp[k]->t;
+                    uint64_t at = 0;
+                    while (at < n_subj && seen[at] != sj) ++at;
+                    if (at == n_subj) seen[n_subj++] = sj;
+                    if (at < (uint64_t)p->top_k) keep[tmp[k] - hits] = 1;
+                }
+                free(seen);
+            } else
             for (uint64_t k = 0; k < m && k < (uint64_t)p->top_k; ++k) keep[tmp[k] - hits] = 1;
         }
         a = b;

@@ -68,6 +68,8 @@ def lib():
         _lib = C.CDLL(LIB)
         _lib.oracle_min_score.restype = C.c_int32
         _lib.oracle_min_score.argtypes = [C.c_uint32, C.c_double, C.c_double]
+        _lib.oracle_set_subjects.argtypes = [C.c_void_p]
+        _lib.oracle_set_subjects.restype = None
         _lib.oracle_set_threads(granted_cpus())
     return _lib
 
@@ -124,8 +126,8 @@ def pack(seqs):
     return np.ascontiguousarray(res), off
 
 
-def search(q_seqs, t_seqs, params=None, min_scores=None, dbsize=5e6, max_evalue=1.):
-    """q_seqs / t_seqs: lists of uint8 residue-code arrays.
+def search(q_seqs, t_seqs, params=None, min_scores=None, dbsize=5e6, max_evalue=1., subjects=None):
+    """q_seqs / t_seqs: lists of uint8 residue-code arrays.  subjects (hsp_mode 2): the sequence every target is a strand / frame of.
     returns (hits structured array, cigar uint32 array (len<<2|op), stats dict)"""
     L = lib()
     p = params or default_params()
@@ -141,9 +143,13 @@ def search(q_seqs, t_seqs, params=None, min_scores=None, dbsize=5e6, max_evalue=
         qr = np.zeros(1, np.uint8)
     if len(tr) == 0:
         tr = np.zeros(1, np.uint8)
+    subj = None if subjects is None else np.ascontiguousarray(subjects, dtype=np.uint32)
+    assert subj is None or len(subj) == len(t_seqs)
+    L.oracle_set_subjects(None if subj is None else subj.ctypes.data_as(C.c_void_p))
     rc = L.oracle_search(C.byref(p), qr.ctypes.data_as(C.c_void_p), qo.ctypes.data_as(C.c_void_p), C.c_uint32(len(q_seqs)),
                          tr.ctypes.data_as(C.c_void_p), to.ctypes.data_as(C.c_void_p), C.c_uint32(len(t_seqs)),
                          min_scores.ctypes.data_as(C.c_void_p), C.byref(hits_p), C.byref(nh), C.byref(cig_p), C.byref(ncg), stats)
+    L.oracle_set_subjects(None)
     assert rc == 0
     n = nh.value
     hits = np.zeros(n, dtype=HIT_DTYPE)

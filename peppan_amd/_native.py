@@ -137,7 +137,7 @@ def min_score(qlen, dbsize=5e6, max_evalue=1.):
     return int(load_library().pep_min_score(int(qlen), float(dbsize), float(max_evalue)))
 
 
-def nucleotide_params(min_id_pct=0., min_qcov_pct=0., top_k=1000, dbsize=5e6, max_evalue=1e-2):
+def nucleotide_params(min_id_pct=0., min_qcov_pct=0., top_k=1000, dbsize=5e6, max_evalue=1e-2, hsp_mode=1):
     """the search engine configured like the reference's blastn call (uberBlast.py:294): residues A0 C1 G2 T3 (other 4),
     exact 17-mers (-word_size 17), reward 2 / penalty -3, gap 6 + 2k, e-value 1e-2 at dbsize 5e6, 1000 targets per query.
     Karlin-Altschul lambda 0.625 / K 0.41 are NCBI's published values for 2/-3 with gap costs 5/2 (closest tabulated)."""
@@ -156,7 +156,9 @@ def nucleotide_params(min_id_pct=0., min_qcov_pct=0., top_k=1000, dbsize=5e6, ma
     p.ungapped_min, p.xdrop, p.ext_right, p.ext_left = 40, 16, 40, 24
     p.stage1_min = 0                     # (an exact 17-mer scores 32 over its first 16 bases: the first stage has nothing to reject here)
     p.ka_lambda, p.ka_k = 0.625, 0.41
-    p.hsp_mode = 1                       # blastn reports every HSP of a subject; a contig can carry several copies of a gene
+    if hsp_mode not in (1, 2):
+        raise ValueError('nucleotide_params: hsp_mode 1 (every band that reaches the threshold) or 2 (BLAST-like culling, top_k counts subjects)')
+    p.hsp_mode = hsp_mode                # blastn reports every HSP of a subject; a contig can carry several copies of a gene.  2: include/peppan_hip.h
     return p
 
 

@@ -540,7 +540,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
     if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
     if (ctx->pin_ms.p) (void)hipHostFree(ctx->pin_ms.p);
-    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->fused_state[0].buf, &ctx->fused_state[1].buf, &ctx->fused_state[2].buf, &ctx->fused_state[3].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_trace_defer, &ctx->d_k1_base, &ctx->d_t_class, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
+    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->fused_state[0].buf, &ctx->fused_state[1].buf, &ctx->fused_state[2].buf, &ctx->fused_state[3].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_trace_defer, &ctx->d_k1_base, &ctx->d_t_class, &ctx->d_t_subject, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq,
                       &ctx->sort_state, &ctx->sort_hist, &ctx->d_set, &ctx->d_zero, &ctx->d_k1_desc_q, &ctx->d_k1_desc_t, &ctx->d_mail_copy,
                       &ctx->nucl_q.d_off, &ctx->nucl_q.d_len, &ctx->nucl_q.d_desc, &ctx->nucl_t.d_off, &ctx->nucl_t.d_len, &ctx->nucl_t.d_desc};
@@ -721,7 +721,7 @@ static int build_t_class(pep_ctx *ctx)
         ++local;
     }
     PEP_TRY(dev_reserve(ctx, ctx->d_t_class, (size_t)(nt + 1) * 4));
-    PEP_HIP(ctx, hipMemcpy(ctx->d_t_class.p, cls.data(), (size_t)(nt + 1) * 4, hipMemcpyHostToDevice));
+    PEP_TRY(pep_h2d(ctx, ctx->d_t_class.p, cls.data(), (size_t)(nt + 1) * 4));
     ctx->t_class_ready = true;
     return PEP_OK;
 }
@@ -748,7 +748,7 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
                 if (params->reduce[c] != 0xFF && params->reduce[c] >= params->base) return pep_fail(ctx, PEP_ERR_ARG, "reduced letter outside the alphabet");
         }
         if (params->t_index_base < 0) return pep_fail(ctx, PEP_ERR_ARG, "t_index_base must not be negative");
-        if (params->hsp_mode != 0 && params->hsp_mode != 1) return pep_fail(ctx, PEP_ERR_ARG, "hsp_mode must be 0 or 1");
+        if (params->hsp_mode < 0 || params->hsp_mode > 2) return pep_fail(ctx, PEP_ERR_ARG, "hsp_mode must be 0, 1 or 2");
         if (params->stage1_min < 0 || (params->ungapped_min > 0 && params->stage1_min > params->ungapped_min))
             return pep_fail(ctx, PEP_ERR_ARG, "stage1_min must lie between 0 and ungapped_min");
         if (!(params->ka_lambda > 0.) || !(params->ka_k > 0.)) return pep_fail(ctx, PEP_ERR_ARG, "invalid Karlin-Altschul parameters");

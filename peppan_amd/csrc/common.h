@@ -132,6 +132,7 @@ struct pep_ctx {
     DevBuf d_trace_mode;                    // per traced pair: first lane of the sub-band its traceback codes cover, -1 = the full band (sw.hip)
     std::vector<uint32_t> group_of_seq;     // optional: competition group of every reference sequence (pep_set_target_groups)
     DevBuf d_t_class;
+    DevBuf d_t_subject;                         // hsp_mode 2: the reference sequence every target is a strand / frame / chunk of (uploaded per search)
     bool t_class_ready = false;
     // workspaces (grow-only, reused between searches)
     DevBuf ws[24];

@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void select_gather(const uint64_t *__restrict_
     const int heads = __syncthreads_count(head);                 // (q, t) groups that start in this tile: one atomic per block
     if (threadIdx.x == 0 && heads) atomicAdd(&counters[0], (uint32_t)heads);
     uint32_t f = 0, b = (uint32_t)c;
-    if (live && hsp_mode == 1) {
-        // every band that reaches the threshold is traced; duplicates are removed after the walk (dedupe_bands)
+    if (live && hsp_mode != 0) {
+        // every band that reaches the threshold is traced; duplicates are removed after the walk (dedupe_bands; hsp_mode 2: cull_hsps)
         if (sw[c].x > 0 && sw[c].x >= min_score[key_q(cands[c])]) f = 1;
     } else if (head) {
         int best = sw[c].x;
@@ -353,6 +353,67 @@ __global__ __launch_bounds__(256) void dedupe_bands(const uint32_t *__restrict__
     if (dead) sel[s].pad = 1u;
 }
 
+// hsp_mode 2 (BLAST's way with the HSPs of one subject strand, oracle/align_oracle.c align_group): the alignments of a (q, t) group in the order score
+// descending, position ascending; one is dropped when an ACCEPTED one in front of it shares its start cell or its end cell, or holds its query range and
+// its subject range inside its own.  Order-dependent, so the group's first thread works the group off alone; groups are a handful of bands (a repeat
+// family makes dozens).  pad: 0 not looked at yet, 2 accepted (back to 0 at the end), 1 dropped.
+__global__ __launch_bounds__(256) void cull_hsps(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands)
+{
+    const int64_t n_sel = (int64_t)*d_n_sel;
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_sel) return;
+    const uint64_t g = cands[sel[s].cand] >> 18;
+    if (s > 0 && (cands[sel[s - 1].cand] >> 18) == g) return;
+    int64_t e = s + 1;
+    while (e < n_sel && (cands[sel[e].cand] >> 18) == g) ++e;
+    if (e - s == 1) return;
+    for (int64_t it = s; it < e; ++it) {
+        int64_t best = -1;
+        int32_t best_score = 0;
+        for (int64_t x = s; x < e; ++x)
+            if (sel[x].pad == 0u && (best < 0 || sel[x].score > best_score)) { best = x; best_score = sel[x].score; }
+        const SelInfo me = sel[best];
+        bool dead = false;
+        for (int64_t y = s; y < e && !dead; ++y) {
+            if (sel[y].pad != 2u) continue;
+            const SelInfo o = sel[y];
+            dead = (o.iend == me.iend && o.jend == me.jend) || (o.istart == me.istart && o.jstart == me.jstart) ||
+                   (o.istart <= me.istart && me.iend <= o.iend && o.jstart <= me.jstart && me.jend <= o.jend);
+        }
+        sel[best].pad = dead ? 1u : 2u;
+    }
+    for (int64_t x = s; x < e; ++x)
+        if (sel[x].pad == 2u) sel[x].pad = 0u;
+}
+
+// hsp_mode 2, in front of topk: keep = 1 for the best alignment of its subject among the query's passing alignments of one competition class
+// (score descending, position ascending - the order topk ranks in)
+__global__ __launch_bounds__(256) void subject_best(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int n_splits, uint32_t t_base,
+                                                    const uint32_t *__restrict__ t_class, const uint32_t *__restrict__ t_subject)
+{
+    const int64_t n_sel = (int64_t)*d_n_sel;
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_sel) return;
+    const SelInfo me = sel[s];
+    uint32_t best = 0;
+    if (me.pass) {
+        const uint64_t key = cands[me.cand];
+        const uint32_t q = key_q(key), t = key_t(key), split = t_class ? t_class[t] : (t + t_base) % (uint32_t)n_splits, sj = t_subject[t];
+        best = 1;
+        for (int dir = -1; dir <= 1 && best; dir += 2) {
+            for (int64_t x = s + dir; x >= 0 && x < n_sel; x += dir) {
+                const SelInfo o = sel[x];
+                const uint64_t ko = cands[o.cand];
+                if (key_q(ko) != q) break;
+                const uint32_t to = key_t(ko);
+                if (!o.pass || t_subject[to] != sj || (t_class ? t_class[to] : (to + t_base) % (uint32_t)n_splits) != split) continue;
+                if (o.score > me.score || (o.score == me.score && x < s)) { best = 0; break; }
+            }
+        }
+    }
+    sel[s].keep = best;
+}
+
 __global__ __launch_bounds__(256) void apply_dedupe(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel)
 {
     const uint64_t s = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -365,7 +426,7 @@ __global__ __launch_bounds__(256) void apply_dedupe(const uint32_t *__restrict__
 __global__ __launch_bounds__(256) void topk(const uint32_t *__restrict__ d_n_sel, SelInfo *__restrict__ sel, const uint64_t *__restrict__ cands, int top_k, int n_splits, uint32_t t_base,
                                             const uint32_t *__restrict__ t_class, uint32_t *__restrict__ keep_flag, uint32_t *__restrict__ hit_pos, uint64_t *__restrict__ cig_pos,
                                             const unsigned long long *__restrict__ score_hdr, const unsigned long long *__restrict__ trace_hdr, unsigned long long *__restrict__ mail,
-                                            SelectState st)
+                                            SelectState st, const uint32_t *__restrict__ t_subject = nullptr)
 {
     // top-k decision per selected pair AND the two compactions behind it (slot of the hit record, slot of its CIGAR runs) in one launch:
     // the tile scans (kept, runs of the kept) and finds the totals in front of it by look-back (lookback.h)
@@ -389,6 +450,32 @@ __global__ __launch_bounds__(256) void topk(const uint32_t *__restrict__ d_n_sel
             const uint64_t key = cands[me.cand];
             const uint32_t q = key_q(key), t = key_t(key), split = t_class ? t_class[t] : (t + t_base) % (uint32_t)n_splits;
             uint32_t rank = 0;
+            if (t_subject) {
+                // hsp_mode 2: top_k counts subjects.  This alignment's subject is as good as its best alignment (subject_best marked it: keep = 1);
+                // its rank = the subjects of the same query and class whose best alignment stands in front of that one
+                const uint32_t sj = t_subject[t];
+                int64_t mine = (int64_t)s;
+                int32_t mine_score = me.score;
+                if (!me.keep)
+                    for (int dir = -1; dir <= 1 && mine == (int64_t)s; dir += 2)
+                        for (int64_t x = (int64_t)s + dir; x >= 0 && x < (int64_t)n_sel; x += dir) {
+                            const SelInfo o = sel[x];
+                            const uint64_t ko = cands[o.cand];
+                            if (key_q(ko) != q) break;
+                            const uint32_t to = key_t(ko);
+                            if (o.pass && o.keep && t_subject[to] == sj && (t_class ? t_class[to] : (to + t_base) % (uint32_t)n_splits) == split) { mine = x; mine_score = o.score; break; }
+                        }
+                for (int dir = -1; dir <= 1; dir += 2) {
+                    for (int64_t x = (int64_t)s + dir; x >= 0 && x < (int64_t)n_sel; x += dir) {
+                        const SelInfo o = sel[x];
+                        const uint64_t ko = cands[o.cand];
+                        if (key_q(ko) != q) break;
+                        const uint32_t to = key_t(ko);
+                        if (!o.pass || !o.keep || t_subject[to] == sj || (t_class ? t_class[to] : (to + t_base) % (uint32_t)n_splits) != split) continue;
+                        if (o.score > mine_score || (o.score == mine_score && x < mine)) ++rank;
+                    }
+                }
+            } else
             for (int dir = -1; dir <= 1; dir += 2) {
                 for (int64_t x = (int64_t)s + dir; x >= 0 && x < (int64_t)n_sel; x += dir) {
                     const SelInfo o = sel[x];
@@ -646,9 +733,23 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
         hipLaunchKernelGGL(finalize, dim3(gfin), dim3(256), 0, st, d_n_sel, sel, (const uint64_t *)sel_keys, ctx->q.res.as<const uint8_t>(),
                            ctx->q.off.as<const uint32_t>(), ctx->q.len.as<const uint32_t>(), ctx->t.res.as<const uint8_t>(),
                            ctx->t.off.as<const uint32_t>(), (const uint64_t *)run_off, (const uint32_t *)runs, P.min_id_pct, P.min_qcov_pct);
+        const uint32_t *t_subject = nullptr;
         if (P.hsp_mode == 1) {
             hipLaunchKernelGGL(dedupe_bands, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, sel, (const uint64_t *)sel_keys);
             hipLaunchKernelGGL(apply_dedupe, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, sel);
+        } else if (P.hsp_mode == 2) {
+            hipLaunchKernelGGL(cull_hsps, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, sel, (const uint64_t *)sel_keys);
+            hipLaunchKernelGGL(apply_dedupe, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, sel);
+            // the subject of every target: the reference sequence it is a strand / frame / chunk of (K1's table)
+            PEP_TRY(pep_k1_host_tables(ctx));
+            if (ctx->t_meta.size() != ctx->t.n) return pep_fail(ctx, PEP_ERR_STATE, "hsp_mode 2 needs the targets' sequence table (targets made by pep_translate / pep_use_nt_as_residues)");
+            std::vector<uint32_t> subj(ctx->t.n + 1, 0u);
+            for (uint32_t t = 0; t < ctx->t.n; ++t) subj[t] = ctx->t_meta[t].seq;
+            PEP_TRY(dev_reserve(ctx, ctx->d_t_subject, ((size_t)ctx->t.n + 1) * 4));
+            PEP_TRY(pep_h2d(ctx, ctx->d_t_subject.p, subj.data(), ((size_t)ctx->t.n + 1) * 4));
+            t_subject = ctx->d_t_subject.as<const uint32_t>();
+            hipLaunchKernelGGL(subject_best, dim3((unsigned)ceil_div(n_b, 256)), dim3(256), 0, st, d_n_sel, sel, (const uint64_t *)sel_keys, P.n_splits, (uint32_t)(P.t_index_base % P.n_splits),
+                               ctx->t_class_ready ? ctx->d_t_class.as<const uint32_t>() : (const uint32_t *)nullptr, t_subject);
         }
         // top-k, then compaction of hits and CIGAR runs
         PEP_TRY(dev_reserve(ctx, ctx->ws[22], ((size_t)n_b + 2) * (4 + 4 + 8)));
@@ -664,7 +765,7 @@ int pep_extend(pep_ctx *ctx, const uint64_t *d_cands, uint64_t n, const int32_t 
             ts.epoch_run = ep;
             hipLaunchKernelGGL(topk, dim3((unsigned)tiles), dim3(256), 0, st, d_n_sel, sel, (const uint64_t *)sel_keys, P.top_k, P.n_splits,
                                (uint32_t)(P.t_index_base % P.n_splits), ctx->t_class_ready ? ctx->d_t_class.as<const uint32_t>() : (const uint32_t *)nullptr, keep_flag, hit_pos, cig_pos,
-                               (const unsigned long long *)score_hdr, (const unsigned long long *)trace_hdr, mail, ts);
+                               (const unsigned long long *)score_hdr, (const unsigned long long *)trace_hdr, mail, ts, t_subject);
         }
         if (fast && !ctx->device_results && pin_reserve(ctx, ctx->pin_stage, PACK_HEADER) == PEP_OK) {
             // the result leaves through pack_out: output buffers from the same upper bounds, no look at the sizes, no synchronisation here

@@ -330,6 +330,9 @@ class RunBlast(object):
         self._nt_loaded = None
         self._batch = None                  # (reference names genome-major, genome id per name) in run_batch
         self._as_tables = False             # True: run() / run_batch() hand over the numeric HitTable instead of object rows
+        # how the nucleotide tool treats the HSPs of one subject: 1 (default) every 64-diagonal band that reaches the threshold; 2 BLAST-like culling
+        # (start / end cell shared with, or ranges inside, a better accepted HSP) and -num_alignments counted per subject (include/peppan_hip.h, hsp_mode)
+        self.blast_hsp_mode = int(os.environ.get('PEPPAN_BLAST_HSP_MODE', '1'))
 
     # ---------------------------------------------------------------------------------------------- driver
     def run(self, ref, qry, methods, min_id, min_cov, min_ratio, table_id=11, n_thread=8, useProcess=False, re_score=0,
@@ -614,7 +617,7 @@ class RunBlast(object):
         logger('Run BLASTn starts')
         self._load(ref, qry)
         ctx = get_nucl_context(self.device) if self._batch is None else get_context(self.device)        # (a batch of genomes: one context, tool after tool)
-        params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100.)
+        params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100., hsp_mode=self.blast_hsp_mode)
         if max(map(len, self.refSeq.values()), default=0) <= N.MAX_SEQ_LEN:
             # the usual case: the nucleotide sets that K1 and K7 read on the device are packed THERE into the base-code residue sets of this
             # search (forward strands, then reverse complements, per reference set) - no encoding, concatenation or upload on the host

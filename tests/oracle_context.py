@@ -39,6 +39,7 @@ class OracleContext(object):
     def set_ref_aa(self, seqs):
         self.t_aa = self._unpack(seqs)
         self._direct = True
+        self._raw_targets = True
 
     def alleles(self, contigs, rows, cigar, grp_off, grp_qlen, gtable=11):
         return O.alleles([c.encode('ascii') if isinstance(c, str) else bytes(c) for c in contigs], rows, cigar, grp_off, grp_qlen, gtable)
@@ -62,6 +63,7 @@ class OracleContext(object):
         self._qm = np.array([(i, 1, len(c), len(c)) for i, c in enumerate(self.q_aa)], dtype=N.QUERY_META_DTYPE).reshape(-1)
         self._tm = np.array([(i % n, 1 if i < n else 4, 0, len(c)) for i, c in enumerate(self.t_aa)], dtype=N.TARGET_META_DTYPE).reshape(-1)
         self._direct = True
+        self._raw_targets = False
 
     def translate(self, force=False):
         if hasattr(self, 'q_nt') and hasattr(self, 'r_nt') and getattr(self, 'q_aa_given', False) is False:
@@ -85,6 +87,7 @@ class OracleContext(object):
                     self.t_aa.append(O.aa_codes(c))
         self._qm = np.array(qm, dtype=N.QUERY_META_DTYPE).reshape(-1)
         self._tm = np.array(tm, dtype=N.TARGET_META_DTYPE).reshape(-1)
+        self._raw_targets = False
 
     def query_meta(self):
         return self._qm
@@ -96,7 +99,11 @@ class OracleContext(object):
         self._translate_now()
         p = O.params_from(params)
         ms = np.array([O.min_score(len(s), params.dbsize, params.max_evalue, params.ka_lambda, params.ka_k) for s in self.q_aa], dtype=np.int32)
-        h, c, st = O.search(self.q_aa, self.t_aa, p, min_scores=ms)
+        subjects = None
+        if params.hsp_mode == 2:            # the reference sequence every target is a strand / frame / chunk of (the library takes it from K1's table)
+            tm = getattr(self, '_tm', None)
+            subjects = tm['seq'] if tm is not None and len(tm) == len(self.t_aa) and not getattr(self, '_raw_targets', False) else np.arange(len(self.t_aa))
+        h, c, st = O.search(self.q_aa, self.t_aa, p, min_scores=ms, subjects=subjects)
         out = np.zeros(len(h), dtype=N.HIT_DTYPE)
         for f in out.dtype.names:
             out[f] = h[f]

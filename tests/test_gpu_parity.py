@@ -1588,3 +1588,56 @@ def test_k1_inside_the_search_equals_translate_in_front(ctx):
     ctx.set_query_nt([], 11); ctx.set_ref_nt(seqs[:50], 6, 11)
     h4, c4, s4 = ctx.search(p)
     assert len(h4) == 0 and len(ctx.target_meta()) >= 300
+
+
+@pytest.mark.gpu
+def test_blast_hsp_mode_2_equals_the_oracle(ctx):
+    """hsp_mode 2 (BLAST's way with the HSPs of a subject; the definition and its made-up cases: tests/test_hsp_mode.py): the kernels - cull_hsps,
+    subject_best, topk's subject ranking - against the oracle, bit for bit.  Genes with tandem repeats and second copies through the nucleotide tool's
+    own layout (forward strands, then reverse complements: the two strands of a sequence are ONE subject), hit lists short enough to cut (top_k 1000 /
+    3 / 1), a contig with several copies of a gene as a raw target, and mode 1 on the same data as the superset."""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    names, seqs = synth.make_genes(150, 0, seed=9)
+    texts = [s.decode() for s in seqs]
+    for i in range(0, 150, 3):
+        t = texts[i]
+        a, b = sorted(rng.integers(50, len(t) - 50, size=2).tolist())
+        rep = t[a:a + 90]
+        texts[i] = t[:a + 90] + rep + t[a + 90:b] + rep[:70] + t[b:]
+    texts[7] = texts[6]                                    # identical genes: ties in score, decided by position
+    codes = [O.nt_codes(t) for t in texts]
+    rc = [(3 - c[::-1]).astype(np.uint8) for c in codes]
+    ctx.set_query_nt(texts)
+    ctx.set_ref_nt(texts, 6, 11)
+    subjects = list(range(len(codes))) * 2
+    sizes = {}
+    for top_k in (1000, 3, 1):
+        for mode in (2, 1):
+            p = N.nucleotide_params(60., 10., top_k=top_k, hsp_mode=mode)
+            ctx.use_nt_as_residues(2)
+            gh, gc, st = ctx.search(p)
+            ms = np.array([O.min_score(len(c), p.dbsize, p.max_evalue, p.ka_lambda, p.ka_k) for c in codes], dtype=np.int32)
+            oh, oc, ost = O.search(codes, codes + rc, O.params_from(p), min_scores=ms, subjects=subjects if mode == 2 else None)
+            _cmp_hits(gh, gc, oh, oc)
+            sizes[(top_k, mode)] = len(gh)
+    print(sizes)
+    assert sizes[(1000, 2)] < sizes[(1000, 1)]             # nested HSPs went
+    assert sizes[(1, 1)] == len(codes) <= sizes[(1, 2)]    # one SUBJECT per query: at least its best alignment
+    assert sizes[(3, 2)] < sizes[(1000, 2)]                # and the list does cut
+    # raw targets (every target its own subject): a contig with two copies of gene 0 and one of gene 4 per strand
+    sp = lambda n: rng.integers(0, 4, n).astype(np.uint8)
+    def mutated(c, rate):
+        c = c.copy(); m = rng.random(len(c)) < rate; c[m] = rng.integers(0, 4, int(m.sum())); return c
+    comp = lambda c: (3 - c[::-1]).astype(np.uint8)
+    contig = np.concatenate([sp(700), codes[0], sp(333), mutated(codes[0], 0.04), sp(90), comp(codes[4]), sp(2000), mutated(codes[4], 0.08), sp(50)])
+    targets = [contig, comp(contig)] + codes[:10]
+    ctx.set_query_aa(codes[:20])
+    ctx.set_ref_aa(targets)
+    p = N.nucleotide_params(70., 25., hsp_mode=2)
+    gh, gc, st = ctx.search(p)
+    ms = np.array([O.min_score(len(c), p.dbsize, p.max_evalue, p.ka_lambda, p.ka_k) for c in codes[:20]], dtype=np.int32)
+    oh, oc, ost = O.search(codes[:20], targets, O.params_from(p), min_scores=ms)
+    _cmp_hits(gh, gc, oh, oc)
+    assert ((gh['q'] == 0) & (gh['t'] == 0) & (gh['q_end'] - gh['q_start'] > 0.9 * len(codes[0]))).sum() == 2       # both copies of gene 0 stay: neither lies inside the other

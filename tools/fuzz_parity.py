@@ -45,7 +45,7 @@ def nucleotide_cases(ctx, cases, rng):
             elif kind == 3: c[-1] = 4
             codes.append(c); codes.append(c.copy())
         targets = codes + [rc[c[::-1]] for c in codes]
-        p = N.nucleotide_params(float(rng.choice([70., 90.])), float(rng.choice([25., 50.])))
+        p = N.nucleotide_params(float(rng.choice([70., 90.])), float(rng.choice([25., 50.])), top_k=int(rng.choice([1000, 1000, 3, 1])), hsp_mode=int(rng.choice([1, 2])))
         flags = int(rng.choice([0, 1, 2, 3, 4, 5]))
         p.reserved2 = flags
         p.reserved[1] = int(rng.integers(0, 4) == 0)
@@ -56,8 +56,8 @@ def nucleotide_cases(ctx, cases, rng):
         bad = [f for f in FIELDS if len(gh) != len(oh) or not np.array_equal(gh[f], oh[f])]
         bad += ['cigar arena'] if not np.array_equal(gc, oc) else []
         bad += ['stat ' + k for k in ('candidates', 'pairs', 'cells', 'tracebacks') if st[k] != ost[k]]
-        print('nucleotide case %3d: %4d sequences x 2 strands, switches %d/%d: %6d candidates (%5d settled), %6d hits  %s'
-              % (case, len(codes), flags, p.reserved[1], st['candidates'], st['candidates_settled'], len(gh), 'ok' if not bad else 'DIFFERENT: ' + ', '.join(bad)), flush=True)
+        print('nucleotide case %3d: %4d sequences x 2 strands, hsp_mode %d top_k %4d, switches %d/%d: %6d candidates (%5d settled), %6d hits  %s'
+              % (case, len(codes), p.hsp_mode, p.top_k, flags, p.reserved[1], st['candidates'], st['candidates_settled'], len(gh), 'ok' if not bad else 'DIFFERENT: ' + ', '.join(bad)), flush=True)
         if bad:
             sys.exit(1)
     print('all %d nucleotide cases identical to the oracle' % cases)
