@@ -745,6 +745,7 @@ def iter_map_bsn(data):
 
 
 # ------------------------------------------------------------------------------------------------ all genomes
+POOL_ROUND = 8                         # genomes per round of a worker pool on one GPU (get_map_bsn)
 MAT_STRATEGY = FAST_DEFLATE            # how the members of the .mat store are deflated: hit rows as a pickle stream - repeated opcodes, similar numbers; zlib's level 1 took 13 ms of CPU per mapped genome
 SEQ_STRATEGY = zlib.Z_HUFFMAN_ONLY      # how the members of the .seq store are deflated.  Packed alleles are all but incompressible by matching (a byte
 #                       holds three bases of three different thirds of an allele): entropy coding alone (pep_deflate_literals, 590 MB/s; zlib's Z_HUFFMAN_ONLY: 130) makes 0.75 of a gene set's alleles where
@@ -1157,7 +1158,10 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         pool, own_pool = (workers, False) if isinstance(workers, MapWorkers) else (MapWorkers(int(workers), device=getattr(ctx, 'device', None)), True)     # (the workers' contexts: on the caller's device)
         if _dist_world(group)[1] == 1:     # (under torch.distributed `per_round` is the dealing unit of the RANKS - block k*world + rank, the number of gathers -
             #                                 and must be the same on every rank whatever CPUs each was granted: the caller's value stays)
-            per_round = max(min(4, per_round), min(per_round, -(-len(jobs) // (4 * pool.n))))      # four rounds per worker or more: the last ones even the load out
+            # four rounds per worker or more - the last ones even the load out - and never more than POOL_ROUND genomes: a worker searches its next round while it
+            # groups the one in front, and rounds of 8 keep that pipeline and the order of the rounds' first ids tight (2 000 genomes: 454 genomes/s against 418 with
+            # rounds of 16 and 354 with 32; 4 costs the searches' fixed launches more than it evens out)
+            per_round = max(min(4, per_round), min(per_round, POOL_ROUND, -(-len(jobs) // (4 * pool.n))))
         try:
             from . import _native
             pool.setup(prefix, clust, orthoGroup, old_prediction, params, search=search, per_batch=per_round,
