@@ -745,7 +745,8 @@ def iter_map_bsn(data):
 
 
 # ------------------------------------------------------------------------------------------------ all genomes
-POOL_ROUND = 8                         # genomes per round of a worker pool on one GPU (get_map_bsn)
+POOL_ROUND = 8                         # genomes per round of a worker pool on one GPU (get_map_bsn) ...
+POOL_ROUND_NT = 32000000               # ... and nucleotides per round (mean genome size x genomes)
 MAT_STRATEGY = FAST_DEFLATE            # how the members of the .mat store are deflated: hit rows as a pickle stream - repeated opcodes, similar numbers; zlib's level 1 took 13 ms of CPU per mapped genome
 SEQ_STRATEGY = zlib.Z_HUFFMAN_ONLY      # how the members of the .seq store are deflated.  Packed alleles are all but incompressible by matching (a byte
 #                       holds three bases of three different thirds of an allele): entropy coding alone (pep_deflate_literals, 590 MB/s; zlib's Z_HUFFMAN_ONLY: 130) makes 0.75 of a gene set's alleles where
@@ -1161,7 +1162,10 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
             # four rounds per worker or more - the last ones even the load out - and never more than POOL_ROUND genomes: a worker searches its next round while it
             # groups the one in front, and rounds of 8 keep that pipeline and the order of the rounds' first ids tight (2 000 genomes: 454 genomes/s against 418 with
             # rounds of 16 and 354 with 32; 4 costs the searches' fixed launches more than it evens out)
-            per_round = max(min(4, per_round), min(per_round, POOL_ROUND, -(-len(jobs) // (4 * pool.n))))
+            # - and of at most POOL_ROUND_NT nucleotides: 50 000 exemplars on genomes of 7.7 Mb map 109 genomes/s in rounds of 4 against 94 in rounds of 8 (and of 2)
+            mean_nt = sum(len(sq) for job in jobs for _, sq in job[2]) / float(len(jobs))
+            short = max(1, min(POOL_ROUND, int(POOL_ROUND_NT // max(1., mean_nt))))
+            per_round = max(min(4, per_round, short), min(per_round, short, -(-len(jobs) // (4 * pool.n))))
         try:
             from . import _native
             pool.setup(prefix, clust, orthoGroup, old_prediction, params, search=search, per_batch=per_round,
