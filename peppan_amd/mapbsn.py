@@ -1054,7 +1054,7 @@ class _StoreWriter(object):
 
     def __init__(self, conn, seq_conn, mat_conn, clf_conn, save_seq):
         self.conn = conn
-        self.n_group, self.table, self.table_rows, self.t_table = 0, [], 0, 0.
+        self.n_group, self.table, self.table_rows, self.t_table = 0, None, 0, 0.      # table: ONE growing int64 block the rows are copied into as they arrive
         self.conflicts = _ConflictBlocks(clf_conn)
         self.seqs = _MemberQueue(seq_conn, _emit_seq, SEQ_STRATEGY) if save_seq else None
         self.mats = _MemberQueue(mat_conn, _emit_mat, MAT_STRATEGY)
@@ -1075,7 +1075,7 @@ class _StoreWriter(object):
         rows = B.table
         rows[:, 1] = taxon
         rows[:, 5] += first
-        self.table.append(rows)
+        self._take_rows(rows)
         self.table_rows += n
         if self.table_rows >= TABLE_ROWS:
             self.write_table()
@@ -1098,18 +1098,34 @@ class _StoreWriter(object):
             q.add_finished(part['first_member'], part['members'])
             for block, n in part['tail']:
                 q.add(block, n)
-        self.table.append(P['table'])
+        self._take_rows(P['table'])
         self.table_rows += P['n']
         if self.table_rows >= TABLE_ROWS:
             self.write_table()
 
+    def _take_rows(self, rows):
+        """rows of the gene table into the block that goes to the store at the end (a list of per-round blocks cost a copy of everything - 740 MB for 2 000
+        genomes - when nobody else had anything left to do)"""
+        rows = np.asarray(rows, dtype=np.int64)
+        if rows.ndim != 2 or len(rows) == 0:
+            return
+        if self.table is None:
+            self.table, self._filled = np.empty((max(1 << 16, 2 * len(rows)), rows.shape[1]), dtype=np.int64), 0
+        need = self._filled + len(rows)
+        if need > len(self.table):
+            grown = np.empty((max(need, 2 * len(self.table)), self.table.shape[1]), dtype=np.int64)
+            grown[:self._filled] = self.table[:self._filled]
+            self.table = grown
+        self.table[self._filled:need] = rows
+        self._filled = need
+
     def write_table(self):
-        if not self.table:
+        if self.table is None or self._filled == 0:
             return
         t0 = time.perf_counter()
-        tab = np.vstack(self.table)
+        tab = self.table[:self._filled]
         self.conn.update_table(tab, order=_stable_order_of_ids(tab[:, 0]))
-        self.table, self.table_rows = [], 0
+        self.table, self.table_rows = None, 0
         self.t_table += time.perf_counter() - t0
 
     def close(self):
