@@ -1061,9 +1061,12 @@ def main():
             import io
             with contextlib.redirect_stderr(io.StringIO()):
                 UB.uberBlast(argv)                     # warm: FASTA cache, second context, workspaces
-                t2 = time.perf_counter()
-                tab = UB.uberBlast(argv)
-                extras['uberblast_e2e_ms'] = (time.perf_counter() - t2) * 1e3
+                e2e = []
+                for _ in range(7):                     # (one call is 20 ms of mostly host work: the median of seven, the fastest beside it)
+                    t2 = time.perf_counter()
+                    tab = UB.uberBlast(argv)
+                    e2e.append((time.perf_counter() - t2) * 1e3)
+                extras['uberblast_e2e_ms'], extras['uberblast_e2e_min_ms'] = sorted(e2e)[len(e2e) // 2], min(e2e)
             extras['uberblast_e2e_rows'] = int(tab.shape[0])
             # (c) the consumer of that table, PEPPAN's get_similar_pairs (PEPPAN.py:194-294), through the product's own entry point: numeric table,
             # host scan (C++), get_similar as K14 on the GPU, resolve, exemplar file rewritten - `decide` is everything behind the search
