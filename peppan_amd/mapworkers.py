@@ -258,6 +258,8 @@ def _serve(address, authkey):
         if msg[0] == 'setup':                           # (between two calls of the pool: both threads are idle)
             try:
                 from . import mapbsn
+                while not replies.empty():              # (round numbers start again with every call: nothing of an earlier one may be taken for an answer)
+                    replies.get_nowait()
                 a = msg[1]
                 old = a['old_prediction']
                 if state.get('old_is_mine'):
