@@ -170,13 +170,13 @@ int pep_k12_alleles(pep_ctx *ctx, const uint8_t *h_nt, const uint64_t *h_nt_off,
     PEP_TRY(dev_reserve(ctx, W[9], ((size_t)n_groups + 1) * 8));
     PEP_TRY(dev_reserve(ctx, W[10], pack_off[n_groups] + 1));
     PEP_TRY(pep_h2d(ctx, W[0].p, h_nt, nt_total));
-    PEP_HIP(ctx, hipMemcpyAsync(W[1].p, h_nt_off, ((size_t)n_contigs + 1) * 8, hipMemcpyHostToDevice, st));
+    PEP_TRY(pep_h2d(ctx, W[1].p, h_nt_off, ((size_t)n_contigs + 1) * 8));
     PEP_TRY(pep_h2d(ctx, W[2].p, h_rows, n * sizeof(pep_locus)));
     PEP_TRY(pep_h2d(ctx, W[3].p, h_cigar, n_cigar * 4));
-    PEP_HIP(ctx, hipMemcpyAsync(W[4].p, row_off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(W[7].p, h_grp_off, ((size_t)n_groups + 1) * 8, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(W[8].p, h_grp_qlen, (size_t)n_groups * 4, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(W[9].p, pack_off.data(), ((size_t)n_groups + 1) * 8, hipMemcpyHostToDevice, st));
+    PEP_TRY(pep_h2d(ctx, W[4].p, row_off.data(), (n + 1) * 8));        // (22 000 groups of a 50 000-exemplar genome: these tables pass the runtime's staging limit too)
+    PEP_TRY(pep_h2d(ctx, W[7].p, h_grp_off, ((size_t)n_groups + 1) * 8));
+    PEP_TRY(pep_h2d(ctx, W[8].p, h_grp_qlen, (size_t)n_groups * 4));
+    PEP_TRY(pep_h2d(ctx, W[9].p, pack_off.data(), ((size_t)n_groups + 1) * 8));
     long long *d_frame = W[6].as<long long>(), *d_orf = W[6].as<long long>() + n;
     if (n) {
         hipLaunchKernelGGL(k12_codes, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, W[2].as<const pep_locus>(), W[3].as<const uint32_t>(),

@@ -58,10 +58,10 @@ int pep_k11_overlaps(pep_ctx *ctx, uint64_t n, const int32_t *h_contig, const in
     PEP_TRY(dev_reserve(ctx, W[3], n * 8));
     PEP_TRY(dev_reserve(ctx, W[4], (n + 2) * 8));
     PEP_TRY(dev_reserve(ctx, W[5], (n + 2) * 8));
-    PEP_HIP(ctx, hipMemcpyAsync(W[0].p, h_contig, n * 4, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(W[1].p, h_start, n * 8, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(W[2].p, h_end, n * 8, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(W[3].p, h_rid, n * 8, hipMemcpyHostToDevice, st));
+    PEP_TRY(pep_h2d(ctx, W[0].p, h_contig, n * 4));
+    PEP_TRY(pep_h2d(ctx, W[1].p, h_start, n * 8));
+    PEP_TRY(pep_h2d(ctx, W[2].p, h_end, n * 8));
+    PEP_TRY(pep_h2d(ctx, W[3].p, h_rid, n * 8));
     OvlArgs a;
     a.contig = W[0].as<const int32_t>(); a.start = W[1].as<const int64_t>(); a.end = W[2].as<const int64_t>(); a.rid = W[3].as<const int64_t>();
     a.n = n; a.ovl_l = ovl_l; a.ovl_p = ovl_p;

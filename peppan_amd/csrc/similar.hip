@@ -251,8 +251,8 @@ int pep_k14_pair_support(pep_ctx *ctx, uint64_t n_rows, const pep_support_row *h
     if (n_cigar) PEP_TRY(pep_h2d(ctx, ctx->ws[1].p, h_cigar, n_cigar * 4));
     PEP_TRY(pep_h2d(ctx, d_off, h_grp_off, (n_groups + 1) * 8));
     PEP_TRY(pep_h2d(ctx, d_scr, scr.data(), (n_groups + 1) * 8));
-    PEP_HIP(ctx, hipMemcpyAsync(d_ql, h_qlen, n_groups * 4, hipMemcpyHostToDevice, st));
-    PEP_HIP(ctx, hipMemcpyAsync(d_rl, h_rlen, n_groups * 4, hipMemcpyHostToDevice, st));
+    PEP_TRY(pep_h2d(ctx, d_ql, h_qlen, n_groups * 4));
+    PEP_TRY(pep_h2d(ctx, d_rl, h_rlen, n_groups * 4));
     SupportArgs a;
     a.rows = ctx->ws[0].as<const pep_support_row>(); a.cigar = ctx->ws[1].as<const uint32_t>();
     a.grp_off = d_off; a.grp_qlen = d_ql; a.grp_rlen = d_rl; a.scr_off = d_scr;
