@@ -833,12 +833,15 @@ def test_c_abi_error_conventions():
         N.Context(99)
 
 
-def test_run_batch_equals_per_genome_runs(tmp_path, monkeypatch):
+@pytest.mark.parametrize('hsp_mode', ['1', '2'])
+def test_run_batch_equals_per_genome_runs(tmp_path, monkeypatch, hsp_mode):
     """GPU-native batching of the genes->genomes mapping (PEPPAN.py:907-922): ONE search per tool over several genomes,
-    ranking inside each genome, gives exactly the per-genome uberBlast results (tables and overlaps)"""
+    ranking inside each genome, gives exactly the per-genome uberBlast results (tables and overlaps).  hsp_mode 2: the nucleotide tool's
+    BLAST-like culling and its hit list counted in subjects work per genome of a batch too (competition classes x subjects)"""
     import io, contextlib
     from peppan_amd import uberBlast as UB, synth, configure
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv('PEPPAN_BLAST_HSP_MODE', hsp_mode)
     rng = np.random.default_rng(12)
     names, seqs = synth.make_genes(80, 0, seed=19, family=4)
     _write_fasta('genes.fa', [str(i) for i in range(len(seqs))], seqs)
