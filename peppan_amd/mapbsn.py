@@ -745,6 +745,7 @@ def iter_map_bsn(data):
 
 
 # ------------------------------------------------------------------------------------------------ all genomes
+ONE_PROCESS_BATCH = 8                  # genomes per search of a mapping without worker processes (the next batch is searched while this one gets its groups)
 POOL_ROUND = 8                         # genomes per round of a worker pool on one GPU (get_map_bsn) ...
 POOL_ROUND_NT = 32000000               # ... and nucleotides per round (mean genome size x genomes)
 MAT_STRATEGY = FAST_DEFLATE            # how the members of the .mat store are deflated: hit rows as a pickle stream - repeated opcodes, similar numbers; zlib's level 1 took 13 ms of CPU per mapped genome
@@ -774,6 +775,55 @@ def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
             yield r
 
 
+def _ahead(make, depth):
+    """the items of the generator make() - made by a thread of its own, at most `depth` of them ahead of the consumer.  The genome mapping of ONE
+    process runs its searches through this: a search's waits for the GPU happen inside the library, without the interpreter lock, while the caller's
+    thread makes the groups of the genomes in front (the worker processes of mapworkers.py do the same thing with their two threads).  Whatever
+    the generator raises is raised here; a consumer that stops early stops the thread at its next item."""
+    import queue
+    import threading
+    box, stop = queue.Queue(maxsize=max(1, depth)), threading.Event()
+
+    def produce():
+        try:
+            gen = make()
+            try:
+                for item in gen:
+                    while not stop.is_set():
+                        try:
+                            box.put(('item', item), timeout=0.2)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
+            finally:
+                gen.close()
+            box.put(('end', None))
+        except BaseException as e:
+            while not stop.is_set():
+                try:
+                    box.put(('error', e), timeout=0.2)
+                    return
+                except queue.Full:
+                    pass
+
+    t = threading.Thread(target=produce, daemon=True)
+    t.start()
+    try:
+        while True:
+            kind, val = box.get()
+            if kind == 'item':
+                yield val
+            elif kind == 'error':
+                raise val
+            else:
+                return
+    finally:
+        stop.set()
+        t.join(30.)
+
+
 def _dist_world(group):
     dist = sys.modules.get('torch.distributed')            # only a caller that set up a process group has imported it
     if dist is not None and dist.is_available() and dist.is_initialized():
@@ -799,7 +849,8 @@ def _all_groups(prefix, clust, jobs, ortho, old_prediction, params, search, ctx,
             for job, G in pool.rounds(jobs, per_round):     # (form 'members': the jobs of a round, what the stores take from it)
                 yield job, G
             return
-        for job, (blastab, overlap) in zip(jobs, search(prefix, clust, jobs, params)):
+        found = search(prefix, clust, jobs, params) if not getattr(search, 'runs_ahead', False) else _ahead(lambda: search(prefix, clust, jobs, params), 2 * per_round)
+        for job, (blastab, overlap) in zip(jobs, found):
             yield job, build_groups(blastab, overlap, job[2], ortho, old_prediction, params, ctx)
         return
     n_rounds = -(-len(jobs) // (per_round * world))
@@ -1168,6 +1219,7 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
     per_round = max(1, int(genomes_per_round))
     searcher = search or (lambda *a: _gpu_search(*a, genomes_per_batch=per_round))
     pool, own_pool = None, False
+    own_ctx = None
     if workers is None and search is None and len(jobs) >= 64:
         workers = min(8, int(params.get('n_thread', 0) or 0), effective_cpus() // 2)     # the reference's pool has n_thread workers (PEPPAN.py:1841); a GPU feeds about eight, a worker wants two CPUs
     if workers is not None and not (isinstance(workers, int) and workers <= 1):
@@ -1193,6 +1245,18 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
             if old_is_mine:
                 old_prediction.close()
             raise
+    if pool is None and search is None and ctx is None and _dist_world(group)[1] == 1 and len(jobs) > 1:
+        # ONE process, the product's own search: the searches run on a thread of their own (_ahead), in batches of at most ONE_PROCESS_BATCH genomes so that
+        # the second batch is being searched while the first gets its groups - and K12, inside build_groups, works in a context of its own (the shared one of
+        # uberBlast.get_context belongs to the search thread)
+        from . import _native
+        from .uberBlast import get_context
+        ctx = own_ctx = _native.Context(get_context().device)
+        batch = max(1, min(per_round, ONE_PROCESS_BATCH))
+        searcher = lambda *a: _gpu_search(*a, genomes_per_batch=batch)
+        searcher.runs_ahead = True
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(1e-3)
     stores = _StoreWriter(conn, seq_conn, mat_conn, clf_conn, saveSeq)
     clock = time.perf_counter
     spent = dict(stores=0.)
@@ -1241,6 +1305,9 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
             pool.close()
         if old_is_mine:
             old_prediction.close()
+        if own_ctx is not None:
+            sys.setswitchinterval(interval)
+            own_ctx.close()
     if failure:
         raise failure[0]
     t0 = clock()

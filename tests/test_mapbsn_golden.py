@@ -399,3 +399,36 @@ def test_store_writer_against_the_definition_of_the_stores(tmp_path, monkeypatch
             assert [r[1] for r in got] == sorted(r[1] for r in got)                   # genome order inside a gene
             for r0, r1 in zip(got[:-1], got[1:]):
                 assert r0[1] != r1[1] or r0[2] >= r1[2]                               # and best score first inside a genome
+
+
+def test_a_generator_run_ahead_by_a_thread_gives_the_same_items_and_errors():
+    """mapbsn._ahead (the searches of a one-process mapping run on a thread of their own): the items in order, at most `depth` made ahead of the
+    consumer, an error of the generator raised at the point it occurred, a consumer that stops early stops the producer"""
+    import threading
+    import time
+    from peppan_amd.mapbsn import _ahead
+    made = []
+
+    def gen(n, fail_at=None):
+        for i in range(n):
+            if i == fail_at:
+                raise ValueError('item %d' % i)
+            made.append(i)
+            yield i
+    assert list(_ahead(lambda: gen(50), 3)) == list(range(50))
+    del made[:]
+    it = _ahead(lambda: gen(1000), 4)
+    assert [next(it) for _ in range(5)] == [0, 1, 2, 3, 4]
+    time.sleep(0.3)
+    assert len(made) <= 5 + 4 + 1                       # what the consumer took, the queue's depth, the one the producer holds
+    it.close()
+    time.sleep(0.5)
+    n = len(made)
+    time.sleep(0.3)
+    assert len(made) == n < 1000                        # the producer has stopped
+    got = []
+    with pytest.raises(ValueError, match='item 7'):
+        for x in _ahead(lambda: gen(20, fail_at=7), 2):
+            got.append(x)
+    assert got == list(range(7))
+    assert threading.active_count() < 20
