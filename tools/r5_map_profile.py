@@ -24,3 +24,7 @@ for key in ('cumulative', 'tottime'):
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats(key).print_stats(34)
     print('\n'.join(l[:170] for l in s.getvalue().splitlines()[6:]))
+for what in ('prod', 'shape_base.py:380', "'reduce' of 'numpy.ufunc'"):
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).sort_stats('tottime').print_callers(what)
+    print('\n'.join(l[:170] for l in s.getvalue().splitlines()[:40]))
