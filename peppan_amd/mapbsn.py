@@ -1249,9 +1249,8 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         # ONE process, the product's own search: the searches run on a thread of their own (_ahead), in batches of at most ONE_PROCESS_BATCH genomes so that
         # the second batch is being searched while the first gets its groups - and K12, inside build_groups, works in a context of its own (the shared one of
         # uberBlast.get_context belongs to the search thread)
-        from . import _native
-        from .uberBlast import get_context
-        ctx = own_ctx = _native.Context(get_context().device)
+        from . import uberBlast
+        ctx = own_ctx = uberBlast.get_side_context('k12')              # (kept by the process like the search contexts: making and closing one costs 30 ms a call)
         batch = max(1, min(per_round, ONE_PROCESS_BATCH))
         searcher = lambda *a: _gpu_search(*a, genomes_per_batch=batch)
         searcher.runs_ahead = True
@@ -1307,7 +1306,6 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
             old_prediction.close()
         if own_ctx is not None:
             sys.setswitchinterval(interval)
-            own_ctx.close()
     if failure:
         raise failure[0]
     t0 = clock()

@@ -160,6 +160,17 @@ def get_nucl_context(device=None):
     return _CTX[key]
 
 
+def get_side_context(role, device=None):
+    """one more HIP context of this process on the device, kept under `role` like the search contexts: work that runs on a thread of its own beside the
+    searches (K12 inside build_groups while the next batch of genomes is being searched, mapbsn.get_map_bsn) must not share their stream and work space"""
+    if device is None:
+        device = get_context().device
+    key = (os.getpid(), device, role)
+    if key not in _CTX:
+        _CTX[key] = N.Context(device)
+    return _CTX[key]
+
+
 # ------------------------------------------------------------------------------------------------------------
 # GPU hits -> the reference's table rows (coordinate algebra of parseDiamond, uberBlast.py:25-58)
 # ------------------------------------------------------------------------------------------------------------
