@@ -1251,7 +1251,8 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         # uberBlast.get_context belongs to the search thread)
         from . import uberBlast
         ctx = own_ctx = uberBlast.get_side_context('k12')              # (kept by the process like the search contexts: making and closing one costs 30 ms a call)
-        batch = max(1, min(per_round, ONE_PROCESS_BATCH))
+        mean_nt = sum(len(sq) for job in jobs for _, sq in job[2]) / float(len(jobs))
+        batch = max(1, min(per_round, ONE_PROCESS_BATCH, int(POOL_ROUND_NT // max(1., mean_nt))))          # (large genomes: fewer per search, as in a pool's rounds)
         searcher = lambda *a: _gpu_search(*a, genomes_per_batch=batch)
         searcher.runs_ahead = True
         interval = sys.getswitchinterval()
