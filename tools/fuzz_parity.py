@@ -49,10 +49,16 @@ def nucleotide_cases(ctx, cases, rng):
         flags = int(rng.choice([0, 1, 2, 3, 4, 5]))
         p.reserved2 = flags
         p.reserved[1] = int(rng.integers(0, 4) == 0)
-        ctx.set_query_aa(codes); ctx.set_ref_aa(targets)
+        subjects = None
+        if case % 2:                               # the nucleotide tool's own layout (forward strands, then reverse complements): the two strands of a sequence are ONE subject in hsp_mode 2
+            texts = [''.join('ACGTN'[x] for x in c) for c in codes]
+            ctx.set_query_nt(texts); ctx.set_ref_nt(texts, 6, 11); ctx.use_nt_as_residues(2)
+            subjects = list(range(len(codes))) * 2 if p.hsp_mode == 2 else None
+        else:
+            ctx.set_query_aa(codes); ctx.set_ref_aa(targets)
         gh, gc, st = ctx.search(p)
         ms = np.array([O.min_score(len(c), p.dbsize, p.max_evalue, p.ka_lambda, p.ka_k) for c in codes], dtype=np.int32)
-        oh, oc, ost = O.search(codes, targets, O.params_from(p), min_scores=ms)
+        oh, oc, ost = O.search(codes, targets, O.params_from(p), min_scores=ms, subjects=subjects)
         bad = [f for f in FIELDS if len(gh) != len(oh) or not np.array_equal(gh[f], oh[f])]
         bad += ['cigar arena'] if not np.array_equal(gc, oc) else []
         bad += ['stat ' + k for k in ('candidates', 'pairs', 'cells', 'tracebacks') if st[k] != ost[k]]
