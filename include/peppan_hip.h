@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 12
+#define PEP_ABI_VERSION 13
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -469,6 +469,10 @@ int64_t pep_deflate_literals(const uint8_t *src, int64_t n, uint8_t *out, int64_
  * them at zlib's default level inside zipfile): about the size of zlib's level 1 at several times its rate.  Host C++, no context, any inflate reads
  * it.  Returns the stream's length; when it exceeds `cap` nothing usable was written (n + n / 8 + 1024 always suffices).  Negative: PEP_ERR_ARG. */
 int64_t pep_deflate_fast(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap);
+/* np.argsort(v.astype(object)) for float64 v without NaN (host, no context): the order numpy's generic index quicksort leaves an object column of
+ * Python floats in, ties included - the order of equal scores in the reference's .tab store (PEPPAN.py:957-960 sorts an object array's score column).
+ * PEP_ERR_LIMIT when the sort's depth limit is reached (numpy switches to heapsort there: the caller asks numpy itself). */
+int pep_argsort_object_order(const double *v, int64_t n, int64_t *order);
 
 #ifdef __cplusplus
 }

@@ -7,14 +7,14 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params', 'pep_set_sensitivity',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_fasta_records', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast',
+           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_fasta_records', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast', 'pep_argsort_object_order',
            'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather']
 
 
@@ -460,6 +460,20 @@ def store_tab_members(rows, off, keys, date_time, threads=None, order=None):
             return buf[:need], crc, csize, usize, at
         cap = int(need)
     raise PepError('pep_store_tab_members: the entries did not fit the size it had asked for')
+
+
+def argsort_object_order(values):
+    """np.argsort(values.astype(object)) for float64 values without NaN - the same steps as numpy's generic index sort, on the doubles (pep_argsort_object_order)"""
+    v = np.ascontiguousarray(values, dtype=np.float64)
+    if len(v) and np.isnan(v).any():
+        return np.argsort(v.astype(object))
+    out = np.empty(len(v), dtype=np.int64)
+    rc_ = load_library().pep_argsort_object_order(_ptr(v), C.c_int64(len(v)), _ptr(out))
+    if rc_ == -3:                                    # the sort's depth limit: numpy goes on with heapsort there
+        return np.argsort(v.astype(object))
+    if rc_ != 0:
+        raise PepError('pep_argsort_object_order failed (%d)' % rc_)
+    return out
 
 
 def store_tab_archive(rows, off, keys, date_time, threads=None, order=None):

@@ -231,3 +231,26 @@ def test_read_fasta_through_the_library_equals_the_record_by_record_reader(tmp_p
         CF._fasta_records(b'>\nACGT\n')
     with pytest.raises(IndexError):
         CF._fasta_text_records('>\nACGT\n')
+
+
+def test_argsort_object_order_equals_numpy_on_ties():
+    """pep_argsort_object_order against np.argsort of the object column itself: sizes around the sort's insertion-sort threshold, many ties, sorted and
+    reversed input, the sizes of a genome's groups (the .tab store's rows of equal score keep the order numpy's sort leaves them in, PEPPAN.py:957-960)"""
+    from peppan_amd import _native as N
+    rng = np.random.default_rng(0)
+    for case in range(400):
+        n = int(rng.choice([0, 1, 2, 5, 15, 16, 17, 18, 33, 100, 500, 3000, 6600]))
+        kind = case % 5
+        if kind == 0:
+            x = rng.random(n)
+        elif kind == 1:
+            x = rng.integers(0, max(1, n // 4 + 1), size=n).astype(np.float64)
+        elif kind == 2:
+            x = np.round(rng.random(n) * 50) / 7.
+        elif kind == 3:
+            x = np.sort(rng.integers(0, 10, size=n).astype(np.float64))[::-1].copy()
+        else:
+            x = np.repeat(rng.random(max(1, n // 3 + 1)), 3)[:n].copy()
+            rng.shuffle(x)
+        assert np.array_equal(N.argsort_object_order(-x), np.argsort((-x).astype(object))), (case, n, kind)
+    assert np.array_equal(N.argsort_object_order(np.array([1., np.nan, 0.])), np.argsort(np.array([1., np.nan, 0.]).astype(object)))      # (NaN: numpy's own way)
