@@ -313,10 +313,14 @@ class MapWorkers(object):
         self._listener = Listener(address, family='AF_UNIX', authkey=authkey)
         env = dict(os.environ, PEPPAN_WORKER_KEY=authkey.hex(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         env.setdefault('PEPPAN_HIP_SPIN_US', '0')           # the workers nap while they wait for the GPU they share: spinning would eat the CPU time the others need
-        # one hardware queue per worker process: with the runtime's default (up to four per process) eight workers of three streams each - search, nucleotide
+        # few hardware queues per worker process: with the runtime's default (up to four per process) eight workers of three streams each - search, nucleotide
         # tool, the groups thread's K12 - ask for more queues than the GPU has slots for, and the scheduler spends its time swapping them: the driver's busy counter
-        # reads 100 % at 330 genomes/s where it reads 44 % at 360 with one queue each (profiles/r05_pool_experiments.txt)
-        env.setdefault('GPU_MAX_HW_QUEUES', '1')
+        # reads 100 % at 330 genomes/s where it reads 44 % at 360 with one or two queues each (profiles/r05_pool_experiments.txt) ...
+        # ... and two are what a worker needs: its two tools run one after the other and share ONE context (PEPPAN_ONE_CONTEXT: the second context of
+        # uberBlast.get_nucl_context is for a process that runs them side by side), the groups thread's K12 has the other queue - on one queue a genome's K12
+        # waited 4 ms behind the kernels of the search thread's next round (2 000 genomes: 452 -> 496 genomes/s)
+        env.setdefault('GPU_MAX_HW_QUEUES', '2')
+        env.setdefault('PEPPAN_ONE_CONTEXT', '1')
         if device is not None:
             env['PEPPAN_HIP_DEVICE'] = str(int(device))
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
