@@ -39,6 +39,18 @@ from multiprocessing.connection import Client, Listener
 __all__ = ['MapWorkers']
 
 
+def _this_process_uses_the_gpu():
+    """has this process made a HIP context (the drop-in's own, or torch's)?  Its hardware queues count against the GPU's slots like the workers'"""
+    try:
+        ub = sys.modules.get('peppan_amd.uberBlast')
+        if ub is not None and any(k[0] == os.getpid() for k in getattr(ub, '_CTX', {})):
+            return True
+        torch = sys.modules.get('torch')
+        return bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        return True
+
+
 def _scratch_root():
     """where the bulk of the traffic between the processes lives for a moment: memory-backed if the machine offers it"""
     shm = '/dev/shm'
@@ -319,7 +331,9 @@ class MapWorkers(object):
         # ... and two are what a worker needs: its two tools run one after the other and share ONE context (PEPPAN_ONE_CONTEXT: the second context of
         # uberBlast.get_nucl_context is for a process that runs them side by side), the groups thread's K12 has the other queue - on one queue a genome's K12
         # waited 4 ms behind the kernels of the search thread's next round (2 000 genomes: 452 -> 496 genomes/s)
-        env.setdefault('GPU_MAX_HW_QUEUES', '2')
+        # - IF this process holds no queues of its own: a parent that has searched on the GPU itself (PEPPAN's has: get_similar_pairs runs before the mapping)
+        # brings up to four, and 4 + 8 x 2 are over the limit again (the bench's pool leg: 383 genomes/s with the counter at 100 % against 423 with one queue each)
+        env.setdefault('GPU_MAX_HW_QUEUES', '1' if _this_process_uses_the_gpu() else '2')
         env.setdefault('PEPPAN_ONE_CONTEXT', '1')
         if device is not None:
             env['PEPPAN_HIP_DEVICE'] = str(int(device))
