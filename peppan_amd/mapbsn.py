@@ -594,7 +594,66 @@ def _int_names(tab):
 
 
 def build_groups(blastab, overlap, seq, ortho, old_prediction, params, ctx=None):
-    """(17-column table with merge groups, int[m, 3] overlaps) of ONE genome -> GenomeGroups.  PEPPAN.py:773-866.
+    """(17-column table with merge groups, int[m, 3] overlaps) of ONE genome -> GenomeGroups (PEPPAN.py:773-866; the steps: _build_groups_steps)"""
+    return build_groups_round([(blastab, overlap, seq)], ortho, old_prediction, params, ctx)[0]
+
+
+def build_groups_round(items, ortho, old_prediction, params, ctx=None):
+    """build_groups for several genomes - items = [(blastab, overlap, seq), ...] - with ONE K12 call for all of them: a genome's K12 is 0.1 ms of kernels, and
+    on a GPU that eight worker processes share each call waits milliseconds for its turn (4 ms per genome in a worker's groups thread).  The genomes' requests
+    are put behind one another - contig, group and CIGAR indices shifted - and the answer is cut back per genome; the result is what one call per genome gives."""
+    steps = [_build_groups_steps(blastab, overlap, seq, ortho, old_prediction, params) for blastab, overlap, seq in items]
+    out, asked = [None] * len(steps), []
+    for i, g in enumerate(steps):
+        try:
+            asked.append((i, next(g)))
+        except StopIteration as e:                  # (a genome without groups never asks)
+            out[i] = e.value
+    if asked:
+        if ctx is None:
+            from .uberBlast import get_context
+            ctx = get_context()
+        if len(asked) == 1:
+            answers = [ctx.alleles(*asked[0][1])]
+        else:
+            from ._native import LOCUS_DTYPE
+            same_arena = all(r[2] is asked[0][1][2] for _, r in asked)
+            contigs, loci, arenas, grp_off, qlen, n_rows, n_pack = [], [], [], [], [], [], []
+            base_c = base_g = base_r = base_a = 0
+            for _, (cs, lc, arena, go, ql, gtable) in asked:
+                lc = np.array(lc, dtype=LOCUS_DTYPE)
+                lc['contig'] += base_c
+                lc['group'] += base_g
+                if not same_arena:
+                    lc['cigar_off'] += base_a
+                    arenas.append(np.asarray(arena, dtype=np.uint32))
+                    base_a += len(arena)
+                contigs += list(cs)
+                loci.append(lc)
+                go = np.asarray(go, dtype=np.int64)
+                grp_off.append(go[:-1] + base_r)
+                qlen.append(np.asarray(ql, dtype=np.int64))
+                n_rows.append(len(lc))
+                n_pack.append(int(((qlen[-1] + 2) // 3).sum()))
+                base_c, base_g, base_r = base_c + len(cs), base_g + len(ql), base_r + len(lc)
+            in_frame, orf, packed = ctx.alleles(contigs, np.concatenate(loci), asked[0][1][2] if same_arena else np.concatenate(arenas),
+                                                np.concatenate(grp_off + [np.array([base_r], dtype=np.int64)]).astype(np.uint64), np.concatenate(qlen), asked[0][1][5])
+            answers, r0, p0 = [], 0, 0
+            for nr, npk in zip(n_rows, n_pack):
+                answers.append((in_frame[r0:r0 + nr], orf[r0:r0 + nr], packed[p0:p0 + npk]))
+                r0, p0 = r0 + nr, p0 + npk
+        for (i, _), answer in zip(asked, answers):
+            try:
+                steps[i].send(answer)
+                raise RuntimeError('build_groups: the steps of a genome asked twice')
+            except StopIteration as e:
+                out[i] = e.value
+    return out
+
+
+def _build_groups_steps(blastab, overlap, seq, ortho, old_prediction, params):
+    """The steps of build_groups for one genome as a generator: it yields ONE request - the arguments of K12 (`Context.alleles`) - is sent the answer,
+    and returns the GenomeGroups (a genome without groups returns at once).  (17-column table with merge groups, int[m, 3] overlaps) -> GenomeGroups.  PEPPAN.py:773-866.
     `blastab` is the HitTable the search chain ends with (the product path: no Python row is made at all) or the same thing as object
     rows; `ortho` an OrthoRelation (or what it is built from).  The per-hit allele strings, their in-frame / stop-free lengths and the
     packing run on the GPU (K12, `ctx.alleles`).
@@ -606,9 +665,6 @@ def build_groups(blastab, overlap, seq, ortho, old_prediction, params, ctx=None)
     T = blastab if isinstance(blastab, HitTable) else HitTable.from_rows(blastab)
     if len(T) == 0:
         return GenomeGroups.none()
-    if ctx is None:
-        from .uberBlast import get_context
-        ctx = get_context()
     T.q_tab, T.r_tab = _int_names(T.q_tab), _int_names(T.r_tab)
     T.q_sorted = T.r_sorted = False           # (integer names order numerically from here on)
     T = _with_known(T, old_prediction)
@@ -660,7 +716,7 @@ def build_groups(blastab, overlap, seq, ortho, old_prediction, params, ctx=None)
     loci['cigar_runs'], loci['cigar_off'] = T.c_runs[flat], T.c_off[flat]
     loci['group'] = np.repeat(np.arange(n_groups), n_rows)
     ql = T.ql[flat]
-    in_frame, orf, packed = ctx.alleles(contigs, loci, T.arena, grp_off, ql[first], params['gtable'])
+    in_frame, orf, packed = yield (contigs, loci, T.arena, grp_off, ql[first], params['gtable'])
     sc = np.minimum(in_frame, orf + 3)
     iden, known = T.iden[flat], T.evalue[flat]
     q_lo, q_hi = T.qs[flat], T.qe[flat]

@@ -213,10 +213,10 @@ def _serve(address, authkey):
                     continue
                 from . import mapbsn
                 t0 = clock()
-                out = []
-                for (id, taxon, seq), (blastab, overlap) in zip(jobs, found):
-                    G = mapbsn.build_groups(blastab, overlap, seq, state['ortho'], state['old'], state['params'], state['ctx'])
-                    out.append(G if state['form'] == 'groups' else mapbsn.StoreBlock(G))
+                groups = mapbsn.build_groups_round([(blastab, overlap, seq) for (id, taxon, seq), (blastab, overlap) in zip(jobs, found)],
+                                                   state['ortho'], state['old'], state['params'], state['ctx'])           # (ONE K12 call for the round)
+                out = [G if state['form'] == 'groups' else mapbsn.StoreBlock(G) for G in groups]
+                del groups
                 del found, item
                 spent['groups'] += clock() - t0
                 spent['genomes'] += len(out)

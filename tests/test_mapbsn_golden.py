@@ -432,3 +432,38 @@ def test_a_generator_run_ahead_by_a_thread_gives_the_same_items_and_errors():
             got.append(x)
     assert got == list(range(7))
     assert threading.active_count() < 20
+
+
+def test_groups_of_a_round_with_one_k12_call_equal_groups_per_genome(world):
+    """mapbsn.build_groups_round puts the K12 requests of several genomes behind one another (contig, group and CIGAR indices shifted) and cuts the answer
+    back per genome: the same GenomeGroups as one call per genome - G14's three genomes, whose tables carry arenas of their own (the arenas are
+    put behind one another too), in every order, with an empty genome in between"""
+    from map_pool_helpers import canned_search
+    g, old_fn, bsn_fn = world
+    jobs = [(i, 0, [[int(c), s] for c, s in g['cases'][i]['contigs'].items()]) for i in range(3)]
+    found = list(canned_search('m', 'CL', jobs, g['params']))
+    ortho = mapbsn.OrthoRelation(bsn_fn)
+    ctx = OracleContext()
+    calls = []
+    plain = ctx.alleles
+    ctx.alleles = lambda *a, **k: (calls.append(len(a[0])), plain(*a, **k))[1]
+
+    def same(a, b):
+        for f in ('gene', 'contig', 'score', 'iden', 'packed', 'pack_off', 'row_off', 'ovl'):
+            assert np.array_equal(np.asarray(getattr(a, f)), np.asarray(getattr(b, f))), f
+        for f in ('qi', 'ri', 'qs', 'qe', 'ss', 'se', 'iden', 'score', 'c_runs'):
+            assert np.array_equal(getattr(a.rows, f), getattr(b.rows, f)), f
+        assert [a.rows.arena[o:o + k].tolist() for o, k in zip(a.rows.c_off.tolist(), a.rows.c_runs.tolist())] == [b.rows.arena[o:o + k].tolist() for o, k in zip(b.rows.c_off.tolist(), b.rows.c_runs.tolist())]
+    with mapbsn.MapBsn(old_fn) as old:
+        single = [mapbsn.build_groups(t, o, job[2], ortho, old, g['params'], ctx) for job, (t, o) in zip(jobs, found)]
+        assert len(calls) == 3
+        empty = (np.empty([0, 17], dtype=object), np.zeros([0, 3], dtype=int), jobs[0][2])
+        for order in ((0, 1, 2), (2, 0, 1), (1, 1, 0)):
+            del calls[:]
+            items = [(found[i][0], found[i][1], jobs[i][2]) for i in order]
+            items.insert(1, empty)
+            got = mapbsn.build_groups_round(items, ortho, old, g['params'], ctx)
+            assert len(calls) == 1 and calls[0] == sum(len(jobs[i][2]) for i in order)          # ONE call, over the contigs of all genomes
+            assert len(got) == 4 and len(got[1].gene) == 0
+            for G, i in zip([got[0]] + got[2:], order):
+                same(G, single[i])
