@@ -71,29 +71,59 @@ def linear_merge_table(T, gap_dist, len_diff):
     return out
 
 
+def _intervals(T):
+    """intervals [contig id, row id, start, end] sorted by (contig, start, end), ties in table order; the reference numbers a contig
+    by the LAST row that names it (dict comprehension, uberBlast.py:380)"""
+    n = len(T)
+    if n == 0:
+        return np.empty((0, 4), dtype=int)
+    last = np.zeros(int(T.ri.max()) + 1, dtype=np.int64)
+    np.maximum.at(last, T.ri, np.arange(n))
+    lo, hi, cid = np.minimum(T.ss, T.se), np.maximum(T.ss, T.se), last[T.ri]
+    return np.stack([cid, T.rid, lo, hi], axis=1)[np.lexsort((hi, lo, cid))].astype(int)
+
+
+def _swept(res, batch):
+    """the pairs of one table's sweep as the reference returns them"""
+    if len(res) >= batch:
+        # the reference's resume quirk: the pair that fills a batch is emitted again as the first of the next one, so every later
+        # batch holds batch - 1 new pairs: the duplicated pairs are number batch-1, 2*(batch-1), 3*(batch-1), ... (0-based)
+        dup = np.arange(batch - 1, len(res), batch - 1)
+        res = np.insert(res, dup + 1, res[dup], axis=0)
+    return res[res.T[2] > 0]
+
+
+def overlaps_tables(tables, ovl_l, ovl_p, sweep, batch=1000000):
+    """overlaps_table for several tables (the genomes of one batched search) with ONE sweep: the tables' intervals behind one another, contig numbers and
+    row ids shifted table by table - pairs never cross contigs, so they come out table by table and are cut and shifted back.  A sweep is two launches and two
+    round trips; on a GPU that eight worker processes share each of them waits for its turn."""
+    ivs = [_intervals(T) for T in tables]
+    # contig numbers are row indices of their table (below its length), row ids are whatever the table carries (below its largest + 1)
+    c_base = np.concatenate([[0], np.cumsum([len(T) for T in tables])]).astype(np.int64)
+    r_base = np.concatenate([[0], np.cumsum([int(T.rid.max()) + 1 if len(T) else 0 for T in tables])]).astype(np.int64)
+    big = [iv + np.array([c, r, 0, 0]) for iv, c, r in zip(ivs, c_base[:-1].tolist(), r_base[:-1].tolist()) if len(iv)]
+    if not big:
+        return [np.zeros((0, 3), dtype=int) for _ in tables]
+    iv = np.concatenate(big)
+    res = np.asarray(sweep(iv[:, 0], iv[:, 2], iv[:, 3], iv[:, 1], float(ovl_l), float(ovl_p)), dtype=int).reshape(-1, 3)
+    owner = np.searchsorted(r_base, res[:, 0], side='right') - 1          # the table of every pair: the sweep goes contig by contig, so table by table
+    in_order = len(res) == 0 or bool((np.diff(owner) >= 0).all())
+    cuts = np.searchsorted(owner, np.arange(len(tables) + 1)) if in_order else None
+    out = []
+    for k in range(len(tables)):
+        part = res[cuts[k]:cuts[k + 1]] if in_order else res[owner == k]
+        out.append(_swept(part - np.array([r_base[k], r_base[k], 0]), batch))
+    return out
+
+
 def overlaps_table(T, ovl_l, ovl_p, batch=1000000, sweep=None):
     """flag -O (RunBlast.returnOverlap + tab2overlaps, uberBlast.py:73-97, 378-395): pairs of hits (row ids) whose reference intervals
     overlap by >= min(ovl_l, ovl_p*len1) or >= ovl_p*len2.  The reference sweeps in batches of 1e6 pairs and, on resuming, emits
     the last pair of a full batch again (uberBlast.py:76-92); reproduced.  `sweep(contig, start, end, row_id, ovl_l, ovl_p)` runs
     the sweep itself (the GPU kernel K11 in the product); without it a plain Python loop does (used by the CPU tests)."""
-    # intervals [contig id, row id, start, end] sorted by (contig, start, end), ties in table order; the reference numbers a contig
-    # by the LAST row that names it (dict comprehension, uberBlast.py:380)
-    n = len(T)
-    if n:
-        last = np.zeros(int(T.ri.max()) + 1, dtype=np.int64)
-        np.maximum.at(last, T.ri, np.arange(n))
-        lo, hi, cid = np.minimum(T.ss, T.se), np.maximum(T.ss, T.se), last[T.ri]
-        iv = np.stack([cid, T.rid, lo, hi], axis=1)[np.lexsort((hi, lo, cid))].astype(int)
-    else:
-        iv = np.empty((0, 4), dtype=int)
+    iv = _intervals(T)
     if sweep is not None and len(iv):
-        res = np.asarray(sweep(iv[:, 0], iv[:, 2], iv[:, 3], iv[:, 1], float(ovl_l), float(ovl_p)), dtype=int).reshape(-1, 3)
-        if len(res) >= batch:
-            # the reference's resume quirk: the pair that fills a batch is emitted again as the first of the next one, so every later
-            # batch holds batch - 1 new pairs: the duplicated pairs are number batch-1, 2*(batch-1), 3*(batch-1), ... (0-based)
-            dup = np.arange(batch - 1, len(res), batch - 1)
-            res = np.insert(res, dup + 1, res[dup], axis=0)
-        return res[res.T[2] > 0]
+        return _swept(np.asarray(sweep(iv[:, 0], iv[:, 2], iv[:, 3], iv[:, 1], float(ovl_l), float(ovl_p)), dtype=int).reshape(-1, 3), batch)
     out = []
     n = len(iv)
     emitted = 0

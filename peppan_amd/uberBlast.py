@@ -452,6 +452,17 @@ class RunBlast(object):
         """everything RunBlast.run does after the tools returned (uberBlast.py:352-376), on the numeric table; the object rows the
         caller gets are made at the very end.  rescored: the tables carry the rescored identity / score already (run_batch does K7 for all
         genomes of a batch at once) and only the identity cut is left"""
+        steps = self._post_steps(tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end, rescored)
+        try:
+            T = next(steps)                                  # (-O: the table whose overlaps are wanted)
+            steps.send(mapfilters.overlaps_table(T, return_overlap[1], return_overlap[2], sweep=get_context(self.device).overlaps))
+        except StopIteration as e:
+            return e.value
+        raise RuntimeError('RunBlast._post: the steps asked twice')
+
+    def _post_steps(self, tables, ref, qry, re_score, filter, linear_merge, return_overlap, fix_end, rescored=False):
+        """_post as a generator: with -O it yields the table whose overlaps are wanted ONCE and is sent them (run_batch sweeps the tables of all
+        genomes of a batch in one K11 call); its return value is _post's"""
         T = HitTable.concat(tables)
         if len(T) == 0:
             none = HitTable.empty() if self._as_tables else np.empty([0, 16], dtype=object)
@@ -475,7 +486,7 @@ class RunBlast(object):
         T.fix_end(*fix_end)
         overlap = None
         if return_overlap[0]:
-            overlap = mapfilters.overlaps_table(T, return_overlap[1], return_overlap[2], sweep=get_context(self.device).overlaps)
+            overlap = yield T
         order = T.final_order()
         T = T.take(order if keep is None else order[keep[order]])
         rows = T if self._as_tables else T.to_rows(cigar='str')
@@ -542,10 +553,24 @@ class RunBlast(object):
             owner = np.array([genome_of[r] for r in T.r_tab], dtype=np.int64)[T.ri]
             order = np.argsort(owner, kind='stable')
             cuts = np.searchsorted(owner[order], np.arange(len(refs) + 1))
-        out = []
+        # every genome's chain up to its overlaps, then ONE K11 sweep over the tables of all genomes (mapfilters.overlaps_tables), then the chains' ends
+        steps, out, asked = [], [None] * len(refs), []
         for g in range(len(refs)):
             part = [T.take(order[cuts[g]:cuts[g + 1]])] if len(T) else []
-            out.append(self._post(part, None, None, re_score, filter, linear_merge, return_overlap, fix_end, rescored=batch_rescore))
+            st = self._post_steps(part, None, None, re_score, filter, linear_merge, return_overlap, fix_end, rescored=batch_rescore)
+            steps.append(st)
+            try:
+                asked.append((g, next(st)))
+            except StopIteration as e:
+                out[g] = e.value
+        if asked:
+            swept = mapfilters.overlaps_tables([t for _, t in asked], return_overlap[1], return_overlap[2], get_context(self.device).overlaps)
+            for (g, _), ovl in zip(asked, swept):
+                try:
+                    steps[g].send(ovl)
+                    raise RuntimeError('RunBlast._post_steps asked twice')
+                except StopIteration as e:
+                    out[g] = e.value
         return out
 
     # ---------------------------------------------------------------------------------------------- inputs

@@ -254,3 +254,31 @@ def test_argsort_object_order_equals_numpy_on_ties():
             rng.shuffle(x)
         assert np.array_equal(N.argsort_object_order(-x), np.argsort((-x).astype(object))), (case, n, kind)
     assert np.array_equal(N.argsort_object_order(np.array([1., np.nan, 0.])), np.argsort(np.array([1., np.nan, 0.]).astype(object)))      # (NaN: numpy's own way)
+
+
+def test_overlaps_of_several_tables_in_one_sweep_equal_one_sweep_per_table():
+    """mapfilters.overlaps_tables (the genomes of a batched search swept by ONE K11 call) against overlaps_table per table: tables that lost rows to
+    the filters (row ids with holes, larger than the table), several contigs per table, an empty table in between, the batch quirk"""
+    from oracle import oracle as O
+    from peppan_amd import mapfilters
+    from peppan_amd.hittable import HitTable
+    rng = np.random.default_rng(4)
+
+    def table(n, n_contigs, id_span):
+        ri = rng.integers(0, n_contigs, size=n)
+        ss = rng.integers(1, 4000, size=n)
+        ln = rng.integers(50, 900, size=n)
+        rev = rng.random(n) < 0.4
+        se = ss + ln
+        runs = np.ones(n, dtype=np.int64)
+        T = HitTable(list(range(5)), [100 + c for c in range(n_contigs)], rng.integers(0, 5, size=n), ri, np.full(n, 0.9), ln, np.zeros(n, int), np.zeros(n, int),
+                     np.ones(n, int), ln, np.where(rev, se, ss), np.where(rev, ss, se), np.zeros(n), ln.astype(float), np.full(n, 1000), np.full(n, 10 ** 6),
+                     (ln.astype(np.uint32) << 2), np.arange(n), runs, rid=np.sort(rng.choice(id_span, size=n, replace=False)))
+        return T
+    tables = [table(200, 3, 500), table(0, 1, 1), table(350, 1, 351), table(60, 6, 4000)]
+    for ovl_l, ovl_p, batch in ((300, 0.6, 1000000), (50, 0.1, 1000000), (50, 0.1, 37)):
+        want = [mapfilters.overlaps_table(T, ovl_l, ovl_p, batch=batch, sweep=O.overlaps_sweep) for T in tables]
+        got = mapfilters.overlaps_tables(tables, ovl_l, ovl_p, O.overlaps_sweep, batch=batch)
+        assert len(got) == 4 and sum(map(len, want)) > 100
+        for w, g in zip(want, got):
+            assert np.array_equal(np.asarray(w).reshape(-1, 3), np.asarray(g).reshape(-1, 3))
