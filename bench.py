@@ -763,6 +763,129 @@ def _profile_tables(path=None):
     return counters, cyc4
 
 
+COMPACT_LIMIT = 4096             # bytes of the final stdout line (the driver's parser lost round 5's 25 KB line)
+
+
+def _short(s, n=118):
+    """strings of the compact line stay under the 120 characters the driver keeps of one"""
+    if not isinstance(s, str) or len(s) <= n:
+        return s
+    return s[:n - 3] + '...'
+
+
+def _num(x, digits=6):
+    """a float with `digits` significant digits (None, ints and everything else pass)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float('inf'), float('-inf')):
+        return None                                  # (strict JSON has no NaN / Infinity)
+    return float('%.*g' % (digits, x))
+
+
+def _get(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(detail, detail_file='bench_detail.json'):
+    """The ONE line bench.py prints on stdout: the contract's keys, `roofline` of the dominant kernel, `cpu_baseline`, the parity check and one scalar
+    per secondary leg - under COMPACT_LIMIT bytes, strict JSON.  Everything else (`workloads`, `roofline_kernels`, notes, sources) is `detail`,
+    written to bench_detail.json beside this script."""
+    d = detail
+    rl, cb = d.get('roofline') or {}, d.get('cpu_baseline') or {}
+    line = {k: d.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
+    cfg = d.get('config') or {}
+    line['config'] = {k: _short(v) for k, v in cfg.items()}
+    line['sw_cell_updates_per_s_per_gpu'] = d.get('sw_cell_updates_per_s_per_gpu')
+    if rl.get('bound') == 'valu':
+        # an integer-VALU bound kernel on top (small workloads): the contract's roofline is the HBM one - its HBM side goes into the line, the issue fraction beside it
+        rl = dict(rl, bound='hbm', **(rl.get('hbm') or {}))
+        line['roofline_valu_issue_frac'] = rl.get('valu_issue_frac')
+    line['roofline'] = ({k: _short(rl.get(k), 60) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes', 'traffic_over_algorithmic',
+                                                             'ms_per_launch', 'launches_per_step', 'ms_per_step', 'counters_stale')} if rl else None)
+    line['cpu_baseline'] = ({k: _short(cb.get(k)) for k in ('value', 'unit', 'cores', 'kind', 'cpu_model', 'sample', 'seconds', 'sw_cells_per_s', 'gpu_hits_identical', 'hits_compared')}
+                            if cb else None)
+    pc = d.get('parity_check')
+    line['parity_check'] = {'gpu_hits_identical': pc.get('gpu_hits_identical'), 'hits_compared': pc.get('hits_compared'), 'against': 'oracle/align_oracle.c'} if pc else None
+    # the Smith-Waterman passes beside the dominant kernel: their issue fraction (they are integer-VALU bound, SURVEY.md 8d)
+    for e in d.get('roofline_kernels') or []:
+        if e.get('bound') == 'valu':
+            line[e['kernel'].replace('_kernel', '') + '_valu_issue_frac'] = e.get('valu_issue_frac')
+            line[e['kernel'].replace('_kernel', '') + '_ms'] = e.get('ms_per_step')
+    for k in ('hits_per_step', 'candidates_per_step', 'clusters', 'rccl_ranks_seen', 'collective_backend', 'ms_per_step_after_device_sync', 'ms_per_step_incl_h2d',
+              'north_star_call_ms', 'uberblast_e2e_ms', 'get_similar_pairs_ms'):
+        if d.get(k) is not None:
+            line[k] = d[k]
+    scal = {
+        'get_similar_pairs_search_ms': _get(d, 'get_similar_pairs', 'search_ms'),
+        'two_searches_in_flight_ms': _get(d, 'two_searches_in_flight', 'ms_per_step'),
+        'search_50k_ms': _get(d, 'workloads', 'search_50k', 'ms_per_step'),
+        'search_50k_seed_match_frac': _get(d, 'workloads', 'search_50k', 'roofline', 'frac'),
+        'search_10k_blastn_ms': _get(d, 'workloads', 'search_10k_blastn', 'ms_per_step'),
+        'map_genomes_per_s': _get(d, 'map_workload', 'genomes_per_s'),
+        'pool_genomes_per_s': _get(d, 'map_workload', 'worker_pool', 'genomes_per_s_with_stores'),
+        'pool_gpu_busy_frac': _get(d, 'map_workload', 'worker_pool', 'gpu_busy_frac'),
+        'pool_cpu_s_per_genome': _get(d, 'map_workload', 'worker_pool', 'cpu_s_per_genome'),
+        'map_50k_genomes_per_s': _get(d, 'workloads', 'map_50k', 'genomes_per_s'),
+    }
+    line.update({k: v for k, v in scal.items() if v is not None})
+    err = [k for k in ('workloads', 'map_workload', 'two_searches_in_flight') if _get(d, k, 'error')]
+    if err:
+        line['leg_errors'] = err
+    line['detail'] = detail_file
+
+    def rnd(o):
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [rnd(v) for v in o]
+        return _num(o)
+    line = rnd(line)
+    text = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    # belt and braces: drop the secondary scalars from the end until the line fits
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline',
+            'parity_check', 'sw_cell_updates_per_s_per_gpu')
+    while len(text) >= COMPACT_LIMIT:
+        extra = [k for k in line if k not in keep]
+        if not extra:
+            break
+        del line[extra[-1]]
+        text = json.dumps(line, allow_nan=False, separators=(',', ':'))
+    return text
+
+
+DETAIL_FILE = os.environ.get('PEPPAN_BENCH_DETAIL')          # where the detail record goes instead of beside the script (tests)
+
+
+def emit(detail):
+    """detail -> bench_detail.json (beside the script, and under gpurun_out/ when that exists; or the ONE path PEPPAN_BENCH_DETAIL names); the compact
+    line -> stdout, the only line there"""
+    def clean(o):
+        if isinstance(o, dict):
+            return {str(k): clean(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [clean(v) for v in o]
+        if isinstance(o, float) and (o != o or o in (float('inf'), float('-inf'))):
+            return None
+        if isinstance(o, np.generic):
+            return clean(o.item())
+        return o
+    detail = clean(detail)
+    for where in ([DETAIL_FILE] if DETAIL_FILE else [os.path.join(ROOT, 'bench_detail.json'), os.path.join(ROOT, 'gpurun_out', 'bench_detail.json')]):
+        if os.path.isdir(os.path.dirname(where) or '.'):
+            try:
+                with open(where, 'w') as f:
+                    json.dump(detail, f, indent=1)
+                    f.write('\n')
+            except OSError as e:
+                sys.stderr.write('bench.py: bench_detail.json not written to %s: %r\n' % (where, e))
+    sys.stdout.write(compact_line(detail, os.path.basename(DETAIL_FILE) if DETAIL_FILE else 'bench_detail.json') + '\n')
+    sys.stdout.flush()
+
+
 def main_map(args, rank, local_rank, world):
     import torch
     import torch.distributed as dist
@@ -843,6 +966,7 @@ def main():
     ap.add_argument('--grid', default=None, help='RxC: query shards x reference shards of the all-vs-all (default: peppan_amd.dist.choose_grid); R*C must equal --gpus')
     ap.add_argument('--no-workloads', action='store_true', help='skip the configs[4] legs behind the headline (50k x 50k search step, 50k-exemplar mapping step)')
     args = ap.parse_args()
+    os.environ.setdefault('PEPPAN_LOG', '0')          # the reference-style progress lines of the legs (configure.logger) stay out of the bench's stderr
     if args.gpus > 1 and 'RANK' not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
 
@@ -1169,8 +1293,7 @@ def main():
             'parity_check': parity,
         }
         line.update(extras)
-        print(json.dumps(line))
-        sys.stdout.flush()
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

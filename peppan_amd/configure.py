@@ -9,6 +9,7 @@ external-binary discovery: nothing here shells out, the arithmetic lives in libp
     blosum62               configure.py:49-87    (same 32-stride letter indexing, built from the standard matrix)
 """
 import gzip
+import os
 import io
 import re
 import sys
@@ -20,7 +21,13 @@ xrange = range
 asc2int = np.uint32
 
 
-def logger(log, pipe=sys.stderr):
+def logger(log, pipe=None):
+    """the reference's progress lines (configure.py:23-25: time stamp, tab, text, to stderr).  PEPPAN_LOG=0 in the environment silences them
+    (bench.py does: a run of the mapping legs writes 1 500 of them, and worker processes inherit the setting); the stream is looked up per
+    call, so contextlib.redirect_stderr works on it too"""
+    if os.environ.get('PEPPAN_LOG', '1') == '0':
+        return
+    pipe = pipe if pipe is not None else sys.stderr
     pipe.write('{0}\t{1}\n'.format(str(datetime.now()), log))
     pipe.flush()
 

@@ -526,6 +526,138 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
     if (threadIdx.x < 2 && blk_stats[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)blk_stats[threadIdx.x]);
 }
 
+// ---- the nucleotide tool's matcher (round 6): BLAST's lookup stride (blastn -word_size 17 looks up shorter words at a stride and verifies them,
+// uberBlast.py:294).  The seeds are exact NW-mers over the four bases.  Every NW-mer holds exactly one NK-mer that starts at a packed position
+// = 0 (mod NS), NS = NW - NK + 1: the query index holds the NK-mers of EVERY query position, the targets are probed at every NS-th position only,
+// and a probe that finds its NK-mer at query position q looks at the NS - 1 bases on either side (the target's are in the tile, the query's are one
+// 4-byte read per side): with L matching bases to the left and R to the right (each capped at NS - 1) the NW-mers that start k = NS-1-R .. L bases
+// in front are exactly the seed hits this probe owns.  The raw hits are the plain matcher's, every one of them once - the candidate set, and with it
+// the hit table, is bit-identical - at a quarter of the probes: the plain matcher pays filter word + start[] + entries for EVERY position of an exact
+// run (three scattered requests per raw hit), this one pays them once per four.  NK = 14: 4^14 keys against ~10 M query positions keeps the filter
+// selective (3.7 % of the keys occupied; NK = 12 / stride 6 has 60 % occupied: every probe would walk a bucket and verify 0.6 chance matches).
+constexpr int NK = 14, NS = 4, NW = 17;
+constexpr int NTILE = 256 * NS;                       // target positions per tile: one probe per thread
+constexpr uint32_t PAD4 = 0x01010101u * PEP_PAD_CODE;
+
+__device__ __forceinline__ uint32_t nt_pack4(uint32_t d) { return (d | (d >> 6) | (d >> 12) | (d >> 18)) & 0xFFu; }          // four codes < 4 -> 8 bits, first base lowest (a byte >= 4 would spill into its neighbours' bits)
+__device__ __forceinline__ uint32_t nt_bad4(uint32_t d)                                                                    // bit i: byte i is not one of the four bases
+{
+    const uint32_t t = ((d >> 2) | (d >> 3) | (d >> 4)) & 0x01010101u;
+    return ((t * 0x01020408u) >> 24) & 0xFu;
+}
+
+// dword g of the packed targets (4-byte aligned: the buffers are hipMalloc'ed); padding outside [0, total)
+__device__ __forceinline__ uint32_t nt_fetch(const uint8_t *__restrict__ res, int64_t g, uint64_t total)
+{
+    if (g < 0) return PAD4;
+    const uint64_t b = (uint64_t)g * 4;
+    if (b + 4 <= total) return reinterpret_cast<const uint32_t *>(res)[g];
+    uint32_t v = PAD4;
+    for (int k = 0; k < 4; ++k)
+        if (b + k < total) v = (v & ~(0xFFu << (8 * k))) | ((uint32_t)res[b + k] << (8 * k));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
+{
+    static_assert(NK + NS - 1 == NW && NS == 4 && NK == 14, "one dword of flank per side, the look-up word in four dwords");
+    __shared__ uint64_t buf[HIT_BUF];
+    __shared__ uint32_t win[2][NTILE / 4 + 8];        // bytes [base - 4, base + NTILE + 28) of the tile, as dwords; two tiles in turn (one barrier per tile)
+    __shared__ uint32_t nbuf, blk_stats[2];
+    __shared__ unsigned long long gbase;
+    if (threadIdx.x == 0) { nbuf = 0; blk_stats[0] = blk_stats[1] = 0; }
+    __syncthreads();
+    uint32_t n_seed = 0, n_hit = 0;
+    const uint64_t n_tiles = (a.t_total + NTILE - 1) / NTILE;
+    const int x = threadIdx.x;
+    // this thread's dwords of the NEXT tile are fetched while the current one is worked on
+    uint32_t f0 = 0, f1 = 0;
+    if (blockIdx.x < n_tiles) {
+        const int64_t g0 = (int64_t)blockIdx.x * (NTILE / 4) - 1;
+        f0 = nt_fetch(a.t_res, g0 + x, a.t_total);
+        if (x < 8) f1 = nt_fetch(a.t_res, g0 + 256 + x, a.t_total);
+    }
+    int turn = 0;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, turn ^= 1) {
+        uint32_t *w = win[turn];
+        w[x] = f0;
+        if (x < 8) w[256 + x] = f1;
+        if (tile + gridDim.x < n_tiles) {
+            const int64_t g0 = (int64_t)(tile + gridDim.x) * (NTILE / 4) - 1;
+            f0 = nt_fetch(a.t_res, g0 + x, a.t_total);
+            if (x < 8) f1 = nt_fetch(a.t_res, g0 + 256 + x, a.t_total);
+        }
+        __syncthreads();
+        const uint32_t p = (uint32_t)(tile * NTILE) + 4u * x;            // the probe: packed target position, = 0 (mod NS)
+        const uint32_t d0 = w[x], d1 = w[x + 1], d2 = w[x + 2], d3 = w[x + 3], d4 = w[x + 4], d5 = w[x + 5];      // bytes p - 4 .. p + 19
+        const uint32_t inv = nt_bad4(d1) | (nt_bad4(d2) << 4) | (nt_bad4(d3) << 8) | (nt_bad4(d4) << 12) | (nt_bad4(d5) << 16);
+        // (statistics: target positions that start an NW-mer of the four bases)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) n_seed += ((inv >> j) & ((1u << NW) - 1)) == 0 ? 1u : 0u;
+        uint32_t e0 = 0, e1 = 0;
+        uint64_t key = 0;
+        if ((inv & ((1u << NK) - 1)) == 0) {
+            key = nt_pack4(d1) | (nt_pack4(d2) << 8) | (nt_pack4(d3) << 16) | (nt_pack4(d4 & 0xFFFFu) << 24);
+            const uint32_t b = hash_u64(key, a.bucket_bits);
+            uint32_t word;
+            const uint64_t m = filter_mask(key, a.bucket_bits, word);
+            if ((a.filter[word] & m) == m) { e0 = a.start[b]; e1 = a.start[b + 1]; }
+        }
+        const uint32_t tl = d0, tr = (d4 >> 16) | (d5 << 16);           // target bytes p - 4 .. p - 1 and p + 14 .. p + 17
+        for (uint32_t e = e0; e < e1; e += 2) {
+            uint64_t pair[2];
+            __builtin_memcpy(pair, a.entries + e, 16);
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const uint64_t ent = pair[k2];
+                if (e + k2 >= e1 || (ent >> POS_BITS) != key) continue;
+                const uint32_t qpos = (uint32_t)(ent & POS_MASK);
+                uint32_t ql, qr;                                        // query bytes qpos - 4 .. qpos - 1 and qpos + 14 .. qpos + 17 (>= 16 bytes of padding around every sequence)
+                __builtin_memcpy(&ql, a.q_res + qpos - 4, 4);
+                __builtin_memcpy(&qr, a.q_res + qpos + NK, 4);
+                const uint32_t ml = (ql ^ tl) | (tl & 0xFCFCFCFCu), mr = (qr ^ tr) | (tr & 0xFCFCFCFCu);
+                const int L = min(NS - 1, (int)(__clz((int)ml) >> 3));               // matching bases in front of the word (__clz(0) = 32)
+                const int R = mr ? min(NS - 1, (__ffs((int)mr) - 1) >> 3) : NS - 1;  // ... behind it
+                const int k_lo = NS - 1 - R, k_hi = L;
+                if (k_hi < k_lo) continue;
+                const uint32_t nh = (uint32_t)(k_hi - k_lo + 1);
+                n_hit += nh;
+                const uint32_t idx = atomicAdd(&nbuf, nh);
+                for (int k = k_hi; k >= k_lo; --k) {                    // increasing target position
+                    const uint64_t hit = ((uint64_t)(qpos - k) << 32) | (uint64_t)(p - k);
+                    const uint32_t at = idx + (uint32_t)(k_hi - k);
+                    if (at < HIT_BUF) buf[at] = hit;
+                    else {
+                        const unsigned long long g = atomicAdd(a.hit_count, 1ull);
+                        if (g < a.hit_cap) a.hits[g] = hit; else a.counters[2] = 1u;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t cnt = nbuf;
+        if (cnt > HIT_BUF / 2 || tile + gridDim.x >= n_tiles) {
+            const uint32_t n = min(cnt, (uint32_t)HIT_BUF);
+            if (threadIdx.x == 0) gbase = n ? atomicAdd(a.hit_count, (unsigned long long)n) : 0ull;
+            __syncthreads();
+            const unsigned long long g = gbase;
+            for (uint32_t i = threadIdx.x; i < n; i += 256) {
+                if (g + i < a.hit_cap) a.hits[g + i] = buf[i]; else a.counters[2] = 1u;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) nbuf = 0;
+            __syncthreads();
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        n_seed += __shfl_down(n_seed, d, 64);
+        n_hit += __shfl_down(n_hit, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&blk_stats[0], n_seed); atomicAdd(&blk_stats[1], n_hit); }
+    __syncthreads();
+    if (threadIdx.x < 2 && blk_stats[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)blk_stats[threadIdx.x]);
+}
+
 // Phase 2: raw seed hits -> runs of one candidate -> ungapped x-drop extensions -> candidate set, in ONE kernel (round 4; seed_runs + seed_extend
 // before, with the runs written to and read back from global memory in between: 20 bytes per run, 2 GB per shape at 50 000 genes).
 //
@@ -846,6 +978,10 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
     // query index build: by partition when the bucket count splits into <= 2^13 coarse x <= 2^12 fine buckets (reserved[2] != 0 forces the
     // count -> scan -> fill build, as does a coarse bucket that overflows LDS)
     const int fine_bits = std::min(12, bucket_bits - 8);
+    // the nucleotide tool (exact 17-mers over the four bases, one shape): look-up words at a stride (seed_match_stride); reserved[0] = 8 keeps the plain matcher
+    bool stride_lookup = P.n_shapes == 1 && P.base == 4 && P.weight[0] == NW && P.reserved[0] == 0;
+    for (int i = 0; i < NW && stride_lookup; ++i) stride_lookup = P.offs[0][i] == i;
+    for (int c = 0; c < 32 && stride_lookup; ++c) stride_lookup = P.reduce[c] == (c < 4 ? c : 0xFF);
     bool use_partition = P.reserved[2] == 0 && bucket_bits >= 16 && bucket_bits - fine_bits <= 13;
     for (int attempt = 0; attempt < 8; ++attempt) {
         const uint64_t cap = 1ull << table_bits;
@@ -868,7 +1004,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
         uint64_t q_seeds = 0;
         auto make_shape = [&](int s) {
             SeedShape sh;
-            sh.weight = P.weight[s];
+            sh.weight = stride_lookup ? NK : P.weight[s];      // (the look-up word of seed_match_stride: a prefix of the contiguous NW-mer)
             sh.base = P.base;
             for (int i = 0; i < 32; ++i) sh.offs[i] = P.offs[s][i];
             for (int w = 0; w < 4; ++w) sh.red4[w] = 0;
@@ -897,12 +1033,14 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
     do {                                                                                                              \
         if (sh.weight == 10) hipLaunchKernelGGL(KERNEL<10>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);            \
         else if (sh.weight == 17) hipLaunchKernelGGL(KERNEL<17>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);       \
+        else if (sh.weight == 14) hipLaunchKernelGGL(KERNEL<14>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);       \
         else hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(256), 0, ctx->stream, __VA_ARGS__);                             \
     } while (0)
 #define PEP_SEED_DISPATCH_LDS(KERNEL, GRID, LDS, ...)                                                                 \
     do {                                                                                                              \
         if (sh.weight == 10) hipLaunchKernelGGL(KERNEL<10>, GRID, dim3(256), LDS, ctx->stream, __VA_ARGS__);          \
         else if (sh.weight == 17) hipLaunchKernelGGL(KERNEL<17>, GRID, dim3(256), LDS, ctx->stream, __VA_ARGS__);     \
+        else if (sh.weight == 14) hipLaunchKernelGGL(KERNEL<14>, GRID, dim3(256), LDS, ctx->stream, __VA_ARGS__);     \
         else hipLaunchKernelGGL(KERNEL<0>, GRID, dim3(256), LDS, ctx->stream, __VA_ARGS__);                           \
     } while (0)
             if (use_partition) {
@@ -955,7 +1093,8 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(zero + PEP_ZERO_SHAPE) + 2 * s;      // per shape, cleared by the one fill
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
             pep_timer_begin(ctx, TM_MATCH0 + s);
-            PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 8u)), sh, a);
+            if (stride_lookup) hipLaunchKernelGGL(seed_match_stride, dim3((unsigned)std::min<uint64_t>(ceil_div(T.total, NTILE), 256u * 8u)), dim3(256), 0, ctx->stream, a);
+            else PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 8u)), sh, a);
             pep_timer_end(ctx, TM_MATCH0 + s);
 #ifdef PEP_PROBES
             if (P.reserved[0] == 7 && use_partition && sh.weight == 10) {

@@ -859,7 +859,12 @@ def _ahead(make, depth):
                         return
             finally:
                 gen.close()
-            box.put(('end', None))
+            while not stop.is_set():                 # (a consumer that stopped with the queue full must not leave this thread blocked for good)
+                try:
+                    box.put(('end', None), timeout=0.2)
+                    break
+                except queue.Full:
+                    pass
         except BaseException as e:
             while not stop.is_set():
                 try:
@@ -1316,8 +1321,6 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
         batch = max(1, min(per_round, ONE_PROCESS_BATCH, int(POOL_ROUND_NT // max(1., mean_nt))))          # (large genomes: fewer per search, as in a pool's rounds)
         searcher = lambda *a: _gpu_search(*a, genomes_per_batch=batch)
         searcher.runs_ahead = True
-        interval = sys.getswitchinterval()
-        sys.setswitchinterval(1e-3)
     stores = _StoreWriter(conn, seq_conn, mat_conn, clf_conn, saveSeq)
     clock = time.perf_counter
     spent = dict(stores=0.)
@@ -1353,7 +1356,10 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
     worker = threading.Thread(target=keeper, daemon=True)
     worker.start()
     t_start, main_cpu0 = clock(), time.thread_time()
+    interval = sys.getswitchinterval()
     try:
+        if own_ctx is not None:
+            sys.setswitchinterval(1e-3)             # (one process: the search thread and this one hand the interpreter to each other; restored below whatever happens)
         for job, G in _all_groups(prefix, clust, jobs, ortho, old_prediction, params, searcher, ctx, group, per_round, pool):
             if failure:
                 break
@@ -1366,8 +1372,7 @@ def get_map_bsn(prefix, clust, genomes, orthoGroup, old_prediction, conn, seq_co
             pool.close()
         if old_is_mine:
             old_prediction.close()
-        if own_ctx is not None:
-            sys.setswitchinterval(interval)
+        sys.setswitchinterval(interval)
     if failure:
         raise failure[0]
     t0 = clock()

@@ -427,9 +427,17 @@ class MapWorkers(object):
         for c in self._conns:
             c.send(msg)
         for c in self._conns:
-            r = c.recv()
+            # the answer to THIS message: a worker that is still sending what an abandoned round left behind (a reused pool whose last call
+            # failed half-way) is read past; a worker that says nothing within the deadline is an error, not a wait for ever
+            deadline = time.monotonic() + 300.
+            while True:
+                if not c.poll(max(0., deadline - time.monotonic())):
+                    raise RuntimeError('MapWorkers: a worker did not answer the set-up message within 300 s')
+                r = c.recv()
+                if r[0] in ('ready', 'error'):
+                    break
             if r[0] != 'ready':
-                raise RuntimeError('MapWorkers: a worker failed to set up:\n' + r[2])
+                raise RuntimeError('MapWorkers: a worker failed to set up:\n%s' % (r[2] if isinstance(r[2], str) else repr(r[2]),))
 
     def _replace(self, i):
         """worker i is given up: killed, and a fresh child process - started by this process like the first ones, set up like them - takes its place"""
@@ -600,6 +608,13 @@ class MapWorkers(object):
                 #                                      numbers already and the caller waits for them - it must hear)
                 gone = isinstance(e, (EOFError, OSError))
                 text = ('a mapping worker went away: %r' % (e,)) if gone else traceback.format_exc()
+                if not gone and any(r is not None for r in held):
+                    # the worker still works on (or waits for the answer to) a round this thread will never finish: a process in that state would
+                    # send its 'counts' into the NEXT call of a reused pool.  A fresh process takes its place - the pool stays in step.
+                    try:
+                        self._replace(i)
+                    except Exception:
+                        pass
                 with cond:
                     for r in held:
                         if r is not None and r not in results:

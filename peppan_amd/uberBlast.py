@@ -338,7 +338,7 @@ class RunBlast(object):
         self.qrySeq = self.refSeq = None
         self._q_key = self._r_key = None    # cache keys of the files the sequences came from (None: handed over by the caller)
         self.device = device
-        self._nt_loaded = None
+        self._nt_loaded = {}                # id(context) -> what this instance left on it (one entry per context: the two tools run on two threads)
         self._batch = None                  # (reference names genome-major, genome id per name) in run_batch
         self._as_tables = False             # True: run() / run_batch() hand over the numeric HitTable instead of object rows
         # how the nucleotide tool treats the HSPs of one subject: 1 (default) every 64-diagonal band that reaches the threshold; 2 BLAST-like culling
@@ -421,9 +421,10 @@ class RunBlast(object):
             # (a thread that comes back from the library waits for the interpreter lock until the other one gives it up: at the default 5 ms
             # between such requests the two tools cost more side by side than one after the other - 30.5 against 29.1 ms per call; at 0.1 ms 24.0)
             interval = sys.getswitchinterval()
-            sys.setswitchinterval(1e-4)
-            side.start()
         try:
+            if side is not None:
+                sys.setswitchinterval(1e-4)
+                side.start()
             for k, method in enumerate(todo):
                 if side is None or k != k_side:
                     outcomes[k] = attempt(method)
@@ -431,7 +432,8 @@ class RunBlast(object):
                         break                     # (one after the other: nothing runs behind a failure)
         finally:
             if side is not None:
-                side.join()
+                if side.ident is not None:
+                    side.join()
                 sys.setswitchinterval(interval)
         for k in range(len(todo)):
             o = outcomes.get(k)
@@ -588,7 +590,7 @@ class RunBlast(object):
         membership is reproduced.  The context is shared by every RunBlast of the process: what this instance uploaded is only
         still there while the context's upload generation is the one it left behind (frames None = any frame count will do)."""
         gen = getattr(ctx, 'upload_generation', 0)
-        done = (self._nt_loaded or {}).get(id(ctx))
+        done = self._nt_loaded.get(id(ctx))
         if done is not None and done[2] == gen and done[1] == self.table_id and frames in (None, done[0]):
             return
         frames = frames or 6
@@ -607,8 +609,6 @@ class RunBlast(object):
             ctx.set_ref_nt(r['packed'], frames, self.table_id)
             ctx.r_nt_token = r_token
         ctx.set_target_groups(None if self._batch is None else self._batch[1])
-        if self._nt_loaded is None:
-            self._nt_loaded = {}
         self._nt_loaded[id(ctx)] = (frames, self.table_id, getattr(ctx, 'upload_generation', 0))
 
     @staticmethod
@@ -694,6 +694,11 @@ class RunBlast(object):
         HOME = _TILE_HOME
         halo = ((int(q_len.max()) if len(q_len) else 0) + 256 + 63) // 64 * 64
         tiled = bool(len(r_len)) and int(r_len.max()) > N.MAX_SEQ_LEN
+        if self.blast_hsp_mode == 2:
+            # hsp_mode 2 (unpinned, an option) culls and counts per SUBJECT; on this path every strand and every window of a long sequence is a
+            # target of its own, i.e. its own subject: the list would silently mean something else than on the usual path
+            raise N.PepError('runBlast: PEPPAN_BLAST_HSP_MODE=2 is not defined for reference sequences beyond %d nt (searched as windows: every window '
+                             'would be a subject of its own); use the default hsp_mode 1' % N.MAX_SEQ_LEN)
         if tiled and HOME + 2 * halo > N.MAX_SEQ_LEN:
             raise N.PepError('runBlast: queries of %d nt are too long to tile a %d nt reference sequence (PEP_ERR_LIMIT)' % (int(q_len.max()), int(r_len.max())))
         t_woff, t_hlo, t_hhi = [], [], []
@@ -728,7 +733,8 @@ class RunBlast(object):
         ctx.set_query_aa((q_codes, q_off))
         ctx.set_ref_aa((np.concatenate(parts) if parts else np.zeros(0, np.uint8), t_off))
         ctx.set_target_groups(None if self._batch is None else t_grp)
-        self._nt_loaded = None                      # the packed protein sets of a previous translated search are gone
+        self._nt_loaded.pop(id(ctx), None)          # the packed sets THIS context held from an earlier search are gone (only this context's record: the
+        #                                             other tool's thread may be reading or writing its own entry at this moment)
         hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
         table = blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len,
                                     self.min_id, self.min_cov, self.min_ratio, params, np.array(t_seq, dtype=np.int64), np.array(t_rev, dtype=bool),

@@ -384,6 +384,58 @@ def test_nucleotide_search_engine_vs_oracle(ctx):
     assert (gh['q'] == gh['t']).sum() == 400           # every gene finds itself on the forward strand
 
 
+def test_nucleotide_stride_lookup_equals_plain_matcher_and_oracle(ctx):
+    """seed_match_stride (14-mer look-ups at every fourth target position + flank verification, round 6) against the plain 17-mer matcher
+    (params.reserved[0] = 8) and the oracle: same raw hit COUNT, same target-seed count, same candidates, same table and CIGARs.  Inputs made to
+    sit on the rule's edges: exact runs of 14 .. 21 bases planted at every phase of the stride and across the 1 024-position tile borders,
+    ambiguous bases inside and next to runs, genes shorter than a word, repeats, both strands, a target set that ends inside a tile"""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    rc = np.array([3, 2, 1, 0, 4], dtype=np.uint8)
+    for rep in range(4):
+        names, seqs = synth.make_genes(120 + 40 * rep, 0, seed=90 + rep)
+        codes = [O.nt_codes(s) for s in seqs]
+        # short genes, genes with ambiguous bases
+        codes += [rng.integers(0, 4, size=n).astype(np.uint8) for n in (5, 13, 14, 16, 17, 18, 21, 33)]
+        amb = [c.copy() for c in codes[:30]]
+        for c in amb:
+            c[rng.integers(0, len(c), size=max(1, len(c) // 40))] = 4
+        # targets: the genes, pieces of them of every length around the word size planted in random sequence at every offset, both strands
+        planted = []
+        for ln in range(13, 23):
+            for ph in range(4):
+                g = codes[int(rng.integers(0, 100))]
+                st = int(rng.integers(0, len(g) - ln))
+                left = rng.integers(0, 4, size=40 + ph).astype(np.uint8)
+                right = rng.integers(0, 4, size=37).astype(np.uint8)
+                piece = g[st:st + ln].copy()
+                # the bases right outside the run differ from the gene's, so the exact run is ln long (unless the gene goes on by chance further out)
+                if st > 0:
+                    left[-1] = (g[st - 1] + 1) % 4
+                if st + ln < len(g):
+                    right[0] = (g[st + ln] + 1) % 4
+                planted.append(np.concatenate([left, piece, right]))
+        filler = [rng.integers(0, 4, size=int(n)).astype(np.uint8) for n in rng.integers(900, 1200, size=6)]      # moves what follows across tile borders
+        targets = codes[:60] + planted + filler + amb + codes[60:]
+        targets = targets + [rc[c[::-1]] for c in targets]
+        queries = codes + amb
+        ctx.set_query_aa(queries)
+        ctx.set_ref_aa(targets)
+        out = {}
+        for flag in (0, 8):
+            p = N.nucleotide_params(70., 25.)
+            p.reserved[0] = flag
+            gh, gc, st = ctx.search(p)
+            out[flag] = (gh.tobytes(), gc.tobytes(), st['target_seeds'], st['seed_hits'], st['candidates'], st['pairs'])
+        assert out[0] == out[8], (rep, out[0][2:], out[8][2:])
+        p = N.nucleotide_params(70., 25.)
+        ms = np.array([O.min_score(len(c), p.dbsize, p.max_evalue, p.ka_lambda, p.ka_k) for c in queries], dtype=np.int32)
+        oh, oc, ost = O.search(queries, targets, O.params_from(p), min_scores=ms)
+        _cmp_hits(np.frombuffer(out[0][0], dtype=N.HIT_DTYPE), np.frombuffer(out[0][1], dtype=np.uint32), oh, oc)
+        assert out[0][4] == ost['candidates'] and out[0][3] > 20000
+
+
 def test_uberblast_dropin_blastn_and_diamond(tmp_path, monkeypatch):
     """the reference's actual exemplar call: --blastn --diamond -s 1 (PEPPAN.py:229-230), both tools on the GPU"""
     import io, contextlib
@@ -718,7 +770,7 @@ def test_bench_starts_its_own_ranks(tmp_path):
     with n_gpus 2, and the gathered + merged table equals the CPU oracle's"""
     import json, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, PEPPAN_BENCH_SHARE_GPU='1')
+    env = dict(os.environ, PEPPAN_BENCH_SHARE_GPU='1', PEPPAN_BENCH_DETAIL=str(tmp_path / 'detail.json'))
     env.pop('RANK', None); env.pop('WORLD_SIZE', None)
     out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--genes', '400', '--steps', '2', '--warmup', '1', '--no-e2e'],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
@@ -732,7 +784,10 @@ def test_bench_starts_its_own_ranks(tmp_path):
     one = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--genes', '400', '--steps', '2', '--warmup', '1'],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert one.returncode == 0, one.stderr.decode()[-2000:]
-    l1 = json.loads([l for l in one.stdout.decode().splitlines() if l.startswith('{')][0])
+    assert one.stdout.decode().count('\n') == 1 and len(one.stdout) < 4096          # ONE compact line on stdout, the rest in the detail file
+    l1 = json.loads(one.stdout.decode())
+    assert l1['roofline']['bound'] == 'hbm' and l1['roofline']['frac'] > 0 and l1['cpu_baseline']['kind'] == 'port' and l1['detail'] == 'detail.json'
+    l1 = json.load(open(str(tmp_path / 'detail.json')))
     assert l1['n_gpus'] == 1 and l1['cpu_baseline']['gpu_hits_identical'] is True and l1['hits_per_step'] == line['hits_per_step']
     assert l1['clusters'] == line['clusters'] and l1['uberblast_e2e_ms'] > 0 and l1['ms_per_step_incl_h2d'] > 0
     assert len(l1['roofline_kernels']) == 3 and l1['roofline']['kernel'] == l1['roofline_kernels'][0]['kernel']

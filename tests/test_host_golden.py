@@ -247,7 +247,7 @@ def test_run_end_to_end_with_canned_aligner_output(tmp_path, monkeypatch, oracle
     def init(self, device=None, **kw):
         orig_init(self, device, **kw)
         oracle_ctx['ctx'] = OracleCtx(self)
-        self._nt_loaded = None
+        self._nt_loaded = {}
         made.append(self)
     monkeypatch.setattr(UB.RunBlast, '__init__', init)
     for case in g['cases']:
