@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 13
+#define PEP_ABI_VERSION 14
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -323,6 +323,13 @@ typedef struct {
     double identity_x1e4;                 /* params match_identity * 10000 (PEPPAN.py:213) */
     int32_t any_frame, pad;               /* 'f' in params incompleteCDS (PEPPAN.py:205) */
 } pep_support_limits;
+/* pep_similar_classify (host, no context; ABI 14): the row-local tests of PEPPAN.py:244-263 over the numeric columns, one pass - what pep_similar_scan takes
+ *   as action / forward / iden4.  q / r: gene codes; rank_ge[k] / rank_le[k]: priority rank of row k's query gene >= / <= that of its reference gene
+ *   (PEPPAN.py:252, 257: the caller compares whatever type its priorities have); near_identity = clust_identity, cover = clust_match_prop.
+ *   Float arithmetic as the reference's float() conversions make it (IEEE double, sqrt(cover) correctly rounded). */
+int pep_similar_classify(uint64_t n, const int64_t *q, const int64_t *r, const double *iden, const int64_t *qs, const int64_t *qe, const int64_t *ss,
+                         const int64_t *se, const int64_t *ql, const int64_t *sl, const uint8_t *rank_ge, const uint8_t *rank_le, double near_identity,
+                         double cover, uint8_t *action, uint8_t *forward, int32_t *iden4);
 int pep_similar_scan(uint64_t n, const int64_t *q, const int64_t *r, const uint8_t *action, const uint8_t *forward, const int32_t *iden4, uint64_t n_genes,
                      uint8_t *alive, uint8_t *seen_as_query, int64_t *absorbed, uint64_t *n_absorbed,
                      uint8_t *ev_kind, int64_t *ev_a, int64_t *ev_b, uint64_t *ev_row_off, uint64_t *ev_rows, uint64_t *n_events);

@@ -2,19 +2,20 @@
 if the HIP library is missing or no MI355X is visible every entry point raises."""
 import ctypes as C
 import os
+import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params', 'pep_set_sensitivity',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_fasta_records', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast', 'pep_argsort_object_order',
+           'pep_similar_classify', 'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_fasta_records', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast', 'pep_argsort_object_order',
            'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather']
 
 
@@ -137,10 +138,19 @@ def min_score(qlen, dbsize=5e6, max_evalue=1.):
     return int(load_library().pep_min_score(int(qlen), float(dbsize), float(max_evalue)))
 
 
+_NUCL_PARAMS = {}
+
+
 def nucleotide_params(min_id_pct=0., min_qcov_pct=0., top_k=1000, dbsize=5e6, max_evalue=1e-2, hsp_mode=1):
     """the search engine configured like the reference's blastn call (uberBlast.py:294): residues A0 C1 G2 T3 (other 4),
     exact 17-mers (-word_size 17), reward 2 / penalty -3, gap 6 + 2k, e-value 1e-2 at dbsize 5e6, 1000 targets per query.
     Karlin-Altschul lambda 0.625 / K 0.41 are NCBI's published values for 2/-3 with gap costs 5/2 (closest tabulated)."""
+    if hsp_mode not in (1, 2):
+        raise ValueError('nucleotide_params: hsp_mode 1 (every band that reaches the threshold) or 2 (BLAST-like culling, top_k counts subjects)')
+    key = (float(min_id_pct), float(min_qcov_pct), int(top_k), float(dbsize), float(max_evalue), int(hsp_mode))
+    made = _NUCL_PARAMS.get(key)
+    if made is not None:                 # (the block is 1.4 KB of fields set one by one below - half a millisecond of every nucleotide search: a copy of the first one)
+        return SearchParams.from_buffer_copy(made)
     p = default_params(min_id_pct, min_qcov_pct, top_k, 1, dbsize, max_evalue)
     p.gap_open, p.gap_ext = 6, 2
     p.n_shapes, p.base = 1, 4
@@ -156,9 +166,9 @@ def nucleotide_params(min_id_pct=0., min_qcov_pct=0., top_k=1000, dbsize=5e6, ma
     p.ungapped_min, p.xdrop, p.ext_right, p.ext_left = 40, 16, 40, 24
     p.stage1_min = 0                     # (an exact 17-mer scores 32 over its first 16 bases: the first stage has nothing to reject here)
     p.ka_lambda, p.ka_k = 0.625, 0.41
-    if hsp_mode not in (1, 2):
-        raise ValueError('nucleotide_params: hsp_mode 1 (every band that reaches the threshold) or 2 (BLAST-like culling, top_k counts subjects)')
     p.hsp_mode = hsp_mode                # blastn reports every HSP of a subject; a contig can carry several copies of a gene.  2: include/peppan_hip.h
+    if len(_NUCL_PARAMS) < 64:
+        _NUCL_PARAMS[key] = bytes(p)
     return p
 
 
@@ -504,6 +514,23 @@ def store_tab_archive(rows, off, keys, date_time, threads=None, order=None):
     raise PepError('pep_store_tab_archive: the archive did not fit the size it had asked for')
 
 
+def similar_classify(T, q, r, rank_ge, rank_le, near_identity, cover):
+    """pep_similar_classify: the row-local tests of PEPPAN.py:244-263 over a HitTable's columns -> (action uint8[n], forward uint8[n], iden4 int32[n])"""
+    lib = load_library()
+    n = len(T)
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    q, r = i64(q), i64(r)
+    cols = [i64(T.qs), i64(T.qe), i64(T.ss), i64(T.se), i64(T.ql), i64(T.sl)]
+    iden = np.ascontiguousarray(T.iden, dtype=np.float64)
+    ge, le = np.ascontiguousarray(rank_ge, dtype=np.uint8), np.ascontiguousarray(rank_le, dtype=np.uint8)
+    action, forward, iden4 = np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.uint8), np.empty(n, dtype=np.int32)
+    rc_ = lib.pep_similar_classify(C.c_uint64(n), _ptr(q), _ptr(r), _ptr(iden), *([_ptr(c) for c in cols] + [_ptr(ge), _ptr(le), C.c_double(near_identity), C.c_double(cover),
+                                   _ptr(action), _ptr(forward), _ptr(iden4)]))
+    if rc_ != 0:
+        raise PepError('pep_similar_classify failed (%d)' % rc_)
+    return action, forward, iden4
+
+
 def similar_scan(q, r, action, forward, iden4, n_genes):
     """pep_similar_scan: the ordered pass of get_similar_pairs (PEPPAN.py:231-276) over numeric columns -> dict(alive, seen_as_query,
     absorbed int64[m, 3], ev_kind, ev_a, ev_b, ev_row_off, ev_rows)"""
@@ -561,12 +588,21 @@ def fasta_scan(data, table, n_records):
 _UPPER = np.frombuffer(bytes(range(256)).upper(), dtype=np.uint8)
 
 
-def fasta_records(data):
+_SCRATCH = threading.local()
+
+
+def fasta_records(data, as_dict=False):
     """pep_fasta_records: the records of FASTA text `data` (ASCII bytes without carriage returns) as (names, text, off): names = list of str (first word
     of every header line), text = all sequences upper-cased and without blanks in one str, off = int64[n + 1] where each record's sequence starts in it.
-    None when a header has no name or a sequence holds non-ASCII bytes: the caller then goes its own way."""
+    None when a header has no name or a sequence holds non-ASCII bytes: the caller then goes its own way.  as_dict: the records as {name: sequence}
+    (of two records with one name the later one) instead."""
     lib = load_library()
-    codes = np.empty(max(len(data), 1), dtype=np.uint8)
+    # the cleaned sequences land in a scratch buffer this thread keeps (a fresh 10 MB array costs a page fault per 4 KiB - a third of the scan)
+    codes = getattr(_SCRATCH, 'codes', None)
+    if codes is None or len(codes) < len(data) or not as_dict:
+        codes = np.empty(max(len(data), 1), dtype=np.uint8)
+        if as_dict and len(data) <= (64 << 20):
+            _SCRATCH.codes = codes
     nr, high = C.c_uint64(), C.c_int32()
     cap = max(1024, len(data) // 128)                # (a guess; a file of shorter records is counted and scanned again)
     while True:
@@ -581,6 +617,9 @@ def fasta_records(data):
     n = nr.value
     if high.value or (n and int(name_len[:n].min()) == 0):
         return None
+    if as_dict:                                      # {name: sequence} made by one C loop over the buffers (csrc/pyrows.c)
+        from .hittable import _pyrows
+        return _pyrows().pep_records_dict(data, name_off.ctypes.data, name_len.ctypes.data, codes.ctypes.data, off.ctypes.data, n)
     a = name_off[:n].astype(np.int64)
     b = a + name_len[:n]
     names = [data[x:y].decode('ascii') for x, y in zip(a.tolist(), b.tolist())]

@@ -108,11 +108,9 @@ def _fasta_records(data, headOnly=False):
     decoded as the text-mode reader would and goes record by record."""
     if not headOnly and data.isascii() and b'\r' not in data:
         from . import _native
-        got = _native.fasta_records(data)
+        got = _native.fasta_records(data, as_dict=True)
         if got is not None:
-            names, text, off = got
-            cuts = off.tolist()
-            return dict(zip(names, map(text.__getitem__, map(slice, cuts[:-1], cuts[1:]))))
+            return got
     return _fasta_text_records(io.TextIOWrapper(io.BytesIO(data), encoding='utf-8').read(), headOnly)
 
 

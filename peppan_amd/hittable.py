@@ -33,6 +33,8 @@ def _pyrows():
         lib.pep_strs_pack.argtypes = [C.py_object, C.c_void_p, C.c_int64]
         lib.pep_digest_ints.restype = C.py_object
         lib.pep_digest_ints.argtypes = [C.c_void_p, C.c_ssize_t, C.c_ssize_t]
+        lib.pep_records_dict.restype = C.py_object
+        lib.pep_records_dict.argtypes = [C.c_char_p] + [C.c_void_p] * 4 + [C.c_ssize_t]
         _PYROWS = lib
     return _PYROWS
 

@@ -284,7 +284,8 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
     the names compared as strings) deciding which exemplars are absorbed by a near-identical in-frame partner, which pairs conflict (-2)
     and which are ortholog-like (mean identity * 1e4).  Nothing here walks rows in Python and no row ever becomes a Python object:
       * the search hands over its numeric HitTable (columns + CIGAR arena);
-      * the row-local tests are numpy expressions over the columns (_classify_rows);
+      * the row-local tests are one pass of host C++ over the columns (pep_similar_classify; _classify_rows is their numpy statement, kept as the
+        test's yardstick);
       * the order-dependent state - alive[g] (0 once g was absorbed or found repetitive; rows touching a dead gene are ignored from then
         on) and the pending forward rows of the current (query, reference) pair, settled when the NEXT surviving row belongs to another
         pair - is one pass of host C++ inside the library (pep_similar_scan); it does not depend on what get_similar returns, so
@@ -313,7 +314,8 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
         genes = np.unique(np.concatenate([q_ids[seen_q], r_ids[seen_r]]))      # sorted: codes keep the order of the ids
         q, r = np.searchsorted(genes, q_ids)[T.qi], np.searchsorted(genes, r_ids)[T.ri]
         rank = np.array(list(map(itemgetter(0), map(priorities.__getitem__, genes.tolist()))))
-        action, forward, iden4 = _classify_rows(T, rank[q], rank[r], q, r, params['clust_identity'], params['clust_match_prop'])
+        rank_q, rank_r = rank[q], rank[r]
+        action, forward, iden4 = N.similar_classify(T, q, r, rank_q >= rank_r, rank_q <= rank_r, params['clust_identity'], params['clust_match_prop'])
         mark('classify')
         sc = N.similar_scan(q, r, action, forward, iden4, len(genes))
         mark('scan')

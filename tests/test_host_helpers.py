@@ -282,3 +282,42 @@ def test_overlaps_of_several_tables_in_one_sweep_equal_one_sweep_per_table():
         assert len(got) == 4 and sum(map(len, want)) > 100
         for w, g in zip(want, got):
             assert np.array_equal(np.asarray(w).reshape(-1, 3), np.asarray(g).reshape(-1, 3))
+
+
+def test_similar_classify_equals_its_numpy_statement():
+    """pep_similar_classify (host C++, one pass) against pipeline._classify_rows (the numpy form of PEPPAN.py:244-263) over random tables: coordinates
+    on both strands, every frame relation, identities on both sides of the threshold, equal and unequal lengths, ranks of all three orders"""
+    from peppan_amd import _native as N, pipeline as PL
+
+    class Cols(object):                                               # (the columns the two functions read, as a HitTable holds them)
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def __len__(self):
+            return len(self.iden)
+    rng = np.random.default_rng(5)
+    seen_actions = set()
+    for rep in range(20):
+        n = int(rng.integers(0, 3000))
+        ql, sl = rng.integers(60, 400, size=n), rng.integers(60, 400, size=n)
+        same = rng.random(n) < 0.4
+        sl[same] = ql[same]
+        qs = rng.integers(1, 30, size=n)
+        qe = np.minimum(ql, qs + rng.integers(20, 400, size=n))
+        a, b = rng.integers(1, 30, size=n), rng.integers(20, 400, size=n)
+        lo, hi = np.minimum(a, sl), np.minimum(sl, a + b)
+        rev = rng.random(n) < 0.3
+        ss, se = np.where(rev, hi, lo), np.where(rev, lo, hi)
+        full = rng.random(n) < 0.3                                    # full-length in-frame rows: the absorb branches
+        qs[full], qe[full], ss[full], se[full] = 1, ql[full], 1, sl[full]
+        iden = np.round(rng.uniform(0.8, 1.0, size=n), 3)
+        q, r = rng.integers(0, 50, size=n), rng.integers(0, 50, size=n)
+        rank = rng.integers(0, 3, size=50)
+        T = Cols(iden=iden, qs=qs, qe=qe, ss=ss, se=se, ql=ql, sl=sl)
+        for near, cover in ((0.9, 0.8), (0.95, 0.5), (0.85, 1.0)):
+            want = PL._classify_rows(T, rank[q], rank[r], q, r, near, cover)
+            got = N.similar_classify(T, q, r, rank[q] >= rank[r], rank[q] <= rank[r], near, cover)
+            for w, g in zip(want, got):
+                assert w.dtype == g.dtype and np.array_equal(w, g)
+            seen_actions.update(want[0].tolist())
+    assert seen_actions == {0, 1, 2, 3}                                # every action occurs
