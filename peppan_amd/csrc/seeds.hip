@@ -409,6 +409,8 @@ struct JoinArgs {
     unsigned long long *hit_count;
     uint64_t hit_cap;
     int debug;               // profiling aid (params.reserved[0]): 1 = keys only, 2 = keys + bucket lookup, 3 = + entry compare (no extension), 9 = no wave-level de-duplication
+    const int32_t *self_delta;   // self-search (pep_self_map): per 32-byte block of the targets, target position - query position of the hits that are a gene against itself on
+                                 // diagonal 0 (PEP_SELF_NO_DELTA: none); nullptr = off.  Such hits are counted and dropped: self_candidates settles their candidate.
 };
 
 __device__ __forceinline__ void set_insert(const JoinArgs &a, uint64_t k)
@@ -463,13 +465,19 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
     // the residues of the NEXT tile are fetched into a register while this one is processed: a block walks ~60 tiles one after the
     // other, and without this every tile starts with an exposed global-memory latency
     uint32_t fetched = blockIdx.x < n_tiles ? fetch_tile(a.t_res, blockIdx.x, a.t_total) : 0u;
+    // (self-search: the block's distance word rides along with the residues - eight distinct words per tile, one request per wavefront)
+    int32_t sd_next = (a.self_delta && blockIdx.x < n_tiles) ? a.self_delta[((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 5] : PEP_SELF_NO_DELTA;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t p = tile * 256 + threadIdx.x;
         uint64_t key = 0;
         uint32_t e0 = 0, e1 = 0;
+        const int32_t sd = sd_next;
         red[threadIdx.x] = reduce_letter(sh, fetched);
         if (threadIdx.x < TILE_HALO) red[TILE + threadIdx.x] = reduce_letter(sh, fetched >> 8);
-        if (tile + gridDim.x < n_tiles) fetched = fetch_tile(a.t_res, tile + gridDim.x, a.t_total);
+        if (tile + gridDim.x < n_tiles) {
+            fetched = fetch_tile(a.t_res, tile + gridDim.x, a.t_total);
+            if (a.self_delta) sd_next = a.self_delta[((tile + gridDim.x) * 256 + threadIdx.x) >> 5];
+        }
         __syncthreads();
         if (p + 32 <= a.t_total && tile_key<W>(sh, red, threadIdx.x, key)) {
             ++n_seed;
@@ -493,6 +501,7 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
                 if (e + k >= e1 || (ent >> POS_BITS) != key) continue;
                 ++n_hit;
                 if (a.debug == 3) continue;
+                if ((int32_t)((uint32_t)p - (uint32_t)(ent & POS_MASK)) == sd) continue;      // a gene against itself on diagonal 0: settled by self_candidates
                 const uint64_t hit = ((ent & POS_MASK) << 32) | p;
                 const uint32_t idx = atomicAdd(&nbuf, 1u);
                 if (idx < HIT_BUF) buf[idx] = hit;
@@ -853,6 +862,64 @@ __global__ __launch_bounds__(256) void seed_runs_extend(JoinArgs a)
     if (threadIdx.x == 0 && blk_pass) atomicAdd(&a.stats[2], (unsigned long long)blk_pass);
 }
 
+// Self-search: the candidate of a gene against itself on diagonal 0, whose seed hits seed_match counts and drops (JoinArgs::self_delta).  The candidate set is
+// a SET, and a candidate is in it iff ONE seed hit of its (q, t, diagonal bin) passes the ungapped pre-filter (oracle: find_candidates / ungapped_score) - so the
+// hits on diagonal 0 are judged here, from the sequences alone: every position of query g that starts a seed of one of the shapes IS a hit of g against the target
+// that repeats it (same residues, same key, in the index by construction), and its extension is the oracle's loop over the packed residues (padding scores -64
+// and ends an extension where the sequence ends: x-drop < 64).  One wavefront per query, 64 positions per round, until one passes (the first round, as a rule).
+// Hits of the same pair that seed_match did not drop (the last, partial block; other diagonals of the bin) take the usual way; inserting twice is harmless.
+__global__ __launch_bounds__(256) void self_candidates(SeedShapeSet shs, int n_shapes, JoinArgs a, const uint32_t *__restrict__ self_t, const uint32_t *__restrict__ q_len)
+{
+    __shared__ int8_t sub[1024];
+    reinterpret_cast<uint32_t *>(sub)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.sub)[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= a.nq) return;
+    const uint32_t t = self_t[g];
+    if (t == PEP_SELF_NONE) return;
+    const uint32_t qs = a.q_off[g], ts = a.t_off[t], ql = q_len[g];
+    constexpr int STAGE1_LEN = 16;
+    for (int s = 0; s < n_shapes; ++s) {
+        const SeedShape &sh = shs.s[s];
+        for (uint32_t x0 = 0; x0 < ql; x0 += 64) {
+            const uint32_t x = x0 + (uint32_t)lane;
+            bool pass = false;
+            if (x < ql) {
+                bool seeds = true;
+                for (int i = 0; i < sh.weight; ++i) seeds = seeds && reduce_letter(sh, a.q_res[qs + x + sh.offs[i]]) != 15u;
+                if (seeds) {
+                    const uint8_t *q = a.q_res + qs + x, *tt = a.t_res + ts + x;
+                    int sc = 0, br = 0, bl = 0, k = 0;
+                    bool dead = false;
+                    for (; k < a.ext_right; ++k) {
+                        if (k == STAGE1_LEN && br < a.stage1_min) { dead = true; break; }
+                        sc += sub[(q[k] & 31) * 32 + (tt[k] & 31)];
+                        if (sc > br) br = sc;
+                        else if (br - sc > a.xdrop) break;
+                    }
+                    if (!dead && br >= a.stage1_min) {
+                        sc = 0;
+                        for (k = 1; k <= a.ext_left; ++k) {
+                            sc += sub[(q[-k] & 31) * 32 + (tt[-k] & 31)];
+                            if (sc > bl) bl = sc;
+                            else if (bl - sc > a.xdrop) break;
+                        }
+                        pass = br + bl >= a.ungapped_min;
+                    }
+                }
+            }
+            if (__ballot(pass)) {
+                if (lane == 0) {
+                    set_insert(a, ((uint64_t)g << 43) | ((uint64_t)t << 18) | (uint64_t)((1u << 23) >> 6));      // diagonal 0: bin (0 + 2^23) >> 6
+                    atomicAdd(&a.stats[2], 1ull);
+                }
+                return;
+            }
+        }
+    }
+}
+
 // hash set -> dense list (arbitrary order; sorted afterwards).  One global atomic per block and per COMPACT_ROUNDS x 256 slots:
 // the single counter word sustains ~90 atomics/us, so 4096 blocks with one atomic each spent 45 us waiting for it.
 constexpr int COMPACT_ROUNDS = 16;
@@ -1002,6 +1069,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
         ctx->zero_clean = false;
         for (bool &f : ctx->zero_ok) f = true;
         uint64_t q_seeds = 0;
+        int self_on = 0;
         auto make_shape = [&](int s) {
             SeedShape sh;
             sh.weight = stride_lookup ? NK : P.weight[s];      // (the look-up word of seed_match_stride: a prefix of the contiguous NW-mer)
@@ -1090,6 +1158,8 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             a.counters = counters; a.stats = stats;
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
             a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.stage1_min = P.stage1_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
+            if (s == 0 && !stride_lookup && P.ungapped_min > 0 && P.reserved[0] == 0) PEP_TRY(pep_self_map(ctx, &self_on));     // (reserved[0] = 10: the plain stream, for comparison)
+            a.self_delta = self_on ? ctx->d_self_delta.as<const int32_t>() : nullptr;
             unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(zero + PEP_ZERO_SHAPE) + 2 * s;      // per shape, cleared by the one fill
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
             pep_timer_begin(ctx, TM_MATCH0 + s);
@@ -1114,6 +1184,13 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             // (same-box A/B, tools/ab/phase2_ab.sh: four trips of 64 hits per strip; 8 blocks per CU at 10 k genes - 122 us against 126 with 16 -, 16 at 50 k - 1.71 ms against 1.86)
             hipLaunchKernelGGL(seed_runs_extend, dim3(256u * (T.total > (48ull << 20) ? 16u : 8u)), dim3(256), 0, ctx->stream, a);
             PEP_HIP(ctx, hipGetLastError());
+            if (self_on && s == P.n_shapes - 1) {
+                // the candidates of the genes against themselves, whose diagonal-0 hits the matchers dropped: all shapes in one launch
+                SeedShapeSet shs;
+                for (int y = 0; y < 4; ++y) shs.s[y] = make_shape(std::min(y, P.n_shapes - 1));
+                hipLaunchKernelGGL(self_candidates, dim3((unsigned)ceil_div(Q.n, 4)), dim3(256), 0, ctx->stream, shs, P.n_shapes, a, ctx->d_self_t.as<const uint32_t>(), Q.len.as<const uint32_t>());
+                PEP_HIP(ctx, hipGetLastError());
+            }
         }
         // field widths of the dense key form (see keys_pack)
         const uint32_t bin_min = (uint32_t)(((1 << 23) - (int)std::max<uint32_t>(Q.max_len, 1u) + 1) >> 6);

@@ -690,6 +690,57 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     return k1_ref_finish(ctx);
 }
 
+// ---- self-search (round 6): PEPPAN's hot call searches a gene set against itself (-r CL -q CL, PEPPAN.py:229-230).  Frame 1 of reference gene g then IS protein
+// query g - the same residues at the same offsets - and 57 % of the raw seed hits of the 10 000-gene search are a gene against itself on diagonal 0
+// (DESIGN.md section 4.11).  Nothing is assumed about the caller: the decision is taken on the device from the packed residues.  One wavefront per target:
+// a target that K1 made from frame 1, offset 0 of reference sequence g is compared with query g over the query's length.
+__global__ __launch_bounds__(256) void self_detect(uint32_t nt, uint32_t nq, const PackDesc *__restrict__ desc_t, const uint32_t *__restrict__ t_off,
+                                                   const uint32_t *__restrict__ t_len, const uint8_t *__restrict__ t_res, const uint32_t *__restrict__ q_off,
+                                                   const uint32_t *__restrict__ q_len, const uint8_t *__restrict__ q_res, uint32_t *__restrict__ self_t,
+                                                   int32_t *__restrict__ delta)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= nt) return;
+    const PackDesc d = desc_t[t];
+    if (d.frame != 1u || d.aa_off != 0u || d.seq >= nq) return;
+    const uint32_t g = d.seq, ql = q_len[g], tl = t_len[t];
+    if (ql == 0u || tl < ql) return;
+    const uint32_t qs = q_off[g], ts = t_off[t];                 // (16-aligned starts: the 8-byte reads below are aligned)
+    bool ok = true;
+    for (uint32_t x = (uint32_t)lane * 8u; x < ql && ok; x += 512u) {
+        if (x + 8u <= ql) {
+            const uint64_t u = *reinterpret_cast<const uint64_t *>(q_res + qs + x), v = *reinterpret_cast<const uint64_t *>(t_res + ts + x);
+            ok = u == v;
+        } else for (uint32_t y = x; y < ql; ++y) ok = ok && q_res[qs + y] == t_res[ts + y];
+    }
+    if (!__all(ok)) return;
+    if (lane == 0) self_t[g] = t;
+    // blocks that lie inside [ts, ts + ql): a hit at target position p of such a block whose query position is p - (ts - qs) is this gene against itself on
+    // diagonal 0 (the block that holds ts starts in the padding in front of the target; a block that reaches beyond ts + ql is left out - what lies behind
+    // the query's end in the query layout is another query's)
+    const uint32_t b0 = ts >> 5, b1 = (ts + ql) >> 5;            // b1: the first block that is not completely inside
+    for (uint32_t b = b0 + (uint32_t)lane; b < b1; b += 64u) delta[b] = (int32_t)(ts - qs);
+}
+
+int pep_self_map(pep_ctx *ctx, int *on)
+{
+    *on = 0;
+    const SeqSet &Q = ctx->q, &T = ctx->t;
+    if (!ctx->q_from_nt || !ctx->t_from_nt || ctx->resid_from_nucl || !ctx->d_k1_desc_t.p || Q.n == 0 || T.n == 0 || T.n > ctx->k1_desc_cap) return PEP_OK;
+    const size_t blocks = (size_t)(T.total / 32 + 16);                   // (the matcher reads the word of every position of its last 256-position tile)
+    PEP_TRY(dev_reserve(ctx, ctx->d_self_delta, blocks * 4));
+    PEP_TRY(dev_reserve(ctx, ctx->d_self_t, ((size_t)Q.n + 1) * 4));
+    PEP_HIP(ctx, hipMemsetAsync(ctx->d_self_delta.p, 0x80, blocks * 4, ctx->stream));            // PEP_SELF_NO_DELTA
+    PEP_HIP(ctx, hipMemsetAsync(ctx->d_self_t.p, 0xFF, ((size_t)Q.n + 1) * 4, ctx->stream));     // PEP_SELF_NONE
+    hipLaunchKernelGGL(self_detect, dim3((unsigned)ceil_div(T.n, 4)), dim3(256), 0, ctx->stream, T.n, Q.n, ctx->d_k1_desc_t.as<const PackDesc>(), T.off.as<const uint32_t>(),
+                       T.len.as<const uint32_t>(), T.res.as<const uint8_t>(), Q.off.as<const uint32_t>(), Q.len.as<const uint32_t>(), Q.res.as<const uint8_t>(),
+                       ctx->d_self_t.as<uint32_t>(), ctx->d_self_delta.as<int32_t>());
+    PEP_HIP(ctx, hipGetLastError());
+    *on = 1;
+    return PEP_OK;
+}
+
 // The packed residue set of one side from its nucleotide set: `order` lists (sequence, strand) per packed sequence.  Everything but the residues
 // themselves - offsets, lengths, descriptors, the host mirrors - depends on the uploaded nucleotide sets (and the target groups) only and is kept
 // (NuclSide) between calls: PEPPAN's hot call runs the nucleotide tool and the translated tool in turn on the same sets, and K1 overwrites the packed

@@ -100,7 +100,7 @@ def test_allgather_hits_two_ranks_gloo():
     assert len(exp_h) > 20
 
 
-def _map_worker(rank, world, port, tmp, out_q, workers=0):
+def _map_worker(rank, world, port, tmp, out_q, workers=0, cpus=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     import copy
@@ -108,6 +108,10 @@ def _map_worker(rank, world, port, tmp, out_q, workers=0):
     from conftest import load_golden
     from oracle_context import OracleContext
     from peppan_amd import mapbsn
+    if isinstance(workers, (tuple, list)):                # ranks whose containers were granted different CPUs size their pools differently
+        workers = workers[rank]
+    if cpus is not None:
+        mapbsn.effective_cpus = lambda: cpus[rank]
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
     g = load_golden('g14_mapbsn.json')
     want = load_golden('g15_getmapbsn.json')
@@ -166,6 +170,41 @@ def test_get_map_bsn_sharded_over_two_ranks(tmp_path, workers):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert workers or (got[0] == [0, 2] and got[1] == [1])
+    want = load_golden('g15_getmapbsn.json')['stores']['saveSeq_1']
+
+    def plain(x):
+        if isinstance(x, np.ndarray):
+            return [plain(v) for v in x.tolist()]
+        if isinstance(x, (list, tuple)):
+            return [plain(v) for v in x]
+        if isinstance(x, (np.integer,)):
+            return int(x)
+        if isinstance(x, (np.floating,)):
+            return float(x)
+        return x
+    for x in ('tab', 'seq', 'mat', 'conflicts'):
+        with mapbsn.MapBsn(str(tmp_path / ('mm.%s.npz' % x))) as c:
+            assert {k: plain(c.get(k)) for k in sorted(c.keys())} == want[x], x
+
+
+def test_get_map_bsn_ranks_with_different_cpu_grants(tmp_path):
+    """the dealing unit of the RANKS does not depend on what a rank's container was granted (round 4's advisor finding: a unit derived from
+    effective_cpus() or the pool size differed per rank and the gathers fell out of step).  Three gloo ranks - granted 2, 16 and 6 CPUs, pools
+    of 2, 3 and 0 worker processes - map golden G15's genomes in blocks of genomes_per_round: rank 0's stores are the single-process stores"""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from conftest import load_golden
+    from peppan_amd import mapbsn
+    world, port = 3, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_map_worker, args=(r, world, port, str(tmp_path), q, (2, 3, 0), (2, 16, 6))) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[2] == [2]                                   # (the rank without a pool searched its own block, genome 2, itself)
     want = load_golden('g15_getmapbsn.json')['stores']['saveSeq_1']
 
     def plain(x):

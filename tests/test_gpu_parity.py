@@ -436,6 +436,82 @@ def test_nucleotide_stride_lookup_equals_plain_matcher_and_oracle(ctx):
         assert out[0][4] == ost['candidates'] and out[0][3] > 20000
 
 
+def test_self_search_drops_diagonal_zero_self_hits_exactly(ctx):
+    """PEPPAN's hot call searches a gene set against itself (PEPPAN.py:229-230): frame 1 of reference gene g IS query g, and more than half of the raw seed
+    hits are a gene against itself on diagonal 0.  Round 6: the matcher counts and drops them (pep_self_map decides on the device which targets repeat a
+    query) and self_candidates settles their one candidate from the sequences.  The table, the CIGARs, the candidate count and every seed statistic equal
+    the plain stream's (params.reserved[0] = 10) and the oracle's.  The gene set holds what decides gene by gene: genes whose query frame is not 1 (stops in
+    frame 1), genes beyond 1 000 codons (several chunks per frame), an empty and a tiny gene, lower-case and ambiguous bases, duplicates, a gene of X runs
+    whose self hits do not all pass the pre-filter; then reference sets that differ from the queries in one gene, in one base, in their order and number."""
+    from peppan_amd import _native as N, synth
+    from oracle import oracle as O
+    rng = np.random.default_rng(77)
+    names, seqs = synth.make_genes(160, 0, seed=12)
+    seqs = [bytes(s) for s in seqs]
+    seqs[3] = b'ATGTAATAGTGA' + seqs[3][12:]                         # stops at the start of frame 1: another frame wins or ties
+    seqs[4] = seqs[4][:100] + b'TAA' + seqs[4][103:200] + b'TAG' + seqs[4][203:]
+    seqs[5] = b'C' + seqs[5]                                          # frame 2 is the reading frame
+    seqs[6] = b''
+    seqs[7] = b'ATGAAATAA'
+    seqs[8] = seqs[8].lower()
+    seqs[9] = seqs[9][:50] + b'NNNRY' + seqs[9][55:]
+    seqs[10] = seqs[11]                                               # duplicates
+    long_codons = rng.integers(0, 61, size=1400)
+    sense = [a + b + c for a in 'ACGT' for b in 'ACGT' for c in 'ACGT' if a + b + c not in ('TAA', 'TAG', 'TGA')]
+    seqs[12] = ('ATG' + ''.join(sense[i] for i in long_codons) + 'TAA').encode()      # 1 402 codons: frame 1 is cut into chunks
+    seqs[13] = seqs[12][:2000] + b'A' + seqs[12][2001:]
+    # short stretches of seeding residues between ambiguous codons: self hits whose extension is cut on both sides
+    seqs[14] = b'ATG' + b''.join((b'GGTGCTTCTGCAGGTTCAGCTGGT' + b'NNN' * 3) for _ in range(12)) + b'TAA'
+    seqs[15] = b'ATG' + b'GCTGGTTCTGCAGGTGCTTCAGGT' * 2 + b'NNN' * 40 + b'TAA'
+    p_on, p_off = N.default_params(45., 25., 10, 5), N.default_params(45., 25., 10, 5)
+    p_off.reserved[0] = 10
+
+    def oracle_table(q, r):
+        q_aa = [O.aa_codes(O.query_frame(s.decode(), 11)[1]) for s in q]
+        t_aa = []
+        for s in r:
+            for aa in O.translate_frames(s.decode(), range(1, 7), 11):
+                t_aa += [O.aa_codes(c) for o, c in O.ref_chunks(aa)]
+        return O.search(q_aa, t_aa, O.default_params(45., 25., 10, 5))
+
+    def both(q, r, inside=False):
+        out = []
+        for p in (p_on, p_off):
+            ctx.set_query_nt(q, 11)
+            ctx.set_ref_nt(r, 6, 11)
+            if inside:
+                ctx.invalidate_translation()                          # K1 inside the search: the map is made behind it on the stream
+            out.append(ctx.search(p))
+        (h1, c1, s1), (h0, c0, s0) = out
+        _cmp_hits(h1, c1, h0, c0)
+        for k in ('query_seeds', 'target_seeds', 'seed_hits', 'candidates', 'pairs', 'tracebacks', 'hits', 'cells'):
+            assert s1[k] == s0[k], k
+        return h1, c1, s1
+
+    h, c, st = both(seqs, seqs)
+    oh, oc, ost = oracle_table(seqs, seqs)
+    _cmp_hits(h, c, oh, oc)
+    assert st['candidates'] == ost['candidates'] and len(h) > 300
+    h2, c2, st2 = both(seqs, seqs, inside=True)
+    _cmp_hits(h2, c2, h, c)
+    # a second search on the same sets without a new translation
+    h3, c3, st3 = ctx.search(p_on)
+    _cmp_hits(h3, c3, h, c)
+    # reference sets that are not the query set: one gene replaced, one base changed, another order, one gene less, one more; queries that are a part
+    other = list(seqs); other[20] = seqs[21]
+    base = list(seqs); base[30] = seqs[30][:40] + (b'A' if seqs[30][40:41] != b'A' else b'C') + seqs[30][41:]
+    for q, r in ((seqs, other), (seqs, base), (seqs, seqs[::-1]), (seqs, seqs[:-1]), (seqs, seqs + [seqs[0]]), (seqs[:50], seqs), (seqs[40:90], seqs)):
+        both(q, r)
+    oh, oc, ost = oracle_table(seqs, base)
+    h, c, st = both(seqs, base)
+    _cmp_hits(h, c, oh, oc)
+    assert st['candidates'] == ost['candidates']
+    # bigger sets with families, log-normal lengths
+    names, big = synth.make_genes(1500, 0, seed=31)
+    h, c, st = both(big, big, inside=True)
+    assert len(h) > 3000
+
+
 def test_uberblast_dropin_blastn_and_diamond(tmp_path, monkeypatch):
     """the reference's actual exemplar call: --blastn --diamond -s 1 (PEPPAN.py:229-230), both tools on the GPU"""
     import io, contextlib
