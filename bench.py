@@ -20,11 +20,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
-PROFILE_COUNTERS = os.path.join(ROOT, 'profiles', 'r05_counters.json')          # rocprofv3 PMC passes of the headline workload (tools/profile_round.sh)
-PROFILE_COUNTERS_50K = os.path.join(ROOT, 'profiles', 'r05_counters_50k.json')  # the same passes over the 50 000-gene all-vs-all (the `workloads` block)
-PROFILE_COUNTERS_BLASTN = os.path.join(ROOT, 'profiles', 'r05_counters_blastn.json')   # ... over the nucleotide tool on the headline's genes (tools/one_search.py 10000 blastn)
-PROFILE_COUNTERS_MAP50K = os.path.join(ROOT, 'profiles', 'r05_counters_map50k.json')   # ... over one mapping step of the map_50k leg (tools/one_map_step.py)
-PROFILE_VALU = os.path.join(ROOT, 'profiles', 'r05_valu_rate.txt')              # tools/micro/valu_rate on the same GPU
+def _profile(name):
+    """the newest tracked copy of a profile file: this round's (r06) when tools/profile_round.sh has been run on the final code, else round 5's"""
+    for rnd in ('r06', 'r05'):
+        path = os.path.join(ROOT, 'profiles', '%s_%s' % (rnd, name))
+        if os.path.exists(path):
+            return path
+    return os.path.join(ROOT, 'profiles', 'r06_' + name)
+
+
+PROFILE_COUNTERS = _profile('counters.json')                 # rocprofv3 PMC passes of the headline workload (tools/profile_round.sh)
+PROFILE_COUNTERS_50K = _profile('counters_50k.json')         # the same passes over the 50 000-gene all-vs-all (the `workloads` block)
+PROFILE_COUNTERS_BLASTN = _profile('counters_blastn.json')   # ... over the nucleotide tool on the headline's genes (tools/one_search.py 10000 blastn)
+PROFILE_COUNTERS_MAP50K = _profile('counters_map50k.json')   # ... over one mapping step of the map_50k leg (tools/one_map_step.py)
+PROFILE_VALU = _profile('valu_rate.txt')                     # tools/micro/valu_rate on the same GPU
+PROFILE_VALU_MIX = _profile('valu_mix.json')                 # tools/valu_mix.py: the sweep loops' instruction mix from the compiler's assembly
 
 
 REFERENCE_TOOLS = ('diamond', 'blastn', 'makeblastdb', 'mmseqs')
@@ -621,6 +631,21 @@ def _ranks_seen(dist, torch, world, share, local_rank):
 VALU_PEAK_CLOCK = 2.4e9          # MI355X peak engine clock; 1024 SIMDs (256 CUs x 4)
 
 
+class ValuCycles(float):
+    """cycles per wave64 VALU instruction and SIMD.  As a number: the packed-16 / DPP / three-operand class (4.16, tools/micro/valu_rate).  of(kernel): weighted by
+    the kernel's sweep-loop mix (tools/valu_mix.py) - plain 32-bit VOP1 / VOP2 instructions issue at 2.27, and pricing them at 4.16 put round 5's score pass at
+    1.0026 of a 'ceiling'"""
+    two = None
+    mix = {}
+
+    def of(self, kernel):
+        k = self.mix.get(kernel.split('<')[0])
+        if not k or not self.two:
+            return float(self)
+        f2 = float(k.get('two_cycle_frac') or 0.)
+        return float(self) * (1. - f2) + float(self.two) * f2
+
+
 def _kernel_counters(counters, kernel):
     """the tracked PMC record of a kernel; the Smith-Waterman kernels are templates (<false> = the launch of the pairs that fit the LDS staging area,
     <true> = the long pairs): a name without its argument takes whichever instance the profile holds"""
@@ -664,13 +689,15 @@ def roofline_entry(counters, cyc4, source, kernel, what, ms, alg_bytes, valu=Fal
     if valu:
         e['bound'] = 'valu'
         e['hbm'] = hbm
-        peak = 1024 * VALU_PEAK_CLOCK / cyc4 / 1e9 if cyc4 else None          # G wave64-instructions / s the chip issues of this class
+        cyc = cyc4.of(kernel) if isinstance(cyc4, ValuCycles) else cyc4       # (cycles per instruction of THIS kernel's sweep-loop mix)
+        peak = 1024 * VALU_PEAK_CLOCK / cyc / 1e9 if cyc else None           # G wave64-instructions / s the chip issues of this mix
         if cyc4 and 'SQ_INSTS_VALU' in prof and ms > 0:
             # wave-instructions per launch (PMC) x measured cycles per instruction of the packed-16 / DPP / add3 class (tools/micro/valu_rate.hip)
             # against 1024 SIMDs at the 2.4 GHz peak clock for the launch's live duration
             rate = prof['SQ_INSTS_VALU'] / (ms * 1e-3) / 1e9
             e.update(achieved=rate, peak=peak, unit='G wave64 VALU instructions/s', frac=rate / peak, valu_issue_frac=rate / peak,
-                     valu_issue_source='SQ_INSTS_VALU from profiles/%s x %.3f cycles/instruction from profiles/%s' % (source, cyc4, os.path.basename(PROFILE_VALU)))
+                     valu_issue_source='SQ_INSTS_VALU from profiles/%s x %.3f cycles/instruction (profiles/%s weighted by the sweep loop\'s mix, profiles/%s)' % (
+                         source, cyc, os.path.basename(PROFILE_VALU), os.path.basename(PROFILE_VALU_MIX)))
         else:
             e.update(achieved=None, peak=peak, unit='G wave64 VALU instructions/s', frac=None, valu_issue_frac=None,
                      valu_issue_source='no tracked SQ_INSTS_VALU for this kernel on this workload (or stale): the issue fraction is not stated; hbm holds the HBM side')
@@ -728,7 +755,8 @@ def family_rooflines(path, per, Lq, cyc4, note, seed_what):
         if traffic and alg:
             e['traffic_over_algorithmic'] = traffic / alg
         if valu:
-            peak = 1024 * VALU_PEAK_CLOCK / cyc4 / 1e9 if cyc4 else None
+            cyc = cyc4.of(prefix) if isinstance(cyc4, ValuCycles) else cyc4
+            peak = 1024 * VALU_PEAK_CLOCK / cyc / 1e9 if cyc else None
             rate = insts / (ms_step * 1e-3) / 1e9 if insts and ms_step > 0 else None
             e.update(bound='valu', hbm=hbm, achieved=rate, peak=peak, unit='G wave64 VALU instructions/s', frac=(rate / peak) if rate and peak else None,
                      valu_issue_frac=(rate / peak) if rate and peak else None)
@@ -755,11 +783,19 @@ def _profile_tables(path=None):
     path = path or PROFILE_COUNTERS
     if os.path.exists(path):
         counters = json.load(open(path)).get('kernels', {})
+    cyc2 = None
     if os.path.exists(PROFILE_VALU):
         for line in open(PROFILE_VALU):
             f = line.split()
             if len(f) >= 5 and f[0] == 'v_pk_max_i16' and f[1] == '8':
                 cyc4 = float(f[2])                     # cycles per wave64 instruction per SIMD at 8 waves/SIMD (packed-16 / DPP / add3 class)
+            if len(f) >= 5 and f[0] == 'v_mov_b32' and f[1] == '8':
+                cyc2 = float(f[2])                     # ... of plain 32-bit VOP1 / VOP2 instructions
+    if cyc4:
+        cyc4 = ValuCycles(cyc4)
+        cyc4.two = cyc2
+        if os.path.exists(PROFILE_VALU_MIX):
+            cyc4.mix = json.load(open(PROFILE_VALU_MIX)).get('kernels', {})
     return counters, cyc4
 
 

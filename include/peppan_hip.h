@@ -86,7 +86,7 @@ typedef struct {
                                      of the packed 16-bit ones, [2] != 0 forces the count -> scan -> fill build of the query seed index */
     double ka_lambda, ka_k;       /* Karlin-Altschul parameters of the scoring system (protein default 0.267 / 0.041) */
     int32_t hsp_mode;             /* 0: one alignment per (q, t), its best band (diamond --max-hsps 1); 1: every band reaching the
-                                     score threshold, duplicates (same end cell) removed - several copies on one subject; 2: BLAST's way with the
+                                     score threshold, duplicates (same end cell) removed - several copies on one subject; 2 (UNPINNED: restated from NCBI's published rules, no blastn binary to hold it to): BLAST's way with the
                                      HSPs of a subject (blastn behind uberBlast.py:294): the bands of (q, t) in the order score descending, band ascending,
                                      one dropped when an ACCEPTED one in front shares its start or its end cell or holds its query and subject ranges
                                      inside its own; top_k counts subjects (the reference sequence a target is a strand / frame of), every alignment of

@@ -81,7 +81,9 @@ struct pep_ctx {
     int n_pending = 0;
     PinBuf pin_k1, pin_k1q;                 // grow-only: what K1's kernels write for the host - the set's summary (reference), summary + lengths (queries)
     DevBuf d_k1_desc_q, d_k1_desc_t;        // K1's descriptors (+ the summary's accumulators behind them): fetched only when the host tables are asked for
-    DevBuf d_self_delta, d_self_t;          // seed stage, self-search (pep_self_map): per 32-byte block of the target layout the distance to the query that IS that target, per query that target
+    DevBuf d_self_delta, d_self_t;          // seed stage, self-search: per 32-byte block of the target layout the distance to the query that IS that target (pep_self_map, self_prepare);
+                                            // per reference sequence the packed sequence its frame 1 starts with (K1: k1_ref_desc)
+    uint32_t self_first_n = 0;              // entries of d_self_t (reference sequences of the last K1 of the reference side)
     hipEvent_t k1_event = nullptr;          // the point of the stream where the reference side's downloads have arrived
     hipEvent_t k1q_event = nullptr;         // ... and the query side's
     bool k1q_event_set = false;
@@ -326,10 +328,9 @@ int pep_k9_linclust(pep_ctx *ctx, const uint8_t *h_res, const uint64_t *h_off, u
 
 static inline uint64_t ceil_div(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 int pep_upload_blk2seq(pep_ctx *ctx, SeqSet &s);
-// translate.hip, for the seed stage of a self-search (seeds.hip): which targets ARE a query (same residues from the target's first position on: frame 1, first
-// chunk of the reference gene with the query's index) -> ctx->d_self_t[q] = that target or PEP_SELF_NONE, ctx->d_self_delta[b] = (target start - query start) for
-// every 32-byte block b of the target layout that lies inside the stretch the query covers, PEP_SELF_NO_DELTA elsewhere.  *on = 0: not applicable to the current sets
-// (no K1 descriptors on the device), nothing queued.
+// translate.hip, for the seed stage of a self-search (seeds.hip: self_prepare): K1 leaves ctx->d_self_t[g] = the packed sequence that frame 1 of reference sequence g
+// starts with (PEP_SELF_NONE: none); pep_self_map clears ctx->d_self_delta - one word per 32-byte block of the target layout, PEP_SELF_NO_DELTA - and says whether
+// the current sets came out of K1 at all (*on = 0: not applicable, nothing queued).
 #define PEP_SELF_NONE 0xFFFFFFFFu
 #define PEP_SELF_NO_DELTA ((int32_t)0x80808080)
 int pep_self_map(pep_ctx *ctx, int *on);

@@ -410,7 +410,7 @@ struct JoinArgs {
     uint64_t hit_cap;
     int debug;               // profiling aid (params.reserved[0]): 1 = keys only, 2 = keys + bucket lookup, 3 = + entry compare (no extension), 9 = no wave-level de-duplication
     const int32_t *self_delta;   // self-search (pep_self_map): per 32-byte block of the targets, target position - query position of the hits that are a gene against itself on
-                                 // diagonal 0 (PEP_SELF_NO_DELTA: none); nullptr = off.  Such hits are counted and dropped: self_candidates settles their candidate.
+                                 // diagonal 0 (PEP_SELF_NO_DELTA: none); nullptr = off.  Such hits are counted and dropped: self_prepare has settled their candidate.
 };
 
 __device__ __forceinline__ void set_insert(const JoinArgs &a, uint64_t k)
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
                 if (e + k >= e1 || (ent >> POS_BITS) != key) continue;
                 ++n_hit;
                 if (a.debug == 3) continue;
-                if ((int32_t)((uint32_t)p - (uint32_t)(ent & POS_MASK)) == sd) continue;      // a gene against itself on diagonal 0: settled by self_candidates
+                if ((int32_t)((uint32_t)p - (uint32_t)(ent & POS_MASK)) == sd) continue;      // a gene against itself on diagonal 0: settled by self_prepare
                 const uint64_t hit = ((ent & POS_MASK) << 32) | p;
                 const uint32_t idx = atomicAdd(&nbuf, 1u);
                 if (idx < HIT_BUF) buf[idx] = hit;
@@ -862,58 +862,91 @@ __global__ __launch_bounds__(256) void seed_runs_extend(JoinArgs a)
     if (threadIdx.x == 0 && blk_pass) atomicAdd(&a.stats[2], (unsigned long long)blk_pass);
 }
 
-// Self-search: the candidate of a gene against itself on diagonal 0, whose seed hits seed_match counts and drops (JoinArgs::self_delta).  The candidate set is
-// a SET, and a candidate is in it iff ONE seed hit of its (q, t, diagonal bin) passes the ungapped pre-filter (oracle: find_candidates / ungapped_score) - so the
-// hits on diagonal 0 are judged here, from the sequences alone: every position of query g that starts a seed of one of the shapes IS a hit of g against the target
-// that repeats it (same residues, same key, in the index by construction), and its extension is the oracle's loop over the packed residues (padding scores -64
-// and ends an extension where the sequence ends: x-drop < 64).  One wavefront per query, 64 positions per round, until one passes (the first round, as a rule).
-// Hits of the same pair that seed_match did not drop (the last, partial block; other diagonals of the bin) take the usual way; inserting twice is harmless.
-__global__ __launch_bounds__(256) void self_candidates(SeedShapeSet shs, int n_shapes, JoinArgs a, const uint32_t *__restrict__ self_t, const uint32_t *__restrict__ q_len)
+// Self-search (PEPPAN's hot call is one: -r CL -q CL): one wavefront per query g, in front of the matchers.
+//  1. Is the packed sequence that frame 1 of reference sequence g starts with (first_t[g], left by K1) query g over again - the same residues from its first
+//     position on, at least the query's length?  Decided from the data; a target that is not is left to the stream as it is.
+//  2. If so, the 32-byte blocks of the target layout inside [ts, ts + ql) get delta = ts - qs: seed_match counts and DROPS the hits of those blocks whose query
+//     position is the target position - delta - the gene against itself on diagonal 0, 57 % of the raw hits of the 10 000-gene search.  (The block that holds
+//     ts begins in the padding in front of the target; a block that reaches beyond ts + ql is left out: behind the query's end lies another query.)
+//  3. Their candidate is settled here.  The candidate set is a SET, and (q, t, bin of diagonal 0) is in it iff ONE seed hit of that bin passes the ungapped
+//     pre-filter (oracle: find_candidates / ungapped_score).  The hits on diagonal 0 follow from the sequence alone: every position of the query that starts a
+//     seed of one of the shapes is a hit against the target that repeats it (same residues, same key, in the index by construction), and its extension is the
+//     oracle's loop over the packed residues (padding scores -64 and ends an extension where a sequence ends: x-drop < 64).  64 positions per round until one
+//     passes - the first round, as a rule; an extension stops as soon as its right side alone has reached the threshold (it can only grow).  Hits of the same
+//     pair that the matcher does not drop (the last, partial block; other diagonals of the bin) take the usual way; inserting a key twice is harmless.
+__global__ __launch_bounds__(256) void self_prepare(SeedShapeSet shs, int n_shapes, JoinArgs a, const uint32_t *__restrict__ first_t, uint32_t n_first,
+                                                    const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len, int32_t *__restrict__ delta)
 {
     __shared__ int8_t sub[1024];
     reinterpret_cast<uint32_t *>(sub)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.sub)[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (g >= a.nq) return;
-    const uint32_t t = self_t[g];
-    if (t == PEP_SELF_NONE) return;
-    const uint32_t qs = a.q_off[g], ts = a.t_off[t], ql = q_len[g];
+    if (g >= a.nq || g >= n_first) return;
+    const uint32_t t = first_t[g];
+    if (t >= a.nt) return;                                      // (PEP_SELF_NONE included)
+    const uint32_t ql = q_len[g], tl = t_len[t];
+    if (ql == 0u || tl < ql) return;
+    const uint32_t qs = a.q_off[g], ts = a.t_off[t];             // (16-aligned starts: the 8-byte reads below are aligned)
+    bool same = true;
+    for (uint32_t x = (uint32_t)lane * 8u; x < ql && same; x += 512u) {
+        if (x + 8u <= ql) same = *reinterpret_cast<const uint64_t *>(a.q_res + qs + x) == *reinterpret_cast<const uint64_t *>(a.t_res + ts + x);
+        else for (uint32_t y = x; y < ql; ++y) same = same && a.q_res[qs + y] == a.t_res[ts + y];
+    }
+    if (!__all(same)) return;
+    for (uint32_t b = (ts >> 5) + (uint32_t)lane, b1 = (ts + ql) >> 5; b < b1; b += 64u) delta[b] = (int32_t)(ts - qs);
+    if (a.ungapped_min <= 0) return;                            // (no pre-filter: every hit nominates; the caller does not drop hits then)
     constexpr int STAGE1_LEN = 16;
+    const int thr = a.ungapped_min, early = max(a.ungapped_min, a.stage1_min);
     for (int s = 0; s < n_shapes; ++s) {
         const SeedShape &sh = shs.s[s];
         for (uint32_t x0 = 0; x0 < ql; x0 += 64) {
             const uint32_t x = x0 + (uint32_t)lane;
             bool pass = false;
             if (x < ql) {
+                const uint8_t *q = a.q_res + qs + x, *tt = a.t_res + ts + x;
                 bool seeds = true;
-                for (int i = 0; i < sh.weight; ++i) seeds = seeds && reduce_letter(sh, a.q_res[qs + x + sh.offs[i]]) != 15u;
+                for (int i = 0; i < sh.weight; ++i) seeds = seeds && reduce_letter(sh, q[sh.offs[i]]) != 15u;
                 if (seeds) {
-                    const uint8_t *q = a.q_res + qs + x, *tt = a.t_res + ts + x;
                     int sc = 0, br = 0, bl = 0, k = 0;
-                    bool dead = false;
-                    for (; k < a.ext_right; ++k) {
+                    bool dead = false, over = false;
+                    // the first sixteen residues of the right side from four 8-byte reads issued together (a loop of byte reads that may end at every step is a chain
+                    // of dependent round trips: 30 us for the 10 000 genes); the rest - rarely needed - byte by byte
+                    uint64_t qw[2], tw[2];
+                    __builtin_memcpy(qw, q, 16);
+                    __builtin_memcpy(tw, tt, 16);
+#pragma unroll
+                    for (int j = 0; j < STAGE1_LEN; ++j) {
+                        const int qc = (int)((qw[j >> 3] >> ((j & 7) * 8)) & 31u), tc = (int)((tw[j >> 3] >> ((j & 7) * 8)) & 31u);
+                        if (!over && j < a.ext_right) {
+                            sc += sub[qc * 32 + tc];
+                            if (sc > br) { br = sc; over = br >= early; }                // passed whatever follows: br never falls, stage 1 is met
+                            else over = br - sc > a.xdrop;
+                            k = j + 1;
+                        }
+                    }
+                    if (!over) for (k = STAGE1_LEN; k < a.ext_right; ++k) {
                         if (k == STAGE1_LEN && br < a.stage1_min) { dead = true; break; }
                         sc += sub[(q[k] & 31) * 32 + (tt[k] & 31)];
-                        if (sc > br) br = sc;
+                        if (sc > br) { br = sc; if (br >= early) break; }
                         else if (br - sc > a.xdrop) break;
                     }
                     if (!dead && br >= a.stage1_min) {
-                        sc = 0;
-                        for (k = 1; k <= a.ext_left; ++k) {
-                            sc += sub[(q[-k] & 31) * 32 + (tt[-k] & 31)];
-                            if (sc > bl) bl = sc;
-                            else if (bl - sc > a.xdrop) break;
+                        if (br < thr) {
+                            sc = 0;
+                            for (k = 1; k <= a.ext_left; ++k) {
+                                sc += sub[(q[-k] & 31) * 32 + (tt[-k] & 31)];
+                                if (sc > bl) { bl = sc; if (br + bl >= thr) break; }
+                                else if (bl - sc > a.xdrop) break;
+                            }
                         }
-                        pass = br + bl >= a.ungapped_min;
+                        pass = br + bl >= thr;
                     }
                 }
             }
             if (__ballot(pass)) {
-                if (lane == 0) {
-                    set_insert(a, ((uint64_t)g << 43) | ((uint64_t)t << 18) | (uint64_t)((1u << 23) >> 6));      // diagonal 0: bin (0 + 2^23) >> 6
-                    atomicAdd(&a.stats[2], 1ull);
-                }
+                // (not counted in stats[2], the passed-hits statistic: ten thousand wavefronts adding to one word take 110 us - the word sustains ~90 atomics/us)
+                if (lane == 0) set_insert(a, ((uint64_t)g << 43) | ((uint64_t)t << 18) | (uint64_t)((1u << 23) >> 6));      // diagonal 0: bin (0 + 2^23) >> 6
                 return;
             }
         }
@@ -1158,10 +1191,19 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             a.counters = counters; a.stats = stats;
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
             a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.stage1_min = P.stage1_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
+            a.self_delta = nullptr;
             if (s == 0 && !stride_lookup && P.ungapped_min > 0 && P.reserved[0] == 0) PEP_TRY(pep_self_map(ctx, &self_on));     // (reserved[0] = 10: the plain stream, for comparison)
-            a.self_delta = self_on ? ctx->d_self_delta.as<const int32_t>() : nullptr;
+            if (self_on) a.self_delta = ctx->d_self_delta.as<const int32_t>();
             unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(zero + PEP_ZERO_SHAPE) + 2 * s;      // per shape, cleared by the one fill
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
+            if (self_on && s == 0) {
+                // which targets repeat a query, the blocks whose diagonal-0 self hits the matchers drop, and those genes' own candidates: one launch, all shapes
+                SeedShapeSet shs;
+                for (int y = 0; y < 4; ++y) shs.s[y] = make_shape(std::min(y, P.n_shapes - 1));
+                hipLaunchKernelGGL(self_prepare, dim3((unsigned)ceil_div(Q.n, 4)), dim3(256), 0, ctx->stream, shs, P.n_shapes, a, ctx->d_self_t.as<const uint32_t>(), ctx->self_first_n,
+                                   Q.len.as<const uint32_t>(), T.len.as<const uint32_t>(), ctx->d_self_delta.as<int32_t>());
+                PEP_HIP(ctx, hipGetLastError());
+            }
             pep_timer_begin(ctx, TM_MATCH0 + s);
             if (stride_lookup) hipLaunchKernelGGL(seed_match_stride, dim3((unsigned)std::min<uint64_t>(ceil_div(T.total, NTILE), 256u * 8u)), dim3(256), 0, ctx->stream, a);
             else PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 8u)), sh, a);
@@ -1184,13 +1226,6 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             // (same-box A/B, tools/ab/phase2_ab.sh: four trips of 64 hits per strip; 8 blocks per CU at 10 k genes - 122 us against 126 with 16 -, 16 at 50 k - 1.71 ms against 1.86)
             hipLaunchKernelGGL(seed_runs_extend, dim3(256u * (T.total > (48ull << 20) ? 16u : 8u)), dim3(256), 0, ctx->stream, a);
             PEP_HIP(ctx, hipGetLastError());
-            if (self_on && s == P.n_shapes - 1) {
-                // the candidates of the genes against themselves, whose diagonal-0 hits the matchers dropped: all shapes in one launch
-                SeedShapeSet shs;
-                for (int y = 0; y < 4; ++y) shs.s[y] = make_shape(std::min(y, P.n_shapes - 1));
-                hipLaunchKernelGGL(self_candidates, dim3((unsigned)ceil_div(Q.n, 4)), dim3(256), 0, ctx->stream, shs, P.n_shapes, a, ctx->d_self_t.as<const uint32_t>(), Q.len.as<const uint32_t>());
-                PEP_HIP(ctx, hipGetLastError());
-            }
         }
         // field widths of the dense key form (see keys_pack)
         const uint32_t bin_min = (uint32_t)(((1 << 23) - (int)std::max<uint32_t>(Q.max_len, 1u) + 1) >> 6);

@@ -414,7 +414,8 @@ struct K1Scan { uint64_t *state; uint32_t ticket_base; uint64_t epoch; };
 __global__ __launch_bounds__(256) void k1_ref_desc(uint64_t nw, int n_frames, const uint64_t *__restrict__ chunk_base, const uint32_t *__restrict__ chunk_cnt,
                                                    const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_len,
                                                    PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, K1Summary *__restrict__ sum,
-                                                   uint32_t *__restrict__ n_targets, K1Scan sc, const uint64_t *__restrict__ nt_off, K1Src *__restrict__ src_of)
+                                                   uint32_t *__restrict__ n_targets, K1Scan sc, const uint64_t *__restrict__ nt_off, K1Src *__restrict__ src_of,
+                                                   uint32_t *__restrict__ first_t)
 {
     __shared__ uint32_t s_tile, lds[4];
     __shared__ uint64_t s_pre;
@@ -434,6 +435,7 @@ __global__ __launch_bounds__(256) void k1_ref_desc(uint64_t nw, int n_frames, co
     const uint32_t g = (uint32_t)(w / n_frames), f = (uint32_t)(w % n_frames) + 1;
     const uint64_t base = chunk_base[w];
     const uint32_t at = (uint32_t)s_pre + ex;
+    if (f == 1u) first_t[g] = cnt ? at : PEP_SELF_NONE;          // the packed sequence frame 1 of reference sequence g starts with (seeds.hip: self_prepare)
     const uint64_t o = nt_off[g];
     const K1Src so{o, (uint32_t)(nt_off[g + 1] - o), 0u};
     for (uint32_t c = 0; c < cnt; ++c) {
@@ -661,6 +663,8 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     PEP_TRY(dev_reserve(ctx, W[5], (nw + 2) * 4));
     PEP_TRY(dev_reserve(ctx, W[6], (slots + 1) * 4));
     PEP_TRY(reserve_packed(ctx, ctx->t, (uint32_t)slots, upper));
+    PEP_TRY(dev_reserve(ctx, ctx->d_self_t, ((size_t)n + 1) * 4));
+    ctx->self_first_n = n;
     const uint64_t *d_base = ctx->d_k1_base.as<const uint64_t>();
     if (nw) {
         hipLaunchKernelGGL(k1_ref_chunks, dim3((unsigned)ceil_div(nw, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, nf, tab,
@@ -672,7 +676,7 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
             hipLaunchKernelGGL(k1_ref_desc, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, nw, nf, d_base, W[1].as<const uint32_t>(),
                                W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), D.as<PackDesc>(), W[6].as<uint32_t>(),
                                ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + slots), W[5].as<uint32_t>() + nw, sc,
-                               nt.off.as<const uint64_t>(), k1_src_of(D.as<const PackDesc>(), (uint32_t)slots));         // W[5][nw] = number of targets
+                               nt.off.as<const uint64_t>(), k1_src_of(D.as<const PackDesc>(), (uint32_t)slots), ctx->d_self_t.as<uint32_t>());         // W[5][nw] = number of targets
         }
         PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
                                 W[7], W[8], pin_sum));
@@ -692,51 +696,17 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
 
 // ---- self-search (round 6): PEPPAN's hot call searches a gene set against itself (-r CL -q CL, PEPPAN.py:229-230).  Frame 1 of reference gene g then IS protein
 // query g - the same residues at the same offsets - and 57 % of the raw seed hits of the 10 000-gene search are a gene against itself on diagonal 0
-// (DESIGN.md section 4.11).  Nothing is assumed about the caller: the decision is taken on the device from the packed residues.  One wavefront per target:
-// a target that K1 made from frame 1, offset 0 of reference sequence g is compared with query g over the query's length.
-__global__ __launch_bounds__(256) void self_detect(uint32_t nt, uint32_t nq, const PackDesc *__restrict__ desc_t, const uint32_t *__restrict__ t_off,
-                                                   const uint32_t *__restrict__ t_len, const uint8_t *__restrict__ t_res, const uint32_t *__restrict__ q_off,
-                                                   const uint32_t *__restrict__ q_len, const uint8_t *__restrict__ q_res, uint32_t *__restrict__ self_t,
-                                                   int32_t *__restrict__ delta)
-{
-    const int lane = threadIdx.x & 63;
-    const uint32_t t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (t >= nt) return;
-    const PackDesc d = desc_t[t];
-    if (d.frame != 1u || d.aa_off != 0u || d.seq >= nq) return;
-    const uint32_t g = d.seq, ql = q_len[g], tl = t_len[t];
-    if (ql == 0u || tl < ql) return;
-    const uint32_t qs = q_off[g], ts = t_off[t];                 // (16-aligned starts: the 8-byte reads below are aligned)
-    bool ok = true;
-    for (uint32_t x = (uint32_t)lane * 8u; x < ql && ok; x += 512u) {
-        if (x + 8u <= ql) {
-            const uint64_t u = *reinterpret_cast<const uint64_t *>(q_res + qs + x), v = *reinterpret_cast<const uint64_t *>(t_res + ts + x);
-            ok = u == v;
-        } else for (uint32_t y = x; y < ql; ++y) ok = ok && q_res[qs + y] == t_res[ts + y];
-    }
-    if (!__all(ok)) return;
-    if (lane == 0) self_t[g] = t;
-    // blocks that lie inside [ts, ts + ql): a hit at target position p of such a block whose query position is p - (ts - qs) is this gene against itself on
-    // diagonal 0 (the block that holds ts starts in the padding in front of the target; a block that reaches beyond ts + ql is left out - what lies behind
-    // the query's end in the query layout is another query's)
-    const uint32_t b0 = ts >> 5, b1 = (ts + ql) >> 5;            // b1: the first block that is not completely inside
-    for (uint32_t b = b0 + (uint32_t)lane; b < b1; b += 64u) delta[b] = (int32_t)(ts - qs);
-}
-
+// (DESIGN.md section 4.11).  K1 leaves d_self_t[g] = the packed sequence that frame 1 of reference sequence g starts with (k1_ref_desc); whether that target
+// really repeats query g is decided on the device from the packed residues (seeds.hip: self_prepare), nothing is assumed about the caller.  Here: is the map
+// applicable to the current sets at all, and the distance table cleared.
 int pep_self_map(pep_ctx *ctx, int *on)
 {
     *on = 0;
     const SeqSet &Q = ctx->q, &T = ctx->t;
-    if (!ctx->q_from_nt || !ctx->t_from_nt || ctx->resid_from_nucl || !ctx->d_k1_desc_t.p || Q.n == 0 || T.n == 0 || T.n > ctx->k1_desc_cap) return PEP_OK;
+    if (!ctx->q_from_nt || !ctx->t_from_nt || ctx->resid_from_nucl || !ctx->d_self_t.p || Q.n == 0 || T.n == 0 || ctx->self_first_n == 0) return PEP_OK;
     const size_t blocks = (size_t)(T.total / 32 + 16);                   // (the matcher reads the word of every position of its last 256-position tile)
     PEP_TRY(dev_reserve(ctx, ctx->d_self_delta, blocks * 4));
-    PEP_TRY(dev_reserve(ctx, ctx->d_self_t, ((size_t)Q.n + 1) * 4));
     PEP_HIP(ctx, hipMemsetAsync(ctx->d_self_delta.p, 0x80, blocks * 4, ctx->stream));            // PEP_SELF_NO_DELTA
-    PEP_HIP(ctx, hipMemsetAsync(ctx->d_self_t.p, 0xFF, ((size_t)Q.n + 1) * 4, ctx->stream));     // PEP_SELF_NONE
-    hipLaunchKernelGGL(self_detect, dim3((unsigned)ceil_div(T.n, 4)), dim3(256), 0, ctx->stream, T.n, Q.n, ctx->d_k1_desc_t.as<const PackDesc>(), T.off.as<const uint32_t>(),
-                       T.len.as<const uint32_t>(), T.res.as<const uint8_t>(), Q.off.as<const uint32_t>(), Q.len.as<const uint32_t>(), Q.res.as<const uint8_t>(),
-                       ctx->d_self_t.as<uint32_t>(), ctx->d_self_delta.as<int32_t>());
-    PEP_HIP(ctx, hipGetLastError());
     *on = 1;
     return PEP_OK;
 }

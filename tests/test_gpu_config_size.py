@@ -171,7 +171,9 @@ def test_front_end_gene_instances_at_size(ctx, tmp_path, monkeypatch, n_base, co
 
 def test_all_vs_all_50k_bit_exact_vs_oracle(ctx):
     """BASELINE configs[4] search stage: 50 000 genes x 1 002 nt all-vs-all on one GPU; every field of every hit and the CIGAR arena equal the
-    CPU oracle's (OpenMP, all host cores: about a minute and a half)"""
+    CPU oracle's (OpenMP, all host cores: about a minute and a half).  Division of labour: the oracle is fed the proteins K1 made on the GPU
+    (ctx.query_aa() / ctx.target_aa()), so at this size K1 - translation, frame choice, chunking - is held to itself; K1 against the oracle and the
+    reference's golden vectors is test_gpu_parity.py's business (test_k1_*, G1 / G2 on the GPU) at sizes the numpy translation finishes in seconds."""
     from peppan_amd import _native as N, synth
     from oracle import oracle as O
     names, seqs = synth.make_genes(50000, 1002, seed=355)

@@ -3,8 +3,8 @@
 #   kernel trace + stats of the default bench, the step timeline, FETCH_SIZE / WRITE_SIZE / SQ / GRBM / TCC counters in separate PMC passes - over the
 #   headline workload (10 000 genes), over the 50 000-gene all-vs-all of the `workloads` block, over the nucleotide tool on the headline's genes and
 #   over a mapping step of the map_50k leg -, the kernel table of a mapping step, the VALU issue-rate probe, the gather-rate probe, the bench line
-#   (which reads profiles/r05_counters*.json written here).
-R=r05
+#   (which reads profiles/r06_counters*.json written here).
+R=r06
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 timeout 300 tools/micro/valu_rate > gpurun_out/valu_rate.txt 2>&1

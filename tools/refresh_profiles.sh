@@ -2,11 +2,12 @@
 # after `gpurun -- 'bash tools/profile_round.sh'`: copy the summaries from gpurun_out/ into profiles/ with their header lines
 set -e
 cd "$(dirname "$0")/.."
-R=${1:-r05}
+R=${1:-r06}
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-e2e   (MI355X; tools/rocpd_summary.py over the rocpd database)"; cat gpurun_out/final_stats.txt; } > profiles/${R}_final_kernel_stats.txt
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --genes 50000 --steps 5 --warmup 2 --no-cpu-baseline --no-e2e   (the 50 000 x 50 000 gene all-vs-all of BASELINE configs[4]; MI355X)"; cat gpurun_out/final50_stats.txt; } > profiles/${R}_kernel_stats_50k.txt
 { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --workload map --map-genomes 16 --steps 2 --warmup 1   (10 000 exemplars x 16 genomes per step, 3 steps: the kernels of the mapping path;"; echo "# GPU-busy fraction of a step = total_us of all kernels / 3 steps / the step's wall time in the line below)"; tail -1 gpurun_out/mapk.log | cut -c1-600; cat gpurun_out/mapk_stats.txt; } > profiles/${R}_map_kernel_stats.txt
 { echo "# python bench.py  (MI355X; default flags: 1 GPU, 250 steps, 5 warmup; cpu baseline = probe for the reference's binaries, then the oracle C port with OpenMP on every host thread)"; cat gpurun_out/bench_line.txt; } > profiles/${R}_bench_line.txt
+cp gpurun_out/bench_detail.json profiles/${R}_bench_detail.json      # the full record behind the compact line (bench.py emit)
 cp gpurun_out/counters.json profiles/${R}_counters.json
 cp gpurun_out/counters_50k.json profiles/${R}_counters_50k.json
 cp gpurun_out/counters_blastn.json profiles/${R}_counters_blastn.json
