@@ -701,6 +701,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_BLOCK, 4) void sw_trace_kernel(SwArg
             if (packed) {
                 bool ok[4];
                 sw_four_pk16_trace<LONG>(a, cc, gg, L0, ok, smem, lds_res, lane);
+#ifdef PEP_WALK_PROXY
+                // MEASUREMENT ONLY (make EXTRA=-DPEP_WALK_PROXY=2500; profiles/r06_walk_fusion_proxy.txt): what the four walks of this item would cost the pass if they ran
+                // here, one lane per pair - a dependent chain of 3 x PEP_WALK_PROXY vector instructions on four lanes (the walk kernel issues 4.5 M wave instructions for 590
+                // wavefronts: 7 600 per wavefront, whatever the number of its lanes that walk)
+                {
+                    uint32_t x = (uint32_t)cc[0] + (uint32_t)lane;
+                    if (lane < 4) for (int i = 0; i < PEP_WALK_PROXY; ++i) x = (x ^ (uint32_t)i) + (x >> 3);
+                    if (x == 0x12345u) a.mode[cc[0]] = -7;
+                }
+#endif
                 // a pair whose alignment left its sub-band is swept once more in the full band, one pair per wavefront in 32 bits: the longest single
                 // piece of work of the pass (a millisecond for a pair of 1 000 bases).  It is not done here - a wavefront that met three of them held the
                 // whole launch up (nucleotide tool, 10 000 genes: 1 % of the pairs, 1.98 ms with 1.9 of 4 wavefronts per SIMD resident on average) - but
