@@ -472,10 +472,30 @@ def store_tab_members(rows, off, keys, date_time, threads=None, order=None):
     raise PepError('pep_store_tab_members: the entries did not fit the size it had asked for')
 
 
+_ARGSORT_OK = None
+
+
+def _argsort_matches_numpy():
+    """once per process: does pep_argsort_object_order still leave EQUAL elements where the installed numpy's generic index sort leaves them?  (it restates a private
+    routine of numpy - npy_aquicksort - step by step; a release that changes that routine would change the row order of the .tab store silently.)  A few tie-heavy arrays
+    of the sizes a genome's rows have; on a difference numpy itself is asked from then on - as _fast_append_ok guards the zip fast path."""
+    global _ARGSORT_OK
+    if _ARGSORT_OK is None:
+        rng = np.random.default_rng(20261003)
+        ok = True
+        lib = load_library()
+        for n, k in ((17, 3), (200, 5), (1500, 30)):
+            v = np.ascontiguousarray(rng.integers(0, k, size=n).astype(np.float64))
+            out = np.empty(n, dtype=np.int64)
+            ok = ok and lib.pep_argsort_object_order(_ptr(v), C.c_int64(n), _ptr(out)) == 0 and np.array_equal(out, np.argsort(v.astype(object)))
+        _ARGSORT_OK = bool(ok)
+    return _ARGSORT_OK
+
+
 def argsort_object_order(values):
     """np.argsort(values.astype(object)) for float64 values without NaN - the same steps as numpy's generic index sort, on the doubles (pep_argsort_object_order)"""
     v = np.ascontiguousarray(values, dtype=np.float64)
-    if len(v) and np.isnan(v).any():
+    if (len(v) and np.isnan(v).any()) or not _argsort_matches_numpy():
         return np.argsort(v.astype(object))
     out = np.empty(len(v), dtype=np.int64)
     rc_ = load_library().pep_argsort_object_order(_ptr(v), C.c_int64(len(v)), _ptr(out))
