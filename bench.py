@@ -1275,6 +1275,7 @@ def main():
             extras['map_workload']['worker_pool'] = {'workers': n_pool, 'genomes': n_set, 'genomes_per_s_with_stores': n_set / ps['seconds'], 'seconds': ps['seconds'],
                                                      'first_pass_s': ps['first_pass_s'], 'workers_startup_s': ps['workers_startup_s'], 'phase_s': ps['phase_s_rank0'],
                                                      'container_cpu_s': ps.get('container_cpu_s'), 'cpu_throttled_periods': ps.get('throttled_periods'), 'cpus_granted': effective_cpus(),
+                                                     'cpu_s_per_genome': (ps['container_cpu_s'] / n_set) if ps.get('container_cpu_s') else None,
                                                      'gpu_busy_frac': ps.get('gpu_busy_frac'), 'gpu_busy_samples': ps.get('gpu_busy_samples'),
                                                      'gpu_busy_note': "the driver's gpu_busy_percent (sysfs) sampled every 10 ms over the timed pass by a process of its own, setup and archive closes included",
                                                      'rounds_genomes_per_s': n_set / ps['phase_s_rank0']['groups'] if ps['phase_s_rank0'].get('groups') else None,

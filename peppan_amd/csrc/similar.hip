@@ -531,14 +531,23 @@ int pep_fasta_keep(const char *path, const int64_t *ids, uint64_t n_ids, uint64_
     if (n_kept) *n_kept = kept;
     if (kept == start.size() && (start.empty() || start[0] == 0)) return PEP_OK;       // every record stays: the file is left alone
     start.push_back(n);
-    std::vector<char> out;
-    out.reserve(n);
-    for (size_t k = 0; k + 1 < start.size(); ++k)
-        if (keep[k]) out.insert(out.end(), d + start[k], d + start[k + 1]);
+    // the kept records are moved together inside the buffer the file was read into (runs of kept neighbours in one piece; nothing moves in front of the first
+    // record that goes) and written with one call: a second 10 MB buffer filled record by record was a third of this function's time
+    char *w = data.data();
+    size_t at = 0;
+    for (size_t k = 0; k + 1 < start.size();) {
+        if (!keep[k]) { ++k; continue; }
+        size_t j = k;
+        while (j + 1 < start.size() - 1 && keep[j + 1]) ++j;                 // records k .. j stay
+        const size_t from = start[k], len = start[j + 1] - start[k];
+        if (from != at) memmove(w + at, w + from, len);
+        at += len;
+        k = j + 1;
+    }
     f = fopen(path, "wb");
     if (!f) return PEP_ERR_INTERNAL;
-    const size_t put = out.empty() ? 0 : fwrite(out.data(), 1, out.size(), f);
-    if (fclose(f) != 0 || put != out.size()) return PEP_ERR_INTERNAL;
+    const size_t put = at ? fwrite(w, 1, at, f) : 0;
+    if (fclose(f) != 0 || put != at) return PEP_ERR_INTERNAL;
     return PEP_OK;
 }
 

@@ -301,11 +301,8 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
     marks = [('search', t1)]
     mark = lambda what: marks.append((what, time.perf_counter()))
     if len(T):
-        def as_ids(tab):                                                                # the reference casts both name columns to int (PEPPAN.py:231)
-            try:
-                return np.array(tab).astype(np.int64)                                   # (one C conversion of the whole column)
-            except (ValueError, TypeError, OverflowError):
-                return np.array([int(x) for x in tab], dtype=np.int64)
+        def as_ids(tab):                                                                # the reference casts both name columns to int (PEPPAN.py:231): int() of every name
+            return np.fromiter(map(int, tab), dtype=np.int64, count=len(tab))           # (a quarter of the time of numpy's own text -> integer conversion of a str array)
         q_ids = as_ids(T.q_tab)
         r_ids = q_ids if T.r_tab is T.q_tab else as_ids(T.r_tab)
         seen_q, seen_r = np.zeros(len(q_ids), dtype=bool), np.zeros(len(r_ids), dtype=bool)
