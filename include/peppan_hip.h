@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 14
+#define PEP_ABI_VERSION 15
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -381,6 +381,15 @@ int pep_dedup(pep_ctx *ctx, uint32_t n, const uint32_t *len, const uint8_t *dige
  * n_keep / n_ids return the needed sizes; when they exceed keep_cap / ids_cap nothing is written and the caller calls again. */
 int pep_ovl_filter(uint64_t n, const int64_t *q, const int64_t *r, const int64_t *qs, const int64_t *qe, const int64_t *ss, const int64_t *se,
                    const double *score, double *iden, double coverage, double delta);
+/* pep_known_order (host, no context; ABI 15): compare_prediction (PEPPAN.py:869-901) over the columns of one genome's hit table.  For every hit the largest fraction of an
+ * original gene of the same contig that it covers in frame and on the same strand (0.1 when there is none): the genes of contig c (row code ri) are
+ * g1 / g2 / g_plus [g_off[c], g_off[c + 1]) - start, end, strand '+' - in the store's order; g_sorted[c] != 0: in start order (every gene between the first whose
+ * running maximum of ends reaches the hit and the last that starts at or before its end is judged), else the reference's forward-only pointer sweep.  The table is
+ * walked by (contig code, lower reference coordinate) and returned in the order (query code, contig code, score), each stable: order[k] = the row that comes k-th,
+ * known[k] = its value. */
+int pep_known_order(uint64_t n, const int64_t *ri, const int64_t *r_code, const int64_t *q_code, const int64_t *ss, const int64_t *se, const int64_t *qs,
+                    const int64_t *qe, const int64_t *ql, const double *score, uint64_t n_contigs, const uint64_t *g_off, const int64_t *g1, const int64_t *g2,
+                    const uint8_t *g_plus, const uint8_t *g_sorted, int64_t *order, double *known);
 int pep_linear_merge(uint64_t n, const int64_t *q, const int64_t *r, const double *iden, const int64_t *qs, const int64_t *qe, const int64_t *ss,
                      const int64_t *se, const double *score, const int64_t *ql, const int64_t *sl, const int64_t *rid, double gap_dist, double len_diff,
                      int64_t *keep_seq, uint64_t keep_cap, uint64_t *n_keep, uint64_t *query_off, uint8_t *query_ascending, uint64_t *n_query,

@@ -8,13 +8,13 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set
 EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy', 'pep_last_error', 'pep_default_params', 'pep_set_sensitivity',
            'pep_min_score', 'pep_min_score_ka', 'pep_set_query_nt', 'pep_set_ref_nt', 'pep_set_query_aa', 'pep_set_ref_aa', 'pep_translate', 'pep_use_nt_as_residues',
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
-           'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
+           'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_known_order', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
            'pep_similar_classify', 'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_fasta_records', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast', 'pep_argsort_object_order',
            'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather']
 
@@ -224,6 +224,35 @@ def ovl_filter(q, r, qs, qe, ss, se, score, iden, coverage, delta):
     rc_ = lib.pep_ovl_filter(C.c_uint64(n), *[_ptr(a) for a in arrs], _ptr(score), _ptr(iden), C.c_double(coverage), C.c_double(delta))
     if rc_ != 0:
         raise PepError('pep_ovl_filter failed (%d)' % rc_)
+
+
+def known_order(T, genes_of):
+    """pep_known_order: compare_prediction over a HitTable's columns -> (order int64[n], known float64[n]) - the rows in the order (query, contig, score) and their
+    column 10.  genes_of(c): the original genes of the contig with row code c as (start int64[], end int64[], plus bool[]) in the store's order, or None"""
+    lib = load_library()
+    n = len(T)
+    i64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+    ri, r_code, q_code = i64(T.ri), i64(T.r_codes()), i64(T.q_codes())
+    n_contigs = len(T.r_tab)
+    g_off = np.zeros(n_contigs + 1, dtype=np.uint64)
+    parts, is_sorted = {}, np.ones(max(n_contigs, 1), dtype=np.uint8)
+    for c in (np.unique(ri).tolist() if n else []):
+        g = genes_of(c)
+        if g is not None and len(g[0]):
+            parts[c] = g
+            g_off[c + 1] = len(g[0])
+            is_sorted[c] = 0 if (np.diff(g[0]) < 0).any() else 1
+    np.cumsum(g_off, out=g_off)
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([parts[c][k] for c in sorted(parts)]) if parts else np.zeros(1), dtype=dt)
+    g1, g2, plus = cat(0, np.int64), cat(1, np.int64), cat(2, np.uint8)
+    cols = [i64(a) for a in (T.ss, T.se, T.qs, T.qe, T.ql)]
+    score = np.ascontiguousarray(T.score, dtype=np.float64)
+    order, known = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.float64)
+    rc_ = lib.pep_known_order(C.c_uint64(n), _ptr(ri), _ptr(r_code), _ptr(q_code), *([_ptr(c) for c in cols] + [_ptr(score), C.c_uint64(n_contigs), _ptr(g_off), _ptr(g1), _ptr(g2),
+                              _ptr(plus), _ptr(is_sorted), _ptr(order), _ptr(known)]))
+    if rc_ != 0:
+        raise PepError('pep_known_order failed (%d)' % rc_)
+    return order, known
 
 
 def linear_merge(q, r, iden, qs, qe, ss, se, score, ql, sl, rid, gap_dist, len_diff):

@@ -257,4 +257,76 @@ int pep_linear_merge(uint64_t n, const int64_t *q, const int64_t *r, const doubl
     return PEP_OK;
 }
 
+// compare_prediction over the columns of one genome's table (PEPPAN.py:869-901; mapbsn._with_known is its numpy statement and the test's yardstick): see peppan_hip.h
+int pep_known_order(uint64_t n, const int64_t *ri, const int64_t *r_code, const int64_t *q_code, const int64_t *ss, const int64_t *se, const int64_t *qs,
+                    const int64_t *qe, const int64_t *ql, const double *score, uint64_t n_contigs, const uint64_t *g_off, const int64_t *g1, const int64_t *g2,
+                    const uint8_t *g_plus, const uint8_t *g_sorted, int64_t *order, double *known)
+{
+    if (n && (!ri || !r_code || !q_code || !ss || !se || !qs || !qe || !ql || !score || !g_off || !order || !known)) return PEP_ERR_ARG;
+    auto mod3 = [](int64_t x) { const int64_t m = x % 3; return m < 0 ? m + 3 : m; };          // numpy's %: the sign of the divisor
+    std::vector<int64_t> lo(n), hi(n), first(n);
+    for (uint64_t i = 0; i < n; ++i) { lo[i] = std::min(ss[i], se[i]); hi[i] = std::max(ss[i], se[i]); first[i] = (int64_t)i; }
+    // the order the reference walks the table in: (contig, lower reference coordinate), stable
+    std::stable_sort(first.begin(), first.end(), [&](int64_t a, int64_t b) { return r_code[a] != r_code[b] ? r_code[a] < r_code[b] : lo[a] < lo[b]; });
+    std::vector<double> kn(n, 0.1);                  // known[k] belongs to row first[k]
+    std::vector<int64_t> cmax;
+    for (uint64_t a = 0; a < n;) {
+        uint64_t b = a + 1;
+        while (b < n && ri[first[b]] == ri[first[a]]) ++b;
+        const int64_t c = ri[first[a]];
+        if (c < 0 || (uint64_t)c >= n_contigs) return PEP_ERR_ARG;
+        const uint64_t g0 = g_off[c], ng = g_off[c + 1] - g_off[c];
+        if (ng) {
+            const int64_t *p1 = g1 + g0, *p2 = g2 + g0;
+            const uint8_t *pl = g_plus + g0;
+            auto judge = [&](uint64_t k, uint64_t j) {          // gene j against the row at position k of the walk
+                const int64_t row = first[k], s = lo[row], e = hi[row];
+                const bool fwd = ss[row] < se[row];
+                const int64_t head = ss[row] - qs[row] + 1, tail = se[row] + (ql[row] - qe[row]);
+                const int64_t f1 = fwd ? mod3(head) + 1 : mod3(-head) - 1, f2 = fwd ? mod3(tail + 1) + 1 : mod3(-(tail - 1)) - 1;
+                const int64_t m1 = pl[j] ? mod3(p1[j]) + 1 : mod3(-(p1[j] - 1)) - 1, m2 = pl[j] ? mod3(p2[j] + 1) + 1 : mod3(-p2[j]) - 1;
+                if (m1 != f1 && m1 != f2 && m2 != f1 && m2 != f2) return;
+                const int64_t plen = p2[j] - p1[j] + 1;
+                const double ovl = (double)(std::min(e, p2[j]) - std::max(s, p1[j]) + 1);
+                if (ovl >= 0.6 * (double)plen || ovl >= 0.6 * (double)(e - s + 1)) kn[k] = std::max(kn[k], ovl / (double)plen);
+            };
+            if (g_sorted[c]) {
+                // genes in start order: every gene from the first whose running maximum of ends reaches the hit's start to the last that starts at or before its end
+                cmax.resize(ng);
+                int64_t m = p2[0];
+                for (uint64_t j = 0; j < ng; ++j) { m = std::max(m, p2[j]); cmax[j] = m; }
+                for (uint64_t k = a; k < b; ++k) {
+                    const int64_t row = first[k];
+                    const uint64_t f = (uint64_t)(std::lower_bound(cmax.begin(), cmax.end(), lo[row]) - cmax.begin());
+                    const uint64_t l = std::max<uint64_t>((uint64_t)(std::upper_bound(p1, p1 + ng, hi[row]) - p1), f);
+                    for (uint64_t j = f; j < l; ++j) judge(k, j);
+                }
+            } else {
+                // any order: the reference's pointer sweep, row by row
+                uint64_t at = 0;
+                for (uint64_t k = a; k < b; ++k) {
+                    const int64_t row = first[k];
+                    while (at < ng && lo[row] > p2[at]) ++at;
+                    for (uint64_t j = at; j < ng; ++j) {
+                        if (hi[row] < p1[j]) break;
+                        judge(k, j);
+                    }
+                }
+            }
+        }
+        a = b;
+    }
+    // the order compare_prediction returns the table in: (query, contig, score), stable on top of the walk
+    std::vector<int64_t> again(n);
+    for (uint64_t k = 0; k < n; ++k) again[k] = (int64_t)k;
+    std::stable_sort(again.begin(), again.end(), [&](int64_t x, int64_t y) {
+        const int64_t a = first[x], b = first[y];
+        if (q_code[a] != q_code[b]) return q_code[a] < q_code[b];
+        if (r_code[a] != r_code[b]) return r_code[a] < r_code[b];
+        return score[a] < score[b];
+    });
+    for (uint64_t k = 0; k < n; ++k) { order[k] = first[again[k]]; known[k] = kn[again[k]]; }
+    return PEP_OK;
+}
+
 }  // extern "C"

@@ -475,7 +475,27 @@ def _known_fraction_rows(s, e, f1, f2, g1, g2, plus):
 
 def _with_known(T, old_prediction):
     """the table in the order compare_prediction returns it - (query, contig, score), stable on top of the (contig, position) walk -
-    with column 10 replaced"""
+    with column 10 replaced.  One pass of host C++ over the columns (pep_known_order: both orders and the interval sweep; round 6 - as numpy expressions,
+    _with_known_numpy below, this was 3.2 of the 5.4 ms build_groups spent on a genome); the store is asked for the genes of the contigs the table names"""
+    from . import _native as N
+    if len(T) == 0:
+        return T
+    with (contextlib.nullcontext(old_prediction) if isinstance(old_prediction, MapBsn) else MapBsn(old_prediction)) as op:       # (an open store is read as it is)
+        def genes_of(c):
+            genes = op.get(T.r_tab[c])
+            if len(genes) == 0:
+                return None
+            if isinstance(genes, np.ndarray) and genes.ndim == 2 and genes.shape[1] >= 4:       # (the store's object rows: three column conversions in C instead of three loops)
+                return genes[:, 1].astype(np.int64), genes[:, 2].astype(np.int64), np.asarray(genes[:, 3] == '+', dtype=bool)
+            return (np.array([p[1] for p in genes], dtype=np.int64), np.array([p[2] for p in genes], dtype=np.int64), np.array([p[3] == '+' for p in genes], dtype=bool))
+        order, known = N.known_order(T, genes_of)
+    T = T.take(order)
+    T.evalue = known
+    return T
+
+
+def _with_known_numpy(T, old_prediction):
+    """_with_known as numpy expressions over the columns (_known_fraction + two lexsorts): the statement pep_known_order is held to (tests/test_mapbsn_golden.py)"""
     order, known = _known_fraction(T, old_prediction)
     # (the second sort is stable on top of the first order: sorted over the three key columns taken in that order, the table itself is gathered once)
     again = np.lexsort((T.score[order], T.r_codes()[order], T.q_codes()[order]))
@@ -830,6 +850,15 @@ def _gpu_search(prefix, clust, jobs, params, genomes_per_batch=64):
     from .uberBlast import uberBlastBatch
     argv = _map_argv(clust, params)
     for lo in range(0, len(jobs), genomes_per_batch):
+        # a contig handed over as str is turned into ASCII bytes ONCE, in place in the job's own list: the search packs it, K12 (build_groups) packs it again, and
+        # every packing of a str is another encode of the genome (1.2 ms per genome; the pool's workers get bytes from their files anyway)
+        for id, taxon, seq in jobs[lo:lo + genomes_per_batch]:
+            for pair in seq:
+                if isinstance(pair, list) and isinstance(pair[1], str):
+                    try:
+                        pair[1] = pair[1].encode('ascii')
+                    except UnicodeEncodeError:
+                        pass
         # (strict: a search tool that fails fails the mapping - stores made of one tool's hits only would look like results)
         for r in uberBlastBatch([seq for id, taxon, seq in jobs[lo:lo + genomes_per_batch]], argv, as_tables=True, strict=True):        # (HitTable, overlaps) per genome
             yield r

@@ -467,3 +467,49 @@ def test_groups_of_a_round_with_one_k12_call_equal_groups_per_genome(world):
             assert len(got) == 4 and len(got[1].gene) == 0
             for G, i in zip([got[0]] + got[2:], order):
                 same(G, single[i])
+
+
+def test_known_order_equals_its_numpy_statement(tmp_path):
+    """pep_known_order (host C++: compare_prediction's walk, interval test and final order in one pass) against mapbsn._with_known_numpy over random tables: several
+    contigs, both strands, every frame relation, gene lists in start order and not (the reference's forward-only pointer sweep), contigs without genes, tied scores and
+    tied coordinates (the two stable sorts), names that are integers"""
+    from peppan_amd import mapbsn
+    from peppan_amd.hittable import HitTable
+    rng = np.random.default_rng(11)
+    for rep in range(25):
+        n = int(rng.integers(0, 1500))
+        n_contig, n_q = int(rng.integers(1, 6)), int(rng.integers(1, 40))
+        r_tab, q_tab = [int(x) for x in rng.permutation(50)[:n_contig] + 100], [int(x) for x in rng.permutation(500)[:n_q]]
+        with mapbsn.MapBsn(str(tmp_path / ('old%d.npz' % rep)), 'w') as op:
+            for c, name in enumerate(r_tab):
+                if c == 1 and rep % 3 == 0:
+                    continue                                                       # a contig without original genes
+                m = int(rng.integers(1, 60))
+                st = np.sort(rng.integers(1, 20000, size=m))
+                if c == 2 or rep % 5 == 4:
+                    st = rng.permutation(st)                                       # not in start order: the pointer sweep
+                en = st + rng.integers(30, 1500, size=m)
+                op.save(name, np.array([[k, int(a), int(b), '+' if rng.random() < 0.5 else '-', 1] for k, (a, b) in enumerate(zip(st, en))], dtype=object))
+        ql = rng.integers(60, 1500, size=n)
+        qs = rng.integers(1, 30, size=n)
+        qe = np.minimum(ql, qs + rng.integers(20, 1500, size=n))
+        a = rng.integers(1, 20000, size=n)
+        if n > 10:
+            a[::7] = a[0]                                                          # tied coordinates
+        b = a + (qe - qs) + rng.integers(-3, 4, size=n)
+        rev = rng.random(n) < 0.4
+        ss, se = np.where(rev, b, a), np.where(rev, a, b)
+        score = np.round(rng.uniform(50, 60, size=n), 0 if rep % 2 else 3)          # (rounded: ties)
+        z = np.zeros(n, dtype=np.int64)
+        def table():
+            return HitTable(list(q_tab), list(r_tab), rng2.integers(0, n_q, size=n), rng2.integers(0, n_contig, size=n), np.round(rng2.uniform(0.7, 1, size=n), 3), z, z, z, qs, qe, ss, se,
+                            np.zeros(n), score, ql, ql + 10, np.zeros(1, np.uint32), z, z, rid=np.arange(n))
+        rng2 = np.random.default_rng(rep)
+        T1 = table()
+        rng2 = np.random.default_rng(rep)
+        T2 = table()
+        want = mapbsn._with_known_numpy(T1, str(tmp_path / ('old%d.npz' % rep)))
+        got = mapbsn._with_known(T2, str(tmp_path / ('old%d.npz' % rep)))
+        assert np.array_equal(want.rid, got.rid) and np.array_equal(want.evalue, got.evalue), rep
+        if n > 500:
+            assert (got.evalue != 0.1).any()

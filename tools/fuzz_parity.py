@@ -1,7 +1,8 @@
 """Randomised parity of the whole search against the CPU oracle: random protein sets (families, exact duplicates, X and B at the ends and inside,
 repeats), random thresholds, score tables other than BLOSUM62 (ties on the diagonal, residues that are neither dominant nor harmless, cheap
 gaps), every combination of the test switches (exact sizing of the alignment stage, identical pairs compared / swept, 32-bit sweeps, LSD sort).
-python3 tools/fuzz_parity.py [cases] [seed] [nucl]   - exits 1 on the first difference; nucl: the nucleotide configuration of the engine"""
+python3 tools/fuzz_parity.py [cases] [seed] [nucl | nt]   - exits 1 on the first difference; nucl: the nucleotide configuration of the engine; nt: the translated
+search from nucleotide sets (K1 inside, the self-search path) against the oracle and against the plain stream"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
@@ -69,12 +70,83 @@ def nucleotide_cases(ctx, cases, rng):
     print('all %d nucleotide cases identical to the oracle' % cases)
 
 
+def from_nucleotide_cases(ctx, cases, rng):
+    """the translated search FROM NUCLEOTIDES (K1 inside; the self-search path of round 6: self_prepare decides which targets repeat a query, seed_match drops their
+    diagonal-0 hits): gene sets with stops in frame 1, frame shifts, ambiguous bases, duplicates, empty and tiny genes, genes of several chunks; reference = the queries,
+    or the queries with genes replaced / edited / reordered / missing / added; K1 in front of or inside the search; the plain stream (reserved[0] = 10) beside it"""
+    sense = [a + b + c for a in 'ACGT' for b in 'ACGT' for c in 'ACGT' if a + b + c not in ('TAA', 'TAG', 'TGA')]
+    for case in range(cases):
+        names, seqs = synth.make_genes(int(rng.integers(20, 260)), 0, seed=int(rng.integers(1, 1 << 30)))
+        seqs = [bytes(x) for x in seqs]
+        for _ in range(int(rng.integers(0, 12))):
+            i = int(rng.integers(0, len(seqs)))
+            g = seqs[i]
+            kind = int(rng.integers(0, 9))
+            if kind == 0 and len(g) > 40: at = 3 * int(rng.integers(1, len(g) // 3 - 2)); g = g[:at] + b'TAA' + g[at + 3:]         # a stop inside frame 1
+            elif kind == 1: g = b'ACG'[:int(rng.integers(1, 3))] + g                                                               # another reading frame
+            elif kind == 2: g = b''
+            elif kind == 3: g = b'ATGAAATAA'
+            elif kind == 4: g = g.lower()
+            elif kind == 5 and len(g) > 60: at = int(rng.integers(0, len(g) - 9)); g = g[:at] + b'NNNRYKN'[:int(rng.integers(1, 8))] + g[at + 7:]
+            elif kind == 6: seqs.append(g)                                                                                          # a duplicate
+            elif kind == 7: g = ('ATG' + ''.join(sense[k] for k in rng.integers(0, 61, size=int(rng.integers(1001, 1500)))) + 'TAA').encode()     # several chunks per frame
+            elif kind == 8 and len(g) > 90: at = 3 * int(rng.integers(1, len(g) // 3 - 12)); g = g[:at] + b'NNN' * int(rng.integers(1, 12)) + g[at + 3:]
+            seqs[i] = g
+        ref = list(seqs)
+        how = int(rng.integers(0, 7))
+        if how == 1 and len(ref) > 3: ref[int(rng.integers(0, len(ref)))] = ref[int(rng.integers(0, len(ref)))]
+        elif how == 2:
+            i = int(rng.integers(0, len(ref)))
+            if len(ref[i]) > 50:
+                at = int(rng.integers(0, len(ref[i]) - 1)); ref[i] = ref[i][:at] + (b'A' if ref[i][at:at + 1].upper() != b'A' else b'C') + ref[i][at + 1:]
+        elif how == 3: ref = ref[::-1]
+        elif how == 4: ref = ref[:-int(rng.integers(1, 4))]
+        elif how == 5: ref = ref + [ref[0]]
+        qry = seqs if how != 6 else seqs[int(rng.integers(0, 10)):][:int(rng.integers(5, 120))]
+        gtable = int(rng.choice([11, 11, 4]))
+        frames = 6
+        inside = int(rng.integers(0, 2))
+        res = []
+        for flag in (0, 10):
+            p = N.default_params(float(rng.choice([45., 45., 30., 70.])) if flag == 0 else res_p.min_id_pct, 25., 10, 5)
+            if flag == 0:
+                p.top_k = int(rng.choice([10, 10, 2, 50])); res_p = p
+            else:
+                p.top_k = res_p.top_k
+            p.reserved[0] = flag
+            ctx.set_query_nt(qry, gtable); ctx.set_ref_nt(ref, frames, gtable)
+            if inside:
+                ctx.invalidate_translation()
+            res.append(ctx.search(p))
+        (gh, gc, st), (ph, pc, pst) = res
+        q_aa = [O.aa_codes(O.query_frame(x.decode(), gtable)[1]) for x in qry]
+        t_aa = []
+        for x in ref:
+            for aa in O.translate_frames(x.decode(), range(1, 7), gtable):
+                t_aa += [O.aa_codes(c) for o, c in O.ref_chunks(aa)]
+        op = O.default_params(res_p.min_id_pct, 25., res_p.top_k, 5)
+        oh, oc, ost = O.search(q_aa, t_aa, op)
+        bad = [f for f in FIELDS if len(gh) != len(oh) or not np.array_equal(gh[f], oh[f])]
+        bad += ['cigar arena'] if not np.array_equal(gc, oc) else []
+        bad += ['stat ' + k for k in ('candidates', 'pairs', 'cells', 'tracebacks') if st[k] != ost[k]]
+        bad += ['plain stream: ' + f for f in FIELDS if len(gh) != len(ph) or not np.array_equal(gh[f], ph[f])]
+        bad += ['plain stream: stat ' + k for k in ('query_seeds', 'target_seeds', 'seed_hits', 'candidates') if st[k] != pst[k]]
+        print('nt case %3d: %4d queries x %4d reference genes (variant %d, table %d, K1 %s), min_id %.0f top_k %d: %8d raw hits %6d candidates, %6d hits  %s'
+              % (case, len(qry), len(ref), how, gtable, 'inside' if inside else 'in front', res_p.min_id_pct, res_p.top_k, st['seed_hits'], st['candidates'], len(gh),
+                 'ok' if not bad else 'DIFFERENT: ' + ', '.join(bad)), flush=True)
+        if bad:
+            sys.exit(1)
+    print('all %d from-nucleotide cases identical to the oracle and to the plain stream' % cases)
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2024)
     ctx = N.Context(0)
     if len(sys.argv) > 3 and sys.argv[3] == 'nucl':
         return nucleotide_cases(ctx, cases, rng)
+    if len(sys.argv) > 3 and sys.argv[3] == 'nt':
+        return from_nucleotide_cases(ctx, cases, rng)
     for case in range(cases):
         prots = make_set(rng)
         p = N.default_params(float(rng.choice([0., 30., 45., 70.])), float(rng.choice([0., 10., 25., 60.])), int(rng.choice([1, 2, 10, 50])), int(rng.choice([1, 5])))
