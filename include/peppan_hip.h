@@ -35,8 +35,9 @@
  *   pep_table_from_hits / pep_cols_fix_end / pep_cols_order / pep_cols_gather   RunBlast.run's numeric chain between a search and the caller (host C++:
  *                           parseDiamond / parseBlast columns, fixEnd, the final sort)   uberBlast.py:25-58, 275-290, 375, 462-480
  *   pep_store_tab_members   all members of the .tab store (gene -> int rows) as finished zip entries, host threads   PEPPAN.py:91-113, 972-975
- *   pep_similar_scan / pep_pair_support / pep_similar_resolve   the pass of get_similar_pairs over the all-vs-all table and its
- *                           get_similar (host state machine, K14 on the GPU, host dictionary)   PEPPAN.py:195-224, 231-276, 294
+ *   pep_similar_classify / pep_similar_scan / pep_pair_support / pep_similar_resolve   the pass of get_similar_pairs over the all-vs-all table and its
+ *                           get_similar (row-local tests, host state machine, K14 on the GPU, host dictionary)   PEPPAN.py:195-224, 231-276, 294
+ *   pep_known_order         compare_prediction over a genome's hit table (host C++)   PEPPAN.py:869-901
  */
 #ifndef PEPPAN_HIP_H
 #define PEPPAN_HIP_H
