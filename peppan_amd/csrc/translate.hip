@@ -176,6 +176,113 @@ __global__ __launch_bounds__(256) void k1_query_frames(const uint8_t *__restrict
     }
 }
 
+// The chunks of a reference frame (uberBlast.py:539-544: regex `.{1000,}?X|.{1,1000}$` over the frame string + 'X'): a chunk that starts at c0 ends with the first stop at
+// or behind c0 + 1000, or with the string.  chunk_end: that position, found by the whole wavefront 64 characters at a time.
+__device__ __forceinline__ int64_t chunk_end(const uint8_t *s, int64_t L, int f, int tab, int64_t na, int64_t c0, int lane)
+{
+    if (na + 1 - c0 < 1001) return na;
+    int64_t x0 = c0 + 1000;
+    for (;;) {
+        const int64_t a = x0 + lane;
+        bool isx = false;
+        if (a < na) { bool gap; isx = (translate_at(s, (int)L, f, (int)a, tab, &gap) == 23) && !gap; }
+        else if (a == na) isx = true;
+        const unsigned long long m = __ballot(isx);
+        if (m) return x0 + (int64_t)__ffsll((long long)m) - 1;
+        x0 += 64;
+    }
+}
+
+// A chunk's start follows from the chunk in front of it: one wavefront walking a 7.7 Mb contig's frame takes 2 500 dependent round trips to memory (4 ms per search of a
+// mapping batch at 50 000 exemplars: a third of the batch's GPU time, whatever the number of contigs).  Chains that start at different places MERGE, though - two chunks
+// whose starts + 1000 fall between the same two stops end with the same stop, and from there on the chains are one.  Frames of more than 2 x K1_SEG characters are
+// therefore cut into segments of K1_SEG characters: k1_ref_chunks_spec walks every segment from its first character as if a chunk started there (all segments of all
+// frames side by side) and keeps the starts it finds; k1_ref_chunks_join then walks the TRUE chain of a frame segment by segment, and as soon as a true start is one the
+// segment's speculative walk has found - after one to three chunks, as a rule - takes the rest of the segment from that list.
+constexpr int64_t K1_SEG = 49152;             // (a 2.6 M-character frame of a 7.7 Mb contig: 53 segments; the join walks one to three chunks per segment before it meets the speculative list)
+constexpr int K1_SPEC_CAP = 56;                  // starts per segment: at most K1_SEG / 1001 + 1 = 50 - one per lane of the joining wavefront
+static_assert(K1_SEG / 1001 + 2 <= K1_SPEC_CAP && K1_SPEC_CAP <= 64, "a segment's starts: one per lane");
+struct K1Seg { uint32_t w, seg; };
+struct K1Long { uint32_t w, first_seg, n_seg, pad; };
+
+__global__ __launch_bounds__(256) void k1_ref_chunks_spec(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ off, int n_frames, int tab, const K1Seg *__restrict__ segs,
+                                                          uint32_t n_seg, uint32_t *__restrict__ spec)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (x >= n_seg) return;
+    const K1Seg sg = segs[x];
+    const uint32_t g = sg.w / (uint32_t)n_frames;
+    const int f = (int)(sg.w % (uint32_t)n_frames) + 1;
+    const uint8_t *s = nt + off[g];
+    const int64_t L = (int64_t)(off[g + 1] - off[g]);
+    const int64_t na = frame_len(L, f);
+    const int64_t lo = (int64_t)sg.seg * K1_SEG, hi = lo + K1_SEG;
+    uint32_t *out = spec + (size_t)x * (K1_SPEC_CAP + 2);         // [0] = number of starts, [1] = the first start behind the segment, [2 ..] the starts
+    uint32_t cnt = 0;
+    int64_t c0 = lo;
+    while (c0 < hi && c0 < na + 1) {
+        if (lane == 0 && cnt < (uint32_t)K1_SPEC_CAP) out[2 + cnt] = (uint32_t)c0;
+        ++cnt;
+        c0 = chunk_end(s, L, f, tab, na, c0, lane) + 1;
+    }
+    if (lane == 0) { out[0] = min(cnt, (uint32_t)K1_SPEC_CAP); out[1] = (uint32_t)c0; }
+}
+
+// one wavefront per LONG frame: its true chain from the segments' speculative starts; chunk_off / chunk_len / chunk_cnt as k1_ref_chunks writes them
+__global__ __launch_bounds__(256) void k1_ref_chunks_join(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ off, int n_frames, int tab, const K1Long *__restrict__ longs,
+                                                          uint32_t n_long, const uint32_t *__restrict__ spec, const uint64_t *__restrict__ chunk_base,
+                                                          uint32_t *__restrict__ chunk_cnt, uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ chunk_len)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (x >= n_long) return;
+    const K1Long lg = longs[x];
+    const uint32_t g = lg.w / (uint32_t)n_frames;
+    const int f = (int)(lg.w % (uint32_t)n_frames) + 1;
+    const uint8_t *s = nt + off[g];
+    const int64_t L = (int64_t)(off[g + 1] - off[g]);
+    const int64_t na = frame_len(L, f);
+    uint32_t *starts = chunk_off + chunk_base[lg.w];               // the chunk starts in order (their lengths are taken from them at the end)
+    uint32_t cnt = 0;
+    int64_t t = 0;                                                  // the next true start
+    for (uint32_t k = 0; k < lg.n_seg && t < na + 1; ++k) {
+        const int64_t hi = (int64_t)(k + 1) * K1_SEG;
+        if (t >= hi) continue;                                      // (a chunk that spans the whole segment)
+        const uint32_t *sp = spec + (size_t)(lg.first_seg + k) * (K1_SPEC_CAP + 2);
+        const uint32_t m = sp[0];
+        const uint32_t mine = lane < (int)m ? sp[2 + lane] : 0xFFFFFFFFu;      // (m <= K1_SPEC_CAP <= 64: one start per lane)
+        while (t < hi && t < na + 1) {
+            const unsigned long long at = __ballot(mine == (uint32_t)t);
+            if (at) {
+                // the speculative walk of this segment came through here: the rest of the segment is its list
+                const int i = __ffsll((long long)at) - 1;
+                if (lane >= i && lane < (int)m) starts[cnt + (uint32_t)(lane - i)] = mine;
+                cnt += m - (uint32_t)i;
+                t = (int64_t)sp[1];
+                break;
+            }
+            if (lane == 0) starts[cnt] = (uint32_t)t;
+            ++cnt;
+            t = chunk_end(s, L, f, tab, na, t, lane) + 1;
+        }
+    }
+    // (a frame whose segments are used up before its end cannot occur: the segments cover [0, na + 1))
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // lengths: a chunk reaches up to the start of the next one; the last one ends with the string (the appended 'X' does not count) and is dropped when nothing is left
+    uint32_t *lens = chunk_len + chunk_base[lg.w];
+    uint32_t kept = cnt;
+    for (uint32_t i = (uint32_t)lane; i < cnt; i += 64) {
+        const uint32_t c0 = __builtin_nontemporal_load(&starts[i]);
+        const uint32_t len = i + 1 < cnt ? __builtin_nontemporal_load(&starts[i + 1]) - c0 : (uint32_t)(na - (int64_t)c0);
+        lens[i] = len;
+    }
+    if (cnt && (int64_t)__builtin_nontemporal_load(&starts[cnt - 1]) >= na) kept = cnt - 1;
+    if (lane == 0) chunk_cnt[lg.w] = kept;
+}
+
 // one wavefront per (reference sequence, frame): chunk boundaries.  chunk_base[w] = first slot of this frame's chunk list.
 __global__ __launch_bounds__(256) void k1_ref_chunks(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ off, uint32_t n, int n_frames, int tab,
                                                      const uint64_t *__restrict__ chunk_base, uint32_t *__restrict__ chunk_cnt,
@@ -189,23 +296,12 @@ __global__ __launch_bounds__(256) void k1_ref_chunks(const uint8_t *__restrict__
     const uint8_t *s = nt + off[g];
     const int64_t L = (int64_t)(off[g + 1] - off[g]);
     const int64_t na = frame_len(L, f);         // the frame string; the reference appends one more 'X' at index na
+    if (na + 1 > 2 * K1_SEG) return;            // a long frame: k1_ref_chunks_spec / k1_ref_chunks_join
     const uint64_t base = chunk_base[w];
     uint32_t cnt = 0;
     int64_t c0 = 0;
     while (c0 < na + 1) {
-        int64_t end;                             // index of the chunk's last character in s + 'X'
-        if (na + 1 - c0 >= 1001) {
-            int64_t x0 = c0 + 1000;
-            end = -1;
-            while (end < 0) {
-                const int64_t a = x0 + lane;
-                bool isx = false;
-                if (a < na) { bool gap; isx = (translate_at(s, (int)L, f, (int)a, tab, &gap) == 23) && !gap; }
-                else if (a == na) isx = true;
-                const unsigned long long m = __ballot(isx);
-                if (m) end = x0 + (int64_t)__ffsll((long long)m) - 1; else x0 += 64;
-            }
-        } else end = na;
+        const int64_t end = chunk_end(s, L, f, tab, na, c0, lane);      // index of the chunk's last character in s + 'X'
         int64_t len = end - c0 + 1;
         if (end == na) --len;                    // drop the appended 'X'
         if (len > 0) {
@@ -648,6 +744,29 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
         ctx->k1_upper = upper;
         PEP_TRY(dev_reserve(ctx, ctx->d_k1_base, (nw + 1) * 8));
         PEP_HIP(ctx, hipMemcpy(ctx->d_k1_base.p, base.data(), (nw + 1) * 8, hipMemcpyHostToDevice));
+        // the segments of the long frames (k1_ref_chunks_spec / _join): a function of the lengths as well
+        std::vector<K1Seg> segs;
+        std::vector<K1Long> longs;
+        for (uint32_t g = 0; g < n; ++g) {
+            const uint64_t L = nt.h_off[g + 1] - nt.h_off[g];
+            for (int f = 1; f <= nf; ++f) {
+                const uint64_t shift = (uint64_t)(f <= 3 ? f - 1 : f - 4);
+                const uint64_t na = L > shift ? (L - shift + 2) / 3 : 0;
+                if (na + 1 <= 2 * (uint64_t)K1_SEG) continue;
+                const uint32_t w = g * (uint32_t)nf + (uint32_t)(f - 1), n_seg = (uint32_t)((na + 1 + K1_SEG - 1) / K1_SEG);
+                longs.push_back(K1Long{w, (uint32_t)segs.size(), n_seg, 0u});
+                for (uint32_t k = 0; k < n_seg; ++k) segs.push_back(K1Seg{w, k});
+            }
+        }
+        ctx->k1_n_seg = (uint32_t)segs.size();
+        ctx->k1_n_long = (uint32_t)longs.size();
+        if (!segs.empty()) {
+            PEP_TRY(dev_reserve(ctx, ctx->d_k1_seg, segs.size() * sizeof(K1Seg)));
+            PEP_TRY(dev_reserve(ctx, ctx->d_k1_long, longs.size() * sizeof(K1Long)));
+            PEP_TRY(dev_reserve(ctx, ctx->d_k1_spec, segs.size() * (size_t)(K1_SPEC_CAP + 2) * 4));
+            PEP_HIP(ctx, hipMemcpy(ctx->d_k1_seg.p, segs.data(), segs.size() * sizeof(K1Seg), hipMemcpyHostToDevice));
+            PEP_HIP(ctx, hipMemcpy(ctx->d_k1_long.p, longs.data(), longs.size() * sizeof(K1Long), hipMemcpyHostToDevice));
+        }
         ctx->k1_base_frames = nf;
     }
     const uint64_t slots = ctx->k1_base[nw], upper = ctx->k1_upper;
@@ -669,6 +788,13 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     if (nw) {
         hipLaunchKernelGGL(k1_ref_chunks, dim3((unsigned)ceil_div(nw, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, nf, tab,
                            d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>());
+        if (ctx->k1_n_long) {
+            // the frames of contigs: speculative chunk starts per segment, all segments side by side, then the true chain per frame (see k1_ref_chunks_spec)
+            hipLaunchKernelGGL(k1_ref_chunks_spec, dim3((unsigned)ceil_div(ctx->k1_n_seg, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), nf, tab,
+                               ctx->d_k1_seg.as<const K1Seg>(), ctx->k1_n_seg, ctx->d_k1_spec.as<uint32_t>());
+            hipLaunchKernelGGL(k1_ref_chunks_join, dim3((unsigned)ceil_div(ctx->k1_n_long, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), nf, tab,
+                               ctx->d_k1_long.as<const K1Long>(), ctx->k1_n_long, ctx->d_k1_spec.as<const uint32_t>(), d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>());
+        }
         {
             K1Scan sc;
             const uint64_t tiles = ceil_div(nw, 256);

@@ -182,6 +182,55 @@ def test_k1_random_shapes_vs_oracle(ctx):
             assert got == exp, (table, frames)
 
 
+def test_k1_chunks_of_long_contigs_vs_oracle(ctx):
+    """K1's chunk lists for LONG reference sequences (round 6: frames beyond 98 304 characters are cut into segments whose speculative chunk chains are joined to the
+    true chain, k1_ref_chunks_spec / _join) against the reference's regex over the whole frame (oracle.ref_chunks): contigs of random text (a stop every ~21 codons),
+    of gene-like text (open reading frames of hundreds of codons in one frame or the other), with a stop-free stretch longer than a segment, with runs of N, of lengths
+    around the segment size and its multiples; the residues too"""
+    from oracle import oracle as O
+    from peppan_amd import synth
+    rng = np.random.default_rng(97)
+    acgt = np.frombuffer(b'ACGT', dtype=np.uint8)
+    names, genes = synth.make_genes(700, 0, seed=3)
+    def gene_like(n_nt):                                  # genes on both strands with short spacers: long ORFs in every frame now and then
+        parts, total = [], 0
+        while total < n_nt:
+            g = np.frombuffer(genes[int(rng.integers(0, len(genes)))], dtype=np.uint8)
+            if rng.random() < 0.5:
+                g = np.array([84, 0, 71, 0, 0, 0, 67, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 65], dtype=np.uint8)[g[::-1] - 65]       # reverse complement of ACGT
+            sp = rng.choice(acgt, size=int(rng.integers(20, 200)))
+            parts += [g, sp]
+            total += len(g) + len(sp)
+        return np.concatenate(parts)[:n_nt].tobytes()
+    K = 49152 * 3
+    no_stop = bytes(rng.choice(acgt, size=3 * 60000)).replace(b'TAA', b'TCA').replace(b'TAG', b'TCG').replace(b'TGA', b'TCA')      # (stop-free in frame 1 only where no codon boundary was joined: good enough)
+    seqs = [bytes(rng.choice(acgt, size=n)) for n in (2 * K - 5, 2 * K, 2 * K + 1, 2 * K + 2, 2 * K + 3, 2 * K + 7, 3 * K + 11, 5 * K - 1)]
+    seqs += [gene_like(n) for n in (2 * K + 100, 700001, 1234567)]
+    seqs += [gene_like(400000) + no_stop + gene_like(250000), bytes(rng.choice(acgt, size=350000)) + b'N' * 5000 + bytes(rng.choice(acgt, size=300000))]
+    seqs += [genes[0], genes[1], gene_like(90000)]        # short ones beside them (the plain walk)
+    for frames in (6, 3):
+        ctx.set_ref_nt(seqs, frames, 11)
+        ctx.set_query_nt(genes[:3], 11)
+        ctx.translate(force=True)
+        ta, to = ctx.target_aa()
+        tm = ctx.target_meta()
+        exp = []
+        for n, sq in enumerate(seqs):
+            for f, aa_ in zip(range(1, frames + 1), O.translate_frames(sq.decode(), range(1, frames + 1), 11)):
+                exp += [(n, f, o, len(c)) for o, c in O.ref_chunks(aa_)]
+        got = [(int(m['seq']), int(m['frame']), int(m['chunk_off']), int(to[i + 1]) - int(to[i])) for i, m in enumerate(tm)]
+        assert len(got) == len(exp) and got == exp, frames
+        # the residues of a sample of chunks
+        pick = rng.choice(len(got), size=200, replace=False)
+        frames_aa = {}
+        for i in pick.tolist():
+            n, f, o, ln = got[i]
+            if (n, f) not in frames_aa:
+                frames_aa[(n, f)] = O.translate_frames(seqs[n].decode(), [f], 11)[0].replace('-', 'X')
+            assert ''.join(chr(65 + c) for c in ta[int(to[i]):int(to[i + 1])]) == frames_aa[(n, f)][o:o + ln], (frames, i)
+    assert max(len(s) for s in seqs) > 1200000 and sum(1 for n, f, o, ln in got if ln > 5000) >= 1
+
+
 def test_search_from_nucleotides_1k(ctx):
     """BASELINE config 1k synthetic 1 kb genes, all-vs-all, from nucleotides: K1..K8 against the oracle"""
     from peppan_amd import _native as N, synth
