@@ -119,10 +119,10 @@ struct pep_ctx {
     std::vector<uint64_t> k1_base;
     uint64_t k1_upper = 0;
     int k1_base_frames = 0;            // 0 = not computed for the current reference set
-    // ... and the segments of its LONG frames (contigs of genomes: k1_ref_chunks_spec / k1_ref_chunks_join): per segment (frame w, segment number), per long frame
-    // (w, first segment); the speculative chunk starts of every segment
-    DevBuf d_k1_seg, d_k1_long, d_k1_spec;
-    uint32_t k1_n_seg = 0, k1_n_long = 0;
+    // ... and the tables of its LONG frames (contigs of genomes: k1_stop_mask / k1_ref_chunks_mask / k1_ref_desc_fill): tiles of the stop mask, the long frames'
+    // records (+ frame -> record), the stop mask itself, tiles of chunk slots
+    DevBuf d_k1_seg, d_k1_long, d_k1_spec, d_k1_tiles;
+    uint32_t k1_n_seg = 0, k1_n_long = 0, k1_n_tiles = 0;
     // what pep_use_nt_as_residues makes of the nucleotide sets apart from the residues themselves (translate.hip: pep_nucl_sets), kept per pair of uploads
     struct NuclSide {
         uint32_t n = 0, max_len = 0;

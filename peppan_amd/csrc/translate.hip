@@ -193,45 +193,75 @@ __device__ __forceinline__ int64_t chunk_end(const uint8_t *s, int64_t L, int f,
     }
 }
 
-// A chunk's start follows from the chunk in front of it: one wavefront walking a 7.7 Mb contig's frame takes 2 500 dependent round trips to memory (4 ms per search of a
-// mapping batch at 50 000 exemplars: a third of the batch's GPU time, whatever the number of contigs).  Chains that start at different places MERGE, though - two chunks
-// whose starts + 1000 fall between the same two stops end with the same stop, and from there on the chains are one.  Frames of more than 2 x K1_SEG characters are
-// therefore cut into segments of K1_SEG characters: k1_ref_chunks_spec walks every segment from its first character as if a chunk started there (all segments of all
-// frames side by side) and keeps the starts it finds; k1_ref_chunks_join then walks the TRUE chain of a frame segment by segment, and as soon as a true start is one the
-// segment's speculative walk has found - after one to three chunks, as a rule - takes the rest of the segment from that list.
-constexpr int64_t K1_SEG = 49152;             // (a 2.6 M-character frame of a 7.7 Mb contig: 53 segments; the join walks one to three chunks per segment before it meets the speculative list)
-constexpr int K1_SPEC_CAP = 56;                  // starts per segment: at most K1_SEG / 1001 + 1 = 50 - one per lane of the joining wavefront
-static_assert(K1_SEG / 1001 + 2 <= K1_SPEC_CAP && K1_SPEC_CAP <= 64, "a segment's starts: one per lane");
-struct K1Seg { uint32_t w, seg; };
-struct K1Long { uint32_t w, first_seg, n_seg, pad; };
+// A chunk's start follows from the chunk in front of it: one wavefront walking a 7.7 Mb contig's frame this way takes 2 500 dependent round trips to memory - 4 ms per
+// search of a mapping batch at 50 000 exemplars, a third of the batch's GPU time, whatever the number of contigs.  (Chains that start at different places do merge - two
+// chunks whose starts + 1000 fall between the same two stops end with the same stop - and a first version walked segments speculatively and joined them to the true chain:
+// in frames with a stop every ~21 characters two chains keep their distance for tens of chunks, the join did 40 % of the serial work again: 1.65 ms.)  So the chain stays
+// serial, and what a step costs is taken out of it.  Frames of more than K1_LONG characters:
+//   k1_stop_mask    every character of the frame + 'X' as one bit "is a stop" (64 per word, a wavefront per 4 096 characters, all frames side by side);
+//   k1_ref_chunks_mask   one wavefront per frame keeps a WINDOW of the mask in registers - 256 words, 16 384 characters, four words per lane - and the next window on
+//                   its way; "the first stop at or behind c0 + 1000" is a mask, a ballot and a count of trailing zeros: no memory in a step, sixteen steps per window.
+constexpr int64_t K1_LONG = 98304;               // characters of a frame (+ 'X') from which its chunks are found through the stop mask
+struct K1Seg { uint32_t w, seg; };               // (frame, tile of 4 096 characters / of 256 chunk slots)
+constexpr uint32_t K1_FILL_FROM = 128;           // frames with this many chunks or more get their descriptors from k1_ref_desc_fill.  Only the long frames have tiles: a frame with 128 chunks holds more than 128 x 1001 characters
+static_assert((int64_t)K1_FILL_FROM * 1001 > K1_LONG, "a frame that leaves its descriptors to k1_ref_desc_fill is a long one");
+struct K1Long { uint32_t w, pad; uint64_t mask_off; };          // a long frame: its words of the stop mask start at mask_off
 
-__global__ __launch_bounds__(256) void k1_ref_chunks_spec(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ off, int n_frames, int tab, const K1Seg *__restrict__ segs,
-                                                          uint32_t n_seg, uint32_t *__restrict__ spec)
+// "character aa of the frame is a stop" as the chunking sees it (translate_at(...) == 23 and no gap in the codon: a stop codon, or an ambiguous / partial one) without the
+// dependent look-up in the codon table: stop_codons = bit idx set for the codons the table turns into 'X' (a ballot over the table's 64 entries)
+__device__ __forceinline__ bool stop_at(const uint8_t *__restrict__ nt, int L, int frame, int aa, unsigned long long stop_codons)
+{
+    int b[3];
+    const int p0 = (frame <= 3 ? frame - 1 : frame - 4) + 3 * aa;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int p = p0 + k;
+        int v = -1;
+        if (p < L) {
+            if (frame <= 3) v = base2(nt[p]);
+            else { v = base2(nt[L - 1 - p]); if (v >= 0) v = 3 - v; }
+        }
+        b[k] = v;
+    }
+    if ((b[0] == -2) | (b[1] == -2) | (b[2] == -2)) return false;
+    if ((b[0] | b[1] | b[2]) < 0) return true;
+    return (stop_codons >> ((b[0] << 4) | (b[1] << 2) | b[2])) & 1ull;
+}
+
+__global__ __launch_bounds__(256) void k1_stop_mask(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ off, int n_frames, int tab, const K1Seg *__restrict__ tiles,
+                                                    uint32_t n_tiles, const K1Long *__restrict__ longs, const uint32_t *__restrict__ long_of_w, unsigned long long *__restrict__ mask)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t x = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (x >= n_seg) return;
-    const K1Seg sg = segs[x];
-    const uint32_t g = sg.w / (uint32_t)n_frames;
-    const int f = (int)(sg.w % (uint32_t)n_frames) + 1;
+    if (x >= n_tiles) return;
+    const K1Seg tl = tiles[x];
+    const uint32_t g = tl.w / (uint32_t)n_frames;
+    const int f = (int)(tl.w % (uint32_t)n_frames) + 1;
     const uint8_t *s = nt + off[g];
     const int64_t L = (int64_t)(off[g + 1] - off[g]);
     const int64_t na = frame_len(L, f);
-    const int64_t lo = (int64_t)sg.seg * K1_SEG, hi = lo + K1_SEG;
-    uint32_t *out = spec + (size_t)x * (K1_SPEC_CAP + 2);         // [0] = number of starts, [1] = the first start behind the segment, [2 ..] the starts
-    uint32_t cnt = 0;
-    int64_t c0 = lo;
-    while (c0 < hi && c0 < na + 1) {
-        if (lane == 0 && cnt < (uint32_t)K1_SPEC_CAP) out[2 + cnt] = (uint32_t)c0;
-        ++cnt;
-        c0 = chunk_end(s, L, f, tab, na, c0, lane) + 1;
+    unsigned long long *out = mask + longs[long_of_w[tl.w]].mask_off;
+    const int64_t n_words = (na + 1 + 63) >> 6;
+    const unsigned long long stop_codons = __ballot(c_codon[tab][lane] == 23);
+    // four words per trip: their twelve byte reads per lane are in flight together (one word per trip was a round trip to memory per 64 characters)
+    for (int64_t wd = (int64_t)tl.seg * 64; wd < (int64_t)(tl.seg + 1) * 64 && wd < n_words; wd += 4) {
+        bool isx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t a = (wd + u) * 64 + lane;
+            isx[u] = a < na ? stop_at(s, (int)L, f, (int)a, stop_codons) : a == na;      // (a == na: the 'X' the reference appends)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned long long m = __ballot(isx[u]);
+            if (lane == 0 && wd + u < n_words) out[wd + u] = m;
+        }
     }
-    if (lane == 0) { out[0] = min(cnt, (uint32_t)K1_SPEC_CAP); out[1] = (uint32_t)c0; }
 }
 
-// one wavefront per LONG frame: its true chain from the segments' speculative starts; chunk_off / chunk_len / chunk_cnt as k1_ref_chunks writes them
-__global__ __launch_bounds__(256) void k1_ref_chunks_join(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ off, int n_frames, int tab, const K1Long *__restrict__ longs,
-                                                          uint32_t n_long, const uint32_t *__restrict__ spec, const uint64_t *__restrict__ chunk_base,
+// one wavefront per LONG frame; chunk_off / chunk_len / chunk_cnt as k1_ref_chunks writes them
+__global__ __launch_bounds__(256) void k1_ref_chunks_mask(const uint64_t *__restrict__ off, int n_frames, const K1Long *__restrict__ longs, uint32_t n_long,
+                                                          const unsigned long long *__restrict__ mask, const uint64_t *__restrict__ chunk_base,
                                                           uint32_t *__restrict__ chunk_cnt, uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ chunk_len)
 {
     const int lane = threadIdx.x & 63;
@@ -240,34 +270,61 @@ __global__ __launch_bounds__(256) void k1_ref_chunks_join(const uint8_t *__restr
     const K1Long lg = longs[x];
     const uint32_t g = lg.w / (uint32_t)n_frames;
     const int f = (int)(lg.w % (uint32_t)n_frames) + 1;
-    const uint8_t *s = nt + off[g];
     const int64_t L = (int64_t)(off[g + 1] - off[g]);
     const int64_t na = frame_len(L, f);
+    const int64_t n_words = (na + 1 + 63) >> 6;
+    const unsigned long long *mk = mask + lg.mask_off;
     uint32_t *starts = chunk_off + chunk_base[lg.w];               // the chunk starts in order (their lengths are taken from them at the end)
+    // the window: ROWS rows of 64 words, word (win + 64 r + lane) in cur[r]; positions are 32-bit (a sequence stays below 2^31 nucleotides).  A step looks at ONE row as a
+    // rule - a single wavefront issues its instructions one behind the other: with all four rows judged in every step a step took 0.54 us, the walk 1.35 ms
+    constexpr int ROWS = 4, WIN = 64 * ROWS;
+    const int n_w = (int)n_words, n_a = (int)na;
+    // (the reads of a window are unconditional - the index clamped, words behind the mask's end zeroed when the window is TAKEN: a read under a lane condition is a branch, and
+    // the compiler waits for every read in flight where branches meet - the window that should have been on its way for sixteen steps was waited for on the spot)
+    auto load = [&](int base, unsigned long long *dst) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) dst[r] = mk[min(base + 64 * r + lane, n_w - 1)];
+    };
+    auto take = [&](int base, const unsigned long long *src, unsigned long long *dst) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) dst[r] = base + 64 * r + lane < n_w ? src[r] : 0ull;
+    };
+    unsigned long long cur[ROWS], nxt[ROWS];
+    int win = 0;
+    load(0, nxt);
+    take(0, nxt, cur);
+    load(WIN, nxt);
     uint32_t cnt = 0;
-    int64_t t = 0;                                                  // the next true start
-    for (uint32_t k = 0; k < lg.n_seg && t < na + 1; ++k) {
-        const int64_t hi = (int64_t)(k + 1) * K1_SEG;
-        if (t >= hi) continue;                                      // (a chunk that spans the whole segment)
-        const uint32_t *sp = spec + (size_t)(lg.first_seg + k) * (K1_SPEC_CAP + 2);
-        const uint32_t m = sp[0];
-        const uint32_t mine = lane < (int)m ? sp[2 + lane] : 0xFFFFFFFFu;      // (m <= K1_SPEC_CAP <= 64: one start per lane)
-        while (t < hi && t < na + 1) {
-            const unsigned long long at = __ballot(mine == (uint32_t)t);
-            if (at) {
-                // the speculative walk of this segment came through here: the rest of the segment is its list
-                const int i = __ffsll((long long)at) - 1;
-                if (lane >= i && lane < (int)m) starts[cnt + (uint32_t)(lane - i)] = mine;
-                cnt += m - (uint32_t)i;
-                t = (int64_t)sp[1];
-                break;
+    int c0 = 0;
+    while (c0 < n_a + 1) {
+        if (lane == 0) starts[cnt] = (uint32_t)c0;
+        ++cnt;
+        int end = n_a;
+        if (n_a + 1 - c0 >= 1001) {
+            int p = c0 + 1000;                                      // the first stop at or behind p (bit na is set: there is one)
+            for (;;) {
+                int wi = p >> 6;
+                if (wi >= win + 2 * WIN) { win = wi; load(win, nxt); take(win, nxt, cur); load(win + WIN, nxt); }     // (a chunk longer than a window: start over where it ends)
+                else if (wi >= win + WIN) {
+                    win += WIN;
+                    take(win, nxt, cur);
+                    load(win + WIN, nxt);                           // on its way while the next sixteen chunks are cut from cur
+                }
+                const int r0 = (wi - win) >> 6, j = (wi - win) & 63; // row and lane of the word that holds p
+                unsigned long long v = r0 == 0 ? cur[0] : r0 == 1 ? cur[1] : r0 == 2 ? cur[2] : cur[3];
+                v = lane > j ? v : (lane == j ? v & (~0ull << (p & 63)) : 0ull);
+                const unsigned long long any = __ballot(v != 0ull);
+                if (any) {
+                    const int l = __ffsll((long long)any) - 1;
+                    const unsigned long long word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+                    end = ((win + 64 * r0 + l) << 6) + (int)__builtin_ctzll(word);
+                    break;
+                }
+                p = (win + 64 * (r0 + 1)) << 6;                     // no stop in the rest of this row: on with the next row (or window)
             }
-            if (lane == 0) starts[cnt] = (uint32_t)t;
-            ++cnt;
-            t = chunk_end(s, L, f, tab, na, t, lane) + 1;
         }
+        c0 = end + 1;
     }
-    // (a frame whose segments are used up before its end cannot occur: the segments cover [0, na + 1))
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -275,9 +332,8 @@ __global__ __launch_bounds__(256) void k1_ref_chunks_join(const uint8_t *__restr
     uint32_t *lens = chunk_len + chunk_base[lg.w];
     uint32_t kept = cnt;
     for (uint32_t i = (uint32_t)lane; i < cnt; i += 64) {
-        const uint32_t c0 = __builtin_nontemporal_load(&starts[i]);
-        const uint32_t len = i + 1 < cnt ? __builtin_nontemporal_load(&starts[i + 1]) - c0 : (uint32_t)(na - (int64_t)c0);
-        lens[i] = len;
+        const uint32_t s0 = __builtin_nontemporal_load(&starts[i]);
+        lens[i] = i + 1 < cnt ? __builtin_nontemporal_load(&starts[i + 1]) - s0 : (uint32_t)(na - (int64_t)s0);
     }
     if (cnt && (int64_t)__builtin_nontemporal_load(&starts[cnt - 1]) >= na) kept = cnt - 1;
     if (lane == 0) chunk_cnt[lg.w] = kept;
@@ -286,7 +342,7 @@ __global__ __launch_bounds__(256) void k1_ref_chunks_join(const uint8_t *__restr
 // one wavefront per (reference sequence, frame): chunk boundaries.  chunk_base[w] = first slot of this frame's chunk list.
 __global__ __launch_bounds__(256) void k1_ref_chunks(const uint8_t *__restrict__ nt, const uint64_t *__restrict__ off, uint32_t n, int n_frames, int tab,
                                                      const uint64_t *__restrict__ chunk_base, uint32_t *__restrict__ chunk_cnt,
-                                                     uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ chunk_len)
+                                                     uint32_t *__restrict__ chunk_off, uint32_t *__restrict__ chunk_len, int64_t long_from)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -296,7 +352,7 @@ __global__ __launch_bounds__(256) void k1_ref_chunks(const uint8_t *__restrict__
     const uint8_t *s = nt + off[g];
     const int64_t L = (int64_t)(off[g + 1] - off[g]);
     const int64_t na = frame_len(L, f);         // the frame string; the reference appends one more 'X' at index na
-    if (na + 1 > 2 * K1_SEG) return;            // a long frame: k1_ref_chunks_spec / k1_ref_chunks_join
+    if (na + 1 > long_from) return;             // a long frame: k1_stop_mask / k1_ref_chunks_mask
     const uint64_t base = chunk_base[w];
     uint32_t cnt = 0;
     int64_t c0 = 0;
@@ -511,7 +567,7 @@ __global__ __launch_bounds__(256) void k1_ref_desc(uint64_t nw, int n_frames, co
                                                    const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_len,
                                                    PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out, K1Summary *__restrict__ sum,
                                                    uint32_t *__restrict__ n_targets, K1Scan sc, const uint64_t *__restrict__ nt_off, K1Src *__restrict__ src_of,
-                                                   uint32_t *__restrict__ first_t)
+                                                   uint32_t *__restrict__ first_t, uint32_t *__restrict__ first_w, uint32_t fill_from)
 {
     __shared__ uint32_t s_tile, lds[4];
     __shared__ uint64_t s_pre;
@@ -534,12 +590,32 @@ __global__ __launch_bounds__(256) void k1_ref_desc(uint64_t nw, int n_frames, co
     if (f == 1u) first_t[g] = cnt ? at : PEP_SELF_NONE;          // the packed sequence frame 1 of reference sequence g starts with (seeds.hip: self_prepare)
     const uint64_t o = nt_off[g];
     const K1Src so{o, (uint32_t)(nt_off[g + 1] - o), 0u};
+    first_w[w] = at;
+    if (cnt >= fill_from) return;            // a contig's frame - thousands of chunks: its records are written by k1_ref_desc_fill, a thread per chunk (one thread walking them here was 1.1 ms of a mapping batch's K1)
     for (uint32_t c = 0; c < cnt; ++c) {
         desc[at + c] = PackDesc{g, f, chunk_off[base + c], chunk_len[base + c]};
         src_of[at + c] = so;
         padded[at + c] = padded_len(chunk_len[base + c]);
         len_out[at + c] = chunk_len[base + c];
     }
+}
+
+// the descriptor, source record and lengths of every chunk of the LONG frames (k1_ref_desc left them out): tile x of 256 chunk slots of frame tiles[x].w
+__global__ __launch_bounds__(256) void k1_ref_desc_fill(const K1Seg *__restrict__ tiles, int n_frames, const uint64_t *__restrict__ chunk_base, const uint32_t *__restrict__ chunk_cnt,
+                                                        const uint32_t *__restrict__ chunk_off, const uint32_t *__restrict__ chunk_len, const uint32_t *__restrict__ first_w,
+                                                        uint32_t fill_from, PackDesc *__restrict__ desc, uint32_t *__restrict__ padded, uint32_t *__restrict__ len_out,
+                                                        const uint64_t *__restrict__ nt_off, K1Src *__restrict__ src_of)
+{
+    const K1Seg tl = tiles[blockIdx.x];
+    const uint32_t w = tl.w, c = tl.seg * 256u + threadIdx.x, cnt = chunk_cnt[w];
+    if (cnt < fill_from || c >= cnt) return;
+    const uint32_t g = w / (uint32_t)n_frames, f = w % (uint32_t)n_frames + 1u;
+    const uint64_t base = chunk_base[w], o = nt_off[g];
+    const uint32_t at = first_w[w] + c, len = chunk_len[base + c];
+    desc[at] = PackDesc{g, f, chunk_off[base + c], len};
+    src_of[at] = K1Src{o, (uint32_t)(nt_off[g + 1] - o), 0u};
+    padded[at] = padded_len(len);
+    len_out[at] = len;
 }
 
 // pk_off[i] = start of packed sequence i = END_PAD + exclusive scan of the padded lengths (taken inside this kernel by look-back; slots behind
@@ -744,29 +820,42 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
         ctx->k1_upper = upper;
         PEP_TRY(dev_reserve(ctx, ctx->d_k1_base, (nw + 1) * 8));
         PEP_HIP(ctx, hipMemcpy(ctx->d_k1_base.p, base.data(), (nw + 1) * 8, hipMemcpyHostToDevice));
-        // the segments of the long frames (k1_ref_chunks_spec / _join): a function of the lengths as well
-        std::vector<K1Seg> segs;
+        // the long frames' tables (k1_stop_mask / k1_ref_chunks_mask / k1_ref_desc_fill): a function of the lengths as well (PEPPAN_K1_PLAIN_CHUNKS=1: every frame by
+        // the one-wavefront walk over the nucleotides, for comparison)
+        static const bool plain_chunks = [] { const char *e = getenv("PEPPAN_K1_PLAIN_CHUNKS"); return e && atoi(e) != 0; }();
+        std::vector<K1Seg> segs, tiles;                 // tiles of 4 096 characters of the stop mask / of 256 chunk slots
         std::vector<K1Long> longs;
+        std::vector<uint32_t> long_of_w;
+        uint64_t mask_words = 0;
         for (uint32_t g = 0; g < n; ++g) {
             const uint64_t L = nt.h_off[g + 1] - nt.h_off[g];
             for (int f = 1; f <= nf; ++f) {
                 const uint64_t shift = (uint64_t)(f <= 3 ? f - 1 : f - 4);
                 const uint64_t na = L > shift ? (L - shift + 2) / 3 : 0;
-                if (na + 1 <= 2 * (uint64_t)K1_SEG) continue;
-                const uint32_t w = g * (uint32_t)nf + (uint32_t)(f - 1), n_seg = (uint32_t)((na + 1 + K1_SEG - 1) / K1_SEG);
-                longs.push_back(K1Long{w, (uint32_t)segs.size(), n_seg, 0u});
-                for (uint32_t k = 0; k < n_seg; ++k) segs.push_back(K1Seg{w, k});
+                if (na + 1 <= (uint64_t)K1_LONG || plain_chunks) continue;
+                const uint32_t w = g * (uint32_t)nf + (uint32_t)(f - 1);
+                if (long_of_w.empty()) long_of_w.assign(nw, 0u);
+                long_of_w[w] = (uint32_t)longs.size();
+                longs.push_back(K1Long{w, 0u, mask_words});
+                const uint64_t n_words = (na + 1 + 63) / 64;
+                mask_words += n_words;
+                for (uint32_t k = 0, nt_ = (uint32_t)((n_words + 63) / 64); k < nt_; ++k) segs.push_back(K1Seg{w, k});
+                for (uint32_t k = 0, n_tiles = (uint32_t)(((na + 1) / 1001 + 1 + 255) / 256); k < n_tiles; ++k) tiles.push_back(K1Seg{w, k});
             }
         }
         ctx->k1_n_seg = (uint32_t)segs.size();
         ctx->k1_n_long = (uint32_t)longs.size();
         if (!segs.empty()) {
             PEP_TRY(dev_reserve(ctx, ctx->d_k1_seg, segs.size() * sizeof(K1Seg)));
-            PEP_TRY(dev_reserve(ctx, ctx->d_k1_long, longs.size() * sizeof(K1Long)));
-            PEP_TRY(dev_reserve(ctx, ctx->d_k1_spec, segs.size() * (size_t)(K1_SPEC_CAP + 2) * 4));
+            PEP_TRY(dev_reserve(ctx, ctx->d_k1_long, longs.size() * sizeof(K1Long) + (size_t)nw * 4));       // (the frame -> long frame table behind the records)
+            PEP_TRY(dev_reserve(ctx, ctx->d_k1_spec, (mask_words + 1) * 8));
             PEP_HIP(ctx, hipMemcpy(ctx->d_k1_seg.p, segs.data(), segs.size() * sizeof(K1Seg), hipMemcpyHostToDevice));
             PEP_HIP(ctx, hipMemcpy(ctx->d_k1_long.p, longs.data(), longs.size() * sizeof(K1Long), hipMemcpyHostToDevice));
+            PEP_HIP(ctx, hipMemcpy(ctx->d_k1_long.as<char>() + longs.size() * sizeof(K1Long), long_of_w.data(), (size_t)nw * 4, hipMemcpyHostToDevice));
+            PEP_TRY(dev_reserve(ctx, ctx->d_k1_tiles, tiles.size() * sizeof(K1Seg)));
+            PEP_HIP(ctx, hipMemcpy(ctx->d_k1_tiles.p, tiles.data(), tiles.size() * sizeof(K1Seg), hipMemcpyHostToDevice));
         }
+        ctx->k1_n_tiles = (uint32_t)tiles.size();
         ctx->k1_base_frames = nf;
     }
     const uint64_t slots = ctx->k1_base[nw], upper = ctx->k1_upper;
@@ -787,13 +876,15 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
     const uint64_t *d_base = ctx->d_k1_base.as<const uint64_t>();
     if (nw) {
         hipLaunchKernelGGL(k1_ref_chunks, dim3((unsigned)ceil_div(nw, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), n, nf, tab,
-                           d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>());
+                           d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>(), ctx->k1_n_long ? K1_LONG : INT64_MAX);
         if (ctx->k1_n_long) {
-            // the frames of contigs: speculative chunk starts per segment, all segments side by side, then the true chain per frame (see k1_ref_chunks_spec)
-            hipLaunchKernelGGL(k1_ref_chunks_spec, dim3((unsigned)ceil_div(ctx->k1_n_seg, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), nf, tab,
-                               ctx->d_k1_seg.as<const K1Seg>(), ctx->k1_n_seg, ctx->d_k1_spec.as<uint32_t>());
-            hipLaunchKernelGGL(k1_ref_chunks_join, dim3((unsigned)ceil_div(ctx->k1_n_long, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), nf, tab,
-                               ctx->d_k1_long.as<const K1Long>(), ctx->k1_n_long, ctx->d_k1_spec.as<const uint32_t>(), d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>());
+            // the frames of contigs: their stops as a bit mask (all frames side by side), then the chunk chain of every frame out of register windows of that mask
+            const K1Long *d_longs = ctx->d_k1_long.as<const K1Long>();
+            const uint32_t *d_long_of_w = reinterpret_cast<const uint32_t *>(ctx->d_k1_long.as<const char>() + (size_t)ctx->k1_n_long * sizeof(K1Long));
+            hipLaunchKernelGGL(k1_stop_mask, dim3((unsigned)ceil_div(ctx->k1_n_seg, 4)), dim3(256), 0, ctx->stream, nt.nt.as<const uint8_t>(), nt.off.as<const uint64_t>(), nf, tab,
+                               ctx->d_k1_seg.as<const K1Seg>(), ctx->k1_n_seg, d_longs, d_long_of_w, ctx->d_k1_spec.as<unsigned long long>());
+            hipLaunchKernelGGL(k1_ref_chunks_mask, dim3((unsigned)ceil_div(ctx->k1_n_long, 4)), dim3(256), 0, ctx->stream, nt.off.as<const uint64_t>(), nf, d_longs, ctx->k1_n_long,
+                               ctx->d_k1_spec.as<const unsigned long long>(), d_base, W[1].as<uint32_t>(), W[2].as<uint32_t>(), W[3].as<uint32_t>());
         }
         {
             K1Scan sc;
@@ -802,7 +893,12 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
             hipLaunchKernelGGL(k1_ref_desc, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, nw, nf, d_base, W[1].as<const uint32_t>(),
                                W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), D.as<PackDesc>(), W[6].as<uint32_t>(),
                                ctx->t.len.as<uint32_t>(), reinterpret_cast<K1Summary *>(D.as<PackDesc>() + slots), W[5].as<uint32_t>() + nw, sc,
-                               nt.off.as<const uint64_t>(), k1_src_of(D.as<const PackDesc>(), (uint32_t)slots), ctx->d_self_t.as<uint32_t>());         // W[5][nw] = number of targets
+                               nt.off.as<const uint64_t>(), k1_src_of(D.as<const PackDesc>(), (uint32_t)slots), ctx->d_self_t.as<uint32_t>(), W[5].as<uint32_t>(),
+                               ctx->k1_n_tiles ? K1_FILL_FROM : 0xFFFFFFFFu);         // W[5][nw] = number of targets, W[5][w] = the first packed sequence of frame w
+            if (ctx->k1_n_tiles)
+                hipLaunchKernelGGL(k1_ref_desc_fill, dim3(ctx->k1_n_tiles), dim3(256), 0, ctx->stream, ctx->d_k1_tiles.as<const K1Seg>(), nf, d_base, W[1].as<const uint32_t>(),
+                                   W[2].as<const uint32_t>(), W[3].as<const uint32_t>(), W[5].as<const uint32_t>(), K1_FILL_FROM, D.as<PackDesc>(), W[6].as<uint32_t>(),
+                                   ctx->t.len.as<uint32_t>(), nt.off.as<const uint64_t>(), k1_src_of(D.as<const PackDesc>(), (uint32_t)slots));
         }
         PEP_TRY(layout_and_pack(ctx, nt, tab, D.as<const PackDesc>(), W[6].as<const uint32_t>(), (uint32_t)slots, W[5].as<const uint32_t>() + nw, upper, ctx->t,
                                 W[7], W[8], pin_sum));

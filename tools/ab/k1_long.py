@@ -20,4 +20,4 @@ for _ in range(10):
     ts.append((time.perf_counter() - t0) * 1e3)
 tm = ctx.target_meta()
 print('%d contigs, %.1f Mnt: translate (K1, both sides) median %.2f ms, fastest %.2f ms; %d chunks, longest %d' % (
-    len(contigs), sum(map(len, contigs)) / 1e6, sorted(ts)[len(ts) // 2], min(ts), len(tm), int(tm['len'].max())))
+    len(contigs), sum(map(len, contigs)) / 1e6, sorted(ts)[len(ts) // 2], min(ts), len(tm), int(tm['aa_len'].max())))
