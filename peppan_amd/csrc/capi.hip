@@ -543,7 +543,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->fused_state[0].buf, &ctx->fused_state[1].buf, &ctx->fused_state[2].buf, &ctx->fused_state[3].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_trace_defer, &ctx->d_k1_base, &ctx->d_k1_seg, &ctx->d_k1_long, &ctx->d_k1_spec, &ctx->d_k1_tiles, &ctx->d_t_class, &ctx->d_t_subject, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq,
                       &ctx->sort_state, &ctx->sort_hist, &ctx->d_set, &ctx->d_zero, &ctx->d_k1_desc_q, &ctx->d_k1_desc_t, &ctx->d_self_delta, &ctx->d_self_t, &ctx->d_mail_copy,
-                      &ctx->nucl_q.d_off, &ctx->nucl_q.d_len, &ctx->nucl_q.d_desc, &ctx->nucl_t.d_off, &ctx->nucl_t.d_len, &ctx->nucl_t.d_desc};
+                      &ctx->nucl_q.d_off, &ctx->nucl_q.d_len, &ctx->nucl_q.d_desc, &ctx->nucl_t.d_off, &ctx->nucl_t.d_len, &ctx->nucl_t.d_desc, &ctx->nucl_t.d_first};
     for (DevBuf *b : bufs) dev_release(*b);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

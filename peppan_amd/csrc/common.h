@@ -84,6 +84,9 @@ struct pep_ctx {
     DevBuf d_self_delta, d_self_t;          // seed stage, self-search: per 32-byte block of the target layout the distance to the query that IS that target (pep_self_map, self_prepare);
                                             // per reference sequence the packed sequence its frame 1 starts with (K1: k1_ref_desc)
     uint32_t self_first_n = 0;              // entries of d_self_t (reference sequences of the last K1 of the reference side)
+    const uint32_t *self_first = nullptr;   // what pep_self_map found applicable to the current sets: d_self_t (K1's) or the nucleotide tool's nucl_t.d_first; its entries; may a target be longer than its query
+    uint32_t self_first_cnt = 0;
+    int self_exact_len = 0;
     hipEvent_t k1_event = nullptr;          // the point of the stream where the reference side's downloads have arrived
     hipEvent_t k1q_event = nullptr;         // ... and the query side's
     bool k1q_event_set = false;
@@ -131,6 +134,8 @@ struct pep_ctx {
         std::vector<pep_query_meta> q_meta;
         std::vector<pep_target_meta> t_meta;
         DevBuf d_off, d_len, d_desc;
+        DevBuf d_first;                     // targets: per reference sequence the packed sequence that is its forward strand (seeds.hip: self_prepare)
+        uint32_t n_first = 0;
     } nucl_q, nucl_t;
     bool nucl_valid = false;
     int nucl_strands = 0;

@@ -581,20 +581,24 @@ __global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
     const int x = threadIdx.x;
     // this thread's dwords of the NEXT tile are fetched while the current one is worked on
     uint32_t f0 = 0, f1 = 0;
+    int32_t sd_next = PEP_SELF_NO_DELTA;             // self-search: the distance word of this thread's probe position rides along (JoinArgs::self_delta)
     if (blockIdx.x < n_tiles) {
         const int64_t g0 = (int64_t)blockIdx.x * (NTILE / 4) - 1;
         f0 = nt_fetch(a.t_res, g0 + x, a.t_total);
         if (x < 8) f1 = nt_fetch(a.t_res, g0 + 256 + x, a.t_total);
+        if (a.self_delta) sd_next = a.self_delta[((uint64_t)blockIdx.x * NTILE + 4u * x) >> 5];
     }
     int turn = 0;
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, turn ^= 1) {
         uint32_t *w = win[turn];
         w[x] = f0;
         if (x < 8) w[256 + x] = f1;
+        const int32_t sd = sd_next;
         if (tile + gridDim.x < n_tiles) {
             const int64_t g0 = (int64_t)(tile + gridDim.x) * (NTILE / 4) - 1;
             f0 = nt_fetch(a.t_res, g0 + x, a.t_total);
             if (x < 8) f1 = nt_fetch(a.t_res, g0 + 256 + x, a.t_total);
+            if (a.self_delta) sd_next = a.self_delta[((tile + gridDim.x) * NTILE + 4u * x) >> 5];
         }
         __syncthreads();
         const uint32_t p = (uint32_t)(tile * NTILE) + 4u * x;            // the probe: packed target position, = 0 (mod NS)
@@ -621,6 +625,14 @@ __global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
                 const uint64_t ent = pair[k2];
                 if (e + k2 >= e1 || (ent >> POS_BITS) != key) continue;
                 const uint32_t qpos = (uint32_t)(ent & POS_MASK);
+                if ((int32_t)(p - qpos) == sd) {
+                    // a gene against itself on diagonal 0 (self_prepare: the target repeats the query base for base, with the same length, and has settled the candidate):
+                    // the bases next to the word are the same on both sides - or padding on both -, so the target's side alone says how many there are; counted, not emitted
+                    const uint32_t vl = tl & 0xFCFCFCFCu, vr = tr & 0xFCFCFCFCu;
+                    const int Ls = min(NS - 1, (int)(__clz((int)vl) >> 3)), Rs = vr ? min(NS - 1, (__ffs((int)vr) - 1) >> 3) : NS - 1;
+                    if (Ls >= NS - 1 - Rs) n_hit += (uint32_t)(Ls - (NS - 1 - Rs) + 1);
+                    continue;
+                }
                 uint32_t ql, qr;                                        // query bytes qpos - 4 .. qpos - 1 and qpos + 14 .. qpos + 17 (>= 16 bytes of padding around every sequence)
                 __builtin_memcpy(&ql, a.q_res + qpos - 4, 4);
                 __builtin_memcpy(&qr, a.q_res + qpos + NK, 4);
@@ -875,7 +887,7 @@ __global__ __launch_bounds__(256) void seed_runs_extend(JoinArgs a)
 //     passes - the first round, as a rule; an extension stops as soon as its right side alone has reached the threshold (it can only grow).  Hits of the same
 //     pair that the matcher does not drop (the last, partial block; other diagonals of the bin) take the usual way; inserting a key twice is harmless.
 __global__ __launch_bounds__(256) void self_prepare(SeedShapeSet shs, int n_shapes, JoinArgs a, const uint32_t *__restrict__ first_t, uint32_t n_first,
-                                                    const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len, int32_t *__restrict__ delta)
+                                                    const uint32_t *__restrict__ q_len, const uint32_t *__restrict__ t_len, int32_t *__restrict__ delta, int exact_len)
 {
     __shared__ int8_t sub[1024];
     reinterpret_cast<uint32_t *>(sub)[threadIdx.x] = reinterpret_cast<const uint32_t *>(a.sub)[threadIdx.x];
@@ -886,7 +898,7 @@ __global__ __launch_bounds__(256) void self_prepare(SeedShapeSet shs, int n_shap
     const uint32_t t = first_t[g];
     if (t >= a.nt) return;                                      // (PEP_SELF_NONE included)
     const uint32_t ql = q_len[g], tl = t_len[t];
-    if (ql == 0u || tl < ql) return;
+    if (ql == 0u || tl < ql || (exact_len && tl != ql)) return;
     const uint32_t qs = a.q_off[g], ts = a.t_off[t];             // (16-aligned starts: the 8-byte reads below are aligned)
     bool same = true;
     for (uint32_t x = (uint32_t)lane * 8u; x < ql && same; x += 512u) {
@@ -1192,16 +1204,16 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
             a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.stage1_min = P.stage1_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
             a.self_delta = nullptr;
-            if (s == 0 && !stride_lookup && P.ungapped_min > 0 && P.reserved[0] == 0) PEP_TRY(pep_self_map(ctx, &self_on));     // (reserved[0] = 10: the plain stream, for comparison)
+            if (s == 0 && P.ungapped_min > 0 && P.reserved[0] == 0) PEP_TRY(pep_self_map(ctx, &self_on));     // (reserved[0] = 10 / 8: the plain stream, for comparison)
             if (self_on) a.self_delta = ctx->d_self_delta.as<const int32_t>();
             unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(zero + PEP_ZERO_SHAPE) + 2 * s;      // per shape, cleared by the one fill
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
             if (self_on && s == 0) {
                 // which targets repeat a query, the blocks whose diagonal-0 self hits the matchers drop, and those genes' own candidates: one launch, all shapes
                 SeedShapeSet shs;
-                for (int y = 0; y < 4; ++y) shs.s[y] = make_shape(std::min(y, P.n_shapes - 1));
-                hipLaunchKernelGGL(self_prepare, dim3((unsigned)ceil_div(Q.n, 4)), dim3(256), 0, ctx->stream, shs, P.n_shapes, a, ctx->d_self_t.as<const uint32_t>(), ctx->self_first_n,
-                                   Q.len.as<const uint32_t>(), T.len.as<const uint32_t>(), ctx->d_self_delta.as<int32_t>());
+                for (int y = 0; y < 4; ++y) { shs.s[y] = make_shape(std::min(y, P.n_shapes - 1)); shs.s[y].weight = P.weight[std::min(y, P.n_shapes - 1)]; }      // (the seed itself, not the stride matcher's look-up word)
+                hipLaunchKernelGGL(self_prepare, dim3((unsigned)ceil_div(Q.n, 4)), dim3(256), 0, ctx->stream, shs, P.n_shapes, a, ctx->self_first, ctx->self_first_cnt,
+                                   Q.len.as<const uint32_t>(), T.len.as<const uint32_t>(), ctx->d_self_delta.as<int32_t>(), ctx->self_exact_len);
                 PEP_HIP(ctx, hipGetLastError());
             }
             pep_timer_begin(ctx, TM_MATCH0 + s);

@@ -919,13 +919,26 @@ int pep_k1_ref(pep_ctx *ctx, int frames, int gtable, int phase)
 // ---- self-search (round 6): PEPPAN's hot call searches a gene set against itself (-r CL -q CL, PEPPAN.py:229-230).  Frame 1 of reference gene g then IS protein
 // query g - the same residues at the same offsets - and 57 % of the raw seed hits of the 10 000-gene search are a gene against itself on diagonal 0
 // (DESIGN.md section 4.11).  K1 leaves d_self_t[g] = the packed sequence that frame 1 of reference sequence g starts with (k1_ref_desc); whether that target
-// really repeats query g is decided on the device from the packed residues (seeds.hip: self_prepare), nothing is assumed about the caller.  Here: is the map
-// applicable to the current sets at all, and the distance table cleared.
+// really repeats query g is decided on the device from the packed residues (seeds.hip: self_prepare), nothing is assumed about the caller.  The nucleotide tool's sets
+// (pep_use_nt_as_residues) have the forward strand of reference sequence g in that place (pep_nucl_sets).  Here: is the map applicable to the current sets at all, which table
+// it is, and the distance table cleared.
 int pep_self_map(pep_ctx *ctx, int *on)
 {
     *on = 0;
     const SeqSet &Q = ctx->q, &T = ctx->t;
-    if (!ctx->q_from_nt || !ctx->t_from_nt || ctx->resid_from_nucl || !ctx->d_self_t.p || Q.n == 0 || T.n == 0 || ctx->self_first_n == 0) return PEP_OK;
+    if (!ctx->q_from_nt || !ctx->t_from_nt || Q.n == 0 || T.n == 0) return PEP_OK;
+    if (ctx->resid_from_nucl) {
+        // the nucleotide tool's sets (pep_use_nt_as_residues): the forward strand of reference sequence g; it must have the query's length exactly - the matcher judges the
+        // bases next to a look-up word by the target's side alone where the hit is a gene against itself
+        if (!ctx->nucl_valid || !ctx->nucl_t.d_first.p || ctx->nucl_t.n_first == 0) return PEP_OK;
+        ctx->self_first = ctx->nucl_t.d_first.as<const uint32_t>(); ctx->self_first_cnt = ctx->nucl_t.n_first; ctx->self_exact_len = 1;
+    } else {
+        if (!ctx->d_self_t.p || ctx->self_first_n == 0) return PEP_OK;
+        ctx->self_first = ctx->d_self_t.as<const uint32_t>(); ctx->self_first_cnt = ctx->self_first_n; ctx->self_exact_len = 0;
+    }
+    // a self-search has as many queries as reference sequences; anything else - genes against the contigs of genomes, above all - is not worth the distance table's fill,
+    // self_prepare's launch and the matcher's extra word per tile (8 % of the nucleotide matcher's launch over a mapping batch)
+    if (ctx->self_first_cnt != Q.n) return PEP_OK;
     const size_t blocks = (size_t)(T.total / 32 + 16);                   // (the matcher reads the word of every position of its last 256-position tile)
     PEP_TRY(dev_reserve(ctx, ctx->d_self_delta, blocks * 4));
     PEP_HIP(ctx, hipMemsetAsync(ctx->d_self_delta.p, 0x80, blocks * 4, ctx->stream));            // PEP_SELF_NO_DELTA
@@ -1004,6 +1017,14 @@ int pep_nucl_sets(pep_ctx *ctx, int strands)
             a = b;
         }
         PEP_TRY(nucl_build(ctx, ctx->r_nt, to, PEP_MAX_TARGETS, ctx->t, ctx->nucl_t));
+        {
+            // per reference sequence its forward strand among the targets: where a self-search finds the target that repeats query g (seeds.hip: self_prepare)
+            std::vector<uint32_t> first(nr, PEP_SELF_NONE);
+            for (size_t i = 0; i < to.size(); ++i) if (!to[i].rev) first[to[i].seq] = (uint32_t)i;
+            PEP_TRY(dev_reserve(ctx, ctx->nucl_t.d_first, ((size_t)nr + 1) * 4));
+            if (nr) PEP_HIP(ctx, hipMemcpy(ctx->nucl_t.d_first.p, first.data(), (size_t)nr * 4, hipMemcpyHostToDevice));
+            ctx->nucl_t.n_first = nr;
+        }
         ctx->nucl_q.q_meta.resize(ctx->q_nt.n);
         for (uint32_t i = 0; i < ctx->q_nt.n; ++i) ctx->nucl_q.q_meta[i] = pep_query_meta{i, 1u, ctx->nucl_q.h_len[i], ctx->nucl_q.h_len[i]};
         ctx->nucl_t.t_meta.resize(to.size());

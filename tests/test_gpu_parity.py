@@ -483,6 +483,35 @@ def test_nucleotide_stride_lookup_equals_plain_matcher_and_oracle(ctx):
         oh, oc, ost = O.search(queries, targets, O.params_from(p), min_scores=ms)
         _cmp_hits(np.frombuffer(out[0][0], dtype=N.HIT_DTYPE), np.frombuffer(out[0][1], dtype=np.uint32), oh, oc)
         assert out[0][4] == ost['candidates'] and out[0][3] > 20000
+    # the tool's own layout from nucleotide sets (pep_use_nt_as_residues: forward strands, then reverse complements) - here the forward strand of reference gene g IS query g
+    # and the matcher counts but drops the gene's diagonal-0 hits against itself, judging the bases next to a look-up word by the target's side alone (self_prepare has settled
+    # the candidate): the same table, raw hit count and candidates as the plain matcher and the oracle; also with a reference that differs in a gene, a base, its order and size
+    names, seqs = synth.make_genes(260, 0, seed=77)
+    seqs = [bytes(x) for x in seqs]
+    seqs[5] = seqs[5][:200] + b'NNNN' + seqs[5][204:]
+    seqs[6] = seqs[7]
+    seqs[8] = b'ACGTACGTACGTACGTAC'
+    seqs[9] = b''
+    other = list(seqs); other[20] = seqs[21]
+    base = list(seqs); base[30] = seqs[30][:40] + (b'A' if seqs[30][40:41] != b'A' else b'C') + seqs[30][41:]
+    longer = list(seqs); longer[40] = seqs[40] + b'ACGTTGCA'
+    for ref in (seqs, other, base, longer, seqs[::-1], seqs[:-3], seqs + [seqs[0]]):
+        res = {}
+        for flag in (0, 8):
+            p = N.nucleotide_params(70., 25.)
+            p.reserved[0] = flag
+            ctx.set_query_nt(seqs, 11); ctx.set_ref_nt(ref, 6, 11); ctx.use_nt_as_residues(2)
+            gh, gc, st = ctx.search(p)
+            res[flag] = (gh.tobytes(), gc.tobytes(), st['target_seeds'], st['seed_hits'], st['candidates'], st['pairs'])
+        assert res[0] == res[8], (len(ref), res[0][2:], res[8][2:])
+    codes = [O.nt_codes(x.upper()) for x in seqs]
+    p = N.nucleotide_params(70., 25.)
+    ctx.set_query_nt(seqs, 11); ctx.set_ref_nt(seqs, 6, 11); ctx.use_nt_as_residues(2)
+    gh, gc, st = ctx.search(p)
+    ms = np.array([O.min_score(len(c), p.dbsize, p.max_evalue, p.ka_lambda, p.ka_k) for c in codes], dtype=np.int32)
+    oh, oc, ost = O.search(codes, codes + [rc[c[::-1]] for c in codes], O.params_from(p), min_scores=ms)
+    _cmp_hits(gh, gc, oh, oc)
+    assert st['candidates'] == ost['candidates'] and (gh['q'] == gh['t']).sum() >= 255
 
 
 def test_self_search_drops_diagonal_zero_self_hits_exactly(ctx):
