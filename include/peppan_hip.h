@@ -478,6 +478,11 @@ int pep_cols_order(uint64_t n, const int64_t *q_code, const int64_t *r_code, con
 /* dst[c][k] = src[c][idx[k]] for n_cols columns of 8-byte elements (n_src rows each): the rows `idx` of a whole table in one call */
 int pep_cols_gather(int32_t n_cols, const void *const *src, void *const *dst, const int64_t *idx, uint64_t n_idx, uint64_t n_src);
 
+/* Host threads: the passes above (pep_table_from_hits, pep_cols_fix_end, pep_cols_gather) split tables of 16 384 rows and more over up to `n` threads that
+ * live for the call (1 .. 16).  Default: the environment's PEPPAN_HOST_THREADS, else a quarter of the hardware threads, four at most; 0 returns to that.
+ * Returns the value in force before.  The results do not depend on it. */
+int pep_set_host_threads(int n);
+
 /* A raw DEFLATE stream (RFC 1951; what a zip member of method 8 holds) of `src` made of dynamic-Huffman blocks with literals only - entropy
  * coding without a match search, for the members of <prefix>.seq.npz (packed alleles: nothing to match).  Host C++, no context, any inflate
  * reads it.  Returns the stream's length; when it exceeds `cap` nothing usable was written (n + n / 64 + 512 always suffices).  Negative: PEP_ERR_ARG. */
@@ -488,6 +493,15 @@ int64_t pep_deflate_literals(const uint8_t *src, int64_t n, uint8_t *out, int64_
  * them at zlib's default level inside zipfile): about the size of zlib's level 1 at several times its rate.  Host C++, no context, any inflate reads
  * it.  Returns the stream's length; when it exceeds `cap` nothing usable was written (n + n / 8 + 1024 always suffices).  Negative: PEP_ERR_ARG. */
 int64_t pep_deflate_fast(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap);
+
+/* CRC-32 of the zip format (what zlib.crc32 returns) of src[0 .. n) continued from `crc` (0 to start): by carry-less multiplication where the CPU has the
+ * instruction (an order of magnitude above zlib's table walk), zlib's otherwise.  Every member MapBsn appends carries one (zipfile computes it inside
+ * ZipFile.writestr, PEPPAN.py:81-85 through numpy.savez). */
+uint32_t pep_crc32(const uint8_t *src, int64_t n, uint32_t crc);
+
+/* A store member ready for its archive in one call: the raw DEFLATE stream of `src` by coder 0 (pep_deflate_literals) or 1 (pep_deflate_fast) and, in *crc,
+ * the CRC-32 of `src`.  Returns the stream's length; beyond `cap` nothing usable was written.  Negative: PEP_ERR_ARG. */
+int64_t pep_pack_member(const uint8_t *src, int64_t n, int32_t coder, uint8_t *out, int64_t cap, uint32_t *crc);
 /* np.argsort(v.astype(object)) for float64 v without NaN (host, no context): the order numpy's generic index quicksort leaves an object column of
  * Python floats in, ties included - the order of equal scores in the reference's .tab store (PEPPAN.py:957-960 sorts an object array's score column).
  * PEP_ERR_LIMIT when the sort's depth limit is reached (numpy switches to heapsort there: the caller asks numpy itself). */

@@ -15,8 +15,8 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_query_count', 'pep_target_count', 'pep_get_query_meta', 'pep_get_target_meta', 'pep_get_query_aa',
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_known_order', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
-           'pep_similar_classify', 'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_fasta_records', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast', 'pep_argsort_object_order',
-           'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather']
+           'pep_similar_classify', 'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_fasta_records', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast', 'pep_crc32', 'pep_pack_member', 'pep_argsort_object_order',
+           'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather', 'pep_set_host_threads']
 
 
 class PepError(RuntimeError):
@@ -81,6 +81,10 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise PepError('libpeppan_hip.so is not built (run `python -c "import __graft_entry__ as g; g.build()"` '
                        'or `make -C peppan_amd/csrc`); there is no CPU fallback')
+    if 'PEPPAN_HOST_THREADS' not in os.environ:
+        # threads a pass of the host chain (csrc/hostchain.hip) may use on a large table: a quarter of the CPUs the container grants, four at most
+        from .configure import effective_cpus
+        os.environ['PEPPAN_HOST_THREADS'] = str(max(1, min(4, effective_cpus() // 4)))
     lib = C.CDLL(LIB_PATH)
     for name in EXPORTS:
         if not hasattr(lib, name):
@@ -366,6 +370,28 @@ def deflate_literals(data):
     return out[:n].tobytes()
 
 
+def crc32(data, crc=0):
+    """pep_crc32: zlib.crc32 of a bytes-like object, by carry-less multiplication where the CPU has it"""
+    lib = load_library()
+    lib.pep_crc32.restype = C.c_uint32
+    src = np.frombuffer(data, dtype=np.uint8)
+    return int(lib.pep_crc32(_ptr(src) if len(src) else None, C.c_int64(len(src)), C.c_uint32(crc)))
+
+
+def pack_member(data, coder):
+    """pep_pack_member: bytes -> (raw DEFLATE stream, crc32 of the bytes); coder 0 = literals only (deflate_literals), 1 = single-probe matcher (deflate_fast)"""
+    lib = load_library()
+    lib.pep_pack_member.restype = C.c_int64
+    src = np.frombuffer(data, dtype=np.uint8)
+    cap = len(src) + len(src) // 8 + 1024
+    out = np.empty(cap, dtype=np.uint8)
+    crc = C.c_uint32(0)
+    n = lib.pep_pack_member(_ptr(src) if len(src) else None, C.c_int64(len(src)), C.c_int32(coder), _ptr(out), C.c_int64(cap), C.byref(crc))
+    if n < 0 or n > cap:
+        raise PepError('pep_pack_member failed (%d)' % n)
+    return out[:n].tobytes(), int(crc.value)
+
+
 def deflate_fast(data):
     """pep_deflate_fast: bytes -> raw DEFLATE stream (zlib.decompress(x, -15) gives them back): single-probe matcher + dynamic Huffman blocks"""
     lib = load_library()
@@ -441,6 +467,11 @@ def cols_fix_end(cols, arena, se_lim, ee_lim):
     if rc_ < 0:
         raise IndexError('fix_end: a row without CIGAR runs cannot be extended (the reference fails on cigar[0] here, uberBlast.py:468), or runs outside the arena')
     return out[:int(cols['c_runs'].sum()) if n else 0]
+
+
+def set_host_threads(n):
+    """pep_set_host_threads: the most threads a pass of the host chain may use (0: the default again); returns the value before"""
+    return int(load_library().pep_set_host_threads(C.c_int(int(n))))
 
 
 def cols_order(q_code, r_code, score):

@@ -205,6 +205,7 @@ struct TabJob {
 
 }   // namespace
 extern "C" int64_t pep_deflate_fast(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap);
+extern "C" uint32_t pep_crc32(const uint8_t *src, int64_t n, uint32_t crc);
 namespace {
 
 void tab_members(TabJob *j)
@@ -227,7 +228,7 @@ void tab_members(TabJob *j)
             uint8_t *dst = npy.data() + 10 + hlen;
             for (int64_t i = 0; i < k; ++i) memcpy(dst + i * j->n_cols * 8, j->rows + j->order[j->off[m] + i] * j->n_cols, (size_t)j->n_cols * 8);
         } else memcpy(npy.data() + 10 + hlen, j->rows + j->off[m] * j->n_cols, (size_t)body);
-        const uint32_t crc = (uint32_t)crc32(0L, npy.data(), (uInt)npy.size());
+        const uint32_t crc = pep_crc32(npy.data(), (int64_t)npy.size(), 0u);
         const uint8_t *payload = npy.data();
         int64_t plen = (int64_t)npy.size();
         int method = 0;
@@ -307,10 +308,35 @@ struct BitSink {
         while (fill > 0) { if (n < cap) p[n] = (uint8_t)acc; ++n; acc >>= 8; fill -= 8; }
         fill = 0;
     }
+    // room for `bits` more bits written eight bytes at a time (the stores below run past the last bit by up to seven bytes)
+    bool roomy(int64_t bits) const { return n + ((fill + bits + 7) >> 3) + 16 <= cap; }
 };
 
-// code lengths (<= 15) of a Huffman code for the symbols with freq > 0 (at least two of them)
-void huffman_lengths(const uint32_t *freq_in, int n_sym, uint8_t *len)
+// The sink's hot loop when the room is known to suffice: whole bytes leave the 64-bit accumulator with ONE unaligned 8-byte store per group of codes
+// (<= 56 bits a group, <= 7 bits left behind), no bounds checked.  Opened on a BitSink, closed back into it.
+struct FastBits {
+    BitSink &s;
+    uint8_t *o;
+    uint64_t acc;
+    int fill;
+    explicit FastBits(BitSink &sink) : s(sink), o(sink.p + sink.n), acc(sink.acc), fill(sink.fill)
+    {
+        while (fill >= 8) { *o++ = (uint8_t)acc; acc >>= 8; fill -= 8; }
+    }
+    __attribute__((always_inline)) void put(uint64_t bits, int len)          // len <= 56
+    {
+        acc |= bits << fill;
+        fill += len;
+        memcpy(o, &acc, 8);
+        o += fill >> 3;
+        acc >>= fill & ~7;
+        fill &= 7;
+    }
+    void close() { s.n = o - s.p; s.acc = acc; s.fill = fill; }
+};
+
+// code lengths (<= limit <= 15) of a Huffman code for the symbols with freq > 0 (at least two of them)
+void huffman_lengths(const uint32_t *freq_in, int n_sym, uint8_t *len, int limit = 15)
 {
     uint32_t freq[288];
     for (int i = 0; i < n_sym; ++i) freq[i] = freq_in[i];
@@ -338,7 +364,7 @@ void huffman_lengths(const uint32_t *freq_in, int n_sym, uint8_t *len)
             depth[nodes[k].left] = depth[nodes[k].right] = depth[k] + 1;
             deepest = std::max(deepest, depth[k] + 1);
         }
-        if (deepest <= 15) {
+        if (deepest <= limit) {
             for (int i = 0; i < n_sym; ++i) len[i] = 0;
             for (int i = 0; i < n_leaf; ++i) len[order[i]] = (uint8_t)depth[i];
             return;
@@ -364,6 +390,66 @@ void canonical_codes(const uint8_t *len, int n_sym, uint16_t *code)
 
 }   // namespace
 
+// CRC-32 of the zip format (IEEE 802.3, reflected) by carry-less multiplication: four 128-bit lanes folded per 64 bytes, then 128 -> 64 -> 32 bits by Barrett
+// reduction - the published folding scheme for this polynomial (Gopal et al., "Fast CRC computation for generic polynomials using PCLMULQDQ").  zlib's table
+// walk does 1 - 2 GB/s; a store member is checksummed once where it is made, 2.9 MB per mapped genome.  Without the instruction: zlib's crc32.
+#include <immintrin.h>
+
+namespace {
+
+__attribute__((target("pclmul,sse4.1"))) inline __m128i crc_load(const uint8_t *p) { return _mm_loadu_si128(reinterpret_cast<const __m128i *>(p)); }
+__attribute__((target("pclmul,sse4.1"))) inline __m128i crc_fold(__m128i x, __m128i k, __m128i next)
+{
+    return _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x, k, 0x11), _mm_clmulepi64_si128(x, k, 0x00)), next);
+}
+
+__attribute__((target("pclmul,sse4.1"))) uint32_t crc32_clmul(const uint8_t *buf, int64_t len, uint32_t crc)        // len >= 64, a multiple of 16; crc: the running (inverted) register
+{
+    const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596ll, 0x0154442bd4ll), k3k4 = _mm_set_epi64x(0x00ccaa009ell, 0x01751997d0ll);
+    const __m128i k5 = _mm_set_epi64x(0, 0x0163cd6124ll), poly = _mm_set_epi64x(0x01f7011641ll, 0x01db710641ll);
+    __m128i x1 = _mm_xor_si128(crc_load(buf), _mm_cvtsi32_si128((int)crc)), x2 = crc_load(buf + 16), x3 = crc_load(buf + 32), x4 = crc_load(buf + 48);
+    buf += 64; len -= 64;
+    while (len >= 64) {
+        const __m128i a1 = _mm_clmulepi64_si128(x1, k1k2, 0x00), a2 = _mm_clmulepi64_si128(x2, k1k2, 0x00), a3 = _mm_clmulepi64_si128(x3, k1k2, 0x00), a4 = _mm_clmulepi64_si128(x4, k1k2, 0x00);
+        x1 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x1, k1k2, 0x11), a1), crc_load(buf));
+        x2 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x2, k1k2, 0x11), a2), crc_load(buf + 16));
+        x3 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x3, k1k2, 0x11), a3), crc_load(buf + 32));
+        x4 = _mm_xor_si128(_mm_xor_si128(_mm_clmulepi64_si128(x4, k1k2, 0x11), a4), crc_load(buf + 48));
+        buf += 64; len -= 64;
+    }
+    x1 = crc_fold(x1, k3k4, x2); x1 = crc_fold(x1, k3k4, x3); x1 = crc_fold(x1, k3k4, x4);
+    while (len >= 16) { x1 = crc_fold(x1, k3k4, crc_load(buf)); buf += 16; len -= 16; }
+    const __m128i low32 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x2 = _mm_clmulepi64_si128(x1, k3k4, 0x10);
+    x1 = _mm_xor_si128(_mm_srli_si128(x1, 8), x2);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_xor_si128(_mm_clmulepi64_si128(_mm_and_si128(x1, low32), k5, 0x00), x2);
+    x2 = _mm_clmulepi64_si128(_mm_and_si128(x1, low32), poly, 0x10);
+    x2 = _mm_clmulepi64_si128(_mm_and_si128(x2, low32), poly, 0x00);
+    return (uint32_t)_mm_extract_epi32(_mm_xor_si128(x1, x2), 1);
+}
+
+const bool g_have_clmul = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+
+}   // namespace
+
+// crc32(src[0 .. n)) continued from `crc` (0 to start): the value zlib.crc32 / the zip directory holds
+extern "C" uint32_t pep_crc32(const uint8_t *src, int64_t n, uint32_t crc)
+{
+    if (n <= 0 || !src) return crc;
+    if (g_have_clmul && n >= 64) {
+        const int64_t body = n & ~(int64_t)15;
+        crc = ~crc32_clmul(src, body, ~crc);
+        src += body; n -= body;
+    }
+    while (n > 0) {                                   // (zlib takes a 32-bit length)
+        const int64_t m = std::min<int64_t>(n, (int64_t)1 << 30);
+        crc = (uint32_t)crc32((uLong)crc, src, (uInt)m);
+        src += m; n -= m;
+    }
+    return crc;
+}
+
 extern "C" int64_t pep_deflate_literals(const uint8_t *src, int64_t n, uint8_t *out, int64_t cap)
 {
     if (n < 0 || (n > 0 && !src) || (cap > 0 && !out)) return PEP_ERR_ARG;
@@ -373,30 +459,38 @@ extern "C" int64_t pep_deflate_literals(const uint8_t *src, int64_t n, uint8_t *
     static const uint8_t cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     for (int64_t at = 0; at < n; at += BLOCK) {
         const int64_t m = std::min(BLOCK, n - at);
-        uint32_t freq[257] = {0};
-        for (int64_t i = 0; i < m; ++i) ++freq[src[at + i]];
+        const uint8_t *p = src + at;
+        uint32_t freq[257] = {0}, f1[256] = {0}, f2[256] = {0}, f3[256] = {0};            // four counters side by side: a run of one byte value does not wait for its own last store
+        int64_t i = 0;
+        for (; i + 4 <= m; i += 4) { ++freq[p[i]]; ++f1[p[i + 1]]; ++f2[p[i + 2]]; ++f3[p[i + 3]]; }
+        for (; i < m; ++i) ++freq[p[i]];
+        for (int k = 0; k < 256; ++k) freq[k] += f1[k] + f2[k] + f3[k];
         freq[256] = 1;                                                                   // the end mark
         uint8_t len[257];
         uint16_t code[257];
-        huffman_lengths(freq, 257, len);
+        huffman_lengths(freq, 257, len, 14);                                             // (14 bits at most: four codes per store of the loop below; the 15th bit is worth nothing on a 256-letter alphabet)
         canonical_codes(len, 257, code);
         s.put(at + m >= n ? 1u : 0u, 1);                                                 // BFINAL
         s.put(2, 2);                                                                     // BTYPE = dynamic Huffman
         s.put(0, 5); s.put(1, 5); s.put(15, 4);                                          // 257 literal/length codes, 2 distance codes, all 19 code-length codes listed
         for (int k = 0; k < 19; ++k) s.put(cl_order[k] >= 16 ? 0u : 4u, 3);              // lengths 0..15 cost four bits each (the complete 4-bit code), no repeat codes
         auto put_len = [&](int v) { uint32_t r = 0; for (int b = 0; b < 4; ++b) r = (r << 1) | ((v >> b) & 1); s.put(r, 4); };      // code of length symbol v = v itself, bit-reversed
-        for (int i = 0; i < 257; ++i) put_len(len[i]);
+        for (int k = 0; k < 257; ++k) put_len(len[k]);
         put_len(1); put_len(1);                                                          // two distance codes of one bit: a complete code that the data never uses
-        uint32_t packed[256];
-        for (int i = 0; i < 256; ++i) packed[i] = (uint32_t)code[i] | ((uint32_t)len[i] << 16);
-        const uint8_t *p = src + at;
-        int64_t i = 0;
-        for (; i + 2 <= m; i += 2) {                                                      // two symbols (<= 30 bits) per trip through the sink
-            const uint32_t a = packed[p[i]], b = packed[p[i + 1]];
-            const int la = (int)(a >> 16);
-            s.put((a & 0xFFFFu) | ((b & 0xFFFFu) << la), la + (int)(b >> 16));
+        int64_t bits = len[256];
+        for (int k = 0; k < 256; ++k) bits += (int64_t)freq[k] * len[k];
+        i = 0;
+        if (s.roomy(bits)) {
+            FastBits f(s);
+            for (; i + 4 <= m; i += 4) {                                                  // four symbols (<= 56 bits) per store
+                const int la = len[p[i]], lb = la + len[p[i + 1]], lc = lb + len[p[i + 2]];
+                f.put((uint64_t)code[p[i]] | ((uint64_t)code[p[i + 1]] << la) | ((uint64_t)code[p[i + 2]] << lb) | ((uint64_t)code[p[i + 3]] << lc), lc + len[p[i + 3]]);
+            }
+            for (; i < m; ++i) f.put(code[p[i]], len[p[i]]);
+            f.close();
+        } else {
+            for (; i < m; ++i) s.put(code[p[i]], len[p[i]]);
         }
-        if (i < m) s.put(packed[p[i]] & 0xFFFFu, (int)(packed[p[i]] >> 16));
         s.put(code[256], len[256]);
     }
     s.finish();
@@ -511,32 +605,56 @@ extern "C" int64_t pep_deflate_fast(const uint8_t *src, int64_t n, uint8_t *out,
         for (int k = 0; k < 19; ++k) s.put(cl_order[k] >= 16 ? 0u : 4u, 3);  // lengths 0..15 as the complete 4-bit code, no repeat codes (158 bytes per 64 KiB block)
         for (int i = 0; i < 286; ++i) put_len4(l_len[i]);
         for (int i = 0; i < 30; ++i) put_len4(d_len[i]);
-        uint32_t lit_pk[256];                                                // code | length << 16 per literal
-        for (int i = 0; i < 256; ++i) lit_pk[i] = (uint32_t)l_code[i] | ((uint32_t)l_len[i] << 16);
+        int64_t bits = l_len[256];
+        for (int i = 0; i < 286; ++i) bits += (int64_t)f_lit[i] * (l_len[i] + (i >= 257 ? g_ld.len_extra[i - 257] : 0));
+        for (int i = 0; i < 30; ++i) bits += (int64_t)f_dist[i] * (d_len[i] + g_ld.dist_extra[i]);
         tok[nt] = 0x80000000u;                                               // (a sentinel behind the last token: the pairing below looks one ahead)
-        for (size_t k = 0; k < nt;) {
-            const uint32_t t = tok[k];
-            if (!(t & 0x80000000u)) {
-                const uint32_t a = lit_pk[t], u = tok[k + 1];
-                if (!(u & 0x80000000u)) {                                    // two literals (<= 30 bits) per trip through the sink
-                    const uint32_t b = lit_pk[u];
-                    const int la = (int)(a >> 16);
-                    s.put((a & 0xFFFFu) | ((b & 0xFFFFu) << la), la + (int)(b >> 16));
-                    k += 2;
-                } else { s.put(a & 0xFFFFu, (int)(a >> 16)); ++k; }
-                continue;
+        if (s.roomy(bits)) {
+            FastBits f(s);
+            for (size_t k = 0; k < nt;) {
+                const uint32_t t = tok[k];
+                if (!(t & 0x80000000u)) {
+                    const uint32_t u = tok[k + 1];
+                    if (!(u & 0x80000000u)) {                                // two literals (<= 30 bits) per store
+                        f.put((uint64_t)l_code[t] | ((uint64_t)l_code[u] << l_len[t]), l_len[t] + l_len[u]);
+                        k += 2;
+                    } else { f.put(l_code[t], l_len[t]); ++k; }
+                    continue;
+                }
+                const uint32_t len = (t >> 16) & 0x1FFu, d = (t & 0xFFFFu) + 1u;
+                const int ls = g_ld.len_sym[len], li = ls - 257, ds = g_ld.dist_sym(d);
+                // length symbol + its extra bits (<= 20 bits), then distance symbol + its extra bits (<= 28 bits): one store
+                const int ll = l_len[ls] + g_ld.len_extra[li];
+                f.put(((uint64_t)l_code[ls] | ((uint64_t)(len - g_ld.len_base[li]) << l_len[ls])) |
+                      (((uint64_t)d_code[ds] | ((uint64_t)(d - g_ld.dist_base[ds]) << d_len[ds])) << ll), ll + d_len[ds] + g_ld.dist_extra[ds]);
+                ++k;
             }
-            const uint32_t len = (t >> 16) & 0x1FFu, d = (t & 0xFFFFu) + 1u;
-            const int ls = g_ld.len_sym[len], li = ls - 257, ds = g_ld.dist_sym(d);
-            // length symbol + its extra bits (<= 20 bits), then distance symbol + its extra bits (<= 28 bits)
-            s.put((uint32_t)l_code[ls] | ((len - g_ld.len_base[li]) << l_len[ls]), l_len[ls] + g_ld.len_extra[li]);
-            s.put((uint32_t)d_code[ds] | ((d - g_ld.dist_base[ds]) << d_len[ds]), d_len[ds] + g_ld.dist_extra[ds]);
-            ++k;
+            f.close();
+        } else {
+            for (size_t k = 0; k < nt; ++k) {
+                const uint32_t t = tok[k];
+                if (!(t & 0x80000000u)) { s.put(l_code[t], l_len[t]); continue; }
+                const uint32_t len = (t >> 16) & 0x1FFu, d = (t & 0xFFFFu) + 1u;
+                const int ls = g_ld.len_sym[len], li = ls - 257, ds = g_ld.dist_sym(d);
+                s.put((uint32_t)l_code[ls] | ((len - g_ld.len_base[li]) << l_len[ls]), l_len[ls] + g_ld.len_extra[li]);
+                s.put((uint32_t)d_code[ds] | ((d - g_ld.dist_base[ds]) << d_len[ds]), d_len[ds] + g_ld.dist_extra[ds]);
+            }
         }
         s.put(l_code[256], l_len[256]);
     }
     s.finish();
     return s.n;
+}
+
+// A store member ready for its archive in ONE call: the raw DEFLATE stream of `src` by the coder asked for (0: pep_deflate_literals, 1: pep_deflate_fast) and the
+// CRC-32 of `src` that the member's zip header carries.  Returns the stream's length (> cap: nothing usable written, as the coders do).
+extern "C" int64_t pep_pack_member(const uint8_t *src, int64_t n, int32_t coder, uint8_t *out, int64_t cap, uint32_t *crc)
+{
+    if (!crc || coder < 0 || coder > 1) return PEP_ERR_ARG;
+    const int64_t got = coder == 0 ? pep_deflate_literals(src, n, out, cap) : pep_deflate_fast(src, n, out, cap);
+    if (got < 0) return got;
+    *crc = pep_crc32(src, n, 0u);
+    return got;
 }
 
 extern "C" int64_t pep_store_tab_members(const int64_t *rows, int64_t n_cols, const int64_t *order, const int64_t *off, const int64_t *key, int64_t n_members, uint32_t dos_time, uint32_t dos_date,

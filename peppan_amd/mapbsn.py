@@ -60,14 +60,15 @@ def _pack_member(data, strategy=zlib.Z_DEFAULT_STRATEGY):
         data = data()               # a member whose bytes are made here, off the caller's thread (C emitters: no GIL held)
     if len(data) < 4096:
         return data, zlib.crc32(data), len(data), zipfile.ZIP_STORED
-    if strategy == zlib.Z_HUFFMAN_ONLY:          # the library's own literal-only coder: the sizes of zlib's Z_HUFFMAN_ONLY at 590 instead of 130 MB/s
-        from ._native import deflate_literals
-        return deflate_literals(data), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
-    if strategy == FAST_DEFLATE:                 # the library's single-probe matcher (pep_deflate_fast): the sizes of zlib's level 1 at three times its rate
-        from ._native import deflate_fast
-        return deflate_fast(data), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
+    if strategy == zlib.Z_HUFFMAN_ONLY or strategy == FAST_DEFLATE:
+        # the library's own coders, stream and CRC from one call (pep_pack_member): literals only - the sizes of zlib's Z_HUFFMAN_ONLY at several times its
+        # rate -, or the single-probe matcher - the sizes of zlib's level 1 at three times its rate; the CRC by carry-less multiplication (zlib's: 1 ms per 2 MB)
+        from ._native import pack_member
+        payload, crc = pack_member(data, 0 if strategy == zlib.Z_HUFFMAN_ONLY else 1)
+        return payload, crc, len(data), zipfile.ZIP_DEFLATED
+    from ._native import crc32
     co = zlib.compressobj(1, zlib.DEFLATED, -15, 8, strategy)
-    return co.compress(data) + co.flush(), zlib.crc32(data), len(data), zipfile.ZIP_DEFLATED
+    return co.compress(data) + co.flush(), crc32(data), len(data), zipfile.ZIP_DEFLATED
 
 
 def _archive(where, mode):

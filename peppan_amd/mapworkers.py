@@ -135,6 +135,19 @@ def _members_from_file(P):
     return P
 
 
+def _thread_cpu(names={}):
+    """[(name, user + system CPU seconds)] of every thread of this process, the library's and the runtime's included (/proc/self/task), largest first"""
+    tick, out = float(os.sysconf('SC_CLK_TCK')), []
+    for tid in os.listdir('/proc/self/task'):
+        try:
+            stat = open('/proc/self/task/%s/stat' % tid).read()
+        except OSError:
+            continue
+        comm, rest = stat[stat.index('(') + 1:stat.rindex(')')], stat[stat.rindex(')') + 2:].split()
+        out.append((names.get(int(tid), comm) + ':' + tid, (int(rest[11]) + int(rest[12])) / tick))
+    return sorted(out, key=lambda kv: -kv[1])
+
+
 def _serve(address, authkey):
     """The worker's life: set-ups and rounds until 'stop' or until the parent goes away.
 
@@ -152,6 +165,7 @@ def _serve(address, authkey):
     todo, searched, replies = queue.Queue(), queue.Queue(maxsize=1), queue.Queue()
     send_lock = threading.Lock()
     profiles = []
+    tids = {threading.get_native_id(): 'socket'}
 
     def say(msg):
         with send_lock:
@@ -176,6 +190,7 @@ def _serve(address, authkey):
         while True:
             msg = todo.get()
             if msg is None:
+                spent['search_thread_cpu'] = time.thread_time()
                 searched.put(None)
                 return
             k, jobs = msg[1], msg[2]
@@ -205,6 +220,7 @@ def _serve(address, authkey):
         while True:
             item = searched.get()
             if item is None:
+                spent['groups_thread_cpu'] = time.thread_time()
                 return
             k, jobs, found, failed = item
             try:
@@ -259,7 +275,10 @@ def _serve(address, authkey):
             for t in threads:
                 t.join(30.)
             if os.environ.get('PEPPAN_WORKERS_TIMING'):             # seconds this worker spent where (a line per worker on stderr)
-                sys.stderr.write('mapping worker %d: %s\n' % (os.getpid(), ' '.join('%s %.2f' % kv for kv in spent.items())))
+                tm = os.times()
+                spent['process_cpu_user'], spent['process_cpu_system'] = tm.user, tm.system
+                sys.stderr.write('mapping worker %d: %s; threads still alive: %s\n' % (os.getpid(), ' '.join('%s %.2f' % kv for kv in spent.items()),
+                                                                                        ' '.join('%s %.2f' % kv for kv in _thread_cpu(tids) if kv[1] >= 0.05)))
             if profiles:
                 import pstats
                 st = pstats.Stats(profiles[0], stream=sys.stderr)
@@ -323,7 +342,8 @@ class MapWorkers(object):
         self._address = address = os.path.join(self._dir, 's')
         authkey = os.urandom(16)
         self._listener = Listener(address, family='AF_UNIX', authkey=authkey)
-        env = dict(os.environ, PEPPAN_WORKER_KEY=authkey.hex(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env = dict(os.environ, PEPPAN_WORKER_KEY=authkey.hex(), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                   PEPPAN_HOST_THREADS='1')             # (the workers ARE the parallelism: their host chain stays on the thread that runs it)
         env.setdefault('PEPPAN_HIP_SPIN_US', '0')           # the workers nap while they wait for the GPU they share: spinning would eat the CPU time the others need
         # few hardware queues per worker process: with the runtime's default (up to four per process) eight workers of three streams each - search, nucleotide
         # tool, the groups thread's K12 - ask for more queues than the GPU has slots for, and the scheduler spends its time swapping them: the driver's busy counter

@@ -382,6 +382,7 @@ class RunBlast(object):
         tools = self._tool_table()
         tables, self.failed_tools = [], []
         self._rescored_by_tools = False
+        self._nucl_searched = None
         todo = [m for m in methods if m.lower() in tools]
 
         def attempt(method):
@@ -417,7 +418,19 @@ class RunBlast(object):
             self._ensure_nt(get_nucl_context(self.device))
             k_side = names.index('blastn')
             self._rescored_by_tools = rescore == 1
-            side = threading.Thread(target=lambda: outcomes.__setitem__(k_side, attempt(todo[k_side])))
+            # Whose turn the GPU is.  The two searches together take the GPU as long side by side as one after the other (6.0 ms of kernels at 10 000 genes either
+            # way), so what counts is which tool's host chain starts first: the nucleotide tool has the longer one behind its search (table 1.6 + K7 1.1 ms against
+            # 0.55 + 1.0), so its search goes first and the translated search starts when it is back - the nucleotide table is then built while the translated search
+            # has the GPU to itself.  PEPPAN_TOOL_TURNS=0: both searches at once (round 5).
+            turn = self._nucl_searched = threading.Event() if os.environ.get('PEPPAN_TOOL_TURNS', '1') != '0' else None
+
+            def side_tool():
+                try:
+                    outcomes[k_side] = attempt(todo[k_side])
+                finally:
+                    if turn is not None:
+                        turn.set()                # (also when the tool failed before or inside its search)
+            side = threading.Thread(target=side_tool)
             # (a thread that comes back from the library waits for the interpreter lock until the other one gives it up: at the default 5 ms
             # between such requests the two tools cost more side by side than one after the other - 30.5 against 29.1 ms per call; at 0.1 ms 24.0)
             interval = sys.getswitchinterval()
@@ -637,6 +650,8 @@ class RunBlast(object):
         params = N.default_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100., top_k=nhits, n_splits=5,
                                   dbsize=5000000., max_evalue=1., sensitive=self.sensitive)
         ctx.translate()                                                # (K1; a nucleotide search before this one left base codes in the packed sets)
+        if getattr(self, '_nucl_searched', None) is not None:
+            self._nucl_searched.wait()                                 # (_run_tools: the nucleotide tool's search goes first)
         hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
         table = hits_to_table(hits, cigar, ctx.query_meta(), ctx.target_meta(), self._q_tab, self._r_tab, self._q_len, self._r_len,
                               self.min_id, self.min_cov, self.min_ratio)
@@ -654,12 +669,16 @@ class RunBlast(object):
         self._load(ref, qry)
         ctx = get_nucl_context(self.device) if self._batch is None else get_context(self.device)        # (a batch of genomes: one context, tool after tool)
         params = N.nucleotide_params(min_id_pct=self.min_id * 100., min_qcov_pct=self.min_ratio * 100., hsp_mode=self.blast_hsp_mode)
-        if max(map(len, self.refSeq.values()), default=0) <= N.MAX_SEQ_LEN:
+        side = _SIDE_CACHE.get(getattr(self, '_r_key', None)) if self._batch is None else None      # (the prepared side knows the lengths: 10 000 len() calls are 0.3 ms of the hot call's start)
+        longest = (int(side['lens'].max()) if len(side['lens']) else 0) if side is not None else max(map(len, self.refSeq.values()), default=0)
+        if longest <= N.MAX_SEQ_LEN:
             # the usual case: the nucleotide sets that K1 and K7 read on the device are packed THERE into the base-code residue sets of this
             # search (forward strands, then reverse complements, per reference set) - no encoding, concatenation or upload on the host
             self._ensure_nt(ctx)
             ctx.use_nt_as_residues(2)
             hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
+            if getattr(self, '_nucl_searched', None) is not None:
+                self._nucl_searched.set()                                  # (_run_tools: the translated tool's search may start)
             tm = ctx.target_meta()
             table = blast_hits_to_table(hits, cigar, self._q_tab, self._r_tab, self._q_len, self._r_len, self.min_id, self.min_cov, self.min_ratio, params,
                                         tm['seq'].astype(np.int64), tm['frame'] > 3)
@@ -736,6 +755,8 @@ class RunBlast(object):
         self._nt_loaded.pop(id(ctx), None)          # the packed sets THIS context held from an earlier search are gone (only this context's record: the
         #                                             other tool's thread may be reading or writing its own entry at this moment)
         hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
+        if getattr(self, '_nucl_searched', None) is not None:
+            self._nucl_searched.set()
         table = blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len,
                                     self.min_id, self.min_cov, self.min_ratio, params, np.array(t_seq, dtype=np.int64), np.array(t_rev, dtype=bool),
                                     windows=(np.array(t_woff, dtype=np.int64), np.array(t_hlo, dtype=np.int64), np.array(t_hhi, dtype=np.int64)) if tiled else None)

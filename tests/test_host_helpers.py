@@ -321,3 +321,73 @@ def test_similar_classify_equals_its_numpy_statement():
                 assert w.dtype == g.dtype and np.array_equal(w, g)
             seen_actions.update(want[0].tolist())
     assert seen_actions == {0, 1, 2, 3}                                # every action occurs
+
+
+def _random_hits(rng, n, n_q, n_t, tool):
+    from peppan_amd import _native as N
+    h = np.zeros(n, dtype=N.HIT_DTYPE)
+    h['q'], h['t'] = rng.integers(0, n_q, n), rng.integers(0, n_t, n)
+    h['q_start'] = rng.integers(1, 100, n)
+    h['q_end'] = h['q_start'] + rng.integers(5, 300, n)
+    h['t_start'] = rng.integers(1, 100, n)
+    h['t_end'] = h['t_start'] + rng.integers(5, 300, n)
+    h['score'] = rng.integers(20, 2000, n)
+    h['aln_len'] = rng.integers(30, 400, n)
+    h['nm'] = (h['aln_len'] * rng.random(n) * 0.6).astype(np.uint32)
+    h['n_ident'] = h['aln_len'] - h['nm']
+    h['cigar_runs'] = rng.integers(1, 6, n)
+    h['cigar_off'] = np.concatenate([[0], np.cumsum(h['cigar_runs'])[:-1]])
+    cigar = (rng.integers(1, 120, int(h['cigar_runs'].sum())).astype(np.uint32) << 2) | rng.choice([0, 0, 0, 1, 2], int(h['cigar_runs'].sum())).astype(np.uint32)
+    return h, cigar
+
+
+def test_host_chain_passes_do_not_depend_on_their_thread_count():
+    """pep_table_from_hits (both tools, rows failing the cuts in every chunk), pep_cols_fix_end and pep_cols_gather over tables beyond the 16 384 rows from which
+    they use threads: one thread and four give the same columns, arenas and counts; pep_cols_order against numpy's lexsort (its packed-record radix path, and the
+    wide-code path behind it)"""
+    from peppan_amd import _native as N
+    rng = np.random.default_rng(77)
+    n, n_q, n_t = 70001, 3000, 5000
+    q_len, r_len = rng.integers(300, 3000, n_q), rng.integers(3000, 9000, n_t)
+    results = {}
+    before = N.set_host_threads(1)
+    try:
+        for threads in (1, 4):
+            N.set_host_threads(threads)
+            out = []
+            # translated tool
+            rng = np.random.default_rng(5)                                   # (the same inputs for both thread counts)
+            h, cigar = _random_hits(rng, n, n_q, n_t, 0)
+            qm = np.zeros(n_q, dtype=N.QUERY_META_DTYPE); qm['seq'] = np.arange(n_q); qm['frame'] = 1
+            tm = np.zeros(n_t, dtype=N.TARGET_META_DTYPE); tm['seq'] = np.arange(n_t); tm['frame'] = rng.integers(1, 7, n_t); tm['chunk_off'] = rng.integers(0, 50, n_t)
+            cols, arena = N.table_from_hits(0, h, cigar, q_len, r_len, 0.55, 60., 0.02, q_meta=qm, t_meta=tm)
+            assert 0.2 * n < len(cols['qs']) < 0.95 * n                      # (the cuts bite in every chunk)
+            out.append(({k: v.copy() for k, v in cols.items()}, arena.copy()))
+            # nucleotide tool
+            h, cigar = _random_hits(np.random.default_rng(6), n, n_q, n_t, 1)
+            cols, arena = N.table_from_hits(1, h, cigar, q_len, r_len, 0.55, 60., 0.02, t_seq=np.arange(n_t), t_rev=rng.integers(0, 2, n_t).astype(bool), evalue=rng.random(n))
+            assert 0.2 * n < len(cols['qs']) < 0.95 * n
+            out.append(({k: v.copy() for k, v in cols.items()}, arena.copy()))
+            # fixEnd over the nucleotide table (ends near the query's: many rows change), then a gather of every column
+            m = len(cols['qs'])
+            work = {k: np.ascontiguousarray(v.copy()) for k, v in cols.items()}
+            work['qs'] = np.minimum(work['qs'], rng.integers(1, 12, m)); work['ql'] = work['qe'] + rng.integers(0, 12, m)
+            work['ss'] = work['ss'] + 20; work['se'] = work['ss'] + (work['qe'] - work['qs']); work['sl'] = work['se'] + rng.integers(0, 12, m)
+            fixed_arena = N.cols_fix_end(work, arena, 6., 6.)
+            out.append((work, fixed_arena.copy()))
+            idx = rng.permutation(m)[:m - 17]
+            names = sorted(work)
+            out.append((dict(zip(names, N.cols_gather([work[k] for k in names], idx))), np.zeros(0)))
+            results[threads] = out
+    finally:
+        N.set_host_threads(before)
+    for (c1, a1), (c4, a4) in zip(results[1], results[4]):
+        assert sorted(c1) == sorted(c4)
+        for k in c1:
+            assert c1[k].dtype == c4[k].dtype and np.array_equal(c1[k], c4[k]), k
+        assert np.array_equal(a1, a4)
+    # the order: (query code, reference code, score), stable
+    for n_rows, q_hi, r_hi in ((70001, 10000, 10000), (50000, 3, 2), (40000, 1 << 20, 1 << 20), (1, 5, 5), (0, 1, 1), (30000, 1, 1)):
+        q, r = rng.integers(0, q_hi, n_rows), rng.integers(0, r_hi, n_rows)
+        score = rng.integers(0, 40, n_rows).astype(np.float64) / 4
+        assert np.array_equal(N.cols_order(q, r, score), np.lexsort((score, r, q))), (n_rows, q_hi, r_hi)
