@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define PEP_ABI_VERSION 15
+#define PEP_ABI_VERSION 16
 
 #define PEP_OK 0
 #define PEP_ERR_HIP (-1)       /* a HIP runtime call failed */
@@ -238,6 +238,15 @@ int pep_merge_hits(uint64_t n, const pep_hit *hits, const uint32_t *cigar, uint6
 /* K7: integer counts of mode-1 rescoring per hit, out[5*i..] = nMatch, nMismatch, nGap, bGap, mGap.
  * Uses the nucleotide sets given to pep_set_query_nt / pep_set_ref_nt. */
 int pep_rescore_nt(pep_ctx *ctx, uint64_t n, const pep_nt_hit *hits, const uint32_t *cigar, uint64_t n_cigar, int64_t *out);
+
+/* K7 as the tail of every search of this context (-s 1 in PEPPAN's hot call, PEPPAN.py:229-230: every hit of both tools is rescored, uberBlast.py:352-353):
+ * with on = 1 pep_search ends with the count of identical nucleotide columns of every hit it emits - K7's n_match, the one of its five counts that needs the
+ * sequences - computed from the table on the device (the row a hit becomes follows from the hit and the descriptors of its packed sequences; nothing is
+ * uploaded again, same stream, same wait).  pep_result_nt_match hands out the counts, one per hit in hit order (NULL when the search had none or the switch
+ * was off); pep_table_from_hits turns them into the rescored identity and score.  Needs packed sets made from the context's nucleotide sets (K1 or
+ * pep_use_nt_as_residues): a search over sets given as residues fails with PEP_ERR_STATE while the switch is on. */
+int pep_set_nt_match(pep_ctx *ctx, int on);
+int pep_result_nt_match(const pep_result *r, const uint32_t **nt_match);
 
 /* K10: connected components; label[x] = smallest node id of x's component */
 int pep_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const uint32_t *a, const uint32_t *b, uint32_t *label);
@@ -459,11 +468,14 @@ typedef struct pep_hit_cols {
  *   with blastn's three printed decimals, mismatches = length - identities - gap columns, `evalue[i]` per HIT as the caller computed it, the cuts
  *   identity >= min_id, aligned query span >= min_cov and >= min_ratio * ql; win_off / home_lo / home_hi (NULL or per target): targets that are
  *   windows of a long strand - a hit is shifted to strand coordinates and kept by the window whose home stretch holds its midpoint.  q_meta / t_meta unused.
- * q_len / r_len: nucleotide lengths per sequence.  Negative: PEP_ERR_ARG. */
+ * q_len / r_len: nucleotide lengths per sequence.  Negative: PEP_ERR_ARG.
+ * nt_match (NULL, or per HIT the count pep_result_nt_match hands out): the rows come out rescored - RunBlast.reScore's mode 1 (uberBlast.py:397-415,
+ *   cigar2score :226-249) applied to every kept row: identity = matches / (matches + mismatches + gap bases - gap bases of gaps longer than 3) and
+ *   score = 3 matches - mismatches - 5 gaps - gap bases in float64, rounded to three decimals; the cuts still look at the tool's own identity. */
 int64_t pep_table_from_hits(int32_t tool, uint64_t n, const pep_hit *hits, const uint32_t *cigar, uint64_t n_cigar, const pep_query_meta *q_meta,
                             const pep_target_meta *t_meta, const int64_t *q_len, const int64_t *r_len, const int64_t *t_seq, const uint8_t *t_rev,
                             const int64_t *win_off, const int64_t *home_lo, const int64_t *home_hi, const double *evalue, double min_id, double min_cov,
-                            double min_ratio, pep_hit_cols *out, uint32_t *arena_out);
+                            double min_ratio, pep_hit_cols *out, uint32_t *arena_out, const uint32_t *nt_match);
 
 /* RunBlast.fixEnd (uberBlast.py:462-480) over all rows, in place: an alignment is stretched over an unaligned query head of at most se_lim / tail of
  * at most ee_lim bases as far as the reference sequence allows, its first / last CIGAR run growing by the same amount.  The rows' runs are copied

@@ -531,6 +531,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_k1.p) (void)hipHostFree(ctx->pin_k1.p);
     if (ctx->pin_k1q.p) (void)hipHostFree(ctx->pin_k1q.p);
     if (ctx->pin_labels.p) (void)hipHostFree(ctx->pin_labels.p);
+    if (ctx->pin_nt_match.p) (void)hipHostFree(ctx->pin_nt_match.p);
     if (ctx->k1_event) (void)hipEventDestroy(ctx->k1_event);
     if (ctx->k1q_event) (void)hipEventDestroy(ctx->k1q_event);
     if (ctx->k1_t0) (void)hipEventDestroy(ctx->k1_t0);
@@ -540,7 +541,7 @@ void pep_ctx_destroy(pep_ctx *ctx)
     if (ctx->pin_down.p) (void)hipHostFree(ctx->pin_down.p);
     if (ctx->pin_up.p) (void)hipHostFree(ctx->pin_up.p);
     if (ctx->pin_ms.p) (void)hipHostFree(ctx->pin_ms.p);
-    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->fused_state[0].buf, &ctx->fused_state[1].buf, &ctx->fused_state[2].buf, &ctx->fused_state[3].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_trace_defer, &ctx->d_k1_base, &ctx->d_k1_seg, &ctx->d_k1_long, &ctx->d_k1_spec, &ctx->d_k1_tiles, &ctx->d_t_class, &ctx->d_t_subject, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
+    DevBuf *bufs[] = {&ctx->sub_lds, &ctx->d_params, &ctx->scan_state[0].buf, &ctx->scan_state[1].buf, &ctx->fused_state[0].buf, &ctx->fused_state[1].buf, &ctx->fused_state[2].buf, &ctx->fused_state[3].buf, &ctx->d_min_score, &ctx->d_trace_mode, &ctx->d_trace_defer, &ctx->d_k1_base, &ctx->d_k1_seg, &ctx->d_k1_long, &ctx->d_k1_spec, &ctx->d_k1_tiles, &ctx->d_t_class, &ctx->d_t_subject, &ctx->d_nt_match, &ctx->q_nt.nt, &ctx->q_nt.off, &ctx->r_nt.nt, &ctx->r_nt.off,
                       &ctx->q.res, &ctx->q.off, &ctx->q.len, &ctx->t.res, &ctx->t.off, &ctx->t.len, &ctx->q.blk2seq, &ctx->t.blk2seq,
                       &ctx->sort_state, &ctx->sort_hist, &ctx->d_set, &ctx->d_zero, &ctx->d_k1_desc_q, &ctx->d_k1_desc_t, &ctx->d_self_delta, &ctx->d_self_t, &ctx->d_mail_copy,
                       &ctx->nucl_q.d_off, &ctx->nucl_q.d_len, &ctx->nucl_q.d_desc, &ctx->nucl_t.d_off, &ctx->nucl_t.d_len, &ctx->nucl_t.d_desc, &ctx->nucl_t.d_first};
@@ -830,6 +831,11 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
     if (grouped)                                  // single linkage over the table that was just emitted, same stream, same wait
         rc = ctx->ext.pending ? pep_k10_queue(ctx, ctx->ext.n_bound, reinterpret_cast<const pep_hit *>(ctx->ext.d_hits), ctx->ext.d_n_hits)
                               : pep_k10_queue(ctx, res->n_hits, res->d_hits);
+    // K7's count of identical nucleotide columns for every hit of this search (pep_set_nt_match), from the table on the device: same stream, same wait
+    const bool counted = rc == PEP_OK && ctx->want_nt_match;
+    if (counted)
+        rc = ctx->ext.pending ? pep_k7_hits_queue(ctx, ctx->ext.n_bound, reinterpret_cast<const pep_hit *>(ctx->ext.d_hits), reinterpret_cast<const uint32_t *>(ctx->ext.d_cig), ctx->ext.d_n_hits)
+                              : pep_k7_hits_queue(ctx, res->n_hits, res->d_hits, res->d_cigar);
     pep_timer_end(ctx, TM_TOTAL);
     const hipError_t se = pep_stream_wait(ctx);
     if (rc == PEP_OK && se != hipSuccess) rc = pep_fail(ctx, PEP_ERR_HIP, std::string("stream sync: ") + hipGetErrorString(se));
@@ -841,11 +847,29 @@ int pep_search(pep_ctx *ctx, const pep_search_params *params, pep_result **out)
         const uint32_t *lab = reinterpret_cast<const uint32_t *>(ctx->pin_labels.p);
         res->labels.assign(lab, lab + ctx->grp_nodes);
     }
+    if (counted && res->n_hits) {
+        const uint32_t *cnt = reinterpret_cast<const uint32_t *>(ctx->pin_nt_match.p);
+        res->nt_match.assign(cnt, cnt + res->n_hits);
+    }
     res->stats = ctx->stats;
     ctx->dev_result = res->d_hits ? res : nullptr;
     if (res->st_hits || res->st_cigar) ctx->staged_result = res;
     else if (!res->d_hits) res->ctx = nullptr;             // owns its (possibly empty) table from the start: nothing ties it to the context
     *out = res;
+    return PEP_OK;
+}
+
+int pep_set_nt_match(pep_ctx *ctx, int on)
+{
+    if (!ctx || (on != 0 && on != 1)) return PEP_ERR_ARG;
+    ctx->want_nt_match = on != 0;
+    return PEP_OK;
+}
+
+int pep_result_nt_match(const pep_result *r, const uint32_t **nt_match)
+{
+    if (!r || !nt_match) return PEP_ERR_ARG;
+    *nt_match = (r->n_hits && r->nt_match.size() == r->n_hits) ? r->nt_match.data() : nullptr;
     return PEP_OK;
 }
 

@@ -72,6 +72,17 @@ struct PinBuf {
 
 struct pep_result;
 
+// K1's descriptor of a packed sequence (translate.hip): the nucleotide sequence it was translated from, the frame (1 - 3 forward, 4 - 6 reverse strand), the residue its
+// chunk starts at inside that frame, its length in residues.  One per query (d_k1_desc_q) / target (d_k1_desc_t), on the device; the host's meta records are made from them.
+struct PackDesc {
+    uint32_t seq;
+    uint32_t frame;
+    uint32_t aa_off;
+    uint32_t len;
+};
+// ... and of a packed nucleotide sequence (pep_use_nt_as_residues: NuclSide::d_desc): the sequence and whether it is its reverse complement
+struct NuclDesc { uint32_t seq, rev; };
+
 struct pep_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -172,6 +183,9 @@ struct pep_ctx {
     struct { bool pending = false; pep_result *res = nullptr; const void *d_hits = nullptr, *d_cig = nullptr; const uint32_t *d_n_hits = nullptr; uint64_t n_bound = 0; bool parent_ready = false; } ext;
                                             // a search whose result left through pack_out and whose host half (sizes, statistics, views) is still to be done (pep_extend_finish)
     struct { void *d_dst = nullptr; const void *pinned_src = nullptr; uint64_t n_words = 0; } upload;   // an upload out of pinned memory that rides on the next read-back kernel
+    bool want_nt_match = false;              // pep_set_nt_match: the searches of this context end with K7's count of identical nucleotide columns per hit (rescore.hip: pep_k7_hits_queue)
+    DevBuf d_nt_match;
+    PinBuf pin_nt_match;                     // grow-only: those counts on their way to the result
     uint32_t grp_nodes = 0, grp_q_base = 0;  // pep_set_grouping: the searches of this context end with K10 over their own hit table (0 = off)
     bool device_results = false;            // pep_set_result_mode: searches leave their table on the device; the host copy is fetched on demand
     pep_result *dev_result = nullptr;       // the result whose hit table is still intact on the device (ws[23]): the newest search's, until the workspace is reused
@@ -195,6 +209,7 @@ struct pep_result {
     const uint32_t *d_cigar = nullptr;
     pep_stats stats;
     std::vector<uint32_t> labels;           // pep_set_grouping: the partition of the search's hit graph (one label per node)
+    std::vector<uint32_t> nt_match;         // pep_set_nt_match: identical nucleotide columns per hit (K7's n_match)
 };
 
 // HIP-event stopwatch on one stream (the kernel times bench.py reports are taken with it, inside the library,
@@ -315,6 +330,7 @@ int pep_k10_components(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_edges, const u
 int pep_k10_components_dev(pep_ctx *ctx, uint32_t n_nodes, uint64_t n_hits, const pep_hit *d_hits, uint32_t q_base, const uint32_t *h_node_of_target,
                            uint64_t n_targets, uint32_t *h_label);
 
+int pep_k7_hits_queue(pep_ctx *ctx, uint64_t n_hits, const pep_hit *d_hits, const uint32_t *d_cigar, const uint32_t *d_n_hits = nullptr);   // K7's match counts of a search's own hits -> ctx->pin_nt_match (no wait; rescore.hip)
 int pep_k10_queue(pep_ctx *ctx, uint64_t n_hits, const pep_hit *d_hits, const uint32_t *d_n_hits = nullptr);   // d_n_hits: the count lives on the device, n_hits bounds it       // K10 behind a search, labels -> ctx->pin_labels (no wait)
 int pep_k10_set_grouping(pep_ctx *ctx, uint32_t n_nodes, uint32_t q_base, const uint32_t *h_node_of_target, uint64_t n_targets);
 

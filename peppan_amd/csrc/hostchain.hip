@@ -81,7 +81,7 @@ int pep_set_host_threads(int n)
 int64_t pep_table_from_hits(int32_t tool, uint64_t n, const pep_hit *hits, const uint32_t *cigar, uint64_t n_cigar, const pep_query_meta *q_meta,
                             const pep_target_meta *t_meta, const int64_t *q_len, const int64_t *r_len, const int64_t *t_seq, const uint8_t *t_rev,
                             const int64_t *win_off, const int64_t *home_lo, const int64_t *home_hi, const double *evalue, double min_id, double min_cov,
-                            double min_ratio, pep_hit_cols *out, uint32_t *arena_out)
+                            double min_ratio, pep_hit_cols *out, uint32_t *arena_out, const uint32_t *nt_match)
 {
     if ((n && (!hits || !out || !q_len || !r_len)) || (n_cigar && (!cigar || !arena_out))) return PEP_ERR_ARG;
     if (tool == 0 && n && (!q_meta || !t_meta)) return PEP_ERR_ARG;
@@ -90,6 +90,7 @@ int64_t pep_table_from_hits(int32_t tool, uint64_t n, const pep_hit *hits, const
     // rows in chunks, a thread each: chunk t writes its rows from row lo_t on and the gaps the filters left are closed afterwards (few rows fail the cuts)
     const int T = host_threads(n);
     std::vector<int64_t> made((size_t)T, 0);
+    const int64_t unit = tool == 0 ? 3 : 1;       // nucleotides per CIGAR column
     auto chunk = [&](int t, uint64_t lo, uint64_t hi) {
     // the CIGAR arena in nucleotide units: the translated tool's runs count residues
     const uint64_t c_lo = n_cigar * (uint64_t)t / (uint64_t)T, c_hi = n_cigar * (uint64_t)(t + 1) / (uint64_t)T;
@@ -99,10 +100,11 @@ int64_t pep_table_from_hits(int32_t tool, uint64_t n, const pep_hit *hits, const
     for (uint64_t i = lo; i < hi; ++i) {
         const pep_hit &h = hits[i];
         if (h.cigar_off + h.cigar_runs > n_cigar) { made[(size_t)t] = PEP_ERR_ARG; return; }
-        int64_t gap_cols = 0, gap_open = 0;
+        int64_t gap_cols = 0, gap_open = 0, m_cols = 0, long_gap_cols = 0;      // (in the units of the runs: residues for the translated tool)
         for (uint32_t k = 0; k < h.cigar_runs; ++k) {
             const uint32_t run = cigar[h.cigar_off + k];
-            if (run & 3u) { gap_cols += run >> 2; ++gap_open; }
+            if (run & 3u) { gap_cols += run >> 2; ++gap_open; if ((int64_t)(run >> 2) * unit > 3) long_gap_cols += run >> 2; }
+            else m_cols += run >> 2;
         }
         if (tool == 0) {
             // parseDiamond: names q:frame / r:frame:offset, CIGAR x 3, identity from NM, coordinates back to nucleotides of either strand
@@ -144,6 +146,15 @@ int64_t pep_table_from_hits(int32_t tool, uint64_t n, const pep_hit *hits, const
             out->qs[m] = qs; out->qe[m] = qe;
             out->ss[m] = rev ? sl - ts + 1 : ts; out->se[m] = rev ? sl - te + 1 : te;
             out->evalue[m] = evalue ? evalue[i] : 0.0; out->score[m] = (double)h.score; out->ql[m] = ql; out->sl[m] = sl;
+        }
+        if (nt_match) {
+            // reScore mode 1 (uberBlast.py:397-415, cigar2score :226-249) on the row that was just made: identity and score from K7's counts - identical columns from
+            // the device (the search counted them for its own hits: pep_set_nt_match), the gap counts from the CIGAR - in the float64 arithmetic of the numpy form:
+            // identity = matches / (matches + mismatches + gap bases - gap bases of gaps longer than 3), score = 3 matches - mismatches - 5 gaps - gap bases,
+            // both rounded to three decimals half to even.  (The cuts above looked at the tool's own identity, as the reference's parsers do.)
+            const int64_t n_match = nt_match[i], n_mis = m_cols * unit - n_match, b_gap = gap_cols * unit, m_gap = long_gap_cols * unit;
+            out->iden[m] = round3((double)n_match / (double)(n_match + n_mis + b_gap - m_gap));
+            out->score[m] = round3((double)(n_match * 3 - n_mis - gap_open * (6 - 1) - b_gap * 1));
         }
         out->c_off[m] = (int64_t)h.cigar_off; out->c_runs[m] = h.cigar_runs;
         if (out->rid) out->rid[m] = -1;

@@ -60,7 +60,89 @@ __global__ __launch_bounds__(256) void k7_rescore(uint64_t n, const pep_nt_hit *
     }
 }
 
+// K7 over the hits of a search where they lie - the device copy of the table the search has just emitted (pep_set_nt_match).  The table row a hit becomes is a
+// function of the hit and of K1's descriptors of its two packed sequences (pep_table_from_hits: parseDiamond's / parseBlast's coordinate algebra, uberBlast.py:25-58,
+// 275-290), so the walk can start from the hit itself: no table is uploaded again, no second round trip, and of K7's five counts only this one needs the sequences -
+// the gap counts are functions of the CIGAR alone and are taken by the host while it builds the table.
+//   TOOL 0, translated search: CIGAR runs count residues (x 3), the query's frame and the target's (sequence, frame, chunk offset) give the nucleotide coordinates
+//   TOOL 1, nucleotide search: runs count bases, a target is a strand of its sequence
+template <int TOOL, typename DESC>
+__global__ __launch_bounds__(256) void k7_hits(uint64_t n_bound, const uint32_t *__restrict__ d_n_hits, const pep_hit *__restrict__ hits, const uint32_t *__restrict__ cigar,
+                                               const DESC *__restrict__ q_desc, const DESC *__restrict__ t_desc,
+                                               const uint8_t *__restrict__ q_nt, const uint64_t *__restrict__ q_off,
+                                               const uint8_t *__restrict__ r_nt, const uint64_t *__restrict__ r_off, uint32_t *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t h = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t n = d_n_hits ? min((uint64_t)*d_n_hits, n_bound) : n_bound;
+    if (h >= n) return;
+    const pep_hit hit = hits[h];
+    long long qi, ri;
+    bool rev;
+    uint32_t r_seq;
+    if (TOOL == 0) {
+        const PackDesc dq = reinterpret_cast<const PackDesc *>(q_desc)[hit.q], dt = reinterpret_cast<const PackDesc *>(t_desc)[hit.t];
+        r_seq = dt.seq;
+        const long long rl = (long long)(r_off[r_seq + 1] - r_off[r_seq]), rf = dt.frame, rs_aa = (long long)hit.t_start + dt.aa_off;
+        rev = rf > 3;
+        qi = (long long)hit.q_start * 3 + dq.frame - 3 - 1;
+        ri = (rev ? rl - (rs_aa * 3 + rf - 6) + 1 : rs_aa * 3 + rf - 3) - 1;
+    } else {
+        const NuclDesc dt = reinterpret_cast<const NuclDesc *>(t_desc)[hit.t];
+        r_seq = dt.seq;
+        const long long sl = (long long)(r_off[r_seq + 1] - r_off[r_seq]);
+        rev = dt.rev != 0;
+        qi = (long long)hit.q_start - 1;
+        ri = (rev ? sl - (long long)hit.t_start + 1 : (long long)hit.t_start) - 1;
+    }
+    const uint8_t *q = q_nt + q_off[hit.q], *r = r_nt + r_off[r_seq];
+    uint32_t nmatch = 0;
+    const uint32_t *cg = cigar + hit.cigar_off;
+    for (uint32_t k = 0; k < hit.cigar_runs; ++k) {
+        const uint32_t run = cg[k];
+        const long long len = (long long)(run >> 2) * (TOOL == 0 ? 3 : 1);
+        const uint32_t op = run & 3u;
+        if (op == 0) {
+            for (long long x = lane; x < len; x += 64) {
+                const int a = enc(q[qi + x]);
+                const int b = rev ? 4 - enc(r[ri - x]) : enc(r[ri + x]);
+                nmatch += (a == b) ? 1u : 0u;
+            }
+            qi += len; ri += rev ? -len : len;
+        } else if (op == 1) qi += len;
+        else ri += rev ? -len : len;
+    }
+    for (int d = 32; d > 0; d >>= 1) nmatch += __shfl_xor(nmatch, d, 64);
+    if (lane == 0) out[h] = nmatch;
+}
+
 }  // namespace
+
+// queued behind a search on its stream: counts for hits [0, n) - or [0, *d_n_hits) with n as the bound when the count is still on the device - into
+// ctx->pin_nt_match; the caller waits for the stream.  The packed sets must come from the context's nucleotide sets (K1 or pep_use_nt_as_residues).
+int pep_k7_hits_queue(pep_ctx *ctx, uint64_t n, const pep_hit *d_hits, const uint32_t *d_cigar, const uint32_t *d_n_hits)
+{
+    if (n == 0) return PEP_OK;
+    if (!ctx->q_nt.nt.p || !ctx->r_nt.nt.p) return pep_fail(ctx, PEP_ERR_STATE, "pep_set_nt_match needs pep_set_query_nt and pep_set_ref_nt first");
+    const bool nucl = ctx->resid_from_nucl;
+    if (!nucl && !(ctx->q_from_nt && ctx->t_from_nt))
+        return pep_fail(ctx, PEP_ERR_STATE, "pep_set_nt_match: the packed sets of this search were not made from the context's nucleotide sets");
+    if (nucl ? (!ctx->nucl_q.d_desc.p || !ctx->nucl_t.d_desc.p) : (!ctx->d_k1_desc_q.p || !ctx->d_k1_desc_t.p))
+        return pep_fail(ctx, PEP_ERR_STATE, "pep_set_nt_match: no descriptors of the packed sets on the device");
+    PEP_TRY(dev_reserve(ctx, ctx->d_nt_match, n * 4));
+    PEP_TRY(pin_reserve(ctx, ctx->pin_nt_match, n * 4));
+    const dim3 grid((unsigned)ceil_div(n, 4)), block(256);
+    uint32_t *out = ctx->d_nt_match.as<uint32_t>();
+    if (nucl)
+        hipLaunchKernelGGL((k7_hits<1, NuclDesc>), grid, block, 0, ctx->stream, n, d_n_hits, d_hits, d_cigar, ctx->nucl_q.d_desc.as<const NuclDesc>(), ctx->nucl_t.d_desc.as<const NuclDesc>(),
+                           ctx->q_nt.nt.as<const uint8_t>(), ctx->q_nt.off.as<const uint64_t>(), ctx->r_nt.nt.as<const uint8_t>(), ctx->r_nt.off.as<const uint64_t>(), out);
+    else
+        hipLaunchKernelGGL((k7_hits<0, PackDesc>), grid, block, 0, ctx->stream, n, d_n_hits, d_hits, d_cigar, ctx->d_k1_desc_q.as<const PackDesc>(), ctx->d_k1_desc_t.as<const PackDesc>(),
+                           ctx->q_nt.nt.as<const uint8_t>(), ctx->q_nt.off.as<const uint64_t>(), ctx->r_nt.nt.as<const uint8_t>(), ctx->r_nt.off.as<const uint64_t>(), out);
+    PEP_HIP(ctx, hipGetLastError());
+    PEP_HIP(ctx, hipMemcpyAsync(ctx->pin_nt_match.p, out, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return PEP_OK;
+}
 
 int pep_k7_rescore(pep_ctx *ctx, uint64_t n, const pep_nt_hit *h_hits, const uint32_t *h_cigar, uint64_t n_cigar, int64_t *h_out)
 {

@@ -78,12 +78,7 @@ struct K1Summary {
 };
 static_assert(sizeof(K1Summary) == 2 * 16, "the summary takes two descriptor slots");
 
-struct PackDesc {          // one per packed sequence: where its residues come from
-    uint32_t seq;
-    uint32_t frame;
-    uint32_t aa_off;
-    uint32_t len;
-};
+// (PackDesc - one per packed sequence: where its residues come from - is common.h's: K7 behind a search reads the descriptors too)
 
 // where a packed sequence's nucleotides lie (one record per descriptor slot, written by the kernel that writes the descriptor): k1_pack
 // fetches it together with the descriptor instead of chasing nt_off[desc.seq] behind it - a wave of k1_pack lives for a chain of
@@ -482,7 +477,7 @@ __global__ __launch_bounds__(256) void k1_pack(const uint8_t *__restrict__ nt, c
 // ---- nucleotide sets as residue sets (the blastn-equivalent tool, uberBlast.py:294, 482-509): base codes A0 C1 G2 T3, anything else 4;
 // a reverse-strand target is the reverse complement.  One wavefront per packed sequence, eight consecutive bytes per lane (one unaligned
 // 8-byte load where the whole window lies inside the sequence, byte loads at its two ends), padding and block -> sequence map as k1_pack.
-struct NuclDesc { uint32_t seq, rev; };
+// (NuclDesc { seq, rev }: common.h)
 // one wavefront per (sequence, slice of NUCL_SLICE packed bytes): blockIdx.y is the slice.  (One wavefront per SEQUENCE until round 4: fine for genes,
 // but a genome's contig of 2 Mb was packed by a single wavefront - 4 - 8 ms per mapping batch, the largest kernel of the mapping path's trace.)
 constexpr uint32_t NUCL_SLICE = 32768;

@@ -77,7 +77,7 @@ def _name_codes(names, idx):
 
 class HitTable(object):
     __slots__ = ('q_tab', 'r_tab', 'qi', 'ri', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'score_is_int',
-                 'ql', 'sl', 'arena', 'c_off', 'c_runs', 'rid', 'merge', 'm_score', 'm_iden', 'm_span', 'm_start', 'm_len', 'm_ids', 'q_sorted', 'r_sorted')
+                 'ql', 'sl', 'arena', 'c_off', 'c_runs', 'rid', 'merge', 'm_score', 'm_iden', 'm_span', 'm_start', 'm_len', 'm_ids', 'q_sorted', 'r_sorted', 'rescored')
     _ROW_COLS = ('qi', 'ri', 'iden', 'aln', 'mis', 'gap', 'qs', 'qe', 'ss', 'se', 'evalue', 'score', 'ql', 'sl', 'c_off', 'c_runs', 'rid')
     # column 16 after -m in numeric form: per row the group's score / identity / span (span < 0: the row has no group and shows the
     # reference's shared empty list) and the slice [m_start, m_start + m_len) of m_ids that holds the group's row ids
@@ -98,6 +98,7 @@ class HitTable(object):
         self.m_score = self.m_iden = self.m_span = self.m_start = self.m_len = self.m_ids = None
         self.score_is_int = score_is_int
         self.q_sorted = self.r_sorted = False   # True: the name table is a list of str in ascending code-point order (row codes = indices)
+        self.rescored = False                   # True on a tool's table whose identity / score are reScore mode 1's already (the search counted the identical columns: Context.set_nt_match)
 
     def __len__(self):
         return len(self.qi)

@@ -185,14 +185,16 @@ def _str_table(names):
     return names if isinstance(names, _NameTable) else _NameTable(str(x) for x in names)
 
 
-def hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
+def hits_to_table(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, nt_match=None):
     """hits/cigar: output of Context.search for a translated search.  q_len / r_len: nucleotide lengths per sequence index.
     Returns the numeric HitTable of the rows parseDiamond would keep (coordinate algebra and filters of uberBlast.py:25-58)."""
     if len(hits) == 0:
         return HitTable.empty()
-    c, arena = N.table_from_hits(0, hits, cigar, q_len, r_len, min_id, min_cov, min_ratio, q_meta=q_meta, t_meta=t_meta)      # host C++: one pass over the records
-    return HitTable(_str_table(q_names), _str_table(r_names), c['qi'], c['ri'], c['iden'], c['aln'], c['mis'], c['gap'], c['qs'], c['qe'], c['ss'], c['se'],
-                    c['evalue'], c['score'], c['ql'], c['sl'], arena, c['c_off'], c['c_runs'], rid=c['rid'])
+    c, arena = N.table_from_hits(0, hits, cigar, q_len, r_len, min_id, min_cov, min_ratio, q_meta=q_meta, t_meta=t_meta, nt_match=nt_match)      # host C++: one pass over the records
+    T = HitTable(_str_table(q_names), _str_table(r_names), c['qi'], c['ri'], c['iden'], c['aln'], c['mis'], c['gap'], c['qs'], c['qe'], c['ss'], c['se'],
+                 c['evalue'], c['score'], c['ql'], c['sl'], arena, c['c_off'], c['c_runs'], rid=c['rid'], score_is_int=nt_match is None)
+    T.rescored = nt_match is not None        # (nt_match: the search counted K7's identical columns - the rows carry reScore mode 1's identity and score)
+    return T
 
 
 def hits_to_blastab(hits, cigar, q_meta, t_meta, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio):
@@ -230,7 +232,7 @@ def _encode_nt(texts):
     return _NT_CODE[np.frombuffer(raw, dtype=np.uint8)], off
 
 
-def blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev, windows=None):
+def blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev, windows=None, nt_match=None):
     """nucleotide-search hits -> the rows parseBlast builds from blastn's outfmt 6 (uberBlast.py:275-290, 311-320), as a HitTable:
     t_seq / t_rev give the reference sequence and strand of every target (reverse strand: sstart > send); identity
     carries blastn's 3 printed decimals"""
@@ -238,9 +240,11 @@ def blast_hits_to_table(hits, cigar, q_names, r_names, q_len, r_len, min_id, min
         return HitTable.empty()
     q_len = np.asarray(q_len, dtype=np.int64)
     evalue = params.ka_k * q_len[hits['q'].astype(np.int64)] * params.dbsize * np.exp(-params.ka_lambda * hits['score'].astype(np.int64))
-    c, arena = N.table_from_hits(1, hits, cigar, q_len, r_len, min_id, min_cov, min_ratio, t_seq=t_seq, t_rev=t_rev, windows=windows, evalue=evalue)
-    return HitTable(_str_table(q_names), _str_table(r_names), c['qi'], c['ri'], c['iden'], c['aln'], c['mis'], c['gap'], c['qs'], c['qe'], c['ss'], c['se'],
-                    c['evalue'], c['score'], c['ql'], c['sl'], arena, c['c_off'], c['c_runs'], rid=c['rid'])
+    c, arena = N.table_from_hits(1, hits, cigar, q_len, r_len, min_id, min_cov, min_ratio, t_seq=t_seq, t_rev=t_rev, windows=windows, evalue=evalue, nt_match=nt_match)
+    T = HitTable(_str_table(q_names), _str_table(r_names), c['qi'], c['ri'], c['iden'], c['aln'], c['mis'], c['gap'], c['qs'], c['qe'], c['ss'], c['se'],
+                 c['evalue'], c['score'], c['ql'], c['sl'], arena, c['c_off'], c['c_runs'], rid=c['rid'], score_is_int=nt_match is None)
+    T.rescored = nt_match is not None
+    return T
 
 
 def blast_hits_to_blastab(hits, cigar, q_names, r_names, q_len, r_len, min_id, min_cov, min_ratio, params, t_seq, t_rev, windows=None):
@@ -373,7 +377,7 @@ class RunBlast(object):
             diamondself = lambda ref, qry: self.runDiamond(ref, qry, nhits=200, frames='F')
         return dict(blastn=blastn, diamond=diamond, diamondself=diamondself, gpu=diamond)
 
-    def _run_tools(self, methods, ref, qry, rescore=0):
+    def _run_tools(self, methods, ref, qry, rescore=0, nt_match=False):
         """the tools of one run in the order given.  A tool that fails is reported and the other tools' tables are kept - the reference's
         convention (uberBlast.py:347-349) - but never silently: `failed_tools` lists (tool, message) of this run, and a PEP_ERR_LIMIT
         (an input beyond a documented limit) is raised instead of costing a whole table.
@@ -383,13 +387,14 @@ class RunBlast(object):
         tables, self.failed_tools = [], []
         self._rescored_by_tools = False
         self._nucl_searched = None
+        self._want_nt_match = bool(nt_match) and os.environ.get('PEPPAN_NT_MATCH_IN_SEARCH', '1') != '0'       # (run_batch: every tool's table is rescored, mode 1)
         todo = [m for m in methods if m.lower() in tools]
 
         def attempt(method):
             """one tool -> ('ok', table) | ('limit', exception) | ('failed', method, message)"""
             try:
                 T = _as_table(tools[method.lower()](ref, qry))
-                if self._rescored_by_tools:
+                if self._rescored_by_tools and not T.rescored:
                     try:
                         ctx = get_nucl_context(self.device) if method.lower() == 'blastn' else get_context(self.device)
                         T = self._rescore_table(ref, qry, T, 1, None, self.table_id, cut=False, ctx=ctx)
@@ -418,6 +423,7 @@ class RunBlast(object):
             self._ensure_nt(get_nucl_context(self.device))
             k_side = names.index('blastn')
             self._rescored_by_tools = rescore == 1
+            self._want_nt_match = rescore == 1 and os.environ.get('PEPPAN_NT_MATCH_IN_SEARCH', '1') != '0'
             # Whose turn the GPU is.  The two searches together take the GPU as long side by side as one after the other (6.0 ms of kernels at 10 000 genes either
             # way), so what counts is which tool's host chain starts first: the nucleotide tool has the longer one behind its search (table 1.6 + K7 1.1 ms against
             # 0.55 + 1.0), so its search goes first and the translated search starts when it is back - the nucleotide table is then built while the translated search
@@ -553,13 +559,14 @@ class RunBlast(object):
         self.refSeq, self._batch = combined, (names, groups)
         genome_of = dict(zip(names, groups))
         with _gpu_gate():
-            tables = self._run_tools(methods, None, None)
+            tables = self._run_tools(methods, None, None, nt_match=re_score == 1)
         # mode-1 rescoring is a function of the row alone: K7 once per tool over the rows of ALL genomes (a launch and a round trip per genome
         # otherwise: 84 us of GPU and a synchronisation each, sixteen times per batch), the identity cut stays with the genome's table (_post)
         batch_rescore = re_score == 1
         if batch_rescore:
             for T in tables:
-                self._rescore_table(None, None, T, 1, None, table_id, cut=False)
+                if not T.rescored:                # (a built-in tool's table comes rescored: its search counted the identical columns, _search)
+                    self._rescore_table(None, None, T, 1, None, table_id, cut=False)
         # rows by genome (the reference set of a row's reference sequence): the tools' tables are put one behind the other ONCE per batch - their
         # name tables are the same objects, their arenas end up side by side - and a genome takes its rows of every tool, in tool and table order, with one
         # gather (a gather per tool and a concatenation per genome copied both tools' whole CIGAR arenas sixteen times per batch)
@@ -640,6 +647,20 @@ class RunBlast(object):
     def runBlast(self, ref, qry):
         return self._runBlast_table(ref, qry).to_rows(with_rid=False)
 
+    def _search(self, ctx, params):
+        """ctx.search for a tool of this run -> (hits, cigar, stats, nt_match).  With -s 1 (`_want_nt_match`, set by the run) the search also counts the identical
+        nucleotide columns of every hit - K7's one count that needs the sequences, from the table on the device, inside the search's own wait - and the table
+        builder turns them into the rescored identity and score: no second upload of the table, no K7 round trip, no pass of numpy expressions per tool"""
+        want = bool(getattr(self, '_want_nt_match', False)) and hasattr(ctx, 'set_nt_match')       # (the CPU tests' oracle-backed context has no such switch: K7 afterwards, as before)
+        if not want:
+            return ctx.search(params, copy=False) + (None,)
+        ctx.set_nt_match(True)
+        try:
+            hits, cigar, stats = ctx.search(params, copy=False)
+        finally:
+            ctx.set_nt_match(False)
+        return hits, cigar, stats, (ctx.last_nt_match if len(hits) else np.zeros(0, np.uint32))
+
     def _runDiamond_table(self, ref, qry, nhits=10, frames='7'):
         """translated search on the GPU: K1 translate/pack, K2-K4 seeds, K5/K6 banded Smith-Waterman + traceback,
         K8 filters/top-k; thresholds as on the reference's diamond command line (uberBlast.py:550)"""
@@ -652,9 +673,9 @@ class RunBlast(object):
         ctx.translate()                                                # (K1; a nucleotide search before this one left base codes in the packed sets)
         if getattr(self, '_nucl_searched', None) is not None:
             self._nucl_searched.wait()                                 # (_run_tools: the nucleotide tool's search goes first)
-        hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
+        hits, cigar, stats, nt_match = self._search(ctx, params)       # consumed at once by the table builder below
         table = hits_to_table(hits, cigar, ctx.query_meta(), ctx.target_meta(), self._q_tab, self._r_tab, self._q_len, self._r_len,
-                              self.min_id, self.min_cov, self.min_ratio)
+                              self.min_id, self.min_cov, self.min_ratio, nt_match=nt_match)
         table.q_sorted, table.r_sorted = self._q_sorted, self._r_sorted
         self.last_stats = stats
         logger('Run diamond finishes. Got {0} alignments'.format(len(table)))
@@ -676,12 +697,12 @@ class RunBlast(object):
             # search (forward strands, then reverse complements, per reference set) - no encoding, concatenation or upload on the host
             self._ensure_nt(ctx)
             ctx.use_nt_as_residues(2)
-            hits, cigar, stats = ctx.search(params, copy=False)            # consumed at once by the table builder below
+            hits, cigar, stats, nt_match = self._search(ctx, params)       # consumed at once by the table builder below
             if getattr(self, '_nucl_searched', None) is not None:
                 self._nucl_searched.set()                                  # (_run_tools: the translated tool's search may start)
             tm = ctx.target_meta()
             table = blast_hits_to_table(hits, cigar, self._q_tab, self._r_tab, self._q_len, self._r_len, self.min_id, self.min_cov, self.min_ratio, params,
-                                        tm['seq'].astype(np.int64), tm['frame'] > 3)
+                                        tm['seq'].astype(np.int64), tm['frame'] > 3, nt_match=nt_match)
             table.q_sorted, table.r_sorted = self._q_sorted, self._r_sorted
             logger('Run BLASTn finishes. Got {0} alignments'.format(len(table)))
             return table

@@ -1853,3 +1853,63 @@ def test_blast_hsp_mode_2_equals_the_oracle(ctx):
     oh, oc, ost = O.search(codes[:20], targets, O.params_from(p), min_scores=ms)
     _cmp_hits(gh, gc, oh, oc)
     assert ((gh['q'] == 0) & (gh['t'] == 0) & (gh['q_end'] - gh['q_start'] > 0.9 * len(codes[0]))).sum() == 2       # both copies of gene 0 stay: neither lies inside the other
+
+
+@pytest.mark.gpu
+def test_rescoring_inside_the_search_equals_k7_behind_it(tmp_path, monkeypatch):
+    """-s 1 (reScore mode 1, uberBlast.py:397-415).  The product has the search count K7's identical nucleotide columns for its own hits from the table on the
+    device (pep_set_nt_match) and pep_table_from_hits make identity and score from them; PEPPAN_NT_MATCH_IN_SEARCH=0 is the chain as it was - table built, uploaded
+    again, K7 (pep_rescore_nt), numpy arithmetic.  Same tables, cell for cell: the hot call's shape (genes against themselves and their mutated relatives, both
+    tools side by side), and the mapping's (genes against genomes in one batch: both strands, frames cut into chunks at stop codons - chunk offsets -, contigs with
+    N runs and lower-case stretches - K7's 'other' code -, gaps of one to several codons)"""
+    import io, contextlib
+    from peppan_amd import uberBlast as UB, synth, configure
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(41)
+    names, seqs = synth.make_genes(120, 0, seed=23, family=4)
+    seqs = [bytearray(s) for s in seqs]
+    for s in seqs[::7]:                                      # N runs and lower-case stretches inside genes
+        a = int(rng.integers(30, len(s) - 60))
+        s[a:a + int(rng.integers(1, 9))] = b'N' * 8
+        b = int(rng.integers(30, len(s) - 60))
+        s[b:b + 25] = bytes(s[b:b + 25]).lower()
+    seqs = [bytes(s) for s in seqs]
+    _write_fasta('genes.fa', [str(i) for i in range(len(seqs))], seqs)
+
+    def mutated(s):                                          # substitutions, a deleted codon or two, an inserted base triple
+        s = bytearray(s.upper())
+        for k in rng.integers(0, len(s), max(1, len(s) // 25)):
+            s[k] = b'ACGT'[int(rng.integers(0, 4))]
+        a = int(rng.integers(60, len(s) - 60))
+        del s[a:a + 3 * int(rng.integers(1, 3))]
+        b = int(rng.integers(60, len(s) - 60))
+        s[b:b] = b'GCA' * int(rng.integers(1, 3))
+        return bytes(s)
+    spacer = lambda: bytes(rng.choice(list(b'ACGTN'), int(rng.integers(40, 300)), p=[.24, .24, .24, .24, .04]).tolist())
+    genomes = []
+    for g in range(3):
+        contigs, cur = [], spacer()
+        for k in rng.permutation(len(seqs))[:60]:
+            s = mutated(seqs[k]) if rng.random() < 0.6 else seqs[k]
+            if rng.random() < 0.5:
+                s = configure.rc(s.decode()).encode()
+            cur += s + spacer()
+            if rng.random() < 0.1:
+                contigs.append(cur); cur = spacer()
+        contigs.append(cur)
+        _write_fasta('genome%d.fa' % g, ['%d:c%d' % (g, i) for i in range(len(contigs))], contigs)
+        genomes.append('genome%d.fa' % g)
+    hot = '-r genes.fa -q genes.fa --blastn --diamond -s 1 --min_id 0.45 --min_cov 50 -t 2 --min_ratio 0.25 -e 3,3 -p --gtable 11'.split()
+    mapping = '-q genes.fa -f -m -O --blastn --diamond --min_id 0.4 --min_cov 50 --min_ratio 0.25 --merge_gap 600 --merge_diff 1.5 -t 1 -s 1 -e 0,3 --gtable 11'.split()
+    out = {}
+    with contextlib.redirect_stderr(io.StringIO()):
+        for mode in ('1', '0'):
+            monkeypatch.setenv('PEPPAN_NT_MATCH_IN_SEARCH', mode)
+            out[mode] = (UB.uberBlast(hot), UB.uberBlastBatch(genomes, mapping), UB.uberBlast(['-r', genomes[0]] + mapping))
+    (h1, b1, s1), (h0, b0, s0) = out['1'], out['0']
+    assert h1.shape[0] > 300 and h1.tolist() == h0.tolist()
+    assert len({r[2] for r in h1.tolist()}) > 30                       # (identities of many values: the relatives are mutated)
+    for (t1, o1), (t0, o0) in zip(b1 + [s1], b0 + [s0]):
+        assert t1.shape[0] > 50 and t1.tolist() == t0.tolist() and o1.tolist() == o0.tolist()
+    assert any(r[8] > r[9] for t, _ in b1 for r in t.tolist()) and any(r[8] < r[9] for t, _ in b1 for r in t.tolist())      # both strands
+    assert any('I' in r[14] or 'D' in r[14] for t, _ in b1 for r in t.tolist())                                             # gapped alignments among them
