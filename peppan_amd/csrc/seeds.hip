@@ -485,7 +485,9 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
                 const uint32_t b = hash_u64(key, a.bucket_bits);
                 uint32_t word;
                 const uint64_t m = filter_mask(key, a.bucket_bits, word);
-                if ((a.filter[word] & m) == m) { e0 = a.start[b]; e1 = a.start[b + 1]; }
+                // (a position inside a stretch that repeats a query holds that query's key: it is in the index, the filter's word need not be asked - the filter only ever
+                // saves look-ups, so a block that is marked beyond the stretch's end costs a look-up and nothing else; debug 11: ask anyway, for comparison)
+                if ((sd != PEP_SELF_NO_DELTA && a.debug != 11) || (a.filter[word] & m) == m) { e0 = a.start[b]; e1 = a.start[b + 1]; }
                 if (a.debug == 2) { n_hit += e1 - e0; e1 = e0; }
             }
         }
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
             const uint32_t b = hash_u64(key, a.bucket_bits);
             uint32_t word;
             const uint64_t m = filter_mask(key, a.bucket_bits, word);
-            if ((a.filter[word] & m) == m) { e0 = a.start[b]; e1 = a.start[b + 1]; }
+            if ((sd != PEP_SELF_NO_DELTA && a.debug != 11) || (a.filter[word] & m) == m) { e0 = a.start[b]; e1 = a.start[b + 1]; }      // (as in seed_match: a self stretch's keys are in the index)
         }
         const uint32_t tl = d0, tr = (d4 >> 16) | (d5 << 16);           // target bytes p - 4 .. p - 1 and p + 14 .. p + 17
         for (uint32_t e = e0; e < e1; e += 2) {
@@ -1091,7 +1093,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
     // count -> scan -> fill build, as does a coarse bucket that overflows LDS)
     const int fine_bits = std::min(12, bucket_bits - 8);
     // the nucleotide tool (exact 17-mers over the four bases, one shape): look-up words at a stride (seed_match_stride); reserved[0] = 8 keeps the plain matcher
-    bool stride_lookup = P.n_shapes == 1 && P.base == 4 && P.weight[0] == NW && P.reserved[0] == 0;
+    bool stride_lookup = P.n_shapes == 1 && P.base == 4 && P.weight[0] == NW && (P.reserved[0] == 0 || P.reserved[0] == 11);
     for (int i = 0; i < NW && stride_lookup; ++i) stride_lookup = P.offs[0][i] == i;
     for (int c = 0; c < 32 && stride_lookup; ++c) stride_lookup = P.reduce[c] == (c < 4 ? c : 0xFF);
     bool use_partition = P.reserved[2] == 0 && bucket_bits >= 16 && bucket_bits - fine_bits <= 13;
@@ -1204,7 +1206,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
             a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.stage1_min = P.stage1_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
             a.self_delta = nullptr;
-            if (s == 0 && P.ungapped_min > 0 && P.reserved[0] == 0) PEP_TRY(pep_self_map(ctx, &self_on));     // (reserved[0] = 10 / 8: the plain stream, for comparison)
+            if (s == 0 && P.ungapped_min > 0 && (P.reserved[0] == 0 || P.reserved[0] == 11)) PEP_TRY(pep_self_map(ctx, &self_on));     // (reserved[0] = 10 / 8: the plain stream, for comparison)
             if (self_on) a.self_delta = ctx->d_self_delta.as<const int32_t>();
             unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(zero + PEP_ZERO_SHAPE) + 2 * s;      // per shape, cleared by the one fill
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
