@@ -487,6 +487,11 @@ int64_t pep_cols_fix_end(uint64_t n, pep_hit_cols *cols, const uint32_t *arena_i
  * score), stable; the codes are non-negative integers that sort like the names of columns 0 and 1 do (the caller ranks the name tables once). */
 int pep_cols_order(uint64_t n, const int64_t *q_code, const int64_t *r_code, const double *score, int64_t *order);
 
+/* order = numpy.lexsort(keys) for n_keys int64 key columns of n rows: stable, the LAST key the primary one - the sorts in front of RunBlast.ovlFilter (uberBlast.py:421:
+ * by reference, query, start, query start) and _linearMerge (:455) of every genome's table in the mapping path.  Radix passes over (key - its minimum); PEP_ERR_LIMIT
+ * when a key's range needs more than 44 bits (the caller sorts with numpy then). */
+int pep_lex_order(uint64_t n, int32_t n_keys, const int64_t *const *keys, int64_t *order);
+
 /* dst[c][k] = src[c][idx[k]] for n_cols columns of 8-byte elements (n_src rows each): the rows `idx` of a whole table in one call */
 int pep_cols_gather(int32_t n_cols, const void *const *src, void *const *dst, const int64_t *idx, uint64_t n_idx, uint64_t n_src);
 

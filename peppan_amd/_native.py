@@ -16,7 +16,7 @@ EXPORTS = ['pep_version', 'pep_device_count', 'pep_ctx_create', 'pep_ctx_destroy
            'pep_get_target_aa', 'pep_set_target_groups', 'pep_set_result_mode', 'pep_set_timing', 'pep_set_grouping', 'pep_result_labels', 'pep_invalidate_translation', 'pep_search', 'pep_result_size', 'pep_result_copy', 'pep_result_data', 'pep_result_device', 'pep_result_stats', 'pep_components_of_result', 'pep_result_free',
            'pep_merge_hits', 'pep_rescore_nt', 'pep_components', 'pep_components_of_hits', 'pep_linclust', 'pep_overlaps', 'pep_alleles', 'pep_ovl_filter', 'pep_known_order', 'pep_linear_merge', 'pep_sha1', 'pep_dedup',
            'pep_similar_classify', 'pep_similar_scan', 'pep_pair_support', 'pep_similar_resolve', 'pep_fasta_keep', 'pep_fasta_scan', 'pep_fasta_records', 'pep_store_mat_member', 'pep_store_seq_member', 'pep_store_tab_members', 'pep_store_tab_archive', 'pep_deflate_literals', 'pep_deflate_fast', 'pep_crc32', 'pep_pack_member', 'pep_argsort_object_order',
-           'pep_set_nt_match', 'pep_result_nt_match', 'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather', 'pep_set_host_threads']
+           'pep_set_nt_match', 'pep_result_nt_match', 'pep_table_from_hits', 'pep_cols_fix_end', 'pep_cols_order', 'pep_cols_gather', 'pep_lex_order', 'pep_set_host_threads']
 
 
 class PepError(RuntimeError):
@@ -489,6 +489,21 @@ def cols_fix_end(cols, arena, se_lim, ee_lim):
     if rc_ < 0:
         raise IndexError('fix_end: a row without CIGAR runs cannot be extended (the reference fails on cigar[0] here, uberBlast.py:468), or runs outside the arena')
     return out[:int(cols['c_runs'].sum()) if n else 0]
+
+
+def lex_order(keys):
+    """pep_lex_order: numpy.lexsort(keys) for int64 key columns (the last key is the primary one), by radix passes; numpy's own for keys it does not take"""
+    lib = load_library()
+    keys = [np.ascontiguousarray(k) for k in keys]
+    n = len(keys[0]) if keys else 0
+    if not keys or n < 64 or any(k.dtype != np.int64 or len(k) != n for k in keys):
+        return np.lexsort(keys)
+    order = np.empty(n, dtype=np.int64)
+    ptrs = (C.c_void_p * len(keys))(*[k.ctypes.data for k in keys])
+    rc_ = lib.pep_lex_order(C.c_uint64(n), C.c_int32(len(keys)), ptrs, _ptr(order))
+    if rc_ != 0:
+        return np.lexsort(keys)
+    return order
 
 
 def set_host_threads(n):

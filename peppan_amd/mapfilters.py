@@ -29,7 +29,7 @@ def ovl_filter_table(T, coverage, delta):
         return T
     ss, se = _folded(T)
     q, r = T.q_codes(), T.r_codes()
-    order = np.lexsort((T.qs, ss, q, r))
+    order = N.lex_order((T.qs, ss, q, r))                    # (= np.lexsort: radix passes in host C++)
     iden = T.iden[order].copy()
     N.ovl_filter(q[order], r[order], T.qs[order], T.qe[order], ss[order], se[order], T.score[order], iden, coverage, delta)
     return T.take(order[iden >= 0])
@@ -46,7 +46,7 @@ def linear_merge_table(T, gap_dist, len_diff):
         return T
     ss, se = _folded(T)
     q, r = T.q_codes(), T.r_codes()
-    first = np.lexsort((T.qs, ss, r, q))
+    first = N.lex_order((T.qs, ss, r, q))                    # (= np.lexsort)
     q = q[first]
     keep, q_off, asc, g_score, g_iden, g_span, ids_off, ids = N.linear_merge(q, r[first], T.iden[first], T.qs[first], T.qe[first], ss[first], se[first],
                                                                               T.score[first], T.ql[first], T.sl[first], T.rid[first], gap_dist, len_diff)
@@ -80,7 +80,8 @@ def _intervals(T):
     last = np.zeros(int(T.ri.max()) + 1, dtype=np.int64)
     np.maximum.at(last, T.ri, np.arange(n))
     lo, hi, cid = np.minimum(T.ss, T.se), np.maximum(T.ss, T.se), last[T.ri]
-    return np.stack([cid, T.rid, lo, hi], axis=1)[np.lexsort((hi, lo, cid))].astype(int)
+    from . import _native as N
+    return np.stack([cid, T.rid, lo, hi], axis=1)[N.lex_order((hi, lo, cid))].astype(int)
 
 
 def _swept(res, batch):

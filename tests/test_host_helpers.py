@@ -391,3 +391,19 @@ def test_host_chain_passes_do_not_depend_on_their_thread_count():
         q, r = rng.integers(0, q_hi, n_rows), rng.integers(0, r_hi, n_rows)
         score = rng.integers(0, 40, n_rows).astype(np.float64) / 4
         assert np.array_equal(N.cols_order(q, r, score), np.lexsort((score, r, q))), (n_rows, q_hi, r_hi)
+
+
+def test_lex_order_equals_numpy_lexsort():
+    """pep_lex_order (the sorts in front of -f and -m, uberBlast.py:421, 455): numpy.lexsort's order for int64 keys - ties, constant keys, negative values, a handful of
+    rows and 100 000, a key whose range is beyond the radix passes (numpy's sort takes over), a key that is not int64"""
+    from peppan_amd import _native as N
+    rng = np.random.default_rng(8)
+    for n in (0, 1, 63, 64, 1000, 12000, 100000):
+        for trial in range(3):
+            q, r = rng.integers(0, 10000 if trial else 3, n), rng.integers(0, 3, n)
+            ss, qs = rng.integers(-2200000, 2200000, n), rng.integers(1, 1000 if trial < 2 else 2, n)
+            assert np.array_equal(N.lex_order((qs, ss, q, r)), np.lexsort((qs, ss, q, r))), n
+            assert np.array_equal(N.lex_order((qs, ss, r, q)), np.lexsort((qs, ss, r, q))), n
+            wide = rng.integers(-2 ** 50, 2 ** 50, n)
+            assert np.array_equal(N.lex_order((qs, wide, q)), np.lexsort((qs, wide, q))), n
+            assert np.array_equal(N.lex_order((qs.astype(np.float64), q)), np.lexsort((qs.astype(np.float64), q))), n
