@@ -305,6 +305,7 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
             return np.fromiter(map(int, tab), dtype=np.int64, count=len(tab))           # (a quarter of the time of numpy's own text -> integer conversion of a str array)
         q_ids = as_ids(T.q_tab)
         r_ids = q_ids if T.r_tab is T.q_tab else as_ids(T.r_tab)
+        mark('ids')
         seen_q, seen_r = np.zeros(len(q_ids), dtype=bool), np.zeros(len(r_ids), dtype=bool)
         seen_q[T.qi] = True
         seen_r[T.ri] = True
@@ -312,6 +313,7 @@ def get_similar_pairs(clust, priorities, params, pool=None, ctx=None, timing=Non
         q, r = np.searchsorted(genes, q_ids)[T.qi], np.searchsorted(genes, r_ids)[T.ri]
         rank = np.array(list(map(itemgetter(0), map(priorities.__getitem__, genes.tolist()))))
         rank_q, rank_r = rank[q], rank[r]
+        mark('codes')
         action, forward, iden4 = N.similar_classify(T, q, r, rank_q >= rank_r, rank_q <= rank_r, params['clust_identity'], params['clust_match_prop'])
         mark('classify')
         sc = N.similar_scan(q, r, action, forward, iden4, len(genes))
