@@ -6,7 +6,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpeppan_hip.so')
+LIB_PATH = os.environ.get('PEPPAN_HIP_LIB') or os.path.join(_HERE, 'libpeppan_hip.so')      # (PEPPAN_HIP_LIB: a measurement build of the library, tools/ab only)
 
 ABI_VERSION = 16
 MAX_SEQ_LEN = (1 << 23) - 256          # PEP_MAX_SEQ_LEN: longest single sequence of a packed set

@@ -286,7 +286,8 @@ void dev_release(DevBuf &b);
 #define PEP_ZERO_SW_SCORE (PEP_ZERO_SORT + 8 * 2048 * 4)
 #define PEP_ZERO_SW_TRACE (PEP_ZERO_SW_SCORE + PEP_ZERO_SW_BYTES)
 #define PEP_ZERO_SELECT (PEP_ZERO_SW_TRACE + PEP_ZERO_SW_BYTES)  // 256 B: counters of the selection stage (trace.hip)
-#define PEP_ZERO_TOTAL (PEP_ZERO_SELECT + 256)
+#define PEP_ZERO_TILES (PEP_ZERO_SELECT + 256)                  // 4 x 8 x 128 B: the matchers' tile claims per seed shape: eight counters, a cache line each (seeds.hip: TileClaims)
+#define PEP_ZERO_TOTAL (PEP_ZERO_TILES + 4 * 8 * 128)
 enum { PEP_ZC_SW_SCORE = 0, PEP_ZC_SW_TRACE, PEP_ZC_SELECT, PEP_ZC_SORT };
 // the block of consumer `which` (PEP_ZC_*), zeroed: taken from the search's one fill when it is still untouched, cleared here otherwise
 int pep_zero_block(pep_ctx *ctx, int which, size_t offset, size_t bytes, void **out);

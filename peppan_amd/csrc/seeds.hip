@@ -409,6 +409,9 @@ struct JoinArgs {
     unsigned long long *hit_count;
     uint64_t hit_cap;
     int debug;               // profiling aid (params.reserved[0]): 1 = keys only, 2 = keys + bucket lookup, 3 = + entry compare (no extension), 9 = no wave-level de-duplication
+    unsigned int *tile_ctr;      // the matchers' tile claims (TileClaims): tile_groups counters, 128 bytes apart, zero when the launch starts
+    uint32_t tile_groups;        // 8 (a launch of 64 blocks and more: block b claims from counter b mod 8 - neighbouring blocks go to different XCCs, a counter a group keeps the
+                                 // atomics of one word at a tenth of what it sustains) or 1
     const int32_t *self_delta;   // self-search (pep_self_map): per 32-byte block of the targets, target position - query position of the hits that are a gene against itself on
                                  // diagonal 0 (PEP_SELF_NO_DELTA: none); nullptr = off.  Such hits are counted and dropped: self_prepare has settled their candidate.
 };
@@ -446,11 +449,62 @@ __device__ __forceinline__ bool set_contains(const JoinArgs &a, uint64_t k)
 // (the ungapped x-drop extension itself - BLOSUM62 along the diagonal through a seed hit, on PACKED positions: the >= 16 padding bytes around every
 // sequence score -64, which ends an extension exactly where the sequence ends (x-drop < 64), so no bounds are needed - lives in seed_extend below)
 
-// Phase 1 of the join (persistent, grid-stride over 256-position tiles): target seed keys are looked up in the
+// Which tiles a block of a matcher works on: claims of TILE_CLAIM consecutive tiles, handed out by atomic counters - group g of the blocks (block number mod tile_groups)
+// owns the claims g, g + tile_groups, ... and counts through them.  A claim is asked for one claim AHEAD (when the block starts the claim in front) and looked at when that
+// claim's last tile has been staged, so the atomic's round trip is never waited for alone.  Every member function is called by all threads of the block.
+constexpr uint32_t TILE_CLAIM = 4;
+struct TileClaims {
+    const JoinArgs &a;
+    const uint64_t n_tiles;
+    const uint32_t grp;
+    unsigned int *ctr;
+    uint32_t ahead = 0;              // thread 0: the answer to the claim that is in flight
+    uint64_t end = 0;                // one behind the last tile of the claim the block is in
+    bool asked = false;
+    uint32_t turn = 0;               // which of the two slots the claim behind this one is handed over in (two: a slot is written again only after a barrier that every reader of its last value has passed)
+    __device__ TileClaims(const JoinArgs &args, uint64_t tiles) : a(args), n_tiles(tiles), grp(args.tile_groups > 1 ? blockIdx.x % args.tile_groups : 0u), ctr(args.tile_ctr + 32u * grp) {}
+    __device__ uint64_t first_tile_of(uint32_t j) const { return ((uint64_t)j * a.tile_groups + grp) * TILE_CLAIM; }
+    __device__ uint64_t first()
+    {
+        __shared__ uint32_t s_first;
+        if (threadIdx.x == 0) s_first = atomicAdd(ctr, 1u);
+        __syncthreads();
+        const uint64_t t = first_tile_of(s_first);
+        end = min(t + TILE_CLAIM, n_tiles);
+        return t;
+    }
+    // in front of the barrier that follows the staging of `tile`
+    __device__ void before_barrier(uint64_t tile)
+    {
+        if (!asked) { if (threadIdx.x == 0) ahead = atomicAdd(ctr, 1u); asked = true; }
+        if (tile + 1 == end && threadIdx.x == 0) slot()[turn] = ahead;
+    }
+    // behind that barrier: the tile that follows `tile` for this block (>= n_tiles: none)
+    __device__ uint64_t next(uint64_t tile)
+    {
+        if (tile + 1 != end) return tile + 1;
+        const uint64_t t = first_tile_of(slot()[turn]);
+        end = min(t + TILE_CLAIM, n_tiles);
+        asked = false;
+        turn ^= 1u;
+        return t;
+    }
+    __device__ static uint32_t *slot() { __shared__ uint32_t s_claim[2]; return s_claim; }
+};
+
+// Phase 1 of the join (persistent over 256-position tiles, claimed four at a time): target seed keys are looked up in the
 // query index and every equal-key pair is appended as a raw seed hit (qpos << 32 | tpos).  Hits are staged in an
 // LDS buffer and flushed with ONE global atomic per flush (a single global counter word only sustains ~90
 // atomics/us).  Every memory operation of this phase is independent across lanes: high memory-level parallelism.
-constexpr int HIT_BUF = 2048;
+#ifndef PEP_HIT_BUF
+#define PEP_HIT_BUF 2048
+#endif
+#ifdef PEP_PROBES
+// MEASUREMENT ONLY (make PROBES=1; tools/ab/block_times.py): when and where every block of the last seed_match launch ran - start and end on the device's wall clock,
+// the hardware id of the wavefront that wrote them (compute unit, shader engine, XCC)
+__device__ unsigned long long g_block_probe[4 * 2048];
+#endif
+constexpr int HIT_BUF = PEP_HIT_BUF;          // (make EXTRA=-DPEP_HIT_BUF=1024: a measurement build - how many of the matcher's blocks a CU holds at once is a matter of this buffer)
 template <int W>
 __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
 {
@@ -459,26 +513,41 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
     __shared__ uint32_t nbuf, blk_stats[2];
     __shared__ unsigned long long gbase;
     if (threadIdx.x == 0) { nbuf = 0; blk_stats[0] = blk_stats[1] = 0; }
+#ifdef PEP_PROBES
+    if (threadIdx.x == 0 && blockIdx.x < 2048) {
+        g_block_probe[4 * blockIdx.x] = wall_clock64();
+        g_block_probe[4 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 20) << 32) | __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);      // XCC_ID | HW_ID
+    }
+#endif
     __syncthreads();
     uint32_t n_seed = 0, n_hit = 0;
     const uint64_t n_tiles = (a.t_total + 255) / 256;
-    // the residues of the NEXT tile are fetched into a register while this one is processed: a block walks ~60 tiles one after the
+    // The tiles are CLAIMED, TILE_CLAIM consecutive ones at a time (TileClaims above), not dealt out by block number: the launch asks for as many blocks as the chip
+    // holds at once (eight per compute unit), but which unit a block lands on is the dispatcher's business - on most boxes of the pool it gives some units nine to
+    // eleven of these blocks and others seven, and the blocks beyond a unit's eighth start when its first ones END.  With a fixed share of the tiles per block those
+    // late blocks (an eighth of all) made the launch half as long again (324 us against 183 us for the blocks that started at once, profiles/r06_block_times.txt);
+    // a block that starts late now finds what is left.
+    TileClaims claims(a, n_tiles);
+    uint64_t tile = claims.first();
+    // the residues of the NEXT tile are fetched into a register while this one is processed: a block walks ~40 tiles one after the
     // other, and without this every tile starts with an exposed global-memory latency
-    uint32_t fetched = blockIdx.x < n_tiles ? fetch_tile(a.t_res, blockIdx.x, a.t_total) : 0u;
+    uint32_t fetched = tile < n_tiles ? fetch_tile(a.t_res, tile, a.t_total) : 0u;
     // (self-search: the block's distance word rides along with the residues - eight distinct words per tile, one request per wavefront)
-    int32_t sd_next = (a.self_delta && blockIdx.x < n_tiles) ? a.self_delta[((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 5] : PEP_SELF_NO_DELTA;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    int32_t sd_next = (a.self_delta && tile < n_tiles) ? a.self_delta[(tile * 256 + threadIdx.x) >> 5] : PEP_SELF_NO_DELTA;
+    while (tile < n_tiles) {
         const uint64_t p = tile * 256 + threadIdx.x;
         uint64_t key = 0;
         uint32_t e0 = 0, e1 = 0;
         const int32_t sd = sd_next;
         red[threadIdx.x] = reduce_letter(sh, fetched);
         if (threadIdx.x < TILE_HALO) red[TILE + threadIdx.x] = reduce_letter(sh, fetched >> 8);
-        if (tile + gridDim.x < n_tiles) {
-            fetched = fetch_tile(a.t_res, tile + gridDim.x, a.t_total);
-            if (a.self_delta) sd_next = a.self_delta[((tile + gridDim.x) * 256 + threadIdx.x) >> 5];
-        }
+        claims.before_barrier(tile);
         __syncthreads();
+        const uint64_t next_tile = claims.next(tile);          // (block-uniform; >= n_tiles: this is the block's last tile)
+        if (next_tile < n_tiles) {
+            fetched = fetch_tile(a.t_res, next_tile, a.t_total);
+            if (a.self_delta) sd_next = a.self_delta[(next_tile * 256 + threadIdx.x) >> 5];
+        }
         if (p + 32 <= a.t_total && tile_key<W>(sh, red, threadIdx.x, key)) {
             ++n_seed;
             if (a.debug != 1) {
@@ -487,7 +556,11 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
                 const uint64_t m = filter_mask(key, a.bucket_bits, word);
                 // (a position inside a stretch that repeats a query holds that query's key: it is in the index, the filter's word need not be asked - the filter only ever
                 // saves look-ups, so a block that is marked beyond the stretch's end costs a look-up and nothing else; debug 11: ask anyway, for comparison)
-                if ((sd != PEP_SELF_NO_DELTA && a.debug != 11) || (a.filter[word] & m) == m) { e0 = a.start[b]; e1 = a.start[b + 1]; }
+                if ((sd != PEP_SELF_NO_DELTA && a.debug != 11) || (a.filter[word] & m) == m) {
+                    // (both ends of the bucket with ONE 8-byte request - the two words lie side by side, and what this kernel pays for is requests; debug 12: two loads, for comparison)
+                    if (a.debug == 12) { e0 = a.start[b]; e1 = a.start[b + 1]; }
+                    else { uint32_t ends[2]; __builtin_memcpy(ends, a.start + b, 8); e0 = ends[0]; e1 = ends[1]; }
+                }
                 if (a.debug == 2) { n_hit += e1 - e0; e1 = e0; }
             }
         }
@@ -515,7 +588,7 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
         }
         __syncthreads();
         const uint32_t cnt = nbuf;                   // block-uniform after the barrier
-        if (cnt > HIT_BUF / 2 || tile + gridDim.x >= n_tiles) {
+        if (cnt > HIT_BUF / 2 || next_tile >= n_tiles) {
             const uint32_t n = min(cnt, (uint32_t)HIT_BUF);
             if (threadIdx.x == 0) gbase = n ? atomicAdd(a.hit_count, (unsigned long long)n) : 0ull;
             __syncthreads();
@@ -527,6 +600,7 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
             if (threadIdx.x == 0) nbuf = 0;
             __syncthreads();
         }
+        tile = next_tile;
     }
     for (int d = 32; d > 0; d >>= 1) {
         n_seed += __shfl_down(n_seed, d, 64);
@@ -535,7 +609,17 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
     if ((threadIdx.x & 63) == 0) { atomicAdd(&blk_stats[0], n_seed); atomicAdd(&blk_stats[1], n_hit); }
     __syncthreads();
     if (threadIdx.x < 2 && blk_stats[threadIdx.x]) atomicAdd(&a.stats[threadIdx.x], (unsigned long long)blk_stats[threadIdx.x]);
+#ifdef PEP_PROBES
+    if (threadIdx.x == 0 && blockIdx.x < 2048) g_block_probe[4 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
+
+#ifdef PEP_PROBES
+extern "C" int pep_probe_block_times(unsigned long long *out)          // 4 words per block of the last seed_match launch: start, end, XCC_ID << 32 | HW_ID, unused
+{
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_probe), sizeof(g_block_probe)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ---- the nucleotide tool's matcher (round 6): BLAST's lookup stride (blastn -word_size 17 looks up shorter words at a stride and verifies them,
 // uberBlast.py:294).  The seeds are exact NW-mers over the four bases.  Every NW-mer holds exactly one NK-mer that starts at a packed position
@@ -584,25 +668,28 @@ __global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
     // this thread's dwords of the NEXT tile are fetched while the current one is worked on
     uint32_t f0 = 0, f1 = 0;
     int32_t sd_next = PEP_SELF_NO_DELTA;             // self-search: the distance word of this thread's probe position rides along (JoinArgs::self_delta)
-    if (blockIdx.x < n_tiles) {
-        const int64_t g0 = (int64_t)blockIdx.x * (NTILE / 4) - 1;
+    TileClaims claims(a, n_tiles);                   // (the tiles are claimed four at a time, as seed_match's are: a block that the dispatcher starts late finds what is left)
+    uint64_t tile = claims.first();
+    if (tile < n_tiles) {
+        const int64_t g0 = (int64_t)tile * (NTILE / 4) - 1;
         f0 = nt_fetch(a.t_res, g0 + x, a.t_total);
         if (x < 8) f1 = nt_fetch(a.t_res, g0 + 256 + x, a.t_total);
-        if (a.self_delta) sd_next = a.self_delta[((uint64_t)blockIdx.x * NTILE + 4u * x) >> 5];
+        if (a.self_delta) sd_next = a.self_delta[(tile * NTILE + 4u * x) >> 5];
     }
-    int turn = 0;
-    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, turn ^= 1) {
+    for (int turn = 0; tile < n_tiles; turn ^= 1) {
         uint32_t *w = win[turn];
         w[x] = f0;
         if (x < 8) w[256 + x] = f1;
         const int32_t sd = sd_next;
-        if (tile + gridDim.x < n_tiles) {
-            const int64_t g0 = (int64_t)(tile + gridDim.x) * (NTILE / 4) - 1;
+        claims.before_barrier(tile);
+        __syncthreads();
+        const uint64_t next_tile = claims.next(tile);          // (block-uniform; >= n_tiles: this is the block's last tile)
+        if (next_tile < n_tiles) {
+            const int64_t g0 = (int64_t)next_tile * (NTILE / 4) - 1;
             f0 = nt_fetch(a.t_res, g0 + x, a.t_total);
             if (x < 8) f1 = nt_fetch(a.t_res, g0 + 256 + x, a.t_total);
-            if (a.self_delta) sd_next = a.self_delta[((tile + gridDim.x) * NTILE + 4u * x) >> 5];
+            if (a.self_delta) sd_next = a.self_delta[(next_tile * NTILE + 4u * x) >> 5];
         }
-        __syncthreads();
         const uint32_t p = (uint32_t)(tile * NTILE) + 4u * x;            // the probe: packed target position, = 0 (mod NS)
         const uint32_t d0 = w[x], d1 = w[x + 1], d2 = w[x + 2], d3 = w[x + 3], d4 = w[x + 4], d5 = w[x + 5];      // bytes p - 4 .. p + 19
         const uint32_t inv = nt_bad4(d1) | (nt_bad4(d2) << 4) | (nt_bad4(d3) << 8) | (nt_bad4(d4) << 12) | (nt_bad4(d5) << 16);
@@ -616,7 +703,10 @@ __global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
             const uint32_t b = hash_u64(key, a.bucket_bits);
             uint32_t word;
             const uint64_t m = filter_mask(key, a.bucket_bits, word);
-            if ((sd != PEP_SELF_NO_DELTA && a.debug != 11) || (a.filter[word] & m) == m) { e0 = a.start[b]; e1 = a.start[b + 1]; }      // (as in seed_match: a self stretch's keys are in the index)
+            if ((sd != PEP_SELF_NO_DELTA && a.debug != 11) || (a.filter[word] & m) == m) {      // (as in seed_match: a self stretch's keys are in the index; one request for both ends of the bucket)
+                if (a.debug == 12) { e0 = a.start[b]; e1 = a.start[b + 1]; }
+                else { uint32_t ends[2]; __builtin_memcpy(ends, a.start + b, 8); e0 = ends[0]; e1 = ends[1]; }
+            }
         }
         const uint32_t tl = d0, tr = (d4 >> 16) | (d5 << 16);           // target bytes p - 4 .. p - 1 and p + 14 .. p + 17
         for (uint32_t e = e0; e < e1; e += 2) {
@@ -659,7 +749,7 @@ __global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
         }
         __syncthreads();
         const uint32_t cnt = nbuf;
-        if (cnt > HIT_BUF / 2 || tile + gridDim.x >= n_tiles) {
+        if (cnt > HIT_BUF / 2 || next_tile >= n_tiles) {
             const uint32_t n = min(cnt, (uint32_t)HIT_BUF);
             if (threadIdx.x == 0) gbase = n ? atomicAdd(a.hit_count, (unsigned long long)n) : 0ull;
             __syncthreads();
@@ -671,6 +761,7 @@ __global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
             if (threadIdx.x == 0) nbuf = 0;
             __syncthreads();
         }
+        tile = next_tile;
     }
     for (int d = 32; d > 0; d >>= 1) {
         n_seed += __shfl_down(n_seed, d, 64);
@@ -1093,7 +1184,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
     // count -> scan -> fill build, as does a coarse bucket that overflows LDS)
     const int fine_bits = std::min(12, bucket_bits - 8);
     // the nucleotide tool (exact 17-mers over the four bases, one shape): look-up words at a stride (seed_match_stride); reserved[0] = 8 keeps the plain matcher
-    bool stride_lookup = P.n_shapes == 1 && P.base == 4 && P.weight[0] == NW && (P.reserved[0] == 0 || P.reserved[0] == 11);
+    bool stride_lookup = P.n_shapes == 1 && P.base == 4 && P.weight[0] == NW && (P.reserved[0] == 0 || P.reserved[0] == 11 || P.reserved[0] == 12);
     for (int i = 0; i < NW && stride_lookup; ++i) stride_lookup = P.offs[0][i] == i;
     for (int c = 0; c < 32 && stride_lookup; ++c) stride_lookup = P.reduce[c] == (c < 4 ? c : 0xFF);
     bool use_partition = P.reserved[2] == 0 && bucket_bits >= 16 && bucket_bits - fine_bits <= 13;
@@ -1206,7 +1297,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
             a.q_res = Q.res.as<const uint8_t>(); a.sub = ctx->d_params.as<const int8_t>();
             a.debug = P.reserved[0]; a.ungapped_min = P.ungapped_min; a.stage1_min = P.stage1_min; a.xdrop = P.xdrop; a.ext_right = P.ext_right; a.ext_left = P.ext_left;
             a.self_delta = nullptr;
-            if (s == 0 && P.ungapped_min > 0 && (P.reserved[0] == 0 || P.reserved[0] == 11)) PEP_TRY(pep_self_map(ctx, &self_on));     // (reserved[0] = 10 / 8: the plain stream, for comparison)
+            if (s == 0 && P.ungapped_min > 0 && (P.reserved[0] == 0 || P.reserved[0] == 11 || P.reserved[0] == 12)) PEP_TRY(pep_self_map(ctx, &self_on));     // (reserved[0] = 10 / 8: the plain stream, for comparison)
             if (self_on) a.self_delta = ctx->d_self_delta.as<const int32_t>();
             unsigned long long *hit_count = reinterpret_cast<unsigned long long *>(zero + PEP_ZERO_SHAPE) + 2 * s;      // per shape, cleared by the one fill
             a.hits = ctx->ws[8].as<uint64_t>(); a.hit_count = hit_count; a.hit_cap = hit_cap;
@@ -1219,8 +1310,16 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
                 PEP_HIP(ctx, hipGetLastError());
             }
             pep_timer_begin(ctx, TM_MATCH0 + s);
-            if (stride_lookup) hipLaunchKernelGGL(seed_match_stride, dim3((unsigned)std::min<uint64_t>(ceil_div(T.total, NTILE), 256u * 8u)), dim3(256), 0, ctx->stream, a);
-            else PEP_SEED_DISPATCH(seed_match, dim3(std::min(tb, 256u * 8u)), sh, a);
+            a.tile_ctr = reinterpret_cast<unsigned int *>(zero + PEP_ZERO_TILES) + (size_t)s * 8 * 32;          // (cleared by the search's one fill)
+            if (stride_lookup) {
+                const unsigned grid = (unsigned)std::min<uint64_t>(ceil_div(T.total, NTILE), 256u * 8u);
+                a.tile_groups = grid >= 64 ? 8u : 1u;
+                hipLaunchKernelGGL(seed_match_stride, dim3(grid), dim3(256), 0, ctx->stream, a);
+            } else {
+                const unsigned grid = std::min(tb, 256u * 8u);          // (with claimed tiles 8 .. 16 blocks per compute unit take the same time: profiles/r06_block_times.txt)
+                a.tile_groups = grid >= 64 ? 8u : 1u;
+                PEP_SEED_DISPATCH(seed_match, dim3(grid), sh, a);
+            }
             pep_timer_end(ctx, TM_MATCH0 + s);
 #ifdef PEP_PROBES
             if (P.reserved[0] == 7 && use_partition && sh.weight == 10) {

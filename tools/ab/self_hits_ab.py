@@ -12,7 +12,7 @@ order = sorted(range(len(names)), key=lambda i: names[i])
 seqs = [seqs[i] for i in order]
 flags = tuple(int(x) for x in sys.argv[3].split(',')) if len(sys.argv) > 3 else (0, 10)        # e.g. 0,11: the filter word asked for self positions too (11)
 blastn = len(sys.argv) > 4 and sys.argv[4] == 'blastn'                                        # the nucleotide tool's search instead of the translated one
-LABEL = {0: 'self hits dropped', 10: 'plain stream', 11: 'filter asked too', 8: 'plain matcher'}
+LABEL = {0: 'default', 10: 'plain stream', 11: 'filter asked too', 12: 'two start[] loads', 8: 'plain matcher'}
 ctx = N.Context(0)
 ctx.set_query_nt(seqs, 11); ctx.set_ref_nt(seqs, 6, 11)
 keep = {}
