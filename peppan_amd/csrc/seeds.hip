@@ -452,7 +452,9 @@ __device__ __forceinline__ bool set_contains(const JoinArgs &a, uint64_t k)
 // Which tiles a block of a matcher works on: claims of TILE_CLAIM consecutive tiles, handed out by atomic counters - group g of the blocks (block number mod tile_groups)
 // owns the claims g, g + tile_groups, ... and counts through them.  A claim is asked for one claim AHEAD (when the block starts the claim in front) and looked at when that
 // claim's last tile has been staged, so the atomic's round trip is never waited for alone.  Every member function is called by all threads of the block.
-constexpr uint32_t TILE_CLAIM = 4;
+// (TILE_CLAIM: four tiles of 256 positions for seed_match - 1, 2, 4, 8 take the same time -, two of the stride matcher's tiles of 1 024: a block has ten of those in all at
+// 10 000 genes - 0.167 ms with 2, 0.178 with 4, 0.193 with 8; profiles/r06_block_times.txt)
+template <uint32_t TILE_CLAIM>
 struct TileClaims {
     const JoinArgs &a;
     const uint64_t n_tiles;
@@ -527,7 +529,7 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
     // eleven of these blocks and others seven, and the blocks beyond a unit's eighth start when its first ones END.  With a fixed share of the tiles per block those
     // late blocks (an eighth of all) made the launch half as long again (324 us against 183 us for the blocks that started at once, profiles/r06_block_times.txt);
     // a block that starts late now finds what is left.
-    TileClaims claims(a, n_tiles);
+    TileClaims<4> claims(a, n_tiles);
     uint64_t tile = claims.first();
     // the residues of the NEXT tile are fetched into a register while this one is processed: a block walks ~40 tiles one after the
     // other, and without this every tile starts with an exposed global-memory latency
@@ -668,7 +670,7 @@ __global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
     // this thread's dwords of the NEXT tile are fetched while the current one is worked on
     uint32_t f0 = 0, f1 = 0;
     int32_t sd_next = PEP_SELF_NO_DELTA;             // self-search: the distance word of this thread's probe position rides along (JoinArgs::self_delta)
-    TileClaims claims(a, n_tiles);                   // (the tiles are claimed four at a time, as seed_match's are: a block that the dispatcher starts late finds what is left)
+    TileClaims<2> claims(a, n_tiles);                // (the tiles are claimed, two at a time, as seed_match's are: a block that the dispatcher starts late finds what is left)
     uint64_t tile = claims.first();
     if (tile < n_tiles) {
         const int64_t g0 = (int64_t)tile * (NTILE / 4) - 1;
