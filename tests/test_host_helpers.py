@@ -407,3 +407,22 @@ def test_lex_order_equals_numpy_lexsort():
             wide = rng.integers(-2 ** 50, 2 ** 50, n)
             assert np.array_equal(N.lex_order((qs, wide, q)), np.lexsort((qs, wide, q))), n
             assert np.array_equal(N.lex_order((qs.astype(np.float64), q)), np.lexsort((qs.astype(np.float64), q))), n
+
+
+def test_crc32_equals_zlib():
+    """pep_crc32 (the store members' checksum: carry-less multiplication where the CPU has it, zlib's otherwise): zlib.crc32 for every length around the
+    folding steps (16, 64 bytes), for unaligned starts, continued from a running value, and inside pep_pack_member for both coders"""
+    import zlib
+    from peppan_amd import _native as N
+    rng = np.random.default_rng(21)
+    blob = bytes(rng.integers(0, 256, 300000).astype(np.uint8))
+    for n in list(range(0, 200)) + [255, 256, 257, 1023, 4096, 65535, 65536, 65537, 299999]:
+        for start in (0, 1, 7):
+            d = blob[start:start + n]
+            assert N.crc32(d) == zlib.crc32(d), (n, start)
+            cut = len(d) // 3
+            assert N.crc32(d[cut:], N.crc32(d[:cut])) == zlib.crc32(d), (n, start)
+    for coder in (0, 1):
+        for d in (b'', b'abc', blob[:5000], blob[:70000] + blob[:70000], bytes(100000)):
+            payload, crc = N.pack_member(d, coder)
+            assert crc == zlib.crc32(d) and zlib.decompress(payload, -15) == d
