@@ -506,6 +506,14 @@ struct TileClaims {
 // the hardware id of the wavefront that wrote them (compute unit, shader engine, XCC)
 __device__ unsigned long long g_block_probe[4 * 2048];
 #endif
+#ifndef PEP_ENTRY_TRIP
+#define PEP_ENTRY_TRIP 4
+#endif
+#ifndef PEP_STRIDE_ENTRY_TRIP
+#define PEP_STRIDE_ENTRY_TRIP 2
+#endif
+constexpr int STRIDE_ENTRY_TRIP = PEP_STRIDE_ENTRY_TRIP;      // ... and of seed_match_stride's
+constexpr int ENTRY_TRIP = PEP_ENTRY_TRIP;      // entries of a bucket per trip of seed_match's walk (make EXTRA=-DPEP_ENTRY_TRIP=4: a measurement build)
 constexpr int HIT_BUF = PEP_HIT_BUF;          // (make EXTRA=-DPEP_HIT_BUF=1024: a measurement build - how many of the matcher's blocks a CU holds at once is a matter of this buffer)
 template <int W>
 __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
@@ -569,11 +577,11 @@ __global__ __launch_bounds__(256) void seed_match(SeedShape sh, JoinArgs a)
         // two entries per trip (one unaligned 16-byte load): a bucket that holds the key usually holds one to four entries - the members of a
         // gene family - and every trip of this loop is a dependent round trip to the L2 (the entry behind the bucket's last one is read and
         // ignored; the array has a spare slot)
-        for (uint32_t e = e0; e < e1; e += 2) {
-            uint64_t pair[2];
-            __builtin_memcpy(pair, a.entries + e, 16);
+        for (uint32_t e = e0; e < e1; e += ENTRY_TRIP) {
+            uint64_t pair[ENTRY_TRIP];
+            __builtin_memcpy(pair, a.entries + e, 8 * ENTRY_TRIP);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < ENTRY_TRIP; ++k) {
                 const uint64_t ent = pair[k];
                 if (e + k >= e1 || (ent >> POS_BITS) != key) continue;
                 ++n_hit;
@@ -711,11 +719,11 @@ __global__ __launch_bounds__(256) void seed_match_stride(JoinArgs a)
             }
         }
         const uint32_t tl = d0, tr = (d4 >> 16) | (d5 << 16);           // target bytes p - 4 .. p - 1 and p + 14 .. p + 17
-        for (uint32_t e = e0; e < e1; e += 2) {
-            uint64_t pair[2];
-            __builtin_memcpy(pair, a.entries + e, 16);
+        for (uint32_t e = e0; e < e1; e += STRIDE_ENTRY_TRIP) {
+            uint64_t pair[STRIDE_ENTRY_TRIP];
+            __builtin_memcpy(pair, a.entries + e, 8 * STRIDE_ENTRY_TRIP);
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) {
+            for (int k2 = 0; k2 < STRIDE_ENTRY_TRIP; ++k2) {
                 const uint64_t ent = pair[k2];
                 if (e + k2 >= e1 || (ent >> POS_BITS) != key) continue;
                 const uint32_t qpos = (uint32_t)(ent & POS_MASK);
@@ -1164,7 +1172,7 @@ int pep_find_candidates(pep_ctx *ctx, uint64_t **d_cands, uint64_t *n_cands, int
     bool same_weight = true;
     for (int s = 1; s < P.n_shapes && s < 4; ++s) same_weight = same_weight && P.weight[s] == P.weight[0];
     const int n_idx = same_weight ? std::max(1, std::min<int>(P.n_shapes, 4)) : 1;
-    const uint64_t start_stride = (n_buckets + 2 + 15) & ~15ull, entries_stride = (Q.total + 1 + 7) & ~7ull, filter_stride = ((n_buckets >> FILTER_SHIFT) + 2 + 7) & ~7ull;
+    const uint64_t start_stride = (n_buckets + 2 + 15) & ~15ull, entries_stride = (Q.total + 4 + 7) & ~7ull, filter_stride = ((n_buckets >> FILTER_SHIFT) + 2 + 7) & ~7ull;
     PEP_TRY(dev_reserve(ctx, ctx->ws[0], (n_buckets + 1) * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[1], n_idx * start_stride * sizeof(uint32_t)));
     PEP_TRY(dev_reserve(ctx, ctx->ws[2], n_idx * entries_stride * sizeof(uint64_t)));
