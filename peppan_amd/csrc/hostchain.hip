@@ -46,7 +46,12 @@ template <class F> void in_chunks(uint64_t n, int T, F f)
 {
     if (T <= 1) { f(0, (uint64_t)0, n); return; }
     std::vector<std::thread> pool;
-    for (int t = 1; t < T; ++t) pool.emplace_back([=]() { f(t, n * (uint64_t)t / (uint64_t)T, n * (uint64_t)(t + 1) / (uint64_t)T); });
+    pool.reserve((size_t)T);
+    for (int t = 1; t < T; ++t) {
+        const uint64_t lo = n * (uint64_t)t / (uint64_t)T, hi = n * (uint64_t)(t + 1) / (uint64_t)T;
+        try { pool.emplace_back([=]() { f(t, lo, hi); }); }
+        catch (...) { f(t, lo, hi); }                    // (no thread to be had: the chunk runs here - nothing may leave this library as a C++ exception)
+    }
     f(0, (uint64_t)0, n / (uint64_t)T);
     for (auto &th : pool) th.join();
 }
