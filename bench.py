@@ -605,20 +605,22 @@ def north_star_workloads(local_rank, names, order, seqs, nts, min_id, min_qcov, 
             return T
         with contextlib.redirect_stderr(io.StringIO()):
             call(); call()
-            reps, parts, seq_parts = 10, {}, {}
+            reps, parts, seq_parts, each = 10, {}, {}, []
             t0 = clock()
             for _ in range(reps):
+                t_call = clock()
                 T = call(parts)
+                each.append((clock() - t_call) * 1e3)
             dt = clock() - t0
             call(one_by_one=True)
             t0 = clock()
             for _ in range(reps):
                 call(seq_parts, one_by_one=True)
             dt_seq = clock() - t0
-        out['north_star_call'] = {'north_star_call_ms': dt / reps * 1e3, 'rows': int(len(T)), 'parts_ms': {k: v / reps for k, v in parts.items()}, 'reps': reps,
+        out['north_star_call'] = {'north_star_call_ms': sorted(each)[len(each) // 2], 'mean_ms': dt / reps * 1e3, 'fastest_ms': min(each), 'rows': int(len(T)), 'parts_ms': {k: v / reps for k, v in parts.items()}, 'reps': reps,
                                   'tools_one_after_the_other': {'ms': dt_seq / reps * 1e3, 'parts_ms': {k: v / reps for k, v in seq_parts.items()}},
                                   'what': 'RunBlast: nucleotide tool + translated tool on the %d genes against themselves (FASTA read once and cached; sets resident on the GPU), tables joined, '
-                                          'K7 rescoring (-s 1), fixEnd 3,3, final order - the numeric HitTable, no object rows' % len(nts)}
+                                          'K7 rescoring (-s 1), fixEnd 3,3, final order - the numeric HitTable, no object rows; the median of the calls (a host-bound call on a shared box: one of ten is up to twice the others), mean and fastest beside it' % len(nts)}
     return out
 
 
