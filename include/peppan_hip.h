@@ -84,8 +84,8 @@ typedef struct {
     int32_t ext_right, ext_left;  /* residues scored right of (from) / left of the seed's first position (<= 48 / <= 48) */
     int32_t reserved[3];          /* profiling/test switches, 0 in production: [0] seed-join stage limiter (1 keys, 2 +buckets, 3 +entries,
                                      9 no wave-level de-duplication of seed hits; 8 the nucleotide tool's plain 17-mer matcher instead of look-up words
-                                     at a stride; 10 the plain stream of a self-search instead of dropping diagonal-0 self hits - same results, for
-                                     comparison), [1] != 0 forces the 32-bit Smith-Waterman passes instead
+                                     at a stride; 10 the plain stream of a self-search instead of dropping diagonal-0 self hits, 11 the filter word asked inside self
+                                     stretches too, 12 a bucket's two ends as two loads - same results, for comparison: tools/ab/self_hits_ab.py), [1] != 0 forces the 32-bit Smith-Waterman passes instead
                                      of the packed 16-bit ones, [2] != 0 forces the count -> scan -> fill build of the query seed index */
     double ka_lambda, ka_k;       /* Karlin-Altschul parameters of the scoring system (protein default 0.267 / 0.041) */
     int32_t hsp_mode;             /* 0: one alignment per (q, t), its best band (diamond --max-hsps 1); 1: every band reaching the
